@@ -1,0 +1,231 @@
+"""ctypes mirrors of the PODs in include/ilqg.h (the C-ABI drop-in boundary).
+
+Python is only the test/bench harness here; the product is libilqg_hip.so and
+the C++ mirror of the reference API under include/ilqgames/.
+"""
+import ctypes as C
+
+MAX_PLAYERS = 8
+MAX_XDIM = 32
+
+F32, F64 = 0, 1
+
+OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_NO_DEVICE = 0, 1, 2, 3, 4
+
+# ilqg_dyn_kind
+DYN_UNICYCLE_4D, DYN_CAR_5D, DYN_CAR_6D = 1, 2, 3
+# ilqg_cost_kind
+(COST_QUADRATIC, COST_QUADRATIC_POLYLINE2, COST_SEMIQUADRATIC, COST_SEMIQUADRATIC_POLYLINE2,
+ COST_PROXIMITY, COST_SIGNED_DISTANCE, COST_EXTREME_VALUE, CONSTRAINT_PROXIMITY,
+ CONSTRAINT_SINGLE_DIMENSION) = range(1, 10)
+# ilqg_cost_role
+ROLE_STATE_COST, ROLE_CONTROL_COST, ROLE_STATE_CONSTRAINT, ROLE_CONTROL_CONSTRAINT, ROLE_CHILD = range(5)
+FLAG_ORIENTED, FLAG_IS_MIN = 1, 2
+SUM, MAX, MIN = 0, 1, 2
+
+
+class Pair(C.Structure):
+    _fields_ = [("i", C.c_int32), ("j", C.c_int32)]
+
+
+class Dims(C.Structure):
+    _fields_ = [("n", C.c_int32), ("num_players", C.c_int32), ("udim", C.c_int32 * MAX_PLAYERS),
+                ("T", C.c_int32), ("batch", C.c_int32), ("dtype", C.c_int32),
+                ("adaptive_regularization", C.c_int32)]
+
+
+class Subsystem(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("xdim", C.c_int32), ("udim", C.c_int32), ("param0", C.c_float)]
+
+
+class CostTerm(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("role", C.c_int32), ("player", C.c_int32), ("arg", C.c_int32),
+                ("idx", C.c_int32 * 4), ("weight", C.c_float), ("value", C.c_float), ("flags", C.c_int32),
+                ("polyline", C.c_int32), ("child_begin", C.c_int32), ("child_count", C.c_int32),
+                ("constraint_slot", C.c_int32)]
+
+
+class PlayerCost(C.Structure):
+    _fields_ = [("state_regularization", C.c_float), ("control_regularization", C.c_float),
+                ("structure", C.c_int32)]
+
+
+class SolverParams(C.Structure):
+    """SolverParams, include/ilqgames/solver/solver_params.h:50-84 (defaults as there)."""
+    _fields_ = [("convergence_tolerance", C.c_float), ("max_solver_iters", C.c_int32),
+                ("linesearch", C.c_int32), ("initial_alpha_scaling", C.c_float),
+                ("geometric_alpha_scaling", C.c_float), ("max_backtracking_steps", C.c_int32),
+                ("expected_decrease_fraction", C.c_float), ("open_loop", C.c_int32),
+                ("unconstrained_solver_max_iters", C.c_int32), ("geometric_mu_scaling", C.c_float),
+                ("geometric_mu_downscaling", C.c_float), ("geometric_lambda_downscaling", C.c_float),
+                ("constraint_error_tolerance", C.c_float)]
+
+    @staticmethod
+    def default():
+        return SolverParams(1e-1, 1000, 1, 0.5, 0.5, 10, 0.1, 0, 10, 1.1, 0.5, 0.5, 1e-1)
+
+
+class ProblemDesc(C.Structure):
+    _fields_ = [("num_players", C.c_int32), ("subsystems", Subsystem * MAX_PLAYERS),
+                ("player_costs", PlayerCost * MAX_PLAYERS), ("num_terms", C.c_int32),
+                ("terms", C.POINTER(CostTerm)), ("num_polylines", C.c_int32),
+                ("polyline_offsets", C.POINTER(C.c_int32)), ("polyline_points", C.POINTER(C.c_float)),
+                ("T", C.c_int32), ("dt", C.c_double), ("dtype", C.c_int32), ("params", SolverParams)]
+
+
+def make_dims(n, udims, T, batch, dtype, adaptive_regularization=True):
+    d = Dims()
+    d.n, d.num_players, d.T, d.batch, d.dtype = n, len(udims), T, batch, dtype
+    for i, u in enumerate(udims):
+        d.udim[i] = u
+    d.adaptive_regularization = 1 if adaptive_regularization else 0
+    return d
+
+
+def make_pairs(pairs):
+    arr = (Pair * max(1, len(pairs)))()
+    for q, (i, j) in enumerate(pairs):
+        arr[q].i, arr[q].j = i, j
+    return arr
+
+
+class ProblemSpec:
+    """Host-side builder of an ilqg_problem_desc; mirrors how a reference `Problem`
+    subclass wires dynamics and PlayerCosts (include/ilqgames/solver/problem.h:66-73,136-148)."""
+
+    def __init__(self, T=100, dt=0.1, params=None):
+        self.subsystems = []   # (kind, xdim, udim, param0)
+        self.player_costs = []  # (state_reg, control_reg, structure)
+        self.terms = []
+        self.polylines = []    # list of [(x, y), ...]
+        self.T, self.dt = T, dt
+        self.params = params or SolverParams.default()
+        self.x0 = None
+        self._num_constraints = 0
+
+    # --- dynamics (ConcatenatedDynamicalSystem subsystem list) ---
+    def add_player(self, kind, param0=0.0, state_reg=0.0, control_reg=0.0, structure=SUM):
+        xdim = {DYN_UNICYCLE_4D: 4, DYN_CAR_5D: 5, DYN_CAR_6D: 6}[kind]
+        self.subsystems.append((kind, xdim, 2, param0))
+        self.player_costs.append((state_reg, control_reg, structure))
+        return len(self.subsystems) - 1
+
+    @property
+    def n(self):
+        return sum(s[1] for s in self.subsystems)
+
+    @property
+    def udims(self):
+        return [s[2] for s in self.subsystems]
+
+    @property
+    def m(self):
+        return sum(self.udims)
+
+    def xoff(self, i):
+        return sum(s[1] for s in self.subsystems[:i])
+
+    def add_polyline(self, pts):
+        self.polylines.append([(float(x), float(y)) for x, y in pts])
+        return len(self.polylines) - 1
+
+    def _term(self, kind, role, player, arg=-1, idx=(0, 0, 0, 0), weight=1.0, value=0.0, flags=0,
+              polyline=-1, child_begin=0, child_count=0, constraint=False):
+        idx = tuple(idx) + (0,) * (4 - len(idx))
+        slot = -1
+        if constraint:
+            slot = self._num_constraints
+            self._num_constraints += 1
+        self.terms.append(dict(kind=kind, role=role, player=player, arg=arg, idx=idx, weight=weight,
+                               value=value, flags=flags, polyline=polyline, child_begin=child_begin,
+                               child_count=child_count, constraint_slot=slot))
+        return len(self.terms) - 1
+
+    # --- PlayerCost::AddStateCost / AddControlCost / Add*Constraint with the reference cost ctors ---
+    def quadratic(self, player, weight, dim, nominal=0.0, control_of=None):
+        role, arg = (ROLE_STATE_COST, -1) if control_of is None else (ROLE_CONTROL_COST, control_of)
+        return self._term(COST_QUADRATIC, role, player, arg, (dim,), weight, nominal)
+
+    def semiquadratic(self, player, weight, dim, threshold, oriented_right, control_of=None):
+        role, arg = (ROLE_STATE_COST, -1) if control_of is None else (ROLE_CONTROL_COST, control_of)
+        return self._term(COST_SEMIQUADRATIC, role, player, arg, (dim,), weight, threshold,
+                          FLAG_ORIENTED if oriented_right else 0)
+
+    def quadratic_polyline2(self, player, weight, polyline, xy):
+        return self._term(COST_QUADRATIC_POLYLINE2, ROLE_STATE_COST, player, -1, xy, weight, 0.0, 0, polyline)
+
+    def semiquadratic_polyline2(self, player, weight, polyline, xy, threshold, oriented_right):
+        return self._term(COST_SEMIQUADRATIC_POLYLINE2, ROLE_STATE_COST, player, -1, xy, weight, threshold,
+                          FLAG_ORIENTED if oriented_right else 0, polyline)
+
+    def proximity(self, player, weight, xy1, xy2, threshold):
+        return self._term(COST_PROXIMITY, ROLE_STATE_COST, player, -1, tuple(xy1) + tuple(xy2), weight, threshold)
+
+    def signed_distance(self, player, xy1, xy2, nominal=0.0, less_is_positive=True, role=ROLE_STATE_COST):
+        return self._term(COST_SIGNED_DISTANCE, role, player, -1, tuple(xy1) + tuple(xy2), 1.0, nominal,
+                          FLAG_ORIENTED if less_is_positive else 0)
+
+    def extreme_value(self, player, children, is_min):
+        """children: list of callables(role) -> term index, created contiguously as CHILD terms."""
+        begin = len(self.terms)
+        for mk in children:
+            mk(ROLE_CHILD)
+        cnt = len(self.terms) - begin
+        return self._term(COST_EXTREME_VALUE, ROLE_STATE_COST, player, -1, (0,), 1.0, 0.0,
+                          FLAG_IS_MIN if is_min else 0, -1, begin, cnt)
+
+    def proximity_constraint(self, player, xy1, xy2, threshold, keep_within):
+        return self._term(CONSTRAINT_PROXIMITY, ROLE_STATE_CONSTRAINT, player, -1, tuple(xy1) + tuple(xy2), 1.0,
+                          threshold, FLAG_ORIENTED if keep_within else 0, constraint=True)
+
+    def single_dimension_constraint(self, player, dim, threshold, keep_below, control_of=None):
+        role, arg = (ROLE_STATE_CONSTRAINT, -1) if control_of is None else (ROLE_CONTROL_CONSTRAINT, control_of)
+        return self._term(CONSTRAINT_SINGLE_DIMENSION, role, player, arg, (dim,), 1.0, threshold,
+                          FLAG_ORIENTED if keep_below else 0, constraint=True)
+
+    @property
+    def num_constraints(self):
+        return self._num_constraints
+
+    def pairs(self):
+        """(i, j) control blocks in PlayerCost first-touch order (src/player_cost.cpp:59-86)."""
+        out = []
+        for i in range(len(self.subsystems)):
+            for role in (ROLE_CONTROL_COST, ROLE_CONTROL_CONSTRAINT):
+                for t in self.terms:
+                    if t["player"] == i and t["role"] == role and (i, t["arg"]) not in out:
+                        out.append((i, t["arg"]))
+        return out
+
+    def build(self, dtype):
+        """Returns (ProblemDesc, keepalive) — keepalive owns the arrays the desc points into."""
+        d = ProblemDesc()
+        d.num_players = len(self.subsystems)
+        for i, (kind, xdim, udim, p0) in enumerate(self.subsystems):
+            d.subsystems[i] = Subsystem(kind, xdim, udim, p0)
+            sr, cr, st = self.player_costs[i]
+            d.player_costs[i] = PlayerCost(sr, cr, st)
+        terms = (CostTerm * max(1, len(self.terms)))()
+        for q, t in enumerate(self.terms):
+            ct = terms[q]
+            for k in ("kind", "role", "player", "arg", "weight", "value", "flags", "polyline", "child_begin",
+                      "child_count", "constraint_slot"):
+                setattr(ct, k, t[k])
+            for a in range(4):
+                ct.idx[a] = t["idx"][a]
+        d.num_terms = len(self.terms)
+        d.terms = terms
+        offs = [0]
+        pts = []
+        for pl in self.polylines:
+            for x, y in pl:
+                pts += [x, y]
+            offs.append(offs[-1] + len(pl))
+        offs_arr = (C.c_int32 * len(offs))(*offs)
+        pts_arr = (C.c_float * max(1, len(pts)))(*pts)
+        d.num_polylines = len(self.polylines)
+        d.polyline_offsets = offs_arr
+        d.polyline_points = pts_arr
+        d.T, d.dt, d.dtype = self.T, self.dt, dtype
+        d.params = self.params
+        return d, (terms, offs_arr, pts_arr)

@@ -1,0 +1,265 @@
+"""Descriptor builders for the reference example Problems used by BASELINE.json's configs.
+
+Each function restates the constants and the cost wiring of one reference
+`Problem` subclass (file:line cited) as an `abi.ProblemSpec`; the reference's
+quirks are reproduced, not fixed (e.g. roundabout players 2-4 penalising P1's
+acceleration index).  x0 is the reference's ConstructInitialState.
+"""
+import math
+
+import numpy as np
+
+from . import abi
+from .abi import DYN_CAR_5D, DYN_CAR_6D, DYN_UNICYCLE_4D, ProblemSpec, SolverParams
+
+
+def _lane_costs(spec, player, lane, xy, lane_w, boundary_w, half_width):
+    # QuadraticPolyline2Cost + right/left SemiquadraticPolyline2Cost, e.g.
+    # src/modified_three_player_intersection_example.cpp:196-209
+    spec.quadratic_polyline2(player, lane_w, lane, xy)
+    spec.semiquadratic_polyline2(player, boundary_w, lane, xy, half_width, True)
+    spec.semiquadratic_polyline2(player, boundary_w, lane, xy, -half_width, False)
+
+
+def modified_three_player_intersection(T=100, dt=0.1):
+    """ModifiedThreePlayerIntersectionExample — n=14 (Car5D, Car5D, Unicycle4D), unconstrained.
+    src/modified_three_player_intersection_example.cpp:76-329; params from
+    exec/modified_three_player_intersection_example/main.cpp:74-76,110-116."""
+    prm = SolverParams.default()
+    prm.max_backtracking_steps = 100
+    prm.initial_alpha_scaling = 1.0
+    prm.convergence_tolerance = 1.0
+    prm.expected_decrease_fraction = 0.9
+    s = ProblemSpec(T, dt, prm)
+    L = 4.0
+    for kind in (DYN_CAR_5D, DYN_CAR_5D, DYN_UNICYCLE_4D):
+        s.add_player(kind, L, state_reg=10.0, control_reg=10.0)
+    P1X, P1Y, P1H, P1PHI, P1V = 0, 1, 2, 3, 4
+    P2X, P2Y, P2H, P2PHI, P2V = 5, 6, 7, 8, 9
+    P3X, P3Y, P3H, P3V = 10, 11, 12, 13
+    p1x0, p2x0, p3x0 = -2.0, -10.0, -11.0
+    p1y0, p2y0, p3y0 = -30.0, 45.0, 16.0
+    lane1 = s.add_polyline([(p1x0, -1000.0), (p1x0, 1000.0)])
+    lane2 = s.add_polyline([(p2x0, 1000.0), (p2x0, 28.0), (p2x0 + 0.5, 25.0), (p2x0 + 1.0, 24.0),
+                            (p2x0 + 3.0, 22.5), (p2x0 + 6.0, 22.0), (1000.0, 22.0)])
+    lane3 = s.add_polyline([(-1000.0, p3y0), (1000.0, p3y0)])
+    _lane_costs(s, 0, lane1, (P1X, P1Y), 25.0, 100.0, 2.5)
+    _lane_costs(s, 1, lane2, (P2X, P2Y), 25.0, 100.0, 2.5)
+    _lane_costs(s, 2, lane3, (P3X, P3Y), 25.0, 100.0, 2.5)
+    for pl, vidx, vmax, vnom in ((0, P1V, 12.0, 8.0), (1, P2V, 12.0, 6.0), (2, P3V, 2.0, 1.5)):
+        s.semiquadratic(pl, 100.0, vidx, 1.0, False)   # MinV
+        s.semiquadratic(pl, 100.0, vidx, vmax, True)   # MaxV
+        s.quadratic(pl, 10.0, vidx, vnom)              # NominalV
+    for pl in range(3):
+        s.quadratic(pl, 0.1, 0, 0.0, control_of=pl)
+        s.quadratic(pl, 0.1, 1, 0.0, control_of=pl)
+    w = 0.0  # kProximityCostWeight = 0.0 (:89)
+    s.proximity(0, w, (P1X, P1Y), (P2X, P2Y), 6.0)
+    s.proximity(0, w, (P1X, P1Y), (P3X, P3Y), 6.0)
+    s.proximity(1, w, (P2X, P2Y), (P1X, P1Y), 6.0)
+    s.proximity(1, w, (P2X, P2Y), (P3X, P3Y), 6.0)
+    s.proximity(2, w, (P3X, P3Y), (P1X, P1Y), 6.0)
+    s.proximity(2, w, (P3X, P3Y), (P2X, P2Y), 6.0)
+    x0 = np.zeros(14)
+    x0[[P1X, P1Y, P1H, P1V]] = [p1x0, p1y0, np.float32(math.pi / 2), 4.0]
+    x0[[P2X, P2Y, P2H, P2V]] = [p2x0, p2y0, np.float32(-math.pi / 2), 3.0]
+    x0[[P3X, P3Y, P3H, P3V]] = [p3x0, p3y0, 0.0, 1.25]
+    s.x0 = x0
+    s.position_dims = [(P1X, P1Y), (P2X, P2Y), (P3X, P3Y)]
+    s.heading_dims = [P1H, P2H, P3H]
+    s.speed_dims = [P1V, P2V, P3V]
+    return s
+
+
+def three_player_intersection(T=100, dt=0.1):
+    """ThreePlayerIntersectionExample — n=16 (Car6D, Car6D, Unicycle4D) with six
+    ProximityConstraints.  src/three_player_intersection_example.cpp:78-394;
+    params from exec/three_player_intersection/main.cpp:109-120."""
+    prm = SolverParams.default()
+    prm.max_backtracking_steps = 100
+    prm.max_solver_iters = 100
+    prm.unconstrained_solver_max_iters = 10
+    prm.initial_alpha_scaling = 0.1
+    prm.convergence_tolerance = 1.0
+    prm.expected_decrease_fraction = 0.001
+    s = ProblemSpec(T, dt, prm)
+    L = 4.0
+    for kind in (DYN_CAR_6D, DYN_CAR_6D, DYN_UNICYCLE_4D):
+        s.add_player(kind, L, state_reg=1.0, control_reg=5.0)
+    P1X, P1Y, P1H, P1V = 0, 1, 2, 4
+    P2X, P2Y, P2H, P2V = 6, 7, 8, 10
+    P3X, P3Y, P3H, P3V = 12, 13, 14, 15
+    p1x0, p2x0, p3x0 = -2.0, -10.0, -11.0
+    p1y0, p2y0, p3y0 = -30.0, 45.0, 16.0
+    lane1 = s.add_polyline([(p1x0, -1000.0), (p1x0, 1000.0)])
+    lane2 = s.add_polyline([(p2x0, 1000.0), (p2x0, 18.0), (p2x0 + 0.5, 15.0), (p2x0 + 1.0, 14.0),
+                            (p2x0 + 3.0, 12.5), (p2x0 + 6.0, 12.0), (1000.0, 12.0)])
+    lane3 = s.add_polyline([(-1000.0, p3y0), (1000.0, p3y0)])
+    s.quadratic_polyline2(0, 25.0, lane1, (P1X, P1Y))
+    s.quadratic_polyline2(1, 25.0, lane2, (P2X, P2Y))
+    s.quadratic_polyline2(2, 25.0, lane3, (P3X, P3Y))
+    s.quadratic(0, 100.0, P1V, 8.0)
+    s.quadratic(1, 100.0, P2V, 5.0)
+    s.quadratic(2, 100.0, P3V, 1.5)
+    for pl in range(3):
+        s.quadratic(pl, 0.1, 0, 0.0, control_of=pl)
+        s.quadratic(pl, 0.1, 1, 0.0, control_of=pl)
+    keep_close = True
+    s.proximity_constraint(0, (P1X, P1Y), (P2X, P2Y), 6.0, not keep_close)
+    s.proximity_constraint(0, (P1X, P1Y), (P3X, P3Y), 6.0, not keep_close)
+    s.proximity_constraint(1, (P2X, P2Y), (P1X, P1Y), 6.0, not keep_close)
+    s.proximity_constraint(1, (P2X, P2Y), (P3X, P3Y), 6.0, not keep_close)
+    s.proximity_constraint(2, (P3X, P3Y), (P1X, P1Y), 6.0, not keep_close)
+    s.proximity_constraint(2, (P3X, P3Y), (P2X, P2Y), 6.0, not keep_close)
+    x0 = np.zeros(16)
+    x0[[P1X, P1Y, P1H, P1V]] = [p1x0, p1y0, np.float32(math.pi / 2), 4.0]
+    x0[[P2X, P2Y, P2H, P2V]] = [p2x0, p2y0, np.float32(-math.pi / 2), 3.0]
+    x0[[P3X, P3Y, P3H, P3V]] = [p3x0, p3y0, 0.0, 1.25]
+    s.x0 = x0
+    s.position_dims = [(P1X, P1Y), (P2X, P2Y), (P3X, P3Y)]
+    s.heading_dims = [P1H, P2H, P3H]
+    s.speed_dims = [P1V, P2V, P3V]
+    return s
+
+
+def roundabout_lane_center(entrance_angle, exit_angle, distance_from_roundabout):
+    """RoundaboutLaneCenter, src/roundabout_lane_center.cpp:50-106 (fp32 arithmetic)."""
+    f = np.float32
+    R, hw = f(12.0), f(2.5)
+    ea = f(entrance_angle)
+    xa = f(exit_angle)
+    cx, cy = (R + hw) * f(math.cos(ea)), (R + hw) * f(math.sin(ea))
+    a0 = f(ea - f(math.pi / 2))
+    fx, fy = cx + hw * f(math.cos(a0)), cy + hw * f(math.sin(a0))
+    d = f(distance_from_roundabout)
+    pts = [(fx + d * f(math.cos(ea)), fy + d * f(math.sin(ea))), (fx, fy)]
+    for ii in range(1, 4):
+        ang = f(a0 - f(math.pi / 2) * f(ii) / f(3))
+        pts.append((cx + hw * f(math.cos(ang)), cy + hw * f(math.sin(ang))))
+    for ii in range(1, 11):
+        na = f(ea + (xa - ea) * f(ii) / f(10))
+        pts.append((R * f(math.cos(na)), R * f(math.sin(na))))
+    far = f(1e4)
+    pts.append((far * f(math.cos(xa)), far * f(math.sin(xa))))
+    return [(float(x), float(y)) for x, y in pts]
+
+
+def roundabout_merging(T=100, dt=0.1, open_loop=True):
+    """RoundaboutMergingExample — n=24 (4 x Car6D).  src/roundabout_merging_example.cpp:76-436;
+    params exec/roundabout_merging_example/main.cpp:73-75,108-113 (BASELINE config 4 asks
+    for the open-loop LQ solver)."""
+    prm = SolverParams.default()
+    prm.max_backtracking_steps = 100
+    prm.initial_alpha_scaling = 0.75
+    prm.convergence_tolerance = 0.01
+    prm.expected_decrease_fraction = 0.1
+    prm.open_loop = 1 if open_loop else 0
+    s = ProblemSpec(T, dt, prm)
+    for _ in range(4):
+        s.add_player(DYN_CAR_6D, 4.0)
+    f = np.float32
+    off = f(math.pi / 2 * 0.5)
+    wedge = f(math.pi)
+    angles = [off, f(off + f(2.0 * math.pi / 4.0)), f(off + f(2.0 * 2.0 * math.pi / 4.0)),
+              f(off + f(3.0 * 2.0 * math.pi / 4.0))]
+    dists = [25.0, 10.0, 25.0, 10.0]
+    speeds = [3.0, 2.0, 3.0, 2.0]
+    x0 = np.zeros(24)
+    s.position_dims, s.heading_dims, s.speed_dims = [], [], []
+    for i in range(4):
+        pts = roundabout_lane_center(angles[i], f(angles[i] + wedge), dists[i])
+        lane = s.add_polyline(pts)
+        X, Y, H, V, Aidx = 6 * i, 6 * i + 1, 6 * i + 2, 6 * i + 4, 6 * i + 5
+        _lane_costs(s, i, lane, (X, Y), 25.0, 100.0, 2.5)
+        (ax, ay), (bx, by) = pts[0], pts[1]
+        x0[X], x0[Y] = ax, ay
+        x0[H] = np.float32(math.atan2(f(by - ay), f(bx - ax)))  # LineSegment2::Heading
+        x0[V] = speeds[i]
+        s.position_dims.append((X, Y))
+        s.heading_dims.append(H)
+        s.speed_dims.append(V)
+    for i in range(4):
+        V = 6 * i + 4
+        s.semiquadratic(i, 1000.0, V, 1.0, False)
+        s.semiquadratic(i, 1000.0, V, 12.0, True)
+        s.quadratic(i, 10.0, V, 10.0)
+    for i in range(4):
+        s.quadratic(i, 50.0, 5, 0.0)  # every player uses kP1AIdx (:356-365), reproduced
+    for i in range(4):
+        s.quadratic(i, 500.0, 0, 0.0, control_of=i)
+        s.quadratic(i, 5.0, 1, 0.0, control_of=i)
+
+    def xy(i):
+        return (6 * i, 6 * i + 1)
+    for i, (a, b) in enumerate(((1, 3), (0, 2), (1, 3), (0, 2))):  # :395-436 (which pairs are ADDED)
+        s.proximity(i, 100.0, xy(i), xy(a), 6.0)
+        s.proximity(i, 100.0, xy(i), xy(b), 6.0)
+    s.x0 = x0
+    return s
+
+
+def three_player_collision_avoidance_reachability(T=100, dt=0.1, d0=5.0, v0=5.0, buffer=3.0):
+    """ThreePlayerCollisionAvoidanceReachabilityExample — n=15 (3 x Car5D), max-over-time
+    costs, control box constraints.  src/three_player_collision_avoidance_reachability_example.cpp:62-219;
+    params exec/receding_horizon_three_player_collision_avoidance_reachability_example/main.cpp:74-81,116-124."""
+    prm = SolverParams.default()
+    prm.max_backtracking_steps = 100
+    prm.initial_alpha_scaling = 0.1
+    prm.convergence_tolerance = 0.01
+    prm.expected_decrease_fraction = 0.1
+    s = ProblemSpec(T, dt, prm)
+    for _ in range(3):
+        s.add_player(DYN_CAR_5D, 4.0, structure=abi.MAX)
+    X = [0, 5, 10]
+    Y = [1, 6, 11]
+    H = [2, 7, 12]
+    V = [4, 9, 14]
+    for i in range(3):
+        s.quadratic(i, 0.1, -1, 0.0, control_of=i)
+    for i in range(3):
+        s.single_dimension_constraint(i, 0, 1.0, True, control_of=i)
+        s.single_dimension_constraint(i, 0, -1.0, False, control_of=i)
+        s.single_dimension_constraint(i, 1, 0.1, True, control_of=i)
+        s.single_dimension_constraint(i, 1, -0.1, False, control_of=i)
+
+    def sd(a, b):
+        return lambda role: s.signed_distance(-1, (X[a], Y[a]), (X[b], Y[b]), buffer, True, role=role)
+    children = [[sd(0, 1), sd(0, 2)], [sd(0, 1), sd(1, 2)], [sd(1, 2), sd(0, 2)]]
+    for i in range(3):
+        begin = len(s.terms)
+        s.extreme_value(i, children[i], is_min=False)
+        for t in s.terms[begin:]:
+            t["player"] = i
+    x0 = np.zeros(15)
+    pert = 0.1
+    f = np.float32
+    x0[[X[0], Y[0], H[0], V[0]]] = [d0, 0.0, f(-math.pi + pert), v0]
+    x0[[X[1], Y[1], H[1], V[1]]] = [-0.5 * d0, 0.5 * math.sqrt(3.0) * d0, f(-math.pi / 3.0 + pert), v0]
+    x0[[X[2], Y[2], H[2], V[2]]] = [-0.5 * d0, -0.5 * math.sqrt(3.0) * d0, f(math.pi / 3.0 + pert), v0]
+    s.x0 = x0
+    s.position_dims = list(zip(X, Y))
+    s.heading_dims = H
+    s.speed_dims = V
+    return s
+
+
+def jittered_x0(spec, batch, seed=0):
+    """Per-instance initial states of SURVEY.md §8(d): U(-1,1) m on px,py, U(-0.1,0.1) rad
+    heading, U(-0.5,0.5) m/s speed; instance b uses numpy default_rng(seed + b)."""
+    x0 = np.tile(np.asarray(spec.x0, dtype=np.float64), (batch, 1))
+    for b in range(batch):
+        rng = np.random.default_rng(seed + b)
+        for (xi, yi), hi, vi in zip(spec.position_dims, spec.heading_dims, spec.speed_dims):
+            x0[b, xi] += rng.uniform(-1, 1)
+            x0[b, yi] += rng.uniform(-1, 1)
+            x0[b, hi] += rng.uniform(-0.1, 0.1)
+            x0[b, vi] += rng.uniform(-0.5, 0.5)
+    return x0
+
+
+CONFIGS = {
+    "modified_three_player_intersection": modified_three_player_intersection,
+    "three_player_intersection": three_player_intersection,
+    "roundabout_merging": roundabout_merging,
+    "three_player_collision_avoidance_reachability": three_player_collision_avoidance_reachability,
+}

@@ -1,0 +1,311 @@
+/*
+ * ilqg.h — C ABI of the MI355X-native iLQGames inner solver (libilqg_hip.so).
+ *
+ * This is the drop-in boundary for the hot path of HJReachability/ilqgames:
+ * forward rollout + linearisation, per-player cost quadraticisation, the
+ * coupled backward LQ Nash sweep, and the iterative-LQ loop around them,
+ * batched over independent game instances.
+ *
+ * The reference has no FFI of its own; each entry point below replaces the
+ * body of one reference C++ method (cited per function, paths relative to the
+ * reference repo root).  The host-side C++ mirror of the reference classes
+ * (include/ilqgames/...) packs its objects into the POD descriptors declared
+ * here and calls these functions.  INTEGRATION.md shows the binding a
+ * reference maintainer would add.
+ *
+ * Conventions
+ *  - Plain pointers and sizes only; no torch / STL / Eigen types.
+ *  - All array arguments are DEVICE pointers (HBM resident) unless the
+ *    parameter name ends in `_host`.
+ *  - Every small matrix is stored column-major (Eigen's default), so buffers
+ *    can be handed back through `Strategy::Ps` etc. without reordering.
+ *  - Arrays are trajectory-major per instance: [batch][T][...].
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *  - Return value: ilqg_status; no exceptions cross the boundary; programmer
+ *    errors that glog CHECKs abort on in the reference (dimension mismatch,
+ *    missing R_ii — src/lq_feedback_solver.cpp:77-78,139-140) are reported as
+ *    ILQG_ERR_INVALID.  Algorithmic failure (line-search exhausted,
+ *    src/ilq_solver.cpp:146-155) is reported per instance in `status[]`.
+ */
+#ifndef ILQG_H_
+#define ILQG_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ILQG_MAX_PLAYERS 8
+#define ILQG_MAX_XDIM 32
+#define ILQG_MAX_UDIM_TOTAL 16
+#define ILQG_MAX_PAIRS 64
+
+typedef enum {
+  ILQG_OK = 0,
+  ILQG_ERR_INVALID = 1,     /* bad argument / dimension mismatch / missing R_ii */
+  ILQG_ERR_UNSUPPORTED = 2, /* dims or model kind have no device kernel */
+  ILQG_ERR_HIP = 3,         /* HIP runtime error (see ilqg_last_error) */
+  ILQG_ERR_NO_DEVICE = 4    /* no gfx950 device visible */
+} ilqg_status;
+
+typedef enum { ILQG_F32 = 0, ILQG_F64 = 1 } ilqg_dtype;
+
+/* (i, j): player i's cost carries a control block (R_ij, r_ij) on player j's
+ * input — the keys of QuadraticCostApproximation::control
+ * (include/ilqgames/utils/quadratic_cost_approximation.h:61-86). */
+typedef struct {
+  int32_t i;
+  int32_t j;
+} ilqg_pair;
+
+/* Dimensions of one batched LQ game. */
+typedef struct {
+  int32_t n;                      /* state dimension                      */
+  int32_t num_players;            /* N                                    */
+  int32_t udim[ILQG_MAX_PLAYERS]; /* m_i                                  */
+  int32_t T;                      /* number of time steps                 */
+  int32_t batch;                  /* B independent instances              */
+  int32_t dtype;                  /* ilqg_dtype                           */
+  int32_t adaptive_regularization;/* Gershgorin step of lq_feedback_solver.cpp:163-176 */
+} ilqg_dims;
+
+/* ------------------------------------------------------------------------ *
+ *  LQ Nash sweeps                                                          *
+ * ------------------------------------------------------------------------ */
+
+/* Replaces LQFeedbackSolver::Solve (src/lq_feedback_solver.cpp:71-244).
+ *
+ *  A      [B][T][n*n]            lin.A
+ *  Bm     [B][T][n*m]            [lin.Bs[0] | lin.Bs[1] | ...], m = sum m_i
+ *  Q      [B][T][N][n*n]         quad[k][i].state.hess
+ *  l      [B][T][N][n]           quad[k][i].state.grad
+ *  R      [B][T][sum_p m_j^2]    quad[k][i].control[j].hess, pair order
+ *  r      [B][T][sum_p m_j]      quad[k][i].control[j].grad, pair order
+ *  pairs_host / npairs           which (i,j) blocks exist; (i,i) is mandatory
+ *  x0     [B][n] or NULL (=0)    initial delta-x for the forward pass
+ *  P      [B][T][m*n]            stacked gains, rows of player i at sum_{p<i} m_p
+ *  alpha  [B][T][m]
+ *  dx     [B][T][n] or NULL      delta_xs (forward pass, lq_feedback_solver.cpp:217-241)
+ *  costates [B][T][N][n] or NULL
+ *  Entry T-1 of P/alpha is written as zero (strategy.h:64-70; loop starts at T-2).
+ */
+ilqg_status ilqg_lq_feedback_batch(const ilqg_dims* d, const void* A,
+                                   const void* Bm, const void* Q, const void* l,
+                                   const void* R, const void* r,
+                                   const ilqg_pair* pairs_host, int32_t npairs,
+                                   const void* x0, void* P, void* alpha,
+                                   void* dx, void* costates, void* stream);
+
+/* Replaces LQOpenLoopSolver::Solve (src/lq_open_loop_solver.cpp:73-195).
+ * Same inputs; P is written as zero, alpha/dx/costates as the reference. */
+ilqg_status ilqg_lq_openloop_batch(const ilqg_dims* d, const void* A,
+                                   const void* Bm, const void* Q, const void* l,
+                                   const void* R, const void* r,
+                                   const ilqg_pair* pairs_host, int32_t npairs,
+                                   const void* x0, void* P, void* alpha,
+                                   void* dx, void* costates, void* stream);
+
+/* ------------------------------------------------------------------------ *
+ *  Problem descriptor (what Problem::Initialize builds, flattened to PODs)  *
+ * ------------------------------------------------------------------------ */
+
+typedef enum {
+  ILQG_DYN_UNICYCLE_4D = 1, /* include/ilqgames/dynamics/single_player_unicycle_4d.h:90-116 */
+  ILQG_DYN_CAR_5D = 2,      /* include/ilqgames/dynamics/single_player_car_5d.h:100-133     */
+  ILQG_DYN_CAR_6D = 3       /* include/ilqgames/dynamics/single_player_car_6d.h:102-138     */
+} ilqg_dyn_kind;
+
+/* One block of a ConcatenatedDynamicalSystem
+ * (src/concatenated_dynamical_system.cpp:52-107); player i owns subsystem i. */
+typedef struct {
+  int32_t kind; /* ilqg_dyn_kind */
+  int32_t xdim;
+  int32_t udim;
+  float param0; /* inter-axle distance for the car models */
+} ilqg_subsystem;
+
+typedef enum {
+  ILQG_COST_QUADRATIC = 1,           /* src/quadratic_cost.cpp:51-94             */
+  ILQG_COST_QUADRATIC_POLYLINE2 = 2, /* src/quadratic_polyline2_cost.cpp:52-126  */
+  ILQG_COST_SEMIQUADRATIC = 3,       /* src/semiquadratic_cost.cpp:51-85         */
+  ILQG_COST_SEMIQUADRATIC_POLYLINE2 = 4, /* src/semiquadratic_polyline2_cost.cpp:52-142 */
+  ILQG_COST_PROXIMITY = 5,           /* src/proximity_cost.cpp:52-122            */
+  ILQG_COST_SIGNED_DISTANCE = 6,     /* src/signed_distance_cost.cpp:51-113      */
+  ILQG_COST_EXTREME_VALUE = 7,       /* src/extreme_value_cost.cpp:51-85         */
+  ILQG_CONSTRAINT_PROXIMITY = 8,     /* src/proximity_constraint.cpp:56-116      */
+  ILQG_CONSTRAINT_SINGLE_DIMENSION = 9 /* include/ilqgames/constraint/single_dimension_constraint.h:57-103 */
+} ilqg_cost_kind;
+
+/* Where a term sits inside PlayerCost::Quadraticize (src/player_cost.cpp:194-215):
+ * state costs, control costs, state constraints, control constraints — in that
+ * order; CHILD terms are only reached through an EXTREME_VALUE parent. */
+typedef enum {
+  ILQG_ROLE_STATE_COST = 0,
+  ILQG_ROLE_CONTROL_COST = 1,
+  ILQG_ROLE_STATE_CONSTRAINT = 2,
+  ILQG_ROLE_CONTROL_CONSTRAINT = 3,
+  ILQG_ROLE_CHILD = 4
+} ilqg_cost_role;
+
+#define ILQG_FLAG_ORIENTED 1 /* oriented_right / keep_within / keep_below / less_is_positive */
+#define ILQG_FLAG_IS_MIN 2   /* ExtremeValueCost::is_min_ */
+
+typedef struct {
+  int32_t kind;        /* ilqg_cost_kind                                       */
+  int32_t role;        /* ilqg_cost_role                                       */
+  int32_t player;      /* owning PlayerCost                                    */
+  int32_t arg;         /* control costs/constraints: which player's u; else -1 */
+  int32_t idx[4];      /* QUADRATIC/SEMIQUADRATIC/SINGLE_DIM: idx[0]=dimension (-1 = all dims);
+                          *_POLYLINE2: (xidx, yidx); PROXIMITY/SIGNED_DISTANCE/
+                          CONSTRAINT_PROXIMITY: (x1, y1, x2, y2)                */
+  float weight;        /* Cost::weight_                                        */
+  float value;         /* nominal_ or threshold_                               */
+  int32_t flags;       /* ILQG_FLAG_*                                          */
+  int32_t polyline;    /* index into the polyline table or -1                  */
+  int32_t child_begin; /* EXTREME_VALUE: first child term index                */
+  int32_t child_count; /* EXTREME_VALUE: number of children                    */
+  int32_t constraint_slot; /* constraints: index into the per-instance lambda table, else -1 */
+} ilqg_cost_term;
+
+typedef enum { ILQG_SUM = 0, ILQG_MAX = 1, ILQG_MIN = 2 } ilqg_cost_structure;
+
+/* PlayerCost ctor arguments + cost structure (include/ilqgames/cost/player_cost.h:63-109). */
+typedef struct {
+  float state_regularization;
+  float control_regularization;
+  int32_t structure; /* ilqg_cost_structure */
+} ilqg_player_cost;
+
+/* SolverParams (include/ilqgames/solver/solver_params.h:50-84). */
+typedef struct {
+  float convergence_tolerance;
+  int32_t max_solver_iters;
+  int32_t linesearch;
+  float initial_alpha_scaling;
+  float geometric_alpha_scaling;
+  int32_t max_backtracking_steps;
+  float expected_decrease_fraction;
+  int32_t open_loop;
+  int32_t unconstrained_solver_max_iters;
+  float geometric_mu_scaling;
+  float geometric_mu_downscaling;
+  float geometric_lambda_downscaling;
+  float constraint_error_tolerance;
+} ilqg_solver_params;
+
+typedef struct {
+  int32_t num_players;
+  ilqg_subsystem subsystems[ILQG_MAX_PLAYERS];
+  ilqg_player_cost player_costs[ILQG_MAX_PLAYERS];
+  int32_t num_terms;
+  const ilqg_cost_term* terms;     /* host array                             */
+  int32_t num_polylines;
+  const int32_t* polyline_offsets; /* host, num_polylines+1, in points       */
+  const float* polyline_points;    /* host, 2 floats per point               */
+  int32_t T;                       /* time::kNumTimeSteps (types.h:141-142)  */
+  double dt;                       /* time::kTimeStep     (types.h:135)      */
+  int32_t dtype;                   /* ilqg_dtype of state/gain arithmetic    */
+  ilqg_solver_params params;
+} ilqg_problem_desc;
+
+void ilqg_default_solver_params(ilqg_solver_params* p);
+
+typedef struct ilqg_problem ilqg_problem;
+
+/* Builds the device-side tables of one Problem (what Problem::Initialize +
+ * ILQSolver::ILQSolver set up, include/ilqgames/solver/problem.h:66-73,
+ * include/ilqgames/solver/ilq_solver.h:69-95). */
+ilqg_status ilqg_problem_create(const ilqg_problem_desc* desc, ilqg_problem** out);
+void ilqg_problem_destroy(ilqg_problem* p);
+
+/* Bytes of device workspace ilqg_ilq_solve_batch needs for `batch` instances. */
+ilqg_status ilqg_workspace_bytes(const ilqg_problem* p, int32_t batch, uint64_t* bytes);
+
+/* ------------------------------------------------------------------------ *
+ *  Hot-path stages (each also usable on its own; all batched)               *
+ * ------------------------------------------------------------------------ */
+
+/* Replaces ILQSolver::CurrentOperatingPoint (src/ilq_solver.cpp:174-206):
+ * closed-loop rollout from x0 under u_i = u_ref_i - P_i (x - x_ref) - alpha_i
+ * with the RK4(2 sub-steps) integrator of
+ * src/multi_player_dynamical_system.cpp:52-77.
+ *  x0 [B][n]; xs_ref [B][T][n]; us_ref [B][T][m]; P [B][T][m*n]; alpha [B][T][m]
+ *  alpha_scale [B] or NULL (=1): step size applied to alpha on the fly (the
+ *  reference scales alphas destructively, ilq_solver.cpp:66-72,314,339)
+ *  xs [B][T][n], us [B][T][m] outputs.  active [B] int32 mask or NULL. */
+ilqg_status ilqg_rollout_batch(const ilqg_problem* p, int32_t batch,
+                               const void* x0, const void* xs_ref,
+                               const void* us_ref, const void* P,
+                               const void* alpha, const void* alpha_scale,
+                               void* xs, void* us, const int32_t* active,
+                               void* stream);
+
+/* Replaces ILQSolver::ComputeLinearization (src/ilq_solver.cpp:437-455) ->
+ * ConcatenatedDynamicalSystem::Linearize (src/concatenated_dynamical_system.cpp:86-107).
+ *  A [B][T][n*n], Bm [B][T][n*m]. */
+ilqg_status ilqg_linearize_batch(const ilqg_problem* p, int32_t batch,
+                                 const void* xs, const void* us, void* A,
+                                 void* Bm, const int32_t* active, void* stream);
+
+/* Replaces ILQSolver::ComputeCostQuadraticization (src/ilq_solver.cpp:471-490)
+ * -> PlayerCost::Quadraticize (src/player_cost.cpp:194-225).
+ *  lambdas [B][num_constraints][T] or NULL; mu [B] or NULL (constraint.h:98-117)
+ *  t_extreme [B][N] int32 or NULL: time of extreme cost for MAX/MIN players.
+ *  Q,l,R,r: layouts of ilqg_lq_feedback_batch, pair order = ilqg_problem_pairs. */
+ilqg_status ilqg_quadraticize_batch(const ilqg_problem* p, int32_t batch,
+                                    const void* xs, const void* us,
+                                    const void* lambdas, const void* mu,
+                                    const int32_t* t_extreme, void* Q, void* l,
+                                    void* R, void* r, const int32_t* active,
+                                    void* stream);
+
+/* The (i,j) control blocks PlayerCost::Quadraticize creates for this problem. */
+ilqg_status ilqg_problem_pairs(const ilqg_problem* p, ilqg_pair* pairs_host,
+                               int32_t* npairs);
+
+/* Replaces ILQSolver::TotalCosts (src/ilq_solver.cpp:220-257).
+ *  costs [B][N]; t_extreme [B][N] int32 (written for MAX/MIN players). */
+ilqg_status ilqg_total_costs_batch(const ilqg_problem* p, int32_t batch,
+                                   const void* xs, const void* us, void* costs,
+                                   int32_t* t_extreme, const int32_t* active,
+                                   void* stream);
+
+/* ------------------------------------------------------------------------ *
+ *  Whole iterative-LQ solve                                                 *
+ * ------------------------------------------------------------------------ */
+
+/* Replaces ILQSolver::Solve (src/ilq_solver.cpp:76-172) for `batch`
+ * independent instances that share one Problem definition and differ in x0
+ * (and warm start).
+ *  x0        [B][n]        Problem::InitialState per instance
+ *  xs, us    [B][T][n|m]   in: warm-start operating point; out: final one
+ *  P, alpha  [B][T][..]    in: warm-start strategies; out: final strategies
+ *                          (alpha carries the accepted step scaling, as the
+ *                          strategies the reference logs do)
+ *  total_costs [B][N]      ILQSolver::TotalCosts of the final iterate
+ *  iters     [B] int32     outer iterations performed
+ *  status    [B] int32     1 = success flag true (src/ilq_solver.cpp:169),
+ *                          0 = line-search failure (:146-155)
+ *  converged [B] int32     has_converged at exit
+ *  workspace               device scratch of ilqg_workspace_bytes() bytes
+ *  fixed_iters > 0 runs exactly that many outer iterations per instance
+ *  ignoring convergence (throughput benchmarking); 0 = reference semantics. */
+ilqg_status ilqg_ilq_solve_batch(ilqg_problem* p, int32_t batch, const void* x0,
+                                 void* xs, void* us, void* P, void* alpha,
+                                 void* total_costs, int32_t* iters,
+                                 int32_t* status, int32_t* converged,
+                                 void* workspace, int32_t fixed_iters,
+                                 void* stream);
+
+/* Last HIP / validation error text of the calling thread. */
+const char* ilqg_last_error(void);
+
+/* Library / device introspection (used by the loader to fail loudly). */
+int32_t ilqg_abi_version(void);
+ilqg_status ilqg_device_info(char* name_out, int32_t name_len, int32_t* num_cus);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ILQG_H_ */

@@ -1,0 +1,1355 @@
+// ilqg_oracle.hpp — CPU restatement of the iLQGames hot path.  TEST INFRASTRUCTURE ONLY.
+//
+// This file is the parity oracle and the CPU baseline for the MI355X kernels in
+// ilqgames_amd/csrc.  Only tests/, __graft_entry__.smoke() and bench.py's
+// `cpu_baseline` leg may build, link or call it; the product path never does.
+//
+// It follows the reference C++ (paths relative to the reference repo root)
+// function by function; every routine cites the lines it restates.  It is
+// templated on the scalar type: S=float mirrors the reference's arithmetic
+// (types.h:68-69 — Eigen MatrixXf/VectorXf everywhere), S=double is the ground
+// truth the fp64 device path is compared against.
+//
+// Pinning: the reference C++ cannot be built in this image (Eigen3/glog/gflags
+// absent), so the oracle is pinned against
+//   * the reference's importable numpy LQ solver python/solve_lq_game.py
+//     (fixtures under tests/golden/, generator tests/golden/make_golden.py),
+//   * the known-answer tables of test/test_polyline2.cpp, test/test_line_segment2.cpp,
+//   * the properties of test/test_lq_solver.cpp, test_linearization.cpp,
+//     test_quadraticization.cpp, test_player_cost.cpp re-expressed in tests/.
+// Bitwise parity with Eigen's own summation order / QR is NOT pinned.
+#pragma once
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <map>
+#include <vector>
+
+#include "../include/ilqg.h"
+
+namespace oracle {
+
+// ---------------------------------------------------------------------------
+// Minimal dense column-major matrix (Eigen's default storage order).
+// ---------------------------------------------------------------------------
+template <class S>
+struct Mat {
+  int r = 0, c = 0;
+  std::vector<S> d;
+  Mat() {}
+  Mat(int rows, int cols) : r(rows), c(cols), d(size_t(rows) * cols, S(0)) {}
+  S& operator()(int i, int j) { return d[size_t(i) + size_t(j) * r]; }
+  S operator()(int i, int j) const { return d[size_t(i) + size_t(j) * r]; }
+  static Mat Identity(int n, S scale = S(1)) {
+    Mat m(n, n);
+    for (int i = 0; i < n; i++) m(i, i) = scale;
+    return m;
+  }
+  void setZero() { std::fill(d.begin(), d.end(), S(0)); }
+};
+template <class S>
+using Vec = std::vector<S>;
+
+template <class S>
+Mat<S> matmul(const Mat<S>& a, const Mat<S>& b) {
+  Mat<S> o(a.r, b.c);
+  for (int j = 0; j < b.c; j++)
+    for (int k = 0; k < a.c; k++) {
+      const S bkj = b(k, j);
+      for (int i = 0; i < a.r; i++) o(i, j) += a(i, k) * bkj;
+    }
+  return o;
+}
+template <class S>
+Mat<S> matmulTN(const Mat<S>& a, const Mat<S>& b) {  // a^T b
+  Mat<S> o(a.c, b.c);
+  for (int j = 0; j < b.c; j++)
+    for (int i = 0; i < a.c; i++) {
+      S s = 0;
+      for (int k = 0; k < a.r; k++) s += a(k, i) * b(k, j);
+      o(i, j) = s;
+    }
+  return o;
+}
+template <class S>
+Vec<S> matvec(const Mat<S>& a, const Vec<S>& x) {
+  Vec<S> o(a.r, S(0));
+  for (int k = 0; k < a.c; k++)
+    for (int i = 0; i < a.r; i++) o[i] += a(i, k) * x[k];
+  return o;
+}
+template <class S>
+Vec<S> matvecT(const Mat<S>& a, const Vec<S>& x) {  // a^T x
+  Vec<S> o(a.c, S(0));
+  for (int i = 0; i < a.c; i++) {
+    S s = 0;
+    for (int k = 0; k < a.r; k++) s += a(k, i) * x[k];
+    o[i] = s;
+  }
+  return o;
+}
+
+// ---------------------------------------------------------------------------
+// Householder QR solve, restating Eigen's HouseholderQR (unblocked path) +
+// solve: the call `S_.householderQr().solve(Y_)` of
+// src/lq_feedback_solver.cpp:180 and src/lq_open_loop_solver.cpp:131,144,148,165.
+// Eigen is an un-vendored dependency of the reference (cmake/Dependencies.cmake:5,
+// any Eigen >= 2.91); the algorithm restated is Eigen 3.3's
+// householder_qr_inplace_unblocked + MatrixBase::makeHouseholder +
+// applyHouseholderOnTheLeft, then back substitution on R.
+// ---------------------------------------------------------------------------
+template <class S>
+struct HouseholderQR {
+  Mat<S> qr;
+  Vec<S> tau;
+  void compute(const Mat<S>& a) {
+    qr = a;
+    const int rows = a.r, cols = a.c, size = std::min(rows, cols);
+    tau.assign(size, S(0));
+    for (int k = 0; k < size; k++) {
+      const int rem = rows - k;
+      // makeHouseholderInPlace on qr.col(k).tail(rem)
+      S tailsq = 0;
+      for (int i = k + 1; i < rows; i++) tailsq += qr(i, k) * qr(i, k);
+      const S c0 = qr(k, k);
+      S beta, t;
+      if (rem == 1 || tailsq <= std::numeric_limits<S>::min()) {
+        t = 0;
+        beta = c0;
+        for (int i = k + 1; i < rows; i++) qr(i, k) = 0;
+      } else {
+        beta = std::sqrt(c0 * c0 + tailsq);
+        if (c0 >= S(0)) beta = -beta;
+        for (int i = k + 1; i < rows; i++) qr(i, k) = qr(i, k) / (c0 - beta);
+        t = (beta - c0) / beta;
+      }
+      tau[k] = t;
+      qr(k, k) = beta;
+      // apply H_k to the trailing columns
+      for (int j = k + 1; j < cols; j++) applyReflector(k, t, qr, j);
+    }
+  }
+  // x(:, j) <- H_k x(:, j), H_k = I - tau v v^T, v = [1; qr(k+1:, k)]
+  void applyReflector(int k, S t, Mat<S>& x, int j) const {
+    const int rows = qr.r;
+    if (rows - k == 1) {
+      x(k, j) *= (S(1) - t);
+      return;
+    }
+    if (t == S(0)) return;
+    S tmp = 0;
+    for (int i = k + 1; i < rows; i++) tmp += qr(i, k) * x(i, j);
+    tmp += x(k, j);
+    x(k, j) -= t * tmp;
+    for (int i = k + 1; i < rows; i++) x(i, j) -= t * qr(i, k) * tmp;
+  }
+  Mat<S> solve(const Mat<S>& b) const {
+    Mat<S> c = b;
+    const int n = qr.c, size = (int)tau.size();
+    for (int k = 0; k < size; k++)
+      for (int j = 0; j < c.c; j++) applyReflector(k, tau[k], c, j);
+    // back substitution with R = upper triangle of qr
+    Mat<S> x(n, b.c);
+    for (int j = 0; j < b.c; j++)
+      for (int i = n - 1; i >= 0; i--) {
+        S s = c(i, j);
+        for (int k2 = i + 1; k2 < n; k2++) s -= qr(i, k2) * x(k2, j);
+        x(i, j) = s / qr(i, i);
+      }
+    return x;
+  }
+};
+
+// LDLT solve for the small SPD R_ii blocks (Eigen::LDLT, lq_open_loop_solver.cpp:124-126).
+// Symmetric-pivoting order of Eigen's LDLT is not restated (unpinned; R_ii is
+// diagonal-dominant in every config) — plain LDL^T.
+template <class S>
+struct LDLT {
+  Mat<S> L;
+  Vec<S> D;
+  void compute(const Mat<S>& a) {
+    const int n = a.r;
+    L = Mat<S>::Identity(n);
+    D.assign(n, S(0));
+    for (int j = 0; j < n; j++) {
+      S dj = a(j, j);
+      for (int k = 0; k < j; k++) dj -= L(j, k) * L(j, k) * D[k];
+      D[j] = dj;
+      for (int i = j + 1; i < n; i++) {
+        S s = a(i, j);
+        for (int k = 0; k < j; k++) s -= L(i, k) * L(j, k) * D[k];
+        L(i, j) = s / dj;
+      }
+    }
+  }
+  Mat<S> solve(const Mat<S>& b) const {
+    const int n = L.r;
+    Mat<S> x = b;
+    for (int c = 0; c < b.c; c++) {
+      for (int i = 0; i < n; i++)
+        for (int k = 0; k < i; k++) x(i, c) -= L(i, k) * x(k, c);
+      for (int i = 0; i < n; i++) x(i, c) /= D[i];
+      for (int i = n - 1; i >= 0; i--)
+        for (int k = i + 1; k < n; k++) x(i, c) -= L(k, i) * x(k, c);
+    }
+    return x;
+  }
+};
+
+template <class S>
+inline S sgn(S x) {  // types.h:147-155
+  return S((S(0) < x) - (x < S(0)));
+}
+
+// ---------------------------------------------------------------------------
+// Geometry: LineSegment2 / Polyline2
+// ---------------------------------------------------------------------------
+template <class S>
+struct Segment2 {  // include/ilqgames/geometry/line_segment2.h:52-91
+  S p1x, p1y, p2x, p2y, length, ux, uy;
+  Segment2() : p1x(0), p1y(0), p2x(1), p2y(1) { init(); }
+  Segment2(S ax, S ay, S bx, S by) : p1x(ax), p1y(ay), p2x(bx), p2y(by) { init(); }
+  void init() {
+    const S dx = p1x - p2x, dy = p1y - p2y;
+    length = std::sqrt(dx * dx + dy * dy);
+    ux = (p2x - p1x) / length;
+    uy = (p2y - p1y) / length;
+  }
+  // src/line_segment2.cpp:48-54
+  bool Side(S qx, S qy) const {
+    const S rx = qx - p1x, ry = qy - p1y;
+    const S cross = rx * uy - ux * ry;
+    return cross > S(0);
+  }
+  // src/line_segment2.cpp:56-100
+  void ClosestPoint(S qx, S qy, S* cx, S* cy, bool* is_endpoint, S* ssd) const {
+    const S rx = qx - p1x, ry = qy - p1y;
+    const S dot = rx * ux + ry * uy;
+    const S cross = rx * uy - ux * ry;
+    const S csign = sgn(cross);
+    if (dot < S(0)) {
+      *is_endpoint = true;
+      *ssd = csign * (rx * rx + ry * ry);
+      *cx = p1x;
+      *cy = p1y;
+      return;
+    } else if (dot > length) {
+      *is_endpoint = true;
+      const S ex = qx - p2x, ey = qy - p2y;
+      *ssd = csign * (ex * ex + ey * ey);
+      *cx = p2x;
+      *cy = p2y;
+      return;
+    }
+    *is_endpoint = false;
+    *ssd = csign * cross * cross;
+    *cx = p1x + dot * ux;
+    *cy = p1y + dot * uy;
+  }
+};
+
+template <class S>
+struct Polyline2 {  // src/polyline2.cpp:52-63
+  std::vector<Segment2<S>> segs;
+  Polyline2() {}
+  Polyline2(const float* pts, int npts) {
+    for (int i = 1; i < npts; i++)
+      segs.emplace_back(S(pts[2 * (i - 1)]), S(pts[2 * (i - 1) + 1]), S(pts[2 * i]),
+                        S(pts[2 * i + 1]));
+  }
+  // src/polyline2.cpp:105-174
+  void ClosestPoint(S qx, S qy, S* cx, S* cy, bool* is_vertex, Segment2<S>* segment,
+                    S* signed_sq, bool* is_endpoint) const {
+    S closest = std::numeric_limits<S>::infinity();
+    S bx = 0, by = 0;
+    int seg_idx = 0;
+    bool vertex = false;
+    const int nseg = (int)segs.size();
+    for (int counter = 0; counter < nseg; counter++) {
+      const Segment2<S>& s = segs[counter];
+      S px, py, cur;
+      bool seg_end;
+      s.ClosestPoint(qx, qy, &px, &py, &seg_end, &cur);
+      if (std::abs(cur) < std::abs(closest)) {
+        const bool at_second = (px == s.p2x && py == s.p2y);
+        const bool at_first = (px == s.p1x && py == s.p1y);
+        if (seg_end && (counter > 0 || at_second) && (counter < nseg - 1 || at_first)) {
+          const Segment2<S> shortcut =
+              at_first ? Segment2<S>(segs[counter - 1].p1x, segs[counter - 1].p1y, s.p2x, s.p2y)
+                       : Segment2<S>(s.p1x, s.p1y, segs[counter + 1].p2x, segs[counter + 1].p2y);
+          cur *= shortcut.Side(qx, qy) ? sgn(cur) : -sgn(cur);
+        }
+        closest = cur;
+        bx = px;
+        by = py;
+        vertex = seg_end;
+        seg_idx = counter;
+      }
+    }
+    if (segment) *segment = segs[seg_idx];
+    if (signed_sq) *signed_sq = closest;
+    if (is_vertex) *is_vertex = vertex;
+    if (is_endpoint) {
+      auto same = [](S ax, S ay, S cx2, S cy2) {
+        const S dx = ax - cx2, dy = ay - cy2;
+        return dx * dx + dy * dy < S(1e-4f);  // constants::kSmallNumber, types.h:115
+      };
+      *is_endpoint = same(bx, by, segs.front().p1x, segs.front().p1y) ||
+                     same(bx, by, segs.back().p2x, segs.back().p2y);
+    }
+    *cx = bx;
+    *cy = by;
+  }
+};
+
+// ---------------------------------------------------------------------------
+// Problem: flattened Problem/PlayerCost/ConcatenatedDynamicalSystem
+// ---------------------------------------------------------------------------
+template <class S>
+struct Problem {
+  int N = 0, n = 0, m = 0, T = 0;
+  double dt = 0.1;
+  std::vector<ilqg_subsystem> subs;
+  std::vector<int> xoff, uoff;  // subsystem_start_dims_, concatenated_dynamical_system.cpp:62-66
+  std::vector<ilqg_player_cost> pcs;
+  std::vector<ilqg_cost_term> terms;
+  std::vector<Polyline2<S>> polylines;
+  std::vector<ilqg_pair> pairs;          // fixed (i,j) block order
+  std::vector<int> pair_from_cost;       // 1 if a control COST (not only a constraint) touches it
+  std::vector<int> roff, rgoff;          // offsets of pair blocks inside R / r rows
+  int Rsz = 0, rsz = 0;
+  int num_constraints = 0;
+  ilqg_solver_params params;
+
+  explicit Problem(const ilqg_problem_desc& d) {
+    N = d.num_players;
+    T = d.T;
+    dt = d.dt;
+    params = d.params;
+    xoff.push_back(0);
+    uoff.push_back(0);
+    for (int i = 0; i < N; i++) {
+      subs.push_back(d.subsystems[i]);
+      pcs.push_back(d.player_costs[i]);
+      xoff.push_back(xoff.back() + d.subsystems[i].xdim);
+      uoff.push_back(uoff.back() + d.subsystems[i].udim);
+    }
+    n = xoff.back();
+    m = uoff.back();
+    terms.assign(d.terms, d.terms + d.num_terms);
+    for (int p = 0; p < d.num_polylines; p++) {
+      const int b = d.polyline_offsets[p], e = d.polyline_offsets[p + 1];
+      polylines.emplace_back(d.polyline_points + 2 * b, e - b);
+    }
+    // Pair table: per player, first-touch order over control costs then control
+    // constraints (player_cost.cpp:59-86 creates a block at first touch).
+    for (int i = 0; i < N; i++) {
+      for (int pass = 0; pass < 2; pass++)
+        for (const auto& t : terms) {
+          if (t.player != i) continue;
+          if (pass == 0 && t.role != ILQG_ROLE_CONTROL_COST) continue;
+          if (pass == 1 && t.role != ILQG_ROLE_CONTROL_CONSTRAINT) continue;
+          int found = -1;
+          for (size_t q = 0; q < pairs.size(); q++)
+            if (pairs[q].i == i && pairs[q].j == t.arg) found = (int)q;
+          if (found < 0) {
+            pairs.push_back({i, t.arg});
+            pair_from_cost.push_back(pass == 0 ? 1 : 0);
+          }
+        }
+    }
+    for (const auto& pr : pairs) {
+      roff.push_back(Rsz);
+      rgoff.push_back(rsz);
+      Rsz += subs[pr.j].udim * subs[pr.j].udim;
+      rsz += subs[pr.j].udim;
+    }
+    for (const auto& t : terms)
+      if (t.constraint_slot >= 0) num_constraints = std::max(num_constraints, t.constraint_slot + 1);
+  }
+  // LQ-only problem: dimensions + (i,j) block table, no dynamics/cost models.
+  Problem(const ilqg_dims& d, const ilqg_pair* prs, int npairs) {
+    N = d.num_players;
+    T = d.T;
+    n = d.n;
+    xoff.push_back(0);
+    uoff.push_back(0);
+    for (int i = 0; i < N; i++) {
+      ilqg_subsystem s{};
+      s.udim = d.udim[i];
+      subs.push_back(s);
+      xoff.push_back(0);
+      uoff.push_back(uoff.back() + d.udim[i]);
+    }
+    m = uoff.back();
+    ilqg_default_params_local(&params);
+    for (int q = 0; q < npairs; q++) {
+      pairs.push_back(prs[q]);
+      pair_from_cost.push_back(1);
+      roff.push_back(Rsz);
+      rgoff.push_back(rsz);
+      Rsz += d.udim[prs[q].j] * d.udim[prs[q].j];
+      rsz += d.udim[prs[q].j];
+    }
+  }
+  static void ilqg_default_params_local(ilqg_solver_params* p) {  // solver_params.h:50-84
+    p->convergence_tolerance = 1e-1f;
+    p->max_solver_iters = 1000;
+    p->linesearch = 1;
+    p->initial_alpha_scaling = 0.5f;
+    p->geometric_alpha_scaling = 0.5f;
+    p->max_backtracking_steps = 10;
+    p->expected_decrease_fraction = 0.1f;
+    p->open_loop = 0;
+    p->unconstrained_solver_max_iters = 10;
+    p->geometric_mu_scaling = 1.1f;
+    p->geometric_mu_downscaling = 0.5f;
+    p->geometric_lambda_downscaling = 0.5f;
+    p->constraint_error_tolerance = 1e-1f;
+  }
+  int udim(int i) const { return subs[i].udim; }
+  int pairIndex(int i, int j) const {
+    for (size_t q = 0; q < pairs.size(); q++)
+      if (pairs[q].i == i && pairs[q].j == j) return (int)q;
+    return -1;
+  }
+};
+
+// Per-instance augmented-Lagrangian state: what the reference keeps in
+// Constraint::lambdas_ (constraint.h:136) and the process-global
+// Constraint::mu_ (src/constraint.cpp:61) — one copy per instance here.
+template <class S>
+struct ALState {
+  std::vector<S> lambdas;  // [num_constraints][T]
+  S mu = S(10);            // constants::kDefaultMu, types.h:128-129
+  double t_init = 0.0;     // RelativeTimeTracker::initial_time_
+  double dt = 0.1;
+  int T = 0;
+  ALState() {}
+  ALState(int nc, int T_, double dt_) : lambdas(size_t(nc) * T_, S(0)), dt(dt_), T(T_) {}
+  // RelativeTimeTracker::TimeIndex, relative_time_tracker.h:69-72 (double arithmetic,
+  // truncation aliases k=43,81,86,91 onto k-1 for dt=0.1 — reproduced, not fixed).
+  size_t TimeIndex(double t) const { return static_cast<size_t>((t - t_init) / dt); }
+  S& lambda(int slot, double t) { return lambdas[size_t(slot) * T + TimeIndex(t)]; }
+  S lambda(int slot, double t) const { return lambdas[size_t(slot) * T + TimeIndex(t)]; }
+};
+
+// ---------------------------------------------------------------------------
+// Dynamics
+// ---------------------------------------------------------------------------
+// SinglePlayer{Unicycle4D,Car5D,Car6D}::Evaluate —
+// single_player_unicycle_4d.h:90-100, single_player_car_5d.h:100-111,
+// single_player_car_6d.h:102-114.
+template <class S>
+void EvaluateSubsystem(const ilqg_subsystem& s, const S* x, const S* u, S* xdot) {
+  const S L = S(s.param0);
+  switch (s.kind) {
+    case ILQG_DYN_UNICYCLE_4D:
+      xdot[0] = x[3] * std::cos(x[2]);
+      xdot[1] = x[3] * std::sin(x[2]);
+      xdot[2] = u[0];
+      xdot[3] = u[1];
+      break;
+    case ILQG_DYN_CAR_5D:
+      xdot[0] = x[4] * std::cos(x[2]);
+      xdot[1] = x[4] * std::sin(x[2]);
+      xdot[2] = (x[4] / L) * std::tan(x[3]);
+      xdot[3] = u[0];
+      xdot[4] = u[1];
+      break;
+    case ILQG_DYN_CAR_6D:
+      xdot[0] = x[4] * std::cos(x[2]);
+      xdot[1] = x[4] * std::sin(x[2]);
+      xdot[2] = (x[4] / L) * std::tan(x[3]);
+      xdot[3] = u[0];
+      xdot[4] = x[5];
+      xdot[5] = u[1];
+      break;
+  }
+}
+
+// ConcatenatedDynamicalSystem::Evaluate, src/concatenated_dynamical_system.cpp:69-84
+template <class S>
+Vec<S> Evaluate(const Problem<S>& p, const Vec<S>& x, const Vec<S>& u) {
+  Vec<S> xdot(p.n);
+  for (int i = 0; i < p.N; i++)
+    EvaluateSubsystem(p.subs[i], &x[p.xoff[i]], &u[p.uoff[i]], &xdot[p.xoff[i]]);
+  return xdot;
+}
+
+// MultiPlayerDynamicalSystem::Integrate, src/multi_player_dynamical_system.cpp:52-77.
+// RK4 with 2 sub-steps; `dt` is double in the reference and narrows to the
+// matrix scalar when it multiplies an Eigen expression.
+template <class S>
+Vec<S> Integrate(const Problem<S>& p, double t0, double interval, const Vec<S>& x0, const Vec<S>& u,
+                 bool euler = false) {
+  Vec<S> x = x0;
+  const int n = p.n;
+  if (euler) {
+    const Vec<S> f = Evaluate(p, x0, u);
+    for (int i = 0; i < n; i++) x[i] += S(interval) * f[i];
+    return x;
+  }
+  const double dt = interval / 2.0;
+  const S h = S(dt);
+  for (double t = t0; t < t0 + interval - 0.5 * dt; t += dt) {
+    Vec<S> k1 = Evaluate(p, x, u), xt(n);
+    for (int i = 0; i < n; i++) { k1[i] = h * k1[i]; xt[i] = x[i] + S(0.5) * k1[i]; }
+    Vec<S> k2 = Evaluate(p, xt, u);
+    for (int i = 0; i < n; i++) { k2[i] = h * k2[i]; xt[i] = x[i] + S(0.5) * k2[i]; }
+    Vec<S> k3 = Evaluate(p, xt, u);
+    for (int i = 0; i < n; i++) { k3[i] = h * k3[i]; xt[i] = x[i] + k3[i]; }
+    Vec<S> k4 = Evaluate(p, xt, u);
+    for (int i = 0; i < n; i++) {
+      k4[i] = h * k4[i];
+      x[i] += (k1[i] + S(2.0) * (k2[i] + k3[i]) + k4[i]) / S(6.0);
+    }
+  }
+  return x;
+}
+
+// ConcatenatedDynamicalSystem::Linearize (src/concatenated_dynamical_system.cpp:86-107)
+// on top of LinearDynamicsApproximation's (I, 0) init
+// (linear_dynamics_approximation.h:62-68) and the per-model `+=` Jacobians
+// (single_player_unicycle_4d.h:102-116, single_player_car_5d.h:113-133,
+// single_player_car_6d.h:116-138).  Mixed float*double products are kept
+// exactly as the reference writes them (time::kTimeStep is double).
+template <class S>
+void Linearize(const Problem<S>& p, const Vec<S>& x, const Vec<S>& u, Mat<S>* A, Mat<S>* B) {
+  const int n = p.n;
+  const double dt = p.dt;
+  *A = Mat<S>::Identity(n);
+  *B = Mat<S>(n, p.m);
+  for (int i = 0; i < p.N; i++) {
+    const int o = p.xoff[i], uo = p.uoff[i];
+    const S* xs = &x[o];
+    const ilqg_subsystem& s = p.subs[i];
+    const int vidx = (s.kind == ILQG_DYN_UNICYCLE_4D) ? 3 : 4;
+    const S ctheta = S(double(std::cos(xs[2])) * dt);
+    const S stheta = S(double(std::sin(xs[2])) * dt);
+    (*A)(o + 0, o + 2) += -xs[vidx] * stheta;
+    (*A)(o + 0, o + vidx) += ctheta;
+    (*A)(o + 1, o + 2) += xs[vidx] * ctheta;
+    (*A)(o + 1, o + vidx) += stheta;
+    if (s.kind == ILQG_DYN_UNICYCLE_4D) {
+      (*B)(o + 2, uo + 0) = S(dt);
+      (*B)(o + 3, uo + 1) = S(dt);
+    } else {
+      const S L = S(s.param0);
+      const S cphi = std::cos(xs[3]);
+      const S tphi = std::tan(xs[3]);
+      (*A)(o + 2, o + 3) += S(double(xs[4]) * dt / double(L * cphi * cphi));
+      (*A)(o + 2, o + 4) += S(double(tphi) * dt / double(L));
+      if (s.kind == ILQG_DYN_CAR_5D) {
+        (*B)(o + 3, uo + 0) = S(dt);
+        (*B)(o + 4, uo + 1) = S(dt);
+      } else {
+        (*A)(o + 4, o + 5) += S(dt);
+        (*B)(o + 3, uo + 0) = S(dt);
+        (*B)(o + 5, uo + 1) = S(dt);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Costs
+// ---------------------------------------------------------------------------
+// Constraint::Mu(lambda, g), constraint.h:112-117
+template <class S>
+inline S ConstraintMu(S lambda, S g, S mu) {
+  if (g <= S(1e-4f) && std::abs(lambda) <= S(1e-4f)) return S(0);  // all in-scope constraints are inequalities
+  return mu;
+}
+
+// Cost::Evaluate for every in-scope kind.
+template <class S>
+S EvaluateTerm(const Problem<S>& p, int ti, const S* v, int dim) {
+  const ilqg_cost_term& c = p.terms[ti];
+  const S w = S(c.weight), val = S(c.value);
+  const bool oriented = c.flags & ILQG_FLAG_ORIENTED;
+  switch (c.kind) {
+    case ILQG_COST_QUADRATIC: {  // src/quadratic_cost.cpp:51-63
+      if (c.idx[0] >= 0) {
+        const S delta = v[c.idx[0]] - val;
+        return S(0.5) * w * delta * delta;
+      }
+      S sq = 0;
+      for (int i = 0; i < dim; i++) sq += (v[i] - val) * (v[i] - val);
+      return S(0.5) * w * sq;
+    }
+    case ILQG_COST_SEMIQUADRATIC: {  // src/semiquadratic_cost.cpp:51-59
+      const S diff = v[c.idx[0]] - val;
+      if ((diff > S(0) && oriented) || (diff < S(0) && !oriented)) return S(0.5) * w * diff * diff;
+      return S(0);
+    }
+    case ILQG_COST_QUADRATIC_POLYLINE2: {  // src/quadratic_polyline2_cost.cpp:52-69
+      S cx, cy, ssd;
+      bool endp;
+      p.polylines[c.polyline].ClosestPoint(v[c.idx[0]], v[c.idx[1]], &cx, &cy, nullptr, nullptr, &ssd,
+                                           &endp);
+      if (endp) ssd = S(0);
+      return S(0.5) * w * std::abs(ssd);
+    }
+    case ILQG_COST_SEMIQUADRATIC_POLYLINE2: {  // src/semiquadratic_polyline2_cost.cpp:52-74
+      S cx, cy, ssd;
+      bool endp;
+      p.polylines[c.polyline].ClosestPoint(v[c.idx[0]], v[c.idx[1]], &cx, &cy, nullptr, nullptr, &ssd,
+                                           &endp);
+      if (endp) return S(0);
+      const S sst = sgn(val) * val * val;  // semiquadratic_polyline2_cost.h:66
+      const bool active = (ssd > sst && oriented) || (ssd < sst && !oriented);
+      if (!active) return S(0);
+      const S sd = sgn(ssd) * std::sqrt(std::abs(ssd));
+      const S diff = sd - val;
+      return S(0.5) * w * diff * diff;
+    }
+    case ILQG_COST_PROXIMITY: {  // src/proximity_cost.cpp:52-61
+      const S dx = v[c.idx[0]] - v[c.idx[2]], dy = v[c.idx[1]] - v[c.idx[3]];
+      const S dsq = dx * dx + dy * dy;
+      if (dsq >= val * val) return S(0);
+      const S gap = val - std::sqrt(dsq);
+      return S(0.5) * w * gap * gap;
+    }
+    case ILQG_COST_SIGNED_DISTANCE: {  // src/signed_distance_cost.cpp:51-63
+      const S dx = v[c.idx[0]] - v[c.idx[2]], dy = v[c.idx[1]] - v[c.idx[3]];
+      const S cost = val - std::hypot(dx, dy);
+      return oriented ? cost : -cost;
+    }
+    case ILQG_COST_EXTREME_VALUE: {  // src/extreme_value_cost.cpp:51-85
+      const bool is_min = c.flags & ILQG_FLAG_IS_MIN;
+      S ext = is_min ? std::numeric_limits<S>::infinity() : -std::numeric_limits<S>::infinity();
+      for (int q = 0; q < c.child_count; q++) {
+        const S value = EvaluateTerm(p, c.child_begin + q, v, dim);
+        if ((is_min && value < ext) || (!is_min && value > ext)) ext = value;
+      }
+      return ext;
+    }
+    case ILQG_CONSTRAINT_PROXIMITY: {  // src/proximity_constraint.cpp:56-62
+      const S dx = v[c.idx[0]] - v[c.idx[2]], dy = v[c.idx[1]] - v[c.idx[3]];
+      const S value = std::hypot(dx, dy) - val;
+      return oriented ? value : -value;
+    }
+    case ILQG_CONSTRAINT_SINGLE_DIMENSION:  // single_dimension_constraint.h:68-70
+      return oriented ? v[c.idx[0]] - val : val - v[c.idx[0]];
+  }
+  return S(0);
+}
+
+// Constraint::ModifyDerivatives, src/constraint.cpp:63-89
+template <class S>
+void ModifyDerivatives(S lambda, S mu_in, S g, S* dx, S* ddx, S* dy = nullptr, S* ddy = nullptr,
+                       S* dxdy = nullptr) {
+  const S mu = ConstraintMu(lambda, g, mu_in);
+  const S new_dx = lambda * *dx + mu * g * *dx;
+  const S new_ddx = lambda * *ddx + mu * (*dx * *dx + g * *ddx);
+  if (dy) {
+    const S new_dy = lambda * *dy + mu * g * *dy;
+    const S new_ddy = lambda * *ddy + mu * (*dy * *dy + g * *ddy);
+    const S new_dxdy = lambda * *dxdy + mu * (*dy * *dx + g * *dxdy);
+    *dy = new_dy;
+    *ddy = new_ddy;
+    *dxdy = new_dxdy;
+  }
+  *dx = new_dx;
+  *ddx = new_ddx;
+}
+
+// Cost::Quadraticize (accumulating) for every in-scope kind.
+template <class S>
+void QuadraticizeTerm(const Problem<S>& p, int ti, double t, const S* v, int dim, Mat<S>* hess,
+                      Vec<S>* grad, const ALState<S>* al) {
+  const ilqg_cost_term& c = p.terms[ti];
+  const S w = S(c.weight), val = S(c.value);
+  const bool oriented = c.flags & ILQG_FLAG_ORIENTED;
+  Mat<S>& H = *hess;
+  Vec<S>& G = *grad;
+  switch (c.kind) {
+    case ILQG_COST_QUADRATIC: {  // src/quadratic_cost.cpp:65-94
+      if (c.idx[0] >= 0) {
+        const int d = c.idx[0];
+        const S delta = v[d] - val;
+        G[d] += w * delta;
+        H(d, d) += w;
+      } else {
+        for (int i = 0; i < dim; i++) {
+          G[i] += w * (v[i] - val);
+          H(i, i) = H(i, i) + w;
+        }
+      }
+      return;
+    }
+    case ILQG_COST_SEMIQUADRATIC: {  // src/semiquadratic_cost.cpp:63-85
+      const int d = c.idx[0];
+      const S diff = v[d] - val;
+      if ((diff < S(0) && oriented) || (diff > S(0) && !oriented)) return;
+      G[d] += w * diff;
+      H(d, d) += w;
+      return;
+    }
+    case ILQG_COST_QUADRATIC_POLYLINE2: {  // src/quadratic_polyline2_cost.cpp:71-126
+      const int xi = c.idx[0], yi = c.idx[1];
+      const S px = v[xi], py = v[yi];
+      S cx, cy;
+      bool is_vertex, is_endpoint;
+      Segment2<S> seg;
+      p.polylines[c.polyline].ClosestPoint(px, py, &cx, &cy, &is_vertex, &seg, nullptr, &is_endpoint);
+      if (is_endpoint) return;
+      S ddx = w, ddy = w, dxdy = 0;
+      S dx = w * (px - cx), dy = w * (py - cy);
+      if (!is_vertex) {
+        const S relx = px - seg.p1x, rely = py - seg.p1y;
+        ddx = w * seg.uy * seg.uy;
+        ddy = w * seg.ux * seg.ux;
+        dxdy = -w * seg.ux * seg.uy;
+        const S w_cross = w * (relx * seg.uy - rely * seg.ux);
+        dx = w_cross * seg.uy;
+        dy = -w_cross * seg.ux;
+      }
+      G[xi] += dx;
+      G[yi] += dy;
+      H(xi, xi) += ddx;
+      H(yi, yi) += ddy;
+      H(xi, yi) += dxdy;
+      H(yi, xi) += dxdy;
+      return;
+    }
+    case ILQG_COST_SEMIQUADRATIC_POLYLINE2: {  // src/semiquadratic_polyline2_cost.cpp:76-142
+      const int xi = c.idx[0], yi = c.idx[1];
+      const S px = v[xi], py = v[yi];
+      S cx, cy, ssd;
+      bool is_vertex, is_endpoint;
+      Segment2<S> seg;
+      p.polylines[c.polyline].ClosestPoint(px, py, &cx, &cy, &is_vertex, &seg, &ssd, &is_endpoint);
+      const S sst = sgn(val) * val * val;
+      const bool active = (ssd > sst && oriented) || (ssd < sst && !oriented);
+      if (!active) return;
+      if (is_endpoint) return;
+      S ddx = w, ddy = w, dxdy = 0;
+      S scaling = std::sqrt(std::abs(ssd));
+      scaling = (scaling - std::abs(val)) / scaling;
+      S dx = w * scaling * (px - cx);
+      S dy = w * scaling * (py - cy);
+      if (!is_vertex) {
+        const S relx = px - seg.p1x, rely = py - seg.p1y;
+        ddx = w * seg.uy * seg.uy;
+        ddy = w * seg.ux * seg.ux;
+        dxdy = -w * seg.ux * seg.uy;
+        const S w_cross = w * (relx * seg.uy - rely * seg.ux - val);
+        dx = w_cross * seg.uy;
+        dy = -w_cross * seg.ux;
+      }
+      G[xi] += dx;
+      G[yi] += dy;
+      H(xi, xi) += ddx;
+      H(yi, yi) += ddy;
+      H(xi, yi) += dxdy;
+      H(yi, xi) += dxdy;
+      return;
+    }
+    case ILQG_COST_PROXIMITY: {  // src/proximity_cost.cpp:63-122
+      const int x1 = c.idx[0], y1 = c.idx[1], x2 = c.idx[2], y2 = c.idx[3];
+      const S dx = v[x1] - v[x2], dy = v[y1] - v[y2];
+      const S dsq = dx * dx + dy * dy;
+      if (dsq >= val * val) return;
+      const S delta = std::sqrt(dsq);
+      const S gap = val - delta;
+      const S wd = w / delta;
+      const S dxd = dx / delta, dyd = dy / delta;
+      const S ddx1 = -wd * gap * dx;
+      const S ddy1 = -wd * gap * dy;
+      const S hxx = wd * (dxd * (gap * dxd + dx) - gap);
+      const S hyy = wd * (dyd * (gap * dyd + dy) - gap);
+      const S hxy = wd * (dxd * (gap * dyd + dy));
+      G[x1] += ddx1; G[x2] -= ddx1; G[y1] += ddy1; G[y2] -= ddy1;
+      H(x1, x1) += hxx; H(x1, x2) -= hxx; H(x2, x1) -= hxx; H(x2, x2) += hxx;
+      H(y1, y1) += hyy; H(y1, y2) -= hyy; H(y2, y1) -= hyy; H(y2, y2) += hyy;
+      H(x1, y1) += hxy; H(y1, x1) += hxy;
+      H(x1, y2) -= hxy; H(y2, x1) -= hxy;
+      H(x2, y1) -= hxy; H(y1, x2) -= hxy;
+      H(x2, y2) += hxy; H(y2, x2) += hxy;
+      return;
+    }
+    case ILQG_COST_SIGNED_DISTANCE: {  // src/signed_distance_cost.cpp:65-113
+      const int x1 = c.idx[0], y1 = c.idx[1], x2 = c.idx[2], y2 = c.idx[3];
+      const S s = oriented ? S(1) : S(-1);
+      const S ex = v[x1] - v[x2], ey = v[y1] - v[y2];
+      const S norm = std::hypot(ex, ey);
+      const S norm3 = norm * norm * norm;
+      const S dx1 = -s * ex / norm, dy1 = -s * ey / norm;
+      const S ddx1 = -s * ey * ey / norm3, ddy1 = -s * ex * ex / norm3;
+      const S dxy = s * ex * ey / norm3;
+      G[x1] += dx1; G[y1] += dy1; G[x2] -= dx1; G[y2] -= dy1;
+      H(x1, x1) += ddx1; H(y1, y1) += ddy1; H(x1, y1) += dxy; H(y1, x1) += dxy;
+      H(x2, x2) += ddx1; H(y2, y2) += ddy1; H(x2, y2) += dxy; H(y2, x2) += dxy;
+      H(x1, x2) -= ddx1; H(x1, y2) -= dxy; H(y1, x2) -= dxy; H(y1, y2) -= ddy1;
+      H(x2, x1) -= ddx1; H(x2, y1) -= dxy; H(y2, x1) -= dxy; H(y2, y1) -= ddy1;
+      return;
+    }
+    case ILQG_COST_EXTREME_VALUE: {  // src/extreme_value_cost.cpp:58-85
+      const bool is_min = c.flags & ILQG_FLAG_IS_MIN;
+      S ext = is_min ? std::numeric_limits<S>::infinity() : -std::numeric_limits<S>::infinity();
+      int best = c.child_begin;
+      for (int q = 0; q < c.child_count; q++) {
+        const S value = EvaluateTerm(p, c.child_begin + q, v, dim);
+        if ((is_min && value < ext) || (!is_min && value > ext)) {
+          ext = value;
+          best = c.child_begin + q;
+        }
+      }
+      QuadraticizeTerm(p, best, t, v, dim, hess, grad, al);
+      return;
+    }
+    case ILQG_CONSTRAINT_PROXIMITY: {  // src/proximity_constraint.cpp:64-116
+      const int x1 = c.idx[0], y1 = c.idx[1], x2 = c.idx[2], y2 = c.idx[3];
+      const S dx = v[x1] - v[x2], dy = v[y1] - v[y2];
+      const S prox = std::hypot(dx, dy);
+      const S sign = oriented ? S(1) : S(-1);
+      const S g = sign * (prox - val);
+      const S rdx = dx / prox, rdy = dy / prox;
+      S gx = sign * rdx, gy = sign * rdy;
+      S hxx = sign * (S(1) - rdx * rdx) / prox;
+      S hyy = sign * (S(1) - rdy * rdy) / prox;
+      S hxy = -sign * rdx * rdy / prox;
+      const S lambda = al ? al->lambda(c.constraint_slot, t) : S(0);
+      const S mu = al ? al->mu : S(10);
+      ModifyDerivatives(lambda, mu, g, &gx, &hxx, &gy, &hyy, &hxy);
+      G[x1] += gx; G[x2] -= gx; G[y1] += gy; G[y2] -= gy;
+      H(x1, x1) += hxx; H(x1, x2) -= hxx; H(x2, x1) -= hxx; H(x2, x2) += hxx;
+      H(y1, y1) += hyy; H(y1, y2) -= hyy; H(y2, y1) -= hyy; H(y2, y2) += hyy;
+      H(x1, y1) += hxy; H(x1, y2) -= hxy; H(x2, y1) -= hxy; H(x2, y2) += hxy;
+      H(y1, x1) += hxy; H(y1, x2) -= hxy; H(y2, x1) -= hxy; H(y2, x2) += hxy;
+      return;
+    }
+    case ILQG_CONSTRAINT_SINGLE_DIMENSION: {  // single_dimension_constraint.h:74-97
+      const int d = c.idx[0];
+      const S sign = oriented ? S(1) : S(-1);
+      const S g = sign * (v[d] - val);
+      S dx = sign, ddx = 0;
+      const S lambda = al ? al->lambda(c.constraint_slot, t) : S(0);
+      const S mu = al ? al->mu : S(10);
+      ModifyDerivatives(lambda, mu, g, &dx, &ddx);
+      G[d] += dx;
+      H(d, d) += ddx;
+      return;
+    }
+  }
+}
+
+// QuadraticCostApproximation for one (k, player): Q, l and the pair blocks.
+template <class S>
+struct Quad {
+  Mat<S> Q;
+  Vec<S> l;
+  std::vector<Mat<S>> R;   // per pair of the problem table (unused pairs stay empty)
+  std::vector<Vec<S>> r;
+  std::vector<char> has;   // control.find(j) != end
+};
+
+// PlayerCost::Quadraticize / QuadraticizeControlCosts, src/player_cost.cpp:194-225
+// (with AccumulateControlCostsBase :59-86 creating sigma_u*I blocks at first touch).
+template <class S>
+Quad<S> QuadraticizePlayer(const Problem<S>& p, int i, double t, const Vec<S>& x, const Vec<S>& u,
+                           bool control_only, const ALState<S>* al) {
+  Quad<S> q;
+  q.Q = Mat<S>::Identity(p.n, S(p.pcs[i].state_regularization));
+  q.l.assign(p.n, S(0));
+  const int np = (int)p.pairs.size();
+  q.R.resize(np);
+  q.r.resize(np);
+  q.has.assign(np, 0);
+  auto touch = [&](int j) {
+    const int pi = p.pairIndex(i, j);
+    if (!q.has[pi]) {
+      q.R[pi] = Mat<S>::Identity(p.udim(j), S(p.pcs[i].control_regularization));
+      q.r[pi].assign(p.udim(j), S(0));
+      q.has[pi] = 1;
+    }
+    return pi;
+  };
+  const int nt = (int)p.terms.size();
+  if (!control_only)
+    for (int ti = 0; ti < nt; ti++)
+      if (p.terms[ti].player == i && p.terms[ti].role == ILQG_ROLE_STATE_COST)
+        QuadraticizeTerm(p, ti, t, x.data(), p.n, &q.Q, &q.l, al);
+  for (int ti = 0; ti < nt; ti++)
+    if (p.terms[ti].player == i && p.terms[ti].role == ILQG_ROLE_CONTROL_COST) {
+      const int j = p.terms[ti].arg, pi = touch(j);
+      QuadraticizeTerm(p, ti, t, &u[p.uoff[j]], p.udim(j), &q.R[pi], &q.r[pi], al);
+    }
+  if (!control_only) {
+    for (int ti = 0; ti < nt; ti++)
+      if (p.terms[ti].player == i && p.terms[ti].role == ILQG_ROLE_STATE_CONSTRAINT)
+        QuadraticizeTerm(p, ti, t, x.data(), p.n, &q.Q, &q.l, al);
+    for (int ti = 0; ti < nt; ti++)
+      if (p.terms[ti].player == i && p.terms[ti].role == ILQG_ROLE_CONTROL_CONSTRAINT) {
+        const int j = p.terms[ti].arg, pi = touch(j);
+        QuadraticizeTerm(p, ti, t, &u[p.uoff[j]], p.udim(j), &q.R[pi], &q.r[pi], al);
+      }
+  }
+  return q;
+}
+
+// PlayerCost::Evaluate(t, x, us), src/player_cost.cpp:128-144 (constraints excluded).
+template <class S>
+S EvaluatePlayer(const Problem<S>& p, int i, const Vec<S>& x, const Vec<S>& u) {
+  S total = 0;
+  const int nt = (int)p.terms.size();
+  for (int ti = 0; ti < nt; ti++)
+    if (p.terms[ti].player == i && p.terms[ti].role == ILQG_ROLE_STATE_COST)
+      total += EvaluateTerm(p, ti, x.data(), p.n);
+  for (int ti = 0; ti < nt; ti++)
+    if (p.terms[ti].player == i && p.terms[ti].role == ILQG_ROLE_CONTROL_COST) {
+      const int j = p.terms[ti].arg;
+      total += EvaluateTerm(p, ti, &u[p.uoff[j]], p.udim(j));
+    }
+  return total;
+}
+
+// ---------------------------------------------------------------------------
+// Containers for one instance
+// ---------------------------------------------------------------------------
+template <class S>
+struct Trajectory {  // OperatingPoint, operating_point.h:55-85 (us stacked per step)
+  std::vector<Vec<S>> xs, us;
+  Trajectory() {}
+  Trajectory(int T, int n, int m) : xs(T, Vec<S>(n, S(0))), us(T, Vec<S>(m, S(0))) {}
+};
+template <class S>
+struct Strategies {  // vector<Strategy>, strategy.h:59-85 — stacked (m x n) gain per step
+  std::vector<Mat<S>> P;
+  std::vector<Vec<S>> alpha;
+  Strategies() {}
+  Strategies(int T, int n, int m) : P(T, Mat<S>(m, n)), alpha(T, Vec<S>(m, S(0))) {}
+};
+template <class S>
+struct LQInputs {
+  std::vector<Mat<S>> A, B;           // [T]
+  std::vector<std::vector<Quad<S>>> q;  // [T][N]
+};
+
+// ---------------------------------------------------------------------------
+// LQFeedbackSolver::Solve, src/lq_feedback_solver.cpp:71-244
+// ---------------------------------------------------------------------------
+template <class S>
+void SolveLQFeedback(const Problem<S>& p, const LQInputs<S>& in, const Vec<S>& x0,
+                     bool adaptive_regularization, Strategies<S>* out, std::vector<Vec<S>>* delta_xs,
+                     std::vector<std::vector<Vec<S>>>* costates) {
+  const int T = (int)in.A.size(), N = p.N, n = p.n, m = p.m;
+  *out = Strategies<S>(T, n, m);
+  std::vector<std::vector<Mat<S>>> Zs(T, std::vector<Mat<S>>(N));
+  std::vector<std::vector<Vec<S>>> zetas(T, std::vector<Vec<S>>(N));
+  for (int i = 0; i < N; i++) {  // :102-105
+    Zs[T - 1][i] = in.q[T - 1][i].Q;
+    zetas[T - 1][i] = in.q[T - 1][i].l;
+  }
+  for (int k = T - 2; k >= 0; k--) {  // :110
+    const Mat<S>& A = in.A[k];
+    const Mat<S>& B = in.B[k];
+    const auto& quad = in.q[k];
+    Mat<S> Sm(m, m), Y(m, n + 1);
+    for (int i = 0; i < N; i++) {
+      const int ro = p.uoff[i], mi = p.udim(i);
+      // BiZi = B_i^T Z_i  (:128)
+      Mat<S> Bi(n, mi);
+      for (int c = 0; c < mi; c++)
+        for (int rr = 0; rr < n; rr++) Bi(rr, c) = B(rr, ro + c);
+      const Mat<S> BiZi = matmulTN(Bi, Zs[k + 1][i]);
+      const Mat<S> Srow = matmul(BiZi, B);  // all column blocks at once (:131-149)
+      const int pii = p.pairIndex(i, i);
+      for (int a = 0; a < mi; a++)
+        for (int c = 0; c < m; c++) {
+          S v = Srow(a, c);
+          if (c >= ro && c < ro + mi) v = v + quad[i].R[pii](a, c - ro);
+          Sm(ro + a, c) = v;
+        }
+      const Mat<S> Yrow = matmul(BiZi, A);  // :152-153
+      const Vec<S> yz = matvecT(Bi, zetas[k + 1][i]);  // :154-157
+      for (int a = 0; a < mi; a++) {
+        for (int c = 0; c < n; c++) Y(ro + a, c) = Yrow(a, c);
+        Y(ro + a, n) = yz[a] + quad[i].r[pii][a];
+      }
+    }
+    if (adaptive_regularization) {  // :163-176 (column-wise, in place, sequential)
+      for (int c = 0; c < m; c++) {
+        S l1 = 0;
+        for (int rr = 0; rr < m; rr++) l1 += std::abs(Sm(rr, c));
+        const S radius = l1 - std::abs(Sm(c, c));
+        const S eval_lo = Sm(c, c) - radius;
+        const S min_eval = S(1e-3f);
+        if (eval_lo < min_eval) Sm(c, c) += radius + min_eval;
+      }
+    }
+    HouseholderQR<S> qr;  // :180
+    qr.compute(Sm);
+    const Mat<S> X = qr.solve(Y);
+    Mat<S>& P = out->P[k];
+    Vec<S>& alpha = out->alpha[k];
+    for (int a = 0; a < m; a++) {
+      for (int c = 0; c < n; c++) P(a, c) = X(a, c);
+      alpha[a] = X(a, n);
+    }
+    // F = A - sum B_i P_i ; beta = - sum B_i alpha_i  (:189-194)
+    Mat<S> F = A;
+    const Mat<S> BP = matmul(B, P);
+    for (size_t e = 0; e < F.d.size(); e++) F.d[e] -= BP.d[e];
+    Vec<S> beta = matvec(B, alpha);
+    for (auto& b : beta) b = -b;
+    for (int i = 0; i < N; i++) {  // :198-212
+      Vec<S> tmp = matvec(Zs[k + 1][i], beta);
+      for (int e = 0; e < n; e++) tmp[e] += zetas[k + 1][i][e];
+      Vec<S> zeta = matvecT(F, tmp);
+      for (int e = 0; e < n; e++) zeta[e] += quad[i].l[e];
+      Mat<S> Z = matmulTN(F, matmul(Zs[k + 1][i], F));
+      for (size_t e = 0; e < Z.d.size(); e++) Z.d[e] += quad[i].Q.d[e];
+      for (size_t q = 0; q < p.pairs.size(); q++) {
+        if (p.pairs[q].i != i || !quad[i].has[q]) continue;
+        const int j = p.pairs[q].j, jo = p.uoff[j], mj = p.udim(j);
+        Mat<S> Pj(mj, n);
+        Vec<S> aj(mj);
+        for (int a = 0; a < mj; a++) {
+          aj[a] = alpha[jo + a];
+          for (int c = 0; c < n; c++) Pj(a, c) = P(jo + a, c);
+        }
+        Vec<S> w = matvec(quad[i].R[q], aj);
+        for (int a = 0; a < mj; a++) w[a] -= quad[i].r[q][a];
+        const Vec<S> add = matvecT(Pj, w);
+        for (int e = 0; e < n; e++) zeta[e] += add[e];
+        const Mat<S> PRP = matmulTN(Pj, matmul(quad[i].R[q], Pj));
+        for (size_t e = 0; e < Z.d.size(); e++) Z.d[e] += PRP.d[e];
+      }
+      Zs[k][i] = Z;
+      zetas[k][i] = zeta;
+    }
+  }
+  if (delta_xs) {  // forward pass, :217-241 (feedback term deliberately absent)
+    delta_xs->assign(T, Vec<S>(n, S(0)));
+    if (costates) costates->assign(T, std::vector<Vec<S>>(N, Vec<S>(n, S(0))));
+    Vec<S> xstar = x0;
+    for (int k = 0; k < T; k++) {
+      (*delta_xs)[k] = xstar;
+      if (costates)
+        for (int i = 0; i < N; i++)
+          if (k < T - 1) {
+            Vec<S> c = matvec(Zs[k + 1][i], xstar);
+            for (int e = 0; e < n; e++) c[e] = -c[e] - zetas[k + 1][i][e];
+            (*costates)[k][i] = c;
+          }
+      Vec<S> nx = matvec(in.A[k], xstar);
+      const Vec<S> ba = matvec(in.B[k], out->alpha[k]);
+      for (int e = 0; e < n; e++) nx[e] -= ba[e];
+      xstar = nx;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// LQOpenLoopSolver::Solve, src/lq_open_loop_solver.cpp:73-195
+// ---------------------------------------------------------------------------
+template <class S>
+void SolveLQOpenLoop(const Problem<S>& p, const LQInputs<S>& in, const Vec<S>& x0, Strategies<S>* out,
+                     std::vector<Vec<S>>* delta_xs, std::vector<std::vector<Vec<S>>>* costates) {
+  const int T = (int)in.A.size(), N = p.N, n = p.n, m = p.m;
+  *out = Strategies<S>(T, n, m);
+  std::vector<std::vector<Mat<S>>> Ms(T, std::vector<Mat<S>>(N)), warpedB(T, std::vector<Mat<S>>(N));
+  std::vector<std::vector<Vec<S>>> ms(T, std::vector<Vec<S>>(N)), warpedr(T, std::vector<Vec<S>>(N));
+  std::vector<HouseholderQR<S>> qrs(T);
+  std::vector<Vec<S>> inter(T, Vec<S>(n, S(0)));
+  for (int i = 0; i < N; i++) {  // :105-108
+    ms[T - 1][i] = in.q[T - 1][i].l;
+    Ms[T - 1][i] = in.q[T - 1][i].Q;
+  }
+  for (int k = T - 2; k >= 0; k--) {  // :113-151
+    const Mat<S>& A = in.A[k];
+    const Mat<S>& B = in.B[k];
+    const auto& quad = in.q[k];
+    Mat<S> Lam = Mat<S>::Identity(n);
+    std::vector<Mat<S>> Bis(N);
+    for (int i = 0; i < N; i++) {
+      const int ro = p.uoff[i], mi = p.udim(i), pii = p.pairIndex(i, i);
+      Mat<S> Bi(n, mi), BiT(mi, n);
+      for (int c = 0; c < mi; c++)
+        for (int rr = 0; rr < n; rr++) { Bi(rr, c) = B(rr, ro + c); BiT(c, rr) = B(rr, ro + c); }
+      Bis[i] = Bi;
+      LDLT<S> chol;
+      chol.compute(quad[i].R[pii]);
+      warpedB[k][i] = chol.solve(BiT);
+      Mat<S> rcol(mi, 1);
+      for (int a = 0; a < mi; a++) rcol(a, 0) = quad[i].r[pii][a];
+      const Mat<S> wr = chol.solve(rcol);
+      warpedr[k][i].assign(mi, S(0));
+      for (int a = 0; a < mi; a++) warpedr[k][i][a] = wr(a, 0);
+      const Mat<S> add = matmul(matmul(Bi, warpedB[k][i]), Ms[k + 1][i]);
+      for (size_t e = 0; e < Lam.d.size(); e++) Lam.d[e] += add.d[e];
+    }
+    qrs[k].compute(Lam);
+    for (int i = 0; i < N; i++) {
+      Vec<S> w = matvec(warpedB[k][i], ms[k + 1][i]);
+      for (int a = 0; a < p.udim(i); a++) w[a] += warpedr[k][i][a];
+      const Vec<S> bw = matvec(Bis[i], w);
+      for (int e = 0; e < n; e++) inter[k][e] -= bw[e];
+    }
+    const Mat<S> LinvA = qrs[k].solve(A);
+    Mat<S> ic(n, 1);
+    for (int e = 0; e < n; e++) ic(e, 0) = inter[k][e];
+    const Mat<S> Linvc = qrs[k].solve(ic);
+    Vec<S> lc(n);
+    for (int e = 0; e < n; e++) lc[e] = Linvc(e, 0);
+    for (int i = 0; i < N; i++) {
+      Mat<S> M = matmulTN(A, matmul(Ms[k + 1][i], LinvA));
+      for (size_t e = 0; e < M.d.size(); e++) M.d[e] += quad[i].Q.d[e];
+      Vec<S> tmp = matvec(Ms[k + 1][i], lc);
+      for (int e = 0; e < n; e++) tmp[e] += ms[k + 1][i][e];
+      Vec<S> mm = matvecT(A, tmp);
+      for (int e = 0; e < n; e++) mm[e] += quad[i].l[e];
+      Ms[k][i] = M;
+      ms[k][i] = mm;
+    }
+  }
+  if (delta_xs) delta_xs->assign(T, Vec<S>(n, S(0)));
+  if (costates) costates->assign(T, std::vector<Vec<S>>(N, Vec<S>(n, S(0))));
+  Vec<S> xstar = x0;
+  for (int k = 0; k < T - 1; k++) {  // :156-185
+    if (delta_xs) (*delta_xs)[k] = xstar;
+    Vec<S> rhs = matvec(in.A[k], xstar);
+    Mat<S> rc(n, 1);
+    for (int e = 0; e < n; e++) rc(e, 0) = rhs[e] + inter[k][e];
+    const Mat<S> sol = qrs[k].solve(rc);
+    for (int e = 0; e < n; e++) xstar[e] = sol(e, 0);
+    for (int i = 0; i < N; i++) {
+      Vec<S> it = matvec(Ms[k + 1][i], xstar);
+      for (int e = 0; e < n; e++) it[e] += ms[k + 1][i][e];
+      const Vec<S> a = matvec(warpedB[k][i], it);
+      for (int q = 0; q < p.udim(i); q++) out->alpha[k][p.uoff[i] + q] = a[q] + warpedr[k][i][q];
+      if (costates) (*costates)[k][i] = matvecT(in.A[k], it);
+    }
+  }
+  if (delta_xs) delta_xs->back() = xstar;  // :188-192
+}
+
+// ---------------------------------------------------------------------------
+// ILQSolver pieces, src/ilq_solver.cpp
+// ---------------------------------------------------------------------------
+// ILQSolver::CurrentOperatingPoint, :174-206 (Strategy::operator(), strategy.h:73-76)
+template <class S>
+void Rollout(const Problem<S>& p, const Vec<S>& x0, const Trajectory<S>& last, const Strategies<S>& st,
+             Trajectory<S>* cur, bool euler = false) {
+  const int T = p.T, n = p.n, m = p.m;
+  if ((int)cur->xs.size() != T) *cur = Trajectory<S>(T, n, m);
+  Vec<S> x = x0;
+  for (int k = 0; k < T; k++) {
+    const double t = double(k) * p.dt;
+    Vec<S> dx(n);
+    for (int e = 0; e < n; e++) dx[e] = x[e] - last.xs[k][e];
+    cur->xs[k] = x;
+    const Vec<S> Pdx = matvec(st.P[k], dx);
+    for (int a = 0; a < m; a++) cur->us[k][a] = last.us[k][a] - Pdx[a] - st.alpha[k][a];
+    if (k < T - 1) x = Integrate(p, t, p.dt, x, cur->us[k], euler);
+  }
+}
+
+// ILQSolver::ComputeLinearization, :437-455
+template <class S>
+void ComputeLinearization(const Problem<S>& p, const Trajectory<S>& op, LQInputs<S>* lq) {
+  lq->A.resize(p.T);
+  lq->B.resize(p.T);
+  for (int k = 0; k < p.T; k++) Linearize(p, op.xs[k], op.us[k], &lq->A[k], &lq->B[k]);
+}
+
+// ILQSolver::ComputeCostQuadraticization, :471-490
+template <class S>
+void ComputeQuadraticization(const Problem<S>& p, const Trajectory<S>& op, const std::vector<int>& t_extreme,
+                             const ALState<S>* al, LQInputs<S>* lq) {
+  lq->q.assign(p.T, std::vector<Quad<S>>(p.N));
+  for (int k = 0; k < p.T; k++) {
+    const double t = double(k) * p.dt;
+    for (int i = 0; i < p.N; i++) {
+      const bool full = p.pcs[i].structure == ILQG_SUM || t_extreme[i] == k;
+      lq->q[k][i] = QuadraticizePlayer(p, i, t, op.xs[k], op.us[k], !full, al);
+    }
+  }
+}
+
+// ILQSolver::TotalCosts, :220-257
+template <class S>
+void TotalCosts(const Problem<S>& p, const Trajectory<S>& op, Vec<S>* costs, std::vector<int>* t_extreme) {
+  costs->assign(p.N, S(0));
+  for (int i = 0; i < p.N; i++) {
+    if (p.pcs[i].structure == ILQG_MAX) (*costs)[i] = -std::numeric_limits<S>::infinity();
+    if (p.pcs[i].structure == ILQG_MIN) (*costs)[i] = std::numeric_limits<S>::infinity();
+  }
+  for (int k = 0; k < p.T; k++)
+    for (int i = 0; i < p.N; i++) {
+      const S c = EvaluatePlayer(p, i, op.xs[k], op.us[k]);
+      if (p.pcs[i].structure == ILQG_SUM)
+        (*costs)[i] += c;
+      else if (p.pcs[i].structure == ILQG_MAX && c > (*costs)[i]) {
+        (*costs)[i] = c;
+        (*t_extreme)[i] = k;
+      } else if (p.pcs[i].structure == ILQG_MIN && c < (*costs)[i]) {
+        (*costs)[i] = c;
+        (*t_extreme)[i] = k;
+      }
+    }
+}
+
+// ILQSolver::MeritFunction (:400-435) minus the re-quadraticization it triggers.
+template <class S>
+S MeritFromQuad(const Problem<S>& p, const LQInputs<S>& lq) {
+  S merit = 0;
+  for (int k = 0; k < p.T; k++)
+    for (int i = 0; i < p.N; i++) {
+      const Quad<S>& q = lq.q[k][i];
+      const int pii = p.pairIndex(i, i);
+      S s = 0;
+      for (S v : q.r[pii]) s += v * v;
+      merit += s;
+      if (k > 0) {
+        S s2 = 0;
+        for (S v : q.l) s2 += v * v;
+        merit += s2;
+      }
+    }
+  return S(0.5) * merit;
+}
+
+// ILQSolver::ExpectedDecrease, :364-398
+template <class S>
+S ExpectedDecrease(const Problem<S>& p, const LQInputs<S>& lq, const Strategies<S>& st,
+                   const std::vector<Vec<S>>& delta_xs) {
+  S ed = 0;
+  for (int k = 0; k < p.T; k++)
+    for (int i = 0; i < p.N; i++) {
+      const Quad<S>& q = lq.q[k][i];
+      const int pii = p.pairIndex(i, i), mi = p.udim(i), uo = p.uoff[i];
+      // neg_ui^T * R_ii * r_ii   (Eigen evaluates (a^T R) r left to right)
+      S acc = 0;
+      for (int c = 0; c < mi; c++) {
+        S aR = 0;
+        for (int a = 0; a < mi; a++) aR += st.alpha[k][uo + a] * q.R[pii](a, c);
+        acc += aR * q.r[pii][c];
+      }
+      ed -= acc;
+      if (k > 0) {
+        S acc2 = 0;
+        for (int c = 0; c < p.n; c++) {
+          S dQ = 0;
+          for (int a = 0; a < p.n; a++) dQ += delta_xs[k][a] * q.Q(a, c);
+          acc2 += dQ * q.l[c];
+        }
+        ed -= acc2;
+      }
+    }
+  return ed;
+}
+
+// Per-iteration record (what tests compare against the device path).
+template <class S>
+struct IterLog {
+  S merit, expected_decrease, step;
+  int backtracks;
+  Vec<S> costs;
+};
+
+// Persistent solver state: ILQSolver members last_merit_function_value_,
+// expected_decrease_ (ilq_solver.h:73-74,189-190) survive across Solve() calls.
+template <class S>
+struct ILQState {
+  S last_merit = std::numeric_limits<S>::infinity();
+  S expected_decrease = std::numeric_limits<S>::infinity();
+  std::vector<int> t_extreme;  // PlayerCost::time_of_extreme_cost_, player_cost.h:70
+};
+
+// ILQSolver::Solve, :76-172, with ModifyLQStrategies :289-348 inlined.
+// `fixed_iters` > 0: run exactly that many outer iterations (ignore has_converged).
+// If `raw` is non-null it receives the unscaled LQ strategies of the LAST LQ solve
+// (the object P_t / alpha_t parity is defined on).
+template <class S>
+bool SolveILQ(const Problem<S>& p, const Vec<S>& x0, Trajectory<S>* op_io, Strategies<S>* st_io,
+              ILQState<S>* state, const ALState<S>* al, int fixed_iters, std::vector<IterLog<S>>* log,
+              Vec<S>* final_costs, int* iters_out, int* converged_out, Strategies<S>* raw = nullptr) {
+  const ilqg_solver_params& prm = p.params;
+  if ((int)state->t_extreme.size() != p.N) state->t_extreme.assign(p.N, 0);
+  Trajectory<S> last_op = *op_io, cur_op = *op_io;
+  cur_op.xs[0] = x0;
+  last_op.xs[0] = x0;
+  Strategies<S> strategies = *st_io;
+  int num_iterations = 0;
+  bool has_converged = false;
+  Vec<S> total_costs;
+  std::swap(last_op, cur_op);  // :100
+  Rollout(p, x0, last_op, strategies, &cur_op);
+  TotalCosts(p, cur_op, &total_costs, &state->t_extreme);
+  // What the returned SolverLog ends with (log->AddSolverIterate, :111,164): the
+  // last ACCEPTED iterate; a failed line search returns the log as it stood.
+  Trajectory<S> logged_op = cur_op;
+  Strategies<S> logged_st = strategies;
+  Vec<S> logged_costs = total_costs;
+  LQInputs<S> lq;
+  ComputeQuadraticization(p, cur_op, state->t_extreme, al, &lq);
+  std::vector<Vec<S>> delta_xs;
+  const int max_iters = fixed_iters > 0 ? fixed_iters : prm.max_solver_iters;
+  bool ok = true;
+  while (num_iterations < max_iters && (fixed_iters > 0 || !has_converged)) {
+    num_iterations++;
+    ComputeLinearization(p, cur_op, &lq);
+    Vec<S> dx0(p.n);
+    for (int e = 0; e < p.n; e++) dx0[e] = x0[e] - cur_op.xs[0][e];
+    if (prm.open_loop)
+      SolveLQOpenLoop(p, lq, dx0, &strategies, &delta_xs, (std::vector<std::vector<Vec<S>>>*)nullptr);
+    else
+      SolveLQFeedback(p, lq, dx0, true, &strategies, &delta_xs, (std::vector<std::vector<Vec<S>>>*)nullptr);
+    if (raw) *raw = strategies;
+    // ---- ModifyLQStrategies ----
+    state->expected_decrease = ExpectedDecrease(p, lq, strategies, delta_xs);
+    auto scale = [&](S s) {
+      for (auto& a : strategies.alpha)
+        for (auto& v : a) v *= s;
+    };
+    scale(S(prm.initial_alpha_scaling));
+    const Trajectory<S> last = cur_op;
+    S step = S(prm.initial_alpha_scaling);
+    Rollout(p, last.xs[0], last, strategies, &cur_op);
+    int backtracks = 0;
+    S merit = std::numeric_limits<S>::quiet_NaN();
+    bool accepted = !prm.linesearch;
+    if (prm.linesearch) {
+      for (int bb = 0; bb < prm.max_backtracking_steps; bb++) {
+        ComputeQuadraticization(p, cur_op, state->t_extreme, al, &lq);  // MeritFunction :405
+        merit = MeritFromQuad(p, lq);
+        const S scaled = S(prm.expected_decrease_fraction) * step * state->expected_decrease;
+        if (state->last_merit - merit >= scaled) {  // CheckArmijoCondition :350-362
+          has_converged = (merit <= state->last_merit) &&
+                          std::abs(state->last_merit - merit) < S(prm.convergence_tolerance);
+          state->last_merit = merit;
+          accepted = true;
+          break;
+        }
+        scale(S(prm.geometric_alpha_scaling));
+        step *= S(prm.geometric_alpha_scaling);
+        Rollout(p, last.xs[0], last, strategies, &cur_op);
+        backtracks++;
+      }
+    }
+    if (!accepted) {  // :146-155
+      ok = false;
+      break;
+    }
+    TotalCosts(p, cur_op, &total_costs, &state->t_extreme);
+    if (log) log->push_back({merit, state->expected_decrease, step, backtracks, total_costs});
+    logged_op = cur_op;
+    logged_st = strategies;
+    logged_costs = total_costs;
+  }
+  *op_io = logged_op;
+  *st_io = logged_st;
+  if (final_costs) *final_costs = logged_costs;
+  if (iters_out) *iters_out = num_iterations;
+  if (converged_out) *converged_out = has_converged ? 1 : 0;
+  return ok;
+}
+
+}  // namespace oracle

@@ -1,0 +1,427 @@
+// oracle_capi.cpp — C entry points over ilqg_oracle.hpp for ctypes.  TEST INFRASTRUCTURE ONLY
+// (see the header of ilqg_oracle.hpp).  All pointers are HOST pointers; array
+// layouts are exactly those of include/ilqg.h so tests can feed both sides the
+// same buffers.  `threads` > 1 parallelises over instances with OpenMP (used
+// only by bench.py's cpu_baseline leg; the reference itself is single-threaded).
+#include <cstdio>
+#include <memory>
+
+#include "ilqg_oracle.hpp"
+
+using namespace oracle;
+
+namespace {
+
+template <class S>
+void UnpackLQ(const Problem<S>& p, int T, const S* A, const S* Bm, const S* Q, const S* l, const S* R,
+              const S* r, LQInputs<S>* in) {
+  const int n = p.n, m = p.m, N = p.N;
+  in->A.assign(T, Mat<S>(n, n));
+  in->B.assign(T, Mat<S>(n, m));
+  in->q.assign(T, std::vector<Quad<S>>(N));
+  const int np = (int)p.pairs.size();
+  for (int k = 0; k < T; k++) {
+    std::memcpy(in->A[k].d.data(), A + size_t(k) * n * n, sizeof(S) * n * n);
+    std::memcpy(in->B[k].d.data(), Bm + size_t(k) * n * m, sizeof(S) * n * m);
+    for (int i = 0; i < N; i++) {
+      Quad<S>& q = in->q[k][i];
+      q.Q = Mat<S>(n, n);
+      std::memcpy(q.Q.d.data(), Q + (size_t(k) * N + i) * n * n, sizeof(S) * n * n);
+      q.l.assign(l + (size_t(k) * N + i) * n, l + (size_t(k) * N + i + 1) * n);
+      q.R.resize(np);
+      q.r.resize(np);
+      q.has.assign(np, 0);
+      for (int pr = 0; pr < np; pr++) {
+        if (p.pairs[pr].i != i) continue;
+        const int mj = p.udim(p.pairs[pr].j);
+        q.R[pr] = Mat<S>(mj, mj);
+        std::memcpy(q.R[pr].d.data(), R + size_t(k) * p.Rsz + p.roff[pr], sizeof(S) * mj * mj);
+        q.r[pr].assign(r + size_t(k) * p.rsz + p.rgoff[pr], r + size_t(k) * p.rsz + p.rgoff[pr] + mj);
+        q.has[pr] = 1;
+      }
+    }
+  }
+}
+
+template <class S>
+void PackStrategies(const Problem<S>& p, const Strategies<S>& st, S* P, S* alpha) {
+  const int T = (int)st.P.size(), n = p.n, m = p.m;
+  for (int k = 0; k < T; k++) {
+    std::memcpy(P + size_t(k) * m * n, st.P[k].d.data(), sizeof(S) * m * n);
+    std::memcpy(alpha + size_t(k) * m, st.alpha[k].data(), sizeof(S) * m);
+  }
+}
+template <class S>
+void UnpackStrategies(const Problem<S>& p, int T, const S* P, const S* alpha, Strategies<S>* st) {
+  const int n = p.n, m = p.m;
+  *st = Strategies<S>(T, n, m);
+  for (int k = 0; k < T; k++) {
+    std::memcpy(st->P[k].d.data(), P + size_t(k) * m * n, sizeof(S) * m * n);
+    std::memcpy(st->alpha[k].data(), alpha + size_t(k) * m, sizeof(S) * m);
+  }
+}
+template <class S>
+void UnpackTraj(const Problem<S>& p, int T, const S* xs, const S* us, Trajectory<S>* tr) {
+  *tr = Trajectory<S>(T, p.n, p.m);
+  for (int k = 0; k < T; k++) {
+    std::memcpy(tr->xs[k].data(), xs + size_t(k) * p.n, sizeof(S) * p.n);
+    std::memcpy(tr->us[k].data(), us + size_t(k) * p.m, sizeof(S) * p.m);
+  }
+}
+template <class S>
+void PackTraj(const Problem<S>& p, const Trajectory<S>& tr, S* xs, S* us) {
+  const int T = (int)tr.xs.size();
+  for (int k = 0; k < T; k++) {
+    std::memcpy(xs + size_t(k) * p.n, tr.xs[k].data(), sizeof(S) * p.n);
+    std::memcpy(us + size_t(k) * p.m, tr.us[k].data(), sizeof(S) * p.m);
+  }
+}
+template <class S>
+void PackQuad(const Problem<S>& p, const LQInputs<S>& lq, S* Q, S* l, S* R, S* r) {
+  const int T = (int)lq.q.size(), n = p.n, N = p.N;
+  for (int k = 0; k < T; k++) {
+    std::memset(R + size_t(k) * p.Rsz, 0, sizeof(S) * p.Rsz);
+    std::memset(r + size_t(k) * p.rsz, 0, sizeof(S) * p.rsz);
+    for (int i = 0; i < N; i++) {
+      const Quad<S>& q = lq.q[k][i];
+      std::memcpy(Q + (size_t(k) * N + i) * n * n, q.Q.d.data(), sizeof(S) * n * n);
+      std::memcpy(l + (size_t(k) * N + i) * n, q.l.data(), sizeof(S) * n);
+      for (size_t pr = 0; pr < p.pairs.size(); pr++) {
+        if (p.pairs[pr].i != i || !q.has[pr]) continue;
+        const int mj = p.udim(p.pairs[pr].j);
+        std::memcpy(R + size_t(k) * p.Rsz + p.roff[pr], q.R[pr].d.data(), sizeof(S) * mj * mj);
+        std::memcpy(r + size_t(k) * p.rsz + p.rgoff[pr], q.r[pr].data(), sizeof(S) * mj);
+      }
+    }
+  }
+}
+
+template <class S>
+int LQBatch(const ilqg_dims* d, const void* A_, const void* B_, const void* Q_, const void* l_, const void* R_,
+            const void* r_, const ilqg_pair* pairs, int npairs, const void* x0_, void* P_, void* alpha_,
+            void* dx_, void* co_, int open_loop, int threads) {
+  Problem<S> p(*d, pairs, npairs);
+  for (int i = 0; i < p.N; i++)
+    if (p.pairIndex(i, i) < 0) return ILQG_ERR_INVALID;  // CHECK at lq_feedback_solver.cpp:139-140
+  const int T = d->T, n = p.n, m = p.m, N = p.N;
+  const S *A = (const S*)A_, *B = (const S*)B_, *Q = (const S*)Q_, *l = (const S*)l_, *R = (const S*)R_,
+          *r = (const S*)r_, *x0 = (const S*)x0_;
+  S *P = (S*)P_, *alpha = (S*)alpha_, *dx = (S*)dx_, *co = (S*)co_;
+#pragma omp parallel for num_threads(threads) schedule(dynamic) if (threads > 1)
+  for (int b = 0; b < d->batch; b++) {
+    LQInputs<S> in;
+    UnpackLQ(p, T, A + size_t(b) * T * n * n, B + size_t(b) * T * n * m, Q + size_t(b) * T * N * n * n,
+             l + size_t(b) * T * N * n, R + size_t(b) * T * p.Rsz, r + size_t(b) * T * p.rsz, &in);
+    Vec<S> x0v(n, S(0));
+    if (x0) x0v.assign(x0 + size_t(b) * n, x0 + size_t(b + 1) * n);
+    Strategies<S> st;
+    std::vector<Vec<S>> dxs;
+    std::vector<std::vector<Vec<S>>> cos;
+    if (open_loop)
+      SolveLQOpenLoop(p, in, x0v, &st, dx ? &dxs : nullptr, co ? &cos : nullptr);
+    else
+      SolveLQFeedback(p, in, x0v, d->adaptive_regularization != 0, &st, dx || co ? &dxs : nullptr,
+                      co ? &cos : nullptr);
+    PackStrategies(p, st, P + size_t(b) * T * m * n, alpha + size_t(b) * T * m);
+    if (dx)
+      for (int k = 0; k < T; k++) std::memcpy(dx + (size_t(b) * T + k) * n, dxs[k].data(), sizeof(S) * n);
+    if (co)
+      for (int k = 0; k < T; k++)
+        for (int i = 0; i < N; i++)
+          std::memcpy(co + ((size_t(b) * T + k) * N + i) * n, cos[k][i].data(), sizeof(S) * n);
+  }
+  return ILQG_OK;
+}
+
+struct OracleProblem {
+  std::vector<ilqg_cost_term> terms;
+  std::vector<int32_t> poly_off;
+  std::vector<float> poly_pts;
+  ilqg_problem_desc desc;
+  std::unique_ptr<Problem<float>> pf;
+  std::unique_ptr<Problem<double>> pd;
+};
+template <class S>
+const Problem<S>& Get(const OracleProblem* op);
+template <>
+const Problem<float>& Get<float>(const OracleProblem* op) { return *op->pf; }
+template <>
+const Problem<double>& Get<double>(const OracleProblem* op) { return *op->pd; }
+
+template <class S>
+ALState<S> MakeAL(const Problem<S>& p, const void* lambdas, const void* mu, int b) {
+  ALState<S> al(p.num_constraints, p.T, p.dt);
+  if (lambdas && p.num_constraints)
+    al.lambdas.assign((const S*)lambdas + size_t(b) * p.num_constraints * p.T,
+                      (const S*)lambdas + size_t(b + 1) * p.num_constraints * p.T);
+  if (mu) al.mu = ((const S*)mu)[b];
+  return al;
+}
+
+template <class S>
+void RolloutBatch(const OracleProblem* op, int batch, const void* x0, const void* xs_ref, const void* us_ref,
+                  const void* P, const void* alpha, const void* alpha_scale, void* xs, void* us) {
+  const Problem<S>& p = Get<S>(op);
+  const int T = p.T, n = p.n, m = p.m;
+  for (int b = 0; b < batch; b++) {
+    Trajectory<S> last, cur;
+    Strategies<S> st;
+    UnpackTraj(p, T, (const S*)xs_ref + size_t(b) * T * n, (const S*)us_ref + size_t(b) * T * m, &last);
+    UnpackStrategies(p, T, (const S*)P + size_t(b) * T * m * n, (const S*)alpha + size_t(b) * T * m, &st);
+    if (alpha_scale)
+      for (auto& a : st.alpha)
+        for (auto& v : a) v *= ((const S*)alpha_scale)[b];
+    Vec<S> x0v((const S*)x0 + size_t(b) * n, (const S*)x0 + size_t(b + 1) * n);
+    Rollout(p, x0v, last, st, &cur);
+    PackTraj(p, cur, (S*)xs + size_t(b) * T * n, (S*)us + size_t(b) * T * m);
+  }
+}
+
+template <class S>
+void LinearizeBatch(const OracleProblem* op, int batch, const void* xs, const void* us, void* A, void* Bm) {
+  const Problem<S>& p = Get<S>(op);
+  const int T = p.T, n = p.n, m = p.m;
+  for (int b = 0; b < batch; b++) {
+    Trajectory<S> tr;
+    UnpackTraj(p, T, (const S*)xs + size_t(b) * T * n, (const S*)us + size_t(b) * T * m, &tr);
+    LQInputs<S> lq;
+    ComputeLinearization(p, tr, &lq);
+    for (int k = 0; k < T; k++) {
+      std::memcpy((S*)A + (size_t(b) * T + k) * n * n, lq.A[k].d.data(), sizeof(S) * n * n);
+      std::memcpy((S*)Bm + (size_t(b) * T + k) * n * m, lq.B[k].d.data(), sizeof(S) * n * m);
+    }
+  }
+}
+
+template <class S>
+void QuadraticizeBatch(const OracleProblem* op, int batch, const void* xs, const void* us, const void* lambdas,
+                       const void* mu, const int32_t* t_extreme, void* Q, void* l, void* R, void* r) {
+  const Problem<S>& p = Get<S>(op);
+  const int T = p.T, n = p.n, m = p.m, N = p.N;
+  for (int b = 0; b < batch; b++) {
+    Trajectory<S> tr;
+    UnpackTraj(p, T, (const S*)xs + size_t(b) * T * n, (const S*)us + size_t(b) * T * m, &tr);
+    std::vector<int> te(N, 0);
+    if (t_extreme)
+      for (int i = 0; i < N; i++) te[i] = t_extreme[size_t(b) * N + i];
+    ALState<S> al = MakeAL(p, lambdas, mu, b);
+    LQInputs<S> lq;
+    ComputeQuadraticization(p, tr, te, &al, &lq);
+    PackQuad(p, lq, (S*)Q + size_t(b) * T * N * n * n, (S*)l + size_t(b) * T * N * n,
+             (S*)R + size_t(b) * T * p.Rsz, (S*)r + size_t(b) * T * p.rsz);
+  }
+}
+
+template <class S>
+void TotalCostsBatch(const OracleProblem* op, int batch, const void* xs, const void* us, void* costs,
+                     int32_t* t_extreme) {
+  const Problem<S>& p = Get<S>(op);
+  const int T = p.T, n = p.n, m = p.m, N = p.N;
+  for (int b = 0; b < batch; b++) {
+    Trajectory<S> tr;
+    UnpackTraj(p, T, (const S*)xs + size_t(b) * T * n, (const S*)us + size_t(b) * T * m, &tr);
+    std::vector<int> te(N, 0);
+    if (t_extreme)
+      for (int i = 0; i < N; i++) te[i] = t_extreme[size_t(b) * N + i];
+    Vec<S> c;
+    TotalCosts(p, tr, &c, &te);
+    std::memcpy((S*)costs + size_t(b) * N, c.data(), sizeof(S) * N);
+    if (t_extreme)
+      for (int i = 0; i < N; i++) t_extreme[size_t(b) * N + i] = te[i];
+  }
+}
+
+template <class S>
+void SolveBatch(const OracleProblem* op, int batch, const void* x0, void* xs, void* us, void* P, void* alpha,
+                void* costs, int32_t* iters, int32_t* status, int32_t* converged, int fixed_iters, void* rawP,
+                void* rawAlpha, void* merit_log, int merit_log_len, int threads) {
+  const Problem<S>& p = Get<S>(op);
+  const int T = p.T, n = p.n, m = p.m, N = p.N;
+#pragma omp parallel for num_threads(threads) schedule(dynamic) if (threads > 1)
+  for (int b = 0; b < batch; b++) {
+    Trajectory<S> tr;
+    Strategies<S> st, raw;
+    UnpackTraj(p, T, (S*)xs + size_t(b) * T * n, (S*)us + size_t(b) * T * m, &tr);
+    UnpackStrategies(p, T, (S*)P + size_t(b) * T * m * n, (S*)alpha + size_t(b) * T * m, &st);
+    Vec<S> x0v((const S*)x0 + size_t(b) * n, (const S*)x0 + size_t(b + 1) * n);
+    ILQState<S> state;
+    ALState<S> al(p.num_constraints, T, p.dt);
+    std::vector<IterLog<S>> log;
+    Vec<S> fc;
+    int it = 0, conv = 0;
+    const bool ok = SolveILQ(p, x0v, &tr, &st, &state, &al, fixed_iters, &log, &fc, &it, &conv, &raw);
+    PackTraj(p, tr, (S*)xs + size_t(b) * T * n, (S*)us + size_t(b) * T * m);
+    PackStrategies(p, st, (S*)P + size_t(b) * T * m * n, (S*)alpha + size_t(b) * T * m);
+    if (rawP && !raw.P.empty())
+      PackStrategies(p, raw, (S*)rawP + size_t(b) * T * m * n, (S*)rawAlpha + size_t(b) * T * m);
+    std::memcpy((S*)costs + size_t(b) * N, fc.data(), sizeof(S) * N);
+    iters[b] = it;
+    status[b] = ok ? 1 : 0;
+    converged[b] = conv;
+    if (merit_log) {
+      // per iteration: merit, expected_decrease, step, backtracks
+      S* ml = (S*)merit_log + size_t(b) * merit_log_len * 4;
+      for (int q = 0; q < merit_log_len * 4; q++) ml[q] = std::numeric_limits<S>::quiet_NaN();
+      for (size_t q = 0; q < log.size() && (int)q < merit_log_len; q++) {
+        ml[4 * q + 0] = log[q].merit;
+        ml[4 * q + 1] = log[q].expected_decrease;
+        ml[4 * q + 2] = log[q].step;
+        ml[4 * q + 3] = S(log[q].backtracks);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int oracle_lq_feedback(const ilqg_dims* d, const void* A, const void* Bm, const void* Q, const void* l,
+                       const void* R, const void* r, const ilqg_pair* pairs, int npairs, const void* x0, void* P,
+                       void* alpha, void* dx, void* costates, int threads) {
+  if (d->dtype == ILQG_F32)
+    return LQBatch<float>(d, A, Bm, Q, l, R, r, pairs, npairs, x0, P, alpha, dx, costates, 0, threads);
+  return LQBatch<double>(d, A, Bm, Q, l, R, r, pairs, npairs, x0, P, alpha, dx, costates, 0, threads);
+}
+
+int oracle_lq_openloop(const ilqg_dims* d, const void* A, const void* Bm, const void* Q, const void* l,
+                       const void* R, const void* r, const ilqg_pair* pairs, int npairs, const void* x0, void* P,
+                       void* alpha, void* dx, void* costates, int threads) {
+  if (d->dtype == ILQG_F32)
+    return LQBatch<float>(d, A, Bm, Q, l, R, r, pairs, npairs, x0, P, alpha, dx, costates, 1, threads);
+  return LQBatch<double>(d, A, Bm, Q, l, R, r, pairs, npairs, x0, P, alpha, dx, costates, 1, threads);
+}
+
+void* oracle_problem_create(const ilqg_problem_desc* desc) {
+  auto* op = new OracleProblem;
+  op->terms.assign(desc->terms, desc->terms + desc->num_terms);
+  op->poly_off.assign(desc->polyline_offsets, desc->polyline_offsets + desc->num_polylines + 1);
+  const int npts = desc->num_polylines ? desc->polyline_offsets[desc->num_polylines] : 0;
+  op->poly_pts.assign(desc->polyline_points, desc->polyline_points + 2 * npts);
+  op->desc = *desc;
+  op->desc.terms = op->terms.data();
+  op->desc.polyline_offsets = op->poly_off.data();
+  op->desc.polyline_points = op->poly_pts.data();
+  op->pf.reset(new Problem<float>(op->desc));
+  op->pd.reset(new Problem<double>(op->desc));
+  return op;
+}
+void oracle_problem_destroy(void* h) { delete (OracleProblem*)h; }
+
+int oracle_problem_pairs(void* h, ilqg_pair* pairs, int* npairs) {
+  const auto* op = (OracleProblem*)h;
+  *npairs = (int)op->pd->pairs.size();
+  for (int q = 0; q < *npairs; q++) pairs[q] = op->pd->pairs[q];
+  return 0;
+}
+int oracle_problem_num_constraints(void* h) { return ((OracleProblem*)h)->pd->num_constraints; }
+
+#define DISPATCH(dtype, fn, ...)        \
+  do {                                  \
+    if ((dtype) == ILQG_F32)            \
+      fn<float>(__VA_ARGS__);           \
+    else                                \
+      fn<double>(__VA_ARGS__);          \
+  } while (0)
+
+void oracle_rollout(void* h, int dtype, int batch, const void* x0, const void* xs_ref, const void* us_ref,
+                    const void* P, const void* alpha, const void* alpha_scale, void* xs, void* us) {
+  DISPATCH(dtype, RolloutBatch, (OracleProblem*)h, batch, x0, xs_ref, us_ref, P, alpha, alpha_scale, xs, us);
+}
+void oracle_linearize(void* h, int dtype, int batch, const void* xs, const void* us, void* A, void* Bm) {
+  DISPATCH(dtype, LinearizeBatch, (OracleProblem*)h, batch, xs, us, A, Bm);
+}
+void oracle_quadraticize(void* h, int dtype, int batch, const void* xs, const void* us, const void* lambdas,
+                         const void* mu, const int32_t* t_extreme, void* Q, void* l, void* R, void* r) {
+  DISPATCH(dtype, QuadraticizeBatch, (OracleProblem*)h, batch, xs, us, lambdas, mu, t_extreme, Q, l, R, r);
+}
+void oracle_total_costs(void* h, int dtype, int batch, const void* xs, const void* us, void* costs,
+                        int32_t* t_extreme) {
+  DISPATCH(dtype, TotalCostsBatch, (OracleProblem*)h, batch, xs, us, costs, t_extreme);
+}
+void oracle_ilq_solve(void* h, int dtype, int batch, const void* x0, void* xs, void* us, void* P, void* alpha,
+                      void* costs, int32_t* iters, int32_t* status, int32_t* converged, int fixed_iters,
+                      void* rawP, void* rawAlpha, void* merit_log, int merit_log_len, int threads) {
+  DISPATCH(dtype, SolveBatch, (OracleProblem*)h, batch, x0, xs, us, P, alpha, costs, iters, status, converged,
+           fixed_iters, rawP, rawAlpha, merit_log, merit_log_len, threads);
+}
+
+// xdot = f(x, u) and one Integrate step (double I/O regardless of dtype, for the
+// finite-difference tests that restate test/test_linearization.cpp).
+void oracle_dynamics(void* h, int dtype, const double* x, const double* u, double* xdot, double* xnext, int euler) {
+  const auto* op = (OracleProblem*)h;
+  if (dtype == ILQG_F32) {
+    const auto& p = *op->pf;
+    Vec<float> xv(x, x + p.n), uv(u, u + p.m);
+    const Vec<float> f = Evaluate(p, xv, uv);
+    const Vec<float> nx = Integrate(p, 0.0, p.dt, xv, uv, euler != 0);
+    for (int i = 0; i < p.n; i++) { xdot[i] = f[i]; xnext[i] = nx[i]; }
+  } else {
+    const auto& p = *op->pd;
+    Vec<double> xv(x, x + p.n), uv(u, u + p.m);
+    const Vec<double> f = Evaluate(p, xv, uv);
+    const Vec<double> nx = Integrate(p, 0.0, p.dt, xv, uv, euler != 0);
+    for (int i = 0; i < p.n; i++) { xdot[i] = f[i]; xnext[i] = nx[i]; }
+  }
+}
+
+// PlayerCost::Evaluate at one (x, u) in double (restating test_quadraticization.cpp's
+// numerical-derivative checks needs cost values).  If include_constraints, adds the
+// augmented-Lagrangian value of every constraint of the player
+// (Constraint::EvaluateAugmentedLagrangian, constraint.h:83-87) with lambda/mu given.
+double oracle_player_value(void* h, int player, const double* x, const double* u, int include_constraints,
+                           double lambda, double mu) {
+  const auto& p = *((OracleProblem*)h)->pd;
+  Vec<double> xv(x, x + p.n), uv(u, u + p.m);
+  double v = EvaluatePlayer(p, player, xv, uv);
+  if (include_constraints)
+    for (size_t ti = 0; ti < p.terms.size(); ti++) {
+      const auto& t = p.terms[ti];
+      if (t.player != player) continue;
+      double g;
+      if (t.role == ILQG_ROLE_STATE_CONSTRAINT)
+        g = EvaluateTerm(p, (int)ti, xv.data(), p.n);
+      else if (t.role == ILQG_ROLE_CONTROL_CONSTRAINT)
+        g = EvaluateTerm(p, (int)ti, &uv[p.uoff[t.arg]], p.udim(t.arg));
+      else
+        continue;
+      v += lambda * g + 0.5 * ConstraintMu(lambda, g, mu) * g * g;
+    }
+  return v;
+}
+
+// Known-answer access to the geometry (test/test_line_segment2.cpp, test_polyline2.cpp).
+// out = {closest.x, closest.y, signed_squared_distance, is_vertex, is_endpoint, seg.p1x, seg.p1y, seg.p2x, seg.p2y}
+void oracle_polyline_closest_point(int dtype, const float* pts, int npts, double qx, double qy, double* out) {
+  if (dtype == ILQG_F32) {
+    Polyline2<float> pl(pts, npts);
+    float cx, cy, ssd;
+    bool v, e;
+    Segment2<float> s;
+    pl.ClosestPoint((float)qx, (float)qy, &cx, &cy, &v, &s, &ssd, &e);
+    const double o[9] = {cx, cy, ssd, double(v), double(e), s.p1x, s.p1y, s.p2x, s.p2y};
+    std::memcpy(out, o, sizeof(o));
+  } else {
+    Polyline2<double> pl(pts, npts);
+    double cx, cy, ssd;
+    bool v, e;
+    Segment2<double> s;
+    pl.ClosestPoint(qx, qy, &cx, &cy, &v, &s, &ssd, &e);
+    const double o[9] = {cx, cy, ssd, double(v), double(e), s.p1x, s.p1y, s.p2x, s.p2y};
+    std::memcpy(out, o, sizeof(o));
+  }
+}
+// out = {closest.x, closest.y, signed_squared_distance, is_endpoint, side}
+void oracle_segment_closest_point(const float* p1p2, double qx, double qy, double* out) {
+  Segment2<float> s(p1p2[0], p1p2[1], p1p2[2], p1p2[3]);
+  float cx, cy, ssd;
+  bool e;
+  s.ClosestPoint((float)qx, (float)qy, &cx, &cy, &e, &ssd);
+  out[0] = cx;
+  out[1] = cy;
+  out[2] = ssd;
+  out[3] = e;
+  out[4] = s.Side((float)qx, (float)qy);
+}
+
+}  // extern "C"

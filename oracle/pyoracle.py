@@ -1,0 +1,174 @@
+"""ctypes access to oracle/liboracle.so — the CPU restatement of the reference hot path.
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+`cpu_baseline` leg of bench.py, never by the product path (ilqgames_amd/).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from ilqgames_amd import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("oracle_capi.cpp", "ilqg_oracle.hpp")] + [
+        os.path.join(_HERE, "..", "include", "ilqg.h")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-B", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.oracle_problem_create.restype = C.c_void_p
+        _LIB.oracle_player_value.restype = C.c_double
+    return _LIB
+
+
+def _np(dtype):
+    return np.float32 if dtype == abi.F32 else np.float64
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def lq_solve(dims, A, Bm, Q, l, R, r, pairs, x0=None, open_loop=False, want_dx=True, want_costates=False,
+             threads=1):
+    """LQFeedbackSolver::Solve / LQOpenLoopSolver::Solve on host arrays (layouts of include/ilqg.h)."""
+    dt = _np(dims.dtype)
+    B, T, n, N = dims.batch, dims.T, dims.n, dims.num_players
+    m = sum(dims.udim[i] for i in range(N))
+    arrs = [np.ascontiguousarray(a, dtype=dt) for a in (A, Bm, Q, l, R, r)]
+    P = np.zeros((B, T, m * n), dt)
+    alpha = np.zeros((B, T, m), dt)
+    dx = np.zeros((B, T, n), dt) if want_dx else None
+    co = np.zeros((B, T, N, n), dt) if want_costates else None
+    x0a = None if x0 is None else np.ascontiguousarray(x0, dtype=dt)
+    fn = lib().oracle_lq_openloop if open_loop else lib().oracle_lq_feedback
+    rc = fn(C.byref(dims), *[_p(a) for a in arrs], abi.make_pairs(pairs), len(pairs), _p(x0a), _p(P), _p(alpha),
+            _p(dx), _p(co), int(threads))
+    if rc != 0:
+        raise ValueError("oracle LQ solve: status %d" % rc)
+    return P, alpha, dx, co
+
+
+class OracleProblem:
+    def __init__(self, spec):
+        self.spec = spec
+        self.desc, self._keep = spec.build(abi.F64)
+        self.h = C.c_void_p(lib().oracle_problem_create(C.byref(self.desc)))
+        self.n, self.m, self.N, self.T = spec.n, spec.m, len(spec.subsystems), spec.T
+        self.pairs = spec.pairs()
+        self.Rsz = sum(spec.udims[j] ** 2 for _, j in self.pairs)
+        self.rsz = sum(spec.udims[j] for _, j in self.pairs)
+        self.nc = spec.num_constraints
+
+    def __del__(self):
+        try:
+            lib().oracle_problem_destroy(self.h)
+        except Exception:
+            pass
+
+    def rollout(self, dtype, x0, xs_ref, us_ref, P, alpha, alpha_scale=None):
+        dt = _np(dtype)
+        B = x0.shape[0]
+        xs = np.zeros((B, self.T, self.n), dt)
+        us = np.zeros((B, self.T, self.m), dt)
+        a = [np.ascontiguousarray(v, dtype=dt) for v in (x0, xs_ref, us_ref, P, alpha)]
+        sc = None if alpha_scale is None else np.ascontiguousarray(alpha_scale, dtype=dt)
+        lib().oracle_rollout(self.h, dtype, B, *[_p(v) for v in a], _p(sc), _p(xs), _p(us))
+        return xs, us
+
+    def linearize(self, dtype, xs, us):
+        dt = _np(dtype)
+        B = xs.shape[0]
+        A = np.zeros((B, self.T, self.n * self.n), dt)
+        Bm = np.zeros((B, self.T, self.n * self.m), dt)
+        xs, us = np.ascontiguousarray(xs, dtype=dt), np.ascontiguousarray(us, dtype=dt)
+        lib().oracle_linearize(self.h, dtype, B, _p(xs), _p(us), _p(A), _p(Bm))
+        return A, Bm
+
+    def quadraticize(self, dtype, xs, us, lambdas=None, mu=None, t_extreme=None):
+        dt = _np(dtype)
+        B = xs.shape[0]
+        Q = np.zeros((B, self.T, self.N, self.n * self.n), dt)
+        l = np.zeros((B, self.T, self.N, self.n), dt)
+        R = np.zeros((B, self.T, self.Rsz), dt)
+        r = np.zeros((B, self.T, self.rsz), dt)
+        xs, us = np.ascontiguousarray(xs, dtype=dt), np.ascontiguousarray(us, dtype=dt)
+        lam = None if lambdas is None else np.ascontiguousarray(lambdas, dtype=dt)
+        mua = None if mu is None else np.ascontiguousarray(mu, dtype=dt)
+        te = None if t_extreme is None else np.ascontiguousarray(t_extreme, dtype=np.int32)
+        lib().oracle_quadraticize(self.h, dtype, B, _p(xs), _p(us), _p(lam), _p(mua), _p(te), _p(Q), _p(l), _p(R),
+                                  _p(r))
+        return Q, l, R, r
+
+    def total_costs(self, dtype, xs, us, t_extreme=None):
+        dt = _np(dtype)
+        B = xs.shape[0]
+        costs = np.zeros((B, self.N), dt)
+        te = np.zeros((B, self.N), np.int32) if t_extreme is None else np.ascontiguousarray(t_extreme, np.int32).copy()
+        xs, us = np.ascontiguousarray(xs, dtype=dt), np.ascontiguousarray(us, dtype=dt)
+        lib().oracle_total_costs(self.h, dtype, B, _p(xs), _p(us), _p(costs), _p(te))
+        return costs, te
+
+    def solve(self, dtype, x0, xs=None, us=None, P=None, alpha=None, fixed_iters=0, merit_log_len=0, threads=1):
+        """ILQSolver::Solve per instance. Returns dict with final op/strategies/costs/iters/status."""
+        dt = _np(dtype)
+        B = x0.shape[0]
+        x0 = np.ascontiguousarray(x0, dtype=dt)
+        xs = np.zeros((B, self.T, self.n), dt) if xs is None else np.ascontiguousarray(xs, dtype=dt).copy()
+        us = np.zeros((B, self.T, self.m), dt) if us is None else np.ascontiguousarray(us, dtype=dt).copy()
+        P = np.zeros((B, self.T, self.m * self.n), dt) if P is None else np.ascontiguousarray(P, dtype=dt).copy()
+        alpha = np.zeros((B, self.T, self.m), dt) if alpha is None else np.ascontiguousarray(alpha, dtype=dt).copy()
+        costs = np.zeros((B, self.N), dt)
+        iters = np.zeros(B, np.int32)
+        status = np.zeros(B, np.int32)
+        conv = np.zeros(B, np.int32)
+        rawP = np.zeros_like(P)
+        rawA = np.zeros_like(alpha)
+        ml = np.zeros((B, merit_log_len, 4), dt) if merit_log_len else None
+        lib().oracle_ilq_solve(self.h, dtype, B, _p(x0), _p(xs), _p(us), _p(P), _p(alpha), _p(costs), _p(iters),
+                               _p(status), _p(conv), int(fixed_iters), _p(rawP), _p(rawA), _p(ml),
+                               int(merit_log_len), int(threads))
+        return dict(xs=xs, us=us, P=P, alpha=alpha, costs=costs, iters=iters, status=status, converged=conv,
+                    rawP=rawP, rawAlpha=rawA, log=ml)
+
+    def dynamics(self, dtype, x, u, euler=False):
+        x = np.ascontiguousarray(x, np.float64)
+        u = np.ascontiguousarray(u, np.float64)
+        xdot = np.zeros(self.n)
+        xn = np.zeros(self.n)
+        lib().oracle_dynamics(self.h, dtype, _p(x), _p(u), _p(xdot), _p(xn), int(euler))
+        return xdot, xn
+
+    def player_value(self, player, x, u, include_constraints=False, lam=0.0, mu=10.0):
+        x = np.ascontiguousarray(x, np.float64)
+        u = np.ascontiguousarray(u, np.float64)
+        return lib().oracle_player_value(self.h, int(player), _p(x), _p(u), int(include_constraints),
+                                         C.c_double(lam), C.c_double(mu))
+
+
+def polyline_closest_point(pts, q, dtype=abi.F32):
+    pts = np.ascontiguousarray(np.asarray(pts, np.float32).reshape(-1))
+    out = np.zeros(9)
+    lib().oracle_polyline_closest_point(dtype, pts.ctypes.data_as(C.POINTER(C.c_float)), len(pts) // 2,
+                                        C.c_double(q[0]), C.c_double(q[1]), _p(out))
+    return dict(point=out[0:2], ssd=out[2], is_vertex=bool(out[3]), is_endpoint=bool(out[4]), segment=out[5:9])
+
+
+def segment_closest_point(p1, p2, q):
+    a = np.ascontiguousarray(np.array([p1[0], p1[1], p2[0], p2[1]], np.float32))
+    out = np.zeros(5)
+    lib().oracle_segment_closest_point(a.ctypes.data_as(C.POINTER(C.c_float)), C.c_double(q[0]), C.c_double(q[1]),
+                                       _p(out))
+    return dict(point=out[0:2], ssd=out[2], is_endpoint=bool(out[3]), side=bool(out[4]))
