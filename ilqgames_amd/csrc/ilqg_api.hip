@@ -1,0 +1,569 @@
+// ilqg_api.hip — kernels and the C ABI of libilqg_hip.so (gfx950 only).
+// Entry points and the reference methods they replace: include/ilqg.h.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "ilqg_common.hpp"
+#include "ilqg_lq.hpp"
+#include "ilqg_models.hpp"
+#include "ilqg_solve.hpp"
+#include "ilqg_stages.hpp"
+
+using namespace ilqg;
+
+namespace {
+
+thread_local std::string g_err;
+
+ilqg_status fail(ilqg_status s, const std::string& msg) {
+  g_err = msg;
+  return s;
+}
+#define HIP_TRY(expr)                                                                   \
+  do {                                                                                  \
+    hipError_t e_ = (expr);                                                             \
+    if (e_ != hipSuccess)                                                               \
+      return fail(ILQG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));     \
+  } while (0)
+
+// ------------------------------------------------------------------------------------
+// Kernels — one workgroup per game instance
+// ------------------------------------------------------------------------------------
+template <typename T>
+struct LQBatchArgs {
+  const T *A, *Bm, *Q, *l, *R, *r, *x0;
+  T *P, *alpha, *dx, *scratch;
+  int T_steps, adaptive, batch;
+};
+
+template <typename T, int NX, int NP, int MU>
+__global__ void __launch_bounds__((LQCfg<T, NX, NP, MU>::NT))
+lq_feedback_kernel(LQBatchArgs<T> g, PairTable pt) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  T* sm = reinterpret_cast<T*>(smem_raw);
+  const int b = blockIdx.x;
+  constexpr int M = NP * MU;
+  const size_t Tn = g.T_steps;
+  LQArgs<T> a;
+  a.A = g.A + b * Tn * NX * NX;
+  a.Bm = g.Bm + b * Tn * NX * M;
+  a.Q = g.Q + b * Tn * NP * NX * NX;
+  a.l = g.l + b * Tn * NP * NX;
+  a.R = g.R + b * Tn * pt.Rsz;
+  a.r = g.r + b * Tn * pt.rsz;
+  a.x0 = g.x0 ? g.x0 + size_t(b) * NX : nullptr;
+  a.P = g.P + b * Tn * M * NX;
+  a.alpha = g.alpha + b * Tn * M;
+  a.dx = g.dx ? g.dx + b * Tn * NX : nullptr;
+  a.scratch = g.scratch ? g.scratch + b * Tn * (NP * (NX + 1) + NX) : nullptr;
+  a.ed_out = nullptr;
+  a.T_steps = g.T_steps;
+  a.adaptive = g.adaptive;
+  lq_feedback_instance<T, NX, NP, MU>(a, pt, sm);
+}
+
+template <typename T>
+struct RolloutBatchArgs {
+  const T *x0, *xs_ref, *us_ref, *P, *alpha, *alpha_scale;
+  T *xs, *us;
+  const int* active;
+};
+
+template <typename T>
+__global__ void rollout_kernel(DevProblem p, RolloutBatchArgs<T> g) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  T* sm = reinterpret_cast<T*>(smem_raw);
+  const size_t b = blockIdx.x;
+  if (g.active && !g.active[b]) return;
+  const size_t Tn = p.T, n = p.n, m = p.m;
+  RolloutArgs<T> a{g.x0 + b * n,          g.xs_ref + b * Tn * n, g.us_ref + b * Tn * m, g.P + b * Tn * m * n,
+                   g.alpha + b * Tn * m,  g.alpha_scale ? g.alpha_scale[b] : T(1),
+                   g.xs + b * Tn * n,     g.us + b * Tn * m};
+  rollout_instance<T>(p, a, sm);
+}
+
+template <typename T>
+struct QuadBatchArgs {
+  const T *xs, *us, *lambdas, *mu;
+  const int* t_extreme;
+  T *A, *Bm, *Q, *l, *R, *r, *merit_part, *cost_part;
+  const int* active;
+};
+
+// grid = (T, B): every (instance, time step) is independent here
+template <typename T>
+__global__ void linquad_kernel(DevProblem p, QuadBatchArgs<T> g) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  T* sm = reinterpret_cast<T*>(smem_raw);
+  const size_t b = blockIdx.y;
+  const int k = blockIdx.x;
+  if (g.active && !g.active[b]) return;
+  const size_t Tn = p.T, n = p.n, m = p.m, N = p.N;
+  QuadArgs<T> a;
+  a.xs = g.xs + b * Tn * n;
+  a.us = g.us + b * Tn * m;
+  a.lambdas = g.lambdas ? g.lambdas + b * p.num_constraints * Tn : nullptr;
+  a.mu = g.mu ? g.mu[b] : T(10);
+  a.t_extreme = g.t_extreme ? g.t_extreme + b * N : nullptr;
+  a.t_init = 0.0;
+  a.A = g.A ? g.A + b * Tn * n * n : nullptr;
+  a.Bm = g.Bm ? g.Bm + b * Tn * n * m : nullptr;
+  a.Q = g.Q ? g.Q + b * Tn * N * n * n : nullptr;
+  a.l = g.l ? g.l + b * Tn * N * n : nullptr;
+  a.R = g.R ? g.R + b * Tn * p.pairs.Rsz : nullptr;
+  a.r = g.r ? g.r + b * Tn * p.pairs.rsz : nullptr;
+  a.merit_part = g.merit_part ? g.merit_part + b * Tn * N * 2 : nullptr;
+  a.cost_part = g.cost_part ? g.cost_part + b * Tn * N : nullptr;
+  linquad_step<T>(p, a, k, sm);
+}
+
+template <typename T>
+__global__ void costs_reduce_kernel(DevProblem p, const T* cost_part, T* costs, int* t_extreme, const int* active) {
+  const size_t b = blockIdx.x;
+  if (active && !active[b]) return;
+  costs_reduce<T>(p, cost_part + b * p.T * p.N, costs + b * p.N, t_extreme ? t_extreme + b * p.N : nullptr);
+}
+
+template <typename T, int NX, int NP, int MU>
+__global__ void __launch_bounds__((LQCfg<T, NX, NP, MU>::NT))
+ilq_solve_kernel(DevProblem p, SolveArgs<T> sa) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  T* sm = reinterpret_cast<T*>(smem_raw);
+  const int b = blockIdx.x;
+  const int n = NX;
+  T* xs0 = sa.xs + size_t(b) * p.T * n;
+  if (threadIdx.x < n) xs0[threadIdx.x] = sa.x0[size_t(b) * n + threadIdx.x];  // xs[0] = x0 (:89-90)
+  __syncthreads();
+  ilq_solve_instance<T, NX, NP, MU>(p, sa, b, sm);
+}
+
+// ------------------------------------------------------------------------------------
+// Host side
+// ------------------------------------------------------------------------------------
+struct Scratch {  // grow-only device scratch for entry points without a workspace argument
+  void* ptr = nullptr;
+  size_t bytes = 0;
+  ilqg_status reserve(size_t need) {
+    if (need <= bytes) return ILQG_OK;
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    bytes = 0;
+    HIP_TRY(hipMalloc(&ptr, need));
+    bytes = need;
+    return ILQG_OK;
+  }
+};
+thread_local Scratch g_scratch;
+
+bool build_pairs(const ilqg_pair* pairs, int npairs, const int* udim, int N, PairTable* pt, std::string* err) {
+  if (npairs > kMaxPairs) {
+    *err = "too many control blocks";
+    return false;
+  }
+  std::memset(pt, 0, sizeof(*pt));
+  pt->npairs = npairs;
+  for (int i = 0; i < kMaxPlayers; i++) pt->pii[i] = -1;
+  int Rsz = 0, rsz = 0;
+  for (int q = 0; q < npairs; q++) {
+    const int i = pairs[q].i, j = pairs[q].j;
+    if (i < 0 || i >= N || j < 0 || j >= N) {
+      *err = "control block index out of range";
+      return false;
+    }
+    pt->pi[q] = i;
+    pt->pj[q] = j;
+    pt->roff[q] = Rsz;
+    pt->rgoff[q] = rsz;
+    pt->from_cost[q] = 1;
+    Rsz += udim[j] * udim[j];
+    rsz += udim[j];
+    if (i == j) pt->pii[i] = q;
+  }
+  pt->Rsz = Rsz;
+  pt->rsz = rsz;
+  for (int i = 0; i < N; i++)
+    if (pt->pii[i] < 0) {
+      *err = "player " + std::to_string(i) + " is missing a control Hessian";  // lq_feedback_solver.cpp:139-140
+      return false;
+    }
+  return true;
+}
+
+// Supported (n, N, m_i) instantiations.  n=14/16/15/24: BASELINE configs 2-5;
+// (4,2,2): config 1 (TwoPlayerUnicycle4D); (2,2,1): test_lq_solver's point mass;
+// (6,3,2): synthetic parity cases.
+#define ILQG_FOR_DIMS(X) X(14, 3, 2) X(16, 3, 2) X(15, 3, 2) X(24, 4, 2) X(4, 2, 2) X(2, 2, 1) X(6, 3, 2) X(2, 1, 2)
+
+template <typename T, int NX, int NP, int MU>
+ilqg_status launch_lq(const ilqg_dims* d, const PairTable& pt, const void* A, const void* Bm, const void* Q,
+                      const void* l, const void* R, const void* r, const void* x0, void* P, void* alpha, void* dx,
+                      hipStream_t stream) {
+  using C = LQCfg<T, NX, NP, MU>;
+  LQBatchArgs<T> g;
+  g.A = (const T*)A; g.Bm = (const T*)Bm; g.Q = (const T*)Q; g.l = (const T*)l;
+  g.R = (const T*)R; g.r = (const T*)r; g.x0 = (const T*)x0;
+  g.P = (T*)P; g.alpha = (T*)alpha; g.dx = (T*)dx;
+  g.scratch = nullptr;
+  if (dx) {
+    const size_t need = size_t(d->batch) * d->T * (NP * (NX + 1) + NX) * sizeof(T);
+    ilqg_status s = g_scratch.reserve(need);
+    if (s != ILQG_OK) return s;
+    g.scratch = (T*)g_scratch.ptr;
+  }
+  g.T_steps = d->T;
+  g.adaptive = d->adaptive_regularization;
+  g.batch = d->batch;
+  const size_t lds = size_t(C::LDS_ELEMS) * sizeof(T);
+  auto kern = lq_feedback_kernel<T, NX, NP, MU>;
+  if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3(d->batch), dim3(C::NT), lds, stream, g, pt);
+  HIP_TRY(hipGetLastError());
+  return ILQG_OK;
+}
+
+bool uniform_udim(const int32_t* udim, int N, int* mu) {
+  for (int i = 1; i < N; i++)
+    if (udim[i] != udim[0]) return false;
+  *mu = udim[0];
+  return true;
+}
+
+ilqg_status check_device() {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
+    return fail(ILQG_ERR_NO_DEVICE, "no HIP device visible: libilqg_hip.so has no CPU fallback");
+  return ILQG_OK;
+}
+
+}  // namespace
+
+struct ilqg_problem {
+  DevProblem dev;
+  ilqg_problem_desc desc;
+  std::vector<ilqg_cost_term> terms_host;
+  DevTerm* d_terms = nullptr;
+  int* d_poly_off = nullptr;
+  float* d_poly_pts = nullptr;
+  int mu_uniform = 0;
+};
+
+#define DT_DISPATCH(p, CALL) ((p)->desc.dtype == ILQG_F32 ? CALL(float) : CALL(double))
+
+static ilqg_status launch_linquad(const ilqg_problem* p, int32_t batch, const void* xs, const void* us,
+                                  const void* lambdas, const void* mu, const int32_t* t_extreme, void* A, void* Bm,
+                                  void* Q, void* l, void* R, void* r, void* merit_part, void* cost_part,
+                                  const int32_t* active, void* stream) {
+  const DevProblem& d = p->dev;
+#define CALL(TY_)                                                                                                 \
+  [&]() -> ilqg_status {                                                                                        \
+    QuadBatchArgs<TY_> g{(const TY_*)xs, (const TY_*)us, (const TY_*)lambdas, (const TY_*)mu, t_extreme, (TY_*)A, (TY_*)Bm,   \
+                       (TY_*)Q, (TY_*)l, (TY_*)R, (TY_*)r, (TY_*)merit_part, (TY_*)cost_part, active};                      \
+    const size_t lds = quad_lds_elems(d.n, d.m, d.N, d.pairs.Rsz, d.pairs.rsz) * sizeof(TY_);                     \
+    hipLaunchKernelGGL(linquad_kernel<TY_>, dim3(d.T, batch), dim3(64), lds, (hipStream_t)stream, d, g);          \
+    HIP_TRY(hipGetLastError());                                                                                 \
+    return ILQG_OK;                                                                                             \
+  }()
+  return DT_DISPATCH(p, CALL);
+#undef CALL
+}
+
+template <typename T, int NX, int NP, int MU>
+static ilqg_status launch_solve(ilqg_problem* p, int32_t batch, const void* x0, void* xs, void* us, void* P,
+                                void* alpha, void* total_costs, int32_t* iters, int32_t* status, int32_t* converged,
+                                void* workspace, int32_t fixed_iters, hipStream_t stream) {
+  using C = LQCfg<T, NX, NP, MU>;
+  const DevProblem& d = p->dev;
+  const WsLayout L(d.n, d.m, d.N, d.T, d.pairs.Rsz, d.pairs.rsz);
+  SolveArgs<T> sa;
+  sa.x0 = (const T*)x0; sa.xs = (T*)xs; sa.us = (T*)us; sa.P = (T*)P; sa.alpha = (T*)alpha;
+  sa.total_costs = (T*)total_costs; sa.iters = iters; sa.status = status; sa.converged = converged;
+  sa.ws = (T*)workspace; sa.ws_stride = L.total; sa.fixed_iters = fixed_iters; sa.batch = batch;
+  sa.prm = p->desc.params;
+  size_t elems = C::LDS_ELEMS;
+  const size_t e2 = rollout_lds_elems(d.n, d.m), e3 = quad_lds_elems(d.n, d.m, d.N, d.pairs.Rsz, d.pairs.rsz);
+  if (e2 > elems) elems = e2;
+  if (e3 > elems) elems = e3;
+  const size_t lds = elems * sizeof(T);
+  auto kern = ilq_solve_kernel<T, NX, NP, MU>;
+  if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3(batch), dim3(C::NT), lds, stream, d, sa);
+  HIP_TRY(hipGetLastError());
+  return ILQG_OK;
+}
+
+extern "C" {
+
+const char* ilqg_last_error(void) { return g_err.c_str(); }
+int32_t ilqg_abi_version(void) { return 1; }
+
+ilqg_status ilqg_device_info(char* name_out, int32_t name_len, int32_t* num_cus) {
+  ilqg_status s = check_device();
+  if (s != ILQG_OK) return s;
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, 0));
+  if (name_out && name_len > 0) {
+    std::snprintf(name_out, name_len, "%s (%s)", prop.name, prop.gcnArchName);
+  }
+  if (num_cus) *num_cus = prop.multiProcessorCount;
+  return ILQG_OK;
+}
+
+void ilqg_default_solver_params(ilqg_solver_params* p) {  // solver_params.h:50-84
+  p->convergence_tolerance = 1e-1f;
+  p->max_solver_iters = 1000;
+  p->linesearch = 1;
+  p->initial_alpha_scaling = 0.5f;
+  p->geometric_alpha_scaling = 0.5f;
+  p->max_backtracking_steps = 10;
+  p->expected_decrease_fraction = 0.1f;
+  p->open_loop = 0;
+  p->unconstrained_solver_max_iters = 10;
+  p->geometric_mu_scaling = 1.1f;
+  p->geometric_mu_downscaling = 0.5f;
+  p->geometric_lambda_downscaling = 0.5f;
+  p->constraint_error_tolerance = 1e-1f;
+}
+
+ilqg_status ilqg_lq_feedback_batch(const ilqg_dims* d, const void* A, const void* Bm, const void* Q, const void* l,
+                                   const void* R, const void* r, const ilqg_pair* pairs_host, int32_t npairs,
+                                   const void* x0, void* P, void* alpha, void* dx, void* costates, void* stream) {
+  if (!d || !A || !Bm || !Q || !l || !R || !r || !pairs_host || !P || !alpha)
+    return fail(ILQG_ERR_INVALID, "null argument");
+  if (d->num_players < 1 || d->num_players > ILQG_MAX_PLAYERS || d->n < 1 || d->n > ILQG_MAX_XDIM || d->T < 1 ||
+      d->T > kMaxT || d->batch < 0)
+    return fail(ILQG_ERR_INVALID, "bad dimensions");
+  if (costates) return fail(ILQG_ERR_UNSUPPORTED, "costates are not produced on device (ILQSolver ignores them)");
+  PairTable pt;
+  std::string err;
+  if (!build_pairs(pairs_host, npairs, d->udim, d->num_players, &pt, &err)) return fail(ILQG_ERR_INVALID, err);
+  int mu = 0;
+  if (!uniform_udim(d->udim, d->num_players, &mu))
+    return fail(ILQG_ERR_UNSUPPORTED, "device kernels need equal control dimensions for all players");
+  ilqg_status s = check_device();
+  if (s != ILQG_OK) return s;
+  if (d->batch == 0) return ILQG_OK;
+  hipStream_t st = (hipStream_t)stream;
+#define X(NX_, NP_, MU_)                                                                              \
+  if (d->n == NX_ && d->num_players == NP_ && mu == MU_) {                                            \
+    return d->dtype == ILQG_F32                                                                       \
+               ? launch_lq<float, NX_, NP_, MU_>(d, pt, A, Bm, Q, l, R, r, x0, P, alpha, dx, st)      \
+               : launch_lq<double, NX_, NP_, MU_>(d, pt, A, Bm, Q, l, R, r, x0, P, alpha, dx, st);    \
+  }
+  ILQG_FOR_DIMS(X)
+#undef X
+  return fail(ILQG_ERR_UNSUPPORTED, "no device kernel instantiated for n=" + std::to_string(d->n) +
+                                        " N=" + std::to_string(d->num_players) + " m_i=" + std::to_string(mu));
+}
+
+ilqg_status ilqg_lq_openloop_batch(const ilqg_dims*, const void*, const void*, const void*, const void*, const void*,
+                                   const void*, const ilqg_pair*, int32_t, const void*, void*, void*, void*, void*,
+                                   void*) {
+  return fail(ILQG_ERR_UNSUPPORTED, "open-loop sweep: device kernel not built yet");
+}
+
+ilqg_status ilqg_problem_create(const ilqg_problem_desc* desc, ilqg_problem** out) {
+  if (!desc || !out) return fail(ILQG_ERR_INVALID, "null argument");
+  if (desc->num_players < 1 || desc->num_players > ILQG_MAX_PLAYERS) return fail(ILQG_ERR_INVALID, "bad player count");
+  if (desc->T < 2 || desc->T > kMaxT) return fail(ILQG_ERR_INVALID, "bad horizon");
+  ilqg_status s = check_device();
+  if (s != ILQG_OK) return s;
+  auto* p = new ilqg_problem;
+  p->desc = *desc;
+  DevProblem& d = p->dev;
+  std::memset(&d, 0, sizeof(d));
+  d.N = desc->num_players;
+  d.T = desc->T;
+  d.dt = desc->dt;
+  d.xoff[0] = 0;
+  d.uoff[0] = 0;
+  for (int i = 0; i < d.N; i++) {
+    const ilqg_subsystem& sub = desc->subsystems[i];
+    const int want_x = sub.kind == ILQG_DYN_UNICYCLE_4D ? 4 : sub.kind == ILQG_DYN_CAR_5D ? 5 : sub.kind == ILQG_DYN_CAR_6D ? 6 : -1;
+    if (want_x < 0 || sub.xdim != want_x || sub.udim != 2) {
+      delete p;
+      return fail(ILQG_ERR_UNSUPPORTED, "unknown subsystem kind / dimension");
+    }
+    d.sub_kind[i] = sub.kind;
+    d.sub_param[i] = sub.param0;
+    d.udim[i] = sub.udim;
+    d.xoff[i + 1] = d.xoff[i] + sub.xdim;
+    d.uoff[i + 1] = d.uoff[i] + sub.udim;
+    d.state_reg[i] = desc->player_costs[i].state_regularization;
+    d.control_reg[i] = desc->player_costs[i].control_regularization;
+    d.structure[i] = desc->player_costs[i].structure;
+  }
+  d.n = d.xoff[d.N];
+  d.m = d.uoff[d.N];
+  // pair table in PlayerCost first-touch order: control costs, then control constraints
+  std::vector<ilqg_pair> pairs;
+  std::vector<int> from_cost;
+  for (int i = 0; i < d.N; i++)
+    for (int pass = 0; pass < 2; pass++)
+      for (int ti = 0; ti < desc->num_terms; ti++) {
+        const ilqg_cost_term& t = desc->terms[ti];
+        if (t.player != i) continue;
+        if (pass == 0 && t.role != ILQG_ROLE_CONTROL_COST) continue;
+        if (pass == 1 && t.role != ILQG_ROLE_CONTROL_CONSTRAINT) continue;
+        bool found = false;
+        for (auto& pr : pairs) found = found || (pr.i == i && pr.j == t.arg);
+        if (!found) {
+          pairs.push_back({i, t.arg});
+          from_cost.push_back(pass == 0 ? 1 : 0);
+        }
+      }
+  std::string err;
+  if (!build_pairs(pairs.data(), (int)pairs.size(), d.udim, d.N, &d.pairs, &err)) {
+    delete p;
+    return fail(ILQG_ERR_INVALID, err);
+  }
+  for (size_t q = 0; q < pairs.size(); q++) d.pairs.from_cost[q] = from_cost[q];
+  d.num_terms = desc->num_terms;
+  d.num_polylines = desc->num_polylines;
+  std::vector<DevTerm> dt(desc->num_terms > 0 ? desc->num_terms : 1);
+  int nc = 0;
+  for (int ti = 0; ti < desc->num_terms; ti++) {
+    const ilqg_cost_term& t = desc->terms[ti];
+    DevTerm& o = dt[ti];
+    o.kind = t.kind; o.role = t.role; o.player = t.player; o.arg = t.arg;
+    for (int q = 0; q < 4; q++) o.idx[q] = t.idx[q];
+    o.weight = t.weight; o.value = t.value; o.flags = t.flags; o.polyline = t.polyline;
+    o.child_begin = t.child_begin; o.child_count = t.child_count; o.slot = t.constraint_slot;
+    if (t.constraint_slot >= 0 && t.constraint_slot + 1 > nc) nc = t.constraint_slot + 1;
+  }
+  d.num_constraints = nc;
+  p->terms_host.assign(desc->terms, desc->terms + desc->num_terms);
+  const int npts = desc->num_polylines ? desc->polyline_offsets[desc->num_polylines] : 0;
+  hipError_t e = hipMalloc(&p->d_terms, sizeof(DevTerm) * dt.size());
+  if (e == hipSuccess) e = hipMemcpy(p->d_terms, dt.data(), sizeof(DevTerm) * dt.size(), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMalloc(&p->d_poly_off, sizeof(int) * (desc->num_polylines + 1));
+  if (e == hipSuccess && desc->num_polylines)
+    e = hipMemcpy(p->d_poly_off, desc->polyline_offsets, sizeof(int) * (desc->num_polylines + 1), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMalloc(&p->d_poly_pts, sizeof(float) * 2 * (npts > 0 ? npts : 1));
+  if (e == hipSuccess && npts)
+    e = hipMemcpy(p->d_poly_pts, desc->polyline_points, sizeof(float) * 2 * npts, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    ilqg_problem_destroy(p);
+    return fail(ILQG_ERR_HIP, std::string("problem tables: ") + hipGetErrorString(e));
+  }
+  d.terms = p->d_terms;
+  d.poly_off = p->d_poly_off;
+  d.poly_pts = p->d_poly_pts;
+  p->desc.terms = nullptr;
+  p->desc.polyline_offsets = nullptr;
+  p->desc.polyline_points = nullptr;
+  uniform_udim(d.udim, d.N, &p->mu_uniform);
+  *out = p;
+  return ILQG_OK;
+}
+
+void ilqg_problem_destroy(ilqg_problem* p) {
+  if (!p) return;
+  if (p->d_terms) (void)hipFree(p->d_terms);
+  if (p->d_poly_off) (void)hipFree(p->d_poly_off);
+  if (p->d_poly_pts) (void)hipFree(p->d_poly_pts);
+  delete p;
+}
+
+ilqg_status ilqg_problem_pairs(const ilqg_problem* p, ilqg_pair* pairs_host, int32_t* npairs) {
+  if (!p || !pairs_host || !npairs) return fail(ILQG_ERR_INVALID, "null argument");
+  *npairs = p->dev.pairs.npairs;
+  for (int q = 0; q < *npairs; q++) pairs_host[q] = {p->dev.pairs.pi[q], p->dev.pairs.pj[q]};
+  return ILQG_OK;
+}
+
+ilqg_status ilqg_workspace_bytes(const ilqg_problem* p, int32_t batch, uint64_t* bytes) {
+  if (!p || !bytes) return fail(ILQG_ERR_INVALID, "null argument");
+  const DevProblem& d = p->dev;
+  const WsLayout L(d.n, d.m, d.N, d.T, d.pairs.Rsz, d.pairs.rsz);
+  *bytes = uint64_t(L.total) * (p->desc.dtype == ILQG_F32 ? 4 : 8) * uint64_t(batch > 0 ? batch : 0);
+  return ILQG_OK;
+}
+
+
+ilqg_status ilqg_rollout_batch(const ilqg_problem* p, int32_t batch, const void* x0, const void* xs_ref,
+                               const void* us_ref, const void* P, const void* alpha, const void* alpha_scale,
+                               void* xs, void* us, const int32_t* active, void* stream) {
+  if (!p || !x0 || !xs_ref || !us_ref || !P || !alpha || !xs || !us) return fail(ILQG_ERR_INVALID, "null argument");
+  if (batch <= 0) return ILQG_OK;
+  const DevProblem& d = p->dev;
+  if (d.m * d.n + 2 * d.m + d.n > 4 * 64) return fail(ILQG_ERR_UNSUPPORTED, "rollout staging block too large");
+#define CALL(TY_)                                                                                              \
+  [&]() -> ilqg_status {                                                                                     \
+    RolloutBatchArgs<TY_> g{(const TY_*)x0, (const TY_*)xs_ref, (const TY_*)us_ref, (const TY_*)P, (const TY_*)alpha,    \
+                          (const TY_*)alpha_scale, (TY_*)xs, (TY_*)us, active};                                    \
+    hipLaunchKernelGGL(rollout_kernel<TY_>, dim3(batch), dim3(64), rollout_lds_elems(d.n, d.m) * sizeof(TY_),    \
+                       (hipStream_t)stream, d, g);                                                           \
+    HIP_TRY(hipGetLastError());                                                                              \
+    return ILQG_OK;                                                                                          \
+  }()
+  return DT_DISPATCH(p, CALL);
+#undef CALL
+}
+
+ilqg_status ilqg_linearize_batch(const ilqg_problem* p, int32_t batch, const void* xs, const void* us, void* A,
+                                 void* Bm, const int32_t* active, void* stream) {
+  if (!p || !xs || !us || !A || !Bm) return fail(ILQG_ERR_INVALID, "null argument");
+  if (batch <= 0) return ILQG_OK;
+  return launch_linquad(p, batch, xs, us, nullptr, nullptr, nullptr, A, Bm, nullptr, nullptr, nullptr, nullptr,
+                        nullptr, nullptr, active, stream);
+}
+
+ilqg_status ilqg_quadraticize_batch(const ilqg_problem* p, int32_t batch, const void* xs, const void* us,
+                                    const void* lambdas, const void* mu, const int32_t* t_extreme, void* Q, void* l,
+                                    void* R, void* r, const int32_t* active, void* stream) {
+  if (!p || !xs || !us || !Q || !l || !R || !r) return fail(ILQG_ERR_INVALID, "null argument");
+  if (batch <= 0) return ILQG_OK;
+  return launch_linquad(p, batch, xs, us, lambdas, mu, t_extreme, nullptr, nullptr, Q, l, R, r, nullptr, nullptr,
+                        active, stream);
+}
+
+ilqg_status ilqg_total_costs_batch(const ilqg_problem* p, int32_t batch, const void* xs, const void* us, void* costs,
+                                   int32_t* t_extreme, const int32_t* active, void* stream) {
+  if (!p || !xs || !us || !costs) return fail(ILQG_ERR_INVALID, "null argument");
+  if (batch <= 0) return ILQG_OK;
+  const DevProblem& d = p->dev;
+  const size_t esz = p->desc.dtype == ILQG_F32 ? 4 : 8;
+  ilqg_status s = g_scratch.reserve(size_t(batch) * d.T * d.N * esz);
+  if (s != ILQG_OK) return s;
+  s = launch_linquad(p, batch, xs, us, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                     nullptr, nullptr, g_scratch.ptr, active, stream);
+  if (s != ILQG_OK) return s;
+#define CALL(TY_)                                                                                             \
+  [&]() -> ilqg_status {                                                                                    \
+    hipLaunchKernelGGL(costs_reduce_kernel<TY_>, dim3(batch), dim3(64), 0, (hipStream_t)stream, d,            \
+                       (const TY_*)g_scratch.ptr, (TY_*)costs, t_extreme, active);                              \
+    HIP_TRY(hipGetLastError());                                                                             \
+    return ILQG_OK;                                                                                         \
+  }()
+  return DT_DISPATCH(p, CALL);
+#undef CALL
+}
+
+ilqg_status ilqg_ilq_solve_batch(ilqg_problem* p, int32_t batch, const void* x0, void* xs, void* us, void* P,
+                                 void* alpha, void* total_costs, int32_t* iters, int32_t* status, int32_t* converged,
+                                 void* workspace, int32_t fixed_iters, void* stream) {
+  if (!p || !x0 || !xs || !us || !P || !alpha || !total_costs || !iters || !status || !converged || !workspace)
+    return fail(ILQG_ERR_INVALID, "null argument");
+  if (batch <= 0) return ILQG_OK;
+  if (p->desc.params.open_loop) return fail(ILQG_ERR_UNSUPPORTED, "open-loop iLQ: device kernel not built yet");
+  const DevProblem& d = p->dev;
+  if (!p->mu_uniform) return fail(ILQG_ERR_UNSUPPORTED, "non-uniform control dimensions");
+  hipStream_t st = (hipStream_t)stream;
+#define X(NX_, NP_, MU_)                                                                                        \
+  if (d.n == NX_ && d.N == NP_ && p->mu_uniform == MU_) {                                                       \
+    return p->desc.dtype == ILQG_F32                                                                            \
+               ? launch_solve<float, NX_, NP_, MU_>(p, batch, x0, xs, us, P, alpha, total_costs, iters, status,  \
+                                                    converged, workspace, fixed_iters, st)                      \
+               : launch_solve<double, NX_, NP_, MU_>(p, batch, x0, xs, us, P, alpha, total_costs, iters, status, \
+                                                     converged, workspace, fixed_iters, st);                    \
+  }
+  ILQG_FOR_DIMS(X)
+#undef X
+  return fail(ILQG_ERR_UNSUPPORTED, "no device kernel instantiated for this problem's dimensions");
+}
+
+}  // extern "C"

@@ -1,0 +1,466 @@
+// ilqg_lq.hpp — coupled backward LQ Nash sweep for ONE game instance per workgroup (gfx950).
+//
+// Computes what LQFeedbackSolver::Solve computes (src/lq_feedback_solver.cpp:71-244):
+//   k = T-2 .. 0:  S X = Y  (stacked Nash system, Gershgorin-regularised, Householder QR)
+//                  F = A - B P, beta = -B alpha,
+//                  Z_i <- F^T Z_i F + Q_i + sum_j P_j^T R_ij P_j
+//                  zeta_i <- F^T (zeta_i + Z_i beta) + l_i + sum_j P_j^T (R_ij alpha_j - r_ij)
+//   forward pass:  dx_{k+1} = A dx_k - B alpha_k   (no feedback term, :237-239)
+// and, fused into the same pass over the data, ILQSolver::ExpectedDecrease
+// (src/ilq_solver.cpp:364-398).
+//
+// Mapping (this is not the reference's loop nest):
+//   * lane t = i*NX + c owns COLUMN c of Z_i in registers for the whole sweep;
+//   * the per-step blocks [B|A|Q|l|R|r] are prefetched global->VGPR one step ahead
+//     (coalesced: consecutive lanes, consecutive elements) and committed to an LDS
+//     image after the step's last LDS read, so HBM latency hides under the math;
+//   * F^T Z_i F is two passes of "uniform matrix x private column":
+//       U_i[:,c] = F^T Z_i[:,c]          (F broadcast from LDS, Z column in VGPRs)
+//       Z_i'[:,c] = U_i F[:,c]           (U_i rows broadcast from LDS, F column in VGPRs)
+//     so every FMA takes one broadcast LDS operand and no cross-lane reduction;
+//   * the (m x m) Nash system with its n+1 right-hand sides lives one COLUMN PER LANE
+//     in wave 0; Householder reflectors are broadcast with __shfl, back substitution
+//     pulls R entries with __shfl — no LDS, no barriers inside the factorisation.
+#pragma once
+
+#include "ilqg_common.hpp"
+
+namespace ilqg {
+
+template <typename T>
+struct LQArgs {
+  const T *A, *Bm, *Q, *l, *R, *r;  // instance bases: [T][n*n], [T][n*m], [T][N][n*n], [T][N][n], [T][Rsz], [T][rsz]
+  const T* x0;                      // [n] or nullptr (zero)
+  T *P, *alpha, *dx;                // [T][m*n], [T][m], [T][n] (dx may be nullptr)
+  T* scratch;                       // [T][N*(n+1) + n] when dx/ed requested, else nullptr
+  T* ed_out;                        // expected decrease (one scalar) or nullptr
+  int T_steps;
+  int adaptive;
+};
+
+template <typename T, int NX, int NP, int MU>
+struct LQCfg {
+  static constexpr int M = NP * MU;
+  static constexpr int L = NP * NX;
+  static constexpr int NSOLVE = M + NX + 1;  // columns of [S | Y]
+  static constexpr int NT = ((L > NSOLVE ? L : NSOLVE) + 63) / 64 * 64;
+  static constexpr int RMAX = NP * NP * MU * MU;
+  static constexpr int rMAX = NP * NP * MU;
+  // staged image [B | A | Q | l | R | r]
+  static constexpr int oB = 0;
+  static constexpr int oA = oB + NX * M;
+  static constexpr int oQ = oA + NX * NX;
+  static constexpr int ol = oQ + NP * NX * NX;
+  static constexpr int oR = ol + NP * NX;
+  static constexpr int or_ = oR + RMAX;
+  static constexpr int WMAIN = oR;  // elements streamed by the generic prefetcher
+  static constexpr int PRE = (WMAIN + NT - 1) / NT;
+  // intermediates
+  static constexpr int NXS = NX | 1;  // odd leading dimension: conflict-free column writes
+  static constexpr int oF = or_ + rMAX;
+  static constexpr int oUt = oF + NX * NXS;
+  static constexpr int oBZ = oUt + NP * NX * NXS;
+  static constexpr int oP = oBZ + M * NX;
+  static constexpr int oAl = oP + M * NX;
+  static constexpr int oBeta = oAl + M;
+  static constexpr int oZeta = oBeta + NX;
+  static constexpr int oYz = oZeta + NP * NX;
+  static constexpr int oX = oYz + M;
+  static constexpr int LDS_ELEMS = oX + NX;
+  static_assert(RMAX <= NT, "R blocks are loaded one element per lane");
+  static_assert(NSOLVE <= 64, "the stacked Nash system must fit one wavefront");
+};
+
+template <typename T>
+__device__ __forceinline__ T shfl(T v, int lane) {
+  return __shfl(v, lane, 64);
+}
+__device__ __forceinline__ float lq_sqrt(float x) { return sqrtf(x); }
+__device__ __forceinline__ double lq_sqrt(double x) { return sqrt(x); }
+
+// Householder QR solve of S X = Y with one column of [S | Y] per lane (wave 0).
+// Restates Eigen's householder_qr_inplace_unblocked + makeHouseholder +
+// applyHouseholderOnTheLeft + triangular solve — the arithmetic behind
+// `S_.householderQr().solve(Y_)` (src/lq_feedback_solver.cpp:180).
+// On return lanes >= M hold the solution column in x[].
+template <typename T, int M>
+__device__ __forceinline__ void qr_solve_columns(T (&col)[M], int lane, T (&x)[M]) {
+#pragma unroll
+  for (int k = 0; k < M; k++) {
+    T tailsq = T(0);
+#pragma unroll
+    for (int i = k + 1; i < M; i++) tailsq += col[i] * col[i];
+    const T c0 = col[k];
+    T beta, tau;
+    T ess[M];
+    if (M - k == 1 || tailsq <= (sizeof(T) == 4 ? T(1.17549435e-38f) : T(2.2250738585072014e-308))) {
+      tau = T(0);
+      beta = c0;
+#pragma unroll
+      for (int i = k + 1; i < M; i++) ess[i] = T(0);
+    } else {
+      beta = lq_sqrt(c0 * c0 + tailsq);
+      if (c0 >= T(0)) beta = -beta;
+#pragma unroll
+      for (int i = k + 1; i < M; i++) ess[i] = col[i] / (c0 - beta);
+      tau = (beta - c0) / beta;
+    }
+    const T tau_k = shfl(tau, k);
+    T v[M];
+#pragma unroll
+    for (int i = k + 1; i < M; i++) v[i] = shfl(ess[i], k);
+    if (lane == k) {
+      col[k] = beta;
+#pragma unroll
+      for (int i = k + 1; i < M; i++) col[i] = ess[i];
+    } else if (lane > k) {
+      if (M - k == 1) {
+        col[k] *= (T(1) - tau_k);
+      } else if (tau_k != T(0)) {
+        T tmp = T(0);
+#pragma unroll
+        for (int i = k + 1; i < M; i++) tmp += v[i] * col[i];
+        tmp += col[k];
+        col[k] -= tau_k * tmp;
+#pragma unroll
+        for (int i = k + 1; i < M; i++) col[i] -= tau_k * v[i] * tmp;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = M - 1; i >= 0; i--) {
+    T s = col[i];
+#pragma unroll
+    for (int k2 = i + 1; k2 < M; k2++) s -= shfl(col[i], k2) * x[k2];
+    x[i] = s / shfl(col[i], i);
+  }
+}
+
+// One instance, executed by a workgroup of LQCfg::NT threads.  `sm` is LDS scratch
+// of LQCfg::LDS_ELEMS elements.  All threads of the workgroup must call.
+template <typename T, int NX, int NP, int MU>
+__device__ void lq_feedback_instance(const LQArgs<T>& a, const PairTable& pt, T* sm) {
+  using C = LQCfg<T, NX, NP, MU>;
+  constexpr int M = C::M, L = C::L, NT = C::NT, NXS = C::NXS;
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const bool zl = t < L;  // this lane owns a Z column
+  const int pi = zl ? t / NX : 0;
+  const int pc = zl ? t % NX : 0;
+  const int Tn = a.T_steps;
+  const int Rsz = pt.Rsz, rsz = pt.rsz;
+  const bool want_fwd = a.dx != nullptr || a.ed_out != nullptr;
+  const int SCR = NP * (NX + 1) + NX;  // scratch row: [ql (N*n) | ctrl (N) | beta (n)]
+
+  T* sB = sm + C::oB;
+  T* sA = sm + C::oA;
+  T* sQ = sm + C::oQ;
+  T* sl = sm + C::ol;
+  T* sR = sm + C::oR;
+  T* sr = sm + C::or_;
+  T* sF = sm + C::oF;
+  T* sUt = sm + C::oUt;
+  T* sBZ = sm + C::oBZ;
+  T* sP = sm + C::oP;
+  T* sAl = sm + C::oAl;
+  T* sBeta = sm + C::oBeta;
+  T* sZeta = sm + C::oZeta;
+  T* sYz = sm + C::oYz;
+  T* sX = sm + C::oX;
+
+  T pre[C::PRE];
+  T preR = T(0), prer = T(0);
+  auto issue = [&](int k) {
+    const T* gB = a.Bm + size_t(k) * NX * M;
+    const T* gA = a.A + size_t(k) * NX * NX;
+    const T* gQ = a.Q + size_t(k) * NP * NX * NX;
+    const T* gl = a.l + size_t(k) * NP * NX;
+#pragma unroll
+    for (int q = 0; q < C::PRE; q++) {
+      const int e = t + q * NT;
+      if (e < C::oA)
+        pre[q] = gB[e];
+      else if (e < C::oQ)
+        pre[q] = gA[e - C::oA];
+      else if (e < C::ol)
+        pre[q] = gQ[e - C::oQ];
+      else if (e < C::oR)
+        pre[q] = gl[e - C::ol];
+    }
+    if (t < Rsz) preR = a.R[size_t(k) * Rsz + t];
+    if (t < rsz) prer = a.r[size_t(k) * rsz + t];
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int q = 0; q < C::PRE; q++) {
+      const int e = t + q * NT;
+      if (e < C::oR) sm[e] = pre[q];
+    }
+    if (t < Rsz) sR[t] = preR;
+    if (t < rsz) sr[t] = prer;
+  };
+  // (Q_i l_i) of the step currently staged -> scratch, for ExpectedDecrease
+  auto stash_ql = [&](int k) {
+    if (want_fwd && zl) {
+      T s = T(0);
+#pragma unroll
+      for (int c = 0; c < NX; c++) s += sQ[pi * NX * NX + pc + NX * c] * sl[pi * NX + c];
+      a.scratch[size_t(k) * SCR + pi * NX + pc] = s;
+    }
+  };
+
+  // ---- terminal step: Z_i = Q_i[T-1], zeta_i = l_i[T-1]  (:102-105) ----
+  issue(Tn - 1);
+  commit();
+  __syncthreads();
+  T z[NX];
+  T zeta = T(0);
+  if (zl) {
+#pragma unroll
+    for (int r = 0; r < NX; r++) z[r] = sQ[pi * NX * NX + r + NX * pc];
+    zeta = sl[pi * NX + pc];
+  } else {
+#pragma unroll
+    for (int r = 0; r < NX; r++) z[r] = T(0);
+  }
+  stash_ql(Tn - 1);
+  // strategies at T-1 stay zero (strategy.h:64-70)
+  for (int e = t; e < M * NX; e += NT) a.P[size_t(Tn - 1) * M * NX + e] = T(0);
+  if (t < M) a.alpha[size_t(Tn - 1) * M + t] = T(0);
+  if (want_fwd) {
+    if (t < NP) a.scratch[size_t(Tn - 1) * SCR + NP * NX + t] = T(0);
+    if (t < NX) a.scratch[size_t(Tn - 1) * SCR + NP * (NX + 1) + t] = T(0);
+  }
+  if (Tn >= 2) issue(Tn - 2);
+  __syncthreads();
+  if (zl) sZeta[t] = zeta;
+  if (Tn >= 2) commit();
+  __syncthreads();
+
+#pragma unroll 1
+  for (int k = Tn - 2; k >= 0; k--) {
+    if (k > 0) issue(k - 1);
+    stash_ql(k);
+
+    // ---- P1: BZ = B_i^T Z_i (rows of the stacked system), y_zeta = B_i^T zeta_i + r_ii ----
+    if (zl) {
+#pragma unroll
+      for (int aa = 0; aa < MU; aa++) {
+        T s = T(0);
+#pragma unroll
+        for (int r = 0; r < NX; r++) s += sB[r + NX * (pi * MU + aa)] * z[r];
+        sBZ[(pi * MU + aa) + M * pc] = s;
+      }
+      if (pc < MU) {
+        T s = T(0);
+#pragma unroll
+        for (int r = 0; r < NX; r++) s += sB[r + NX * (pi * MU + pc)] * sZeta[pi * NX + r];
+        sYz[pi * MU + pc] = s + sr[pt.rgoff[pt.pii[pi]] + pc];
+      }
+    }
+    __syncthreads();
+
+    // ---- P2: column `t` of [S | Y], Gershgorin, QR solve (wave 0) ----
+    if (t < 64) {
+      T col[M], x[M];
+#pragma unroll
+      for (int r = 0; r < M; r++) { col[r] = T(0); x[r] = T(0); }
+      if (t < M + NX) {
+        // column t of [B | A] is contiguous in the staged image
+        T mc[NX];
+#pragma unroll
+        for (int c = 0; c < NX; c++) mc[c] = sm[C::oB + c + NX * t];
+#pragma unroll
+        for (int r = 0; r < M; r++) {
+          T s = T(0);
+#pragma unroll
+          for (int c = 0; c < NX; c++) s += sBZ[r + M * c] * mc[c];
+          col[r] = s;
+        }
+        if (t < M) {
+          // + R_ii on the diagonal block (:131-149)
+          const int pj = t / MU, b = t % MU;
+          const T* Rii = sR + pt.roff[pt.pii[pj]];
+#pragma unroll
+          for (int r = 0; r < M; r++)
+            if (r / MU == pj) col[r] = col[r] + Rii[(r % MU) + MU * b];
+          if (a.adaptive) {  // :163-176 — columns are independent, so lane-parallel is exact
+            T l1 = T(0), diag = T(0);
+#pragma unroll
+            for (int r = 0; r < M; r++) {
+              l1 += (col[r] < T(0) ? -col[r] : col[r]);
+              if (r == t) diag = col[r];
+            }
+            const T radius = l1 - (diag < T(0) ? -diag : diag);
+            const T eval_lo = diag - radius;
+            if (eval_lo < T(1e-3f)) {
+#pragma unroll
+              for (int r = 0; r < M; r++)
+                if (r == t) col[r] += radius + T(1e-3f);
+            }
+          }
+        }
+      } else if (t == M + NX) {
+#pragma unroll
+        for (int r = 0; r < M; r++) col[r] = sYz[r];
+      }
+      qr_solve_columns<T, M>(col, lane, x);
+      if (t >= M && t < M + NX) {
+#pragma unroll
+        for (int r = 0; r < M; r++) {
+          sP[r + M * (t - M)] = x[r];
+          a.P[size_t(k) * M * NX + r + M * (t - M)] = x[r];
+        }
+      } else if (t == M + NX) {
+#pragma unroll
+        for (int r = 0; r < M; r++) {
+          sAl[r] = x[r];
+          a.alpha[size_t(k) * M + r] = x[r];
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- P3: F[:,c] = A[:,c] - B P[:,c]; beta = -B alpha ----
+    T f[NX], pcol[M];
+#pragma unroll
+    for (int r = 0; r < M; r++) pcol[r] = zl ? sP[r + M * pc] : T(0);
+#pragma unroll
+    for (int r = 0; r < NX; r++) {
+      T s = zl ? sA[r + NX * pc] : T(0);
+#pragma unroll
+      for (int q = 0; q < M; q++) s -= sB[r + NX * q] * pcol[q];
+      f[r] = s;
+    }
+    if (t < NX) {
+#pragma unroll
+      for (int r = 0; r < NX; r++) sF[r + NXS * t] = f[r];
+      T s = T(0);
+#pragma unroll
+      for (int q = 0; q < M; q++) s -= sB[t + NX * q] * sAl[q];
+      sBeta[t] = s;
+      if (want_fwd) a.scratch[size_t(k) * SCR + NP * (NX + 1) + t] = s;
+    }
+    if (want_fwd && t < NP) {
+      // alpha_i^T R_ii r_ii, evaluated (alpha^T R) r like Eigen (ilq_solver.cpp:384-386)
+      const int q = pt.pii[t];
+      T acc = T(0);
+#pragma unroll
+      for (int c = 0; c < MU; c++) {
+        T aR = T(0);
+#pragma unroll
+        for (int b = 0; b < MU; b++) aR += sAl[t * MU + b] * sR[pt.roff[q] + b + MU * c];
+        acc += aR * sr[pt.rgoff[q] + c];
+      }
+      a.scratch[size_t(k) * SCR + NP * NX + t] = acc;
+    }
+    __syncthreads();
+
+    // ---- P4: U_i[:,c] = F^T Z_i[:,c], stored transposed for row access ----
+    if (zl) {
+#pragma unroll
+      for (int r = 0; r < NX; r++) {
+        T s = T(0);
+#pragma unroll
+        for (int kk = 0; kk < NX; kk++) s += sF[kk + NXS * r] * z[kk];
+        sUt[(pi * NX + r) * NXS + pc] = s;
+      }
+    }
+    __syncthreads();
+
+    // ---- P5: Z_i'[:,c] = U_i F[:,c] + Q_i[:,c] + sum_j P_j^T R_ij P_j[:,c]; zeta update ----
+    T zeta_new = T(0);
+    if (zl) {
+#pragma unroll
+      for (int r = 0; r < NX; r++) {
+        T s = T(0);
+#pragma unroll
+        for (int cc = 0; cc < NX; cc++) s += sUt[(pi * NX + r) * NXS + cc] * f[cc];
+        z[r] = s + sQ[pi * NX * NX + r + NX * pc];
+      }
+      // zeta_i'[c] = F[:,c].zeta_i + U_i[c,:].beta + l_i[c] + ...
+      T s1 = T(0), s2 = T(0);
+#pragma unroll
+      for (int kk = 0; kk < NX; kk++) {
+        s1 += f[kk] * sZeta[pi * NX + kk];
+        s2 += sUt[(pi * NX + pc) * NXS + kk] * sBeta[kk];
+      }
+      zeta_new = (s1 + s2) + sl[pi * NX + pc];
+      for (int q = 0; q < pt.npairs; q++) {
+        if (pt.pi[q] != pi) continue;
+        const int j = pt.pj[q];
+        const T* Rij = sR + pt.roff[q];
+        const T* rij = sr + pt.rgoff[q];
+        T v[MU], w[MU];
+#pragma unroll
+        for (int aa = 0; aa < MU; aa++) {
+          T sv = T(0), sw = T(0);
+#pragma unroll
+          for (int b = 0; b < MU; b++) {
+            sv += Rij[aa + MU * b] * sP[(j * MU + b) + M * pc];
+            sw += Rij[aa + MU * b] * sAl[j * MU + b];
+          }
+          v[aa] = sv;
+          w[aa] = sw - rij[aa];
+        }
+        T add = T(0);
+#pragma unroll
+        for (int aa = 0; aa < MU; aa++) {
+          add += sP[(j * MU + aa) + M * pc] * w[aa];
+        }
+        zeta_new += add;
+#pragma unroll
+        for (int r = 0; r < NX; r++) {
+          T s = T(0);
+#pragma unroll
+          for (int aa = 0; aa < MU; aa++) s += sP[(j * MU + aa) + M * r] * v[aa];
+          z[r] += s;
+        }
+      }
+    }
+    __syncthreads();
+    if (zl) sZeta[t] = zeta_new;
+    if (k > 0) commit();
+    __syncthreads();
+  }
+
+  // ---- forward pass: delta_xs (:217-241) + ExpectedDecrease (ilq_solver.cpp:364-398) ----
+  if (!want_fwd) return;
+  if (t < NX) sX[t] = a.x0 ? a.x0[t] : T(0);
+  T ed = T(0);
+  __syncthreads();
+#pragma unroll 1
+  for (int k = 0; k < Tn; k++) {
+    // stage A_k (coalesced) into the image's A slot
+    for (int e = t; e < NX * NX; e += NT) sA[e] = a.A[size_t(k) * NX * NX + e];
+    if (a.dx && t < NX) a.dx[size_t(k) * NX + t] = sX[t];
+    if (a.ed_out && t < 64) {
+      T st = T(0), ct = T(0);
+      if (t < NP) {
+        ct = a.scratch[size_t(k) * SCR + NP * NX + t];
+        if (k > 0) {
+#pragma unroll
+          for (int c = 0; c < NX; c++) st += sX[c] * a.scratch[size_t(k) * SCR + t * NX + c];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NP; i++) {
+        ed -= shfl(ct, i);
+        if (k > 0) ed -= shfl(st, i);
+      }
+    }
+    __syncthreads();
+    T xn = T(0);
+    if (t < NX) {
+#pragma unroll
+      for (int c = 0; c < NX; c++) xn += sA[t + NX * c] * sX[c];
+      xn += a.scratch[size_t(k) * SCR + NP * (NX + 1) + t];  // beta_k = -B alpha_k
+    }
+    __syncthreads();
+    if (t < NX) sX[t] = xn;
+    __syncthreads();
+  }
+  if (a.ed_out && t == 0) *a.ed_out = ed;
+}
+
+}  // namespace ilqg

@@ -1,0 +1,497 @@
+// ilqg_models.hpp — device-side dynamics, geometry and cost models (gfx950).
+//
+// Restates, for one lane, the closed-form models the reference evaluates through
+// virtual calls; every function cites the reference lines it computes the same
+// quantity as.  Written for the "one lane integrates one subsystem / walks one
+// player's cost list" mapping of the rollout and quadraticisation stages.
+#pragma once
+
+#include "ilqg_common.hpp"
+
+namespace ilqg {
+
+template <typename T> __device__ __forceinline__ T t_sin(T x);
+template <> __device__ __forceinline__ float t_sin<float>(float x) { return sinf(x); }
+template <> __device__ __forceinline__ double t_sin<double>(double x) { return sin(x); }
+template <typename T> __device__ __forceinline__ T t_cos(T x);
+template <> __device__ __forceinline__ float t_cos<float>(float x) { return cosf(x); }
+template <> __device__ __forceinline__ double t_cos<double>(double x) { return cos(x); }
+template <typename T> __device__ __forceinline__ T t_tan(T x);
+template <> __device__ __forceinline__ float t_tan<float>(float x) { return tanf(x); }
+template <> __device__ __forceinline__ double t_tan<double>(double x) { return tan(x); }
+template <typename T> __device__ __forceinline__ T t_sqrt(T x);
+template <> __device__ __forceinline__ float t_sqrt<float>(float x) { return sqrtf(x); }
+template <> __device__ __forceinline__ double t_sqrt<double>(double x) { return sqrt(x); }
+template <typename T> __device__ __forceinline__ T t_hypot(T x, T y);
+template <> __device__ __forceinline__ float t_hypot<float>(float x, float y) { return hypotf(x, y); }
+template <> __device__ __forceinline__ double t_hypot<double>(double x, double y) { return hypot(x, y); }
+template <typename T> __device__ __forceinline__ T t_abs(T x) { return x < T(0) ? -x : x; }
+
+// ---------------------------------------------------------------------------
+// Dynamics — x is one subsystem's state (<= 6), u its 2 inputs.
+// single_player_unicycle_4d.h:90-100, single_player_car_5d.h:100-111,
+// single_player_car_6d.h:102-114.
+// ---------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void sub_eval(int kind, T L, const T* x, T u0, T u1, T* xd) {
+  if (kind == ILQG_DYN_UNICYCLE_4D) {
+    xd[0] = x[3] * t_cos(x[2]);
+    xd[1] = x[3] * t_sin(x[2]);
+    xd[2] = u0;
+    xd[3] = u1;
+    xd[4] = T(0);
+    xd[5] = T(0);
+  } else {
+    xd[0] = x[4] * t_cos(x[2]);
+    xd[1] = x[4] * t_sin(x[2]);
+    xd[2] = (x[4] / L) * t_tan(x[3]);
+    xd[3] = u0;
+    if (kind == ILQG_DYN_CAR_5D) {
+      xd[4] = u1;
+      xd[5] = T(0);
+    } else {
+      xd[4] = x[5];
+      xd[5] = u1;
+    }
+  }
+}
+
+// MultiPlayerDynamicalSystem::Integrate (src/multi_player_dynamical_system.cpp:52-77):
+// RK4, 2 sub-steps of dt/2.  Subsystems of a ConcatenatedDynamicalSystem are
+// decoupled once u is fixed, so one lane integrates one block in registers.
+template <typename T>
+__device__ __forceinline__ void sub_integrate(int kind, T L, double interval, T* x, T u0, T u1) {
+  const T h = T(interval / 2.0);
+#pragma unroll 1
+  for (int s = 0; s < 2; s++) {
+    T k1[6], k2[6], k3[6], k4[6], xt[6];
+    sub_eval(kind, L, x, u0, u1, k1);
+#pragma unroll
+    for (int i = 0; i < 6; i++) { k1[i] = h * k1[i]; xt[i] = x[i] + T(0.5) * k1[i]; }
+    sub_eval(kind, L, xt, u0, u1, k2);
+#pragma unroll
+    for (int i = 0; i < 6; i++) { k2[i] = h * k2[i]; xt[i] = x[i] + T(0.5) * k2[i]; }
+    sub_eval(kind, L, xt, u0, u1, k3);
+#pragma unroll
+    for (int i = 0; i < 6; i++) { k3[i] = h * k3[i]; xt[i] = x[i] + k3[i]; }
+    sub_eval(kind, L, xt, u0, u1, k4);
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      k4[i] = h * k4[i];
+      x[i] += (k1[i] + T(2.0) * (k2[i] + k3[i]) + k4[i]) / T(6.0);
+    }
+  }
+}
+
+// Per-model Jacobian entries added on top of (I, 0)
+// (single_player_unicycle_4d.h:102-116, single_player_car_5d.h:113-133,
+//  single_player_car_6d.h:116-138; mixed float*double products kept).
+// A: pointer to the (o,o) corner of a column-major matrix with leading dim ld;
+// B: pointer to the (o,uo) corner, same ld.
+template <typename T>
+__device__ __forceinline__ void sub_linearize(int kind, T L, double dt, const T* x, T* A, T* B, int ld) {
+  const int v = (kind == ILQG_DYN_UNICYCLE_4D) ? 3 : 4;
+  const T ct = T(double(t_cos(x[2])) * dt);
+  const T st = T(double(t_sin(x[2])) * dt);
+  A[0 + ld * 2] += -x[v] * st;
+  A[0 + ld * v] += ct;
+  A[1 + ld * 2] += x[v] * ct;
+  A[1 + ld * v] += st;
+  if (kind == ILQG_DYN_UNICYCLE_4D) {
+    B[2 + ld * 0] = T(dt);
+    B[3 + ld * 1] = T(dt);
+  } else {
+    const T cphi = t_cos(x[3]);
+    const T tphi = t_tan(x[3]);
+    A[2 + ld * 3] += T(double(x[4]) * dt / double(L * cphi * cphi));
+    A[2 + ld * 4] += T(double(tphi) * dt / double(L));
+    if (kind == ILQG_DYN_CAR_5D) {
+      B[3 + ld * 0] = T(dt);
+      B[4 + ld * 1] = T(dt);
+    } else {
+      A[4 + ld * 5] += T(dt);
+      B[3 + ld * 0] = T(dt);
+      B[5 + ld * 1] = T(dt);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Geometry
+// ---------------------------------------------------------------------------
+template <typename T>
+struct Seg {
+  T p1x, p1y, p2x, p2y, len, ux, uy;
+};
+
+// LineSegment2 ctor, include/ilqgames/geometry/line_segment2.h:55-62
+template <typename T>
+__device__ __forceinline__ Seg<T> make_seg(T ax, T ay, T bx, T by) {
+  Seg<T> s;
+  s.p1x = ax; s.p1y = ay; s.p2x = bx; s.p2y = by;
+  const T dx = ax - bx, dy = ay - by;
+  s.len = t_sqrt(dx * dx + dy * dy);
+  s.ux = (bx - ax) / s.len;
+  s.uy = (by - ay) / s.len;
+  return s;
+}
+
+// LineSegment2::Side, src/line_segment2.cpp:48-54
+template <typename T>
+__device__ __forceinline__ bool seg_side(const Seg<T>& s, T qx, T qy) {
+  const T rx = qx - s.p1x, ry = qy - s.p1y;
+  return (rx * s.uy - s.ux * ry) > T(0);
+}
+
+// LineSegment2::ClosestPoint, src/line_segment2.cpp:56-100
+template <typename T>
+__device__ __forceinline__ void seg_closest(const Seg<T>& s, T qx, T qy, T* cx, T* cy, bool* endp, T* ssd) {
+  const T rx = qx - s.p1x, ry = qy - s.p1y;
+  const T dot = rx * s.ux + ry * s.uy;
+  const T cross = rx * s.uy - s.ux * ry;
+  const T cs = sgn(cross);
+  if (dot < T(0)) {
+    *endp = true;
+    *ssd = cs * (rx * rx + ry * ry);
+    *cx = s.p1x;
+    *cy = s.p1y;
+  } else if (dot > s.len) {
+    *endp = true;
+    const T ex = qx - s.p2x, ey = qy - s.p2y;
+    *ssd = cs * (ex * ex + ey * ey);
+    *cx = s.p2x;
+    *cy = s.p2y;
+  } else {
+    *endp = false;
+    *ssd = cs * cross * cross;
+    *cx = s.p1x + dot * s.ux;
+    *cy = s.p1y + dot * s.uy;
+  }
+}
+
+template <typename T>
+struct Closest {
+  T cx, cy, ssd;
+  bool is_vertex, is_endpoint;
+  Seg<T> seg;
+};
+
+// Polyline2::ClosestPoint, src/polyline2.cpp:105-174 — linear scan over the
+// 1..15 segments of a lane; the "shortcut" sign rule at interior vertices and the
+// 1e-4 endpoint rule are reproduced.
+template <typename T>
+__device__ Closest<T> polyline_closest(const float* pts, int npts, T qx, T qy) {
+  Closest<T> out;
+  T best = dinf<T>();
+  out.cx = T(0);
+  out.cy = T(0);
+  out.is_vertex = false;
+  const int nseg = npts - 1;
+  int best_idx = 0;
+  for (int c = 0; c < nseg; c++) {
+    const Seg<T> s = make_seg<T>(T(pts[2 * c]), T(pts[2 * c + 1]), T(pts[2 * c + 2]), T(pts[2 * c + 3]));
+    T px, py, cur;
+    bool se;
+    seg_closest(s, qx, qy, &px, &py, &se, &cur);
+    if (t_abs(cur) < t_abs(best)) {
+      const bool at2 = (px == s.p2x && py == s.p2y);
+      const bool at1 = (px == s.p1x && py == s.p1y);
+      if (se && (c > 0 || at2) && (c < nseg - 1 || at1)) {
+        const Seg<T> sc = at1 ? make_seg<T>(T(pts[2 * c - 2]), T(pts[2 * c - 1]), s.p2x, s.p2y)
+                              : make_seg<T>(s.p1x, s.p1y, T(pts[2 * c + 4]), T(pts[2 * c + 5]));
+        cur *= seg_side(sc, qx, qy) ? sgn(cur) : -sgn(cur);
+      }
+      best = cur;
+      out.cx = px;
+      out.cy = py;
+      out.is_vertex = se;
+      best_idx = c;
+    }
+  }
+  out.seg = make_seg<T>(T(pts[2 * best_idx]), T(pts[2 * best_idx + 1]), T(pts[2 * best_idx + 2]),
+                        T(pts[2 * best_idx + 3]));
+  out.ssd = best;
+  const T ax = out.cx - T(pts[0]), ay = out.cy - T(pts[1]);
+  const T bx = out.cx - T(pts[2 * nseg]), by = out.cy - T(pts[2 * nseg + 1]);
+  out.is_endpoint = (ax * ax + ay * ay < T(1e-4f)) || (bx * bx + by * by < T(1e-4f));
+  return out;
+}
+
+// ---------------------------------------------------------------------------
+// Costs.  `v` is the argument vector (state x or one player's u) in LDS/global,
+// `dim` its length.  H is a column-major tile with leading dimension ld.
+// ---------------------------------------------------------------------------
+// Constraint::Mu(lambda, g), include/ilqgames/constraint/constraint.h:112-117
+template <typename T>
+__device__ __forceinline__ T constraint_mu(T lambda, T g, T mu) {
+  return (g <= T(1e-4f) && t_abs(lambda) <= T(1e-4f)) ? T(0) : mu;
+}
+
+template <typename T>
+__device__ T term_evaluate_leaf(const DevProblem& p, int ti, const T* v, int dim) {
+  const DevTerm c = p.terms[ti];
+  const T w = T(c.weight), val = T(c.value);
+  const bool oriented = c.flags & ILQG_FLAG_ORIENTED;
+  switch (c.kind) {
+    case ILQG_COST_QUADRATIC: {  // src/quadratic_cost.cpp:51-63
+      if (c.idx[0] >= 0) {
+        const T d = v[c.idx[0]] - val;
+        return T(0.5) * w * d * d;
+      }
+      T sq = 0;
+      for (int i = 0; i < dim; i++) sq += (v[i] - val) * (v[i] - val);
+      return T(0.5) * w * sq;
+    }
+    case ILQG_COST_SEMIQUADRATIC: {  // src/semiquadratic_cost.cpp:51-59
+      const T d = v[c.idx[0]] - val;
+      if ((d > T(0) && oriented) || (d < T(0) && !oriented)) return T(0.5) * w * d * d;
+      return T(0);
+    }
+    case ILQG_COST_QUADRATIC_POLYLINE2: {  // src/quadratic_polyline2_cost.cpp:52-69
+      const float* pts = p.poly_pts + 2 * p.poly_off[c.polyline];
+      const Closest<T> cl = polyline_closest<T>(pts, p.poly_off[c.polyline + 1] - p.poly_off[c.polyline],
+                                                v[c.idx[0]], v[c.idx[1]]);
+      const T ssd = cl.is_endpoint ? T(0) : cl.ssd;
+      return T(0.5) * w * t_abs(ssd);
+    }
+    case ILQG_COST_SEMIQUADRATIC_POLYLINE2: {  // src/semiquadratic_polyline2_cost.cpp:52-74
+      const float* pts = p.poly_pts + 2 * p.poly_off[c.polyline];
+      const Closest<T> cl = polyline_closest<T>(pts, p.poly_off[c.polyline + 1] - p.poly_off[c.polyline],
+                                                v[c.idx[0]], v[c.idx[1]]);
+      if (cl.is_endpoint) return T(0);
+      const T sst = sgn(val) * val * val;
+      const bool active = (cl.ssd > sst && oriented) || (cl.ssd < sst && !oriented);
+      if (!active) return T(0);
+      const T sd = sgn(cl.ssd) * t_sqrt(t_abs(cl.ssd));
+      const T d = sd - val;
+      return T(0.5) * w * d * d;
+    }
+    case ILQG_COST_PROXIMITY: {  // src/proximity_cost.cpp:52-61
+      const T dx = v[c.idx[0]] - v[c.idx[2]], dy = v[c.idx[1]] - v[c.idx[3]];
+      const T dsq = dx * dx + dy * dy;
+      if (dsq >= val * val) return T(0);
+      const T gap = val - t_sqrt(dsq);
+      return T(0.5) * w * gap * gap;
+    }
+    case ILQG_COST_SIGNED_DISTANCE: {  // src/signed_distance_cost.cpp:51-63
+      const T dx = v[c.idx[0]] - v[c.idx[2]], dy = v[c.idx[1]] - v[c.idx[3]];
+      const T cost = val - t_hypot(dx, dy);
+      return oriented ? cost : -cost;
+    }
+    case ILQG_CONSTRAINT_PROXIMITY: {  // src/proximity_constraint.cpp:56-62
+      const T dx = v[c.idx[0]] - v[c.idx[2]], dy = v[c.idx[1]] - v[c.idx[3]];
+      const T value = t_hypot(dx, dy) - val;
+      return oriented ? value : -value;
+    }
+    case ILQG_CONSTRAINT_SINGLE_DIMENSION:  // single_dimension_constraint.h:68-70
+      return oriented ? v[c.idx[0]] - val : val - v[c.idx[0]];
+  }
+  return T(0);
+}
+
+// ExtremeValueCost::ExtremeCost, src/extreme_value_cost.cpp:66-85: index of the active child.
+template <typename T>
+__device__ int extreme_child(const DevProblem& p, const DevTerm& c, const T* v, int dim, T* value_out) {
+  const bool is_min = c.flags & ILQG_FLAG_IS_MIN;
+  T ext = is_min ? dinf<T>() : -dinf<T>();
+  int best = c.child_begin;
+  for (int q = 0; q < c.child_count; q++) {
+    const T value = term_evaluate_leaf(p, c.child_begin + q, v, dim);
+    if ((is_min && value < ext) || (!is_min && value > ext)) {
+      ext = value;
+      best = c.child_begin + q;
+    }
+  }
+  *value_out = ext;
+  return best;
+}
+
+template <typename T>
+__device__ T term_evaluate(const DevProblem& p, int ti, const T* v, int dim) {
+  if (p.terms[ti].kind == ILQG_COST_EXTREME_VALUE) {  // src/extreme_value_cost.cpp:51-56
+    T value;
+    extreme_child(p, p.terms[ti], v, dim, &value);
+    return value;
+  }
+  return term_evaluate_leaf(p, ti, v, dim);
+}
+
+// Constraint::ModifyDerivatives, src/constraint.cpp:63-89
+template <typename T>
+__device__ __forceinline__ void modify_derivatives(T lambda, T mu_in, T g, T* dx, T* ddx, T* dy, T* ddy,
+                                                   T* dxdy) {
+  const T mu = constraint_mu(lambda, g, mu_in);
+  const T ndx = lambda * *dx + mu * g * *dx;
+  const T nddx = lambda * *ddx + mu * (*dx * *dx + g * *ddx);
+  if (dy) {
+    const T ndy = lambda * *dy + mu * g * *dy;
+    const T nddy = lambda * *ddy + mu * (*dy * *dy + g * *ddy);
+    const T ndxdy = lambda * *dxdy + mu * (*dy * *dx + g * *dxdy);
+    *dy = ndy;
+    *ddy = nddy;
+    *dxdy = ndxdy;
+  }
+  *dx = ndx;
+  *ddx = nddx;
+}
+
+// Cost::Quadraticize (accumulating) — one lane scatters <= 16 Hessian entries
+// into its player's LDS tile.  lambda/mu: per-instance augmented-Lagrangian
+// state (nullptr lambdas => 0), tidx = RelativeTimeTracker::TimeIndex of the step.
+template <typename T>
+__device__ void term_quadraticize_leaf(const DevProblem& p, int ti, const T* v, int dim, T* H, int ld, T* G,
+                                       const T* lambdas, T mu, int tidx) {
+  const DevTerm c = p.terms[ti];
+  const T w = T(c.weight), val = T(c.value);
+  const bool oriented = c.flags & ILQG_FLAG_ORIENTED;
+#define HH(a, b) H[(a) + ld * (b)]
+  switch (c.kind) {
+    case ILQG_COST_QUADRATIC: {  // src/quadratic_cost.cpp:65-94
+      if (c.idx[0] >= 0) {
+        const int d = c.idx[0];
+        G[d] += w * (v[d] - val);
+        HH(d, d) += w;
+      } else {
+        for (int i = 0; i < dim; i++) {
+          G[i] += w * (v[i] - val);
+          HH(i, i) = HH(i, i) + w;
+        }
+      }
+      return;
+    }
+    case ILQG_COST_SEMIQUADRATIC: {  // src/semiquadratic_cost.cpp:63-85
+      const int d = c.idx[0];
+      const T diff = v[d] - val;
+      if ((diff < T(0) && oriented) || (diff > T(0) && !oriented)) return;
+      G[d] += w * diff;
+      HH(d, d) += w;
+      return;
+    }
+    case ILQG_COST_QUADRATIC_POLYLINE2:        // src/quadratic_polyline2_cost.cpp:71-126
+    case ILQG_COST_SEMIQUADRATIC_POLYLINE2: {  // src/semiquadratic_polyline2_cost.cpp:76-142
+      const bool semi = c.kind == ILQG_COST_SEMIQUADRATIC_POLYLINE2;
+      const int xi = c.idx[0], yi = c.idx[1];
+      const T px = v[xi], py = v[yi];
+      const float* pts = p.poly_pts + 2 * p.poly_off[c.polyline];
+      const Closest<T> cl = polyline_closest<T>(pts, p.poly_off[c.polyline + 1] - p.poly_off[c.polyline], px, py);
+      T thr = T(0);
+      T dx, dy;
+      if (semi) {
+        const T sst = sgn(val) * val * val;
+        const bool active = (cl.ssd > sst && oriented) || (cl.ssd < sst && !oriented);
+        if (!active) return;
+        if (cl.is_endpoint) return;
+        T scaling = t_sqrt(t_abs(cl.ssd));
+        scaling = (scaling - t_abs(val)) / scaling;
+        dx = w * scaling * (px - cl.cx);
+        dy = w * scaling * (py - cl.cy);
+        thr = val;
+      } else {
+        if (cl.is_endpoint) return;
+        dx = w * (px - cl.cx);
+        dy = w * (py - cl.cy);
+      }
+      T ddx = w, ddy = w, dxdy = T(0);
+      if (!cl.is_vertex) {
+        const T relx = px - cl.seg.p1x, rely = py - cl.seg.p1y;
+        ddx = w * cl.seg.uy * cl.seg.uy;
+        ddy = w * cl.seg.ux * cl.seg.ux;
+        dxdy = -w * cl.seg.ux * cl.seg.uy;
+        const T w_cross = semi ? w * (relx * cl.seg.uy - rely * cl.seg.ux - thr)
+                               : w * (relx * cl.seg.uy - rely * cl.seg.ux);
+        dx = w_cross * cl.seg.uy;
+        dy = -w_cross * cl.seg.ux;
+      }
+      G[xi] += dx;
+      G[yi] += dy;
+      HH(xi, xi) += ddx;
+      HH(yi, yi) += ddy;
+      HH(xi, yi) += dxdy;
+      HH(yi, xi) += dxdy;
+      return;
+    }
+    case ILQG_COST_PROXIMITY: {  // src/proximity_cost.cpp:63-122
+      const int x1 = c.idx[0], y1 = c.idx[1], x2 = c.idx[2], y2 = c.idx[3];
+      const T dx = v[x1] - v[x2], dy = v[y1] - v[y2];
+      const T dsq = dx * dx + dy * dy;
+      if (dsq >= val * val) return;
+      const T delta = t_sqrt(dsq);
+      const T gap = val - delta;
+      const T wd = w / delta;
+      const T dxd = dx / delta, dyd = dy / delta;
+      const T g1 = -wd * gap * dx;
+      const T g2 = -wd * gap * dy;
+      const T hxx = wd * (dxd * (gap * dxd + dx) - gap);
+      const T hyy = wd * (dyd * (gap * dyd + dy) - gap);
+      const T hxy = wd * (dxd * (gap * dyd + dy));
+      G[x1] += g1; G[x2] -= g1; G[y1] += g2; G[y2] -= g2;
+      HH(x1, x1) += hxx; HH(x1, x2) -= hxx; HH(x2, x1) -= hxx; HH(x2, x2) += hxx;
+      HH(y1, y1) += hyy; HH(y1, y2) -= hyy; HH(y2, y1) -= hyy; HH(y2, y2) += hyy;
+      HH(x1, y1) += hxy; HH(y1, x1) += hxy;
+      HH(x1, y2) -= hxy; HH(y2, x1) -= hxy;
+      HH(x2, y1) -= hxy; HH(y1, x2) -= hxy;
+      HH(x2, y2) += hxy; HH(y2, x2) += hxy;
+      return;
+    }
+    case ILQG_COST_SIGNED_DISTANCE: {  // src/signed_distance_cost.cpp:65-113
+      const int x1 = c.idx[0], y1 = c.idx[1], x2 = c.idx[2], y2 = c.idx[3];
+      const T s = oriented ? T(1) : T(-1);
+      const T ex = v[x1] - v[x2], ey = v[y1] - v[y2];
+      const T norm = t_hypot(ex, ey);
+      const T n3 = norm * norm * norm;
+      const T dx1 = -s * ex / norm, dy1 = -s * ey / norm;
+      const T ddx1 = -s * ey * ey / n3, ddy1 = -s * ex * ex / n3;
+      const T dxy = s * ex * ey / n3;
+      G[x1] += dx1; G[y1] += dy1; G[x2] -= dx1; G[y2] -= dy1;
+      HH(x1, x1) += ddx1; HH(y1, y1) += ddy1; HH(x1, y1) += dxy; HH(y1, x1) += dxy;
+      HH(x2, x2) += ddx1; HH(y2, y2) += ddy1; HH(x2, y2) += dxy; HH(y2, x2) += dxy;
+      HH(x1, x2) -= ddx1; HH(x1, y2) -= dxy; HH(y1, x2) -= dxy; HH(y1, y2) -= ddy1;
+      HH(x2, x1) -= ddx1; HH(x2, y1) -= dxy; HH(y2, x1) -= dxy; HH(y2, y1) -= ddy1;
+      return;
+    }
+    case ILQG_CONSTRAINT_PROXIMITY: {  // src/proximity_constraint.cpp:64-116
+      const int x1 = c.idx[0], y1 = c.idx[1], x2 = c.idx[2], y2 = c.idx[3];
+      const T dx = v[x1] - v[x2], dy = v[y1] - v[y2];
+      const T prox = t_hypot(dx, dy);
+      const T sign = oriented ? T(1) : T(-1);
+      const T g = sign * (prox - val);
+      const T rdx = dx / prox, rdy = dy / prox;
+      T gx = sign * rdx, gy = sign * rdy;
+      T hxx = sign * (T(1) - rdx * rdx) / prox;
+      T hyy = sign * (T(1) - rdy * rdy) / prox;
+      T hxy = -sign * rdx * rdy / prox;
+      const T lambda = lambdas ? lambdas[c.slot * p.T + tidx] : T(0);
+      modify_derivatives(lambda, mu, g, &gx, &hxx, &gy, &hyy, &hxy);
+      G[x1] += gx; G[x2] -= gx; G[y1] += gy; G[y2] -= gy;
+      HH(x1, x1) += hxx; HH(x1, x2) -= hxx; HH(x2, x1) -= hxx; HH(x2, x2) += hxx;
+      HH(y1, y1) += hyy; HH(y1, y2) -= hyy; HH(y2, y1) -= hyy; HH(y2, y2) += hyy;
+      HH(x1, y1) += hxy; HH(x1, y2) -= hxy; HH(x2, y1) -= hxy; HH(x2, y2) += hxy;
+      HH(y1, x1) += hxy; HH(y1, x2) -= hxy; HH(y2, x1) -= hxy; HH(y2, x2) += hxy;
+      return;
+    }
+    case ILQG_CONSTRAINT_SINGLE_DIMENSION: {  // single_dimension_constraint.h:74-97
+      const int d = c.idx[0];
+      const T sign = oriented ? T(1) : T(-1);
+      const T g = sign * (v[d] - val);
+      T dx = sign, ddx = T(0);
+      const T lambda = lambdas ? lambdas[c.slot * p.T + tidx] : T(0);
+      modify_derivatives<T>(lambda, mu, g, &dx, &ddx, nullptr, nullptr, nullptr);
+      G[d] += dx;
+      HH(d, d) += ddx;
+      return;
+    }
+  }
+#undef HH
+}
+
+template <typename T>
+__device__ void term_quadraticize(const DevProblem& p, int ti, const T* v, int dim, T* H, int ld, T* G,
+                                  const T* lambdas, T mu, int tidx) {
+  if (p.terms[ti].kind == ILQG_COST_EXTREME_VALUE) {  // src/extreme_value_cost.cpp:58-64
+    T value;
+    ti = extreme_child(p, p.terms[ti], v, dim, &value);
+  }
+  term_quadraticize_leaf(p, ti, v, dim, H, ld, G, lambdas, mu, tidx);
+}
+
+}  // namespace ilqg

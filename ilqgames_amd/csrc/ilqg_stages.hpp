@@ -1,0 +1,289 @@
+// ilqg_stages.hpp — rollout, linearise+quadraticise and reduction stages for ONE game
+// instance per workgroup (gfx950).  Runtime dimensions (these stages are bound by the
+// bytes they write and by the sequential rollout chain, not by unrolled math).
+#pragma once
+
+#include "ilqg_common.hpp"
+#include "ilqg_models.hpp"
+
+namespace ilqg {
+
+// ---------------------------------------------------------------------------
+// Rollout — ILQSolver::CurrentOperatingPoint (src/ilq_solver.cpp:174-206).
+// Lane j < N integrates subsystem j in registers (RK4, 2 sub-steps); lanes rho < m
+// evaluate u_rho = u_ref - P[rho,:] dx - s*alpha (Strategy::operator(), strategy.h:73-76)
+// against dx broadcast through LDS.  The step's (P, alpha, u_ref, x_ref) block is
+// prefetched one step ahead so the only exposed latency is the dependent chain.
+// ---------------------------------------------------------------------------
+template <typename T>
+struct RolloutArgs {
+  const T* x0;      // [n]
+  const T* xs_ref;  // [T][n]
+  const T* us_ref;  // [T][m]
+  const T* P;       // [T][m*n]
+  const T* alpha;   // [T][m]
+  T alpha_scale;
+  T* xs;            // [T][n]
+  T* us;            // [T][m]
+};
+
+__host__ __device__ inline int rollout_lds_elems(int n, int m) { return 2 * n + 2 * m + m * n + m + n; }
+
+template <typename T>
+__device__ void rollout_instance(const DevProblem& p, const RolloutArgs<T>& a, T* sm) {
+  const int n = p.n, m = p.m, N = p.N, Tn = p.T;
+  const int t = threadIdx.x, NT = blockDim.x;
+  T* sx = sm;             // [n] current state
+  T* sdx = sx + n;        // [n]
+  T* su = sdx + n;        // [m]
+  T* sP = su + m;         // [m*n] staged gains of this step
+  T* sal = sP + m * n;    // [m]
+  T* sur = sal + m;       // [m] u_ref
+  T* sxr = sur + m;       // [n] x_ref
+  const int W = m * n + 2 * m + n;  // contiguous staged block [P | alpha | u_ref | x_ref]
+  constexpr int PRE = 4;            // W <= 4*NT for every supported config (checked on host)
+  T pre[PRE];
+  auto issue = [&](int k) {
+#pragma unroll
+    for (int q = 0; q < PRE; q++) {
+      const int e = t + q * NT;
+      if (e < m * n)
+        pre[q] = a.P[size_t(k) * m * n + e];
+      else if (e < m * n + m)
+        pre[q] = a.alpha[size_t(k) * m + (e - m * n)];
+      else if (e < m * n + 2 * m)
+        pre[q] = a.us_ref[size_t(k) * m + (e - m * n - m)];
+      else if (e < W)
+        pre[q] = a.xs_ref[size_t(k) * n + (e - m * n - 2 * m)];
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int q = 0; q < PRE; q++) {
+      const int e = t + q * NT;
+      if (e < W) sP[e] = pre[q];
+    }
+  };
+  T xj[6];
+  int kind = 0, xo = 0, uo = 0, xd = 0;
+  T Lp = T(1);
+  if (t < N) {
+    kind = p.sub_kind[t];
+    xo = p.xoff[t];
+    uo = p.uoff[t];
+    xd = p.xoff[t + 1] - xo;
+    Lp = T(p.sub_param[t]);
+#pragma unroll
+    for (int e = 0; e < 6; e++) xj[e] = (e < xd) ? a.x0[xo + e] : T(0);
+  }
+  issue(0);
+  commit();
+  __syncthreads();
+#pragma unroll 1
+  for (int k = 0; k < Tn; k++) {
+    if (k + 1 < Tn) issue(k + 1);
+    if (t < N) {
+#pragma unroll
+      for (int e = 0; e < 6; e++)
+        if (e < xd) {
+          sx[xo + e] = xj[e];
+          sdx[xo + e] = xj[e] - sxr[xo + e];
+          a.xs[size_t(k) * n + xo + e] = xj[e];
+        }
+    }
+    __syncthreads();
+    if (t < m) {
+      T s = T(0);
+      for (int c = 0; c < n; c++) s += sP[t + m * c] * sdx[c];
+      const T u = (sur[t] - s) - a.alpha_scale * sal[t];
+      su[t] = u;
+      a.us[size_t(k) * m + t] = u;
+    }
+    __syncthreads();
+    if (t < N && k + 1 < Tn) sub_integrate<T>(kind, Lp, p.dt, xj, su[uo], su[uo + 1]);
+    if (k + 1 < Tn) commit();
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Linearise + quadraticise one time step of one instance:
+//   ILQSolver::ComputeLinearization (src/ilq_solver.cpp:437-455),
+//   ILQSolver::ComputeCostQuadraticization (:471-490) -> PlayerCost::Quadraticize
+//   (src/player_cost.cpp:194-225), plus the per-step pieces of MeritFunction
+//   (:400-435) and TotalCosts (:220-257).
+// The step's [A | B | Q | l | R | r] image is assembled in LDS (lane i < N walks
+// player i's cost list in the reference's accumulation order and scatters <= 16
+// entries per term), then streamed out with fully coalesced stores — the stage's
+// cost is the ~n^2 N words it has to write.
+// ---------------------------------------------------------------------------
+template <typename T>
+struct QuadArgs {
+  const T* xs;         // [T][n]
+  const T* us;         // [T][m]
+  const T* lambdas;    // [num_constraints][T] or nullptr
+  T mu;
+  const int* t_extreme;  // [N] or nullptr
+  double t_init;
+  T *A, *Bm;           // [T][n*n], [T][n*m] or nullptr (skip linearisation)
+  T *Q, *l, *R, *r;    // or nullptr (skip quadraticisation outputs)
+  T* merit_part;       // [T][N][2] = (|r_ii|^2, |l_i|^2) or nullptr
+  T* cost_part;        // [T][N] PlayerCost::Evaluate or nullptr
+};
+
+__host__ __device__ inline int quad_lds_elems(int n, int m, int N, int Rsz, int rsz) {
+  return n + m + n * n + n * m + N * n * n + N * n + Rsz + rsz;
+}
+
+template <typename T>
+__device__ void linquad_step(const DevProblem& p, const QuadArgs<T>& a, int k, T* sm) {
+  const int n = p.n, m = p.m, N = p.N;
+  const int t = threadIdx.x, NT = blockDim.x;
+  const PairTable& pt = p.pairs;
+  T* sx = sm;
+  T* su = sx + n;
+  T* sA = su + m;
+  T* sB = sA + n * n;
+  T* sQ = sB + n * m;
+  T* sl = sQ + N * n * n;
+  T* sR = sl + N * n;
+  T* sr = sR + pt.Rsz;
+  const bool do_quad = a.Q != nullptr || a.merit_part != nullptr;
+  // ---- init tiles ----
+  for (int e = t; e < n; e += NT) sx[e] = a.xs[size_t(k) * n + e];
+  for (int e = t; e < m; e += NT) su[e] = a.us[size_t(k) * m + e];
+  if (a.A) {
+    for (int e = t; e < n * n; e += NT) sA[e] = (e / n == e % n) ? T(1) : T(0);
+    for (int e = t; e < n * m; e += NT) sB[e] = T(0);
+  }
+  if (do_quad) {
+    for (int e = t; e < N * n * n; e += NT) {
+      const int i = e / (n * n), rc = e % (n * n);
+      sQ[e] = (rc / n == rc % n) ? T(p.state_reg[i]) : T(0);
+    }
+    for (int e = t; e < N * n + pt.Rsz + pt.rsz; e += NT) sl[e] = T(0);
+  }
+  __syncthreads();
+  // ---- lane i: subsystem Jacobian + player i's cost list ----
+  if (t < N) {
+    const int i = t;
+    if (a.A) {
+      const int xo = p.xoff[i], uo = p.uoff[i];
+      sub_linearize<T>(p.sub_kind[i], T(p.sub_param[i]), p.dt, sx + xo, sA + xo + n * xo, sB + xo + n * uo, n);
+    }
+    const double tt = double(k) * p.dt;
+    const int tidx = int(static_cast<size_t>((tt - a.t_init) / p.dt));  // relative_time_tracker.h:69-72
+    const bool full = p.structure[i] == ILQG_SUM || (a.t_extreme && a.t_extreme[i] == k) ||
+                      (!a.t_extreme && k == 0);
+    if (do_quad) {
+      T* Qi = sQ + i * n * n;
+      T* li = sl + i * n;
+      // sigma_u I on every block the reference would have created (player_cost.cpp:70-74)
+      for (int q = 0; q < pt.npairs; q++) {
+        if (pt.pi[q] != i) continue;
+        if (!full && !pt.from_cost[q]) continue;  // block exists only through a constraint
+        const int mj = p.udim[pt.pj[q]];
+        for (int d = 0; d < mj; d++) sR[pt.roff[q] + d + mj * d] = T(p.control_reg[i]);
+      }
+      for (int pass = 0; pass < 4; pass++) {
+        if (!full && pass != ILQG_ROLE_CONTROL_COST) continue;  // QuadraticizeControlCosts, :217-225
+        for (int ti = 0; ti < p.num_terms; ti++) {
+          const DevTerm& c = p.terms[ti];
+          if (c.player != i || c.role != pass) continue;
+          if (pass == ILQG_ROLE_STATE_COST || pass == ILQG_ROLE_STATE_CONSTRAINT) {
+            term_quadraticize<T>(p, ti, sx, n, Qi, n, li, a.lambdas, a.mu, tidx);
+          } else {
+            const int j = c.arg;
+            int q = 0;
+            for (int qq = 0; qq < pt.npairs; qq++)
+              if (pt.pi[qq] == i && pt.pj[qq] == j) q = qq;
+            term_quadraticize<T>(p, ti, su + p.uoff[j], p.udim[j], sR + pt.roff[q], p.udim[j], sr + pt.rgoff[q],
+                                 a.lambdas, a.mu, tidx);
+          }
+        }
+      }
+      if (a.merit_part) {
+        const int q = pt.pii[i];
+        T s1 = T(0), s2 = T(0);
+        for (int d = 0; d < p.udim[i]; d++) s1 += sr[pt.rgoff[q] + d] * sr[pt.rgoff[q] + d];
+        for (int d = 0; d < n; d++) s2 += li[d] * li[d];
+        a.merit_part[(size_t(k) * N + i) * 2 + 0] = s1;
+        a.merit_part[(size_t(k) * N + i) * 2 + 1] = s2;
+      }
+    }
+    if (a.cost_part) {  // PlayerCost::Evaluate, src/player_cost.cpp:128-144
+      T total = T(0);
+      for (int pass = 0; pass < 2; pass++)
+        for (int ti = 0; ti < p.num_terms; ti++) {
+          const DevTerm& c = p.terms[ti];
+          if (c.player != i || c.role != pass) continue;
+          if (pass == 0)
+            total += term_evaluate<T>(p, ti, sx, n);
+          else
+            total += term_evaluate<T>(p, ti, su + p.uoff[c.arg], p.udim[c.arg]);
+        }
+      a.cost_part[size_t(k) * N + i] = total;
+    }
+  }
+  __syncthreads();
+  // ---- coalesced write-out ----
+  if (a.A) {
+    for (int e = t; e < n * n; e += NT) a.A[size_t(k) * n * n + e] = sA[e];
+    for (int e = t; e < n * m; e += NT) a.Bm[size_t(k) * n * m + e] = sB[e];
+  }
+  if (a.Q) {
+    for (int e = t; e < N * n * n; e += NT) a.Q[size_t(k) * N * n * n + e] = sQ[e];
+    for (int e = t; e < N * n; e += NT) a.l[size_t(k) * N * n + e] = sl[e];
+    for (int e = t; e < pt.Rsz; e += NT) a.R[size_t(k) * pt.Rsz + e] = sR[e];
+    for (int e = t; e < pt.rsz; e += NT) a.r[size_t(k) * pt.rsz + e] = sr[e];
+  }
+  __syncthreads();
+}
+
+// ILQSolver::MeritFunction's reduction (:408-434): 0.5 * sum_k sum_i (|r_ii|^2 + [k>0]|l_i|^2),
+// accumulated in the reference's order by one lane.  Returns the value on every thread.
+template <typename T>
+__device__ T merit_reduce(const DevProblem& p, const T* merit_part, T* sm) {
+  if (threadIdx.x == 0) {
+    T merit = T(0);
+    for (int k = 0; k < p.T; k++)
+      for (int i = 0; i < p.N; i++) {
+        merit += merit_part[(size_t(k) * p.N + i) * 2 + 0];
+        if (k > 0) merit += merit_part[(size_t(k) * p.N + i) * 2 + 1];
+      }
+    sm[0] = T(0.5) * merit;
+  }
+  __syncthreads();
+  const T v = sm[0];
+  __syncthreads();
+  return v;
+}
+
+// ILQSolver::TotalCosts reduction (:220-257): sum / max / min over time per player, and
+// the time of the extreme cost (first strict improvement wins, as the reference's `>` / `<`).
+template <typename T>
+__device__ void costs_reduce(const DevProblem& p, const T* cost_part, T* costs_out, int* t_extreme) {
+  const int i = threadIdx.x;
+  if (i < p.N) {
+    const int st = p.structure[i];
+    T c = st == ILQG_SUM ? T(0) : (st == ILQG_MAX ? -dinf<T>() : dinf<T>());
+    int te = t_extreme ? t_extreme[i] : 0;
+    for (int k = 0; k < p.T; k++) {
+      const T v = cost_part[size_t(k) * p.N + i];
+      if (st == ILQG_SUM)
+        c += v;
+      else if (st == ILQG_MAX && v > c) {
+        c = v;
+        te = k;
+      } else if (st == ILQG_MIN && v < c) {
+        c = v;
+        te = k;
+      }
+    }
+    costs_out[i] = c;
+    if (t_extreme) t_extreme[i] = te;
+  }
+  __syncthreads();
+}
+
+}  // namespace ilqg

@@ -1,0 +1,185 @@
+"""ctypes loader for libilqg_hip.so — the product path.
+
+There is NO CPU fallback: if the HIP library is missing or no gfx950 device is visible
+every entry point raises.  torch is used only to own HBM buffers and streams.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libilqg_hip.so")
+_LIB = None
+
+EXPORTS = [
+    "ilqg_lq_feedback_batch", "ilqg_lq_openloop_batch", "ilqg_default_solver_params", "ilqg_problem_create",
+    "ilqg_problem_destroy", "ilqg_workspace_bytes", "ilqg_rollout_batch", "ilqg_linearize_batch",
+    "ilqg_quadraticize_batch", "ilqg_problem_pairs", "ilqg_total_costs_batch", "ilqg_ilq_solve_batch",
+    "ilqg_last_error", "ilqg_abi_version", "ilqg_device_info",
+]
+
+
+class IlqgError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("ilqg status %d: %s" % (status, msg))
+        self.status = status
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libilqg_hip.so is not built (run __graft_entry__.build()); "
+                               "the HIP path has no CPU fallback")
+        _LIB = C.CDLL(LIB_PATH)
+        _LIB.ilqg_last_error.restype = C.c_char_p
+    return _LIB
+
+
+def _check(rc):
+    if rc != 0:
+        raise IlqgError(rc, lib().ilqg_last_error().decode())
+
+
+def torch_dtype(dtype):
+    import torch
+    return torch.float32 if dtype == abi.F32 else torch.float64
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _dev(a, dtype):
+    import torch
+    if a is None:
+        return None
+    if isinstance(a, torch.Tensor):
+        return a.to(device="cuda", dtype=torch_dtype(dtype)).contiguous()
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=torch_dtype(dtype), device="cuda").contiguous()
+
+
+def _stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def device_info():
+    name = C.create_string_buffer(256)
+    cus = C.c_int32(0)
+    _check(lib().ilqg_device_info(name, 256, C.byref(cus)))
+    return name.value.decode(), cus.value
+
+
+def lq_feedback(dims, A, Bm, Q, l, R, r, pairs, x0=None, want_dx=True):
+    """ilqg_lq_feedback_batch on device tensors (numpy inputs are uploaded). Returns torch tensors."""
+    import torch
+    dt = dims.dtype
+    B, T, n, N = dims.batch, dims.T, dims.n, dims.num_players
+    m = sum(dims.udim[i] for i in range(N))
+    A, Bm, Q, l, R, r, x0 = [_dev(v, dt) for v in (A, Bm, Q, l, R, r, x0)]
+    P = torch.empty((B, T, m * n), dtype=torch_dtype(dt), device="cuda")
+    alpha = torch.empty((B, T, m), dtype=torch_dtype(dt), device="cuda")
+    dx = torch.empty((B, T, n), dtype=torch_dtype(dt), device="cuda") if want_dx else None
+    _check(lib().ilqg_lq_feedback_batch(C.byref(dims), _ptr(A), _ptr(Bm), _ptr(Q), _ptr(l), _ptr(R), _ptr(r),
+                                        abi.make_pairs(pairs), len(pairs), _ptr(x0), _ptr(P), _ptr(alpha), _ptr(dx),
+                                        None, _stream()))
+    return P, alpha, dx
+
+
+class Problem:
+    """Owns an ilqg_problem* (device tables of one reference `Problem`)."""
+
+    def __init__(self, spec, dtype):
+        self.spec, self.dtype = spec, dtype
+        self.desc, self._keep = spec.build(dtype)
+        self.h = C.c_void_p()
+        _check(lib().ilqg_problem_create(C.byref(self.desc), C.byref(self.h)))
+        self.n, self.m, self.N, self.T = spec.n, spec.m, len(spec.subsystems), spec.T
+        arr = (abi.Pair * 64)()
+        npairs = C.c_int32(0)
+        _check(lib().ilqg_problem_pairs(self.h, arr, C.byref(npairs)))
+        self.pairs = [(arr[q].i, arr[q].j) for q in range(npairs.value)]
+        self.Rsz = sum(spec.udims[j] ** 2 for _, j in self.pairs)
+        self.rsz = sum(spec.udims[j] for _, j in self.pairs)
+        self._ws = None
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().ilqg_problem_destroy(self.h)
+        except Exception:
+            pass
+
+    def _empty(self, *shape):
+        import torch
+        return torch.empty(shape, dtype=torch_dtype(self.dtype), device="cuda")
+
+    def rollout(self, x0, xs_ref, us_ref, P, alpha, alpha_scale=None):
+        x0, xs_ref, us_ref, P, alpha, alpha_scale = [_dev(v, self.dtype) for v in
+                                                     (x0, xs_ref, us_ref, P, alpha, alpha_scale)]
+        B = x0.shape[0]
+        xs, us = self._empty(B, self.T, self.n), self._empty(B, self.T, self.m)
+        _check(lib().ilqg_rollout_batch(self.h, B, _ptr(x0), _ptr(xs_ref), _ptr(us_ref), _ptr(P), _ptr(alpha),
+                                        _ptr(alpha_scale), _ptr(xs), _ptr(us), None, _stream()))
+        return xs, us
+
+    def linearize(self, xs, us):
+        xs, us = _dev(xs, self.dtype), _dev(us, self.dtype)
+        B = xs.shape[0]
+        A, Bm = self._empty(B, self.T, self.n * self.n), self._empty(B, self.T, self.n * self.m)
+        _check(lib().ilqg_linearize_batch(self.h, B, _ptr(xs), _ptr(us), _ptr(A), _ptr(Bm), None, _stream()))
+        return A, Bm
+
+    def quadraticize(self, xs, us, lambdas=None, mu=None, t_extreme=None):
+        import torch
+        xs, us, lambdas, mu = [_dev(v, self.dtype) for v in (xs, us, lambdas, mu)]
+        te = None if t_extreme is None else torch.as_tensor(np.ascontiguousarray(t_extreme, dtype=np.int32),
+                                                            device="cuda")
+        B = xs.shape[0]
+        Q, l = self._empty(B, self.T, self.N, self.n * self.n), self._empty(B, self.T, self.N, self.n)
+        R, r = self._empty(B, self.T, self.Rsz), self._empty(B, self.T, self.rsz)
+        _check(lib().ilqg_quadraticize_batch(self.h, B, _ptr(xs), _ptr(us), _ptr(lambdas), _ptr(mu), _ptr(te),
+                                             _ptr(Q), _ptr(l), _ptr(R), _ptr(r), None, _stream()))
+        return Q, l, R, r
+
+    def total_costs(self, xs, us, t_extreme=None):
+        import torch
+        xs, us = _dev(xs, self.dtype), _dev(us, self.dtype)
+        B = xs.shape[0]
+        costs = self._empty(B, self.N)
+        te = torch.zeros((B, self.N), dtype=torch.int32, device="cuda") if t_extreme is None else \
+            torch.as_tensor(np.ascontiguousarray(t_extreme, dtype=np.int32), device="cuda")
+        _check(lib().ilqg_total_costs_batch(self.h, B, _ptr(xs), _ptr(us), _ptr(costs), _ptr(te), None, _stream()))
+        return costs, te
+
+    def workspace_bytes(self, batch):
+        b = C.c_uint64(0)
+        _check(lib().ilqg_workspace_bytes(self.h, batch, C.byref(b)))
+        return b.value
+
+    def alloc_solve_buffers(self, batch):
+        import torch
+        z = lambda *s: torch.zeros(s, dtype=torch_dtype(self.dtype), device="cuda")  # noqa: E731
+        return dict(xs=z(batch, self.T, self.n), us=z(batch, self.T, self.m), P=z(batch, self.T, self.m * self.n),
+                    alpha=z(batch, self.T, self.m), costs=z(batch, self.N),
+                    iters=torch.zeros(batch, dtype=torch.int32, device="cuda"),
+                    status=torch.zeros(batch, dtype=torch.int32, device="cuda"),
+                    converged=torch.zeros(batch, dtype=torch.int32, device="cuda"),
+                    ws=torch.empty(self.workspace_bytes(batch), dtype=torch.uint8, device="cuda"))
+
+    def solve(self, x0, bufs=None, fixed_iters=0):
+        """ilqg_ilq_solve_batch. `bufs` (from alloc_solve_buffers) carries the warm start in and the
+        solution out; zero warm start if omitted."""
+        x0 = _dev(x0, self.dtype)
+        B = x0.shape[0]
+        if bufs is None:
+            bufs = self.alloc_solve_buffers(B)
+        _check(lib().ilqg_ilq_solve_batch(self.h, B, _ptr(x0), _ptr(bufs["xs"]), _ptr(bufs["us"]), _ptr(bufs["P"]),
+                                          _ptr(bufs["alpha"]), _ptr(bufs["costs"]), _ptr(bufs["iters"]),
+                                          _ptr(bufs["status"]), _ptr(bufs["converged"]), _ptr(bufs["ws"]),
+                                          int(fixed_iters), _stream()))
+        return bufs

@@ -1,0 +1,160 @@
+"""GPU parity: HIP path (through the C ABI of libilqg_hip.so) vs the CPU oracle on the same
+seeded inputs, and vs the committed golden vectors.  Tolerances are stated per test:
+fp64 device vs fp64 oracle ~1e-9 relative (same algorithm, different summation order / FMA
+contraction); fp32 device vs fp32 oracle ~1e-3 relative on P (conditioning of S after the
+Gershgorin step x fp32 round-off)."""
+import numpy as np
+import pytest
+
+from ilqgames_amd import abi, examples
+from helpers import dims_of, load_golden_lq, random_lq_game, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    from ilqgames_amd import hip as h
+    name, cus = h.device_info()
+    assert "gfx950" in name, name
+    return h
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.mark.parametrize("name", ["lq_feedback_unicycle.npz", "lq_feedback_pointmass.npz"])
+def test_lq_feedback_matches_reference_python_golden(hip, name):
+    """Device sweep vs the reference's own numpy solver (fixtures of tests/golden/make_golden.py)."""
+    g = load_golden_lq(name)
+    d = dims_of(g, abi.F64, adaptive=False)
+    P, alpha, _ = hip.lq_feedback(d, g["A"], g["Bm"], g["Q"], g["l"], g["R"], g["r"], g["pairs"])
+    assert rel_err(_np(P), g["P_ref"]) < 1e-9
+    assert rel_err(_np(alpha), g["alpha_ref"]) < 1e-9
+    assert np.all(_np(P)[:, -1] == 0) and np.all(_np(alpha)[:, -1] == 0)
+
+
+@pytest.mark.parametrize("dims", [(14, 3, 2), (16, 3, 2), (15, 3, 2), (24, 4, 2), (6, 3, 2), (4, 2, 2), (2, 2, 1)])
+@pytest.mark.parametrize("dtype", [abi.F64, abi.F32])
+def test_lq_feedback_matches_oracle_random(hip, oracle, dims, dtype):
+    n, N, mu = dims
+    rng = np.random.default_rng(100 * n + N)
+    T, B = 25, 5
+    g = random_lq_game(rng, n, [mu] * N, T, B)
+    d = dims_of(g, dtype, adaptive=True)
+    x0 = rng.standard_normal((B, n))
+    Pr, ar, dxr, _ = oracle.lq_solve(d, g["A"], g["Bm"], g["Q"], g["l"], g["R"], g["r"], g["pairs"], x0=x0)
+    P, alpha, dx = hip.lq_feedback(d, g["A"], g["Bm"], g["Q"], g["l"], g["R"], g["r"], g["pairs"], x0=x0)
+    tol = 1e-9 if dtype == abi.F64 else 2e-3
+    assert rel_err(_np(P), Pr) < tol
+    assert rel_err(_np(alpha), ar) < tol
+    assert rel_err(_np(dx), dxr) < tol
+
+
+def test_lq_feedback_partial_pairs_and_no_regularization(hip, oracle):
+    """Only the (i,i) blocks plus one off-diagonal block; adaptive_regularization off."""
+    rng = np.random.default_rng(5)
+    pairs = [(0, 0), (1, 1), (2, 2), (0, 2)]
+    g = random_lq_game(rng, 14, [2, 2, 2], 30, 3, pairs=pairs)
+    d = dims_of(g, abi.F64, adaptive=False)
+    Pr, ar, _, _ = oracle.lq_solve(d, g["A"], g["Bm"], g["Q"], g["l"], g["R"], g["r"], pairs)
+    P, alpha, _ = hip.lq_feedback(d, g["A"], g["Bm"], g["Q"], g["l"], g["R"], g["r"], pairs, want_dx=False)
+    assert rel_err(_np(P), Pr) < 1e-9 and rel_err(_np(alpha), ar) < 1e-9
+
+
+def test_lq_feedback_errors(hip):
+    rng = np.random.default_rng(0)
+    g = random_lq_game(rng, 4, [2, 2], 5, 1, pairs=[(0, 0), (0, 1)])  # player 1 has no R_11
+    with pytest.raises(hip.IlqgError) as e:
+        hip.lq_feedback(dims_of(g, abi.F64), g["A"], g["Bm"], g["Q"], g["l"], g["R"], g["r"], g["pairs"])
+    assert e.value.status == abi.ERR_INVALID
+    g = random_lq_game(rng, 7, [2, 2], 5, 1)  # no kernel for n=7
+    with pytest.raises(hip.IlqgError) as e:
+        hip.lq_feedback(dims_of(g, abi.F64), g["A"], g["Bm"], g["Q"], g["l"], g["R"], g["r"], g["pairs"])
+    assert e.value.status == abi.ERR_UNSUPPORTED
+
+
+def _random_op(spec, rng, B):
+    """A plausible operating point: jittered x0 rolled out under small random strategies."""
+    T, n, m = spec.T, spec.n, spec.m
+    x0 = examples.jittered_x0(spec, B, seed=int(rng.integers(1 << 30)))
+    xs_ref = np.tile(x0[:, None, :], (1, T, 1)) + 0.05 * rng.standard_normal((B, T, n))
+    us_ref = 0.1 * rng.standard_normal((B, T, m))
+    P = 0.05 * rng.standard_normal((B, T, m * n))
+    alpha = 0.1 * rng.standard_normal((B, T, m))
+    return x0, xs_ref, us_ref, P, alpha
+
+
+@pytest.mark.parametrize("cfg", list(examples.CONFIGS))
+@pytest.mark.parametrize("dtype", [abi.F64, abi.F32])
+def test_stage_kernels_match_oracle(hip, oracle, cfg, dtype):
+    """rollout, linearize, quadraticize, total costs — each vs the oracle on the same inputs."""
+    spec = examples.CONFIGS[cfg]()
+    rng = np.random.default_rng(7)
+    B = 4
+    x0, xs_ref, us_ref, P, alpha = _random_op(spec, rng, B)
+    scale = np.array([1.0, 0.5, 0.25, 0.1])
+    op = oracle.OracleProblem(spec)
+    hp = hip.Problem(spec, dtype)
+    assert hp.pairs == op.pairs
+    xs_o, us_o = op.rollout(dtype, x0, xs_ref, us_ref, P, alpha, scale)
+    xs_d, us_d = hp.rollout(x0, xs_ref, us_ref, P, alpha, scale)
+    tol = 1e-10 if dtype == abi.F64 else 5e-4  # fp32: 100 chained RK4 steps of device-libm sin/cos/tan
+    assert rel_err(_np(xs_d), xs_o) < tol
+    assert rel_err(_np(us_d), us_o) < tol
+    # downstream stages are compared at the ORACLE's operating point so errors do not chain
+    A_o, B_o = op.linearize(dtype, xs_o, us_o)
+    A_d, B_d = hp.linearize(xs_o, us_o)
+    tol = 1e-12 if dtype == abi.F64 else 1e-5
+    assert rel_err(_np(A_d), A_o) < tol and rel_err(_np(B_d), B_o) < tol
+    nc = spec.num_constraints
+    lam = np.abs(rng.standard_normal((B, max(nc, 1), spec.T))) if nc else None
+    mu = np.array([10.0, 11.0, 12.1, 5.0]) if nc else None
+    te = rng.integers(0, spec.T, size=(B, len(spec.subsystems))).astype(np.int32)
+    Q_o, l_o, R_o, r_o = op.quadraticize(dtype, xs_o, us_o, lam, mu, te)
+    Q_d, l_d, R_d, r_d = hp.quadraticize(xs_o, us_o, lam, mu, te)
+    tol = 1e-9 if dtype == abi.F64 else 2e-3  # lane-boundary costs amplify ulp differences of hypot/sqrt
+    for a, b in ((Q_d, Q_o), (l_d, l_o), (R_d, R_o), (r_d, r_o)):
+        assert rel_err(_np(a), b) < tol
+    c_o, te_o = op.total_costs(dtype, xs_o, us_o)
+    c_d, te_d = hp.total_costs(xs_o, us_o)
+    assert rel_err(_np(c_d), c_o) < (1e-10 if dtype == abi.F64 else 1e-4)
+    assert np.array_equal(_np(te_d), te_o)
+
+
+@pytest.mark.parametrize("cfg", ["modified_three_player_intersection", "three_player_intersection",
+                                 "three_player_collision_avoidance_reachability"])
+def test_ilq_solve_matches_oracle_fp64(hip, oracle, cfg):
+    """Whole iLQ loop, fp64, fixed iteration count: identical accept/reject decisions are expected,
+    so trajectories, strategies and costs must agree to fp64 accumulation error."""
+    spec = examples.CONFIGS[cfg]()
+    spec.params.initial_alpha_scaling = 0.1 if cfg != "modified_three_player_intersection" else 0.5
+    spec.params.expected_decrease_fraction = 0.001
+    B, K = 6, 6
+    x0 = examples.jittered_x0(spec, B, seed=11)
+    ref = oracle.OracleProblem(spec).solve(abi.F64, x0, fixed_iters=K)
+    out = hip.Problem(spec, abi.F64).solve(x0, fixed_iters=K)
+    assert np.array_equal(_np(out["iters"]), ref["iters"])
+    assert np.array_equal(_np(out["status"]), ref["status"])
+    assert rel_err(_np(out["xs"]), ref["xs"]) < 1e-7
+    assert rel_err(_np(out["us"]), ref["us"]) < 1e-7
+    assert rel_err(_np(out["P"]), ref["P"]) < 1e-6      # north_star: P_t, alpha_t within 1e-6 rel-err (fp64)
+    assert rel_err(_np(out["alpha"]), ref["alpha"]) < 1e-6
+    assert rel_err(_np(out["costs"]), ref["costs"]) < 1e-8
+
+
+def test_ilq_solve_free_running_matches_oracle_fp64(hip, oracle):
+    """Reference semantics (convergence test + line-search failure) on the example's own params."""
+    spec = examples.modified_three_player_intersection()
+    B = 8
+    x0 = examples.jittered_x0(spec, B, seed=3)
+    ref = oracle.OracleProblem(spec).solve(abi.F64, x0)
+    out = hip.Problem(spec, abi.F64).solve(x0)
+    assert np.array_equal(_np(out["iters"]), ref["iters"])
+    assert np.array_equal(_np(out["status"]), ref["status"])
+    assert np.array_equal(_np(out["converged"]), ref["converged"])
+    assert rel_err(_np(out["xs"]), ref["xs"]) < 1e-7
+    assert rel_err(_np(out["costs"]), ref["costs"]) < 1e-8
