@@ -34,6 +34,11 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("libilqg_hip.so is not built (run __graft_entry__.build()); "
                                "the HIP path has no CPU fallback")
+        # torch ships its own libamdhip64; load (and initialise) it first so that both
+        # torch and libilqg_hip.so bind to the same HIP runtime instance.
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
         _LIB = C.CDLL(LIB_PATH)
         _LIB.ilqg_last_error.restype = C.c_char_p
     return _LIB

@@ -1,0 +1,41 @@
+"""Times each stage kernel and the fused solve (diagnostic)."""
+import sys, os, time
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R)
+import numpy as np, torch
+from ilqgames_amd import abi, examples, hip
+import argparse
+ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=1024); ap.add_argument("--dtype", default="f64")
+ap.add_argument("--config", default="modified_three_player_intersection")
+a = ap.parse_args()
+dtype = abi.F64 if a.dtype == "f64" else abi.F32
+spec = examples.CONFIGS[a.config]()
+spec.params.initial_alpha_scaling = 0.1; spec.params.expected_decrease_fraction = 0.001; spec.params.max_backtracking_steps = 100
+B = a.batch
+prob = hip.Problem(spec, dtype)
+x0 = examples.jittered_x0(spec, B, seed=0)
+td = hip.torch_dtype(dtype)
+x0d = torch.as_tensor(x0, dtype=td, device="cuda")
+def timeit(fn, reps=5):
+    fn(); torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+bufs = prob.alloc_solve_buffers(B)
+prob.solve(x0d, bufs, fixed_iters=3); torch.cuda.synchronize()
+xs, us, P, al = bufs["xs"].clone(), bufs["us"].clone(), bufs["P"].clone(), bufs["alpha"].clone()
+print("rollout    %.3f ms" % timeit(lambda: prob.rollout(x0d, xs, us, P, al)))
+print("linearize  %.3f ms" % timeit(lambda: prob.linearize(xs, us)))
+print("quadratize %.3f ms" % timeit(lambda: prob.quadraticize(xs, us)))
+print("totalcosts %.3f ms" % timeit(lambda: prob.total_costs(xs, us)))
+A, Bm = prob.linearize(xs, us); Q, l, Rr, r = prob.quadraticize(xs, us)
+d = abi.make_dims(prob.n, spec.udims, prob.T, B, dtype, True)
+print("lq_feedback (dx) %.3f ms" % timeit(lambda: hip.lq_feedback(d, A, Bm, Q, l, Rr, r, prob.pairs)))
+print("lq_feedback (no dx) %.3f ms" % timeit(lambda: hip.lq_feedback(d, A, Bm, Q, l, Rr, r, prob.pairs, want_dx=False)))
+for K in (1, 2, 4, 8):
+    def f():
+        for k in ("xs", "us", "P", "alpha"): bufs[k].zero_()
+        prob.solve(x0d, bufs, fixed_iters=K)
+    print("fused solve K=%d  %.3f ms" % (K, timeit(f, reps=2)))
