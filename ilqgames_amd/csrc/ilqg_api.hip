@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -37,7 +38,7 @@ template <typename T>
 struct LQBatchArgs {
   const T *A, *Bm, *Q, *l, *R, *r, *x0;
   T *P, *alpha, *dx, *scratch;
-  int T_steps, adaptive, batch;
+  int T_steps, adaptive, batch, force_valu;
 };
 
 template <typename T, int NX, int NP, int MU>
@@ -63,7 +64,7 @@ lq_feedback_kernel(LQBatchArgs<T> g, PairTable pt) {
   a.ed_out = nullptr;
   a.T_steps = g.T_steps;
   a.adaptive = g.adaptive;
-  lq_feedback_instance<T, NX, NP, MU>(a, pt, sm);
+  lq_feedback_dispatch<T, NX, NP, MU>(a, pt, sm, g.force_valu != 0);
 }
 
 template <typename T>
@@ -139,6 +140,11 @@ ilq_solve_kernel(DevProblem p, SolveArgs<T> sa) {
   if (threadIdx.x < n) xs0[threadIdx.x] = sa.x0[size_t(b) * n + threadIdx.x];  // xs[0] = x0 (:89-90)
   __syncthreads();
   ilq_solve_instance<T, NX, NP, MU>(p, sa, b, sm);
+}
+
+template <typename T>
+__global__ void mfma_selftest_kernel(const T* X, const T* Y, const T* C, T* out) {
+  mfma_selftest<T>(X, Y, C, out);
 }
 
 // ------------------------------------------------------------------------------------
@@ -217,6 +223,7 @@ ilqg_status launch_lq(const ilqg_dims* d, const PairTable& pt, const void* A, co
   g.T_steps = d->T;
   g.adaptive = d->adaptive_regularization;
   g.batch = d->batch;
+  g.force_valu = getenv("ILQG_FORCE_VALU") != nullptr;  // A/B switch for profiling the two formulations
   const size_t lds = size_t(C::LDS_ELEMS) * sizeof(T);
   auto kern = lq_feedback_kernel<T, NX, NP, MU>;
   if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -262,7 +269,7 @@ static ilqg_status launch_linquad(const ilqg_problem* p, int32_t batch, const vo
   [&]() -> ilqg_status {                                                                                        \
     QuadBatchArgs<TY_> g{(const TY_*)xs, (const TY_*)us, (const TY_*)lambdas, (const TY_*)mu, t_extreme, (TY_*)A, (TY_*)Bm,   \
                        (TY_*)Q, (TY_*)l, (TY_*)R, (TY_*)r, (TY_*)merit_part, (TY_*)cost_part, active};                      \
-    const size_t lds = quad_lds_elems(d.n, d.m, d.N, d.pairs.Rsz, d.pairs.rsz) * sizeof(TY_);                     \
+    const size_t lds = quad_lds_elems(d.n, d.m, d.N, d.pairs.Rsz, d.pairs.rsz, d.num_terms) * sizeof(TY_);                     \
     hipLaunchKernelGGL(linquad_kernel<TY_>, dim3(d.T, batch), dim3(64), lds, (hipStream_t)stream, d, g);          \
     HIP_TRY(hipGetLastError());                                                                                 \
     return ILQG_OK;                                                                                             \
@@ -284,7 +291,7 @@ static ilqg_status launch_solve(ilqg_problem* p, int32_t batch, const void* x0, 
   sa.ws = (T*)workspace; sa.ws_stride = L.total; sa.fixed_iters = fixed_iters; sa.batch = batch;
   sa.prm = p->desc.params;
   size_t elems = C::LDS_ELEMS;
-  const size_t e2 = rollout_lds_elems(d.n, d.m), e3 = quad_lds_elems(d.n, d.m, d.N, d.pairs.Rsz, d.pairs.rsz);
+  const size_t e2 = rollout_lds_elems(d.n, d.m), e3 = quad_lds_elems(d.n, d.m, d.N, d.pairs.Rsz, d.pairs.rsz, d.num_terms);
   if (e2 > elems) elems = e2;
   if (e3 > elems) elems = e3;
   const size_t lds = elems * sizeof(T);
@@ -298,6 +305,21 @@ static ilqg_status launch_solve(ilqg_problem* p, int32_t batch, const void* x0, 
 extern "C" {
 
 const char* ilqg_last_error(void) { return g_err.c_str(); }
+
+// out = X^T Y + C for 16x16 column-major device matrices, through the MFMA accumulator-layout
+// path the LQ sweep uses (tests pin the register layouts with asymmetric inputs).
+ilqg_status ilqg_selftest_mfma(int32_t dtype, const void* X, const void* Y, const void* C, void* out, void* stream) {
+  ilqg_status s = check_device();
+  if (s != ILQG_OK) return s;
+  if (dtype == ILQG_F32)
+    hipLaunchKernelGGL(mfma_selftest_kernel<float>, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)X,
+                       (const float*)Y, (const float*)C, (float*)out);
+  else
+    hipLaunchKernelGGL(mfma_selftest_kernel<double>, dim3(1), dim3(64), 0, (hipStream_t)stream, (const double*)X,
+                       (const double*)Y, (const double*)C, (double*)out);
+  HIP_TRY(hipGetLastError());
+  return ILQG_OK;
+}
 int32_t ilqg_abi_version(void) { return 1; }
 
 ilqg_status ilqg_device_info(char* name_out, int32_t name_len, int32_t* num_cus) {
@@ -435,6 +457,81 @@ ilqg_status ilqg_problem_create(const ilqg_problem_desc* desc, ilqg_problem** ou
     if (t.constraint_slot >= 0 && t.constraint_slot + 1 > nc) nc = t.constraint_slot + 1;
   }
   d.num_constraints = nc;
+  // ---- metadata of the term-parallel quadraticisation: tiles, argument slices, scatter rounds ----
+  {
+    const int nn = d.n;
+    auto pair_of = [&](int i, int j) {
+      for (int q = 0; q < d.pairs.npairs; q++)
+        if (d.pairs.pi[q] == i && d.pairs.pj[q] == j) return q;
+      return -1;
+    };
+    for (int ti = 0; ti < desc->num_terms; ti++) {
+      DevTerm& o = dt[ti];
+      const bool on_state = o.role == ILQG_ROLE_STATE_COST || o.role == ILQG_ROLE_STATE_CONSTRAINT ||
+                            o.role == ILQG_ROLE_CHILD;
+      if (on_state) {
+        o.tile_h = o.player * nn * nn;
+        o.tile_g = d.N * nn * nn + o.player * nn;
+        o.ld = nn;
+        o.arg_off = 0;
+        o.arg_dim = nn;
+      } else {
+        const int q = pair_of(o.player, o.arg);
+        const int mj = d.udim[o.arg];
+        o.tile_h = d.N * nn * nn + d.N * nn + d.pairs.roff[q];
+        o.tile_g = d.N * nn * nn + d.N * nn + d.pairs.Rsz + d.pairs.rgoff[q];
+        o.ld = mj;
+        o.arg_off = nn + d.uoff[o.arg];
+        o.arg_dim = mj;
+      }
+      o.round = 0;
+    }
+    // indices a term may touch inside its tile (children count for their parent)
+    auto touched = [&](int ti, std::vector<int>* idx) {
+      idx->clear();
+      auto add_leaf = [&](const DevTerm& c) {
+        switch (c.kind) {
+          case ILQG_COST_QUADRATIC:
+            if (c.idx[0] < 0) for (int e = 0; e < dt[ti].arg_dim; e++) idx->push_back(e);
+            else idx->push_back(c.idx[0]);
+            break;
+          case ILQG_COST_SEMIQUADRATIC:
+          case ILQG_CONSTRAINT_SINGLE_DIMENSION: idx->push_back(c.idx[0]); break;
+          case ILQG_COST_QUADRATIC_POLYLINE2:
+          case ILQG_COST_SEMIQUADRATIC_POLYLINE2: idx->push_back(c.idx[0]); idx->push_back(c.idx[1]); break;
+          default: for (int e = 0; e < 4; e++) idx->push_back(c.idx[e]); break;
+        }
+      };
+      if (dt[ti].kind == ILQG_COST_EXTREME_VALUE)
+        for (int q = 0; q < dt[ti].child_count; q++) add_leaf(dt[dt[ti].child_begin + q]);
+      else
+        add_leaf(dt[ti]);
+    };
+    // accumulation order of PlayerCost::Quadraticize: per player, roles 0..3, table order within a role
+    std::vector<int> order;
+    for (int i = 0; i < d.N; i++)
+      for (int role = 0; role < 4; role++)
+        for (int ti = 0; ti < desc->num_terms; ti++)
+          if (dt[ti].player == i && dt[ti].role == role) order.push_back(ti);
+    int max_round = 0;
+    std::vector<int> ia, ib;
+    for (size_t a2 = 0; a2 < order.size(); a2++) {
+      const int ta = order[a2];
+      touched(ta, &ia);
+      int rnd = 0;
+      for (size_t b2 = 0; b2 < a2; b2++) {
+        const int tb = order[b2];
+        if (dt[tb].tile_h != dt[ta].tile_h) continue;
+        touched(tb, &ib);
+        bool hit = false;
+        for (int x : ia) for (int y : ib) hit = hit || (x == y);
+        if (hit && dt[tb].round + 1 > rnd) rnd = dt[tb].round + 1;
+      }
+      dt[ta].round = rnd;
+      if (rnd > max_round) max_round = rnd;
+    }
+    d.num_rounds = max_round + 1;
+  }
   p->terms_host.assign(desc->terms, desc->terms + desc->num_terms);
   const int npts = desc->num_polylines ? desc->polyline_offsets[desc->num_polylines] : 0;
   hipError_t e = hipMalloc(&p->d_terms, sizeof(DevTerm) * dt.size());

@@ -37,6 +37,15 @@ struct DevTerm {
   int idx[4];
   float weight, value;
   int flags, polyline, child_begin, child_count, slot;
+  // filled by ilqg_problem_create for the term-parallel quadraticisation stage:
+  int round;     // scatter round: terms of one round touch disjoint tile entries, and a term's
+                 // round is later than that of every earlier term sharing an entry, so each
+                 // Hessian/gradient entry is accumulated in the reference's order
+  int tile_h;    // offset of the Hessian tile inside the [Q|l|R|r] image
+  int tile_g;    // offset of the gradient vector inside the same image
+  int ld;        // leading dimension of the Hessian tile
+  int arg_off;   // offset of the argument vector inside the [x|u] image
+  int arg_dim;   // its length
 };
 
 // Flattened Problem (dynamics + PlayerCosts) living in kernel-argument space;
@@ -54,12 +63,18 @@ struct DevProblem {
   const int* poly_off;
   const float* poly_pts;
   int num_constraints;
+  int num_rounds;
   PairTable pairs;
 };
 
 template <typename T>
 __device__ __forceinline__ T sgn(T x) {
   return T((T(0) < x) - (x < T(0)));
+}
+
+template <typename T>
+__device__ __forceinline__ T shfl(T v, int lane) {
+  return __shfl(v, lane, 64);
 }
 
 template <typename T>

@@ -24,6 +24,7 @@
 #pragma once
 
 #include "ilqg_common.hpp"
+#include "ilqg_mfma.hpp"
 
 namespace ilqg {
 
@@ -66,15 +67,15 @@ struct LQCfg {
   static constexpr int oZeta = oBeta + NX;
   static constexpr int oYz = oZeta + NP * NX;
   static constexpr int oX = oYz + M;
-  static constexpr int LDS_ELEMS = oX + NX;
+  // MFMA variant (NX <= 16): transpose scratch (16 x 17) and a 16-vector
+  static constexpr bool USE_MFMA = NX <= 16 && NP * NX <= 64;
+  static constexpr int oTr = oX + NX;
+  static constexpr int oTv = oTr + 16 * 17;
+  static constexpr int LDS_ELEMS = oTv + 16;
   static_assert(RMAX <= NT, "R blocks are loaded one element per lane");
   static_assert(NSOLVE <= 64, "the stacked Nash system must fit one wavefront");
 };
 
-template <typename T>
-__device__ __forceinline__ T shfl(T v, int lane) {
-  return __shfl(v, lane, 64);
-}
 __device__ __forceinline__ float lq_sqrt(float x) { return sqrtf(x); }
 __device__ __forceinline__ double lq_sqrt(double x) { return sqrt(x); }
 
@@ -461,6 +462,371 @@ __device__ void lq_feedback_instance(const LQArgs<T>& a, const PairTable& pt, T*
     __syncthreads();
   }
   if (a.ed_out && t == 0) *a.ed_out = ed;
+}
+
+// ---------------------------------------------------------------------------
+// MFMA formulation of the same sweep for n <= 16 (one wavefront per instance).
+// Differences from lq_feedback_instance: Z_i^T lives in the MFMA accumulator layout (4 scalars per
+// lane per player) and F^T Z_i F is two chains of four v_mfma_*_16x16x4 per player (ilqg_mfma.hpp);
+// B_i^T Z_i, Z_i beta and F^T t are "4 FMAs + a cross-group butterfly" in that layout.
+// The Nash-system assembly, Gershgorin step, QR solve and forward pass are shared code paths.
+// ---------------------------------------------------------------------------
+template <typename T, int NX, int NP, int MU>
+__device__ void lq_feedback_instance_mfma(const LQArgs<T>& a, const PairTable& pt, T* sm) {
+  using C = LQCfg<T, NX, NP, MU>;
+  using TL = Tile<T>;
+  using vec = typename TL::vec;
+  constexpr int M = C::M, L = C::L, NT = C::NT;
+  static_assert(NT == 64, "MFMA sweep: one wavefront per instance");
+  const int t = threadIdx.x;
+  const int lane = t & 63, g = lane >> 4, j = lane & 15;
+  const bool zl = t < L;
+  const int pi = zl ? t / NX : 0;
+  const int pc = zl ? t % NX : 0;
+  const int Tn = a.T_steps;
+  const int Rsz = pt.Rsz, rsz = pt.rsz;
+  const bool want_fwd = a.dx != nullptr || a.ed_out != nullptr;
+  const int SCR = NP * (NX + 1) + NX;
+  int rowi[4];
+  bool rowok[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    rowi[r] = TL::row(g, r);
+    rowok[r] = rowi[r] < NX;
+  }
+  const bool jok = j < NX;
+
+  T* sB = sm + C::oB;
+  T* sA = sm + C::oA;
+  T* sQ = sm + C::oQ;
+  T* sl = sm + C::ol;
+  T* sR = sm + C::oR;
+  T* sr = sm + C::or_;
+  T* sBZ = sm + C::oBZ;
+  T* sP = sm + C::oP;
+  T* sAl = sm + C::oAl;
+  T* sBeta = sm + C::oBeta;
+  T* sZeta = sm + C::oZeta;
+  T* sYz = sm + C::oYz;
+  T* sX = sm + C::oX;
+  T* sTr = sm + C::oTr;
+  T* sTv = sm + C::oTv;
+
+  T pre[C::PRE];
+  T preR = T(0), prer = T(0);
+  auto issue = [&](int k) {
+    const T* gB = a.Bm + size_t(k) * NX * M;
+    const T* gA = a.A + size_t(k) * NX * NX;
+    const T* gQ = a.Q + size_t(k) * NP * NX * NX;
+    const T* gl = a.l + size_t(k) * NP * NX;
+#pragma unroll
+    for (int q = 0; q < C::PRE; q++) {
+      const int e = t + q * NT;
+      if (e < C::oA)
+        pre[q] = gB[e];
+      else if (e < C::oQ)
+        pre[q] = gA[e - C::oA];
+      else if (e < C::ol)
+        pre[q] = gQ[e - C::oQ];
+      else if (e < C::oR)
+        pre[q] = gl[e - C::ol];
+    }
+    if (t < Rsz) preR = a.R[size_t(k) * Rsz + t];
+    if (t < rsz) prer = a.r[size_t(k) * rsz + t];
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int q = 0; q < C::PRE; q++) {
+      const int e = t + q * NT;
+      if (e < C::oR) sm[e] = pre[q];
+    }
+    if (t < Rsz) sR[t] = preR;
+    if (t < rsz) sr[t] = prer;
+  };
+  auto stash_ql = [&](int k) {
+    if (want_fwd && zl) {
+      T s = T(0);
+#pragma unroll
+      for (int c = 0; c < NX; c++) s += sQ[pi * NX * NX + pc + NX * c] * sl[pi * NX + c];
+      a.scratch[size_t(k) * SCR + pi * NX + pc] = s;
+    }
+  };
+  auto xgroup_sum = [&](T v) {  // sum over the 4 lane groups holding the same column j
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+  };
+
+  // ---- terminal step: Yd_i = D-layout(Q_i[T-1]^T), zeta_i = l_i[T-1] ----
+  issue(Tn - 1);
+  commit();
+  __syncthreads();
+  vec Yd[NP];
+#pragma unroll
+  for (int i = 0; i < NP; i++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) Yd[i][r] = (rowok[r] && jok) ? sQ[i * NX * NX + j + NX * rowi[r]] : T(0);
+  T zeta = zl ? sl[pi * NX + pc] : T(0);
+  stash_ql(Tn - 1);
+  for (int e = t; e < M * NX; e += NT) a.P[size_t(Tn - 1) * M * NX + e] = T(0);
+  if (t < M) a.alpha[size_t(Tn - 1) * M + t] = T(0);
+  if (want_fwd) {
+    if (t < NP) a.scratch[size_t(Tn - 1) * SCR + NP * NX + t] = T(0);
+    if (t < NX) a.scratch[size_t(Tn - 1) * SCR + NP * (NX + 1) + t] = T(0);
+  }
+  if (Tn >= 2) issue(Tn - 2);
+  __syncthreads();
+  if (zl) sZeta[t] = zeta;
+  if (Tn >= 2) commit();
+  __syncthreads();
+
+#pragma unroll 1
+  for (int k = Tn - 2; k >= 0; k--) {
+    if (k > 0) issue(k - 1);
+    stash_ql(k);
+
+    // ---- P1: BZ_i = B_i^T Z_i.  Z_i in D layout comes from transposing Yd_i through LDS ----
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) sTr[rowi[r] * 17 + j] = Yd[i][r];
+      __syncthreads();
+      T zd[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) zd[r] = sTr[j * 17 + rowi[r]];  // Z_i[row][j]
+#pragma unroll
+      for (int aa = 0; aa < MU; aa++) {
+        T s = T(0);
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          if (rowok[r]) s += sB[rowi[r] + NX * (i * MU + aa)] * zd[r];
+        s = xgroup_sum(s);
+        if (g == 0 && jok) sBZ[(i * MU + aa) + M * j] = s;
+      }
+      __syncthreads();
+    }
+    if (t < M) {
+      const int i = t / MU, aa = t % MU;
+      T s = T(0);
+#pragma unroll
+      for (int r = 0; r < NX; r++) s += sB[r + NX * t] * sZeta[i * NX + r];
+      sYz[t] = s + sr[pt.rgoff[pt.pii[i]] + aa];
+    }
+    __syncthreads();
+
+    // ---- P2: column `t` of [S | Y], Gershgorin, QR solve ----
+    {
+      T col[M], x[M];
+#pragma unroll
+      for (int r = 0; r < M; r++) { col[r] = T(0); x[r] = T(0); }
+      if (t < M + NX) {
+        T mc[NX];
+#pragma unroll
+        for (int c = 0; c < NX; c++) mc[c] = sm[C::oB + c + NX * t];
+#pragma unroll
+        for (int r = 0; r < M; r++) {
+          T s = T(0);
+#pragma unroll
+          for (int c = 0; c < NX; c++) s += sBZ[r + M * c] * mc[c];
+          col[r] = s;
+        }
+        if (t < M) {
+          const int pj = t / MU, b = t % MU;
+          const T* Rii = sR + pt.roff[pt.pii[pj]];
+#pragma unroll
+          for (int r = 0; r < M; r++)
+            if (r / MU == pj) col[r] = col[r] + Rii[(r % MU) + MU * b];
+          if (a.adaptive) {
+            T l1 = T(0), diag = T(0);
+#pragma unroll
+            for (int r = 0; r < M; r++) {
+              l1 += (col[r] < T(0) ? -col[r] : col[r]);
+              if (r == t) diag = col[r];
+            }
+            const T radius = l1 - (diag < T(0) ? -diag : diag);
+            const T eval_lo = diag - radius;
+            if (eval_lo < T(1e-3f)) {
+#pragma unroll
+              for (int r = 0; r < M; r++)
+                if (r == t) col[r] += radius + T(1e-3f);
+            }
+          }
+        }
+      } else if (t == M + NX) {
+#pragma unroll
+        for (int r = 0; r < M; r++) col[r] = sYz[r];
+      }
+      qr_solve_columns<T, M>(col, lane, x);
+      if (t >= M && t < M + NX) {
+#pragma unroll
+        for (int r = 0; r < M; r++) {
+          sP[r + M * (t - M)] = x[r];
+          a.P[size_t(k) * M * NX + r + M * (t - M)] = x[r];
+        }
+      } else if (t == M + NX) {
+#pragma unroll
+        for (int r = 0; r < M; r++) {
+          sAl[r] = x[r];
+          a.alpha[size_t(k) * M + r] = x[r];
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- P3: Fd = D-layout(A - B P); beta = -B alpha ----
+    vec Fd;
+    {
+      T pcol[M];
+#pragma unroll
+      for (int q = 0; q < M; q++) pcol[q] = jok ? sP[q + M * j] : T(0);
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        T s = T(0);
+        if (rowok[r] && jok) {
+          s = sA[rowi[r] + NX * j];
+#pragma unroll
+          for (int q = 0; q < M; q++) s -= sB[rowi[r] + NX * q] * pcol[q];
+        }
+        Fd[r] = s;
+      }
+    }
+    if (t < NX) {
+      T s = T(0);
+#pragma unroll
+      for (int q = 0; q < M; q++) s -= sB[t + NX * q] * sAl[q];
+      sBeta[t] = s;
+      if (want_fwd) a.scratch[size_t(k) * SCR + NP * (NX + 1) + t] = s;
+    }
+    if (want_fwd && t < NP) {
+      const int q = pt.pii[t];
+      T acc = T(0);
+#pragma unroll
+      for (int c = 0; c < MU; c++) {
+        T aR = T(0);
+#pragma unroll
+        for (int b = 0; b < MU; b++) aR += sAl[t * MU + b] * sR[pt.roff[q] + b + MU * c];
+        acc += aR * sr[pt.rgoff[q] + c];
+      }
+      a.scratch[size_t(k) * SCR + NP * NX + t] = acc;
+    }
+    __syncthreads();
+
+    // ---- P4/P5 per player: zeta update (uses the old Z_i), then Yd_i <- (Z_i F)^T F + C_i ----
+    T zeta_new[NP];
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+      // t = zeta_i + Z_i beta ;  (Z beta)[j] = sum_rho Z[j][rho] beta[rho] = sum_r Yd[r] beta[row(r)]
+      T zb = T(0);
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+        if (rowok[r]) zb += Yd[i][r] * sBeta[rowi[r]];
+      zb = xgroup_sum(zb);
+      if (g == 0) sTv[j] = jok ? sZeta[i * NX + j] + zb : T(0);
+      __syncthreads();
+      // (F^T t)[j] = sum_rho F[rho][j] t[rho]
+      T ft = T(0);
+#pragma unroll
+      for (int r = 0; r < 4; r++) ft += Fd[r] * sTv[rowi[r]];
+      ft = xgroup_sum(ft);
+      T zn = jok ? ft + sl[i * NX + j] : T(0);
+      // accumulator init C_i = D-layout(Q_i^T + sum_jj (P_jj^T R_i,jj P_jj)^T)
+      vec Cd;
+#pragma unroll
+      for (int r = 0; r < 4; r++) Cd[r] = (rowok[r] && jok) ? sQ[i * NX * NX + j + NX * rowi[r]] : T(0);
+      for (int q = 0; q < pt.npairs; q++) {
+        if (pt.pi[q] != i) continue;
+        const int jj = pt.pj[q];
+        const T* Rij = sR + pt.roff[q];
+        const T* rij = sr + pt.rgoff[q];
+        if (jok) {
+          // zeta term: P_jj[:,j]^T (R alpha_jj - r)
+          T add = T(0);
+#pragma unroll
+          for (int aa = 0; aa < MU; aa++) {
+            T w = T(0);
+#pragma unroll
+            for (int b = 0; b < MU; b++) w += Rij[aa + MU * b] * sAl[jj * MU + b];
+            add += sP[(jj * MU + aa) + M * j] * (w - rij[aa]);
+          }
+          zn += add;
+          // G[j][row] = sum_{a,b} P[a][j] R[a][b] P[b][row]   (entry (row, j) of the transposed tile)
+#pragma unroll
+          for (int r = 0; r < 4; r++)
+            if (rowok[r]) {
+              T sacc = T(0);
+#pragma unroll
+              for (int aa = 0; aa < MU; aa++) {
+                T v = T(0);
+#pragma unroll
+                for (int b = 0; b < MU; b++) v += Rij[aa + MU * b] * sP[(jj * MU + b) + M * rowi[r]];
+                sacc += sP[(jj * MU + aa) + M * j] * v;
+              }
+              Cd[r] += sacc;
+            }
+        }
+      }
+      zeta_new[i] = zn;
+      vec Wd = {T(0), T(0), T(0), T(0)};
+      Wd = tile_xty<T>(Yd[i], Fd, Wd);   // Z_i F
+      Yd[i] = tile_xty<T>(Wd, Fd, Cd);   // (Z_i F)^T F + C_i
+      __syncthreads();
+    }
+    if (g == 0 && jok) {
+#pragma unroll
+      for (int i = 0; i < NP; i++) sZeta[i * NX + j] = zeta_new[i];
+    }
+    if (k > 0) commit();
+    __syncthreads();
+  }
+
+  // ---- forward pass (identical to the VALU variant) ----
+  if (!want_fwd) return;
+  if (t < NX) sX[t] = a.x0 ? a.x0[t] : T(0);
+  T ed = T(0);
+  __syncthreads();
+#pragma unroll 1
+  for (int k = 0; k < Tn; k++) {
+    for (int e = t; e < NX * NX; e += NT) sA[e] = a.A[size_t(k) * NX * NX + e];
+    if (a.dx && t < NX) a.dx[size_t(k) * NX + t] = sX[t];
+    if (a.ed_out) {
+      T st = T(0), ct = T(0);
+      if (t < NP) {
+        ct = a.scratch[size_t(k) * SCR + NP * NX + t];
+        if (k > 0) {
+#pragma unroll
+          for (int c = 0; c < NX; c++) st += sX[c] * a.scratch[size_t(k) * SCR + t * NX + c];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NP; i++) {
+        ed -= shfl(ct, i);
+        if (k > 0) ed -= shfl(st, i);
+      }
+    }
+    __syncthreads();
+    T xn = T(0);
+    if (t < NX) {
+#pragma unroll
+      for (int c = 0; c < NX; c++) xn += sA[t + NX * c] * sX[c];
+      xn += a.scratch[size_t(k) * SCR + NP * (NX + 1) + t];
+    }
+    __syncthreads();
+    if (t < NX) sX[t] = xn;
+    __syncthreads();
+  }
+  if (a.ed_out && t == 0) *a.ed_out = ed;
+}
+
+// Dispatch: MFMA formulation where the state fits one 16x16 tile, VALU/LDS formulation otherwise.
+template <typename T, int NX, int NP, int MU>
+__device__ __forceinline__ void lq_feedback_dispatch(const LQArgs<T>& a, const PairTable& pt, T* sm, bool force_valu) {
+  if constexpr (LQCfg<T, NX, NP, MU>::USE_MFMA) {
+    if (!force_valu) {
+      lq_feedback_instance_mfma<T, NX, NP, MU>(a, pt, sm);
+      return;
+    }
+  }
+  lq_feedback_instance<T, NX, NP, MU>(a, pt, sm);
 }
 
 }  // namespace ilqg

@@ -83,6 +83,133 @@ __device__ __forceinline__ void sub_integrate(int kind, T L, double interval, T*
   }
 }
 
+template <typename T> __device__ __forceinline__ void t_sincos(T x, T* s, T* c);
+template <> __device__ __forceinline__ void t_sincos<float>(float x, float* s, float* c) { sincosf(x, s, c); }
+template <> __device__ __forceinline__ void t_sincos<double>(double x, double* s, double* c) { sincos(x, s, c); }
+
+template <typename T>
+__device__ __forceinline__ T sel8(const T (&a)[8], int q) {
+  T r = a[0];
+#pragma unroll
+  for (int e = 1; e < 8; e++) r = (q == e) ? a[e] : r;
+  return r;
+}
+
+// The same RK4 (2 sub-steps) as sub_integrate, restructured for the wavefront: the 8 stage
+// evaluations of one subsystem are spread over 8 lanes (`q` = this lane's stage, lanes
+// base..base+7 form the group) so that every transcendental leaves the dependent chain.
+//   1. the trig-free "upper" components (phi, v, a — or theta, v for the unicycle) are integrated
+//      redundantly by all 8 lanes, recording the 8 stage values;
+//   2. lane q evaluates tan(phi_q) — one tan latency for all 8 stages;
+//   3. the theta chain (arithmetic only) is run redundantly from the 8 shuffled tangents;
+//   4. lane q evaluates sincos(theta_q) — one sincos latency for all 8 stages;
+//   5. px, py are accumulated from the 8 shuffled stage derivatives.
+// Every floating-point expression is the one sub_integrate evaluates, component by component, so
+// the result is the sequential RK4's; only the schedule differs (24 serial libm calls -> 2).
+// All 8 lanes return the full new state in x[].
+template <typename T>
+__device__ __forceinline__ void sub_integrate_lanes(int kind, T L, double interval, T* x, T u0, T u1, int q,
+                                                    int base) {
+  const T h = T(interval / 2.0);
+  const bool car = kind != ILQG_DYN_UNICYCLE_4D;
+  const int vi = car ? 4 : 3;
+  // ---- 1. upper components, all stages ----
+  T up[6];  // working copy; lower components are left untouched here
+#pragma unroll
+  for (int e = 0; e < 6; e++) up[e] = x[e];
+  T ang_s[8], v_s[8];  // phi (car) or theta (unicycle), and v, at the 8 stage points
+  auto upper_f = [&](const T* xx, T* xd) {
+#pragma unroll
+    for (int e = 0; e < 6; e++) xd[e] = T(0);
+    if (!car) {
+      xd[2] = u0;
+      xd[3] = u1;
+    } else {
+      xd[3] = u0;
+      if (kind == ILQG_DYN_CAR_5D) {
+        xd[4] = u1;
+      } else {
+        xd[4] = xx[5];
+        xd[5] = u1;
+      }
+    }
+  };
+  const int ai = car ? 3 : 2;
+#pragma unroll
+  for (int s = 0; s < 2; s++) {
+    T k1[6], k2[6], k3[6], k4[6], xt[6];
+    ang_s[4 * s + 0] = up[ai];
+    v_s[4 * s + 0] = up[vi];
+    upper_f(up, k1);
+#pragma unroll
+    for (int e = 2; e < 6; e++) { k1[e] = h * k1[e]; xt[e] = up[e] + T(0.5) * k1[e]; }
+    ang_s[4 * s + 1] = xt[ai];
+    v_s[4 * s + 1] = xt[vi];
+    upper_f(xt, k2);
+#pragma unroll
+    for (int e = 2; e < 6; e++) { k2[e] = h * k2[e]; xt[e] = up[e] + T(0.5) * k2[e]; }
+    ang_s[4 * s + 2] = xt[ai];
+    v_s[4 * s + 2] = xt[vi];
+    upper_f(xt, k3);
+#pragma unroll
+    for (int e = 2; e < 6; e++) { k3[e] = h * k3[e]; xt[e] = up[e] + k3[e]; }
+    ang_s[4 * s + 3] = xt[ai];
+    v_s[4 * s + 3] = xt[vi];
+    upper_f(xt, k4);
+#pragma unroll
+    for (int e = 2; e < 6; e++) {
+      k4[e] = h * k4[e];
+      up[e] += (k1[e] + T(2.0) * (k2[e] + k3[e]) + k4[e]) / T(6.0);
+    }
+  }
+  const T my_v = sel8(v_s, q);
+  // ---- 2./3. theta at the 8 stage points ----
+  T th_s[8];
+  if (car) {
+    const T tq = t_tan(sel8(ang_s, q));
+    T tan_s[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) tan_s[e] = shfl(tq, base + e);
+    T th = x[2];
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+      const T k1 = h * ((v_s[4 * s + 0] / L) * tan_s[4 * s + 0]);
+      th_s[4 * s + 0] = th;
+      th_s[4 * s + 1] = th + T(0.5) * k1;
+      const T k2 = h * ((v_s[4 * s + 1] / L) * tan_s[4 * s + 1]);
+      th_s[4 * s + 2] = th + T(0.5) * k2;
+      const T k3 = h * ((v_s[4 * s + 2] / L) * tan_s[4 * s + 2]);
+      th_s[4 * s + 3] = th + k3;
+      const T k4 = h * ((v_s[4 * s + 3] / L) * tan_s[4 * s + 3]);
+      th += (k1 + T(2.0) * (k2 + k3) + k4) / T(6.0);
+    }
+    up[2] = th;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; e++) th_s[e] = ang_s[e];
+  }
+  // ---- 4. one sincos per lane ----
+  T sn, cs;
+  t_sincos(sel8(th_s, q), &sn, &cs);
+  const T kxq = h * (my_v * cs);
+  const T kyq = h * (my_v * sn);
+  // ---- 5. positions ----
+  T px = x[0], py = x[1];
+#pragma unroll
+  for (int s = 0; s < 2; s++) {
+    const T a1 = shfl(kxq, base + 4 * s + 0), a2 = shfl(kxq, base + 4 * s + 1);
+    const T a3 = shfl(kxq, base + 4 * s + 2), a4 = shfl(kxq, base + 4 * s + 3);
+    const T b1 = shfl(kyq, base + 4 * s + 0), b2 = shfl(kyq, base + 4 * s + 1);
+    const T b3 = shfl(kyq, base + 4 * s + 2), b4 = shfl(kyq, base + 4 * s + 3);
+    px += (a1 + T(2.0) * (a2 + a3) + a4) / T(6.0);
+    py += (b1 + T(2.0) * (b2 + b3) + b4) / T(6.0);
+  }
+  x[0] = px;
+  x[1] = py;
+#pragma unroll
+  for (int e = 2; e < 6; e++) x[e] = up[e];
+}
+
 // Per-model Jacobian entries added on top of (I, 0)
 // (single_player_unicycle_4d.h:102-116, single_player_car_5d.h:113-133,
 //  single_player_car_6d.h:116-138; mixed float*double products kept).
@@ -335,58 +462,85 @@ __device__ __forceinline__ void modify_derivatives(T lambda, T mu_in, T g, T* dx
   *ddx = nddx;
 }
 
-// Cost::Quadraticize (accumulating) — one lane scatters <= 16 Hessian entries
-// into its player's LDS tile.  lambda/mu: per-instance augmented-Lagrangian
-// state (nullptr lambdas => 0), tidx = RelativeTimeTracker::TimeIndex of the step.
+// What one cost term adds to its (Hessian, gradient) tile, as a scatter pattern plus at most
+// five scalars — every in-scope Cost::Quadraticize fits one of these shapes:
+//   SINGLE (d):            G[d] += gx;  H(d,d) += hxx
+//   PAIR2  (x,y):          G[x] += gx; G[y] += gy; H(x,x) += hxx; H(y,y) += hyy; H(x,y), H(y,x) += hxy
+//   PAIR4  (x1,y1,x2,y2):  the relative-position pattern of ProximityCost / SignedDistanceCost /
+//                          ProximityConstraint: with s = (+,+,-,-) over (x1,y1,x2,y2),
+//                          G[p] += s_p g_type(p),  H(p,q) += s_p s_q h_type(p),type(q)
+//   ALL:                   QuadraticCost with dimension < 0: G[i] += w (v[i]-nominal), H(i,i) += w
+enum { PAT_NONE = 0, PAT_SINGLE = 1, PAT_PAIR2 = 2, PAT_PAIR4 = 3, PAT_ALL = 4 };
+
 template <typename T>
-__device__ void term_quadraticize_leaf(const DevProblem& p, int ti, const T* v, int dim, T* H, int ld, T* G,
-                                       const T* lambdas, T mu, int tidx) {
-  const DevTerm c = p.terms[ti];
+struct TermOut {
+  int pattern;
+  int i0, i1, i2, i3;
+  T gx, gy, hxx, hyy, hxy;
+  T value;  // Cost::Evaluate (only meaningful for cost terms)
+};
+
+// Cost::Evaluate + Cost::Quadraticize of one LEAF term in one pass (the polyline closest-point
+// search is shared).  `lambda`, `mu`: augmented-Lagrangian state of a constraint term.
+template <typename T>
+__device__ void term_compute_leaf(const DevProblem& p, const DevTerm& c, const T* v, T lambda, T mu,
+                                  TermOut<T>* o) {
   const T w = T(c.weight), val = T(c.value);
   const bool oriented = c.flags & ILQG_FLAG_ORIENTED;
-#define HH(a, b) H[(a) + ld * (b)]
+  o->pattern = PAT_NONE;
+  o->value = T(0);
+  o->i0 = c.idx[0]; o->i1 = c.idx[1]; o->i2 = c.idx[2]; o->i3 = c.idx[3];
+  o->gx = o->gy = o->hxx = o->hyy = o->hxy = T(0);
   switch (c.kind) {
-    case ILQG_COST_QUADRATIC: {  // src/quadratic_cost.cpp:65-94
+    case ILQG_COST_QUADRATIC: {  // src/quadratic_cost.cpp:51-94
       if (c.idx[0] >= 0) {
-        const int d = c.idx[0];
-        G[d] += w * (v[d] - val);
-        HH(d, d) += w;
+        const T d = v[c.idx[0]] - val;
+        o->value = T(0.5) * w * d * d;
+        o->pattern = PAT_SINGLE;
+        o->gx = w * d;
+        o->hxx = w;
       } else {
-        for (int i = 0; i < dim; i++) {
-          G[i] += w * (v[i] - val);
-          HH(i, i) = HH(i, i) + w;
-        }
+        T sq = T(0);
+        for (int i = 0; i < c.arg_dim; i++) sq += (v[i] - val) * (v[i] - val);
+        o->value = T(0.5) * w * sq;
+        o->pattern = PAT_ALL;
+        o->gx = w;
+        o->gy = val;
       }
       return;
     }
-    case ILQG_COST_SEMIQUADRATIC: {  // src/semiquadratic_cost.cpp:63-85
-      const int d = c.idx[0];
-      const T diff = v[d] - val;
-      if ((diff < T(0) && oriented) || (diff > T(0) && !oriented)) return;
-      G[d] += w * diff;
-      HH(d, d) += w;
+    case ILQG_COST_SEMIQUADRATIC: {  // src/semiquadratic_cost.cpp:51-85
+      const T d = v[c.idx[0]] - val;
+      if ((d > T(0) && oriented) || (d < T(0) && !oriented)) o->value = T(0.5) * w * d * d;
+      if ((d < T(0) && oriented) || (d > T(0) && !oriented)) return;
+      o->pattern = PAT_SINGLE;
+      o->gx = w * d;
+      o->hxx = w;
       return;
     }
-    case ILQG_COST_QUADRATIC_POLYLINE2:        // src/quadratic_polyline2_cost.cpp:71-126
-    case ILQG_COST_SEMIQUADRATIC_POLYLINE2: {  // src/semiquadratic_polyline2_cost.cpp:76-142
+    case ILQG_COST_QUADRATIC_POLYLINE2:        // src/quadratic_polyline2_cost.cpp:52-126
+    case ILQG_COST_SEMIQUADRATIC_POLYLINE2: {  // src/semiquadratic_polyline2_cost.cpp:52-142
       const bool semi = c.kind == ILQG_COST_SEMIQUADRATIC_POLYLINE2;
-      const int xi = c.idx[0], yi = c.idx[1];
-      const T px = v[xi], py = v[yi];
+      const T px = v[c.idx[0]], py = v[c.idx[1]];
       const float* pts = p.poly_pts + 2 * p.poly_off[c.polyline];
       const Closest<T> cl = polyline_closest<T>(pts, p.poly_off[c.polyline + 1] - p.poly_off[c.polyline], px, py);
-      T thr = T(0);
       T dx, dy;
       if (semi) {
         const T sst = sgn(val) * val * val;
         const bool active = (cl.ssd > sst && oriented) || (cl.ssd < sst && !oriented);
+        if (!cl.is_endpoint && active) {
+          const T sd = sgn(cl.ssd) * t_sqrt(t_abs(cl.ssd));
+          const T d = sd - val;
+          o->value = T(0.5) * w * d * d;
+        }
         if (!active) return;
         if (cl.is_endpoint) return;
         T scaling = t_sqrt(t_abs(cl.ssd));
         scaling = (scaling - t_abs(val)) / scaling;
         dx = w * scaling * (px - cl.cx);
         dy = w * scaling * (py - cl.cy);
-        thr = val;
       } else {
+        o->value = T(0.5) * w * t_abs(cl.is_endpoint ? T(0) : cl.ssd);
         if (cl.is_endpoint) return;
         dx = w * (px - cl.cx);
         dy = w * (py - cl.cy);
@@ -397,101 +551,119 @@ __device__ void term_quadraticize_leaf(const DevProblem& p, int ti, const T* v, 
         ddx = w * cl.seg.uy * cl.seg.uy;
         ddy = w * cl.seg.ux * cl.seg.ux;
         dxdy = -w * cl.seg.ux * cl.seg.uy;
-        const T w_cross = semi ? w * (relx * cl.seg.uy - rely * cl.seg.ux - thr)
+        const T w_cross = semi ? w * (relx * cl.seg.uy - rely * cl.seg.ux - val)
                                : w * (relx * cl.seg.uy - rely * cl.seg.ux);
         dx = w_cross * cl.seg.uy;
         dy = -w_cross * cl.seg.ux;
       }
-      G[xi] += dx;
-      G[yi] += dy;
-      HH(xi, xi) += ddx;
-      HH(yi, yi) += ddy;
-      HH(xi, yi) += dxdy;
-      HH(yi, xi) += dxdy;
+      o->pattern = PAT_PAIR2;
+      o->gx = dx; o->gy = dy; o->hxx = ddx; o->hyy = ddy; o->hxy = dxdy;
       return;
     }
-    case ILQG_COST_PROXIMITY: {  // src/proximity_cost.cpp:63-122
-      const int x1 = c.idx[0], y1 = c.idx[1], x2 = c.idx[2], y2 = c.idx[3];
-      const T dx = v[x1] - v[x2], dy = v[y1] - v[y2];
+    case ILQG_COST_PROXIMITY: {  // src/proximity_cost.cpp:52-122
+      const T dx = v[c.idx[0]] - v[c.idx[2]], dy = v[c.idx[1]] - v[c.idx[3]];
       const T dsq = dx * dx + dy * dy;
       if (dsq >= val * val) return;
       const T delta = t_sqrt(dsq);
       const T gap = val - delta;
+      o->value = T(0.5) * w * gap * gap;
       const T wd = w / delta;
       const T dxd = dx / delta, dyd = dy / delta;
-      const T g1 = -wd * gap * dx;
-      const T g2 = -wd * gap * dy;
-      const T hxx = wd * (dxd * (gap * dxd + dx) - gap);
-      const T hyy = wd * (dyd * (gap * dyd + dy) - gap);
-      const T hxy = wd * (dxd * (gap * dyd + dy));
-      G[x1] += g1; G[x2] -= g1; G[y1] += g2; G[y2] -= g2;
-      HH(x1, x1) += hxx; HH(x1, x2) -= hxx; HH(x2, x1) -= hxx; HH(x2, x2) += hxx;
-      HH(y1, y1) += hyy; HH(y1, y2) -= hyy; HH(y2, y1) -= hyy; HH(y2, y2) += hyy;
-      HH(x1, y1) += hxy; HH(y1, x1) += hxy;
-      HH(x1, y2) -= hxy; HH(y2, x1) -= hxy;
-      HH(x2, y1) -= hxy; HH(y1, x2) -= hxy;
-      HH(x2, y2) += hxy; HH(y2, x2) += hxy;
+      o->pattern = PAT_PAIR4;
+      o->gx = -wd * gap * dx;
+      o->gy = -wd * gap * dy;
+      o->hxx = wd * (dxd * (gap * dxd + dx) - gap);
+      o->hyy = wd * (dyd * (gap * dyd + dy) - gap);
+      o->hxy = wd * (dxd * (gap * dyd + dy));
       return;
     }
-    case ILQG_COST_SIGNED_DISTANCE: {  // src/signed_distance_cost.cpp:65-113
-      const int x1 = c.idx[0], y1 = c.idx[1], x2 = c.idx[2], y2 = c.idx[3];
+    case ILQG_COST_SIGNED_DISTANCE: {  // src/signed_distance_cost.cpp:51-113
       const T s = oriented ? T(1) : T(-1);
-      const T ex = v[x1] - v[x2], ey = v[y1] - v[y2];
+      const T ex = v[c.idx[0]] - v[c.idx[2]], ey = v[c.idx[1]] - v[c.idx[3]];
       const T norm = t_hypot(ex, ey);
+      const T cost = val - norm;
+      o->value = oriented ? cost : -cost;
       const T n3 = norm * norm * norm;
-      const T dx1 = -s * ex / norm, dy1 = -s * ey / norm;
-      const T ddx1 = -s * ey * ey / n3, ddy1 = -s * ex * ex / n3;
-      const T dxy = s * ex * ey / n3;
-      G[x1] += dx1; G[y1] += dy1; G[x2] -= dx1; G[y2] -= dy1;
-      HH(x1, x1) += ddx1; HH(y1, y1) += ddy1; HH(x1, y1) += dxy; HH(y1, x1) += dxy;
-      HH(x2, x2) += ddx1; HH(y2, y2) += ddy1; HH(x2, y2) += dxy; HH(y2, x2) += dxy;
-      HH(x1, x2) -= ddx1; HH(x1, y2) -= dxy; HH(y1, x2) -= dxy; HH(y1, y2) -= ddy1;
-      HH(x2, x1) -= ddx1; HH(x2, y1) -= dxy; HH(y2, x1) -= dxy; HH(y2, y1) -= ddy1;
+      o->pattern = PAT_PAIR4;
+      o->gx = -s * ex / norm;
+      o->gy = -s * ey / norm;
+      o->hxx = -s * ey * ey / n3;
+      o->hyy = -s * ex * ex / n3;
+      o->hxy = s * ex * ey / n3;
       return;
     }
-    case ILQG_CONSTRAINT_PROXIMITY: {  // src/proximity_constraint.cpp:64-116
-      const int x1 = c.idx[0], y1 = c.idx[1], x2 = c.idx[2], y2 = c.idx[3];
-      const T dx = v[x1] - v[x2], dy = v[y1] - v[y2];
+    case ILQG_CONSTRAINT_PROXIMITY: {  // src/proximity_constraint.cpp:56-116
+      const T dx = v[c.idx[0]] - v[c.idx[2]], dy = v[c.idx[1]] - v[c.idx[3]];
       const T prox = t_hypot(dx, dy);
       const T sign = oriented ? T(1) : T(-1);
       const T g = sign * (prox - val);
+      o->value = g;
       const T rdx = dx / prox, rdy = dy / prox;
       T gx = sign * rdx, gy = sign * rdy;
       T hxx = sign * (T(1) - rdx * rdx) / prox;
       T hyy = sign * (T(1) - rdy * rdy) / prox;
       T hxy = -sign * rdx * rdy / prox;
-      const T lambda = lambdas ? lambdas[c.slot * p.T + tidx] : T(0);
       modify_derivatives(lambda, mu, g, &gx, &hxx, &gy, &hyy, &hxy);
-      G[x1] += gx; G[x2] -= gx; G[y1] += gy; G[y2] -= gy;
-      HH(x1, x1) += hxx; HH(x1, x2) -= hxx; HH(x2, x1) -= hxx; HH(x2, x2) += hxx;
-      HH(y1, y1) += hyy; HH(y1, y2) -= hyy; HH(y2, y1) -= hyy; HH(y2, y2) += hyy;
-      HH(x1, y1) += hxy; HH(x1, y2) -= hxy; HH(x2, y1) -= hxy; HH(x2, y2) += hxy;
-      HH(y1, x1) += hxy; HH(y1, x2) -= hxy; HH(y2, x1) -= hxy; HH(y2, x2) += hxy;
+      o->pattern = PAT_PAIR4;
+      o->gx = gx; o->gy = gy; o->hxx = hxx; o->hyy = hyy; o->hxy = hxy;
       return;
     }
-    case ILQG_CONSTRAINT_SINGLE_DIMENSION: {  // single_dimension_constraint.h:74-97
-      const int d = c.idx[0];
+    case ILQG_CONSTRAINT_SINGLE_DIMENSION: {  // single_dimension_constraint.h:68-97
       const T sign = oriented ? T(1) : T(-1);
-      const T g = sign * (v[d] - val);
+      const T g = sign * (v[c.idx[0]] - val);
+      o->value = g;
       T dx = sign, ddx = T(0);
-      const T lambda = lambdas ? lambdas[c.slot * p.T + tidx] : T(0);
       modify_derivatives<T>(lambda, mu, g, &dx, &ddx, nullptr, nullptr, nullptr);
-      G[d] += dx;
-      HH(d, d) += ddx;
+      o->pattern = PAT_SINGLE;
+      o->gx = dx;
+      o->hxx = ddx;
       return;
     }
   }
-#undef HH
 }
 
+// Top-level term: ExtremeValueCost dispatches to its active child (src/extreme_value_cost.cpp:51-85).
 template <typename T>
-__device__ void term_quadraticize(const DevProblem& p, int ti, const T* v, int dim, T* H, int ld, T* G,
-                                  const T* lambdas, T mu, int tidx) {
-  if (p.terms[ti].kind == ILQG_COST_EXTREME_VALUE) {  // src/extreme_value_cost.cpp:58-64
+__device__ void term_compute(const DevProblem& p, const DevTerm& c, const T* v, T lambda, T mu, TermOut<T>* o) {
+  if (c.kind == ILQG_COST_EXTREME_VALUE) {
     T value;
-    ti = extreme_child(p, p.terms[ti], v, dim, &value);
+    const int best = extreme_child(p, c, v, c.arg_dim, &value);
+    const DevTerm child = p.terms[best];
+    term_compute_leaf<T>(p, child, v, lambda, mu, o);
+    o->value = value;
+    return;
   }
-  term_quadraticize_leaf(p, ti, v, dim, H, ld, G, lambdas, mu, tidx);
+  term_compute_leaf<T>(p, c, v, lambda, mu, o);
+}
+
+// Scatter one term's contribution into its LDS tiles (H column-major with leading dim ld).
+template <typename T>
+__device__ __forceinline__ void term_scatter(const TermOut<T>& o, const T* v, int dim, T* H, int ld, T* G) {
+  if (o.pattern == PAT_SINGLE) {
+    G[o.i0] += o.gx;
+    H[o.i0 + ld * o.i0] += o.hxx;
+  } else if (o.pattern == PAT_PAIR2) {
+    G[o.i0] += o.gx;
+    G[o.i1] += o.gy;
+    H[o.i0 + ld * o.i0] += o.hxx;
+    H[o.i1 + ld * o.i1] += o.hyy;
+    H[o.i0 + ld * o.i1] += o.hxy;
+    H[o.i1 + ld * o.i0] += o.hxy;
+  } else if (o.pattern == PAT_PAIR4) {
+    const int x1 = o.i0, y1 = o.i1, x2 = o.i2, y2 = o.i3;
+    G[x1] += o.gx; G[x2] -= o.gx; G[y1] += o.gy; G[y2] -= o.gy;
+    H[x1 + ld * x1] += o.hxx; H[x1 + ld * x2] -= o.hxx; H[x2 + ld * x1] -= o.hxx; H[x2 + ld * x2] += o.hxx;
+    H[y1 + ld * y1] += o.hyy; H[y1 + ld * y2] -= o.hyy; H[y2 + ld * y1] -= o.hyy; H[y2 + ld * y2] += o.hyy;
+    H[x1 + ld * y1] += o.hxy; H[y1 + ld * x1] += o.hxy;
+    H[x1 + ld * y2] -= o.hxy; H[y2 + ld * x1] -= o.hxy;
+    H[x2 + ld * y1] -= o.hxy; H[y1 + ld * x2] -= o.hxy;
+    H[x2 + ld * y2] += o.hxy; H[y2 + ld * x2] += o.hxy;
+  } else if (o.pattern == PAT_ALL) {
+    for (int i = 0; i < dim; i++) {
+      G[i] += o.gx * (v[i] - o.gy);
+      H[i + ld * i] = H[i + ld * i] + o.gx;
+    }
+  }
 }
 
 }  // namespace ilqg

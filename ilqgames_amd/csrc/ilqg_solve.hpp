@@ -145,7 +145,7 @@ __device__ void ilq_solve_instance(const DevProblem& p, const SolveArgs<T>& sa, 
     la.ed_out = sm + LQCfg<T, NX, NP, MU>::oX;  // any LDS slot free at the end of the sweep
     la.T_steps = Tn;
     la.adaptive = 1;
-    lq_feedback_instance<T, NX, NP, MU>(la, pt, sm);
+    lq_feedback_dispatch<T, NX, NP, MU>(la, pt, sm, false);
     __syncthreads();
     const T expected_decrease = sm[LQCfg<T, NX, NP, MU>::oX];
     __syncthreads();

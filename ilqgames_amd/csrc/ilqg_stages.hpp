@@ -10,7 +10,8 @@ namespace ilqg {
 
 // ---------------------------------------------------------------------------
 // Rollout — ILQSolver::CurrentOperatingPoint (src/ilq_solver.cpp:174-206).
-// Lane j < N integrates subsystem j in registers (RK4, 2 sub-steps); lanes rho < m
+// Eight lanes per subsystem run the RK4 (2 sub-steps) with one stage each, so the 24 serial
+// sin/cos/tan of a step collapse to two libm latencies (sub_integrate_lanes); lanes rho < m
 // evaluate u_rho = u_ref - P[rho,:] dx - s*alpha (Strategy::operator(), strategy.h:73-76)
 // against dx broadcast through LDS.  The step's (P, alpha, u_ref, x_ref) block is
 // prefetched one step ahead so the only exposed latency is the dependent chain.
@@ -64,15 +65,20 @@ __device__ void rollout_instance(const DevProblem& p, const RolloutArgs<T>& a, T
       if (e < W) sP[e] = pre[q];
     }
   };
+  // lane group g = t / 8 integrates subsystem g; lane q = t % 8 owns RK4 stage q of that group
   T xj[6];
-  int kind = 0, xo = 0, uo = 0, xd = 0;
+  const int grp = t >> 3, q = t & 7;
+  const bool integ = grp < N && t < 64;
+  int kind = ILQG_DYN_UNICYCLE_4D, xo = 0, uo = 0, xd = 0;
   T Lp = T(1);
-  if (t < N) {
-    kind = p.sub_kind[t];
-    xo = p.xoff[t];
-    uo = p.uoff[t];
-    xd = p.xoff[t + 1] - xo;
-    Lp = T(p.sub_param[t]);
+#pragma unroll
+  for (int e = 0; e < 6; e++) xj[e] = T(0);
+  if (integ) {
+    kind = p.sub_kind[grp];
+    xo = p.xoff[grp];
+    uo = p.uoff[grp];
+    xd = p.xoff[grp + 1] - xo;
+    Lp = T(p.sub_param[grp]);
 #pragma unroll
     for (int e = 0; e < 6; e++) xj[e] = (e < xd) ? a.x0[xo + e] : T(0);
   }
@@ -82,11 +88,10 @@ __device__ void rollout_instance(const DevProblem& p, const RolloutArgs<T>& a, T
 #pragma unroll 1
   for (int k = 0; k < Tn; k++) {
     if (k + 1 < Tn) issue(k + 1);
-    if (t < N) {
+    if (integ && q == 0) {
 #pragma unroll
       for (int e = 0; e < 6; e++)
         if (e < xd) {
-          sx[xo + e] = xj[e];
           sdx[xo + e] = xj[e] - sxr[xo + e];
           a.xs[size_t(k) * n + xo + e] = xj[e];
         }
@@ -100,7 +105,10 @@ __device__ void rollout_instance(const DevProblem& p, const RolloutArgs<T>& a, T
       a.us[size_t(k) * m + t] = u;
     }
     __syncthreads();
-    if (t < N && k + 1 < Tn) sub_integrate<T>(kind, Lp, p.dt, xj, su[uo], su[uo + 1]);
+    if (t < 64 && k + 1 < Tn) {  // whole first wave: the shuffles inside need every group lane live
+      const T u0 = integ ? su[uo] : T(0), u1 = integ ? su[uo + 1] : T(0);
+      sub_integrate_lanes<T>(kind, Lp, p.dt, xj, u0, u1, q, t & ~7);
+    }
     if (k + 1 < Tn) commit();
     __syncthreads();
   }
@@ -131,8 +139,8 @@ struct QuadArgs {
   T* cost_part;        // [T][N] PlayerCost::Evaluate or nullptr
 };
 
-__host__ __device__ inline int quad_lds_elems(int n, int m, int N, int Rsz, int rsz) {
-  return n + m + n * n + n * m + N * n * n + N * n + Rsz + rsz;
+__host__ __device__ inline int quad_lds_elems(int n, int m, int N, int Rsz, int rsz, int num_terms) {
+  return n + m + n * n + n * m + N * n * n + N * n + Rsz + rsz + num_terms;
 }
 
 template <typename T>
@@ -140,92 +148,100 @@ __device__ void linquad_step(const DevProblem& p, const QuadArgs<T>& a, int k, T
   const int n = p.n, m = p.m, N = p.N;
   const int t = threadIdx.x, NT = blockDim.x;
   const PairTable& pt = p.pairs;
-  T* sx = sm;
-  T* su = sx + n;
-  T* sA = su + m;
+  T* sx = sm;  // [x | u] argument image
+  T* sA = sx + n + m;
   T* sB = sA + n * n;
-  T* sQ = sB + n * m;
+  T* sQ = sB + n * m;  // [Q | l | R | r] tile image, same element order as the global arrays
   T* sl = sQ + N * n * n;
   T* sR = sl + N * n;
   T* sr = sR + pt.Rsz;
   const bool do_quad = a.Q != nullptr || a.merit_part != nullptr;
-  // ---- init tiles ----
+  // ---- load the argument, initialise the tiles ----
   for (int e = t; e < n; e += NT) sx[e] = a.xs[size_t(k) * n + e];
-  for (int e = t; e < m; e += NT) su[e] = a.us[size_t(k) * m + e];
+  for (int e = t; e < m; e += NT) sx[n + e] = a.us[size_t(k) * m + e];
   if (a.A) {
     for (int e = t; e < n * n; e += NT) sA[e] = (e / n == e % n) ? T(1) : T(0);
     for (int e = t; e < n * m; e += NT) sB[e] = T(0);
   }
+  // PlayerCost::Quadraticize vs QuadraticizeControlCosts (src/ilq_solver.cpp:483-487)
+  auto is_full = [&](int i) {
+    return p.structure[i] == ILQG_SUM || (a.t_extreme ? a.t_extreme[i] == k : k == 0);
+  };
   if (do_quad) {
     for (int e = t; e < N * n * n; e += NT) {
       const int i = e / (n * n), rc = e % (n * n);
-      sQ[e] = (rc / n == rc % n) ? T(p.state_reg[i]) : T(0);
+      sQ[e] = (rc / n == rc % n) ? T(p.state_reg[i]) : T(0);  // sigma_x I (player_cost.cpp:196)
     }
     for (int e = t; e < N * n + pt.Rsz + pt.rsz; e += NT) sl[e] = T(0);
   }
   __syncthreads();
-  // ---- lane i: subsystem Jacobian + player i's cost list ----
-  if (t < N) {
-    const int i = t;
-    if (a.A) {
-      const int xo = p.xoff[i], uo = p.uoff[i];
-      sub_linearize<T>(p.sub_kind[i], T(p.sub_param[i]), p.dt, sx + xo, sA + xo + n * xo, sB + xo + n * uo, n);
+  if (do_quad && t < pt.npairs) {
+    // sigma_u I on every control block the reference would have created (player_cost.cpp:70-74)
+    const int i = pt.pi[t];
+    if (is_full(i) || pt.from_cost[t]) {
+      const int mj = p.udim[pt.pj[t]];
+      for (int d = 0; d < mj; d++) sR[pt.roff[t] + d + mj * d] = T(p.control_reg[i]);
     }
-    const double tt = double(k) * p.dt;
-    const int tidx = int(static_cast<size_t>((tt - a.t_init) / p.dt));  // relative_time_tracker.h:69-72
-    const bool full = p.structure[i] == ILQG_SUM || (a.t_extreme && a.t_extreme[i] == k) ||
-                      (!a.t_extreme && k == 0);
-    if (do_quad) {
-      T* Qi = sQ + i * n * n;
-      T* li = sl + i * n;
-      // sigma_u I on every block the reference would have created (player_cost.cpp:70-74)
-      for (int q = 0; q < pt.npairs; q++) {
-        if (pt.pi[q] != i) continue;
-        if (!full && !pt.from_cost[q]) continue;  // block exists only through a constraint
-        const int mj = p.udim[pt.pj[q]];
-        for (int d = 0; d < mj; d++) sR[pt.roff[q] + d + mj * d] = T(p.control_reg[i]);
-      }
-      for (int pass = 0; pass < 4; pass++) {
-        if (!full && pass != ILQG_ROLE_CONTROL_COST) continue;  // QuadraticizeControlCosts, :217-225
-        for (int ti = 0; ti < p.num_terms; ti++) {
-          const DevTerm& c = p.terms[ti];
-          if (c.player != i || c.role != pass) continue;
-          if (pass == ILQG_ROLE_STATE_COST || pass == ILQG_ROLE_STATE_CONSTRAINT) {
-            term_quadraticize<T>(p, ti, sx, n, Qi, n, li, a.lambdas, a.mu, tidx);
-          } else {
-            const int j = c.arg;
-            int q = 0;
-            for (int qq = 0; qq < pt.npairs; qq++)
-              if (pt.pi[qq] == i && pt.pj[qq] == j) q = qq;
-            term_quadraticize<T>(p, ti, su + p.uoff[j], p.udim[j], sR + pt.roff[q], p.udim[j], sr + pt.rgoff[q],
-                                 a.lambdas, a.mu, tidx);
-          }
+  }
+  if (a.A && t < N) {
+    const int xo = p.xoff[t], uo = p.uoff[t];
+    sub_linearize<T>(p.sub_kind[t], T(p.sub_param[t]), p.dt, sx + xo, sA + xo + n * xo, sB + xo + n * uo, n);
+  }
+  // ---- one lane per cost term: value + derivative pattern (the expensive part, in parallel) ----
+  const double tt = double(k) * p.dt;
+  const int tidx = int(static_cast<size_t>((tt - a.t_init) / p.dt));  // relative_time_tracker.h:69-72
+  T* svals = sr + pt.rsz;  // [num_terms] term values for TotalCosts
+  for (int base = 0; base < p.num_terms; base += NT) {
+    const int ti = base + t;
+    DevTerm c;
+    TermOut<T> o;
+    o.pattern = PAT_NONE;
+    o.value = T(0);
+    bool live = false;
+    if (ti < p.num_terms) {
+      c = p.terms[ti];
+      live = c.role != ILQG_ROLE_CHILD;
+      if (live) {
+        const bool is_cost = c.role == ILQG_ROLE_STATE_COST || c.role == ILQG_ROLE_CONTROL_COST;
+        const bool deriv = do_quad && (is_full(c.player) || c.role == ILQG_ROLE_CONTROL_COST);
+        if (deriv || (a.cost_part && is_cost)) {
+          const T lambda = (c.slot >= 0 && a.lambdas) ? a.lambdas[c.slot * p.T + tidx] : T(0);
+          term_compute<T>(p, c, sx + c.arg_off, lambda, a.mu, &o);
+          if (!deriv) o.pattern = PAT_NONE;
         }
       }
-      if (a.merit_part) {
-        const int q = pt.pii[i];
-        T s1 = T(0), s2 = T(0);
-        for (int d = 0; d < p.udim[i]; d++) s1 += sr[pt.rgoff[q] + d] * sr[pt.rgoff[q] + d];
-        for (int d = 0; d < n; d++) s2 += li[d] * li[d];
-        a.merit_part[(size_t(k) * N + i) * 2 + 0] = s1;
-        a.merit_part[(size_t(k) * N + i) * 2 + 1] = s2;
+      if (a.cost_part) svals[ti] = o.value;
+    }
+    // ---- scatter in rounds: within a round no two terms touch the same entry ----
+    if (do_quad) {
+      for (int r = 0; r < p.num_rounds; r++) {
+        __syncthreads();
+        if (live && c.round == r && o.pattern != PAT_NONE)
+          term_scatter<T>(o, sx + c.arg_off, c.arg_dim, sQ + c.tile_h, c.ld, sQ + c.tile_g);
       }
     }
-    if (a.cost_part) {  // PlayerCost::Evaluate, src/player_cost.cpp:128-144
+  }
+  __syncthreads();
+  if (t < N) {
+    const int i = t;
+    if (a.merit_part) {  // pieces of ILQSolver::MeritFunction (:419-430)
+      const int q = pt.pii[i];
+      T s1 = T(0), s2 = T(0);
+      for (int d = 0; d < p.udim[i]; d++) s1 += sr[pt.rgoff[q] + d] * sr[pt.rgoff[q] + d];
+      for (int d = 0; d < n; d++) s2 += sl[i * n + d] * sl[i * n + d];
+      a.merit_part[(size_t(k) * N + i) * 2 + 0] = s1;
+      a.merit_part[(size_t(k) * N + i) * 2 + 1] = s2;
+    }
+    if (a.cost_part) {  // PlayerCost::Evaluate, src/player_cost.cpp:128-144 (state costs, then control costs)
       T total = T(0);
       for (int pass = 0; pass < 2; pass++)
         for (int ti = 0; ti < p.num_terms; ti++) {
           const DevTerm& c = p.terms[ti];
-          if (c.player != i || c.role != pass) continue;
-          if (pass == 0)
-            total += term_evaluate<T>(p, ti, sx, n);
-          else
-            total += term_evaluate<T>(p, ti, su + p.uoff[c.arg], p.udim[c.arg]);
+          if (c.player == i && c.role == pass) total += svals[ti];
         }
       a.cost_part[size_t(k) * N + i] = total;
     }
   }
-  __syncthreads();
   // ---- coalesced write-out ----
   if (a.A) {
     for (int e = t; e < n * n; e += NT) a.A[size_t(k) * n * n + e] = sA[e];

@@ -18,7 +18,7 @@ EXPORTS = [
     "ilqg_lq_feedback_batch", "ilqg_lq_openloop_batch", "ilqg_default_solver_params", "ilqg_problem_create",
     "ilqg_problem_destroy", "ilqg_workspace_bytes", "ilqg_rollout_batch", "ilqg_linearize_batch",
     "ilqg_quadraticize_batch", "ilqg_problem_pairs", "ilqg_total_costs_batch", "ilqg_ilq_solve_batch",
-    "ilqg_last_error", "ilqg_abi_version", "ilqg_device_info",
+    "ilqg_last_error", "ilqg_abi_version", "ilqg_device_info", "ilqg_selftest_mfma",
 ]
 
 
@@ -77,6 +77,16 @@ def device_info():
     cus = C.c_int32(0)
     _check(lib().ilqg_device_info(name, 256, C.byref(cus)))
     return name.value.decode(), cus.value
+
+
+def selftest_mfma(dtype, X, Y, Cm):
+    """X^T Y + C (16x16, numpy, row/col indexed [i, j]) through the MFMA tile path."""
+    import torch
+    cm = lambda a: _dev(np.ascontiguousarray(np.asarray(a).T), dtype)  # noqa: E731  column-major image
+    Xd, Yd, Cd = cm(X), cm(Y), cm(Cm)
+    out = torch.empty_like(Xd)
+    _check(lib().ilqg_selftest_mfma(dtype, _ptr(Xd), _ptr(Yd), _ptr(Cd), _ptr(out), _stream()))
+    return out.cpu().numpy().T
 
 
 def lq_feedback(dims, A, Bm, Q, l, R, r, pairs, x0=None, want_dx=True):

@@ -298,6 +298,10 @@ ilqg_status ilqg_ilq_solve_batch(ilqg_problem* p, int32_t batch, const void* x0,
                                  void* workspace, int32_t fixed_iters,
                                  void* stream);
 
+/* Diagnostics: out = X^T Y + C for 16x16 column-major device matrices, computed through the
+ * MFMA accumulator-layout path the LQ sweep is built on (pins the gfx950 register layouts). */
+ilqg_status ilqg_selftest_mfma(int32_t dtype, const void* X, const void* Y, const void* C, void* out, void* stream);
+
 /* Last HIP / validation error text of the calling thread. */
 const char* ilqg_last_error(void);
 
