@@ -4,6 +4,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -41,7 +42,7 @@ struct LQBatchArgs {
   int T_steps, adaptive, batch, force_valu;
 };
 
-template <typename T, int NX, int NP, int MU>
+template <typename T, int NX, int NP, int MU, bool FORCE_VALU>
 __global__ void __launch_bounds__((LQCfg<T, NX, NP, MU>::NT))
 lq_feedback_kernel(LQBatchArgs<T> g, PairTable pt) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -64,7 +65,7 @@ lq_feedback_kernel(LQBatchArgs<T> g, PairTable pt) {
   a.ed_out = nullptr;
   a.T_steps = g.T_steps;
   a.adaptive = g.adaptive;
-  lq_feedback_dispatch<T, NX, NP, MU>(a, pt, sm, g.force_valu != 0);
+  lq_feedback_dispatch<T, NX, NP, MU, FORCE_VALU>(a, pt, sm);
 }
 
 template <typename T>
@@ -95,14 +96,16 @@ struct QuadBatchArgs {
   const int* active;
 };
 
-// grid = (T, B): every (instance, time step) is independent here
+// grid = (ceil(T / kStepsPerBlock), B): every (instance, time step) is independent here; a block
+// takes a few consecutive steps so that staging the cost tables into LDS is amortised.
+constexpr int kStepsPerBlock = 4;
 template <typename T>
 __global__ void linquad_kernel(DevProblem p, QuadBatchArgs<T> g) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  T* sm = reinterpret_cast<T*>(smem_raw);
   const size_t b = blockIdx.y;
-  const int k = blockIdx.x;
   if (g.active && !g.active[b]) return;
+  const QuadTables<T> tb = quad_tables_load<T>(p, smem_raw);
+  T* sm = reinterpret_cast<T*>(smem_raw + quad_tables_bytes(p, sizeof(T)));
   const size_t Tn = p.T, n = p.n, m = p.m, N = p.N;
   QuadArgs<T> a;
   a.xs = g.xs + b * Tn * n;
@@ -119,7 +122,8 @@ __global__ void linquad_kernel(DevProblem p, QuadBatchArgs<T> g) {
   a.r = g.r ? g.r + b * Tn * p.pairs.rsz : nullptr;
   a.merit_part = g.merit_part ? g.merit_part + b * Tn * N * 2 : nullptr;
   a.cost_part = g.cost_part ? g.cost_part + b * Tn * N : nullptr;
-  linquad_step<T>(p, a, k, sm);
+  for (int k = blockIdx.x * kStepsPerBlock; k < (blockIdx.x + 1) * kStepsPerBlock && k < p.T; k++)
+    linquad_step<T>(p, tb, a, k, sm);
 }
 
 template <typename T>
@@ -133,13 +137,14 @@ template <typename T, int NX, int NP, int MU>
 __global__ void __launch_bounds__((LQCfg<T, NX, NP, MU>::NT))
 ilq_solve_kernel(DevProblem p, SolveArgs<T> sa) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  T* sm = reinterpret_cast<T*>(smem_raw);
+  const QuadTables<T> tb = quad_tables_load<T>(p, smem_raw);  // resident for the whole solve
+  T* sm = reinterpret_cast<T*>(smem_raw + quad_tables_bytes(p, sizeof(T)));
   const int b = blockIdx.x;
   const int n = NX;
   T* xs0 = sa.xs + size_t(b) * p.T * n;
   if (threadIdx.x < n) xs0[threadIdx.x] = sa.x0[size_t(b) * n + threadIdx.x];  // xs[0] = x0 (:89-90)
   __syncthreads();
-  ilq_solve_instance<T, NX, NP, MU>(p, sa, b, sm);
+  ilq_solve_instance<T, NX, NP, MU>(p, tb, sa, b, sm);
 }
 
 template <typename T>
@@ -164,6 +169,7 @@ struct Scratch {  // grow-only device scratch for entry points without a workspa
   }
 };
 thread_local Scratch g_scratch;
+long long* g_prof = nullptr;  // set through ilqg_debug_set_profile_buffer
 
 bool build_pairs(const ilqg_pair* pairs, int npairs, const int* udim, int N, PairTable* pt, std::string* err) {
   if (npairs > kMaxPairs) {
@@ -223,9 +229,11 @@ ilqg_status launch_lq(const ilqg_dims* d, const PairTable& pt, const void* A, co
   g.T_steps = d->T;
   g.adaptive = d->adaptive_regularization;
   g.batch = d->batch;
-  g.force_valu = getenv("ILQG_FORCE_VALU") != nullptr;  // A/B switch for profiling the two formulations
+  g.force_valu = 0;
   const size_t lds = size_t(C::LDS_ELEMS) * sizeof(T);
-  auto kern = lq_feedback_kernel<T, NX, NP, MU>;
+  // ILQG_FORCE_VALU=1 selects the VALU/LDS formulation where the MFMA one is the default (A/B profiling)
+  auto kern = (C::USE_MFMA && getenv("ILQG_FORCE_VALU") != nullptr) ? lq_feedback_kernel<T, NX, NP, MU, true>
+                                                                    : lq_feedback_kernel<T, NX, NP, MU, false>;
   if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3(d->batch), dim3(C::NT), lds, stream, g, pt);
   HIP_TRY(hipGetLastError());
@@ -255,6 +263,9 @@ struct ilqg_problem {
   DevTerm* d_terms = nullptr;
   int* d_poly_off = nullptr;
   float* d_poly_pts = nullptr;
+  float* d_segs_f = nullptr;
+  double* d_segs_d = nullptr;
+  int* d_cost_order = nullptr;
   int mu_uniform = 0;
 };
 
@@ -269,8 +280,10 @@ static ilqg_status launch_linquad(const ilqg_problem* p, int32_t batch, const vo
   [&]() -> ilqg_status {                                                                                        \
     QuadBatchArgs<TY_> g{(const TY_*)xs, (const TY_*)us, (const TY_*)lambdas, (const TY_*)mu, t_extreme, (TY_*)A, (TY_*)Bm,   \
                        (TY_*)Q, (TY_*)l, (TY_*)R, (TY_*)r, (TY_*)merit_part, (TY_*)cost_part, active};                      \
-    const size_t lds = quad_lds_elems(d.n, d.m, d.N, d.pairs.Rsz, d.pairs.rsz, d.num_terms) * sizeof(TY_);                     \
-    hipLaunchKernelGGL(linquad_kernel<TY_>, dim3(d.T, batch), dim3(64), lds, (hipStream_t)stream, d, g);          \
+    const size_t lds = quad_lds_elems(d.n, d.m, d.N, d.pairs.Rsz, d.pairs.rsz, d.num_terms) * sizeof(TY_) +       \
+                       quad_tables_bytes(d, sizeof(TY_));                                                         \
+    hipLaunchKernelGGL(linquad_kernel<TY_>, dim3((d.T + kStepsPerBlock - 1) / kStepsPerBlock, batch), dim3(64),  \
+                       lds, (hipStream_t)stream, d, g);                                                           \
     HIP_TRY(hipGetLastError());                                                                                 \
     return ILQG_OK;                                                                                             \
   }()
@@ -290,11 +303,12 @@ static ilqg_status launch_solve(ilqg_problem* p, int32_t batch, const void* x0, 
   sa.total_costs = (T*)total_costs; sa.iters = iters; sa.status = status; sa.converged = converged;
   sa.ws = (T*)workspace; sa.ws_stride = L.total; sa.fixed_iters = fixed_iters; sa.batch = batch;
   sa.prm = p->desc.params;
+  sa.prof = g_prof;
   size_t elems = C::LDS_ELEMS;
   const size_t e2 = rollout_lds_elems(d.n, d.m), e3 = quad_lds_elems(d.n, d.m, d.N, d.pairs.Rsz, d.pairs.rsz, d.num_terms);
   if (e2 > elems) elems = e2;
   if (e3 > elems) elems = e3;
-  const size_t lds = elems * sizeof(T);
+  const size_t lds = elems * sizeof(T) + quad_tables_bytes(d, sizeof(T));
   auto kern = ilq_solve_kernel<T, NX, NP, MU>;
   if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3(batch), dim3(C::NT), lds, stream, d, sa);
@@ -305,6 +319,9 @@ static ilqg_status launch_solve(ilqg_problem* p, int32_t batch, const void* x0, 
 extern "C" {
 
 const char* ilqg_last_error(void) { return g_err.c_str(); }
+
+// Diagnostics: device buffer [B][8] of int64 receiving per-stage shader-clock cycles of the next solves.
+void ilqg_debug_set_profile_buffer(void* buf) { g_prof = (long long*)buf; }
 
 // out = X^T Y + C for 16x16 column-major device matrices, through the MFMA accumulator-layout
 // path the LQ sweep uses (tests pin the register layouts with asymmetric inputs).
@@ -542,10 +559,67 @@ ilqg_status ilqg_problem_create(const ilqg_problem_desc* desc, ilqg_problem** ou
   if (e == hipSuccess) e = hipMalloc(&p->d_poly_pts, sizeof(float) * 2 * (npts > 0 ? npts : 1));
   if (e == hipSuccess && npts)
     e = hipMemcpy(p->d_poly_pts, desc->polyline_points, sizeof(float) * 2 * npts, hipMemcpyHostToDevice);
+  // LineSegment2 objects of every polyline, in both precisions (line_segment2.h:55-62)
+  std::vector<float> segs_f;
+  std::vector<double> segs_d;
+  {
+    auto emit = [&](auto& out, auto ax, auto ay, auto bx, auto by) {
+      using S = decltype(ax);
+      const S dx = ax - bx, dy = ay - by;
+      const S len = std::sqrt(dx * dx + dy * dy);
+      out.push_back(ax); out.push_back(ay); out.push_back(bx); out.push_back(by);
+      out.push_back(len); out.push_back((bx - ax) / len); out.push_back((by - ay) / len);
+    };
+    for (int q = 0; q < desc->num_polylines; q++) {
+      const int b0 = desc->polyline_offsets[q], e0 = desc->polyline_offsets[q + 1];
+      const float* pts = desc->polyline_points + 2 * b0;
+      const int nseg = e0 - b0 - 1;
+      for (int c = 0; c < nseg; c++) {
+        auto P = [&](int idx, int xy) { return pts[2 * idx + xy]; };
+        const int pm = c > 0 ? c - 1 : c, pn = c + 2 <= nseg ? c + 2 : c + 1;
+        emit(segs_f, P(c, 0), P(c, 1), P(c + 1, 0), P(c + 1, 1));
+        emit(segs_f, P(pm, 0), P(pm, 1), P(c + 1, 0), P(c + 1, 1));
+        emit(segs_f, P(c, 0), P(c, 1), P(pn, 0), P(pn, 1));
+        emit(segs_d, double(P(c, 0)), double(P(c, 1)), double(P(c + 1, 0)), double(P(c + 1, 1)));
+        emit(segs_d, double(P(pm, 0)), double(P(pm, 1)), double(P(c + 1, 0)), double(P(c + 1, 1)));
+        emit(segs_d, double(P(c, 0)), double(P(c, 1)), double(P(pn, 0)), double(P(pn, 1)));
+      }
+    }
+  }
+  d.total_segs = int(segs_f.size() / kSegStride);
+  // TotalCosts summation order per player: state costs then control costs, table order
+  int maxc = 0;
+  for (int i = 0; i < d.N; i++) {
+    int cnt = 0;
+    for (int ti = 0; ti < desc->num_terms; ti++)
+      if (dt[ti].player == i && (dt[ti].role == ILQG_ROLE_STATE_COST || dt[ti].role == ILQG_ROLE_CONTROL_COST)) cnt++;
+    if (cnt > maxc) maxc = cnt;
+  }
+  d.cost_order_stride = maxc + 1;
+  std::vector<int> order(size_t(d.N) * d.cost_order_stride, 0);
+  for (int i = 0; i < d.N; i++) {
+    int* o = order.data() + size_t(i) * d.cost_order_stride;
+    for (int role = 0; role < 2; role++)
+      for (int ti = 0; ti < desc->num_terms; ti++)
+        if (dt[ti].player == i && dt[ti].role == role) o[1 + o[0]++] = ti;
+  }
+  if (e == hipSuccess) e = hipMalloc(&p->d_segs_f, sizeof(float) * (segs_f.size() + 1));
+  if (e == hipSuccess && !segs_f.empty())
+    e = hipMemcpy(p->d_segs_f, segs_f.data(), sizeof(float) * segs_f.size(), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMalloc(&p->d_segs_d, sizeof(double) * (segs_d.size() + 1));
+  if (e == hipSuccess && !segs_d.empty())
+    e = hipMemcpy(p->d_segs_d, segs_d.data(), sizeof(double) * segs_d.size(), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMalloc(&p->d_cost_order, sizeof(int) * order.size());
+  if (e == hipSuccess) e = hipMemcpy(p->d_cost_order, order.data(), sizeof(int) * order.size(), hipMemcpyHostToDevice);
+  // the term table is uploaded last: it carries the scatter rounds computed above
+  if (e == hipSuccess) e = hipMemcpy(p->d_terms, dt.data(), sizeof(DevTerm) * dt.size(), hipMemcpyHostToDevice);
   if (e != hipSuccess) {
     ilqg_problem_destroy(p);
     return fail(ILQG_ERR_HIP, std::string("problem tables: ") + hipGetErrorString(e));
   }
+  d.segs_f = p->d_segs_f;
+  d.segs_d = p->d_segs_d;
+  d.cost_order = p->d_cost_order;
   d.terms = p->d_terms;
   d.poly_off = p->d_poly_off;
   d.poly_pts = p->d_poly_pts;
@@ -562,6 +636,9 @@ void ilqg_problem_destroy(ilqg_problem* p) {
   if (p->d_terms) (void)hipFree(p->d_terms);
   if (p->d_poly_off) (void)hipFree(p->d_poly_off);
   if (p->d_poly_pts) (void)hipFree(p->d_poly_pts);
+  if (p->d_segs_f) (void)hipFree(p->d_segs_f);
+  if (p->d_segs_d) (void)hipFree(p->d_segs_d);
+  if (p->d_cost_order) (void)hipFree(p->d_cost_order);
   delete p;
 }
 

@@ -60,12 +60,27 @@ struct DevProblem {
   int num_terms;
   const DevTerm* terms;
   int num_polylines;
-  const int* poly_off;
+  const int* poly_off;      // [num_polylines+1] offsets in points (segment s of polyline q is poly_off[q]-q+s)
   const float* poly_pts;
+  // LineSegment2 objects precomputed on the host in both precisions, 21 scalars per segment:
+  // [p1x p1y p2x p2y len ux uy | shortcut(prev.p1 -> p2) | shortcut(p1 -> next.p2)]
+  // (include/ilqgames/geometry/line_segment2.h:55-62; shortcuts: src/polyline2.cpp:126-133)
+  const float* segs_f;
+  const double* segs_d;
+  int total_segs;
+  // TotalCosts summation order: per player [count, term indices...] (state costs, then control costs)
+  const int* cost_order;
+  int cost_order_stride;
   int num_constraints;
   int num_rounds;
   PairTable pairs;
 };
+
+constexpr int kSegStride = 21;
+
+template <typename T> __device__ __forceinline__ const T* problem_segs(const DevProblem& p);
+template <> __device__ __forceinline__ const float* problem_segs<float>(const DevProblem& p) { return p.segs_f; }
+template <> __device__ __forceinline__ const double* problem_segs<double>(const DevProblem& p) { return p.segs_d; }
 
 template <typename T>
 __device__ __forceinline__ T sgn(T x) {
@@ -75,6 +90,22 @@ __device__ __forceinline__ T sgn(T x) {
 template <typename T>
 __device__ __forceinline__ T shfl(T v, int lane) {
   return __shfl(v, lane, 64);
+}
+
+// LDS-only synchronisation inside a stage.  A __syncthreads() also drains the vector-memory
+// queue (s_waitcnt vmcnt(0)), which stalls every step on the prefetch loads and the output stores
+// still in flight (~1-2k cycles each, measured).  Within one wavefront the LDS executes a wave's
+// DS operations in issue order, so a single-wave workgroup only needs the compiler not to reorder
+// them; multi-wave workgroups use a raw s_barrier behind an lgkmcnt-only wait.  Global-memory
+// hand-offs between lanes (stage boundaries) still use __syncthreads().
+__device__ __forceinline__ void lds_sync(bool single_wave) {
+  if (single_wave) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  } else {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
 }
 
 template <typename T>

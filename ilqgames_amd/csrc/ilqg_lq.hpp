@@ -140,7 +140,7 @@ __device__ __forceinline__ void qr_solve_columns(T (&col)[M], int lane, T (&x)[M
 // One instance, executed by a workgroup of LQCfg::NT threads.  `sm` is LDS scratch
 // of LQCfg::LDS_ELEMS elements.  All threads of the workgroup must call.
 template <typename T, int NX, int NP, int MU>
-__device__ void lq_feedback_instance(const LQArgs<T>& a, const PairTable& pt, T* sm) {
+__device__ __forceinline__ void lq_feedback_instance(const LQArgs<T>& a, const PairTable& pt, T* sm) {
   using C = LQCfg<T, NX, NP, MU>;
   constexpr int M = C::M, L = C::L, NT = C::NT, NXS = C::NXS;
   const int t = threadIdx.x;
@@ -213,7 +213,7 @@ __device__ void lq_feedback_instance(const LQArgs<T>& a, const PairTable& pt, T*
   // ---- terminal step: Z_i = Q_i[T-1], zeta_i = l_i[T-1]  (:102-105) ----
   issue(Tn - 1);
   commit();
-  __syncthreads();
+  lds_sync(NT <= 64);
   T z[NX];
   T zeta = T(0);
   if (zl) {
@@ -233,10 +233,10 @@ __device__ void lq_feedback_instance(const LQArgs<T>& a, const PairTable& pt, T*
     if (t < NX) a.scratch[size_t(Tn - 1) * SCR + NP * (NX + 1) + t] = T(0);
   }
   if (Tn >= 2) issue(Tn - 2);
-  __syncthreads();
+  lds_sync(NT <= 64);
   if (zl) sZeta[t] = zeta;
   if (Tn >= 2) commit();
-  __syncthreads();
+  lds_sync(NT <= 64);
 
 #pragma unroll 1
   for (int k = Tn - 2; k >= 0; k--) {
@@ -259,7 +259,7 @@ __device__ void lq_feedback_instance(const LQArgs<T>& a, const PairTable& pt, T*
         sYz[pi * MU + pc] = s + sr[pt.rgoff[pt.pii[pi]] + pc];
       }
     }
-    __syncthreads();
+    lds_sync(NT <= 64);
 
     // ---- P2: column `t` of [S | Y], Gershgorin, QR solve (wave 0) ----
     if (t < 64) {
@@ -320,7 +320,7 @@ __device__ void lq_feedback_instance(const LQArgs<T>& a, const PairTable& pt, T*
         }
       }
     }
-    __syncthreads();
+    lds_sync(NT <= 64);
 
     // ---- P3: F[:,c] = A[:,c] - B P[:,c]; beta = -B alpha ----
     T f[NX], pcol[M];
@@ -355,7 +355,7 @@ __device__ void lq_feedback_instance(const LQArgs<T>& a, const PairTable& pt, T*
       }
       a.scratch[size_t(k) * SCR + NP * NX + t] = acc;
     }
-    __syncthreads();
+    lds_sync(NT <= 64);
 
     // ---- P4: U_i[:,c] = F^T Z_i[:,c], stored transposed for row access ----
     if (zl) {
@@ -367,7 +367,7 @@ __device__ void lq_feedback_instance(const LQArgs<T>& a, const PairTable& pt, T*
         sUt[(pi * NX + r) * NXS + pc] = s;
       }
     }
-    __syncthreads();
+    lds_sync(NT <= 64);
 
     // ---- P5: Z_i'[:,c] = U_i F[:,c] + Q_i[:,c] + sum_j P_j^T R_ij P_j[:,c]; zeta update ----
     T zeta_new = T(0);
@@ -419,17 +419,18 @@ __device__ void lq_feedback_instance(const LQArgs<T>& a, const PairTable& pt, T*
         }
       }
     }
-    __syncthreads();
+    lds_sync(NT <= 64);
     if (zl) sZeta[t] = zeta_new;
     if (k > 0) commit();
-    __syncthreads();
+    lds_sync(NT <= 64);
   }
 
   // ---- forward pass: delta_xs (:217-241) + ExpectedDecrease (ilq_solver.cpp:364-398) ----
   if (!want_fwd) return;
+  __syncthreads();  // scratch rows written by other lanes during the sweep
   if (t < NX) sX[t] = a.x0 ? a.x0[t] : T(0);
   T ed = T(0);
-  __syncthreads();
+  lds_sync(NT <= 64);
 #pragma unroll 1
   for (int k = 0; k < Tn; k++) {
     // stage A_k (coalesced) into the image's A slot
@@ -450,16 +451,16 @@ __device__ void lq_feedback_instance(const LQArgs<T>& a, const PairTable& pt, T*
         if (k > 0) ed -= shfl(st, i);
       }
     }
-    __syncthreads();
+    lds_sync(NT <= 64);
     T xn = T(0);
     if (t < NX) {
 #pragma unroll
       for (int c = 0; c < NX; c++) xn += sA[t + NX * c] * sX[c];
       xn += a.scratch[size_t(k) * SCR + NP * (NX + 1) + t];  // beta_k = -B alpha_k
     }
-    __syncthreads();
+    lds_sync(NT <= 64);
     if (t < NX) sX[t] = xn;
-    __syncthreads();
+    lds_sync(NT <= 64);
   }
   if (a.ed_out && t == 0) *a.ed_out = ed;
 }
@@ -472,7 +473,7 @@ __device__ void lq_feedback_instance(const LQArgs<T>& a, const PairTable& pt, T*
 // The Nash-system assembly, Gershgorin step, QR solve and forward pass are shared code paths.
 // ---------------------------------------------------------------------------
 template <typename T, int NX, int NP, int MU>
-__device__ void lq_feedback_instance_mfma(const LQArgs<T>& a, const PairTable& pt, T* sm) {
+__device__ __forceinline__ void lq_feedback_instance_mfma(const LQArgs<T>& a, const PairTable& pt, T* sm) {
   using C = LQCfg<T, NX, NP, MU>;
   using TL = Tile<T>;
   using vec = typename TL::vec;
@@ -560,7 +561,7 @@ __device__ void lq_feedback_instance_mfma(const LQArgs<T>& a, const PairTable& p
   // ---- terminal step: Yd_i = D-layout(Q_i[T-1]^T), zeta_i = l_i[T-1] ----
   issue(Tn - 1);
   commit();
-  __syncthreads();
+  lds_sync(NT <= 64);
   vec Yd[NP];
 #pragma unroll
   for (int i = 0; i < NP; i++)
@@ -575,10 +576,10 @@ __device__ void lq_feedback_instance_mfma(const LQArgs<T>& a, const PairTable& p
     if (t < NX) a.scratch[size_t(Tn - 1) * SCR + NP * (NX + 1) + t] = T(0);
   }
   if (Tn >= 2) issue(Tn - 2);
-  __syncthreads();
+  lds_sync(NT <= 64);
   if (zl) sZeta[t] = zeta;
   if (Tn >= 2) commit();
-  __syncthreads();
+  lds_sync(NT <= 64);
 
 #pragma unroll 1
   for (int k = Tn - 2; k >= 0; k--) {
@@ -590,7 +591,7 @@ __device__ void lq_feedback_instance_mfma(const LQArgs<T>& a, const PairTable& p
     for (int i = 0; i < NP; i++) {
 #pragma unroll
       for (int r = 0; r < 4; r++) sTr[rowi[r] * 17 + j] = Yd[i][r];
-      __syncthreads();
+      lds_sync(NT <= 64);
       T zd[4];
 #pragma unroll
       for (int r = 0; r < 4; r++) zd[r] = sTr[j * 17 + rowi[r]];  // Z_i[row][j]
@@ -603,7 +604,7 @@ __device__ void lq_feedback_instance_mfma(const LQArgs<T>& a, const PairTable& p
         s = xgroup_sum(s);
         if (g == 0 && jok) sBZ[(i * MU + aa) + M * j] = s;
       }
-      __syncthreads();
+      lds_sync(NT <= 64);
     }
     if (t < M) {
       const int i = t / MU, aa = t % MU;
@@ -612,7 +613,7 @@ __device__ void lq_feedback_instance_mfma(const LQArgs<T>& a, const PairTable& p
       for (int r = 0; r < NX; r++) s += sB[r + NX * t] * sZeta[i * NX + r];
       sYz[t] = s + sr[pt.rgoff[pt.pii[i]] + aa];
     }
-    __syncthreads();
+    lds_sync(NT <= 64);
 
     // ---- P2: column `t` of [S | Y], Gershgorin, QR solve ----
     {
@@ -671,7 +672,7 @@ __device__ void lq_feedback_instance_mfma(const LQArgs<T>& a, const PairTable& p
         }
       }
     }
-    __syncthreads();
+    lds_sync(NT <= 64);
 
     // ---- P3: Fd = D-layout(A - B P); beta = -B alpha ----
     vec Fd;
@@ -709,7 +710,7 @@ __device__ void lq_feedback_instance_mfma(const LQArgs<T>& a, const PairTable& p
       }
       a.scratch[size_t(k) * SCR + NP * NX + t] = acc;
     }
-    __syncthreads();
+    lds_sync(NT <= 64);
 
     // ---- P4/P5 per player: zeta update (uses the old Z_i), then Yd_i <- (Z_i F)^T F + C_i ----
     T zeta_new[NP];
@@ -722,7 +723,7 @@ __device__ void lq_feedback_instance_mfma(const LQArgs<T>& a, const PairTable& p
         if (rowok[r]) zb += Yd[i][r] * sBeta[rowi[r]];
       zb = xgroup_sum(zb);
       if (g == 0) sTv[j] = jok ? sZeta[i * NX + j] + zb : T(0);
-      __syncthreads();
+      lds_sync(NT <= 64);
       // (F^T t)[j] = sum_rho F[rho][j] t[rho]
       T ft = T(0);
 #pragma unroll
@@ -769,21 +770,22 @@ __device__ void lq_feedback_instance_mfma(const LQArgs<T>& a, const PairTable& p
       vec Wd = {T(0), T(0), T(0), T(0)};
       Wd = tile_xty<T>(Yd[i], Fd, Wd);   // Z_i F
       Yd[i] = tile_xty<T>(Wd, Fd, Cd);   // (Z_i F)^T F + C_i
-      __syncthreads();
+      lds_sync(NT <= 64);
     }
     if (g == 0 && jok) {
 #pragma unroll
       for (int i = 0; i < NP; i++) sZeta[i * NX + j] = zeta_new[i];
     }
     if (k > 0) commit();
-    __syncthreads();
+    lds_sync(NT <= 64);
   }
 
   // ---- forward pass (identical to the VALU variant) ----
   if (!want_fwd) return;
+  __syncthreads();  // scratch rows written by other lanes during the sweep
   if (t < NX) sX[t] = a.x0 ? a.x0[t] : T(0);
   T ed = T(0);
-  __syncthreads();
+  lds_sync(NT <= 64);
 #pragma unroll 1
   for (int k = 0; k < Tn; k++) {
     for (int e = t; e < NX * NX; e += NT) sA[e] = a.A[size_t(k) * NX * NX + e];
@@ -803,30 +805,28 @@ __device__ void lq_feedback_instance_mfma(const LQArgs<T>& a, const PairTable& p
         if (k > 0) ed -= shfl(st, i);
       }
     }
-    __syncthreads();
+    lds_sync(NT <= 64);
     T xn = T(0);
     if (t < NX) {
 #pragma unroll
       for (int c = 0; c < NX; c++) xn += sA[t + NX * c] * sX[c];
       xn += a.scratch[size_t(k) * SCR + NP * (NX + 1) + t];
     }
-    __syncthreads();
+    lds_sync(NT <= 64);
     if (t < NX) sX[t] = xn;
-    __syncthreads();
+    lds_sync(NT <= 64);
   }
   if (a.ed_out && t == 0) *a.ed_out = ed;
 }
 
 // Dispatch: MFMA formulation where the state fits one 16x16 tile, VALU/LDS formulation otherwise.
-template <typename T, int NX, int NP, int MU>
-__device__ __forceinline__ void lq_feedback_dispatch(const LQArgs<T>& a, const PairTable& pt, T* sm, bool force_valu) {
-  if constexpr (LQCfg<T, NX, NP, MU>::USE_MFMA) {
-    if (!force_valu) {
-      lq_feedback_instance_mfma<T, NX, NP, MU>(a, pt, sm);
-      return;
-    }
+template <typename T, int NX, int NP, int MU, bool FORCE_VALU = false>
+__device__ __forceinline__ void lq_feedback_dispatch(const LQArgs<T>& a, const PairTable& pt, T* sm) {
+  if constexpr (LQCfg<T, NX, NP, MU>::USE_MFMA && !FORCE_VALU) {
+    lq_feedback_instance_mfma<T, NX, NP, MU>(a, pt, sm);
+  } else {
+    lq_feedback_instance<T, NX, NP, MU>(a, pt, sm);
   }
-  lq_feedback_instance<T, NX, NP, MU>(a, pt, sm);
 }
 
 }  // namespace ilqg

@@ -303,20 +303,38 @@ struct Closest {
   Seg<T> seg;
 };
 
-// Polyline2::ClosestPoint, src/polyline2.cpp:105-174 — linear scan over the
-// 1..15 segments of a lane; the "shortcut" sign rule at interior vertices and the
-// 1e-4 endpoint rule are reproduced.
 template <typename T>
-__device__ Closest<T> polyline_closest(const float* pts, int npts, T qx, T qy) {
+__device__ __forceinline__ Seg<T> load_seg(const T* s) {
+  Seg<T> o;
+  o.p1x = s[0]; o.p1y = s[1]; o.p2x = s[2]; o.p2y = s[3]; o.len = s[4]; o.ux = s[5]; o.uy = s[6];
+  return o;
+}
+
+// Device-side tables the cost stages read (LDS-resident in the kernels).
+template <typename T>
+struct QuadTables {
+  const DevTerm* terms;  // [num_terms]
+  const T* segs;         // [total_segs][kSegStride]
+  const int* poly_off;   // [num_polylines + 1]
+  const int* order;      // [N][cost_order_stride]
+};
+
+// Polyline2::ClosestPoint, src/polyline2.cpp:105-174 — linear scan over the 1..15 segments of a
+// lane; the "shortcut" sign rule at interior vertices and the 1e-4 endpoint rule are reproduced.
+// Segments (and the shortcut segments of interior vertices) are precomputed LineSegment2 objects.
+template <typename T>
+__device__ __forceinline__ Closest<T> polyline_closest(const QuadTables<T>& tb, int poly, T qx, T qy) {
+  const int first = tb.poly_off[poly] - poly;  // segments before this polyline
+  const int nseg = tb.poly_off[poly + 1] - tb.poly_off[poly] - 1;
+  const T* base = tb.segs + size_t(first) * kSegStride;
   Closest<T> out;
   T best = dinf<T>();
   out.cx = T(0);
   out.cy = T(0);
   out.is_vertex = false;
-  const int nseg = npts - 1;
   int best_idx = 0;
   for (int c = 0; c < nseg; c++) {
-    const Seg<T> s = make_seg<T>(T(pts[2 * c]), T(pts[2 * c + 1]), T(pts[2 * c + 2]), T(pts[2 * c + 3]));
+    const Seg<T> s = load_seg<T>(base + c * kSegStride);
     T px, py, cur;
     bool se;
     seg_closest(s, qx, qy, &px, &py, &se, &cur);
@@ -324,8 +342,7 @@ __device__ Closest<T> polyline_closest(const float* pts, int npts, T qx, T qy) {
       const bool at2 = (px == s.p2x && py == s.p2y);
       const bool at1 = (px == s.p1x && py == s.p1y);
       if (se && (c > 0 || at2) && (c < nseg - 1 || at1)) {
-        const Seg<T> sc = at1 ? make_seg<T>(T(pts[2 * c - 2]), T(pts[2 * c - 1]), s.p2x, s.p2y)
-                              : make_seg<T>(s.p1x, s.p1y, T(pts[2 * c + 4]), T(pts[2 * c + 5]));
+        const Seg<T> sc = load_seg<T>(base + c * kSegStride + (at1 ? 7 : 14));
         cur *= seg_side(sc, qx, qy) ? sgn(cur) : -sgn(cur);
       }
       best = cur;
@@ -335,11 +352,11 @@ __device__ Closest<T> polyline_closest(const float* pts, int npts, T qx, T qy) {
       best_idx = c;
     }
   }
-  out.seg = make_seg<T>(T(pts[2 * best_idx]), T(pts[2 * best_idx + 1]), T(pts[2 * best_idx + 2]),
-                        T(pts[2 * best_idx + 3]));
+  out.seg = load_seg<T>(base + best_idx * kSegStride);
   out.ssd = best;
-  const T ax = out.cx - T(pts[0]), ay = out.cy - T(pts[1]);
-  const T bx = out.cx - T(pts[2 * nseg]), by = out.cy - T(pts[2 * nseg + 1]);
+  const Seg<T> s0 = load_seg<T>(base), sl = load_seg<T>(base + (nseg - 1) * kSegStride);
+  const T ax = out.cx - s0.p1x, ay = out.cy - s0.p1y;
+  const T bx = out.cx - sl.p2x, by = out.cy - sl.p2y;
   out.is_endpoint = (ax * ax + ay * ay < T(1e-4f)) || (bx * bx + by * by < T(1e-4f));
   return out;
 }
@@ -355,8 +372,8 @@ __device__ __forceinline__ T constraint_mu(T lambda, T g, T mu) {
 }
 
 template <typename T>
-__device__ T term_evaluate_leaf(const DevProblem& p, int ti, const T* v, int dim) {
-  const DevTerm c = p.terms[ti];
+__device__ __forceinline__ T term_evaluate_leaf(const QuadTables<T>& tb, int ti, const T* v, int dim) {
+  const DevTerm c = tb.terms[ti];
   const T w = T(c.weight), val = T(c.value);
   const bool oriented = c.flags & ILQG_FLAG_ORIENTED;
   switch (c.kind) {
@@ -375,16 +392,12 @@ __device__ T term_evaluate_leaf(const DevProblem& p, int ti, const T* v, int dim
       return T(0);
     }
     case ILQG_COST_QUADRATIC_POLYLINE2: {  // src/quadratic_polyline2_cost.cpp:52-69
-      const float* pts = p.poly_pts + 2 * p.poly_off[c.polyline];
-      const Closest<T> cl = polyline_closest<T>(pts, p.poly_off[c.polyline + 1] - p.poly_off[c.polyline],
-                                                v[c.idx[0]], v[c.idx[1]]);
+      const Closest<T> cl = polyline_closest<T>(tb, c.polyline, v[c.idx[0]], v[c.idx[1]]);
       const T ssd = cl.is_endpoint ? T(0) : cl.ssd;
       return T(0.5) * w * t_abs(ssd);
     }
     case ILQG_COST_SEMIQUADRATIC_POLYLINE2: {  // src/semiquadratic_polyline2_cost.cpp:52-74
-      const float* pts = p.poly_pts + 2 * p.poly_off[c.polyline];
-      const Closest<T> cl = polyline_closest<T>(pts, p.poly_off[c.polyline + 1] - p.poly_off[c.polyline],
-                                                v[c.idx[0]], v[c.idx[1]]);
+      const Closest<T> cl = polyline_closest<T>(tb, c.polyline, v[c.idx[0]], v[c.idx[1]]);
       if (cl.is_endpoint) return T(0);
       const T sst = sgn(val) * val * val;
       const bool active = (cl.ssd > sst && oriented) || (cl.ssd < sst && !oriented);
@@ -418,12 +431,12 @@ __device__ T term_evaluate_leaf(const DevProblem& p, int ti, const T* v, int dim
 
 // ExtremeValueCost::ExtremeCost, src/extreme_value_cost.cpp:66-85: index of the active child.
 template <typename T>
-__device__ int extreme_child(const DevProblem& p, const DevTerm& c, const T* v, int dim, T* value_out) {
+__device__ __forceinline__ int extreme_child(const QuadTables<T>& tb, const DevTerm& c, const T* v, int dim, T* value_out) {
   const bool is_min = c.flags & ILQG_FLAG_IS_MIN;
   T ext = is_min ? dinf<T>() : -dinf<T>();
   int best = c.child_begin;
   for (int q = 0; q < c.child_count; q++) {
-    const T value = term_evaluate_leaf(p, c.child_begin + q, v, dim);
+    const T value = term_evaluate_leaf(tb, c.child_begin + q, v, dim);
     if ((is_min && value < ext) || (!is_min && value > ext)) {
       ext = value;
       best = c.child_begin + q;
@@ -431,16 +444,6 @@ __device__ int extreme_child(const DevProblem& p, const DevTerm& c, const T* v, 
   }
   *value_out = ext;
   return best;
-}
-
-template <typename T>
-__device__ T term_evaluate(const DevProblem& p, int ti, const T* v, int dim) {
-  if (p.terms[ti].kind == ILQG_COST_EXTREME_VALUE) {  // src/extreme_value_cost.cpp:51-56
-    T value;
-    extreme_child(p, p.terms[ti], v, dim, &value);
-    return value;
-  }
-  return term_evaluate_leaf(p, ti, v, dim);
 }
 
 // Constraint::ModifyDerivatives, src/constraint.cpp:63-89
@@ -483,8 +486,8 @@ struct TermOut {
 // Cost::Evaluate + Cost::Quadraticize of one LEAF term in one pass (the polyline closest-point
 // search is shared).  `lambda`, `mu`: augmented-Lagrangian state of a constraint term.
 template <typename T>
-__device__ void term_compute_leaf(const DevProblem& p, const DevTerm& c, const T* v, T lambda, T mu,
-                                  TermOut<T>* o) {
+__device__ __forceinline__ void term_compute_leaf(const QuadTables<T>& tb, const DevTerm& c, const T* v, T lambda,
+                                                  T mu, TermOut<T>* o) {
   const T w = T(c.weight), val = T(c.value);
   const bool oriented = c.flags & ILQG_FLAG_ORIENTED;
   o->pattern = PAT_NONE;
@@ -522,8 +525,7 @@ __device__ void term_compute_leaf(const DevProblem& p, const DevTerm& c, const T
     case ILQG_COST_SEMIQUADRATIC_POLYLINE2: {  // src/semiquadratic_polyline2_cost.cpp:52-142
       const bool semi = c.kind == ILQG_COST_SEMIQUADRATIC_POLYLINE2;
       const T px = v[c.idx[0]], py = v[c.idx[1]];
-      const float* pts = p.poly_pts + 2 * p.poly_off[c.polyline];
-      const Closest<T> cl = polyline_closest<T>(pts, p.poly_off[c.polyline + 1] - p.poly_off[c.polyline], px, py);
+      const Closest<T> cl = polyline_closest<T>(tb, c.polyline, px, py);
       T dx, dy;
       if (semi) {
         const T sst = sgn(val) * val * val;
@@ -624,16 +626,17 @@ __device__ void term_compute_leaf(const DevProblem& p, const DevTerm& c, const T
 
 // Top-level term: ExtremeValueCost dispatches to its active child (src/extreme_value_cost.cpp:51-85).
 template <typename T>
-__device__ void term_compute(const DevProblem& p, const DevTerm& c, const T* v, T lambda, T mu, TermOut<T>* o) {
+__device__ __forceinline__ void term_compute(const QuadTables<T>& tb, const DevTerm& c, const T* v, T lambda, T mu,
+                                             TermOut<T>* o) {
   if (c.kind == ILQG_COST_EXTREME_VALUE) {
     T value;
-    const int best = extreme_child(p, c, v, c.arg_dim, &value);
-    const DevTerm child = p.terms[best];
-    term_compute_leaf<T>(p, child, v, lambda, mu, o);
+    const int best = extreme_child(tb, c, v, c.arg_dim, &value);
+    const DevTerm child = tb.terms[best];
+    term_compute_leaf<T>(tb, child, v, lambda, mu, o);
     o->value = value;
     return;
   }
-  term_compute_leaf<T>(p, c, v, lambda, mu, o);
+  term_compute_leaf<T>(tb, c, v, lambda, mu, o);
 }
 
 // Scatter one term's contribution into its LDS tiles (H column-major with leading dim ld).

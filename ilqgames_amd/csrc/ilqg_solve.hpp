@@ -30,6 +30,7 @@ struct SolveArgs {
   int fixed_iters;
   int batch;
   ilqg_solver_params prm;
+  long long* prof;      // optional [B][8] shader-clock cycles per stage (diagnostics) or nullptr
 };
 
 // Per-instance workspace layout (in elements of T).
@@ -61,18 +62,27 @@ struct WsLayout {
   }
 };
 
+// The loop is written as a small stage interpreter so that each heavy stage (rollout, the
+// per-step linearise+quadraticise, the LQ sweep) is instantiated — and inlined — exactly once
+// in the persistent kernel; all transitions are wave-uniform.
 template <typename T, int NX, int NP, int MU>
-__device__ void ilq_solve_instance(const DevProblem& p, const SolveArgs<T>& sa, int b, T* sm) {
-  const int n = NX, N = NP, m = NP * MU, Tn = p.T;
+__device__ __forceinline__ void ilq_solve_instance(const DevProblem& p, const QuadTables<T>& tb, const SolveArgs<T>& sa,
+                                                   int b, T* sm) {
+  constexpr int n = NX, N = NP, m = NP * MU;
+  const int Tn = p.T;
   const PairTable& pt = p.pairs;
   const ilqg_solver_params& prm = sa.prm;
   const WsLayout L(n, m, N, Tn, pt.Rsz, pt.rsz);
   T* w = sa.ws + size_t(b) * sa.ws_stride;
   // two operating-point buffers and two strategy buffers; buffer 0 is the caller's
-  T* xsb[2] = {sa.xs + size_t(b) * Tn * n, w + L.xs1};
-  T* usb[2] = {sa.us + size_t(b) * Tn * m, w + L.us1};
-  T* Pb[2] = {sa.P + size_t(b) * Tn * m * n, w + L.P1};
-  T* alb[2] = {sa.alpha + size_t(b) * Tn * m, w + L.al1};
+  T* const xs0 = sa.xs + size_t(b) * Tn * n;
+  T* const us0 = sa.us + size_t(b) * Tn * m;
+  T* const P0 = sa.P + size_t(b) * Tn * m * n;
+  T* const al0 = sa.alpha + size_t(b) * Tn * m;
+  auto XS = [&](int i) { return i ? w + L.xs1 : xs0; };
+  auto US = [&](int i) { return i ? w + L.us1 : us0; };
+  auto PB = [&](int i) { return i ? w + L.P1 : P0; };
+  auto AL = [&](int i) { return i ? w + L.al1 : al0; };
   int* t_extreme = reinterpret_cast<int*>(w + L.ints);
   const T* x0 = sa.x0 + size_t(b) * n;
   T* costs = sa.total_costs + size_t(b) * N;
@@ -81,129 +91,146 @@ __device__ void ilq_solve_instance(const DevProblem& p, const SolveArgs<T>& sa, 
   if (t < N) t_extreme[t] = 0;  // PlayerCost::time_of_extreme_cost_ starts at 0 (player_cost.h:70)
   __syncthreads();
 
-  QuadArgs<T> qa;
-  qa.lambdas = nullptr;
-  qa.mu = T(10);
-  qa.t_extreme = t_extreme;
-  qa.t_init = 0.0;
-  qa.A = w + L.A;
-  qa.Bm = w + L.B;
-  qa.Q = w + L.Q;
-  qa.l = w + L.l;
-  qa.R = w + L.R;
-  qa.r = w + L.r;
-  qa.merit_part = w + L.mpart;
-  qa.cost_part = w + L.cpart;
+  long long pr_acc[4] = {0, 0, 0, 0};
+  const long long pr_start = clock64();
 
+  enum { ST_ROLLOUT = 0, ST_QUAD = 1, ST_LQ = 2, ST_DONE = 3 };
+  enum { Q_COSTS = 0, Q_INIT = 1, Q_TRIAL = 2, Q_LIN = 3 };
+  int stage = ST_ROLLOUT, qmode = Q_COSTS;
+  bool initial = true;
   int cur = 0;   // op buffer holding the current (last accepted) operating point
   int sacc = 0;  // strategy buffer holding the last accepted strategies
-  T acc_scale = T(1);
-
-  // ---- initial rollout from the warm start (:100-104) ----
-  {
-    RolloutArgs<T> ra{x0, xsb[0], usb[0], Pb[0], alb[0], T(1), xsb[1], usb[1]};
-    rollout_instance<T>(p, ra, sm);
-    cur = 1;
-  }
-  // TotalCosts (:107) then quadraticise (:116) — costs first: they set t_extreme.
-  {
-    QuadArgs<T> qc = qa;
-    qc.xs = xsb[cur];
-    qc.us = usb[cur];
-    qc.A = nullptr;
-    qc.Q = nullptr;
-    qc.merit_part = nullptr;
-    for (int k = 0; k < Tn; k++) linquad_step<T>(p, qc, k, sm);
-    costs_reduce<T>(p, w + L.cpart, costs, t_extreme);
-    QuadArgs<T> qq = qa;
-    qq.xs = xsb[cur];
-    qq.us = usb[cur];
-    qq.cost_part = nullptr;
-    for (int k = 0; k < Tn; k++) linquad_step<T>(p, qq, k, sm);
-  }
-
-  T last_merit = dinf<T>();
-  int num_iterations = 0;
+  T acc_scale = T(1), step = T(1);
+  T last_merit = dinf<T>(), expected_decrease = dinf<T>();
+  int num_iterations = 0, bt = 0;
   bool has_converged = false, ok = true;
   const int max_iters = sa.fixed_iters > 0 ? sa.fixed_iters : prm.max_solver_iters;
-  while (num_iterations < max_iters && (sa.fixed_iters > 0 || !has_converged)) {
-    num_iterations++;
-    // ---- LQ game at the current operating point (:136-143) + ExpectedDecrease (:303) ----
-    const int snew = 1 - sacc;
-    LQArgs<T> la;
-    la.A = w + L.A;
-    la.Bm = w + L.B;
-    la.Q = w + L.Q;
-    la.l = w + L.l;
-    la.R = w + L.R;
-    la.r = w + L.r;
-    la.x0 = nullptr;
-    la.P = Pb[snew];
-    la.alpha = alb[snew];
-    la.dx = w + L.dx;
-    la.scratch = w + L.lqscr;
-    la.ed_out = sm + LQCfg<T, NX, NP, MU>::oX;  // any LDS slot free at the end of the sweep
-    la.T_steps = Tn;
-    la.adaptive = 1;
-    lq_feedback_dispatch<T, NX, NP, MU>(la, pt, sm, false);
-    __syncthreads();
-    const T expected_decrease = sm[LQCfg<T, NX, NP, MU>::oX];
-    __syncthreads();
 
-    // ---- line search (:309-347) ----
-    T step = T(prm.initial_alpha_scaling);
-    {
-      RolloutArgs<T> ra{xsb[cur], xsb[cur], usb[cur], Pb[snew], alb[snew], step, xsb[1 - cur], usb[1 - cur]};
+#pragma unroll 1
+  while (stage != ST_DONE) {
+    __syncthreads();  // stage boundary: global-memory hand-off between lanes
+    const long long pr_t0 = clock64();
+    const int stage_was = stage;
+    if (stage == ST_ROLLOUT) {
+      // initial: from the warm start (:100-104); later: trial point of the line search (:309-342)
+      const int snew = 1 - sacc;
+      RolloutArgs<T> ra;
+      ra.x0 = initial ? x0 : XS(cur);
+      ra.xs_ref = initial ? XS(0) : XS(cur);
+      ra.us_ref = initial ? US(0) : US(cur);
+      ra.P = initial ? PB(0) : PB(snew);
+      ra.alpha = initial ? AL(0) : AL(snew);
+      ra.alpha_scale = initial ? T(1) : step;
+      ra.xs = initial ? XS(1) : XS(1 - cur);
+      ra.us = initial ? US(1) : US(1 - cur);
       rollout_instance<T>(p, ra, sm);
-    }
-    bool accepted = !prm.linesearch;
-    if (!prm.linesearch) {
-      // the reference re-linearises every iteration but never re-quadraticises (:322)
-      QuadArgs<T> ql = qa;
-      ql.xs = xsb[1 - cur];
-      ql.us = usb[1 - cur];
-      ql.Q = nullptr;
-      ql.merit_part = nullptr;
-      for (int k = 0; k < Tn; k++) linquad_step<T>(p, ql, k, sm);
-    } else {
-      for (int bt = 0; bt < prm.max_backtracking_steps; bt++) {
-        QuadArgs<T> qt = qa;
-        qt.xs = xsb[1 - cur];
-        qt.us = usb[1 - cur];
-        for (int k = 0; k < Tn; k++) linquad_step<T>(p, qt, k, sm);
-        const T merit = merit_reduce<T>(p, w + L.mpart, sm);
-        const T scaled = T(prm.expected_decrease_fraction) * step * expected_decrease;
-        if (last_merit - merit >= scaled) {  // CheckArmijoCondition :350-362
-          const T diff = last_merit - merit;
-          has_converged = (merit <= last_merit) && ((diff < T(0) ? -diff : diff) < T(prm.convergence_tolerance));
-          last_merit = merit;
-          accepted = true;
-          break;
-        }
-        step *= T(prm.geometric_alpha_scaling);
-        RolloutArgs<T> ra{xsb[cur], xsb[cur], usb[cur], Pb[snew], alb[snew], step, xsb[1 - cur], usb[1 - cur]};
-        rollout_instance<T>(p, ra, sm);
+      if (initial) {
+        cur = 1;
+        qmode = Q_COSTS;  // TotalCosts (:107) before quadraticising (:116): costs set t_extreme
+      } else {
+        qmode = prm.linesearch ? Q_TRIAL : Q_LIN;
       }
+      stage = ST_QUAD;
+    } else if (stage == ST_QUAD) {
+      const int at = (qmode == Q_COSTS || qmode == Q_INIT) ? cur : 1 - cur;
+      QuadArgs<T> qa;
+      qa.xs = XS(at);
+      qa.us = US(at);
+      qa.lambdas = nullptr;
+      qa.mu = T(10);
+      qa.t_extreme = t_extreme;
+      qa.t_init = 0.0;
+      const bool lin = qmode != Q_COSTS, quad = qmode == Q_INIT || qmode == Q_TRIAL;
+      qa.A = lin ? w + L.A : nullptr;
+      qa.Bm = lin ? w + L.B : nullptr;
+      qa.Q = quad ? w + L.Q : nullptr;
+      qa.l = quad ? w + L.l : nullptr;
+      qa.R = quad ? w + L.R : nullptr;
+      qa.r = quad ? w + L.r : nullptr;
+      qa.merit_part = qmode == Q_TRIAL ? w + L.mpart : nullptr;
+      qa.cost_part = (qmode == Q_COSTS || qmode == Q_TRIAL || qmode == Q_LIN) ? w + L.cpart : nullptr;
+#pragma unroll 1
+      for (int k = 0; k < Tn; k++) linquad_step<T>(p, tb, qa, k, sm);
+      if (qmode == Q_COSTS) {
+        costs_reduce<T>(p, w + L.cpart, costs, t_extreme);
+        qmode = Q_INIT;
+      } else if (qmode == Q_INIT) {
+        initial = false;
+        stage = (num_iterations < max_iters) ? ST_LQ : ST_DONE;
+      } else {
+        bool accepted = true;
+        if (qmode == Q_TRIAL) {
+          const T merit = merit_reduce<T>(p, w + L.mpart, sm);
+          const T scaled = T(prm.expected_decrease_fraction) * step * expected_decrease;
+          accepted = (last_merit - merit >= scaled);  // CheckArmijoCondition :350-362
+          if (accepted) {
+            const T diff = last_merit - merit;
+            has_converged =
+                (merit <= last_merit) && ((diff < T(0) ? -diff : diff) < T(prm.convergence_tolerance));
+            last_merit = merit;
+          }
+        }
+        if (accepted) {
+          cur = 1 - cur;
+          sacc = 1 - sacc;
+          acc_scale = step;
+          costs_reduce<T>(p, w + L.cpart, costs, t_extreme);  // TotalCosts of the accepted iterate (:158)
+          stage = (num_iterations < max_iters && (sa.fixed_iters > 0 || !has_converged)) ? ST_LQ : ST_DONE;
+        } else {
+          bt++;
+          if (bt >= prm.max_backtracking_steps) {  // :346-347, :146-155 — keep the last accepted iterate
+            ok = false;
+            stage = ST_DONE;
+          } else {
+            step *= T(prm.geometric_alpha_scaling);
+            stage = ST_ROLLOUT;
+          }
+        }
+      }
+    } else {  // ST_LQ: LQ game at the current operating point (:136-143) + ExpectedDecrease (:303)
+      num_iterations++;
+      LQArgs<T> la;
+      la.A = w + L.A;
+      la.Bm = w + L.B;
+      la.Q = w + L.Q;
+      la.l = w + L.l;
+      la.R = w + L.R;
+      la.r = w + L.r;
+      la.x0 = nullptr;
+      la.P = PB(1 - sacc);
+      la.alpha = AL(1 - sacc);
+      la.dx = w + L.dx;
+      la.scratch = w + L.lqscr;
+      la.ed_out = sm + LQCfg<T, NX, NP, MU>::oX;  // an LDS slot that is free once the sweep ends
+      la.T_steps = Tn;
+      la.adaptive = 1;
+      lq_feedback_dispatch<T, NX, NP, MU>(la, pt, sm);
+      __syncthreads();
+      expected_decrease = sm[LQCfg<T, NX, NP, MU>::oX];
+      __syncthreads();
+      step = T(prm.initial_alpha_scaling);
+      bt = 0;
+      stage = ST_ROLLOUT;
     }
-    if (!accepted) {  // :146-155 — keep the last accepted iterate
-      ok = false;
-      break;
-    }
-    cur = 1 - cur;
-    sacc = snew;
-    acc_scale = step;
-    costs_reduce<T>(p, w + L.cpart, costs, t_extreme);  // TotalCosts of the accepted iterate (:158)
+    pr_acc[stage_was] += clock64() - pr_t0;
   }
 
   // ---- hand the result back through buffer 0 ----
   __syncthreads();
   if (cur == 1) {
-    for (int e = t; e < Tn * n; e += blockDim.x) xsb[0][e] = xsb[1][e];
-    for (int e = t; e < Tn * m; e += blockDim.x) usb[0][e] = usb[1][e];
+    for (int e = t; e < Tn * n; e += blockDim.x) xs0[e] = (w + L.xs1)[e];
+    for (int e = t; e < Tn * m; e += blockDim.x) us0[e] = (w + L.us1)[e];
   }
   if (sacc == 1)
-    for (int e = t; e < Tn * m * n; e += blockDim.x) Pb[0][e] = Pb[1][e];
-  for (int e = t; e < Tn * m; e += blockDim.x) alb[0][e] = alb[sacc][e] * acc_scale;
+    for (int e = t; e < Tn * m * n; e += blockDim.x) P0[e] = (w + L.P1)[e];
+  {
+    const T* src = AL(sacc);
+    for (int e = t; e < Tn * m; e += blockDim.x) al0[e] = src[e] * acc_scale;
+  }
+  if (t == 0 && sa.prof) {
+    long long* o = sa.prof + size_t(b) * 8;
+    o[0] = pr_acc[0]; o[1] = pr_acc[1]; o[2] = pr_acc[2]; o[3] = 0; o[4] = clock64() - pr_start;
+  }
   if (t == 0) {
     sa.iters[b] = num_iterations;
     sa.status[b] = ok ? 1 : 0;

@@ -31,7 +31,7 @@ struct RolloutArgs {
 __host__ __device__ inline int rollout_lds_elems(int n, int m) { return 2 * n + 2 * m + m * n + m + n; }
 
 template <typename T>
-__device__ void rollout_instance(const DevProblem& p, const RolloutArgs<T>& a, T* sm) {
+__device__ __forceinline__ void rollout_instance(const DevProblem& p, const RolloutArgs<T>& a, T* sm) {
   const int n = p.n, m = p.m, N = p.N, Tn = p.T;
   const int t = threadIdx.x, NT = blockDim.x;
   T* sx = sm;             // [n] current state
@@ -96,7 +96,7 @@ __device__ void rollout_instance(const DevProblem& p, const RolloutArgs<T>& a, T
           a.xs[size_t(k) * n + xo + e] = xj[e];
         }
     }
-    __syncthreads();
+    lds_sync(NT <= 64);
     if (t < m) {
       T s = T(0);
       for (int c = 0; c < n; c++) s += sP[t + m * c] * sdx[c];
@@ -104,13 +104,13 @@ __device__ void rollout_instance(const DevProblem& p, const RolloutArgs<T>& a, T
       su[t] = u;
       a.us[size_t(k) * m + t] = u;
     }
-    __syncthreads();
+    lds_sync(NT <= 64);
     if (t < 64 && k + 1 < Tn) {  // whole first wave: the shuffles inside need every group lane live
       const T u0 = integ ? su[uo] : T(0), u1 = integ ? su[uo + 1] : T(0);
       sub_integrate_lanes<T>(kind, Lp, p.dt, xj, u0, u1, q, t & ~7);
     }
     if (k + 1 < Tn) commit();
-    __syncthreads();
+    lds_sync(NT <= 64);
   }
 }
 
@@ -125,6 +125,39 @@ __device__ void rollout_instance(const DevProblem& p, const RolloutArgs<T>& a, T
 // entries per term), then streamed out with fully coalesced stores — the stage's
 // cost is the ~n^2 N words it has to write.
 // ---------------------------------------------------------------------------
+// Bytes of LDS the cost tables take (terms, precomputed segments, polyline offsets, cost order).
+__host__ __device__ inline size_t quad_tables_bytes(const DevProblem& p, size_t elem) {
+  size_t b = size_t(p.total_segs) * kSegStride * elem;          // segs first: keeps T alignment
+  b += size_t(p.num_terms > 0 ? p.num_terms : 1) * sizeof(DevTerm);
+  b += size_t(p.num_polylines + 1) * sizeof(int);
+  b += size_t(p.N) * p.cost_order_stride * sizeof(int);
+  return (b + 15) & ~size_t(15);
+}
+
+// Cooperative copy of the tables into LDS; every thread of the workgroup calls, then syncs.
+template <typename T>
+__device__ __forceinline__ QuadTables<T> quad_tables_load(const DevProblem& p, void* region) {
+  const int t = threadIdx.x, NT = blockDim.x;
+  T* segs = reinterpret_cast<T*>(region);
+  const T* gsegs = problem_segs<T>(p);
+  for (int e = t; e < p.total_segs * kSegStride; e += NT) segs[e] = gsegs[e];
+  int* terms_i = reinterpret_cast<int*>(segs + size_t(p.total_segs) * kSegStride);
+  const int* gterms = reinterpret_cast<const int*>(p.terms);
+  const int nti = p.num_terms * int(sizeof(DevTerm) / sizeof(int));
+  for (int e = t; e < nti; e += NT) terms_i[e] = gterms[e];
+  int* poff = terms_i + (p.num_terms > 0 ? p.num_terms : 1) * int(sizeof(DevTerm) / sizeof(int));
+  for (int e = t; e <= p.num_polylines; e += NT) poff[e] = p.poly_off[e];
+  int* order = poff + p.num_polylines + 1;
+  for (int e = t; e < p.N * p.cost_order_stride; e += NT) order[e] = p.cost_order[e];
+  __syncthreads();
+  QuadTables<T> tb;
+  tb.terms = reinterpret_cast<const DevTerm*>(terms_i);
+  tb.segs = segs;
+  tb.poly_off = poff;
+  tb.order = order;
+  return tb;
+}
+
 template <typename T>
 struct QuadArgs {
   const T* xs;         // [T][n]
@@ -144,7 +177,8 @@ __host__ __device__ inline int quad_lds_elems(int n, int m, int N, int Rsz, int 
 }
 
 template <typename T>
-__device__ void linquad_step(const DevProblem& p, const QuadArgs<T>& a, int k, T* sm) {
+__device__ __forceinline__ void linquad_step(const DevProblem& p, const QuadTables<T>& tb, const QuadArgs<T>& a, int k,
+                                             T* sm) {
   const int n = p.n, m = p.m, N = p.N;
   const int t = threadIdx.x, NT = blockDim.x;
   const PairTable& pt = p.pairs;
@@ -159,22 +193,20 @@ __device__ void linquad_step(const DevProblem& p, const QuadArgs<T>& a, int k, T
   // ---- load the argument, initialise the tiles ----
   for (int e = t; e < n; e += NT) sx[e] = a.xs[size_t(k) * n + e];
   for (int e = t; e < m; e += NT) sx[n + e] = a.us[size_t(k) * m + e];
-  if (a.A) {
-    for (int e = t; e < n * n; e += NT) sA[e] = (e / n == e % n) ? T(1) : T(0);
-    for (int e = t; e < n * m; e += NT) sB[e] = T(0);
-  }
+  if (a.A)
+    for (int e = t; e < n * n + n * m; e += NT) sA[e] = T(0);
   // PlayerCost::Quadraticize vs QuadraticizeControlCosts (src/ilq_solver.cpp:483-487)
   auto is_full = [&](int i) {
     return p.structure[i] == ILQG_SUM || (a.t_extreme ? a.t_extreme[i] == k : k == 0);
   };
-  if (do_quad) {
-    for (int e = t; e < N * n * n; e += NT) {
-      const int i = e / (n * n), rc = e % (n * n);
-      sQ[e] = (rc / n == rc % n) ? T(p.state_reg[i]) : T(0);  // sigma_x I (player_cost.cpp:196)
-    }
-    for (int e = t; e < N * n + pt.Rsz + pt.rsz; e += NT) sl[e] = T(0);
+  if (do_quad)
+    for (int e = t; e < N * n * n + N * n + pt.Rsz + pt.rsz; e += NT) sQ[e] = T(0);
+  lds_sync(NT <= 64);
+  if (t < n) {
+    if (a.A) sA[t * (n + 1)] = T(1);  // LinearDynamicsApproximation starts from (I, 0)
+    if (do_quad)
+      for (int i = 0; i < N; i++) sQ[i * n * n + t * (n + 1)] = T(p.state_reg[i]);  // sigma_x I (player_cost.cpp:196)
   }
-  __syncthreads();
   if (do_quad && t < pt.npairs) {
     // sigma_u I on every control block the reference would have created (player_cost.cpp:70-74)
     const int i = pt.pi[t];
@@ -183,6 +215,7 @@ __device__ void linquad_step(const DevProblem& p, const QuadArgs<T>& a, int k, T
       for (int d = 0; d < mj; d++) sR[pt.roff[t] + d + mj * d] = T(p.control_reg[i]);
     }
   }
+  lds_sync(NT <= 64);
   if (a.A && t < N) {
     const int xo = p.xoff[t], uo = p.uoff[t];
     sub_linearize<T>(p.sub_kind[t], T(p.sub_param[t]), p.dt, sx + xo, sA + xo + n * xo, sB + xo + n * uo, n);
@@ -199,14 +232,14 @@ __device__ void linquad_step(const DevProblem& p, const QuadArgs<T>& a, int k, T
     o.value = T(0);
     bool live = false;
     if (ti < p.num_terms) {
-      c = p.terms[ti];
+      c = tb.terms[ti];
       live = c.role != ILQG_ROLE_CHILD;
       if (live) {
         const bool is_cost = c.role == ILQG_ROLE_STATE_COST || c.role == ILQG_ROLE_CONTROL_COST;
         const bool deriv = do_quad && (is_full(c.player) || c.role == ILQG_ROLE_CONTROL_COST);
         if (deriv || (a.cost_part && is_cost)) {
           const T lambda = (c.slot >= 0 && a.lambdas) ? a.lambdas[c.slot * p.T + tidx] : T(0);
-          term_compute<T>(p, c, sx + c.arg_off, lambda, a.mu, &o);
+          term_compute<T>(tb, c, sx + c.arg_off, lambda, a.mu, &o);
           if (!deriv) o.pattern = PAT_NONE;
         }
       }
@@ -215,13 +248,13 @@ __device__ void linquad_step(const DevProblem& p, const QuadArgs<T>& a, int k, T
     // ---- scatter in rounds: within a round no two terms touch the same entry ----
     if (do_quad) {
       for (int r = 0; r < p.num_rounds; r++) {
-        __syncthreads();
+        lds_sync(NT <= 64);
         if (live && c.round == r && o.pattern != PAT_NONE)
           term_scatter<T>(o, sx + c.arg_off, c.arg_dim, sQ + c.tile_h, c.ld, sQ + c.tile_g);
       }
     }
   }
-  __syncthreads();
+  lds_sync(NT <= 64);
   if (t < N) {
     const int i = t;
     if (a.merit_part) {  // pieces of ILQSolver::MeritFunction (:419-430)
@@ -234,11 +267,8 @@ __device__ void linquad_step(const DevProblem& p, const QuadArgs<T>& a, int k, T
     }
     if (a.cost_part) {  // PlayerCost::Evaluate, src/player_cost.cpp:128-144 (state costs, then control costs)
       T total = T(0);
-      for (int pass = 0; pass < 2; pass++)
-        for (int ti = 0; ti < p.num_terms; ti++) {
-          const DevTerm& c = p.terms[ti];
-          if (c.player == i && c.role == pass) total += svals[ti];
-        }
+      const int* ord = tb.order + i * p.cost_order_stride;
+      for (int q = 0; q < ord[0]; q++) total += svals[ord[1 + q]];
       a.cost_part[size_t(k) * N + i] = total;
     }
   }
@@ -253,13 +283,14 @@ __device__ void linquad_step(const DevProblem& p, const QuadArgs<T>& a, int k, T
     for (int e = t; e < pt.Rsz; e += NT) a.R[size_t(k) * pt.Rsz + e] = sR[e];
     for (int e = t; e < pt.rsz; e += NT) a.r[size_t(k) * pt.rsz + e] = sr[e];
   }
-  __syncthreads();
+  lds_sync(NT <= 64);
 }
 
 // ILQSolver::MeritFunction's reduction (:408-434): 0.5 * sum_k sum_i (|r_ii|^2 + [k>0]|l_i|^2),
 // accumulated in the reference's order by one lane.  Returns the value on every thread.
 template <typename T>
-__device__ T merit_reduce(const DevProblem& p, const T* merit_part, T* sm) {
+__device__ __forceinline__ T merit_reduce(const DevProblem& p, const T* merit_part, T* sm) {
+  __syncthreads();  // partials were written to global memory by other lanes
   if (threadIdx.x == 0) {
     T merit = T(0);
     for (int k = 0; k < p.T; k++)
@@ -278,7 +309,8 @@ __device__ T merit_reduce(const DevProblem& p, const T* merit_part, T* sm) {
 // ILQSolver::TotalCosts reduction (:220-257): sum / max / min over time per player, and
 // the time of the extreme cost (first strict improvement wins, as the reference's `>` / `<`).
 template <typename T>
-__device__ void costs_reduce(const DevProblem& p, const T* cost_part, T* costs_out, int* t_extreme) {
+__device__ __forceinline__ void costs_reduce(const DevProblem& p, const T* cost_part, T* costs_out, int* t_extreme) {
+  __syncthreads();  // partials were written to global memory by other lanes
   const int i = threadIdx.x;
   if (i < p.N) {
     const int st = p.structure[i];

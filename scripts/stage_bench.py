@@ -39,3 +39,13 @@ for K in (1, 2, 4, 8):
         for k in ("xs", "us", "P", "alpha"): bufs[k].zero_()
         prob.solve(x0d, bufs, fixed_iters=K)
     print("fused solve K=%d  %.3f ms" % (K, timeit(f, reps=2)))
+prof = torch.zeros((B, 8), dtype=torch.int64, device="cuda")
+import ctypes
+hip.lib().ilqg_debug_set_profile_buffer(ctypes.c_void_p(prof.data_ptr()))
+for k in ("xs", "us", "P", "alpha"): bufs[k].zero_()
+prob.solve(x0d, bufs, fixed_iters=4); torch.cuda.synchronize()
+pm = prof.double().mean(0).cpu().numpy()
+print("fused K=4 mean cycles/instance: rollout %.0f quad %.0f lq %.0f reduce %.0f total %.0f" % tuple(pm[:5]))
+print("  per call: rollout %.0f (5 calls) quad+reduce %.0f (6 passes) lq %.0f (4)" % (pm[0]/5, pm[1]/6, pm[2]/4))
+hip.lib().ilqg_debug_set_profile_buffer(None)
+
