@@ -376,6 +376,8 @@ ilqg_status ilqg_lq_feedback_batch(const ilqg_dims* d, const void* A, const void
       d->T > kMaxT || d->batch < 0)
     return fail(ILQG_ERR_INVALID, "bad dimensions");
   if (costates) return fail(ILQG_ERR_UNSUPPORTED, "costates are not produced on device (ILQSolver ignores them)");
+  for (const void* ptr : {A, Bm, Q, l, R, r})
+    if (reinterpret_cast<uintptr_t>(ptr) % 16 != 0) return fail(ILQG_ERR_INVALID, "array bases must be 16-byte aligned");
   PairTable pt;
   std::string err;
   if (!build_pairs(pairs_host, npairs, d->udim, d->num_players, &pt, &err)) return fail(ILQG_ERR_INVALID, err);

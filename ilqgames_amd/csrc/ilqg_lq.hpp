@@ -47,18 +47,18 @@ struct LQCfg {
   static constexpr int NT = ((L > NSOLVE ? L : NSOLVE) + 63) / 64 * 64;
   static constexpr int RMAX = NP * NP * MU * MU;
   static constexpr int rMAX = NP * NP * MU;
-  // staged image [B | A | Q | l | R | r]
+  // staged image [B | A | Q | l | R | r] — same element order as the global arrays.  Two images:
+  // the step being processed and the one the LDS-DMA engine is filling for the next step.
   static constexpr int oB = 0;
   static constexpr int oA = oB + NX * M;
   static constexpr int oQ = oA + NX * NX;
   static constexpr int ol = oQ + NP * NX * NX;
   static constexpr int oR = ol + NP * NX;
   static constexpr int or_ = oR + RMAX;
-  static constexpr int WMAIN = oR;  // elements streamed by the generic prefetcher
-  static constexpr int PRE = (WMAIN + NT - 1) / NT;
+  static constexpr int IMG = (or_ + rMAX + 3) & ~3;  // keeps the second image 16-byte aligned
   // intermediates
   static constexpr int NXS = NX | 1;  // odd leading dimension: conflict-free column writes
-  static constexpr int oF = or_ + rMAX;
+  static constexpr int oF = 2 * IMG;
   static constexpr int oUt = oF + NX * NXS;
   static constexpr int oBZ = oUt + NP * NX * NXS;
   static constexpr int oP = oBZ + M * NX;
@@ -72,9 +72,52 @@ struct LQCfg {
   static constexpr int oTr = oX + NX;
   static constexpr int oTv = oTr + 16 * 17;
   static constexpr int LDS_ELEMS = oTv + 16;
-  static_assert(RMAX <= NT, "R blocks are loaded one element per lane");
+  static constexpr int SCR = NP * (NX + 1) + NX;  // scratch row: [Q_i l_i (N*n) | alpha_i^T R_ii r_ii (N) | beta (n)]
+  static_assert(RMAX <= 64, "R blocks are copied by one DMA instruction");
   static_assert(NSOLVE <= 64, "the stacked Nash system must fit one wavefront");
+  static_assert(SCR <= NP * NX * NX + NP * NX, "the forward pass parks the scratch row in the [Q|l] slots");
 };
+
+// ---- global -> LDS DMA (global_load_lds_*): no VGPR round trip, completes in the background ----
+typedef __attribute__((address_space(3))) void* lds_vptr;
+typedef const __attribute__((address_space(1))) void* glb_vptr;
+
+// Copies `nbytes` (a multiple of 4) from global `g` to LDS `l` with the workgroup's NT threads.
+// The LDS destination of one instruction is wave-uniform base + lane * width, i.e. the LDS image is
+// the global image.  WIDE = 16-byte pieces (both addresses 16-byte aligned), else 4-byte pieces.
+template <int NT, bool WIDE>
+__device__ __forceinline__ void dma_g2l(const void* g, void* l, int nbytes, int t) {
+  constexpr int BPL = WIDE ? 16 : 4;
+  const int wbase = (t & ~63) * BPL;  // this wave's slice of each NT*BPL chunk
+  const int lane = t & 63;
+  for (int off = 0; off < nbytes; off += NT * BPL) {
+    const int my = off + wbase + lane * BPL;
+    if (my < nbytes) {
+      if constexpr (WIDE)
+        __builtin_amdgcn_global_load_lds((glb_vptr)((const char*)g + my), (lds_vptr)((char*)l + off + wbase), 16, 0, 0);
+      else
+        __builtin_amdgcn_global_load_lds((glb_vptr)((const char*)g + my), (lds_vptr)((char*)l + off + wbase), 4, 0, 0);
+    }
+  }
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// Starts the DMA of step k's [B|A|Q|l|R|r] block into the image at `img`.
+template <typename T, int NX, int NP, int MU>
+__device__ __forceinline__ void lq_stage_issue(const LQArgs<T>& a, const PairTable& pt, int k, T* img, int t) {
+  using C = LQCfg<T, NX, NP, MU>;
+  constexpr int NT = C::NT, M = C::M, S = int(sizeof(T));
+  constexpr bool wB = (NX * M * S) % 16 == 0 && (C::oB * S) % 16 == 0;
+  constexpr bool wA = (NX * NX * S) % 16 == 0 && (C::oA * S) % 16 == 0;
+  constexpr bool wQ = (NP * NX * NX * S) % 16 == 0 && (C::oQ * S) % 16 == 0;
+  constexpr bool wl = (NP * NX * S) % 16 == 0 && (C::ol * S) % 16 == 0;
+  dma_g2l<NT, wB>(a.Bm + size_t(k) * NX * M, img + C::oB, NX * M * S, t);
+  dma_g2l<NT, wA>(a.A + size_t(k) * NX * NX, img + C::oA, NX * NX * S, t);
+  dma_g2l<NT, wQ>(a.Q + size_t(k) * NP * NX * NX, img + C::oQ, NP * NX * NX * S, t);
+  dma_g2l<NT, wl>(a.l + size_t(k) * NP * NX, img + C::ol, NP * NX * S, t);
+  dma_g2l<NT, false>(a.R + size_t(k) * pt.Rsz, img + C::oR, pt.Rsz * S, t);
+  dma_g2l<NT, false>(a.r + size_t(k) * pt.rsz, img + C::or_, pt.rsz * S, t);
+}
 
 __device__ __forceinline__ float lq_sqrt(float x) { return sqrtf(x); }
 __device__ __forceinline__ double lq_sqrt(double x) { return sqrt(x); }
@@ -102,8 +145,9 @@ __device__ __forceinline__ void qr_solve_columns(T (&col)[M], int lane, T (&x)[M
     } else {
       beta = lq_sqrt(c0 * c0 + tailsq);
       if (c0 >= T(0)) beta = -beta;
+      const T inv = T(1) / (c0 - beta);  // one division; Eigen divides each entry (last-ulp difference)
 #pragma unroll
-      for (int i = k + 1; i < M; i++) ess[i] = col[i] / (c0 - beta);
+      for (int i = k + 1; i < M; i++) ess[i] = col[i] * inv;
       tau = (beta - c0) / beta;
     }
     const T tau_k = shfl(tau, k);
@@ -128,13 +172,77 @@ __device__ __forceinline__ void qr_solve_columns(T (&col)[M], int lane, T (&x)[M
       }
     }
   }
+  // reciprocal of R's diagonal, one division per lane off the back-substitution chain
+  T diag = T(1);
+#pragma unroll
+  for (int i = 0; i < M; i++) diag = (lane == i) ? col[i] : diag;
+  const T dinv = T(1) / diag;
 #pragma unroll
   for (int i = M - 1; i >= 0; i--) {
     T s = col[i];
 #pragma unroll
     for (int k2 = i + 1; k2 < M; k2++) s -= shfl(col[i], k2) * x[k2];
-    x[i] = s / shfl(col[i], i);
+    x[i] = s * shfl(dinv, i);
   }
+}
+
+// Forward pass of the sweep: delta_xs (src/lq_feedback_solver.cpp:217-241 — no feedback term) and
+// ILQSolver::ExpectedDecrease (src/ilq_solver.cpp:364-398) from the per-step scratch rows.
+// A_{k+1} and scratch row k+1 are DMA'd into the idle image while step k is computed.
+template <typename T, int NX, int NP, int MU>
+__device__ __forceinline__ void lq_forward_pass(const LQArgs<T>& a, T* sm, int t) {
+  using C = LQCfg<T, NX, NP, MU>;
+  constexpr int NT = C::NT, SCR = C::SCR, S = int(sizeof(T));
+  constexpr bool wA = (NX * NX * S) % 16 == 0 && (C::oA * S) % 16 == 0 && (C::IMG * S) % 16 == 0;
+  if (a.dx == nullptr && a.ed_out == nullptr) return;
+  const int Tn = a.T_steps;
+  T* sX = sm + C::oX;
+  __syncthreads();  // scratch rows were written to global memory by other lanes during the sweep
+  auto stage = [&](int k, int which) {
+    T* img = sm + which * C::IMG;
+    dma_g2l<NT, wA>(a.A + size_t(k) * NX * NX, img + C::oA, NX * NX * S, t);
+    dma_g2l<NT, false>(a.scratch + size_t(k) * SCR, img + C::oQ, SCR * S, t);
+  };
+  int cur = 0;
+  stage(0, 0);
+  if (t < NX) sX[t] = a.x0 ? a.x0[t] : T(0);
+  T ed = T(0);
+  dma_wait();
+  lds_sync(NT <= 64);
+#pragma unroll 1
+  for (int k = 0; k < Tn; k++) {
+    if (k + 1 < Tn) stage(k + 1, 1 - cur);
+    const T* fA = sm + cur * C::IMG + C::oA;
+    const T* fS = sm + cur * C::IMG + C::oQ;  // [ql (N*n) | ctrl (N) | beta (n)]
+    if (a.dx && t < NX) a.dx[size_t(k) * NX + t] = sX[t];
+    if (a.ed_out && t < 64) {
+      T st = T(0), ct = T(0);
+      if (t < NP) {
+        ct = fS[NP * NX + t];
+        if (k > 0) {
+#pragma unroll
+          for (int c = 0; c < NX; c++) st += sX[c] * fS[t * NX + c];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NP; i++) {
+        ed -= shfl(ct, i);
+        if (k > 0) ed -= shfl(st, i);
+      }
+    }
+    T xn = T(0);
+    if (t < NX) {
+#pragma unroll
+      for (int c = 0; c < NX; c++) xn += fA[t + NX * c] * sX[c];
+      xn += fS[NP * (NX + 1) + t];  // beta_k = -B alpha_k
+    }
+    lds_sync(NT <= 64);
+    if (t < NX) sX[t] = xn;
+    dma_wait();
+    lds_sync(NT <= 64);
+    cur = 1 - cur;
+  }
+  if (a.ed_out && t == 0) *a.ed_out = ed;
 }
 
 // One instance, executed by a workgroup of LQCfg::NT threads.  `sm` is LDS scratch
@@ -149,16 +257,20 @@ __device__ __forceinline__ void lq_feedback_instance(const LQArgs<T>& a, const P
   const int pi = zl ? t / NX : 0;
   const int pc = zl ? t % NX : 0;
   const int Tn = a.T_steps;
-  const int Rsz = pt.Rsz, rsz = pt.rsz;
   const bool want_fwd = a.dx != nullptr || a.ed_out != nullptr;
-  const int SCR = NP * (NX + 1) + NX;  // scratch row: [ql (N*n) | ctrl (N) | beta (n)]
+  constexpr int SCR = C::SCR;
 
-  T* sB = sm + C::oB;
-  T* sA = sm + C::oA;
-  T* sQ = sm + C::oQ;
-  T* sl = sm + C::ol;
-  T* sR = sm + C::oR;
-  T* sr = sm + C::or_;
+  T *sB, *sA, *sQ, *sl, *sR, *sr;  // views into the image of the step being processed
+  auto set_img = [&](int which) {
+    T* img = sm + which * C::IMG;
+    sB = img + C::oB;
+    sA = img + C::oA;
+    sQ = img + C::oQ;
+    sl = img + C::ol;
+    sR = img + C::oR;
+    sr = img + C::or_;
+  };
+  int cur = 0;
   T* sF = sm + C::oF;
   T* sUt = sm + C::oUt;
   T* sBZ = sm + C::oBZ;
@@ -167,39 +279,7 @@ __device__ __forceinline__ void lq_feedback_instance(const LQArgs<T>& a, const P
   T* sBeta = sm + C::oBeta;
   T* sZeta = sm + C::oZeta;
   T* sYz = sm + C::oYz;
-  T* sX = sm + C::oX;
 
-  T pre[C::PRE];
-  T preR = T(0), prer = T(0);
-  auto issue = [&](int k) {
-    const T* gB = a.Bm + size_t(k) * NX * M;
-    const T* gA = a.A + size_t(k) * NX * NX;
-    const T* gQ = a.Q + size_t(k) * NP * NX * NX;
-    const T* gl = a.l + size_t(k) * NP * NX;
-#pragma unroll
-    for (int q = 0; q < C::PRE; q++) {
-      const int e = t + q * NT;
-      if (e < C::oA)
-        pre[q] = gB[e];
-      else if (e < C::oQ)
-        pre[q] = gA[e - C::oA];
-      else if (e < C::ol)
-        pre[q] = gQ[e - C::oQ];
-      else if (e < C::oR)
-        pre[q] = gl[e - C::ol];
-    }
-    if (t < Rsz) preR = a.R[size_t(k) * Rsz + t];
-    if (t < rsz) prer = a.r[size_t(k) * rsz + t];
-  };
-  auto commit = [&]() {
-#pragma unroll
-    for (int q = 0; q < C::PRE; q++) {
-      const int e = t + q * NT;
-      if (e < C::oR) sm[e] = pre[q];
-    }
-    if (t < Rsz) sR[t] = preR;
-    if (t < rsz) sr[t] = prer;
-  };
   // (Q_i l_i) of the step currently staged -> scratch, for ExpectedDecrease
   auto stash_ql = [&](int k) {
     if (want_fwd && zl) {
@@ -211,9 +291,10 @@ __device__ __forceinline__ void lq_feedback_instance(const LQArgs<T>& a, const P
   };
 
   // ---- terminal step: Z_i = Q_i[T-1], zeta_i = l_i[T-1]  (:102-105) ----
-  issue(Tn - 1);
-  commit();
-  lds_sync(NT <= 64);
+  lq_stage_issue<T, NX, NP, MU>(a, pt, Tn - 1, sm, t);
+  dma_wait();
+  __syncthreads();
+  set_img(0);
   T z[NX];
   T zeta = T(0);
   if (zl) {
@@ -232,15 +313,16 @@ __device__ __forceinline__ void lq_feedback_instance(const LQArgs<T>& a, const P
     if (t < NP) a.scratch[size_t(Tn - 1) * SCR + NP * NX + t] = T(0);
     if (t < NX) a.scratch[size_t(Tn - 1) * SCR + NP * (NX + 1) + t] = T(0);
   }
-  if (Tn >= 2) issue(Tn - 2);
-  lds_sync(NT <= 64);
+  if (Tn >= 2) lq_stage_issue<T, NX, NP, MU>(a, pt, Tn - 2, sm + C::IMG, t);
   if (zl) sZeta[t] = zeta;
-  if (Tn >= 2) commit();
+  dma_wait();
   lds_sync(NT <= 64);
+  cur = 1;
+  set_img(1);
 
 #pragma unroll 1
   for (int k = Tn - 2; k >= 0; k--) {
-    if (k > 0) issue(k - 1);
+    if (k > 0) lq_stage_issue<T, NX, NP, MU>(a, pt, k - 1, sm + (1 - cur) * C::IMG, t);
     stash_ql(k);
 
     // ---- P1: BZ = B_i^T Z_i (rows of the stacked system), y_zeta = B_i^T zeta_i + r_ii ----
@@ -270,7 +352,7 @@ __device__ __forceinline__ void lq_feedback_instance(const LQArgs<T>& a, const P
         // column t of [B | A] is contiguous in the staged image
         T mc[NX];
 #pragma unroll
-        for (int c = 0; c < NX; c++) mc[c] = sm[C::oB + c + NX * t];
+        for (int c = 0; c < NX; c++) mc[c] = sB[c + NX * t];  // column t of [B | A], contiguous in the image
 #pragma unroll
         for (int r = 0; r < M; r++) {
           T s = T(0);
@@ -421,48 +503,13 @@ __device__ __forceinline__ void lq_feedback_instance(const LQArgs<T>& a, const P
     }
     lds_sync(NT <= 64);
     if (zl) sZeta[t] = zeta_new;
-    if (k > 0) commit();
+    dma_wait();
     lds_sync(NT <= 64);
+    cur = 1 - cur;
+    set_img(cur);
   }
 
-  // ---- forward pass: delta_xs (:217-241) + ExpectedDecrease (ilq_solver.cpp:364-398) ----
-  if (!want_fwd) return;
-  __syncthreads();  // scratch rows written by other lanes during the sweep
-  if (t < NX) sX[t] = a.x0 ? a.x0[t] : T(0);
-  T ed = T(0);
-  lds_sync(NT <= 64);
-#pragma unroll 1
-  for (int k = 0; k < Tn; k++) {
-    // stage A_k (coalesced) into the image's A slot
-    for (int e = t; e < NX * NX; e += NT) sA[e] = a.A[size_t(k) * NX * NX + e];
-    if (a.dx && t < NX) a.dx[size_t(k) * NX + t] = sX[t];
-    if (a.ed_out && t < 64) {
-      T st = T(0), ct = T(0);
-      if (t < NP) {
-        ct = a.scratch[size_t(k) * SCR + NP * NX + t];
-        if (k > 0) {
-#pragma unroll
-          for (int c = 0; c < NX; c++) st += sX[c] * a.scratch[size_t(k) * SCR + t * NX + c];
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < NP; i++) {
-        ed -= shfl(ct, i);
-        if (k > 0) ed -= shfl(st, i);
-      }
-    }
-    lds_sync(NT <= 64);
-    T xn = T(0);
-    if (t < NX) {
-#pragma unroll
-      for (int c = 0; c < NX; c++) xn += sA[t + NX * c] * sX[c];
-      xn += a.scratch[size_t(k) * SCR + NP * (NX + 1) + t];  // beta_k = -B alpha_k
-    }
-    lds_sync(NT <= 64);
-    if (t < NX) sX[t] = xn;
-    lds_sync(NT <= 64);
-  }
-  if (a.ed_out && t == 0) *a.ed_out = ed;
+  lq_forward_pass<T, NX, NP, MU>(a, sm, t);
 }
 
 // ---------------------------------------------------------------------------
@@ -485,9 +532,8 @@ __device__ __forceinline__ void lq_feedback_instance_mfma(const LQArgs<T>& a, co
   const int pi = zl ? t / NX : 0;
   const int pc = zl ? t % NX : 0;
   const int Tn = a.T_steps;
-  const int Rsz = pt.Rsz, rsz = pt.rsz;
   const bool want_fwd = a.dx != nullptr || a.ed_out != nullptr;
-  const int SCR = NP * (NX + 1) + NX;
+  constexpr int SCR = C::SCR;
   int rowi[4];
   bool rowok[4];
 #pragma unroll
@@ -497,12 +543,17 @@ __device__ __forceinline__ void lq_feedback_instance_mfma(const LQArgs<T>& a, co
   }
   const bool jok = j < NX;
 
-  T* sB = sm + C::oB;
-  T* sA = sm + C::oA;
-  T* sQ = sm + C::oQ;
-  T* sl = sm + C::ol;
-  T* sR = sm + C::oR;
-  T* sr = sm + C::or_;
+  T *sB, *sA, *sQ, *sl, *sR, *sr;  // views into the image of the step being processed
+  auto set_img = [&](int which) {
+    T* img = sm + which * C::IMG;
+    sB = img + C::oB;
+    sA = img + C::oA;
+    sQ = img + C::oQ;
+    sl = img + C::ol;
+    sR = img + C::oR;
+    sr = img + C::or_;
+  };
+  int cur = 0;
   T* sBZ = sm + C::oBZ;
   T* sP = sm + C::oP;
   T* sAl = sm + C::oAl;
@@ -513,37 +564,6 @@ __device__ __forceinline__ void lq_feedback_instance_mfma(const LQArgs<T>& a, co
   T* sTr = sm + C::oTr;
   T* sTv = sm + C::oTv;
 
-  T pre[C::PRE];
-  T preR = T(0), prer = T(0);
-  auto issue = [&](int k) {
-    const T* gB = a.Bm + size_t(k) * NX * M;
-    const T* gA = a.A + size_t(k) * NX * NX;
-    const T* gQ = a.Q + size_t(k) * NP * NX * NX;
-    const T* gl = a.l + size_t(k) * NP * NX;
-#pragma unroll
-    for (int q = 0; q < C::PRE; q++) {
-      const int e = t + q * NT;
-      if (e < C::oA)
-        pre[q] = gB[e];
-      else if (e < C::oQ)
-        pre[q] = gA[e - C::oA];
-      else if (e < C::ol)
-        pre[q] = gQ[e - C::oQ];
-      else if (e < C::oR)
-        pre[q] = gl[e - C::ol];
-    }
-    if (t < Rsz) preR = a.R[size_t(k) * Rsz + t];
-    if (t < rsz) prer = a.r[size_t(k) * rsz + t];
-  };
-  auto commit = [&]() {
-#pragma unroll
-    for (int q = 0; q < C::PRE; q++) {
-      const int e = t + q * NT;
-      if (e < C::oR) sm[e] = pre[q];
-    }
-    if (t < Rsz) sR[t] = preR;
-    if (t < rsz) sr[t] = prer;
-  };
   auto stash_ql = [&](int k) {
     if (want_fwd && zl) {
       T s = T(0);
@@ -559,9 +579,10 @@ __device__ __forceinline__ void lq_feedback_instance_mfma(const LQArgs<T>& a, co
   };
 
   // ---- terminal step: Yd_i = D-layout(Q_i[T-1]^T), zeta_i = l_i[T-1] ----
-  issue(Tn - 1);
-  commit();
-  lds_sync(NT <= 64);
+  lq_stage_issue<T, NX, NP, MU>(a, pt, Tn - 1, sm, t);
+  dma_wait();
+  __syncthreads();
+  set_img(0);
   vec Yd[NP];
 #pragma unroll
   for (int i = 0; i < NP; i++)
@@ -575,15 +596,16 @@ __device__ __forceinline__ void lq_feedback_instance_mfma(const LQArgs<T>& a, co
     if (t < NP) a.scratch[size_t(Tn - 1) * SCR + NP * NX + t] = T(0);
     if (t < NX) a.scratch[size_t(Tn - 1) * SCR + NP * (NX + 1) + t] = T(0);
   }
-  if (Tn >= 2) issue(Tn - 2);
-  lds_sync(NT <= 64);
+  if (Tn >= 2) lq_stage_issue<T, NX, NP, MU>(a, pt, Tn - 2, sm + C::IMG, t);
   if (zl) sZeta[t] = zeta;
-  if (Tn >= 2) commit();
+  dma_wait();
   lds_sync(NT <= 64);
+  cur = 1;
+  set_img(1);
 
 #pragma unroll 1
   for (int k = Tn - 2; k >= 0; k--) {
-    if (k > 0) issue(k - 1);
+    if (k > 0) lq_stage_issue<T, NX, NP, MU>(a, pt, k - 1, sm + (1 - cur) * C::IMG, t);
     stash_ql(k);
 
     // ---- P1: BZ_i = B_i^T Z_i.  Z_i in D layout comes from transposing Yd_i through LDS ----
@@ -623,7 +645,7 @@ __device__ __forceinline__ void lq_feedback_instance_mfma(const LQArgs<T>& a, co
       if (t < M + NX) {
         T mc[NX];
 #pragma unroll
-        for (int c = 0; c < NX; c++) mc[c] = sm[C::oB + c + NX * t];
+        for (int c = 0; c < NX; c++) mc[c] = sB[c + NX * t];  // column t of [B | A], contiguous in the image
 #pragma unroll
         for (int r = 0; r < M; r++) {
           T s = T(0);
@@ -776,47 +798,13 @@ __device__ __forceinline__ void lq_feedback_instance_mfma(const LQArgs<T>& a, co
 #pragma unroll
       for (int i = 0; i < NP; i++) sZeta[i * NX + j] = zeta_new[i];
     }
-    if (k > 0) commit();
+    dma_wait();
     lds_sync(NT <= 64);
+    cur = 1 - cur;
+    set_img(cur);
   }
 
-  // ---- forward pass (identical to the VALU variant) ----
-  if (!want_fwd) return;
-  __syncthreads();  // scratch rows written by other lanes during the sweep
-  if (t < NX) sX[t] = a.x0 ? a.x0[t] : T(0);
-  T ed = T(0);
-  lds_sync(NT <= 64);
-#pragma unroll 1
-  for (int k = 0; k < Tn; k++) {
-    for (int e = t; e < NX * NX; e += NT) sA[e] = a.A[size_t(k) * NX * NX + e];
-    if (a.dx && t < NX) a.dx[size_t(k) * NX + t] = sX[t];
-    if (a.ed_out) {
-      T st = T(0), ct = T(0);
-      if (t < NP) {
-        ct = a.scratch[size_t(k) * SCR + NP * NX + t];
-        if (k > 0) {
-#pragma unroll
-          for (int c = 0; c < NX; c++) st += sX[c] * a.scratch[size_t(k) * SCR + t * NX + c];
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < NP; i++) {
-        ed -= shfl(ct, i);
-        if (k > 0) ed -= shfl(st, i);
-      }
-    }
-    lds_sync(NT <= 64);
-    T xn = T(0);
-    if (t < NX) {
-#pragma unroll
-      for (int c = 0; c < NX; c++) xn += sA[t + NX * c] * sX[c];
-      xn += a.scratch[size_t(k) * SCR + NP * (NX + 1) + t];
-    }
-    lds_sync(NT <= 64);
-    if (t < NX) sX[t] = xn;
-    lds_sync(NT <= 64);
-  }
-  if (a.ed_out && t == 0) *a.ed_out = ed;
+  lq_forward_pass<T, NX, NP, MU>(a, sm, t);
 }
 
 // Dispatch: MFMA formulation where the state fits one 16x16 tile, VALU/LDS formulation otherwise.

@@ -40,7 +40,7 @@ struct WsLayout {
     size_t o = 0;
     auto take = [&](size_t cnt) {
       const size_t at = o;
-      o += (cnt + 1) & ~size_t(1);  // keep 16-byte alignment for fp64, 8 for fp32
+      o += (cnt + 3) & ~size_t(3);  // every array starts 16-byte aligned (fp32 and fp64): LDS-DMA pieces
       return at;
     };
     xs1 = take(size_t(T) * n);
