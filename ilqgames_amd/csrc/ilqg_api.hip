@@ -133,8 +133,12 @@ __global__ void costs_reduce_kernel(DevProblem p, const T* cost_part, T* costs, 
   costs_reduce<T>(p, cost_part + b * p.T * p.N, costs + b * p.N, t_extreme ? t_extreme + b * p.N : nullptr);
 }
 
+// Second launch-bound argument = minimum waves per SIMD the register allocation must allow: a single
+// wave issues roughly one instruction per 8-10 cycles here (dependent LDS / MFMA / libm chains), so
+// throughput at large batch comes from co-resident instances, i.e. from staying under 128 VGPRs
+// (fp32) / 256 (fp64) per lane.
 template <typename T, int NX, int NP, int MU>
-__global__ void __launch_bounds__((LQCfg<T, NX, NP, MU>::NT))
+__global__ void __launch_bounds__((LQCfg<T, NX, NP, MU>::NT), (sizeof(T) == 4 ? 2 : 1))
 ilq_solve_kernel(DevProblem p, SolveArgs<T> sa) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const QuadTables<T> tb = quad_tables_load<T>(p, smem_raw);  // resident for the whole solve

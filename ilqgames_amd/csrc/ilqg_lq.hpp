@@ -37,6 +37,7 @@ struct LQArgs {
   T* ed_out;                        // expected decrease (one scalar) or nullptr
   int T_steps;
   int adaptive;
+  long long* ph = nullptr;          // optional: 8 shader-clock accumulators per instance (phase profile)
 };
 
 template <typename T, int NX, int NP, int MU>
@@ -71,11 +72,43 @@ struct LQCfg {
   static constexpr bool USE_MFMA = NX <= 16 && NP * NX <= 64;
   static constexpr int oTr = oX + NX;
   static constexpr int oTv = oTr + 16 * 17;
-  static constexpr int LDS_ELEMS = oTv + 16;
+  static constexpr int oSY = oTv + 16;  // [S | Y] bounce buffer of the MFMA variant: M x 32, column-major
+  static constexpr int LDS_ELEMS = oSY + M * 32;
   static constexpr int SCR = NP * (NX + 1) + NX;  // scratch row: [Q_i l_i (N*n) | alpha_i^T R_ii r_ii (N) | beta (n)]
   static_assert(RMAX <= 64, "R blocks are copied by one DMA instruction");
   static_assert(NSOLVE <= 64, "the stacked Nash system must fit one wavefront");
   static_assert(SCR <= NP * NX * NX + NP * NX, "the forward pass parks the scratch row in the [Q|l] slots");
+};
+
+// The (i,j) block table pulled into registers once per sweep.  Indexing the kernel-argument copy
+// with a run-time q costs a dependent scalar load (~100+ cycles) per access — dozens per step.
+template <int NP>
+struct PairRegs {
+  int q[NP][NP];   // block index of (i,j) or -1
+  int ro[NP][NP];  // offset inside the R row
+  int rg[NP][NP];  // offset inside the r row
+  __device__ __forceinline__ explicit PairRegs(const PairTable& pt) {
+#pragma unroll
+    for (int i = 0; i < NP; i++)
+#pragma unroll
+      for (int j = 0; j < NP; j++) {
+        q[i][j] = -1;
+        ro[i][j] = 0;
+        rg[i][j] = 0;
+      }
+    for (int e = 0; e < pt.npairs; e++) {
+      const int pi = pt.pi[e], pj = pt.pj[e], r0 = pt.roff[e], g0 = pt.rgoff[e];
+#pragma unroll
+      for (int i = 0; i < NP; i++)
+#pragma unroll
+        for (int j = 0; j < NP; j++)
+          if (pi == i && pj == j) {
+            q[i][j] = e;
+            ro[i][j] = r0;
+            rg[i][j] = g0;
+          }
+    }
+  }
 };
 
 // ---- global -> LDS DMA (global_load_lds_*): no VGPR round trip, completes in the background ----
@@ -119,6 +152,16 @@ __device__ __forceinline__ void lq_stage_issue(const LQArgs<T>& a, const PairTab
   dma_g2l<NT, false>(a.r + size_t(k) * pt.rsz, img + C::or_, pt.rsz * S, t);
 }
 
+// Broadcast from a compile-time-known lane through v_readlane (scalar path): no LDS crossbar
+// round trip, unlike __shfl -> ds_bpermute.  `l` must be wave-uniform.
+__device__ __forceinline__ float bcast(float v, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+__device__ __forceinline__ double bcast(double v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ float lq_sqrt(float x) { return sqrtf(x); }
 __device__ __forceinline__ double lq_sqrt(double x) { return sqrt(x); }
 
@@ -150,10 +193,10 @@ __device__ __forceinline__ void qr_solve_columns(T (&col)[M], int lane, T (&x)[M
       for (int i = k + 1; i < M; i++) ess[i] = col[i] * inv;
       tau = (beta - c0) / beta;
     }
-    const T tau_k = shfl(tau, k);
+    const T tau_k = bcast(tau, k);
     T v[M];
 #pragma unroll
-    for (int i = k + 1; i < M; i++) v[i] = shfl(ess[i], k);
+    for (int i = k + 1; i < M; i++) v[i] = bcast(ess[i], k);
     if (lane == k) {
       col[k] = beta;
 #pragma unroll
@@ -181,8 +224,8 @@ __device__ __forceinline__ void qr_solve_columns(T (&col)[M], int lane, T (&x)[M
   for (int i = M - 1; i >= 0; i--) {
     T s = col[i];
 #pragma unroll
-    for (int k2 = i + 1; k2 < M; k2++) s -= shfl(col[i], k2) * x[k2];
-    x[i] = s * shfl(dinv, i);
+    for (int k2 = i + 1; k2 < M; k2++) s -= bcast(col[i], k2) * x[k2];
+    x[i] = s * bcast(dinv, i);
   }
 }
 
@@ -514,34 +557,52 @@ __device__ __forceinline__ void lq_feedback_instance(const LQArgs<T>& a, const P
 
 // ---------------------------------------------------------------------------
 // MFMA formulation of the same sweep for n <= 16 (one wavefront per instance).
-// Differences from lq_feedback_instance: Z_i^T lives in the MFMA accumulator layout (4 scalars per
-// lane per player) and F^T Z_i F is two chains of four v_mfma_*_16x16x4 per player (ilqg_mfma.hpp);
-// B_i^T Z_i, Z_i beta and F^T t are "4 FMAs + a cross-group butterfly" in that layout.
-// The Nash-system assembly, Gershgorin step, QR solve and forward pass are shared code paths.
+// Both Z_i and Z_i^T live in the MFMA accumulator layout (4 scalars per lane per player each);
+// every matrix product of the step is a chain of four v_mfma_*_16x16x4 on those registers
+// (ilqg_mfma.hpp: tile_xty(X, Y, C) = X^T Y + C):
+//     G        = [Z_0^T B_0 | Z_1^T B_1 | ...]           (B_i^T Z_i)^T, columns picked per player
+//     [S | Y]  = G^T [B | A]                              two 16-column tiles
+//     F        = A - B P        = (-B^T)^T P + A
+//     W_i      = Z_i F          = (Z_i^T)^T F
+//     Z_i'^T   = W_i^T F + C_i^T ,   Z_i' = F^T W_i + C_i
+//     Z_i beta = (Z_i^T)^T [beta in column i] ,  F^T [t_0 t_1 ...] for the zeta update
+// so the step has no LDS-broadcast FMAs, no cross-lane reductions and no re-layouts; LDS is only
+// the DMA image, the 6 x 21 [S | Y] bounce into the column-per-lane QR, and P/alpha/beta/zeta.
 // ---------------------------------------------------------------------------
 template <typename T, int NX, int NP, int MU>
 __device__ __forceinline__ void lq_feedback_instance_mfma(const LQArgs<T>& a, const PairTable& pt, T* sm) {
   using C = LQCfg<T, NX, NP, MU>;
   using TL = Tile<T>;
   using vec = typename TL::vec;
-  constexpr int M = C::M, L = C::L, NT = C::NT;
+  constexpr int M = C::M, L = C::L, NT = C::NT, NS = C::NSOLVE;
   static_assert(NT == 64, "MFMA sweep: one wavefront per instance");
+  static_assert(M <= 16 && NS <= 32, "the Nash system must fit two 16-column tiles");
   const int t = threadIdx.x;
   const int lane = t & 63, g = lane >> 4, j = lane & 15;
   const bool zl = t < L;
   const int pi = zl ? t / NX : 0;
   const int pc = zl ? t % NX : 0;
   const int Tn = a.T_steps;
+  const PairRegs<NP> pr(pt);
   const bool want_fwd = a.dx != nullptr || a.ed_out != nullptr;
   constexpr int SCR = C::SCR;
   int rowi[4];
-  bool rowok[4];
 #pragma unroll
-  for (int r = 0; r < 4; r++) {
-    rowi[r] = TL::row(g, r);
-    rowok[r] = rowi[r] < NX;
-  }
-  const bool jok = j < NX;
+  for (int r = 0; r < 4; r++) rowi[r] = TL::row(g, r);
+  const vec zero4 = {T(0), T(0), T(0), T(0)};
+  // D-layout loads of a column-major block: element [row][col] = ptr[row + ld*col] / transposed
+  auto ldD = [&](const T* ptr, int ld, int nrows, int ncols) {
+    vec v;
+#pragma unroll
+    for (int r = 0; r < 4; r++) v[r] = (rowi[r] < nrows && j < ncols) ? ptr[rowi[r] + ld * j] : T(0);
+    return v;
+  };
+  auto ldDT = [&](const T* ptr, int ld, int nrows, int ncols) {  // [row][col] = ptr[col + ld*row]
+    vec v;
+#pragma unroll
+    for (int r = 0; r < 4; r++) v[r] = (rowi[r] < nrows && j < ncols) ? ptr[j + ld * rowi[r]] : T(0);
+    return v;
+  };
 
   T *sB, *sA, *sQ, *sl, *sR, *sr;  // views into the image of the step being processed
   auto set_img = [&](int which) {
@@ -554,16 +615,14 @@ __device__ __forceinline__ void lq_feedback_instance_mfma(const LQArgs<T>& a, co
     sr = img + C::or_;
   };
   int cur = 0;
-  T* sBZ = sm + C::oBZ;
   T* sP = sm + C::oP;
   T* sAl = sm + C::oAl;
   T* sBeta = sm + C::oBeta;
   T* sZeta = sm + C::oZeta;
   T* sYz = sm + C::oYz;
-  T* sX = sm + C::oX;
-  T* sTr = sm + C::oTr;
-  T* sTv = sm + C::oTv;
+  T* sSY = sm + C::oSY;
 
+  // (Q_i l_i) of the step currently staged -> scratch, for ExpectedDecrease
   auto stash_ql = [&](int k) {
     if (want_fwd && zl) {
       T s = T(0);
@@ -572,23 +631,19 @@ __device__ __forceinline__ void lq_feedback_instance_mfma(const LQArgs<T>& a, co
       a.scratch[size_t(k) * SCR + pi * NX + pc] = s;
     }
   };
-  auto xgroup_sum = [&](T v) {  // sum over the 4 lane groups holding the same column j
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    return v;
-  };
 
-  // ---- terminal step: Yd_i = D-layout(Q_i[T-1]^T), zeta_i = l_i[T-1] ----
+  // ---- terminal step: Z_i = Q_i[T-1], zeta_i = l_i[T-1]  (:102-105) ----
   lq_stage_issue<T, NX, NP, MU>(a, pt, Tn - 1, sm, t);
   dma_wait();
   __syncthreads();
   set_img(0);
-  vec Yd[NP];
+  vec Zd[NP], Yd[NP];
 #pragma unroll
-  for (int i = 0; i < NP; i++)
-#pragma unroll
-    for (int r = 0; r < 4; r++) Yd[i][r] = (rowok[r] && jok) ? sQ[i * NX * NX + j + NX * rowi[r]] : T(0);
-  T zeta = zl ? sl[pi * NX + pc] : T(0);
+  for (int i = 0; i < NP; i++) {
+    Zd[i] = ldD(sQ + i * NX * NX, NX, NX, NX);
+    Yd[i] = ldDT(sQ + i * NX * NX, NX, NX, NX);
+  }
+  const T zeta0 = zl ? sl[pi * NX + pc] : T(0);
   stash_ql(Tn - 1);
   for (int e = t; e < M * NX; e += NT) a.P[size_t(Tn - 1) * M * NX + e] = T(0);
   if (t < M) a.alpha[size_t(Tn - 1) * M + t] = T(0);
@@ -597,87 +652,84 @@ __device__ __forceinline__ void lq_feedback_instance_mfma(const LQArgs<T>& a, co
     if (t < NX) a.scratch[size_t(Tn - 1) * SCR + NP * (NX + 1) + t] = T(0);
   }
   if (Tn >= 2) lq_stage_issue<T, NX, NP, MU>(a, pt, Tn - 2, sm + C::IMG, t);
-  if (zl) sZeta[t] = zeta;
+  if (zl) sZeta[t] = zeta0;
   dma_wait();
-  lds_sync(NT <= 64);
+  lds_sync(true);
   cur = 1;
   set_img(1);
 
 #pragma unroll 1
   for (int k = Tn - 2; k >= 0; k--) {
+    long long pc0 = a.ph ? clock64() : 0, pc1;
+#define ILQG_PH(i) do { if (a.ph) { pc1 = clock64(); if (t == 0) a.ph[i] += pc1 - pc0; pc0 = pc1; } } while (0)
     if (k > 0) lq_stage_issue<T, NX, NP, MU>(a, pt, k - 1, sm + (1 - cur) * C::IMG, t);
     stash_ql(k);
+    ILQG_PH(0);
 
-    // ---- P1: BZ_i = B_i^T Z_i.  Z_i in D layout comes from transposing Yd_i through LDS ----
+    // ---- rows of the stacked Nash system: [S | Y] = (B_i^T Z_i)_i [B | A] ----
+    const vec Bd = ldD(sB, NX, NX, M);
+    const vec BA0 = ldD(sB, NX, NX, (M + NX < 16) ? M + NX : 16);      // columns 0..15 of [B | A]
+    const vec BA1 = ldD(sB + NX * 16, NX, NX, M + NX - 16);            // columns 16.. (empty if M+NX <= 16)
+    vec G = zero4;
 #pragma unroll
     for (int i = 0; i < NP; i++) {
+      const vec Gi = tile_xty<T>(Zd[i], Bd, zero4);  // Z_i^T B
 #pragma unroll
-      for (int r = 0; r < 4; r++) sTr[rowi[r] * 17 + j] = Yd[i][r];
-      lds_sync(NT <= 64);
-      T zd[4];
-#pragma unroll
-      for (int r = 0; r < 4; r++) zd[r] = sTr[j * 17 + rowi[r]];  // Z_i[row][j]
-#pragma unroll
-      for (int aa = 0; aa < MU; aa++) {
-        T s = T(0);
-#pragma unroll
-        for (int r = 0; r < 4; r++)
-          if (rowok[r]) s += sB[rowi[r] + NX * (i * MU + aa)] * zd[r];
-        s = xgroup_sum(s);
-        if (g == 0 && jok) sBZ[(i * MU + aa) + M * j] = s;
-      }
-      lds_sync(NT <= 64);
+      for (int r = 0; r < 4; r++) G[r] = (j / MU == i) ? Gi[r] : G[r];
     }
-    if (t < M) {
+    const vec SY0 = tile_xty<T>(G, BA0, zero4);
+    const vec SY1 = tile_xty<T>(G, BA1, zero4);
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+      if (rowi[r] < M) {
+        sSY[rowi[r] + M * j] = SY0[r];
+        sSY[rowi[r] + M * (16 + j)] = SY1[r];
+      }
+    if (t < M) {  // y_zeta = B_i^T zeta_i + r_ii (:154-157)
       const int i = t / MU, aa = t % MU;
       T s = T(0);
 #pragma unroll
       for (int r = 0; r < NX; r++) s += sB[r + NX * t] * sZeta[i * NX + r];
-      sYz[t] = s + sr[pt.rgoff[pt.pii[i]] + aa];
+      int rg_ii = 0;
+#pragma unroll
+      for (int e = 0; e < NP; e++) rg_ii = (i == e) ? pr.rg[e][e] : rg_ii;
+      sYz[t] = s + sr[rg_ii + aa];
     }
-    lds_sync(NT <= 64);
+    lds_sync(true);
+    ILQG_PH(1);
 
-    // ---- P2: column `t` of [S | Y], Gershgorin, QR solve ----
+    // ---- column `t` of [S | Y]: + R_ii, Gershgorin (:163-176), Householder QR solve (:180) ----
     {
       T col[M], x[M];
 #pragma unroll
-      for (int r = 0; r < M; r++) { col[r] = T(0); x[r] = T(0); }
-      if (t < M + NX) {
-        T mc[NX];
+      for (int r = 0; r < M; r++) {
+        col[r] = (t < M + NX) ? sSY[r + M * t] : ((t == M + NX) ? sYz[r] : T(0));
+        x[r] = T(0);
+      }
+      if (t < M) {
+        const int pj = t / MU, b = t % MU;
+        int ro_ii = 0;
 #pragma unroll
-        for (int c = 0; c < NX; c++) mc[c] = sB[c + NX * t];  // column t of [B | A], contiguous in the image
+        for (int e = 0; e < NP; e++) ro_ii = (pj == e) ? pr.ro[e][e] : ro_ii;
+        const T* Rii = sR + ro_ii;
 #pragma unroll
-        for (int r = 0; r < M; r++) {
-          T s = T(0);
+        for (int r = 0; r < M; r++)
+          if (r / MU == pj) col[r] = col[r] + Rii[(r % MU) + MU * b];
+        if (a.adaptive) {  // columns are independent, so lane-parallel reproduces the sequential loop
+          T l1 = T(0), diag = T(0);
 #pragma unroll
-          for (int c = 0; c < NX; c++) s += sBZ[r + M * c] * mc[c];
-          col[r] = s;
-        }
-        if (t < M) {
-          const int pj = t / MU, b = t % MU;
-          const T* Rii = sR + pt.roff[pt.pii[pj]];
+          for (int r = 0; r < M; r++) {
+            l1 += (col[r] < T(0) ? -col[r] : col[r]);
+            if (r == t) diag = col[r];
+          }
+          const T radius = l1 - (diag < T(0) ? -diag : diag);
+          const T eval_lo = diag - radius;
+          if (eval_lo < T(1e-3f)) {
 #pragma unroll
-          for (int r = 0; r < M; r++)
-            if (r / MU == pj) col[r] = col[r] + Rii[(r % MU) + MU * b];
-          if (a.adaptive) {
-            T l1 = T(0), diag = T(0);
-#pragma unroll
-            for (int r = 0; r < M; r++) {
-              l1 += (col[r] < T(0) ? -col[r] : col[r]);
-              if (r == t) diag = col[r];
-            }
-            const T radius = l1 - (diag < T(0) ? -diag : diag);
-            const T eval_lo = diag - radius;
-            if (eval_lo < T(1e-3f)) {
-#pragma unroll
-              for (int r = 0; r < M; r++)
-                if (r == t) col[r] += radius + T(1e-3f);
-            }
+            for (int r = 0; r < M; r++)
+              if (r == t) col[r] += radius + T(1e-3f);
           }
         }
-      } else if (t == M + NX) {
-#pragma unroll
-        for (int r = 0; r < M; r++) col[r] = sYz[r];
       }
       qr_solve_columns<T, M>(col, lane, x);
       if (t >= M && t < M + NX) {
@@ -694,26 +746,17 @@ __device__ __forceinline__ void lq_feedback_instance_mfma(const LQArgs<T>& a, co
         }
       }
     }
-    lds_sync(NT <= 64);
+    lds_sync(true);
+    ILQG_PH(2);
 
-    // ---- P3: Fd = D-layout(A - B P); beta = -B alpha ----
-    vec Fd;
-    {
-      T pcol[M];
+    // ---- F = A - B P (:189-194) ----
+    const vec Pd = ldD(sP, M, M, NX);
+    vec nBT = ldDT(sB, NX, M, NX);  // B^T, negated below
 #pragma unroll
-      for (int q = 0; q < M; q++) pcol[q] = jok ? sP[q + M * j] : T(0);
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        T s = T(0);
-        if (rowok[r] && jok) {
-          s = sA[rowi[r] + NX * j];
-#pragma unroll
-          for (int q = 0; q < M; q++) s -= sB[rowi[r] + NX * q] * pcol[q];
-        }
-        Fd[r] = s;
-      }
-    }
-    if (t < NX) {
+    for (int r = 0; r < 4; r++) nBT[r] = -nBT[r];
+    const vec Ad = ldD(sA, NX, NX, NX);
+    const vec Fd = tile_xty<T>(nBT, Pd, Ad);
+    if (t < NX) {  // beta = -B alpha
       T s = T(0);
 #pragma unroll
       for (int q = 0; q < M; q++) s -= sB[t + NX * q] * sAl[q];
@@ -721,88 +764,110 @@ __device__ __forceinline__ void lq_feedback_instance_mfma(const LQArgs<T>& a, co
       if (want_fwd) a.scratch[size_t(k) * SCR + NP * (NX + 1) + t] = s;
     }
     if (want_fwd && t < NP) {
-      const int q = pt.pii[t];
+      // alpha_i^T R_ii r_ii, evaluated (alpha^T R) r like Eigen (ilq_solver.cpp:384-386)
+      int ro_ii = 0, rg_ii = 0;
+#pragma unroll
+      for (int e = 0; e < NP; e++) {
+        ro_ii = (t == e) ? pr.ro[e][e] : ro_ii;
+        rg_ii = (t == e) ? pr.rg[e][e] : rg_ii;
+      }
       T acc = T(0);
 #pragma unroll
       for (int c = 0; c < MU; c++) {
         T aR = T(0);
 #pragma unroll
-        for (int b = 0; b < MU; b++) aR += sAl[t * MU + b] * sR[pt.roff[q] + b + MU * c];
-        acc += aR * sr[pt.rgoff[q] + c];
+        for (int b = 0; b < MU; b++) aR += sAl[t * MU + b] * sR[ro_ii + b + MU * c];
+        acc += aR * sr[rg_ii + c];
       }
       a.scratch[size_t(k) * SCR + NP * NX + t] = acc;
     }
-    lds_sync(NT <= 64);
+    lds_sync(true);
+    ILQG_PH(3);
 
-    // ---- P4/P5 per player: zeta update (uses the old Z_i), then Yd_i <- (Z_i F)^T F + C_i ----
-    T zeta_new[NP];
+    // ---- per player: Z_i <- F^T Z_i F + Q_i + sum_jj P_jj^T R_i,jj P_jj  (:198-212), both layouts ----
+    vec TD = zero4;  // column i = zeta_i + Z_i beta
 #pragma unroll
     for (int i = 0; i < NP; i++) {
-      // t = zeta_i + Z_i beta ;  (Z beta)[j] = sum_rho Z[j][rho] beta[rho] = sum_r Yd[r] beta[row(r)]
-      T zb = T(0);
+      const vec Wd = tile_xty<T>(Yd[i], Fd, zero4);  // Z_i F
+      vec BetaD;
+#pragma unroll
+      for (int r = 0; r < 4; r++) BetaD[r] = (j == i && rowi[r] < NX) ? sBeta[rowi[r]] : T(0);
+      const vec ZB = tile_xty<T>(Yd[i], BetaD, zero4);  // column i = Z_i beta
 #pragma unroll
       for (int r = 0; r < 4; r++)
-        if (rowok[r]) zb += Yd[i][r] * sBeta[rowi[r]];
-      zb = xgroup_sum(zb);
-      if (g == 0) sTv[j] = jok ? sZeta[i * NX + j] + zb : T(0);
-      lds_sync(NT <= 64);
-      // (F^T t)[j] = sum_rho F[rho][j] t[rho]
-      T ft = T(0);
+        if (j == i && rowi[r] < NX) TD[r] = ZB[r] + sZeta[i * NX + rowi[r]];
+      vec Cd = ldD(sQ + i * NX * NX, NX, NX, NX);
+      vec CTd = ldDT(sQ + i * NX * NX, NX, NX, NX);
 #pragma unroll
-      for (int r = 0; r < 4; r++) ft += Fd[r] * sTv[rowi[r]];
-      ft = xgroup_sum(ft);
-      T zn = jok ? ft + sl[i * NX + j] : T(0);
-      // accumulator init C_i = D-layout(Q_i^T + sum_jj (P_jj^T R_i,jj P_jj)^T)
-      vec Cd;
+      for (int jj = 0; jj < NP; jj++) {
+        if (pr.q[i][jj] < 0) continue;
+        // + P_jj^T R_i,jj P_jj (and its transpose): H = R P_jj and H' = R^T P_jj sit in rows
+        // jj*MU.. of a tile, P_jj likewise, so both products are one MFMA chain each.
+        const T* Rij = sR + pr.ro[i][jj];
+        vec Pj, Hd, Htd;
 #pragma unroll
-      for (int r = 0; r < 4; r++) Cd[r] = (rowok[r] && jok) ? sQ[i * NX * NX + j + NX * rowi[r]] : T(0);
-      for (int q = 0; q < pt.npairs; q++) {
-        if (pt.pi[q] != i) continue;
-        const int jj = pt.pj[q];
-        const T* Rij = sR + pt.roff[q];
-        const T* rij = sr + pt.rgoff[q];
-        if (jok) {
-          // zeta term: P_jj[:,j]^T (R alpha_jj - r)
+        for (int r = 0; r < 4; r++) {
+          const int aa = rowi[r] - jj * MU;
+          const bool in = aa >= 0 && aa < MU && j < NX;
+          T h = T(0), ht = T(0);
+          if (in) {
+#pragma unroll
+            for (int b = 0; b < MU; b++) {
+              const T pb = sP[(jj * MU + b) + M * j];
+              h += Rij[aa + MU * b] * pb;
+              ht += Rij[b + MU * aa] * pb;
+            }
+          }
+          Pj[r] = in ? Pd[r] : T(0);
+          Hd[r] = h;
+          Htd[r] = ht;
+        }
+        Cd = tile_xty<T>(Pj, Hd, Cd);     // P_jj^T (R P_jj)
+        CTd = tile_xty<T>(Pj, Htd, CTd);  // P_jj^T (R^T P_jj) = (P_jj^T R P_jj)^T
+      }
+      Yd[i] = tile_xty<T>(Wd, Fd, CTd);  // (Z_i F)^T F + C_i^T
+      Zd[i] = tile_xty<T>(Fd, Wd, Cd);   // F^T (Z_i F) + C_i
+    }
+    const vec FT = tile_xty<T>(Fd, TD, zero4);  // column i = F^T (zeta_i + Z_i beta)
+    lds_sync(true);  // every read of the old zeta is done
+    ILQG_PH(4);
+    if (j < NP) {
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+        if (rowi[r] < NX) sZeta[j * NX + rowi[r]] = FT[r];  // F^T (zeta_i + Z_i beta)
+    }
+    lds_sync(true);
+    if (zl) {  // + l_i + sum_jj P_jj^T (R_i,jj alpha_jj - r_i,jj)   (:198-201, 206-212)
+      T zn = sZeta[t] + sl[t];
+#pragma unroll
+      for (int i = 0; i < NP; i++) {
+        if (pi != i) continue;
+#pragma unroll
+        for (int jj = 0; jj < NP; jj++) {
+          if (pr.q[i][jj] < 0) continue;
+          const T* Rij = sR + pr.ro[i][jj];
+          const T* rij = sr + pr.rg[i][jj];
           T add = T(0);
 #pragma unroll
           for (int aa = 0; aa < MU; aa++) {
             T w = T(0);
 #pragma unroll
             for (int b = 0; b < MU; b++) w += Rij[aa + MU * b] * sAl[jj * MU + b];
-            add += sP[(jj * MU + aa) + M * j] * (w - rij[aa]);
+            add += sP[(jj * MU + aa) + M * pc] * (w - rij[aa]);
           }
           zn += add;
-          // G[j][row] = sum_{a,b} P[a][j] R[a][b] P[b][row]   (entry (row, j) of the transposed tile)
-#pragma unroll
-          for (int r = 0; r < 4; r++)
-            if (rowok[r]) {
-              T sacc = T(0);
-#pragma unroll
-              for (int aa = 0; aa < MU; aa++) {
-                T v = T(0);
-#pragma unroll
-                for (int b = 0; b < MU; b++) v += Rij[aa + MU * b] * sP[(jj * MU + b) + M * rowi[r]];
-                sacc += sP[(jj * MU + aa) + M * j] * v;
-              }
-              Cd[r] += sacc;
-            }
         }
       }
-      zeta_new[i] = zn;
-      vec Wd = {T(0), T(0), T(0), T(0)};
-      Wd = tile_xty<T>(Yd[i], Fd, Wd);   // Z_i F
-      Yd[i] = tile_xty<T>(Wd, Fd, Cd);   // (Z_i F)^T F + C_i
-      lds_sync(NT <= 64);
+      sZeta[t] = zn;
     }
-    if (g == 0 && jok) {
-#pragma unroll
-      for (int i = 0; i < NP; i++) sZeta[i * NX + j] = zeta_new[i];
-    }
+    ILQG_PH(5);
     dma_wait();
-    lds_sync(NT <= 64);
+    lds_sync(true);
     cur = 1 - cur;
     set_img(cur);
+    ILQG_PH(6);
   }
+#undef ILQG_PH
 
   lq_forward_pass<T, NX, NP, MU>(a, sm, t);
 }

@@ -204,6 +204,7 @@ __device__ __forceinline__ void ilq_solve_instance(const DevProblem& p, const Qu
       la.ed_out = sm + LQCfg<T, NX, NP, MU>::oX;  // an LDS slot that is free once the sweep ends
       la.T_steps = Tn;
       la.adaptive = 1;
+      la.ph = sa.prof ? sa.prof + size_t(b) * 16 + 8 : nullptr;
       lq_feedback_dispatch<T, NX, NP, MU>(la, pt, sm);
       __syncthreads();
       expected_decrease = sm[LQCfg<T, NX, NP, MU>::oX];
@@ -228,7 +229,7 @@ __device__ __forceinline__ void ilq_solve_instance(const DevProblem& p, const Qu
     for (int e = t; e < Tn * m; e += blockDim.x) al0[e] = src[e] * acc_scale;
   }
   if (t == 0 && sa.prof) {
-    long long* o = sa.prof + size_t(b) * 8;
+    long long* o = sa.prof + size_t(b) * 16;
     o[0] = pr_acc[0]; o[1] = pr_acc[1]; o[2] = pr_acc[2]; o[3] = 0; o[4] = clock64() - pr_start;
   }
   if (t == 0) {

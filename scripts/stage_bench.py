@@ -39,7 +39,7 @@ for K in (1, 2, 4, 8):
         for k in ("xs", "us", "P", "alpha"): bufs[k].zero_()
         prob.solve(x0d, bufs, fixed_iters=K)
     print("fused solve K=%d  %.3f ms" % (K, timeit(f, reps=2)))
-prof = torch.zeros((B, 8), dtype=torch.int64, device="cuda")
+prof = torch.zeros((B, 16), dtype=torch.int64, device="cuda")
 import ctypes
 hip.lib().ilqg_debug_set_profile_buffer(ctypes.c_void_p(prof.data_ptr()))
 for k in ("xs", "us", "P", "alpha"): bufs[k].zero_()
@@ -49,3 +49,4 @@ print("fused K=4 mean cycles/instance: rollout %.0f quad %.0f lq %.0f reduce %.0
 print("  per call: rollout %.0f (5 calls) quad+reduce %.0f (6 passes) lq %.0f (4)" % (pm[0]/5, pm[1]/6, pm[2]/4))
 hip.lib().ilqg_debug_set_profile_buffer(None)
 
+print("  lq phases (cycles/step): issue+ql %.0f  G,SY %.0f  solve %.0f  F,beta %.0f  players %.0f  zeta %.0f  wait+swap %.0f" % tuple(pm[8:15] / 396))
