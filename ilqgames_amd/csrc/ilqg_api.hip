@@ -11,6 +11,7 @@
 
 #include "ilqg_common.hpp"
 #include "ilqg_lq.hpp"
+#include "ilqg_lq_openloop.hpp"
 #include "ilqg_models.hpp"
 #include "ilqg_solve.hpp"
 #include "ilqg_stages.hpp"
@@ -66,6 +67,32 @@ lq_feedback_kernel(LQBatchArgs<T> g, PairTable pt) {
   a.T_steps = g.T_steps;
   a.adaptive = g.adaptive;
   lq_feedback_dispatch<T, NX, NP, MU, FORCE_VALU>(a, pt, sm);
+}
+
+template <typename T, int NX, int NP, int MU>
+__global__ void __launch_bounds__((LQCfg<T, NX, NP, MU>::NT))
+lq_openloop_kernel(LQBatchArgs<T> g, PairTable pt) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  T* sm = reinterpret_cast<T*>(smem_raw);
+  const int b = blockIdx.x;
+  constexpr int M = NP * MU;
+  const size_t Tn = g.T_steps;
+  LQArgs<T> a;
+  a.A = g.A + b * Tn * NX * NX;
+  a.Bm = g.Bm + b * Tn * NX * M;
+  a.Q = g.Q + b * Tn * NP * NX * NX;
+  a.l = g.l + b * Tn * NP * NX;
+  a.R = g.R + b * Tn * pt.Rsz;
+  a.r = g.r + b * Tn * pt.rsz;
+  a.x0 = g.x0 ? g.x0 + size_t(b) * NX : nullptr;
+  a.P = g.P + b * Tn * M * NX;
+  a.alpha = g.alpha + b * Tn * M;
+  a.dx = g.dx ? g.dx + b * Tn * NX : nullptr;
+  a.scratch = g.scratch + b * Tn * OLCfg<T, NX, NP, MU>::ROW;
+  a.ed_out = nullptr;
+  a.T_steps = g.T_steps;
+  a.adaptive = 0;
+  lq_openloop_instance<T, NX, NP, MU>(a, pt, sm);
 }
 
 template <typename T>
@@ -175,6 +202,13 @@ struct Scratch {  // grow-only device scratch for entry points without a workspa
 thread_local Scratch g_scratch;
 long long* g_prof = nullptr;  // set through ilqg_debug_set_profile_buffer
 
+// Large dynamic-LDS launches: ask for the opt-in limit; a refusal is not fatal by itself (the launch
+// reports the real error if the size is unusable), so it must not poison the sticky error state.
+void raise_lds_limit(const void* kern, size_t lds) {
+  if (lds <= 48 * 1024) return;
+  if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) (void)hipGetLastError();
+}
+
 bool build_pairs(const ilqg_pair* pairs, int npairs, const int* udim, int N, PairTable* pt, std::string* err) {
   if (npairs > kMaxPairs) {
     *err = "too many control blocks";
@@ -238,7 +272,33 @@ ilqg_status launch_lq(const ilqg_dims* d, const PairTable& pt, const void* A, co
   // ILQG_FORCE_VALU=1 selects the VALU/LDS formulation where the MFMA one is the default (A/B profiling)
   auto kern = (C::USE_MFMA && getenv("ILQG_FORCE_VALU") != nullptr) ? lq_feedback_kernel<T, NX, NP, MU, true>
                                                                     : lq_feedback_kernel<T, NX, NP, MU, false>;
-  if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  raise_lds_limit((const void*)kern, lds);
+  hipLaunchKernelGGL(kern, dim3(d->batch), dim3(C::NT), lds, stream, g, pt);
+  HIP_TRY(hipGetLastError());
+  return ILQG_OK;
+}
+
+template <typename T, int NX, int NP, int MU>
+ilqg_status launch_lq_openloop(const ilqg_dims* d, const PairTable& pt, const void* A, const void* Bm, const void* Q,
+                               const void* l, const void* R, const void* r, const void* x0, void* P, void* alpha,
+                               void* dx, hipStream_t stream) {
+  using C = LQCfg<T, NX, NP, MU>;
+  using O = OLCfg<T, NX, NP, MU>;
+  LQBatchArgs<T> g;
+  g.A = (const T*)A; g.Bm = (const T*)Bm; g.Q = (const T*)Q; g.l = (const T*)l;
+  g.R = (const T*)R; g.r = (const T*)r; g.x0 = (const T*)x0;
+  g.P = (T*)P; g.alpha = (T*)alpha; g.dx = (T*)dx;
+  const size_t need = size_t(d->batch) * d->T * O::ROW * sizeof(T);
+  ilqg_status s = g_scratch.reserve(need);
+  if (s != ILQG_OK) return s;
+  g.scratch = (T*)g_scratch.ptr;
+  g.T_steps = d->T;
+  g.adaptive = 0;
+  g.batch = d->batch;
+  g.force_valu = 0;
+  const size_t lds = size_t(O::LDS_ELEMS) * sizeof(T);
+  auto kern = lq_openloop_kernel<T, NX, NP, MU>;
+  raise_lds_limit((const void*)kern, lds);
   hipLaunchKernelGGL(kern, dim3(d->batch), dim3(C::NT), lds, stream, g, pt);
   HIP_TRY(hipGetLastError());
   return ILQG_OK;
@@ -301,20 +361,24 @@ static ilqg_status launch_solve(ilqg_problem* p, int32_t batch, const void* x0, 
                                 void* workspace, int32_t fixed_iters, hipStream_t stream) {
   using C = LQCfg<T, NX, NP, MU>;
   const DevProblem& d = p->dev;
-  const WsLayout L(d.n, d.m, d.N, d.T, d.pairs.Rsz, d.pairs.rsz);
+  static_assert(OLCfg<T, NX, NP, MU>::ROW == ((NX * NX + NX + NP * MU * NX + NP * MU + NP * NX * NX + 2 * NP * NX + 3) & ~3), "ol_row_elems");
+  const int ol_row = p->desc.params.open_loop ? ol_row_elems(d.n, d.m, d.N) : 0;
+  const WsLayout L(d.n, d.m, d.N, d.T, d.pairs.Rsz, d.pairs.rsz, ol_row);
   SolveArgs<T> sa;
+  sa.ol_row = ol_row;
   sa.x0 = (const T*)x0; sa.xs = (T*)xs; sa.us = (T*)us; sa.P = (T*)P; sa.alpha = (T*)alpha;
   sa.total_costs = (T*)total_costs; sa.iters = iters; sa.status = status; sa.converged = converged;
   sa.ws = (T*)workspace; sa.ws_stride = L.total; sa.fixed_iters = fixed_iters; sa.batch = batch;
   sa.prm = p->desc.params;
   sa.prof = g_prof;
   size_t elems = C::LDS_ELEMS;
+  if (p->desc.params.open_loop && size_t(OLCfg<T, NX, NP, MU>::LDS_ELEMS) > elems) elems = OLCfg<T, NX, NP, MU>::LDS_ELEMS;
   const size_t e2 = rollout_lds_elems(d.n, d.m), e3 = quad_lds_elems(d.n, d.m, d.N, d.pairs.Rsz, d.pairs.rsz, d.num_terms);
   if (e2 > elems) elems = e2;
   if (e3 > elems) elems = e3;
   const size_t lds = elems * sizeof(T) + quad_tables_bytes(d, sizeof(T));
   auto kern = ilq_solve_kernel<T, NX, NP, MU>;
-  if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  raise_lds_limit((const void*)kern, lds);
   hipLaunchKernelGGL(kern, dim3(batch), dim3(C::NT), lds, stream, d, sa);
   HIP_TRY(hipGetLastError());
   return ILQG_OK;
@@ -404,10 +468,37 @@ ilqg_status ilqg_lq_feedback_batch(const ilqg_dims* d, const void* A, const void
                                         " N=" + std::to_string(d->num_players) + " m_i=" + std::to_string(mu));
 }
 
-ilqg_status ilqg_lq_openloop_batch(const ilqg_dims*, const void*, const void*, const void*, const void*, const void*,
-                                   const void*, const ilqg_pair*, int32_t, const void*, void*, void*, void*, void*,
-                                   void*) {
-  return fail(ILQG_ERR_UNSUPPORTED, "open-loop sweep: device kernel not built yet");
+ilqg_status ilqg_lq_openloop_batch(const ilqg_dims* d, const void* A, const void* Bm, const void* Q, const void* l,
+                                   const void* R, const void* r, const ilqg_pair* pairs_host, int32_t npairs,
+                                   const void* x0, void* P, void* alpha, void* dx, void* costates, void* stream) {
+  if (!d || !A || !Bm || !Q || !l || !R || !r || !pairs_host || !P || !alpha)
+    return fail(ILQG_ERR_INVALID, "null argument");
+  if (d->num_players < 1 || d->num_players > ILQG_MAX_PLAYERS || d->n < 1 || d->n > ILQG_MAX_XDIM || d->T < 2 ||
+      d->T > kMaxT || d->batch < 0)
+    return fail(ILQG_ERR_INVALID, "bad dimensions");
+  if (costates) return fail(ILQG_ERR_UNSUPPORTED, "costates are not produced on device (ILQSolver ignores them)");
+  for (const void* ptr : {A, Bm, Q, l, R, r})
+    if (reinterpret_cast<uintptr_t>(ptr) % 16 != 0) return fail(ILQG_ERR_INVALID, "array bases must be 16-byte aligned");
+  PairTable pt;
+  std::string err;
+  if (!build_pairs(pairs_host, npairs, d->udim, d->num_players, &pt, &err)) return fail(ILQG_ERR_INVALID, err);
+  int mu = 0;
+  if (!uniform_udim(d->udim, d->num_players, &mu))
+    return fail(ILQG_ERR_UNSUPPORTED, "device kernels need equal control dimensions for all players");
+  ilqg_status s = check_device();
+  if (s != ILQG_OK) return s;
+  if (d->batch == 0) return ILQG_OK;
+  hipStream_t st = (hipStream_t)stream;
+#define X(NX_, NP_, MU_)                                                                                      \
+  if (d->n == NX_ && d->num_players == NP_ && mu == MU_) {                                                    \
+    return d->dtype == ILQG_F32                                                                               \
+               ? launch_lq_openloop<float, NX_, NP_, MU_>(d, pt, A, Bm, Q, l, R, r, x0, P, alpha, dx, st)     \
+               : launch_lq_openloop<double, NX_, NP_, MU_>(d, pt, A, Bm, Q, l, R, r, x0, P, alpha, dx, st);   \
+  }
+  ILQG_FOR_DIMS(X)
+#undef X
+  return fail(ILQG_ERR_UNSUPPORTED, "no device kernel instantiated for n=" + std::to_string(d->n) +
+                                        " N=" + std::to_string(d->num_players) + " m_i=" + std::to_string(mu));
 }
 
 ilqg_status ilqg_problem_create(const ilqg_problem_desc* desc, ilqg_problem** out) {
@@ -658,7 +749,7 @@ ilqg_status ilqg_problem_pairs(const ilqg_problem* p, ilqg_pair* pairs_host, int
 ilqg_status ilqg_workspace_bytes(const ilqg_problem* p, int32_t batch, uint64_t* bytes) {
   if (!p || !bytes) return fail(ILQG_ERR_INVALID, "null argument");
   const DevProblem& d = p->dev;
-  const WsLayout L(d.n, d.m, d.N, d.T, d.pairs.Rsz, d.pairs.rsz);
+  const WsLayout L(d.n, d.m, d.N, d.T, d.pairs.Rsz, d.pairs.rsz, p->desc.params.open_loop ? ol_row_elems(d.n, d.m, d.N) : 0);
   *bytes = uint64_t(L.total) * (p->desc.dtype == ILQG_F32 ? 4 : 8) * uint64_t(batch > 0 ? batch : 0);
   return ILQG_OK;
 }
@@ -729,7 +820,6 @@ ilqg_status ilqg_ilq_solve_batch(ilqg_problem* p, int32_t batch, const void* x0,
   if (!p || !x0 || !xs || !us || !P || !alpha || !total_costs || !iters || !status || !converged || !workspace)
     return fail(ILQG_ERR_INVALID, "null argument");
   if (batch <= 0) return ILQG_OK;
-  if (p->desc.params.open_loop) return fail(ILQG_ERR_UNSUPPORTED, "open-loop iLQ: device kernel not built yet");
   const DevProblem& d = p->dev;
   if (!p->mu_uniform) return fail(ILQG_ERR_UNSUPPORTED, "non-uniform control dimensions");
   hipStream_t st = (hipStream_t)stream;

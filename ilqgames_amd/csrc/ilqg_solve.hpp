@@ -14,6 +14,7 @@
 #pragma once
 
 #include "ilqg_lq.hpp"
+#include "ilqg_lq_openloop.hpp"
 #include "ilqg_stages.hpp"
 
 namespace ilqg {
@@ -29,14 +30,20 @@ struct SolveArgs {
   size_t ws_stride;
   int fixed_iters;
   int batch;
+  int ol_row;           // elements per open-loop scratch row (0 when the feedback sweep is used)
   ilqg_solver_params prm;
   long long* prof;      // optional [B][8] shader-clock cycles per stage (diagnostics) or nullptr
 };
 
+// Elements of one open-loop scratch row ([X|y|W|w|M|m|Q l], OLCfg::ROW) from run-time dimensions.
+__host__ __device__ inline int ol_row_elems(int n, int m, int N) {
+  return (n * n + n + m * n + m + N * n * n + N * n + N * n + 3) & ~3;
+}
+
 // Per-instance workspace layout (in elements of T).
 struct WsLayout {
   size_t xs1, us1, P1, al1, A, B, Q, l, R, r, lqscr, dx, mpart, cpart, ints, total;
-  __host__ __device__ WsLayout(int n, int m, int N, int T, int Rsz, int rsz) {
+  __host__ __device__ WsLayout(int n, int m, int N, int T, int Rsz, int rsz, int ol_row = 0) {
     size_t o = 0;
     auto take = [&](size_t cnt) {
       const size_t at = o;
@@ -53,7 +60,7 @@ struct WsLayout {
     l = take(size_t(T) * N * n);
     R = take(size_t(T) * Rsz);
     r = take(size_t(T) * rsz);
-    lqscr = take(size_t(T) * (N * (n + 1) + n));
+    lqscr = take(size_t(T) * (size_t(ol_row) > size_t(N * (n + 1) + n) ? size_t(ol_row) : size_t(N * (n + 1) + n)));
     dx = take(size_t(T) * n);
     mpart = take(size_t(T) * N * 2);
     cpart = take(size_t(T) * N);
@@ -72,7 +79,7 @@ __device__ __forceinline__ void ilq_solve_instance(const DevProblem& p, const Qu
   const int Tn = p.T;
   const PairTable& pt = p.pairs;
   const ilqg_solver_params& prm = sa.prm;
-  const WsLayout L(n, m, N, Tn, pt.Rsz, pt.rsz);
+  const WsLayout L(n, m, N, Tn, pt.Rsz, pt.rsz, sa.ol_row);
   T* w = sa.ws + size_t(b) * sa.ws_stride;
   // two operating-point buffers and two strategy buffers; buffer 0 is the caller's
   T* const xs0 = sa.xs + size_t(b) * Tn * n;
@@ -123,7 +130,7 @@ __device__ __forceinline__ void ilq_solve_instance(const DevProblem& p, const Qu
       ra.alpha_scale = initial ? T(1) : step;
       ra.xs = initial ? XS(1) : XS(1 - cur);
       ra.us = initial ? US(1) : US(1 - cur);
-      rollout_instance<T>(p, ra, sm);
+      rollout_instance<T, NX, NP * MU>(p, ra, sm);
       if (initial) {
         cur = 1;
         qmode = Q_COSTS;  // TotalCosts (:107) before quadraticising (:116): costs set t_extreme
@@ -150,7 +157,7 @@ __device__ __forceinline__ void ilq_solve_instance(const DevProblem& p, const Qu
       qa.merit_part = qmode == Q_TRIAL ? w + L.mpart : nullptr;
       qa.cost_part = (qmode == Q_COSTS || qmode == Q_TRIAL || qmode == Q_LIN) ? w + L.cpart : nullptr;
 #pragma unroll 1
-      for (int k = 0; k < Tn; k++) linquad_step<T>(p, tb, qa, k, sm);
+      for (int k = 0; k < Tn; k++) linquad_step<T, NX, NP * MU, NP>(p, tb, qa, k, sm);
       if (qmode == Q_COSTS) {
         costs_reduce<T>(p, w + L.cpart, costs, t_extreme);
         qmode = Q_INIT;
@@ -205,7 +212,10 @@ __device__ __forceinline__ void ilq_solve_instance(const DevProblem& p, const Qu
       la.T_steps = Tn;
       la.adaptive = 1;
       la.ph = sa.prof ? sa.prof + size_t(b) * 16 + 8 : nullptr;
-      lq_feedback_dispatch<T, NX, NP, MU>(la, pt, sm);
+      if (prm.open_loop)
+        lq_openloop_instance<T, NX, NP, MU>(la, pt, sm);  // SolverParams::open_loop (ilq_solver.h:76-81)
+      else
+        lq_feedback_dispatch<T, NX, NP, MU>(la, pt, sm);
       __syncthreads();
       expected_decrease = sm[LQCfg<T, NX, NP, MU>::oX];
       __syncthreads();

@@ -30,9 +30,10 @@ struct RolloutArgs {
 
 __host__ __device__ inline int rollout_lds_elems(int n, int m) { return 2 * n + 2 * m + m * n + m + n; }
 
-template <typename T>
+// CN, CM > 0: compile-time state / control dimensions (fully unrolled inner loops); 0: run-time.
+template <typename T, int CN = 0, int CM = 0>
 __device__ __forceinline__ void rollout_instance(const DevProblem& p, const RolloutArgs<T>& a, T* sm) {
-  const int n = p.n, m = p.m, N = p.N, Tn = p.T;
+  const int n = CN > 0 ? CN : p.n, m = CM > 0 ? CM : p.m, N = p.N, Tn = p.T;
   const int t = threadIdx.x, NT = blockDim.x;
   T* sx = sm;             // [n] current state
   T* sdx = sx + n;        // [n]
@@ -99,7 +100,18 @@ __device__ __forceinline__ void rollout_instance(const DevProblem& p, const Roll
     lds_sync(NT <= 64);
     if (t < m) {
       T s = T(0);
-      for (int c = 0; c < n; c++) s += sP[t + m * c] * sdx[c];
+      if constexpr (CN > 0) {
+        T pr[CN], dv[CN];  // all loads first, then the reference's left-to-right accumulation
+#pragma unroll
+        for (int c = 0; c < CN; c++) {
+          pr[c] = sP[t + m * c];
+          dv[c] = sdx[c];
+        }
+#pragma unroll
+        for (int c = 0; c < CN; c++) s += pr[c] * dv[c];
+      } else {
+        for (int c = 0; c < n; c++) s += sP[t + m * c] * sdx[c];
+      }
       const T u = (sur[t] - s) - a.alpha_scale * sal[t];
       su[t] = u;
       a.us[size_t(k) * m + t] = u;
@@ -176,10 +188,10 @@ __host__ __device__ inline int quad_lds_elems(int n, int m, int N, int Rsz, int 
   return n + m + n * n + n * m + N * n * n + N * n + Rsz + rsz + num_terms;
 }
 
-template <typename T>
+template <typename T, int CN = 0, int CM = 0, int CNP = 0>
 __device__ __forceinline__ void linquad_step(const DevProblem& p, const QuadTables<T>& tb, const QuadArgs<T>& a, int k,
                                              T* sm) {
-  const int n = p.n, m = p.m, N = p.N;
+  const int n = CN > 0 ? CN : p.n, m = CM > 0 ? CM : p.m, N = CNP > 0 ? CNP : p.N;
   const int t = threadIdx.x, NT = blockDim.x;
   const PairTable& pt = p.pairs;
   T* sx = sm;  // [x | u] argument image
@@ -261,7 +273,15 @@ __device__ __forceinline__ void linquad_step(const DevProblem& p, const QuadTabl
       const int q = pt.pii[i];
       T s1 = T(0), s2 = T(0);
       for (int d = 0; d < p.udim[i]; d++) s1 += sr[pt.rgoff[q] + d] * sr[pt.rgoff[q] + d];
-      for (int d = 0; d < n; d++) s2 += sl[i * n + d] * sl[i * n + d];
+      if constexpr (CN > 0) {
+        T lv[CN];  // loads first, then the sequential sum (same order as the reference)
+#pragma unroll
+        for (int d = 0; d < CN; d++) lv[d] = sl[i * CN + d];
+#pragma unroll
+        for (int d = 0; d < CN; d++) s2 += lv[d] * lv[d];
+      } else {
+        for (int d = 0; d < n; d++) s2 += sl[i * n + d] * sl[i * n + d];
+      }
       a.merit_part[(size_t(k) * N + i) * 2 + 0] = s1;
       a.merit_part[(size_t(k) * N + i) * 2 + 1] = s2;
     }

@@ -89,8 +89,8 @@ def selftest_mfma(dtype, X, Y, Cm):
     return out.cpu().numpy().T
 
 
-def lq_feedback(dims, A, Bm, Q, l, R, r, pairs, x0=None, want_dx=True):
-    """ilqg_lq_feedback_batch on device tensors (numpy inputs are uploaded). Returns torch tensors."""
+def lq_feedback(dims, A, Bm, Q, l, R, r, pairs, x0=None, want_dx=True, open_loop=False):
+    """ilqg_lq_feedback_batch / ilqg_lq_openloop_batch on device tensors (numpy inputs are uploaded)."""
     import torch
     dt = dims.dtype
     B, T, n, N = dims.batch, dims.T, dims.n, dims.num_players
@@ -99,7 +99,8 @@ def lq_feedback(dims, A, Bm, Q, l, R, r, pairs, x0=None, want_dx=True):
     P = torch.empty((B, T, m * n), dtype=torch_dtype(dt), device="cuda")
     alpha = torch.empty((B, T, m), dtype=torch_dtype(dt), device="cuda")
     dx = torch.empty((B, T, n), dtype=torch_dtype(dt), device="cuda") if want_dx else None
-    _check(lib().ilqg_lq_feedback_batch(C.byref(dims), _ptr(A), _ptr(Bm), _ptr(Q), _ptr(l), _ptr(R), _ptr(r),
+    fn = lib().ilqg_lq_openloop_batch if open_loop else lib().ilqg_lq_feedback_batch
+    _check(fn(C.byref(dims), _ptr(A), _ptr(Bm), _ptr(Q), _ptr(l), _ptr(R), _ptr(r),
                                         abi.make_pairs(pairs), len(pairs), _ptr(x0), _ptr(P), _ptr(alpha), _ptr(dx),
                                         None, _stream()))
     return P, alpha, dx

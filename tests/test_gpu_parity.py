@@ -68,6 +68,44 @@ def test_lq_feedback_matches_oracle_random(hip, oracle, dims, dtype):
     assert rel_err(_np(dx), dxr) < tol
 
 
+@pytest.mark.parametrize("dims", [(14, 3, 2), (16, 3, 2), (24, 4, 2), (6, 3, 2), (2, 2, 1)])
+@pytest.mark.parametrize("dtype", [abi.F64, abi.F32])
+def test_lq_openloop_matches_oracle_random(hip, oracle, dims, dtype):
+    """ilqg_lq_openloop_batch vs the oracle's LQOpenLoopSolver restatement (alpha, delta_xs; P == 0)."""
+    n, N, mu = dims
+    rng = np.random.default_rng(7 * n + N)
+    T, B = 20, 4
+    g = random_lq_game(rng, n, [mu] * N, T, B)
+    g["A"] = np.asarray(g["A"])
+    d = dims_of(g, dtype)
+    x0 = rng.standard_normal((B, n))
+    Pr, ar, dxr, _ = oracle.lq_solve(d, g["A"], g["Bm"], g["Q"], g["l"], g["R"], g["r"], g["pairs"], x0=x0,
+                                     open_loop=True)
+    P, alpha, dx = hip.lq_feedback(d, g["A"], g["Bm"], g["Q"], g["l"], g["R"], g["r"], g["pairs"], x0=x0,
+                                   open_loop=True)
+    tol = 1e-8 if dtype == abi.F64 else 5e-3
+    assert np.all(_np(P) == 0)
+    assert rel_err(_np(alpha), ar) < tol
+    assert rel_err(_np(dx), dxr) < tol
+
+
+def test_ilq_solve_open_loop_matches_oracle_fp64(hip, oracle):
+    """BASELINE config 4: roundabout merging (n=24, 4 players) with SolverParams::open_loop, fp64."""
+    spec = examples.roundabout_merging(open_loop=True)
+    spec.params.expected_decrease_fraction = 0.001
+    B, K = 4, 3
+    x0 = examples.jittered_x0(spec, B, seed=5)
+    ref = oracle.OracleProblem(spec).solve(abi.F64, x0, fixed_iters=K, merit_log_len=K)
+    out = hip.Problem(spec, abi.F64).solve(x0, fixed_iters=K)
+    ok = _clean(ref)
+    assert len(ok) >= 2
+    assert np.array_equal(_np(out["iters"])[ok], ref["iters"][ok])
+    assert rel_err(_np(out["xs"])[ok], ref["xs"][ok]) < 1e-6
+    assert rel_err(_np(out["alpha"])[ok], ref["alpha"][ok]) < 1e-5
+    assert np.all(_np(out["P"]) == 0)
+    assert rel_err(_np(out["costs"])[ok], ref["costs"][ok]) < 1e-7
+
+
 def test_lq_feedback_partial_pairs_and_no_regularization(hip, oracle):
     """Only the (i,i) blocks plus one off-diagonal block; adaptive_regularization off."""
     rng = np.random.default_rng(5)
