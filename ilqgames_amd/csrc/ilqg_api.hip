@@ -358,14 +358,15 @@ static ilqg_status launch_linquad(const ilqg_problem* p, int32_t batch, const vo
 template <typename T, int NX, int NP, int MU>
 static ilqg_status launch_solve(ilqg_problem* p, int32_t batch, const void* x0, void* xs, void* us, void* P,
                                 void* alpha, void* total_costs, int32_t* iters, int32_t* status, int32_t* converged,
-                                void* workspace, int32_t fixed_iters, hipStream_t stream) {
+                                void* workspace, int32_t fixed_iters, int al_mode, hipStream_t stream) {
   using C = LQCfg<T, NX, NP, MU>;
   const DevProblem& d = p->dev;
   static_assert(OLCfg<T, NX, NP, MU>::ROW == ((NX * NX + NX + NP * MU * NX + NP * MU + NP * NX * NX + 2 * NP * NX + 3) & ~3), "ol_row_elems");
   const int ol_row = p->desc.params.open_loop ? ol_row_elems(d.n, d.m, d.N) : 0;
-  const WsLayout L(d.n, d.m, d.N, d.T, d.pairs.Rsz, d.pairs.rsz, ol_row);
+  const WsLayout L(d.n, d.m, d.N, d.T, d.pairs.Rsz, d.pairs.rsz, ol_row, d.num_constraints, al_mode);
   SolveArgs<T> sa;
   sa.ol_row = ol_row;
+  sa.al_mode = al_mode;
   sa.x0 = (const T*)x0; sa.xs = (T*)xs; sa.us = (T*)us; sa.P = (T*)P; sa.alpha = (T*)alpha;
   sa.total_costs = (T*)total_costs; sa.iters = iters; sa.status = status; sa.converged = converged;
   sa.ws = (T*)workspace; sa.ws_stride = L.total; sa.fixed_iters = fixed_iters; sa.batch = batch;
@@ -749,7 +750,8 @@ ilqg_status ilqg_problem_pairs(const ilqg_problem* p, ilqg_pair* pairs_host, int
 ilqg_status ilqg_workspace_bytes(const ilqg_problem* p, int32_t batch, uint64_t* bytes) {
   if (!p || !bytes) return fail(ILQG_ERR_INVALID, "null argument");
   const DevProblem& d = p->dev;
-  const WsLayout L(d.n, d.m, d.N, d.T, d.pairs.Rsz, d.pairs.rsz, p->desc.params.open_loop ? ol_row_elems(d.n, d.m, d.N) : 0);
+  const WsLayout L(d.n, d.m, d.N, d.T, d.pairs.Rsz, d.pairs.rsz, p->desc.params.open_loop ? ol_row_elems(d.n, d.m, d.N) : 0,
+                   d.num_constraints, 1);
   *bytes = uint64_t(L.total) * (p->desc.dtype == ILQG_F32 ? 4 : 8) * uint64_t(batch > 0 ? batch : 0);
   return ILQG_OK;
 }
@@ -814,9 +816,9 @@ ilqg_status ilqg_total_costs_batch(const ilqg_problem* p, int32_t batch, const v
 #undef CALL
 }
 
-ilqg_status ilqg_ilq_solve_batch(ilqg_problem* p, int32_t batch, const void* x0, void* xs, void* us, void* P,
-                                 void* alpha, void* total_costs, int32_t* iters, int32_t* status, int32_t* converged,
-                                 void* workspace, int32_t fixed_iters, void* stream) {
+static ilqg_status solve_impl(ilqg_problem* p, int32_t batch, const void* x0, void* xs, void* us, void* P,
+                              void* alpha, void* total_costs, int32_t* iters, int32_t* status, int32_t* converged,
+                              void* workspace, int32_t fixed_iters, int al_mode, void* stream) {
   if (!p || !x0 || !xs || !us || !P || !alpha || !total_costs || !iters || !status || !converged || !workspace)
     return fail(ILQG_ERR_INVALID, "null argument");
   if (batch <= 0) return ILQG_OK;
@@ -827,13 +829,26 @@ ilqg_status ilqg_ilq_solve_batch(ilqg_problem* p, int32_t batch, const void* x0,
   if (d.n == NX_ && d.N == NP_ && p->mu_uniform == MU_) {                                                       \
     return p->desc.dtype == ILQG_F32                                                                            \
                ? launch_solve<float, NX_, NP_, MU_>(p, batch, x0, xs, us, P, alpha, total_costs, iters, status,  \
-                                                    converged, workspace, fixed_iters, st)                      \
+                                                    converged, workspace, fixed_iters, al_mode, st)                      \
                : launch_solve<double, NX_, NP_, MU_>(p, batch, x0, xs, us, P, alpha, total_costs, iters, status, \
-                                                     converged, workspace, fixed_iters, st);                    \
+                                                     converged, workspace, fixed_iters, al_mode, st);                    \
   }
   ILQG_FOR_DIMS(X)
 #undef X
   return fail(ILQG_ERR_UNSUPPORTED, "no device kernel instantiated for this problem's dimensions");
+}
+
+ilqg_status ilqg_ilq_solve_batch(ilqg_problem* p, int32_t batch, const void* x0, void* xs, void* us, void* P,
+                                 void* alpha, void* total_costs, int32_t* iters, int32_t* status, int32_t* converged,
+                                 void* workspace, int32_t fixed_iters, void* stream) {
+  return solve_impl(p, batch, x0, xs, us, P, alpha, total_costs, iters, status, converged, workspace, fixed_iters, 0,
+                    stream);
+}
+
+ilqg_status ilqg_al_solve_batch(ilqg_problem* p, int32_t batch, const void* x0, void* xs, void* us, void* P,
+                                void* alpha, void* total_costs, int32_t* iters, int32_t* status, int32_t* converged,
+                                void* workspace, void* stream) {
+  return solve_impl(p, batch, x0, xs, us, P, alpha, total_costs, iters, status, converged, workspace, 0, 1, stream);
 }
 
 }  // extern "C"

@@ -31,6 +31,7 @@ struct SolveArgs {
   int fixed_iters;
   int batch;
   int ol_row;           // elements per open-loop scratch row (0 when the feedback sweep is used)
+  int al_mode;          // 1: AugmentedLagrangianSolver::Solve around the inner iLQ solve
   ilqg_solver_params prm;
   long long* prof;      // optional [B][8] shader-clock cycles per stage (diagnostics) or nullptr
 };
@@ -42,8 +43,9 @@ __host__ __device__ inline int ol_row_elems(int n, int m, int N) {
 
 // Per-instance workspace layout (in elements of T).
 struct WsLayout {
-  size_t xs1, us1, P1, al1, A, B, Q, l, R, r, lqscr, dx, mpart, cpart, ints, total;
-  __host__ __device__ WsLayout(int n, int m, int N, int T, int Rsz, int rsz, int ol_row = 0) {
+  size_t xs1, us1, P1, al1, A, B, Q, l, R, r, lqscr, dx, mpart, cpart, ints, lambdas, wxs, wus, wP, wal, total;
+  __host__ __device__ WsLayout(int n, int m, int N, int T, int Rsz, int rsz, int ol_row = 0, int num_constraints = 0,
+                               int al_mode = 0) {
     size_t o = 0;
     auto take = [&](size_t cnt) {
       const size_t at = o;
@@ -65,6 +67,11 @@ struct WsLayout {
     mpart = take(size_t(T) * N * 2);
     cpart = take(size_t(T) * N);
     ints = take(2 * kMaxPlayers);  // t_extreme as int32 (room for fp32 or fp64 elements)
+    lambdas = take(size_t(num_constraints) * T);  // per-instance Constraint::lambdas_ (constraint.h:136)
+    wxs = take(al_mode ? size_t(T) * n : 0);      // Problem's stored solution = warm start of the next inner solve
+    wus = take(al_mode ? size_t(T) * m : 0);
+    wP = take(al_mode ? size_t(T) * m * n : 0);
+    wal = take(al_mode ? size_t(T) * m : 0);
     total = o;
   }
 };
@@ -79,7 +86,7 @@ __device__ __forceinline__ void ilq_solve_instance(const DevProblem& p, const Qu
   const int Tn = p.T;
   const PairTable& pt = p.pairs;
   const ilqg_solver_params& prm = sa.prm;
-  const WsLayout L(n, m, N, Tn, pt.Rsz, pt.rsz, sa.ol_row);
+  const WsLayout L(n, m, N, Tn, pt.Rsz, pt.rsz, sa.ol_row, p.num_constraints, sa.al_mode);
   T* w = sa.ws + size_t(b) * sa.ws_stride;
   // two operating-point buffers and two strategy buffers; buffer 0 is the caller's
   T* const xs0 = sa.xs + size_t(b) * Tn * n;
@@ -96,12 +103,21 @@ __device__ __forceinline__ void ilq_solve_instance(const DevProblem& p, const Qu
   const int t = threadIdx.x;
 
   if (t < N) t_extreme[t] = 0;  // PlayerCost::time_of_extreme_cost_ starts at 0 (player_cost.h:70)
+  T* lambdas = w + L.lambdas;     // Constraint::lambdas_, zero-initialised (types.h:128)
+  for (int e = t; e < p.num_constraints * Tn; e += blockDim.x) lambdas[e] = T(0);
+  T mu = T(10);                   // Constraint::mu_ = kDefaultMu (src/constraint.cpp:61) — one per instance
+  if (sa.al_mode) {               // Problem's stored solution (what OverwriteSolution maintains)
+    for (int e = t; e < Tn * n; e += blockDim.x) (w + L.wxs)[e] = xs0[e];
+    for (int e = t; e < Tn * m; e += blockDim.x) (w + L.wus)[e] = us0[e];
+    for (int e = t; e < Tn * m * n; e += blockDim.x) (w + L.wP)[e] = P0[e];
+    for (int e = t; e < Tn * m; e += blockDim.x) (w + L.wal)[e] = al0[e];
+  }
   __syncthreads();
 
-  long long pr_acc[4] = {0, 0, 0, 0};
+  long long pr_acc[5] = {0, 0, 0, 0, 0};
   const long long pr_start = clock64();
 
-  enum { ST_ROLLOUT = 0, ST_QUAD = 1, ST_LQ = 2, ST_DONE = 3 };
+  enum { ST_ROLLOUT = 0, ST_QUAD = 1, ST_LQ = 2, ST_INNER_DONE = 3, ST_DONE = 4 };
   enum { Q_COSTS = 0, Q_INIT = 1, Q_TRIAL = 2, Q_LIN = 3 };
   int stage = ST_ROLLOUT, qmode = Q_COSTS;
   bool initial = true;
@@ -109,9 +125,15 @@ __device__ __forceinline__ void ilq_solve_instance(const DevProblem& p, const Qu
   int sacc = 0;  // strategy buffer holding the last accepted strategies
   T acc_scale = T(1), step = T(1);
   T last_merit = dinf<T>(), expected_decrease = dinf<T>();
-  int num_iterations = 0, bt = 0;
+  int num_iterations = 0, bt = 0, accepted_iters = 0;
   bool has_converged = false, ok = true;
-  const int max_iters = sa.fixed_iters > 0 ? sa.fixed_iters : prm.max_solver_iters;
+  // AugmentedLagrangianSolver builds its inner ILQSolver with unconstrained_solver_max_iters
+  // (augmented_lagrangian_solver.h:80-84)
+  const int max_iters = sa.fixed_iters > 0 ? sa.fixed_iters
+                                          : (sa.al_mode ? prm.unconstrained_solver_max_iters : prm.max_solver_iters);
+  int logged = 0, inner_calls = 0;
+  bool al_success = true;
+  T max_err = dinf<T>();
 
 #pragma unroll 1
   while (stage != ST_DONE) {
@@ -143,8 +165,8 @@ __device__ __forceinline__ void ilq_solve_instance(const DevProblem& p, const Qu
       QuadArgs<T> qa;
       qa.xs = XS(at);
       qa.us = US(at);
-      qa.lambdas = nullptr;
-      qa.mu = T(10);
+      qa.lambdas = p.num_constraints > 0 ? lambdas : nullptr;
+      qa.mu = mu;
       qa.t_extreme = t_extreme;
       qa.t_init = 0.0;
       const bool lin = qmode != Q_COSTS, quad = qmode == Q_INIT || qmode == Q_TRIAL;
@@ -163,7 +185,7 @@ __device__ __forceinline__ void ilq_solve_instance(const DevProblem& p, const Qu
         qmode = Q_INIT;
       } else if (qmode == Q_INIT) {
         initial = false;
-        stage = (num_iterations < max_iters) ? ST_LQ : ST_DONE;
+        stage = (num_iterations < max_iters) ? ST_LQ : ST_INNER_DONE;
       } else {
         bool accepted = true;
         if (qmode == Q_TRIAL) {
@@ -181,20 +203,21 @@ __device__ __forceinline__ void ilq_solve_instance(const DevProblem& p, const Qu
           cur = 1 - cur;
           sacc = 1 - sacc;
           acc_scale = step;
+          accepted_iters++;
           costs_reduce<T>(p, w + L.cpart, costs, t_extreme);  // TotalCosts of the accepted iterate (:158)
-          stage = (num_iterations < max_iters && (sa.fixed_iters > 0 || !has_converged)) ? ST_LQ : ST_DONE;
+          stage = (num_iterations < max_iters && (sa.fixed_iters > 0 || !has_converged)) ? ST_LQ : ST_INNER_DONE;
         } else {
           bt++;
           if (bt >= prm.max_backtracking_steps) {  // :346-347, :146-155 — keep the last accepted iterate
             ok = false;
-            stage = ST_DONE;
+            stage = ST_INNER_DONE;
           } else {
             step *= T(prm.geometric_alpha_scaling);
             stage = ST_ROLLOUT;
           }
         }
       }
-    } else {  // ST_LQ: LQ game at the current operating point (:136-143) + ExpectedDecrease (:303)
+    } else if (stage == ST_LQ) {  // LQ game at the current operating point (:136-143) + ExpectedDecrease (:303)
       num_iterations++;
       LQArgs<T> la;
       la.A = w + L.A;
@@ -222,29 +245,100 @@ __device__ __forceinline__ void ilq_solve_instance(const DevProblem& p, const Qu
       step = T(prm.initial_alpha_scaling);
       bt = 0;
       stage = ST_ROLLOUT;
+    } else {  // ST_INNER_DONE: one ILQSolver::Solve call has returned
+      // ---- the log's final iterate goes back through buffer 0 (alpha carries the accepted step) ----
+      if (cur == 1) {
+        for (int e = t; e < Tn * n; e += blockDim.x) xs0[e] = (w + L.xs1)[e];
+        for (int e = t; e < Tn * m; e += blockDim.x) us0[e] = (w + L.us1)[e];
+      }
+      if (sacc == 1)
+        for (int e = t; e < Tn * m * n; e += blockDim.x) P0[e] = (w + L.P1)[e];
+      {
+        const T* src = AL(sacc);
+        for (int e = t; e < Tn * m; e += blockDim.x) al0[e] = src[e] * acc_scale;
+      }
+      __syncthreads();
+      stage = ST_DONE;
+      if (sa.al_mode) {  // AugmentedLagrangianSolver::Solve, src/augmented_lagrangian_solver.cpp:72-210
+        logged += 1 + accepted_iters;  // SolverLog entries of this inner call (:94, :185)
+        al_success = al_success && ok;
+        if (inner_calls > 0 && !ok) {  // :166-178
+          for (int e = t; e < p.num_constraints * Tn; e += blockDim.x)
+            lambdas[e] *= T(prm.geometric_lambda_downscaling);
+          mu *= T(prm.geometric_mu_downscaling);
+          __syncthreads();
+        }
+        inner_calls++;
+        if (p.num_constraints > 0 && logged < prm.max_solver_iters &&
+            max_err > T(prm.constraint_error_tolerance)) {
+          // ---- multiplier update at the final operating point (:116-140) ----
+          T my_err = -dinf<T>();
+          if (t < p.num_constraints) {
+            int ti = 0;
+            for (int e = 0; e < p.num_terms; e++)
+              if (tb.terms[e].slot == t) ti = e;
+            const DevTerm c = tb.terms[ti];
+            const bool on_state = c.role == ILQG_ROLE_STATE_CONSTRAINT;
+            for (int k = 0; k < Tn; k++) {
+              const T* v = on_state ? xs0 + size_t(k) * n : us0 + size_t(k) * m + p.uoff[c.arg];
+              const T err = term_evaluate_leaf<T>(tb, ti, v, c.arg_dim);
+              my_err = err > my_err ? err : my_err;
+              // Constraint::IncrementLambda (constraint.h:98-102) at TimeIndex(t0 + dt*float(k))
+              const double tt = 0.0 + p.dt * double(float(k));
+              const int tidx = int(static_cast<size_t>(tt / p.dt));
+              const T nl = lambdas[t * Tn + tidx] + mu * err;
+              lambdas[t * Tn + tidx] = nl > T(0) ? nl : T(0);
+            }
+          }
+          if (t < 64) {
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+              const T o = __shfl_xor(my_err, off, 64);
+              my_err = o > my_err ? o : my_err;
+            }
+            if (t == 0) sm[0] = my_err;
+          }
+          __syncthreads();
+          max_err = sm[0];
+          __syncthreads();
+          mu *= T(prm.geometric_mu_scaling);  // :143
+          // Problem::OverwriteSolution only after a successful inner solve (:151-154)
+          if (ok) {
+            for (int e = t; e < Tn * n; e += blockDim.x) (w + L.wxs)[e] = xs0[e];
+            for (int e = t; e < Tn * m; e += blockDim.x) (w + L.wus)[e] = us0[e];
+            for (int e = t; e < Tn * m * n; e += blockDim.x) (w + L.wP)[e] = P0[e];
+            for (int e = t; e < Tn * m; e += blockDim.x) (w + L.wal)[e] = al0[e];
+          } else {
+            for (int e = t; e < Tn * n; e += blockDim.x) xs0[e] = (w + L.wxs)[e];
+            for (int e = t; e < Tn * m; e += blockDim.x) us0[e] = (w + L.wus)[e];
+            for (int e = t; e < Tn * m * n; e += blockDim.x) P0[e] = (w + L.wP)[e];
+            for (int e = t; e < Tn * m; e += blockDim.x) al0[e] = (w + L.wal)[e];
+          }
+          __syncthreads();
+          // ---- next ILQSolver::Solve call: fresh locals, persistent last_merit / t_extreme ----
+          stage = ST_ROLLOUT;
+          initial = true;
+          cur = 0;
+          sacc = 0;
+          acc_scale = T(1);
+          num_iterations = 0;
+          accepted_iters = 0;
+          has_converged = false;
+          ok = true;
+        }
+      }
     }
     pr_acc[stage_was] += clock64() - pr_t0;
   }
+  if (sa.al_mode && p.num_constraints > 0 && max_err > T(prm.constraint_error_tolerance)) al_success = false;  // :188-191
 
-  // ---- hand the result back through buffer 0 ----
-  __syncthreads();
-  if (cur == 1) {
-    for (int e = t; e < Tn * n; e += blockDim.x) xs0[e] = (w + L.xs1)[e];
-    for (int e = t; e < Tn * m; e += blockDim.x) us0[e] = (w + L.us1)[e];
-  }
-  if (sacc == 1)
-    for (int e = t; e < Tn * m * n; e += blockDim.x) P0[e] = (w + L.P1)[e];
-  {
-    const T* src = AL(sacc);
-    for (int e = t; e < Tn * m; e += blockDim.x) al0[e] = src[e] * acc_scale;
-  }
   if (t == 0 && sa.prof) {
     long long* o = sa.prof + size_t(b) * 16;
     o[0] = pr_acc[0]; o[1] = pr_acc[1]; o[2] = pr_acc[2]; o[3] = 0; o[4] = clock64() - pr_start;
   }
   if (t == 0) {
-    sa.iters[b] = num_iterations;
-    sa.status[b] = ok ? 1 : 0;
+    sa.iters[b] = sa.al_mode ? logged : num_iterations;
+    sa.status[b] = (sa.al_mode ? al_success : ok) ? 1 : 0;
     sa.converged[b] = has_converged ? 1 : 0;
   }
 }

@@ -18,7 +18,7 @@ EXPORTS = [
     "ilqg_lq_feedback_batch", "ilqg_lq_openloop_batch", "ilqg_default_solver_params", "ilqg_problem_create",
     "ilqg_problem_destroy", "ilqg_workspace_bytes", "ilqg_rollout_batch", "ilqg_linearize_batch",
     "ilqg_quadraticize_batch", "ilqg_problem_pairs", "ilqg_total_costs_batch", "ilqg_ilq_solve_batch",
-    "ilqg_last_error", "ilqg_abi_version", "ilqg_device_info", "ilqg_selftest_mfma",
+    "ilqg_last_error", "ilqg_abi_version", "ilqg_device_info", "ilqg_selftest_mfma", "ilqg_al_solve_batch",
 ]
 
 
@@ -187,13 +187,19 @@ class Problem:
                     converged=torch.zeros(batch, dtype=torch.int32, device="cuda"),
                     ws=torch.empty(self.workspace_bytes(batch), dtype=torch.uint8, device="cuda"))
 
-    def solve(self, x0, bufs=None, fixed_iters=0):
-        """ilqg_ilq_solve_batch. `bufs` (from alloc_solve_buffers) carries the warm start in and the
-        solution out; zero warm start if omitted."""
+    def solve(self, x0, bufs=None, fixed_iters=0, augmented_lagrangian=False):
+        """ilqg_ilq_solve_batch (or ilqg_al_solve_batch). `bufs` (from alloc_solve_buffers) carries the
+        warm start in and the solution out; zero warm start if omitted."""
         x0 = _dev(x0, self.dtype)
         B = x0.shape[0]
         if bufs is None:
             bufs = self.alloc_solve_buffers(B)
+        if augmented_lagrangian:
+            _check(lib().ilqg_al_solve_batch(self.h, B, _ptr(x0), _ptr(bufs["xs"]), _ptr(bufs["us"]),
+                                             _ptr(bufs["P"]), _ptr(bufs["alpha"]), _ptr(bufs["costs"]),
+                                             _ptr(bufs["iters"]), _ptr(bufs["status"]), _ptr(bufs["converged"]),
+                                             _ptr(bufs["ws"]), _stream()))
+            return bufs
         _check(lib().ilqg_ilq_solve_batch(self.h, B, _ptr(x0), _ptr(bufs["xs"]), _ptr(bufs["us"]), _ptr(bufs["P"]),
                                           _ptr(bufs["alpha"]), _ptr(bufs["costs"]), _ptr(bufs["iters"]),
                                           _ptr(bufs["status"]), _ptr(bufs["converged"]), _ptr(bufs["ws"]),

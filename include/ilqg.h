@@ -298,6 +298,21 @@ ilqg_status ilqg_ilq_solve_batch(ilqg_problem* p, int32_t batch, const void* x0,
                                  void* workspace, int32_t fixed_iters,
                                  void* stream);
 
+/* Replaces AugmentedLagrangianSolver::Solve (src/augmented_lagrangian_solver.cpp:72-210) with
+ * max_runtime = infinity: inner ilqg_ilq_solve_batch calls capped at
+ * params.unconstrained_solver_max_iters, multiplier update lambda <- max(0, lambda + mu g) at the
+ * final operating point (with the reference's TimeIndex aliasing), mu *= geometric_mu_scaling,
+ * warm restart from the last successful inner solve, down-scaling of lambda and mu after a failed
+ * one, until the SolverLog would hold max_solver_iters iterates or max g <= constraint_error_tolerance.
+ * One (lambda, mu) state per instance replaces the reference's process-global Constraint::mu_.
+ *  iters [B]  = number of SolverLog iterates;  status [B] = overall success flag.
+ * Same buffers as ilqg_ilq_solve_batch; workspace from ilqg_workspace_bytes. */
+ilqg_status ilqg_al_solve_batch(ilqg_problem* p, int32_t batch, const void* x0,
+                                void* xs, void* us, void* P, void* alpha,
+                                void* total_costs, int32_t* iters,
+                                int32_t* status, int32_t* converged,
+                                void* workspace, void* stream);
+
 /* Diagnostics: out = X^T Y + C for 16x16 column-major device matrices, computed through the
  * MFMA accumulator-layout path the LQ sweep is built on (pins the gfx950 register layouts). */
 ilqg_status ilqg_selftest_mfma(int32_t dtype, const void* X, const void* Y, const void* C, void* out, void* stream);

@@ -1270,7 +1270,8 @@ struct ILQState {
 template <class S>
 bool SolveILQ(const Problem<S>& p, const Vec<S>& x0, Trajectory<S>* op_io, Strategies<S>* st_io,
               ILQState<S>* state, const ALState<S>* al, int fixed_iters, std::vector<IterLog<S>>* log,
-              Vec<S>* final_costs, int* iters_out, int* converged_out, Strategies<S>* raw = nullptr) {
+              Vec<S>* final_costs, int* iters_out, int* converged_out, Strategies<S>* raw = nullptr,
+              int* logged_out = nullptr) {
   const ilqg_solver_params& prm = p.params;
   if ((int)state->t_extreme.size() != p.N) state->t_extreme.assign(p.N, 0);
   Trajectory<S> last_op = *op_io, cur_op = *op_io;
@@ -1349,7 +1350,80 @@ bool SolveILQ(const Problem<S>& p, const Vec<S>& x0, Trajectory<S>* op_io, Strat
   if (final_costs) *final_costs = logged_costs;
   if (iters_out) *iters_out = num_iterations;
   if (converged_out) *converged_out = has_converged ? 1 : 0;
+  // SolverLog entries this call produced: iterate 0 + one per accepted iteration (:111,164)
+  if (logged_out) *logged_out = 1 + (ok ? num_iterations : num_iterations - 1);
   return ok;
+}
+
+// ---------------------------------------------------------------------------
+// AugmentedLagrangianSolver::Solve, src/augmented_lagrangian_solver.cpp:72-210, with
+// max_runtime = infinity (the reference's per-call time budget is wall-clock).
+// One ALState per instance replaces Constraint::lambdas_ / the process-global Constraint::mu_.
+// Returns overall success; *logged_out = log->NumIterates() at exit.
+// ---------------------------------------------------------------------------
+template <class S>
+bool SolveAL(const Problem<S>& p, const Vec<S>& x0, Trajectory<S>* op_io, Strategies<S>* st_io,
+             Vec<S>* final_costs, int* logged_out, S* max_err_out) {
+  ilqg_solver_params inner = p.params;
+  inner.max_solver_iters = p.params.unconstrained_solver_max_iters;  // augmented_lagrangian_solver.h:80-84
+  Problem<S> pin = p;
+  pin.params = inner;
+  ILQState<S> state;
+  ALState<S> al(p.num_constraints, p.T, p.dt);
+  Trajectory<S> warm_op = *op_io, res_op = *op_io;
+  Strategies<S> warm_st = *st_io, res_st = *st_io;
+  Vec<S> costs;
+  int logged = 0, it = 0, conv = 0, lg = 0;
+  bool success = true;
+  bool inner_ok = SolveILQ(pin, x0, &res_op, &res_st, &state, &al, 0, (std::vector<IterLog<S>>*)nullptr, &costs,
+                           &it, &conv, (Strategies<S>*)nullptr, &lg);
+  logged += lg;
+  success = success && inner_ok;
+  S max_err = std::numeric_limits<S>::infinity();
+  if (p.num_constraints > 0) {
+    while (logged < p.params.max_solver_iters && max_err > S(p.params.constraint_error_tolerance)) {
+      max_err = -std::numeric_limits<S>::infinity();
+      // multiplier update at the last logged operating point (:116-140); terms are visited per
+      // player in PlayerCost order: state constraints then control constraints, k outer.
+      for (int i = 0; i < p.N; i++)
+        for (int k = 0; k < p.T; k++) {
+          const double t = 0.0 + p.dt * double(float(k));
+          for (int role = ILQG_ROLE_STATE_CONSTRAINT; role <= ILQG_ROLE_CONTROL_CONSTRAINT; role++)
+            for (size_t ti = 0; ti < p.terms.size(); ti++) {
+              const ilqg_cost_term& c = p.terms[ti];
+              if (c.player != i || c.role != role) continue;
+              const S err = (role == ILQG_ROLE_STATE_CONSTRAINT)
+                                ? EvaluateTerm(p, (int)ti, res_op.xs[k].data(), p.n)
+                                : EvaluateTerm(p, (int)ti, &res_op.us[k][p.uoff[c.arg]], p.udim(c.arg));
+              max_err = std::max(max_err, err);
+              S& lam = al.lambda(c.constraint_slot, t);  // Constraint::IncrementLambda, constraint.h:98-102
+              lam = std::max(S(0), lam + al.mu * err);
+            }
+        }
+      al.mu *= S(p.params.geometric_mu_scaling);  // :143
+      if (inner_ok) {                              // :151-154
+        warm_op = res_op;
+        warm_st = res_st;
+      }
+      res_op = warm_op;
+      res_st = warm_st;
+      inner_ok = SolveILQ(pin, x0, &res_op, &res_st, &state, &al, 0, (std::vector<IterLog<S>>*)nullptr, &costs,
+                          &it, &conv, (Strategies<S>*)nullptr, &lg);
+      if (!inner_ok) {  // :166-178
+        for (auto& l : al.lambdas) l *= S(p.params.geometric_lambda_downscaling);
+        al.mu *= S(p.params.geometric_mu_downscaling);
+      }
+      success = success && inner_ok;
+      logged += lg;
+    }
+    if (max_err > S(p.params.constraint_error_tolerance)) success = false;  // :188-191
+  }
+  *op_io = res_op;
+  *st_io = res_st;
+  if (final_costs) *final_costs = costs;
+  if (logged_out) *logged_out = logged;
+  if (max_err_out) *max_err_out = max_err;
+  return success;
 }
 
 }  // namespace oracle

@@ -249,7 +249,13 @@ void SolveBatch(const OracleProblem* op, int batch, const void* x0, void* xs, vo
     std::vector<IterLog<S>> log;
     Vec<S> fc;
     int it = 0, conv = 0;
-    const bool ok = SolveILQ(p, x0v, &tr, &st, &state, &al, fixed_iters, &log, &fc, &it, &conv, &raw);
+    bool ok;
+    if (fixed_iters == -1) {  // AugmentedLagrangianSolver::Solve
+      S maxerr;
+      ok = SolveAL(p, x0v, &tr, &st, &fc, &it, &maxerr);
+    } else {
+      ok = SolveILQ(p, x0v, &tr, &st, &state, &al, fixed_iters, &log, &fc, &it, &conv, &raw);
+    }
     PackTraj(p, tr, (S*)xs + size_t(b) * T * n, (S*)us + size_t(b) * T * m);
     PackStrategies(p, st, (S*)P + size_t(b) * T * m * n, (S*)alpha + size_t(b) * T * m);
     if (rawP && !raw.P.empty())

@@ -121,8 +121,12 @@ class OracleProblem:
         lib().oracle_total_costs(self.h, dtype, B, _p(xs), _p(us), _p(costs), _p(te))
         return costs, te
 
-    def solve(self, dtype, x0, xs=None, us=None, P=None, alpha=None, fixed_iters=0, merit_log_len=0, threads=1):
-        """ILQSolver::Solve per instance. Returns dict with final op/strategies/costs/iters/status."""
+    def solve(self, dtype, x0, xs=None, us=None, P=None, alpha=None, fixed_iters=0, merit_log_len=0, threads=1,
+              augmented_lagrangian=False):
+        """ILQSolver::Solve (or AugmentedLagrangianSolver::Solve) per instance.
+        Returns dict with final op/strategies/costs/iters/status."""
+        if augmented_lagrangian:
+            fixed_iters = -1
         dt = _np(dtype)
         B = x0.shape[0]
         x0 = np.ascontiguousarray(x0, dtype=dt)

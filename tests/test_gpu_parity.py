@@ -238,3 +238,24 @@ def test_ilq_solve_free_running_matches_oracle_fp64(hip, oracle):
     assert rel_err(_np(out["xs"])[ok], ref["xs"][ok]) < 1e-7
     assert rel_err(_np(out["P"])[ok], ref["P"][ok]) < 1e-6
     assert rel_err(_np(out["costs"])[ok], ref["costs"][ok]) < 1e-8
+
+
+def test_augmented_lagrangian_solve_matches_oracle_fp64(hip, oracle):
+    """ilqg_al_solve_batch vs the oracle's AugmentedLagrangianSolver restatement on the constrained
+    three-player intersection (n=16, six ProximityConstraints), fp64, a 30-iterate log budget.
+    Multiplier updates, mu schedule, warm restarts and failure down-scaling must all line up for the
+    final iterate to agree; instances whose line searches are noise-limited are excluded as above."""
+    spec = examples.three_player_intersection()
+    spec.params.max_solver_iters = 30
+    spec.params.unconstrained_solver_max_iters = 5
+    B = 12
+    x0 = examples.jittered_x0(spec, B, seed=21)
+    ref = oracle.OracleProblem(spec).solve(abi.F64, x0, augmented_lagrangian=True)
+    out = hip.Problem(spec, abi.F64).solve(x0, augmented_lagrangian=True)
+    same = np.where((_np(out["iters"]) == ref["iters"]) & (_np(out["status"]) == ref["status"]))[0]
+    assert len(same) >= 0.5 * B, (_np(out["iters"]), ref["iters"])
+    err = np.array([rel_err(_np(out["xs"])[b], ref["xs"][b]) for b in same])
+    good = same[err < 1e-6]
+    assert len(good) >= 0.5 * len(same), err
+    assert rel_err(_np(out["costs"])[good], ref["costs"][good]) < 1e-6
+    assert np.isfinite(_np(out["xs"])).all()
