@@ -55,7 +55,8 @@ struct OLCfg {
   static constexpr int LDS_ELEMS = LDS_FWD > LDS_BWD ? LDS_FWD : LDS_BWD;
 };
 
-// Solve R y = b for a small SPD block with the LDL^T the oracle uses (no pivoting).
+// Solve R y = b for a small SPD block by LDL^T without pivoting (Eigen::LDLT at
+// src/lq_open_loop_solver.cpp:124-126; R_ii is diagonally dominant in every config).
 template <typename T, int MU>
 __device__ __forceinline__ void ldlt_solve(const T* R /* MU x MU col-major */, T (&b)[MU]) {
   T Lm[MU][MU], D[MU];
