@@ -187,6 +187,67 @@ class ProblemSpec:
     def num_constraints(self):
         return self._num_constraints
 
+    @staticmethod
+    def from_dump(text):
+        """Parse host::DumpDescription output (include/ilqgames/host/api.hpp) — the flattened form of a
+        C++ `Problem` built through the mirrored reference API — back into a ProblemSpec."""
+        spec = None
+        subs, pcs = [], []
+        for line in text.splitlines():
+            tok = line.split()
+            if not tok:
+                continue
+            if tok[0] == "problem":
+                spec = ProblemSpec(int(tok[2]), float(tok[3]))
+            elif tok[0] == "subsystem":
+                subs.append((int(tok[1]), int(tok[2]), int(tok[3]), float(tok[4])))
+            elif tok[0] == "player_cost":
+                pcs.append((float(tok[1]), float(tok[2]), int(tok[3])))
+            elif tok[0] == "term":
+                v = tok[1:]
+                spec.terms.append(dict(kind=int(v[0]), role=int(v[1]), player=int(v[2]), arg=int(v[3]),
+                                       idx=tuple(int(a) for a in v[4:8]), weight=float(v[8]), value=float(v[9]),
+                                       flags=int(v[10]), polyline=int(v[11]), child_begin=int(v[12]),
+                                       child_count=int(v[13]), constraint_slot=int(v[14])))
+                if int(v[14]) >= 0:
+                    spec._num_constraints = max(spec._num_constraints, int(v[14]) + 1)
+            elif tok[0] == "polyline":
+                f = [float(a) for a in tok[1:]]
+                spec.polylines.append(list(zip(f[0::2], f[1::2])))
+            elif tok[0] == "params":
+                v = tok[1:]
+                spec.params = SolverParams(float(v[0]), int(v[1]), int(v[2]), float(v[3]), float(v[4]), int(v[5]),
+                                           float(v[6]), int(v[7]), int(v[8]), float(v[9]), float(v[10]),
+                                           float(v[11]), float(v[12]))
+            elif tok[0] == "x0":
+                spec.x0 = [float(a) for a in tok[1:]]
+        spec.subsystems, spec.player_costs = subs, pcs
+        return spec
+
+    def canonical(self):
+        """Order-insensitive view for comparing two specs of the same problem: per (player, role) the
+        terms in order (that order fixes the floating-point summation), polylines by content, constraint
+        slots dropped (slot numbering only indexes the multiplier table)."""
+        import numpy as np
+        f32 = lambda v: float(np.float32(v))
+
+        def term_key(t):
+            # polyline by content, to 6 significant digits: libm's cosf/sinf and a correctly rounded
+            # double->float cos/sin may differ in the last bit of a vertex
+            poly = tuple((float('%.6g' % x), float('%.6g' % y)) for x, y in self.polylines[t["polyline"]]) \
+                if t["polyline"] >= 0 else None
+            kids = tuple(term_key(self.terms[c]) for c in range(t["child_begin"], t["child_begin"] + t["child_count"]))
+            return (t["kind"], t["arg"], tuple(t["idx"]), f32(t["weight"]), f32(t["value"]), t["flags"], poly, kids)
+
+        groups = {}
+        for t in self.terms:
+            if t["role"] == ROLE_CHILD:
+                continue
+            groups.setdefault((t["player"], t["role"]), []).append(term_key(t))
+        subs = [(k, xd, ud, 0.0 if k == DYN_UNICYCLE_4D else f32(p0)) for k, xd, ud, p0 in self.subsystems]
+        pcs = [(f32(a), f32(b), c) for a, b, c in self.player_costs]
+        return dict(T=self.T, dt=self.dt, subsystems=subs, player_costs=pcs, groups=groups, pairs=self.pairs())
+
     def pairs(self):
         """(i, j) control blocks in PlayerCost first-touch order (src/player_cost.cpp:59-86)."""
         out = []

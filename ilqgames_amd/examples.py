@@ -129,12 +129,12 @@ def roundabout_lane_center(entrance_angle, exit_angle, distance_from_roundabout)
     ea = f(entrance_angle)
     xa = f(exit_angle)
     cx, cy = (R + hw) * f(math.cos(ea)), (R + hw) * f(math.sin(ea))
-    a0 = f(ea - f(math.pi / 2))
+    a0 = f(float(ea) - math.pi / 2)  # double subtraction, rounded once
     fx, fy = cx + hw * f(math.cos(a0)), cy + hw * f(math.sin(a0))
     d = f(distance_from_roundabout)
     pts = [(fx + d * f(math.cos(ea)), fy + d * f(math.sin(ea))), (fx, fy)]
     for ii in range(1, 4):
-        ang = f(a0 - f(math.pi / 2) * f(ii) / f(3))
+        ang = f(float(a0) - math.pi / 2 * float(ii) / 3.0)
         pts.append((cx + hw * f(math.cos(ang)), cy + hw * f(math.sin(ang))))
     for ii in range(1, 11):
         na = f(ea + (xa - ea) * f(ii) / f(10))
@@ -160,8 +160,9 @@ def roundabout_merging(T=100, dt=0.1, open_loop=True):
     f = np.float32
     off = f(math.pi / 2 * 0.5)
     wedge = f(math.pi)
-    angles = [off, f(off + f(2.0 * math.pi / 4.0)), f(off + f(2.0 * 2.0 * math.pi / 4.0)),
-              f(off + f(3.0 * 2.0 * math.pi / 4.0))]
+    # float + double, rounded once when stored into the std::vector<float> (roundabout_merging_example.cpp:172-175)
+    angles = [off, f(float(off) + 2.0 * math.pi / 4.0), f(float(off) + 2.0 * 2.0 * math.pi / 4.0),
+              f(float(off) + 3.0 * 2.0 * math.pi / 4.0)]
     dists = [25.0, 10.0, 25.0, 10.0]
     speeds = [3.0, 2.0, 3.0, 2.0]
     x0 = np.zeros(24)

@@ -1,0 +1,680 @@
+// Host-side mirror of the reference API (include/ilqgames/host/api.hpp): flattens Problem objects
+// into the C-ABI descriptor and stages trajectories to and from the device.  No numerics of the
+// hot path live here; every Solve() ends in a call into libilqg_hip.so.
+#include <ilqgames/host/api.hpp>
+
+#include <hip/hip_runtime_api.h>
+
+#include <cstring>
+#include <sstream>
+
+namespace ilqgames {
+
+// ------------------------------------------------------------------------------------------
+// Model index constants (src/single_player_{unicycle_4d,car_5d,car_6d}.cpp)
+// ------------------------------------------------------------------------------------------
+const Dimension SinglePlayerUnicycle4D::kNumXDims = 4;
+const Dimension SinglePlayerUnicycle4D::kPxIdx = 0;
+const Dimension SinglePlayerUnicycle4D::kPyIdx = 1;
+const Dimension SinglePlayerUnicycle4D::kThetaIdx = 2;
+const Dimension SinglePlayerUnicycle4D::kVIdx = 3;
+const Dimension SinglePlayerUnicycle4D::kNumUDims = 2;
+const Dimension SinglePlayerUnicycle4D::kOmegaIdx = 0;
+const Dimension SinglePlayerUnicycle4D::kAIdx = 1;
+
+const Dimension SinglePlayerCar5D::kNumXDims = 5;
+const Dimension SinglePlayerCar5D::kPxIdx = 0;
+const Dimension SinglePlayerCar5D::kPyIdx = 1;
+const Dimension SinglePlayerCar5D::kThetaIdx = 2;
+const Dimension SinglePlayerCar5D::kPhiIdx = 3;
+const Dimension SinglePlayerCar5D::kVIdx = 4;
+const Dimension SinglePlayerCar5D::kNumUDims = 2;
+const Dimension SinglePlayerCar5D::kOmegaIdx = 0;
+const Dimension SinglePlayerCar5D::kAIdx = 1;
+
+const Dimension SinglePlayerCar6D::kNumXDims = 6;
+const Dimension SinglePlayerCar6D::kPxIdx = 0;
+const Dimension SinglePlayerCar6D::kPyIdx = 1;
+const Dimension SinglePlayerCar6D::kThetaIdx = 2;
+const Dimension SinglePlayerCar6D::kPhiIdx = 3;
+const Dimension SinglePlayerCar6D::kVIdx = 4;
+const Dimension SinglePlayerCar6D::kAIdx = 5;
+const Dimension SinglePlayerCar6D::kNumUDims = 2;
+const Dimension SinglePlayerCar6D::kOmegaIdx = 0;
+const Dimension SinglePlayerCar6D::kJerkIdx = 1;
+
+// ------------------------------------------------------------------------------------------
+// Geometry
+// ------------------------------------------------------------------------------------------
+LineSegment2::LineSegment2(const Point2& point1, const Point2& point2)
+    : p1_(point1), p2_(point2), length_((point1 - point2).norm()), unit_direction_((point2 - point1) / length_) {
+  CHECK_GT(length_, constants::kSmallNumber);
+}
+
+Polyline2::Polyline2(const PointList2& points) : length_(0.0f) {
+  CHECK_GT(points.size(), 1);
+  cumulative_lengths_.push_back(length_);
+  for (size_t ii = 1; ii < points.size(); ii++) {
+    segments_.emplace_back(points[ii - 1], points[ii]);
+    length_ += segments_.back().Length();
+    cumulative_lengths_.push_back(length_);
+  }
+}
+
+void Polyline2::AddPoint(const Point2& point) {
+  CHECK(!segments_.empty());
+  segments_.emplace_back(segments_.back().SecondPoint(), point);
+  length_ += segments_.back().Length();
+  cumulative_lengths_.push_back(length_);
+}
+
+PointList2 Polyline2::Points() const {
+  PointList2 pts;
+  if (segments_.empty()) return pts;
+  pts.push_back(segments_.front().FirstPoint());
+  for (const auto& s : segments_) pts.push_back(s.SecondPoint());
+  return pts;
+}
+
+// Lane centre of one arm of the roundabout scene: approach, quarter arc onto the circle, ten
+// chords around it, far-away exit point (same construction and float arithmetic as
+// src/roundabout_lane_center.cpp:50-106, which the example problem definitions call).
+PointList2 RoundaboutLaneCenter(float entrance_angle, float exit_angle, float distance_from_roundabout) {
+  const float radius = 12.0f, half_width = 2.5f;
+  const Point2 arc_center((radius + half_width) * std::cos(entrance_angle),
+                          (radius + half_width) * std::sin(entrance_angle));
+  const float arc_start = static_cast<float>(entrance_angle - M_PI_2);  // double subtraction, as there
+  const Point2 arc_first = arc_center + half_width * Point2(std::cos(arc_start), std::sin(arc_start));
+  PointList2 pts;
+  pts.push_back(arc_first + distance_from_roundabout * Point2(std::cos(entrance_angle), std::sin(entrance_angle)));
+  pts.push_back(arc_first);
+  const int arc_points = 3, circle_points = 10;
+  for (int ii = 1; ii <= arc_points; ii++) {
+    const float a = static_cast<float>(arc_start - M_PI_2 * static_cast<float>(ii) / arc_points);
+    pts.push_back(arc_center + half_width * Point2(std::cos(a), std::sin(a)));
+  }
+  const Point2 on_circle(radius * std::cos(entrance_angle), radius * std::sin(entrance_angle));
+  CHECK_LT((pts.back() - on_circle).norm(), constants::kSmallNumber);
+  for (int ii = 1; ii <= circle_points; ii++) {
+    const float a = entrance_angle + (exit_angle - entrance_angle) * static_cast<float>(ii) / circle_points;
+    pts.emplace_back(radius * std::cos(a), radius * std::sin(a));
+  }
+  const float far = 1e4f;
+  pts.emplace_back(far * std::cos(exit_angle), far * std::sin(exit_angle));
+  return pts;
+}
+
+// ------------------------------------------------------------------------------------------
+// Cost / constraint descriptions
+// ------------------------------------------------------------------------------------------
+namespace {
+void FillTerm(host::TermDescription* out, int kind, float weight, float value, int flags,
+              std::initializer_list<int> idx) {
+  out->term = ilqg_cost_term{};
+  out->term.kind = kind;
+  out->term.weight = weight;
+  out->term.value = value;
+  out->term.flags = flags;
+  out->term.polyline = -1;
+  out->term.arg = -1;
+  out->term.constraint_slot = -1;
+  int a = 0;
+  for (int v : idx) out->term.idx[a++] = v;
+}
+}  // namespace
+
+bool QuadraticCost::Describe(host::TermDescription* out) const {
+  FillTerm(out, ILQG_COST_QUADRATIC, weight_, nominal_, 0, {dimension_ < 0 ? -1 : dimension_});
+  return true;
+}
+bool SemiquadraticCost::Describe(host::TermDescription* out) const {
+  FillTerm(out, ILQG_COST_SEMIQUADRATIC, weight_, threshold_, oriented_right_ ? ILQG_FLAG_ORIENTED : 0, {dimension_});
+  return true;
+}
+bool QuadraticPolyline2Cost::Describe(host::TermDescription* out) const {
+  FillTerm(out, ILQG_COST_QUADRATIC_POLYLINE2, weight_, 0.0f, 0, {xidx_, yidx_});
+  out->polyline = &polyline_;
+  return true;
+}
+bool SemiquadraticPolyline2Cost::Describe(host::TermDescription* out) const {
+  FillTerm(out, ILQG_COST_SEMIQUADRATIC_POLYLINE2, weight_, threshold_, oriented_right_ ? ILQG_FLAG_ORIENTED : 0,
+           {xidx_, yidx_});
+  out->polyline = &polyline_;
+  return true;
+}
+bool ProximityCost::Describe(host::TermDescription* out) const {
+  FillTerm(out, ILQG_COST_PROXIMITY, weight_, threshold_, 0, {xidx1_, yidx1_, xidx2_, yidx2_});
+  return true;
+}
+bool SignedDistanceCost::Describe(host::TermDescription* out) const {
+  FillTerm(out, ILQG_COST_SIGNED_DISTANCE, weight_, nominal_, less_is_positive_ ? ILQG_FLAG_ORIENTED : 0,
+           {xdim1_, ydim1_, xdim2_, ydim2_});
+  return true;
+}
+bool ExtremeValueCost::Describe(host::TermDescription* out) const {
+  FillTerm(out, ILQG_COST_EXTREME_VALUE, weight_, 0.0f, is_min_ ? ILQG_FLAG_IS_MIN : 0, {0});
+  out->children = costs_;
+  return true;
+}
+bool ProximityConstraint::Describe(host::TermDescription* out) const {
+  FillTerm(out, ILQG_CONSTRAINT_PROXIMITY, 1.0f, threshold_, keep_within_ ? ILQG_FLAG_ORIENTED : 0,
+           {xidx1_, yidx1_, xidx2_, yidx2_});
+  return true;
+}
+bool SingleDimensionConstraint::Describe(host::TermDescription* out) const {
+  FillTerm(out, ILQG_CONSTRAINT_SINGLE_DIMENSION, 1.0f, threshold_, keep_below_ ? ILQG_FLAG_ORIENTED : 0, {dim_});
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------
+// Dynamics / Problem
+// ------------------------------------------------------------------------------------------
+namespace {
+Dimension TotalXDim(const SubsystemList& subsystems) {
+  Dimension total = 0;
+  for (const auto& s : subsystems) total += CHECK_NOTNULL(s.get())->XDim();
+  return total;
+}
+}  // namespace
+
+ConcatenatedDynamicalSystem::ConcatenatedDynamicalSystem(const SubsystemList& subsystems)
+    : MultiPlayerDynamicalSystem(TotalXDim(subsystems)), subsystems_(subsystems) {
+  Dimension start = 0;
+  for (const auto& s : subsystems_) {
+    subsystem_start_dims_.push_back(start);
+    start += s->XDim();
+  }
+}
+
+std::vector<Dimension> ConcatenatedDynamicalSystem::PositionDimensions() const {
+  std::vector<Dimension> dims;
+  for (size_t ii = 0; ii < subsystems_.size(); ii++)
+    for (Dimension d : subsystems_[ii]->PositionDimensions()) dims.push_back(subsystem_start_dims_[ii] + d);
+  return dims;
+}
+
+void Problem::OverwriteSolution(const OperatingPoint& operating_point, const std::vector<Strategy>& strategies) {
+  CHECK(initialized_);
+  *operating_point_ = operating_point;
+  *strategies_ = strategies;
+}
+
+bool Problem::IsConstrained() const {
+  for (const auto& pc : player_costs_)
+    if (pc.IsConstrained()) return true;
+  return false;
+}
+
+// ------------------------------------------------------------------------------------------
+// Descriptor packing
+// ------------------------------------------------------------------------------------------
+namespace host {
+
+DeviceOptions& Options() {
+  static DeviceOptions options;
+  return options;
+}
+
+namespace {
+
+class Packer {
+ public:
+  explicit Packer(ProblemDescription* out) : out_(out) { out_->polyline_offsets.assign(1, 0); }
+
+  bool Add(const Cost& cost, int role, int player, int arg, bool is_constraint, std::string* why) {
+    TermDescription td;
+    if (!cost.Describe(&td)) {
+      *why = "cost '" + cost.Name() + "' of player " + std::to_string(player) + " has no device kernel";
+      return false;
+    }
+    if (td.term.kind == ILQG_COST_EXTREME_VALUE) {
+      // children sit contiguously in front of their parent
+      const int begin = static_cast<int>(out_->terms.size());
+      for (const auto& child : td.children)
+        if (!Add(*child, ILQG_ROLE_CHILD, player, -1, false, why)) return false;
+      td.term.child_begin = begin;
+      td.term.child_count = static_cast<int>(out_->terms.size()) - begin;
+    }
+    if (td.polyline != nullptr) td.term.polyline = InternPolyline(*td.polyline);
+    td.term.role = role;
+    td.term.player = player;
+    td.term.arg = arg;
+    td.term.constraint_slot = is_constraint ? out_->num_constraints++ : -1;
+    out_->terms.push_back(td.term);
+    return true;
+  }
+
+ private:
+  // Costs hold their polyline by value; identical vertex lists share one device table.
+  int InternPolyline(const Polyline2& polyline) {
+    std::vector<float> flat;
+    for (const auto& p : polyline.Points()) {
+      flat.push_back(p.x());
+      flat.push_back(p.y());
+    }
+    for (size_t q = 0; q + 1 < out_->polyline_offsets.size(); q++) {
+      const int b = out_->polyline_offsets[q], e = out_->polyline_offsets[q + 1];
+      if (static_cast<size_t>(2 * (e - b)) == flat.size() &&
+          std::equal(flat.begin(), flat.end(), out_->polyline_points.begin() + 2 * b))
+        return static_cast<int>(q);
+    }
+    out_->polyline_points.insert(out_->polyline_points.end(), flat.begin(), flat.end());
+    out_->polyline_offsets.push_back(out_->polyline_offsets.back() + static_cast<int>(flat.size() / 2));
+    return static_cast<int>(out_->polyline_offsets.size()) - 2;
+  }
+
+  ProblemDescription* out_;
+};
+
+}  // namespace
+
+bool DescribeProblem(const Problem& problem, const SolverParams& params, ilqg_dtype dtype,
+                     ProblemDescription* out, std::string* why) {
+  std::string scratch;
+  if (why == nullptr) why = &scratch;
+  *out = ProblemDescription();
+  const auto* dyn = dynamic_cast<const ConcatenatedDynamicalSystem*>(problem.Dynamics().get());
+  if (dyn == nullptr) {
+    *why = "dynamics are not a ConcatenatedDynamicalSystem";
+    return false;
+  }
+  const int N = dyn->NumPlayers();
+  if (N > ILQG_MAX_PLAYERS || static_cast<size_t>(N) != problem.PlayerCosts().size()) {
+    *why = "player count mismatch between dynamics and player costs";
+    return false;
+  }
+  ilqg_problem_desc& d = out->desc;
+  d.num_players = N;
+  for (int i = 0; i < N; i++) {
+    d.subsystems[i] = dyn->Subsystems()[i]->Describe();
+    if (d.subsystems[i].kind == 0) {
+      *why = "subsystem " + std::to_string(i) + " has no device model";
+      return false;
+    }
+    const PlayerCost& pc = problem.PlayerCosts()[i];
+    d.player_costs[i].state_regularization = pc.StateRegularization();
+    d.player_costs[i].control_regularization = pc.ControlRegularization();
+    d.player_costs[i].structure = pc.IsTimeAdditive() ? ILQG_SUM : (pc.IsMaxOverTime() ? ILQG_MAX : ILQG_MIN);
+  }
+  // PlayerCost::Quadraticize visits state costs, control costs, state constraints, control
+  // constraints in that order (src/player_cost.cpp:194-215); the (i, j) block list follows the
+  // first touch of each j among player i's control costs then control constraints (:59-86).
+  Packer packer(out);
+  for (int i = 0; i < N; i++) {
+    const PlayerCost& pc = problem.PlayerCosts()[i];
+    for (const auto& c : pc.StateCosts())
+      if (!packer.Add(*c, ILQG_ROLE_STATE_COST, i, -1, false, why)) return false;
+    for (const auto& e : pc.ControlCosts())
+      if (!packer.Add(*e.second, ILQG_ROLE_CONTROL_COST, i, e.first, false, why)) return false;
+    for (const auto& c : pc.StateConstraints())
+      if (!packer.Add(*c, ILQG_ROLE_STATE_CONSTRAINT, i, -1, true, why)) return false;
+    for (const auto& e : pc.ControlConstraints())
+      if (!packer.Add(*e.second, ILQG_ROLE_CONTROL_CONSTRAINT, i, e.first, true, why)) return false;
+    auto touch = [&](int j) {
+      for (const auto& p : out->pairs)
+        if (p.i == i && p.j == j) return;
+      out->pairs.push_back(ilqg_pair{i, j});
+    };
+    for (const auto& e : pc.ControlCosts()) touch(e.first);
+    for (const auto& e : pc.ControlConstraints()) touch(e.first);
+  }
+  d.num_terms = static_cast<int>(out->terms.size());
+  d.terms = out->terms.data();
+  d.num_polylines = static_cast<int>(out->polyline_offsets.size()) - 1;
+  d.polyline_offsets = out->polyline_offsets.data();
+  d.polyline_points = out->polyline_points.data();
+  d.T = static_cast<int>(time::kNumTimeSteps);
+  d.dt = time::kTimeStep;
+  d.dtype = dtype;
+  ilqg_solver_params& sp = d.params;
+  sp.convergence_tolerance = params.convergence_tolerance;
+  sp.max_solver_iters = static_cast<int>(params.max_solver_iters);
+  sp.linesearch = params.linesearch ? 1 : 0;
+  sp.initial_alpha_scaling = params.initial_alpha_scaling;
+  sp.geometric_alpha_scaling = params.geometric_alpha_scaling;
+  sp.max_backtracking_steps = static_cast<int>(params.max_backtracking_steps);
+  sp.expected_decrease_fraction = params.expected_decrease_fraction;
+  sp.open_loop = params.open_loop ? 1 : 0;
+  sp.unconstrained_solver_max_iters = static_cast<int>(params.unconstrained_solver_max_iters);
+  sp.geometric_mu_scaling = params.geometric_mu_scaling;
+  sp.geometric_mu_downscaling = params.geometric_mu_downscaling;
+  sp.geometric_lambda_downscaling = params.geometric_lambda_downscaling;
+  sp.constraint_error_tolerance = params.constraint_error_tolerance;
+  return true;
+}
+
+std::string DumpDescription(const ProblemDescription& description) {
+  const ilqg_problem_desc& d = description.desc;
+  std::ostringstream os;
+  os.precision(9);
+  os << "problem " << d.num_players << " " << d.T << " " << d.dt << "\n";
+  for (int i = 0; i < d.num_players; i++) {
+    os << "subsystem " << d.subsystems[i].kind << " " << d.subsystems[i].xdim << " " << d.subsystems[i].udim << " "
+       << d.subsystems[i].param0 << "\n";
+    os << "player_cost " << d.player_costs[i].state_regularization << " " << d.player_costs[i].control_regularization
+       << " " << d.player_costs[i].structure << "\n";
+  }
+  for (const auto& t : description.terms)
+    os << "term " << t.kind << " " << t.role << " " << t.player << " " << t.arg << " " << t.idx[0] << " " << t.idx[1]
+       << " " << t.idx[2] << " " << t.idx[3] << " " << t.weight << " " << t.value << " " << t.flags << " "
+       << t.polyline << " " << t.child_begin << " " << t.child_count << " " << t.constraint_slot << "\n";
+  for (int q = 0; q < d.num_polylines; q++) {
+    os << "polyline";
+    for (int p = description.polyline_offsets[q]; p < description.polyline_offsets[q + 1]; p++)
+      os << " " << description.polyline_points[2 * p] << " " << description.polyline_points[2 * p + 1];
+    os << "\n";
+  }
+  const ilqg_solver_params& sp = d.params;
+  os << "params " << sp.convergence_tolerance << " " << sp.max_solver_iters << " " << sp.linesearch << " "
+     << sp.initial_alpha_scaling << " " << sp.geometric_alpha_scaling << " " << sp.max_backtracking_steps << " "
+     << sp.expected_decrease_fraction << " " << sp.open_loop << " " << sp.unconstrained_solver_max_iters << " "
+     << sp.geometric_mu_scaling << " " << sp.geometric_mu_downscaling << " " << sp.geometric_lambda_downscaling
+     << " " << sp.constraint_error_tolerance << "\n";
+  return os.str();
+}
+
+// ------------------------------------------------------------------------------------------
+// Device staging
+// ------------------------------------------------------------------------------------------
+namespace {
+
+void HipCheck(hipError_t e, const char* what) {
+  CHECK(e == hipSuccess) << what << ": " << hipGetErrorString(e);
+}
+
+// One HBM allocation, grown on demand.
+class DeviceBuffer {
+ public:
+  ~DeviceBuffer() {
+    if (ptr_ != nullptr) (void)hipFree(ptr_);
+  }
+  void* Reserve(size_t bytes) {
+    if (bytes > cap_) {
+      if (ptr_ != nullptr) HipCheck(hipFree(ptr_), "hipFree");
+      HipCheck(hipMalloc(&ptr_, bytes), "hipMalloc");
+      cap_ = bytes;
+    }
+    return ptr_;
+  }
+  void* get() const { return ptr_; }
+
+ private:
+  void* ptr_ = nullptr;
+  size_t cap_ = 0;
+};
+
+// float host values <-> device scalars of `dtype`
+void Upload(DeviceBuffer* buf, const std::vector<float>& host, ilqg_dtype dtype) {
+  if (dtype == ILQG_F32) {
+    HipCheck(hipMemcpy(buf->Reserve(host.size() * 4), host.data(), host.size() * 4, hipMemcpyHostToDevice), "H2D");
+  } else {
+    std::vector<double> wide(host.begin(), host.end());
+    HipCheck(hipMemcpy(buf->Reserve(wide.size() * 8), wide.data(), wide.size() * 8, hipMemcpyHostToDevice), "H2D");
+  }
+}
+std::vector<float> Download(const DeviceBuffer& buf, size_t count, ilqg_dtype dtype) {
+  std::vector<float> out(count);
+  if (dtype == ILQG_F32) {
+    HipCheck(hipMemcpy(out.data(), buf.get(), count * 4, hipMemcpyDeviceToHost), "D2H");
+  } else {
+    std::vector<double> wide(count);
+    HipCheck(hipMemcpy(wide.data(), buf.get(), count * 8, hipMemcpyDeviceToHost), "D2H");
+    for (size_t i = 0; i < count; i++) out[i] = static_cast<float>(wide[i]);
+  }
+  return out;
+}
+std::vector<int32_t> DownloadInts(const DeviceBuffer& buf, size_t count) {
+  std::vector<int32_t> out(count);
+  HipCheck(hipMemcpy(out.data(), buf.get(), count * 4, hipMemcpyDeviceToHost), "D2H");
+  return out;
+}
+size_t ElemBytes(ilqg_dtype dtype) { return dtype == ILQG_F32 ? 4 : 8; }
+
+}  // namespace
+
+class DeviceSolve {
+ public:
+  DeviceSolve(const Problem& problem, const SolverParams& params) : dtype_(Options().dtype) {
+    std::string why;
+    CHECK(DescribeProblem(problem, params, dtype_, &description_, &why)) << why;
+    const ilqg_status s = ilqg_problem_create(&description_.desc, &handle_);
+    CHECK_EQ(s, ILQG_OK) << ilqg_last_error();
+    n_ = problem.Dynamics()->XDim();
+    m_ = problem.Dynamics()->TotalUDim();
+    N_ = problem.Dynamics()->NumPlayers();
+    T_ = description_.desc.T;
+    for (int i = 0; i < N_; i++) udims_.push_back(problem.Dynamics()->UDim(i));
+  }
+  ~DeviceSolve() {
+    if (handle_ != nullptr) ilqg_problem_destroy(handle_);
+  }
+
+  BatchResult Run(const std::vector<VectorXf>& x0s, const OperatingPoint& warm_op,
+                  const std::vector<Strategy>& warm_strategies, bool augmented_lagrangian) {
+    const size_t B = x0s.size();
+    CHECK_GT(B, 0);
+    const auto start = Clock::now();
+    // pack the warm start once, replicate per instance
+    std::vector<float> x0(B * n_), xs(B * T_ * n_), us(B * T_ * m_), P(B * T_ * m_ * n_), alpha(B * T_ * m_);
+    for (size_t b = 0; b < B; b++) {
+      CHECK_EQ(x0s[b].size(), n_);
+      std::memcpy(&x0[b * n_], x0s[b].data(), n_ * sizeof(float));
+      for (int k = 0; k < T_; k++) {
+        std::memcpy(&xs[(b * T_ + k) * n_], warm_op.xs[k].data(), n_ * sizeof(float));
+        int row = 0;
+        for (int i = 0; i < N_; i++) {
+          std::memcpy(&us[(b * T_ + k) * m_ + row], warm_op.us[k][i].data(), udims_[i] * sizeof(float));
+          std::memcpy(&alpha[(b * T_ + k) * m_ + row], warm_strategies[i].alphas[k].data(),
+                      udims_[i] * sizeof(float));
+          // stacked (m x n) gain, column-major: player i owns rows [row, row + m_i)
+          for (int c = 0; c < n_; c++)
+            for (int r = 0; r < udims_[i]; r++)
+              P[((b * T_ + k) * n_ + c) * m_ + row + r] = warm_strategies[i].Ps[k](r, c);
+          row += udims_[i];
+        }
+      }
+    }
+    Upload(&d_x0_, x0, dtype_);
+    Upload(&d_xs_, xs, dtype_);
+    Upload(&d_us_, us, dtype_);
+    Upload(&d_P_, P, dtype_);
+    Upload(&d_alpha_, alpha, dtype_);
+    d_costs_.Reserve(B * N_ * ElemBytes(dtype_));
+    d_iters_.Reserve(B * 4);
+    d_status_.Reserve(B * 4);
+    d_conv_.Reserve(B * 4);
+    uint64_t ws_bytes = 0;
+    CHECK_EQ(ilqg_workspace_bytes(handle_, static_cast<int32_t>(B), &ws_bytes), ILQG_OK) << ilqg_last_error();
+    d_workspace_.Reserve(ws_bytes);
+
+    ilqg_status s;
+    if (augmented_lagrangian)
+      s = ilqg_al_solve_batch(handle_, static_cast<int32_t>(B), d_x0_.get(), d_xs_.get(), d_us_.get(), d_P_.get(),
+                              d_alpha_.get(), d_costs_.get(), static_cast<int32_t*>(d_iters_.get()),
+                              static_cast<int32_t*>(d_status_.get()), static_cast<int32_t*>(d_conv_.get()),
+                              d_workspace_.get(), nullptr);
+    else
+      s = ilqg_ilq_solve_batch(handle_, static_cast<int32_t>(B), d_x0_.get(), d_xs_.get(), d_us_.get(), d_P_.get(),
+                               d_alpha_.get(), d_costs_.get(), static_cast<int32_t*>(d_iters_.get()),
+                               static_cast<int32_t*>(d_status_.get()), static_cast<int32_t*>(d_conv_.get()),
+                               d_workspace_.get(), /*fixed_iters=*/0, nullptr);
+    CHECK_EQ(s, ILQG_OK) << ilqg_last_error();
+    HipCheck(hipDeviceSynchronize(), "solve");
+
+    xs = Download(d_xs_, xs.size(), dtype_);
+    us = Download(d_us_, us.size(), dtype_);
+    P = Download(d_P_, P.size(), dtype_);
+    alpha = Download(d_alpha_, alpha.size(), dtype_);
+    const std::vector<float> costs = Download(d_costs_, B * N_, dtype_);
+    const std::vector<int32_t> iters = DownloadInts(d_iters_, B), status = DownloadInts(d_status_, B),
+                               conv = DownloadInts(d_conv_, B);
+    const Time elapsed = std::chrono::duration<Time>(Clock::now() - start).count();
+
+    BatchResult result;
+    for (size_t b = 0; b < B; b++) {
+      OperatingPoint op(warm_op);
+      std::vector<Strategy> strategies(warm_strategies);
+      for (int k = 0; k < T_; k++) {
+        std::memcpy(op.xs[k].data(), &xs[(b * T_ + k) * n_], n_ * sizeof(float));
+        int row = 0;
+        for (int i = 0; i < N_; i++) {
+          std::memcpy(op.us[k][i].data(), &us[(b * T_ + k) * m_ + row], udims_[i] * sizeof(float));
+          std::memcpy(strategies[i].alphas[k].data(), &alpha[(b * T_ + k) * m_ + row], udims_[i] * sizeof(float));
+          for (int c = 0; c < n_; c++)
+            for (int r = 0; r < udims_[i]; r++)
+              strategies[i].Ps[k](r, c) = P[((b * T_ + k) * n_ + c) * m_ + row + r];
+          row += udims_[i];
+        }
+      }
+      auto log = std::make_shared<SolverLog>();
+      log->AddSolverIterate(op, strategies, std::vector<float>(costs.begin() + b * N_, costs.begin() + (b + 1) * N_),
+                            elapsed, conv[b] != 0);
+      log->SetDeviceIterations(iters[b]);
+      result.logs.push_back(log);
+      result.success.push_back(status[b] != 0);
+    }
+    return result;
+  }
+
+ private:
+  const ilqg_dtype dtype_;
+  ProblemDescription description_;
+  ilqg_problem* handle_ = nullptr;
+  int n_ = 0, m_ = 0, N_ = 0, T_ = 0;
+  std::vector<int> udims_;
+  DeviceBuffer d_x0_, d_xs_, d_us_, d_P_, d_alpha_, d_costs_, d_iters_, d_status_, d_conv_, d_workspace_;
+};
+
+}  // namespace host
+
+// ------------------------------------------------------------------------------------------
+// Solvers
+// ------------------------------------------------------------------------------------------
+GameSolver::GameSolver(const std::shared_ptr<Problem>& problem, const SolverParams& params,
+                       bool augmented_lagrangian)
+    : problem_(problem), params_(params), augmented_lagrangian_(augmented_lagrangian) {
+  CHECK_NOTNULL(problem_.get());
+  CHECK_NOTNULL(problem_->Dynamics().get());
+}
+
+GameSolver::~GameSolver() {}
+
+host::BatchResult GameSolver::SolveBatch(const std::vector<VectorXf>& x0s) {
+  if (!device_) device_.reset(new host::DeviceSolve(*problem_, params_));
+  return device_->Run(x0s, problem_->CurrentOperatingPoint(), problem_->CurrentStrategies(), augmented_lagrangian_);
+}
+
+// `max_runtime` (the reference's wall-clock anytime exit, src/ilq_solver.cpp:101-104) is not
+// reproduced: the loop runs on the device; bound it with SolverParams::max_solver_iters.
+std::shared_ptr<SolverLog> ILQSolver::Solve(bool* success, Time max_runtime) {
+  (void)max_runtime;
+  host::BatchResult r = SolveBatch({problem_->InitialState()});
+  if (success != nullptr) *success = r.success[0];
+  return r.logs[0];
+}
+
+std::shared_ptr<SolverLog> AugmentedLagrangianSolver::Solve(bool* success, Time max_runtime) {
+  (void)max_runtime;
+  host::BatchResult r = SolveBatch({problem_->InitialState()});
+  if (success != nullptr) *success = r.success[0];
+  return r.logs[0];
+}
+
+std::vector<Strategy> LQSolver::SolveOnDevice(
+    bool open_loop, const std::vector<LinearDynamicsApproximation>& linearization,
+    const std::vector<std::vector<QuadraticCostApproximation>>& quadraticization, const VectorXf& x0,
+    std::vector<VectorXf>* delta_xs, std::vector<std::vector<VectorXf>>* costates) {
+  using namespace host;
+  const int T = static_cast<int>(num_time_steps_), n = dynamics_->XDim(), N = dynamics_->NumPlayers();
+  const int m = dynamics_->TotalUDim();
+  CHECK_EQ(linearization.size(), num_time_steps_);
+  CHECK_EQ(quadraticization.size(), num_time_steps_);
+  const ilqg_dtype dtype = Options().dtype;
+
+  ilqg_dims d{};
+  d.n = n;
+  d.num_players = N;
+  d.T = T;
+  d.batch = 1;
+  d.dtype = dtype;
+  d.adaptive_regularization = 1;
+  std::vector<int> uoff(N + 1, 0);
+  for (int i = 0; i < N; i++) {
+    d.udim[i] = dynamics_->UDim(i);
+    uoff[i + 1] = uoff[i] + d.udim[i];
+  }
+  // (i, j) blocks = keys of quad[0][i].control, in stored order; offsets into the R / r slabs
+  std::vector<ilqg_pair> pairs;
+  std::vector<int> Roff(1, 0), roff(1, 0);
+  for (int i = 0; i < N; i++) {
+    CHECK_EQ(quadraticization[0].size(), static_cast<size_t>(N));
+    for (const auto& e : quadraticization[0][i].control) {
+      pairs.push_back(ilqg_pair{i, static_cast<int>(e.first)});
+      Roff.push_back(Roff.back() + d.udim[e.first] * d.udim[e.first]);
+      roff.push_back(roff.back() + d.udim[e.first]);
+    }
+  }
+  const int Rsz = Roff.back(), rsz = roff.back();
+  std::vector<float> A(T * n * n), Bm(T * n * m), Q(T * N * n * n), l(T * N * n), R(T * Rsz), r(T * rsz);
+  for (int k = 0; k < T; k++) {
+    const auto& lin = linearization[k];
+    CHECK_EQ(lin.A.rows(), n);
+    std::memcpy(&A[k * n * n], lin.A.data(), n * n * sizeof(float));
+    for (int i = 0; i < N; i++)
+      std::memcpy(&Bm[k * n * m + n * uoff[i]], lin.Bs[i].data(), n * d.udim[i] * sizeof(float));
+    int q = 0;
+    for (int i = 0; i < N; i++) {
+      const auto& quad = quadraticization[k][i];
+      std::memcpy(&Q[(k * N + i) * n * n], quad.state.hess.data(), n * n * sizeof(float));
+      std::memcpy(&l[(k * N + i) * n], quad.state.grad.data(), n * sizeof(float));
+      for (const auto& e : quad.control) {
+        CHECK_EQ(pairs[q].j, static_cast<int>(e.first)) << "control blocks must not change along the horizon";
+        const int mj = d.udim[e.first];
+        std::memcpy(&R[k * Rsz + Roff[q]], e.second.hess.data(), mj * mj * sizeof(float));
+        std::memcpy(&r[k * rsz + roff[q]], e.second.grad.data(), mj * sizeof(float));
+        q++;
+      }
+    }
+  }
+  DeviceBuffer dA, dB, dQ, dl, dR, dr, dx0, dP, dalpha, ddx;
+  Upload(&dA, A, dtype);
+  Upload(&dB, Bm, dtype);
+  Upload(&dQ, Q, dtype);
+  Upload(&dl, l, dtype);
+  Upload(&dR, R, dtype);
+  Upload(&dr, r, dtype);
+  Upload(&dx0, std::vector<float>(x0.data(), x0.data() + n), dtype);
+  dP.Reserve(T * m * n * ElemBytes(dtype));
+  dalpha.Reserve(T * m * ElemBytes(dtype));
+  ddx.Reserve(T * n * ElemBytes(dtype));
+
+  auto fn = open_loop ? ilqg_lq_openloop_batch : ilqg_lq_feedback_batch;
+  const ilqg_status s = fn(&d, dA.get(), dB.get(), dQ.get(), dl.get(), dR.get(), dr.get(), pairs.data(),
+                           static_cast<int32_t>(pairs.size()), dx0.get(), dP.get(), dalpha.get(), ddx.get(),
+                           /*costates=*/nullptr, nullptr);
+  // dimension mismatches / a missing R_ii abort in the reference (glog CHECK); same here
+  CHECK_EQ(s, ILQG_OK) << ilqg_last_error();
+  HipCheck(hipDeviceSynchronize(), "lq solve");
+
+  const std::vector<float> P = Download(dP, T * m * n, dtype), alpha = Download(dalpha, T * m, dtype),
+                           dxs = Download(ddx, T * n, dtype);
+  std::vector<Strategy> strategies;
+  for (int i = 0; i < N; i++) {
+    strategies.emplace_back(num_time_steps_, n, d.udim[i]);
+    for (int k = 0; k < T; k++) {
+      for (int c = 0; c < n; c++)
+        for (int rr = 0; rr < d.udim[i]; rr++) strategies[i].Ps[k](rr, c) = P[(k * n + c) * m + uoff[i] + rr];
+      for (int rr = 0; rr < d.udim[i]; rr++) strategies[i].alphas[k](rr) = alpha[k * m + uoff[i] + rr];
+    }
+  }
+  if (delta_xs != nullptr) {
+    delta_xs->assign(T, VectorXf::Zero(n));
+    for (int k = 0; k < T; k++) std::memcpy((*delta_xs)[k].data(), &dxs[k * n], n * sizeof(float));
+  }
+  // Costates are not produced on the device: ILQSolver discards them (src/ilq_solver.cpp:382-385,
+  // 419-422), so callers get correctly shaped zeros.
+  if (costates != nullptr) costates->assign(T, std::vector<VectorXf>(N, VectorXf::Zero(n)));
+  return strategies;
+}
+
+}  // namespace ilqgames

@@ -1,0 +1,818 @@
+// Host-side C++ mirror of the reference's problem-definition and solver API, bound to the
+// MI355X kernels through the C ABI of include/ilqg.h.
+//
+// Same class names, constructor arguments and call sequence as the reference (cited per class,
+// paths relative to the reference repo) so a `Problem` subclass written for the reference compiles
+// unchanged — but the objects here are *descriptors*: they record what the user asked for and are
+// flattened into an `ilqg_problem_desc` (host::DescribeProblem).  All arithmetic of the hot path
+// (rollout, linearisation, quadraticisation, LQ sweep, line search, AL loop) runs on the GPU inside
+// libilqg_hip.so; there is no CPU evaluation path behind `Cost`, `Constraint` or
+// `SinglePlayerDynamicalSystem`, so user-defined subclasses with their own Evaluate() have no device
+// kernel and make Solve() report ILQG_ERR_UNSUPPORTED through a CHECK, the reference's error style.
+#ifndef ILQGAMES_HOST_API_HPP_
+#define ILQGAMES_HOST_API_HPP_
+
+#include <ilqg.h>
+#include <ilqgames/host/linalg.hpp>
+#include <ilqgames/host/logging.hpp>
+
+#include <math.h>
+#include <algorithm>
+#include <chrono>
+#include <functional>
+#include <limits>
+#include <memory>
+#include <string>
+#include <type_traits>
+#include <unordered_map>
+#include <utility>
+#include <vector>
+
+namespace ilqgames {
+
+// ---------------------------------------------------------------------------------------------
+// Types and constants (include/ilqgames/utils/types.h:60-147)
+// ---------------------------------------------------------------------------------------------
+using VectorXf = host::Vector<float>;
+using MatrixXf = host::Matrix<float>;
+using Point2 = host::Point2f;
+using PointList2 = std::vector<Point2>;
+using PlayerIndex = unsigned short;
+using Dimension = int;
+using Time = double;
+using Clock = std::chrono::system_clock;
+
+template <typename T>
+using PtrVector = std::vector<std::shared_ptr<T>>;
+template <typename T>
+using PlayerMap = std::unordered_map<PlayerIndex, T>;
+// Insertion-ordered (player, object) list.  The reference keeps control costs in an
+// unordered_multimap (types.h:84-86); an ordered list makes the per-player summation order —
+// and therefore the floating-point result — a defined property of the problem definition.
+template <typename T>
+class PlayerPtrMultiMap : public std::vector<std::pair<PlayerIndex, std::shared_ptr<T>>> {
+ public:
+  void emplace(PlayerIndex idx, const std::shared_ptr<T>& ptr) { this->emplace_back(idx, ptr); }
+};
+
+namespace constants {
+static constexpr float kSmallNumber = 1e-4;
+static constexpr float kInfinity = std::numeric_limits<float>::infinity();
+static constexpr float kInvalidValue = std::numeric_limits<float>::quiet_NaN();
+static constexpr float kDefaultLambda = 0.0;
+static constexpr float kDefaultMu = 10.0;
+}  // namespace constants
+
+namespace time {
+static constexpr Time kTimeStep = 0.1;
+static constexpr Time kTimeHorizon = 10.0;
+static constexpr size_t kNumTimeSteps =
+    static_cast<size_t>((kTimeHorizon + constants::kSmallNumber) / kTimeStep);
+}  // namespace time
+
+template <typename T, typename... Args>
+std::unique_ptr<T> make_unique(Args&&... args) {
+  return std::unique_ptr<T>(new T(std::forward<Args>(args)...));
+}
+template <typename T>
+inline constexpr T sgn(T x) {
+  return static_cast<T>((T(0) < x) - (x < T(0)));
+}
+
+class Cost;
+class Constraint;
+class Polyline2;
+
+namespace host {
+// What one Cost / Constraint contributes to the device descriptor.
+struct TermDescription {
+  ilqg_cost_term term{};                            // kind, idx, weight, value, flags
+  const Polyline2* polyline = nullptr;              // for *_POLYLINE2 kinds
+  std::vector<std::shared_ptr<const Cost>> children;  // EXTREME_VALUE
+};
+}  // namespace host
+
+// ---------------------------------------------------------------------------------------------
+// Geometry (include/ilqgames/geometry/line_segment2.h:52-92, polyline2.h:54-96)
+// ---------------------------------------------------------------------------------------------
+class LineSegment2 {
+ public:
+  LineSegment2(const Point2& point1, const Point2& point2);
+  float Length() const { return length_; }
+  const Point2& FirstPoint() const { return p1_; }
+  const Point2& SecondPoint() const { return p2_; }
+  const Point2& UnitDirection() const { return unit_direction_; }
+  float Heading() const { return std::atan2(unit_direction_.y(), unit_direction_.x()); }
+
+ private:
+  Point2 p1_, p2_;
+  float length_;
+  Point2 unit_direction_;
+};
+
+class Polyline2 {
+ public:
+  Polyline2() : length_(0.0f) {}
+  Polyline2(const PointList2& points);
+  void AddPoint(const Point2& point);
+  float Length() const { return length_; }
+  const std::vector<LineSegment2>& Segments() const { return segments_; }
+  // Vertices in order (what the device tables are built from).
+  PointList2 Points() const;
+
+ private:
+  std::vector<LineSegment2> segments_;
+  std::vector<float> cumulative_lengths_;
+  float length_;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Costs (include/ilqgames/cost/cost.h:55-96 and the concrete classes cited below)
+// ---------------------------------------------------------------------------------------------
+class Cost {
+ public:
+  virtual ~Cost() {}
+  void SetWeight(float weight) { weight_ = weight; }
+  void ScaleWeight(float scale) { weight_ *= scale; }
+  float Weight() const { return weight_; }
+  const std::string& Name() const { return name_; }
+
+  // Device description; false = this cost has no gfx950 kernel.
+  virtual bool Describe(host::TermDescription* out) const { (void)out; return false; }
+
+ protected:
+  explicit Cost(float weight, const std::string& name) : weight_(weight), name_(name) {}
+  float weight_;
+  std::string name_;
+};
+
+class TimeInvariantCost : public Cost {
+ protected:
+  explicit TimeInvariantCost(float weight, const std::string& name) : Cost(weight, name) {}
+};
+
+// include/ilqgames/cost/quadratic_cost.h:55-84 — dim < 0 penalises every dimension.
+class QuadraticCost : public TimeInvariantCost {
+ public:
+  QuadraticCost(float weight, Dimension dim, float nominal = 0.0, const std::string& name = "")
+      : TimeInvariantCost(weight, name), dimension_(dim), nominal_(nominal) {}
+  bool Describe(host::TermDescription* out) const override;
+
+ private:
+  Dimension dimension_;
+  float nominal_;
+};
+
+// include/ilqgames/cost/semiquadratic_cost.h:54-85
+class SemiquadraticCost : public TimeInvariantCost {
+ public:
+  SemiquadraticCost(float weight, Dimension dim, float threshold, bool oriented_right,
+                    const std::string& name = "")
+      : TimeInvariantCost(weight, name), dimension_(dim), threshold_(threshold), oriented_right_(oriented_right) {
+    CHECK_GE(dimension_, 0);
+  }
+  bool Describe(host::TermDescription* out) const override;
+
+ private:
+  Dimension dimension_;
+  float threshold_;
+  bool oriented_right_;
+};
+
+// include/ilqgames/cost/quadratic_polyline2_cost.h:56-85
+class QuadraticPolyline2Cost : public TimeInvariantCost {
+ public:
+  QuadraticPolyline2Cost(float weight, const Polyline2& polyline,
+                         const std::pair<Dimension, Dimension>& position_idxs, const std::string& name = "")
+      : TimeInvariantCost(weight, name), polyline_(polyline), xidx_(position_idxs.first), yidx_(position_idxs.second) {}
+  bool Describe(host::TermDescription* out) const override;
+
+ private:
+  Polyline2 polyline_;
+  Dimension xidx_, yidx_;
+};
+
+// include/ilqgames/cost/semiquadratic_polyline2_cost.h:57-103
+class SemiquadraticPolyline2Cost : public TimeInvariantCost {
+ public:
+  SemiquadraticPolyline2Cost(float weight, const Polyline2& polyline,
+                             const std::pair<Dimension, Dimension>& position_idxs, float threshold,
+                             bool oriented_right, const std::string& name = "")
+      : TimeInvariantCost(weight, name), polyline_(polyline), xidx_(position_idxs.first),
+        yidx_(position_idxs.second), threshold_(threshold), oriented_right_(oriented_right) {}
+  bool Describe(host::TermDescription* out) const override;
+
+ private:
+  Polyline2 polyline_;
+  Dimension xidx_, yidx_;
+  float threshold_;
+  bool oriented_right_;
+};
+
+// include/ilqgames/cost/proximity_cost.h:55-90
+class ProximityCost : public TimeInvariantCost {
+ public:
+  ProximityCost(float weight, const std::pair<Dimension, Dimension>& position_idxs1,
+                const std::pair<Dimension, Dimension>& position_idxs2, float threshold,
+                const std::string& name = "")
+      : TimeInvariantCost(weight, name), threshold_(threshold), xidx1_(position_idxs1.first),
+        yidx1_(position_idxs1.second), xidx2_(position_idxs2.first), yidx2_(position_idxs2.second) {}
+  bool Describe(host::TermDescription* out) const override;
+
+ private:
+  float threshold_;
+  Dimension xidx1_, yidx1_, xidx2_, yidx2_;
+};
+
+// include/ilqgames/cost/signed_distance_cost.h:56-92
+class SignedDistanceCost : public TimeInvariantCost {
+ public:
+  SignedDistanceCost(const std::pair<Dimension, Dimension>& dims1, const std::pair<Dimension, Dimension>& dims2,
+                     float nominal = 0.0, bool less_is_positive = true, const std::string& name = "")
+      : TimeInvariantCost(1.0, name), xdim1_(dims1.first), ydim1_(dims1.second), xdim2_(dims2.first),
+        ydim2_(dims2.second), nominal_(nominal), less_is_positive_(less_is_positive) {
+    CHECK_GE(nominal_, 0.0);
+  }
+  bool Describe(host::TermDescription* out) const override;
+
+ private:
+  Dimension xdim1_, ydim1_, xdim2_, ydim2_;
+  float nominal_;
+  bool less_is_positive_;
+};
+
+// include/ilqgames/cost/extreme_value_cost.h:56-88
+class ExtremeValueCost : public Cost {
+ public:
+  ExtremeValueCost(const std::vector<std::shared_ptr<const Cost>>& costs, bool is_min,
+                   const std::string& name = "")
+      : Cost(1.0, name), costs_(costs), is_min_(is_min) {
+    CHECK_GT(costs_.size(), 0);
+  }
+  bool Describe(host::TermDescription* out) const override;
+
+ private:
+  std::vector<std::shared_ptr<const Cost>> costs_;
+  bool is_min_;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Constraints (include/ilqgames/constraint/constraint.h:62-155).  Multipliers live per instance
+// on the device (one lambda per constraint and time step, one mu per instance), not in these
+// objects and not in a process-global as the reference's Constraint::mu_.
+// ---------------------------------------------------------------------------------------------
+class Constraint : public Cost {
+ public:
+  bool IsEquality() const { return is_equality_; }
+
+ protected:
+  explicit Constraint(bool is_equality, const std::string& name) : Cost(1.0, name), is_equality_(is_equality) {}
+  bool is_equality_;
+};
+
+class TimeInvariantConstraint : public Constraint {
+ protected:
+  explicit TimeInvariantConstraint(bool is_equality, const std::string& name) : Constraint(is_equality, name) {}
+};
+
+// include/ilqgames/constraint/proximity_constraint.h:56-92
+class ProximityConstraint : public TimeInvariantConstraint {
+ public:
+  ProximityConstraint(const std::pair<Dimension, Dimension>& dims1, const std::pair<Dimension, Dimension>& dims2,
+                      float threshold, bool keep_within, const std::string& name = "")
+      : TimeInvariantConstraint(false, name), xidx1_(dims1.first), yidx1_(dims1.second), xidx2_(dims2.first),
+        yidx2_(dims2.second), threshold_(threshold), keep_within_(keep_within) {
+    CHECK_GT(threshold_, 0.0);
+  }
+  bool Describe(host::TermDescription* out) const override;
+
+ private:
+  Dimension xidx1_, yidx1_, xidx2_, yidx2_;
+  float threshold_;
+  bool keep_within_;
+};
+
+// include/ilqgames/constraint/single_dimension_constraint.h:54-104
+class SingleDimensionConstraint : public TimeInvariantConstraint {
+ public:
+  SingleDimensionConstraint(Dimension dim, float threshold, bool keep_below, const std::string& name = "")
+      : TimeInvariantConstraint(false, name), dim_(dim), threshold_(threshold), keep_below_(keep_below) {}
+  bool Describe(host::TermDescription* out) const override;
+
+ private:
+  Dimension dim_;
+  float threshold_;
+  bool keep_below_;
+};
+
+// include/ilqgames/constraint/polyline2_signed_distance_constraint.h:57-91 — constructible so
+// problem definitions that build one compile; it has no device kernel yet (Describe() is false).
+class Polyline2SignedDistanceConstraint : public TimeInvariantConstraint {
+ public:
+  Polyline2SignedDistanceConstraint(const Polyline2& polyline, const std::pair<Dimension, Dimension>& dims,
+                                    float threshold, bool keep_left, const std::string& name = "")
+      : TimeInvariantConstraint(false, name), polyline_(polyline), xidx_(dims.first), yidx_(dims.second),
+        threshold_(threshold), keep_left_(keep_left) {}
+
+ private:
+  Polyline2 polyline_;
+  Dimension xidx_, yidx_;
+  float threshold_;
+  bool keep_left_;
+};
+
+// ---------------------------------------------------------------------------------------------
+// PlayerCost (include/ilqgames/cost/player_cost.h:60-170)
+// ---------------------------------------------------------------------------------------------
+class PlayerCost {
+ public:
+  explicit PlayerCost(const std::string& name = "", float state_regularization = 0.0,
+                      float control_regularization = 0.0)
+      : name_(name), state_regularization_(state_regularization),
+        control_regularization_(control_regularization), cost_structure_(SUM), time_of_extreme_cost_(0) {}
+
+  void AddStateCost(const std::shared_ptr<Cost>& cost) { state_costs_.push_back(cost); }
+  void AddControlCost(PlayerIndex idx, const std::shared_ptr<Cost>& cost) { control_costs_.emplace(idx, cost); }
+  void AddStateConstraint(const std::shared_ptr<Constraint>& constraint) { state_constraints_.push_back(constraint); }
+  void AddControlConstraint(PlayerIndex idx, const std::shared_ptr<Constraint>& constraint) {
+    control_constraints_.emplace(idx, constraint);
+  }
+
+  enum CostStructure { SUM, MAX, MIN };
+  void SetTimeAdditive() { cost_structure_ = SUM; }
+  void SetMaxOverTime() { cost_structure_ = MAX; }
+  void SetMinOverTime() { cost_structure_ = MIN; }
+  bool IsTimeAdditive() const { return cost_structure_ == SUM; }
+  bool IsMaxOverTime() const { return cost_structure_ == MAX; }
+  bool IsMinOverTime() const { return cost_structure_ == MIN; }
+  size_t TimeOfExtremeCost() { return time_of_extreme_cost_; }
+  void SetTimeOfExtremeCost(size_t kk) { time_of_extreme_cost_ = kk; }
+
+  const PtrVector<Cost>& StateCosts() const { return state_costs_; }
+  const PlayerPtrMultiMap<Cost>& ControlCosts() const { return control_costs_; }
+  const PtrVector<Constraint>& StateConstraints() const { return state_constraints_; }
+  const PlayerPtrMultiMap<Constraint>& ControlConstraints() const { return control_constraints_; }
+  bool IsConstrained() const { return !state_constraints_.empty() || !control_constraints_.empty(); }
+  float StateRegularization() const { return state_regularization_; }
+  float ControlRegularization() const { return control_regularization_; }
+  CostStructure Structure() const { return cost_structure_; }
+  const std::string& Name() const { return name_; }
+
+ private:
+  std::string name_;
+  PtrVector<Cost> state_costs_;
+  PlayerPtrMultiMap<Cost> control_costs_;
+  PtrVector<Constraint> state_constraints_;
+  PlayerPtrMultiMap<Constraint> control_constraints_;
+  float state_regularization_;
+  float control_regularization_;
+  CostStructure cost_structure_;
+  size_t time_of_extreme_cost_;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Dynamics (include/ilqgames/dynamics/*.h).  Subsystems name a device model (ilqg_dyn_kind).
+// ---------------------------------------------------------------------------------------------
+class SinglePlayerDynamicalSystem {
+ public:
+  virtual ~SinglePlayerDynamicalSystem() {}
+  Dimension XDim() const { return xdim_; }
+  Dimension UDim() const { return udim_; }
+  virtual std::vector<Dimension> PositionDimensions() const = 0;
+  // Device model of this subsystem; kind 0 = none.
+  virtual ilqg_subsystem Describe() const { return ilqg_subsystem{0, xdim_, udim_, 0.0f}; }
+
+ protected:
+  SinglePlayerDynamicalSystem(Dimension xdim, Dimension udim) : xdim_(xdim), udim_(udim) {}
+  const Dimension xdim_;
+  const Dimension udim_;
+};
+
+// include/ilqgames/dynamics/single_player_unicycle_4d.h:55-88
+class SinglePlayerUnicycle4D : public SinglePlayerDynamicalSystem {
+ public:
+  SinglePlayerUnicycle4D() : SinglePlayerDynamicalSystem(kNumXDims, kNumUDims) {}
+  std::vector<Dimension> PositionDimensions() const override { return {kPxIdx, kPyIdx}; }
+  ilqg_subsystem Describe() const override { return ilqg_subsystem{ILQG_DYN_UNICYCLE_4D, xdim_, udim_, 0.0f}; }
+  static const Dimension kNumXDims, kPxIdx, kPyIdx, kThetaIdx, kVIdx;
+  static const Dimension kNumUDims, kOmegaIdx, kAIdx;
+};
+
+// include/ilqgames/dynamics/single_player_car_5d.h:59-98
+class SinglePlayerCar5D : public SinglePlayerDynamicalSystem {
+ public:
+  SinglePlayerCar5D(float inter_axle_distance)
+      : SinglePlayerDynamicalSystem(kNumXDims, kNumUDims), inter_axle_distance_(inter_axle_distance) {}
+  std::vector<Dimension> PositionDimensions() const override { return {kPxIdx, kPyIdx}; }
+  ilqg_subsystem Describe() const override {
+    return ilqg_subsystem{ILQG_DYN_CAR_5D, xdim_, udim_, inter_axle_distance_};
+  }
+  static const Dimension kNumXDims, kPxIdx, kPyIdx, kThetaIdx, kPhiIdx, kVIdx;
+  static const Dimension kNumUDims, kOmegaIdx, kAIdx;
+
+ private:
+  const float inter_axle_distance_;
+};
+
+// include/ilqgames/dynamics/single_player_car_6d.h:60-100
+class SinglePlayerCar6D : public SinglePlayerDynamicalSystem {
+ public:
+  SinglePlayerCar6D(float inter_axle_distance)
+      : SinglePlayerDynamicalSystem(kNumXDims, kNumUDims), inter_axle_distance_(inter_axle_distance) {}
+  std::vector<Dimension> PositionDimensions() const override { return {kPxIdx, kPyIdx}; }
+  ilqg_subsystem Describe() const override {
+    return ilqg_subsystem{ILQG_DYN_CAR_6D, xdim_, udim_, inter_axle_distance_};
+  }
+  static const Dimension kNumXDims, kPxIdx, kPyIdx, kThetaIdx, kPhiIdx, kVIdx, kAIdx;
+  static const Dimension kNumUDims, kOmegaIdx, kJerkIdx;
+
+ private:
+  const float inter_axle_distance_;
+};
+
+// include/ilqgames/dynamics/multi_player_integrable_system.h:57-140 (shape queries only; the
+// RK4 integrator is ilqg_rollout_batch on the device).
+class MultiPlayerIntegrableSystem {
+ public:
+  virtual ~MultiPlayerIntegrableSystem() {}
+  virtual bool TreatAsLinear() const { return false; }
+  Dimension XDim() const { return xdim_; }
+  Dimension TotalUDim() const {
+    Dimension total = 0;
+    for (PlayerIndex ii = 0; ii < NumPlayers(); ii++) total += UDim(ii);
+    return total;
+  }
+  virtual Dimension UDim(PlayerIndex player_idx) const = 0;
+  virtual PlayerIndex NumPlayers() const = 0;
+  virtual std::vector<Dimension> PositionDimensions() const = 0;
+  // The reference toggles Euler / RK4 globally (multi_player_integrable_system.h:118-120); the device
+  // integrator is RK4 with two sub-steps, the reference default.
+  static bool IntegrationUsesEuler() { return false; }
+
+ protected:
+  MultiPlayerIntegrableSystem(Dimension xdim) : xdim_(xdim) {}
+  const Dimension xdim_;
+};
+
+class MultiPlayerDynamicalSystem : public MultiPlayerIntegrableSystem {
+ protected:
+  MultiPlayerDynamicalSystem(Dimension xdim) : MultiPlayerIntegrableSystem(xdim) {}
+};
+
+using SubsystemList = std::vector<std::shared_ptr<SinglePlayerDynamicalSystem>>;
+
+// include/ilqgames/dynamics/concatenated_dynamical_system.h:57-104
+class ConcatenatedDynamicalSystem : public MultiPlayerDynamicalSystem {
+ public:
+  ConcatenatedDynamicalSystem(const SubsystemList& subsystems);
+  const SubsystemList& Subsystems() const { return subsystems_; }
+  PlayerIndex NumPlayers() const override { return static_cast<PlayerIndex>(subsystems_.size()); }
+  Dimension SubsystemStartDim(PlayerIndex player_idx) const { return subsystem_start_dims_[player_idx]; }
+  Dimension SubsystemXDim(PlayerIndex player_idx) const { return subsystems_[player_idx]->XDim(); }
+  Dimension UDim(PlayerIndex player_idx) const override { return subsystems_[player_idx]->UDim(); }
+  std::vector<Dimension> PositionDimensions() const override;
+
+ private:
+  const SubsystemList subsystems_;
+  std::vector<Dimension> subsystem_start_dims_;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Trajectory containers (include/ilqgames/utils/{strategy,operating_point,
+// linear_dynamics_approximation,quadratic_cost_approximation,solver_log}.h)
+// ---------------------------------------------------------------------------------------------
+struct Strategy {
+  std::vector<MatrixXf> Ps;
+  std::vector<VectorXf> alphas;
+  Strategy(size_t horizon, Dimension xdim, Dimension udim) : Ps(horizon), alphas(horizon) {
+    for (size_t kk = 0; kk < horizon; kk++) {
+      Ps[kk] = MatrixXf::Zero(udim, xdim);
+      alphas[kk] = VectorXf::Zero(udim);
+    }
+  }
+  VectorXf operator()(size_t time_index, const VectorXf& delta_x, const VectorXf& u_ref) const {
+    return u_ref - Ps[time_index] * delta_x - alphas[time_index];
+  }
+  size_t NumVariables() const { return Ps.size() * (Ps.front().size() + alphas.front().size()); }
+};
+
+struct OperatingPoint {
+  std::vector<VectorXf> xs;
+  std::vector<std::vector<VectorXf>> us;
+  Time t0;
+  OperatingPoint(size_t num_time_steps, PlayerIndex num_players, Time initial_time)
+      : xs(num_time_steps), us(num_time_steps, std::vector<VectorXf>(num_players)), t0(initial_time) {}
+  template <typename MultiPlayerSystemType>
+  OperatingPoint(size_t num_time_steps, Time initial_time,
+                 const std::shared_ptr<const MultiPlayerSystemType>& dynamics)
+      : OperatingPoint(num_time_steps, dynamics->NumPlayers(), initial_time) {
+    for (size_t kk = 0; kk < num_time_steps; kk++) {
+      xs[kk] = VectorXf::Zero(dynamics->XDim());
+      for (PlayerIndex ii = 0; ii < dynamics->NumPlayers(); ii++) us[kk][ii] = VectorXf::Zero(dynamics->UDim(ii));
+    }
+  }
+  void swap(OperatingPoint& other) {
+    xs.swap(other.xs);
+    us.swap(other.us);
+    std::swap(t0, other.t0);
+  }
+};
+
+struct LinearDynamicsApproximation {
+  MatrixXf A;
+  std::vector<MatrixXf> Bs;
+  LinearDynamicsApproximation() {}
+  template <typename MultiPlayerSystemType>
+  explicit LinearDynamicsApproximation(const MultiPlayerSystemType& system)
+      : A(MatrixXf::Identity(system.XDim(), system.XDim())), Bs(system.NumPlayers()) {
+    for (size_t ii = 0; ii < system.NumPlayers(); ii++) Bs[ii] = MatrixXf::Zero(system.XDim(), system.UDim(ii));
+  }
+};
+
+struct SingleCostApproximation {
+  MatrixXf hess;
+  VectorXf grad;
+  SingleCostApproximation(const MatrixXf& hessian, const VectorXf& gradient) : hess(hessian), grad(gradient) {
+    CHECK_EQ(hess.rows(), hess.cols());
+    CHECK_EQ(hess.rows(), grad.size());
+  }
+  SingleCostApproximation(Dimension dim, float regularization = 0.0)
+      : hess(regularization * MatrixXf::Identity(dim, dim)), grad(VectorXf::Zero(dim)) {}
+};
+
+struct QuadraticCostApproximation {
+  SingleCostApproximation state;
+  // Ordered so the (i, j) block list handed to the device is deterministic.
+  std::vector<std::pair<PlayerIndex, SingleCostApproximation>> control;
+  explicit QuadraticCostApproximation(Dimension xdim, float regularization = 0.0) : state(xdim, regularization) {}
+  SingleCostApproximation& Control(PlayerIndex jj, Dimension udim) {
+    for (auto& e : control)
+      if (e.first == jj) return e.second;
+    control.emplace_back(jj, SingleCostApproximation(udim));
+    return control.back().second;
+  }
+};
+
+// include/ilqgames/utils/solver_log.h:62-160 — the device solve keeps no per-iteration deep copies
+// (that is the point of running it on the GPU), so a log holds the final iterate of each solve.
+class SolverLog {
+ public:
+  SolverLog() {}
+  void AddSolverIterate(const OperatingPoint& operating_point, const std::vector<Strategy>& strategies,
+                        const std::vector<float>& total_costs, Time cumulative_runtime, bool was_converged) {
+    operating_points_.push_back(operating_point);
+    strategies_.push_back(strategies);
+    total_player_costs_.push_back(total_costs);
+    cumulative_runtimes_.push_back(cumulative_runtime);
+    was_converged_.push_back(was_converged);
+  }
+  bool WasConverged() const { return was_converged_.back(); }
+  bool WasConverged(size_t idx) const { return was_converged_[idx]; }
+  PlayerIndex NumPlayers() const { return static_cast<PlayerIndex>(strategies_[0].size()); }
+  size_t NumIterates() const { return operating_points_.size(); }
+  std::vector<float> TotalCosts() const { return total_player_costs_.back(); }
+  const std::vector<Strategy>& InitialStrategies() const { return strategies_.front(); }
+  const OperatingPoint& InitialOperatingPoint() const { return operating_points_.front(); }
+  const std::vector<Strategy>& FinalStrategies() const { return strategies_.back(); }
+  const OperatingPoint& FinalOperatingPoint() const { return operating_points_.back(); }
+  Time CumulativeRuntime() const { return cumulative_runtimes_.back(); }
+  // Outer iterations the device performed for the solve this log belongs to.
+  int DeviceIterations() const { return device_iterations_; }
+  void SetDeviceIterations(int iters) { device_iterations_ = iters; }
+
+ private:
+  std::vector<OperatingPoint> operating_points_;
+  std::vector<std::vector<Strategy>> strategies_;
+  std::vector<std::vector<float>> total_player_costs_;
+  std::vector<Time> cumulative_runtimes_;
+  std::vector<bool> was_converged_;
+  int device_iterations_ = 0;
+};
+
+// ---------------------------------------------------------------------------------------------
+// SolverParams (include/ilqgames/solver/solver_params.h:50-106)
+// ---------------------------------------------------------------------------------------------
+struct SolverParams {
+  float convergence_tolerance = 1e-1;
+  size_t max_solver_iters = 1000;
+  bool linesearch = true;
+  float initial_alpha_scaling = 0.5;
+  float geometric_alpha_scaling = 0.5;
+  size_t max_backtracking_steps = 10;
+  float expected_decrease_fraction = 0.1;
+  bool open_loop = false;
+  float state_regularization = 0.0;
+  float control_regularization = 0.0;
+  size_t unconstrained_solver_max_iters = 10;
+  float geometric_mu_scaling = 1.1;
+  float geometric_mu_downscaling = 0.5;
+  float geometric_lambda_downscaling = 0.5;
+  float constraint_error_tolerance = 1e-1;
+  bool reset_problem = true;
+  bool reset_lambdas = true;
+  bool reset_mu = true;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Problem (include/ilqgames/solver/problem.h:61-185)
+// ---------------------------------------------------------------------------------------------
+class Problem {
+ public:
+  virtual ~Problem() {}
+  virtual void Initialize() {
+    ConstructDynamics();
+    ConstructPlayerCosts();
+    ConstructInitialState();
+    ConstructInitialOperatingPoint();
+    ConstructInitialStrategies();
+    initialized_ = true;
+  }
+  void ResetInitialTime(Time t0) {
+    CHECK(initialized_);
+    operating_point_->t0 = t0;
+  }
+  void ResetInitialState(const VectorXf& x0) {
+    CHECK(initialized_);
+    x0_ = x0;
+  }
+  virtual void OverwriteSolution(const OperatingPoint& operating_point, const std::vector<Strategy>& strategies);
+  bool IsConstrained() const;
+  virtual Time InitialTime() const { return operating_point_->t0; }
+  const VectorXf& InitialState() const { return x0_; }
+  std::vector<PlayerCost>& PlayerCosts() { return player_costs_; }
+  const std::vector<PlayerCost>& PlayerCosts() const { return player_costs_; }
+  const std::shared_ptr<const MultiPlayerIntegrableSystem>& Dynamics() const { return dynamics_; }
+  virtual const OperatingPoint& CurrentOperatingPoint() const { return *operating_point_; }
+  virtual const std::vector<Strategy>& CurrentStrategies() const { return *strategies_; }
+
+ protected:
+  Problem() : initialized_(false) {}
+  virtual void ConstructDynamics() = 0;
+  virtual void ConstructPlayerCosts() = 0;
+  virtual void ConstructInitialState() = 0;
+  virtual void ConstructInitialOperatingPoint() {
+    operating_point_.reset(new OperatingPoint(time::kNumTimeSteps, 0.0, dynamics_));
+  }
+  virtual void ConstructInitialStrategies() {
+    strategies_.reset(new std::vector<Strategy>());
+    for (PlayerIndex ii = 0; ii < dynamics_->NumPlayers(); ii++)
+      strategies_->emplace_back(time::kNumTimeSteps, dynamics_->XDim(), dynamics_->UDim(ii));
+  }
+
+  std::shared_ptr<const MultiPlayerIntegrableSystem> dynamics_;
+  std::vector<PlayerCost> player_costs_;
+  VectorXf x0_;
+  std::unique_ptr<OperatingPoint> operating_point_;
+  std::unique_ptr<std::vector<Strategy>> strategies_;
+  bool initialized_;
+};
+
+// include/ilqgames/solver/top_down_renderable_problem.h:52-65
+class TopDownRenderableProblem : public Problem {
+ public:
+  virtual ~TopDownRenderableProblem() {}
+  virtual std::vector<float> Xs(const VectorXf& x) const = 0;
+  virtual std::vector<float> Ys(const VectorXf& x) const = 0;
+  virtual std::vector<float> Thetas(const VectorXf& x) const = 0;
+
+ protected:
+  TopDownRenderableProblem() : Problem() {}
+};
+
+// ---------------------------------------------------------------------------------------------
+// Device binding helpers
+// ---------------------------------------------------------------------------------------------
+namespace host {
+
+// Arithmetic type of the device solve (the containers above stay float, as in the reference).
+struct DeviceOptions {
+  ilqg_dtype dtype = ILQG_F64;
+};
+DeviceOptions& Options();
+
+// Flattened, self-owning form of a Problem: the arrays `desc` points into live in this object.
+struct ProblemDescription {
+  ilqg_problem_desc desc{};
+  std::vector<ilqg_cost_term> terms;
+  std::vector<int32_t> polyline_offsets;
+  std::vector<float> polyline_points;
+  std::vector<ilqg_pair> pairs;  // (i, j) control blocks in PlayerCost first-touch order
+  int num_constraints = 0;
+};
+
+// Walks Problem::Dynamics() and Problem::PlayerCosts() (after Initialize()) and fills the POD
+// descriptor of include/ilqg.h.  Returns false and sets *why when some object has no device kernel.
+bool DescribeProblem(const Problem& problem, const SolverParams& params, ilqg_dtype dtype,
+                     ProblemDescription* out, std::string* why);
+
+// One line per subsystem / player cost / term / polyline; read back by the test harness
+// (ilqgames_amd/abi.py: ProblemSpec.from_dump).
+std::string DumpDescription(const ProblemDescription& description);
+
+class DeviceSolve;  // device buffers + ilqg_problem handle (src: ilqgames_amd/host/ilqgames_host.cpp)
+
+// Result of one instance of a batched solve.
+struct BatchResult {
+  std::vector<std::shared_ptr<SolverLog>> logs;
+  std::vector<bool> success;
+};
+
+}  // namespace host
+
+// ---------------------------------------------------------------------------------------------
+// Solvers
+// ---------------------------------------------------------------------------------------------
+
+// include/ilqgames/solver/lq_solver.h:58-86
+class LQSolver {
+ public:
+  virtual ~LQSolver() {}
+  virtual std::vector<Strategy> Solve(const std::vector<LinearDynamicsApproximation>& linearization,
+                                      const std::vector<std::vector<QuadraticCostApproximation>>& quadraticization,
+                                      const VectorXf& x0, std::vector<VectorXf>* delta_xs = nullptr,
+                                      std::vector<std::vector<VectorXf>>* costates = nullptr) = 0;
+
+ protected:
+  LQSolver(const std::shared_ptr<const MultiPlayerIntegrableSystem>& dynamics, size_t num_time_steps)
+      : dynamics_(dynamics), num_time_steps_(num_time_steps) {
+    CHECK_NOTNULL(dynamics.get());
+  }
+  std::vector<Strategy> SolveOnDevice(bool open_loop, const std::vector<LinearDynamicsApproximation>& linearization,
+                                      const std::vector<std::vector<QuadraticCostApproximation>>& quadraticization,
+                                      const VectorXf& x0, std::vector<VectorXf>* delta_xs,
+                                      std::vector<std::vector<VectorXf>>* costates);
+  const std::shared_ptr<const MultiPlayerIntegrableSystem> dynamics_;
+  const size_t num_time_steps_;
+};
+
+// include/ilqgames/solver/lq_feedback_solver.h:62-111 -> ilqg_lq_feedback_batch
+class LQFeedbackSolver : public LQSolver {
+ public:
+  LQFeedbackSolver(const std::shared_ptr<const MultiPlayerIntegrableSystem>& dynamics, size_t num_time_steps)
+      : LQSolver(dynamics, num_time_steps) {}
+  std::vector<Strategy> Solve(const std::vector<LinearDynamicsApproximation>& linearization,
+                              const std::vector<std::vector<QuadraticCostApproximation>>& quadraticization,
+                              const VectorXf& x0, std::vector<VectorXf>* delta_xs = nullptr,
+                              std::vector<std::vector<VectorXf>>* costates = nullptr) override {
+    return SolveOnDevice(false, linearization, quadraticization, x0, delta_xs, costates);
+  }
+};
+
+// include/ilqgames/solver/lq_open_loop_solver.h:64-112 -> ilqg_lq_openloop_batch
+class LQOpenLoopSolver : public LQSolver {
+ public:
+  LQOpenLoopSolver(const std::shared_ptr<const MultiPlayerIntegrableSystem>& dynamics, size_t num_time_steps)
+      : LQSolver(dynamics, num_time_steps) {}
+  std::vector<Strategy> Solve(const std::vector<LinearDynamicsApproximation>& linearization,
+                              const std::vector<std::vector<QuadraticCostApproximation>>& quadraticization,
+                              const VectorXf& x0, std::vector<VectorXf>* delta_xs = nullptr,
+                              std::vector<std::vector<VectorXf>>* costates = nullptr) override {
+    return SolveOnDevice(true, linearization, quadraticization, x0, delta_xs, costates);
+  }
+};
+
+// include/ilqgames/solver/game_solver.h:69-112
+class GameSolver {
+ public:
+  virtual ~GameSolver();
+  virtual std::shared_ptr<SolverLog> Solve(bool* success = nullptr, Time max_runtime = constants::kInfinity) = 0;
+  Problem& GetProblem() { return *problem_; }
+
+  // Batched form of Solve(): one instance per entry of x0s, all sharing the Problem definition and
+  // its current operating point / strategies as warm start.  This is the call that fills the GPU.
+  host::BatchResult SolveBatch(const std::vector<VectorXf>& x0s);
+
+ protected:
+  GameSolver(const std::shared_ptr<Problem>& problem, const SolverParams& params, bool augmented_lagrangian);
+  virtual std::shared_ptr<SolverLog> CreateNewLog() const { return std::make_shared<SolverLog>(); }
+  const std::shared_ptr<Problem> problem_;
+  const SolverParams params_;
+
+ private:
+  const bool augmented_lagrangian_;
+  std::unique_ptr<host::DeviceSolve> device_;
+};
+
+// include/ilqgames/solver/ilq_solver.h:66-190 -> ilqg_ilq_solve_batch
+class ILQSolver : public GameSolver {
+ public:
+  ILQSolver(const std::shared_ptr<Problem>& problem, const SolverParams& params = SolverParams())
+      : GameSolver(problem, params, false) {}
+  std::shared_ptr<SolverLog> Solve(bool* success = nullptr,
+                                   Time max_runtime = std::numeric_limits<Time>::infinity()) override;
+};
+
+// include/ilqgames/solver/augmented_lagrangian_solver.h:69-92 -> ilqg_al_solve_batch
+class AugmentedLagrangianSolver : public GameSolver {
+ public:
+  AugmentedLagrangianSolver(const std::shared_ptr<Problem>& problem, const SolverParams& params)
+      : GameSolver(problem, params, true) {}
+  std::shared_ptr<SolverLog> Solve(bool* success = nullptr, Time max_runtime = 5.0) override;
+};
+
+// include/ilqgames/examples/roundabout_lane_center.h:55-57
+PointList2 RoundaboutLaneCenter(float entrance_angle, float exit_angle, float distance_from_roundabout);
+
+}  // namespace ilqgames
+
+#endif  // ILQGAMES_HOST_API_HPP_

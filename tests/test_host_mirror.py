@@ -1,0 +1,179 @@
+"""Host-side C++ mirror of the reference API (include/ilqgames/, ilqgames_amd/host/).
+
+CPU part: the mirror compiles, and — where the reference checkout is present (this container, not
+the GPU box) — the reference's own example problem definitions compile UNCHANGED against it and
+flatten to the same descriptor as the hand-written builders in ilqgames_amd/examples.py.
+GPU part: tests/host/host_solve_demo.cpp drives Problem / ILQSolver / AugmentedLagrangianSolver /
+LQFeedbackSolver through the C ABI and is checked against the oracle.
+"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from ilqgames_amd import abi, examples
+import __graft_entry__ as entry
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+BIN = os.path.join(ROOT, "tests", "host", "_bin")
+
+EXAMPLES = [
+    ("ModifiedThreePlayerIntersectionExample", "modified_three_player_intersection_example",
+     examples.modified_three_player_intersection),
+    ("ThreePlayerIntersectionExample", "three_player_intersection_example", examples.three_player_intersection),
+    ("RoundaboutMergingExample", "roundabout_merging_example", examples.roundabout_merging),
+    ("ThreePlayerCollisionAvoidanceReachabilityExample", "three_player_collision_avoidance_reachability_example",
+     examples.three_player_collision_avoidance_reachability),
+]
+
+
+def _compile(out, sources, defines=()):
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    cmd = ["g++", "-std=c++17", "-O1"] + entry.host_compile_flags() + list(defines) + ["-o", out] + sources + \
+        entry.host_link_flags()
+    subprocess.check_call(cmd)
+
+
+def test_host_library_builds_and_links_the_c_abi():
+    so = entry.build_host()
+    syms = subprocess.check_output(["nm", "-D", "--undefined-only", so], text=True)
+    # the mirror is a binding: it must resolve its numerics from the C ABI, not carry its own
+    for s in ("ilqg_problem_create", "ilqg_ilq_solve_batch", "ilqg_al_solve_batch", "ilqg_lq_feedback_batch",
+              "ilqg_lq_openloop_batch", "ilqg_workspace_bytes"):
+        assert s in syms, s
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present")
+@pytest.mark.parametrize("cls,stem,builder", EXAMPLES, ids=[e[1] for e in EXAMPLES])
+def test_reference_example_source_compiles_unchanged_and_flattens_like_examples_py(cls, stem, builder, tmp_path):
+    entry.build_host()
+    exe = str(tmp_path / ("dump_" + stem))
+    _compile(exe, [os.path.join(ROOT, "tests", "host", "dump_example.cpp"), os.path.join(REF, "src", stem + ".cpp")],
+             ['-DEXAMPLE_HEADER=<ilqgames/examples/%s.h>' % stem, "-DEXAMPLE_CLASS=" + cls])
+    text = subprocess.check_output([exe], text=True)
+    got = abi.ProblemSpec.from_dump(text)
+    want = builder()
+    g, w = got.canonical(), want.canonical()
+    assert g["subsystems"] == w["subsystems"]
+    assert g["player_costs"] == w["player_costs"]
+    assert g["pairs"] == w["pairs"]
+    assert (g["T"], g["dt"]) == (w["T"], w["dt"])
+    assert set(g["groups"]) == set(w["groups"])
+    for key in w["groups"]:
+        assert g["groups"][key] == w["groups"][key], key
+    np.testing.assert_allclose(np.array(got.x0, np.float32), np.array(want.x0, np.float32), rtol=1e-6, atol=1e-6)
+    assert got.num_constraints == want.num_constraints
+
+
+# ------------------------------------------------------------------------------------------------
+# GPU: the C++ mirror end to end (Problem -> descriptor -> C ABI -> kernels -> SolverLog)
+# ------------------------------------------------------------------------------------------------
+def _parse_log(path):
+    out = dict(xs=[], us=[], alpha=[])
+    for line in open(path):
+        tok = line.split()
+        if tok[0] == "x0":
+            out["x0"] = np.array([float(v) for v in tok[1:]])
+        elif tok[0] == "success":
+            out["success"], out["converged"], out["iters"] = int(tok[1]), int(tok[3]), int(tok[5])
+        elif tok[0] == "costs":
+            out["costs"] = np.array([float(v) for v in tok[1:]])
+        elif tok[0] == "x":
+            out["xs"].append([float(v) for v in tok[1:]])
+        elif tok[0] == "u":
+            out["us"].append([float(v) for v in tok[1:]])
+        elif tok[0] == "alpha":
+            out["alpha"].append([float(v) for v in tok[1:]])
+    for k in ("xs", "us", "alpha"):
+        out[k] = np.array(out[k])
+    return out
+
+
+@pytest.fixture(scope="module")
+def demo_out(tmp_path_factory):
+    exe = os.path.join(BIN, "host_solve_demo")
+    if not os.path.exists(exe):
+        entry.build_host()
+    out = str(tmp_path_factory.mktemp("host_demo"))
+    subprocess.check_call([exe, out], timeout=600)
+    return out
+
+
+def _oracle_solve(oracle, scene_file, x0, augmented_lagrangian=False):
+    spec = abi.ProblemSpec.from_dump(open(scene_file).read())
+    return spec, oracle.OracleProblem(spec).solve(abi.F64, x0[None, :], augmented_lagrangian=augmented_lagrangian)
+
+
+def _check_against_oracle(got, ref, tol=2e-4):
+    # host containers are float (as the reference's), the device solve ran in fp64
+    assert got["iters"] == int(ref["iters"][0])
+    assert got["success"] == int(ref["status"][0])
+    assert got["converged"] == int(ref["converged"][0])
+    scale = max(1.0, np.max(np.abs(ref["xs"])))
+    assert np.max(np.abs(got["xs"] - ref["xs"][0])) < tol * scale
+    assert np.max(np.abs(got["us"] - ref["us"][0])) < tol * max(1.0, np.max(np.abs(ref["us"])))
+    assert np.max(np.abs(got["alpha"] - ref["alpha"][0])) < tol * max(1.0, np.max(np.abs(ref["alpha"])))
+    np.testing.assert_allclose(got["costs"], ref["costs"][0], rtol=1e-4)
+
+
+@pytest.mark.gpu
+def test_cpp_ilq_solver_single_solve_matches_oracle(demo_out, oracle):
+    got = _parse_log(os.path.join(demo_out, "ilq_single.txt"))
+    spec, ref = _oracle_solve(oracle, os.path.join(demo_out, "scene.txt"), got["x0"])
+    assert got["iters"] >= 2
+    _check_against_oracle(got, ref)
+
+
+@pytest.mark.gpu
+def test_cpp_solve_batch_matches_oracle_per_instance(demo_out, oracle):
+    for b in range(6):
+        got = _parse_log(os.path.join(demo_out, "ilq_batch_%d.txt" % b))
+        spec, ref = _oracle_solve(oracle, os.path.join(demo_out, "scene.txt"), got["x0"])
+        _check_against_oracle(got, ref)
+
+
+@pytest.mark.gpu
+def test_cpp_augmented_lagrangian_solver_matches_oracle(demo_out, oracle):
+    got = _parse_log(os.path.join(demo_out, "al_single.txt"))
+    spec, ref = _oracle_solve(oracle, os.path.join(demo_out, "scene_constrained.txt"), got["x0"],
+                              augmented_lagrangian=True)
+    assert spec.num_constraints == 2
+    _check_against_oracle(got, ref)
+
+
+def _parse_lq(path):
+    rows = {}
+    order = []
+    for line in open(path):
+        tok = line.split()
+        if tok[0] == "dims":
+            n, N, mi, T = (int(v) for v in tok[1:])
+        else:
+            rows.setdefault(tok[0], []).append([float(v) for v in tok[1:]])
+    return (n, N, mi, T), {k: np.array(v) for k, v in rows.items()}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("open_loop", [False, True])
+def test_cpp_lq_solvers_match_oracle(demo_out, oracle, open_loop):
+    (n, N, mi, T), d = _parse_lq(os.path.join(demo_out, "lq_openloop.txt" if open_loop else "lq_feedback.txt"))
+    m = N * mi
+    dims = abi.make_dims(n, [mi] * N, T, 1, abi.F64)
+    pairs = [(i, j) for i in range(N) for j in range(N)]
+    A = d["A"].reshape(1, T, n * n)
+    Bm = d["B"].reshape(1, T, n * m)
+    Q = d["Q"].reshape(1, T, N, n * n)
+    l = d["l"].reshape(1, T, N, n)
+    R = d["R"].reshape(1, T, len(pairs) * mi * mi)
+    r = d["r"].reshape(1, T, len(pairs) * mi)
+    P, alpha, dx, _ = oracle.lq_solve(dims, A, Bm, Q, l, R, r, pairs, x0=d["x0"].reshape(1, n), open_loop=open_loop)
+    # C++ side printed per-player (m_i x n) gains; restack to the (m x n) column-major layout
+    gotP = d["P"].reshape(T, N, n, mi).transpose(0, 2, 1, 3).reshape(T, n * m)
+    gotA = d["alpha"].reshape(T, m)
+    tol = 2e-5
+    assert np.max(np.abs(gotP - P[0])) < tol * max(1.0, np.max(np.abs(P)))
+    assert np.max(np.abs(gotA - alpha[0])) < tol * max(1.0, np.max(np.abs(alpha)))
+    assert np.max(np.abs(d["dx"] - dx[0])) < tol * max(1.0, np.max(np.abs(dx)))
+    assert np.max(np.abs(gotA)) > 1e-3
