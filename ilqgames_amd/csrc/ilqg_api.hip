@@ -112,7 +112,7 @@ __global__ void rollout_kernel(DevProblem p, RolloutBatchArgs<T> g) {
   RolloutArgs<T> a{g.x0 + b * n,          g.xs_ref + b * Tn * n, g.us_ref + b * Tn * m, g.P + b * Tn * m * n,
                    g.alpha + b * Tn * m,  g.alpha_scale ? g.alpha_scale[b] : T(1),
                    g.xs + b * Tn * n,     g.us + b * Tn * m};
-  rollout_instance<T>(p, a, sm);
+  rollout_instance<T>(p, a, sm, threadIdx.x);
 }
 
 template <typename T>
@@ -150,7 +150,7 @@ __global__ void linquad_kernel(DevProblem p, QuadBatchArgs<T> g) {
   a.merit_part = g.merit_part ? g.merit_part + b * Tn * N * 2 : nullptr;
   a.cost_part = g.cost_part ? g.cost_part + b * Tn * N : nullptr;
   for (int k = blockIdx.x * kStepsPerBlock; k < (blockIdx.x + 1) * kStepsPerBlock && k < p.T; k++)
-    linquad_step<T>(p, tb, a, k, sm);
+    linquad_step<T>(p, tb, a, k, sm, threadIdx.x);
 }
 
 template <typename T>
@@ -160,22 +160,53 @@ __global__ void costs_reduce_kernel(DevProblem p, const T* cost_part, T* costs, 
   costs_reduce<T>(p, cost_part + b * p.T * p.N, costs + b * p.N, t_extreme ? t_extreme + b * p.N : nullptr);
 }
 
-// Second launch-bound argument = minimum waves per SIMD the register allocation must allow: a single
-// wave issues roughly one instruction per 8-10 cycles here (dependent LDS / MFMA / libm chains), so
-// throughput at large batch comes from co-resident instances, i.e. from staying under 128 VGPRs
-// (fp32) / 256 (fp64) per lane.
-template <typename T, int NX, int NP, int MU>
-__global__ void __launch_bounds__((LQCfg<T, NX, NP, MU>::NT), (sizeof(T) == 4 ? 2 : 1))
-ilq_solve_kernel(DevProblem p, SolveArgs<T> sa) {
+// Wavefronts per instance in the trial kernel.  fp64 keeps the 256-register budget (two waves per
+// SIMD at the headline batch of 1024 instances on 1024 SIMDs); fp32 takes four.
+#ifndef ILQG_TRIAL_WAVES_F32
+#define ILQG_TRIAL_WAVES_F32 4
+#endif
+#ifndef ILQG_TRIAL_WAVES_F64
+#define ILQG_TRIAL_WAVES_F64 2
+#endif
+template <typename T>
+struct TrialWaves {
+  static constexpr int W = sizeof(T) == 4 ? ILQG_TRIAL_WAVES_F32 : ILQG_TRIAL_WAVES_F64;
+};
+
+// Trial kernel: rollout + linearise/quadraticise + line-search decision (ilqg_solve.hpp).  The second
+// launch-bound argument is the number of waves per SIMD the register allocation must allow.
+template <typename T, int NX, int NP, int MU, int W>
+__global__ void __launch_bounds__(64 * W, W) ilq_trial_kernel(DevProblem p, SolveArgs<T> sa) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  const QuadTables<T> tb = quad_tables_load<T>(p, smem_raw);  // resident for the whole solve
-  T* sm = reinterpret_cast<T*>(smem_raw + quad_tables_bytes(p, sizeof(T)));
   const int b = blockIdx.x;
-  const int n = NX;
-  T* xs0 = sa.xs + size_t(b) * p.T * n;
-  if (threadIdx.x < n) xs0[threadIdx.x] = sa.x0[size_t(b) * n + threadIdx.x];  // xs[0] = x0 (:89-90)
-  __syncthreads();
-  ilq_solve_instance<T, NX, NP, MU>(p, tb, sa, b, sm);
+  if (!sa.first) {  // instances that are done (or waiting for the LQ kernel) leave without touching LDS
+    const WsLayout L(p.n, p.m, p.N, p.T, p.pairs.Rsz, p.pairs.rsz, sa.ol_row, p.num_constraints, sa.al_mode);
+    const int stage = reinterpret_cast<const SolveState<T>*>(sa.ws + size_t(b) * sa.ws_stride + L.state)->stage;
+    if (stage != ST_ROLLOUT && stage != ST_QUAD) return;
+  }
+  const QuadTables<T> tb = quad_tables_load<T>(p, smem_raw);
+  T* sm = reinterpret_cast<T*>(smem_raw + quad_tables_bytes(p, sizeof(T)));
+  trial_part_instance<T, NX, NP, MU, W>(p, tb, sa, b, sm);
+}
+
+// LQ kernel: the Riccati sweep at the accepted operating point, and the exit path of the solve.
+template <typename T, int NX, int NP, int MU>
+__global__ void __launch_bounds__((LQCfg<T, NX, NP, MU>::NT)) ilq_lq_kernel(DevProblem p, SolveArgs<T> sa) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int b = blockIdx.x;
+  {
+    const WsLayout L(p.n, p.m, p.N, p.T, p.pairs.Rsz, p.pairs.rsz, sa.ol_row, p.num_constraints, sa.al_mode);
+    const int stage = reinterpret_cast<const SolveState<T>*>(sa.ws + size_t(b) * sa.ws_stride + L.state)->stage;
+    if (stage != ST_LQ && stage != ST_INNER_DONE) return;
+  }
+  QuadTables<T> tb{};
+  size_t off = 0;
+  if (sa.al_mode) {  // the multiplier update evaluates constraints: it needs the cost tables
+    tb = quad_tables_load<T>(p, smem_raw);
+    off = quad_tables_bytes(p, sizeof(T));
+  }
+  T* sm = reinterpret_cast<T*>(smem_raw + off);
+  lq_part_instance<T, NX, NP, MU>(p, tb, sa, b, sm);
 }
 
 template <typename T>
@@ -330,6 +361,8 @@ struct ilqg_problem {
   float* d_segs_f = nullptr;
   double* d_segs_d = nullptr;
   int* d_cost_order = nullptr;
+  int* d_unfinished = nullptr;  // instances still running after an LQ-kernel launch
+  int* h_unfinished = nullptr;  // pinned host mirror
   int mu_uniform = 0;
 };
 
@@ -372,16 +405,48 @@ static ilqg_status launch_solve(ilqg_problem* p, int32_t batch, const void* x0, 
   sa.ws = (T*)workspace; sa.ws_stride = L.total; sa.fixed_iters = fixed_iters; sa.batch = batch;
   sa.prm = p->desc.params;
   sa.prof = g_prof;
-  size_t elems = C::LDS_ELEMS;
-  if (p->desc.params.open_loop && size_t(OLCfg<T, NX, NP, MU>::LDS_ELEMS) > elems) elems = OLCfg<T, NX, NP, MU>::LDS_ELEMS;
-  const size_t e2 = rollout_lds_elems(d.n, d.m), e3 = quad_lds_elems(d.n, d.m, d.N, d.pairs.Rsz, d.pairs.rsz, d.num_terms);
-  if (e2 > elems) elems = e2;
-  if (e3 > elems) elems = e3;
-  const size_t lds = elems * sizeof(T) + quad_tables_bytes(d, sizeof(T));
-  auto kern = ilq_solve_kernel<T, NX, NP, MU>;
-  raise_lds_limit((const void*)kern, lds);
-  hipLaunchKernelGGL(kern, dim3(batch), dim3(C::NT), lds, stream, d, sa);
+  if (!p->d_unfinished) {
+    HIP_TRY(hipMalloc(&p->d_unfinished, sizeof(int)));
+    HIP_TRY(hipHostMalloc(&p->h_unfinished, sizeof(int)));
+  }
+  sa.unfinished = p->d_unfinished;
+  constexpr int W = TrialWaves<T>::W;
+  if (d.m * d.n + 2 * d.m + d.n > 4 * 64) return fail(ILQG_ERR_UNSUPPORTED, "rollout staging block too large");
+  size_t lq_elems = C::LDS_ELEMS;
+  if (p->desc.params.open_loop && size_t(OLCfg<T, NX, NP, MU>::LDS_ELEMS) > lq_elems) lq_elems = OLCfg<T, NX, NP, MU>::LDS_ELEMS;
+  const size_t lds_lq = lq_elems * sizeof(T) + (al_mode ? quad_tables_bytes(d, sizeof(T)) : 0);
+  const size_t lds_trial = trial_lds_bytes<T>(d, W);
+  auto k_trial = ilq_trial_kernel<T, NX, NP, MU, W>;
+  auto k_lq = ilq_lq_kernel<T, NX, NP, MU>;
+  raise_lds_limit((const void*)k_trial, lds_trial);
+  raise_lds_limit((const void*)k_lq, lds_lq);
+
+  // trial, then (LQ, trial) rounds.  With fixed_iters = K the sequence is known: K sweeps, each followed
+  // by a trial pass, and one last LQ-kernel launch that runs the exit path.  Otherwise the LQ kernel
+  // counts the instances it leaves unfinished and the host reads that count back each round (which
+  // makes a free-running solve synchronous with respect to `stream`).
+  sa.first = 1;
+  hipLaunchKernelGGL(k_trial, dim3(batch), dim3(64 * W), lds_trial, stream, d, sa);
   HIP_TRY(hipGetLastError());
+  sa.first = 0;
+  const bool counted = !(fixed_iters > 0 && !al_mode);
+  const long long cap = al_mode ? (long long)(sa.prm.max_solver_iters + 1) * (sa.prm.unconstrained_solver_max_iters + 2)
+                                : (long long)sa.prm.max_solver_iters + 2;
+  for (long long round = 0;; round++) {
+    if (counted) HIP_TRY(hipMemsetAsync(p->d_unfinished, 0, sizeof(int), stream));
+    hipLaunchKernelGGL(k_lq, dim3(batch), dim3(C::NT), lds_lq, stream, d, sa);
+    HIP_TRY(hipGetLastError());
+    if (counted) {
+      HIP_TRY(hipMemcpyAsync(p->h_unfinished, p->d_unfinished, sizeof(int), hipMemcpyDeviceToHost, stream));
+      HIP_TRY(hipStreamSynchronize(stream));
+      if (*p->h_unfinished == 0) break;
+      if (round > cap) return fail(ILQG_ERR_HIP, "solve did not terminate within its iteration bound");
+    } else if (round == fixed_iters) {
+      break;
+    }
+    hipLaunchKernelGGL(k_trial, dim3(batch), dim3(64 * W), lds_trial, stream, d, sa);
+    HIP_TRY(hipGetLastError());
+  }
   return ILQG_OK;
 }
 
@@ -737,6 +802,8 @@ void ilqg_problem_destroy(ilqg_problem* p) {
   if (p->d_segs_f) (void)hipFree(p->d_segs_f);
   if (p->d_segs_d) (void)hipFree(p->d_segs_d);
   if (p->d_cost_order) (void)hipFree(p->d_cost_order);
+  if (p->d_unfinished) (void)hipFree(p->d_unfinished);
+  if (p->h_unfinished) (void)hipHostFree(p->h_unfinished);
   delete p;
 }
 

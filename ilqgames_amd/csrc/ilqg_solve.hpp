@@ -33,7 +33,9 @@ struct SolveArgs {
   int ol_row;           // elements per open-loop scratch row (0 when the feedback sweep is used)
   int al_mode;          // 1: AugmentedLagrangianSolver::Solve around the inner iLQ solve
   ilqg_solver_params prm;
-  long long* prof;      // optional [B][8] shader-clock cycles per stage (diagnostics) or nullptr
+  long long* prof;      // optional [B][16] shader-clock cycles (diagnostics) or nullptr
+  int first;            // trial kernel: 1 on the first launch of a solve (initialises the state)
+  int* unfinished;      // LQ kernel: incremented once per instance that is not DONE when it exits
 };
 
 // Elements of one open-loop scratch row ([X|y|W|w|M|m|Q l], OLCfg::ROW) from run-time dimensions.
@@ -41,9 +43,24 @@ __host__ __device__ inline int ol_row_elems(int n, int m, int N) {
   return (n * n + n + m * n + m + N * n * n + N * n + N * n + 3) & ~3;
 }
 
+// Loop state of one instance's ILQSolver::Solve (the locals of src/ilq_solver.cpp:76-172 plus the
+// AugmentedLagrangianSolver bookkeeping).  It lives in registers inside a kernel and in the
+// workspace between the trial kernel and the LQ kernel.
+enum { ST_ROLLOUT = 0, ST_QUAD = 1, ST_LQ = 2, ST_INNER_DONE = 3, ST_DONE = 4 };
+enum { Q_COSTS = 0, Q_INIT = 1, Q_TRIAL = 2, Q_LIN = 3 };
+template <typename T>
+struct SolveState {
+  int stage, qmode, initial, cur, sacc, num_iterations, bt, accepted_iters;
+  int has_converged, ok, logged, inner_calls, al_success, pad0, pad1, pad2;
+  T acc_scale, step, last_merit, expected_decrease, max_err, mu;
+};
+constexpr int kStateElems = 32;  // >= sizeof(SolveState<T>) / sizeof(T) for float and double
+static_assert(sizeof(SolveState<float>) <= kStateElems * sizeof(float), "state slot");
+static_assert(sizeof(SolveState<double>) <= kStateElems * sizeof(double), "state slot");
+
 // Per-instance workspace layout (in elements of T).
 struct WsLayout {
-  size_t xs1, us1, P1, al1, A, B, Q, l, R, r, lqscr, dx, mpart, cpart, ints, lambdas, wxs, wus, wP, wal, total;
+  size_t xs1, us1, P1, al1, A, B, Q, l, R, r, lqscr, dx, mpart, cpart, ints, state, lambdas, wxs, wus, wP, wal, total;
   __host__ __device__ WsLayout(int n, int m, int N, int T, int Rsz, int rsz, int ol_row = 0, int num_constraints = 0,
                                int al_mode = 0) {
     size_t o = 0;
@@ -67,6 +84,7 @@ struct WsLayout {
     mpart = take(size_t(T) * N * 2);
     cpart = take(size_t(T) * N);
     ints = take(2 * kMaxPlayers);  // t_extreme as int32 (room for fp32 or fp64 elements)
+    state = take(kStateElems);    // SolveState carried between the two kernels of a solve
     lambdas = take(size_t(num_constraints) * T);  // per-instance Constraint::lambdas_ (constraint.h:136)
     wxs = take(al_mode ? size_t(T) * n : 0);      // Problem's stored solution = warm start of the next inner solve
     wus = take(al_mode ? size_t(T) * m : 0);
@@ -76,149 +94,245 @@ struct WsLayout {
   }
 };
 
-// The loop is written as a small stage interpreter so that each heavy stage (rollout, the
-// per-step linearise+quadraticise, the LQ sweep) is instantiated — and inlined — exactly once
-// in the persistent kernel; all transitions are wave-uniform.
+// One solve is a sequence of two kernels that alternate until every instance is done:
+//
+//   trial kernel  (W wavefronts per instance)  rollout of the warm start or of a line-search trial,
+//                 linearise + quadraticise + merit/cost pieces of that trajectory, Armijo decision —
+//                 repeated inside the kernel until a trial is accepted or the search gives up;
+//   LQ kernel     (one workgroup per instance)  the coupled Riccati sweep at the accepted operating
+//                 point + ExpectedDecrease, and the return path of ILQSolver::Solve / the
+//                 AugmentedLagrangianSolver outer loop.
+//
+// They are separate kernels because their register needs differ by 2x (the MFMA sweep wants the whole
+// 512-entry file of a SIMD, the trial stages fit in a quarter of it): fused, the sweep's allocation
+// caps the kernel at one wave per SIMD and leaves nothing to run beside the serial rollout chain.
+// Split, the trial kernel runs the rollout on wave 0 while the other waves of the workgroup already
+// linearise / quadraticise the steps it has produced (the steps are independent of each other).
+template <typename T>
+__device__ __forceinline__ SolveState<T> state_load(const T* w, const WsLayout& L) {
+  return *reinterpret_cast<const SolveState<T>*>(w + L.state);
+}
+template <typename T>
+__device__ __forceinline__ void state_store(T* w, const WsLayout& L, const SolveState<T>& s) {
+  if (threadIdx.x == 0) *reinterpret_cast<SolveState<T>*>(w + L.state) = s;
+}
+
+template <typename T>
+struct InstanceBuffers {
+  T *w, *xs0, *us0, *P0, *al0;
+  const WsLayout L;
+  __device__ InstanceBuffers(const DevProblem& p, const SolveArgs<T>& sa, int b)
+      : L(p.n, p.m, p.N, p.T, p.pairs.Rsz, p.pairs.rsz, sa.ol_row, p.num_constraints, sa.al_mode) {
+    w = sa.ws + size_t(b) * sa.ws_stride;
+    // two operating-point buffers and two strategy buffers; buffer 0 is the caller's
+    xs0 = sa.xs + size_t(b) * p.T * p.n;
+    us0 = sa.us + size_t(b) * p.T * p.m;
+    P0 = sa.P + size_t(b) * p.T * p.m * p.n;
+    al0 = sa.alpha + size_t(b) * p.T * p.m;
+  }
+  __device__ T* XS(int i) const { return i ? w + L.xs1 : xs0; }
+  __device__ T* US(int i) const { return i ? w + L.us1 : us0; }
+  __device__ T* PB(int i) const { return i ? w + L.P1 : P0; }
+  __device__ T* AL(int i) const { return i ? w + L.al1 : al0; }
+  __device__ int* t_extreme() const { return reinterpret_cast<int*>(w + L.ints); }
+};
+
+template <typename T>
+__device__ __forceinline__ int solve_max_iters(const SolveArgs<T>& sa) {
+  // AugmentedLagrangianSolver builds its inner ILQSolver with unconstrained_solver_max_iters
+  // (augmented_lagrangian_solver.h:80-84)
+  return sa.fixed_iters > 0 ? sa.fixed_iters
+                            : (sa.al_mode ? sa.prm.unconstrained_solver_max_iters : sa.prm.max_solver_iters);
+}
+
+// LDS of the trial kernel: [cost tables | rollout scratch | W x linquad scratch | 4 ints]
+template <typename T>
+__host__ __device__ inline size_t trial_lds_bytes(const DevProblem& p, int waves) {
+  const size_t re = (rollout_lds_elems(p.n, p.m) + 3) & ~size_t(3);
+  const size_t qe = (quad_lds_elems(p.n, p.m, p.N, p.pairs.Rsz, p.pairs.rsz, p.num_terms) + 3) & ~size_t(3);
+  return quad_tables_bytes(p, sizeof(T)) + (re + size_t(waves) * qe) * sizeof(T) + 16;
+}
+
+// ---------------------------------------------------------------------------
+// Trial part.  Runs while the instance's stage is ROLLOUT or QUAD; W = wavefronts per instance.
+// ---------------------------------------------------------------------------
+template <typename T, int NX, int NP, int MU, int W>
+__device__ __forceinline__ void trial_part_instance(const DevProblem& p, const QuadTables<T>& tb,
+                                                    const SolveArgs<T>& sa, int b, T* sm) {
+  constexpr int n = NX, N = NP, m = NP * MU;
+  const int Tn = p.T;
+  const ilqg_solver_params& prm = sa.prm;
+  const InstanceBuffers<T> ib(p, sa, b);
+  const WsLayout& L = ib.L;
+  T* const w = ib.w;
+  int* const t_extreme = ib.t_extreme();
+  T* const lambdas = w + L.lambdas;  // Constraint::lambdas_, zero-initialised (types.h:128)
+  T* const costs = sa.total_costs + size_t(b) * N;
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+
+  const size_t re = (rollout_lds_elems(n, m) + 3) & ~size_t(3);
+  const size_t qe = (quad_lds_elems(n, m, N, p.pairs.Rsz, p.pairs.rsz, p.num_terms) + 3) & ~size_t(3);
+  T* const sm_roll = sm;
+  T* const sm_quad = sm + re + size_t(wave) * qe;
+  int* const flags = reinterpret_cast<int*>(sm + re + size_t(W) * qe);  // [0] rows ready, [1] next row to claim
+
+  SolveState<T> s;
+  if (sa.first) {
+    if (t < n) ib.xs0[t] = sa.x0[size_t(b) * n + t];  // xs[0] = x0 (src/ilq_solver.cpp:89-90)
+    if (t < N) t_extreme[t] = 0;  // PlayerCost::time_of_extreme_cost_ starts at 0 (player_cost.h:70)
+    for (int e = t; e < p.num_constraints * Tn; e += blockDim.x) lambdas[e] = T(0);
+    if (sa.al_mode) {  // Problem's stored solution (what OverwriteSolution maintains)
+      for (int e = t; e < Tn * n; e += blockDim.x) (w + L.wxs)[e] = ib.xs0[e];
+      for (int e = t; e < Tn * m; e += blockDim.x) (w + L.wus)[e] = ib.us0[e];
+      for (int e = t; e < Tn * m * n; e += blockDim.x) (w + L.wP)[e] = ib.P0[e];
+      for (int e = t; e < Tn * m; e += blockDim.x) (w + L.wal)[e] = ib.al0[e];
+    }
+    s.stage = ST_ROLLOUT; s.qmode = Q_COSTS; s.initial = 1; s.cur = 0; s.sacc = 0;
+    s.num_iterations = 0; s.bt = 0; s.accepted_iters = 0; s.has_converged = 0; s.ok = 1;
+    s.logged = 0; s.inner_calls = 0; s.al_success = 1; s.pad0 = s.pad1 = s.pad2 = 0;
+    s.acc_scale = T(1); s.step = T(1); s.last_merit = dinf<T>(); s.expected_decrease = dinf<T>();
+    s.max_err = dinf<T>();
+    s.mu = T(10);  // Constraint::mu_ = kDefaultMu (src/constraint.cpp:61) — one per instance
+  } else {
+    s = state_load<T>(w, L);
+  }
+  const int max_iters = solve_max_iters(sa);
+  const long long pr_start = clock64();
+
+#pragma unroll 1
+  while (s.stage == ST_ROLLOUT || s.stage == ST_QUAD) {
+    __syncthreads();  // pass boundary: global-memory hand-off between waves
+    const bool roll = s.stage == ST_ROLLOUT;
+    RolloutArgs<T> ra;
+    if (roll) {
+      // initial: from the warm start (:100-104); later: trial point of the line search (:309-342)
+      const int snew = 1 - s.sacc;
+      ra.x0 = s.initial ? sa.x0 + size_t(b) * n : ib.XS(s.cur);
+      ra.xs_ref = s.initial ? ib.XS(0) : ib.XS(s.cur);
+      ra.us_ref = s.initial ? ib.US(0) : ib.US(s.cur);
+      ra.P = s.initial ? ib.PB(0) : ib.PB(snew);
+      ra.alpha = s.initial ? ib.AL(0) : ib.AL(snew);
+      ra.alpha_scale = s.initial ? T(1) : s.step;
+      ra.xs = s.initial ? ib.XS(1) : ib.XS(1 - s.cur);
+      ra.us = s.initial ? ib.US(1) : ib.US(1 - s.cur);
+      if (s.initial) {
+        s.cur = 1;
+        s.qmode = Q_COSTS;  // TotalCosts (:107) before quadraticising (:116): costs set t_extreme
+      } else {
+        s.qmode = prm.linesearch ? Q_TRIAL : Q_LIN;
+      }
+    }
+    if (t == 0) {
+      flags[0] = roll ? 0 : Tn;
+      flags[1] = 0;
+    }
+    __syncthreads();
+    if (roll && wave == 0) rollout_instance<T, NX, NP * MU>(p, ra, sm_roll, lane, W > 1 ? &flags[0] : nullptr);
+    if (roll && W == 1) {
+      __syncthreads();
+      if (t == 0) flags[0] = Tn;
+      __syncthreads();
+    }
+
+    // ---- linearise / quadraticise the trajectory: every wave claims rows as they become ready ----
+    const int qmode = s.qmode;
+    const int at = (qmode == Q_COSTS || qmode == Q_INIT) ? s.cur : 1 - s.cur;
+    QuadArgs<T> qa;
+    qa.xs = ib.XS(at);
+    qa.us = ib.US(at);
+    qa.lambdas = p.num_constraints > 0 ? lambdas : nullptr;
+    qa.mu = s.mu;
+    qa.t_extreme = t_extreme;
+    qa.t_init = 0.0;
+    const bool lin = qmode != Q_COSTS, quad = qmode == Q_INIT || qmode == Q_TRIAL;
+    qa.A = lin ? w + L.A : nullptr;
+    qa.Bm = lin ? w + L.B : nullptr;
+    qa.Q = quad ? w + L.Q : nullptr;
+    qa.l = quad ? w + L.l : nullptr;
+    qa.R = quad ? w + L.R : nullptr;
+    qa.r = quad ? w + L.r : nullptr;
+    qa.merit_part = qmode == Q_TRIAL ? w + L.mpart : nullptr;
+    qa.cost_part = (qmode == Q_COSTS || qmode == Q_TRIAL || qmode == Q_LIN) ? w + L.cpart : nullptr;
+#pragma unroll 1
+    while (true) {
+      int k = 0;
+      if (lane == 0) k = atomicAdd(&flags[1], 1);
+      k = __builtin_amdgcn_readfirstlane(k);
+      if (k >= Tn) break;
+      while (progress_observe(&flags[0]) <= k) __builtin_amdgcn_s_sleep(8);
+      linquad_step<T, NX, NP * MU, NP>(p, tb, qa, k, sm_quad, lane);
+    }
+
+    // ---- reductions and the line-search decision (wave-uniform, identical on every wave) ----
+    if (qmode == Q_COSTS) {
+      costs_reduce<T>(p, w + L.cpart, costs, t_extreme);
+      s.qmode = Q_INIT;
+      s.stage = ST_QUAD;
+    } else if (qmode == Q_INIT) {
+      s.initial = 0;
+      s.stage = (s.num_iterations < max_iters) ? ST_LQ : ST_INNER_DONE;
+    } else {
+      bool accepted = true;
+      if (qmode == Q_TRIAL) {
+        const T merit = merit_reduce<T>(p, w + L.mpart, sm_roll);
+        const T scaled = T(prm.expected_decrease_fraction) * s.step * s.expected_decrease;
+        accepted = (s.last_merit - merit >= scaled);  // CheckArmijoCondition :350-362
+        if (accepted) {
+          const T diff = s.last_merit - merit;
+          s.has_converged =
+              (merit <= s.last_merit) && ((diff < T(0) ? -diff : diff) < T(prm.convergence_tolerance));
+          s.last_merit = merit;
+        }
+      } else {
+        __syncthreads();
+      }
+      if (accepted) {
+        s.cur = 1 - s.cur;
+        s.sacc = 1 - s.sacc;
+        s.acc_scale = s.step;
+        s.accepted_iters++;
+        costs_reduce<T>(p, w + L.cpart, costs, t_extreme);  // TotalCosts of the accepted iterate (:158)
+        s.stage = (s.num_iterations < max_iters && (sa.fixed_iters > 0 || !s.has_converged)) ? ST_LQ : ST_INNER_DONE;
+      } else {
+        s.bt++;
+        if (s.bt >= prm.max_backtracking_steps) {  // :346-347, :146-155 — keep the last accepted iterate
+          s.ok = 0;
+          s.stage = ST_INNER_DONE;
+        } else {
+          s.step *= T(prm.geometric_alpha_scaling);
+          s.stage = ST_ROLLOUT;
+        }
+      }
+    }
+  }
+  state_store<T>(w, L, s);
+  if (t == 0 && sa.prof) sa.prof[size_t(b) * 16 + 1] += clock64() - pr_start;
+}
+
+// ---------------------------------------------------------------------------
+// LQ part.  Runs while the instance's stage is LQ or INNER_DONE.
+// ---------------------------------------------------------------------------
 template <typename T, int NX, int NP, int MU>
-__device__ __forceinline__ void ilq_solve_instance(const DevProblem& p, const QuadTables<T>& tb, const SolveArgs<T>& sa,
-                                                   int b, T* sm) {
+__device__ __forceinline__ void lq_part_instance(const DevProblem& p, const QuadTables<T>& tb, const SolveArgs<T>& sa,
+                                                 int b, T* sm) {
   constexpr int n = NX, N = NP, m = NP * MU;
   const int Tn = p.T;
   const PairTable& pt = p.pairs;
   const ilqg_solver_params& prm = sa.prm;
-  const WsLayout L(n, m, N, Tn, pt.Rsz, pt.rsz, sa.ol_row, p.num_constraints, sa.al_mode);
-  T* w = sa.ws + size_t(b) * sa.ws_stride;
-  // two operating-point buffers and two strategy buffers; buffer 0 is the caller's
-  T* const xs0 = sa.xs + size_t(b) * Tn * n;
-  T* const us0 = sa.us + size_t(b) * Tn * m;
-  T* const P0 = sa.P + size_t(b) * Tn * m * n;
-  T* const al0 = sa.alpha + size_t(b) * Tn * m;
-  auto XS = [&](int i) { return i ? w + L.xs1 : xs0; };
-  auto US = [&](int i) { return i ? w + L.us1 : us0; };
-  auto PB = [&](int i) { return i ? w + L.P1 : P0; };
-  auto AL = [&](int i) { return i ? w + L.al1 : al0; };
-  int* t_extreme = reinterpret_cast<int*>(w + L.ints);
-  const T* x0 = sa.x0 + size_t(b) * n;
-  T* costs = sa.total_costs + size_t(b) * N;
+  const InstanceBuffers<T> ib(p, sa, b);
+  const WsLayout& L = ib.L;
+  T* const w = ib.w;
+  T *const xs0 = ib.xs0, *const us0 = ib.us0, *const P0 = ib.P0, *const al0 = ib.al0;
+  T* const lambdas = w + L.lambdas;
   const int t = threadIdx.x;
-
-  if (t < N) t_extreme[t] = 0;  // PlayerCost::time_of_extreme_cost_ starts at 0 (player_cost.h:70)
-  T* lambdas = w + L.lambdas;     // Constraint::lambdas_, zero-initialised (types.h:128)
-  for (int e = t; e < p.num_constraints * Tn; e += blockDim.x) lambdas[e] = T(0);
-  T mu = T(10);                   // Constraint::mu_ = kDefaultMu (src/constraint.cpp:61) — one per instance
-  if (sa.al_mode) {               // Problem's stored solution (what OverwriteSolution maintains)
-    for (int e = t; e < Tn * n; e += blockDim.x) (w + L.wxs)[e] = xs0[e];
-    for (int e = t; e < Tn * m; e += blockDim.x) (w + L.wus)[e] = us0[e];
-    for (int e = t; e < Tn * m * n; e += blockDim.x) (w + L.wP)[e] = P0[e];
-    for (int e = t; e < Tn * m; e += blockDim.x) (w + L.wal)[e] = al0[e];
-  }
-  __syncthreads();
-
-  long long pr_acc[5] = {0, 0, 0, 0, 0};
+  SolveState<T> s = state_load<T>(w, L);
   const long long pr_start = clock64();
 
-  enum { ST_ROLLOUT = 0, ST_QUAD = 1, ST_LQ = 2, ST_INNER_DONE = 3, ST_DONE = 4 };
-  enum { Q_COSTS = 0, Q_INIT = 1, Q_TRIAL = 2, Q_LIN = 3 };
-  int stage = ST_ROLLOUT, qmode = Q_COSTS;
-  bool initial = true;
-  int cur = 0;   // op buffer holding the current (last accepted) operating point
-  int sacc = 0;  // strategy buffer holding the last accepted strategies
-  T acc_scale = T(1), step = T(1);
-  T last_merit = dinf<T>(), expected_decrease = dinf<T>();
-  int num_iterations = 0, bt = 0, accepted_iters = 0;
-  bool has_converged = false, ok = true;
-  // AugmentedLagrangianSolver builds its inner ILQSolver with unconstrained_solver_max_iters
-  // (augmented_lagrangian_solver.h:80-84)
-  const int max_iters = sa.fixed_iters > 0 ? sa.fixed_iters
-                                          : (sa.al_mode ? prm.unconstrained_solver_max_iters : prm.max_solver_iters);
-  int logged = 0, inner_calls = 0;
-  bool al_success = true;
-  T max_err = dinf<T>();
-
 #pragma unroll 1
-  while (stage != ST_DONE) {
-    __syncthreads();  // stage boundary: global-memory hand-off between lanes
-    const long long pr_t0 = clock64();
-    const int stage_was = stage;
-    if (stage == ST_ROLLOUT) {
-      // initial: from the warm start (:100-104); later: trial point of the line search (:309-342)
-      const int snew = 1 - sacc;
-      RolloutArgs<T> ra;
-      ra.x0 = initial ? x0 : XS(cur);
-      ra.xs_ref = initial ? XS(0) : XS(cur);
-      ra.us_ref = initial ? US(0) : US(cur);
-      ra.P = initial ? PB(0) : PB(snew);
-      ra.alpha = initial ? AL(0) : AL(snew);
-      ra.alpha_scale = initial ? T(1) : step;
-      ra.xs = initial ? XS(1) : XS(1 - cur);
-      ra.us = initial ? US(1) : US(1 - cur);
-      rollout_instance<T, NX, NP * MU>(p, ra, sm);
-      if (initial) {
-        cur = 1;
-        qmode = Q_COSTS;  // TotalCosts (:107) before quadraticising (:116): costs set t_extreme
-      } else {
-        qmode = prm.linesearch ? Q_TRIAL : Q_LIN;
-      }
-      stage = ST_QUAD;
-    } else if (stage == ST_QUAD) {
-      const int at = (qmode == Q_COSTS || qmode == Q_INIT) ? cur : 1 - cur;
-      QuadArgs<T> qa;
-      qa.xs = XS(at);
-      qa.us = US(at);
-      qa.lambdas = p.num_constraints > 0 ? lambdas : nullptr;
-      qa.mu = mu;
-      qa.t_extreme = t_extreme;
-      qa.t_init = 0.0;
-      const bool lin = qmode != Q_COSTS, quad = qmode == Q_INIT || qmode == Q_TRIAL;
-      qa.A = lin ? w + L.A : nullptr;
-      qa.Bm = lin ? w + L.B : nullptr;
-      qa.Q = quad ? w + L.Q : nullptr;
-      qa.l = quad ? w + L.l : nullptr;
-      qa.R = quad ? w + L.R : nullptr;
-      qa.r = quad ? w + L.r : nullptr;
-      qa.merit_part = qmode == Q_TRIAL ? w + L.mpart : nullptr;
-      qa.cost_part = (qmode == Q_COSTS || qmode == Q_TRIAL || qmode == Q_LIN) ? w + L.cpart : nullptr;
-#pragma unroll 1
-      for (int k = 0; k < Tn; k++) linquad_step<T, NX, NP * MU, NP>(p, tb, qa, k, sm);
-      if (qmode == Q_COSTS) {
-        costs_reduce<T>(p, w + L.cpart, costs, t_extreme);
-        qmode = Q_INIT;
-      } else if (qmode == Q_INIT) {
-        initial = false;
-        stage = (num_iterations < max_iters) ? ST_LQ : ST_INNER_DONE;
-      } else {
-        bool accepted = true;
-        if (qmode == Q_TRIAL) {
-          const T merit = merit_reduce<T>(p, w + L.mpart, sm);
-          const T scaled = T(prm.expected_decrease_fraction) * step * expected_decrease;
-          accepted = (last_merit - merit >= scaled);  // CheckArmijoCondition :350-362
-          if (accepted) {
-            const T diff = last_merit - merit;
-            has_converged =
-                (merit <= last_merit) && ((diff < T(0) ? -diff : diff) < T(prm.convergence_tolerance));
-            last_merit = merit;
-          }
-        }
-        if (accepted) {
-          cur = 1 - cur;
-          sacc = 1 - sacc;
-          acc_scale = step;
-          accepted_iters++;
-          costs_reduce<T>(p, w + L.cpart, costs, t_extreme);  // TotalCosts of the accepted iterate (:158)
-          stage = (num_iterations < max_iters && (sa.fixed_iters > 0 || !has_converged)) ? ST_LQ : ST_INNER_DONE;
-        } else {
-          bt++;
-          if (bt >= prm.max_backtracking_steps) {  // :346-347, :146-155 — keep the last accepted iterate
-            ok = false;
-            stage = ST_INNER_DONE;
-          } else {
-            step *= T(prm.geometric_alpha_scaling);
-            stage = ST_ROLLOUT;
-          }
-        }
-      }
-    } else if (stage == ST_LQ) {  // LQ game at the current operating point (:136-143) + ExpectedDecrease (:303)
-      num_iterations++;
+  while (s.stage == ST_LQ || s.stage == ST_INNER_DONE) {
+    __syncthreads();
+    if (s.stage == ST_LQ) {  // LQ game at the current operating point (:136-143) + ExpectedDecrease (:303)
+      s.num_iterations++;
       LQArgs<T> la;
       la.A = w + L.A;
       la.Bm = w + L.B;
@@ -227,8 +341,8 @@ __device__ __forceinline__ void ilq_solve_instance(const DevProblem& p, const Qu
       la.R = w + L.R;
       la.r = w + L.r;
       la.x0 = nullptr;
-      la.P = PB(1 - sacc);
-      la.alpha = AL(1 - sacc);
+      la.P = ib.PB(1 - s.sacc);
+      la.alpha = ib.AL(1 - s.sacc);
       la.dx = w + L.dx;
       la.scratch = w + L.lqscr;
       la.ed_out = sm + LQCfg<T, NX, NP, MU>::oX;  // an LDS slot that is free once the sweep ends
@@ -240,37 +354,37 @@ __device__ __forceinline__ void ilq_solve_instance(const DevProblem& p, const Qu
       else
         lq_feedback_dispatch<T, NX, NP, MU>(la, pt, sm);
       __syncthreads();
-      expected_decrease = sm[LQCfg<T, NX, NP, MU>::oX];
+      s.expected_decrease = sm[LQCfg<T, NX, NP, MU>::oX];
       __syncthreads();
-      step = T(prm.initial_alpha_scaling);
-      bt = 0;
-      stage = ST_ROLLOUT;
+      s.step = T(prm.initial_alpha_scaling);
+      s.bt = 0;
+      s.stage = ST_ROLLOUT;
     } else {  // ST_INNER_DONE: one ILQSolver::Solve call has returned
       // ---- the log's final iterate goes back through buffer 0 (alpha carries the accepted step) ----
-      if (cur == 1) {
+      if (s.cur == 1) {
         for (int e = t; e < Tn * n; e += blockDim.x) xs0[e] = (w + L.xs1)[e];
         for (int e = t; e < Tn * m; e += blockDim.x) us0[e] = (w + L.us1)[e];
       }
-      if (sacc == 1)
+      if (s.sacc == 1)
         for (int e = t; e < Tn * m * n; e += blockDim.x) P0[e] = (w + L.P1)[e];
       {
-        const T* src = AL(sacc);
-        for (int e = t; e < Tn * m; e += blockDim.x) al0[e] = src[e] * acc_scale;
+        const T* src = ib.AL(s.sacc);
+        for (int e = t; e < Tn * m; e += blockDim.x) al0[e] = src[e] * s.acc_scale;
       }
       __syncthreads();
-      stage = ST_DONE;
+      s.stage = ST_DONE;
       if (sa.al_mode) {  // AugmentedLagrangianSolver::Solve, src/augmented_lagrangian_solver.cpp:72-210
-        logged += 1 + accepted_iters;  // SolverLog entries of this inner call (:94, :185)
-        al_success = al_success && ok;
-        if (inner_calls > 0 && !ok) {  // :166-178
+        s.logged += 1 + s.accepted_iters;  // SolverLog entries of this inner call (:94, :185)
+        s.al_success = s.al_success && s.ok;
+        if (s.inner_calls > 0 && !s.ok) {  // :166-178
           for (int e = t; e < p.num_constraints * Tn; e += blockDim.x)
             lambdas[e] *= T(prm.geometric_lambda_downscaling);
-          mu *= T(prm.geometric_mu_downscaling);
+          s.mu *= T(prm.geometric_mu_downscaling);
           __syncthreads();
         }
-        inner_calls++;
-        if (p.num_constraints > 0 && logged < prm.max_solver_iters &&
-            max_err > T(prm.constraint_error_tolerance)) {
+        s.inner_calls++;
+        if (p.num_constraints > 0 && s.logged < prm.max_solver_iters &&
+            s.max_err > T(prm.constraint_error_tolerance)) {
           // ---- multiplier update at the final operating point (:116-140) ----
           T my_err = -dinf<T>();
           if (t < p.num_constraints) {
@@ -286,7 +400,7 @@ __device__ __forceinline__ void ilq_solve_instance(const DevProblem& p, const Qu
               // Constraint::IncrementLambda (constraint.h:98-102) at TimeIndex(t0 + dt*float(k))
               const double tt = 0.0 + p.dt * double(float(k));
               const int tidx = int(static_cast<size_t>(tt / p.dt));
-              const T nl = lambdas[t * Tn + tidx] + mu * err;
+              const T nl = lambdas[t * Tn + tidx] + s.mu * err;
               lambdas[t * Tn + tidx] = nl > T(0) ? nl : T(0);
             }
           }
@@ -299,11 +413,11 @@ __device__ __forceinline__ void ilq_solve_instance(const DevProblem& p, const Qu
             if (t == 0) sm[0] = my_err;
           }
           __syncthreads();
-          max_err = sm[0];
+          s.max_err = sm[0];
           __syncthreads();
-          mu *= T(prm.geometric_mu_scaling);  // :143
+          s.mu *= T(prm.geometric_mu_scaling);  // :143
           // Problem::OverwriteSolution only after a successful inner solve (:151-154)
-          if (ok) {
+          if (s.ok) {
             for (int e = t; e < Tn * n; e += blockDim.x) (w + L.wxs)[e] = xs0[e];
             for (int e = t; e < Tn * m; e += blockDim.x) (w + L.wus)[e] = us0[e];
             for (int e = t; e < Tn * m * n; e += blockDim.x) (w + L.wP)[e] = P0[e];
@@ -316,31 +430,31 @@ __device__ __forceinline__ void ilq_solve_instance(const DevProblem& p, const Qu
           }
           __syncthreads();
           // ---- next ILQSolver::Solve call: fresh locals, persistent last_merit / t_extreme ----
-          stage = ST_ROLLOUT;
-          initial = true;
-          cur = 0;
-          sacc = 0;
-          acc_scale = T(1);
-          num_iterations = 0;
-          accepted_iters = 0;
-          has_converged = false;
-          ok = true;
+          s.stage = ST_ROLLOUT;
+          s.initial = 1;
+          s.cur = 0;
+          s.sacc = 0;
+          s.acc_scale = T(1);
+          s.num_iterations = 0;
+          s.accepted_iters = 0;
+          s.has_converged = 0;
+          s.ok = 1;
+        }
+      }
+      if (s.stage == ST_DONE) {
+        if (sa.al_mode && p.num_constraints > 0 && s.max_err > T(prm.constraint_error_tolerance))
+          s.al_success = 0;  // :188-191
+        if (t == 0) {
+          sa.iters[b] = sa.al_mode ? s.logged : s.num_iterations;
+          sa.status[b] = (sa.al_mode ? s.al_success : s.ok) ? 1 : 0;
+          sa.converged[b] = s.has_converged ? 1 : 0;
         }
       }
     }
-    pr_acc[stage_was] += clock64() - pr_t0;
   }
-  if (sa.al_mode && p.num_constraints > 0 && max_err > T(prm.constraint_error_tolerance)) al_success = false;  // :188-191
-
-  if (t == 0 && sa.prof) {
-    long long* o = sa.prof + size_t(b) * 16;
-    o[0] = pr_acc[0]; o[1] = pr_acc[1]; o[2] = pr_acc[2]; o[3] = 0; o[4] = clock64() - pr_start;
-  }
-  if (t == 0) {
-    sa.iters[b] = sa.al_mode ? logged : num_iterations;
-    sa.status[b] = (sa.al_mode ? al_success : ok) ? 1 : 0;
-    sa.converged[b] = has_converged ? 1 : 0;
-  }
+  state_store<T>(w, L, s);
+  if (t == 0 && s.stage != ST_DONE) atomicAdd(sa.unfinished, 1);
+  if (t == 0 && sa.prof) sa.prof[size_t(b) * 16 + 2] += clock64() - pr_start;
 }
 
 }  // namespace ilqg

@@ -30,11 +30,25 @@ struct RolloutArgs {
 
 __host__ __device__ inline int rollout_lds_elems(int n, int m) { return 2 * n + 2 * m + m * n + m + n; }
 
+// Workgroup-scope publish / observe of a progress counter in LDS.  Waves of one workgroup share the
+// CU's vector L1, so release/acquire at workgroup scope is enough for the global-memory rows the
+// counter covers (no cache maintenance on gfx950 outside tgsplit mode).
+__device__ __forceinline__ void progress_publish(int* flag, int value) {
+  __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ int progress_observe(int* flag) {
+  return __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 // CN, CM > 0: compile-time state / control dimensions (fully unrolled inner loops); 0: run-time.
+// Executed by ONE wavefront (lane t of 64).  `ready` (LDS, may be null) is set to k+1 once row k of
+// xs / us is in memory, so other waves of the workgroup can consume the trajectory while it is
+// still being integrated.
 template <typename T, int CN = 0, int CM = 0>
-__device__ __forceinline__ void rollout_instance(const DevProblem& p, const RolloutArgs<T>& a, T* sm) {
+__device__ __forceinline__ void rollout_instance(const DevProblem& p, const RolloutArgs<T>& a, T* sm, int t,
+                                                 int* ready = nullptr) {
   const int n = CN > 0 ? CN : p.n, m = CM > 0 ? CM : p.m, N = p.N, Tn = p.T;
-  const int t = threadIdx.x, NT = blockDim.x;
+  constexpr int NT = 64;
   T* sx = sm;             // [n] current state
   T* sdx = sx + n;        // [n]
   T* su = sdx + n;        // [m]
@@ -85,9 +99,12 @@ __device__ __forceinline__ void rollout_instance(const DevProblem& p, const Roll
   }
   issue(0);
   commit();
-  __syncthreads();
+  lds_sync(true);
 #pragma unroll 1
   for (int k = 0; k < Tn; k++) {
+    // rows < k were stored at least one integration ago: the release finds nothing left to wait for,
+    // and it sits in front of the prefetch so it never waits on fresh loads either
+    if (ready) progress_publish(ready, k);
     if (k + 1 < Tn) issue(k + 1);
     if (integ && q == 0) {
 #pragma unroll
@@ -124,6 +141,7 @@ __device__ __forceinline__ void rollout_instance(const DevProblem& p, const Roll
     if (k + 1 < Tn) commit();
     lds_sync(NT <= 64);
   }
+  if (ready) progress_publish(ready, Tn);
 }
 
 // ---------------------------------------------------------------------------
@@ -188,11 +206,13 @@ __host__ __device__ inline int quad_lds_elems(int n, int m, int N, int Rsz, int 
   return n + m + n * n + n * m + N * n * n + N * n + Rsz + rsz + num_terms;
 }
 
+// Executed by ONE wavefront (lane t of 64) with its own LDS scratch `sm`, so several waves of a
+// workgroup can take different time steps of the same instance concurrently.
 template <typename T, int CN = 0, int CM = 0, int CNP = 0>
 __device__ __forceinline__ void linquad_step(const DevProblem& p, const QuadTables<T>& tb, const QuadArgs<T>& a, int k,
-                                             T* sm) {
+                                             T* sm, int t) {
   const int n = CN > 0 ? CN : p.n, m = CM > 0 ? CM : p.m, N = CNP > 0 ? CNP : p.N;
-  const int t = threadIdx.x, NT = blockDim.x;
+  constexpr int NT = 64;
   const PairTable& pt = p.pairs;
   T* sx = sm;  // [x | u] argument image
   T* sA = sx + n + m;

@@ -45,8 +45,8 @@ hip.lib().ilqg_debug_set_profile_buffer(ctypes.c_void_p(prof.data_ptr()))
 for k in ("xs", "us", "P", "alpha"): bufs[k].zero_()
 prob.solve(x0d, bufs, fixed_iters=4); torch.cuda.synchronize()
 pm = prof.double().mean(0).cpu().numpy()
-print("fused K=4 mean cycles/instance: rollout %.0f quad %.0f lq %.0f reduce %.0f total %.0f" % tuple(pm[:5]))
-print("  per call: rollout %.0f (5 calls) quad+reduce %.0f (6 passes) lq %.0f (4)" % (pm[0]/5, pm[1]/6, pm[2]/4))
+print("solve K=4 mean cycles/instance: trial kernel %.0f (5 launches)  lq kernel %.0f (5 launches, 4 sweeps)" % (pm[1], pm[2]))
+print("  per launch: trial %.0f  lq sweep %.0f" % (pm[1] / 5, pm[2] / 4))
 hip.lib().ilqg_debug_set_profile_buffer(None)
 
 print("  lq phases (cycles/step): issue+ql %.0f  G,SY %.0f  solve %.0f  F,beta %.0f  players %.0f  zeta %.0f  wait+swap %.0f" % tuple(pm[8:15] / 396))
