@@ -44,7 +44,8 @@ struct LQBatchArgs {
 };
 
 template <typename T, int NX, int NP, int MU, bool FORCE_VALU>
-__global__ void __launch_bounds__((LQCfg<T, NX, NP, MU>::NT))
+__global__ void __launch_bounds__((LQFeedbackThreads<T, NX, NP, MU, FORCE_VALU>::NT),
+                                  (LQFeedbackThreads<T, NX, NP, MU, FORCE_VALU>::PLAYER_WAVES ? NP : 1))
 lq_feedback_kernel(LQBatchArgs<T> g, PairTable pt) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   T* sm = reinterpret_cast<T*>(smem_raw);
@@ -182,31 +183,25 @@ __global__ void __launch_bounds__(64 * W, W) ilq_trial_kernel(DevProblem p, Solv
   if (!sa.first) {  // instances that are done (or waiting for the LQ kernel) leave without touching LDS
     const WsLayout L(p.n, p.m, p.N, p.T, p.pairs.Rsz, p.pairs.rsz, sa.ol_row, p.num_constraints, sa.al_mode);
     const int stage = reinterpret_cast<const SolveState<T>*>(sa.ws + size_t(b) * sa.ws_stride + L.state)->stage;
-    if (stage != ST_ROLLOUT && stage != ST_QUAD) return;
+    if (stage != ST_ROLLOUT && stage != ST_QUAD && stage != ST_INNER_DONE) return;
   }
   const QuadTables<T> tb = quad_tables_load<T>(p, smem_raw);
   T* sm = reinterpret_cast<T*>(smem_raw + quad_tables_bytes(p, sizeof(T)));
   trial_part_instance<T, NX, NP, MU, W>(p, tb, sa, b, sm);
 }
 
-// LQ kernel: the Riccati sweep at the accepted operating point, and the exit path of the solve.
-template <typename T, int NX, int NP, int MU>
-__global__ void __launch_bounds__((LQCfg<T, NX, NP, MU>::NT)) ilq_lq_kernel(DevProblem p, SolveArgs<T> sa) {
+// LQ kernel: the Riccati sweep at the accepted operating point of every instance that asked for one.
+template <typename T, int NX, int NP, int MU, bool PW>
+__global__ void __launch_bounds__((PW ? 64 * NP : LQCfg<T, NX, NP, MU>::NT), (PW ? NP : 1))
+ilq_lq_kernel(DevProblem p, SolveArgs<T> sa) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int b = blockIdx.x;
   {
     const WsLayout L(p.n, p.m, p.N, p.T, p.pairs.Rsz, p.pairs.rsz, sa.ol_row, p.num_constraints, sa.al_mode);
     const int stage = reinterpret_cast<const SolveState<T>*>(sa.ws + size_t(b) * sa.ws_stride + L.state)->stage;
-    if (stage != ST_LQ && stage != ST_INNER_DONE) return;
+    if (stage != ST_LQ) return;
   }
-  QuadTables<T> tb{};
-  size_t off = 0;
-  if (sa.al_mode) {  // the multiplier update evaluates constraints: it needs the cost tables
-    tb = quad_tables_load<T>(p, smem_raw);
-    off = quad_tables_bytes(p, sizeof(T));
-  }
-  T* sm = reinterpret_cast<T*>(smem_raw + off);
-  lq_part_instance<T, NX, NP, MU>(p, tb, sa, b, sm);
+  lq_part_instance<T, NX, NP, MU, PW>(p, sa, b, reinterpret_cast<T*>(smem_raw));
 }
 
 template <typename T>
@@ -299,12 +294,14 @@ ilqg_status launch_lq(const ilqg_dims* d, const PairTable& pt, const void* A, co
   g.adaptive = d->adaptive_regularization;
   g.batch = d->batch;
   g.force_valu = 0;
-  const size_t lds = size_t(C::LDS_ELEMS) * sizeof(T);
+  const bool use_pw = C::USE_MFMA && getenv("ILQG_FORCE_VALU") == nullptr;
+  const size_t lds = size_t(use_pw ? PWCfg<T, NX, NP, MU>::LDS_ELEMS : C::LDS_ELEMS) * sizeof(T);
   // ILQG_FORCE_VALU=1 selects the VALU/LDS formulation where the MFMA one is the default (A/B profiling)
-  auto kern = (C::USE_MFMA && getenv("ILQG_FORCE_VALU") != nullptr) ? lq_feedback_kernel<T, NX, NP, MU, true>
-                                                                    : lq_feedback_kernel<T, NX, NP, MU, false>;
+  const bool valu = C::USE_MFMA && getenv("ILQG_FORCE_VALU") != nullptr;
+  auto kern = valu ? lq_feedback_kernel<T, NX, NP, MU, true> : lq_feedback_kernel<T, NX, NP, MU, false>;
+  const int nt = valu ? LQFeedbackThreads<T, NX, NP, MU, true>::NT : LQFeedbackThreads<T, NX, NP, MU, false>::NT;
   raise_lds_limit((const void*)kern, lds);
-  hipLaunchKernelGGL(kern, dim3(d->batch), dim3(C::NT), lds, stream, g, pt);
+  hipLaunchKernelGGL(kern, dim3(d->batch), dim3(nt), lds, stream, g, pt);
   HIP_TRY(hipGetLastError());
   return ILQG_OK;
 }
@@ -412,30 +409,30 @@ static ilqg_status launch_solve(ilqg_problem* p, int32_t batch, const void* x0, 
   sa.unfinished = p->d_unfinished;
   constexpr int W = TrialWaves<T>::W;
   if (d.m * d.n + 2 * d.m + d.n > 4 * 64) return fail(ILQG_ERR_UNSUPPORTED, "rollout staging block too large");
-  size_t lq_elems = C::LDS_ELEMS;
+  size_t lq_elems = (C::USE_MFMA && !p->desc.params.open_loop) ? PWCfg<T, NX, NP, MU>::LDS_ELEMS : C::LDS_ELEMS;
   if (p->desc.params.open_loop && size_t(OLCfg<T, NX, NP, MU>::LDS_ELEMS) > lq_elems) lq_elems = OLCfg<T, NX, NP, MU>::LDS_ELEMS;
-  const size_t lds_lq = lq_elems * sizeof(T) + (al_mode ? quad_tables_bytes(d, sizeof(T)) : 0);
+  const size_t lds_lq = lq_elems * sizeof(T);
   const size_t lds_trial = trial_lds_bytes<T>(d, W);
   auto k_trial = ilq_trial_kernel<T, NX, NP, MU, W>;
-  auto k_lq = ilq_lq_kernel<T, NX, NP, MU>;
+  const bool pw = C::USE_MFMA && !p->desc.params.open_loop;  // one wave per player (MFMA feedback sweep)
+  auto k_lq = pw ? ilq_lq_kernel<T, NX, NP, MU, C::USE_MFMA> : ilq_lq_kernel<T, NX, NP, MU, false>;
+  const int nt_lq = pw ? 64 * NP : C::NT;
   raise_lds_limit((const void*)k_trial, lds_trial);
   raise_lds_limit((const void*)k_lq, lds_lq);
 
-  // trial, then (LQ, trial) rounds.  With fixed_iters = K the sequence is known: K sweeps, each followed
-  // by a trial pass, and one last LQ-kernel launch that runs the exit path.  Otherwise the LQ kernel
-  // counts the instances it leaves unfinished and the host reads that count back each round (which
-  // makes a free-running solve synchronous with respect to `stream`).
-  sa.first = 1;
-  hipLaunchKernelGGL(k_trial, dim3(batch), dim3(64 * W), lds_trial, stream, d, sa);
-  HIP_TRY(hipGetLastError());
-  sa.first = 0;
+  // trial, then (LQ, trial) rounds.  The trial kernel counts the instances it leaves waiting for a
+  // sweep; with fixed_iters = K the sequence is known (K sweeps, each followed by a trial pass),
+  // otherwise the host reads the count back each round — which makes a free-running solve
+  // synchronous with respect to `stream`.
   const bool counted = !(fixed_iters > 0 && !al_mode);
   const long long cap = al_mode ? (long long)(sa.prm.max_solver_iters + 1) * (sa.prm.unconstrained_solver_max_iters + 2)
                                 : (long long)sa.prm.max_solver_iters + 2;
+  sa.first = 1;
   for (long long round = 0;; round++) {
     if (counted) HIP_TRY(hipMemsetAsync(p->d_unfinished, 0, sizeof(int), stream));
-    hipLaunchKernelGGL(k_lq, dim3(batch), dim3(C::NT), lds_lq, stream, d, sa);
+    hipLaunchKernelGGL(k_trial, dim3(batch), dim3(64 * W), lds_trial, stream, d, sa);
     HIP_TRY(hipGetLastError());
+    sa.first = 0;
     if (counted) {
       HIP_TRY(hipMemcpyAsync(p->h_unfinished, p->d_unfinished, sizeof(int), hipMemcpyDeviceToHost, stream));
       HIP_TRY(hipStreamSynchronize(stream));
@@ -444,7 +441,7 @@ static ilqg_status launch_solve(ilqg_problem* p, int32_t batch, const void* x0, 
     } else if (round == fixed_iters) {
       break;
     }
-    hipLaunchKernelGGL(k_trial, dim3(batch), dim3(64 * W), lds_trial, stream, d, sa);
+    hipLaunchKernelGGL(k_lq, dim3(batch), dim3(nt_lq), lds_lq, stream, d, sa);
     HIP_TRY(hipGetLastError());
   }
   return ILQG_OK;

@@ -136,10 +136,10 @@ __device__ __forceinline__ void dma_g2l(const void* g, void* l, int nbytes, int 
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // Starts the DMA of step k's [B|A|Q|l|R|r] block into the image at `img`.
-template <typename T, int NX, int NP, int MU>
+template <typename T, int NX, int NP, int MU, int NT = LQCfg<T, NX, NP, MU>::NT>
 __device__ __forceinline__ void lq_stage_issue(const LQArgs<T>& a, const PairTable& pt, int k, T* img, int t) {
   using C = LQCfg<T, NX, NP, MU>;
-  constexpr int NT = C::NT, M = C::M, S = int(sizeof(T));
+  constexpr int M = C::M, S = int(sizeof(T));
   constexpr bool wB = (NX * M * S) % 16 == 0 && (C::oB * S) % 16 == 0;
   constexpr bool wA = (NX * NX * S) % 16 == 0 && (C::oA * S) % 16 == 0;
   constexpr bool wQ = (NP * NX * NX * S) % 16 == 0 && (C::oQ * S) % 16 == 0;
@@ -229,18 +229,49 @@ __device__ __forceinline__ void qr_solve_columns(T (&col)[M], int lane, T (&x)[M
   }
 }
 
+// Gaussian elimination solve of S X = Y in the same column-per-lane layout, no pivoting.
+// Used when the Gershgorin step (:163-176) has run: it leaves every column of S strictly diagonally
+// dominant, for which elimination without pivoting is backward stable (growth factor <= 2).  The
+// reference factors the same S with Householder QR (:180); both return the solution of the same
+// well-conditioned system, so they agree to a few ulps times cond(S) — far inside the 1e-6 bar —
+// while the elimination has no square roots and no dependent dot-product chains: each step is one
+// reciprocal, M-k-1 independent broadcasts and M-k-1 independent FMAs per lane.
+template <typename T, int M>
+__device__ __forceinline__ void lu_solve_columns(T (&col)[M], int lane, T (&x)[M]) {
+#pragma unroll
+  for (int k = 0; k + 1 < M; k++) {
+    const T rinv = T(1) / col[k];  // the pivot's reciprocal where it matters: on lane k
+    T f[M];
+#pragma unroll
+    for (int i = k + 1; i < M; i++) f[i] = bcast(col[i] * rinv, k);  // multipliers S[i][k] / S[k][k]
+#pragma unroll
+    for (int i = k + 1; i < M; i++) col[i] -= f[i] * col[k];        // row_i -= f_i row_k, every column at once
+  }
+  T diag = T(1);
+#pragma unroll
+  for (int i = 0; i < M; i++) diag = (lane == i) ? col[i] : diag;
+  const T dinv = T(1) / diag;
+#pragma unroll
+  for (int i = M - 1; i >= 0; i--) {
+    T s = col[i];
+#pragma unroll
+    for (int k2 = i + 1; k2 < M; k2++) s -= bcast(col[i], k2) * x[k2];
+    x[i] = s * bcast(dinv, i);
+  }
+}
+
 // Forward pass of the sweep: delta_xs (src/lq_feedback_solver.cpp:217-241 — no feedback term) and
 // ILQSolver::ExpectedDecrease (src/ilq_solver.cpp:364-398) from the per-step scratch rows.
 // A_{k+1} and scratch row k+1 are DMA'd into the idle image while step k is computed.
-template <typename T, int NX, int NP, int MU>
-__device__ __forceinline__ void lq_forward_pass(const LQArgs<T>& a, T* sm, int t) {
+// NT = number of threads that execute the pass (the caller has already made the scratch rows
+// visible: __syncthreads after the sweep).
+template <typename T, int NX, int NP, int MU, int NT = LQCfg<T, NX, NP, MU>::NT>
+__device__ __forceinline__ void lq_forward_pass_body(const LQArgs<T>& a, T* sm, int t) {
   using C = LQCfg<T, NX, NP, MU>;
-  constexpr int NT = C::NT, SCR = C::SCR, S = int(sizeof(T));
+  constexpr int SCR = C::SCR, S = int(sizeof(T));
   constexpr bool wA = (NX * NX * S) % 16 == 0 && (C::oA * S) % 16 == 0 && (C::IMG * S) % 16 == 0;
-  if (a.dx == nullptr && a.ed_out == nullptr) return;
   const int Tn = a.T_steps;
   T* sX = sm + C::oX;
-  __syncthreads();  // scratch rows were written to global memory by other lanes during the sweep
   auto stage = [&](int k, int which) {
     T* img = sm + which * C::IMG;
     dma_g2l<NT, wA>(a.A + size_t(k) * NX * NX, img + C::oA, NX * NX * S, t);
@@ -286,6 +317,13 @@ __device__ __forceinline__ void lq_forward_pass(const LQArgs<T>& a, T* sm, int t
     cur = 1 - cur;
   }
   if (a.ed_out && t == 0) *a.ed_out = ed;
+}
+
+template <typename T, int NX, int NP, int MU>
+__device__ __forceinline__ void lq_forward_pass(const LQArgs<T>& a, T* sm, int t) {
+  if (a.dx == nullptr && a.ed_out == nullptr) return;
+  __syncthreads();  // scratch rows were written to global memory by other lanes during the sweep
+  lq_forward_pass_body<T, NX, NP, MU>(a, sm, t);
 }
 
 // One instance, executed by a workgroup of LQCfg::NT threads.  `sm` is LDS scratch
@@ -872,11 +910,451 @@ __device__ __forceinline__ void lq_feedback_instance_mfma(const LQArgs<T>& a, co
   lq_forward_pass<T, NX, NP, MU>(a, sm, t);
 }
 
-// Dispatch: MFMA formulation where the state fits one 16x16 tile, VALU/LDS formulation otherwise.
+// ---------------------------------------------------------------------------
+// Player-parallel MFMA sweep: a workgroup of NP wavefronts per instance, wave i owns player i.
+//
+// The step's dependency chain is  [S|Y] rows  ->  M x M Nash solve  ->  F  ->  Z_i update; the first
+// and the last link are per player and independent of each other, so each wave keeps ITS Z_i / Z_i^T
+// in registers and produces its MU rows of [S | Y] and its own Z_i', zeta_i'.  Only the small solve is
+// serial (wave 0, column per lane).  Three workgroup barriers per step: [S|Y] complete,
+// (P, alpha) published, image swap.
+//
+// Staging: A, B and every Q_i are DMA'd (global_load_lds with a per-lane gather address) straight into
+// zero-padded 16 x 16 LDS tiles, so every accumulator-layout operand is read with one per-lane base
+// offset plus immediates — no predication, no selects, no masks kept live across the step loop; the
+// padding is zeroed once per sweep and never written again (the DMA only touches the valid pieces).
+//
+// When the state leaves a spare tile column (NX < 16) two matrix-vector products ride along in
+// column NX of tile products that are needed anyway:  W_i = Z_i [F | beta]  carries Z_i beta, and
+// Z_i' = F^T [W_i | zeta_i + Z_i beta] + C_i  carries F^T (zeta_i + Z_i beta).
+// ---------------------------------------------------------------------------
+template <typename T, int NX, int NP, int MU>
+struct PWCfg {
+  using C = LQCfg<T, NX, NP, MU>;
+  static constexpr int M = NP * MU;
+  // leading dimension of a padded tile: 16 would put every other column on the same LDS banks
+  // (8-way conflicts on accumulator-layout reads); 18 doubles / 17 floats spread them
+  static constexpr int LD = sizeof(T) == 8 ? 18 : 17;
+  static constexpr int TILE = (16 * LD + 3) & ~3;
+  // one staged step: [tA | tB | tQ_0.. | l | R | r]
+  static constexpr int oTA = 0;
+  static constexpr int oTB = oTA + TILE;
+  static constexpr int oTQ = oTB + TILE;
+  static constexpr int oVl = oTQ + NP * TILE;
+  static constexpr int oVR = (oVl + NP * NX + 3) & ~3;
+  static constexpr int oVr = (oVR + C::RMAX + 3) & ~3;
+  static constexpr int IMG = (oVr + C::rMAX + 3) & ~3;
+  // intermediates
+  static constexpr int oPt = 2 * IMG;           // P as a padded tile: [row][col] at row + 16*col
+  static constexpr int oAl = oPt + TILE;        // alpha (M, padded to 16)
+  static constexpr int oYz = oAl + 16;          // y_zeta (M, padded to 16)
+  static constexpr int oSY = oYz + 16;          // [S | Y] bounce: M x 32, column-major
+  static constexpr int oVec = oSY + M * 32;     // per player: beta strip (16) and zeta strip (16)
+  static constexpr int ELEMS_PW = oVec + 2 * NP * 16;
+  // the forward pass reuses the LDS with the single-wave layout
+  static constexpr int LDS_ELEMS = ELEMS_PW > C::LDS_ELEMS ? ELEMS_PW : C::LDS_ELEMS;
+  // DMA piece: 16 bytes when every column of the source and of the padded tile starts 16-byte aligned, else 4
+  static constexpr int PS = ((NX * int(sizeof(T))) % 16 == 0 && (LD * int(sizeof(T))) % 16 == 0) ? 16 : 4;
+  static constexpr int WAVE_INSTRS = (16 * LD * int(sizeof(T)) / PS + 63) / 64;  // DMA instructions of one wave per tile
+};
+
+// DMA of an (nrows x ncols) column-major matrix with leading dimension NX into a zero-padded 16 x 16
+// tile, executed by ONE wave.  Lane `lane` of instruction h moves piece 64*h + lane of the tile.
+template <typename T, int NX, int LD, int PS, int WI>
+__device__ __forceinline__ void dma_tile(const T* g, T* tile, int nrows, int ncols, int lane) {
+  constexpr int COLB = LD * int(sizeof(T));  // bytes of a padded column
+#pragma unroll
+  for (int h = 0; h < WI; h++) {
+    const int pos = (64 * h + lane) * PS;  // byte position inside the padded tile
+    const int c = pos / COLB, inb = pos % COLB;
+    if (c < ncols && inb + PS <= nrows * int(sizeof(T))) {
+      const char* src = reinterpret_cast<const char*>(g) + c * NX * int(sizeof(T)) + inb;
+      char* dst = reinterpret_cast<char*>(tile) + 64 * h * PS;  // wave-uniform; the hardware adds lane * PS
+      if constexpr (PS == 16)
+        __builtin_amdgcn_global_load_lds((glb_vptr)src, (lds_vptr)dst, 16, 0, 0);
+      else
+        __builtin_amdgcn_global_load_lds((glb_vptr)src, (lds_vptr)dst, 4, 0, 0);
+    }
+  }
+}
+
+template <typename T, int NX, int NP, int MU>
+__device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a, const PairTable& pt, T* sm) {
+  using C = LQCfg<T, NX, NP, MU>;
+  using W = PWCfg<T, NX, NP, MU>;
+  using TL = Tile<T>;
+  using vec = typename TL::vec;
+  constexpr int M = C::M, NT = 64 * NP, NS = C::NSOLVE, S = int(sizeof(T)), LD = W::LD;
+  static_assert(M <= 16 && NS <= 32, "the Nash system must fit two 16-column tiles");
+  constexpr bool SPARE = NX < 16;     // tile column NX is free
+  constexpr int JB = SPARE ? NX : 0;  // the column that carries vector operands when SPARE
+  const int t = threadIdx.x;
+  const int w = t >> 6;  // wave = player
+  const int lane = t & 63, g = lane >> 4, j = lane & 15;
+  const int Tn = a.T_steps;
+  const PairRegs<NP> pr(pt);
+  const bool want_fwd = a.dx != nullptr || a.ed_out != nullptr;
+  constexpr int SCR = C::SCR;
+  const vec zero4 = {T(0), T(0), T(0), T(0)};
+  constexpr int RS = TL::row(0, 1) - TL::row(0, 0);  // row step between accumulator registers
+  const int row0 = TL::row(g, 0);
+  const int offD = row0 + LD * j;  // [row][col] of a padded tile
+  const int offT = j + LD * row0;  // its transpose
+  auto ldD = [&](const T* tile) {
+    vec v;
+#pragma unroll
+    for (int r = 0; r < 4; r++) v[r] = tile[offD + RS * r];
+    return v;
+  };
+  auto ldDT = [&](const T* tile) {
+    vec v;
+#pragma unroll
+    for (int r = 0; r < 4; r++) v[r] = tile[offT + LD * RS * r];
+    return v;
+  };
+  // 0/1 multipliers instead of selects (all masked quantities are finite)
+  const T mCols = (j < NX) ? T(1) : T(0);      // a proper state column
+  const T mOwn = (j / MU == w) ? T(1) : T(0);  // one of this player's control columns
+  const T mVecCol = (j == (SPARE ? JB : w)) ? T(1) : T(0);
+
+  // this player's offsets in the R / r rows (wave-uniform selects on a register table)
+  int ro_ww = 0, rg_ww = 0;
+#pragma unroll
+  for (int e = 0; e < NP; e++) {
+    ro_ww = (w == e) ? pr.ro[e][e] : ro_ww;
+    rg_ww = (w == e) ? pr.rg[e][e] : rg_ww;
+  }
+
+  T* img = sm;  // image of the step being processed
+  T *tA, *tB, *tQ, *sl, *sR, *sr;
+  auto set_img = [&](int which) {
+    img = sm + which * W::IMG;
+    tA = img + W::oTA;
+    tB = img + W::oTB;
+    tQ = img + W::oTQ + w * W::TILE;
+    sl = img + W::oVl;
+    sR = img + W::oVR;
+    sr = img + W::oVr;
+  };
+  T* sPt = sm + W::oPt;
+  T* sAl = sm + W::oAl;
+  T* sYz = sm + W::oYz;
+  T* sSY = sm + W::oSY;
+  T* sBw = sm + W::oVec + w * 16;         // this player's beta, entries NX..15 zero
+  T* sZw = sm + W::oVec + (NP + w) * 16;  // this player's zeta, entries NX..15 zero
+
+  // every wave stages its own Q_w; A, B and the vectors are dealt round-robin
+  auto stage = [&](int k, int which) {
+    T* dst = sm + which * W::IMG;
+    dma_tile<T, NX, W::LD, W::PS, W::WAVE_INSTRS>(a.Q + (size_t(k) * NP + w) * NX * NX, dst + W::oTQ + w * W::TILE, NX, NX, lane);
+    if (w == 0) dma_tile<T, NX, W::LD, W::PS, W::WAVE_INSTRS>(a.A + size_t(k) * NX * NX, dst + W::oTA, NX, NX, lane);
+    if (w == 1 % NP) dma_tile<T, NX, W::LD, W::PS, W::WAVE_INSTRS>(a.Bm + size_t(k) * NX * M, dst + W::oTB, NX, M, lane);
+    if (w == 2 % NP) {
+      dma_g2l<64, false>(a.l + size_t(k) * NP * NX, dst + W::oVl, NP * NX * S, lane);
+      dma_g2l<64, false>(a.R + size_t(k) * pt.Rsz, dst + W::oVR, pt.Rsz * S, lane);
+      dma_g2l<64, false>(a.r + size_t(k) * pt.rsz, dst + W::oVr, pt.rsz * S, lane);
+    }
+  };
+
+  // (Q_w l_w) of the staged step -> scratch, for ExpectedDecrease
+  auto stash_ql = [&](int k) {
+    if (want_fwd && lane < NX) {
+      T s = T(0);
+#pragma unroll
+      for (int c = 0; c < NX; c++) s += tQ[lane + LD * c] * sl[w * NX + c];
+      a.scratch[size_t(k) * SCR + w * NX + lane] = s;
+    }
+  };
+
+  // ---- zero the tile padding (and everything else the DMA does not write), once ----
+  for (int e = t; e < W::oVec + 2 * NP * 16; e += NT) sm[e] = T(0);
+  __syncthreads();
+
+  // ---- terminal step: Z_w = Q_w[T-1], zeta_w = l_w[T-1]  (:102-105) ----
+  stage(Tn - 1, 0);
+  dma_wait();
+  __syncthreads();
+  set_img(0);
+  vec Zd = ldD(tQ);
+  vec Yd = ldDT(tQ);
+  if (lane < NX) sZw[lane] = sl[w * NX + lane];
+  stash_ql(Tn - 1);
+  for (int e = t; e < M * NX; e += NT) a.P[size_t(Tn - 1) * M * NX + e] = T(0);
+  if (t < M) a.alpha[size_t(Tn - 1) * M + t] = T(0);
+  if (want_fwd) {
+    if (t < NP) a.scratch[size_t(Tn - 1) * SCR + NP * NX + t] = T(0);
+    if (t < NX) a.scratch[size_t(Tn - 1) * SCR + NP * (NX + 1) + t] = T(0);
+  }
+  if (Tn >= 2) stage(Tn - 2, 1);
+  dma_wait();
+  __syncthreads();
+  int cur = 1;
+  set_img(1);
+
+  long long phacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // phase profile, kept in registers until the sweep ends
+#pragma unroll 1
+  for (int k = Tn - 2; k >= 0; k--) {
+    long long pc0 = a.ph ? clock64() : 0, pc1;
+#define ILQG_PH(i) do { if (a.ph) { __builtin_amdgcn_sched_barrier(0); pc1 = clock64(); __builtin_amdgcn_sched_barrier(0); phacc[i] += pc1 - pc0; pc0 = pc1; } } while (0)
+    if (k > 0) stage(k - 1, 1 - cur);
+    stash_ql(k);
+    ILQG_PH(0);
+
+    // ---- this player's MU rows of the stacked Nash system: (B_w^T Z_w) [B | A] ----
+    const vec Bd = ldD(tB);
+    vec G = tile_xty<T>(Zd, Bd, zero4);  // Z_w^T B
+#pragma unroll
+    for (int r = 0; r < 4; r++) G[r] *= mOwn;
+    const vec Ad = ldD(tA);
+    const vec Sd = tile_xty<T>(G, Bd, zero4);  // rows of player w: B_w^T Z_w B
+    const vec Yy = tile_xty<T>(G, Ad, zero4);  //                    B_w^T Z_w A
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int row = row0 + RS * r;
+      if (row / MU == w && row < M) {
+        if (j < M) sSY[row + M * j] = Sd[r];
+        if (j < NX) sSY[row + M * (M + j)] = Yy[r];
+      }
+    }
+    if (lane < MU) {  // y_zeta = B_w^T zeta_w + r_ww (:154-157)
+      const int tt = w * MU + lane;
+      T s = T(0);
+#pragma unroll
+      for (int r = 0; r < NX; r++) s += tB[r + LD * tt] * sZw[r];
+      sYz[tt] = s + sr[rg_ww + lane];
+    }
+    ILQG_PH(1);
+    lds_sync(false);  // [S | Y] and y_zeta complete (LDS only: no wait on the DMA or on global stores)
+    ILQG_PH(7);
+
+    // ---- wave 0: column `lane` of [S | Y]: + R_ii, Gershgorin (:163-176), then the M x M solve (:180) ----
+    if (w == 0) {
+      T col[M], x[M];
+#pragma unroll
+      for (int r = 0; r < M; r++) {
+        col[r] = (lane < M + NX) ? sSY[r + M * lane] : ((lane == M + NX) ? sYz[r] : T(0));
+        x[r] = T(0);
+      }
+      if (lane < M) {
+        const int pj = lane / MU, b = lane % MU;
+        int ro_ii = 0;
+#pragma unroll
+        for (int e = 0; e < NP; e++) ro_ii = (pj == e) ? pr.ro[e][e] : ro_ii;
+        const T* Rii = sR + ro_ii;
+#pragma unroll
+        for (int r = 0; r < M; r++)
+          if (r / MU == pj) col[r] = col[r] + Rii[(r % MU) + MU * b];
+        if (a.adaptive) {  // columns are independent, so lane-parallel reproduces the sequential loop
+          T l1 = T(0), diag = T(0);
+#pragma unroll
+          for (int r = 0; r < M; r++) {
+            l1 += (col[r] < T(0) ? -col[r] : col[r]);
+            if (r == lane) diag = col[r];
+          }
+          const T radius = l1 - (diag < T(0) ? -diag : diag);
+          const T eval_lo = diag - radius;
+          if (eval_lo < T(1e-3f)) {
+#pragma unroll
+            for (int r = 0; r < M; r++)
+              if (r == lane) col[r] += radius + T(1e-3f);
+          }
+        }
+      }
+      if (a.adaptive)
+        lu_solve_columns<T, M>(col, lane, x);
+      else
+        qr_solve_columns<T, M>(col, lane, x);
+      if (lane >= M && lane < M + NX) {
+#pragma unroll
+        for (int r = 0; r < M; r++) {
+          sPt[r + LD * (lane - M)] = x[r];
+          a.P[size_t(k) * M * NX + r + M * (lane - M)] = x[r];
+        }
+      } else if (lane == M + NX) {
+#pragma unroll
+        for (int r = 0; r < M; r++) {
+          sAl[r] = x[r];
+          a.alpha[size_t(k) * M + r] = x[r];
+        }
+      }
+    }
+    ILQG_PH(2);
+    lds_sync(false);  // (P, alpha) published
+    ILQG_PH(8);
+
+    // ---- F = A - B P (:189-194), beta = -B alpha; every wave needs them, so every wave computes them ----
+    const vec Pd = ldD(sPt);
+    vec nBT = ldDT(tB);  // B^T
+#pragma unroll
+    for (int r = 0; r < 4; r++) nBT[r] = -nBT[r];
+    const vec Fd = tile_xty<T>(nBT, Pd, ldD(tA));
+    {
+      T s = T(0);  // one entry of beta per lane (rows >= NX of the padded B are zero)
+#pragma unroll
+      for (int q = 0; q < M; q++) s -= tB[(lane & 15) + LD * q] * sAl[q];
+      if (lane < 16) sBw[lane] = s;
+    }
+    lds_sync(true);
+    vec BetaD, zetaD;  // beta / zeta_w down the vector column, zero elsewhere
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      BetaD[r] = sBw[row0 + RS * r] * mVecCol;
+      zetaD[r] = sZw[row0 + RS * r] * mVecCol;
+    }
+    if (want_fwd && w == 0) {
+      if (lane < NX) a.scratch[size_t(k) * SCR + NP * (NX + 1) + lane] = sBw[lane];
+      if (lane < NP) {
+        // alpha_i^T R_ii r_ii, evaluated (alpha^T R) r like Eigen (ilq_solver.cpp:384-386)
+        int ro_ii = 0, rg_ii = 0;
+#pragma unroll
+        for (int e = 0; e < NP; e++) {
+          ro_ii = (lane == e) ? pr.ro[e][e] : ro_ii;
+          rg_ii = (lane == e) ? pr.rg[e][e] : rg_ii;
+        }
+        T acc = T(0);
+#pragma unroll
+        for (int c = 0; c < MU; c++) {
+          T aR = T(0);
+#pragma unroll
+          for (int b = 0; b < MU; b++) aR += sAl[lane * MU + b] * sR[ro_ii + b + MU * c];
+          acc += aR * sr[rg_ii + c];
+        }
+        a.scratch[size_t(k) * SCR + NP * NX + lane] = acc;
+      }
+    }
+    ILQG_PH(3);
+
+    // ---- Z_w <- F^T Z_w F + Q_w + sum_jj P_jj^T R_w,jj P_jj  (:198-212), both layouts ----
+    vec Cd = ldD(tQ);
+    vec CTd = ldDT(tQ);
+#pragma unroll
+    for (int jj = 0; jj < NP; jj++) {
+      // + P_jj^T R_w,jj P_jj (and its transpose): H = R P_jj and H' = R^T P_jj sit in rows
+      // jj*MU.. of a tile, P_jj likewise, so both products are one MFMA chain each.
+      int qw = -1, ro_wj = 0;
+#pragma unroll
+      for (int e = 0; e < NP; e++) {
+        qw = (w == e) ? pr.q[e][jj] : qw;
+        ro_wj = (w == e) ? pr.ro[e][jj] : ro_wj;
+      }
+      if (qw < 0) continue;  // wave-uniform
+      const T* Rij = sR + ro_wj;
+      T pb[MU];
+#pragma unroll
+      for (int b = 0; b < MU; b++) pb[b] = sPt[(jj * MU + b) + LD * j];  // zero for j >= NX
+      vec Pj, Hd, Htd;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int aa = row0 + RS * r - jj * MU;
+        const bool in = aa >= 0 && aa < MU;
+        const int ac = in ? aa : 0;
+        const T mk = in ? T(1) : T(0);
+        T h = T(0), ht = T(0);
+#pragma unroll
+        for (int b = 0; b < MU; b++) {
+          h += Rij[ac + MU * b] * pb[b];
+          ht += Rij[b + MU * ac] * pb[b];
+        }
+        Pj[r] = Pd[r] * mk;
+        Hd[r] = h * mk;
+        Htd[r] = ht * mk;
+      }
+      Cd = tile_xty<T>(Pj, Hd, Cd);     // P_jj^T (R P_jj)
+      CTd = tile_xty<T>(Pj, Htd, CTd);  // P_jj^T (R^T P_jj) = (P_jj^T R P_jj)^T
+    }
+    vec FT;
+    if constexpr (SPARE) {
+      vec Fx;  // [F | beta]: F is zero in column JB, beta is zero outside it
+#pragma unroll
+      for (int r = 0; r < 4; r++) Fx[r] = Fd[r] + BetaD[r];
+      const vec Wd = tile_xty<T>(Yd, Fx, zero4);  // Z_w [F | beta]
+      vec Wm, Wz;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        Wm[r] = Wd[r] * mCols;
+        Wz[r] = Wm[r] + (Wd[r] * mVecCol + zetaD[r]);  // column JB: zeta_w + Z_w beta (Wm is zero there)
+      }
+      Yd = tile_xty<T>(Wm, Fd, CTd);           // (Z_w F)^T F + C_w^T
+      const vec Zx = tile_xty<T>(Fd, Wz, Cd);  // F^T [Z_w F | zeta_w + Z_w beta] + C_w
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        Zd[r] = Zx[r] * mCols;
+        FT[r] = Zx[r];
+      }
+    } else {
+      const vec Wd = tile_xty<T>(Yd, Fd, zero4);     // Z_w F
+      const vec ZB = tile_xty<T>(Yd, BetaD, zero4);  // column w = Z_w beta
+      vec TD;
+#pragma unroll
+      for (int r = 0; r < 4; r++) TD[r] = ZB[r] * mVecCol + zetaD[r];
+      Yd = tile_xty<T>(Wd, Fd, CTd);
+      Zd = tile_xty<T>(Fd, Wd, Cd);
+      FT = tile_xty<T>(Fd, TD, zero4);  // column w = F^T (zeta_w + Z_w beta)
+    }
+    ILQG_PH(4);
+    if (j == (SPARE ? JB : w)) {  // the reads of the old zeta (zetaD) precede this by data dependence
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+        if (row0 + RS * r < NX) sZw[row0 + RS * r] = FT[r];  // F^T (zeta_w + Z_w beta)
+    }
+    lds_sync(true);
+    if (lane < NX) {  // + l_w + sum_jj P_jj^T (R_w,jj alpha_jj - r_w,jj)   (:198-201, 206-212)
+      T zn = sZw[lane] + sl[w * NX + lane];
+#pragma unroll
+      for (int jj = 0; jj < NP; jj++) {
+        int qw = -1, ro_wj = 0, rg_wj = 0;
+#pragma unroll
+        for (int e = 0; e < NP; e++) {
+          qw = (w == e) ? pr.q[e][jj] : qw;
+          ro_wj = (w == e) ? pr.ro[e][jj] : ro_wj;
+          rg_wj = (w == e) ? pr.rg[e][jj] : rg_wj;
+        }
+        if (qw < 0) continue;
+        const T* Rij = sR + ro_wj;
+        const T* rij = sr + rg_wj;
+        T add = T(0);
+#pragma unroll
+        for (int aa = 0; aa < MU; aa++) {
+          T ww = T(0);
+#pragma unroll
+          for (int b = 0; b < MU; b++) ww += Rij[aa + MU * b] * sAl[jj * MU + b];
+          add += sPt[(jj * MU + aa) + LD * lane] * (ww - rij[aa]);
+        }
+        zn += add;
+      }
+      sZw[lane] = zn;
+    }
+    ILQG_PH(5);
+    dma_wait();
+    ILQG_PH(9);
+    lds_sync(false);  // next image complete; everyone is done with P / alpha / this image
+    cur = 1 - cur;
+    set_img(cur);
+    ILQG_PH(6);
+  }
+#undef ILQG_PH
+  if (a.ph && lane == 0) {  // wave w's row of the profile: a.ph[16 * w + i]
+#pragma unroll
+    for (int i = 0; i < 10; i++) a.ph[16 * w + i] += phacc[i];
+  }
+
+  if (want_fwd) {
+    __syncthreads();  // scratch rows written by all waves
+    if (w == 0) lq_forward_pass_body<T, NX, NP, MU, 64>(a, sm, lane);
+  }
+}
+
+// Threads per instance of the feedback sweep.
+template <typename T, int NX, int NP, int MU, bool FORCE_VALU = false>
+struct LQFeedbackThreads {
+  static constexpr bool PLAYER_WAVES = LQCfg<T, NX, NP, MU>::USE_MFMA && !FORCE_VALU;
+  static constexpr int NT = PLAYER_WAVES ? 64 * NP : LQCfg<T, NX, NP, MU>::NT;
+};
+
 template <typename T, int NX, int NP, int MU, bool FORCE_VALU = false>
 __device__ __forceinline__ void lq_feedback_dispatch(const LQArgs<T>& a, const PairTable& pt, T* sm) {
   if constexpr (LQCfg<T, NX, NP, MU>::USE_MFMA && !FORCE_VALU) {
-    lq_feedback_instance_mfma<T, NX, NP, MU>(a, pt, sm);
+    lq_feedback_instance_mfma_pw<T, NX, NP, MU>(a, pt, sm);
   } else {
     lq_feedback_instance<T, NX, NP, MU>(a, pt, sm);
   }

@@ -26,14 +26,14 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 template <typename T> struct Tile;
 template <> struct Tile<double> {
   using vec = v4d;
-  static __device__ __forceinline__ int row(int g, int r) { return g + 4 * r; }
+  static constexpr __host__ __device__ __forceinline__ int row(int g, int r) { return g + 4 * r; }
   static __device__ __forceinline__ vec mfma(double a, double b, vec c) {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
   }
 };
 template <> struct Tile<float> {
   using vec = v4f;
-  static __device__ __forceinline__ int row(int g, int r) { return 4 * g + r; }
+  static constexpr __host__ __device__ __forceinline__ int row(int g, int r) { return 4 * g + r; }
   static __device__ __forceinline__ vec mfma(float a, float b, vec c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
   }

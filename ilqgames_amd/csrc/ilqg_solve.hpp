@@ -35,7 +35,7 @@ struct SolveArgs {
   ilqg_solver_params prm;
   long long* prof;      // optional [B][16] shader-clock cycles (diagnostics) or nullptr
   int first;            // trial kernel: 1 on the first launch of a solve (initialises the state)
-  int* unfinished;      // LQ kernel: incremented once per instance that is not DONE when it exits
+  int* unfinished;      // trial kernel: incremented once per instance that leaves it waiting for an LQ sweep
 };
 
 // Elements of one open-loop scratch row ([X|y|W|w|M|m|Q l], OLCfg::ROW) from run-time dimensions.
@@ -154,6 +154,115 @@ __host__ __device__ inline size_t trial_lds_bytes(const DevProblem& p, int waves
 }
 
 // ---------------------------------------------------------------------------
+// Return path of one ILQSolver::Solve call (stage INNER_DONE): final iterate back into the caller's
+// buffers, and — in AL mode — the AugmentedLagrangianSolver bookkeeping that may start the next inner
+// solve.  Executed by every thread of the trial kernel's workgroup.
+// ---------------------------------------------------------------------------
+template <typename T, int NX, int NP, int MU>
+__device__ __forceinline__ void solve_exit_path(const DevProblem& p, const QuadTables<T>& tb, const SolveArgs<T>& sa,
+                                                const InstanceBuffers<T>& ib, SolveState<T>& s, int b, T* sm) {
+  constexpr int n = NX, m = NP * MU;
+  const int Tn = p.T;
+  const ilqg_solver_params& prm = sa.prm;
+  const WsLayout& L = ib.L;
+  T* const w = ib.w;
+  T *const xs0 = ib.xs0, *const us0 = ib.us0, *const P0 = ib.P0, *const al0 = ib.al0;
+  T* const lambdas = w + L.lambdas;
+  const int t = threadIdx.x;
+  __syncthreads();
+      // ---- the log's final iterate goes back through buffer 0 (alpha carries the accepted step) ----
+      if (s.cur == 1) {
+        for (int e = t; e < Tn * n; e += blockDim.x) xs0[e] = (w + L.xs1)[e];
+        for (int e = t; e < Tn * m; e += blockDim.x) us0[e] = (w + L.us1)[e];
+      }
+      if (s.sacc == 1)
+        for (int e = t; e < Tn * m * n; e += blockDim.x) P0[e] = (w + L.P1)[e];
+      {
+        const T* src = ib.AL(s.sacc);
+        for (int e = t; e < Tn * m; e += blockDim.x) al0[e] = src[e] * s.acc_scale;
+      }
+      __syncthreads();
+      s.stage = ST_DONE;
+      if (sa.al_mode) {  // AugmentedLagrangianSolver::Solve, src/augmented_lagrangian_solver.cpp:72-210
+        s.logged += 1 + s.accepted_iters;  // SolverLog entries of this inner call (:94, :185)
+        s.al_success = s.al_success && s.ok;
+        if (s.inner_calls > 0 && !s.ok) {  // :166-178
+          for (int e = t; e < p.num_constraints * Tn; e += blockDim.x)
+            lambdas[e] *= T(prm.geometric_lambda_downscaling);
+          s.mu *= T(prm.geometric_mu_downscaling);
+          __syncthreads();
+        }
+        s.inner_calls++;
+        if (p.num_constraints > 0 && s.logged < prm.max_solver_iters &&
+            s.max_err > T(prm.constraint_error_tolerance)) {
+          // ---- multiplier update at the final operating point (:116-140) ----
+          T my_err = -dinf<T>();
+          if (t < p.num_constraints) {
+            int ti = 0;
+            for (int e = 0; e < p.num_terms; e++)
+              if (tb.terms[e].slot == t) ti = e;
+            const DevTerm c = tb.terms[ti];
+            const bool on_state = c.role == ILQG_ROLE_STATE_CONSTRAINT;
+            for (int k = 0; k < Tn; k++) {
+              const T* v = on_state ? xs0 + size_t(k) * n : us0 + size_t(k) * m + p.uoff[c.arg];
+              const T err = term_evaluate_leaf<T>(tb, ti, v, c.arg_dim);
+              my_err = err > my_err ? err : my_err;
+              // Constraint::IncrementLambda (constraint.h:98-102) at TimeIndex(t0 + dt*float(k))
+              const double tt = 0.0 + p.dt * double(float(k));
+              const int tidx = int(static_cast<size_t>(tt / p.dt));
+              const T nl = lambdas[t * Tn + tidx] + s.mu * err;
+              lambdas[t * Tn + tidx] = nl > T(0) ? nl : T(0);
+            }
+          }
+          if (t < 64) {
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+              const T o = __shfl_xor(my_err, off, 64);
+              my_err = o > my_err ? o : my_err;
+            }
+            if (t == 0) sm[0] = my_err;
+          }
+          __syncthreads();
+          s.max_err = sm[0];
+          __syncthreads();
+          s.mu *= T(prm.geometric_mu_scaling);  // :143
+          // Problem::OverwriteSolution only after a successful inner solve (:151-154)
+          if (s.ok) {
+            for (int e = t; e < Tn * n; e += blockDim.x) (w + L.wxs)[e] = xs0[e];
+            for (int e = t; e < Tn * m; e += blockDim.x) (w + L.wus)[e] = us0[e];
+            for (int e = t; e < Tn * m * n; e += blockDim.x) (w + L.wP)[e] = P0[e];
+            for (int e = t; e < Tn * m; e += blockDim.x) (w + L.wal)[e] = al0[e];
+          } else {
+            for (int e = t; e < Tn * n; e += blockDim.x) xs0[e] = (w + L.wxs)[e];
+            for (int e = t; e < Tn * m; e += blockDim.x) us0[e] = (w + L.wus)[e];
+            for (int e = t; e < Tn * m * n; e += blockDim.x) P0[e] = (w + L.wP)[e];
+            for (int e = t; e < Tn * m; e += blockDim.x) al0[e] = (w + L.wal)[e];
+          }
+          __syncthreads();
+          // ---- next ILQSolver::Solve call: fresh locals, persistent last_merit / t_extreme ----
+          s.stage = ST_ROLLOUT;
+          s.initial = 1;
+          s.cur = 0;
+          s.sacc = 0;
+          s.acc_scale = T(1);
+          s.num_iterations = 0;
+          s.accepted_iters = 0;
+          s.has_converged = 0;
+          s.ok = 1;
+        }
+      }
+      if (s.stage == ST_DONE) {
+        if (sa.al_mode && p.num_constraints > 0 && s.max_err > T(prm.constraint_error_tolerance))
+          s.al_success = 0;  // :188-191
+        if (t == 0) {
+          sa.iters[b] = sa.al_mode ? s.logged : s.num_iterations;
+          sa.status[b] = (sa.al_mode ? s.al_success : s.ok) ? 1 : 0;
+          sa.converged[b] = s.has_converged ? 1 : 0;
+        }
+      }
+}
+
+// ---------------------------------------------------------------------------
 // Trial part.  Runs while the instance's stage is ROLLOUT or QUAD; W = wavefronts per instance.
 // ---------------------------------------------------------------------------
 template <typename T, int NX, int NP, int MU, int W>
@@ -200,7 +309,9 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const Q
   const long long pr_start = clock64();
 
 #pragma unroll 1
-  while (s.stage == ST_ROLLOUT || s.stage == ST_QUAD) {
+  while (true) {
+    if (s.stage == ST_INNER_DONE) solve_exit_path<T, NX, NP, MU>(p, tb, sa, ib, s, b, sm_roll);
+    if (s.stage != ST_ROLLOUT && s.stage != ST_QUAD) break;
     __syncthreads();  // pass boundary: global-memory hand-off between waves
     const bool roll = s.stage == ST_ROLLOUT;
     RolloutArgs<T> ra;
@@ -306,155 +417,58 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const Q
     }
   }
   state_store<T>(w, L, s);
-  if (t == 0 && sa.prof) sa.prof[size_t(b) * 16 + 1] += clock64() - pr_start;
+  if (t == 0 && s.stage == ST_LQ) atomicAdd(sa.unfinished, 1);  // this instance wants another sweep
+  if (t == 0 && sa.prof) sa.prof[size_t(b) * 64 + 1] += clock64() - pr_start;
 }
 
 // ---------------------------------------------------------------------------
-// LQ part.  Runs while the instance's stage is LQ or INNER_DONE.
+// LQ part: the Riccati sweep of one instance whose stage is LQ.  Kept free of everything else (the
+// exit path lives in the trial kernel) so that the sweep's registers are all it has to hold.
+// PW: the workgroup has one wave per player and runs the player-parallel MFMA feedback sweep;
+// otherwise LQCfg::NT threads run the open-loop sweep or the VALU feedback sweep.
 // ---------------------------------------------------------------------------
-template <typename T, int NX, int NP, int MU>
-__device__ __forceinline__ void lq_part_instance(const DevProblem& p, const QuadTables<T>& tb, const SolveArgs<T>& sa,
-                                                 int b, T* sm) {
-  constexpr int n = NX, N = NP, m = NP * MU;
+template <typename T, int NX, int NP, int MU, bool PW>
+__device__ __forceinline__ void lq_part_instance(const DevProblem& p, const SolveArgs<T>& sa, int b, T* sm) {
   const int Tn = p.T;
-  const PairTable& pt = p.pairs;
-  const ilqg_solver_params& prm = sa.prm;
-  const InstanceBuffers<T> ib(p, sa, b);
-  const WsLayout& L = ib.L;
-  T* const w = ib.w;
-  T *const xs0 = ib.xs0, *const us0 = ib.us0, *const P0 = ib.P0, *const al0 = ib.al0;
-  T* const lambdas = w + L.lambdas;
-  const int t = threadIdx.x;
-  SolveState<T> s = state_load<T>(w, L);
+  const WsLayout L(p.n, p.m, p.N, p.T, p.pairs.Rsz, p.pairs.rsz, sa.ol_row, p.num_constraints, sa.al_mode);
+  T* const w = sa.ws + size_t(b) * sa.ws_stride;
+  SolveState<T>* const st = reinterpret_cast<SolveState<T>*>(w + L.state);
+  const int sacc = __builtin_amdgcn_readfirstlane(st->sacc);
   const long long pr_start = clock64();
-
-#pragma unroll 1
-  while (s.stage == ST_LQ || s.stage == ST_INNER_DONE) {
-    __syncthreads();
-    if (s.stage == ST_LQ) {  // LQ game at the current operating point (:136-143) + ExpectedDecrease (:303)
-      s.num_iterations++;
-      LQArgs<T> la;
-      la.A = w + L.A;
-      la.Bm = w + L.B;
-      la.Q = w + L.Q;
-      la.l = w + L.l;
-      la.R = w + L.R;
-      la.r = w + L.r;
-      la.x0 = nullptr;
-      la.P = ib.PB(1 - s.sacc);
-      la.alpha = ib.AL(1 - s.sacc);
-      la.dx = w + L.dx;
-      la.scratch = w + L.lqscr;
-      la.ed_out = sm + LQCfg<T, NX, NP, MU>::oX;  // an LDS slot that is free once the sweep ends
-      la.T_steps = Tn;
-      la.adaptive = 1;
-      la.ph = sa.prof ? sa.prof + size_t(b) * 16 + 8 : nullptr;
-      if (prm.open_loop)
-        lq_openloop_instance<T, NX, NP, MU>(la, pt, sm);  // SolverParams::open_loop (ilq_solver.h:76-81)
-      else
-        lq_feedback_dispatch<T, NX, NP, MU>(la, pt, sm);
-      __syncthreads();
-      s.expected_decrease = sm[LQCfg<T, NX, NP, MU>::oX];
-      __syncthreads();
-      s.step = T(prm.initial_alpha_scaling);
-      s.bt = 0;
-      s.stage = ST_ROLLOUT;
-    } else {  // ST_INNER_DONE: one ILQSolver::Solve call has returned
-      // ---- the log's final iterate goes back through buffer 0 (alpha carries the accepted step) ----
-      if (s.cur == 1) {
-        for (int e = t; e < Tn * n; e += blockDim.x) xs0[e] = (w + L.xs1)[e];
-        for (int e = t; e < Tn * m; e += blockDim.x) us0[e] = (w + L.us1)[e];
-      }
-      if (s.sacc == 1)
-        for (int e = t; e < Tn * m * n; e += blockDim.x) P0[e] = (w + L.P1)[e];
-      {
-        const T* src = ib.AL(s.sacc);
-        for (int e = t; e < Tn * m; e += blockDim.x) al0[e] = src[e] * s.acc_scale;
-      }
-      __syncthreads();
-      s.stage = ST_DONE;
-      if (sa.al_mode) {  // AugmentedLagrangianSolver::Solve, src/augmented_lagrangian_solver.cpp:72-210
-        s.logged += 1 + s.accepted_iters;  // SolverLog entries of this inner call (:94, :185)
-        s.al_success = s.al_success && s.ok;
-        if (s.inner_calls > 0 && !s.ok) {  // :166-178
-          for (int e = t; e < p.num_constraints * Tn; e += blockDim.x)
-            lambdas[e] *= T(prm.geometric_lambda_downscaling);
-          s.mu *= T(prm.geometric_mu_downscaling);
-          __syncthreads();
-        }
-        s.inner_calls++;
-        if (p.num_constraints > 0 && s.logged < prm.max_solver_iters &&
-            s.max_err > T(prm.constraint_error_tolerance)) {
-          // ---- multiplier update at the final operating point (:116-140) ----
-          T my_err = -dinf<T>();
-          if (t < p.num_constraints) {
-            int ti = 0;
-            for (int e = 0; e < p.num_terms; e++)
-              if (tb.terms[e].slot == t) ti = e;
-            const DevTerm c = tb.terms[ti];
-            const bool on_state = c.role == ILQG_ROLE_STATE_CONSTRAINT;
-            for (int k = 0; k < Tn; k++) {
-              const T* v = on_state ? xs0 + size_t(k) * n : us0 + size_t(k) * m + p.uoff[c.arg];
-              const T err = term_evaluate_leaf<T>(tb, ti, v, c.arg_dim);
-              my_err = err > my_err ? err : my_err;
-              // Constraint::IncrementLambda (constraint.h:98-102) at TimeIndex(t0 + dt*float(k))
-              const double tt = 0.0 + p.dt * double(float(k));
-              const int tidx = int(static_cast<size_t>(tt / p.dt));
-              const T nl = lambdas[t * Tn + tidx] + s.mu * err;
-              lambdas[t * Tn + tidx] = nl > T(0) ? nl : T(0);
-            }
-          }
-          if (t < 64) {
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-              const T o = __shfl_xor(my_err, off, 64);
-              my_err = o > my_err ? o : my_err;
-            }
-            if (t == 0) sm[0] = my_err;
-          }
-          __syncthreads();
-          s.max_err = sm[0];
-          __syncthreads();
-          s.mu *= T(prm.geometric_mu_scaling);  // :143
-          // Problem::OverwriteSolution only after a successful inner solve (:151-154)
-          if (s.ok) {
-            for (int e = t; e < Tn * n; e += blockDim.x) (w + L.wxs)[e] = xs0[e];
-            for (int e = t; e < Tn * m; e += blockDim.x) (w + L.wus)[e] = us0[e];
-            for (int e = t; e < Tn * m * n; e += blockDim.x) (w + L.wP)[e] = P0[e];
-            for (int e = t; e < Tn * m; e += blockDim.x) (w + L.wal)[e] = al0[e];
-          } else {
-            for (int e = t; e < Tn * n; e += blockDim.x) xs0[e] = (w + L.wxs)[e];
-            for (int e = t; e < Tn * m; e += blockDim.x) us0[e] = (w + L.wus)[e];
-            for (int e = t; e < Tn * m * n; e += blockDim.x) P0[e] = (w + L.wP)[e];
-            for (int e = t; e < Tn * m; e += blockDim.x) al0[e] = (w + L.wal)[e];
-          }
-          __syncthreads();
-          // ---- next ILQSolver::Solve call: fresh locals, persistent last_merit / t_extreme ----
-          s.stage = ST_ROLLOUT;
-          s.initial = 1;
-          s.cur = 0;
-          s.sacc = 0;
-          s.acc_scale = T(1);
-          s.num_iterations = 0;
-          s.accepted_iters = 0;
-          s.has_converged = 0;
-          s.ok = 1;
-        }
-      }
-      if (s.stage == ST_DONE) {
-        if (sa.al_mode && p.num_constraints > 0 && s.max_err > T(prm.constraint_error_tolerance))
-          s.al_success = 0;  // :188-191
-        if (t == 0) {
-          sa.iters[b] = sa.al_mode ? s.logged : s.num_iterations;
-          sa.status[b] = (sa.al_mode ? s.al_success : s.ok) ? 1 : 0;
-          sa.converged[b] = s.has_converged ? 1 : 0;
-        }
-      }
-    }
+  // LQ game at the current operating point (src/ilq_solver.cpp:136-143) + ExpectedDecrease (:303)
+  LQArgs<T> la;
+  la.A = w + L.A;
+  la.Bm = w + L.B;
+  la.Q = w + L.Q;
+  la.l = w + L.l;
+  la.R = w + L.R;
+  la.r = w + L.r;
+  la.x0 = nullptr;
+  la.P = sacc ? sa.P + size_t(b) * Tn * p.m * p.n : w + L.P1;  // strategy buffer 1 - sacc
+  la.alpha = sacc ? sa.alpha + size_t(b) * Tn * p.m : w + L.al1;
+  la.dx = w + L.dx;
+  la.scratch = w + L.lqscr;
+  la.ed_out = sm + LQCfg<T, NX, NP, MU>::oX;  // an LDS slot that is free once the sweep ends
+  la.T_steps = Tn;
+  la.adaptive = 1;
+  la.ph = sa.prof ? sa.prof + size_t(b) * 64 + 8 : nullptr;
+  if constexpr (PW) {
+    lq_feedback_instance_mfma_pw<T, NX, NP, MU>(la, p.pairs, sm);
+  } else {
+    if (sa.prm.open_loop)
+      lq_openloop_instance<T, NX, NP, MU>(la, p.pairs, sm);  // SolverParams::open_loop (ilq_solver.h:76-81)
+    else
+      lq_feedback_instance<T, NX, NP, MU>(la, p.pairs, sm);
   }
-  state_store<T>(w, L, s);
-  if (t == 0 && s.stage != ST_DONE) atomicAdd(sa.unfinished, 1);
-  if (t == 0 && sa.prof) sa.prof[size_t(b) * 16 + 2] += clock64() - pr_start;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    st->expected_decrease = sm[LQCfg<T, NX, NP, MU>::oX];
+    st->num_iterations += 1;
+    st->step = T(sa.prm.initial_alpha_scaling);
+    st->bt = 0;
+    st->stage = ST_ROLLOUT;
+    if (sa.prof) sa.prof[size_t(b) * 64 + 2] += clock64() - pr_start;
+  }
 }
 
 }  // namespace ilqg

@@ -39,7 +39,7 @@ for K in (1, 2, 4, 8):
         for k in ("xs", "us", "P", "alpha"): bufs[k].zero_()
         prob.solve(x0d, bufs, fixed_iters=K)
     print("fused solve K=%d  %.3f ms" % (K, timeit(f, reps=2)))
-prof = torch.zeros((B, 16), dtype=torch.int64, device="cuda")
+prof = torch.zeros((B, 64), dtype=torch.int64, device="cuda")
 import ctypes
 hip.lib().ilqg_debug_set_profile_buffer(ctypes.c_void_p(prof.data_ptr()))
 for k in ("xs", "us", "P", "alpha"): bufs[k].zero_()
@@ -49,4 +49,7 @@ print("solve K=4 mean cycles/instance: trial kernel %.0f (5 launches)  lq kernel
 print("  per launch: trial %.0f  lq sweep %.0f" % (pm[1] / 5, pm[2] / 4))
 hip.lib().ilqg_debug_set_profile_buffer(None)
 
-print("  lq phases (cycles/step): issue+ql %.0f  G,SY %.0f  solve %.0f  F,beta %.0f  players %.0f  zeta %.0f  wait+swap %.0f" % tuple(pm[8:15] / 396))
+for wv in range(3):
+    q = pm[8 + 16 * wv: 8 + 16 * wv + 10] / 396
+    print("  wave %d (cycles/step): issue+ql %.0f | G,SY %.0f | bar1 %.0f | solve %.0f | bar2 %.0f | F,beta %.0f | players %.0f | zeta %.0f | dmawait %.0f | bar3 %.0f   sum %.0f" %
+          (wv, q[0], q[1], q[7], q[2], q[8], q[3], q[4], q[5], q[9], q[6], q.sum()))
