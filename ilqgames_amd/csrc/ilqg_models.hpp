@@ -317,6 +317,17 @@ struct QuadTables {
   const T* segs;         // [total_segs][kSegStride]
   const int* poly_off;   // [num_polylines + 1]
   const int* order;      // [N][cost_order_stride]
+  // Lane-indexed fields of DevProblem (per-player and per-block tables).  Reading them from the
+  // kernel-argument copy with a per-lane index is a global load (and `rgoff[pii[i]]` a chain of two);
+  // from LDS it is a 64-cycle read.  Layout: LC_* offsets below, floats stored as their bit patterns.
+  const int* lc;
+};
+enum {
+  LC_KIND = 0, LC_XOFF = LC_KIND + kMaxPlayers, LC_UOFF = LC_XOFF + kMaxPlayers + 1,
+  LC_UDIM = LC_UOFF + kMaxPlayers + 1, LC_PARAM = LC_UDIM + kMaxPlayers, LC_SREG = LC_PARAM + kMaxPlayers,
+  LC_CREG = LC_SREG + kMaxPlayers, LC_STRUCT = LC_CREG + kMaxPlayers, LC_PI = LC_STRUCT + kMaxPlayers,
+  LC_PJ = LC_PI + kMaxPairs, LC_ROFF = LC_PJ + kMaxPairs, LC_RGOFF = LC_ROFF + kMaxPairs,
+  LC_FROMCOST = LC_RGOFF + kMaxPairs, LC_PII = LC_FROMCOST + kMaxPairs, LC_COUNT = (LC_PII + kMaxPlayers + 3) & ~3
 };
 
 // Polyline2::ClosestPoint, src/polyline2.cpp:105-174 — linear scan over the 1..15 segments of a

@@ -307,6 +307,7 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const Q
   }
   const int max_iters = solve_max_iters(sa);
   const long long pr_start = clock64();
+  long long qph[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // linquad phase profile of this wave (diagnostics)
 
 #pragma unroll 1
   while (true) {
@@ -364,14 +365,31 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const Q
     qa.r = quad ? w + L.r : nullptr;
     qa.merit_part = qmode == Q_TRIAL ? w + L.mpart : nullptr;
     qa.cost_part = (qmode == Q_COSTS || qmode == Q_TRIAL || qmode == Q_LIN) ? w + L.cpart : nullptr;
-#pragma unroll 1
-    while (true) {
+    qa.phacc = sa.prof ? qph : nullptr;
+    long long tq0 = sa.prof ? clock64() : 0;
+    // Claim rows as they become ready.  The next row's argument is requested before this row's stores
+    // are issued (see linquad_compute / linquad_store).
+    auto claim = [&]() {
       int k = 0;
       if (lane == 0) k = atomicAdd(&flags[1], 1);
       k = __builtin_amdgcn_readfirstlane(k);
-      if (k >= Tn) break;
-      while (progress_observe(&flags[0]) <= k) __builtin_amdgcn_s_sleep(8);
-      linquad_step<T, NX, NP * MU, NP>(p, tb, qa, k, sm_quad, lane);
+      if (k < Tn)
+        while (progress_observe(&flags[0]) <= k) __builtin_amdgcn_s_sleep(8);
+      return k;
+    };
+    int k = claim();
+    T argv = k < Tn ? linquad_load_arg<T>(qa, k, n, m, lane) : T(0);
+#pragma unroll 1
+    while (k < Tn) {
+      if (sa.prof) { const long long tq1 = clock64(); qph[6] += tq1 - tq0; }
+      LinquadCarry<T> carry;
+      linquad_compute<T, NX, NP * MU, NP>(p, tb, qa, k, sm_quad, lane, argv, carry);
+      const int kn = claim();
+      const T argn = kn < Tn ? linquad_load_arg<T>(qa, kn, n, m, lane) : T(0);
+      linquad_store<T, NX, NP * MU, NP>(p, qa, k, sm_quad, lane, carry);
+      if (sa.prof) { tq0 = clock64(); qph[7] += 1; }
+      k = kn;
+      argv = argn;
     }
 
     // ---- reductions and the line-search decision (wave-uniform, identical on every wave) ----
@@ -418,7 +436,11 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const Q
   }
   state_store<T>(w, L, s);
   if (t == 0 && s.stage == ST_LQ) atomicAdd(sa.unfinished, 1);  // this instance wants another sweep
-  if (t == 0 && sa.prof) sa.prof[size_t(b) * 64 + 1] += clock64() - pr_start;
+  if (t == 0 && sa.prof) sa.prof[size_t(b) * 96 + 1] += clock64() - pr_start;
+  if (lane == 0 && sa.prof && wave < 2) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) sa.prof[size_t(b) * 96 + 64 + 8 * wave + i] += qph[i];
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -451,7 +473,7 @@ __device__ __forceinline__ void lq_part_instance(const DevProblem& p, const Solv
   la.ed_out = sm + LQCfg<T, NX, NP, MU>::oX;  // an LDS slot that is free once the sweep ends
   la.T_steps = Tn;
   la.adaptive = 1;
-  la.ph = sa.prof ? sa.prof + size_t(b) * 64 + 8 : nullptr;
+  la.ph = sa.prof ? sa.prof + size_t(b) * 96 + 8 : nullptr;
   if constexpr (PW) {
     lq_feedback_instance_mfma_pw<T, NX, NP, MU>(la, p.pairs, sm);
   } else {
@@ -467,7 +489,7 @@ __device__ __forceinline__ void lq_part_instance(const DevProblem& p, const Solv
     st->step = T(sa.prm.initial_alpha_scaling);
     st->bt = 0;
     st->stage = ST_ROLLOUT;
-    if (sa.prof) sa.prof[size_t(b) * 64 + 2] += clock64() - pr_start;
+    if (sa.prof) sa.prof[size_t(b) * 96 + 2] += clock64() - pr_start;
   }
 }
 

@@ -161,6 +161,7 @@ __host__ __device__ inline size_t quad_tables_bytes(const DevProblem& p, size_t 
   b += size_t(p.num_terms > 0 ? p.num_terms : 1) * sizeof(DevTerm);
   b += size_t(p.num_polylines + 1) * sizeof(int);
   b += size_t(p.N) * p.cost_order_stride * sizeof(int);
+  b += size_t(LC_COUNT) * sizeof(int);
   return (b + 15) & ~size_t(15);
 }
 
@@ -179,12 +180,34 @@ __device__ __forceinline__ QuadTables<T> quad_tables_load(const DevProblem& p, v
   for (int e = t; e <= p.num_polylines; e += NT) poff[e] = p.poly_off[e];
   int* order = poff + p.num_polylines + 1;
   for (int e = t; e < p.N * p.cost_order_stride; e += NT) order[e] = p.cost_order[e];
+  int* lc = order + p.N * p.cost_order_stride;
+  if (t < kMaxPlayers) {
+    lc[LC_KIND + t] = p.sub_kind[t];
+    lc[LC_UDIM + t] = p.udim[t];
+    lc[LC_PARAM + t] = __float_as_int(p.sub_param[t]);
+    lc[LC_SREG + t] = __float_as_int(p.state_reg[t]);
+    lc[LC_CREG + t] = __float_as_int(p.control_reg[t]);
+    lc[LC_STRUCT + t] = p.structure[t];
+    lc[LC_PII + t] = p.pairs.pii[t];
+  }
+  if (t <= kMaxPlayers) {
+    lc[LC_XOFF + t] = p.xoff[t];
+    lc[LC_UOFF + t] = p.uoff[t];
+  }
+  if (t < kMaxPairs) {
+    lc[LC_PI + t] = p.pairs.pi[t];
+    lc[LC_PJ + t] = p.pairs.pj[t];
+    lc[LC_ROFF + t] = p.pairs.roff[t];
+    lc[LC_RGOFF + t] = p.pairs.rgoff[t];
+    lc[LC_FROMCOST + t] = p.pairs.from_cost[t];
+  }
   __syncthreads();
   QuadTables<T> tb;
   tb.terms = reinterpret_cast<const DevTerm*>(terms_i);
   tb.segs = segs;
   tb.poly_off = poff;
   tb.order = order;
+  tb.lc = lc;
   return tb;
 }
 
@@ -200,6 +223,7 @@ struct QuadArgs {
   T *Q, *l, *R, *r;    // or nullptr (skip quadraticisation outputs)
   T* merit_part;       // [T][N][2] = (|r_ii|^2, |l_i|^2) or nullptr
   T* cost_part;        // [T][N] PlayerCost::Evaluate or nullptr
+  long long* phacc = nullptr;  // optional phase profile accumulators (registers of the caller)
 };
 
 __host__ __device__ inline int quad_lds_elems(int n, int m, int N, int Rsz, int rsz, int num_terms) {
@@ -208,9 +232,29 @@ __host__ __device__ inline int quad_lds_elems(int n, int m, int N, int Rsz, int 
 
 // Executed by ONE wavefront (lane t of 64) with its own LDS scratch `sm`, so several waves of a
 // workgroup can take different time steps of the same instance concurrently.
+//
+// The step comes in three pieces so that a caller looping over steps can request the NEXT step's
+// argument before it issues THIS step's stores: vmcnt retires in order, so a load queued behind 8 KB of
+// stores would not be usable until they have all drained.
+template <typename T>
+struct LinquadCarry {
+  T ms1, ms2, ctot;  // merit pieces and PlayerCost::Evaluate of this lane's player (lanes < N)
+};
+
+// Element t of the step's [x | u] row (0 for lanes beyond n + m).
+template <typename T>
+__device__ __forceinline__ T linquad_load_arg(const QuadArgs<T>& a, int k, int n, int m, int t) {
+  T argv = T(0);
+  if (t < n)
+    argv = a.xs[size_t(k) * n + t];
+  else if (t < n + m)
+    argv = a.us[size_t(k) * m + (t - n)];
+  return argv;
+}
+
 template <typename T, int CN = 0, int CM = 0, int CNP = 0>
-__device__ __forceinline__ void linquad_step(const DevProblem& p, const QuadTables<T>& tb, const QuadArgs<T>& a, int k,
-                                             T* sm, int t) {
+__device__ __forceinline__ void linquad_compute(const DevProblem& p, const QuadTables<T>& tb, const QuadArgs<T>& a,
+                                                int k, T* sm, int t, T argv, LinquadCarry<T>& carry) {
   const int n = CN > 0 ? CN : p.n, m = CM > 0 ? CM : p.m, N = CNP > 0 ? CNP : p.N;
   constexpr int NT = 64;
   const PairTable& pt = p.pairs;
@@ -222,40 +266,57 @@ __device__ __forceinline__ void linquad_step(const DevProblem& p, const QuadTabl
   T* sR = sl + N * n;
   T* sr = sR + pt.Rsz;
   const bool do_quad = a.Q != nullptr || a.merit_part != nullptr;
+  long long qc0 = a.phacc ? clock64() : 0, qc1;
+#define ILQG_QPH(i) do { if (a.phacc) { __builtin_amdgcn_sched_barrier(0); qc1 = clock64(); __builtin_amdgcn_sched_barrier(0); a.phacc[i] += qc1 - qc0; qc0 = qc1; } } while (0)
   // ---- load the argument, initialise the tiles ----
-  for (int e = t; e < n; e += NT) sx[e] = a.xs[size_t(k) * n + e];
-  for (int e = t; e < m; e += NT) sx[n + e] = a.us[size_t(k) * m + e];
-  if (a.A)
-    for (int e = t; e < n * n + n * m; e += NT) sA[e] = T(0);
+  // The (x, u) row was requested by the caller (argv); the tile image is cleared while that load is in
+  // flight (16-byte LDS writes where the image is 16-byte aligned and even-sized).
   // PlayerCost::Quadraticize vs QuadraticizeControlCosts (src/ilq_solver.cpp:483-487)
   auto is_full = [&](int i) {
-    return p.structure[i] == ILQG_SUM || (a.t_extreme ? a.t_extreme[i] == k : k == 0);
+    return tb.lc[LC_STRUCT + i] == ILQG_SUM || (a.t_extreme ? a.t_extreme[i] == k : k == 0);
   };
-  if (do_quad)
-    for (int e = t; e < N * n * n + N * n + pt.Rsz + pt.rsz; e += NT) sQ[e] = T(0);
+  {
+    const int z0 = a.A ? 0 : n * n + n * m;  // clear [A | B] only when linearising
+    const int z1 = do_quad ? n * n + n * m + N * n * n + N * n + pt.Rsz + pt.rsz : n * n + n * m;
+    T* zb = sA;
+    if (((n + m) & 1) == 0 && (z0 & 1) == 0 && (z1 & 1) == 0) {
+      typedef T pair2 __attribute__((ext_vector_type(2)));
+      const pair2 zz = {T(0), T(0)};
+      for (int e = z0 + 2 * t; e < z1; e += 2 * NT) *reinterpret_cast<pair2*>(zb + e) = zz;
+    } else {
+      for (int e = z0 + t; e < z1; e += NT) zb[e] = T(0);
+    }
+  }
+  if (t < n + m) sx[t] = argv;
   lds_sync(NT <= 64);
   if (t < n) {
     if (a.A) sA[t * (n + 1)] = T(1);  // LinearDynamicsApproximation starts from (I, 0)
     if (do_quad)
-      for (int i = 0; i < N; i++) sQ[i * n * n + t * (n + 1)] = T(p.state_reg[i]);  // sigma_x I (player_cost.cpp:196)
+      for (int i = 0; i < N; i++)
+        sQ[i * n * n + t * (n + 1)] = T(__int_as_float(tb.lc[LC_SREG + i]));  // sigma_x I (player_cost.cpp:196)
   }
   if (do_quad && t < pt.npairs) {
     // sigma_u I on every control block the reference would have created (player_cost.cpp:70-74)
-    const int i = pt.pi[t];
-    if (is_full(i) || pt.from_cost[t]) {
-      const int mj = p.udim[pt.pj[t]];
-      for (int d = 0; d < mj; d++) sR[pt.roff[t] + d + mj * d] = T(p.control_reg[i]);
+    const int i = tb.lc[LC_PI + t];
+    if (is_full(i) || tb.lc[LC_FROMCOST + t]) {
+      const int mj = tb.lc[LC_UDIM + tb.lc[LC_PJ + t]];
+      const int ro = tb.lc[LC_ROFF + t];
+      const T creg = T(__int_as_float(tb.lc[LC_CREG + i]));
+      for (int d = 0; d < mj; d++) sR[ro + d + mj * d] = creg;
     }
   }
   lds_sync(NT <= 64);
+  ILQG_QPH(0);
   if (a.A && t < N) {
-    const int xo = p.xoff[t], uo = p.uoff[t];
-    sub_linearize<T>(p.sub_kind[t], T(p.sub_param[t]), p.dt, sx + xo, sA + xo + n * xo, sB + xo + n * uo, n);
+    const int xo = tb.lc[LC_XOFF + t], uo = tb.lc[LC_UOFF + t];
+    sub_linearize<T>(tb.lc[LC_KIND + t], T(__int_as_float(tb.lc[LC_PARAM + t])), p.dt, sx + xo, sA + xo + n * xo,
+                     sB + xo + n * uo, n);
   }
   // ---- one lane per cost term: value + derivative pattern (the expensive part, in parallel) ----
   const double tt = double(k) * p.dt;
   const int tidx = int(static_cast<size_t>((tt - a.t_init) / p.dt));  // relative_time_tracker.h:69-72
   T* svals = sr + pt.rsz;  // [num_terms] term values for TotalCosts
+  ILQG_QPH(1);
   for (int base = 0; base < p.num_terms; base += NT) {
     const int ti = base + t;
     DevTerm c;
@@ -277,6 +338,7 @@ __device__ __forceinline__ void linquad_step(const DevProblem& p, const QuadTabl
       }
       if (a.cost_part) svals[ti] = o.value;
     }
+    ILQG_QPH(2);
     // ---- scatter in rounds: within a round no two terms touch the same entry ----
     if (do_quad) {
       for (int r = 0; r < p.num_rounds; r++) {
@@ -287,12 +349,17 @@ __device__ __forceinline__ void linquad_step(const DevProblem& p, const QuadTabl
     }
   }
   lds_sync(NT <= 64);
+  ILQG_QPH(3);
+  // Values first, stores last: a register that feeds a global store cannot be rewritten until the store
+  // has drained (the compiler waits vmcnt(0) for it), so every store of the step is issued in one
+  // burst at the very end, from registers nothing else needs.
+  T ms1 = T(0), ms2 = T(0), ctot = T(0);
   if (t < N) {
     const int i = t;
     if (a.merit_part) {  // pieces of ILQSolver::MeritFunction (:419-430)
-      const int q = pt.pii[i];
+      const int rg = tb.lc[LC_RGOFF + tb.lc[LC_PII + i]], ud = tb.lc[LC_UDIM + i];
       T s1 = T(0), s2 = T(0);
-      for (int d = 0; d < p.udim[i]; d++) s1 += sr[pt.rgoff[q] + d] * sr[pt.rgoff[q] + d];
+      for (int d = 0; d < ud; d++) s1 += sr[rg + d] * sr[rg + d];
       if constexpr (CN > 0) {
         T lv[CN];  // loads first, then the sequential sum (same order as the reference)
 #pragma unroll
@@ -302,28 +369,134 @@ __device__ __forceinline__ void linquad_step(const DevProblem& p, const QuadTabl
       } else {
         for (int d = 0; d < n; d++) s2 += sl[i * n + d] * sl[i * n + d];
       }
-      a.merit_part[(size_t(k) * N + i) * 2 + 0] = s1;
-      a.merit_part[(size_t(k) * N + i) * 2 + 1] = s2;
+      ms1 = s1;
+      ms2 = s2;
     }
     if (a.cost_part) {  // PlayerCost::Evaluate, src/player_cost.cpp:128-144 (state costs, then control costs)
+      // Same left-to-right sum as the reference; indices and values are fetched eight at a time so the
+      // LDS round trips overlap instead of chaining (index -> value -> add).
       T total = T(0);
       const int* ord = tb.order + i * p.cost_order_stride;
-      for (int q = 0; q < ord[0]; q++) total += svals[ord[1 + q]];
-      a.cost_part[size_t(k) * N + i] = total;
+      const int cnt = ord[0];
+      for (int q0 = 0; q0 < cnt; q0 += 8) {
+        int idx[8];
+        T val[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) idx[u] = ord[1 + ((q0 + u < cnt) ? q0 + u : cnt - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; u++) val[u] = svals[idx[u]];
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+          if (q0 + u < cnt) total += val[u];
+      }
+      ctot = total;
     }
   }
-  // ---- coalesced write-out ----
-  if (a.A) {
-    for (int e = t; e < n * n; e += NT) a.A[size_t(k) * n * n + e] = sA[e];
-    for (int e = t; e < n * m; e += NT) a.Bm[size_t(k) * n * m + e] = sB[e];
+  carry.ms1 = ms1;
+  carry.ms2 = ms2;
+  carry.ctot = ctot;
+  ILQG_QPH(4);
+#undef ILQG_QPH
+}
+
+template <typename T, int CN = 0, int CM = 0, int CNP = 0>
+__device__ __forceinline__ void linquad_store(const DevProblem& p, const QuadArgs<T>& a, int k, T* sm, int t,
+                                              const LinquadCarry<T>& carry) {
+  const int n = CN > 0 ? CN : p.n, m = CM > 0 ? CM : p.m, N = CNP > 0 ? CNP : p.N;
+  constexpr int NT = 64;
+  const PairTable& pt = p.pairs;
+  T* sx = sm;
+  T* sA = sx + n + m;
+  T* sB = sA + n * n;
+  T* sQ = sB + n * m;
+  T* sl = sQ + N * n * n;
+  T* sR = sl + N * n;
+  T* sr = sR + pt.Rsz;
+  const T ms1 = carry.ms1, ms2 = carry.ms2, ctot = carry.ctot;
+  long long qc0 = a.phacc ? clock64() : 0, qc1;
+#define ILQG_QPH(i) do { if (a.phacc) { __builtin_amdgcn_sched_barrier(0); qc1 = clock64(); __builtin_amdgcn_sched_barrier(0); a.phacc[i] += qc1 - qc0; qc0 = qc1; } } while (0)
+  // ---- coalesced write-out: the whole image is read into registers, then stored in one burst ----
+  typedef T pair2 __attribute__((ext_vector_type(2)));
+  bool burst = false;
+  if constexpr (CN > 0 && CM > 0 && CNP > 0) {
+    constexpr int cA = CN * CN, cB = CN * CM, cQ = CNP * CN * CN, cl = CNP * CN;
+    constexpr bool even = (cA % 2 == 0) && (cB % 2 == 0) && (cQ % 2 == 0) && (cl % 2 == 0) && ((CN + CM) % 2 == 0);
+    constexpr int UA = (cA / 2 + NT - 1) / NT, UB = (cB / 2 + NT - 1) / NT, UQ = (cQ / 2 + NT - 1) / NT,
+                  UL = (cl / 2 + NT - 1) / NT;
+    if (even && UA + UB + UQ + UL <= 12 && (pt.Rsz & 1) == 0 && (pt.rsz & 1) == 0 && pt.Rsz <= 2 * NT &&
+        pt.rsz <= 2 * NT && a.A != nullptr && a.Q != nullptr) {
+      burst = true;
+      pair2 rA[UA], rB[UB], rQ[UQ], rl[UL], rR = {T(0), T(0)}, rr = {T(0), T(0)};
+#pragma unroll
+      for (int u = 0; u < UA; u++)
+        if (2 * (t + NT * u) < cA) rA[u] = *reinterpret_cast<const pair2*>(sA + 2 * (t + NT * u));
+#pragma unroll
+      for (int u = 0; u < UB; u++)
+        if (2 * (t + NT * u) < cB) rB[u] = *reinterpret_cast<const pair2*>(sB + 2 * (t + NT * u));
+#pragma unroll
+      for (int u = 0; u < UQ; u++)
+        if (2 * (t + NT * u) < cQ) rQ[u] = *reinterpret_cast<const pair2*>(sQ + 2 * (t + NT * u));
+#pragma unroll
+      for (int u = 0; u < UL; u++)
+        if (2 * (t + NT * u) < cl) rl[u] = *reinterpret_cast<const pair2*>(sl + 2 * (t + NT * u));
+      if (2 * t < pt.Rsz) rR = *reinterpret_cast<const pair2*>(sR + 2 * t);
+      if (2 * t < pt.rsz) rr = *reinterpret_cast<const pair2*>(sr + 2 * t);
+      T* gA = a.A + size_t(k) * cA;
+      T* gB = a.Bm + size_t(k) * cB;
+      T* gQ = a.Q + size_t(k) * cQ;
+      T* gl = a.l + size_t(k) * cl;
+      T* gR = a.R + size_t(k) * pt.Rsz;
+      T* gr = a.r + size_t(k) * pt.rsz;
+#pragma unroll
+      for (int u = 0; u < UA; u++)
+        if (2 * (t + NT * u) < cA) *reinterpret_cast<pair2*>(gA + 2 * (t + NT * u)) = rA[u];
+#pragma unroll
+      for (int u = 0; u < UB; u++)
+        if (2 * (t + NT * u) < cB) *reinterpret_cast<pair2*>(gB + 2 * (t + NT * u)) = rB[u];
+#pragma unroll
+      for (int u = 0; u < UQ; u++)
+        if (2 * (t + NT * u) < cQ) *reinterpret_cast<pair2*>(gQ + 2 * (t + NT * u)) = rQ[u];
+#pragma unroll
+      for (int u = 0; u < UL; u++)
+        if (2 * (t + NT * u) < cl) *reinterpret_cast<pair2*>(gl + 2 * (t + NT * u)) = rl[u];
+      if (2 * t < pt.Rsz) *reinterpret_cast<pair2*>(gR + 2 * t) = rR;
+      if (2 * t < pt.rsz) *reinterpret_cast<pair2*>(gr + 2 * t) = rr;
+    }
   }
-  if (a.Q) {
-    for (int e = t; e < N * n * n; e += NT) a.Q[size_t(k) * N * n * n + e] = sQ[e];
-    for (int e = t; e < N * n; e += NT) a.l[size_t(k) * N * n + e] = sl[e];
-    for (int e = t; e < pt.Rsz; e += NT) a.R[size_t(k) * pt.Rsz + e] = sR[e];
-    for (int e = t; e < pt.rsz; e += NT) a.r[size_t(k) * pt.rsz + e] = sr[e];
+  if (!burst) {
+    auto copy_out = [&](T* dst, const T* src, int count) {
+      for (int e = t; e < count; e += NT) dst[e] = src[e];
+    };
+    if (a.A) {
+      copy_out(a.A + size_t(k) * n * n, sA, n * n);
+      copy_out(a.Bm + size_t(k) * n * m, sB, n * m);
+    }
+    if (a.Q) {
+      copy_out(a.Q + size_t(k) * N * n * n, sQ, N * n * n);
+      copy_out(a.l + size_t(k) * N * n, sl, N * n);
+      copy_out(a.R + size_t(k) * pt.Rsz, sR, pt.Rsz);
+      copy_out(a.r + size_t(k) * pt.rsz, sr, pt.rsz);
+    }
+  }
+  if (t < N) {
+    if (a.merit_part) {
+      a.merit_part[(size_t(k) * N + t) * 2 + 0] = ms1;
+      a.merit_part[(size_t(k) * N + t) * 2 + 1] = ms2;
+    }
+    if (a.cost_part) a.cost_part[size_t(k) * N + t] = ctot;
   }
   lds_sync(NT <= 64);
+  ILQG_QPH(5);
+#undef ILQG_QPH
+}
+
+template <typename T, int CN = 0, int CM = 0, int CNP = 0>
+__device__ __forceinline__ void linquad_step(const DevProblem& p, const QuadTables<T>& tb, const QuadArgs<T>& a, int k,
+                                             T* sm, int t) {
+  const int n = CN > 0 ? CN : p.n, m = CM > 0 ? CM : p.m;
+  LinquadCarry<T> carry;
+  linquad_compute<T, CN, CM, CNP>(p, tb, a, k, sm, t, linquad_load_arg<T>(a, k, n, m, t), carry);
+  linquad_store<T, CN, CM, CNP>(p, a, k, sm, t, carry);
 }
 
 // ILQSolver::MeritFunction's reduction (:408-434): 0.5 * sum_k sum_i (|r_ii|^2 + [k>0]|l_i|^2),

@@ -39,7 +39,7 @@ for K in (1, 2, 4, 8):
         for k in ("xs", "us", "P", "alpha"): bufs[k].zero_()
         prob.solve(x0d, bufs, fixed_iters=K)
     print("fused solve K=%d  %.3f ms" % (K, timeit(f, reps=2)))
-prof = torch.zeros((B, 64), dtype=torch.int64, device="cuda")
+prof = torch.zeros((B, 96), dtype=torch.int64, device="cuda")
 import ctypes
 hip.lib().ilqg_debug_set_profile_buffer(ctypes.c_void_p(prof.data_ptr()))
 for k in ("xs", "us", "P", "alpha"): bufs[k].zero_()
@@ -53,3 +53,9 @@ for wv in range(3):
     q = pm[8 + 16 * wv: 8 + 16 * wv + 10] / 396
     print("  wave %d (cycles/step): issue+ql %.0f | G,SY %.0f | bar1 %.0f | solve %.0f | bar2 %.0f | F,beta %.0f | players %.0f | zeta %.0f | dmawait %.0f | bar3 %.0f   sum %.0f" %
           (wv, q[0], q[1], q[7], q[2], q[8], q[3], q[4], q[5], q[9], q[6], q.sum()))
+
+for wv in range(2):
+    q = pm[64 + 8 * wv: 72 + 8 * wv]
+    steps = max(q[7], 1.0)
+    print("  trial wave %d: %.0f linquad steps over 5 launches; cycles/step: load+init %.0f | linearize %.0f | terms %.0f | rounds %.0f | merit+cost %.0f | writeout %.0f | claim/wait %.0f" %
+          (wv, q[7], q[0] / steps, q[1] / steps, q[2] / steps, q[3] / steps, q[4] / steps, q[5] / steps, q[6] / steps))
