@@ -236,11 +236,26 @@ __device__ __forceinline__ void qr_solve_columns(T (&col)[M], int lane, T (&x)[M
 // well-conditioned system, so they agree to a few ulps times cond(S) — far inside the 1e-6 bar —
 // while the elimination has no square roots and no dependent dot-product chains: each step is one
 // reciprocal, M-k-1 independent broadcasts and M-k-1 independent FMAs per lane.
+// 1 / x from the hardware reciprocal refined by Newton steps (to within an ulp of the correctly rounded
+// quotient): a fraction of the latency of the IEEE division sequence, and the pivots' reciprocals
+// sit on the solve's critical path.
+__device__ __forceinline__ double fast_recip(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  return r;
+}
+__device__ __forceinline__ float fast_recip(float x) {
+  float r = __builtin_amdgcn_rcpf(x);
+  r = __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
+  return r;
+}
+
 template <typename T, int M>
 __device__ __forceinline__ void lu_solve_columns(T (&col)[M], int lane, T (&x)[M]) {
 #pragma unroll
   for (int k = 0; k + 1 < M; k++) {
-    const T rinv = T(1) / col[k];  // the pivot's reciprocal where it matters: on lane k
+    const T rinv = fast_recip(col[k]);  // the pivot's reciprocal where it matters: on lane k
     T f[M];
 #pragma unroll
     for (int i = k + 1; i < M; i++) f[i] = bcast(col[i] * rinv, k);  // multipliers S[i][k] / S[k][k]
@@ -250,7 +265,7 @@ __device__ __forceinline__ void lu_solve_columns(T (&col)[M], int lane, T (&x)[M
   T diag = T(1);
 #pragma unroll
   for (int i = 0; i < M; i++) diag = (lane == i) ? col[i] : diag;
-  const T dinv = T(1) / diag;
+  const T dinv = fast_recip(diag);
 #pragma unroll
   for (int i = M - 1; i >= 0; i--) {
     T s = col[i];
@@ -264,54 +279,74 @@ __device__ __forceinline__ void lu_solve_columns(T (&col)[M], int lane, T (&x)[M
 // ILQSolver::ExpectedDecrease (src/ilq_solver.cpp:364-398) from the per-step scratch rows.
 // A_{k+1} and scratch row k+1 are DMA'd into the idle image while step k is computed.
 // NT = number of threads that execute the pass (the caller has already made the scratch rows
-// visible: __syncthreads after the sweep).
-template <typename T, int NX, int NP, int MU, int NT = LQCfg<T, NX, NP, MU>::NT>
+// visible: __syncthreads after the sweep).  LDSE = LDS elements available at `sm`.
+// One step is a 14-FMA chain (~300 cycles), far shorter than the global-load latency of its operands, so
+// A_k and scratch row k are staged G steps at a time into two LDS groups: the DMA of group g+1 runs
+// while group g is computed and only one wait per group is exposed.
+template <typename T, int NX, int NP, int MU, int NT = LQCfg<T, NX, NP, MU>::NT, int LDSE = LQCfg<T, NX, NP, MU>::LDS_ELEMS>
 __device__ __forceinline__ void lq_forward_pass_body(const LQArgs<T>& a, T* sm, int t) {
   using C = LQCfg<T, NX, NP, MU>;
   constexpr int SCR = C::SCR, S = int(sizeof(T));
-  constexpr bool wA = (NX * NX * S) % 16 == 0 && (C::oA * S) % 16 == 0 && (C::IMG * S) % 16 == 0;
+  constexpr int FSLOT = (NX * NX + SCR + 3) & ~3;
+  constexpr int GFIT = (LDSE - NX - 4) / (2 * FSLOT);
+  constexpr int G = GFIT < 1 ? 1 : (GFIT > 8 ? 8 : GFIT);
+  static_assert(2 * G * FSLOT + NX <= LDSE, "forward-pass staging does not fit the LDS of the sweep");
+  constexpr bool wA = (NX * NX * S) % 16 == 0 && (FSLOT * S) % 16 == 0;
   const int Tn = a.T_steps;
-  T* sX = sm + C::oX;
-  auto stage = [&](int k, int which) {
-    T* img = sm + which * C::IMG;
-    dma_g2l<NT, wA>(a.A + size_t(k) * NX * NX, img + C::oA, NX * NX * S, t);
-    dma_g2l<NT, false>(a.scratch + size_t(k) * SCR, img + C::oQ, SCR * S, t);
+  T* sX = sm + 2 * G * FSLOT;
+  auto stage_group = [&](int grp, int which) {
+#pragma unroll
+    for (int s = 0; s < G; s++) {
+      const int k = grp * G + s;
+      if (k < Tn) {
+        T* slot = sm + (which * G + s) * FSLOT;
+        dma_g2l<NT, wA>(a.A + size_t(k) * NX * NX, slot, NX * NX * S, t);
+        dma_g2l<NT, false>(a.scratch + size_t(k) * SCR, slot + NX * NX, SCR * S, t);
+      }
+    }
   };
   int cur = 0;
-  stage(0, 0);
+  stage_group(0, 0);
   if (t < NX) sX[t] = a.x0 ? a.x0[t] : T(0);
   T ed = T(0);
   dma_wait();
   lds_sync(NT <= 64);
+  const int ngroups = (Tn + G - 1) / G;
 #pragma unroll 1
-  for (int k = 0; k < Tn; k++) {
-    if (k + 1 < Tn) stage(k + 1, 1 - cur);
-    const T* fA = sm + cur * C::IMG + C::oA;
-    const T* fS = sm + cur * C::IMG + C::oQ;  // [ql (N*n) | ctrl (N) | beta (n)]
-    if (a.dx && t < NX) a.dx[size_t(k) * NX + t] = sX[t];
-    if (a.ed_out && t < 64) {
-      T st = T(0), ct = T(0);
-      if (t < NP) {
-        ct = fS[NP * NX + t];
-        if (k > 0) {
+  for (int grp = 0; grp < ngroups; grp++) {
+    if (grp + 1 < ngroups) stage_group(grp + 1, 1 - cur);
+#pragma unroll 1
+    for (int s = 0; s < G; s++) {
+      const int k = grp * G + s;
+      if (k >= Tn) break;
+      const T* fA = sm + (cur * G + s) * FSLOT;
+      const T* fS = fA + NX * NX;  // [ql (N*n) | ctrl (N) | beta (n)]
+      if (a.dx && t < NX) a.dx[size_t(k) * NX + t] = sX[t];
+      if (a.ed_out && t < 64) {
+        T st = T(0), ct = T(0);
+        if (t < NP) {
+          ct = fS[NP * NX + t];
+          if (k > 0) {
 #pragma unroll
-          for (int c = 0; c < NX; c++) st += sX[c] * fS[t * NX + c];
+            for (int c = 0; c < NX; c++) st += sX[c] * fS[t * NX + c];
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+          ed -= shfl(ct, i);
+          if (k > 0) ed -= shfl(st, i);
         }
       }
+      T xn = T(0);
+      if (t < NX) {
 #pragma unroll
-      for (int i = 0; i < NP; i++) {
-        ed -= shfl(ct, i);
-        if (k > 0) ed -= shfl(st, i);
+        for (int c = 0; c < NX; c++) xn += fA[t + NX * c] * sX[c];
+        xn += fS[NP * (NX + 1) + t];  // beta_k = -B alpha_k
       }
+      lds_sync(NT <= 64);
+      if (t < NX) sX[t] = xn;
+      lds_sync(NT <= 64);
     }
-    T xn = T(0);
-    if (t < NX) {
-#pragma unroll
-      for (int c = 0; c < NX; c++) xn += fA[t + NX * c] * sX[c];
-      xn += fS[NP * (NX + 1) + t];  // beta_k = -B alpha_k
-    }
-    lds_sync(NT <= 64);
-    if (t < NX) sX[t] = xn;
     dma_wait();
     lds_sync(NT <= 64);
     cur = 1 - cur;
@@ -1340,7 +1375,7 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
 
   if (want_fwd) {
     __syncthreads();  // scratch rows written by all waves
-    if (w == 0) lq_forward_pass_body<T, NX, NP, MU, 64>(a, sm, lane);
+    if (w == 0) lq_forward_pass_body<T, NX, NP, MU, 64, W::LDS_ELEMS>(a, sm, lane);
   }
 }
 

@@ -215,11 +215,15 @@ __device__ __forceinline__ void sub_integrate_lanes(int kind, T L, double interv
 //  single_player_car_6d.h:116-138; mixed float*double products kept).
 // A: pointer to the (o,o) corner of a column-major matrix with leading dim ld;
 // B: pointer to the (o,uo) corner, same ld.
+// The trigonometry comes in as arguments: (sth, cth) = sincos(heading), (sphi, cphi) = sincos(steering
+// angle) for the car models — callers evaluate them for all subsystems at once, one sincos latency per
+// angle instead of a cos, a sin, a cos and a tan in sequence; tan(phi) is formed as sphi / cphi.
 template <typename T>
-__device__ __forceinline__ void sub_linearize(int kind, T L, double dt, const T* x, T* A, T* B, int ld) {
+__device__ __forceinline__ void sub_linearize_trig(int kind, T L, double dt, const T* x, T sth, T cth, T sphi, T cphi,
+                                                   T* A, T* B, int ld) {
   const int v = (kind == ILQG_DYN_UNICYCLE_4D) ? 3 : 4;
-  const T ct = T(double(t_cos(x[2])) * dt);
-  const T st = T(double(t_sin(x[2])) * dt);
+  const T ct = T(double(cth) * dt);
+  const T st = T(double(sth) * dt);
   A[0 + ld * 2] += -x[v] * st;
   A[0 + ld * v] += ct;
   A[1 + ld * 2] += x[v] * ct;
@@ -228,8 +232,7 @@ __device__ __forceinline__ void sub_linearize(int kind, T L, double dt, const T*
     B[2 + ld * 0] = T(dt);
     B[3 + ld * 1] = T(dt);
   } else {
-    const T cphi = t_cos(x[3]);
-    const T tphi = t_tan(x[3]);
+    const T tphi = sphi / cphi;
     A[2 + ld * 3] += T(double(x[4]) * dt / double(L * cphi * cphi));
     A[2 + ld * 4] += T(double(tphi) * dt / double(L));
     if (kind == ILQG_DYN_CAR_5D) {
@@ -241,6 +244,14 @@ __device__ __forceinline__ void sub_linearize(int kind, T L, double dt, const T*
       B[5 + ld * 1] = T(dt);
     }
   }
+}
+
+template <typename T>
+__device__ __forceinline__ void sub_linearize(int kind, T L, double dt, const T* x, T* A, T* B, int ld) {
+  T sth, cth, sphi = T(0), cphi = T(1);
+  t_sincos(x[2], &sth, &cth);
+  if (kind != ILQG_DYN_UNICYCLE_4D) t_sincos(x[3], &sphi, &cphi);
+  sub_linearize_trig<T>(kind, L, dt, x, sth, cth, sphi, cphi, A, B, ld);
 }
 
 // ---------------------------------------------------------------------------

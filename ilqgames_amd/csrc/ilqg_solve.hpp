@@ -283,6 +283,7 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const Q
   const size_t qe = (quad_lds_elems(n, m, N, p.pairs.Rsz, p.pairs.rsz, p.num_terms) + 3) & ~size_t(3);
   T* const sm_roll = sm;
   T* const sm_quad = sm + re + size_t(wave) * qe;
+  T* const sm_quad0 = sm + re;  // wave 0's linquad scratch doubles as reduction scratch between passes
   int* const flags = reinterpret_cast<int*>(sm + re + size_t(W) * qe);  // [0] rows ready, [1] next row to claim
 
   SolveState<T> s;
@@ -394,7 +395,7 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const Q
 
     // ---- reductions and the line-search decision (wave-uniform, identical on every wave) ----
     if (qmode == Q_COSTS) {
-      costs_reduce<T>(p, w + L.cpart, costs, t_extreme);
+      costs_reduce<T>(p, w + L.cpart, costs, t_extreme, sm_quad0, int(qe));
       s.qmode = Q_INIT;
       s.stage = ST_QUAD;
     } else if (qmode == Q_INIT) {
@@ -403,7 +404,7 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const Q
     } else {
       bool accepted = true;
       if (qmode == Q_TRIAL) {
-        const T merit = merit_reduce<T>(p, w + L.mpart, sm_roll);
+        const T merit = merit_reduce<T>(p, w + L.mpart, sm_quad0, int(qe));
         const T scaled = T(prm.expected_decrease_fraction) * s.step * s.expected_decrease;
         accepted = (s.last_merit - merit >= scaled);  // CheckArmijoCondition :350-362
         if (accepted) {
@@ -420,7 +421,7 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const Q
         s.sacc = 1 - s.sacc;
         s.acc_scale = s.step;
         s.accepted_iters++;
-        costs_reduce<T>(p, w + L.cpart, costs, t_extreme);  // TotalCosts of the accepted iterate (:158)
+        costs_reduce<T>(p, w + L.cpart, costs, t_extreme, sm_quad0, int(qe));  // TotalCosts of the accepted iterate (:158)
         s.stage = (s.num_iterations < max_iters && (sa.fixed_iters > 0 || !s.has_converged)) ? ST_LQ : ST_INNER_DONE;
       } else {
         s.bt++;

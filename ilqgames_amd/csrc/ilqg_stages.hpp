@@ -307,10 +307,19 @@ __device__ __forceinline__ void linquad_compute(const DevProblem& p, const QuadT
   }
   lds_sync(NT <= 64);
   ILQG_QPH(0);
-  if (a.A && t < N) {
-    const int xo = tb.lc[LC_XOFF + t], uo = tb.lc[LC_UOFF + t];
-    sub_linearize<T>(tb.lc[LC_KIND + t], T(__int_as_float(tb.lc[LC_PARAM + t])), p.dt, sx + xo, sA + xo + n * xo,
-                     sB + xo + n * uo, n);
+  if (a.A) {
+    // lanes [0, N): heading of subsystem t; lanes [N, 2N): steering angle of subsystem t - N.  One
+    // sincos for the whole wave, then the steering pair hops N lanes down.
+    const int sub = t < N ? t : (t < 2 * N ? t - N : 0);
+    const int xo = tb.lc[LC_XOFF + sub];
+    T sn, cs;
+    t_sincos(sx[xo + (t < N ? 2 : 3)], &sn, &cs);
+    const T sphi = shfl(sn, (t + N) & 63), cphi = shfl(cs, (t + N) & 63);
+    if (t < N) {
+      const int uo = tb.lc[LC_UOFF + t];
+      sub_linearize_trig<T>(tb.lc[LC_KIND + t], T(__int_as_float(tb.lc[LC_PARAM + t])), p.dt, sx + xo, sn, cs, sphi,
+                            cphi, sA + xo + n * xo, sB + xo + n * uo, n);
+    }
   }
   // ---- one lane per cost term: value + derivative pattern (the expensive part, in parallel) ----
   const double tt = double(k) * p.dt;
@@ -499,11 +508,45 @@ __device__ __forceinline__ void linquad_step(const DevProblem& p, const QuadTabl
   linquad_store<T, CN, CM, CNP>(p, a, k, sm, t, carry);
 }
 
+// Sequential left-to-right sum of `count` LDS values, eight loads in flight at a time (the adds keep
+// the reference's order; only the LDS latency overlaps).
+template <typename T, typename F>
+__device__ __forceinline__ void lds_ordered_visit(const T* v, int count, F&& visit) {
+  int e = 0;
+  for (; e + 8 <= count; e += 8) {
+    T x[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) x[u] = v[e + u];
+#pragma unroll
+    for (int u = 0; u < 8; u++) visit(e + u, x[u]);
+  }
+  for (; e < count; e++) visit(e, v[e]);
+}
+
 // ILQSolver::MeritFunction's reduction (:408-434): 0.5 * sum_k sum_i (|r_ii|^2 + [k>0]|l_i|^2),
 // accumulated in the reference's order by one lane.  Returns the value on every thread.
+// `sm` is LDS scratch of `sm_elems` elements: when the partials fit they are pulled in by the whole
+// workgroup first (one global round trip instead of one per term of the sum).
 template <typename T>
-__device__ __forceinline__ T merit_reduce(const DevProblem& p, const T* merit_part, T* sm) {
+__device__ __forceinline__ T merit_reduce(const DevProblem& p, const T* merit_part, T* sm, int sm_elems = 0) {
   __syncthreads();  // partials were written to global memory by other lanes
+  const int count = p.T * p.N * 2;
+  if (count + 1 <= sm_elems) {
+    for (int e = threadIdx.x; e < count; e += blockDim.x) sm[e] = merit_part[e];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      T merit = T(0);
+      const int skip = p.N * 2;  // the |l_i|^2 terms of k = 0 do not enter (:421)
+      lds_ordered_visit<T>(sm, count, [&](int e, T x) {
+        if ((e & 1) == 0 || e >= skip) merit += x;
+      });
+      sm[count] = T(0.5) * merit;
+    }
+    __syncthreads();
+    const T v = sm[count];
+    __syncthreads();
+    return v;
+  }
   if (threadIdx.x == 0) {
     T merit = T(0);
     for (int k = 0; k < p.T; k++)
@@ -522,15 +565,21 @@ __device__ __forceinline__ T merit_reduce(const DevProblem& p, const T* merit_pa
 // ILQSolver::TotalCosts reduction (:220-257): sum / max / min over time per player, and
 // the time of the extreme cost (first strict improvement wins, as the reference's `>` / `<`).
 template <typename T>
-__device__ __forceinline__ void costs_reduce(const DevProblem& p, const T* cost_part, T* costs_out, int* t_extreme) {
+__device__ __forceinline__ void costs_reduce(const DevProblem& p, const T* cost_part, T* costs_out, int* t_extreme,
+                                             T* sm = nullptr, int sm_elems = 0) {
   __syncthreads();  // partials were written to global memory by other lanes
   const int i = threadIdx.x;
+  const int count = p.T * p.N;
+  const bool staged = sm != nullptr && count <= sm_elems;
+  if (staged) {
+    for (int e = threadIdx.x; e < count; e += blockDim.x) sm[e] = cost_part[e];
+    __syncthreads();
+  }
   if (i < p.N) {
     const int st = p.structure[i];
     T c = st == ILQG_SUM ? T(0) : (st == ILQG_MAX ? -dinf<T>() : dinf<T>());
     int te = t_extreme ? t_extreme[i] : 0;
-    for (int k = 0; k < p.T; k++) {
-      const T v = cost_part[size_t(k) * p.N + i];
+    auto visit = [&](int k, T v) {
       if (st == ILQG_SUM)
         c += v;
       else if (st == ILQG_MAX && v > c) {
@@ -540,6 +589,19 @@ __device__ __forceinline__ void costs_reduce(const DevProblem& p, const T* cost_
         c = v;
         te = k;
       }
+    };
+    if (staged) {
+      int k = 0;
+      for (; k + 8 <= p.T; k += 8) {
+        T x[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) x[u] = sm[(k + u) * p.N + i];
+#pragma unroll
+        for (int u = 0; u < 8; u++) visit(k + u, x[u]);
+      }
+      for (; k < p.T; k++) visit(k, sm[k * p.N + i]);
+    } else {
+      for (int k = 0; k < p.T; k++) visit(k, cost_part[size_t(k) * p.N + i]);
     }
     costs_out[i] = c;
     if (t_extreme) t_extreme[i] = te;
