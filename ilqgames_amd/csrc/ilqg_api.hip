@@ -183,11 +183,27 @@ __global__ void __launch_bounds__(64 * W, W) ilq_trial_kernel(DevProblem p, Solv
   if (!sa.first) {  // instances that are done (or waiting for the LQ kernel) leave without touching LDS
     const WsLayout L(p.n, p.m, p.N, p.T, p.pairs.Rsz, p.pairs.rsz, sa.ol_row, p.num_constraints, sa.al_mode);
     const int stage = reinterpret_cast<const SolveState<T>*>(sa.ws + size_t(b) * sa.ws_stride + L.state)->stage;
-    if (stage != ST_ROLLOUT && stage != ST_QUAD && stage != ST_INNER_DONE) return;
+    if (stage != ST_ROLLOUT && stage != ST_QUAD) return;
   }
   const QuadTables<T> tb = quad_tables_load<T>(p, smem_raw);
   T* sm = reinterpret_cast<T*>(smem_raw + quad_tables_bytes(p, sizeof(T)));
   trial_part_instance<T, NX, NP, MU, W>(p, tb, sa, b, sm);
+}
+
+// Exit kernel: return path of ILQSolver::Solve / AugmentedLagrangianSolver bookkeeping for the instances
+// whose inner solve has ended (converged, out of iterations, or line search exhausted).
+template <typename T, int NX, int NP, int MU>
+__global__ void __launch_bounds__(64) ilq_exit_kernel(DevProblem p, SolveArgs<T> sa) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int b = blockIdx.x;
+  {
+    const WsLayout L(p.n, p.m, p.N, p.T, p.pairs.Rsz, p.pairs.rsz, sa.ol_row, p.num_constraints, sa.al_mode);
+    const int stage = reinterpret_cast<const SolveState<T>*>(sa.ws + size_t(b) * sa.ws_stride + L.state)->stage;
+    if (stage != ST_INNER_DONE) return;
+  }
+  const QuadTables<T> tb = quad_tables_load<T>(p, smem_raw);
+  T* sm = reinterpret_cast<T*>(smem_raw + quad_tables_bytes(p, sizeof(T)));
+  exit_part_instance<T, NX, NP, MU>(p, tb, sa, b, sm);
 }
 
 // LQ kernel: the Riccati sweep at the accepted operating point of every instance that asked for one.
@@ -403,8 +419,8 @@ static ilqg_status launch_solve(ilqg_problem* p, int32_t batch, const void* x0, 
   sa.prm = p->desc.params;
   sa.prof = g_prof;
   if (!p->d_unfinished) {
-    HIP_TRY(hipMalloc(&p->d_unfinished, sizeof(int)));
-    HIP_TRY(hipHostMalloc(&p->h_unfinished, sizeof(int)));
+    HIP_TRY(hipMalloc(&p->d_unfinished, 4 * sizeof(int)));
+    HIP_TRY(hipHostMalloc(&p->h_unfinished, 4 * sizeof(int)));
   }
   sa.unfinished = p->d_unfinished;
   constexpr int W = TrialWaves<T>::W;
@@ -420,29 +436,46 @@ static ilqg_status launch_solve(ilqg_problem* p, int32_t batch, const void* x0, 
   raise_lds_limit((const void*)k_trial, lds_trial);
   raise_lds_limit((const void*)k_lq, lds_lq);
 
-  // trial, then (LQ, trial) rounds.  The trial kernel counts the instances it leaves waiting for a
-  // sweep; with fixed_iters = K the sequence is known (K sweeps, each followed by a trial pass),
-  // otherwise the host reads the count back each round — which makes a free-running solve
-  // synchronous with respect to `stream`.
+  // One round = trial kernel, then (for the instances that asked) the exit kernel and the LQ kernel.
+  // The trial kernel counts what its instances wait for; with fixed_iters = K (no AL) the sequence is
+  // known — trial, K x (LQ, trial), exit — otherwise the host reads the counts back each round, which
+  // makes a free-running solve synchronous with respect to `stream`.
+  auto k_exit = ilq_exit_kernel<T, NX, NP, MU>;
+  const size_t lds_exit = quad_tables_bytes(d, sizeof(T)) + 64 * sizeof(T);
   const bool counted = !(fixed_iters > 0 && !al_mode);
   const long long cap = al_mode ? (long long)(sa.prm.max_solver_iters + 1) * (sa.prm.unconstrained_solver_max_iters + 2)
                                 : (long long)sa.prm.max_solver_iters + 2;
   sa.first = 1;
   for (long long round = 0;; round++) {
-    if (counted) HIP_TRY(hipMemsetAsync(p->d_unfinished, 0, sizeof(int), stream));
+    if (counted) HIP_TRY(hipMemsetAsync(p->d_unfinished, 0, 4 * sizeof(int), stream));
     hipLaunchKernelGGL(k_trial, dim3(batch), dim3(64 * W), lds_trial, stream, d, sa);
     HIP_TRY(hipGetLastError());
     sa.first = 0;
+    int want_lq = 1, want_exit = 0, restarted = 0;
     if (counted) {
-      HIP_TRY(hipMemcpyAsync(p->h_unfinished, p->d_unfinished, sizeof(int), hipMemcpyDeviceToHost, stream));
+      HIP_TRY(hipMemcpyAsync(p->h_unfinished, p->d_unfinished, 4 * sizeof(int), hipMemcpyDeviceToHost, stream));
       HIP_TRY(hipStreamSynchronize(stream));
-      if (*p->h_unfinished == 0) break;
-      if (round > cap) return fail(ILQG_ERR_HIP, "solve did not terminate within its iteration bound");
+      want_lq = p->h_unfinished[0];
+      want_exit = p->h_unfinished[1];
     } else if (round == fixed_iters) {
-      break;
+      want_lq = 0;
+      want_exit = 1;
     }
-    hipLaunchKernelGGL(k_lq, dim3(batch), dim3(nt_lq), lds_lq, stream, d, sa);
-    HIP_TRY(hipGetLastError());
+    if (want_exit) {
+      hipLaunchKernelGGL(k_exit, dim3(batch), dim3(64), lds_exit, stream, d, sa);
+      HIP_TRY(hipGetLastError());
+      if (counted && al_mode) {
+        HIP_TRY(hipMemcpyAsync(p->h_unfinished, p->d_unfinished, 4 * sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        restarted = p->h_unfinished[2];
+      }
+    }
+    if (want_lq) {
+      hipLaunchKernelGGL(k_lq, dim3(batch), dim3(nt_lq), lds_lq, stream, d, sa);
+      HIP_TRY(hipGetLastError());
+    }
+    if (!want_lq && !restarted) break;
+    if (round > cap) return fail(ILQG_ERR_HIP, "solve did not terminate within its iteration bound");
   }
   return ILQG_OK;
 }

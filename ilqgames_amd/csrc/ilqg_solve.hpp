@@ -35,7 +35,7 @@ struct SolveArgs {
   ilqg_solver_params prm;
   long long* prof;      // optional [B][16] shader-clock cycles (diagnostics) or nullptr
   int first;            // trial kernel: 1 on the first launch of a solve (initialises the state)
-  int* unfinished;      // trial kernel: incremented once per instance that leaves it waiting for an LQ sweep
+  int* unfinished;      // [3] instances left waiting for: an LQ sweep, the exit path, a restart (AL)
 };
 
 // Elements of one open-loop scratch row ([X|y|W|w|M|m|Q l], OLCfg::ROW) from run-time dimensions.
@@ -262,6 +262,18 @@ __device__ __forceinline__ void solve_exit_path(const DevProblem& p, const QuadT
       }
 }
 
+// Exit part: one workgroup per instance whose stage is INNER_DONE (its own small kernel, so that the
+// augmented-Lagrangian bookkeeping does not sit in the register budget of the trial kernel).
+template <typename T, int NX, int NP, int MU>
+__device__ __forceinline__ void exit_part_instance(const DevProblem& p, const QuadTables<T>& tb, const SolveArgs<T>& sa,
+                                                   int b, T* sm) {
+  const InstanceBuffers<T> ib(p, sa, b);
+  SolveState<T> s = state_load<T>(ib.w, ib.L);
+  solve_exit_path<T, NX, NP, MU>(p, tb, sa, ib, s, b, sm);
+  state_store<T>(ib.w, ib.L, s);
+  if (threadIdx.x == 0 && s.stage == ST_ROLLOUT) atomicAdd(sa.unfinished + 2, 1);  // next inner solve (AL)
+}
+
 // ---------------------------------------------------------------------------
 // Trial part.  Runs while the instance's stage is ROLLOUT or QUAD; W = wavefronts per instance.
 // ---------------------------------------------------------------------------
@@ -311,9 +323,7 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const Q
   long long qph[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // linquad phase profile of this wave (diagnostics)
 
 #pragma unroll 1
-  while (true) {
-    if (s.stage == ST_INNER_DONE) solve_exit_path<T, NX, NP, MU>(p, tb, sa, ib, s, b, sm_roll);
-    if (s.stage != ST_ROLLOUT && s.stage != ST_QUAD) break;
+  while (s.stage == ST_ROLLOUT || s.stage == ST_QUAD) {
     __syncthreads();  // pass boundary: global-memory hand-off between waves
     const bool roll = s.stage == ST_ROLLOUT;
     RolloutArgs<T> ra;
@@ -436,7 +446,7 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const Q
     }
   }
   state_store<T>(w, L, s);
-  if (t == 0 && s.stage == ST_LQ) atomicAdd(sa.unfinished, 1);  // this instance wants another sweep
+  if (t == 0) atomicAdd(sa.unfinished + (s.stage == ST_LQ ? 0 : 1), 1);  // wants a sweep / wants the exit path
   if (t == 0 && sa.prof) sa.prof[size_t(b) * 96 + 1] += clock64() - pr_start;
   if (lane == 0 && sa.prof && wave < 2) {
 #pragma unroll

@@ -118,14 +118,22 @@ __device__ __forceinline__ void rollout_instance(const DevProblem& p, const Roll
     if (t < m) {
       T s = T(0);
       if constexpr (CN > 0) {
-        T pr[CN], dv[CN];  // all loads first, then the reference's left-to-right accumulation
+        // loads in blocks of eight ahead of the reference's left-to-right accumulation (the whole row
+        // at once costs 4 CN registers in the kernel's tightest loop)
+        constexpr int CH = 8;
 #pragma unroll
-        for (int c = 0; c < CN; c++) {
-          pr[c] = sP[t + m * c];
-          dv[c] = sdx[c];
+        for (int c0 = 0; c0 < CN; c0 += CH) {
+          T pr[CH], dv[CH];
+#pragma unroll
+          for (int c = 0; c < CH; c++)
+            if (c0 + c < CN) {
+              pr[c] = sP[t + m * (c0 + c)];
+              dv[c] = sdx[c0 + c];
+            }
+#pragma unroll
+          for (int c = 0; c < CH; c++)
+            if (c0 + c < CN) s += pr[c] * dv[c];
         }
-#pragma unroll
-        for (int c = 0; c < CN; c++) s += pr[c] * dv[c];
       } else {
         for (int c = 0; c < n; c++) s += sP[t + m * c] * sdx[c];
       }
