@@ -741,6 +741,48 @@ ilqg_status ilqg_problem_create(const ilqg_problem_desc* desc, ilqg_problem** ou
       if (rnd > max_round) max_round = rnd;
     }
     d.num_rounds = max_round + 1;
+    // shared closest-point queries of the top-level polyline terms on the state
+    d.num_cq = 0;
+    d.num_cq_items = 0;
+    for (int ti = 0; ti < desc->num_terms; ti++) dt[ti].cq = -1;
+    bool fits = true;
+    int cq_key[kMaxClosestQueries][3];
+    for (int ti = 0; ti < desc->num_terms && fits; ti++) {
+      DevTerm& o = dt[ti];
+      const bool poly_kind = o.kind == ILQG_COST_QUADRATIC_POLYLINE2 || o.kind == ILQG_COST_SEMIQUADRATIC_POLYLINE2;
+      if (!poly_kind || o.role == ILQG_ROLE_CHILD || o.arg_off != 0 || o.polyline < 0) continue;
+      int q = -1;
+      for (int e = 0; e < d.num_cq; e++)
+        if (cq_key[e][0] == o.polyline && cq_key[e][1] == o.idx[0] && cq_key[e][2] == o.idx[1]) q = e;
+      if (q < 0) {
+        const int nseg = desc->polyline_offsets[o.polyline + 1] - desc->polyline_offsets[o.polyline] - 1;
+        if (d.num_cq == kMaxClosestQueries || d.num_cq_items + nseg > kMaxClosestItems || nseg > 255 || nseg < 1 ||
+            o.idx[0] > 255 || o.idx[1] > 255) {
+          fits = false;
+          break;
+        }
+        q = d.num_cq++;
+        cq_key[q][0] = o.polyline;
+        cq_key[q][1] = o.idx[0];
+        cq_key[q][2] = o.idx[1];
+        const int first_seg = desc->polyline_offsets[o.polyline] - o.polyline;  // segments before this polyline
+        d.cq_tab[q][0] = d.num_cq_items;
+        d.cq_tab[q][1] = nseg;
+        d.cq_tab[q][2] = first_seg;
+        d.cq_tab[q][3] = 0;
+        for (int c = 0; c < nseg; c++) {
+          d.cq_items[d.num_cq_items][0] = first_seg + c;
+          d.cq_items[d.num_cq_items][1] = o.idx[0] | (o.idx[1] << 8) | (c << 16) | (nseg << 24);
+          d.num_cq_items++;
+        }
+      }
+      o.cq = q;
+    }
+    if (!fits) {  // too many distinct searches for one wave: every term searches on its own
+      d.num_cq = 0;
+      d.num_cq_items = 0;
+      for (int ti = 0; ti < desc->num_terms; ti++) dt[ti].cq = -1;
+    }
   }
   p->terms_host.assign(desc->terms, desc->terms + desc->num_terms);
   const int npts = desc->num_polylines ? desc->polyline_offsets[desc->num_polylines] : 0;

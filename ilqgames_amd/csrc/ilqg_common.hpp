@@ -20,6 +20,14 @@ namespace ilqg {
 constexpr int kMaxPlayers = ILQG_MAX_PLAYERS;
 constexpr int kMaxPairs = 16;  // device kernels: at most NP*NP <= 16 control blocks
 constexpr int kMaxT = 256;
+// Phase-profile instrumentation (scripts/stage_bench.py) is compiled in only with -DILQG_PROFILE=1: the
+// accumulators are live across the hot loops and the kernels are register-bound.
+#ifndef ILQG_PROFILE
+#define ILQG_PROFILE 0
+#endif
+constexpr bool kProfile = ILQG_PROFILE != 0;
+constexpr int kMaxClosestQueries = 8;   // distinct (polyline, x index, y index) among the polyline terms
+constexpr int kMaxClosestItems = 64;    // their segments, one lane each
 
 // (i,j) control-block table of one problem (QuadraticCostApproximation::control keys).
 struct PairTable {
@@ -46,6 +54,7 @@ struct DevTerm {
   int ld;        // leading dimension of the Hessian tile
   int arg_off;   // offset of the argument vector inside the [x|u] image
   int arg_dim;   // its length
+  int cq;        // index of the shared closest-point query of a polyline term, or -1
 };
 
 // Flattened Problem (dynamics + PlayerCosts) living in kernel-argument space;
@@ -73,6 +82,13 @@ struct DevProblem {
   int cost_order_stride;
   int num_constraints;
   int num_rounds;
+  // Shared Polyline2::ClosestPoint work of the polyline terms, flattened so that a lane needs one table
+  // read: query q = (first item, segments, first segment of the polyline in the segment table, 0);
+  // item = (segment-table index, xi | yi << 8 | segment << 16 | segments << 24).  num_cq = 0 disables the
+  // pre-pass (terms search on their own).
+  int num_cq, num_cq_items;
+  int cq_tab[kMaxClosestQueries][4];
+  int cq_items[kMaxClosestItems][2];
   PairTable pairs;
 };
 

@@ -1129,8 +1129,8 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
   long long phacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // phase profile, kept in registers until the sweep ends
 #pragma unroll 1
   for (int k = Tn - 2; k >= 0; k--) {
-    long long pc0 = a.ph ? clock64() : 0, pc1;
-#define ILQG_PH(i) do { if (a.ph) { __builtin_amdgcn_sched_barrier(0); pc1 = clock64(); __builtin_amdgcn_sched_barrier(0); phacc[i] += pc1 - pc0; pc0 = pc1; } } while (0)
+    long long pc0 = (kProfile && a.ph) ? clock64() : 0, pc1;
+#define ILQG_PH(i) do { if (kProfile && a.ph) { __builtin_amdgcn_sched_barrier(0); pc1 = clock64(); __builtin_amdgcn_sched_barrier(0); phacc[i] += pc1 - pc0; pc0 = pc1; } } while (0)
     if (k > 0) stage(k - 1, 1 - cur);
     stash_ql(k);
     ILQG_PH(0);
@@ -1368,7 +1368,7 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
     ILQG_PH(6);
   }
 #undef ILQG_PH
-  if (a.ph && lane == 0) {  // wave w's row of the profile: a.ph[16 * w + i]
+  if (kProfile && a.ph && lane == 0) {  // wave w's row of the profile: a.ph[16 * w + i]
 #pragma unroll
     for (int i = 0; i < 10; i++) a.ph[16 * w + i] += phacc[i];
   }

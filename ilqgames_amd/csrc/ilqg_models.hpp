@@ -338,8 +338,10 @@ enum {
   LC_UDIM = LC_UOFF + kMaxPlayers + 1, LC_PARAM = LC_UDIM + kMaxPlayers, LC_SREG = LC_PARAM + kMaxPlayers,
   LC_CREG = LC_SREG + kMaxPlayers, LC_STRUCT = LC_CREG + kMaxPlayers, LC_PI = LC_STRUCT + kMaxPlayers,
   LC_PJ = LC_PI + kMaxPairs, LC_ROFF = LC_PJ + kMaxPairs, LC_RGOFF = LC_ROFF + kMaxPairs,
-  LC_FROMCOST = LC_RGOFF + kMaxPairs, LC_PII = LC_FROMCOST + kMaxPairs, LC_COUNT = (LC_PII + kMaxPlayers + 3) & ~3
+  LC_FROMCOST = LC_RGOFF + kMaxPairs, LC_PII = LC_FROMCOST + kMaxPairs, LC_CQTAB = LC_PII + kMaxPlayers,
+  LC_CQITEMS = LC_CQTAB + 4 * kMaxClosestQueries, LC_COUNT = (LC_CQITEMS + 2 * kMaxClosestItems + 3) & ~3
 };
+constexpr int kClosestStride = 12;  // LDS image of a Closest<T>: cx cy ssd is_vertex is_endpoint seg[7]
 
 // Polyline2::ClosestPoint, src/polyline2.cpp:105-174 — linear scan over the 1..15 segments of a
 // lane; the "shortcut" sign rule at interior vertices and the 1e-4 endpoint rule are reproduced.
@@ -381,6 +383,86 @@ __device__ __forceinline__ Closest<T> polyline_closest(const QuadTables<T>& tb, 
   const T bx = out.cx - sl.p2x, by = out.cy - sl.p2y;
   out.is_endpoint = (ax * ax + ay * ay < T(1e-4f)) || (bx * bx + by * by < T(1e-4f));
   return out;
+}
+
+// The same search, shared and lane-parallel.  Several terms of a player (lane centre, left and right
+// boundary) ask for the closest point of the same polyline to the same position, and a lane with k
+// segments makes every other lane of the wave wait k iterations.  closest_items evaluates ONE segment per
+// lane for every distinct query; closest_select lets one lane per query pick the winner exactly as the
+// sequential scan does (strictly smaller |signed squared distance| wins, so the first minimum is kept;
+// the shortcut-sign rule only flips the sign of a candidate, never its magnitude) and leaves a Closest<T>
+// image in LDS for the terms to read.
+template <typename T>
+__device__ __forceinline__ void closest_items(const QuadTables<T>& tb, int num_items, const T* sx, T* sitem, int t) {
+  if (t >= num_items) return;
+  const int seg_index = tb.lc[LC_CQITEMS + 2 * t], packed = tb.lc[LC_CQITEMS + 2 * t + 1];
+  const int c = (packed >> 16) & 255, nseg = (packed >> 24) & 255;
+  const T qx = sx[packed & 255], qy = sx[(packed >> 8) & 255];
+  const T* sb = tb.segs + size_t(seg_index) * kSegStride;
+  const Seg<T> s = load_seg<T>(sb);
+  T px, py, cur;
+  bool se;
+  seg_closest(s, qx, qy, &px, &py, &se, &cur);
+  const bool at2 = (px == s.p2x && py == s.p2y);
+  const bool at1 = (px == s.p1x && py == s.p1y);
+  if (se && (c > 0 || at2) && (c < nseg - 1 || at1)) {
+    const Seg<T> sc = load_seg<T>(sb + (at1 ? 7 : 14));
+    cur *= seg_side(sc, qx, qy) ? sgn(cur) : -sgn(cur);
+  }
+  sitem[4 * t + 0] = px;
+  sitem[4 * t + 1] = py;
+  sitem[4 * t + 2] = cur;
+  sitem[4 * t + 3] = se ? T(1) : T(0);
+}
+
+template <typename T>
+__device__ __forceinline__ void closest_select(const QuadTables<T>& tb, int num_cq, const T* sitem, T* sclo, int t) {
+  if (t >= num_cq) return;
+  const int first_item = tb.lc[LC_CQTAB + 4 * t], nseg = tb.lc[LC_CQTAB + 4 * t + 1];
+  const T* base = tb.segs + size_t(tb.lc[LC_CQTAB + 4 * t + 2]) * kSegStride;
+  T best = dinf<T>();
+  int bi = 0;
+  for (int c0 = 0; c0 < nseg; c0 += 8) {  // candidates eight at a time: the LDS reads overlap
+    T cur[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) cur[u] = sitem[4 * (first_item + (c0 + u < nseg ? c0 + u : nseg - 1)) + 2];
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+      if (c0 + u < nseg && t_abs(cur[u]) < t_abs(best)) {
+        best = cur[u];
+        bi = c0 + u;
+      }
+  }
+  const T* it = sitem + 4 * (first_item + bi);
+  const T* sg = base + size_t(bi) * kSegStride;
+  const T* sl = base + size_t(nseg - 1) * kSegStride;
+  const T cx = it[0], cy = it[1], sev = it[3];
+  const T s0x = base[0], s0y = base[1], slx = sl[2], sly = sl[3];
+  T sgv[7];
+#pragma unroll
+  for (int e = 0; e < 7; e++) sgv[e] = sg[e];
+  T* o = sclo + kClosestStride * t;
+  o[0] = cx;
+  o[1] = cy;
+  o[2] = best;
+  o[3] = sev;
+  const T ax = cx - s0x, ay = cy - s0y;
+  const T bx = cx - slx, by = cy - sly;
+  o[4] = ((ax * ax + ay * ay < T(1e-4f)) || (bx * bx + by * by < T(1e-4f))) ? T(1) : T(0);
+#pragma unroll
+  for (int e = 0; e < 7; e++) o[5 + e] = sgv[e];
+}
+
+template <typename T>
+__device__ __forceinline__ Closest<T> closest_load(const T* o) {
+  Closest<T> c;
+  c.cx = o[0];
+  c.cy = o[1];
+  c.ssd = o[2];
+  c.is_vertex = o[3] != T(0);
+  c.is_endpoint = o[4] != T(0);
+  c.seg = load_seg<T>(o + 5);
+  return c;
 }
 
 // ---------------------------------------------------------------------------
@@ -509,7 +591,7 @@ struct TermOut {
 // search is shared).  `lambda`, `mu`: augmented-Lagrangian state of a constraint term.
 template <typename T>
 __device__ __forceinline__ void term_compute_leaf(const QuadTables<T>& tb, const DevTerm& c, const T* v, T lambda,
-                                                  T mu, TermOut<T>* o) {
+                                                  T mu, TermOut<T>* o, const T* sclo = nullptr) {
   const T w = T(c.weight), val = T(c.value);
   const bool oriented = c.flags & ILQG_FLAG_ORIENTED;
   o->pattern = PAT_NONE;
@@ -547,7 +629,8 @@ __device__ __forceinline__ void term_compute_leaf(const QuadTables<T>& tb, const
     case ILQG_COST_SEMIQUADRATIC_POLYLINE2: {  // src/semiquadratic_polyline2_cost.cpp:52-142
       const bool semi = c.kind == ILQG_COST_SEMIQUADRATIC_POLYLINE2;
       const T px = v[c.idx[0]], py = v[c.idx[1]];
-      const Closest<T> cl = polyline_closest<T>(tb, c.polyline, px, py);
+      const Closest<T> cl = (sclo != nullptr && c.cq >= 0) ? closest_load<T>(sclo + kClosestStride * c.cq)
+                                                           : polyline_closest<T>(tb, c.polyline, px, py);
       T dx, dy;
       if (semi) {
         const T sst = sgn(val) * val * val;
@@ -649,7 +732,7 @@ __device__ __forceinline__ void term_compute_leaf(const QuadTables<T>& tb, const
 // Top-level term: ExtremeValueCost dispatches to its active child (src/extreme_value_cost.cpp:51-85).
 template <typename T>
 __device__ __forceinline__ void term_compute(const QuadTables<T>& tb, const DevTerm& c, const T* v, T lambda, T mu,
-                                             TermOut<T>* o) {
+                                             TermOut<T>* o, const T* sclo = nullptr) {
   if (c.kind == ILQG_COST_EXTREME_VALUE) {
     T value;
     const int best = extreme_child(tb, c, v, c.arg_dim, &value);
@@ -658,7 +741,7 @@ __device__ __forceinline__ void term_compute(const QuadTables<T>& tb, const DevT
     o->value = value;
     return;
   }
-  term_compute_leaf<T>(tb, c, v, lambda, mu, o);
+  term_compute_leaf<T>(tb, c, v, lambda, mu, o, sclo);
 }
 
 // Scatter one term's contribution into its LDS tiles (H column-major with leading dim ld).

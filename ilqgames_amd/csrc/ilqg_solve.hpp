@@ -376,8 +376,8 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const Q
     qa.r = quad ? w + L.r : nullptr;
     qa.merit_part = qmode == Q_TRIAL ? w + L.mpart : nullptr;
     qa.cost_part = (qmode == Q_COSTS || qmode == Q_TRIAL || qmode == Q_LIN) ? w + L.cpart : nullptr;
-    qa.phacc = sa.prof ? qph : nullptr;
-    long long tq0 = sa.prof ? clock64() : 0;
+    qa.phacc = (kProfile && sa.prof) ? qph : nullptr;
+    long long tq0 = (kProfile && sa.prof) ? clock64() : 0;
     // Claim rows as they become ready.  The next row's argument is requested before this row's stores
     // are issued (see linquad_compute / linquad_store).
     auto claim = [&]() {
@@ -392,13 +392,13 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const Q
     T argv = k < Tn ? linquad_load_arg<T>(qa, k, n, m, lane) : T(0);
 #pragma unroll 1
     while (k < Tn) {
-      if (sa.prof) { const long long tq1 = clock64(); qph[6] += tq1 - tq0; }
+      if (kProfile && sa.prof) { const long long tq1 = clock64(); qph[6] += tq1 - tq0; }
       LinquadCarry<T> carry;
       linquad_compute<T, NX, NP * MU, NP>(p, tb, qa, k, sm_quad, lane, argv, carry);
       const int kn = claim();
       const T argn = kn < Tn ? linquad_load_arg<T>(qa, kn, n, m, lane) : T(0);
       linquad_store<T, NX, NP * MU, NP>(p, qa, k, sm_quad, lane, carry);
-      if (sa.prof) { tq0 = clock64(); qph[7] += 1; }
+      if (kProfile && sa.prof) { tq0 = clock64(); qph[7] += 1; }
       k = kn;
       argv = argn;
     }
@@ -447,8 +447,8 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const Q
   }
   state_store<T>(w, L, s);
   if (t == 0) atomicAdd(sa.unfinished + (s.stage == ST_LQ ? 0 : 1), 1);  // wants a sweep / wants the exit path
-  if (t == 0 && sa.prof) sa.prof[size_t(b) * 96 + 1] += clock64() - pr_start;
-  if (lane == 0 && sa.prof && wave < 2) {
+  if (kProfile && t == 0 && sa.prof) sa.prof[size_t(b) * 96 + 1] += clock64() - pr_start;
+  if (kProfile && lane == 0 && sa.prof && wave < 2) {
 #pragma unroll
     for (int i = 0; i < 8; i++) sa.prof[size_t(b) * 96 + 64 + 8 * wave + i] += qph[i];
   }
@@ -484,7 +484,7 @@ __device__ __forceinline__ void lq_part_instance(const DevProblem& p, const Solv
   la.ed_out = sm + LQCfg<T, NX, NP, MU>::oX;  // an LDS slot that is free once the sweep ends
   la.T_steps = Tn;
   la.adaptive = 1;
-  la.ph = sa.prof ? sa.prof + size_t(b) * 96 + 8 : nullptr;
+  la.ph = (kProfile && sa.prof) ? sa.prof + size_t(b) * 96 + 8 : nullptr;
   if constexpr (PW) {
     lq_feedback_instance_mfma_pw<T, NX, NP, MU>(la, p.pairs, sm);
   } else {
@@ -500,7 +500,7 @@ __device__ __forceinline__ void lq_part_instance(const DevProblem& p, const Solv
     st->step = T(sa.prm.initial_alpha_scaling);
     st->bt = 0;
     st->stage = ST_ROLLOUT;
-    if (sa.prof) sa.prof[size_t(b) * 96 + 2] += clock64() - pr_start;
+    if (kProfile && sa.prof) sa.prof[size_t(b) * 96 + 2] += clock64() - pr_start;
   }
 }
 

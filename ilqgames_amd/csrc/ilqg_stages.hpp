@@ -209,6 +209,8 @@ __device__ __forceinline__ QuadTables<T> quad_tables_load(const DevProblem& p, v
     lc[LC_RGOFF + t] = p.pairs.rgoff[t];
     lc[LC_FROMCOST + t] = p.pairs.from_cost[t];
   }
+  for (int e = t; e < 4 * kMaxClosestQueries; e += NT) lc[LC_CQTAB + e] = p.cq_tab[e / 4][e % 4];
+  for (int e = t; e < 2 * kMaxClosestItems; e += NT) lc[LC_CQITEMS + e] = p.cq_items[e / 2][e % 2];
   __syncthreads();
   QuadTables<T> tb;
   tb.terms = reinterpret_cast<const DevTerm*>(terms_i);
@@ -235,7 +237,9 @@ struct QuadArgs {
 };
 
 __host__ __device__ inline int quad_lds_elems(int n, int m, int N, int Rsz, int rsz, int num_terms) {
-  return n + m + n * n + n * m + N * n * n + N * n + Rsz + rsz + num_terms;
+  // + the shared closest-point pre-pass: 4 scalars per segment item, a Closest image per query
+  return n + m + n * n + n * m + N * n * n + N * n + Rsz + rsz + num_terms + 4 * kMaxClosestItems +
+         kClosestStride * kMaxClosestQueries;
 }
 
 // Executed by ONE wavefront (lane t of 64) with its own LDS scratch `sm`, so several waves of a
@@ -274,8 +278,8 @@ __device__ __forceinline__ void linquad_compute(const DevProblem& p, const QuadT
   T* sR = sl + N * n;
   T* sr = sR + pt.Rsz;
   const bool do_quad = a.Q != nullptr || a.merit_part != nullptr;
-  long long qc0 = a.phacc ? clock64() : 0, qc1;
-#define ILQG_QPH(i) do { if (a.phacc) { __builtin_amdgcn_sched_barrier(0); qc1 = clock64(); __builtin_amdgcn_sched_barrier(0); a.phacc[i] += qc1 - qc0; qc0 = qc1; } } while (0)
+  long long qc0 = (kProfile && a.phacc) ? clock64() : 0, qc1;
+#define ILQG_QPH(i) do { if (kProfile && a.phacc) { __builtin_amdgcn_sched_barrier(0); qc1 = clock64(); __builtin_amdgcn_sched_barrier(0); a.phacc[i] += qc1 - qc0; qc0 = qc1; } } while (0)
   // ---- load the argument, initialise the tiles ----
   // The (x, u) row was requested by the caller (argv); the tile image is cleared while that load is in
   // flight (16-byte LDS writes where the image is 16-byte aligned and even-sized).
@@ -333,6 +337,16 @@ __device__ __forceinline__ void linquad_compute(const DevProblem& p, const QuadT
   const double tt = double(k) * p.dt;
   const int tidx = int(static_cast<size_t>((tt - a.t_init) / p.dt));  // relative_time_tracker.h:69-72
   T* svals = sr + pt.rsz;  // [num_terms] term values for TotalCosts
+  // ---- shared Polyline2::ClosestPoint searches: one lane per (query, segment), one lane per query ----
+  T* sitem = svals + p.num_terms;
+  T* sclo = sitem + 4 * kMaxClosestItems;
+  const bool shared_closest = p.num_cq > 0;
+  if (shared_closest) {
+    closest_items<T>(tb, p.num_cq_items, sx, sitem, t);
+    lds_sync(NT <= 64);
+    closest_select<T>(tb, p.num_cq, sitem, sclo, t);
+    lds_sync(NT <= 64);
+  }
   ILQG_QPH(1);
   for (int base = 0; base < p.num_terms; base += NT) {
     const int ti = base + t;
@@ -349,7 +363,7 @@ __device__ __forceinline__ void linquad_compute(const DevProblem& p, const QuadT
         const bool deriv = do_quad && (is_full(c.player) || c.role == ILQG_ROLE_CONTROL_COST);
         if (deriv || (a.cost_part && is_cost)) {
           const T lambda = (c.slot >= 0 && a.lambdas) ? a.lambdas[c.slot * p.T + tidx] : T(0);
-          term_compute<T>(tb, c, sx + c.arg_off, lambda, a.mu, &o);
+          term_compute<T>(tb, c, sx + c.arg_off, lambda, a.mu, &o, shared_closest ? sclo : nullptr);
           if (!deriv) o.pattern = PAT_NONE;
         }
       }
@@ -430,8 +444,8 @@ __device__ __forceinline__ void linquad_store(const DevProblem& p, const QuadArg
   T* sR = sl + N * n;
   T* sr = sR + pt.Rsz;
   const T ms1 = carry.ms1, ms2 = carry.ms2, ctot = carry.ctot;
-  long long qc0 = a.phacc ? clock64() : 0, qc1;
-#define ILQG_QPH(i) do { if (a.phacc) { __builtin_amdgcn_sched_barrier(0); qc1 = clock64(); __builtin_amdgcn_sched_barrier(0); a.phacc[i] += qc1 - qc0; qc0 = qc1; } } while (0)
+  long long qc0 = (kProfile && a.phacc) ? clock64() : 0, qc1;
+#define ILQG_QPH(i) do { if (kProfile && a.phacc) { __builtin_amdgcn_sched_barrier(0); qc1 = clock64(); __builtin_amdgcn_sched_barrier(0); a.phacc[i] += qc1 - qc0; qc0 = qc1; } } while (0)
   // ---- coalesced write-out: the whole image is read into registers, then stored in one burst ----
   typedef T pair2 __attribute__((ext_vector_type(2)));
   bool burst = false;
