@@ -108,9 +108,28 @@ struct WsLayout {
 // caps the kernel at one wave per SIMD and leaves nothing to run beside the serial rollout chain.
 // Split, the trial kernel runs the rollout on wave 0 while the other waves of the workgroup already
 // linearise / quadraticise the steps it has produced (the steps are independent of each other).
+// The state is wave-uniform; pinning every field to the scalar register file keeps ~26 vector registers
+// free across the kernel's tightest loops (a uniform value loaded through the vector memory path would
+// otherwise sit in a VGPR for the whole kernel).
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float uniform(float v) {
+  return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+}
+__device__ __forceinline__ double uniform(double v) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)),
+                          __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
 template <typename T>
 __device__ __forceinline__ SolveState<T> state_load(const T* w, const WsLayout& L) {
-  return *reinterpret_cast<const SolveState<T>*>(w + L.state);
+  SolveState<T> s = *reinterpret_cast<const SolveState<T>*>(w + L.state);
+  s.stage = uniform(s.stage); s.qmode = uniform(s.qmode); s.initial = uniform(s.initial); s.cur = uniform(s.cur);
+  s.sacc = uniform(s.sacc); s.num_iterations = uniform(s.num_iterations); s.bt = uniform(s.bt);
+  s.accepted_iters = uniform(s.accepted_iters); s.has_converged = uniform(s.has_converged); s.ok = uniform(s.ok);
+  s.logged = uniform(s.logged); s.inner_calls = uniform(s.inner_calls); s.al_success = uniform(s.al_success);
+  s.pad0 = s.pad1 = s.pad2 = 0;
+  s.acc_scale = uniform(s.acc_scale); s.step = uniform(s.step); s.last_merit = uniform(s.last_merit);
+  s.expected_decrease = uniform(s.expected_decrease); s.max_err = uniform(s.max_err); s.mu = uniform(s.mu);
+  return s;
 }
 template <typename T>
 __device__ __forceinline__ void state_store(T* w, const WsLayout& L, const SolveState<T>& s) {
@@ -414,7 +433,7 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const Q
     } else {
       bool accepted = true;
       if (qmode == Q_TRIAL) {
-        const T merit = merit_reduce<T>(p, w + L.mpart, sm_quad0, int(qe));
+        const T merit = uniform(merit_reduce<T>(p, w + L.mpart, sm_quad0, int(qe)));
         const T scaled = T(prm.expected_decrease_fraction) * s.step * s.expected_decrease;
         accepted = (s.last_merit - merit >= scaled);  // CheckArmijoCondition :350-362
         if (accepted) {
