@@ -778,7 +778,7 @@ ilqg_status ilqg_problem_create(const ilqg_problem_desc* desc, ilqg_problem** ou
       }
       o.cq = q;
     }
-    if (!fits) {  // too many distinct searches for one wave: every term searches on its own
+    if (!fits || getenv("ILQG_NO_SHARED_CLOSEST") != nullptr) {  // too many distinct searches for one wave (or A/B switch): every term searches on its own
       d.num_cq = 0;
       d.num_cq_items = 0;
       for (int ti = 0; ti < desc->num_terms; ti++) dt[ti].cq = -1;
