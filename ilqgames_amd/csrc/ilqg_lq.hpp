@@ -37,6 +37,7 @@ struct LQArgs {
   T* ed_out;                        // expected decrease (one scalar) or nullptr
   int T_steps;
   int adaptive;
+  int symmetric = 0;                // 1: every Q_i and R_ij is exactly symmetric (what the quadraticisation stage writes)
   long long* ph = nullptr;          // optional: 8 shader-clock accumulators per instance (phase profile)
 };
 
@@ -1110,8 +1111,12 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
   dma_wait();
   __syncthreads();
   set_img(0);
+  // With symmetric costs Z_w is symmetric up to rounding, so Z_w^T (only ever used as the left factor of
+  // W = Z_w F) is replaced by Z_w itself: two of the nine tile products of a step and the transposed loads
+  // disappear.  The C ABI's general LQ entry (arbitrary Q, R) keeps both layouts.
+  const bool sym = a.symmetric != 0;
   vec Zd = ldD(tQ);
-  vec Yd = ldDT(tQ);
+  vec Yd = sym ? Zd : ldDT(tQ);
   if (lane < NX) sZw[lane] = sl[w * NX + lane];
   stash_ql(Tn - 1);
   for (int e = t; e < M * NX; e += NT) a.P[size_t(Tn - 1) * M * NX + e] = T(0);
@@ -1261,7 +1266,7 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
 
     // ---- Z_w <- F^T Z_w F + Q_w + sum_jj P_jj^T R_w,jj P_jj  (:198-212), both layouts ----
     vec Cd = ldD(tQ);
-    vec CTd = ldDT(tQ);
+    vec CTd = sym ? Cd : ldDT(tQ);
 #pragma unroll
     for (int jj = 0; jj < NP; jj++) {
       // + P_jj^T R_w,jj P_jj (and its transpose): H = R P_jj and H' = R^T P_jj sit in rows
@@ -1294,8 +1299,8 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
         Hd[r] = h * mk;
         Htd[r] = ht * mk;
       }
-      Cd = tile_xty<T>(Pj, Hd, Cd);     // P_jj^T (R P_jj)
-      CTd = tile_xty<T>(Pj, Htd, CTd);  // P_jj^T (R^T P_jj) = (P_jj^T R P_jj)^T
+      Cd = tile_xty<T>(Pj, Hd, Cd);                 // P_jj^T (R P_jj)
+      if (!sym) CTd = tile_xty<T>(Pj, Htd, CTd);  // P_jj^T (R^T P_jj) = (P_jj^T R P_jj)^T
     }
     vec FT;
     if constexpr (SPARE) {
@@ -1309,21 +1314,23 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
         Wm[r] = Wd[r] * mCols;
         Wz[r] = Wm[r] + (Wd[r] * mVecCol + zetaD[r]);  // column JB: zeta_w + Z_w beta (Wm is zero there)
       }
-      Yd = tile_xty<T>(Wm, Fd, CTd);           // (Z_w F)^T F + C_w^T
-      const vec Zx = tile_xty<T>(Fd, Wz, Cd);  // F^T [Z_w F | zeta_w + Z_w beta] + C_w
+      if (!sym) Yd = tile_xty<T>(Wm, Fd, CTd);  // (Z_w F)^T F + C_w^T
+      const vec Zx = tile_xty<T>(Fd, Wz, Cd);   // F^T [Z_w F | zeta_w + Z_w beta] + C_w
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         Zd[r] = Zx[r] * mCols;
         FT[r] = Zx[r];
       }
+      if (sym) Yd = Zd;
     } else {
       const vec Wd = tile_xty<T>(Yd, Fd, zero4);     // Z_w F
       const vec ZB = tile_xty<T>(Yd, BetaD, zero4);  // column w = Z_w beta
       vec TD;
 #pragma unroll
       for (int r = 0; r < 4; r++) TD[r] = ZB[r] * mVecCol + zetaD[r];
-      Yd = tile_xty<T>(Wd, Fd, CTd);
+      if (!sym) Yd = tile_xty<T>(Wd, Fd, CTd);
       Zd = tile_xty<T>(Fd, Wd, Cd);
+      if (sym) Yd = Zd;
       FT = tile_xty<T>(Fd, TD, zero4);  // column w = F^T (zeta_w + Z_w beta)
     }
     ILQG_PH(4);

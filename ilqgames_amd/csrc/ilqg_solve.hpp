@@ -503,6 +503,7 @@ __device__ __forceinline__ void lq_part_instance(const DevProblem& p, const Solv
   la.ed_out = sm + LQCfg<T, NX, NP, MU>::oX;  // an LDS slot that is free once the sweep ends
   la.T_steps = Tn;
   la.adaptive = 1;
+  la.symmetric = 1;  // linquad_compute writes H(x,y) and H(y,x) from the same value
   la.ph = (kProfile && sa.prof) ? sa.prof + size_t(b) * 96 + 8 : nullptr;
   if constexpr (PW) {
     lq_feedback_instance_mfma_pw<T, NX, NP, MU>(la, p.pairs, sm);
