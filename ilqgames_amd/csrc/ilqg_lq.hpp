@@ -1079,35 +1079,49 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
   T* sBw = sm + W::oVec + w * 16;         // this player's beta, entries NX..15 zero
   T* sZw = sm + W::oVec + (NP + w) * 16;  // this player's zeta, entries NX..15 zero
 
-  // every wave stages its own Q_w; A, B and the vectors are dealt round-robin
-  auto stage = [&](int k, int which) {
+  // Staging jobs of one step: Q_0 .. Q_{NP-1}, A, B, the vectors (l, R, r) — NP + 3 of them, each executed
+  // by one wave.  `slot` of `nslots` takes every nslots-th job.  Before the loop all NP waves share the
+  // work; inside it the waves that would otherwise idle through wave 0's solve do all of it, so staging
+  // (and the Q_i l_i products for ExpectedDecrease) leaves the step's critical path.
+  auto stage = [&](int k, int which, int slot, int nslots) {
     T* dst = sm + which * W::IMG;
-    dma_tile<T, NX, W::LD, W::PS, W::WAVE_INSTRS>(a.Q + (size_t(k) * NP + w) * NX * NX, dst + W::oTQ + w * W::TILE, NX, NX, lane);
-    if (w == 0) dma_tile<T, NX, W::LD, W::PS, W::WAVE_INSTRS>(a.A + size_t(k) * NX * NX, dst + W::oTA, NX, NX, lane);
-    if (w == 1 % NP) dma_tile<T, NX, W::LD, W::PS, W::WAVE_INSTRS>(a.Bm + size_t(k) * NX * M, dst + W::oTB, NX, M, lane);
-    if (w == 2 % NP) {
-      dma_g2l<64, false>(a.l + size_t(k) * NP * NX, dst + W::oVl, NP * NX * S, lane);
-      dma_g2l<64, false>(a.R + size_t(k) * pt.Rsz, dst + W::oVR, pt.Rsz * S, lane);
-      dma_g2l<64, false>(a.r + size_t(k) * pt.rsz, dst + W::oVr, pt.rsz * S, lane);
+#pragma unroll
+    for (int job = 0; job < NP + 3; job++) {
+      if (job % nslots != slot) continue;
+      if (job < NP) {
+        dma_tile<T, NX, W::LD, W::PS, W::WAVE_INSTRS>(a.Q + (size_t(k) * NP + job) * NX * NX, dst + W::oTQ + job * W::TILE,
+                                                        NX, NX, lane);
+      } else if (job == NP) {
+        dma_tile<T, NX, W::LD, W::PS, W::WAVE_INSTRS>(a.A + size_t(k) * NX * NX, dst + W::oTA, NX, NX, lane);
+      } else if (job == NP + 1) {
+        dma_tile<T, NX, W::LD, W::PS, W::WAVE_INSTRS>(a.Bm + size_t(k) * NX * M, dst + W::oTB, NX, M, lane);
+      } else {
+        dma_g2l<64, false>(a.l + size_t(k) * NP * NX, dst + W::oVl, NP * NX * S, lane);
+        dma_g2l<64, false>(a.R + size_t(k) * pt.Rsz, dst + W::oVR, pt.Rsz * S, lane);
+        dma_g2l<64, false>(a.r + size_t(k) * pt.rsz, dst + W::oVr, pt.rsz * S, lane);
+      }
     }
   };
 
-  // (Q_w l_w) of the staged step -> scratch, for ExpectedDecrease
-  auto stash_ql = [&](int k) {
+  // (Q_i l_i) of the staged step -> scratch, for ExpectedDecrease
+  auto stash_ql_of = [&](int k, int i) {
     if (want_fwd && lane < NX) {
+      const T* tQi = img + W::oTQ + i * W::TILE;
       T s = T(0);
 #pragma unroll
-      for (int c = 0; c < NX; c++) s += tQ[lane + LD * c] * sl[w * NX + c];
-      a.scratch[size_t(k) * SCR + w * NX + lane] = s;
+      for (int c = 0; c < NX; c++) s += tQi[lane + LD * c] * sl[i * NX + c];
+      a.scratch[size_t(k) * SCR + i * NX + lane] = s;
     }
   };
+  auto stash_ql = [&](int k) { stash_ql_of(k, w); };
+  constexpr int HELPERS = NP > 1 ? NP - 1 : 1;  // waves that stage inside the loop (wave 0 itself when NP == 1)
 
   // ---- zero the tile padding (and everything else the DMA does not write), once ----
   for (int e = t; e < W::oVec + 2 * NP * 16; e += NT) sm[e] = T(0);
   __syncthreads();
 
   // ---- terminal step: Z_w = Q_w[T-1], zeta_w = l_w[T-1]  (:102-105) ----
-  stage(Tn - 1, 0);
+  stage(Tn - 1, 0, w, NP);
   dma_wait();
   __syncthreads();
   set_img(0);
@@ -1125,7 +1139,7 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
     if (t < NP) a.scratch[size_t(Tn - 1) * SCR + NP * NX + t] = T(0);
     if (t < NX) a.scratch[size_t(Tn - 1) * SCR + NP * (NX + 1) + t] = T(0);
   }
-  if (Tn >= 2) stage(Tn - 2, 1);
+  if (Tn >= 2) stage(Tn - 2, 1, w, NP);
   dma_wait();
   __syncthreads();
   int cur = 1;
@@ -1136,8 +1150,10 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
   for (int k = Tn - 2; k >= 0; k--) {
     long long pc0 = (kProfile && a.ph) ? clock64() : 0, pc1;
 #define ILQG_PH(i) do { if (kProfile && a.ph) { __builtin_amdgcn_sched_barrier(0); pc1 = clock64(); __builtin_amdgcn_sched_barrier(0); phacc[i] += pc1 - pc0; pc0 = pc1; } } while (0)
-    if (k > 0) stage(k - 1, 1 - cur);
-    stash_ql(k);
+    if (NP == 1) {
+      if (k > 0) stage(k - 1, 1 - cur, 0, 1);
+      stash_ql(k);
+    }
     ILQG_PH(0);
 
     // ---- this player's MU rows of the stacked Nash system: (B_w^T Z_w) [B | A] ----
@@ -1166,6 +1182,11 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
     ILQG_PH(1);
     lds_sync(false);  // [S | Y] and y_zeta complete (LDS only: no wait on the DMA or on global stores)
     ILQG_PH(7);
+    if (NP > 1 && w != 0) {  // while wave 0 solves: next step's image and this step's Q_i l_i
+      if (k > 0) stage(k - 1, 1 - cur, w - 1, HELPERS);
+      stash_ql(k);
+      if (w == 1) stash_ql_of(k, 0);
+    }
 
     // ---- wave 0: column `lane` of [S | Y]: + R_ii, Gershgorin (:163-176), then the M x M solve (:180) ----
     if (w == 0) {
