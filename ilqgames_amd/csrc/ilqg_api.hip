@@ -424,7 +424,6 @@ static ilqg_status launch_solve(ilqg_problem* p, int32_t batch, const void* x0, 
   }
   sa.unfinished = p->d_unfinished;
   constexpr int W = TrialWaves<T>::W;
-  if (d.m * d.n + 2 * d.m + d.n > 4 * 64) return fail(ILQG_ERR_UNSUPPORTED, "rollout staging block too large");
   size_t lq_elems = (C::USE_MFMA && !p->desc.params.open_loop) ? PWCfg<T, NX, NP, MU>::LDS_ELEMS : C::LDS_ELEMS;
   if (p->desc.params.open_loop && size_t(OLCfg<T, NX, NP, MU>::LDS_ELEMS) > lq_elems) lq_elems = OLCfg<T, NX, NP, MU>::LDS_ELEMS;
   const size_t lds_lq = lq_elems * sizeof(T);
@@ -902,7 +901,6 @@ ilqg_status ilqg_rollout_batch(const ilqg_problem* p, int32_t batch, const void*
   if (!p || !x0 || !xs_ref || !us_ref || !P || !alpha || !xs || !us) return fail(ILQG_ERR_INVALID, "null argument");
   if (batch <= 0) return ILQG_OK;
   const DevProblem& d = p->dev;
-  if (d.m * d.n + 2 * d.m + d.n > 4 * 64) return fail(ILQG_ERR_UNSUPPORTED, "rollout staging block too large");
 #define CALL(TY_)                                                                                              \
   [&]() -> ilqg_status {                                                                                     \
     RolloutBatchArgs<TY_> g{(const TY_*)x0, (const TY_*)xs_ref, (const TY_*)us_ref, (const TY_*)P, (const TY_*)alpha,    \

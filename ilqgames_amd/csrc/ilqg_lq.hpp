@@ -112,30 +112,6 @@ struct PairRegs {
   }
 };
 
-// ---- global -> LDS DMA (global_load_lds_*): no VGPR round trip, completes in the background ----
-typedef __attribute__((address_space(3))) void* lds_vptr;
-typedef const __attribute__((address_space(1))) void* glb_vptr;
-
-// Copies `nbytes` (a multiple of 4) from global `g` to LDS `l` with the workgroup's NT threads.
-// The LDS destination of one instruction is wave-uniform base + lane * width, i.e. the LDS image is
-// the global image.  WIDE = 16-byte pieces (both addresses 16-byte aligned), else 4-byte pieces.
-template <int NT, bool WIDE>
-__device__ __forceinline__ void dma_g2l(const void* g, void* l, int nbytes, int t) {
-  constexpr int BPL = WIDE ? 16 : 4;
-  const int wbase = (t & ~63) * BPL;  // this wave's slice of each NT*BPL chunk
-  const int lane = t & 63;
-  for (int off = 0; off < nbytes; off += NT * BPL) {
-    const int my = off + wbase + lane * BPL;
-    if (my < nbytes) {
-      if constexpr (WIDE)
-        __builtin_amdgcn_global_load_lds((glb_vptr)((const char*)g + my), (lds_vptr)((char*)l + off + wbase), 16, 0, 0);
-      else
-        __builtin_amdgcn_global_load_lds((glb_vptr)((const char*)g + my), (lds_vptr)((char*)l + off + wbase), 4, 0, 0);
-    }
-  }
-}
-__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
 // Starts the DMA of step k's [B|A|Q|l|R|r] block into the image at `img`.
 template <typename T, int NX, int NP, int MU, int NT = LQCfg<T, NX, NP, MU>::NT>
 __device__ __forceinline__ void lq_stage_issue(const LQArgs<T>& a, const PairTable& pt, int k, T* img, int t) {

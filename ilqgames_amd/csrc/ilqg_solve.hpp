@@ -340,6 +340,7 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const Q
   const int max_iters = solve_max_iters(sa);
   const long long pr_start = clock64();
   long long qph[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // linquad phase profile of this wave (diagnostics)
+  long long rph[4] = {0, 0, 0, 0};              // rollout phase profile (wave 0)
 
 #pragma unroll 1
   while (s.stage == ST_ROLLOUT || s.stage == ST_QUAD) {
@@ -369,7 +370,9 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const Q
       flags[1] = 0;
     }
     __syncthreads();
-    if (roll && wave == 0) rollout_instance<T, NX, NP * MU>(p, ra, sm_roll, lane, W > 1 ? &flags[0] : nullptr);
+    if (roll && wave == 0)
+      rollout_instance<T, NX, NP * MU>(p, ra, sm_roll, lane, W > 1 ? &flags[0] : nullptr,
+                                       (kProfile && sa.prof) ? rph : nullptr);
     if (roll && W == 1) {
       __syncthreads();
       if (t == 0) flags[0] = Tn;
@@ -467,6 +470,10 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const Q
   state_store<T>(w, L, s);
   if (t == 0) atomicAdd(sa.unfinished + (s.stage == ST_LQ ? 0 : 1), 1);  // wants a sweep / wants the exit path
   if (kProfile && t == 0 && sa.prof) sa.prof[size_t(b) * 96 + 1] += clock64() - pr_start;
+  if (kProfile && t == 0 && sa.prof) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) sa.prof[size_t(b) * 96 + 88 + i] += rph[i];
+  }
   if (kProfile && lane == 0 && sa.prof && wave < 2) {
 #pragma unroll
     for (int i = 0; i < 8; i++) sa.prof[size_t(b) * 96 + 64 + 8 * wave + i] += qph[i];

@@ -28,7 +28,11 @@ struct RolloutArgs {
   T* us;            // [T][m]
 };
 
-__host__ __device__ inline int rollout_lds_elems(int n, int m) { return 2 * n + 2 * m + m * n + m + n; }
+// [x | dx | u] + two staged [P | alpha | u_ref | x_ref] blocks (the one in use, the one the DMA is filling)
+__host__ __device__ inline int rollout_stage_elems(int n, int m) { return (m * n + 2 * m + n + 3) & ~3; }
+__host__ __device__ inline int rollout_lds_elems(int n, int m) {
+  return ((2 * n + m + 3) & ~3) + 2 * rollout_stage_elems(n, m);
+}
 
 // Workgroup-scope publish / observe of a progress counter in LDS.  Waves of one workgroup share the
 // CU's vector L1, so release/acquire at workgroup scope is enough for the global-memory rows the
@@ -46,39 +50,23 @@ __device__ __forceinline__ int progress_observe(int* flag) {
 // still being integrated.
 template <typename T, int CN = 0, int CM = 0>
 __device__ __forceinline__ void rollout_instance(const DevProblem& p, const RolloutArgs<T>& a, T* sm, int t,
-                                                 int* ready = nullptr) {
+                                                 int* ready = nullptr, long long* phacc = nullptr) {
   const int n = CN > 0 ? CN : p.n, m = CM > 0 ? CM : p.m, N = p.N, Tn = p.T;
   constexpr int NT = 64;
-  T* sx = sm;             // [n] current state
-  T* sdx = sx + n;        // [n]
-  T* su = sdx + n;        // [m]
-  T* sP = su + m;         // [m*n] staged gains of this step
-  T* sal = sP + m * n;    // [m]
-  T* sur = sal + m;       // [m] u_ref
-  T* sxr = sur + m;       // [n] x_ref
-  const int W = m * n + 2 * m + n;  // contiguous staged block [P | alpha | u_ref | x_ref]
-  constexpr int PRE = 4;            // W <= 4*NT for every supported config (checked on host)
-  T pre[PRE];
-  auto issue = [&](int k) {
-#pragma unroll
-    for (int q = 0; q < PRE; q++) {
-      const int e = t + q * NT;
-      if (e < m * n)
-        pre[q] = a.P[size_t(k) * m * n + e];
-      else if (e < m * n + m)
-        pre[q] = a.alpha[size_t(k) * m + (e - m * n)];
-      else if (e < m * n + 2 * m)
-        pre[q] = a.us_ref[size_t(k) * m + (e - m * n - m)];
-      else if (e < W)
-        pre[q] = a.xs_ref[size_t(k) * n + (e - m * n - 2 * m)];
-    }
-  };
-  auto commit = [&]() {
-#pragma unroll
-    for (int q = 0; q < PRE; q++) {
-      const int e = t + q * NT;
-      if (e < W) sP[e] = pre[q];
-    }
+  T* sx = sm;       // [n] current state
+  T* sdx = sx + n;  // [n]
+  T* su = sdx + n;  // [m]
+  T* stg = sm + ((2 * n + m + 3) & ~3);  // two staged blocks [P (m*n) | alpha (m) | u_ref (m) | x_ref (n)]
+  const int WP = rollout_stage_elems(n, m);
+  constexpr int S = int(sizeof(T));
+  // The step's gains and references go global -> LDS by DMA, one step ahead, into the block not in use:
+  // no registers are held across the integration (the loop is the kernel's tightest spot for registers).
+  auto issue = [&](int k, int buf) {
+    T* d = stg + buf * WP;
+    dma_g2l<NT, false>(a.P + size_t(k) * m * n, d, m * n * S, t);
+    dma_g2l<NT, false>(a.alpha + size_t(k) * m, d + m * n, m * S, t);
+    dma_g2l<NT, false>(a.us_ref + size_t(k) * m, d + m * n + m, m * S, t);
+    dma_g2l<NT, false>(a.xs_ref + size_t(k) * n, d + m * n + 2 * m, n * S, t);
   };
   // lane group g = t / 8 integrates subsystem g; lane q = t % 8 owns RK4 stage q of that group
   T xj[6];
@@ -97,15 +85,21 @@ __device__ __forceinline__ void rollout_instance(const DevProblem& p, const Roll
 #pragma unroll
     for (int e = 0; e < 6; e++) xj[e] = (e < xd) ? a.x0[xo + e] : T(0);
   }
-  issue(0);
-  commit();
+  issue(0, 0);
+  dma_wait();
   lds_sync(true);
+  long long rc0 = (kProfile && phacc) ? clock64() : 0, rc1;
+#define ILQG_RPH(i) do { if (kProfile && phacc) { __builtin_amdgcn_sched_barrier(0); rc1 = clock64(); __builtin_amdgcn_sched_barrier(0); phacc[i] += rc1 - rc0; rc0 = rc1; } } while (0)
 #pragma unroll 1
   for (int k = 0; k < Tn; k++) {
     // rows < k were stored at least one integration ago: the release finds nothing left to wait for,
     // and it sits in front of the prefetch so it never waits on fresh loads either
     if (ready) progress_publish(ready, k);
-    if (k + 1 < Tn) issue(k + 1);
+    if (k + 1 < Tn) issue(k + 1, (k + 1) & 1);
+    const T* sP = stg + (k & 1) * WP;  // [m*n] gains of this step
+    const T* sal = sP + m * n;         // [m]
+    const T* sur = sal + m;            // [m] u_ref
+    const T* sxr = sur + m;            // [n] x_ref
     if (integ && q == 0) {
 #pragma unroll
       for (int e = 0; e < 6; e++)
@@ -115,6 +109,7 @@ __device__ __forceinline__ void rollout_instance(const DevProblem& p, const Roll
         }
     }
     lds_sync(NT <= 64);
+    ILQG_RPH(0);
     if (t < m) {
       T s = T(0);
       if constexpr (CN > 0) {
@@ -142,13 +137,17 @@ __device__ __forceinline__ void rollout_instance(const DevProblem& p, const Roll
       a.us[size_t(k) * m + t] = u;
     }
     lds_sync(NT <= 64);
+    ILQG_RPH(1);
     if (t < 64 && k + 1 < Tn) {  // whole first wave: the shuffles inside need every group lane live
       const T u0 = integ ? su[uo] : T(0), u1 = integ ? su[uo + 1] : T(0);
       sub_integrate_lanes<T>(kind, Lp, p.dt, xj, u0, u1, q, t & ~7);
     }
-    if (k + 1 < Tn) commit();
+    ILQG_RPH(2);
+    dma_wait();  // next block landed (this step's row stores are long retired by now)
     lds_sync(NT <= 64);
+    ILQG_RPH(3);
   }
+#undef ILQG_RPH
   if (ready) progress_publish(ready, Tn);
 }
 

@@ -59,3 +59,5 @@ for wv in range(2):
     steps = max(q[7], 1.0)
     print("  trial wave %d: %.0f linquad steps over 5 launches; cycles/step: load+init %.0f | linearize %.0f | terms %.0f | rounds %.0f | merit+cost %.0f | writeout %.0f | claim/wait %.0f" %
           (wv, q[7], q[0] / steps, q[1] / steps, q[2] / steps, q[3] / steps, q[4] / steps, q[5] / steps, q[6] / steps))
+q = pm[88:92] / 500.0
+print("  rollout (cycles/step, 5 rollouts x 100 steps): publish+dx %.0f | u = u_ref - P dx - alpha %.0f | RK4 %.0f | commit prefetch %.0f" % tuple(q))
