@@ -133,7 +133,16 @@ __device__ __forceinline__ void sub_integrate_lanes(int kind, T L, double interv
   T up[6];  // working copy; lower components are left untouched here
 #pragma unroll
   for (int e = 0; e < 6; e++) up[e] = x[e];
-  T ang_s[8], v_s[8];  // phi (car) or theta (unicycle), and v, at the 8 stage points
+  // v at the 8 stage points (the theta chain reads them with constant indices), and THIS lane's stage values
+  // picked as they are produced — a select chain over an 8-entry array is turned into a stack array with a
+  // per-lane index by the compiler, i.e. scratch stores and a dependent scratch load in the serial loop.
+  T v_s[8];
+  T my_ang = T(0), my_v = T(0);
+  auto pick = [&](int idx, T ang, T v) {
+    v_s[idx] = v;
+    my_ang = (q == idx) ? ang : my_ang;
+    my_v = (q == idx) ? v : my_v;
+  };
   auto upper_f = [&](const T* xx, T* xd) {
 #pragma unroll
     for (int e = 0; e < 6; e++) xd[e] = T(0);
@@ -154,23 +163,19 @@ __device__ __forceinline__ void sub_integrate_lanes(int kind, T L, double interv
 #pragma unroll
   for (int s = 0; s < 2; s++) {
     T k1[6], k2[6], k3[6], k4[6], xt[6];
-    ang_s[4 * s + 0] = up[ai];
-    v_s[4 * s + 0] = up[vi];
+    pick(4 * s + 0, up[ai], up[vi]);
     upper_f(up, k1);
 #pragma unroll
     for (int e = 2; e < 6; e++) { k1[e] = h * k1[e]; xt[e] = up[e] + T(0.5) * k1[e]; }
-    ang_s[4 * s + 1] = xt[ai];
-    v_s[4 * s + 1] = xt[vi];
+    pick(4 * s + 1, xt[ai], xt[vi]);
     upper_f(xt, k2);
 #pragma unroll
     for (int e = 2; e < 6; e++) { k2[e] = h * k2[e]; xt[e] = up[e] + T(0.5) * k2[e]; }
-    ang_s[4 * s + 2] = xt[ai];
-    v_s[4 * s + 2] = xt[vi];
+    pick(4 * s + 2, xt[ai], xt[vi]);
     upper_f(xt, k3);
 #pragma unroll
     for (int e = 2; e < 6; e++) { k3[e] = h * k3[e]; xt[e] = up[e] + k3[e]; }
-    ang_s[4 * s + 3] = xt[ai];
-    v_s[4 * s + 3] = xt[vi];
+    pick(4 * s + 3, xt[ai], xt[vi]);
     upper_f(xt, k4);
 #pragma unroll
     for (int e = 2; e < 6; e++) {
@@ -178,35 +183,32 @@ __device__ __forceinline__ void sub_integrate_lanes(int kind, T L, double interv
       up[e] += div_by(k1[e] + T(2.0) * (k2[e] + k3[e]) + k4[e], six, rsix);
     }
   }
-  const T my_v = sel8(v_s, q);
   // ---- 2./3. theta at the 8 stage points ----
-  T th_s[8];
+  T my_th = my_ang;  // unicycle: the angle integrated above is the heading itself
   if (car) {
-    const T tq = t_tan(sel8(ang_s, q));
+    const T tq = t_tan(my_ang);
     T tan_s[8];
 #pragma unroll
     for (int e = 0; e < 8; e++) tan_s[e] = shfl(tq, base + e);
     T th = x[2];
+    auto pick_th = [&](int idx, T v) { my_th = (q == idx) ? v : my_th; };
 #pragma unroll
     for (int s = 0; s < 2; s++) {
       const T k1 = h * (div_by(v_s[4 * s + 0], L, rL) * tan_s[4 * s + 0]);
-      th_s[4 * s + 0] = th;
-      th_s[4 * s + 1] = th + T(0.5) * k1;
+      pick_th(4 * s + 0, th);
+      pick_th(4 * s + 1, th + T(0.5) * k1);
       const T k2 = h * (div_by(v_s[4 * s + 1], L, rL) * tan_s[4 * s + 1]);
-      th_s[4 * s + 2] = th + T(0.5) * k2;
+      pick_th(4 * s + 2, th + T(0.5) * k2);
       const T k3 = h * (div_by(v_s[4 * s + 2], L, rL) * tan_s[4 * s + 2]);
-      th_s[4 * s + 3] = th + k3;
+      pick_th(4 * s + 3, th + k3);
       const T k4 = h * (div_by(v_s[4 * s + 3], L, rL) * tan_s[4 * s + 3]);
       th += div_by(k1 + T(2.0) * (k2 + k3) + k4, six, rsix);
     }
     up[2] = th;
-  } else {
-#pragma unroll
-    for (int e = 0; e < 8; e++) th_s[e] = ang_s[e];
   }
   // ---- 4. one sincos per lane ----
   T sn, cs;
-  t_sincos(sel8(th_s, q), &sn, &cs);
+  t_sincos(my_th, &sn, &cs);
   const T kxq = h * (my_v * cs);
   const T kyq = h * (my_v * sn);
   // ---- 5. positions ----
