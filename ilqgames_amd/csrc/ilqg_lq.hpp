@@ -606,323 +606,6 @@ __device__ __forceinline__ void lq_feedback_instance(const LQArgs<T>& a, const P
 }
 
 // ---------------------------------------------------------------------------
-// MFMA formulation of the same sweep for n <= 16 (one wavefront per instance).
-// Both Z_i and Z_i^T live in the MFMA accumulator layout (4 scalars per lane per player each);
-// every matrix product of the step is a chain of four v_mfma_*_16x16x4 on those registers
-// (ilqg_mfma.hpp: tile_xty(X, Y, C) = X^T Y + C):
-//     G        = [Z_0^T B_0 | Z_1^T B_1 | ...]           (B_i^T Z_i)^T, columns picked per player
-//     [S | Y]  = G^T [B | A]                              two 16-column tiles
-//     F        = A - B P        = (-B^T)^T P + A
-//     W_i      = Z_i F          = (Z_i^T)^T F
-//     Z_i'^T   = W_i^T F + C_i^T ,   Z_i' = F^T W_i + C_i
-//     Z_i beta = (Z_i^T)^T [beta in column i] ,  F^T [t_0 t_1 ...] for the zeta update
-// so the step has no LDS-broadcast FMAs, no cross-lane reductions and no re-layouts; LDS is only
-// the DMA image, the 6 x 21 [S | Y] bounce into the column-per-lane QR, and P/alpha/beta/zeta.
-// ---------------------------------------------------------------------------
-template <typename T, int NX, int NP, int MU>
-__device__ __forceinline__ void lq_feedback_instance_mfma(const LQArgs<T>& a, const PairTable& pt, T* sm) {
-  using C = LQCfg<T, NX, NP, MU>;
-  using TL = Tile<T>;
-  using vec = typename TL::vec;
-  constexpr int M = C::M, L = C::L, NT = C::NT, NS = C::NSOLVE;
-  static_assert(NT == 64, "MFMA sweep: one wavefront per instance");
-  static_assert(M <= 16 && NS <= 32, "the Nash system must fit two 16-column tiles");
-  const int t = threadIdx.x;
-  const int lane = t & 63, g = lane >> 4, j = lane & 15;
-  const bool zl = t < L;
-  const int pi = zl ? t / NX : 0;
-  const int pc = zl ? t % NX : 0;
-  const int Tn = a.T_steps;
-  const PairRegs<NP> pr(pt);
-  const bool want_fwd = a.dx != nullptr || a.ed_out != nullptr;
-  constexpr int SCR = C::SCR;
-  int rowi[4];
-#pragma unroll
-  for (int r = 0; r < 4; r++) rowi[r] = TL::row(g, r);
-  const vec zero4 = {T(0), T(0), T(0), T(0)};
-  // D-layout loads of a column-major block: element [row][col] = ptr[row + ld*col] / transposed
-  auto ldD = [&](const T* ptr, int ld, int nrows, int ncols) {
-    vec v;
-#pragma unroll
-    for (int r = 0; r < 4; r++) v[r] = (rowi[r] < nrows && j < ncols) ? ptr[rowi[r] + ld * j] : T(0);
-    return v;
-  };
-  auto ldDT = [&](const T* ptr, int ld, int nrows, int ncols) {  // [row][col] = ptr[col + ld*row]
-    vec v;
-#pragma unroll
-    for (int r = 0; r < 4; r++) v[r] = (rowi[r] < nrows && j < ncols) ? ptr[j + ld * rowi[r]] : T(0);
-    return v;
-  };
-
-  T *sB, *sA, *sQ, *sl, *sR, *sr;  // views into the image of the step being processed
-  auto set_img = [&](int which) {
-    T* img = sm + which * C::IMG;
-    sB = img + C::oB;
-    sA = img + C::oA;
-    sQ = img + C::oQ;
-    sl = img + C::ol;
-    sR = img + C::oR;
-    sr = img + C::or_;
-  };
-  int cur = 0;
-  T* sP = sm + C::oP;
-  T* sAl = sm + C::oAl;
-  T* sBeta = sm + C::oBeta;
-  T* sZeta = sm + C::oZeta;
-  T* sYz = sm + C::oYz;
-  T* sSY = sm + C::oSY;
-
-  // (Q_i l_i) of the step currently staged -> scratch, for ExpectedDecrease
-  auto stash_ql = [&](int k) {
-    if (want_fwd && zl) {
-      T s = T(0);
-#pragma unroll
-      for (int c = 0; c < NX; c++) s += sQ[pi * NX * NX + pc + NX * c] * sl[pi * NX + c];
-      a.scratch[size_t(k) * SCR + pi * NX + pc] = s;
-    }
-  };
-
-  // ---- terminal step: Z_i = Q_i[T-1], zeta_i = l_i[T-1]  (:102-105) ----
-  lq_stage_issue<T, NX, NP, MU>(a, pt, Tn - 1, sm, t);
-  dma_wait();
-  __syncthreads();
-  set_img(0);
-  vec Zd[NP], Yd[NP];
-#pragma unroll
-  for (int i = 0; i < NP; i++) {
-    Zd[i] = ldD(sQ + i * NX * NX, NX, NX, NX);
-    Yd[i] = ldDT(sQ + i * NX * NX, NX, NX, NX);
-  }
-  const T zeta0 = zl ? sl[pi * NX + pc] : T(0);
-  stash_ql(Tn - 1);
-  for (int e = t; e < M * NX; e += NT) a.P[size_t(Tn - 1) * M * NX + e] = T(0);
-  if (t < M) a.alpha[size_t(Tn - 1) * M + t] = T(0);
-  if (want_fwd) {
-    if (t < NP) a.scratch[size_t(Tn - 1) * SCR + NP * NX + t] = T(0);
-    if (t < NX) a.scratch[size_t(Tn - 1) * SCR + NP * (NX + 1) + t] = T(0);
-  }
-  if (Tn >= 2) lq_stage_issue<T, NX, NP, MU>(a, pt, Tn - 2, sm + C::IMG, t);
-  if (zl) sZeta[t] = zeta0;
-  dma_wait();
-  lds_sync(true);
-  cur = 1;
-  set_img(1);
-
-#pragma unroll 1
-  for (int k = Tn - 2; k >= 0; k--) {
-    long long pc0 = a.ph ? clock64() : 0, pc1;
-#define ILQG_PH(i) do { if (a.ph) { pc1 = clock64(); if (t == 0) a.ph[i] += pc1 - pc0; pc0 = pc1; } } while (0)
-    if (k > 0) lq_stage_issue<T, NX, NP, MU>(a, pt, k - 1, sm + (1 - cur) * C::IMG, t);
-    stash_ql(k);
-    ILQG_PH(0);
-
-    // ---- rows of the stacked Nash system: [S | Y] = (B_i^T Z_i)_i [B | A] ----
-    const vec Bd = ldD(sB, NX, NX, M);
-    const vec BA0 = ldD(sB, NX, NX, (M + NX < 16) ? M + NX : 16);      // columns 0..15 of [B | A]
-    const vec BA1 = ldD(sB + NX * 16, NX, NX, M + NX - 16);            // columns 16.. (empty if M+NX <= 16)
-    vec G = zero4;
-#pragma unroll
-    for (int i = 0; i < NP; i++) {
-      const vec Gi = tile_xty<T>(Zd[i], Bd, zero4);  // Z_i^T B
-#pragma unroll
-      for (int r = 0; r < 4; r++) G[r] = (j / MU == i) ? Gi[r] : G[r];
-    }
-    const vec SY0 = tile_xty<T>(G, BA0, zero4);
-    const vec SY1 = tile_xty<T>(G, BA1, zero4);
-#pragma unroll
-    for (int r = 0; r < 4; r++)
-      if (rowi[r] < M) {
-        sSY[rowi[r] + M * j] = SY0[r];
-        sSY[rowi[r] + M * (16 + j)] = SY1[r];
-      }
-    if (t < M) {  // y_zeta = B_i^T zeta_i + r_ii (:154-157)
-      const int i = t / MU, aa = t % MU;
-      T s = T(0);
-#pragma unroll
-      for (int r = 0; r < NX; r++) s += sB[r + NX * t] * sZeta[i * NX + r];
-      int rg_ii = 0;
-#pragma unroll
-      for (int e = 0; e < NP; e++) rg_ii = (i == e) ? pr.rg[e][e] : rg_ii;
-      sYz[t] = s + sr[rg_ii + aa];
-    }
-    lds_sync(true);
-    ILQG_PH(1);
-
-    // ---- column `t` of [S | Y]: + R_ii, Gershgorin (:163-176), Householder QR solve (:180) ----
-    {
-      T col[M], x[M];
-#pragma unroll
-      for (int r = 0; r < M; r++) {
-        col[r] = (t < M + NX) ? sSY[r + M * t] : ((t == M + NX) ? sYz[r] : T(0));
-        x[r] = T(0);
-      }
-      if (t < M) {
-        const int pj = t / MU, b = t % MU;
-        int ro_ii = 0;
-#pragma unroll
-        for (int e = 0; e < NP; e++) ro_ii = (pj == e) ? pr.ro[e][e] : ro_ii;
-        const T* Rii = sR + ro_ii;
-#pragma unroll
-        for (int r = 0; r < M; r++)
-          if (r / MU == pj) col[r] = col[r] + Rii[(r % MU) + MU * b];
-        if (a.adaptive) {  // columns are independent, so lane-parallel reproduces the sequential loop
-          T l1 = T(0), diag = T(0);
-#pragma unroll
-          for (int r = 0; r < M; r++) {
-            l1 += (col[r] < T(0) ? -col[r] : col[r]);
-            if (r == t) diag = col[r];
-          }
-          const T radius = l1 - (diag < T(0) ? -diag : diag);
-          const T eval_lo = diag - radius;
-          if (eval_lo < T(1e-3f)) {
-#pragma unroll
-            for (int r = 0; r < M; r++)
-              if (r == t) col[r] += radius + T(1e-3f);
-          }
-        }
-      }
-      qr_solve_columns<T, M>(col, lane, x);
-      if (t >= M && t < M + NX) {
-#pragma unroll
-        for (int r = 0; r < M; r++) {
-          sP[r + M * (t - M)] = x[r];
-          a.P[size_t(k) * M * NX + r + M * (t - M)] = x[r];
-        }
-      } else if (t == M + NX) {
-#pragma unroll
-        for (int r = 0; r < M; r++) {
-          sAl[r] = x[r];
-          a.alpha[size_t(k) * M + r] = x[r];
-        }
-      }
-    }
-    lds_sync(true);
-    ILQG_PH(2);
-
-    // ---- F = A - B P (:189-194) ----
-    const vec Pd = ldD(sP, M, M, NX);
-    vec nBT = ldDT(sB, NX, M, NX);  // B^T, negated below
-#pragma unroll
-    for (int r = 0; r < 4; r++) nBT[r] = -nBT[r];
-    const vec Ad = ldD(sA, NX, NX, NX);
-    const vec Fd = tile_xty<T>(nBT, Pd, Ad);
-    if (t < NX) {  // beta = -B alpha
-      T s = T(0);
-#pragma unroll
-      for (int q = 0; q < M; q++) s -= sB[t + NX * q] * sAl[q];
-      sBeta[t] = s;
-      if (want_fwd) a.scratch[size_t(k) * SCR + NP * (NX + 1) + t] = s;
-    }
-    if (want_fwd && t < NP) {
-      // alpha_i^T R_ii r_ii, evaluated (alpha^T R) r like Eigen (ilq_solver.cpp:384-386)
-      int ro_ii = 0, rg_ii = 0;
-#pragma unroll
-      for (int e = 0; e < NP; e++) {
-        ro_ii = (t == e) ? pr.ro[e][e] : ro_ii;
-        rg_ii = (t == e) ? pr.rg[e][e] : rg_ii;
-      }
-      T acc = T(0);
-#pragma unroll
-      for (int c = 0; c < MU; c++) {
-        T aR = T(0);
-#pragma unroll
-        for (int b = 0; b < MU; b++) aR += sAl[t * MU + b] * sR[ro_ii + b + MU * c];
-        acc += aR * sr[rg_ii + c];
-      }
-      a.scratch[size_t(k) * SCR + NP * NX + t] = acc;
-    }
-    lds_sync(true);
-    ILQG_PH(3);
-
-    // ---- per player: Z_i <- F^T Z_i F + Q_i + sum_jj P_jj^T R_i,jj P_jj  (:198-212), both layouts ----
-    vec TD = zero4;  // column i = zeta_i + Z_i beta
-#pragma unroll
-    for (int i = 0; i < NP; i++) {
-      const vec Wd = tile_xty<T>(Yd[i], Fd, zero4);  // Z_i F
-      vec BetaD;
-#pragma unroll
-      for (int r = 0; r < 4; r++) BetaD[r] = (j == i && rowi[r] < NX) ? sBeta[rowi[r]] : T(0);
-      const vec ZB = tile_xty<T>(Yd[i], BetaD, zero4);  // column i = Z_i beta
-#pragma unroll
-      for (int r = 0; r < 4; r++)
-        if (j == i && rowi[r] < NX) TD[r] = ZB[r] + sZeta[i * NX + rowi[r]];
-      vec Cd = ldD(sQ + i * NX * NX, NX, NX, NX);
-      vec CTd = ldDT(sQ + i * NX * NX, NX, NX, NX);
-#pragma unroll
-      for (int jj = 0; jj < NP; jj++) {
-        if (pr.q[i][jj] < 0) continue;
-        // + P_jj^T R_i,jj P_jj (and its transpose): H = R P_jj and H' = R^T P_jj sit in rows
-        // jj*MU.. of a tile, P_jj likewise, so both products are one MFMA chain each.
-        const T* Rij = sR + pr.ro[i][jj];
-        vec Pj, Hd, Htd;
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const int aa = rowi[r] - jj * MU;
-          const bool in = aa >= 0 && aa < MU && j < NX;
-          T h = T(0), ht = T(0);
-          if (in) {
-#pragma unroll
-            for (int b = 0; b < MU; b++) {
-              const T pb = sP[(jj * MU + b) + M * j];
-              h += Rij[aa + MU * b] * pb;
-              ht += Rij[b + MU * aa] * pb;
-            }
-          }
-          Pj[r] = in ? Pd[r] : T(0);
-          Hd[r] = h;
-          Htd[r] = ht;
-        }
-        Cd = tile_xty<T>(Pj, Hd, Cd);     // P_jj^T (R P_jj)
-        CTd = tile_xty<T>(Pj, Htd, CTd);  // P_jj^T (R^T P_jj) = (P_jj^T R P_jj)^T
-      }
-      Yd[i] = tile_xty<T>(Wd, Fd, CTd);  // (Z_i F)^T F + C_i^T
-      Zd[i] = tile_xty<T>(Fd, Wd, Cd);   // F^T (Z_i F) + C_i
-    }
-    const vec FT = tile_xty<T>(Fd, TD, zero4);  // column i = F^T (zeta_i + Z_i beta)
-    lds_sync(true);  // every read of the old zeta is done
-    ILQG_PH(4);
-    if (j < NP) {
-#pragma unroll
-      for (int r = 0; r < 4; r++)
-        if (rowi[r] < NX) sZeta[j * NX + rowi[r]] = FT[r];  // F^T (zeta_i + Z_i beta)
-    }
-    lds_sync(true);
-    if (zl) {  // + l_i + sum_jj P_jj^T (R_i,jj alpha_jj - r_i,jj)   (:198-201, 206-212)
-      T zn = sZeta[t] + sl[t];
-#pragma unroll
-      for (int i = 0; i < NP; i++) {
-        if (pi != i) continue;
-#pragma unroll
-        for (int jj = 0; jj < NP; jj++) {
-          if (pr.q[i][jj] < 0) continue;
-          const T* Rij = sR + pr.ro[i][jj];
-          const T* rij = sr + pr.rg[i][jj];
-          T add = T(0);
-#pragma unroll
-          for (int aa = 0; aa < MU; aa++) {
-            T w = T(0);
-#pragma unroll
-            for (int b = 0; b < MU; b++) w += Rij[aa + MU * b] * sAl[jj * MU + b];
-            add += sP[(jj * MU + aa) + M * pc] * (w - rij[aa]);
-          }
-          zn += add;
-        }
-      }
-      sZeta[t] = zn;
-    }
-    ILQG_PH(5);
-    dma_wait();
-    lds_sync(true);
-    cur = 1 - cur;
-    set_img(cur);
-    ILQG_PH(6);
-  }
-#undef ILQG_PH
-
-  lq_forward_pass<T, NX, NP, MU>(a, sm, t);
-}
-
-// ---------------------------------------------------------------------------
 // Player-parallel MFMA sweep: a workgroup of NP wavefronts per instance, wave i owns player i.
 //
 // The step's dependency chain is  [S|Y] rows  ->  M x M Nash solve  ->  F  ->  Z_i update; the first

@@ -87,14 +87,6 @@ template <typename T> __device__ __forceinline__ void t_sincos(T x, T* s, T* c);
 template <> __device__ __forceinline__ void t_sincos<float>(float x, float* s, float* c) { sincosf(x, s, c); }
 template <> __device__ __forceinline__ void t_sincos<double>(double x, double* s, double* c) { sincos(x, s, c); }
 
-template <typename T>
-__device__ __forceinline__ T sel8(const T (&a)[8], int q) {
-  T r = a[0];
-#pragma unroll
-  for (int e = 1; e < 8; e++) r = (q == e) ? a[e] : r;
-  return r;
-}
-
 // The same RK4 (2 sub-steps) as sub_integrate, restructured for the wavefront: the 8 stage
 // evaluations of one subsystem are spread over 8 lanes (`q` = this lane's stage, lanes
 // base..base+7 form the group) so that every transcendental leaves the dependent chain.

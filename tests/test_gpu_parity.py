@@ -216,6 +216,45 @@ def test_ilq_solve_matches_oracle_fp64(hip, oracle, cfg):
     assert np.isfinite(_np(out["xs"])).all() and set(_np(out["status"]).tolist()) <= {0, 1}
 
 
+
+@pytest.mark.parametrize("T,B", [(37, 3), (2, 1), (100, 65)])
+def test_ilq_solve_odd_horizons_and_batches_fp64(hip, oracle, T, B):
+    """Horizons that are not a multiple of anything the kernels stage in groups of (forward-pass groups of
+    6-8 steps, two waves sharing the rows) and batches of 1 / 3 / 65 instances: same parity bar."""
+    spec = examples.modified_three_player_intersection(T=T)
+    spec.params.initial_alpha_scaling = 0.5
+    spec.params.expected_decrease_fraction = 0.001
+    K = 3
+    x0 = examples.jittered_x0(spec, B, seed=5)
+    ref = oracle.OracleProblem(spec).solve(abi.F64, x0, fixed_iters=K, merit_log_len=K)
+    out = hip.Problem(spec, abi.F64).solve(x0, fixed_iters=K)
+    ok = _clean(ref)
+    assert len(ok) >= 1
+    assert np.array_equal(_np(out["iters"])[ok], ref["iters"][ok])
+    assert rel_err(_np(out["xs"])[ok], ref["xs"][ok]) < 1e-7
+    assert rel_err(_np(out["P"])[ok], ref["P"][ok]) < 1e-6
+    assert rel_err(_np(out["alpha"])[ok], ref["alpha"][ok]) < 1e-6
+    assert rel_err(_np(out["costs"])[ok], ref["costs"][ok]) < 1e-8
+
+
+def test_ilq_solve_fp32_tracks_fp64_oracle(hip, oracle):
+    """The fp32 instantiation (the reference's own precision) of the whole loop against the fp64 oracle: two
+    iterations from the same start stay within single-precision distance of it."""
+    spec = examples.modified_three_player_intersection()
+    spec.params.initial_alpha_scaling = 0.5
+    spec.params.expected_decrease_fraction = 0.001
+    B, K = 8, 2
+    x0 = examples.jittered_x0(spec, B, seed=9)
+    ref = oracle.OracleProblem(spec).solve(abi.F64, x0, fixed_iters=K, merit_log_len=K)
+    out = hip.Problem(spec, abi.F32).solve(x0.astype(np.float32), fixed_iters=K)
+    ok = _clean(ref)
+    same = np.array([b for b in ok if _np(out["iters"])[b] == ref["iters"][b]])
+    assert len(same) >= 2
+    assert rel_err(_np(out["xs"])[same].astype(np.float64), ref["xs"][same]) < 2e-3
+    assert rel_err(_np(out["costs"])[same].astype(np.float64), ref["costs"][same]) < 2e-2
+    assert np.isfinite(_np(out["P"])).all()
+
+
 def test_ilq_solve_free_running_matches_oracle_fp64(hip, oracle):
     """Reference semantics (convergence test + line-search failure) on the example's own params."""
     spec = examples.modified_three_player_intersection()
