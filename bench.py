@@ -149,6 +149,16 @@ def main():
         # with HIP events over the K rounds (profiles/: the two kernels' rocprofv3 averages add up to it).
         launch_bytes = bytes_iter * int(iters.sum())
         achieved = launch_bytes / kernel_s / 1e9
+        # HBM traffic per round from the committed PMC passes of this workload (bench.py cannot run rocprofv3
+        # on itself; scripts/profile.sh collects the counters, profiles/traffic.json holds their medians)
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")))
+            ent = tj.get("%s:%s:%d" % (args.config, args.dtype, B))
+            if ent:
+                traffic = ent["bytes_per_round"]
+        except (OSError, ValueError, KeyError):
+            traffic = None
         out = {
             "metric": "iLQ iterations/sec (batch)", "value": value, "unit": "instance-iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -161,7 +171,7 @@ def main():
             "gather_ms": gather_s * 1e3,
             "success_fraction": float(status.mean()),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "ilq_lq_kernel + ilq_trial_kernel (one round = one outer iteration of the batch)",
                          "launch_ms": kernel_s * 1e3 / max(1, args.steps),
                          "algorithmic_bytes_per_launch": launch_bytes / max(1, args.steps),
