@@ -849,36 +849,39 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
 
     // ---- wave 0: column `lane` of [S | Y]: + R_ii, Gershgorin (:163-176), then the M x M solve (:180) ----
     if (w == 0) {
+      // Written without divergent regions: every lane loads a column (lanes past the last right-hand side
+      // re-read y_zeta and are never stored), the R_ii and Gershgorin terms are added as value-or-zero.
       T col[M], x[M];
+      const bool isS = lane < M;
+      const T* src = (lane < M + NX) ? sSY + M * lane : sYz;
 #pragma unroll
       for (int r = 0; r < M; r++) {
-        col[r] = (lane < M + NX) ? sSY[r + M * lane] : ((lane == M + NX) ? sYz[r] : T(0));
+        col[r] = src[r];
         x[r] = T(0);
       }
-      if (lane < M) {
-        const int pj = lane / MU, b = lane % MU;
+      {
+        const int pj = isS ? lane / MU : 0, b = lane % MU;
         int ro_ii = 0;
 #pragma unroll
         for (int e = 0; e < NP; e++) ro_ii = (pj == e) ? pr.ro[e][e] : ro_ii;
         const T* Rii = sR + ro_ii;
 #pragma unroll
-        for (int r = 0; r < M; r++)
-          if (r / MU == pj) col[r] = col[r] + Rii[(r % MU) + MU * b];
-        if (a.adaptive) {  // columns are independent, so lane-parallel reproduces the sequential loop
-          T l1 = T(0), diag = T(0);
-#pragma unroll
-          for (int r = 0; r < M; r++) {
-            l1 += (col[r] < T(0) ? -col[r] : col[r]);
-            if (r == lane) diag = col[r];
-          }
-          const T radius = l1 - (diag < T(0) ? -diag : diag);
-          const T eval_lo = diag - radius;
-          if (eval_lo < T(1e-3f)) {
-#pragma unroll
-            for (int r = 0; r < M; r++)
-              if (r == lane) col[r] += radius + T(1e-3f);
-          }
+        for (int r = 0; r < M; r++) {
+          const T rv = Rii[(r % MU) + MU * b];
+          col[r] = col[r] + ((isS && r / MU == pj) ? rv : T(0));
         }
+        // Gershgorin (columns are independent, so lane-parallel reproduces the sequential loop)
+        T l1 = T(0), diag = T(0);
+#pragma unroll
+        for (int r = 0; r < M; r++) {
+          l1 += (col[r] < T(0) ? -col[r] : col[r]);
+          diag = (r == lane) ? col[r] : diag;
+        }
+        const T radius = l1 - (diag < T(0) ? -diag : diag);
+        const T eval_lo = diag - radius;
+        const T bump = (isS && a.adaptive && eval_lo < T(1e-3f)) ? radius + T(1e-3f) : T(0);
+#pragma unroll
+        for (int r = 0; r < M; r++) col[r] = col[r] + ((r == lane) ? bump : T(0));
       }
       if (a.adaptive)
         lu_solve_columns<T, M>(col, lane, x);
