@@ -154,6 +154,124 @@ __global__ void linquad_kernel(DevProblem p, QuadBatchArgs<T> g) {
     linquad_step<T>(p, tb, a, k, sm, threadIdx.x);
 }
 
+// Problem::SetUpNextRecedingHorizon for one instance per wavefront (see ilqg_receding_horizon_shift_batch).
+template <typename T>
+struct RecedingArgs {
+  const T* x0;
+  T *xs, *us, *P, *alpha, *x0_next;
+  int* first_step;
+  int itn_step;          // IntegrateToNextTimeStep: strategy index,
+  double itn_remaining;  // integration interval,
+  float itn_frac;        // interpolation weight of the reference state
+  int int_begin, int_end;  // whole plan steps integrated afterwards
+};
+
+template <typename T>
+__global__ void __launch_bounds__(64) receding_horizon_kernel(DevProblem p, RecedingArgs<T> a) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  T* sx = reinterpret_cast<T*>(smem_raw);  // [n] state being integrated
+  const int n = p.n, m = p.m, N = p.N, Tn = p.T;
+  T* su = sx + n;                           // [m]
+  const size_t b = blockIdx.x;
+  const int t = threadIdx.x;
+  T* xs = a.xs + b * Tn * n;
+  T* us = a.us + b * Tn * m;
+  T* P = a.P + b * Tn * m * n;
+  T* al = a.alpha + b * Tn * m;
+  // Strategy::operator() of every player at plan step k against the reference state `ref(c)` (strategy.h:73-76)
+  auto controls = [&](int k, bool interpolate) {
+    if (t < m) {
+      const T frac = T(a.itn_frac);
+      T s = T(0);
+      for (int c = 0; c < n; c++) {
+        T ref;
+        if (!interpolate)
+          ref = xs[size_t(k) * n + c];
+        else if (k + 1 < Tn)
+          ref = frac * xs[size_t(k) * n + c] + (T(1) - frac) * xs[size_t(k + 1) * n + c];
+        else
+          ref = xs[size_t(Tn - 1) * n + c];
+        s += P[(size_t(k) * n + c) * m + t] * (sx[c] - ref);
+      }
+      su[t] = (us[size_t(k) * m + t] - s) - al[size_t(k) * m + t];
+    }
+    __syncthreads();
+  };
+  // MultiPlayerDynamicalSystem::Integrate over `interval` with the controls in su (RK4, two sub-steps)
+  auto integrate = [&](double interval) {
+    if (t < N) {
+      const int xo = p.xoff[t], uo = p.uoff[t], xd = p.xoff[t + 1] - xo;
+      T xj[6];
+      for (int e = 0; e < 6; e++) xj[e] = e < xd ? sx[xo + e] : T(0);
+      sub_integrate<T>(p.sub_kind[t], T(p.sub_param[t]), interval, xj, su[uo], su[uo + 1]);
+      for (int e = 0; e < xd; e++) sx[xo + e] = xj[e];
+    }
+    __syncthreads();
+  };
+  if (t < n) sx[t] = a.x0[b * n + t];
+  __syncthreads();
+  controls(a.itn_step, true);  // IntegrateToNextTimeStep, multi_player_integrable_system.cpp:115-129
+  integrate(a.itn_remaining);
+  for (int kk = a.int_begin; kk < a.int_end; kk++) {  // Integrate(initial_timestep, final_timestep, ...), :76-93
+    controls(kk, false);
+    integrate(p.dt);
+  }
+  // nearest plan state by the first subsystem's position (concatenated_dynamical_system.cpp:109-113);
+  // std::min_element keeps the first minimum
+  T bestd = dinf<T>();
+  int bestk = 0x7fffffff;
+  for (int k = t; k < Tn; k += 64) {
+    const T dx = sx[0] - xs[size_t(k) * n + 0], dy = sx[1] - xs[size_t(k) * n + 1];
+    const T d = dx * dx + dy * dy;
+    if (d < bestd) {
+      bestd = d;
+      bestk = k;
+    }
+  }
+  for (int off = 32; off >= 1; off >>= 1) {
+    const T od = __shfl_xor(bestd, off, 64);
+    const int ok = __shfl_xor(bestk, off, 64);
+    if (od < bestd || (od == bestd && ok < bestk)) {
+      bestd = od;
+      bestk = ok;
+    }
+  }
+  const int first = bestk;
+  if (t == 0) a.first_step[b] = first;
+  // Stitch (concatenated_dynamical_system.h:75-84)
+  const int ego = p.xoff[1] - p.xoff[0];
+  if (t < n) a.x0_next[b * n + t] = t < ego ? xs[size_t(first) * n + t] : sx[t];
+  // what the tail starts from: the plan's last row (read before the shift moves things)
+  const int keep = Tn - first;
+  __syncthreads();
+  if (t < n) sx[t] = xs[size_t(Tn - 1) * n + t];
+  if (t < m) su[t] = us[size_t(Tn - 1) * m + t];
+  __syncthreads();
+  if (first > 0) {
+    // shift rows [first, T) to [0, keep) (:136-157): ascending rows, source row always ahead of the writes
+    for (int kk = 0; kk < keep; kk++) {
+      for (int e = t; e < n; e += 64) xs[size_t(kk) * n + e] = xs[size_t(kk + first) * n + e];
+      for (int e = t; e < m; e += 64) {
+        us[size_t(kk) * m + e] = us[size_t(kk + first) * m + e];
+        al[size_t(kk) * m + e] = al[size_t(kk + first) * m + e];
+      }
+      for (int e = t; e < m * n; e += 64) P[size_t(kk) * m * n + e] = P[size_t(kk + first) * m * n + e];
+    }
+    // zero strategies / controls of the tail and propagate the state through it (:170-184)
+    for (int kk = keep; kk < Tn; kk++) {
+      integrate(p.dt);  // xs[kk] = Integrate(dt, xs[kk-1], us[kk-1])
+      if (t < n) xs[size_t(kk) * n + t] = sx[t];
+      if (t < m) {
+        su[t] = T(0);
+        us[size_t(kk) * m + t] = T(0);
+        al[size_t(kk) * m + t] = T(0);
+      }
+      for (int e = t; e < m * n; e += 64) P[size_t(kk) * m * n + e] = T(0);
+      __syncthreads();
+    }
+  }
+}
+
 template <typename T>
 __global__ void costs_reduce_kernel(DevProblem p, const T* cost_part, T* costs, int* t_extreme, const int* active) {
   const size_t b = blockIdx.x;
@@ -986,6 +1104,52 @@ ilqg_status ilqg_al_solve_batch(ilqg_problem* p, int32_t batch, const void* x0, 
                                 void* alpha, void* total_costs, int32_t* iters, int32_t* status, int32_t* converged,
                                 void* workspace, void* stream) {
   return solve_impl(p, batch, x0, xs, us, P, alpha, total_costs, iters, status, converged, workspace, 0, 1, stream);
+}
+
+ilqg_status ilqg_receding_horizon_shift_batch(const ilqg_problem* p, int32_t batch, const void* x0, double t0,
+                                              double planner_runtime, double plan_t0, void* xs, void* us, void* P,
+                                              void* alpha, void* x0_next, int32_t* first_step,
+                                              double* new_plan_t0_host, void* stream) {
+  if (!p || !x0 || !xs || !us || !P || !alpha || !x0_next || !first_step) return fail(ILQG_ERR_INVALID, "null argument");
+  const DevProblem& d = p->dev;
+  const double dt = d.dt, horizon = dt * d.T;
+  // the reference's CHECKs (src/problem.cpp:68-70)
+  if (planner_runtime < 0.0 || planner_runtime + t0 > plan_t0 + horizon || t0 < plan_t0)
+    return fail(ILQG_ERR_INVALID, "receding horizon: t0 / planner_runtime outside the stored plan");
+  // SyncToExistingProblem's time bookkeeping (:75-102): identical for every instance of the batch
+  const float kRoundingError = 0.9f;
+  const double relative_t0 = t0 - plan_t0;
+  size_t current_timestep = static_cast<size_t>(relative_t0 / dt);
+  double remaining = (current_timestep + 1) * dt - relative_t0;
+  if (remaining < kRoundingError * dt) {
+    current_timestep += 1;
+    remaining = dt - remaining;
+  }
+  const size_t itn_step = static_cast<size_t>((relative_t0 + 1e-4f) / dt);  // IntegrateToNextTimeStep's own (:104-113)
+  if (itn_step >= size_t(d.T)) return fail(ILQG_ERR_INVALID, "receding horizon: t0 past the last plan step");
+  double new_t0 = t0 + remaining;
+  int int_begin = int(current_timestep) + 1, int_end = int_begin;
+  if (remaining <= planner_runtime) {
+    const size_t num_steps = static_cast<size_t>(1e-4f + (planner_runtime - remaining) / dt);
+    int_end = int(current_timestep + num_steps);
+    if (int_end < int_begin) int_end = int_begin;
+    new_t0 += dt * double(num_steps);
+  }
+  if (int_end > d.T) return fail(ILQG_ERR_INVALID, "receding horizon: integration runs past the plan");
+  if (new_plan_t0_host) *new_plan_t0_host = new_t0;
+  if (batch <= 0) return ILQG_OK;
+#define CALL(TY_)                                                                                                  \
+  [&]() -> ilqg_status {                                                                                         \
+    RecedingArgs<TY_> g{(const TY_*)x0, (TY_*)xs, (TY_*)us, (TY_*)P, (TY_*)alpha, (TY_*)x0_next, first_step,       \
+                        int(itn_step), dt * (itn_step + 1) - relative_t0, 0.0f, int_begin, int_end};               \
+    g.itn_frac = float(g.itn_remaining / dt);                                                                      \
+    hipLaunchKernelGGL(receding_horizon_kernel<TY_>, dim3(batch), dim3(64), (d.n + d.m) * sizeof(TY_),             \
+                       (hipStream_t)stream, d, g);                                                                 \
+    HIP_TRY(hipGetLastError());                                                                                  \
+    return ILQG_OK;                                                                                              \
+  }()
+  return DT_DISPATCH(p, CALL);
+#undef CALL
 }
 
 }  // extern "C"

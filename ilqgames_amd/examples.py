@@ -262,5 +262,6 @@ CONFIGS = {
     "modified_three_player_intersection": modified_three_player_intersection,
     "three_player_intersection": three_player_intersection,
     "roundabout_merging": roundabout_merging,
+    "roundabout_merging_T150": lambda: roundabout_merging(T=150),  # BASELINE.json config 4 (n=24, T=150, open loop)
     "three_player_collision_avoidance_reachability": three_player_collision_avoidance_reachability,
 }

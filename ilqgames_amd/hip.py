@@ -19,6 +19,7 @@ EXPORTS = [
     "ilqg_problem_destroy", "ilqg_workspace_bytes", "ilqg_rollout_batch", "ilqg_linearize_batch",
     "ilqg_quadraticize_batch", "ilqg_problem_pairs", "ilqg_total_costs_batch", "ilqg_ilq_solve_batch",
     "ilqg_last_error", "ilqg_abi_version", "ilqg_device_info", "ilqg_selftest_mfma", "ilqg_al_solve_batch",
+    "ilqg_receding_horizon_shift_batch",
 ]
 
 
@@ -205,3 +206,18 @@ class Problem:
                                           _ptr(bufs["status"]), _ptr(bufs["converged"]), _ptr(bufs["ws"]),
                                           int(fixed_iters), _stream()))
         return bufs
+
+    def receding_horizon_shift(self, x0, t0, planner_runtime, plan_t0, bufs):
+        """ilqg_receding_horizon_shift_batch: turns the solution in `bufs` (xs, us, P, alpha) into the warm start
+        of the next receding-horizon solve, in place.  Returns (x0_next, first_step, new_plan_t0)."""
+        import torch
+        x0 = _dev(x0, self.dtype)
+        B = x0.shape[0]
+        x0_next = torch.empty_like(x0)
+        first = torch.zeros(B, dtype=torch.int32, device="cuda")
+        new_t0 = C.c_double(0.0)
+        _check(lib().ilqg_receding_horizon_shift_batch(self.h, B, _ptr(x0), C.c_double(t0), C.c_double(planner_runtime),
+                                                       C.c_double(plan_t0), _ptr(bufs["xs"]), _ptr(bufs["us"]),
+                                                       _ptr(bufs["P"]), _ptr(bufs["alpha"]), _ptr(x0_next), _ptr(first),
+                                                       C.byref(new_t0), _stream()))
+        return x0_next, first, new_t0.value

@@ -313,6 +313,24 @@ ilqg_status ilqg_al_solve_batch(ilqg_problem* p, int32_t batch, const void* x0,
                                 int32_t* status, int32_t* converged,
                                 void* workspace, void* stream);
 
+/* Replaces Problem::SetUpNextRecedingHorizon (src/problem.cpp:127-186) with Problem::SyncToExistingProblem
+ * (:64-125) and the integrators of src/multi_player_integrable_system.cpp:76-130, for `batch` plans that share
+ * one time base: the measured state is integrated forward under the stored strategies by ~planner_runtime, the
+ * nearest plan state is found (first subsystem's position distance), the plan is shifted to start there, the
+ * tail gets zero strategies / controls and is re-propagated.
+ *  x0          [B][n]   measured state at absolute time t0
+ *  t0, planner_runtime  the reference's arguments;  plan_t0 = OperatingPoint::t0 of the stored plan
+ *  xs, us, P, alpha     in: stored plan (previous solution);  out: warm start of the next solve
+ *  x0_next     [B][n]   out: Problem::x0_ of the next solve (Stitch of the nearest plan state and the integrated one)
+ *  first_step  [B] int32 out: first_timestep_in_new_problem
+ *  new_plan_t0_host     out (host): OperatingPoint::t0 of the shifted plan
+ * Invalid times (t0 before the plan, t0 + planner_runtime past its horizon: the reference's CHECKs) return
+ * ILQG_ERR_INVALID. */
+ilqg_status ilqg_receding_horizon_shift_batch(const ilqg_problem* p, int32_t batch, const void* x0, double t0,
+                                              double planner_runtime, double plan_t0, void* xs, void* us,
+                                              void* P, void* alpha, void* x0_next, int32_t* first_step,
+                                              double* new_plan_t0_host, void* stream);
+
 /* Diagnostics: out = X^T Y + C for 16x16 column-major device matrices, computed through the
  * MFMA accumulator-layout path the LQ sweep is built on (pins the gfx950 register layouts). */
 ilqg_status ilqg_selftest_mfma(int32_t dtype, const void* X, const void* Y, const void* C, void* out, void* stream);

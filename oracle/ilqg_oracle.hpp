@@ -1426,4 +1426,110 @@ bool SolveAL(const Problem<S>& p, const Vec<S>& x0, Trajectory<S>* op_io, Strate
   return success;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Receding-horizon warm start: Problem::SyncToExistingProblem (src/problem.cpp:64-125) and
+// Problem::SetUpNextRecedingHorizon (:127-186), with the integrators of
+// src/multi_player_integrable_system.cpp:76-130.
+// The time bookkeeping (which step the measured state falls in, how long to integrate) depends only on
+// (t0, planner_runtime, plan t0), so it is computed once for a batch; everything state-dependent is per
+// instance.
+// ---------------------------------------------------------------------------------------------
+struct RecedingHorizonTimes {
+  int itn_step;          // timestep IntegrateToNextTimeStep reads the strategy from (:106-110)
+  double itn_remaining;  // its integration interval (:111-112)
+  float itn_frac;        // interpolation weight of x0_ref (:117)
+  int integrate_begin, integrate_end;  // whole steps [begin, end) integrated afterwards (:95-101); begin == end: none
+  double new_plan_t0;    // OperatingPoint::t0 of the shifted plan (:92, :102)
+};
+inline RecedingHorizonTimes RecedingHorizonTimesOf(double t0, double planner_runtime, double plan_t0, double dt) {
+  RecedingHorizonTimes r;
+  // SyncToExistingProblem :75-85
+  const float kRoundingError = 0.9f;
+  const double relative_t0 = t0 - plan_t0;
+  size_t current_timestep = static_cast<size_t>(relative_t0 / dt);
+  double remaining = (current_timestep + 1) * dt - relative_t0;
+  if (remaining < kRoundingError * dt) {
+    current_timestep += 1;
+    remaining = dt - remaining;
+  }
+  // IntegrateToNextTimeStep recomputes its own step and interval (multi_player_integrable_system.cpp:104-113)
+  const size_t itn_step = static_cast<size_t>((relative_t0 + 1e-4f) / dt);
+  r.itn_step = int(itn_step);
+  r.itn_remaining = dt * (itn_step + 1) - relative_t0;
+  r.itn_frac = float(r.itn_remaining / dt);
+  r.new_plan_t0 = t0 + remaining;
+  r.integrate_begin = r.integrate_end = int(current_timestep) + 1;
+  if (remaining <= planner_runtime) {
+    const size_t num_steps = static_cast<size_t>(1e-4f + (planner_runtime - remaining) / dt);
+    r.integrate_end = int(current_timestep + num_steps);
+    if (r.integrate_end < r.integrate_begin) r.integrate_end = r.integrate_begin;  // Integrate(a, b): empty loop
+    r.new_plan_t0 += dt * double(num_steps);
+  }
+  return r;
+}
+
+// Strategy::operator() for all players at step k (strategy.h:73-76): u = u_ref - P (x - x_ref) - alpha
+template <class S>
+inline Vec<S> ApplyStrategies(const Problem<S>& p, const Strategies<S>& st, int k, const Vec<S>& x, const Vec<S>& x_ref,
+                              const Vec<S>& u_ref) {
+  Vec<S> dx(p.n);
+  for (int e = 0; e < p.n; e++) dx[e] = x[e] - x_ref[e];
+  const Vec<S> Pdx = matvec(st.P[k], dx);
+  Vec<S> u(p.m);
+  for (int a = 0; a < p.m; a++) u[a] = u_ref[a] - Pdx[a] - st.alpha[k][a];
+  return u;
+}
+
+// Returns first_timestep_in_new_problem; x0_next = the next solve's initial state; op / st are shifted in place.
+template <class S>
+int RecedingHorizonShift(const Problem<S>& p, const RecedingHorizonTimes& tm, const Vec<S>& x0, Trajectory<S>* op,
+                         Strategies<S>* st, Vec<S>* x0_next) {
+  const int T = p.T, n = p.n, m = p.m;
+  // IntegrateToNextTimeStep (:115-129)
+  const int ks = tm.itn_step;
+  Vec<S> x0_ref(n);
+  if (ks + 1 < T) {
+    const S frac = S(tm.itn_frac);
+    for (int e = 0; e < n; e++) x0_ref[e] = frac * op->xs[ks][e] + (S(1) - frac) * op->xs[ks + 1][e];
+  } else {
+    x0_ref = op->xs[T - 1];
+  }
+  Vec<S> x = Integrate(p, 0.0, tm.itn_remaining, x0, ApplyStrategies(p, *st, ks, x0, x0_ref, op->us[ks]), false);
+  // Integrate(initial_timestep, final_timestep, ...) (:76-93)
+  for (int kk = tm.integrate_begin; kk < tm.integrate_end; kk++)
+    x = Integrate(p, 0.0, p.dt, x, ApplyStrategies(p, *st, kk, x, op->xs[kk], op->us[kk]), false);
+  // nearest plan state: ConcatenatedDynamicalSystem::DistanceBetween looks at the first subsystem only
+  // (concatenated_dynamical_system.cpp:109-113); the car / unicycle models measure squared position distance
+  int first = 0;
+  S best = std::numeric_limits<S>::infinity();
+  for (int k = 0; k < T; k++) {
+    const S dx = x[0] - op->xs[k][0], dy = x[1] - op->xs[k][1];
+    const S d = dx * dx + dy * dy;
+    if (d < best) {  // std::min_element keeps the first minimum
+      best = d;
+      first = k;
+    }
+  }
+  // Stitch (concatenated_dynamical_system.h:75-84): ego block from the plan, the rest from the integration
+  *x0_next = x;
+  const int ego = p.xoff[1] - p.xoff[0];
+  for (int e = 0; e < ego; e++) (*x0_next)[e] = op->xs[first][e];
+  // shift (:136-157), then zero strategies / controls and re-propagate the tail (:170-184)
+  const int keep = T - first;
+  for (int kk = 0; kk < keep; kk++) {
+    op->xs[kk] = op->xs[kk + first];
+    op->us[kk] = op->us[kk + first];
+    st->P[kk] = st->P[kk + first];
+    st->alpha[kk] = st->alpha[kk + first];
+  }
+  for (int kk = keep; kk < T; kk++) {
+    st->P[kk].setZero();
+    for (auto& v : st->alpha[kk]) v = S(0);
+    for (auto& v : op->us[kk]) v = S(0);
+    op->xs[kk] = Integrate(p, 0.0, p.dt, op->xs[kk - 1], op->us[kk - 1], false);
+  }
+  return first;
+}
+
 }  // namespace oracle

@@ -280,6 +280,27 @@ void SolveBatch(const OracleProblem* op, int batch, const void* x0, void* xs, vo
 
 }  // namespace
 
+template <class S>
+void RecedingHorizonBatch(const OracleProblem* op, int batch, const void* x0, double t0, double planner_runtime,
+                          double plan_t0, void* xs, void* us, void* P, void* alpha, void* x0_next, int32_t* first_step,
+                          double* new_plan_t0) {
+  const Problem<S>& p = Get<S>(op);
+  const int T = p.T, n = p.n, m = p.m;
+  const RecedingHorizonTimes tm = RecedingHorizonTimesOf(t0, planner_runtime, plan_t0, p.dt);
+  if (new_plan_t0) *new_plan_t0 = tm.new_plan_t0;
+  for (int b = 0; b < batch; b++) {
+    Trajectory<S> tr;
+    Strategies<S> st;
+    UnpackTraj(p, T, (S*)xs + size_t(b) * T * n, (S*)us + size_t(b) * T * m, &tr);
+    UnpackStrategies(p, T, (S*)P + size_t(b) * T * m * n, (S*)alpha + size_t(b) * T * m, &st);
+    Vec<S> x0v((const S*)x0 + size_t(b) * n, (const S*)x0 + size_t(b + 1) * n), xn;
+    first_step[b] = RecedingHorizonShift(p, tm, x0v, &tr, &st, &xn);
+    PackTraj(p, tr, (S*)xs + size_t(b) * T * n, (S*)us + size_t(b) * T * m);
+    PackStrategies(p, st, (S*)P + size_t(b) * T * m * n, (S*)alpha + size_t(b) * T * m);
+    std::memcpy((S*)x0_next + size_t(b) * n, xn.data(), sizeof(S) * n);
+  }
+}
+
 extern "C" {
 
 int oracle_lq_feedback(const ilqg_dims* d, const void* A, const void* Bm, const void* Q, const void* l,
@@ -350,6 +371,14 @@ void oracle_ilq_solve(void* h, int dtype, int batch, const void* x0, void* xs, v
                       void* rawP, void* rawAlpha, void* merit_log, int merit_log_len, int threads) {
   DISPATCH(dtype, SolveBatch, (OracleProblem*)h, batch, x0, xs, us, P, alpha, costs, iters, status, converged,
            fixed_iters, rawP, rawAlpha, merit_log, merit_log_len, threads);
+}
+
+// Problem::SetUpNextRecedingHorizon for a batch of plans sharing one time base.
+void oracle_receding_horizon_shift(void* h, int dtype, int batch, const void* x0, double t0, double planner_runtime,
+                                   double plan_t0, void* xs, void* us, void* P, void* alpha, void* x0_next,
+                                   int32_t* first_step, double* new_plan_t0) {
+  DISPATCH(dtype, RecedingHorizonBatch, (OracleProblem*)h, batch, x0, t0, planner_runtime, plan_t0, xs, us, P, alpha,
+           x0_next, first_step, new_plan_t0);
 }
 
 // xdot = f(x, u) and one Integrate step (double I/O regardless of dtype, for the

@@ -147,6 +147,21 @@ class OracleProblem:
         return dict(xs=xs, us=us, P=P, alpha=alpha, costs=costs, iters=iters, status=status, converged=conv,
                     rawP=rawP, rawAlpha=rawA, log=ml)
 
+    def receding_horizon_shift(self, dtype, x0, t0, planner_runtime, plan_t0, xs, us, P, alpha):
+        """Problem::SetUpNextRecedingHorizon per instance.  Returns dict(xs, us, P, alpha, x0_next, first_step,
+        new_plan_t0); inputs are not modified."""
+        dt = _np(dtype)
+        B = x0.shape[0]
+        a = [np.ascontiguousarray(v, dtype=dt).copy() for v in (xs, us, P, alpha)]
+        x0 = np.ascontiguousarray(x0, dtype=dt)
+        x0n = np.zeros((B, self.n), dt)
+        first = np.zeros(B, np.int32)
+        npt = C.c_double(0.0)
+        lib().oracle_receding_horizon_shift(self.h, dtype, B, _p(x0), C.c_double(t0), C.c_double(planner_runtime),
+                                            C.c_double(plan_t0), _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), _p(x0n),
+                                            _p(first), C.byref(npt))
+        return dict(xs=a[0], us=a[1], P=a[2], alpha=a[3], x0_next=x0n, first_step=first, new_plan_t0=npt.value)
+
     def dynamics(self, dtype, x, u, euler=False):
         x = np.ascontiguousarray(x, np.float64)
         u = np.ascontiguousarray(u, np.float64)

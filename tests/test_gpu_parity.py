@@ -298,3 +298,53 @@ def test_augmented_lagrangian_solve_matches_oracle_fp64(hip, oracle):
     assert len(good) >= 0.5 * len(same), err
     assert rel_err(_np(out["costs"])[good], ref["costs"][good]) < 1e-6
     assert np.isfinite(_np(out["xs"])).all()
+
+
+@pytest.mark.parametrize("t0,runtime", [(0.33, 0.25), (0.0, 0.1), (1.07, 0.0), (2.5, 0.4)])
+def test_receding_horizon_shift_matches_oracle_fp64(hip, oracle, t0, runtime):
+    """Problem::SetUpNextRecedingHorizon on device vs the oracle's restatement: same nearest-state index, same
+    shifted / zero-extended / re-propagated plan, same stitched initial state; then the warm-started solve from
+    it reproduces the oracle's."""
+    spec = examples.modified_three_player_intersection()
+    spec.params.initial_alpha_scaling = 0.5
+    spec.params.expected_decrease_fraction = 0.001
+    B = 6
+    x0 = examples.jittered_x0(spec, B, seed=21)
+    prob = hip.Problem(spec, abi.F64)
+    bufs = prob.solve(x0, fixed_iters=3)
+    plan = {k: _np(bufs[k]).copy() for k in ("xs", "us", "P", "alpha")}
+    # a measured state near where the plan says the players are at t0, perturbed
+    k_meas = int(t0 / spec.dt)
+    rng = np.random.default_rng(4)
+    x_meas = plan["xs"][:, k_meas, :] + 0.05 * rng.standard_normal((B, prob.n))
+    ref = oracle.OracleProblem(spec).receding_horizon_shift(abi.F64, x_meas, t0, runtime, 0.0, plan["xs"], plan["us"],
+                                                            plan["P"], plan["alpha"])
+    x0n, first, new_t0 = prob.receding_horizon_shift(x_meas, t0, runtime, 0.0, bufs)
+    assert np.array_equal(_np(first), ref["first_step"])
+    assert abs(new_t0 - ref["new_plan_t0"]) < 1e-12 and abs(t0 + runtime - new_t0) <= spec.dt + 1e-9
+    assert rel_err(_np(x0n), ref["x0_next"]) < 1e-12
+    for k in ("xs", "us", "P", "alpha"):
+        assert rel_err(_np(bufs[k]), ref[k]) < 1e-12, k
+    # zero strategies in the re-propagated tail, as the reference leaves them
+    f = int(ref["first_step"][0])
+    if f > 0:
+        assert np.all(_np(bufs["P"])[0, prob.T - f:] == 0) and np.all(_np(bufs["us"])[0, prob.T - f:] == 0)
+    # the next solve, warm-started from the shifted plan, agrees with the oracle's
+    nxt = oracle.OracleProblem(spec).solve(abi.F64, ref["x0_next"], xs=ref["xs"], us=ref["us"], P=ref["P"],
+                                           alpha=ref["alpha"], fixed_iters=2, merit_log_len=2)
+    out = prob.solve(x0n, bufs, fixed_iters=2)
+    ok = _clean(nxt)
+    assert len(ok) >= 2
+    assert rel_err(_np(out["xs"])[ok], nxt["xs"][ok]) < 1e-7
+    assert rel_err(_np(out["P"])[ok], nxt["P"][ok]) < 1e-6
+
+
+def test_receding_horizon_shift_rejects_times_outside_the_plan(hip):
+    spec = examples.modified_three_player_intersection()
+    prob = hip.Problem(spec, abi.F64)
+    x0 = examples.jittered_x0(spec, 2, seed=1)
+    bufs = prob.solve(x0, fixed_iters=1)
+    with pytest.raises(hip.IlqgError):
+        prob.receding_horizon_shift(x0, -0.5, 0.1, 0.0, bufs)   # t0 before the plan (problem.cpp:70)
+    with pytest.raises(hip.IlqgError):
+        prob.receding_horizon_shift(x0, 9.95, 0.2, 0.0, bufs)   # t0 + runtime past the horizon (:69)
