@@ -548,6 +548,72 @@ class DeviceSolve {
 }  // namespace host
 
 // ------------------------------------------------------------------------------------------
+// Receding horizon
+// ------------------------------------------------------------------------------------------
+void Problem::SetUpNextRecedingHorizon(const VectorXf& x0, Time t0, Time planner_runtime) {
+  using namespace host;
+  CHECK(initialized_);
+  const ilqg_dtype dtype = Options().dtype;
+  ProblemDescription description;
+  std::string why;
+  CHECK(DescribeProblem(*this, SolverParams(), dtype, &description, &why)) << why;
+  ilqg_problem* handle = nullptr;
+  CHECK_EQ(ilqg_problem_create(&description.desc, &handle), ILQG_OK) << ilqg_last_error();
+  const int n = dynamics_->XDim(), m = dynamics_->TotalUDim(), N = dynamics_->NumPlayers();
+  const int T = static_cast<int>(operating_point_->xs.size());
+  CHECK_EQ(T, description.desc.T);
+  std::vector<float> xs(T * n), us(T * m), P(T * m * n), alpha(T * m);
+  for (int k = 0; k < T; k++) {
+    std::memcpy(&xs[k * n], operating_point_->xs[k].data(), n * sizeof(float));
+    int row = 0;
+    for (int i = 0; i < N; i++) {
+      const int mi = dynamics_->UDim(i);
+      std::memcpy(&us[k * m + row], operating_point_->us[k][i].data(), mi * sizeof(float));
+      std::memcpy(&alpha[k * m + row], (*strategies_)[i].alphas[k].data(), mi * sizeof(float));
+      for (int c = 0; c < n; c++)
+        for (int r = 0; r < mi; r++) P[(k * n + c) * m + row + r] = (*strategies_)[i].Ps[k](r, c);
+      row += mi;
+    }
+  }
+  DeviceBuffer dx0, dxs, dus, dP, dal, dxn, dfirst;
+  Upload(&dx0, std::vector<float>(x0.data(), x0.data() + n), dtype);
+  Upload(&dxs, xs, dtype);
+  Upload(&dus, us, dtype);
+  Upload(&dP, P, dtype);
+  Upload(&dal, alpha, dtype);
+  dxn.Reserve(n * ElemBytes(dtype));
+  dfirst.Reserve(sizeof(int32_t));
+  double new_t0 = 0.0;
+  // times outside the stored plan abort in the reference (CHECKs at src/problem.cpp:68-70); same here
+  const ilqg_status s = ilqg_receding_horizon_shift_batch(handle, 1, dx0.get(), t0, planner_runtime, operating_point_->t0,
+                                                          dxs.get(), dus.get(), dP.get(), dal.get(), dxn.get(),
+                                                          static_cast<int32_t*>(dfirst.get()), &new_t0, nullptr);
+  CHECK_EQ(s, ILQG_OK) << ilqg_last_error();
+  HipCheck(hipDeviceSynchronize(), "receding horizon");
+  xs = Download(dxs, xs.size(), dtype);
+  us = Download(dus, us.size(), dtype);
+  P = Download(dP, P.size(), dtype);
+  alpha = Download(dal, alpha.size(), dtype);
+  const std::vector<float> xn = Download(dxn, n, dtype);
+  ilqg_problem_destroy(handle);
+  for (int k = 0; k < T; k++) {
+    std::memcpy(operating_point_->xs[k].data(), &xs[k * n], n * sizeof(float));
+    int row = 0;
+    for (int i = 0; i < N; i++) {
+      const int mi = dynamics_->UDim(i);
+      std::memcpy(operating_point_->us[k][i].data(), &us[k * m + row], mi * sizeof(float));
+      std::memcpy((*strategies_)[i].alphas[k].data(), &alpha[k * m + row], mi * sizeof(float));
+      for (int c = 0; c < n; c++)
+        for (int r = 0; r < mi; r++) (*strategies_)[i].Ps[k](r, c) = P[(k * n + c) * m + row + r];
+      row += mi;
+    }
+  }
+  x0_ = VectorXf::Zero(n);
+  std::memcpy(x0_.data(), xn.data(), n * sizeof(float));
+  operating_point_->t0 = new_t0;
+}
+
+// ------------------------------------------------------------------------------------------
 // Solvers
 // ------------------------------------------------------------------------------------------
 GameSolver::GameSolver(const std::shared_ptr<Problem>& problem, const SolverParams& params,

@@ -635,6 +635,10 @@ class Problem {
     CHECK(initialized_);
     x0_ = x0;
   }
+  // Receding-horizon re-sync (src/problem.cpp:127-186): integrates x0 forward under the stored strategies by about
+  // planner_runtime, re-anchors the stored plan at the nearest state, zero-extends and re-propagates its tail, and
+  // sets InitialState() / InitialTime() for the next solve.  Runs on the device (ilqg_receding_horizon_shift_batch).
+  virtual void SetUpNextRecedingHorizon(const VectorXf& x0, Time t0, Time planner_runtime = 0.1);
   virtual void OverwriteSolution(const OperatingPoint& operating_point, const std::vector<Strategy>& strategies);
   bool IsConstrained() const;
   virtual Time InitialTime() const { return operating_point_->t0; }

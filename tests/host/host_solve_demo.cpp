@@ -253,6 +253,26 @@ int main(int argc, char** argv) {
     os << std::setprecision(9) << "x0 " << problem->InitialState() << "\n";
     WriteLog(os, *log, success);
 
+    // receding horizon: adopt the solution, re-sync to a measured state 0.33 s into the plan
+    {
+      auto rh_problem = std::make_shared<MergeScene>(false);
+      rh_problem->Initialize();
+      rh_problem->OverwriteSolution(log->FinalOperatingPoint(), log->FinalStrategies());
+      VectorXf x_meas = log->FinalOperatingPoint().xs[3];
+      for (int e = 0; e < x_meas.size(); e++) x_meas(e) += 0.02f * static_cast<float>((e % 3) - 1);
+      rh_problem->SetUpNextRecedingHorizon(x_meas, 0.33, 0.25);
+      std::ofstream orh(outdir + "/receding.txt");
+      orh << std::setprecision(9) << "x_meas " << x_meas << "\nt0 " << rh_problem->InitialTime() << "\nx0 "
+          << rh_problem->InitialState() << "\n";
+      const OperatingPoint& op = rh_problem->CurrentOperatingPoint();
+      for (size_t k = 0; k < op.xs.size(); k++) {
+        orh << "x " << op.xs[k] << "\n";
+        orh << "u";
+        for (const auto& u : op.us[k]) orh << " " << u;
+        orh << "\n";
+      }
+    }
+
     std::vector<VectorXf> x0s;
     for (int b = 0; b < 6; b++) {
       VectorXf x0 = problem->InitialState();

@@ -127,6 +127,28 @@ def test_cpp_ilq_solver_single_solve_matches_oracle(demo_out, oracle):
 
 
 @pytest.mark.gpu
+def test_cpp_receding_horizon_resync_matches_oracle(demo_out, oracle):
+    """Problem::SetUpNextRecedingHorizon through the C++ mirror (float containers, fp64 device) against the
+    oracle's restatement applied to the same solved plan."""
+    got = _parse_log(os.path.join(demo_out, "ilq_single.txt"))
+    spec, ref = _oracle_solve(oracle, os.path.join(demo_out, "scene.txt"), got["x0"])
+    rows = {}
+    for line in open(os.path.join(demo_out, "receding.txt")):
+        tok = line.split()
+        rows.setdefault(tok[0], []).append([float(v) for v in tok[1:]])
+    x_meas = np.array(rows["x_meas"][0])
+    # the C++ side adopted the float-rounded device solution; do the same with the oracle's plan
+    f32 = lambda a: a.astype(np.float32).astype(np.float64)
+    o = oracle.OracleProblem(spec).receding_horizon_shift(abi.F64, x_meas[None, :], 0.33, 0.25, 0.0, f32(ref["xs"]),
+                                                          f32(ref["us"]), f32(ref["P"]), f32(ref["alpha"]))
+    assert abs(rows["t0"][0][0] - o["new_plan_t0"]) < 1e-6
+    assert np.max(np.abs(np.array(rows["x0"][0]) - o["x0_next"][0])) < 2e-4
+    assert np.max(np.abs(np.array(rows["x"]) - o["xs"][0])) < 2e-4 * max(1.0, np.max(np.abs(o["xs"])))
+    assert np.max(np.abs(np.array(rows["u"]) - o["us"][0])) < 2e-4 * max(1.0, np.max(np.abs(o["us"])))
+    assert int(o["first_step"][0]) > 0
+
+
+@pytest.mark.gpu
 def test_cpp_solve_batch_matches_oracle_per_instance(demo_out, oracle):
     for b in range(6):
         got = _parse_log(os.path.join(demo_out, "ilq_batch_%d.txt" % b))
