@@ -35,8 +35,14 @@ struct OLCfg {
   static constexpr int rm = rM + NP * NX * NX;
   static constexpr int rql = rm + NP * NX;
   static constexpr int ROW = (rql + NP * NX + 3) & ~3;
-  // LDS (elements): two DMA images, then working set
-  static constexpr int oM = 2 * C::IMG;
+  // LDS (elements): DMA image(s), then working set.  Two images (DMA of step k-1 under step k) when that keeps
+  // the instance under ~48 KB; the n = 24 problems would take 92 KB and leave a CU with a single resident
+  // instance (two waves on four SIMDs), so they run single-buffered: a step there is ~40 us, the exposed DMA
+  // round trip ~1 us, and three instances per CU are worth far more than the overlap.
+  static constexpr int FS_ = ROW + NP * NX * NX + NP * NX + 4;
+  static constexpr bool DB = (2 * (C::IMG > FS_ ? C::IMG : FS_) + NP * NX * NX + 2 * NX * NX) * int(sizeof(T)) <= 48 * 1024;
+  static constexpr int NB = DB ? 2 : 1;
+  static constexpr int oM = NB * C::IMG;
   static constexpr int om = oM + NP * NX * NX;
   static constexpr int oW = om + NP * NX;
   static constexpr int ow = oW + M * NX;
@@ -47,8 +53,8 @@ struct OLCfg {
   static constexpr int oT = oy + NX;
   static constexpr int LDS_BWD = oT + NP * NX;
   // forward pass: overlays the backward working set — two staged scratch rows, then x, x+, it, alpha
-  static constexpr int FS = ROW + NP * NX * NX + NP * NX + 4;
-  static constexpr int fxs = 2 * FS;
+  static constexpr int FS = FS_;
+  static constexpr int fxs = NB * FS;
   static constexpr int fT = fxs + 2 * NX;
   static constexpr int fg = fT + NP * NX;
   static constexpr int LDS_FWD = fg + M;
@@ -149,15 +155,23 @@ __device__ __forceinline__ void lq_openloop_instance(const LQArgs<T>& a, const P
   for (int e = t; e < NP * NX; e += NT) smv[e] = sl[e];
   lds_sync(NT <= 64);
   store_value_row(Tn - 1);
-  if (Tn >= 2) lq_stage_issue<T, NX, NP, MU>(a, pt, Tn - 2, sm + C::IMG, t);
-  dma_wait();
-  lds_sync(NT <= 64);
-  cur = 1;
-  set_img(1);
+  if (O::DB) {
+    if (Tn >= 2) lq_stage_issue<T, NX, NP, MU>(a, pt, Tn - 2, sm + C::IMG, t);
+    dma_wait();
+    lds_sync(NT <= 64);
+    cur = 1;
+  } else {
+    lds_sync(NT <= 64);  // every read of the terminal image is done
+    if (Tn >= 2) lq_stage_issue<T, NX, NP, MU>(a, pt, Tn - 2, sm, t);
+    dma_wait();
+    lds_sync(NT <= 64);
+    cur = 0;
+  }
+  set_img(cur);
 
 #pragma unroll 1
   for (int k = Tn - 2; k >= 0; k--) {
-    if (k > 0) lq_stage_issue<T, NX, NP, MU>(a, pt, k - 1, sm + (1 - cur) * C::IMG, t);
+    if (O::DB && k > 0) lq_stage_issue<T, NX, NP, MU>(a, pt, k - 1, sm + (1 - cur) * C::IMG, t);
     // ---- W_i = R_ii^{-1} B_i^T (column c by lane (i,c)), w_i = R_ii^{-1} r_ii ----
     if (zl) {
       T b[MU];
@@ -276,10 +290,17 @@ __device__ __forceinline__ void lq_openloop_instance(const LQArgs<T>& a, const P
     }
     lds_sync(NT <= 64);
     store_value_row(k);
-    dma_wait();
-    lds_sync(NT <= 64);
-    cur = 1 - cur;
-    set_img(cur);
+    if (O::DB) {
+      dma_wait();
+      lds_sync(NT <= 64);
+      cur = 1 - cur;
+      set_img(cur);
+    } else {
+      lds_sync(NT <= 64);  // the image is free: refill it in place
+      if (k > 0) lq_stage_issue<T, NX, NP, MU>(a, pt, k - 1, sm, t);
+      dma_wait();
+      lds_sync(NT <= 64);
+    }
   }
 
   // ---- forward pass (:156-192) ----
@@ -307,7 +328,7 @@ __device__ __forceinline__ void lq_openloop_instance(const LQArgs<T>& a, const P
   lds_sync(NT <= 64);
 #pragma unroll 1
   for (int k = 0; k < Tn - 1; k++) {
-    if (k + 2 < Tn) stage(k + 1, 1 - cur);
+    if (O::DB && k + 2 < Tn) stage(k + 1, 1 - cur);
     const T* fr = f0 + cur * FS;
     if (a.dx && t < NX) a.dx[size_t(k) * NX + t] = sx[t];
     if (t < NX) {
@@ -362,9 +383,16 @@ __device__ __forceinline__ void lq_openloop_instance(const LQArgs<T>& a, const P
     }
     lds_sync(NT <= 64);
     if (t < NX) sx[t] = sxn[t];
-    dma_wait();
-    lds_sync(NT <= 64);
-    cur = 1 - cur;
+    if (O::DB) {
+      dma_wait();
+      lds_sync(NT <= 64);
+      cur = 1 - cur;
+    } else {
+      lds_sync(NT <= 64);  // staged row consumed: refill in place
+      if (k + 2 < Tn) stage(k + 1, 0);
+      dma_wait();
+      lds_sync(NT <= 64);
+    }
   }
   if (a.dx && t < NX) a.dx[size_t(Tn - 1) * NX + t] = sx[t];  // :188-192
   if (t < M) a.alpha[size_t(Tn - 1) * M + t] = T(0);
