@@ -5,7 +5,13 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <sys/stat.h>
+#include <sys/types.h>
+
+#include <cerrno>
 #include <cstring>
+#include <ctime>
+#include <fstream>
 #include <sstream>
 
 namespace ilqgames {
@@ -546,6 +552,97 @@ class DeviceSolve {
 };
 
 }  // namespace host
+
+// ------------------------------------------------------------------------------------------
+// SolverLog on disk (src/solver_log.cpp:113-171, :208-240)
+// ------------------------------------------------------------------------------------------
+namespace {
+
+std::string LogRoot() {
+  const char* env = std::getenv("ILQGAMES_LOG_DIR");
+  return env != nullptr ? std::string(env) : std::string("./logs");
+}
+
+// One row the way Eigen streams `x.transpose()`: every coefficient at the stream's default precision,
+// right-aligned to the widest one, separated by a single space.
+void WriteRow(std::ostream& os, const float* v, std::ptrdiff_t count) {
+  std::vector<std::string> cells;
+  size_t width = 0;
+  for (std::ptrdiff_t i = 0; i < count; i++) {
+    std::ostringstream cell;
+    cell << v[i];
+    cells.push_back(cell.str());
+    width = std::max(width, cells.back().size());
+  }
+  for (size_t i = 0; i < cells.size(); i++) {
+    if (i > 0) os << " ";
+    os << std::string(width - cells[i].size(), ' ') << cells[i];
+  }
+  os << std::endl;
+}
+
+}  // namespace
+
+bool MakeDirectory(const std::string& directory_name) {
+  if (mkdir(directory_name.c_str(), 0777) == -1) {
+    LOG(ERROR) << "Could not create directory " << directory_name << ". Error msg: " << std::strerror(errno);
+    return false;
+  }
+  return true;
+}
+
+std::string SolverLog::DefaultExperimentName() {
+  char buf[64];
+  const std::time_t now = std::time(nullptr);
+  std::strftime(buf, sizeof(buf), "%Y-%m-%d-%H-%M-%S", std::localtime(&now));
+  return std::string("experiment_") + buf;
+}
+
+bool SolverLog::Save(bool only_last_trajectory, const std::string& experiment_name) const {
+  const std::string dir_name = LogRoot() + "/" + experiment_name;
+  if (!MakeDirectory(dir_name)) return false;
+  size_t start = 0;
+  if (only_last_trajectory) start = operating_points_.size() - 1;
+  for (size_t ii = start; ii < operating_points_.size(); ii++) {
+    const OperatingPoint& op = operating_points_[ii];
+    const std::string sub = dir_name + "/" + std::to_string(ii);
+    if (!MakeDirectory(sub)) return false;
+    std::ofstream(sub + "/t0.txt") << op.t0 << std::endl;
+    {
+      std::ofstream file(sub + "/xs.txt");
+      for (const auto& x : op.xs) WriteRow(file, x.data(), x.size());
+    }
+    {
+      std::ofstream file(sub + "/costs.txt");
+      for (float c : total_player_costs_[ii]) file << c << std::endl;
+    }
+    std::ofstream(sub + "/cumulative_runtimes.txt") << cumulative_runtimes_[ii] << std::endl;
+    const size_t players = NumPlayers();
+    for (size_t jj = 0; jj < players; jj++) {
+      std::ofstream file(sub + "/u" + std::to_string(jj) + ".txt");
+      for (const auto& us : op.us) {
+        CHECK_EQ(players, us.size());
+        WriteRow(file, us[jj].data(), us[jj].size());
+      }
+    }
+  }
+  return true;
+}
+
+bool SaveLogs(const std::vector<SolverLog>& logs, bool only_last_trajectory, const std::string& experiment_name) {
+  if (!MakeDirectory(LogRoot() + "/" + experiment_name)) return false;
+  for (size_t ii = 0; ii < logs.size(); ii++)
+    if (!logs[ii].Save(only_last_trajectory, experiment_name + "/" + std::to_string(ii))) return false;
+  return true;
+}
+
+bool SaveLogs(const std::vector<std::shared_ptr<const SolverLog>>& logs, bool only_last_trajectory,
+              const std::string& experiment_name) {
+  if (!MakeDirectory(LogRoot() + "/" + experiment_name)) return false;
+  for (size_t ii = 0; ii < logs.size(); ii++)
+    if (!logs[ii]->Save(only_last_trajectory, experiment_name + "/" + std::to_string(ii))) return false;
+  return true;
+}
 
 // ------------------------------------------------------------------------------------------
 // Receding horizon

@@ -576,6 +576,14 @@ class SolverLog {
   const std::vector<Strategy>& FinalStrategies() const { return strategies_.back(); }
   const OperatingPoint& FinalOperatingPoint() const { return operating_points_.back(); }
   Time CumulativeRuntime() const { return cumulative_runtimes_.back(); }
+  // On-disk layout of the reference (src/solver_log.cpp:113-171), read by its matlab/ scripts and GUI:
+  //   <log dir>/<experiment>/<iterate>/{t0,xs,u<player>,costs,cumulative_runtimes}.txt
+  // one trajectory row per line, Eigen's default stream formatting (6 significant digits, columns right-
+  // aligned to a common width, single-space separator).  <log dir> = $ILQGAMES_LOG_DIR, default "./logs"
+  // (the reference bakes its source tree's logs/ in at configure time).  Directories that already exist make
+  // Save() fail, as MakeDirectory does there.
+  bool Save(bool only_last_trajectory = false, const std::string& experiment_name = DefaultExperimentName()) const;
+  static std::string DefaultExperimentName();
   // Outer iterations the device performed for the solve this log belongs to.
   int DeviceIterations() const { return device_iterations_; }
   void SetDeviceIterations(int iters) { device_iterations_ = iters; }
@@ -588,6 +596,12 @@ class SolverLog {
   std::vector<bool> was_converged_;
   int device_iterations_ = 0;
 };
+
+bool SaveLogs(const std::vector<SolverLog>& logs, bool only_last_trajectory = true,
+              const std::string& experiment_name = SolverLog::DefaultExperimentName());
+bool SaveLogs(const std::vector<std::shared_ptr<const SolverLog>>& logs, bool only_last_trajectory = true,
+              const std::string& experiment_name = SolverLog::DefaultExperimentName());
+bool MakeDirectory(const std::string& directory_name);  // include/ilqgames/utils/make_directory.h
 
 // ---------------------------------------------------------------------------------------------
 // SolverParams (include/ilqgames/solver/solver_params.h:50-106)

@@ -45,6 +45,34 @@ def test_host_library_builds_and_links_the_c_abi():
         assert s in syms, s
 
 
+def test_solver_log_on_disk_layout_and_row_format(tmp_path):
+    """SolverLog::Save / SaveLogs write the reference's layout (src/solver_log.cpp:113-171, :208-240):
+    <dir>/<experiment>/<iterate>/{t0,xs,u<i>,costs,cumulative_runtimes}.txt, one row per time step, Eigen's
+    default formatting (6 significant digits, columns padded to a common width, single space)."""
+    entry.build_host()
+    exe = str(tmp_path / "log_format_check")
+    _compile(exe, [os.path.join(ROOT, "tests", "host", "log_format_check.cpp")])
+    env = dict(os.environ, ILQGAMES_LOG_DIR=str(tmp_path))
+    assert subprocess.check_output([exe, "exp"], env=env, text=True).strip().splitlines()[-1] == "ok"
+    base = tmp_path / "exp"
+    assert sorted(os.listdir(base)) == ["0", "1"]
+    assert sorted(os.listdir(base / "0")) == ["costs.txt", "cumulative_runtimes.txt", "t0.txt", "u0.txt", "u1.txt",
+                                              "xs.txt"]
+    assert (base / "0" / "t0.txt").read_text() == "1.5\n" and (base / "1" / "t0.txt").read_text() == "2\n"
+    assert (base / "0" / "costs.txt").read_text() == "1.5\n2.25\n"
+    assert (base / "1" / "costs.txt").read_text() == "0.75\n0.001\n"
+    assert (base / "1" / "cumulative_runtimes.txt").read_text() == "0.25\n"
+    xs = (base / "0" / "xs.txt").read_text().splitlines()
+    assert xs[0] == "      0     -10 1214.57     -30"      # widest cell sets the width, 6 significant digits
+    assert xs[1] == "   0.25   -9.75 1214.82  -29.75"
+    assert np.allclose(np.loadtxt(base / "0" / "xs.txt")[2], [0.5, -9.5, 1215.07, -29.5], rtol=1e-5)
+    assert (base / "0" / "u0.txt").read_text().splitlines()[1] == "      0.5 -0.333333"
+    assert (base / "0" / "u1.txt").read_text().splitlines() == ["100", "101", "102"]
+    # SaveLogs: one sub-experiment per log, last trajectory only
+    lst = tmp_path / "exp_list"
+    assert sorted(os.listdir(lst)) == ["0", "1"] and os.listdir(lst / "0") == ["1"]
+
+
 @pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present")
 @pytest.mark.parametrize("cls,stem,builder", EXAMPLES, ids=[e[1] for e in EXAMPLES])
 def test_reference_example_source_compiles_unchanged_and_flattens_like_examples_py(cls, stem, builder, tmp_path):
