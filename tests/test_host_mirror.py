@@ -227,3 +227,18 @@ def test_cpp_lq_solvers_match_oracle(demo_out, oracle, open_loop):
     assert np.max(np.abs(gotA - alpha[0])) < tol * max(1.0, np.max(np.abs(alpha)))
     assert np.max(np.abs(d["dx"] - dx[0])) < tol * max(1.0, np.max(np.abs(dx)))
     assert np.max(np.abs(gotA)) > 1e-3
+
+
+@pytest.mark.gpu
+def test_cpp_lq_solver_properties_like_the_reference_suite():
+    """tests/host/lq_solver_checks.cpp restates the properties of the reference's test/test_lq_solver.cpp
+    (:292-434) against LQFeedbackSolver / LQOpenLoopSolver of the mirror, i.e. against the device kernels:
+    Lyapunov iterations, feedback Nash by perturbation (with and without linear terms), single-player
+    open loop = feedback."""
+    exe = os.path.join(BIN, "lq_solver_checks")
+    if not os.path.exists(exe):
+        entry.build_host()
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    print(res.stdout)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert res.stdout.count("PASS") == 4
