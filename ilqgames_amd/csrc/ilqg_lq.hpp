@@ -9,18 +9,16 @@
 // and, fused into the same pass over the data, ILQSolver::ExpectedDecrease
 // (src/ilq_solver.cpp:364-398).
 //
-// Mapping (this is not the reference's loop nest):
-//   * lane t = i*NX + c owns COLUMN c of Z_i in registers for the whole sweep;
-//   * the per-step blocks [B|A|Q|l|R|r] are prefetched global->VGPR one step ahead
-//     (coalesced: consecutive lanes, consecutive elements) and committed to an LDS
-//     image after the step's last LDS read, so HBM latency hides under the math;
-//   * F^T Z_i F is two passes of "uniform matrix x private column":
-//       U_i[:,c] = F^T Z_i[:,c]          (F broadcast from LDS, Z column in VGPRs)
-//       Z_i'[:,c] = U_i F[:,c]           (U_i rows broadcast from LDS, F column in VGPRs)
-//     so every FMA takes one broadcast LDS operand and no cross-lane reduction;
-//   * the (m x m) Nash system with its n+1 right-hand sides lives one COLUMN PER LANE
-//     in wave 0; Householder reflectors are broadcast with __shfl, back substitution
-//     pulls R entries with __shfl — no LDS, no barriers inside the factorisation.
+// Two formulations (this is not the reference's loop nest):
+//   * n <= 16: lq_feedback_instance_mfma_pw — one wavefront per player, Z_i in MFMA accumulator-layout
+//     registers, every product a chain of v_mfma_*_16x16x4, operands DMA'd into zero-padded
+//     conflict-free LDS tiles (see the comment on that function and DESIGN.md §3.2);
+//   * larger n: lq_feedback_instance — lane t = i*NX + c owns COLUMN c of Z_i in registers;
+//     F^T Z_i F is two passes of "uniform matrix x private column" with broadcast LDS operands.
+// In both, the (m x m) Nash system with its n+1 right-hand sides lives one COLUMN PER LANE in wave 0
+// (v_readlane broadcasts, no LDS and no barriers inside the factorisation): Householder QR as the
+// reference, or elimination without pivoting once the Gershgorin step has made S diagonally dominant.
+// The per-step [B|A|Q|l|R|r] block is staged global -> LDS by DMA one step ahead (double-buffered).
 #pragma once
 
 #include "ilqg_common.hpp"

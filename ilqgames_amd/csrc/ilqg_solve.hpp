@@ -1,16 +1,18 @@
-// ilqg_solve.hpp — the whole iterative-LQ loop of one game instance inside one
-// persistent workgroup (gfx950).
+// ilqg_solve.hpp — the iterative-LQ loop of one game instance, as three device parts that the host
+// launches in rounds (gfx950).
 //
-// ILQSolver::Solve (src/ilq_solver.cpp:76-172) with ModifyLQStrategies (:289-348)
-// inlined: rollout -> total costs -> quadraticise, then
+// ILQSolver::Solve (src/ilq_solver.cpp:76-172) with ModifyLQStrategies (:289-348) inlined:
+// rollout -> total costs -> quadraticise, then
 //   { LQ sweep (+ expected decrease) -> scaled rollout -> Armijo back-tracking on the
-//     KKT-residual merit -> total costs } until converged / max_solver_iters / failure.
-// Instances finish after different numbers of outer iterations and back-tracks; since a
-// workgroup owns its instance for the whole solve there are no masks, no host round
-// trips and no compaction — a finished workgroup simply retires and the CU picks up the
-// next instance.  Co-resident workgroups are in different phases, which is what keeps
-// the CU busy: the latency-bound rollout of one instance overlaps the LDS/VALU-bound
-// sweep of its neighbours.
+//     KKT-residual merit -> total costs } until converged / max_solver_iters / failure,
+// and AugmentedLagrangianSolver::Solve (src/augmented_lagrangian_solver.cpp:72-210) around it.
+//   trial part  rollout (initial, or a line-search trial) pipelined with linearise + quadraticise over the
+//               waves of the workgroup, reductions, Armijo decision — loops until a trial is accepted;
+//   LQ part     the Riccati sweep at the accepted operating point;
+//   exit part   the return path of Solve and the AL bookkeeping.
+// Every instance carries its own loop state (SolveState) in the workspace, so instances finish after
+// different numbers of iterations and back-tracks without masks or compaction: a part returns at once
+// for an instance that is not waiting for it.
 #pragma once
 
 #include "ilqg_lq.hpp"
