@@ -15,6 +15,9 @@
 
 #include "../../include/ilqg.h"
 
+#include <type_traits>
+#include <utility>
+
 namespace ilqg {
 
 constexpr int kMaxPlayers = ILQG_MAX_PLAYERS;
@@ -147,6 +150,16 @@ __device__ __forceinline__ void dma_g2l(const void* g, void* l, int nbytes, int 
   }
 }
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// Compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{}).
+template <int... I, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
+}
 
 template <typename T>
 __device__ __forceinline__ T dinf() {

@@ -643,7 +643,8 @@ struct PWCfg {
   static constexpr int oYz = oAl + 16;          // y_zeta (M, padded to 16)
   static constexpr int oSY = oYz + 16;          // [S | Y] bounce: M x 32, column-major
   static constexpr int oVec = oSY + M * 32;     // per player: beta strip (16) and zeta strip (16)
-  static constexpr int ELEMS_PW = oVec + 2 * NP * 16;
+  static constexpr int oG = oVec + 2 * NP * 16;  // per player: its MU columns of G = Z^T B, 16 entries each
+  static constexpr int ELEMS_PW = oG + NP * MU * 16;
   // the forward pass reuses the LDS with the single-wave layout
   static constexpr int LDS_ELEMS = ELEMS_PW > C::LDS_ELEMS ? ELEMS_PW : C::LDS_ELEMS;
   // DMA piece: 16 bytes when every column of the source and of the padded tile starts 16-byte aligned, else 4
@@ -735,6 +736,7 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
   T* sSY = sm + W::oSY;
   T* sBw = sm + W::oVec + w * 16;         // this player's beta, entries NX..15 zero
   T* sZw = sm + W::oVec + (NP + w) * 16;  // this player's zeta, entries NX..15 zero
+  T* sGw = sm + W::oG + w * MU * 16;       // this player's columns of Z_w^T B
 
   // Staging jobs of one step: Q_0 .. Q_{NP-1}, A, B, the vectors (l, R, r) — NP + 3 of them, each executed
   // by one wave.  `slot` of `nslots` takes every nslots-th job.  Before the loop all NP waves share the
@@ -774,7 +776,7 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
   constexpr int HELPERS = NP > 1 ? NP - 1 : 1;  // waves that stage inside the loop (wave 0 itself when NP == 1)
 
   // ---- zero the tile padding (and everything else the DMA does not write), once ----
-  for (int e = t; e < W::oVec + 2 * NP * 16; e += NT) sm[e] = T(0);
+  for (int e = t; e < W::ELEMS_PW; e += NT) sm[e] = T(0);
   __syncthreads();
 
   // ---- terminal step: Z_w = Q_w[T-1], zeta_w = l_w[T-1]  (:102-105) ----
@@ -814,20 +816,30 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
     ILQG_PH(0);
 
     // ---- this player's MU rows of the stacked Nash system: (B_w^T Z_w) [B | A] ----
+    // G = Z_w^T B on the matrix pipe; the MU x (M + NX) block G_w^T [B | A] that follows has two useful rows
+    // out of a 16 x 16 tile, so it is done by the vector unit instead: this player's MU columns of G go through
+    // LDS, lane c < M + NX takes column c of [B | A] and the MU dot products over the state (sequential sums,
+    // as the reference's).  Saves 8 of the step's MFMA and the matrix pipe is shared by the three resident waves.
     const vec Bd = ldD(tB);
-    vec G = tile_xty<T>(Zd, Bd, zero4);  // Z_w^T B
+    const vec G = tile_xty<T>(Zd, Bd, zero4);  // Z_w^T B
+    if (j / MU == w) {
 #pragma unroll
-    for (int r = 0; r < 4; r++) G[r] *= mOwn;
-    const vec Ad = ldD(tA);
-    const vec Sd = tile_xty<T>(G, Bd, zero4);  // rows of player w: B_w^T Z_w B
-    const vec Yy = tile_xty<T>(G, Ad, zero4);  //                    B_w^T Z_w A
+      for (int r = 0; r < 4; r++) sGw[(j - w * MU) * 16 + row0 + RS * r] = G[r];
+    }
+    lds_sync(true);
+    if (lane < M + NX) {
+      const T* colp = lane < M ? tB + LD * lane : tA + LD * (lane - M);
+      T acc[MU];
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int row = row0 + RS * r;
-      if (row / MU == w && row < M) {
-        if (j < M) sSY[row + M * j] = Sd[r];
-        if (j < NX) sSY[row + M * (M + j)] = Yy[r];
+      for (int aa = 0; aa < MU; aa++) acc[aa] = T(0);
+#pragma unroll
+      for (int kk = 0; kk < NX; kk++) {
+        const T v = colp[kk];
+#pragma unroll
+        for (int aa = 0; aa < MU; aa++) acc[aa] += sGw[aa * 16 + kk] * v;
       }
+#pragma unroll
+      for (int aa = 0; aa < MU; aa++) sSY[(w * MU + aa) + M * lane] = acc[aa];
     }
     if (lane < MU) {  // y_zeta = B_w^T zeta_w + r_ww (:154-157)
       const int tt = w * MU + lane;
@@ -908,7 +920,7 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
     vec nBT = ldDT(tB);  // B^T
 #pragma unroll
     for (int r = 0; r < 4; r++) nBT[r] = -nBT[r];
-    const vec Fd = tile_xty<T>(nBT, Pd, ldD(tA));
+    const vec Fd = tile_xty_blocks<T, kblock_mask<T>(0, M)>(nBT, Pd, ldD(tA));  // rows >= M of -B^T are zero
     {
       T s = T(0);  // one entry of beta per lane (rows >= NX of the padded B are zero)
 #pragma unroll
@@ -948,8 +960,8 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
     // ---- Z_w <- F^T Z_w F + Q_w + sum_jj P_jj^T R_w,jj P_jj  (:198-212), both layouts ----
     vec Cd = ldD(tQ);
     vec CTd = sym ? Cd : ldDT(tQ);
-#pragma unroll
-    for (int jj = 0; jj < NP; jj++) {
+    static_for<NP>([&](auto JJ) {  // jj is a compile-time constant: it selects the k blocks of the product
+      constexpr int jj = decltype(JJ)::value;
       // + P_jj^T R_w,jj P_jj (and its transpose): H = R P_jj and H' = R^T P_jj sit in rows
       // jj*MU.. of a tile, P_jj likewise, so both products are one MFMA chain each.
       int qw = -1, ro_wj = 0;
@@ -958,7 +970,7 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
         qw = (w == e) ? pr.q[e][jj] : qw;
         ro_wj = (w == e) ? pr.ro[e][jj] : ro_wj;
       }
-      if (qw < 0) continue;  // wave-uniform
+      if (qw < 0) return;  // wave-uniform
       const T* Rij = sR + ro_wj;
       T pb[MU];
 #pragma unroll
@@ -980,9 +992,10 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
         Hd[r] = h * mk;
         Htd[r] = ht * mk;
       }
-      Cd = tile_xty<T>(Pj, Hd, Cd);                 // P_jj^T (R P_jj)
-      if (!sym) CTd = tile_xty<T>(Pj, Htd, CTd);  // P_jj^T (R^T P_jj) = (P_jj^T R P_jj)^T
-    }
+      // only rows jj*MU .. of P_jj are non-zero: one or two of the four k blocks
+      Cd = tile_xty_blocks<T, kblock_mask<T>(jj * MU, jj * MU + MU)>(Pj, Hd, Cd);  // P_jj^T (R P_jj)
+      if (!sym) CTd = tile_xty_blocks<T, kblock_mask<T>(jj * MU, jj * MU + MU)>(Pj, Htd, CTd);  // (P_jj^T R P_jj)^T
+    });
     vec FT;
     if constexpr (SPARE) {
       vec Fx;  // [F | beta]: F is zero in column JB, beta is zero outside it

@@ -49,6 +49,32 @@ __device__ __forceinline__ typename Tile<T>::vec tile_xty(const typename Tile<T>
   return c;
 }
 
+// Which of the four k blocks of a tile_xty product can be non-zero when the LEFT operand X has non-zero rows only
+// in [row_begin, row_end): register kb of the D layout holds rows {g + 4 kb} (f64) / {4 g + kb} (f32), g = 0..3.
+template <typename T>
+constexpr int kblock_mask(int row_begin, int row_end) {
+  int mask = 0;
+  for (int kb = 0; kb < 4; kb++)
+    for (int g = 0; g < 4; g++) {
+      const int row = Tile<T>::row(g, kb);
+      if (row >= row_begin && row < row_end) mask |= 1 << kb;
+    }
+  return mask;
+}
+
+// tile_xty restricted to the k blocks in MASK (the others multiply rows of X that are identically zero).  fp64
+// MFMA issues at its latency (64 cycles per 16x16x4, no overlap between independent ones — scripts/ubench), so every
+// skipped block is 64 cycles of a SIMD's matrix pipe that the other resident waves get back.
+template <typename T, int MASK>
+__device__ __forceinline__ typename Tile<T>::vec tile_xty_blocks(const typename Tile<T>::vec& xd,
+                                                                 const typename Tile<T>::vec& yd,
+                                                                 typename Tile<T>::vec c) {
+#pragma unroll
+  for (int kb = 0; kb < 4; kb++)
+    if (MASK & (1 << kb)) c = Tile<T>::mfma(xd[kb], yd[kb], c);
+  return c;
+}
+
 // Self-test kernel body: given 16x16 column-major X, Y, C in global memory computes
 // out = X^T * Y + C through the D-layout path (one wavefront).
 template <typename T>
