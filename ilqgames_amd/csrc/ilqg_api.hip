@@ -13,6 +13,7 @@
 #include "ilqg_lq.hpp"
 #include "ilqg_lq_openloop.hpp"
 #include "ilqg_models.hpp"
+#include "ilqg_receding.hpp"
 #include "ilqg_solve.hpp"
 #include "ilqg_stages.hpp"
 
@@ -154,124 +155,6 @@ __global__ void linquad_kernel(DevProblem p, QuadBatchArgs<T> g) {
     linquad_step<T>(p, tb, a, k, sm, threadIdx.x);
 }
 
-// Problem::SetUpNextRecedingHorizon for one instance per wavefront (see ilqg_receding_horizon_shift_batch).
-template <typename T>
-struct RecedingArgs {
-  const T* x0;
-  T *xs, *us, *P, *alpha, *x0_next;
-  int* first_step;
-  int itn_step;          // IntegrateToNextTimeStep: strategy index,
-  double itn_remaining;  // integration interval,
-  float itn_frac;        // interpolation weight of the reference state
-  int int_begin, int_end;  // whole plan steps integrated afterwards
-};
-
-template <typename T>
-__global__ void __launch_bounds__(64) receding_horizon_kernel(DevProblem p, RecedingArgs<T> a) {
-  extern __shared__ __align__(16) unsigned char smem_raw[];
-  T* sx = reinterpret_cast<T*>(smem_raw);  // [n] state being integrated
-  const int n = p.n, m = p.m, N = p.N, Tn = p.T;
-  T* su = sx + n;                           // [m]
-  const size_t b = blockIdx.x;
-  const int t = threadIdx.x;
-  T* xs = a.xs + b * Tn * n;
-  T* us = a.us + b * Tn * m;
-  T* P = a.P + b * Tn * m * n;
-  T* al = a.alpha + b * Tn * m;
-  // Strategy::operator() of every player at plan step k against the reference state `ref(c)` (strategy.h:73-76)
-  auto controls = [&](int k, bool interpolate) {
-    if (t < m) {
-      const T frac = T(a.itn_frac);
-      T s = T(0);
-      for (int c = 0; c < n; c++) {
-        T ref;
-        if (!interpolate)
-          ref = xs[size_t(k) * n + c];
-        else if (k + 1 < Tn)
-          ref = frac * xs[size_t(k) * n + c] + (T(1) - frac) * xs[size_t(k + 1) * n + c];
-        else
-          ref = xs[size_t(Tn - 1) * n + c];
-        s += P[(size_t(k) * n + c) * m + t] * (sx[c] - ref);
-      }
-      su[t] = (us[size_t(k) * m + t] - s) - al[size_t(k) * m + t];
-    }
-    __syncthreads();
-  };
-  // MultiPlayerDynamicalSystem::Integrate over `interval` with the controls in su (RK4, two sub-steps)
-  auto integrate = [&](double interval) {
-    if (t < N) {
-      const int xo = p.xoff[t], uo = p.uoff[t], xd = p.xoff[t + 1] - xo;
-      T xj[6];
-      for (int e = 0; e < 6; e++) xj[e] = e < xd ? sx[xo + e] : T(0);
-      sub_integrate<T>(p.sub_kind[t], T(p.sub_param[t]), interval, xj, su[uo], su[uo + 1]);
-      for (int e = 0; e < xd; e++) sx[xo + e] = xj[e];
-    }
-    __syncthreads();
-  };
-  if (t < n) sx[t] = a.x0[b * n + t];
-  __syncthreads();
-  controls(a.itn_step, true);  // IntegrateToNextTimeStep, multi_player_integrable_system.cpp:115-129
-  integrate(a.itn_remaining);
-  for (int kk = a.int_begin; kk < a.int_end; kk++) {  // Integrate(initial_timestep, final_timestep, ...), :76-93
-    controls(kk, false);
-    integrate(p.dt);
-  }
-  // nearest plan state by the first subsystem's position (concatenated_dynamical_system.cpp:109-113);
-  // std::min_element keeps the first minimum
-  T bestd = dinf<T>();
-  int bestk = 0x7fffffff;
-  for (int k = t; k < Tn; k += 64) {
-    const T dx = sx[0] - xs[size_t(k) * n + 0], dy = sx[1] - xs[size_t(k) * n + 1];
-    const T d = dx * dx + dy * dy;
-    if (d < bestd) {
-      bestd = d;
-      bestk = k;
-    }
-  }
-  for (int off = 32; off >= 1; off >>= 1) {
-    const T od = __shfl_xor(bestd, off, 64);
-    const int ok = __shfl_xor(bestk, off, 64);
-    if (od < bestd || (od == bestd && ok < bestk)) {
-      bestd = od;
-      bestk = ok;
-    }
-  }
-  const int first = bestk;
-  if (t == 0) a.first_step[b] = first;
-  // Stitch (concatenated_dynamical_system.h:75-84)
-  const int ego = p.xoff[1] - p.xoff[0];
-  if (t < n) a.x0_next[b * n + t] = t < ego ? xs[size_t(first) * n + t] : sx[t];
-  // what the tail starts from: the plan's last row (read before the shift moves things)
-  const int keep = Tn - first;
-  __syncthreads();
-  if (t < n) sx[t] = xs[size_t(Tn - 1) * n + t];
-  if (t < m) su[t] = us[size_t(Tn - 1) * m + t];
-  __syncthreads();
-  if (first > 0) {
-    // shift rows [first, T) to [0, keep) (:136-157): ascending rows, source row always ahead of the writes
-    for (int kk = 0; kk < keep; kk++) {
-      for (int e = t; e < n; e += 64) xs[size_t(kk) * n + e] = xs[size_t(kk + first) * n + e];
-      for (int e = t; e < m; e += 64) {
-        us[size_t(kk) * m + e] = us[size_t(kk + first) * m + e];
-        al[size_t(kk) * m + e] = al[size_t(kk + first) * m + e];
-      }
-      for (int e = t; e < m * n; e += 64) P[size_t(kk) * m * n + e] = P[size_t(kk + first) * m * n + e];
-    }
-    // zero strategies / controls of the tail and propagate the state through it (:170-184)
-    for (int kk = keep; kk < Tn; kk++) {
-      integrate(p.dt);  // xs[kk] = Integrate(dt, xs[kk-1], us[kk-1])
-      if (t < n) xs[size_t(kk) * n + t] = sx[t];
-      if (t < m) {
-        su[t] = T(0);
-        us[size_t(kk) * m + t] = T(0);
-        al[size_t(kk) * m + t] = T(0);
-      }
-      for (int e = t; e < m * n; e += 64) P[size_t(kk) * m * n + e] = T(0);
-      __syncthreads();
-    }
-  }
-}
-
 template <typename T>
 __global__ void costs_reduce_kernel(DevProblem p, const T* cost_part, T* costs, int* t_extreme, const int* active) {
   const size_t b = blockIdx.x;
@@ -302,6 +185,11 @@ __global__ void __launch_bounds__(64 * W, W) ilq_trial_kernel(DevProblem p, Solv
     const WsLayout L(p.n, p.m, p.N, p.T, p.pairs.Rsz, p.pairs.rsz, sa.ol_row, p.num_constraints, sa.al_mode);
     const int stage = reinterpret_cast<const SolveState<T>*>(sa.ws + size_t(b) * sa.ws_stride + L.state)->stage;
     if (stage != ST_ROLLOUT && stage != ST_QUAD) return;
+  } else if (sa.active && !sa.active[b]) {  // skipped instance: done before it starts, outputs untouched
+    const WsLayout L(p.n, p.m, p.N, p.T, p.pairs.Rsz, p.pairs.rsz, sa.ol_row, p.num_constraints, sa.al_mode);
+    if (threadIdx.x == 0)
+      reinterpret_cast<SolveState<T>*>(sa.ws + size_t(b) * sa.ws_stride + L.state)->stage = ST_DONE;
+    return;
   }
   const QuadTables<T> tb = quad_tables_load<T>(p, smem_raw);
   T* sm = reinterpret_cast<T*>(smem_raw + quad_tables_bytes(p, sizeof(T)));
@@ -522,7 +410,8 @@ static ilqg_status launch_linquad(const ilqg_problem* p, int32_t batch, const vo
 template <typename T, int NX, int NP, int MU>
 static ilqg_status launch_solve(ilqg_problem* p, int32_t batch, const void* x0, void* xs, void* us, void* P,
                                 void* alpha, void* total_costs, int32_t* iters, int32_t* status, int32_t* converged,
-                                void* workspace, int32_t fixed_iters, int al_mode, hipStream_t stream) {
+                                void* workspace, int32_t fixed_iters, int al_mode, int resume, const int32_t* active,
+                                hipStream_t stream) {
   using C = LQCfg<T, NX, NP, MU>;
   const DevProblem& d = p->dev;
   static_assert(OLCfg<T, NX, NP, MU>::ROW == ((NX * NX + NX + NP * MU * NX + NP * MU + NP * NX * NX + 2 * NP * NX + 3) & ~3), "ol_row_elems");
@@ -535,6 +424,7 @@ static ilqg_status launch_solve(ilqg_problem* p, int32_t batch, const void* x0, 
   sa.total_costs = (T*)total_costs; sa.iters = iters; sa.status = status; sa.converged = converged;
   sa.ws = (T*)workspace; sa.ws_stride = L.total; sa.fixed_iters = fixed_iters; sa.batch = batch;
   sa.prm = p->desc.params;
+  sa.active = active;
   sa.prof = g_prof;
   if (!p->d_unfinished) {
     HIP_TRY(hipMalloc(&p->d_unfinished, 4 * sizeof(int)));
@@ -562,7 +452,7 @@ static ilqg_status launch_solve(ilqg_problem* p, int32_t batch, const void* x0, 
   const bool counted = !(fixed_iters > 0 && !al_mode);
   const long long cap = al_mode ? (long long)(sa.prm.max_solver_iters + 1) * (sa.prm.unconstrained_solver_max_iters + 2)
                                 : (long long)sa.prm.max_solver_iters + 2;
-  sa.first = 1;
+  sa.first = resume ? 2 : 1;
   for (long long round = 0;; round++) {
     if (counted) HIP_TRY(hipMemsetAsync(p->d_unfinished, 0, 4 * sizeof(int), stream));
     hipLaunchKernelGGL(k_trial, dim3(batch), dim3(64 * W), lds_trial, stream, d, sa);
@@ -1073,7 +963,8 @@ ilqg_status ilqg_total_costs_batch(const ilqg_problem* p, int32_t batch, const v
 
 static ilqg_status solve_impl(ilqg_problem* p, int32_t batch, const void* x0, void* xs, void* us, void* P,
                               void* alpha, void* total_costs, int32_t* iters, int32_t* status, int32_t* converged,
-                              void* workspace, int32_t fixed_iters, int al_mode, void* stream) {
+                              void* workspace, int32_t fixed_iters, int al_mode, int resume, const int32_t* active,
+                              void* stream) {
   if (!p || !x0 || !xs || !us || !P || !alpha || !total_costs || !iters || !status || !converged || !workspace)
     return fail(ILQG_ERR_INVALID, "null argument");
   if (batch <= 0) return ILQG_OK;
@@ -1084,9 +975,9 @@ static ilqg_status solve_impl(ilqg_problem* p, int32_t batch, const void* x0, vo
   if (d.n == NX_ && d.N == NP_ && p->mu_uniform == MU_) {                                                       \
     return p->desc.dtype == ILQG_F32                                                                            \
                ? launch_solve<float, NX_, NP_, MU_>(p, batch, x0, xs, us, P, alpha, total_costs, iters, status,  \
-                                                    converged, workspace, fixed_iters, al_mode, st)                      \
+                                                    converged, workspace, fixed_iters, al_mode, resume, active, st)                      \
                : launch_solve<double, NX_, NP_, MU_>(p, batch, x0, xs, us, P, alpha, total_costs, iters, status, \
-                                                     converged, workspace, fixed_iters, al_mode, st);                    \
+                                                     converged, workspace, fixed_iters, al_mode, resume, active, st);                    \
   }
   ILQG_FOR_DIMS(X)
 #undef X
@@ -1097,13 +988,21 @@ ilqg_status ilqg_ilq_solve_batch(ilqg_problem* p, int32_t batch, const void* x0,
                                  void* alpha, void* total_costs, int32_t* iters, int32_t* status, int32_t* converged,
                                  void* workspace, int32_t fixed_iters, void* stream) {
   return solve_impl(p, batch, x0, xs, us, P, alpha, total_costs, iters, status, converged, workspace, fixed_iters, 0,
-                    stream);
+                    0, nullptr, stream);
 }
 
 ilqg_status ilqg_al_solve_batch(ilqg_problem* p, int32_t batch, const void* x0, void* xs, void* us, void* P,
                                 void* alpha, void* total_costs, int32_t* iters, int32_t* status, int32_t* converged,
                                 void* workspace, void* stream) {
-  return solve_impl(p, batch, x0, xs, us, P, alpha, total_costs, iters, status, converged, workspace, 0, 1, stream);
+  return solve_impl(p, batch, x0, xs, us, P, alpha, total_costs, iters, status, converged, workspace, 0, 1, 0, nullptr, stream);
+}
+
+ilqg_status ilqg_solve_again_batch(ilqg_problem* p, int32_t batch, const void* x0, void* xs, void* us, void* P,
+                                   void* alpha, void* total_costs, int32_t* iters, int32_t* status,
+                                   int32_t* converged, void* workspace, int32_t augmented_lagrangian,
+                                   const int32_t* active, void* stream) {
+  return solve_impl(p, batch, x0, xs, us, P, alpha, total_costs, iters, status, converged, workspace, 0,
+                    augmented_lagrangian ? 1 : 0, 1, active, stream);
 }
 
 ilqg_status ilqg_receding_horizon_shift_batch(const ilqg_problem* p, int32_t batch, const void* x0, double t0,
@@ -1116,7 +1015,8 @@ ilqg_status ilqg_receding_horizon_shift_batch(const ilqg_problem* p, int32_t bat
   // the reference's CHECKs (src/problem.cpp:68-70)
   if (planner_runtime < 0.0 || planner_runtime + t0 > plan_t0 + horizon || t0 < plan_t0)
     return fail(ILQG_ERR_INVALID, "receding horizon: t0 / planner_runtime outside the stored plan");
-  // SyncToExistingProblem's time bookkeeping (:75-102): identical for every instance of the batch
+  // SyncToExistingProblem's time bookkeeping (:75-102) is identical for every instance of this batch; the
+  // kernel repeats it per instance, here it validates the call and reports the new plan's start time
   const float kRoundingError = 0.9f;
   const double relative_t0 = t0 - plan_t0;
   size_t current_timestep = static_cast<size_t>(relative_t0 / dt);
@@ -1125,12 +1025,12 @@ ilqg_status ilqg_receding_horizon_shift_batch(const ilqg_problem* p, int32_t bat
     current_timestep += 1;
     remaining = dt - remaining;
   }
-  const size_t itn_step = static_cast<size_t>((relative_t0 + 1e-4f) / dt);  // IntegrateToNextTimeStep's own (:104-113)
+  const size_t itn_step = static_cast<size_t>((relative_t0 + kSmallNumberF) / dt);  // IntegrateToNextTimeStep's own (:104-113)
   if (itn_step >= size_t(d.T)) return fail(ILQG_ERR_INVALID, "receding horizon: t0 past the last plan step");
   double new_t0 = t0 + remaining;
   int int_begin = int(current_timestep) + 1, int_end = int_begin;
   if (remaining <= planner_runtime) {
-    const size_t num_steps = static_cast<size_t>(1e-4f + (planner_runtime - remaining) / dt);
+    const size_t num_steps = static_cast<size_t>(kSmallNumberF + (planner_runtime - remaining) / dt);
     int_end = int(current_timestep + num_steps);
     if (int_end < int_begin) int_end = int_begin;
     new_t0 += dt * double(num_steps);
@@ -1140,11 +1040,102 @@ ilqg_status ilqg_receding_horizon_shift_batch(const ilqg_problem* p, int32_t bat
   if (batch <= 0) return ILQG_OK;
 #define CALL(TY_)                                                                                                  \
   [&]() -> ilqg_status {                                                                                         \
-    RecedingArgs<TY_> g{(const TY_*)x0, (TY_*)xs, (TY_*)us, (TY_*)P, (TY_*)alpha, (TY_*)x0_next, first_step,       \
-                        int(itn_step), dt * (itn_step + 1) - relative_t0, 0.0f, int_begin, int_end};               \
-    g.itn_frac = float(g.itn_remaining / dt);                                                                      \
-    hipLaunchKernelGGL(receding_horizon_kernel<TY_>, dim3(batch), dim3(64), (d.n + d.m) * sizeof(TY_),             \
+    RecedingArgs<TY_> g{};                                                                                         \
+    g.plan = PlanBuffers<TY_>{(TY_*)xs, (TY_*)us, (TY_*)P, (TY_*)alpha, nullptr, nullptr, plan_t0, d.T};          \
+    g.x = (const TY_*)x0; g.t = t0; g.planner_runtime = planner_runtime;                                           \
+    g.xs = (TY_*)xs; g.us = (TY_*)us; g.P = (TY_*)P; g.alpha = (TY_*)alpha; g.x0_next = (TY_*)x0_next;             \
+    g.first_step = first_step;                                                                                     \
+    hipLaunchKernelGGL(receding_sync_kernel<TY_>, dim3(batch), dim3(64), (d.n + d.m) * sizeof(TY_),                \
                        (hipStream_t)stream, d, g);                                                                 \
+    HIP_TRY(hipGetLastError());                                                                                  \
+    return ILQG_OK;                                                                                              \
+  }()
+  return DT_DISPATCH(p, CALL);
+#undef CALL
+}
+
+static ilqg_status check_plan(const ilqg_problem* p, int32_t plan_rows, const void* a, const void* b, const void* c,
+                              const void* d, const void* e, const void* f) {
+  if (!p || !a || !b || !c || !d || !e || !f) return fail(ILQG_ERR_INVALID, "null argument");
+  if (plan_rows < p->dev.T) return fail(ILQG_ERR_INVALID, "plan_rows must be at least the problem's T");
+  return ILQG_OK;
+}
+
+ilqg_status ilqg_plan_integrate_batch(const ilqg_problem* p, int32_t batch, int32_t plan_rows, const void* plan_xs,
+                                      const void* plan_us, const void* plan_P, const void* plan_alpha,
+                                      const int32_t* plan_len, const double* plan_t0, double t_from, double t_to,
+                                      double must_contain, void* x, int32_t* active, void* stream) {
+  ilqg_status s = check_plan(p, plan_rows, plan_xs, plan_us, plan_P, plan_alpha, plan_len, plan_t0);
+  if (s != ILQG_OK) return s;
+  if (!x || !active) return fail(ILQG_ERR_INVALID, "null argument");
+  if (batch <= 0) return ILQG_OK;
+  const DevProblem& d = p->dev;
+#define CALL(TY_)                                                                                                  \
+  [&]() -> ilqg_status {                                                                                         \
+    PlanIntegrateArgs<TY_> g{};                                                                                    \
+    g.plan = PlanBuffers<TY_>{(TY_*)plan_xs, (TY_*)plan_us, (TY_*)plan_P, (TY_*)plan_alpha, (int*)plan_len,       \
+                              (double*)plan_t0, 0.0, plan_rows};                                                   \
+    g.t_from = t_from; g.t_to = t_to; g.must_contain = must_contain; g.x = (TY_*)x; g.active = active;             \
+    hipLaunchKernelGGL(plan_integrate_kernel<TY_>, dim3(batch), dim3(64), (d.n + d.m) * sizeof(TY_),               \
+                       (hipStream_t)stream, d, g);                                                                 \
+    HIP_TRY(hipGetLastError());                                                                                  \
+    return ILQG_OK;                                                                                              \
+  }()
+  return DT_DISPATCH(p, CALL);
+#undef CALL
+}
+
+ilqg_status ilqg_receding_horizon_sync_batch(const ilqg_problem* p, int32_t batch, int32_t plan_rows,
+                                             const void* plan_xs, const void* plan_us, const void* plan_P,
+                                             const void* plan_alpha, const int32_t* plan_len, const double* plan_t0,
+                                             const void* x, double t, double planner_runtime, void* xs, void* us,
+                                             void* P, void* alpha, void* x0_next, double* solve_t0,
+                                             int32_t* first_step, int32_t* active, void* stream) {
+  ilqg_status s = check_plan(p, plan_rows, plan_xs, plan_us, plan_P, plan_alpha, plan_len, plan_t0);
+  if (s != ILQG_OK) return s;
+  if (!x || !xs || !us || !P || !alpha || !x0_next || !solve_t0 || !first_step || !active)
+    return fail(ILQG_ERR_INVALID, "null argument");
+  if (xs == plan_xs || us == plan_us || P == plan_P || alpha == plan_alpha)
+    return fail(ILQG_ERR_INVALID, "the next solve's buffers must not alias the stored plan");
+  if (batch <= 0) return ILQG_OK;
+  const DevProblem& d = p->dev;
+#define CALL(TY_)                                                                                                  \
+  [&]() -> ilqg_status {                                                                                         \
+    RecedingArgs<TY_> g{};                                                                                         \
+    g.plan = PlanBuffers<TY_>{(TY_*)plan_xs, (TY_*)plan_us, (TY_*)plan_P, (TY_*)plan_alpha, (int*)plan_len,       \
+                              (double*)plan_t0, 0.0, plan_rows};                                                   \
+    g.x = (const TY_*)x; g.t = t; g.planner_runtime = planner_runtime;                                             \
+    g.xs = (TY_*)xs; g.us = (TY_*)us; g.P = (TY_*)P; g.alpha = (TY_*)alpha; g.x0_next = (TY_*)x0_next;             \
+    g.solve_t0 = solve_t0; g.first_step = first_step; g.active = active;                                           \
+    hipLaunchKernelGGL(receding_sync_kernel<TY_>, dim3(batch), dim3(64), (d.n + d.m) * sizeof(TY_),                \
+                       (hipStream_t)stream, d, g);                                                                 \
+    HIP_TRY(hipGetLastError());                                                                                  \
+    return ILQG_OK;                                                                                              \
+  }()
+  return DT_DISPATCH(p, CALL);
+#undef CALL
+}
+
+ilqg_status ilqg_solution_splice_batch(const ilqg_problem* p, int32_t batch, int32_t plan_rows, void* plan_xs,
+                                       void* plan_us, void* plan_P, void* plan_alpha, int32_t* plan_len,
+                                       double* plan_t0, const void* xs, const void* us, const void* P,
+                                       const void* alpha, const double* solve_t0, const int32_t* converged,
+                                       const int32_t* active, void* stream) {
+  ilqg_status s = check_plan(p, plan_rows, plan_xs, plan_us, plan_P, plan_alpha, plan_len, plan_t0);
+  if (s != ILQG_OK) return s;
+  if (!xs || !us || !P || !alpha || !solve_t0) return fail(ILQG_ERR_INVALID, "null argument");
+  if (plan_rows < p->dev.T + 5)
+    return fail(ILQG_ERR_INVALID, "plan_rows must leave room for five saved rows (T + 5)");
+  if (batch <= 0) return ILQG_OK;
+  const DevProblem& d = p->dev;
+#define CALL(TY_)                                                                                                  \
+  [&]() -> ilqg_status {                                                                                         \
+    SpliceArgs<TY_> g{};                                                                                           \
+    g.plan = PlanBuffers<TY_>{(TY_*)plan_xs, (TY_*)plan_us, (TY_*)plan_P, (TY_*)plan_alpha, plan_len, plan_t0,    \
+                              0.0, plan_rows};                                                                     \
+    g.xs = (const TY_*)xs; g.us = (const TY_*)us; g.P = (const TY_*)P; g.alpha = (const TY_*)alpha;               \
+    g.solve_t0 = solve_t0; g.converged = converged; g.active = active;                                             \
+    hipLaunchKernelGGL(splice_kernel<TY_>, dim3(batch), dim3(64), 0, (hipStream_t)stream, d, g);                   \
     HIP_TRY(hipGetLastError());                                                                                  \
     return ILQG_OK;                                                                                              \
   }()

@@ -28,6 +28,7 @@ struct SolveArgs {
   T *P, *alpha;         // [B][T][m*n], [B][T][m] in: warm start, out: result (buffer 0)
   T* total_costs;       // [B][N]
   int *iters, *status, *converged;
+  const int* active;  // [B] or null: instances to skip (receding-horizon harness: dropped out of the loop)
   T* ws;                // workspace, ws_stride elements per instance
   size_t ws_stride;
   int fixed_iters;
@@ -333,7 +334,10 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const Q
     s.stage = ST_ROLLOUT; s.qmode = Q_COSTS; s.initial = 1; s.cur = 0; s.sacc = 0;
     s.num_iterations = 0; s.bt = 0; s.accepted_iters = 0; s.has_converged = 0; s.ok = 1;
     s.logged = 0; s.inner_calls = 0; s.al_success = 1; s.pad0 = s.pad1 = s.pad2 = 0;
-    s.acc_scale = T(1); s.step = T(1); s.last_merit = dinf<T>(); s.expected_decrease = dinf<T>();
+    // first == 2: the solver object has been called before on this workspace and its
+    // last_merit_function_value_ (ilq_solver.h:189) is still what the previous call left
+    const T carried = (sa.first == 2) ? state_load<T>(w, L).last_merit : dinf<T>();
+    s.acc_scale = T(1); s.step = T(1); s.last_merit = carried; s.expected_decrease = dinf<T>();
     s.max_err = dinf<T>();
     s.mu = T(10);  // Constraint::mu_ = kDefaultMu (src/constraint.cpp:61) — one per instance
   } else {

@@ -18,7 +18,8 @@ EXPORTS = [
     "ilqg_lq_feedback_batch", "ilqg_lq_openloop_batch", "ilqg_default_solver_params", "ilqg_problem_create",
     "ilqg_problem_destroy", "ilqg_workspace_bytes", "ilqg_rollout_batch", "ilqg_linearize_batch",
     "ilqg_quadraticize_batch", "ilqg_problem_pairs", "ilqg_total_costs_batch", "ilqg_ilq_solve_batch",
-    "ilqg_last_error", "ilqg_abi_version", "ilqg_device_info", "ilqg_selftest_mfma", "ilqg_al_solve_batch",
+    "ilqg_last_error", "ilqg_abi_version", "ilqg_device_info", "ilqg_selftest_mfma", "ilqg_al_solve_batch", "ilqg_plan_integrate_batch", "ilqg_receding_horizon_sync_batch",
+    "ilqg_solution_splice_batch", "ilqg_solve_again_batch",
     "ilqg_receding_horizon_shift_batch",
 ]
 
@@ -221,3 +222,101 @@ class Problem:
                                                        _ptr(bufs["P"]), _ptr(bufs["alpha"]), _ptr(x0_next), _ptr(first),
                                                        C.byref(new_t0), _stream()))
         return x0_next, first, new_t0.value
+
+    # ---- receding-horizon harness (examples/receding_horizon_simulator.h) ----
+    def new_plan(self, batch, rows=None):
+        """Empty SolutionSplicer state on the device: dict(xs, us, P, alpha, len, t0)."""
+        import torch
+        rows = self.T + 5 if rows is None else rows
+        z = lambda *shape: torch.zeros(*shape, dtype=torch_dtype(self.dtype), device="cuda")
+        return dict(xs=z(batch, rows, self.n), us=z(batch, rows, self.m), P=z(batch, rows, self.m * self.n),
+                    alpha=z(batch, rows, self.m), len=torch.zeros(batch, dtype=torch.int32, device="cuda"),
+                    t0=torch.zeros(batch, dtype=torch.float64, device="cuda"))
+
+    def plan_integrate(self, plan, t_from, t_to, must_contain, x, active):
+        """ilqg_plan_integrate_batch: x and active (device tensors) are updated in place."""
+        _check(lib().ilqg_plan_integrate_batch(self.h, x.shape[0], plan["xs"].shape[1], _ptr(plan["xs"]),
+                                               _ptr(plan["us"]), _ptr(plan["P"]), _ptr(plan["alpha"]),
+                                               _ptr(plan["len"]), _ptr(plan["t0"]), C.c_double(t_from),
+                                               C.c_double(t_to), C.c_double(must_contain), _ptr(x), _ptr(active),
+                                               _stream()))
+
+    def receding_horizon_sync(self, plan, x, t, planner_runtime, bufs, active):
+        """ilqg_receding_horizon_sync_batch: fills bufs (xs, us, P, alpha) with the next solve's warm start.
+        Returns (x0_next, solve_t0, first_step) as device tensors."""
+        import torch
+        B = x.shape[0]
+        x0_next = torch.zeros_like(x)
+        solve_t0 = torch.zeros(B, dtype=torch.float64, device="cuda")
+        first = torch.zeros(B, dtype=torch.int32, device="cuda")
+        _check(lib().ilqg_receding_horizon_sync_batch(
+            self.h, B, plan["xs"].shape[1], _ptr(plan["xs"]), _ptr(plan["us"]), _ptr(plan["P"]), _ptr(plan["alpha"]),
+            _ptr(plan["len"]), _ptr(plan["t0"]), _ptr(x), C.c_double(t), C.c_double(planner_runtime),
+            _ptr(bufs["xs"]), _ptr(bufs["us"]), _ptr(bufs["P"]), _ptr(bufs["alpha"]), _ptr(x0_next), _ptr(solve_t0),
+            _ptr(first), _ptr(active), _stream()))
+        return x0_next, solve_t0, first
+
+    def solution_splice(self, plan, bufs, solve_t0, converged=None, active=None):
+        """ilqg_solution_splice_batch: constructs (plan len 0) or splices the solution in bufs into the plan."""
+        _check(lib().ilqg_solution_splice_batch(
+            self.h, plan["xs"].shape[0], plan["xs"].shape[1], _ptr(plan["xs"]), _ptr(plan["us"]), _ptr(plan["P"]),
+            _ptr(plan["alpha"]), _ptr(plan["len"]), _ptr(plan["t0"]), _ptr(bufs["xs"]), _ptr(bufs["us"]),
+            _ptr(bufs["P"]), _ptr(bufs["alpha"]), _ptr(solve_t0), None if converged is None else _ptr(converged),
+            None if active is None else _ptr(active), _stream()))
+
+    def solve_again(self, x0, bufs, augmented_lagrangian=False, active=None):
+        """ilqg_solve_again_batch: the next Solve() of the solver object whose previous call used bufs['ws']."""
+        x0 = _dev(x0, self.dtype)
+        _check(lib().ilqg_solve_again_batch(self.h, x0.shape[0], _ptr(x0), _ptr(bufs["xs"]), _ptr(bufs["us"]),
+                                            _ptr(bufs["P"]), _ptr(bufs["alpha"]), _ptr(bufs["costs"]),
+                                            _ptr(bufs["iters"]), _ptr(bufs["status"]), _ptr(bufs["converged"]),
+                                            _ptr(bufs["ws"]), int(augmented_lagrangian),
+                                            None if active is None else _ptr(active), _stream()))
+        return bufs
+
+    def receding_horizon_simulate(self, x_init, final_time, planner_runtime, extra_time=0.25, solve_time=0.25,
+                                  augmented_lagrangian=False, max_records=64, on_record=None):
+        """RecedingHorizonSimulator (src/receding_horizon_simulator.cpp:64-137) for a batch of initial states, with
+        the wall clock replaced by a fixed simulated `solve_time` per solver call: every instance shares the
+        clock, keeps its own spliced plan and drops out on its own (ContainsTime false, invalid times, or a failed
+        first solve — the reference CHECKs success there).  Everything stays on the device; `on_record(r, info)`
+        is called after every solver call with device tensors (info: t_call, active, x_measured, x0, solve_t0,
+        first_step, bufs).  Returns dict(x, plan, active, num_records [B] tensor, calls)."""
+        import torch
+        x = _dev(x_init, self.dtype).clone()
+        B = x.shape[0]
+        dt = self.spec.dt
+        bufs = self.alloc_solve_buffers(B)
+        plan = self.new_plan(B)
+        active = torch.ones(B, dtype=torch.int32, device="cuda")
+        num_records = torch.ones(B, dtype=torch.int32, device="cuda")
+        self.solve(x, bufs, augmented_lagrangian=augmented_lagrangian)
+        solve_t0 = torch.zeros(B, dtype=torch.float64, device="cuda")
+        if on_record:
+            on_record(0, dict(t_call=0.0, active=active.clone(), x_measured=x, x0=x, solve_t0=solve_t0,
+                              first_step=None, bufs=bufs))
+        self.solution_splice(plan, bufs, solve_t0)
+        active &= bufs["status"]  # CHECK(success) after the first call (:77)
+        t = 0.0
+        calls = 1
+        while calls < max_records:
+            t += extra_time
+            if t >= final_time:
+                break
+            self.plan_integrate(plan, t - extra_time, t, t + planner_runtime + dt, x, active)
+            x0_next, solve_t0, first = self.receding_horizon_sync(plan, x, t, planner_runtime, bufs, active)
+            if int(active.sum().item()) == 0:
+                break
+            x0_all = torch.where(active.bool()[:, None], x0_next, bufs["xs"][:, 0, :])
+            self.solve_again(x0_all, bufs, augmented_lagrangian=augmented_lagrangian, active=active)
+            num_records += active
+            if on_record:
+                on_record(calls, dict(t_call=t, active=active.clone(), x_measured=x.clone(), x0=x0_all,
+                                      solve_t0=solve_t0, first_step=first, bufs=bufs))
+            calls += 1
+            t += solve_time
+            if t >= final_time:
+                break
+            self.plan_integrate(plan, t - solve_time, t, t, x, active)
+            self.solution_splice(plan, bufs, solve_t0, converged=bufs["converged"], active=active)
+        return dict(x=x, plan=plan, active=active, num_records=num_records, calls=calls)

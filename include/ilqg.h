@@ -331,6 +331,66 @@ ilqg_status ilqg_receding_horizon_shift_batch(const ilqg_problem* p, int32_t bat
                                               void* P, void* alpha, void* x0_next, int32_t* first_step,
                                               double* new_plan_t0_host, void* stream);
 
+/* ------------------------------------------------------------------------ *
+ *  Receding-horizon harness (examples/receding_horizon_simulator.h:58-60)   *
+ * ------------------------------------------------------------------------ *
+ * The pieces RecedingHorizonSimulator (src/receding_horizon_simulator.cpp:64-137) strings together, for
+ * `batch` instances that share the simulator's clock but each keep their own stored plan.  A stored plan is
+ * what SolutionSplicer holds (solver/solution_splicer.h:57-86): T .. T+5 rows, its own start time:
+ *  plan_xs/us/P/alpha [B][plan_rows][n | m | m*n | m]   plan_rows >= T + 5
+ *  plan_len [B] int32 (device)    rows in use (0 = not constructed yet)
+ *  plan_t0  [B] double (device)   OperatingPoint::t0 of the stored plan
+ *  active   [B] int32 (device)    1 = instance still running.  Where the reference would leave the loop
+ *                                 (ContainsTime false) or CHECK-abort on the times, the instance is
+ *                                 cleared instead and left untouched; the batch never aborts. */
+
+/* Replaces MultiPlayerIntegrableSystem::Integrate(t0, t, x0, operating_point, strategies)
+ * (src/multi_player_integrable_system.cpp:54-74 with :76-155): x [B][n] is advanced from t_from to t_to under
+ * the stored plan's strategies.  Instances whose plan does not satisfy SolutionSplicer::ContainsTime(must_contain)
+ * (solution_splicer.h:66-71) are deactivated first — the simulator's loop exits (:89-91, :126). */
+ilqg_status ilqg_plan_integrate_batch(const ilqg_problem* p, int32_t batch, int32_t plan_rows, const void* plan_xs,
+                                      const void* plan_us, const void* plan_P, const void* plan_alpha,
+                                      const int32_t* plan_len, const double* plan_t0, double t_from, double t_to,
+                                      double must_contain, void* x, int32_t* active, void* stream);
+
+/* Replaces Problem::OverwriteSolution(stored plan) + Problem::SetUpNextRecedingHorizon(x, t, planner_runtime)
+ * (src/problem.cpp:127-193, receding_horizon_simulator.cpp:98-103) per instance: like
+ * ilqg_receding_horizon_shift_batch, but every instance has its own plan length / start time and the result goes
+ * to the next solve's buffers.
+ *  x          [B][n]       measured state at time t
+ *  xs, us, P, alpha [B][T][..]  out: warm start of the next solve (must not alias the plan)
+ *  x0_next    [B][n]       out: Problem::InitialState of the next solve
+ *  solve_t0   [B] double   out (device): OperatingPoint::t0 of the next solve
+ *  first_step [B] int32    out: first_timestep_in_new_problem, -1 where the times were invalid */
+ilqg_status ilqg_receding_horizon_sync_batch(const ilqg_problem* p, int32_t batch, int32_t plan_rows,
+                                             const void* plan_xs, const void* plan_us, const void* plan_P,
+                                             const void* plan_alpha, const int32_t* plan_len, const double* plan_t0,
+                                             const void* x, double t, double planner_runtime, void* xs, void* us,
+                                             void* P, void* alpha, void* x0_next, double* solve_t0,
+                                             int32_t* first_step, int32_t* active, void* stream);
+
+/* Replaces SolutionSplicer::SolutionSplicer(log) (src/solution_splicer.cpp:56-58; instances with plan_len == 0)
+ * and SolutionSplicer::Splice(log) (:60-129; instances with converged != 0, receding_horizon_simulator.cpp:133):
+ * up to five rows of the old plan in front of the solution's start are kept, the solution follows.
+ *  xs, us, P, alpha [B][T][..] the solve's final operating point / strategies, solve_t0 [B] its start time
+ *  converged, active [B] int32 (device), either may be NULL (= all ones) */
+ilqg_status ilqg_solution_splice_batch(const ilqg_problem* p, int32_t batch, int32_t plan_rows, void* plan_xs,
+                                       void* plan_us, void* plan_P, void* plan_alpha, int32_t* plan_len,
+                                       double* plan_t0, const void* xs, const void* us, const void* P,
+                                       const void* alpha, const double* solve_t0, const int32_t* converged,
+                                       const int32_t* active, void* stream);
+
+/* GameSolver::Solve called AGAIN on the same solver object (the simulator reuses one, :75,108): like
+ * ilqg_ilq_solve_batch / ilqg_al_solve_batch (augmented_lagrangian != 0), except that
+ * ILQSolver::last_merit_function_value_ (solver/ilq_solver.h:189) starts from what the previous call on this
+ * `workspace` left instead of infinity.  The workspace must come from a previous solve of the same kind and
+ * batch.  Constraint multipliers are indexed relative to the start of each window, as in a first solve.
+ * active [B] int32 (device, nullable): instances with 0 are skipped, their buffers and outputs left as they are. */
+ilqg_status ilqg_solve_again_batch(ilqg_problem* p, int32_t batch, const void* x0, void* xs, void* us, void* P,
+                                   void* alpha, void* total_costs, int32_t* iters, int32_t* status,
+                                   int32_t* converged, void* workspace, int32_t augmented_lagrangian,
+                                   const int32_t* active, void* stream);
+
 /* Diagnostics: out = X^T Y + C for 16x16 column-major device matrices, computed through the
  * MFMA accumulator-layout path the LQ sweep is built on (pins the gfx950 register layouts). */
 ilqg_status ilqg_selftest_mfma(int32_t dtype, const void* X, const void* Y, const void* C, void* out, void* stream);

@@ -1363,12 +1363,16 @@ bool SolveILQ(const Problem<S>& p, const Vec<S>& x0, Trajectory<S>* op_io, Strat
 // ---------------------------------------------------------------------------
 template <class S>
 bool SolveAL(const Problem<S>& p, const Vec<S>& x0, Trajectory<S>* op_io, Strategies<S>* st_io,
-             Vec<S>* final_costs, int* logged_out, S* max_err_out) {
+             Vec<S>* final_costs, int* logged_out, S* max_err_out, int* converged_out = nullptr,
+             ILQState<S>* state_io = nullptr) {
   ilqg_solver_params inner = p.params;
   inner.max_solver_iters = p.params.unconstrained_solver_max_iters;  // augmented_lagrangian_solver.h:80-84
   Problem<S> pin = p;
   pin.params = inner;
-  ILQState<S> state;
+  // the inner ILQSolver is a member of the AL solver (augmented_lagrangian_solver.h:80-84): its
+  // last_merit_function_value_ outlives this call when the same solver object is used again
+  ILQState<S> fresh_state;
+  ILQState<S>& state = state_io ? *state_io : fresh_state;
   ALState<S> al(p.num_constraints, p.T, p.dt);
   Trajectory<S> warm_op = *op_io, res_op = *op_io;
   Strategies<S> warm_st = *st_io, res_st = *st_io;
@@ -1423,6 +1427,7 @@ bool SolveAL(const Problem<S>& p, const Vec<S>& x0, Trajectory<S>* op_io, Strate
   if (final_costs) *final_costs = costs;
   if (logged_out) *logged_out = logged;
   if (max_err_out) *max_err_out = max_err;
+  if (converged_out) *converged_out = (inner_ok && conv) ? 1 : 0;  // SolverLog::WasConverged of the merged log
   return success;
 }
 
@@ -1530,6 +1535,253 @@ int RecedingHorizonShift(const Problem<S>& p, const RecedingHorizonTimes& tm, co
     op->xs[kk] = Integrate(p, 0.0, p.dt, op->xs[kk - 1], op->us[kk - 1], false);
   }
   return first;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Receding-horizon harness: the pieces RecedingHorizonSimulator (src/receding_horizon_simulator.cpp:64-137)
+// strings together, on plans that carry their own length and start time (SolutionSplicer keeps up to
+// kNumPreviousTimeStepsToSave = 5 rows of the old plan in front of the new one).
+// ---------------------------------------------------------------------------------------------
+template <class S>
+struct Plan {  // (OperatingPoint, vector<Strategy>) as SolutionSplicer / Problem hold them
+  Trajectory<S> op;
+  Strategies<S> st;
+  double t0 = 0.0;
+  int len() const { return int(op.xs.size()); }
+  void resize(int L) {
+    op.xs.resize(L);
+    op.us.resize(L);
+    st.P.resize(L);
+    st.alpha.resize(L);
+  }
+};
+
+// SolutionSplicer::ContainsTime (solver/solution_splicer.h:66-71)
+template <class S>
+inline bool PlanContainsTime(const Plan<S>& pl, double t, double dt) {
+  return pl.t0 <= t && pl.t0 + pl.len() * dt >= t;
+}
+
+// MultiPlayerIntegrableSystem::IntegrateToNextTimeStep (src/multi_player_integrable_system.cpp:95-130)
+template <class S>
+Vec<S> IntegrateToNextTimeStep(const Problem<S>& p, double t0, const Vec<S>& x0, const Plan<S>& pl) {
+  const double relative_t0 = t0 - pl.t0;
+  const size_t ks = static_cast<size_t>((relative_t0 + 1e-4f) / p.dt);
+  const double remaining = p.dt * (ks + 1) - relative_t0;
+  const float frac = float(remaining / p.dt);
+  Vec<S> x0_ref(p.n);
+  if (int(ks) + 1 < pl.len()) {
+    for (int e = 0; e < p.n; e++) x0_ref[e] = S(frac) * pl.op.xs[ks][e] + (S(1) - S(frac)) * pl.op.xs[ks + 1][e];
+  } else {
+    x0_ref = pl.op.xs.back();
+  }
+  return Integrate(p, t0, remaining, x0, ApplyStrategies(p, pl.st, int(ks), x0, x0_ref, pl.op.us[ks]), false);
+}
+
+// Integrate(initial_timestep, final_timestep, ...) (:76-93)
+template <class S>
+Vec<S> IntegrateSteps(const Problem<S>& p, size_t begin, size_t end, Vec<S> x, const Plan<S>& pl) {
+  for (size_t kk = begin; kk < end; kk++)
+    x = Integrate(p, pl.t0 + kk * p.dt, p.dt, x, ApplyStrategies(p, pl.st, int(kk), x, pl.op.xs[kk], pl.op.us[kk]), false);
+  return x;
+}
+
+// IntegrateFromPriorTimeStep (:132-155)
+template <class S>
+Vec<S> IntegrateFromPriorTimeStep(const Problem<S>& p, double t, const Vec<S>& x0, const Plan<S>& pl) {
+  const double relative_t = t - pl.t0;
+  const size_t ks = static_cast<size_t>(relative_t / p.dt);
+  const double remaining = relative_t - p.dt * ks;
+  return Integrate(p, pl.t0 + p.dt * ks, remaining, x0,
+                   ApplyStrategies(p, pl.st, int(ks), x0, pl.op.xs[ks], pl.op.us[ks]), false);
+}
+
+// Integrate(t0, t, x0, operating_point, strategies) (:54-74).  As written there: when t0 sits exactly on
+// the plan's start no partial step is taken and the whole steps begin at current_timestep + 1.
+template <class S>
+Vec<S> IntegrateInterval(const Problem<S>& p, double t0, double t, const Vec<S>& x0, const Plan<S>& pl) {
+  const size_t current = static_cast<size_t>((t0 - pl.t0) / p.dt);
+  const size_t final_step = static_cast<size_t>((t - pl.t0) / p.dt);
+  Vec<S> x = x0;
+  if (t0 > pl.t0) x = IntegrateToNextTimeStep(p, t0, x0, pl);
+  x = IntegrateSteps(p, current + 1, final_step, x, pl);
+  return IntegrateFromPriorTimeStep(p, t, x, pl);
+}
+
+// Integrate(t0, t, ...)'s own CHECKs (:57-58, :111-112, :141-142) plus the rows it reads: false = abort / out of range.
+template <class S>
+inline bool IntegrateIntervalValid(const Problem<S>& p, const Plan<S>& pl, double t0, double t) {
+  if (t < t0 || t0 < pl.t0) return false;
+  const size_t itn = static_cast<size_t>(((t0 - pl.t0) + 1e-4f) / p.dt);
+  const size_t final_step = static_cast<size_t>((t - pl.t0) / p.dt);
+  return int(itn) < pl.len() && int(final_step) < pl.len();
+}
+
+// What the reference CHECKs before it touches the plan (src/problem.cpp:68-70,
+// multi_player_integrable_system.cpp:111-112,141-142): false = the reference would abort.
+template <class S>
+inline bool RecedingHorizonTimesValid(const Problem<S>& p, const Plan<S>& pl, double t0, double planner_runtime) {
+  if (planner_runtime < 0.0 || planner_runtime + t0 > pl.t0 + p.dt * p.T || t0 < pl.t0) return false;
+  const RecedingHorizonTimes tm = RecedingHorizonTimesOf(t0, planner_runtime, pl.t0, p.dt);
+  return tm.itn_step < pl.len() && tm.integrate_end <= pl.len();
+}
+
+// Problem::SetUpNextRecedingHorizon (src/problem.cpp:127-186) on a stored plan of any length >= T:
+// the plan becomes the next solve's warm start (length T, t0 = the new problem's start), *x0_next its
+// initial state.  Returns first_timestep_in_new_problem.
+template <class S>
+int SetUpNextRecedingHorizon(const Problem<S>& p, const Vec<S>& x0, double t0, double planner_runtime, Plan<S>* pl,
+                             Vec<S>* x0_next) {
+  const int T = p.T;
+  const RecedingHorizonTimes tm = RecedingHorizonTimesOf(t0, planner_runtime, pl->t0, p.dt);
+  Vec<S> x = IntegrateToNextTimeStep(p, t0, x0, *pl);
+  x = IntegrateSteps(p, size_t(tm.integrate_begin), size_t(tm.integrate_end), x, *pl);
+  int first = 0;
+  S best = std::numeric_limits<S>::infinity();
+  for (int k = 0; k < pl->len(); k++) {
+    const S dx = x[0] - pl->op.xs[k][0], dy = x[1] - pl->op.xs[k][1];
+    const S d = dx * dx + dy * dy;
+    if (d < best) {
+      best = d;
+      first = k;
+    }
+  }
+  *x0_next = x;
+  const int ego = p.xoff[1] - p.xoff[0];
+  for (int e = 0; e < ego; e++) (*x0_next)[e] = pl->op.xs[first][e];
+  const int end = std::min(first + T, pl->len());  // timestep_iterator_end (:139-140)
+  for (int kk = first; kk < end; kk++) {
+    pl->op.xs[kk - first] = pl->op.xs[kk];
+    pl->op.us[kk - first] = pl->op.us[kk];
+    pl->st.P[kk - first] = pl->st.P[kk];
+    pl->st.alpha[kk - first] = pl->st.alpha[kk];
+  }
+  pl->resize(T);  // :160-168 (a shorter plan cannot occur: CHECK_GE at :159)
+  for (int kk = end - first; kk < T; kk++) {
+    pl->st.P[kk] = Mat<S>(p.m, p.n);
+    pl->st.alpha[kk].assign(p.m, S(0));
+    pl->op.us[kk].assign(p.m, S(0));
+    pl->op.xs[kk] = Integrate(p, (kk - 1) * p.dt, p.dt, pl->op.xs[kk - 1], pl->op.us[kk - 1], false);
+  }
+  pl->t0 = tm.new_plan_t0;
+  return first;
+}
+
+// SolutionSplicer::Splice (src/solution_splicer.cpp:60-129): keep up to 5 rows of the old plan that
+// precede the new solution's start, then the new solution.
+template <class S>
+void SplicePlan(const Problem<S>& p, const Plan<S>& solution, Plan<S>* pl) {
+  const int T = p.T;
+  if (solution.t0 < pl->t0) return;  // CHECK_GE (:61): the reference aborts; a batch leaves the plan alone
+  const size_t current = static_cast<size_t>(1e-4 + (solution.t0 - pl->t0) / p.dt);
+  if (int(current) > pl->len()) return;  // a gap between plan and solution: rows the reference never has
+  const size_t kSave = 5;
+  const size_t initial = (int(current) < int(kSave)) ? 0 : current - kSave;
+  for (size_t kk = initial; kk < current; kk++) {
+    pl->op.xs[kk - initial] = pl->op.xs[kk];
+    pl->op.us[kk - initial] = pl->op.us[kk];
+    pl->st.P[kk - initial] = pl->st.P[kk];
+    pl->st.alpha[kk - initial] = pl->st.alpha[kk];
+  }
+  const int spliced = int(current - initial) + T;
+  pl->resize(spliced);
+  pl->t0 += initial * p.dt;
+  for (int kk = 0; kk < T; kk++) {
+    const size_t at = current + kk - initial;
+    pl->op.xs[at] = solution.op.xs[kk];
+    pl->op.us[at] = solution.op.us[kk];
+    pl->st.P[at] = solution.st.P[kk];
+    pl->st.alpha[at] = solution.st.alpha[kk];
+  }
+}
+
+// One solver invocation of the harness, as a test can compare it.
+template <class S>
+struct MpcRecord {
+  double t_call;      // the simulator's clock when the solver was called
+  Vec<S> x_measured;  // true state handed to SetUpNextRecedingHorizon (the initial state for record 0)
+  Vec<S> x0;          // Problem::InitialState of the solve
+  double plan_t0;     // OperatingPoint::t0 of the solve
+  int first_step;     // first_timestep_in_new_problem (-1 for record 0)
+  Plan<S> solution;   // SolverLog::FinalOperatingPoint / FinalStrategies
+  int iters, ok, converged;
+  int max_backtracks;  // deepest line search of the solve (-1: not recorded, AL mode)
+};
+
+// RecedingHorizonSimulator (src/receding_horizon_simulator.cpp:64-137) with the wall clock replaced by a
+// fixed `solve_time` per call and no per-call time budget.  `extra_time` is the
+// reference's kExtraTime = 0.25.  use_al: AugmentedLagrangianSolver, else ILQSolver; either way ONE solver
+// object serves every call, so ILQSolver::last_merit_function_value_ carries over (ilq_solver.h:189).
+// A solve whose times the reference would CHECK-abort on ends the run.  Constraint multipliers are indexed
+// relative to the start of each window, as in the first solve (after the first ResetInitialTime the
+// reference's TimeIndex CHECK_GE fails for any constrained problem, so there is nothing else to follow).
+template <class S>
+std::vector<MpcRecord<S>> RecedingHorizonSimulate(const Problem<S>& p, const Vec<S>& x_init, double final_time,
+                                                  double planner_runtime, double extra_time, double solve_time,
+                                                  bool use_al, Plan<S>* final_plan, Vec<S>* final_x,
+                                                  int max_records = 1 << 30) {
+  std::vector<MpcRecord<S>> recs;
+  ILQState<S> state;
+  ALState<S> no_al(p.num_constraints, p.T, p.dt);
+  auto solve = [&](const Vec<S>& x0, Plan<S>* pl, MpcRecord<S>* r) {
+    Vec<S> costs;
+    int it = 0, conv = 0;
+    bool ok;
+    r->max_backtracks = -1;
+    if (use_al) {
+      S maxerr;
+      ok = SolveAL(p, x0, &pl->op, &pl->st, &costs, &it, &maxerr, &conv, &state);
+    } else {
+      std::vector<IterLog<S>> log;
+      ok = SolveILQ(p, x0, &pl->op, &pl->st, &state, &no_al, 0, &log, &costs, &it, &conv);
+      r->max_backtracks = ok ? 0 : p.params.max_backtracking_steps;
+      for (const auto& e : log) r->max_backtracks = std::max(r->max_backtracks, e.backtracks);
+    }
+    r->iters = it;
+    r->ok = ok ? 1 : 0;
+    r->converged = conv;
+  };
+  // first call: the problem as Problem::Initialize leaves it (zero operating point and strategies, t0 = 0)
+  Plan<S> problem;
+  problem.op = Trajectory<S>(p.T, p.n, p.m);
+  problem.st = Strategies<S>(p.T, p.n, p.m);
+  problem.t0 = 0.0;
+  MpcRecord<S> r0;
+  r0.t_call = 0.0;
+  r0.x_measured = x_init;
+  r0.x0 = x_init;
+  r0.plan_t0 = 0.0;
+  r0.first_step = -1;
+  r0.solution = problem;
+  solve(x_init, &r0.solution, &r0);
+  recs.push_back(r0);
+  Plan<S> splicer = r0.solution;  // SolutionSplicer(const SolverLog&), :56-58
+  Vec<S> x = x_init;
+  double t = splicer.t0;
+  while (int(recs.size()) < max_records && r0.ok) {  // CHECK(success) after the first call (:77)
+    t += extra_time;
+    if (t >= final_time || !PlanContainsTime(splicer, t + planner_runtime + p.dt, p.dt)) break;
+    if (!IntegrateIntervalValid(p, splicer, t - extra_time, t)) break;
+    x = IntegrateInterval(p, t - extra_time, t, x, splicer);
+    problem = splicer;  // Problem::OverwriteSolution
+    if (!RecedingHorizonTimesValid(p, problem, t, planner_runtime)) break;
+    MpcRecord<S> r;
+    r.t_call = t;
+    r.x_measured = x;
+    r.first_step = SetUpNextRecedingHorizon(p, x, t, planner_runtime, &problem, &r.x0);
+    r.plan_t0 = problem.t0;
+    r.solution = problem;
+    solve(r.x0, &r.solution, &r);
+    recs.push_back(r);
+    t += solve_time;
+    if (t >= final_time || !PlanContainsTime(splicer, t, p.dt)) break;
+    if (!IntegrateIntervalValid(p, splicer, t - solve_time, t)) break;
+    x = IntegrateInterval(p, t - solve_time, t, x, splicer);
+    if (r.converged) SplicePlan(p, r.solution, &splicer);
+  }
+  if (final_plan) *final_plan = splicer;
+  if (final_x) *final_x = x;
+  return recs;
 }
 
 }  // namespace oracle

@@ -252,7 +252,7 @@ void SolveBatch(const OracleProblem* op, int batch, const void* x0, void* xs, vo
     bool ok;
     if (fixed_iters == -1) {  // AugmentedLagrangianSolver::Solve
       S maxerr;
-      ok = SolveAL(p, x0v, &tr, &st, &fc, &it, &maxerr);
+      ok = SolveAL(p, x0v, &tr, &st, &fc, &it, &maxerr, &conv);
     } else {
       ok = SolveILQ(p, x0v, &tr, &st, &state, &al, fixed_iters, &log, &fc, &it, &conv, &raw);
     }
@@ -298,6 +298,159 @@ void RecedingHorizonBatch(const OracleProblem* op, int batch, const void* x0, do
     PackTraj(p, tr, (S*)xs + size_t(b) * T * n, (S*)us + size_t(b) * T * m);
     PackStrategies(p, st, (S*)P + size_t(b) * T * m * n, (S*)alpha + size_t(b) * T * m);
     std::memcpy((S*)x0_next + size_t(b) * n, xn.data(), sizeof(S) * n);
+  }
+}
+
+
+// ---- receding-horizon harness on plans stored [B][cap][...] with per-instance length and start time ----
+template <class S>
+Plan<S> LoadPlan(const Problem<S>& p, int cap, int len, double t0, const void* xs, const void* us, const void* P,
+                 const void* alpha, int b) {
+  Plan<S> pl;
+  const int n = p.n, m = p.m;
+  UnpackTraj(p, len, (const S*)xs + size_t(b) * cap * n, (const S*)us + size_t(b) * cap * m, &pl.op);
+  UnpackStrategies(p, len, (const S*)P + size_t(b) * cap * m * n, (const S*)alpha + size_t(b) * cap * m, &pl.st);
+  pl.t0 = t0;
+  return pl;
+}
+template <class S>
+void StorePlan(const Problem<S>& p, int cap, const Plan<S>& pl, void* xs, void* us, void* P, void* alpha, int b) {
+  const int n = p.n, m = p.m;
+  PackTraj(p, pl.op, (S*)xs + size_t(b) * cap * n, (S*)us + size_t(b) * cap * m);
+  PackStrategies(p, pl.st, (S*)P + size_t(b) * cap * m * n, (S*)alpha + size_t(b) * cap * m);
+}
+
+template <class S>
+void PlanIntegrateBatch(const OracleProblem* op, int batch, int cap, const void* xs, const void* us, const void* P,
+                        const void* alpha, const int32_t* len, const double* t0, double t_from, double t_to,
+                        double must_contain, void* x, int32_t* active) {
+  const Problem<S>& p = Get<S>(op);
+  for (int b = 0; b < batch; b++) {
+    if (!active[b]) continue;
+    const Plan<S> pl = LoadPlan<S>(p, cap, len[b], t0[b], xs, us, P, alpha, b);
+    if (!PlanContainsTime(pl, must_contain, p.dt) || !IntegrateIntervalValid(p, pl, t_from, t_to)) {
+      active[b] = 0;
+      continue;
+    }
+    S* xb = (S*)x + size_t(b) * p.n;
+    const Vec<S> xn = IntegrateInterval(p, t_from, t_to, Vec<S>(xb, xb + p.n), pl);
+    std::memcpy(xb, xn.data(), sizeof(S) * p.n);
+  }
+}
+
+template <class S>
+void RecedingSyncBatch(const OracleProblem* op, int batch, int cap, const void* pxs, const void* pus, const void* pP,
+                       const void* palpha, const int32_t* len, const double* t0, const void* x, double t,
+                       double planner_runtime, void* xs, void* us, void* P, void* alpha, void* x0_next,
+                       double* solve_t0, int32_t* first_step, int32_t* active) {
+  const Problem<S>& p = Get<S>(op);
+  for (int b = 0; b < batch; b++) {
+    if (!active[b]) continue;
+    Plan<S> pl = LoadPlan<S>(p, cap, len[b], t0[b], pxs, pus, pP, palpha, b);
+    if (!RecedingHorizonTimesValid(p, pl, t, planner_runtime)) {
+      active[b] = 0;
+      first_step[b] = -1;
+      continue;
+    }
+    const S* xb = (const S*)x + size_t(b) * p.n;
+    Vec<S> xn;
+    first_step[b] = SetUpNextRecedingHorizon(p, Vec<S>(xb, xb + p.n), t, planner_runtime, &pl, &xn);
+    StorePlan<S>(p, p.T, pl, xs, us, P, alpha, b);
+    std::memcpy((S*)x0_next + size_t(b) * p.n, xn.data(), sizeof(S) * p.n);
+    solve_t0[b] = pl.t0;
+  }
+}
+
+template <class S>
+void SpliceBatch(const OracleProblem* op, int batch, int cap, void* pxs, void* pus, void* pP, void* palpha, int32_t* len,
+                 double* t0, const void* xs, const void* us, const void* P, const void* alpha, const double* solve_t0,
+                 const int32_t* converged, const int32_t* active) {
+  const Problem<S>& p = Get<S>(op);
+  for (int b = 0; b < batch; b++) {
+    if (active && !active[b]) continue;
+    const Plan<S> sol = LoadPlan<S>(p, p.T, p.T, solve_t0[b], xs, us, P, alpha, b);
+    if (len[b] == 0) {  // SolutionSplicer's constructor
+      StorePlan<S>(p, cap, sol, pxs, pus, pP, palpha, b);
+      len[b] = p.T;
+      t0[b] = sol.t0;
+      continue;
+    }
+    if (converged && !converged[b]) continue;
+    Plan<S> pl = LoadPlan<S>(p, cap, len[b], t0[b], pxs, pus, pP, palpha, b);
+    SplicePlan(p, sol, &pl);
+    StorePlan<S>(p, cap, pl, pxs, pus, pP, palpha, b);
+    len[b] = pl.len();
+    t0[b] = pl.t0;
+  }
+}
+
+// One solver object per instance called again: `last_merit` [B] carries ILQSolver::last_merit_function_value_.
+template <class S>
+void SolveResumeBatch(const OracleProblem* op, int batch, const void* x0, void* xs, void* us, void* P, void* alpha,
+                      void* costs, int32_t* iters, int32_t* status, int32_t* converged, int al_mode, void* last_merit,
+                      int threads) {
+  const Problem<S>& p = Get<S>(op);
+  const int T = p.T, n = p.n, m = p.m, N = p.N;
+#pragma omp parallel for num_threads(threads) schedule(dynamic) if (threads > 1)
+  for (int b = 0; b < batch; b++) {
+    Plan<S> pl = LoadPlan<S>(p, T, T, 0.0, xs, us, P, alpha, b);
+    Vec<S> x0v((const S*)x0 + size_t(b) * n, (const S*)x0 + size_t(b + 1) * n);
+    ILQState<S> state;
+    state.last_merit = ((S*)last_merit)[b];
+    ALState<S> al(p.num_constraints, T, p.dt);
+    Vec<S> fc;
+    int it = 0, conv = 0;
+    bool ok;
+    if (al_mode) {
+      S maxerr;
+      ok = SolveAL(p, x0v, &pl.op, &pl.st, &fc, &it, &maxerr, &conv, &state);
+    } else {
+      ok = SolveILQ(p, x0v, &pl.op, &pl.st, &state, &al, 0, (std::vector<IterLog<S>>*)nullptr, &fc, &it, &conv);
+    }
+    ((S*)last_merit)[b] = state.last_merit;
+    StorePlan<S>(p, T, pl, xs, us, P, alpha, b);
+    std::memcpy((S*)costs + size_t(b) * N, fc.data(), sizeof(S) * N);
+    iters[b] = it;
+    status[b] = ok ? 1 : 0;
+    converged[b] = conv;
+  }
+}
+
+// The whole harness per instance.  Records are stored [B][max_records][...].
+template <class S>
+void SimulateBatch(const OracleProblem* op, int batch, const void* x_init, double final_time, double planner_runtime,
+                   double extra_time, double solve_time, int use_al, int max_records, int32_t* num_records,
+                   double* t_call, void* x_measured, void* x0, double* plan_t0, int32_t* first_step, void* xs, void* us,
+                   void* P, void* alpha, int32_t* iters, int32_t* ok, int32_t* converged, int32_t* max_bt, int cap, void* fxs,
+                   void* fus, void* fP, void* falpha, int32_t* flen, double* ft0, void* fx, int threads) {
+  const Problem<S>& p = Get<S>(op);
+  const int T = p.T, n = p.n, m = p.m;
+#pragma omp parallel for num_threads(threads) schedule(dynamic) if (threads > 1)
+  for (int b = 0; b < batch; b++) {
+    const S* xb = (const S*)x_init + size_t(b) * n;
+    Plan<S> fin;
+    Vec<S> xe;
+    const auto recs = RecedingHorizonSimulate(p, Vec<S>(xb, xb + n), final_time, planner_runtime, extra_time,
+                                              solve_time, use_al != 0, &fin, &xe, max_records);
+    num_records[b] = int(recs.size());
+    for (size_t r = 0; r < recs.size(); r++) {
+      const size_t at = size_t(b) * max_records + r;
+      t_call[at] = recs[r].t_call;
+      plan_t0[at] = recs[r].plan_t0;
+      first_step[at] = recs[r].first_step;
+      iters[at] = recs[r].iters;
+      ok[at] = recs[r].ok;
+      converged[at] = recs[r].converged;
+      max_bt[at] = recs[r].max_backtracks;
+      std::memcpy((S*)x_measured + at * n, recs[r].x_measured.data(), sizeof(S) * n);
+      std::memcpy((S*)x0 + at * n, recs[r].x0.data(), sizeof(S) * n);
+      PackTraj(p, recs[r].solution.op, (S*)xs + at * T * n, (S*)us + at * T * m);
+      PackStrategies(p, recs[r].solution.st, (S*)P + at * T * m * n, (S*)alpha + at * T * m);
+    }
+    StorePlan<S>(p, cap, fin, fxs, fus, fP, falpha, b);
+    flen[b] = fin.len();
+    ft0[b] = fin.t0;
+    std::memcpy((S*)fx + size_t(b) * n, xe.data(), sizeof(S) * n);
   }
 }
 
@@ -379,6 +532,48 @@ void oracle_receding_horizon_shift(void* h, int dtype, int batch, const void* x0
                                    int32_t* first_step, double* new_plan_t0) {
   DISPATCH(dtype, RecedingHorizonBatch, (OracleProblem*)h, batch, x0, t0, planner_runtime, plan_t0, xs, us, P, alpha,
            x0_next, first_step, new_plan_t0);
+}
+
+
+// MultiPlayerIntegrableSystem::Integrate(t0, t, x0, operating_point, strategies) under per-instance plans;
+// instances whose plan does not contain `must_contain` (SolutionSplicer::ContainsTime) are deactivated instead.
+void oracle_plan_integrate(void* h, int dtype, int batch, int cap, const void* xs, const void* us, const void* P,
+                           const void* alpha, const int32_t* len, const double* t0, double t_from, double t_to,
+                           double must_contain, void* x, int32_t* active) {
+  DISPATCH(dtype, PlanIntegrateBatch, (OracleProblem*)h, batch, cap, xs, us, P, alpha, len, t0, t_from, t_to,
+           must_contain, x, active);
+}
+// Problem::OverwriteSolution(plan) + SetUpNextRecedingHorizon(x, t, planner_runtime) per instance.
+void oracle_receding_horizon_sync(void* h, int dtype, int batch, int cap, const void* pxs, const void* pus,
+                                  const void* pP, const void* palpha, const int32_t* len, const double* t0, const void* x,
+                                  double t, double planner_runtime, void* xs, void* us, void* P, void* alpha,
+                                  void* x0_next, double* solve_t0, int32_t* first_step, int32_t* active) {
+  DISPATCH(dtype, RecedingSyncBatch, (OracleProblem*)h, batch, cap, pxs, pus, pP, palpha, len, t0, x, t, planner_runtime,
+           xs, us, P, alpha, x0_next, solve_t0, first_step, active);
+}
+// SolutionSplicer: construction (len == 0) or Splice of a converged solution.
+void oracle_solution_splice(void* h, int dtype, int batch, int cap, void* pxs, void* pus, void* pP, void* palpha,
+                            int32_t* len, double* t0, const void* xs, const void* us, const void* P, const void* alpha,
+                            const double* solve_t0, const int32_t* converged, const int32_t* active) {
+  DISPATCH(dtype, SpliceBatch, (OracleProblem*)h, batch, cap, pxs, pus, pP, palpha, len, t0, xs, us, P, alpha, solve_t0,
+           converged, active);
+}
+void oracle_solve_resume(void* h, int dtype, int batch, const void* x0, void* xs, void* us, void* P, void* alpha,
+                         void* costs, int32_t* iters, int32_t* status, int32_t* converged, int al_mode,
+                         void* last_merit, int threads) {
+  DISPATCH(dtype, SolveResumeBatch, (OracleProblem*)h, batch, x0, xs, us, P, alpha, costs, iters, status, converged,
+           al_mode, last_merit, threads);
+}
+void oracle_receding_horizon_simulate(void* h, int dtype, int batch, const void* x_init, double final_time,
+                                      double planner_runtime, double extra_time, double solve_time, int use_al,
+                                      int max_records, int32_t* num_records, double* t_call, void* x_measured, void* x0,
+                                      double* plan_t0, int32_t* first_step, void* xs, void* us, void* P, void* alpha,
+                                      int32_t* iters, int32_t* ok, int32_t* converged, int32_t* max_bt, int cap, void* fxs,
+                                      void* fus, void* fP, void* falpha, int32_t* flen, double* ft0, void* fx,
+                                      int threads) {
+  DISPATCH(dtype, SimulateBatch, (OracleProblem*)h, batch, x_init, final_time, planner_runtime, extra_time, solve_time,
+           use_al, max_records, num_records, t_call, x_measured, x0, plan_t0, first_step, xs, us, P, alpha, iters, ok,
+           converged, max_bt, cap, fxs, fus, fP, falpha, flen, ft0, fx, threads);
 }
 
 // xdot = f(x, u) and one Integrate step (double I/O regardless of dtype, for the

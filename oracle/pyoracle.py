@@ -162,6 +162,85 @@ class OracleProblem:
                                             _p(first), C.byref(npt))
         return dict(xs=a[0], us=a[1], P=a[2], alpha=a[3], x0_next=x0n, first_step=first, new_plan_t0=npt.value)
 
+    # ---- receding-horizon harness (plans stored [B][cap][...] with per-instance length / start time) ----
+    def new_plan(self, dtype, B, cap=None):
+        """Empty SolutionSplicer state: dict(xs, us, P, alpha, len, t0)."""
+        dt = _np(dtype)
+        cap = self.T + 5 if cap is None else cap
+        return dict(xs=np.zeros((B, cap, self.n), dt), us=np.zeros((B, cap, self.m), dt),
+                    P=np.zeros((B, cap, self.m * self.n), dt), alpha=np.zeros((B, cap, self.m), dt),
+                    len=np.zeros(B, np.int32), t0=np.zeros(B, np.float64))
+
+    def plan_integrate(self, dtype, plan, t_from, t_to, must_contain, x, active):
+        """MultiPlayerIntegrableSystem::Integrate(t0, t, x0, op, strategies); x and active are updated in place."""
+        cap = plan["xs"].shape[1]
+        lib().oracle_plan_integrate(self.h, dtype, x.shape[0], cap, _p(plan["xs"]), _p(plan["us"]), _p(plan["P"]),
+                                    _p(plan["alpha"]), _p(plan["len"]), _p(plan["t0"]), C.c_double(t_from),
+                                    C.c_double(t_to), C.c_double(must_contain), _p(x), _p(active))
+
+    def receding_horizon_sync(self, dtype, plan, x, t, planner_runtime, active):
+        """OverwriteSolution(plan) + SetUpNextRecedingHorizon per instance.  Returns the next solve's
+        dict(xs, us, P, alpha, x0, t0, first_step); active is updated in place."""
+        dt = _np(dtype)
+        B = x.shape[0]
+        cap = plan["xs"].shape[1]
+        o = dict(xs=np.zeros((B, self.T, self.n), dt), us=np.zeros((B, self.T, self.m), dt),
+                 P=np.zeros((B, self.T, self.m * self.n), dt), alpha=np.zeros((B, self.T, self.m), dt),
+                 x0=np.zeros((B, self.n), dt), t0=np.zeros(B, np.float64), first_step=np.zeros(B, np.int32))
+        lib().oracle_receding_horizon_sync(self.h, dtype, B, cap, _p(plan["xs"]), _p(plan["us"]), _p(plan["P"]),
+                                           _p(plan["alpha"]), _p(plan["len"]), _p(plan["t0"]), _p(x), C.c_double(t),
+                                           C.c_double(planner_runtime), _p(o["xs"]), _p(o["us"]), _p(o["P"]),
+                                           _p(o["alpha"]), _p(o["x0"]), _p(o["t0"]), _p(o["first_step"]), _p(active))
+        return o
+
+    def solution_splice(self, dtype, plan, sol, solve_t0, converged=None, active=None):
+        """SolutionSplicer construction (plan len 0) / Splice; plan is updated in place."""
+        cap = plan["xs"].shape[1]
+        B = plan["xs"].shape[0]
+        t0 = np.ascontiguousarray(solve_t0, np.float64)
+        lib().oracle_solution_splice(self.h, dtype, B, cap, _p(plan["xs"]), _p(plan["us"]), _p(plan["P"]),
+                                     _p(plan["alpha"]), _p(plan["len"]), _p(plan["t0"]), _p(sol["xs"]), _p(sol["us"]),
+                                     _p(sol["P"]), _p(sol["alpha"]), _p(t0), _p(converged), _p(active))
+
+    def solve_resume(self, dtype, x0, xs, us, P, alpha, last_merit, augmented_lagrangian=False, threads=1):
+        """Solve() of a solver object that has been called before: last_merit [B] (updated in place) carries
+        ILQSolver::last_merit_function_value_."""
+        dt = _np(dtype)
+        B = x0.shape[0]
+        x0 = np.ascontiguousarray(x0, dtype=dt)
+        a = [np.ascontiguousarray(v, dtype=dt).copy() for v in (xs, us, P, alpha)]
+        costs = np.zeros((B, self.N), dt)
+        iters, status, conv = (np.zeros(B, np.int32) for _ in range(3))
+        lib().oracle_solve_resume(self.h, dtype, B, _p(x0), _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), _p(costs),
+                                  _p(iters), _p(status), _p(conv), int(augmented_lagrangian), _p(last_merit),
+                                  int(threads))
+        return dict(xs=a[0], us=a[1], P=a[2], alpha=a[3], costs=costs, iters=iters, status=status, converged=conv)
+
+    def receding_horizon_simulate(self, dtype, x_init, final_time, planner_runtime, extra_time=0.25, solve_time=0.25,
+                                  augmented_lagrangian=False, max_records=64, threads=1):
+        """RecedingHorizonSimulator with a fixed simulated solve time.  Returns dict of per-record arrays
+        [B][max_records][...], num_records [B], the final spliced plan and the final true state."""
+        dt = _np(dtype)
+        B = x_init.shape[0]
+        R, T, n, m = max_records, self.T, self.n, self.m
+        x_init = np.ascontiguousarray(x_init, dtype=dt)
+        o = dict(num_records=np.zeros(B, np.int32), t_call=np.zeros((B, R)), x_measured=np.zeros((B, R, n), dt),
+                 x0=np.zeros((B, R, n), dt), plan_t0=np.zeros((B, R)), first_step=np.zeros((B, R), np.int32),
+                 xs=np.zeros((B, R, T, n), dt), us=np.zeros((B, R, T, m), dt), P=np.zeros((B, R, T, m * n), dt),
+                 alpha=np.zeros((B, R, T, m), dt), iters=np.zeros((B, R), np.int32), ok=np.zeros((B, R), np.int32),
+                 converged=np.zeros((B, R), np.int32), max_backtracks=np.zeros((B, R), np.int32),
+                 plan=self.new_plan(dtype, B), x=np.zeros((B, n), dt))
+        pl = o["plan"]
+        lib().oracle_receding_horizon_simulate(
+            self.h, dtype, B, _p(x_init), C.c_double(final_time), C.c_double(planner_runtime), C.c_double(extra_time),
+            C.c_double(solve_time), int(augmented_lagrangian), R, _p(o["num_records"]), _p(o["t_call"]),
+            _p(o["x_measured"]), _p(o["x0"]), _p(o["plan_t0"]), _p(o["first_step"]), _p(o["xs"]), _p(o["us"]),
+            _p(o["P"]), _p(o["alpha"]), _p(o["iters"]), _p(o["ok"]), _p(o["converged"]), _p(o["max_backtracks"]),
+            pl["xs"].shape[1],
+            _p(pl["xs"]), _p(pl["us"]), _p(pl["P"]), _p(pl["alpha"]), _p(pl["len"]), _p(pl["t0"]), _p(o["x"]),
+            int(threads))
+        return o
+
     def dynamics(self, dtype, x, u, euler=False):
         x = np.ascontiguousarray(x, np.float64)
         u = np.ascontiguousarray(u, np.float64)
