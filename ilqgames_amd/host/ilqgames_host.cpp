@@ -456,7 +456,8 @@ class DeviceSolve {
   }
 
   BatchResult Run(const std::vector<VectorXf>& x0s, const OperatingPoint& warm_op,
-                  const std::vector<Strategy>& warm_strategies, bool augmented_lagrangian) {
+                  const std::vector<Strategy>& warm_strategies, bool augmented_lagrangian,
+                  bool repeat_single = false) {
     const size_t B = x0s.size();
     CHECK_GT(B, 0);
     const auto start = Clock::now();
@@ -493,8 +494,19 @@ class DeviceSolve {
     CHECK_EQ(ilqg_workspace_bytes(handle_, static_cast<int32_t>(B), &ws_bytes), ILQG_OK) << ilqg_last_error();
     d_workspace_.Reserve(ws_bytes);
 
+    // Solve() called again on this solver object: ILQSolver::last_merit_function_value_ (ilq_solver.h:189) is
+    // a member in the reference and outlives the call; the device keeps it in the workspace.  SolveBatch is
+    // this library's own entry and always behaves like freshly constructed solvers.
+    const bool again = repeat_single && B == 1 && solved_single_ && last_kind_ == augmented_lagrangian;
+    solved_single_ = repeat_single && B == 1;
+    last_kind_ = augmented_lagrangian;
     ilqg_status s;
-    if (augmented_lagrangian)
+    if (again)
+      s = ilqg_solve_again_batch(handle_, 1, d_x0_.get(), d_xs_.get(), d_us_.get(), d_P_.get(), d_alpha_.get(),
+                                 d_costs_.get(), static_cast<int32_t*>(d_iters_.get()),
+                                 static_cast<int32_t*>(d_status_.get()), static_cast<int32_t*>(d_conv_.get()),
+                                 d_workspace_.get(), augmented_lagrangian ? 1 : 0, nullptr, nullptr);
+    else if (augmented_lagrangian)
       s = ilqg_al_solve_batch(handle_, static_cast<int32_t>(B), d_x0_.get(), d_xs_.get(), d_us_.get(), d_P_.get(),
                               d_alpha_.get(), d_costs_.get(), static_cast<int32_t*>(d_iters_.get()),
                               static_cast<int32_t*>(d_status_.get()), static_cast<int32_t*>(d_conv_.get()),
@@ -548,6 +560,7 @@ class DeviceSolve {
   ilqg_problem* handle_ = nullptr;
   int n_ = 0, m_ = 0, N_ = 0, T_ = 0;
   std::vector<int> udims_;
+  bool solved_single_ = false, last_kind_ = false;
   DeviceBuffer d_x0_, d_xs_, d_us_, d_P_, d_alpha_, d_costs_, d_iters_, d_status_, d_conv_, d_workspace_;
 };
 
@@ -647,67 +660,272 @@ bool SaveLogs(const std::vector<std::shared_ptr<const SolverLog>>& logs, bool on
 // ------------------------------------------------------------------------------------------
 // Receding horizon
 // ------------------------------------------------------------------------------------------
+namespace host {
+
+// A stored plan (operating point + strategies of any length) flattened the way the C ABI takes it.
+struct FlatPlan {
+  int rows = 0, n = 0, m = 0;
+  std::vector<float> xs, us, P, alpha;
+};
+
+FlatPlan FlattenPlan(const MultiPlayerIntegrableSystem& dyn, const OperatingPoint& op,
+                     const std::vector<Strategy>& strategies, int capacity) {
+  FlatPlan f;
+  f.rows = static_cast<int>(op.xs.size());
+  f.n = dyn.XDim();
+  f.m = dyn.TotalUDim();
+  const int N = dyn.NumPlayers(), n = f.n, m = f.m;
+  CHECK_LE(f.rows, capacity);
+  CHECK_EQ(static_cast<int>(strategies.size()), N);
+  f.xs.assign(size_t(capacity) * n, 0.0f);
+  f.us.assign(size_t(capacity) * m, 0.0f);
+  f.P.assign(size_t(capacity) * m * n, 0.0f);
+  f.alpha.assign(size_t(capacity) * m, 0.0f);
+  for (int k = 0; k < f.rows; k++) {
+    std::memcpy(&f.xs[size_t(k) * n], op.xs[k].data(), n * sizeof(float));
+    int row = 0;
+    for (int i = 0; i < N; i++) {
+      const int mi = dyn.UDim(i);
+      std::memcpy(&f.us[size_t(k) * m + row], op.us[k][i].data(), mi * sizeof(float));
+      std::memcpy(&f.alpha[size_t(k) * m + row], strategies[i].alphas[k].data(), mi * sizeof(float));
+      for (int c = 0; c < n; c++)
+        for (int r = 0; r < mi; r++) f.P[(size_t(k) * n + c) * m + row + r] = strategies[i].Ps[k](r, c);
+      row += mi;
+    }
+  }
+  return f;
+}
+
+// Device buffers of one stored plan, plus its length / start time as the harness kernels read them.
+struct DevicePlan {
+  DeviceBuffer xs, us, P, alpha, len, t0;
+  int capacity = 0;
+  void Upload(const FlatPlan& f, int cap, Time plan_t0, ilqg_dtype dtype) {
+    capacity = cap;
+    host::Upload(&xs, f.xs, dtype);
+    host::Upload(&us, f.us, dtype);
+    host::Upload(&P, f.P, dtype);
+    host::Upload(&alpha, f.alpha, dtype);
+    const int32_t rows = f.rows;
+    const double start = plan_t0;
+    len.Reserve(sizeof(int32_t));
+    t0.Reserve(sizeof(double));
+    HipCheck(hipMemcpy(len.get(), &rows, sizeof(rows), hipMemcpyHostToDevice), "plan length");
+    HipCheck(hipMemcpy(t0.get(), &start, sizeof(start), hipMemcpyHostToDevice), "plan start time");
+  }
+};
+
+// ilqg_problem handle that only needs the dynamics (the plan kernels never look at cost terms).
+struct DynamicsHandle {
+  ilqg_problem* handle = nullptr;
+  explicit DynamicsHandle(const MultiPlayerIntegrableSystem& dynamics) {
+    const auto* dyn = dynamic_cast<const ConcatenatedDynamicalSystem*>(&dynamics);
+    CHECK(dyn != nullptr) << "dynamics are not a ConcatenatedDynamicalSystem";
+    ilqg_problem_desc d{};
+    d.num_players = dyn->NumPlayers();
+    for (int i = 0; i < d.num_players; i++) {
+      d.subsystems[i] = dyn->Subsystems()[i]->Describe();
+      CHECK_NE(d.subsystems[i].kind, 0) << "subsystem " << i << " has no device model";
+    }
+    // the handle's tables want every player to own a control Hessian; the plan kernels never evaluate it
+    ilqg_cost_term own_control[ILQG_MAX_PLAYERS] = {};
+    for (int i = 0; i < d.num_players; i++) {
+      ilqg_cost_term& c = own_control[i];
+      c.kind = ILQG_COST_QUADRATIC;
+      c.role = ILQG_ROLE_CONTROL_COST;
+      c.player = c.arg = i;
+      c.idx[0] = -1;
+      c.weight = 1.0f;
+      c.polyline = c.constraint_slot = -1;
+    }
+    d.terms = own_control;
+    d.num_terms = d.num_players;
+    const int32_t no_polylines[1] = {0};
+    d.polyline_offsets = no_polylines;
+    d.T = static_cast<int>(time::kNumTimeSteps);
+    d.dt = time::kTimeStep;
+    d.dtype = Options().dtype;
+    CHECK_EQ(ilqg_problem_create(&d, &handle), ILQG_OK) << ilqg_last_error();
+  }
+  ~DynamicsHandle() {
+    if (handle != nullptr) ilqg_problem_destroy(handle);
+  }
+};
+
+}  // namespace host
+
+// include/ilqgames/dynamics/multi_player_integrable_system.h:75-79, src/multi_player_integrable_system.cpp:54-74
+VectorXf MultiPlayerIntegrableSystem::Integrate(Time t0, Time t, const VectorXf& x0,
+                                                const OperatingPoint& operating_point,
+                                                const std::vector<Strategy>& strategies) const {
+  using namespace host;
+  CHECK_GE(t, t0);
+  CHECK_GE(t0, operating_point.t0);
+  const ilqg_dtype dtype = Options().dtype;
+  const int n = XDim();
+  const int cap = std::max<int>(static_cast<int>(operating_point.xs.size()), static_cast<int>(time::kNumTimeSteps));
+  DynamicsHandle dyn(*this);
+  DevicePlan plan;
+  plan.Upload(FlattenPlan(*this, operating_point, strategies, cap), cap, operating_point.t0, dtype);
+  DeviceBuffer dx, dactive;
+  Upload(&dx, std::vector<float>(x0.data(), x0.data() + n), dtype);
+  const int32_t one = 1;
+  dactive.Reserve(sizeof(int32_t));
+  HipCheck(hipMemcpy(dactive.get(), &one, sizeof(one), hipMemcpyHostToDevice), "active flag");
+  // must_contain = t0: always inside the plan here (CHECKed above); rows the integration would read past the
+  // plan clear the flag, which is where the reference CHECK-aborts (:111-112, :141-142)
+  const ilqg_status s = ilqg_plan_integrate_batch(
+      dyn.handle, 1, cap, plan.xs.get(), plan.us.get(), plan.P.get(), plan.alpha.get(),
+      static_cast<const int32_t*>(plan.len.get()), static_cast<const double*>(plan.t0.get()), t0, t, t0, dx.get(),
+      static_cast<int32_t*>(dactive.get()), nullptr);
+  CHECK_EQ(s, ILQG_OK) << ilqg_last_error();
+  HipCheck(hipDeviceSynchronize(), "plan integrate");
+  CHECK_EQ(DownloadInts(dactive, 1)[0], 1) << "Integrate(" << t0 << ", " << t << "): times outside the stored plan";
+  const std::vector<float> xn = Download(dx, n, dtype);
+  VectorXf out = VectorXf::Zero(n);
+  std::memcpy(out.data(), xn.data(), n * sizeof(float));
+  return out;
+}
+
 void Problem::SetUpNextRecedingHorizon(const VectorXf& x0, Time t0, Time planner_runtime) {
   using namespace host;
   CHECK(initialized_);
   const ilqg_dtype dtype = Options().dtype;
-  ProblemDescription description;
-  std::string why;
-  CHECK(DescribeProblem(*this, SolverParams(), dtype, &description, &why)) << why;
-  ilqg_problem* handle = nullptr;
-  CHECK_EQ(ilqg_problem_create(&description.desc, &handle), ILQG_OK) << ilqg_last_error();
   const int n = dynamics_->XDim(), m = dynamics_->TotalUDim(), N = dynamics_->NumPlayers();
-  const int T = static_cast<int>(operating_point_->xs.size());
-  CHECK_EQ(T, description.desc.T);
-  std::vector<float> xs(T * n), us(T * m), P(T * m * n), alpha(T * m);
-  for (int k = 0; k < T; k++) {
-    std::memcpy(&xs[k * n], operating_point_->xs[k].data(), n * sizeof(float));
-    int row = 0;
-    for (int i = 0; i < N; i++) {
-      const int mi = dynamics_->UDim(i);
-      std::memcpy(&us[k * m + row], operating_point_->us[k][i].data(), mi * sizeof(float));
-      std::memcpy(&alpha[k * m + row], (*strategies_)[i].alphas[k].data(), mi * sizeof(float));
-      for (int c = 0; c < n; c++)
-        for (int r = 0; r < mi; r++) P[(k * n + c) * m + row + r] = (*strategies_)[i].Ps[k](r, c);
-      row += mi;
-    }
-  }
-  DeviceBuffer dx0, dxs, dus, dP, dal, dxn, dfirst;
+  const int T = static_cast<int>(time::kNumTimeSteps);
+  const int rows = static_cast<int>(operating_point_->xs.size());
+  CHECK_GE(rows, T);  // src/problem.cpp:159
+  // the stored plan may be what a SolutionSplicer handed over: up to five rows longer than the horizon
+  const int cap = rows;
+  DynamicsHandle dyn(*dynamics_);
+  DevicePlan plan;
+  plan.Upload(FlattenPlan(*dynamics_, *operating_point_, *strategies_, cap), cap, operating_point_->t0, dtype);
+  DeviceBuffer dx0, dxs, dus, dP, dal, dxn, dfirst, dt0, dactive;
   Upload(&dx0, std::vector<float>(x0.data(), x0.data() + n), dtype);
-  Upload(&dxs, xs, dtype);
-  Upload(&dus, us, dtype);
-  Upload(&dP, P, dtype);
-  Upload(&dal, alpha, dtype);
+  dxs.Reserve(size_t(T) * n * ElemBytes(dtype));
+  dus.Reserve(size_t(T) * m * ElemBytes(dtype));
+  dP.Reserve(size_t(T) * m * n * ElemBytes(dtype));
+  dal.Reserve(size_t(T) * m * ElemBytes(dtype));
   dxn.Reserve(n * ElemBytes(dtype));
   dfirst.Reserve(sizeof(int32_t));
-  double new_t0 = 0.0;
-  // times outside the stored plan abort in the reference (CHECKs at src/problem.cpp:68-70); same here
-  const ilqg_status s = ilqg_receding_horizon_shift_batch(handle, 1, dx0.get(), t0, planner_runtime, operating_point_->t0,
-                                                          dxs.get(), dus.get(), dP.get(), dal.get(), dxn.get(),
-                                                          static_cast<int32_t*>(dfirst.get()), &new_t0, nullptr);
+  dt0.Reserve(sizeof(double));
+  const int32_t one = 1;
+  dactive.Reserve(sizeof(int32_t));
+  HipCheck(hipMemcpy(dactive.get(), &one, sizeof(one), hipMemcpyHostToDevice), "active flag");
+  const ilqg_status s = ilqg_receding_horizon_sync_batch(
+      dyn.handle, 1, cap, plan.xs.get(), plan.us.get(), plan.P.get(), plan.alpha.get(),
+      static_cast<const int32_t*>(plan.len.get()), static_cast<const double*>(plan.t0.get()), dx0.get(), t0,
+      planner_runtime, dxs.get(), dus.get(), dP.get(), dal.get(), dxn.get(), static_cast<double*>(dt0.get()),
+      static_cast<int32_t*>(dfirst.get()), static_cast<int32_t*>(dactive.get()), nullptr);
   CHECK_EQ(s, ILQG_OK) << ilqg_last_error();
   HipCheck(hipDeviceSynchronize(), "receding horizon");
-  xs = Download(dxs, xs.size(), dtype);
-  us = Download(dus, us.size(), dtype);
-  P = Download(dP, P.size(), dtype);
-  alpha = Download(dal, alpha.size(), dtype);
-  const std::vector<float> xn = Download(dxn, n, dtype);
-  ilqg_problem_destroy(handle);
+  // times outside the stored plan abort in the reference (CHECKs at src/problem.cpp:68-70); same here
+  CHECK_EQ(DownloadInts(dactive, 1)[0], 1) << "SetUpNextRecedingHorizon: t0 / planner_runtime outside the stored plan";
+  const std::vector<float> xs = Download(dxs, size_t(T) * n, dtype), us = Download(dus, size_t(T) * m, dtype),
+                           P = Download(dP, size_t(T) * m * n, dtype), alpha = Download(dal, size_t(T) * m, dtype),
+                           xn = Download(dxn, n, dtype);
+  double new_t0 = 0.0;
+  HipCheck(hipMemcpy(&new_t0, dt0.get(), sizeof(new_t0), hipMemcpyDeviceToHost), "new plan start time");
+  operating_point_->xs.resize(T);
+  operating_point_->us.resize(T);
+  for (int i = 0; i < N; i++) {
+    (*strategies_)[i].Ps.resize(T);
+    (*strategies_)[i].alphas.resize(T);
+  }
   for (int k = 0; k < T; k++) {
-    std::memcpy(operating_point_->xs[k].data(), &xs[k * n], n * sizeof(float));
+    std::memcpy(operating_point_->xs[k].data(), &xs[size_t(k) * n], n * sizeof(float));
     int row = 0;
     for (int i = 0; i < N; i++) {
       const int mi = dynamics_->UDim(i);
-      std::memcpy(operating_point_->us[k][i].data(), &us[k * m + row], mi * sizeof(float));
-      std::memcpy((*strategies_)[i].alphas[k].data(), &alpha[k * m + row], mi * sizeof(float));
+      std::memcpy(operating_point_->us[k][i].data(), &us[size_t(k) * m + row], mi * sizeof(float));
+      std::memcpy((*strategies_)[i].alphas[k].data(), &alpha[size_t(k) * m + row], mi * sizeof(float));
       for (int c = 0; c < n; c++)
-        for (int r = 0; r < mi; r++) (*strategies_)[i].Ps[k](r, c) = P[(k * n + c) * m + row + r];
+        for (int r = 0; r < mi; r++) (*strategies_)[i].Ps[k](r, c) = P[(size_t(k) * n + c) * m + row + r];
       row += mi;
     }
   }
   x0_ = VectorXf::Zero(n);
   std::memcpy(x0_.data(), xn.data(), n * sizeof(float));
   operating_point_->t0 = new_t0;
+}
+
+// ------------------------------------------------------------------------------------------
+// SolutionSplicer (src/solution_splicer.cpp:56-129) — bookkeeping on the host-side containers; the batched
+// form that keeps plans on the device is ilqg_solution_splice_batch.
+// ------------------------------------------------------------------------------------------
+SolutionSplicer::SolutionSplicer(const SolverLog& log)
+    : strategies_(log.FinalStrategies()), operating_point_(log.FinalOperatingPoint()) {}
+
+void SolutionSplicer::Splice(const SolverLog& log) {
+  const OperatingPoint& fresh = log.FinalOperatingPoint();
+  const std::vector<Strategy>& fresh_strategies = log.FinalStrategies();
+  const size_t T = time::kNumTimeSteps;
+  CHECK_GE(fresh.t0, operating_point_.t0);
+  CHECK_GE(operating_point_.xs.size(), T);
+  CHECK_EQ(fresh.xs.size(), T);
+  // where the new solution begins inside the stored one, and how much of the past to keep in front of it
+  const size_t begins_at = static_cast<size_t>(1e-4 + (fresh.t0 - operating_point_.t0) / time::kTimeStep);
+  const size_t kept = std::min<size_t>(begins_at, 5);
+  const size_t dropped = begins_at - kept;
+  const size_t total = kept + T;
+  OperatingPoint spliced(total, static_cast<PlayerIndex>(strategies_.size()),
+                         operating_point_.t0 + dropped * time::kTimeStep);
+  std::vector<Strategy> spliced_strategies;
+  for (const Strategy& st : strategies_)
+    spliced_strategies.emplace_back(total, static_cast<Dimension>(st.Ps[0].cols()),
+                                    static_cast<Dimension>(st.Ps[0].rows()));
+  for (size_t kk = 0; kk < total; kk++) {
+    const bool old_part = kk < kept;
+    const OperatingPoint& src = old_part ? operating_point_ : fresh;
+    const std::vector<Strategy>& src_strategies = old_part ? strategies_ : fresh_strategies;
+    const size_t at = old_part ? dropped + kk : kk - kept;
+    spliced.xs[kk] = src.xs[at];
+    spliced.us[kk] = src.us[at];
+    for (size_t ii = 0; ii < strategies_.size(); ii++) {
+      spliced_strategies[ii].Ps[kk] = src_strategies[ii].Ps[at];
+      spliced_strategies[ii].alphas[kk] = src_strategies[ii].alphas[at];
+    }
+  }
+  operating_point_.swap(spliced);
+  strategies_.swap(spliced_strategies);
+}
+
+// ------------------------------------------------------------------------------------------
+// RecedingHorizonSimulator (src/receding_horizon_simulator.cpp:64-137)
+// ------------------------------------------------------------------------------------------
+std::vector<std::shared_ptr<const SolverLog>> RecedingHorizonSimulator(Time final_time, Time planner_runtime,
+                                                                       GameSolver* solver) {
+  CHECK_NOTNULL(solver);
+  using Clock = std::chrono::system_clock;
+  const Time fixed_solve_time = host::Options().simulated_solve_time;
+  std::vector<std::shared_ptr<const SolverLog>> logs;
+  bool success = false;
+  logs.push_back(solver->Solve(&success));
+  CHECK(success);
+  Problem& problem = solver->GetProblem();
+  SolutionSplicer splicer(*logs.front());
+  VectorXf x(problem.InitialState());
+  Time t = splicer.CurrentOperatingPoint().t0;
+  const Time kExtraTime = 0.25;
+  while (true) {
+    t += kExtraTime;
+    if (t >= final_time || !splicer.ContainsTime(t + planner_runtime + time::kTimeStep)) break;
+    x = problem.Dynamics()->Integrate(t - kExtraTime, t, x, splicer.CurrentOperatingPoint(),
+                                      splicer.CurrentStrategies());
+    problem.OverwriteSolution(splicer.CurrentOperatingPoint(), splicer.CurrentStrategies());
+    problem.SetUpNextRecedingHorizon(x, t, planner_runtime);
+    const auto call_time = Clock::now();
+    logs.push_back(solver->Solve(&success, planner_runtime));
+    Time elapsed = std::chrono::duration<Time>(Clock::now() - call_time).count();
+    if (fixed_solve_time >= 0.0) elapsed = fixed_solve_time;  // deterministic runs (host::DeviceOptions)
+    CHECK_LE(elapsed, planner_runtime);
+    t += elapsed;
+    if (t >= final_time || !splicer.ContainsTime(t)) break;
+    x = problem.Dynamics()->Integrate(t - elapsed, t, x, splicer.CurrentOperatingPoint(),
+                                      splicer.CurrentStrategies());
+    if (logs.back()->WasConverged()) splicer.Splice(*logs.back());
+  }
+  return logs;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -727,18 +945,24 @@ host::BatchResult GameSolver::SolveBatch(const std::vector<VectorXf>& x0s) {
   return device_->Run(x0s, problem_->CurrentOperatingPoint(), problem_->CurrentStrategies(), augmented_lagrangian_);
 }
 
+host::BatchResult GameSolver::SolveOne() {
+  if (!device_) device_.reset(new host::DeviceSolve(*problem_, params_));
+  return device_->Run({problem_->InitialState()}, problem_->CurrentOperatingPoint(), problem_->CurrentStrategies(),
+                      augmented_lagrangian_, /*repeat_single=*/true);
+}
+
 // `max_runtime` (the reference's wall-clock anytime exit, src/ilq_solver.cpp:101-104) is not
 // reproduced: the loop runs on the device; bound it with SolverParams::max_solver_iters.
 std::shared_ptr<SolverLog> ILQSolver::Solve(bool* success, Time max_runtime) {
   (void)max_runtime;
-  host::BatchResult r = SolveBatch({problem_->InitialState()});
+  host::BatchResult r = SolveOne();
   if (success != nullptr) *success = r.success[0];
   return r.logs[0];
 }
 
 std::shared_ptr<SolverLog> AugmentedLagrangianSolver::Solve(bool* success, Time max_runtime) {
   (void)max_runtime;
-  host::BatchResult r = SolveBatch({problem_->InitialState()});
+  host::BatchResult r = SolveOne();
   if (success != nullptr) *success = r.success[0];
   return r.logs[0];
 }

@@ -432,6 +432,8 @@ class SinglePlayerCar6D : public SinglePlayerDynamicalSystem {
 
 // include/ilqgames/dynamics/multi_player_integrable_system.h:57-140 (shape queries only; the
 // RK4 integrator is ilqg_rollout_batch on the device).
+struct OperatingPoint;
+struct Strategy;
 class MultiPlayerIntegrableSystem {
  public:
   virtual ~MultiPlayerIntegrableSystem() {}
@@ -448,6 +450,11 @@ class MultiPlayerIntegrableSystem {
   // The reference toggles Euler / RK4 globally (multi_player_integrable_system.h:118-120); the device
   // integrator is RK4 with two sub-steps, the reference default.
   static bool IntegrationUsesEuler() { return false; }
+  // Integrate x0 from time t0 to t under the given plan's strategies (multi_player_integrable_system.h:75-79,
+  // src/multi_player_integrable_system.cpp:54-74): partial step to the next plan time, whole steps, partial last
+  // step.  Runs on the device (ilqg_plan_integrate_batch); concatenated systems only.
+  VectorXf Integrate(Time t0, Time t, const VectorXf& x0, const OperatingPoint& operating_point,
+                     const std::vector<Strategy>& strategies) const;
 
  protected:
   MultiPlayerIntegrableSystem(Dimension xdim) : xdim_(xdim) {}
@@ -705,6 +712,9 @@ namespace host {
 // Arithmetic type of the device solve (the containers above stay float, as in the reference).
 struct DeviceOptions {
   ilqg_dtype dtype = ILQG_F64;
+  // RecedingHorizonSimulator: time charged per solver call.  Negative = the wall clock, as the reference does
+  // (src/receding_horizon_simulator.cpp:110-114); a fixed value makes runs reproducible.
+  Time simulated_solve_time = -1.0;
 };
 DeviceOptions& Options();
 
@@ -803,6 +813,7 @@ class GameSolver {
  protected:
   GameSolver(const std::shared_ptr<Problem>& problem, const SolverParams& params, bool augmented_lagrangian);
   virtual std::shared_ptr<SolverLog> CreateNewLog() const { return std::make_shared<SolverLog>(); }
+  host::BatchResult SolveOne();  // Solve(): one instance; a repeated call continues this solver object's state
   const std::shared_ptr<Problem> problem_;
   const SolverParams params_;
 
@@ -827,6 +838,31 @@ class AugmentedLagrangianSolver : public GameSolver {
       : GameSolver(problem, params, true) {}
   std::shared_ptr<SolverLog> Solve(bool* success = nullptr, Time max_runtime = 5.0) override;
 };
+
+// include/ilqgames/solver/solution_splicer.h:57-86
+class SolutionSplicer {
+ public:
+  ~SolutionSplicer() {}
+  explicit SolutionSplicer(const SolverLog& log);
+  // Splice in a new solution: up to five steps of the stored plan that precede the new solution's start are
+  // kept in front of it (src/solution_splicer.cpp:60-129).
+  void Splice(const SolverLog& log);
+  bool ContainsTime(Time t) const {
+    return (operating_point_.t0 <= t) && (operating_point_.t0 + operating_point_.xs.size() * time::kTimeStep >= t);
+  }
+  const std::vector<Strategy>& CurrentStrategies() const { return strategies_; }
+  const OperatingPoint& CurrentOperatingPoint() const { return operating_point_; }
+
+ private:
+  std::vector<Strategy> strategies_;
+  OperatingPoint operating_point_;
+};
+
+// include/ilqgames/examples/receding_horizon_simulator.h:58-60.  The solver is called repeatedly on problems
+// re-anchored at the simulated state; between calls the state follows the spliced plan for 0.25 s plus the
+// solve time (wall clock, or host::Options().simulated_solve_time when that is >= 0).
+std::vector<std::shared_ptr<const SolverLog>> RecedingHorizonSimulator(Time final_time, Time planner_runtime,
+                                                                       GameSolver* solver);
 
 // include/ilqgames/examples/roundabout_lane_center.h:55-57
 PointList2 RoundaboutLaneCenter(float entrance_angle, float exit_angle, float distance_from_roundabout);

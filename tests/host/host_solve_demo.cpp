@@ -17,6 +17,8 @@
 #include <ilqgames/solver/ilq_solver.h>
 #include <ilqgames/solver/lq_feedback_solver.h>
 #include <ilqgames/solver/lq_open_loop_solver.h>
+#include <ilqgames/examples/receding_horizon_simulator.h>
+#include <ilqgames/solver/solution_splicer.h>
 #include <ilqgames/solver/top_down_renderable_problem.h>
 
 #include <fstream>
@@ -309,7 +311,32 @@ int main(int argc, char** argv) {
     WriteLog(os, *log, success);
   }
 
-  // 3. the LQ seam on its own
+  // 3. the receding-horizon loop of the reference's examples, with a fixed simulated solve time
+  {
+    SolverParams rh_params(params);
+    rh_params.max_solver_iters = 8;
+    rh_params.max_backtracking_steps = 100;
+    rh_params.initial_alpha_scaling = 0.5f;
+    rh_params.convergence_tolerance = 0.5f;
+    auto problem = std::make_shared<MergeScene>(false);
+    problem->Initialize();
+    host::ProblemDescription description;
+    std::string why;
+    CHECK(host::DescribeProblem(*problem, rh_params, ILQG_F64, &description, &why)) << why;
+    std::ofstream(outdir + "/scene_rh.txt") << host::DumpDescription(description);
+    ILQSolver solver(problem, rh_params);
+    host::Options().simulated_solve_time = 0.25;
+    const auto logs = RecedingHorizonSimulator(3.0, 0.25, &solver);
+    host::Options().simulated_solve_time = -1.0;
+    std::ofstream os(outdir + "/rh_sim.txt");
+    os << std::setprecision(9) << "calls " << logs.size() << "\n";
+    for (const auto& log : logs) {
+      os << "t0 " << log->FinalOperatingPoint().t0 << "\n";
+      WriteLog(os, *log, true);
+    }
+  }
+
+  // 4. the LQ seam on its own
   RunLqGame(outdir, false);
   RunLqGame(outdir, true);
   std::cout << "host_solve_demo: done\n";

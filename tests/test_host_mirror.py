@@ -73,6 +73,53 @@ def test_solver_log_on_disk_layout_and_row_format(tmp_path):
     assert sorted(os.listdir(lst)) == ["0", "1"] and os.listdir(lst / "0") == ["1"]
 
 
+def test_cpp_solution_splicer_keeps_five_rows_and_moves_the_start_time():
+    """SolutionSplicer of the C++ mirror (tests/host/splicer_check.cpp, no device involved) against the layout
+    src/solution_splicer.cpp:60-129 produces: up to five rows of the stored plan in front of the new solution,
+    start time moved by the rows dropped, everything after the splice point replaced."""
+    exe = os.path.join(BIN, "splicer_check")
+    if not os.path.exists(exe):
+        entry.build_host()
+    lines = subprocess.check_output([exe], timeout=60).decode().splitlines()
+    T, dt, n, m = 100, 0.1, 3, 2
+    f = np.float32
+
+    def rows_of(tag):  # the driver's MakeLog, same float32 arithmetic
+        out = np.zeros((T, n + m + m + m * n), np.float32)
+        for k in range(T):
+            for e in range(n):
+                out[k, e] = f(tag) + f(0.01) * f(k) + f(0.001) * f(e)
+            for e in range(m):
+                out[k, n + e] = -f(tag) - f(0.02) * f(k) + f(0.003) * f(e)
+                out[k, n + m + e] = f(0.5) * f(tag) + f(0.001) * f(k * (e + 1))
+                for c in range(n):  # column-major (m x n) gain
+                    out[k, n + 2 * m + c * m + e] = f(tag) + f(0.1) * f(e) + f(0.01) * f(c) + f(0.0001) * f(k)
+        return out
+
+    def splice(plan, plan_t0, fresh, fresh_t0):
+        at = int(1e-4 + (fresh_t0 - plan_t0) / dt)
+        keep = min(at, 5)
+        return np.concatenate([plan[at - keep:at], fresh]), plan_t0 + (at - keep) * dt
+
+    it = iter(lines)
+    cases = 0
+    for line in it:
+        tok = line.split()
+        assert tok[0] == "case"
+        start = float(tok[1])
+        assert tok[3] == "1" and tok[4] == "0"  # ContainsTime inside / before the plan
+        expect, t0 = splice(rows_of(1.0), 1.5, rows_of(2.0), 1.5 + start)
+        for rnd in range(2):
+            head = next(it).split()
+            assert head[0] == "plan" and int(head[1]) == len(expect) and abs(float(head[2]) - t0) < 1e-6
+            got = np.array([[float(v) for v in next(it).split()[1:]] for _ in range(len(expect))])
+            assert np.max(np.abs(got - expect)) < 1e-5
+            if rnd == 0:
+                expect, t0 = splice(expect, t0, rows_of(3.0), t0 + 0.7)
+        cases += 1
+    assert cases == 5
+
+
 @pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present")
 @pytest.mark.parametrize("cls,stem,builder", EXAMPLES, ids=[e[1] for e in EXAMPLES])
 def test_reference_example_source_compiles_unchanged_and_flattens_like_examples_py(cls, stem, builder, tmp_path):
@@ -174,6 +221,41 @@ def test_cpp_receding_horizon_resync_matches_oracle(demo_out, oracle):
     assert np.max(np.abs(np.array(rows["x"]) - o["xs"][0])) < 2e-4 * max(1.0, np.max(np.abs(o["xs"])))
     assert np.max(np.abs(np.array(rows["u"]) - o["us"][0])) < 2e-4 * max(1.0, np.max(np.abs(o["us"])))
     assert int(o["first_step"][0]) > 0
+
+
+@pytest.mark.gpu
+def test_cpp_receding_horizon_simulator_matches_oracle(demo_out, oracle):
+    """RecedingHorizonSimulator of the C++ mirror (Integrate, OverwriteSolution, SetUpNextRecedingHorizon, repeated
+    Solve() on one ILQSolver, SolutionSplicer) with a fixed 0.25 s per call, against the oracle's restatement of
+    the same loop: same number of solver calls, same window start times and flags, trajectories within the float
+    round-off of the host containers."""
+    logs = []
+    for line in open(os.path.join(demo_out, "rh_sim.txt")):
+        tok = line.split()
+        if tok[0] == "calls":
+            calls = int(tok[1])
+        elif tok[0] == "t0":
+            logs.append(dict(t0=float(tok[1]), xs=[], us=[]))
+        elif tok[0] == "success":
+            logs[-1]["converged"], logs[-1]["iters"] = int(tok[3]), int(tok[5])
+        elif tok[0] == "x":
+            logs[-1]["xs"].append([float(v) for v in tok[1:]])
+        elif tok[0] == "u":
+            logs[-1]["us"].append([float(v) for v in tok[1:]])
+    assert calls == len(logs) and calls >= 4
+    spec = abi.ProblemSpec.from_dump(open(os.path.join(demo_out, "scene_rh.txt")).read())
+    x0 = np.array(logs[0]["xs"][0])
+    ref = oracle.OracleProblem(spec).receding_horizon_simulate(abi.F64, x0[None, :], 3.0, 0.25, max_records=32)
+    R = int(ref["num_records"][0])
+    assert R == calls, (R, calls)
+    for r, log in enumerate(logs):
+        assert abs(log["t0"] - ref["plan_t0"][0, r]) < 1e-6, r
+        assert log["iters"] == ref["iters"][0, r] and log["converged"] == ref["converged"][0, r], r
+        xs, us = np.array(log["xs"]), np.array(log["us"])
+        assert np.max(np.abs(xs - ref["xs"][0, r])) < 5e-4 * max(1.0, np.max(np.abs(ref["xs"][0, r]))), r
+        assert np.max(np.abs(us - ref["us"][0, r])) < 5e-4 * max(1.0, np.max(np.abs(ref["us"][0, r]))), r
+    # the second call already starts from the carried merit value: its line search fails on the first iteration
+    assert ref["iters"][0, 1] == 1 and ref["ok"][0, 1] == 0
 
 
 @pytest.mark.gpu
