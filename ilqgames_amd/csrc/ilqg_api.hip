@@ -114,7 +114,10 @@ __global__ void rollout_kernel(DevProblem p, RolloutBatchArgs<T> g) {
   RolloutArgs<T> a{g.x0 + b * n,          g.xs_ref + b * Tn * n, g.us_ref + b * Tn * m, g.P + b * Tn * m * n,
                    g.alpha + b * Tn * m,  g.alpha_scale ? g.alpha_scale[b] : T(1),
                    g.xs + b * Tn * n,     g.us + b * Tn * m};
-  rollout_instance<T>(p, a, sm, threadIdx.x);
+  if (p.sub_kind[0] == ILQG_DYN_UNICYCLE_4D_DISTURBED)
+    rollout_instance<T, 0, 0, true>(p, a, sm, threadIdx.x);
+  else
+    rollout_instance<T>(p, a, sm, threadIdx.x);
 }
 
 template <typename T>
@@ -621,7 +624,17 @@ ilqg_status ilqg_problem_create(const ilqg_problem_desc* desc, ilqg_problem** ou
   d.uoff[0] = 0;
   for (int i = 0; i < d.N; i++) {
     const ilqg_subsystem& sub = desc->subsystems[i];
-    const int want_x = sub.kind == ILQG_DYN_UNICYCLE_4D ? 4 : sub.kind == ILQG_DYN_CAR_5D ? 5 : sub.kind == ILQG_DYN_CAR_6D ? 6 : -1;
+    const int want_x = (sub.kind == ILQG_DYN_UNICYCLE_4D || sub.kind == ILQG_DYN_UNICYCLE_4D_DISTURBED) ? 4
+                       : sub.kind == ILQG_DYN_CAR_5D ? 5 : sub.kind == ILQG_DYN_CAR_6D ? 6
+                       : sub.kind == ILQG_DYN_PLANAR_DISTURBANCE ? 0 : -1;
+    // TwoPlayerUnicycle4D is exactly the pair (disturbed unicycle, disturbance) and nothing else
+    const bool pair_ok = (sub.kind != ILQG_DYN_UNICYCLE_4D_DISTURBED && sub.kind != ILQG_DYN_PLANAR_DISTURBANCE) ||
+                         (desc->num_players == 2 && desc->subsystems[0].kind == ILQG_DYN_UNICYCLE_4D_DISTURBED &&
+                          desc->subsystems[1].kind == ILQG_DYN_PLANAR_DISTURBANCE);
+    if (!pair_ok) {
+      delete p;
+      return fail(ILQG_ERR_UNSUPPORTED, "the two-player unicycle kinds only occur as the pair (4, 5)");
+    }
     if (want_x < 0 || sub.xdim != want_x || sub.udim != 2) {
       delete p;
       return fail(ILQG_ERR_UNSUPPORTED, "unknown subsystem kind / dimension");

@@ -32,11 +32,17 @@ template <typename T> __device__ __forceinline__ T t_abs(T x) { return x < T(0) 
 // single_player_unicycle_4d.h:90-100, single_player_car_5d.h:100-111,
 // single_player_car_6d.h:102-114.
 // ---------------------------------------------------------------------------
+// TwoPlayerUnicycle4D (two_player_unicycle_4d.h:105-118) is the unicycle with the second player's (d0, d1)
+// added to the position rates; its second row has no state of its own.
+__device__ __forceinline__ bool is_unicycle(int kind) {
+  return kind == ILQG_DYN_UNICYCLE_4D || kind == ILQG_DYN_UNICYCLE_4D_DISTURBED;
+}
+
 template <typename T>
-__device__ __forceinline__ void sub_eval(int kind, T L, const T* x, T u0, T u1, T* xd) {
-  if (kind == ILQG_DYN_UNICYCLE_4D) {
-    xd[0] = x[3] * t_cos(x[2]);
-    xd[1] = x[3] * t_sin(x[2]);
+__device__ __forceinline__ void sub_eval(int kind, T L, const T* x, T u0, T u1, T* xd, T d0 = T(0), T d1 = T(0)) {
+  if (is_unicycle(kind) || kind == ILQG_DYN_PLANAR_DISTURBANCE) {
+    xd[0] = x[3] * t_cos(x[2]) + d0;
+    xd[1] = x[3] * t_sin(x[2]) + d1;
     xd[2] = u0;
     xd[3] = u1;
     xd[4] = T(0);
@@ -60,21 +66,22 @@ __device__ __forceinline__ void sub_eval(int kind, T L, const T* x, T u0, T u1, 
 // RK4, 2 sub-steps of dt/2.  Subsystems of a ConcatenatedDynamicalSystem are
 // decoupled once u is fixed, so one lane integrates one block in registers.
 template <typename T>
-__device__ __forceinline__ void sub_integrate(int kind, T L, double interval, T* x, T u0, T u1) {
+__device__ __forceinline__ void sub_integrate(int kind, T L, double interval, T* x, T u0, T u1, T d0 = T(0),
+                                              T d1 = T(0)) {
   const T h = T(interval / 2.0);
 #pragma unroll 1
   for (int s = 0; s < 2; s++) {
     T k1[6], k2[6], k3[6], k4[6], xt[6];
-    sub_eval(kind, L, x, u0, u1, k1);
+    sub_eval(kind, L, x, u0, u1, k1, d0, d1);
 #pragma unroll
     for (int i = 0; i < 6; i++) { k1[i] = h * k1[i]; xt[i] = x[i] + T(0.5) * k1[i]; }
-    sub_eval(kind, L, xt, u0, u1, k2);
+    sub_eval(kind, L, xt, u0, u1, k2, d0, d1);
 #pragma unroll
     for (int i = 0; i < 6; i++) { k2[i] = h * k2[i]; xt[i] = x[i] + T(0.5) * k2[i]; }
-    sub_eval(kind, L, xt, u0, u1, k3);
+    sub_eval(kind, L, xt, u0, u1, k3, d0, d1);
 #pragma unroll
     for (int i = 0; i < 6; i++) { k3[i] = h * k3[i]; xt[i] = x[i] + k3[i]; }
-    sub_eval(kind, L, xt, u0, u1, k4);
+    sub_eval(kind, L, xt, u0, u1, k4, d0, d1);
 #pragma unroll
     for (int i = 0; i < 6; i++) {
       k4[i] = h * k4[i];
@@ -114,12 +121,14 @@ __device__ __forceinline__ float div_by(float x, float c, float rc) {
   return __builtin_fmaf(r, rc, q);
 }
 
-template <typename T>
+// DIST: the problem may contain the disturbed unicycle; (d0, d1) are then the other player's controls (zero
+// for every other kind) and enter the position rates.  Compiled out otherwise.
+template <typename T, bool DIST = false>
 __device__ __forceinline__ void sub_integrate_lanes(int kind, T L, double interval, T* x, T u0, T u1, int q,
-                                                    int base) {
+                                                    int base, T d0 = T(0), T d1 = T(0)) {
   const T h = T(interval / 2.0);
   const T six = T(6.0), rsix = T(1.0) / T(6.0), rL = T(1.0) / L;
-  const bool car = kind != ILQG_DYN_UNICYCLE_4D;
+  const bool car = DIST ? false : kind != ILQG_DYN_UNICYCLE_4D;  // DIST problems hold unicycle rows only
   const int vi = car ? 4 : 3;
   // ---- 1. upper components, all stages ----
   T up[6];  // working copy; lower components are left untouched here
@@ -201,8 +210,8 @@ __device__ __forceinline__ void sub_integrate_lanes(int kind, T L, double interv
   // ---- 4. one sincos per lane ----
   T sn, cs;
   t_sincos(my_th, &sn, &cs);
-  const T kxq = h * (my_v * cs);
-  const T kyq = h * (my_v * sn);
+  const T kxq = DIST ? h * (my_v * cs + d0) : h * (my_v * cs);
+  const T kyq = DIST ? h * (my_v * sn + d1) : h * (my_v * sn);
   // ---- 5. positions ----
   T px = x[0], py = x[1];
 #pragma unroll
@@ -231,14 +240,21 @@ __device__ __forceinline__ void sub_integrate_lanes(int kind, T L, double interv
 template <typename T>
 __device__ __forceinline__ void sub_linearize_trig(int kind, T L, double dt, const T* x, T sth, T cth, T sphi, T cphi,
                                                    T* A, T* B, int ld) {
-  const int v = (kind == ILQG_DYN_UNICYCLE_4D) ? 3 : 4;
+  if (kind == ILQG_DYN_PLANAR_DISTURBANCE) {
+    // Bs[1](px, dx) = Bs[1](py, dy) = dt (two_player_unicycle_4d.h:135-136): rows of the 4-state block that
+    // ends where this (empty) block begins
+    B[-4 + ld * 0] = T(dt);
+    B[-3 + ld * 1] = T(dt);
+    return;
+  }
+  const int v = is_unicycle(kind) ? 3 : 4;
   const T ct = T(double(cth) * dt);
   const T st = T(double(sth) * dt);
   A[0 + ld * 2] += -x[v] * st;
   A[0 + ld * v] += ct;
   A[1 + ld * 2] += x[v] * ct;
   A[1 + ld * v] += st;
-  if (kind == ILQG_DYN_UNICYCLE_4D) {
+  if (is_unicycle(kind)) {
     B[2 + ld * 0] = T(dt);
     B[3 + ld * 1] = T(dt);
   } else {
@@ -260,7 +276,7 @@ template <typename T>
 __device__ __forceinline__ void sub_linearize(int kind, T L, double dt, const T* x, T* A, T* B, int ld) {
   T sth, cth, sphi = T(0), cphi = T(1);
   t_sincos(x[2], &sth, &cth);
-  if (kind != ILQG_DYN_UNICYCLE_4D) t_sincos(x[3], &sphi, &cphi);
+  if (!is_unicycle(kind) && kind != ILQG_DYN_PLANAR_DISTURBANCE) t_sincos(x[3], &sphi, &cphi);
   sub_linearize_trig<T>(kind, L, dt, x, sth, cth, sphi, cphi, A, B, ld);
 }
 

@@ -57,7 +57,9 @@ struct PlanStepper {
       const int xo = p.xoff[t], uo = p.uoff[t], xd = p.xoff[t + 1] - xo;
       T xj[6];
       for (int e = 0; e < 6; e++) xj[e] = e < xd ? sx[xo + e] : T(0);
-      sub_integrate<T>(p.sub_kind[t], T(p.sub_param[t]), interval, xj, su[uo], su[uo + 1]);
+      const bool dist = p.sub_kind[t] == ILQG_DYN_UNICYCLE_4D_DISTURBED;  // the next player's (dx, dy)
+      sub_integrate<T>(p.sub_kind[t], T(p.sub_param[t]), interval, xj, su[uo], su[uo + 1], dist ? su[uo + 2] : T(0),
+                       dist ? su[uo + 3] : T(0));
       for (int e = 0; e < xd; e++) sx[xo + e] = xj[e];
     }
     __syncthreads();

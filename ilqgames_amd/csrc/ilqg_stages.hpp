@@ -48,7 +48,8 @@ __device__ __forceinline__ int progress_observe(int* flag) {
 // Executed by ONE wavefront (lane t of 64).  `ready` (LDS, may be null) is set to k+1 once row k of
 // xs / us is in memory, so other waves of the workgroup can consume the trajectory while it is
 // still being integrated.
-template <typename T, int CN = 0, int CM = 0>
+// DIST: the dynamics may be TwoPlayerUnicycle4D (a disturbed unicycle row + a state-less disturbance row).
+template <typename T, int CN = 0, int CM = 0, bool DIST = false>
 __device__ __forceinline__ void rollout_instance(const DevProblem& p, const RolloutArgs<T>& a, T* sm, int t,
                                                  int* ready = nullptr, long long* phacc = nullptr) {
   const int n = CN > 0 ? CN : p.n, m = CM > 0 ? CM : p.m, N = p.N, Tn = p.T;
@@ -140,7 +141,13 @@ __device__ __forceinline__ void rollout_instance(const DevProblem& p, const Roll
     ILQG_RPH(1);
     if (t < 64 && k + 1 < Tn) {  // whole first wave: the shuffles inside need every group lane live
       const T u0 = integ ? su[uo] : T(0), u1 = integ ? su[uo + 1] : T(0);
-      sub_integrate_lanes<T>(kind, Lp, p.dt, xj, u0, u1, q, t & ~7);
+      if constexpr (DIST) {
+        const bool dist = integ && kind == ILQG_DYN_UNICYCLE_4D_DISTURBED;  // the next player's (dx, dy)
+        const T d0 = dist ? su[uo + 2] : T(0), d1 = dist ? su[uo + 3] : T(0);
+        sub_integrate_lanes<T, true>(kind, Lp, p.dt, xj, u0, u1, q, t & ~7, d0, d1);
+      } else {
+        sub_integrate_lanes<T>(kind, Lp, p.dt, xj, u0, u1, q, t & ~7);
+      }
     }
     ILQG_RPH(2);
     dma_wait();  // next block landed (this step's row stores are long retired by now)

@@ -10,7 +10,8 @@ import math
 import numpy as np
 
 from . import abi
-from .abi import DYN_CAR_5D, DYN_CAR_6D, DYN_UNICYCLE_4D, ProblemSpec, SolverParams
+from .abi import (DYN_CAR_5D, DYN_CAR_6D, DYN_PLANAR_DISTURBANCE, DYN_UNICYCLE_4D, DYN_UNICYCLE_4D_DISTURBED,
+                  ProblemSpec, SolverParams)
 
 
 def _lane_costs(spec, player, lane, xy, lane_w, boundary_w, half_width):
@@ -244,6 +245,37 @@ def three_player_collision_avoidance_reachability(T=100, dt=0.1, d0=5.0, v0=5.0,
     return s
 
 
+def two_player_unicycle_4d_scene(T=100, dt=0.1):
+    """A test scene on TwoPlayerUnicycle4D (include/ilqgames/dynamics/two_player_unicycle_4d.h:57-139): player 1
+    steers the unicycle (omega, a) towards the origin at a nominal speed, player 2 pushes it with a bounded planar
+    disturbance (dx, dy) towards a point of its own.  Initial state and control weight are those of
+    src/two_player_reachability_example.cpp:62-66,74-75; that example's target cost (Polyline2SignedDistanceCost)
+    is outside the built cost kinds, so quadratic / semiquadratic costs stand in — this is NOT a reference
+    example, it exists to exercise the shared-state dynamics through the whole solve."""
+    prm = SolverParams.default()
+    prm.max_backtracking_steps = 100
+    prm.initial_alpha_scaling = 0.5
+    prm.convergence_tolerance = 0.01
+    prm.expected_decrease_fraction = 0.001
+    s = ProblemSpec(T, dt, prm)
+    s.add_player(DYN_UNICYCLE_4D_DISTURBED, 0.0, state_reg=1.0, control_reg=1.0)
+    s.add_player(DYN_PLANAR_DISTURBANCE, 0.0, state_reg=1.0, control_reg=1.0)
+    PX, PY, TH, V = 0, 1, 2, 3
+    s.quadratic(0, 1.0, PX, 0.0)
+    s.quadratic(0, 1.0, PY, 0.0)
+    s.quadratic(0, 2.0, V, 3.0)
+    s.semiquadratic(0, 50.0, V, 8.0, True)
+    s.quadratic(1, 0.5, PX, 6.0)
+    s.quadratic(1, 0.5, PY, -4.0)
+    s.quadratic(0, 0.1, -1, 0.0, control_of=0)
+    s.quadratic(1, 0.1, -1, 0.0, control_of=1)
+    s.quadratic(1, 5.0, -1, 0.0, control_of=1)  # keeps the disturbance small (kDMax = 0.5 m/s in the reference)
+    s.quadratic(0, 0.05, -1, 0.0, control_of=1)
+    s.x0 = [0.0, -10.0, float(np.float32(np.pi / 4.0)), 5.0]
+    s.position_dims, s.heading_dims, s.speed_dims = [(PX, PY)], [TH], [V]
+    return s
+
+
 def jittered_x0(spec, batch, seed=0):
     """Per-instance initial states of SURVEY.md §8(d): U(-1,1) m on px,py, U(-0.1,0.1) rad
     heading, U(-0.5,0.5) m/s speed; instance b uses numpy default_rng(seed + b)."""
@@ -264,4 +296,5 @@ CONFIGS = {
     "roundabout_merging": roundabout_merging,
     "roundabout_merging_T150": lambda: roundabout_merging(T=150),  # BASELINE.json config 4 (n=24, T=150, open loop)
     "three_player_collision_avoidance_reachability": three_player_collision_avoidance_reachability,
+    "two_player_unicycle_4d_scene": two_player_unicycle_4d_scene,
 }

@@ -19,6 +19,18 @@ namespace ilqgames {
 // ------------------------------------------------------------------------------------------
 // Model index constants (src/single_player_{unicycle_4d,car_5d,car_6d}.cpp)
 // ------------------------------------------------------------------------------------------
+const Dimension TwoPlayerUnicycle4D::kNumXDims = 4;
+const Dimension TwoPlayerUnicycle4D::kPxIdx = 0;
+const Dimension TwoPlayerUnicycle4D::kPyIdx = 1;
+const Dimension TwoPlayerUnicycle4D::kThetaIdx = 2;
+const Dimension TwoPlayerUnicycle4D::kVIdx = 3;
+const PlayerIndex TwoPlayerUnicycle4D::kNumPlayers = 2;
+const Dimension TwoPlayerUnicycle4D::kNumU1Dims = 2;
+const Dimension TwoPlayerUnicycle4D::kOmegaIdx = 0;
+const Dimension TwoPlayerUnicycle4D::kAIdx = 1;
+const Dimension TwoPlayerUnicycle4D::kNumU2Dims = 2;
+const Dimension TwoPlayerUnicycle4D::kDxIdx = 0;
+const Dimension TwoPlayerUnicycle4D::kDyIdx = 1;
 const Dimension SinglePlayerUnicycle4D::kNumXDims = 4;
 const Dimension SinglePlayerUnicycle4D::kPxIdx = 0;
 const Dimension SinglePlayerUnicycle4D::kPyIdx = 1;
@@ -274,29 +286,49 @@ class Packer {
 
 }  // namespace
 
+bool DescribeDynamics(const MultiPlayerIntegrableSystem& dynamics, ilqg_problem_desc* d, std::string* why) {
+  std::string scratch;
+  if (why == nullptr) why = &scratch;
+  if (dynamic_cast<const TwoPlayerUnicycle4D*>(&dynamics) != nullptr) {
+    d->num_players = 2;
+    d->subsystems[0] = ilqg_subsystem{ILQG_DYN_UNICYCLE_4D_DISTURBED, 4, 2, 0.0f};
+    d->subsystems[1] = ilqg_subsystem{ILQG_DYN_PLANAR_DISTURBANCE, 0, 2, 0.0f};
+    return true;
+  }
+  const auto* dyn = dynamic_cast<const ConcatenatedDynamicalSystem*>(&dynamics);
+  if (dyn == nullptr) {
+    *why = "dynamics are neither a ConcatenatedDynamicalSystem nor TwoPlayerUnicycle4D";
+    return false;
+  }
+  const int N = dyn->NumPlayers();
+  if (N > ILQG_MAX_PLAYERS) {
+    *why = "too many players";
+    return false;
+  }
+  d->num_players = N;
+  for (int i = 0; i < N; i++) {
+    d->subsystems[i] = dyn->Subsystems()[i]->Describe();
+    if (d->subsystems[i].kind == 0) {
+      *why = "subsystem " + std::to_string(i) + " has no device model";
+      return false;
+    }
+  }
+  return true;
+}
+
 bool DescribeProblem(const Problem& problem, const SolverParams& params, ilqg_dtype dtype,
                      ProblemDescription* out, std::string* why) {
   std::string scratch;
   if (why == nullptr) why = &scratch;
   *out = ProblemDescription();
-  const auto* dyn = dynamic_cast<const ConcatenatedDynamicalSystem*>(problem.Dynamics().get());
-  if (dyn == nullptr) {
-    *why = "dynamics are not a ConcatenatedDynamicalSystem";
-    return false;
-  }
-  const int N = dyn->NumPlayers();
-  if (N > ILQG_MAX_PLAYERS || static_cast<size_t>(N) != problem.PlayerCosts().size()) {
+  ilqg_problem_desc& d = out->desc;
+  if (!DescribeDynamics(*problem.Dynamics(), &d, why)) return false;
+  const int N = d.num_players;
+  if (static_cast<size_t>(N) != problem.PlayerCosts().size()) {
     *why = "player count mismatch between dynamics and player costs";
     return false;
   }
-  ilqg_problem_desc& d = out->desc;
-  d.num_players = N;
   for (int i = 0; i < N; i++) {
-    d.subsystems[i] = dyn->Subsystems()[i]->Describe();
-    if (d.subsystems[i].kind == 0) {
-      *why = "subsystem " + std::to_string(i) + " has no device model";
-      return false;
-    }
     const PlayerCost& pc = problem.PlayerCosts()[i];
     d.player_costs[i].state_regularization = pc.StateRegularization();
     d.player_costs[i].control_regularization = pc.ControlRegularization();
@@ -719,14 +751,9 @@ struct DevicePlan {
 struct DynamicsHandle {
   ilqg_problem* handle = nullptr;
   explicit DynamicsHandle(const MultiPlayerIntegrableSystem& dynamics) {
-    const auto* dyn = dynamic_cast<const ConcatenatedDynamicalSystem*>(&dynamics);
-    CHECK(dyn != nullptr) << "dynamics are not a ConcatenatedDynamicalSystem";
     ilqg_problem_desc d{};
-    d.num_players = dyn->NumPlayers();
-    for (int i = 0; i < d.num_players; i++) {
-      d.subsystems[i] = dyn->Subsystems()[i]->Describe();
-      CHECK_NE(d.subsystems[i].kind, 0) << "subsystem " << i << " has no device model";
-    }
+    std::string why;
+    CHECK(DescribeDynamics(dynamics, &d, &why)) << why;
     // the handle's tables want every player to own a control Hessian; the plan kernels never evaluate it
     ilqg_cost_term own_control[ILQG_MAX_PLAYERS] = {};
     for (int i = 0; i < d.num_players; i++) {

@@ -113,11 +113,18 @@ ilqg_status ilqg_lq_openloop_batch(const ilqg_dims* d, const void* A,
 typedef enum {
   ILQG_DYN_UNICYCLE_4D = 1, /* include/ilqgames/dynamics/single_player_unicycle_4d.h:90-116 */
   ILQG_DYN_CAR_5D = 2,      /* include/ilqgames/dynamics/single_player_car_5d.h:100-133     */
-  ILQG_DYN_CAR_6D = 3       /* include/ilqgames/dynamics/single_player_car_6d.h:102-138     */
+  ILQG_DYN_CAR_6D = 3,      /* include/ilqgames/dynamics/single_player_car_6d.h:102-138     */
+  /* TwoPlayerUnicycle4D (include/ilqgames/dynamics/two_player_unicycle_4d.h:57-139): ONE 4-state
+   * unicycle driven by two players.  Player 0's row is the unicycle with u = (omega, a)
+   * (xdim 4, udim 2); player 1's row is a planar disturbance u = (dx, dy) added to the position
+   * rates of the row before it (xdim 0, udim 2).  The two kinds only occur as this pair. */
+  ILQG_DYN_UNICYCLE_4D_DISTURBED = 4,
+  ILQG_DYN_PLANAR_DISTURBANCE = 5
 } ilqg_dyn_kind;
 
 /* One block of a ConcatenatedDynamicalSystem
- * (src/concatenated_dynamical_system.cpp:52-107); player i owns subsystem i. */
+ * (src/concatenated_dynamical_system.cpp:52-107); player i owns subsystem i.
+ * (TwoPlayerUnicycle4D is written as two rows, see ilqg_dyn_kind.) */
 typedef struct {
   int32_t kind; /* ilqg_dyn_kind */
   int32_t xdim;

@@ -453,6 +453,14 @@ void EvaluateSubsystem(const ilqg_subsystem& s, const S* x, const S* u, S* xdot)
       xdot[2] = u[0];
       xdot[3] = u[1];
       break;
+    case ILQG_DYN_UNICYCLE_4D_DISTURBED:  // two_player_unicycle_4d.h:105-118; u[2..3] = the other player's (dx, dy)
+      xdot[0] = x[3] * std::cos(x[2]) + u[2];
+      xdot[1] = x[3] * std::sin(x[2]) + u[3];
+      xdot[2] = u[0];
+      xdot[3] = u[1];
+      break;
+    case ILQG_DYN_PLANAR_DISTURBANCE:  // no state of its own
+      break;
     case ILQG_DYN_CAR_5D:
       xdot[0] = x[4] * std::cos(x[2]);
       xdot[1] = x[4] * std::sin(x[2]);
@@ -476,7 +484,7 @@ template <class S>
 Vec<S> Evaluate(const Problem<S>& p, const Vec<S>& x, const Vec<S>& u) {
   Vec<S> xdot(p.n);
   for (int i = 0; i < p.N; i++)
-    EvaluateSubsystem(p.subs[i], &x[p.xoff[i]], &u[p.uoff[i]], &xdot[p.xoff[i]]);
+    EvaluateSubsystem(p.subs[i], x.data() + p.xoff[i], u.data() + p.uoff[i], xdot.data() + p.xoff[i]);
   return xdot;
 }
 
@@ -527,14 +535,21 @@ void Linearize(const Problem<S>& p, const Vec<S>& x, const Vec<S>& u, Mat<S>* A,
     const int o = p.xoff[i], uo = p.uoff[i];
     const S* xs = &x[o];
     const ilqg_subsystem& s = p.subs[i];
-    const int vidx = (s.kind == ILQG_DYN_UNICYCLE_4D) ? 3 : 4;
+    if (s.kind == ILQG_DYN_PLANAR_DISTURBANCE) {  // two_player_unicycle_4d.h:135-136: Bs[1](px, dx) = Bs[1](py, dy) = dt
+      const int po = p.xoff[i - 1];
+      (*B)(po + 0, uo + 0) = S(dt);
+      (*B)(po + 1, uo + 1) = S(dt);
+      continue;
+    }
+    const bool unicycle = s.kind == ILQG_DYN_UNICYCLE_4D || s.kind == ILQG_DYN_UNICYCLE_4D_DISTURBED;
+    const int vidx = unicycle ? 3 : 4;
     const S ctheta = S(double(std::cos(xs[2])) * dt);
     const S stheta = S(double(std::sin(xs[2])) * dt);
     (*A)(o + 0, o + 2) += -xs[vidx] * stheta;
     (*A)(o + 0, o + vidx) += ctheta;
     (*A)(o + 1, o + 2) += xs[vidx] * ctheta;
     (*A)(o + 1, o + vidx) += stheta;
-    if (s.kind == ILQG_DYN_UNICYCLE_4D) {
+    if (unicycle) {
       (*B)(o + 2, uo + 0) = S(dt);
       (*B)(o + 3, uo + 1) = S(dt);
     } else {

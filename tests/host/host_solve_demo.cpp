@@ -13,6 +13,7 @@
 #include <ilqgames/dynamics/concatenated_dynamical_system.h>
 #include <ilqgames/dynamics/single_player_car_5d.h>
 #include <ilqgames/dynamics/single_player_unicycle_4d.h>
+#include <ilqgames/dynamics/two_player_unicycle_4d.h>
 #include <ilqgames/solver/augmented_lagrangian_solver.h>
 #include <ilqgames/solver/ilq_solver.h>
 #include <ilqgames/solver/lq_feedback_solver.h>
@@ -106,6 +107,39 @@ class MergeScene : public TopDownRenderableProblem {
 
  private:
   const bool constrained_;
+};
+
+// One unicycle, two players (TwoPlayerUnicycle4D): the scene of ilqgames_amd/examples.py two_player_unicycle_4d_scene.
+class PushedUnicycle : public TopDownRenderableProblem {
+ public:
+  void ConstructDynamics() override { dynamics_.reset(new TwoPlayerUnicycle4D()); }
+  void ConstructInitialState() override {
+    using Dyn = TwoPlayerUnicycle4D;
+    x0_ = VectorXf::Zero(dynamics_->XDim());
+    x0_(Dyn::kPyIdx) = -10.0f;
+    x0_(Dyn::kThetaIdx) = static_cast<float>(M_PI / 4.0);
+    x0_(Dyn::kVIdx) = 5.0f;
+  }
+  void ConstructPlayerCosts() override {
+    using Dyn = TwoPlayerUnicycle4D;
+    player_costs_.emplace_back("driver", 1.0f, 1.0f);
+    player_costs_.emplace_back("pusher", 1.0f, 1.0f);
+    auto& p1 = player_costs_[0];
+    auto& p2 = player_costs_[1];
+    p1.AddStateCost(std::make_shared<QuadraticCost>(1.0f, Dyn::kPxIdx, 0.0f, "px"));
+    p1.AddStateCost(std::make_shared<QuadraticCost>(1.0f, Dyn::kPyIdx, 0.0f, "py"));
+    p1.AddStateCost(std::make_shared<QuadraticCost>(2.0f, Dyn::kVIdx, 3.0f, "v"));
+    p1.AddStateCost(std::make_shared<SemiquadraticCost>(50.0f, Dyn::kVIdx, 8.0f, true, "vmax"));
+    p2.AddStateCost(std::make_shared<QuadraticCost>(0.5f, Dyn::kPxIdx, 6.0f, "px"));
+    p2.AddStateCost(std::make_shared<QuadraticCost>(0.5f, Dyn::kPyIdx, -4.0f, "py"));
+    p1.AddControlCost(0, std::make_shared<QuadraticCost>(0.1f, -1, 0.0f, "u1"));
+    p2.AddControlCost(1, std::make_shared<QuadraticCost>(0.1f, -1, 0.0f, "u2"));
+    p2.AddControlCost(1, std::make_shared<QuadraticCost>(5.0f, -1, 0.0f, "u2 bound"));
+    p1.AddControlCost(1, std::make_shared<QuadraticCost>(0.05f, -1, 0.0f, "u2 seen by p1"));
+  }
+  std::vector<float> Xs(const VectorXf& x) const override { return {x(TwoPlayerUnicycle4D::kPxIdx)}; }
+  std::vector<float> Ys(const VectorXf& x) const override { return {x(TwoPlayerUnicycle4D::kPyIdx)}; }
+  std::vector<float> Thetas(const VectorXf& x) const override { return {x(TwoPlayerUnicycle4D::kThetaIdx)}; }
 };
 
 void WriteLog(std::ostream& os, const SolverLog& log, bool success) {
@@ -336,7 +370,29 @@ int main(int argc, char** argv) {
     }
   }
 
-  // 4. the LQ seam on its own
+  // 4. shared-state dynamics: TwoPlayerUnicycle4D
+  {
+    SolverParams up(params);
+    up.max_solver_iters = 5;
+    up.max_backtracking_steps = 100;
+    up.initial_alpha_scaling = 0.5f;
+    up.expected_decrease_fraction = 0.001f;
+    up.convergence_tolerance = 0.01f;
+    auto problem = std::make_shared<PushedUnicycle>();
+    problem->Initialize();
+    host::ProblemDescription description;
+    std::string why;
+    CHECK(host::DescribeProblem(*problem, up, ILQG_F64, &description, &why)) << why;
+    std::ofstream(outdir + "/scene_unicycle.txt") << host::DumpDescription(description);
+    ILQSolver solver(problem, up);
+    bool success = false;
+    const std::shared_ptr<SolverLog> log = solver.Solve(&success);
+    std::ofstream os(outdir + "/unicycle_single.txt");
+    os << std::setprecision(9) << "x0 " << problem->InitialState() << "\n";
+    WriteLog(os, *log, success);
+  }
+
+  // 5. the LQ seam on its own
   RunLqGame(outdir, false);
   RunLqGame(outdir, true);
   std::cout << "host_solve_demo: done\n";

@@ -259,6 +259,20 @@ def test_cpp_receding_horizon_simulator_matches_oracle(demo_out, oracle):
 
 
 @pytest.mark.gpu
+def test_cpp_two_player_unicycle_solve_matches_oracle(demo_out, oracle):
+    """TwoPlayerUnicycle4D through the C++ mirror: its descriptor equals the python builder's, and five iLQ
+    iterations on the device match the oracle."""
+    got = _parse_log(os.path.join(demo_out, "unicycle_single.txt"))
+    spec, ref = _oracle_solve(oracle, os.path.join(demo_out, "scene_unicycle.txt"), got["x0"])
+    want = examples.two_player_unicycle_4d_scene()
+    a, b = spec.canonical(), want.canonical()
+    assert a["subsystems"] == b["subsystems"] and a["groups"] == b["groups"] and a["pairs"] == b["pairs"]
+    assert [s[0] for s in spec.subsystems] == [abi.DYN_UNICYCLE_4D_DISTURBED, abi.DYN_PLANAR_DISTURBANCE]
+    assert got["iters"] == 5
+    _check_against_oracle(got, ref)
+
+
+@pytest.mark.gpu
 def test_cpp_solve_batch_matches_oracle_per_instance(demo_out, oracle):
     for b in range(6):
         got = _parse_log(os.path.join(demo_out, "ilq_batch_%d.txt" % b))
