@@ -13,6 +13,7 @@
 #include "ilqg_lq.hpp"
 #include "ilqg_lq_openloop.hpp"
 #include "ilqg_models.hpp"
+#include "ilqg_nash.hpp"
 #include "ilqg_receding.hpp"
 #include "ilqg_solve.hpp"
 #include "ilqg_stages.hpp"
@@ -1060,6 +1061,57 @@ ilqg_status ilqg_receding_horizon_shift_batch(const ilqg_problem* p, int32_t bat
     g.first_step = first_step;                                                                                     \
     hipLaunchKernelGGL(receding_sync_kernel<TY_>, dim3(batch), dim3(64), (d.n + d.m) * sizeof(TY_),                \
                        (hipStream_t)stream, d, g);                                                                 \
+    HIP_TRY(hipGetLastError());                                                                                  \
+    return ILQG_OK;                                                                                              \
+  }()
+  return DT_DISPATCH(p, CALL);
+#undef CALL
+}
+
+static ilqg_status launch_strategy_costs(const ilqg_problem* p, int32_t batch, const void* x0, const void* xs,
+                                         const void* us, const void* P, const void* alpha, double eps, int open_loop,
+                                         int euler, int moves, void* costs, void* stream) {
+  const DevProblem& d = p->dev;
+#define CALL(TY_)                                                                                                  \
+  [&]() -> ilqg_status {                                                                                         \
+    StrategyCostArgs<TY_> g{(const TY_*)x0, (const TY_*)xs, (const TY_*)us, (const TY_*)P, (const TY_*)alpha,      \
+                            (TY_*)costs, TY_(eps), open_loop, euler, batch};                                       \
+    const size_t lds = quad_tables_bytes(d, sizeof(TY_)) + strategy_cost_lds_elems(d.n, d.m, d.num_terms) * sizeof(TY_); \
+    hipLaunchKernelGGL(strategy_costs_kernel<TY_>, dim3(batch, moves), dim3(64), lds, (hipStream_t)stream, d, g);  \
+    HIP_TRY(hipGetLastError());                                                                                  \
+    return ILQG_OK;                                                                                              \
+  }()
+  return DT_DISPATCH(p, CALL);
+#undef CALL
+}
+
+ilqg_status ilqg_strategy_costs_batch(const ilqg_problem* p, int32_t batch, const void* x0, const void* xs,
+                                      const void* us, const void* P, const void* alpha, int32_t open_loop,
+                                      int32_t euler, void* costs, void* stream) {
+  if (!p || !x0 || !xs || !us || !P || !alpha || !costs) return fail(ILQG_ERR_INVALID, "null argument");
+  if (batch <= 0) return ILQG_OK;
+  return launch_strategy_costs(p, batch, x0, xs, us, P, alpha, 0.0, open_loop ? 1 : 0, euler ? 1 : 0, 1, costs, stream);
+}
+
+ilqg_status ilqg_check_local_nash_batch(const ilqg_problem* p, int32_t batch, const void* x0, const void* xs,
+                                        const void* us, const void* P, const void* alpha, double max_perturbation,
+                                        int32_t open_loop, int32_t* is_nash, void* margin, void* stream) {
+  if (!p || !x0 || !xs || !us || !P || !alpha || !is_nash) return fail(ILQG_ERR_INVALID, "null argument");
+  if (batch <= 0) return ILQG_OK;
+  const DevProblem& d = p->dev;
+  const int moves = 1 + 2 * d.m * (d.T - 1);
+  if (moves > 65535) return fail(ILQG_ERR_UNSUPPORTED, "too many perturbations for one launch");
+  const size_t esz = p->desc.dtype == ILQG_F32 ? 4 : 8;
+  ilqg_status s = g_scratch.reserve(size_t(moves) * batch * d.N * esz);
+  if (s != ILQG_OK) return s;
+  // the reference switches the integrator to one-step Euler for this check (check_local_nash_equilibrium.cpp:75-79)
+  s = launch_strategy_costs(p, batch, x0, xs, us, P, alpha, max_perturbation, open_loop ? 1 : 0, 1, moves, g_scratch.ptr,
+                            stream);
+  if (s != ILQG_OK) return s;
+#define CALL(TY_)                                                                                                  \
+  [&]() -> ilqg_status {                                                                                         \
+    hipLaunchKernelGGL(nash_verdict_kernel<TY_>, dim3(batch), dim3(64), 0, (hipStream_t)stream, d,                 \
+                       (const TY_*)g_scratch.ptr, moves, batch, is_nash, (TY_*)margin);                            \
     HIP_TRY(hipGetLastError());                                                                                  \
     return ILQG_OK;                                                                                              \
   }()

@@ -19,7 +19,8 @@ EXPORTS = [
     "ilqg_problem_destroy", "ilqg_workspace_bytes", "ilqg_rollout_batch", "ilqg_linearize_batch",
     "ilqg_quadraticize_batch", "ilqg_problem_pairs", "ilqg_total_costs_batch", "ilqg_ilq_solve_batch",
     "ilqg_last_error", "ilqg_abi_version", "ilqg_device_info", "ilqg_selftest_mfma", "ilqg_al_solve_batch", "ilqg_plan_integrate_batch", "ilqg_receding_horizon_sync_batch",
-    "ilqg_solution_splice_batch", "ilqg_solve_again_batch",
+    "ilqg_solution_splice_batch", "ilqg_solve_again_batch", "ilqg_strategy_costs_batch",
+    "ilqg_check_local_nash_batch",
     "ilqg_receding_horizon_shift_batch",
 ]
 
@@ -320,3 +321,23 @@ class Problem:
             self.plan_integrate(plan, t - solve_time, t, t, x, active)
             self.solution_splice(plan, bufs, solve_t0, converged=bufs["converged"], active=active)
         return dict(x=x, plan=plan, active=active, num_records=num_records, calls=calls)
+
+    # ---- equilibrium checks ----
+    def strategy_costs(self, x0, xs, us, P, alpha, open_loop=False, euler=True):
+        """ilqg_strategy_costs_batch -> [B][N] device tensor."""
+        a = [_dev(v, self.dtype) for v in (x0, xs, us, P, alpha)]
+        costs = self._empty(a[0].shape[0], self.N)
+        _check(lib().ilqg_strategy_costs_batch(self.h, a[0].shape[0], *[_ptr(v) for v in a], int(open_loop), int(euler),
+                                               _ptr(costs), _stream()))
+        return costs
+
+    def check_local_nash(self, x0, xs, us, P, alpha, max_perturbation, open_loop=False):
+        """ilqg_check_local_nash_batch -> (is_nash [B] int32, margin [B]) device tensors."""
+        import torch
+        a = [_dev(v, self.dtype) for v in (x0, xs, us, P, alpha)]
+        B = a[0].shape[0]
+        ok = torch.zeros(B, dtype=torch.int32, device="cuda")
+        margin = self._empty(B)
+        _check(lib().ilqg_check_local_nash_batch(self.h, B, *[_ptr(v) for v in a], C.c_double(max_perturbation),
+                                                 int(open_loop), _ptr(ok), _ptr(margin), _stream()))
+        return ok, margin

@@ -877,6 +877,62 @@ void Problem::SetUpNextRecedingHorizon(const VectorXf& x0, Time t0, Time planner
 }
 
 // ------------------------------------------------------------------------------------------
+// Equilibrium checks (src/compute_strategy_costs.cpp:108-114, src/check_local_nash_equilibrium.cpp:135-142)
+// ------------------------------------------------------------------------------------------
+namespace {
+
+// Runs one of the two device checks on the problem's stored solution.
+void RunEquilibriumCheck(const Problem& problem, bool open_loop, const float* max_perturbation,
+                         std::vector<float>* costs, bool* is_nash) {
+  using namespace host;
+  const ilqg_dtype dtype = Options().dtype;
+  ProblemDescription description;
+  std::string why;
+  CHECK(DescribeProblem(problem, SolverParams(), dtype, &description, &why)) << why;
+  ilqg_problem* handle = nullptr;
+  CHECK_EQ(ilqg_problem_create(&description.desc, &handle), ILQG_OK) << ilqg_last_error();
+  const MultiPlayerIntegrableSystem& dyn = *problem.Dynamics();
+  const int n = dyn.XDim(), N = dyn.NumPlayers(), T = description.desc.T;
+  CHECK_EQ(static_cast<int>(problem.CurrentOperatingPoint().xs.size()), T);
+  DevicePlan plan;
+  plan.Upload(FlattenPlan(dyn, problem.CurrentOperatingPoint(), problem.CurrentStrategies(), T), T,
+              problem.CurrentOperatingPoint().t0, dtype);
+  DeviceBuffer dx0, dout, dflag;
+  const VectorXf& x0 = problem.InitialState();
+  Upload(&dx0, std::vector<float>(x0.data(), x0.data() + n), dtype);
+  ilqg_status s;
+  if (costs != nullptr) {
+    dout.Reserve(N * ElemBytes(dtype));
+    s = ilqg_strategy_costs_batch(handle, 1, dx0.get(), plan.xs.get(), plan.us.get(), plan.P.get(), plan.alpha.get(),
+                                  open_loop ? 1 : 0, /*euler=*/0, dout.get(), nullptr);
+  } else {
+    dflag.Reserve(sizeof(int32_t));
+    s = ilqg_check_local_nash_batch(handle, 1, dx0.get(), plan.xs.get(), plan.us.get(), plan.P.get(),
+                                    plan.alpha.get(), *max_perturbation, open_loop ? 1 : 0,
+                                    static_cast<int32_t*>(dflag.get()), nullptr, nullptr);
+  }
+  CHECK_EQ(s, ILQG_OK) << ilqg_last_error();
+  HipCheck(hipDeviceSynchronize(), "equilibrium check");
+  if (costs != nullptr) *costs = Download(dout, N, dtype);
+  if (is_nash != nullptr) *is_nash = DownloadInts(dflag, 1)[0] != 0;
+  ilqg_problem_destroy(handle);
+}
+
+}  // namespace
+
+std::vector<float> ComputeStrategyCosts(const Problem& problem, bool open_loop) {
+  std::vector<float> costs;
+  RunEquilibriumCheck(problem, open_loop, nullptr, &costs, nullptr);
+  return costs;
+}
+
+bool NumericalCheckLocalNashEquilibrium(const Problem& problem, float max_perturbation, bool open_loop) {
+  bool is_nash = false;
+  RunEquilibriumCheck(problem, open_loop, &max_perturbation, nullptr, &is_nash);
+  return is_nash;
+}
+
+// ------------------------------------------------------------------------------------------
 // SolutionSplicer (src/solution_splicer.cpp:56-129) — bookkeeping on the host-side containers; the batched
 // form that keeps plans on the device is ilqg_solution_splice_batch.
 // ------------------------------------------------------------------------------------------

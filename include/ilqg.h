@@ -398,6 +398,28 @@ ilqg_status ilqg_solve_again_batch(ilqg_problem* p, int32_t batch, const void* x
                                    int32_t* converged, void* workspace, int32_t augmented_lagrangian,
                                    const int32_t* active, void* stream);
 
+/* ------------------------------------------------------------------------ *
+ *  Equilibrium checks                                                       *
+ * ------------------------------------------------------------------------ */
+
+/* Replaces ComputeStrategyCosts (src/compute_strategy_costs.cpp:61-106): the cost every player accumulates when
+ * the strategies (P, alpha) are played from x0 against the operating point (xs, us) — closed loop, or with
+ * open_loop != 0 as u = u_ref - alpha with state costs taken at the next state (PlayerCost::EvaluateOffset,
+ * src/player_cost.cpp:175-190).  euler != 0: one-step Euler integration
+ * (MultiPlayerIntegrableSystem::IntegrateUsingEuler), else the default RK4.  costs [B][N]. */
+ilqg_status ilqg_strategy_costs_batch(const ilqg_problem* p, int32_t batch, const void* x0, const void* xs,
+                                      const void* us, const void* P, const void* alpha, int32_t open_loop,
+                                      int32_t euler, void* costs, void* stream);
+
+/* Replaces NumericalCheckLocalNashEquilibrium (src/check_local_nash_equilibrium.cpp:60-133): every entry of every
+ * alpha_i[k], k < T-1, is moved by -/+ max_perturbation in turn (Euler integration, as there) and the mover's cost
+ * compared with the nominal one — 2 m (T-1) rollouts per instance, all in one launch.
+ *  is_nash [B] int32   1 = no unilateral move lowered its mover's cost
+ *  margin  [B]         out (nullable): min over moves of (moved cost - nominal cost) of the mover */
+ilqg_status ilqg_check_local_nash_batch(const ilqg_problem* p, int32_t batch, const void* x0, const void* xs,
+                                        const void* us, const void* P, const void* alpha, double max_perturbation,
+                                        int32_t open_loop, int32_t* is_nash, void* margin, void* stream);
+
 /* Diagnostics: out = X^T Y + C for 16x16 column-major device matrices, computed through the
  * MFMA accumulator-layout path the LQ sweep is built on (pins the gfx950 register layouts). */
 ilqg_status ilqg_selftest_mfma(int32_t dtype, const void* X, const void* Y, const void* C, void* out, void* stream);

@@ -882,6 +882,13 @@ class SolutionSplicer {
 std::vector<std::shared_ptr<const SolverLog>> RecedingHorizonSimulator(Time final_time, Time planner_runtime,
                                                                        GameSolver* solver);
 
+// include/ilqgames/utils/compute_strategy_costs.h:58-60, include/ilqgames/utils/check_local_nash_equilibrium.h:61-70:
+// the Problem overloads (the problem's current operating point, strategies and initial state).  Both run on the
+// device: ilqg_strategy_costs_batch (default RK4 integration) and ilqg_check_local_nash_batch (one-step Euler, every
+// alpha entry moved down and up by max_perturbation — 2 m (T-1) rollouts in one launch).
+std::vector<float> ComputeStrategyCosts(const Problem& problem, bool open_loop = false);
+bool NumericalCheckLocalNashEquilibrium(const Problem& problem, float max_perturbation, bool open_loop = false);
+
 // include/ilqgames/examples/roundabout_lane_center.h:55-57
 PointList2 RoundaboutLaneCenter(float entrance_angle, float exit_angle, float distance_from_roundabout);
 

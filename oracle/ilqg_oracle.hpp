@@ -1799,4 +1799,54 @@ std::vector<MpcRecord<S>> RecedingHorizonSimulate(const Problem<S>& p, const Vec
   return recs;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Equilibrium checks: ComputeStrategyCosts (src/compute_strategy_costs.cpp:61-106) and
+// NumericalCheckLocalNashEquilibrium (src/check_local_nash_equilibrium.cpp:60-133).
+// ---------------------------------------------------------------------------------------------
+// Cost of every player when the strategies are played from x0 (closed loop: against the operating point;
+// open loop: u = u_ref - alpha), one-step Euler or the default RK4 integration.
+template <class S>
+Vec<S> ComputeStrategyCosts(const Problem<S>& p, const Vec<S>& x0, const Trajectory<S>& op, const Strategies<S>& st,
+                            bool open_loop, bool euler) {
+  Vec<S> x = x0, total(p.N, S(0));
+  double t = 0.0;
+  const int steps = open_loop ? p.T - 1 : p.T;
+  const Vec<S> zero(p.n, S(0));
+  for (int kk = 0; kk < steps; kk++) {
+    const Vec<S> u = open_loop ? ApplyStrategies(p, st, kk, zero, zero, op.us[kk])
+                               : ApplyStrategies(p, st, kk, x, op.xs[kk], op.us[kk]);
+    const Vec<S> next_x = Integrate(p, t, p.dt, x, u, euler);
+    // PlayerCost::EvaluateOffset (player_cost.cpp:175-190): state costs at the next state, control costs now
+    for (int i = 0; i < p.N; i++) total[i] += EvaluatePlayer(p, i, open_loop ? next_x : x, u);
+    x = next_x;
+    t += p.dt;
+  }
+  return total;
+}
+
+// Every entry of every alpha_i[k], k < T-1, moved by -/+ max_perturbation in turn (Euler integration, as the
+// reference forces): a local Nash equilibrium iff no such unilateral move lowers the mover's cost.
+// *margin = min over moves of (perturbed cost - nominal cost) of the mover.
+template <class S>
+bool CheckLocalNash(const Problem<S>& p, const Vec<S>& x0, const Trajectory<S>& op, const Strategies<S>& st,
+                    S max_perturbation, bool open_loop, S* margin) {
+  const Vec<S> nominal = ComputeStrategyCosts(p, x0, op, st, open_loop, true);
+  S worst = std::numeric_limits<S>::infinity();
+  Strategies<S> lower = st, upper = st;
+  for (int i = 0; i < p.N; i++)
+    for (int kk = 0; kk < p.T - 1; kk++)
+      for (int jj = 0; jj < p.udim(i); jj++) {
+        const int a = p.uoff[i] + jj;
+        lower.alpha[kk][a] -= max_perturbation;
+        upper.alpha[kk][a] += max_perturbation;
+        const S cl = ComputeStrategyCosts(p, x0, op, lower, open_loop, true)[i];
+        const S cu = ComputeStrategyCosts(p, x0, op, upper, open_loop, true)[i];
+        worst = std::min(worst, std::min(cl, cu) - nominal[i]);
+        lower.alpha[kk][a] = st.alpha[kk][a];
+        upper.alpha[kk][a] = st.alpha[kk][a];
+      }
+  if (margin) *margin = worst;
+  return !(worst < S(0));
+}
+
 }  // namespace oracle

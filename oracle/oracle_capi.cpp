@@ -454,6 +454,30 @@ void SimulateBatch(const OracleProblem* op, int batch, const void* x_init, doubl
   }
 }
 
+
+template <class S>
+void NashBatch(const OracleProblem* op, int batch, const void* x0, const void* xs, const void* us, const void* P,
+               const void* alpha, double max_perturbation, int open_loop, int euler, void* costs, int32_t* is_nash,
+               void* margin, int threads) {
+  const Problem<S>& p = Get<S>(op);
+  const int T = p.T, n = p.n;
+#pragma omp parallel for num_threads(threads) schedule(dynamic) if (threads > 1)
+  for (int b = 0; b < batch; b++) {
+    const Plan<S> pl = LoadPlan<S>(p, T, T, 0.0, xs, us, P, alpha, b);
+    const S* xb = (const S*)x0 + size_t(b) * n;
+    const Vec<S> x0v(xb, xb + n);
+    if (costs) {
+      const Vec<S> c = ComputeStrategyCosts(p, x0v, pl.op, pl.st, open_loop != 0, euler != 0);
+      std::memcpy((S*)costs + size_t(b) * p.N, c.data(), sizeof(S) * p.N);
+    }
+    if (is_nash) {
+      S mg;
+      is_nash[b] = CheckLocalNash(p, x0v, pl.op, pl.st, S(max_perturbation), open_loop != 0, &mg) ? 1 : 0;
+      if (margin) ((S*)margin)[b] = mg;
+    }
+  }
+}
+
 extern "C" {
 
 int oracle_lq_feedback(const ilqg_dims* d, const void* A, const void* Bm, const void* Q, const void* l,
@@ -574,6 +598,15 @@ void oracle_receding_horizon_simulate(void* h, int dtype, int batch, const void*
   DISPATCH(dtype, SimulateBatch, (OracleProblem*)h, batch, x_init, final_time, planner_runtime, extra_time, solve_time,
            use_al, max_records, num_records, t_call, x_measured, x0, plan_t0, first_step, xs, us, P, alpha, iters, ok,
            converged, max_bt, cap, fxs, fus, fP, falpha, flen, ft0, fx, threads);
+}
+
+
+// ComputeStrategyCosts (costs != NULL) and / or NumericalCheckLocalNashEquilibrium (is_nash != NULL) per instance.
+void oracle_nash(void* h, int dtype, int batch, const void* x0, const void* xs, const void* us, const void* P,
+                 const void* alpha, double max_perturbation, int open_loop, int euler, void* costs, int32_t* is_nash,
+                 void* margin, int threads) {
+  DISPATCH(dtype, NashBatch, (OracleProblem*)h, batch, x0, xs, us, P, alpha, max_perturbation, open_loop, euler, costs,
+           is_nash, margin, threads);
 }
 
 // xdot = f(x, u) and one Integrate step (double I/O regardless of dtype, for the

@@ -241,6 +241,27 @@ class OracleProblem:
             int(threads))
         return o
 
+    def strategy_costs(self, dtype, x0, xs, us, P, alpha, open_loop=False, euler=True):
+        """ComputeStrategyCosts (src/compute_strategy_costs.cpp:61-106) per instance -> [B][N]."""
+        dt = _np(dtype)
+        a = [np.ascontiguousarray(v, dtype=dt) for v in (x0, xs, us, P, alpha)]
+        costs = np.zeros((a[0].shape[0], self.N), dt)
+        lib().oracle_nash(self.h, dtype, a[0].shape[0], _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), _p(a[4]),
+                          C.c_double(0.0), int(open_loop), int(euler), _p(costs), None, None, 1)
+        return costs
+
+    def check_local_nash(self, dtype, x0, xs, us, P, alpha, max_perturbation, open_loop=False, threads=8):
+        """NumericalCheckLocalNashEquilibrium per instance -> (is_nash [B] int32, margin [B])."""
+        dt = _np(dtype)
+        a = [np.ascontiguousarray(v, dtype=dt) for v in (x0, xs, us, P, alpha)]
+        B = a[0].shape[0]
+        ok = np.zeros(B, np.int32)
+        margin = np.zeros(B, dt)
+        lib().oracle_nash(self.h, dtype, B, _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), _p(a[4]),
+                          C.c_double(max_perturbation), int(open_loop), 1, None, _p(ok), _p(margin), int(threads))
+        return ok, margin
+
+
     def dynamics(self, dtype, x, u, euler=False):
         x = np.ascontiguousarray(x, np.float64)
         u = np.ascontiguousarray(u, np.float64)

@@ -21,6 +21,8 @@
 #include <ilqgames/examples/receding_horizon_simulator.h>
 #include <ilqgames/solver/solution_splicer.h>
 #include <ilqgames/solver/top_down_renderable_problem.h>
+#include <ilqgames/utils/check_local_nash_equilibrium.h>
+#include <ilqgames/utils/compute_strategy_costs.h>
 
 #include <fstream>
 #include <iomanip>
@@ -390,6 +392,13 @@ int main(int argc, char** argv) {
     std::ofstream os(outdir + "/unicycle_single.txt");
     os << std::setprecision(9) << "x0 " << problem->InitialState() << "\n";
     WriteLog(os, *log, success);
+    // equilibrium checks on the adopted solution
+    problem->OverwriteSolution(log->FinalOperatingPoint(), log->FinalStrategies());
+    std::ofstream oc(outdir + "/unicycle_checks.txt");
+    oc << std::setprecision(9) << "costs";
+    for (float c : ComputeStrategyCosts(*problem)) oc << " " << c;
+    oc << "\nnash_small " << (NumericalCheckLocalNashEquilibrium(*problem, 0.0f) ? 1 : 0) << "\nnash_large "
+       << (NumericalCheckLocalNashEquilibrium(*problem, 0.5f) ? 1 : 0) << "\n";
   }
 
   // 5. the LQ seam on its own

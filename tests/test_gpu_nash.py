@@ -1,0 +1,74 @@
+"""GPU parity of the equilibrium checks (ilqg_strategy_costs_batch, ilqg_check_local_nash_batch) against the oracle's
+restatements of src/compute_strategy_costs.cpp:61-106 and src/check_local_nash_equilibrium.cpp:60-133, fp64.
+Costs agree to accumulation error (1e-10 relative); the verdict is compared wherever the margin is not within
+rounding of zero."""
+import numpy as np
+import pytest
+
+from ilqgames_amd import abi, examples
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    from ilqgames_amd import hip as h
+    return h
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _solved(oracle, cfg, B, iters):
+    spec = examples.CONFIGS[cfg]()
+    spec.params.initial_alpha_scaling = 0.5 if "intersection" not in cfg or cfg.startswith("modified") else 0.1
+    spec.params.expected_decrease_fraction = 0.001
+    op = oracle.OracleProblem(spec)
+    x0 = examples.jittered_x0(spec, B, seed=5)
+    r = op.solve(abi.F64, x0, fixed_iters=iters)
+    return spec, op, x0, r
+
+
+@pytest.mark.parametrize("cfg", ["modified_three_player_intersection", "three_player_collision_avoidance_reachability",
+                                 "two_player_unicycle_4d_scene", "roundabout_merging"])
+@pytest.mark.parametrize("open_loop,euler", [(False, True), (True, True), (False, False)])
+def test_strategy_costs_match_oracle_fp64(hip, oracle, cfg, open_loop, euler):
+    spec, op, x0, r = _solved(oracle, cfg, 3, 2)
+    ref = op.strategy_costs(abi.F64, x0, r["xs"], r["us"], r["P"], r["alpha"], open_loop=open_loop, euler=euler)
+    out = hip.Problem(spec, abi.F64).strategy_costs(x0, r["xs"], r["us"], r["P"], r["alpha"], open_loop=open_loop,
+                                                    euler=euler)
+    assert np.isfinite(ref).all()
+    assert rel_err(_np(out), ref) < 1e-10
+
+
+@pytest.mark.parametrize("cfg,eps", [("modified_three_player_intersection", 1e-2), ("two_player_unicycle_4d_scene", 1e-2),
+                                     ("three_player_collision_avoidance_reachability", 1e-1)])
+@pytest.mark.parametrize("open_loop", [False, True])
+def test_check_local_nash_matches_oracle_fp64(hip, oracle, cfg, eps, open_loop):
+    """1 + 2 m (T-1) Euler rollouts per instance in one launch: same margins as the oracle's loop, same verdicts
+    wherever the margin is not a rounding-level quantity.  Half of the instances carry the solver's strategies, the
+    other half zero strategies (far from any equilibrium)."""
+    B = 4
+    spec, op, x0, r = _solved(oracle, cfg, B, 8)
+    for k in ("us", "P", "alpha"):
+        r[k][B // 2:] = 0.0
+    r["xs"][B // 2:] = x0[B // 2:, None, :]
+    ok_ref, mg_ref = op.check_local_nash(abi.F64, x0, r["xs"], r["us"], r["P"], r["alpha"], eps, open_loop=open_loop)
+    ok, mg = hip.Problem(spec, abi.F64).check_local_nash(x0, r["xs"], r["us"], r["P"], r["alpha"], eps,
+                                                        open_loop=open_loop)
+    nominal = np.abs(op.strategy_costs(abi.F64, x0, r["xs"], r["us"], r["P"], r["alpha"], open_loop=open_loop)).max(axis=1)
+    tol = 1e-9 * np.maximum(1.0, nominal)  # a margin is the difference of two costs of this size
+    assert np.all(np.abs(_np(mg) - mg_ref) <= tol), (_np(mg), mg_ref)
+    decided = np.abs(mg_ref) > 10 * tol
+    assert decided.sum() >= B // 2
+    assert np.array_equal(_np(ok)[decided], ok_ref[decided])
+
+
+def test_check_local_nash_with_zero_perturbation_is_trivially_true(hip, oracle):
+    spec, op, x0, r = _solved(oracle, "modified_three_player_intersection", 2, 3)
+    ok, mg = hip.Problem(spec, abi.F64).check_local_nash(x0, r["xs"], r["us"], r["P"], r["alpha"], 0.0)
+    assert np.all(_np(ok) == 1) and np.all(_np(mg) == 0.0)

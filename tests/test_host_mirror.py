@@ -270,6 +270,16 @@ def test_cpp_two_player_unicycle_solve_matches_oracle(demo_out, oracle):
     assert [s[0] for s in spec.subsystems] == [abi.DYN_UNICYCLE_4D_DISTURBED, abi.DYN_PLANAR_DISTURBANCE]
     assert got["iters"] == 5
     _check_against_oracle(got, ref)
+    # ComputeStrategyCosts / NumericalCheckLocalNashEquilibrium of the mirror on the adopted (float) solution
+    rows = {ln.split()[0]: [float(v) for v in ln.split()[1:]] for ln in open(os.path.join(demo_out, "unicycle_checks.txt"))}
+    f32 = lambda a: a.astype(np.float32).astype(np.float64)
+    op = oracle.OracleProblem(spec)
+    sol = [f32(ref[k]) for k in ("xs", "us", "P", "alpha")]
+    want_costs = op.strategy_costs(abi.F64, got["x0"][None, :], *sol, euler=False)
+    np.testing.assert_allclose(rows["costs"], want_costs[0], rtol=1e-5)
+    ok_large, margin = op.check_local_nash(abi.F64, got["x0"][None, :], *sol, 0.5)
+    assert rows["nash_small"] == [1.0]
+    assert abs(margin[0]) > 1e-3 and rows["nash_large"] == [float(ok_large[0])]
 
 
 @pytest.mark.gpu

@@ -145,3 +145,25 @@ def test_second_solve_uses_the_previous_merit_value(oracle):
     tiny = np.full(B, 1e-9)
     r2 = op.solve_resume(abi.F64, x0 + 0.2, r1["xs"], r1["us"], r1["P"], r1["alpha"], tiny)
     assert np.all(r2["status"] == 0) and np.all(r2["iters"] == 1) and np.all(tiny == 1e-9)
+
+
+def test_strategy_costs_of_an_open_loop_plan_equal_the_total_costs_of_its_rollout(oracle):
+    """ComputeStrategyCosts (src/compute_strategy_costs.cpp:61-106) with zero gains and zero alphas plays the
+    operating point's own controls: with the default RK4 integration the accumulated per-step costs are
+    ILQSolver::TotalCosts of the rolled-out trajectory (all players of this example are time-additive)."""
+    spec = _spec()
+    B = 3
+    op = oracle.OracleProblem(spec)
+    x0 = examples.jittered_x0(spec, B, seed=6)
+    us = 0.2 * np.random.default_rng(2).standard_normal((B, spec.T, op.m))
+    zP, za = np.zeros((B, spec.T, op.m * op.n)), np.zeros((B, spec.T, op.m))
+    xs, _ = op.rollout(abi.F64, x0, np.zeros((B, spec.T, op.n)), us, zP, za)
+    total, _ = op.total_costs(abi.F64, xs, us)
+    got = op.strategy_costs(abi.F64, x0, xs, us, zP, za, open_loop=False, euler=False)
+    assert np.allclose(got, total, rtol=1e-12)
+    # Euler integration is a different trajectory, hence different costs; zero perturbation decides nothing
+    assert not np.allclose(op.strategy_costs(abi.F64, x0, xs, us, zP, za, euler=True), total, rtol=1e-6)
+    ok, margin = op.check_local_nash(abi.F64, x0, xs, us, zP, za, 0.0)
+    assert np.all(ok == 1) and np.all(margin == 0.0)
+    ok, margin = op.check_local_nash(abi.F64, x0, xs, us, zP, za, 0.05)
+    assert np.all(ok == 0) and np.all(margin < 0)  # random controls are no equilibrium
