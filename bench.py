@@ -178,6 +178,24 @@ def main():
                          "algorithmic_bytes_per_launch": launch_bytes / max(1, args.steps),
                          "bytes_per_iteration_per_instance": bytes_iter},
         }
+        if world == 1:
+            # BASELINE.json's second figure, ms per solve: ONE instance run to its convergence test (free-running:
+            # the host reads the instance's state back after every kernel round), zero warm start, outside the
+            # timed region above.
+            lb = prob.alloc_solve_buffers(1)
+            prob.solve(x0_d[:1], lb)
+            lat = []
+            for _ in range(3):
+                for k in ("xs", "us", "P", "alpha"):
+                    lb[k].zero_()
+                torch.cuda.synchronize()
+                l0 = time.perf_counter()
+                prob.solve(x0_d[:1], lb)
+                torch.cuda.synchronize()
+                lat.append(time.perf_counter() - l0)
+            out["latency"] = {"ms_per_solve": sorted(lat)[1] * 1e3, "iterations": int(lb["iters"][0].item()),
+                              "converged": int(lb["converged"][0].item()), "success": int(lb["status"][0].item()),
+                              "instances": 1, "mode": "free-running to convergence_tolerance, zero warm start"}
         if not args.no_cpu_baseline and world == 1:
             from oracle import pyoracle
             S = min(args.cpu_sample, B)
@@ -201,6 +219,10 @@ def main():
                 c1 = time.perf_counter()
                 out["cpu_baseline"]["value_all_cores"] = int(ref2["iters"].sum()) / (c1 - c0)
                 out["cpu_baseline"]["cores_all"] = ncpu
+            c0 = time.perf_counter()
+            one = op.solve(dtype, x0[:1])
+            out["latency"]["cpu_ms_per_solve"] = (time.perf_counter() - c0) * 1e3
+            out["latency"]["cpu_iterations"] = int(one["iters"][0])
         print(json.dumps(out))
     if distributed:
         dist.barrier()

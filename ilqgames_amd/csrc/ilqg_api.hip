@@ -217,8 +217,9 @@ __global__ void __launch_bounds__(64) ilq_exit_kernel(DevProblem p, SolveArgs<T>
 }
 
 // LQ kernel: the Riccati sweep at the accepted operating point of every instance that asked for one.
-template <typename T, int NX, int NP, int MU, bool PW>
-__global__ void __launch_bounds__((PW ? 64 * NP : LQCfg<T, NX, NP, MU>::NT), (PW ? NP : 1))
+template <typename T, int NX, int NP, int MU, int KIND>
+__global__ void __launch_bounds__((KIND == LQ_PLAYER_WAVES ? 64 * NP : LQCfg<T, NX, NP, MU>::NT),
+                                  (KIND == LQ_PLAYER_WAVES ? NP : 1))
 ilq_lq_kernel(DevProblem p, SolveArgs<T> sa) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int b = blockIdx.x;
@@ -227,7 +228,7 @@ ilq_lq_kernel(DevProblem p, SolveArgs<T> sa) {
     const int stage = reinterpret_cast<const SolveState<T>*>(sa.ws + size_t(b) * sa.ws_stride + L.state)->stage;
     if (stage != ST_LQ) return;
   }
-  lq_part_instance<T, NX, NP, MU, PW>(p, sa, b, reinterpret_cast<T*>(smem_raw));
+  lq_part_instance<T, NX, NP, MU, KIND>(p, sa, b, reinterpret_cast<T*>(smem_raw));
 }
 
 template <typename T>
@@ -436,13 +437,17 @@ static ilqg_status launch_solve(ilqg_problem* p, int32_t batch, const void* x0, 
   }
   sa.unfinished = p->d_unfinished;
   constexpr int W = TrialWaves<T>::W;
+  // LDS of the sweep kernel that will run: the open-loop sweep's own working set plus the slot the expected
+  // decrease is handed over in (n = 24: 54 KB, three instances per CU; the feedback layout would take 85 KB)
   size_t lq_elems = (C::USE_MFMA && !p->desc.params.open_loop) ? PWCfg<T, NX, NP, MU>::LDS_ELEMS : C::LDS_ELEMS;
-  if (p->desc.params.open_loop && size_t(OLCfg<T, NX, NP, MU>::LDS_ELEMS) > lq_elems) lq_elems = OLCfg<T, NX, NP, MU>::LDS_ELEMS;
+  if (p->desc.params.open_loop) lq_elems = OLCfg<T, NX, NP, MU>::LDS_ELEMS + 4;
   const size_t lds_lq = lq_elems * sizeof(T);
   const size_t lds_trial = trial_lds_bytes<T>(d, W);
   auto k_trial = ilq_trial_kernel<T, NX, NP, MU, W>;
   const bool pw = C::USE_MFMA && !p->desc.params.open_loop;  // one wave per player (MFMA feedback sweep)
-  auto k_lq = pw ? ilq_lq_kernel<T, NX, NP, MU, C::USE_MFMA> : ilq_lq_kernel<T, NX, NP, MU, false>;
+  auto k_lq = pw ? ilq_lq_kernel<T, NX, NP, MU, (C::USE_MFMA ? LQ_PLAYER_WAVES : LQ_VALU_FEEDBACK)>
+                 : (p->desc.params.open_loop ? ilq_lq_kernel<T, NX, NP, MU, LQ_OPEN_LOOP>
+                                             : ilq_lq_kernel<T, NX, NP, MU, LQ_VALU_FEEDBACK>);
   const int nt_lq = pw ? 64 * NP : C::NT;
   raise_lds_limit((const void*)k_trial, lds_trial);
   raise_lds_limit((const void*)k_lq, lds_lq);

@@ -145,6 +145,15 @@ __device__ __forceinline__ void lq_openloop_instance(const LQArgs<T>& a, const P
     }
   };
 
+  // diagnostics (ILQG_PROFILE build): shader-clock cycles of thread 0 per phase, summed over the steps
+  long long ph_c = (kProfile && a.ph) ? clock64() : 0;
+  auto PH = [&](int slot) {
+    if (kProfile && a.ph && t == 0) {
+      const long long c = clock64();
+      a.ph[slot] += c - ph_c;
+      ph_c = c;
+    }
+  };
   // ---- terminal step (:105-108) ----
   int cur = 0;
   lq_stage_issue<T, NX, NP, MU>(a, pt, Tn - 1, sm, t);
@@ -190,6 +199,7 @@ __device__ __forceinline__ void lq_openloop_instance(const LQArgs<T>& a, const P
       for (int aa = 0; aa < MU; aa++) sw[t * MU + aa] = b[aa];
     }
     lds_sync(NT <= 64);
+    PH(0);
     // ---- V_i = W_i M_i (column c), g = W_i m_i + w_i ----
     if (zl) {
 #pragma unroll
@@ -208,6 +218,7 @@ __device__ __forceinline__ void lq_openloop_instance(const LQArgs<T>& a, const P
       sg[t] = s + sw[t];
     }
     lds_sync(NT <= 64);
+    PH(1);
     // ---- Lambda [X | y] = [A | c], one column per lane (wave 0) ----
     if (t < 64) {
       T col[NX], x[NX];
@@ -228,19 +239,12 @@ __device__ __forceinline__ void lq_openloop_instance(const LQArgs<T>& a, const P
         x[r] = T(0);
       }
       qr_solve_columns<T, NX>(col, lane, x);
-      T* row = row_of(k);
       if (t >= NX && t < 2 * NX) {
 #pragma unroll
-        for (int r = 0; r < NX; r++) {
-          sX[r + NX * (t - NX)] = x[r];
-          row[O::rX + r + NX * (t - NX)] = x[r];
-        }
+        for (int r = 0; r < NX; r++) sX[r + NX * (t - NX)] = x[r];
       } else if (t == 2 * NX) {
 #pragma unroll
-        for (int r = 0; r < NX; r++) {
-          sy[r] = x[r];
-          row[O::ry + r] = x[r];
-        }
+        for (int r = 0; r < NX; r++) sy[r] = x[r];
       }
     }
     {  // W, w of this step -> scratch row k (forward pass)
@@ -249,6 +253,13 @@ __device__ __forceinline__ void lq_openloop_instance(const LQArgs<T>& a, const P
       if (t < M) row[O::rw + t] = sw[t];
     }
     lds_sync(NT <= 64);
+    {  // X, y -> scratch row k, from LDS so that the stores are contiguous (a lane owns a COLUMN of X: stored
+       // from its registers, every store instruction would touch one cache line per lane)
+      T* row = row_of(k);
+      for (int e = t; e < NX * NX; e += NT) row[O::rX + e] = sX[e];
+      if (t < NX) row[O::ry + t] = sy[t];
+    }
+    PH(2);
     // ---- M_i[:,c] = Q_i[:,c] + A^T (M_i X[:,c]);  t_i = m_i + M_i y ----
     T mn[NX];
     T tv = T(0);
@@ -289,7 +300,9 @@ __device__ __forceinline__ void lq_openloop_instance(const LQArgs<T>& a, const P
       smv[t] = sl[t] + s;
     }
     lds_sync(NT <= 64);
+    PH(3);
     store_value_row(k);
+    PH(4);
     if (O::DB) {
       dma_wait();
       lds_sync(NT <= 64);
@@ -301,6 +314,7 @@ __device__ __forceinline__ void lq_openloop_instance(const LQArgs<T>& a, const P
       dma_wait();
       lds_sync(NT <= 64);
     }
+    PH(5);
   }
 
   // ---- forward pass (:156-192) ----
@@ -394,6 +408,7 @@ __device__ __forceinline__ void lq_openloop_instance(const LQArgs<T>& a, const P
       lds_sync(NT <= 64);
     }
   }
+  PH(6);
   if (a.dx && t < NX) a.dx[size_t(Tn - 1) * NX + t] = sx[t];  // :188-192
   if (t < M) a.alpha[size_t(Tn - 1) * M + t] = T(0);
   if (a.ed_out) {

@@ -492,7 +492,10 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const Q
 // PW: the workgroup has one wave per player and runs the player-parallel MFMA feedback sweep;
 // otherwise LQCfg::NT threads run the open-loop sweep or the VALU feedback sweep.
 // ---------------------------------------------------------------------------
-template <typename T, int NX, int NP, int MU, bool PW>
+// KIND: which sweep this kernel instantiation carries (one each, so that the register allocation of one does not
+// pay for the others): LQ_VALU_FEEDBACK, LQ_PLAYER_WAVES (PW above) or LQ_OPEN_LOOP.
+enum { LQ_VALU_FEEDBACK = 0, LQ_PLAYER_WAVES = 1, LQ_OPEN_LOOP = 2 };
+template <typename T, int NX, int NP, int MU, int KIND>
 __device__ __forceinline__ void lq_part_instance(const DevProblem& p, const SolveArgs<T>& sa, int b, T* sm) {
   const int Tn = p.T;
   const WsLayout L(p.n, p.m, p.N, p.T, p.pairs.Rsz, p.pairs.rsz, sa.ol_row, p.num_constraints, sa.al_mode);
@@ -513,22 +516,24 @@ __device__ __forceinline__ void lq_part_instance(const DevProblem& p, const Solv
   la.alpha = sacc ? sa.alpha + size_t(b) * Tn * p.m : w + L.al1;
   la.dx = w + L.dx;
   la.scratch = w + L.lqscr;
-  la.ed_out = sm + LQCfg<T, NX, NP, MU>::oX;  // an LDS slot that is free once the sweep ends
+  // where the sweep leaves the expected decrease: an LDS slot that is free once it ends (feedback sweeps), or
+  // one past the open-loop sweep's own working set (the launch reserves it)
+  constexpr int ed_slot = (KIND == LQ_OPEN_LOOP) ? OLCfg<T, NX, NP, MU>::LDS_ELEMS : LQCfg<T, NX, NP, MU>::oX;
+  la.ed_out = sm + ed_slot;
   la.T_steps = Tn;
   la.adaptive = 1;
   la.symmetric = 1;  // linquad_compute writes H(x,y) and H(y,x) from the same value
   la.ph = (kProfile && sa.prof) ? sa.prof + size_t(b) * 96 + 8 : nullptr;
-  if constexpr (PW) {
+  if constexpr (KIND == LQ_PLAYER_WAVES) {
     lq_feedback_instance_mfma_pw<T, NX, NP, MU>(la, p.pairs, sm);
+  } else if constexpr (KIND == LQ_OPEN_LOOP) {
+    lq_openloop_instance<T, NX, NP, MU>(la, p.pairs, sm);  // SolverParams::open_loop (ilq_solver.h:76-81)
   } else {
-    if (sa.prm.open_loop)
-      lq_openloop_instance<T, NX, NP, MU>(la, p.pairs, sm);  // SolverParams::open_loop (ilq_solver.h:76-81)
-    else
-      lq_feedback_instance<T, NX, NP, MU>(la, p.pairs, sm);
+    lq_feedback_instance<T, NX, NP, MU>(la, p.pairs, sm);
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    st->expected_decrease = sm[LQCfg<T, NX, NP, MU>::oX];
+    st->expected_decrease = sm[ed_slot];
     st->num_iterations += 1;
     st->step = T(sa.prm.initial_alpha_scaling);
     st->bt = 0;

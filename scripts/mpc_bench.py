@@ -19,10 +19,14 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--al", action="store_true")
     ap.add_argument("--dtype", default="f64")
+    ap.add_argument("--max-iters", type=int, default=50,
+                    help="SolverParams::max_solver_iters of every call (a call costs ~1.2 ms per outer iteration "
+                         "whatever the batch size, so the reference's 1000 makes a 200-call run take minutes)")
     a = ap.parse_args()
     import torch
     from ilqgames_amd import abi, examples, hip
     spec = examples.CONFIGS[a.config]()
+    spec.params.max_solver_iters = a.max_iters
     dtype = abi.F64 if a.dtype == "f64" else abi.F32
     prob = hip.Problem(spec, dtype)
     x0 = examples.jittered_x0(spec, a.batch, seed=1)
@@ -41,7 +45,7 @@ def main():
     wall = time.time() - t0
     solves = int(out["num_records"].sum().item())
     print(json.dumps(dict(config=a.config, dtype=a.dtype, batch=a.batch, solver="al" if a.al else "ilq",
-                          calls=out["calls"], instance_solves=solves, seconds=wall,
+                          max_solver_iters=a.max_iters, calls=out["calls"], instance_solves=solves, seconds=wall,
                           ms_per_call=1e3 * wall / out["calls"], instance_solves_per_s=solves / wall,
                           logged_iterates=int(sum(iters)), active_at_end=int(out["active"].sum().item()),
                           active_per_call=active[:3] + active[-2:],
