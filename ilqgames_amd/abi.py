@@ -19,6 +19,7 @@ DYN_UNICYCLE_4D_DISTURBED, DYN_PLANAR_DISTURBANCE = 4, 5  # the two rows of TwoP
 (COST_QUADRATIC, COST_QUADRATIC_POLYLINE2, COST_SEMIQUADRATIC, COST_SEMIQUADRATIC_POLYLINE2,
  COST_PROXIMITY, COST_SIGNED_DISTANCE, COST_EXTREME_VALUE, CONSTRAINT_PROXIMITY,
  CONSTRAINT_SINGLE_DIMENSION) = range(1, 10)
+COST_POLYLINE2_SIGNED_DISTANCE = 10
 # ilqg_cost_role
 ROLE_STATE_COST, ROLE_CONTROL_COST, ROLE_STATE_CONSTRAINT, ROLE_CONTROL_CONSTRAINT, ROLE_CHILD = range(5)
 FLAG_ORIENTED, FLAG_IS_MIN = 1, 2
@@ -166,6 +167,10 @@ class ProblemSpec:
     def signed_distance(self, player, xy1, xy2, nominal=0.0, less_is_positive=True, role=ROLE_STATE_COST):
         return self._term(COST_SIGNED_DISTANCE, role, player, -1, tuple(xy1) + tuple(xy2), 1.0, nominal,
                           FLAG_ORIENTED if less_is_positive else 0)
+
+    def polyline2_signed_distance(self, player, polyline, xy, nominal=0.0, oriented_same_as_polyline=True):
+        return self._term(COST_POLYLINE2_SIGNED_DISTANCE, ROLE_STATE_COST, player, -1, xy, 1.0, nominal,
+                          FLAG_ORIENTED if oriented_same_as_polyline else 0, polyline)
 
     def extreme_value(self, player, children, is_min):
         """children: list of callables(role) -> term index, created contiguously as CHILD terms."""

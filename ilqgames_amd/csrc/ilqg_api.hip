@@ -734,6 +734,7 @@ ilqg_status ilqg_problem_create(const ilqg_problem_desc* desc, ilqg_problem** ou
           case ILQG_COST_SEMIQUADRATIC:
           case ILQG_CONSTRAINT_SINGLE_DIMENSION: idx->push_back(c.idx[0]); break;
           case ILQG_COST_QUADRATIC_POLYLINE2:
+          case ILQG_COST_POLYLINE2_SIGNED_DISTANCE:
           case ILQG_COST_SEMIQUADRATIC_POLYLINE2: idx->push_back(c.idx[0]); idx->push_back(c.idx[1]); break;
           default: for (int e = 0; e < 4; e++) idx->push_back(c.idx[e]); break;
         }

@@ -548,6 +548,11 @@ __device__ __forceinline__ T term_evaluate_leaf(const QuadTables<T>& tb, int ti,
       const T cost = val - t_hypot(dx, dy);
       return oriented ? cost : -cost;
     }
+    case ILQG_COST_POLYLINE2_SIGNED_DISTANCE: {  // src/polyline2_signed_distance_cost.cpp:52-65
+      const Closest<T> cl = polyline_closest<T>(tb, c.polyline, v[c.idx[0]], v[c.idx[1]]);
+      const T ssd = oriented ? cl.ssd : -cl.ssd;
+      return sgn(ssd) * t_sqrt(t_abs(ssd)) - val;
+    }
     case ILQG_CONSTRAINT_PROXIMITY: {  // src/proximity_constraint.cpp:56-62
       const T dx = v[c.idx[0]] - v[c.idx[2]], dy = v[c.idx[1]] - v[c.idx[3]];
       const T value = t_hypot(dx, dy) - val;
@@ -691,6 +696,24 @@ __device__ __forceinline__ void term_compute_leaf(const QuadTables<T>& tb, const
       }
       o->pattern = PAT_PAIR2;
       o->gx = dx; o->gy = dy; o->hxx = ddx; o->hyy = ddy; o->hxy = dxdy;
+      return;
+    }
+    case ILQG_COST_POLYLINE2_SIGNED_DISTANCE: {  // src/polyline2_signed_distance_cost.cpp:52-126
+      const T px = v[c.idx[0]], py = v[c.idx[1]];
+      const Closest<T> cl = polyline_closest<T>(tb, c.polyline, px, py);
+      const T ssd = oriented ? cl.ssd : -cl.ssd;
+      const T sign = sgn(ssd);
+      const T distance = t_sqrt(t_abs(ssd));
+      o->value = sign * distance - val;
+      const T ex = px - cl.cx, ey = py - cl.cy;
+      const T denom = ssd * distance;
+      o->pattern = PAT_PAIR2;
+      if (cl.is_vertex) {
+        o->gx = sign * ex / distance; o->gy = sign * ey / distance;
+        o->hxx = ey * ey / denom; o->hyy = ex * ex / denom; o->hxy = -ex * ey / denom;
+      } else {  // as written there: the segment normal, whatever the orientation flag
+        o->gx = cl.seg.uy; o->gy = -cl.seg.ux;
+      }
       return;
     }
     case ILQG_COST_PROXIMITY: {  // src/proximity_cost.cpp:52-122

@@ -245,6 +245,41 @@ def three_player_collision_avoidance_reachability(T=100, dt=0.1, d0=5.0, v0=5.0,
     return s
 
 
+def draw_circle(center, radius, num_segments):
+    """DrawCircle (src/draw_shapes.cpp:61-73), same float / double arithmetic."""
+    f = np.float32
+    pts = [(f(center[0]) + f(radius), f(center[1]) + f(0.0))]
+    for ii in range(num_segments):
+        angle = 2.0 * np.pi * float(f(ii + 1) / f(num_segments))
+        pts.append((f(center[0]) + f(radius) * f(np.cos(angle)), f(center[1]) + f(radius) * f(np.sin(angle))))
+    return [(float(x), float(y)) for x, y in pts]
+
+
+def two_player_reachability(T=100, dt=0.1):
+    """TwoPlayerReachabilityExample — TwoPlayerUnicycle4D (n=4), player 1 max-over-time, player 2 min-over-time of
+    the signed distance to a unit circle around the origin.  src/two_player_reachability_example.cpp:62-126;
+    params exec/two_player_reachability_example/main.cpp:71-78,110-119.  As written there the two
+    Polyline2SignedDistanceCost calls pass (!kReach, "Target") / (kReach, "Target") into (nominal,
+    oriented_same_as_polyline): nominal 0 resp. 1, oriented true for both."""
+    prm = SolverParams.default()
+    prm.max_backtracking_steps = 100
+    prm.initial_alpha_scaling = 0.1
+    prm.convergence_tolerance = 0.01
+    prm.expected_decrease_fraction = 0.1
+    s = ProblemSpec(T, dt, prm)
+    s.add_player(DYN_UNICYCLE_4D_DISTURBED, 0.0, structure=abi.MAX)
+    s.add_player(DYN_PLANAR_DISTURBANCE, 0.0, structure=abi.MIN)
+    PX, PY, TH, V = 0, 1, 2, 3
+    circle = s.add_polyline(draw_circle((0.0, 0.0), 1.0, 10))
+    s.polyline2_signed_distance(0, circle, (PX, PY), 0.0, True)
+    s.polyline2_signed_distance(1, circle, (PX, PY), 1.0, True)
+    s.quadratic(0, 0.1, -1, 0.0, control_of=0)
+    s.quadratic(1, 0.1, -1, 0.0, control_of=1)
+    s.x0 = [0.0, -10.0, float(np.float32(np.pi / 4.0)), 5.0]
+    s.position_dims, s.heading_dims, s.speed_dims = [(PX, PY)], [TH], [V]
+    return s
+
+
 def two_player_unicycle_4d_scene(T=100, dt=0.1):
     """A test scene on TwoPlayerUnicycle4D (include/ilqgames/dynamics/two_player_unicycle_4d.h:57-139): player 1
     steers the unicycle (omega, a) towards the origin at a nominal speed, player 2 pushes it with a bounded planar
@@ -297,4 +332,5 @@ CONFIGS = {
     "roundabout_merging_T150": lambda: roundabout_merging(T=150),  # BASELINE.json config 4 (n=24, T=150, open loop)
     "three_player_collision_avoidance_reachability": three_player_collision_avoidance_reachability,
     "two_player_unicycle_4d_scene": two_player_unicycle_4d_scene,
+    "two_player_reachability": two_player_reachability,
 }

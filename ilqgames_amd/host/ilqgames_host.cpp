@@ -122,6 +122,19 @@ PointList2 RoundaboutLaneCenter(float entrance_angle, float exit_angle, float di
   return pts;
 }
 
+// src/draw_shapes.cpp:61-73: the angle is formed in double from a float fraction, the trigonometry narrows to the
+// points' float coordinates.
+Polyline2 DrawCircle(const Point2& center, float radius, size_t num_segments) {
+  CHECK_GT(radius, 0.0);
+  PointList2 rim;
+  rim.push_back(center + Point2(radius, 0.0f));
+  for (size_t step = 1; step <= num_segments; step++) {
+    const double angle = 2.0 * M_PI * (static_cast<float>(step) / static_cast<float>(num_segments));
+    rim.push_back(center + radius * Point2(static_cast<float>(std::cos(angle)), static_cast<float>(std::sin(angle))));
+  }
+  return Polyline2(rim);
+}
+
 // ------------------------------------------------------------------------------------------
 // Cost / constraint descriptions
 // ------------------------------------------------------------------------------------------
@@ -167,6 +180,12 @@ bool ProximityCost::Describe(host::TermDescription* out) const {
 bool SignedDistanceCost::Describe(host::TermDescription* out) const {
   FillTerm(out, ILQG_COST_SIGNED_DISTANCE, weight_, nominal_, less_is_positive_ ? ILQG_FLAG_ORIENTED : 0,
            {xdim1_, ydim1_, xdim2_, ydim2_});
+  return true;
+}
+bool Polyline2SignedDistanceCost::Describe(host::TermDescription* out) const {
+  FillTerm(out, ILQG_COST_POLYLINE2_SIGNED_DISTANCE, weight_, nominal_,
+           oriented_same_as_polyline_ ? ILQG_FLAG_ORIENTED : 0, {xidx_, yidx_});
+  out->polyline = &polyline_;
   return true;
 }
 bool ExtremeValueCost::Describe(host::TermDescription* out) const {

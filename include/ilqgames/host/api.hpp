@@ -241,6 +241,24 @@ class SignedDistanceCost : public TimeInvariantCost {
   bool less_is_positive_;
 };
 
+// include/ilqgames/cost/polyline2_signed_distance_cost.h:55-93 — signed distance to a polyline minus a nominal
+// value (positive on the polyline's right, or on its left when oriented_same_as_polyline is false).
+class Polyline2SignedDistanceCost : public TimeInvariantCost {
+ public:
+  Polyline2SignedDistanceCost(const Polyline2& polyline, const std::pair<Dimension, Dimension>& position_idxs,
+                              const float nominal = 0.0, bool oriented_same_as_polyline = true,
+                              const std::string& name = "")
+      : TimeInvariantCost(1.0, name), polyline_(polyline), xidx_(position_idxs.first), yidx_(position_idxs.second),
+        nominal_(nominal), oriented_same_as_polyline_(oriented_same_as_polyline) {}
+  bool Describe(host::TermDescription* out) const override;
+
+ private:
+  const Polyline2 polyline_;
+  const Dimension xidx_, yidx_;
+  const float nominal_;
+  const bool oriented_same_as_polyline_;
+};
+
 // include/ilqgames/cost/extreme_value_cost.h:56-88
 class ExtremeValueCost : public Cost {
  public:
@@ -888,6 +906,10 @@ std::vector<std::shared_ptr<const SolverLog>> RecedingHorizonSimulator(Time fina
 // alpha entry moved down and up by max_perturbation — 2 m (T-1) rollouts in one launch).
 std::vector<float> ComputeStrategyCosts(const Problem& problem, bool open_loop = false);
 bool NumericalCheckLocalNashEquilibrium(const Problem& problem, float max_perturbation, bool open_loop = false);
+
+// include/ilqgames/geometry/draw_shapes.h:52-53 (src/draw_shapes.cpp:61-73): a circle as a closed polyline of
+// num_segments chords, starting at angle 0 and running counter-clockwise.
+Polyline2 DrawCircle(const Point2& center, float radius, size_t num_segments);
 
 // include/ilqgames/examples/roundabout_lane_center.h:55-57
 PointList2 RoundaboutLaneCenter(float entrance_angle, float exit_angle, float distance_from_roundabout);

@@ -634,6 +634,14 @@ S EvaluateTerm(const Problem<S>& p, int ti, const S* v, int dim) {
       const S cost = val - std::hypot(dx, dy);
       return oriented ? cost : -cost;
     }
+    case ILQG_COST_POLYLINE2_SIGNED_DISTANCE: {  // src/polyline2_signed_distance_cost.cpp:52-65
+      S cx, cy, ssd;
+      bool is_vertex, is_endpoint;
+      Segment2<S> seg;
+      p.polylines[c.polyline].ClosestPoint(v[c.idx[0]], v[c.idx[1]], &cx, &cy, &is_vertex, &seg, &ssd, &is_endpoint);
+      if (!oriented) ssd *= S(-1);
+      return sgn(ssd) * std::sqrt(std::abs(ssd)) - val;
+    }
     case ILQG_COST_EXTREME_VALUE: {  // src/extreme_value_cost.cpp:51-85
       const bool is_min = c.flags & ILQG_FLAG_IS_MIN;
       S ext = is_min ? std::numeric_limits<S>::infinity() : -std::numeric_limits<S>::infinity();
@@ -786,6 +794,29 @@ void QuadraticizeTerm(const Problem<S>& p, int ti, double t, const S* v, int dim
       H(x1, y2) -= hxy; H(y2, x1) -= hxy;
       H(x2, y1) -= hxy; H(y1, x2) -= hxy;
       H(x2, y2) += hxy; H(y2, x2) += hxy;
+      return;
+    }
+    case ILQG_COST_POLYLINE2_SIGNED_DISTANCE: {  // src/polyline2_signed_distance_cost.cpp:67-126
+      const int xi = c.idx[0], yi = c.idx[1];
+      const S px = v[xi], py = v[yi];
+      S cx, cy, ssd;
+      bool is_vertex, is_endpoint;
+      Segment2<S> seg;
+      p.polylines[c.polyline].ClosestPoint(px, py, &cx, &cy, &is_vertex, &seg, &ssd, &is_endpoint);
+      if (!oriented) ssd *= S(-1);
+      const S sign = sgn(ssd);
+      const S distance = std::sqrt(std::abs(ssd));
+      const S ex = px - cx, ey = py - cy;
+      S dx = sign * ex / distance, dy = sign * ey / distance;
+      const S denom = ssd * distance;
+      S ddx = ey * ey / denom, ddy = ex * ex / denom, dxdy = -ex * ey / denom;
+      if (!is_vertex) {  // as written there: the segment normal, whatever the orientation flag
+        dx = seg.uy;
+        dy = -seg.ux;
+        ddx = ddy = dxdy = S(0);
+      }
+      G[xi] += dx; G[yi] += dy;
+      H(xi, xi) += ddx; H(yi, yi) += ddy; H(xi, yi) += dxdy; H(yi, xi) += dxdy;
       return;
     }
     case ILQG_COST_SIGNED_DISTANCE: {  // src/signed_distance_cost.cpp:65-113

@@ -26,6 +26,7 @@ EXAMPLES = [
     ("RoundaboutMergingExample", "roundabout_merging_example", examples.roundabout_merging),
     ("ThreePlayerCollisionAvoidanceReachabilityExample", "three_player_collision_avoidance_reachability_example",
      examples.three_player_collision_avoidance_reachability),
+    ("TwoPlayerReachabilityExample", "two_player_reachability_example", examples.two_player_reachability),
 ]
 
 
