@@ -245,6 +245,39 @@ def three_player_collision_avoidance_reachability(T=100, dt=0.1, d0=5.0, v0=5.0,
     return s
 
 
+def two_player_collision_avoidance_reachability(T=100, dt=0.1, px0=0.0, py0=-5.0):
+    """TwoPlayerCollisionAvoidanceReachabilityExample — n=10 (2 x Car5D), both players max-over-time of one shared
+    SignedDistanceCost whose nominal is the players' distance half-way through the horizon when both drive straight.
+    src/two_player_collision_avoidance_reachability_example.cpp:60-140; params
+    exec/two_player_collision_avoidance_reachability_example/main.cpp:72-79,113-121."""
+    prm = SolverParams.default()
+    prm.max_backtracking_steps = 100
+    prm.initial_alpha_scaling = 0.1
+    prm.convergence_tolerance = 0.01
+    prm.expected_decrease_fraction = 0.1
+    s = ProblemSpec(T, dt, prm)
+    for _ in range(2):
+        s.add_player(DYN_CAR_5D, 4.0, structure=abi.MAX)
+    f = np.float32
+    X, Y, H, V = [0, 5], [1, 6], [2, 7], [4, 9]
+    h1, speed = f(0.1), f(5.0)
+    half = 0.5 * (T * dt)  # 0.5 * time::kTimeHorizon, double
+    reach = f(half * float(speed))  # t * speed narrows to the points' float when it scales them
+    p1 = (f(px0) + reach * f(np.cos(np.float64(h1))), f(py0) + reach * f(np.sin(np.float64(h1))))
+    p2 = (f(0.0) + reach * f(1.0), f(0.0) + reach * f(0.0))
+    dx, dy = f(p1[0] - p2[0]), f(p1[1] - p2[1])
+    nominal = float(np.sqrt(f(dx * dx + dy * dy), dtype=np.float32))
+    for i in range(2):
+        s.quadratic(i, 0.1, -1, 0.0, control_of=i)
+        s.signed_distance(i, (X[0], Y[0]), (X[1], Y[1]), nominal, True)
+    x0 = np.zeros(10)
+    x0[[X[0], Y[0], H[0], V[0]]] = [px0, py0, float(h1), float(speed)]
+    x0[[X[1], Y[1], H[1], V[1]]] = [0.0, 0.0, 0.0, 5.0]
+    s.x0 = x0
+    s.position_dims, s.heading_dims, s.speed_dims = list(zip(X, Y)), H, V
+    return s
+
+
 def draw_circle(center, radius, num_segments):
     """DrawCircle (src/draw_shapes.cpp:61-73), same float / double arithmetic."""
     f = np.float32
@@ -333,4 +366,5 @@ CONFIGS = {
     "three_player_collision_avoidance_reachability": three_player_collision_avoidance_reachability,
     "two_player_unicycle_4d_scene": two_player_unicycle_4d_scene,
     "two_player_reachability": two_player_reachability,
+    "two_player_collision_avoidance_reachability": two_player_collision_avoidance_reachability,
 }

@@ -51,7 +51,8 @@ def test_lq_feedback_matches_reference_python_golden(hip, name):
     assert np.all(_np(P)[:, -1] == 0) and np.all(_np(alpha)[:, -1] == 0)
 
 
-@pytest.mark.parametrize("dims", [(14, 3, 2), (16, 3, 2), (15, 3, 2), (24, 4, 2), (6, 3, 2), (4, 2, 2), (2, 2, 1)])
+@pytest.mark.parametrize("dims", [(14, 3, 2), (16, 3, 2), (15, 3, 2), (24, 4, 2), (10, 2, 2), (6, 3, 2), (4, 2, 2),
+                                  (2, 2, 1)])
 @pytest.mark.parametrize("dtype", [abi.F64, abi.F32])
 def test_lq_feedback_matches_oracle_random(hip, oracle, dims, dtype):
     n, N, mu = dims
@@ -68,7 +69,7 @@ def test_lq_feedback_matches_oracle_random(hip, oracle, dims, dtype):
     assert rel_err(_np(dx), dxr) < tol
 
 
-@pytest.mark.parametrize("dims", [(14, 3, 2), (16, 3, 2), (24, 4, 2), (6, 3, 2), (2, 2, 1)])
+@pytest.mark.parametrize("dims", [(14, 3, 2), (16, 3, 2), (24, 4, 2), (10, 2, 2), (6, 3, 2), (2, 2, 1)])
 @pytest.mark.parametrize("dtype", [abi.F64, abi.F32])
 def test_lq_openloop_matches_oracle_random(hip, oracle, dims, dtype):
     """ilqg_lq_openloop_batch vs the oracle's LQOpenLoopSolver restatement (alpha, delta_xs; P == 0)."""
@@ -216,6 +217,25 @@ def test_ilq_solve_matches_oracle_fp64(hip, oracle, cfg):
     # every instance, clean or not, must come back finite with a sane status word
     assert np.isfinite(_np(out["xs"])).all() and set(_np(out["status"]).tolist()) <= {0, 1}
 
+
+
+def test_ilq_iteration_on_an_unstable_closed_loop_fp64(hip, oracle):
+    """TwoPlayerCollisionAvoidanceReachabilityExample (n=10, no regularisation): the first LQ solution's gains make
+    the closed-loop rollout amplify rounding by ~2.5x per step (measured: 2e-15 at step 0, 7e-13 at step 5), so
+    after 100 steps device and oracle trajectories are unrelated although nothing is wrong.  What is well
+    defined is compared: the strategies of the iteration (1e-9) and the first steps of the rollout."""
+    spec = examples.two_player_collision_avoidance_reachability()
+    spec.params.expected_decrease_fraction = 0.001
+    B = 6
+    x0 = examples.jittered_x0(spec, B, seed=11)
+    ref = oracle.OracleProblem(spec).solve(abi.F64, x0, fixed_iters=1, merit_log_len=1)
+    out = hip.Problem(spec, abi.F64).solve(x0, fixed_iters=1)
+    assert np.array_equal(_np(out["iters"]), ref["iters"]) and np.array_equal(_np(out["status"]), ref["status"])
+    assert rel_err(_np(out["P"]), ref["P"]) < 1e-9
+    assert rel_err(_np(out["alpha"]), ref["alpha"]) < 1e-9
+    assert rel_err(_np(out["xs"])[:, :8], ref["xs"][:, :8]) < 1e-9
+    assert rel_err(_np(out["us"])[:, :8], ref["us"][:, :8]) < 1e-9
+    assert np.isfinite(_np(out["xs"])).all()
 
 
 @pytest.mark.parametrize("T,B", [(37, 3), (2, 1), (100, 65)])

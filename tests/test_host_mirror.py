@@ -27,6 +27,8 @@ EXAMPLES = [
     ("ThreePlayerCollisionAvoidanceReachabilityExample", "three_player_collision_avoidance_reachability_example",
      examples.three_player_collision_avoidance_reachability),
     ("TwoPlayerReachabilityExample", "two_player_reachability_example", examples.two_player_reachability),
+    ("TwoPlayerCollisionAvoidanceReachabilityExample", "two_player_collision_avoidance_reachability_example",
+     examples.two_player_collision_avoidance_reachability),
 ]
 
 
