@@ -245,6 +245,38 @@ def three_player_collision_avoidance_reachability(T=100, dt=0.1, d0=5.0, v0=5.0,
     return s
 
 
+def skeleton(T=100, dt=0.1):
+    """SkeletonExample — the reference's template problem: two Car5D (n=10) crossing paths, lane-centre, speed,
+    control and proximity costs.  src/skeleton_example.cpp:60-185; params exec/skeleton_example/main.cpp:73-80,113-121."""
+    prm = SolverParams.default()
+    prm.max_backtracking_steps = 100
+    prm.initial_alpha_scaling = 0.25
+    prm.convergence_tolerance = 0.01
+    prm.expected_decrease_fraction = 0.1
+    s = ProblemSpec(T, dt, prm)
+    for _ in range(2):
+        s.add_player(DYN_CAR_5D, 4.0)
+    X, Y, H, V = [0, 5], [1, 6], [2, 7], [4, 9]
+    for i in range(2):
+        s.quadratic(i, 25.0, 0, 0.0, control_of=i)  # omega
+        s.quadratic(i, 15.0, 1, 0.0, control_of=i)  # acceleration
+    s.quadratic(0, 10.0, V[0], 8.0)
+    s.quadratic(1, 10.0, V[1], 8.0)
+    lane1 = s.add_polyline([(0.0, -1000.0), (0.0, 1000.0)])
+    lane2 = s.add_polyline([(-5.0, 1000.0), (-5.0, 5.0), (0.0, 0.0), (995.0, 0.0)])
+    s.quadratic_polyline2(0, 25.0, lane1, (X[0], Y[0]))
+    s.quadratic_polyline2(1, 25.0, lane2, (X[1], Y[1]))
+    for i in range(2):
+        s.proximity(i, 100.0, (X[0], Y[0]), (X[1], Y[1]), 6.0)
+    f = np.float32
+    x0 = np.zeros(10)
+    x0[[X[0], Y[0], H[0], V[0]]] = [0.0, -30.0, float(f(np.pi / 2)), 4.0]
+    x0[[X[1], Y[1], H[1], V[1]]] = [-5.0, 30.0, float(f(-np.pi / 2)), 3.0]
+    s.x0 = x0
+    s.position_dims, s.heading_dims, s.speed_dims = list(zip(X, Y)), H, V
+    return s
+
+
 def two_player_collision_avoidance_reachability(T=100, dt=0.1, px0=0.0, py0=-5.0):
     """TwoPlayerCollisionAvoidanceReachabilityExample — n=10 (2 x Car5D), both players max-over-time of one shared
     SignedDistanceCost whose nominal is the players' distance half-way through the horizon when both drive straight.
@@ -367,4 +399,5 @@ CONFIGS = {
     "two_player_unicycle_4d_scene": two_player_unicycle_4d_scene,
     "two_player_reachability": two_player_reachability,
     "two_player_collision_avoidance_reachability": two_player_collision_avoidance_reachability,
+    "skeleton": skeleton,
 }

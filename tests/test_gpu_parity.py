@@ -191,7 +191,7 @@ def _clean(ref, max_bt=12):
 
 @pytest.mark.parametrize("cfg", ["modified_three_player_intersection", "three_player_intersection",
                                  "three_player_collision_avoidance_reachability", "two_player_unicycle_4d_scene",
-                                 "two_player_reachability"])
+                                 "two_player_reachability", "skeleton"])
 def test_ilq_solve_matches_oracle_fp64(hip, oracle, cfg):
     """Whole iLQ loop, fp64, fixed iteration count.  Where the line search is well conditioned the
     device makes the oracle's accept/reject decisions, so trajectories, strategies and costs agree

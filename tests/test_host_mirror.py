@@ -29,6 +29,7 @@ EXAMPLES = [
     ("TwoPlayerReachabilityExample", "two_player_reachability_example", examples.two_player_reachability),
     ("TwoPlayerCollisionAvoidanceReachabilityExample", "two_player_collision_avoidance_reachability_example",
      examples.two_player_collision_avoidance_reachability),
+    ("SkeletonExample", "skeleton_example", examples.skeleton),
 ]
 
 
