@@ -245,6 +245,56 @@ def three_player_collision_avoidance_reachability(T=100, dt=0.1, d0=5.0, v0=5.0,
     return s
 
 
+def three_player_intersection_reachability(T=100, dt=0.1):
+    """ThreePlayerIntersectionReachabilityExample — the n=14 intersection (Car5D, Car5D, Unicycle4D) with player 1
+    as a max-over-time reachability player: its only state cost is the max of its signed distances to the two
+    other players; players 2 and 3 keep the lane / speed / (zero-weight) proximity costs of the modified
+    intersection.  src/three_player_intersection_reachability_example.cpp:72-318 (the reference ships no main
+    for it; solver parameters are those of its other reachability mains)."""
+    prm = SolverParams.default()
+    prm.max_backtracking_steps = 100
+    prm.initial_alpha_scaling = 0.1
+    prm.convergence_tolerance = 0.01
+    prm.expected_decrease_fraction = 0.1
+    s = ProblemSpec(T, dt, prm)
+    s.add_player(DYN_CAR_5D, 4.0, state_reg=10.0, control_reg=10.0, structure=abi.MAX)
+    s.add_player(DYN_CAR_5D, 4.0, state_reg=10.0, control_reg=10.0)
+    s.add_player(DYN_UNICYCLE_4D, 4.0, state_reg=10.0, control_reg=10.0)
+    P1X, P1Y, P1H, P1V = 0, 1, 2, 4
+    P2X, P2Y, P2H, P2V = 5, 6, 7, 9
+    P3X, P3Y, P3H, P3V = 10, 11, 12, 13
+    p2x0, p3y0 = -10.0, 16.0
+    lane2 = s.add_polyline([(p2x0, 1000.0), (p2x0, 28.0), (p2x0 + 0.5, 25.0), (p2x0 + 1.0, 24.0),
+                            (p2x0 + 3.0, 22.5), (p2x0 + 6.0, 22.0), (1000.0, 22.0)])
+    lane3 = s.add_polyline([(-1000.0, p3y0), (1000.0, p3y0)])
+    _lane_costs(s, 1, lane2, (P2X, P2Y), 25.0, 100.0, 2.5)
+    _lane_costs(s, 2, lane3, (P3X, P3Y), 25.0, 100.0, 2.5)
+    for pl, vidx, vmax, vnom in ((1, P2V, 12.0, 6.0), (2, P3V, 2.0, 1.5)):
+        s.semiquadratic(pl, 100.0, vidx, 1.0, False)   # MinV
+        s.semiquadratic(pl, 100.0, vidx, vmax, True)   # MaxV
+        s.quadratic(pl, 10.0, vidx, vnom)              # NominalV
+    for pl in range(3):
+        s.quadratic(pl, 0.1, 0, 0.0, control_of=pl)
+        s.quadratic(pl, 0.1, 1, 0.0, control_of=pl)
+    s.proximity(1, 0.0, (P2X, P2Y), (P1X, P1Y), 6.0)
+    s.proximity(1, 0.0, (P2X, P2Y), (P3X, P3Y), 6.0)
+    s.proximity(2, 0.0, (P3X, P3Y), (P1X, P1Y), 6.0)
+    s.proximity(2, 0.0, (P3X, P3Y), (P2X, P2Y), 6.0)
+    begin = len(s.terms)
+    s.extreme_value(0, [lambda role: s.signed_distance(0, (P1X, P1Y), (P2X, P2Y), 6.0, True, role=role),
+                        lambda role: s.signed_distance(0, (P1X, P1Y), (P3X, P3Y), 6.0, True, role=role)], is_min=False)
+    f = np.float32
+    x0 = np.zeros(14)
+    x0[[P1X, P1Y, P1H, P1V]] = [-2.0, -30.0, float(f(np.pi / 2)), 4.0]
+    x0[[P2X, P2Y, P2H, P2V]] = [-10.0, 45.0, float(f(-np.pi / 2)), 3.0]
+    x0[[P3X, P3Y, P3H, P3V]] = [-11.0, 16.0, 0.0, 1.25]
+    s.x0 = x0
+    s.position_dims = [(P1X, P1Y), (P2X, P2Y), (P3X, P3Y)]
+    s.heading_dims = [P1H, P2H, P3H]
+    s.speed_dims = [P1V, P2V, P3V]
+    return s
+
+
 def skeleton(T=100, dt=0.1):
     """SkeletonExample — the reference's template problem: two Car5D (n=10) crossing paths, lane-centre, speed,
     control and proximity costs.  src/skeleton_example.cpp:60-185; params exec/skeleton_example/main.cpp:73-80,113-121."""
@@ -400,4 +450,5 @@ CONFIGS = {
     "two_player_reachability": two_player_reachability,
     "two_player_collision_avoidance_reachability": two_player_collision_avoidance_reachability,
     "skeleton": skeleton,
+    "three_player_intersection_reachability": three_player_intersection_reachability,
 }

@@ -30,6 +30,8 @@ EXAMPLES = [
     ("TwoPlayerCollisionAvoidanceReachabilityExample", "two_player_collision_avoidance_reachability_example",
      examples.two_player_collision_avoidance_reachability),
     ("SkeletonExample", "skeleton_example", examples.skeleton),
+    ("ThreePlayerIntersectionReachabilityExample", "three_player_intersection_reachability_example",
+     examples.three_player_intersection_reachability),
 ]
 
 
