@@ -48,6 +48,8 @@ def main():
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
     ap.add_argument("--config", default="modified_three_player_intersection")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true",
+                    help="skip the single-instance ms/solve figure (profiling runs: keeps the kernel statistics to the batch)")
     ap.add_argument("--cpu-sample", type=int, default=768,
                     help="instances in the CPU baseline sample (768 x 20 iterations ~ 15 s on one host thread)")
     args = ap.parse_args()
@@ -178,7 +180,7 @@ def main():
                          "algorithmic_bytes_per_launch": launch_bytes / max(1, args.steps),
                          "bytes_per_iteration_per_instance": bytes_iter},
         }
-        if world == 1:
+        if world == 1 and not args.no_latency:
             # BASELINE.json's second figure, ms per solve: ONE instance run to its convergence test (free-running:
             # the host reads the instance's state back after every kernel round), zero warm start, outside the
             # timed region above.
@@ -221,8 +223,9 @@ def main():
                 out["cpu_baseline"]["cores_all"] = ncpu
             c0 = time.perf_counter()
             one = op.solve(dtype, x0[:1])
-            out["latency"]["cpu_ms_per_solve"] = (time.perf_counter() - c0) * 1e3
-            out["latency"]["cpu_iterations"] = int(one["iters"][0])
+            if "latency" in out:
+                out["latency"]["cpu_ms_per_solve"] = (time.perf_counter() - c0) * 1e3
+                out["latency"]["cpu_iterations"] = int(one["iters"][0])
         print(json.dumps(out))
     if distributed:
         dist.barrier()
