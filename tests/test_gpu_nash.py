@@ -72,3 +72,20 @@ def test_check_local_nash_with_zero_perturbation_is_trivially_true(hip, oracle):
     spec, op, x0, r = _solved(oracle, "modified_three_player_intersection", 2, 3)
     ok, mg = hip.Problem(spec, abi.F64).check_local_nash(x0, r["xs"], r["us"], r["P"], r["alpha"], 0.0)
     assert np.all(_np(ok) == 1) and np.all(_np(mg) == 0.0)
+
+
+def test_equilibrium_checks_fp32_track_the_fp32_oracle(hip, oracle):
+    """fp32 (the reference's precision): costs to 1e-4, margins to 1e-3 of the nominal cost, verdicts where decided."""
+    B = 4
+    spec, op, x0, r = _solved(oracle, "modified_three_player_intersection", B, 6)
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)
+    args = [f32(x0)] + [f32(r[k]) for k in ("xs", "us", "P", "alpha")]
+    prob = hip.Problem(spec, abi.F32)
+    ref = op.strategy_costs(abi.F32, *args)
+    assert rel_err(_np(prob.strategy_costs(*args)), ref) < 1e-4
+    ok_ref, mg_ref = op.check_local_nash(abi.F32, *args, 5e-2)
+    ok, mg = prob.check_local_nash(*args, 5e-2)
+    tol = 1e-3 * np.abs(ref).max(axis=1)
+    assert np.all(np.abs(_np(mg) - mg_ref) <= tol), (_np(mg), mg_ref)
+    decided = np.abs(mg_ref) > 10 * tol
+    assert np.array_equal(_np(ok)[decided], ok_ref[decided])

@@ -271,3 +271,47 @@ def test_receding_horizon_simulate_matches_oracle_fp64(hip, oracle, name, al):
             assert rel_err(_np(out["x"])[b], ref["x"][b]) < 1e-6
     assert agree_all >= 2 and matched >= 0.5 * ref["num_records"].sum(), (agree_all, matched, nrec, ref["num_records"])
     assert ref["num_records"].max() >= 6 and (ref["plan"]["len"] > spec.T).any()  # the loop ran and spliced
+
+
+def test_receding_harness_kernels_fp32_match_fp32_oracle(hip, oracle):
+    """The reference computes in float (types.h:68-69): the three plan kernels in fp32 against the fp32 oracle on
+    plans built by the fp64 oracle and rounded.  Row bookkeeping (lengths, start times, nearest index, which rows
+    move where) must be identical; values agree to float round-off accumulated over a few RK4 steps."""
+    import torch
+    spec = _spec()
+    B = 5
+    op = oracle.OracleProblem(spec)
+    prob = hip.Problem(spec, abi.F32)
+    plan64, s1, _ = _spliced_plan(op, spec, B, seed=23)
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)
+    plan = {k: (f32(v) if k in ("xs", "us", "P", "alpha") else v.copy()) for k, v in plan64.items()}
+    dplan = _dev_plan(hip, prob, plan)
+    # integrate
+    x = f32(plan["xs"][:, 4, :] + 0.02)
+    x_ref = x.copy()
+    act_ref = np.ones(B, np.int32)
+    op.plan_integrate(abi.F32, plan, 0.93, 1.37, 1.7, x_ref, act_ref)
+    xd = torch.from_numpy(x.copy()).cuda()
+    act = torch.ones(B, dtype=torch.int32, device="cuda")
+    prob.plan_integrate(dplan, 0.93, 1.37, 1.7, xd, act)
+    assert np.array_equal(_np(act), act_ref) and act_ref.all()
+    assert rel_err(_np(xd), x_ref) < 1e-5
+    # sync
+    act_ref = np.ones(B, np.int32)
+    ref = op.receding_horizon_sync(abi.F32, plan, x_ref, 1.37, 0.25, act_ref)
+    bufs = prob.alloc_solve_buffers(B)
+    x0n, st0, first = prob.receding_horizon_sync(dplan, torch.from_numpy(x_ref).cuda(), 1.37, 0.25, bufs, act)
+    assert np.array_equal(_np(first), ref["first_step"]) and np.allclose(_np(st0), ref["t0"], atol=1e-12)
+    assert rel_err(_np(x0n), ref["x0"]) < 1e-5
+    for key in ("xs", "us", "P", "alpha"):
+        assert rel_err(_np(bufs[key]), ref[key]) < 1e-5, key
+    # splice: pure row movement, bit-exact in any precision
+    sol = {k: f32(s1[k]) for k in ("xs", "us", "P", "alpha")}
+    conv = np.array([1, 0, 1, 1, 1], np.int32)
+    op.solution_splice(abi.F32, plan, sol, ref["t0"], converged=conv)
+    prob.solution_splice(dplan, _dev_plan(hip, prob, sol), st0, converged=torch.from_numpy(conv).cuda())
+    assert np.array_equal(_np(dplan["len"]), plan["len"]) and np.allclose(_np(dplan["t0"]), plan["t0"], atol=1e-12)
+    for b in range(B):
+        L = plan["len"][b]
+        for key in ("xs", "us", "P", "alpha"):
+            assert np.array_equal(_np(dplan[key])[b, :L], plan[key][b, :L]), (b, key)
