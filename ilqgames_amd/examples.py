@@ -295,6 +295,41 @@ def three_player_intersection_reachability(T=100, dt=0.1):
     return s
 
 
+def three_player_overtaking(T=100, dt=0.1):
+    """ThreePlayerOvertakingExample — n=18 (3 x Car6D): a fast car overtakes a slow one with a third ahead in the
+    next lane.  src/three_player_overtaking_example.cpp:68-330 (player 3's proximity costs are constructed there
+    but never added); params exec/three_player_overtaking/main.cpp:72-74,108-112."""
+    prm = SolverParams.default()
+    prm.max_backtracking_steps = 100
+    prm.initial_alpha_scaling = 0.75
+    prm.convergence_tolerance = 0.01
+    prm.expected_decrease_fraction = 0.1
+    s = ProblemSpec(T, dt, prm)
+    for _ in range(3):
+        s.add_player(DYN_CAR_6D, 4.0)
+    X, Y, H, V = [0, 6, 12], [1, 7, 13], [2, 8, 14], [4, 10, 16]
+    lane1 = s.add_polyline([(-1.0, -1000.0), (-1.0, 1000.0)])
+    lane2 = s.add_polyline([(2.5, -1000.0), (2.5, 1000.0)])
+    for pl, lane in ((0, lane1), (1, lane1), (2, lane2)):
+        _lane_costs(s, pl, lane, (X[pl], Y[pl]), 25.0, 100.0, 2.5)
+    for pl, w, vnom in ((0, 10.0, 15.0), (1, 1.0, 10.0), (2, 1.0, 10.0)):
+        s.quadratic(pl, w, V[pl], vnom)
+    for pl in range(3):
+        s.quadratic(pl, 500000.0, 0, 0.0, control_of=pl)  # steering rate
+        s.quadratic(pl, 500.0, 1, 0.0, control_of=pl)     # jerk
+    s.proximity(0, 100.0, (X[0], Y[0]), (X[1], Y[1]), 5.0)
+    s.proximity(0, 100.0, (X[0], Y[0]), (X[2], Y[2]), 5.0)
+    s.proximity(1, 100.0, (X[1], Y[1]), (X[0], Y[0]), 5.0)
+    s.proximity(1, 100.0, (X[1], Y[1]), (X[2], Y[2]), 5.0)
+    f = np.float32
+    x0 = np.zeros(18)
+    for pl, (px, py, v) in enumerate(((2.5, -10.0, 10.0), (-1.0, -10.0, 2.0), (2.5, 10.0, 2.0))):
+        x0[[X[pl], Y[pl], H[pl], V[pl]]] = [px, py, float(f(np.pi / 2)), v]
+    s.x0 = x0
+    s.position_dims, s.heading_dims, s.speed_dims = list(zip(X, Y)), H, V
+    return s
+
+
 def skeleton(T=100, dt=0.1):
     """SkeletonExample — the reference's template problem: two Car5D (n=10) crossing paths, lane-centre, speed,
     control and proximity costs.  src/skeleton_example.cpp:60-185; params exec/skeleton_example/main.cpp:73-80,113-121."""
@@ -450,5 +485,6 @@ CONFIGS = {
     "two_player_reachability": two_player_reachability,
     "two_player_collision_avoidance_reachability": two_player_collision_avoidance_reachability,
     "skeleton": skeleton,
+    "three_player_overtaking": three_player_overtaking,
     "three_player_intersection_reachability": three_player_intersection_reachability,
 }

@@ -32,6 +32,7 @@ EXAMPLES = [
     ("SkeletonExample", "skeleton_example", examples.skeleton),
     ("ThreePlayerIntersectionReachabilityExample", "three_player_intersection_reachability_example",
      examples.three_player_intersection_reachability),
+    ("ThreePlayerOvertakingExample", "three_player_overtaking_example", examples.three_player_overtaking),
 ]
 
 
