@@ -44,7 +44,7 @@ class CostTerm(C.Structure):
     _fields_ = [("kind", C.c_int32), ("role", C.c_int32), ("player", C.c_int32), ("arg", C.c_int32),
                 ("idx", C.c_int32 * 4), ("weight", C.c_float), ("value", C.c_float), ("flags", C.c_int32),
                 ("polyline", C.c_int32), ("child_begin", C.c_int32), ("child_count", C.c_int32),
-                ("constraint_slot", C.c_int32)]
+                ("constraint_slot", C.c_int32), ("first_step", C.c_int32)]
 
 
 class PlayerCost(C.Structure):
@@ -133,7 +133,7 @@ class ProblemSpec:
         return len(self.polylines) - 1
 
     def _term(self, kind, role, player, arg=-1, idx=(0, 0, 0, 0), weight=1.0, value=0.0, flags=0,
-              polyline=-1, child_begin=0, child_count=0, constraint=False):
+              polyline=-1, child_begin=0, child_count=0, constraint=False, first_step=0):
         idx = tuple(idx) + (0,) * (4 - len(idx))
         slot = -1
         if constraint:
@@ -141,8 +141,17 @@ class ProblemSpec:
             self._num_constraints += 1
         self.terms.append(dict(kind=kind, role=role, player=player, arg=arg, idx=idx, weight=weight,
                                value=value, flags=flags, polyline=polyline, child_begin=child_begin,
-                               child_count=child_count, constraint_slot=slot))
+                               child_count=child_count, constraint_slot=slot, first_step=first_step))
         return len(self.terms) - 1
+
+    def final_time(self, threshold_time, term):
+        """FinalTimeCost(cost, threshold_time) (cost/final_time_cost.h:55-88) around the term with index `term`
+        (as returned by the cost methods): inactive while k * dt < threshold_time."""
+        k = 0
+        while float(k) * self.dt < threshold_time:
+            k += 1
+        self.terms[term]["first_step"] = k
+        return term
 
     # --- PlayerCost::AddStateCost / AddControlCost / Add*Constraint with the reference cost ctors ---
     def quadratic(self, player, weight, dim, nominal=0.0, control_of=None):
@@ -215,7 +224,8 @@ class ProblemSpec:
                 spec.terms.append(dict(kind=int(v[0]), role=int(v[1]), player=int(v[2]), arg=int(v[3]),
                                        idx=tuple(int(a) for a in v[4:8]), weight=float(v[8]), value=float(v[9]),
                                        flags=int(v[10]), polyline=int(v[11]), child_begin=int(v[12]),
-                                       child_count=int(v[13]), constraint_slot=int(v[14])))
+                                       child_count=int(v[13]), constraint_slot=int(v[14]),
+                                       first_step=int(v[15]) if len(v) > 15 else 0))
                 if int(v[14]) >= 0:
                     spec._num_constraints = max(spec._num_constraints, int(v[14]) + 1)
             elif tok[0] == "polyline":
@@ -244,7 +254,8 @@ class ProblemSpec:
             poly = tuple((float('%.6g' % x), float('%.6g' % y)) for x, y in self.polylines[t["polyline"]]) \
                 if t["polyline"] >= 0 else None
             kids = tuple(term_key(self.terms[c]) for c in range(t["child_begin"], t["child_begin"] + t["child_count"]))
-            return (t["kind"], t["arg"], tuple(t["idx"]), f32(t["weight"]), f32(t["value"]), t["flags"], poly, kids)
+            return (t["kind"], t["arg"], tuple(t["idx"]), f32(t["weight"]), f32(t["value"]), t["flags"], poly, kids,
+                    t.get("first_step", 0))
 
         groups = {}
         for t in self.terms:
@@ -279,6 +290,7 @@ class ProblemSpec:
             for k in ("kind", "role", "player", "arg", "weight", "value", "flags", "polyline", "child_begin",
                       "child_count", "constraint_slot"):
                 setattr(ct, k, t[k])
+            ct.first_step = t.get("first_step", 0)
             for a in range(4):
                 ct.idx[a] = t["idx"][a]
         d.num_terms = len(self.terms)

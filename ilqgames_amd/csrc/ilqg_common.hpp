@@ -58,6 +58,7 @@ struct DevTerm {
   int arg_off;   // offset of the argument vector inside the [x|u] image
   int arg_dim;   // its length
   int cq;        // index of the shared closest-point query of a polyline term, or -1
+  int k_start;   // FinalTimeCost: first time step the term is active at (0 = always)
 };
 
 // Flattened Problem (dynamics + PlayerCosts) living in kernel-argument space;

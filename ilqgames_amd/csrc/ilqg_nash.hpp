@@ -78,7 +78,9 @@ __global__ void __launch_bounds__(64) strategy_costs_kernel(DevProblem p, Strate
     for (int ti = t; ti < p.num_terms; ti += 64) {
       const DevTerm c = tb.terms[ti];
       T value = T(0);
-      if (c.role == ILQG_ROLE_STATE_COST || c.role == ILQG_ROLE_CONTROL_COST) {
+      // FinalTimeCost gates on the time the term is evaluated AT: next_t for state costs in the open-loop form
+      const int at_step = (a.open_loop && c.role == ILQG_ROLE_STATE_COST) ? kk + 1 : kk;
+      if ((c.role == ILQG_ROLE_STATE_COST || c.role == ILQG_ROLE_CONTROL_COST) && at_step >= c.k_start) {
         if (c.kind == ILQG_COST_EXTREME_VALUE)
           (void)extreme_child<T>(tb, c, at + c.arg_off, c.arg_dim, &value);
         else

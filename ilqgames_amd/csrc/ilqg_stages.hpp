@@ -363,7 +363,7 @@ __device__ __forceinline__ void linquad_compute(const DevProblem& p, const QuadT
     bool live = false;
     if (ti < p.num_terms) {
       c = tb.terms[ti];
-      live = c.role != ILQG_ROLE_CHILD;
+      live = c.role != ILQG_ROLE_CHILD && k >= c.k_start;  // FinalTimeCost: nothing before its threshold
       if (live) {
         const bool is_cost = c.role == ILQG_ROLE_STATE_COST || c.role == ILQG_ROLE_CONTROL_COST;
         const bool deriv = do_quad && (is_full(c.player) || c.role == ILQG_ROLE_CONTROL_COST);

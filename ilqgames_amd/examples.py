@@ -330,6 +330,53 @@ def three_player_overtaking(T=100, dt=0.1):
     return s
 
 
+def two_player_collision(T=100, dt=0.1):
+    """TwoPlayerCollisionExample — n=12 (2 x Car6D) driving at each other in one lane, player 1 with a side
+    road to turn into; goal costs are FinalTimeCosts switched on for the last 0.5 s of the horizon.
+    src/two_player_collision_example.cpp:66-318; params exec/two_player_collision/main.cpp:72-74,108-112."""
+    prm = SolverParams.default()
+    prm.max_backtracking_steps = 100
+    prm.initial_alpha_scaling = 0.75
+    prm.convergence_tolerance = 0.01
+    prm.expected_decrease_fraction = 0.1
+    s = ProblemSpec(T, dt, prm)
+    for _ in range(2):
+        s.add_player(DYN_CAR_6D, 4.0, state_reg=1.0, control_reg=0.0)
+    X, Y, H, V = [0, 6], [1, 7], [2, 8], [4, 10]
+    xy = [(X[0], Y[0]), (X[1], Y[1])]
+    lane_w, bound_w, half = 250.0, 50000.0, 2.5
+    lane1 = s.add_polyline([(2.5, -50.0), (2.5, 50.0)])
+    s.quadratic_polyline2(0, lane_w, lane1, xy[0])
+    s.quadratic_polyline2(1, lane_w * 10, lane1, xy[1])
+    s.semiquadratic_polyline2(0, bound_w * 1000, lane1, xy[0], -half, False)
+    s.semiquadratic_polyline2(1, bound_w * 10, lane1, xy[1], -half, False)
+    s.semiquadratic_polyline2(1, bound_w, lane1, xy[1], half, True)
+    side = [([(2.5 + half, -50.0), (2.5 + half, -5.0)], True), ([(2.5 + half, 5.0), (2.5 + half, 50.0)], True),
+            ([(10.0, -5.0), (10.0, 5.0)], True), ([(2.5 + half, 5.0), (25.0, 5.0)], False),
+            ([(2.5 + half, -5.0), (25.0, -5.0)], True)]
+    for pts, right in side:
+        s.semiquadratic_polyline2(0, bound_w, s.add_polyline(pts), xy[0], 0.0, right)
+    s.quadratic(0, 10.0, V[0], 5.0)
+    s.quadratic(1, 1.0, V[1], 5.0)
+    for pl in range(2):
+        s.quadratic(pl, 5000.0, 0, 0.0, control_of=pl)
+        s.quadratic(pl, 3250.0, 1, 0.0, control_of=pl)
+    window = T * dt - 0.5  # time::kTimeHorizon - kFinalTimeWindow, double minus float
+    s.final_time(window, s.quadratic(0, 1000.0, X[0], 2.5))
+    s.final_time(window, s.quadratic(0, 1000.0, Y[0], 50.0))
+    s.final_time(window, s.quadratic(1, 1000.0, X[1], 2.5))
+    s.final_time(window, s.quadratic(1, 1000.0, Y[1], -50.0))
+    s.proximity(0, 5000.0, xy[0], xy[1], 7.5)
+    s.proximity(1, 5000.0, xy[1], xy[0], 7.5)
+    f = np.float32
+    x0 = np.zeros(12)
+    x0[[X[0], Y[0], H[0], V[0]]] = [2.5, -50.0, float(f(np.pi / 2)), 10.0]
+    x0[[X[1], Y[1], H[1], V[1]]] = [2.5, 50.0, float(f(-np.pi / 2)), 2.0]
+    s.x0 = x0
+    s.position_dims, s.heading_dims, s.speed_dims = xy, H, V
+    return s
+
+
 def skeleton(T=100, dt=0.1):
     """SkeletonExample — the reference's template problem: two Car5D (n=10) crossing paths, lane-centre, speed,
     control and proximity costs.  src/skeleton_example.cpp:60-185; params exec/skeleton_example/main.cpp:73-80,113-121."""
@@ -485,6 +532,7 @@ CONFIGS = {
     "two_player_reachability": two_player_reachability,
     "two_player_collision_avoidance_reachability": two_player_collision_avoidance_reachability,
     "skeleton": skeleton,
+    "two_player_collision": two_player_collision,
     "three_player_overtaking": three_player_overtaking,
     "three_player_intersection_reachability": three_player_intersection_reachability,
 }

@@ -188,6 +188,15 @@ bool Polyline2SignedDistanceCost::Describe(host::TermDescription* out) const {
   out->polyline = &polyline_;
   return true;
 }
+bool FinalTimeCost::Describe(host::TermDescription* out) const {
+  if (!cost_->Describe(out) || out->term.kind == ILQG_COST_EXTREME_VALUE) return false;
+  // the first step whose time ILQSolver hands to Evaluate / Quadraticize (RelativeTime(kk) = kk * kTimeStep,
+  // src/ilq_solver.cpp:236,475) passes `t >= threshold_time` (final_time_cost.h:67,75)
+  int first = 0;
+  while (static_cast<Time>(first) * time::kTimeStep < threshold_time_) first++;
+  out->term.first_step = first;
+  return true;
+}
 bool ExtremeValueCost::Describe(host::TermDescription* out) const {
   FillTerm(out, ILQG_COST_EXTREME_VALUE, weight_, 0.0f, is_min_ ? ILQG_FLAG_IS_MIN : 0, {0});
   out->children = costs_;
@@ -414,7 +423,8 @@ std::string DumpDescription(const ProblemDescription& description) {
   for (const auto& t : description.terms)
     os << "term " << t.kind << " " << t.role << " " << t.player << " " << t.arg << " " << t.idx[0] << " " << t.idx[1]
        << " " << t.idx[2] << " " << t.idx[3] << " " << t.weight << " " << t.value << " " << t.flags << " "
-       << t.polyline << " " << t.child_begin << " " << t.child_count << " " << t.constraint_slot << "\n";
+       << t.polyline << " " << t.child_begin << " " << t.child_count << " " << t.constraint_slot << " " << t.first_step
+       << "\n";
   for (int q = 0; q < d.num_polylines; q++) {
     os << "polyline";
     for (int p = description.polyline_offsets[q]; p < description.polyline_offsets[q + 1]; p++)

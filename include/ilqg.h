@@ -175,6 +175,9 @@ typedef struct {
   int32_t child_begin; /* EXTREME_VALUE: first child term index                */
   int32_t child_count; /* EXTREME_VALUE: number of children                    */
   int32_t constraint_slot; /* constraints: index into the per-instance lambda table, else -1 */
+  int32_t first_step;  /* FinalTimeCost (include/ilqgames/cost/final_time_cost.h:55-88): the term is zero (value
+                          and derivatives) before this time step — the smallest k with k * dt >= threshold_time,
+                          times taken relative to the start of the window.  0 = always active. */
 } ilqg_cost_term;
 
 typedef enum { ILQG_SUM = 0, ILQG_MAX = 1, ILQG_MIN = 2 } ilqg_cost_structure;

@@ -259,6 +259,21 @@ class Polyline2SignedDistanceCost : public TimeInvariantCost {
   const bool oriented_same_as_polyline_;
 };
 
+// include/ilqgames/cost/final_time_cost.h:55-88 — another cost, switched on from `threshold_time` (relative to the
+// start of the window) onwards; zero value and derivatives before.
+class FinalTimeCost : public Cost {
+ public:
+  FinalTimeCost(const std::shared_ptr<const Cost>& cost, Time threshold_time, const std::string& name = "")
+      : Cost(0.0, name), cost_(cost), threshold_time_(threshold_time) {
+    CHECK_NOTNULL(cost.get());
+  }
+  bool Describe(host::TermDescription* out) const override;
+
+ private:
+  const std::shared_ptr<const Cost> cost_;
+  const Time threshold_time_;
+};
+
 // include/ilqgames/cost/extreme_value_cost.h:56-88
 class ExtremeValueCost : public Cost {
  public:

@@ -685,6 +685,8 @@ void ModifyDerivatives(S lambda, S mu_in, S g, S* dx, S* ddx, S* dy = nullptr, S
 template <class S>
 void QuadraticizeTerm(const Problem<S>& p, int ti, double t, const S* v, int dim, Mat<S>* hess,
                       Vec<S>* grad, const ALState<S>* al) {
+  // FinalTimeCost::Quadraticize (cost/final_time_cost.h:73-77): nothing before the threshold step
+  if (p.terms[ti].first_step > 0 && std::llround(t / p.dt) < p.terms[ti].first_step) return;
   const ilqg_cost_term& c = p.terms[ti];
   const S w = S(c.weight), val = S(c.value);
   const bool oriented = c.flags & ILQG_FLAG_ORIENTED;
@@ -940,15 +942,19 @@ Quad<S> QuadraticizePlayer(const Problem<S>& p, int i, double t, const Vec<S>& x
 }
 
 // PlayerCost::Evaluate(t, x, us), src/player_cost.cpp:128-144 (constraints excluded).
+// k_state / k_control: the time steps the state / control costs are evaluated AT (FinalTimeCost::Evaluate,
+// cost/final_time_cost.h:66-69, returns 0 before its threshold step); the default is "late enough for every term".
 template <class S>
-S EvaluatePlayer(const Problem<S>& p, int i, const Vec<S>& x, const Vec<S>& u) {
+S EvaluatePlayer(const Problem<S>& p, int i, const Vec<S>& x, const Vec<S>& u, int k_state = 1 << 30,
+                 int k_control = 1 << 30) {
   S total = 0;
   const int nt = (int)p.terms.size();
   for (int ti = 0; ti < nt; ti++)
-    if (p.terms[ti].player == i && p.terms[ti].role == ILQG_ROLE_STATE_COST)
+    if (p.terms[ti].player == i && p.terms[ti].role == ILQG_ROLE_STATE_COST && k_state >= p.terms[ti].first_step)
       total += EvaluateTerm(p, ti, x.data(), p.n);
   for (int ti = 0; ti < nt; ti++)
-    if (p.terms[ti].player == i && p.terms[ti].role == ILQG_ROLE_CONTROL_COST) {
+    if (p.terms[ti].player == i && p.terms[ti].role == ILQG_ROLE_CONTROL_COST &&
+        k_control >= p.terms[ti].first_step) {
       const int j = p.terms[ti].arg;
       total += EvaluateTerm(p, ti, &u[p.uoff[j]], p.udim(j));
     }
@@ -1229,7 +1235,7 @@ void TotalCosts(const Problem<S>& p, const Trajectory<S>& op, Vec<S>* costs, std
   }
   for (int k = 0; k < p.T; k++)
     for (int i = 0; i < p.N; i++) {
-      const S c = EvaluatePlayer(p, i, op.xs[k], op.us[k]);
+      const S c = EvaluatePlayer(p, i, op.xs[k], op.us[k], k, k);
       if (p.pcs[i].structure == ILQG_SUM)
         (*costs)[i] += c;
       else if (p.pcs[i].structure == ILQG_MAX && c > (*costs)[i]) {
@@ -1848,7 +1854,8 @@ Vec<S> ComputeStrategyCosts(const Problem<S>& p, const Vec<S>& x0, const Traject
                                : ApplyStrategies(p, st, kk, x, op.xs[kk], op.us[kk]);
     const Vec<S> next_x = Integrate(p, t, p.dt, x, u, euler);
     // PlayerCost::EvaluateOffset (player_cost.cpp:175-190): state costs at the next state, control costs now
-    for (int i = 0; i < p.N; i++) total[i] += EvaluatePlayer(p, i, open_loop ? next_x : x, u);
+    for (int i = 0; i < p.N; i++)
+      total[i] += EvaluatePlayer(p, i, open_loop ? next_x : x, u, open_loop ? kk + 1 : kk, kk);
     x = next_x;
     t += p.dt;
   }

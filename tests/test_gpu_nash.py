@@ -89,3 +89,21 @@ def test_equilibrium_checks_fp32_track_the_fp32_oracle(hip, oracle):
     assert np.all(np.abs(_np(mg) - mg_ref) <= tol), (_np(mg), mg_ref)
     decided = np.abs(mg_ref) > 10 * tol
     assert np.array_equal(_np(ok)[decided], ok_ref[decided])
+
+
+@pytest.mark.parametrize("open_loop", [False, True])
+def test_strategy_costs_respect_final_time_costs_fp64(hip, oracle, open_loop):
+    """FinalTimeCost terms (cost/final_time_cost.h:55-88) count from their threshold step on; in the open-loop form
+    state costs are taken at the NEXT step's time (PlayerCost::EvaluateOffset), which moves the switch-on by one."""
+    spec = examples.two_player_unicycle_4d_scene()
+    spec.final_time(4.95, spec.quadratic(0, 40.0, 1, 3.0))
+    spec.final_time(2.0, spec.quadratic(1, 7.0, 0, -2.0))
+    op = oracle.OracleProblem(spec)
+    x0 = examples.jittered_x0(spec, 3, seed=5)
+    r = op.solve(abi.F64, x0, fixed_iters=2)
+    ref = op.strategy_costs(abi.F64, x0, r["xs"], r["us"], r["P"], r["alpha"], open_loop=open_loop)
+    out = hip.Problem(spec, abi.F64).strategy_costs(x0, r["xs"], r["us"], r["P"], r["alpha"], open_loop=open_loop)
+    assert rel_err(_np(out), ref) < 1e-10
+    plain = examples.two_player_unicycle_4d_scene()
+    base = oracle.OracleProblem(plain).strategy_costs(abi.F64, x0, r["xs"], r["us"], r["P"], r["alpha"], open_loop=open_loop)
+    assert np.all(ref > base)  # the gated terms did contribute

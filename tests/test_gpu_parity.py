@@ -223,12 +223,15 @@ def test_ilq_solve_matches_oracle_fp64(hip, oracle, cfg):
 
 
 
-def test_ilq_iteration_on_an_unstable_closed_loop_fp64(hip, oracle):
+@pytest.mark.parametrize("cfg", ["two_player_collision_avoidance_reachability", "two_player_collision"])
+def test_ilq_iteration_on_an_unstable_closed_loop_fp64(hip, oracle, cfg):
     """TwoPlayerCollisionAvoidanceReachabilityExample (n=10, no regularisation): the first LQ solution's gains make
     the closed-loop rollout amplify rounding by ~2.5x per step (measured: 2e-15 at step 0, 7e-13 at step 5), so
-    after 100 steps device and oracle trajectories are unrelated although nothing is wrong.  What is well
-    defined is compared: the strategies of the iteration (1e-9) and the first steps of the rollout."""
-    spec = examples.two_player_collision_avoidance_reachability()
+    after 100 steps device and oracle trajectories are unrelated although nothing is wrong.  TwoPlayerCollisionExample
+    (n=12, lane-boundary weights of 5e7, FinalTimeCost goals) behaves the same way.  What is well defined is
+    compared: the strategies of the iteration (1e-9) and the first steps of the rollout."""
+    spec = examples.CONFIGS[cfg]()
+    spec.params.initial_alpha_scaling = 0.1
     spec.params.expected_decrease_fraction = 0.001
     B = 6
     x0 = examples.jittered_x0(spec, B, seed=11)

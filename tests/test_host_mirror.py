@@ -33,6 +33,7 @@ EXAMPLES = [
     ("ThreePlayerIntersectionReachabilityExample", "three_player_intersection_reachability_example",
      examples.three_player_intersection_reachability),
     ("ThreePlayerOvertakingExample", "three_player_overtaking_example", examples.three_player_overtaking),
+    ("TwoPlayerCollisionExample", "two_player_collision_example", examples.two_player_collision),
 ]
 
 
