@@ -517,7 +517,7 @@ ilqg_status ilqg_selftest_mfma(int32_t dtype, const void* X, const void* Y, cons
   HIP_TRY(hipGetLastError());
   return ILQG_OK;
 }
-int32_t ilqg_abi_version(void) { return 1; }
+int32_t ilqg_abi_version(void) { return ILQG_ABI_VERSION; }
 
 ilqg_status ilqg_device_info(char* name_out, int32_t name_len, int32_t* num_cus) {
   ilqg_status s = check_device();

@@ -44,6 +44,9 @@ def lib():
             torch.cuda.init()
         _LIB = C.CDLL(LIB_PATH)
         _LIB.ilqg_last_error.restype = C.c_char_p
+        if _LIB.ilqg_abi_version() != abi.ABI_VERSION:  # a stale .so next to newer struct mirrors corrupts silently
+            raise RuntimeError("libilqg_hip.so has ABI version %d, the Python mirrors expect %d: rebuild "
+                               "(__graft_entry__.build())" % (_LIB.ilqg_abi_version(), abi.ABI_VERSION))
     return _LIB
 
 

@@ -433,6 +433,7 @@ ilqg_status ilqg_selftest_mfma(int32_t dtype, const void* X, const void* Y, cons
 const char* ilqg_last_error(void);
 
 /* Library / device introspection (used by the loader to fail loudly). */
+#define ILQG_ABI_VERSION 2 /* 2: ilqg_cost_term::first_step, dynamics kinds 4/5, cost kind 10, harness / check entries */
 int32_t ilqg_abi_version(void);
 ilqg_status ilqg_device_info(char* name_out, int32_t name_len, int32_t* num_cus);
 
