@@ -905,6 +905,161 @@ void Problem::SetUpNextRecedingHorizon(const VectorXf& x0, Time t0, Time planner
   operating_point_->t0 = new_t0;
 }
 
+namespace host {
+
+std::vector<std::vector<std::shared_ptr<const SolverLog>>> RecedingHorizonSimulatorBatch(
+    Time final_time, Time planner_runtime, GameSolver* solver, const std::vector<VectorXf>& x0s,
+    Time simulated_solve_time) {
+  CHECK_NOTNULL(solver);
+  CHECK_GE(simulated_solve_time, 0.0);
+  CHECK_LE(simulated_solve_time, planner_runtime);  // receding_horizon_simulator.cpp:119
+  const Problem& problem = solver->GetProblem();
+  const MultiPlayerIntegrableSystem& dyn = *problem.Dynamics();
+  const ilqg_dtype dtype = Options().dtype;
+  const bool al = solver->IsAugmentedLagrangian();
+  ProblemDescription description;
+  std::string why;
+  CHECK(DescribeProblem(problem, solver->Params(), dtype, &description, &why)) << why;
+  ilqg_problem* handle = nullptr;
+  CHECK_EQ(ilqg_problem_create(&description.desc, &handle), ILQG_OK) << ilqg_last_error();
+  const int B = static_cast<int>(x0s.size()), n = dyn.XDim(), m = dyn.TotalUDim(), N = dyn.NumPlayers();
+  const int T = description.desc.T, cap = T + 5;
+  CHECK_GT(B, 0);
+  const size_t eb = ElemBytes(dtype);
+  // true states, solve buffers (zero warm start: Problem::Initialize), stored plans
+  std::vector<float> x(size_t(B) * n);
+  for (int b = 0; b < B; b++) {
+    CHECK_EQ(x0s[b].size(), n);
+    std::memcpy(&x[size_t(b) * n], x0s[b].data(), n * sizeof(float));
+  }
+  DeviceBuffer dx, dx0, dxs, dus, dP, dal, dcosts, diters, dstatus, dconv, dws, dfirst, dt0, dactive;
+  DeviceBuffer pxs, pus, pP, pal, plen, pt0;
+  Upload(&dx, x, dtype);
+  Upload(&dx0, x, dtype);
+  auto zeros = [&](DeviceBuffer* buf, size_t bytes) { HipCheck(hipMemset(buf->Reserve(bytes), 0, bytes), "memset"); };
+  zeros(&dxs, size_t(B) * T * n * eb);
+  zeros(&dus, size_t(B) * T * m * eb);
+  zeros(&dP, size_t(B) * T * m * n * eb);
+  zeros(&dal, size_t(B) * T * m * eb);
+  zeros(&pxs, size_t(B) * cap * n * eb);
+  zeros(&pus, size_t(B) * cap * m * eb);
+  zeros(&pP, size_t(B) * cap * m * n * eb);
+  zeros(&pal, size_t(B) * cap * m * eb);
+  zeros(&plen, size_t(B) * sizeof(int32_t));
+  zeros(&pt0, size_t(B) * sizeof(double));
+  zeros(&dt0, size_t(B) * sizeof(double));
+  zeros(&dfirst, size_t(B) * sizeof(int32_t));
+  dcosts.Reserve(size_t(B) * N * eb);
+  diters.Reserve(size_t(B) * 4);
+  dstatus.Reserve(size_t(B) * 4);
+  dconv.Reserve(size_t(B) * 4);
+  uint64_t ws_bytes = 0;
+  CHECK_EQ(ilqg_workspace_bytes(handle, B, &ws_bytes), ILQG_OK) << ilqg_last_error();
+  dws.Reserve(ws_bytes);
+  std::vector<int32_t> active(B, 1);
+  dactive.Reserve(size_t(B) * 4);
+  auto push_active = [&] { HipCheck(hipMemcpy(dactive.get(), active.data(), size_t(B) * 4, hipMemcpyHostToDevice), "active"); };
+  auto pull_active = [&] { active = DownloadInts(dactive, B); };
+  push_active();
+  auto* act = static_cast<int32_t*>(dactive.get());
+  auto* it = static_cast<int32_t*>(diters.get());
+  auto* st = static_cast<int32_t*>(dstatus.get());
+  auto* cv = static_cast<int32_t*>(dconv.get());
+  std::vector<std::vector<std::shared_ptr<const SolverLog>>> logs(B);
+  std::vector<double> solve_t0(B, 0.0);
+  // one log entry per active instance from what the solve left in the buffers
+  auto record = [&](const std::vector<int32_t>& who, Time elapsed) {
+    const std::vector<float> xs = Download(dxs, size_t(B) * T * n, dtype), us = Download(dus, size_t(B) * T * m, dtype),
+                             P = Download(dP, size_t(B) * T * m * n, dtype), alpha = Download(dal, size_t(B) * T * m, dtype),
+                             costs = Download(dcosts, size_t(B) * N, dtype);
+    const std::vector<int32_t> iters = DownloadInts(diters, B), conv = DownloadInts(dconv, B);
+    for (int b = 0; b < B; b++) {
+      if (!who[b]) continue;
+      OperatingPoint op(T, N, solve_t0[b]);
+      std::vector<Strategy> strategies;
+      for (int i = 0; i < N; i++) strategies.emplace_back(T, n, dyn.UDim(i));
+      for (int k = 0; k < T; k++) {
+        op.xs[k] = VectorXf::Zero(n);
+        std::memcpy(op.xs[k].data(), &xs[(size_t(b) * T + k) * n], n * sizeof(float));
+        int row = 0;
+        for (int i = 0; i < N; i++) {
+          const int mi = dyn.UDim(i);
+          op.us[k][i] = VectorXf::Zero(mi);
+          std::memcpy(op.us[k][i].data(), &us[(size_t(b) * T + k) * m + row], mi * sizeof(float));
+          std::memcpy(strategies[i].alphas[k].data(), &alpha[(size_t(b) * T + k) * m + row], mi * sizeof(float));
+          for (int c = 0; c < n; c++)
+            for (int r = 0; r < mi; r++) strategies[i].Ps[k](r, c) = P[((size_t(b) * T + k) * n + c) * m + row + r];
+          row += mi;
+        }
+      }
+      auto log = std::make_shared<SolverLog>();
+      log->AddSolverIterate(op, strategies,
+                            std::vector<float>(costs.begin() + size_t(b) * N, costs.begin() + size_t(b + 1) * N), elapsed,
+                            conv[b] != 0);
+      log->SetDeviceIterations(iters[b]);
+      logs[b].push_back(log);
+    }
+  };
+  auto check = [&](ilqg_status s) { CHECK_EQ(s, ILQG_OK) << ilqg_last_error(); };
+  // ---- first call (receding_horizon_simulator.cpp:72-82) ----
+  check(al ? ilqg_al_solve_batch(handle, B, dx0.get(), dxs.get(), dus.get(), dP.get(), dal.get(), dcosts.get(), it, st, cv,
+                                 dws.get(), nullptr)
+           : ilqg_ilq_solve_batch(handle, B, dx0.get(), dxs.get(), dus.get(), dP.get(), dal.get(), dcosts.get(), it, st,
+                                  cv, dws.get(), 0, nullptr));
+  HipCheck(hipDeviceSynchronize(), "first solve");
+  record(active, 0.0);
+  check(ilqg_solution_splice_batch(handle, B, cap, pxs.get(), pus.get(), pP.get(), pal.get(),
+                                   static_cast<int32_t*>(plen.get()), static_cast<double*>(pt0.get()), dxs.get(),
+                                   dus.get(), dP.get(), dal.get(), static_cast<double*>(dt0.get()), nullptr, nullptr,
+                                   nullptr));
+  {
+    const std::vector<int32_t> ok = DownloadInts(dstatus, B);  // CHECK(success) there: a failed instance stops here
+    for (int b = 0; b < B; b++) active[b] = ok[b] ? 1 : 0;
+    push_active();
+  }
+  const Time kExtraTime = 0.25;
+  Time t = 0.0;
+  auto any_active = [&] {
+    for (int v : active)
+      if (v) return true;
+    return false;
+  };
+  while (any_active()) {
+    t += kExtraTime;
+    if (t >= final_time) break;
+    check(ilqg_plan_integrate_batch(handle, B, cap, pxs.get(), pus.get(), pP.get(), pal.get(),
+                                    static_cast<int32_t*>(plen.get()), static_cast<double*>(pt0.get()), t - kExtraTime,
+                                    t, t + planner_runtime + time::kTimeStep, dx.get(), act, nullptr));
+    check(ilqg_receding_horizon_sync_batch(handle, B, cap, pxs.get(), pus.get(), pP.get(), pal.get(),
+                                           static_cast<int32_t*>(plen.get()), static_cast<double*>(pt0.get()), dx.get(),
+                                           t, planner_runtime, dxs.get(), dus.get(), dP.get(), dal.get(), dx0.get(),
+                                           static_cast<double*>(dt0.get()), static_cast<int32_t*>(dfirst.get()), act,
+                                           nullptr));
+    HipCheck(hipDeviceSynchronize(), "receding horizon sync");
+    pull_active();
+    if (!any_active()) break;
+    HipCheck(hipMemcpy(solve_t0.data(), dt0.get(), size_t(B) * sizeof(double), hipMemcpyDeviceToHost), "window starts");
+    check(ilqg_solve_again_batch(handle, B, dx0.get(), dxs.get(), dus.get(), dP.get(), dal.get(), dcosts.get(), it, st,
+                                 cv, dws.get(), al ? 1 : 0, act, nullptr));
+    HipCheck(hipDeviceSynchronize(), "solve");
+    record(active, simulated_solve_time);
+    t += simulated_solve_time;
+    if (t >= final_time) break;
+    check(ilqg_plan_integrate_batch(handle, B, cap, pxs.get(), pus.get(), pP.get(), pal.get(),
+                                    static_cast<int32_t*>(plen.get()), static_cast<double*>(pt0.get()),
+                                    t - simulated_solve_time, t, t, dx.get(), act, nullptr));
+    check(ilqg_solution_splice_batch(handle, B, cap, pxs.get(), pus.get(), pP.get(), pal.get(),
+                                     static_cast<int32_t*>(plen.get()), static_cast<double*>(pt0.get()), dxs.get(),
+                                     dus.get(), dP.get(), dal.get(), static_cast<double*>(dt0.get()), cv, act, nullptr));
+    HipCheck(hipDeviceSynchronize(), "splice");
+    pull_active();
+  }
+  ilqg_problem_destroy(handle);
+  return logs;
+}
+
+}  // namespace host
+
 // ------------------------------------------------------------------------------------------
 // Equilibrium checks (src/compute_strategy_costs.cpp:108-114, src/check_local_nash_equilibrium.cpp:135-142)
 // ------------------------------------------------------------------------------------------

@@ -860,6 +860,8 @@ class GameSolver {
   // Batched form of Solve(): one instance per entry of x0s, all sharing the Problem definition and
   // its current operating point / strategies as warm start.  This is the call that fills the GPU.
   host::BatchResult SolveBatch(const std::vector<VectorXf>& x0s);
+  const SolverParams& Params() const { return params_; }
+  bool IsAugmentedLagrangian() const { return augmented_lagrangian_; }
 
  protected:
   GameSolver(const std::shared_ptr<Problem>& problem, const SolverParams& params, bool augmented_lagrangian);
@@ -914,6 +916,17 @@ class SolutionSplicer {
 // solve time (wall clock, or host::Options().simulated_solve_time when that is >= 0).
 std::vector<std::shared_ptr<const SolverLog>> RecedingHorizonSimulator(Time final_time, Time planner_runtime,
                                                                        GameSolver* solver);
+
+namespace host {
+// RecedingHorizonSimulator for a batch of initial states: every instance shares the simulator's clock (0.25 s of
+// motion before each call, `simulated_solve_time` after it) and keeps its own spliced plan; plans, states and the
+// solver's workspace stay on the device between calls (ilqg_plan_integrate_batch, ilqg_receding_horizon_sync_batch,
+// ilqg_solve_again_batch, ilqg_solution_splice_batch).  An instance leaves the loop where the reference would
+// (ContainsTime false, or a failed first solve); logs[b] holds one log per solver call instance b took part in.
+std::vector<std::vector<std::shared_ptr<const SolverLog>>> RecedingHorizonSimulatorBatch(
+    Time final_time, Time planner_runtime, GameSolver* solver, const std::vector<VectorXf>& x0s,
+    Time simulated_solve_time = 0.25);
+}  // namespace host
 
 // include/ilqgames/utils/compute_strategy_costs.h:58-60, include/ilqgames/utils/check_local_nash_equilibrium.h:61-70:
 // the Problem overloads (the problem's current operating point, strategies and initial state).  Both run on the

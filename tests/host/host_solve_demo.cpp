@@ -370,6 +370,26 @@ int main(int argc, char** argv) {
       os << "t0 " << log->FinalOperatingPoint().t0 << "\n";
       WriteLog(os, *log, true);
     }
+    // the same loop for a batch of initial states, plans resident on the device
+    auto batch_problem = std::make_shared<MergeScene>(false);
+    batch_problem->Initialize();
+    ILQSolver batch_solver(batch_problem, rh_params);
+    std::vector<VectorXf> x0s;
+    for (int b = 0; b < 3; b++) {
+      VectorXf x0 = batch_problem->InitialState();
+      x0(kCar1 + Car::kPxIdx) += 0.9f * b;
+      x0(kCar2 + Car::kVIdx) += 0.3f * b;
+      x0s.push_back(x0);
+    }
+    const auto batch_logs = host::RecedingHorizonSimulatorBatch(3.0, 0.25, &batch_solver, x0s, 0.25);
+    for (size_t b = 0; b < x0s.size(); b++) {
+      std::ofstream ob(outdir + "/rh_batch_" + std::to_string(b) + ".txt");
+      ob << std::setprecision(9) << "calls " << batch_logs[b].size() << "\n";
+      for (const auto& log : batch_logs[b]) {
+        ob << "t0 " << log->FinalOperatingPoint().t0 << "\n";
+        WriteLog(ob, *log, true);
+      }
+    }
   }
 
   // 4. shared-state dynamics: TwoPlayerUnicycle4D

@@ -231,6 +231,41 @@ def test_cpp_receding_horizon_resync_matches_oracle(demo_out, oracle):
     assert int(o["first_step"][0]) > 0
 
 
+def _parse_rh(path):
+    logs, calls = [], 0
+    for line in open(path):
+        tok = line.split()
+        if tok[0] == "calls":
+            calls = int(tok[1])
+        elif tok[0] == "t0":
+            logs.append(dict(t0=float(tok[1]), xs=[], us=[]))
+        elif tok[0] == "success":
+            logs[-1]["converged"], logs[-1]["iters"] = int(tok[3]), int(tok[5])
+        elif tok[0] == "x":
+            logs[-1]["xs"].append([float(v) for v in tok[1:]])
+        elif tok[0] == "u":
+            logs[-1]["us"].append([float(v) for v in tok[1:]])
+    assert calls == len(logs)
+    return logs
+
+
+@pytest.mark.gpu
+def test_cpp_receding_horizon_batch_matches_oracle(demo_out, oracle):
+    """host::RecedingHorizonSimulatorBatch (plans, states and solver workspace resident on the device between the
+    solver calls) against the oracle's loop, instance by instance."""
+    spec = abi.ProblemSpec.from_dump(open(os.path.join(demo_out, "scene_rh.txt")).read())
+    for b in range(3):
+        logs = _parse_rh(os.path.join(demo_out, "rh_batch_%d.txt" % b))
+        x0 = np.array(logs[0]["xs"][0])
+        ref = oracle.OracleProblem(spec).receding_horizon_simulate(abi.F64, x0[None, :], 3.0, 0.25, max_records=32)
+        assert len(logs) == int(ref["num_records"][0]) and len(logs) >= 2, (b, len(logs), ref["num_records"])
+        for r, log in enumerate(logs):
+            assert abs(log["t0"] - ref["plan_t0"][0, r]) < 1e-6, (b, r)
+            assert log["iters"] == ref["iters"][0, r] and log["converged"] == ref["converged"][0, r], (b, r)
+            xs = np.array(log["xs"])
+            assert np.max(np.abs(xs - ref["xs"][0, r])) < 5e-4 * max(1.0, np.max(np.abs(ref["xs"][0, r]))), (b, r)
+
+
 @pytest.mark.gpu
 def test_cpp_receding_horizon_simulator_matches_oracle(demo_out, oracle):
     """RecedingHorizonSimulator of the C++ mirror (Integrate, OverwriteSolution, SetUpNextRecedingHorizon, repeated
