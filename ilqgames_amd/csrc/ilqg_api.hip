@@ -1126,6 +1126,51 @@ ilqg_status ilqg_check_local_nash_batch(const ilqg_problem* p, int32_t batch, co
 #undef CALL
 }
 
+ilqg_status ilqg_check_sufficient_nash_batch(const ilqg_problem* p, int32_t batch, const void* xs, const void* us,
+                                             int32_t* is_psd, void* stream) {
+  if (!p || !xs || !us || !is_psd) return fail(ILQG_ERR_INVALID, "null argument");
+  if (batch <= 0) return ILQG_OK;
+  // PlayerCost::Quadraticize of every player at every step (:168-172), whatever the player's time structure: the
+  // quadraticisation kernel is launched on a copy of the problem whose players are all time-additive
+  ilqg_problem full = *p;
+  for (int i = 0; i < full.dev.N; i++) full.dev.structure[i] = ILQG_SUM;
+  const DevProblem& d = full.dev;
+  const size_t esz = p->desc.dtype == ILQG_F32 ? 4 : 8;
+  const size_t per_inst = size_t(d.T) * (size_t(d.N) * d.n * d.n + size_t(d.N) * d.n + d.pairs.Rsz + d.pairs.rsz) * esz;
+  int chunk = int((size_t(256) << 20) / per_inst);
+  if (chunk < 1) chunk = 1;
+  if (chunk > batch) chunk = batch;
+  ilqg_status s = g_scratch.reserve(per_inst * chunk);
+  if (s != ILQG_OK) return s;
+  hipLaunchKernelGGL(fill_int_kernel<int>, dim3((batch + 255) / 256), dim3(256), 0, (hipStream_t)stream, is_psd, 1, batch);
+  HIP_TRY(hipGetLastError());
+  for (int b0 = 0; b0 < batch; b0 += chunk) {
+    const int nb = (batch - b0 < chunk) ? batch - b0 : chunk;
+    char* base = (char*)g_scratch.ptr;
+    char* Q = base;
+    char* l = Q + size_t(nb) * d.T * d.N * d.n * d.n * esz;
+    char* R = l + size_t(nb) * d.T * d.N * d.n * esz;
+    char* r = R + size_t(nb) * d.T * d.pairs.Rsz * esz;
+    const char* xs_c = (const char*)xs + size_t(b0) * d.T * d.n * esz;
+    const char* us_c = (const char*)us + size_t(b0) * d.T * d.m * esz;
+    s = launch_linquad(&full, nb, xs_c, us_c, nullptr, nullptr, nullptr, nullptr, nullptr, Q, l, R, r, nullptr, nullptr,
+                       nullptr, stream);
+    if (s != ILQG_OK) break;
+#define CALL(TY_)                                                                                                  \
+  [&]() -> ilqg_status {                                                                                         \
+    hipLaunchKernelGGL(psd_check_kernel<TY_>, dim3(d.T, nb), dim3(64), 0, (hipStream_t)stream, d, (TY_*)Q, (TY_*)R, \
+                       is_psd + b0);                                                                               \
+    HIP_TRY(hipGetLastError());                                                                                  \
+    return ILQG_OK;                                                                                              \
+  }()
+    s = DT_DISPATCH(p, CALL);
+#undef CALL
+    if (s != ILQG_OK) break;
+  }
+  // `full` is a shallow copy: it must not run the destructor logic of the handle it was copied from
+  return s;
+}
+
 static ilqg_status check_plan(const ilqg_problem* p, int32_t plan_rows, const void* a, const void* b, const void* c,
                               const void* d, const void* e, const void* f) {
   if (!p || !a || !b || !c || !d || !e || !f) return fail(ILQG_ERR_INVALID, "null argument");

@@ -126,4 +126,52 @@ __global__ void __launch_bounds__(64) nash_verdict_kernel(DevProblem p, const T*
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// CheckSufficientLocalNashEquilibrium (src/check_local_nash_equilibrium.cpp:144-201): is every Q_i and R_ij of a
+// full quadraticisation free of eigenvalues below -kErrorMargin = -1e-4?  A symmetric M has no eigenvalue below
+// -eps exactly when M + eps I is positive semidefinite, which a Cholesky factorisation decides (it breaks down on
+// a non-positive pivot otherwise) without computing the spectrum: one lane per matrix, in place in the scratch
+// copy the quadraticisation kernel wrote.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ bool cholesky_is_positive(T* a, int d, T shift) {
+  for (int j = 0; j < d; j++) {
+    T s = a[j + d * j] + shift;
+    for (int k = 0; k < j; k++) s -= a[j + d * k] * a[j + d * k];
+    if (!(s > T(0))) return false;
+    const T ljj = t_sqrt(s);
+    a[j + d * j] = ljj;
+    for (int i = j + 1; i < d; i++) {
+      T v = a[i + d * j];
+      for (int k = 0; k < j; k++) v -= a[i + d * k] * a[j + d * k];
+      a[i + d * j] = v / ljj;
+    }
+  }
+  return true;
+}
+
+// grid = (T, instances of this chunk); ok[b] must hold 1 on entry and is cleared by any failing matrix.
+template <typename T>
+__global__ void __launch_bounds__(64) psd_check_kernel(DevProblem p, T* Q, T* R, int* ok) {
+  const int k = blockIdx.x;
+  const size_t b = blockIdx.y;
+  const int t = threadIdx.x, n = p.n, N = p.N;
+  const T shift = T(1e-4f);  // kErrorMargin (:174)
+  bool good = true;
+  if (t < N) {
+    good = cholesky_is_positive<T>(Q + ((b * p.T + k) * N + t) * size_t(n) * n, n, shift);
+  } else if (t < N + p.pairs.npairs) {
+    const int q = t - N;
+    const int mj = p.udim[p.pairs.pj[q]];
+    good = cholesky_is_positive<T>(R + (b * p.T + k) * size_t(p.pairs.Rsz) + p.pairs.roff[q], mj, shift);
+  }
+  if (!good) atomicAnd(ok + b, 0);
+}
+
+template <typename T>
+__global__ void fill_int_kernel(int* v, int value, int count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) v[i] = value;
+}
+
 }  // namespace ilqg

@@ -20,7 +20,7 @@ EXPORTS = [
     "ilqg_quadraticize_batch", "ilqg_problem_pairs", "ilqg_total_costs_batch", "ilqg_ilq_solve_batch",
     "ilqg_last_error", "ilqg_abi_version", "ilqg_device_info", "ilqg_selftest_mfma", "ilqg_al_solve_batch", "ilqg_plan_integrate_batch", "ilqg_receding_horizon_sync_batch",
     "ilqg_solution_splice_batch", "ilqg_solve_again_batch", "ilqg_strategy_costs_batch",
-    "ilqg_check_local_nash_batch",
+    "ilqg_check_local_nash_batch", "ilqg_check_sufficient_nash_batch",
     "ilqg_receding_horizon_shift_batch",
 ]
 
@@ -344,3 +344,11 @@ class Problem:
         _check(lib().ilqg_check_local_nash_batch(self.h, B, *[_ptr(v) for v in a], C.c_double(max_perturbation),
                                                  int(open_loop), _ptr(ok), _ptr(margin), _stream()))
         return ok, margin
+
+    def check_sufficient_nash(self, xs, us):
+        """ilqg_check_sufficient_nash_batch -> is_psd [B] int32 device tensor."""
+        import torch
+        xs, us = _dev(xs, self.dtype), _dev(us, self.dtype)
+        ok = torch.zeros(xs.shape[0], dtype=torch.int32, device="cuda")
+        _check(lib().ilqg_check_sufficient_nash_batch(self.h, xs.shape[0], _ptr(xs), _ptr(us), _ptr(ok), _stream()))
+        return ok

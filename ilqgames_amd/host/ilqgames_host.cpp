@@ -1110,6 +1110,30 @@ std::vector<float> ComputeStrategyCosts(const Problem& problem, bool open_loop) 
   return costs;
 }
 
+bool CheckSufficientLocalNashEquilibrium(const Problem& problem) {
+  using namespace host;
+  const ilqg_dtype dtype = Options().dtype;
+  ProblemDescription description;
+  std::string why;
+  CHECK(DescribeProblem(problem, SolverParams(), dtype, &description, &why)) << why;
+  ilqg_problem* handle = nullptr;
+  CHECK_EQ(ilqg_problem_create(&description.desc, &handle), ILQG_OK) << ilqg_last_error();
+  const int T = description.desc.T;
+  CHECK_EQ(static_cast<int>(problem.CurrentOperatingPoint().xs.size()), T);
+  DevicePlan plan;
+  plan.Upload(FlattenPlan(*problem.Dynamics(), problem.CurrentOperatingPoint(), problem.CurrentStrategies(), T), T,
+              problem.CurrentOperatingPoint().t0, dtype);
+  DeviceBuffer dflag;
+  dflag.Reserve(sizeof(int32_t));
+  const ilqg_status s = ilqg_check_sufficient_nash_batch(handle, 1, plan.xs.get(), plan.us.get(),
+                                                         static_cast<int32_t*>(dflag.get()), nullptr);
+  CHECK_EQ(s, ILQG_OK) << ilqg_last_error();
+  HipCheck(hipDeviceSynchronize(), "sufficient Nash check");
+  const bool ok = DownloadInts(dflag, 1)[0] != 0;
+  ilqg_problem_destroy(handle);
+  return ok;
+}
+
 bool NumericalCheckLocalNashEquilibrium(const Problem& problem, float max_perturbation, bool open_loop) {
   bool is_nash = false;
   RunEquilibriumCheck(problem, open_loop, &max_perturbation, nullptr, &is_nash);

@@ -425,6 +425,13 @@ ilqg_status ilqg_check_local_nash_batch(const ilqg_problem* p, int32_t batch, co
                                         const void* us, const void* P, const void* alpha, double max_perturbation,
                                         int32_t open_loop, int32_t* is_nash, void* margin, void* stream);
 
+/* Replaces CheckSufficientLocalNashEquilibrium (src/check_local_nash_equilibrium.cpp:144-201): every player's full
+ * PlayerCost::Quadraticize at every step of the operating point (xs, us) has Q_i and all its R_ij without an
+ * eigenvalue below -1e-4 (decided by a Cholesky factorisation of the matrix shifted by 1e-4, not by a spectrum).
+ *  is_psd [B] int32 (device) */
+ilqg_status ilqg_check_sufficient_nash_batch(const ilqg_problem* p, int32_t batch, const void* xs, const void* us,
+                                             int32_t* is_psd, void* stream);
+
 /* Diagnostics: out = X^T Y + C for 16x16 column-major device matrices, computed through the
  * MFMA accumulator-layout path the LQ sweep is built on (pins the gfx950 register layouts). */
 ilqg_status ilqg_selftest_mfma(int32_t dtype, const void* X, const void* Y, const void* C, void* out, void* stream);

@@ -934,6 +934,9 @@ std::vector<std::vector<std::shared_ptr<const SolverLog>>> RecedingHorizonSimula
 // alpha entry moved down and up by max_perturbation — 2 m (T-1) rollouts in one launch).
 std::vector<float> ComputeStrategyCosts(const Problem& problem, bool open_loop = false);
 bool NumericalCheckLocalNashEquilibrium(const Problem& problem, float max_perturbation, bool open_loop = false);
+// check_local_nash_equilibrium.h:76-77: Q_i, R_ij of every player's quadraticisation along the problem's current
+// operating point positive semidefinite to within 1e-4 (ilqg_check_sufficient_nash_batch).
+bool CheckSufficientLocalNashEquilibrium(const Problem& problem);
 
 // include/ilqgames/geometry/draw_shapes.h:52-53 (src/draw_shapes.cpp:61-73): a circle as a closed polyline of
 // num_segments chords, starting at angle 0 and running counter-clockwise.

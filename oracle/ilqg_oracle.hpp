@@ -1887,4 +1887,54 @@ bool CheckLocalNash(const Problem<S>& p, const Vec<S>& x0, const Trajectory<S>& 
   return !(worst < S(0));
 }
 
+// Smallest eigenvalue of a symmetric matrix by cyclic Jacobi rotations (what SelfAdjointEigenSolver::eigenvalues()
+// .minCoeff() returns, src/check_local_nash_equilibrium.cpp:182-194, to rounding).
+template <class S>
+S MinEigenvalueSymmetric(Mat<S> a) {
+  const int n = a.r;
+  for (int sweep = 0; sweep < 60; sweep++) {
+    S off = 0;
+    for (int i = 0; i < n; i++)
+      for (int j = i + 1; j < n; j++) off += a(i, j) * a(i, j);
+    if (off < S(1e-30)) break;
+    for (int pi = 0; pi < n; pi++)
+      for (int q = pi + 1; q < n; q++) {
+        if (a(pi, q) == S(0)) continue;
+        const S theta = (a(q, q) - a(pi, pi)) / (S(2) * a(pi, q));
+        const S t = (theta >= S(0) ? S(1) : S(-1)) / (std::abs(theta) + std::sqrt(theta * theta + S(1)));
+        const S c = S(1) / std::sqrt(t * t + S(1)), sn = t * c;
+        for (int k = 0; k < n; k++) {
+          const S akp = a(k, pi), akq = a(k, q);
+          a(k, pi) = c * akp - sn * akq;
+          a(k, q) = sn * akp + c * akq;
+        }
+        for (int k = 0; k < n; k++) {
+          const S apk = a(pi, k), aqk = a(q, k);
+          a(pi, k) = c * apk - sn * aqk;
+          a(q, k) = sn * apk + c * aqk;
+        }
+      }
+  }
+  S lo = std::numeric_limits<S>::infinity();
+  for (int i = 0; i < n; i++) lo = std::min(lo, a(i, i));
+  return lo;
+}
+
+// CheckSufficientLocalNashEquilibrium (src/check_local_nash_equilibrium.cpp:144-201): every player's full
+// PlayerCost::Quadraticize at every step has Q_i and all its R_ij with no eigenvalue below -1e-4.
+// *worst = the smallest eigenvalue met.
+template <class S>
+bool CheckSufficientLocalNash(const Problem<S>& p, const Trajectory<S>& op, S* worst) {
+  S lo = std::numeric_limits<S>::infinity();
+  for (int k = 0; k < p.T; k++)
+    for (int i = 0; i < p.N; i++) {
+      const Quad<S> q = QuadraticizePlayer(p, i, double(k) * p.dt, op.xs[k], op.us[k], false, (const ALState<S>*)nullptr);
+      lo = std::min(lo, MinEigenvalueSymmetric(q.Q));
+      for (size_t pi = 0; pi < q.R.size(); pi++)
+        if (q.has[pi]) lo = std::min(lo, MinEigenvalueSymmetric(q.R[pi]));
+    }
+  if (worst) *worst = lo;
+  return !(lo < S(-1e-4f));
+}
+
 }  // namespace oracle

@@ -609,6 +609,36 @@ void oracle_nash(void* h, int dtype, int batch, const void* x0, const void* xs, 
            is_nash, margin, threads);
 }
 
+
+// CheckSufficientLocalNashEquilibrium per instance: ok [B], worst eigenvalue [B] (double).
+void oracle_sufficient_nash(void* h, int dtype, int batch, const void* xs, const void* us, int32_t* ok, double* worst) {
+  const auto* op = (OracleProblem*)h;
+  for (int b = 0; b < batch; b++) {
+    if (dtype == ILQG_F32) {
+      const auto& p = *op->pf;
+      Trajectory<float> tr;
+      UnpackTraj(p, p.T, (const float*)xs + size_t(b) * p.T * p.n, (const float*)us + size_t(b) * p.T * p.m, &tr);
+      float w;
+      ok[b] = CheckSufficientLocalNash(p, tr, &w) ? 1 : 0;
+      worst[b] = w;
+    } else {
+      const auto& p = *op->pd;
+      Trajectory<double> tr;
+      UnpackTraj(p, p.T, (const double*)xs + size_t(b) * p.T * p.n, (const double*)us + size_t(b) * p.T * p.m, &tr);
+      double w;
+      ok[b] = CheckSufficientLocalNash(p, tr, &w) ? 1 : 0;
+      worst[b] = w;
+    }
+  }
+}
+// Smallest eigenvalue of a symmetric n x n matrix (column-major doubles) — exposed so the tests can pin the Jacobi
+// routine against numpy.linalg.eigvalsh.
+double oracle_min_eigenvalue(int n, const double* a) {
+  Mat<double> m(n, n);
+  for (int i = 0; i < n * n; i++) m.d[i] = a[i];
+  return MinEigenvalueSymmetric(m);
+}
+
 // xdot = f(x, u) and one Integrate step (double I/O regardless of dtype, for the
 // finite-difference tests that restate test/test_linearization.cpp).
 void oracle_dynamics(void* h, int dtype, const double* x, const double* u, double* xdot, double* xnext, int euler) {

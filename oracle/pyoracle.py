@@ -30,6 +30,7 @@ def lib():
         _LIB = C.CDLL(build())
         _LIB.oracle_problem_create.restype = C.c_void_p
         _LIB.oracle_player_value.restype = C.c_double
+        _LIB.oracle_min_eigenvalue.restype = C.c_double
     return _LIB
 
 
@@ -262,6 +263,17 @@ class OracleProblem:
         return ok, margin
 
 
+    def check_sufficient_nash(self, dtype, xs, us):
+        """CheckSufficientLocalNashEquilibrium per instance -> (ok [B] int32, smallest eigenvalue met [B])."""
+        dt = _np(dtype)
+        xs, us = np.ascontiguousarray(xs, dtype=dt), np.ascontiguousarray(us, dtype=dt)
+        B = xs.shape[0]
+        ok = np.zeros(B, np.int32)
+        worst = np.zeros(B, np.float64)
+        lib().oracle_sufficient_nash(self.h, dtype, B, _p(xs), _p(us), _p(ok), _p(worst))
+        return ok, worst
+
+
     def dynamics(self, dtype, x, u, euler=False):
         x = np.ascontiguousarray(x, np.float64)
         u = np.ascontiguousarray(u, np.float64)
@@ -291,3 +303,8 @@ def segment_closest_point(p1, p2, q):
     lib().oracle_segment_closest_point(a.ctypes.data_as(C.POINTER(C.c_float)), C.c_double(q[0]), C.c_double(q[1]),
                                        _p(out))
     return dict(point=out[0:2], ssd=out[2], is_endpoint=bool(out[3]), side=bool(out[4]))
+
+
+def min_eigenvalue(a):
+    a = np.asfortranarray(np.asarray(a, np.float64))
+    return lib().oracle_min_eigenvalue(a.shape[0], a.ctypes.data_as(C.c_void_p))

@@ -418,7 +418,8 @@ int main(int argc, char** argv) {
     oc << std::setprecision(9) << "costs";
     for (float c : ComputeStrategyCosts(*problem)) oc << " " << c;
     oc << "\nnash_small " << (NumericalCheckLocalNashEquilibrium(*problem, 0.0f) ? 1 : 0) << "\nnash_large "
-       << (NumericalCheckLocalNashEquilibrium(*problem, 0.5f) ? 1 : 0) << "\n";
+       << (NumericalCheckLocalNashEquilibrium(*problem, 0.5f) ? 1 : 0) << "\nsufficient "
+       << (CheckSufficientLocalNashEquilibrium(*problem) ? 1 : 0) << "\n";
   }
 
   // 5. the LQ seam on its own

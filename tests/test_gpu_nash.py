@@ -107,3 +107,21 @@ def test_strategy_costs_respect_final_time_costs_fp64(hip, oracle, open_loop):
     plain = examples.two_player_unicycle_4d_scene()
     base = oracle.OracleProblem(plain).strategy_costs(abi.F64, x0, r["xs"], r["us"], r["P"], r["alpha"], open_loop=open_loop)
     assert np.all(ref > base)  # the gated terms did contribute
+
+
+@pytest.mark.parametrize("cfg", ["modified_three_player_intersection", "three_player_intersection",
+                                 "three_player_collision_avoidance_reachability", "two_player_reachability", "skeleton",
+                                 "roundabout_merging"])
+@pytest.mark.parametrize("dtype", [abi.F64, abi.F32])
+def test_check_sufficient_nash_matches_oracle(hip, oracle, cfg, dtype):
+    """CheckSufficientLocalNashEquilibrium: the device decides positive semidefiniteness (to 1e-4) of every Q_i, R_ij
+    by a shifted Cholesky factorisation, the oracle computes the smallest eigenvalue; same verdict wherever that
+    eigenvalue is not within 1e-6 (fp32: 1e-5) of the -1e-4 margin.  Reachability players' signed-distance costs
+    have indefinite Hessians, the intersection's costs are convex."""
+    B = 6
+    spec, op, x0, r = _solved(oracle, cfg, B, 1)
+    ok_ref, worst = op.check_sufficient_nash(dtype, r["xs"], r["us"])
+    ok = hip.Problem(spec, dtype).check_sufficient_nash(r["xs"], r["us"])
+    decided = np.abs(worst + 1e-4) > (1e-6 if dtype == abi.F64 else 1e-5)
+    assert decided.sum() >= B // 2
+    assert np.array_equal(_np(ok)[decided], ok_ref[decided]), (_np(ok), ok_ref, worst)

@@ -323,6 +323,8 @@ def test_cpp_two_player_unicycle_solve_matches_oracle(demo_out, oracle):
     ok_large, margin = op.check_local_nash(abi.F64, got["x0"][None, :], *sol, 0.5)
     assert rows["nash_small"] == [1.0]
     assert abs(margin[0]) > 1e-3 and rows["nash_large"] == [float(ok_large[0])]
+    psd, worst = op.check_sufficient_nash(abi.F64, sol[0], sol[1])
+    assert abs(worst[0] + 1e-4) > 1e-6 and rows["sufficient"] == [float(psd[0])]
 
 
 @pytest.mark.gpu

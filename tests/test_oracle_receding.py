@@ -167,3 +167,15 @@ def test_strategy_costs_of_an_open_loop_plan_equal_the_total_costs_of_its_rollou
     assert np.all(ok == 1) and np.all(margin == 0.0)
     ok, margin = op.check_local_nash(abi.F64, x0, xs, us, zP, za, 0.05)
     assert np.all(ok == 0) and np.all(margin < 0)  # random controls are no equilibrium
+
+
+def test_jacobi_min_eigenvalue_matches_numpy(oracle):
+    """The oracle's eigenvalue routine (behind CheckSufficientLocalNashEquilibrium) against numpy.linalg.eigvalsh."""
+    rng = np.random.default_rng(5)
+    for n in (1, 2, 4, 6, 14, 24):
+        for _ in range(3):
+            a = rng.standard_normal((n, n))
+            a = a + a.T
+            assert abs(oracle.min_eigenvalue(a) - np.linalg.eigvalsh(a)[0]) < 1e-10 * max(1.0, np.abs(a).max())
+    g = rng.standard_normal((8, 3))
+    assert abs(oracle.min_eigenvalue(g @ g.T)) < 1e-12  # rank-deficient PSD: smallest eigenvalue 0
