@@ -155,8 +155,8 @@ __global__ void linquad_kernel(DevProblem p, QuadBatchArgs<T> g) {
   a.r = g.r ? g.r + b * Tn * p.pairs.rsz : nullptr;
   a.merit_part = g.merit_part ? g.merit_part + b * Tn * N * 2 : nullptr;
   a.cost_part = g.cost_part ? g.cost_part + b * Tn * N : nullptr;
-  for (int k = blockIdx.x * kStepsPerBlock; k < (blockIdx.x + 1) * kStepsPerBlock && k < p.T; k++)
-    linquad_step<T>(p, tb, a, k, sm, threadIdx.x);
+  const int k0 = int(blockIdx.x) * kStepsPerBlock;
+  for (int k = k0; k < k0 + kStepsPerBlock && k < p.T; k++) linquad_step<T>(p, tb, a, k, sm, threadIdx.x);
 }
 
 template <typename T>
@@ -299,7 +299,7 @@ bool build_pairs(const ilqg_pair* pairs, int npairs, const int* udim, int N, Pai
 // Supported (n, N, m_i) instantiations.  n=14/16/15/24: BASELINE configs 2-5;
 // (4,2,2): config 1 (TwoPlayerUnicycle4D); (2,2,1): test_lq_solver's point mass;
 // (6,3,2): synthetic parity cases.
-#define ILQG_FOR_DIMS(X) X(14, 3, 2) X(16, 3, 2) X(15, 3, 2) X(24, 4, 2) X(18, 3, 2) X(12, 2, 2) X(10, 2, 2) X(4, 2, 2) X(2, 2, 1) X(6, 3, 2) X(2, 1, 2)
+#define ILQG_FOR_DIMS(X) X(14, 3, 2) X(16, 3, 2) X(15, 3, 2) X(24, 4, 2) X(18, 3, 2) X(12, 2, 2) X(10, 2, 2) X(4, 2, 2) X(3, 1, 1) X(2, 2, 1) X(6, 3, 2) X(2, 1, 2)
 
 template <typename T, int NX, int NP, int MU>
 ilqg_status launch_lq(const ilqg_dims* d, const PairTable& pt, const void* A, const void* Bm, const void* Q,
@@ -632,7 +632,8 @@ ilqg_status ilqg_problem_create(const ilqg_problem_desc* desc, ilqg_problem** ou
     const ilqg_subsystem& sub = desc->subsystems[i];
     const int want_x = (sub.kind == ILQG_DYN_UNICYCLE_4D || sub.kind == ILQG_DYN_UNICYCLE_4D_DISTURBED) ? 4
                        : sub.kind == ILQG_DYN_CAR_5D ? 5 : sub.kind == ILQG_DYN_CAR_6D ? 6
-                       : sub.kind == ILQG_DYN_PLANAR_DISTURBANCE ? 0 : -1;
+                       : sub.kind == ILQG_DYN_PLANAR_DISTURBANCE ? 0 : sub.kind == ILQG_DYN_DUBINS_CAR ? 3 : -1;
+    const int want_u = sub.kind == ILQG_DYN_DUBINS_CAR ? 1 : 2;
     // TwoPlayerUnicycle4D is exactly the pair (disturbed unicycle, disturbance) and nothing else
     const bool pair_ok = (sub.kind != ILQG_DYN_UNICYCLE_4D_DISTURBED && sub.kind != ILQG_DYN_PLANAR_DISTURBANCE) ||
                          (desc->num_players == 2 && desc->subsystems[0].kind == ILQG_DYN_UNICYCLE_4D_DISTURBED &&
@@ -641,7 +642,7 @@ ilqg_status ilqg_problem_create(const ilqg_problem_desc* desc, ilqg_problem** ou
       delete p;
       return fail(ILQG_ERR_UNSUPPORTED, "the two-player unicycle kinds only occur as the pair (4, 5)");
     }
-    if (want_x < 0 || sub.xdim != want_x || sub.udim != 2) {
+    if (want_x < 0 || sub.xdim != want_x || sub.udim != want_u) {
       delete p;
       return fail(ILQG_ERR_UNSUPPORTED, "unknown subsystem kind / dimension");
     }
@@ -1066,7 +1067,7 @@ ilqg_status ilqg_receding_horizon_shift_batch(const ilqg_problem* p, int32_t bat
     g.x = (const TY_*)x0; g.t = t0; g.planner_runtime = planner_runtime;                                           \
     g.xs = (TY_*)xs; g.us = (TY_*)us; g.P = (TY_*)P; g.alpha = (TY_*)alpha; g.x0_next = (TY_*)x0_next;             \
     g.first_step = first_step;                                                                                     \
-    hipLaunchKernelGGL(receding_sync_kernel<TY_>, dim3(batch), dim3(64), (d.n + d.m) * sizeof(TY_),                \
+    hipLaunchKernelGGL(receding_sync_kernel<TY_>, dim3(batch), dim3(64), (d.n + d.m + 2) * sizeof(TY_),                \
                        (hipStream_t)stream, d, g);                                                                 \
     HIP_TRY(hipGetLastError());                                                                                  \
     return ILQG_OK;                                                                                              \
@@ -1193,7 +1194,7 @@ ilqg_status ilqg_plan_integrate_batch(const ilqg_problem* p, int32_t batch, int3
     g.plan = PlanBuffers<TY_>{(TY_*)plan_xs, (TY_*)plan_us, (TY_*)plan_P, (TY_*)plan_alpha, (int*)plan_len,       \
                               (double*)plan_t0, 0.0, plan_rows};                                                   \
     g.t_from = t_from; g.t_to = t_to; g.must_contain = must_contain; g.x = (TY_*)x; g.active = active;             \
-    hipLaunchKernelGGL(plan_integrate_kernel<TY_>, dim3(batch), dim3(64), (d.n + d.m) * sizeof(TY_),               \
+    hipLaunchKernelGGL(plan_integrate_kernel<TY_>, dim3(batch), dim3(64), (d.n + d.m + 2) * sizeof(TY_),               \
                        (hipStream_t)stream, d, g);                                                                 \
     HIP_TRY(hipGetLastError());                                                                                  \
     return ILQG_OK;                                                                                              \
@@ -1224,7 +1225,7 @@ ilqg_status ilqg_receding_horizon_sync_batch(const ilqg_problem* p, int32_t batc
     g.x = (const TY_*)x; g.t = t; g.planner_runtime = planner_runtime;                                             \
     g.xs = (TY_*)xs; g.us = (TY_*)us; g.P = (TY_*)P; g.alpha = (TY_*)alpha; g.x0_next = (TY_*)x0_next;             \
     g.solve_t0 = solve_t0; g.first_step = first_step; g.active = active;                                           \
-    hipLaunchKernelGGL(receding_sync_kernel<TY_>, dim3(batch), dim3(64), (d.n + d.m) * sizeof(TY_),                \
+    hipLaunchKernelGGL(receding_sync_kernel<TY_>, dim3(batch), dim3(64), (d.n + d.m + 2) * sizeof(TY_),                \
                        (hipStream_t)stream, d, g);                                                                 \
     HIP_TRY(hipGetLastError());                                                                                  \
     return ILQG_OK;                                                                                              \

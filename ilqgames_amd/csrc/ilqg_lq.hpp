@@ -708,7 +708,6 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
   };
   // 0/1 multipliers instead of selects (all masked quantities are finite)
   const T mCols = (j < NX) ? T(1) : T(0);      // a proper state column
-  const T mOwn = (j / MU == w) ? T(1) : T(0);  // one of this player's control columns
   const T mVecCol = (j == (SPARE ? JB : w)) ? T(1) : T(0);
 
   // this player's offsets in the R / r rows (wave-uniform selects on a register table)

@@ -40,7 +40,12 @@ __device__ __forceinline__ bool is_unicycle(int kind) {
 
 template <typename T>
 __device__ __forceinline__ void sub_eval(int kind, T L, const T* x, T u0, T u1, T* xd, T d0 = T(0), T d1 = T(0)) {
-  if (is_unicycle(kind) || kind == ILQG_DYN_PLANAR_DISTURBANCE) {
+  if (kind == ILQG_DYN_DUBINS_CAR) {  // single_player_dubins_car.h:94-103: constant speed L, u = omega
+    xd[0] = L * t_cos(x[2]);
+    xd[1] = L * t_sin(x[2]);
+    xd[2] = u0;
+    xd[3] = xd[4] = xd[5] = T(0);
+  } else if (is_unicycle(kind) || kind == ILQG_DYN_PLANAR_DISTURBANCE) {
     xd[0] = x[3] * t_cos(x[2]) + d0;
     xd[1] = x[3] * t_sin(x[2]) + d1;
     xd[2] = u0;
@@ -128,7 +133,8 @@ __device__ __forceinline__ void sub_integrate_lanes(int kind, T L, double interv
                                                     int base, T d0 = T(0), T d1 = T(0)) {
   const T h = T(interval / 2.0);
   const T six = T(6.0), rsix = T(1.0) / T(6.0), rL = T(1.0) / L;
-  const bool car = DIST ? false : kind != ILQG_DYN_UNICYCLE_4D;  // DIST problems hold unicycle rows only
+  const bool dubins = !DIST && kind == ILQG_DYN_DUBINS_CAR;  // the unicycle's path with a constant speed L
+  const bool car = DIST ? false : (kind != ILQG_DYN_UNICYCLE_4D && !dubins);  // DIST problems hold unicycle rows only
   const int vi = car ? 4 : 3;
   // ---- 1. upper components, all stages ----
   T up[6];  // working copy; lower components are left untouched here
@@ -139,7 +145,8 @@ __device__ __forceinline__ void sub_integrate_lanes(int kind, T L, double interv
   // per-lane index by the compiler, i.e. scratch stores and a dependent scratch load in the serial loop.
   T v_s[8];
   T my_ang = T(0), my_v = T(0);
-  auto pick = [&](int idx, T ang, T v) {
+  auto pick = [&](int idx, T ang, T v_state) {
+    const T v = dubins ? L : v_state;
     v_s[idx] = v;
     my_ang = (q == idx) ? ang : my_ang;
     my_v = (q == idx) ? v : my_v;
@@ -149,7 +156,7 @@ __device__ __forceinline__ void sub_integrate_lanes(int kind, T L, double interv
     for (int e = 0; e < 6; e++) xd[e] = T(0);
     if (!car) {
       xd[2] = u0;
-      xd[3] = u1;
+      xd[3] = dubins ? T(0) : u1;
     } else {
       xd[3] = u0;
       if (kind == ILQG_DYN_CAR_5D) {
@@ -247,6 +254,13 @@ __device__ __forceinline__ void sub_linearize_trig(int kind, T L, double dt, con
     B[-3 + ld * 1] = T(dt);
     return;
   }
+  if (kind == ILQG_DYN_DUBINS_CAR) {  // single_player_dubins_car.h:105-117
+    const T ctd = T(double(cth) * dt), std_ = T(double(sth) * dt);
+    A[0 + ld * 2] += -L * std_;
+    A[1 + ld * 2] += L * ctd;
+    B[2 + ld * 0] = T(dt);
+    return;
+  }
   const int v = is_unicycle(kind) ? 3 : 4;
   const T ct = T(double(cth) * dt);
   const T st = T(double(sth) * dt);
@@ -276,7 +290,8 @@ template <typename T>
 __device__ __forceinline__ void sub_linearize(int kind, T L, double dt, const T* x, T* A, T* B, int ld) {
   T sth, cth, sphi = T(0), cphi = T(1);
   t_sincos(x[2], &sth, &cth);
-  if (!is_unicycle(kind) && kind != ILQG_DYN_PLANAR_DISTURBANCE) t_sincos(x[3], &sphi, &cphi);
+  if (!is_unicycle(kind) && kind != ILQG_DYN_PLANAR_DISTURBANCE && kind != ILQG_DYN_DUBINS_CAR)
+    t_sincos(x[3], &sphi, &cphi);
   sub_linearize_trig<T>(kind, L, dt, x, sth, cth, sphi, cphi, A, B, ld);
 }
 

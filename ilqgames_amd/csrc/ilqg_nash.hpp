@@ -20,7 +20,7 @@ struct StrategyCostArgs {
 
 // LDS elements behind the cost tables: [x | u], [next x | u], term values.
 __host__ __device__ inline size_t strategy_cost_lds_elems(int n, int m, int num_terms) {
-  return size_t(2 * (n + m) + (num_terms > 0 ? num_terms : 1) + 4);
+  return size_t(2 * (n + m) + (num_terms > 0 ? num_terms : 1) + 4 + 2);  // +2: a one-control model's unused second input
 }
 
 template <typename T>

@@ -10,7 +10,8 @@ import math
 import numpy as np
 
 from . import abi
-from .abi import (DYN_CAR_5D, DYN_CAR_6D, DYN_PLANAR_DISTURBANCE, DYN_UNICYCLE_4D, DYN_UNICYCLE_4D_DISTURBED,
+from .abi import (DYN_CAR_5D, DYN_CAR_6D, DYN_DUBINS_CAR, DYN_PLANAR_DISTURBANCE, DYN_UNICYCLE_4D,
+                  DYN_UNICYCLE_4D_DISTURBED,
                   ProblemSpec, SolverParams)
 
 
@@ -377,6 +378,29 @@ def two_player_collision(T=100, dt=0.1):
     return s
 
 
+def one_player_reachability(T=100, dt=0.1, px0=1.75, py0=1.75, theta0=0.0):
+    """OnePlayerReachabilityExample — a single Dubins car (n=3, one control) avoiding a disc of radius 2 around the
+    origin: max-over-time signed distance to the disc's rim, a control cost and box constraints on the turn rate
+    (augmented Lagrangian).  src/one_player_reachability_example.cpp:63-141 (its Polyline2SignedDistanceCost call
+    passes (kAvoid, "Target") into (nominal, oriented_same_as_polyline): nominal 1, oriented true); params
+    exec/one_player_reachability_example/main.cpp:80-82,117-121."""
+    prm = SolverParams.default()
+    prm.max_backtracking_steps = 100
+    prm.initial_alpha_scaling = 0.1
+    prm.convergence_tolerance = 0.01
+    prm.expected_decrease_fraction = 0.1
+    s = ProblemSpec(T, dt, prm)
+    s.add_player(DYN_DUBINS_CAR, 1.0, structure=abi.MAX)
+    s.quadratic(0, 0.1, -1, 0.0, control_of=0)
+    s.single_dimension_constraint(0, 0, 1.0, True, control_of=0)
+    s.single_dimension_constraint(0, 0, -1.0, False, control_of=0)
+    circle = s.add_polyline(draw_circle((0.0, 0.0), 2.0, 10))
+    s.polyline2_signed_distance(0, circle, (0, 1), 1.0, True)
+    s.x0 = [px0, py0, theta0]
+    s.position_dims, s.heading_dims, s.speed_dims = [(0, 1)], [2], []
+    return s
+
+
 def skeleton(T=100, dt=0.1):
     """SkeletonExample — the reference's template problem: two Car5D (n=10) crossing paths, lane-centre, speed,
     control and proximity costs.  src/skeleton_example.cpp:60-185; params exec/skeleton_example/main.cpp:73-80,113-121."""
@@ -514,11 +538,14 @@ def jittered_x0(spec, batch, seed=0):
     x0 = np.tile(np.asarray(spec.x0, dtype=np.float64), (batch, 1))
     for b in range(batch):
         rng = np.random.default_rng(seed + b)
-        for (xi, yi), hi, vi in zip(spec.position_dims, spec.heading_dims, spec.speed_dims):
+        speeds = list(spec.speed_dims) + [None] * (len(spec.position_dims) - len(spec.speed_dims))
+        for (xi, yi), hi, vi in zip(spec.position_dims, spec.heading_dims, speeds):
             x0[b, xi] += rng.uniform(-1, 1)
             x0[b, yi] += rng.uniform(-1, 1)
             x0[b, hi] += rng.uniform(-0.1, 0.1)
-            x0[b, vi] += rng.uniform(-0.5, 0.5)
+            dv = rng.uniform(-0.5, 0.5)  # drawn even for a model without a speed state: same stream per instance
+            if vi is not None:
+                x0[b, vi] += dv
     return x0
 
 
@@ -532,6 +559,7 @@ CONFIGS = {
     "two_player_reachability": two_player_reachability,
     "two_player_collision_avoidance_reachability": two_player_collision_avoidance_reachability,
     "skeleton": skeleton,
+    "one_player_reachability": one_player_reachability,
     "two_player_collision": two_player_collision,
     "three_player_overtaking": three_player_overtaking,
     "three_player_intersection_reachability": three_player_intersection_reachability,

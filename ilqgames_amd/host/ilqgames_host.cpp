@@ -31,6 +31,12 @@ const Dimension TwoPlayerUnicycle4D::kAIdx = 1;
 const Dimension TwoPlayerUnicycle4D::kNumU2Dims = 2;
 const Dimension TwoPlayerUnicycle4D::kDxIdx = 0;
 const Dimension TwoPlayerUnicycle4D::kDyIdx = 1;
+const Dimension SinglePlayerDubinsCar::kNumXDims = 3;
+const Dimension SinglePlayerDubinsCar::kPxIdx = 0;
+const Dimension SinglePlayerDubinsCar::kPyIdx = 1;
+const Dimension SinglePlayerDubinsCar::kThetaIdx = 2;
+const Dimension SinglePlayerDubinsCar::kNumUDims = 1;
+const Dimension SinglePlayerDubinsCar::kOmegaIdx = 0;
 const Dimension SinglePlayerUnicycle4D::kNumXDims = 4;
 const Dimension SinglePlayerUnicycle4D::kPxIdx = 0;
 const Dimension SinglePlayerUnicycle4D::kPyIdx = 1;

@@ -119,7 +119,9 @@ typedef enum {
    * (xdim 4, udim 2); player 1's row is a planar disturbance u = (dx, dy) added to the position
    * rates of the row before it (xdim 0, udim 2).  The two kinds only occur as this pair. */
   ILQG_DYN_UNICYCLE_4D_DISTURBED = 4,
-  ILQG_DYN_PLANAR_DISTURBANCE = 5
+  ILQG_DYN_PLANAR_DISTURBANCE = 5,
+  ILQG_DYN_DUBINS_CAR = 6 /* include/ilqgames/dynamics/single_player_dubins_car.h:57-120: x = (px, py, theta),
+                             u = (omega), constant speed param0; xdim 3, udim 1 */
 } ilqg_dyn_kind;
 
 /* One block of a ConcatenatedDynamicalSystem
@@ -129,7 +131,7 @@ typedef struct {
   int32_t kind; /* ilqg_dyn_kind */
   int32_t xdim;
   int32_t udim;
-  float param0; /* inter-axle distance for the car models */
+  float param0; /* inter-axle distance for the car models; the speed of the Dubins car */
 } ilqg_subsystem;
 
 typedef enum {

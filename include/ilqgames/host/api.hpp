@@ -431,6 +431,19 @@ class SinglePlayerUnicycle4D : public SinglePlayerDynamicalSystem {
   static const Dimension kNumUDims, kOmegaIdx, kAIdx;
 };
 
+// include/ilqgames/dynamics/single_player_dubins_car.h:57-91 — planar car at constant speed, one control (turn rate)
+class SinglePlayerDubinsCar : public SinglePlayerDynamicalSystem {
+ public:
+  SinglePlayerDubinsCar(float v) : SinglePlayerDynamicalSystem(kNumXDims, kNumUDims), v_(v) { CHECK_GT(v_, 0.0); }
+  std::vector<Dimension> PositionDimensions() const override { return {kPxIdx, kPyIdx}; }
+  ilqg_subsystem Describe() const override { return ilqg_subsystem{ILQG_DYN_DUBINS_CAR, xdim_, udim_, v_}; }
+  static const Dimension kNumXDims, kPxIdx, kPyIdx, kThetaIdx;
+  static const Dimension kNumUDims, kOmegaIdx;
+
+ private:
+  const float v_;
+};
+
 // include/ilqgames/dynamics/single_player_car_5d.h:59-98
 class SinglePlayerCar5D : public SinglePlayerDynamicalSystem {
  public:

@@ -461,6 +461,11 @@ void EvaluateSubsystem(const ilqg_subsystem& s, const S* x, const S* u, S* xdot)
       break;
     case ILQG_DYN_PLANAR_DISTURBANCE:  // no state of its own
       break;
+    case ILQG_DYN_DUBINS_CAR:  // single_player_dubins_car.h:94-103
+      xdot[0] = L * std::cos(x[2]);
+      xdot[1] = L * std::sin(x[2]);
+      xdot[2] = u[0];
+      break;
     case ILQG_DYN_CAR_5D:
       xdot[0] = x[4] * std::cos(x[2]);
       xdot[1] = x[4] * std::sin(x[2]);
@@ -539,6 +544,14 @@ void Linearize(const Problem<S>& p, const Vec<S>& x, const Vec<S>& u, Mat<S>* A,
       const int po = p.xoff[i - 1];
       (*B)(po + 0, uo + 0) = S(dt);
       (*B)(po + 1, uo + 1) = S(dt);
+      continue;
+    }
+    if (s.kind == ILQG_DYN_DUBINS_CAR) {  // single_player_dubins_car.h:105-117
+      const S v = S(s.param0);
+      const S ctheta = S(double(std::cos(xs[2])) * dt), stheta = S(double(std::sin(xs[2])) * dt);
+      (*A)(o + 0, o + 2) += -v * stheta;
+      (*A)(o + 1, o + 2) += v * ctheta;
+      (*B)(o + 2, uo + 0) = S(dt);
       continue;
     }
     const bool unicycle = s.kind == ILQG_DYN_UNICYCLE_4D || s.kind == ILQG_DYN_UNICYCLE_4D_DISTURBED;

@@ -34,6 +34,7 @@ EXAMPLES = [
      examples.three_player_intersection_reachability),
     ("ThreePlayerOvertakingExample", "three_player_overtaking_example", examples.three_player_overtaking),
     ("TwoPlayerCollisionExample", "two_player_collision_example", examples.two_player_collision),
+    ("OnePlayerReachabilityExample", "one_player_reachability_example", examples.one_player_reachability),
 ]
 
 
