@@ -115,8 +115,12 @@ __global__ void rollout_kernel(DevProblem p, RolloutBatchArgs<T> g) {
   RolloutArgs<T> a{g.x0 + b * n,          g.xs_ref + b * Tn * n, g.us_ref + b * Tn * m, g.P + b * Tn * m * n,
                    g.alpha + b * Tn * m,  g.alpha_scale ? g.alpha_scale[b] : T(1),
                    g.xs + b * Tn * n,     g.us + b * Tn * m};
+  bool dubins = false;
+  for (int i = 0; i < p.N; i++) dubins = dubins || p.sub_kind[i] == ILQG_DYN_DUBINS_CAR;
   if (p.sub_kind[0] == ILQG_DYN_UNICYCLE_4D_DISTURBED)
     rollout_instance<T, 0, 0, true>(p, a, sm, threadIdx.x);
+  else if (dubins)
+    rollout_instance<T, 0, 0, false, true>(p, a, sm, threadIdx.x);
   else
     rollout_instance<T>(p, a, sm, threadIdx.x);
 }

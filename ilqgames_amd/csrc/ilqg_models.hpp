@@ -128,12 +128,13 @@ __device__ __forceinline__ float div_by(float x, float c, float rc) {
 
 // DIST: the problem may contain the disturbed unicycle; (d0, d1) are then the other player's controls (zero
 // for every other kind) and enter the position rates.  Compiled out otherwise.
-template <typename T, bool DIST = false>
+// DUB: the problem may contain the one-control Dubins car (constant speed L); compiled out otherwise, like DIST.
+template <typename T, bool DIST = false, bool DUB = false>
 __device__ __forceinline__ void sub_integrate_lanes(int kind, T L, double interval, T* x, T u0, T u1, int q,
                                                     int base, T d0 = T(0), T d1 = T(0)) {
   const T h = T(interval / 2.0);
   const T six = T(6.0), rsix = T(1.0) / T(6.0), rL = T(1.0) / L;
-  const bool dubins = !DIST && kind == ILQG_DYN_DUBINS_CAR;  // the unicycle's path with a constant speed L
+  const bool dubins = DUB && kind == ILQG_DYN_DUBINS_CAR;  // the unicycle's path with a constant speed L
   const bool car = DIST ? false : (kind != ILQG_DYN_UNICYCLE_4D && !dubins);  // DIST problems hold unicycle rows only
   const int vi = car ? 4 : 3;
   // ---- 1. upper components, all stages ----

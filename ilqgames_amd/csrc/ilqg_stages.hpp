@@ -49,7 +49,9 @@ __device__ __forceinline__ int progress_observe(int* flag) {
 // xs / us is in memory, so other waves of the workgroup can consume the trajectory while it is
 // still being integrated.
 // DIST: the dynamics may be TwoPlayerUnicycle4D (a disturbed unicycle row + a state-less disturbance row).
-template <typename T, int CN = 0, int CM = 0, bool DIST = false>
+// DUB: it may contain SinglePlayerDubinsCar rows.  Both are compile-time so that the common car / unicycle games
+// keep the integrator they had.
+template <typename T, int CN = 0, int CM = 0, bool DIST = false, bool DUB = false>
 __device__ __forceinline__ void rollout_instance(const DevProblem& p, const RolloutArgs<T>& a, T* sm, int t,
                                                  int* ready = nullptr, long long* phacc = nullptr) {
   const int n = CN > 0 ? CN : p.n, m = CM > 0 ? CM : p.m, N = p.N, Tn = p.T;
@@ -146,7 +148,7 @@ __device__ __forceinline__ void rollout_instance(const DevProblem& p, const Roll
         const T d0 = dist ? su[uo + 2] : T(0), d1 = dist ? su[uo + 3] : T(0);
         sub_integrate_lanes<T, true>(kind, Lp, p.dt, xj, u0, u1, q, t & ~7, d0, d1);
       } else {
-        sub_integrate_lanes<T>(kind, Lp, p.dt, xj, u0, u1, q, t & ~7);
+        sub_integrate_lanes<T, false, DUB>(kind, Lp, p.dt, xj, u0, u1, q, t & ~7);
       }
     }
     ILQG_RPH(2);
