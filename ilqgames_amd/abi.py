@@ -22,6 +22,7 @@ DYN_DUBINS_CAR = 6  # (px, py, theta), u = (omega), param0 = speed
  COST_PROXIMITY, COST_SIGNED_DISTANCE, COST_EXTREME_VALUE, CONSTRAINT_PROXIMITY,
  CONSTRAINT_SINGLE_DIMENSION) = range(1, 10)
 COST_POLYLINE2_SIGNED_DISTANCE = 10
+COST_QUADRATIC_DIFFERENCE = 11
 # ilqg_cost_role
 ROLE_STATE_COST, ROLE_CONTROL_COST, ROLE_STATE_CONSTRAINT, ROLE_CONTROL_CONSTRAINT, ROLE_CHILD = range(5)
 FLAG_ORIENTED, FLAG_IS_MIN = 1, 2
@@ -182,6 +183,9 @@ class ProblemSpec:
     def polyline2_signed_distance(self, player, polyline, xy, nominal=0.0, oriented_same_as_polyline=True):
         return self._term(COST_POLYLINE2_SIGNED_DISTANCE, ROLE_STATE_COST, player, -1, xy, 1.0, nominal,
                           FLAG_ORIENTED if oriented_same_as_polyline else 0, polyline)
+
+    def quadratic_difference(self, player, weight, dims1, dims2):
+        return self._term(COST_QUADRATIC_DIFFERENCE, ROLE_STATE_COST, player, -1, tuple(dims1) + tuple(dims2), weight)
 
     def extreme_value(self, player, children, is_min):
         """children: list of callables(role) -> term index, created contiguously as CHILD terms."""

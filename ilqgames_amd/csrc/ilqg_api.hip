@@ -303,7 +303,7 @@ bool build_pairs(const ilqg_pair* pairs, int npairs, const int* udim, int N, Pai
 // Supported (n, N, m_i) instantiations.  n=14/16/15/24: BASELINE configs 2-5;
 // (4,2,2): config 1 (TwoPlayerUnicycle4D); (2,2,1): test_lq_solver's point mass;
 // (6,3,2): synthetic parity cases.
-#define ILQG_FOR_DIMS(X) X(14, 3, 2) X(16, 3, 2) X(15, 3, 2) X(24, 4, 2) X(18, 3, 2) X(12, 2, 2) X(10, 2, 2) X(4, 2, 2) X(3, 1, 1) X(2, 2, 1) X(6, 3, 2) X(2, 1, 2)
+#define ILQG_FOR_DIMS(X) X(14, 3, 2) X(16, 3, 2) X(15, 3, 2) X(24, 4, 2) X(18, 3, 2) X(12, 2, 2) X(10, 2, 2) X(4, 2, 2) X(6, 2, 1) X(3, 1, 1) X(2, 2, 1) X(6, 3, 2) X(2, 1, 2)
 
 template <typename T, int NX, int NP, int MU>
 ilqg_status launch_lq(const ilqg_dims* d, const PairTable& pt, const void* A, const void* Bm, const void* Q,

@@ -564,6 +564,10 @@ __device__ __forceinline__ T term_evaluate_leaf(const QuadTables<T>& tb, int ti,
       const T cost = val - t_hypot(dx, dy);
       return oriented ? cost : -cost;
     }
+    case ILQG_COST_QUADRATIC_DIFFERENCE: {  // src/quadratic_difference_cost.cpp:51-59
+      const T ex = v[c.idx[0]] - v[c.idx[2]], ey = v[c.idx[1]] - v[c.idx[3]];
+      return T(0.5) * w * (ex * ex + ey * ey);
+    }
     case ILQG_COST_POLYLINE2_SIGNED_DISTANCE: {  // src/polyline2_signed_distance_cost.cpp:52-65
       const Closest<T> cl = polyline_closest<T>(tb, c.polyline, v[c.idx[0]], v[c.idx[1]]);
       const T ssd = oriented ? cl.ssd : -cl.ssd;
@@ -712,6 +716,13 @@ __device__ __forceinline__ void term_compute_leaf(const QuadTables<T>& tb, const
       }
       o->pattern = PAT_PAIR2;
       o->gx = dx; o->gy = dy; o->hxx = ddx; o->hyy = ddy; o->hxy = dxdy;
+      return;
+    }
+    case ILQG_COST_QUADRATIC_DIFFERENCE: {  // src/quadratic_difference_cost.cpp:51-91 (two dimension pairs)
+      const T ex = v[c.idx[0]] - v[c.idx[2]], ey = v[c.idx[1]] - v[c.idx[3]];
+      o->value = T(0.5) * w * (ex * ex + ey * ey);
+      o->pattern = PAT_PAIR4;  // +w on the diagonals, -w between partners; the cross terms get an exact +-0
+      o->gx = w * ex; o->gy = w * ey; o->hxx = w; o->hyy = w; o->hxy = T(0);
       return;
     }
     case ILQG_COST_POLYLINE2_SIGNED_DISTANCE: {  // src/polyline2_signed_distance_cost.cpp:52-126

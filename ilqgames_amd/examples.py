@@ -401,6 +401,29 @@ def one_player_reachability(T=100, dt=0.1, px0=1.75, py0=1.75, theta0=0.0):
     return s
 
 
+def dubins_origin(T=100, dt=0.1):
+    """DubinsOriginExample — two Dubins cars (n=6, one control each): player 2 is attracted to player 1
+    (QuadraticDifferenceCost), player 1 wants player 2 at the origin.  src/dubins_origin_example.cpp:54-128;
+    params exec/dubins_origin_example/main.cpp:73-75,110-114."""
+    prm = SolverParams.default()
+    prm.max_backtracking_steps = 100
+    prm.initial_alpha_scaling = 0.1
+    prm.convergence_tolerance = 0.1
+    prm.expected_decrease_fraction = 0.1
+    s = ProblemSpec(T, dt, prm)
+    for _ in range(2):
+        s.add_player(DYN_DUBINS_CAR, 1.0)
+    s.quadratic_difference(1, 10.0, (0, 1), (3, 4))
+    s.quadratic(0, 100.0, 0, 0.0, control_of=0)
+    s.quadratic(1, 100.0, 0, 0.0, control_of=1)
+    s.quadratic(0, 10.0, 3, 0.0)
+    s.quadratic(0, 10.0, 4, 0.0)
+    f = np.float32
+    s.x0 = [0.0, -10.0, float(f(np.pi - 0.01)), 0.0, 10.0, float(f(1.5 * np.pi))]
+    s.position_dims, s.heading_dims, s.speed_dims = [(0, 1), (3, 4)], [2, 5], []
+    return s
+
+
 def skeleton(T=100, dt=0.1):
     """SkeletonExample — the reference's template problem: two Car5D (n=10) crossing paths, lane-centre, speed,
     control and proximity costs.  src/skeleton_example.cpp:60-185; params exec/skeleton_example/main.cpp:73-80,113-121."""
@@ -559,6 +582,7 @@ CONFIGS = {
     "two_player_reachability": two_player_reachability,
     "two_player_collision_avoidance_reachability": two_player_collision_avoidance_reachability,
     "skeleton": skeleton,
+    "dubins_origin": dubins_origin,
     "one_player_reachability": one_player_reachability,
     "two_player_collision": two_player_collision,
     "three_player_overtaking": three_player_overtaking,

@@ -194,6 +194,11 @@ bool Polyline2SignedDistanceCost::Describe(host::TermDescription* out) const {
   out->polyline = &polyline_;
   return true;
 }
+bool QuadraticDifferenceCost::Describe(host::TermDescription* out) const {
+  if (dims1_.size() != 2) return false;  // other lengths have no device kernel
+  FillTerm(out, ILQG_COST_QUADRATIC_DIFFERENCE, weight_, 0.0f, 0, {dims1_[0], dims1_[1], dims2_[0], dims2_[1]});
+  return true;
+}
 bool FinalTimeCost::Describe(host::TermDescription* out) const {
   if (!cost_->Describe(out) || out->term.kind == ILQG_COST_EXTREME_VALUE) return false;
   // the first step whose time ILQSolver hands to Evaluate / Quadraticize (RelativeTime(kk) = kk * kTimeStep,

@@ -144,8 +144,10 @@ typedef enum {
   ILQG_COST_EXTREME_VALUE = 7,       /* src/extreme_value_cost.cpp:51-85         */
   ILQG_CONSTRAINT_PROXIMITY = 8,     /* src/proximity_constraint.cpp:56-116      */
   ILQG_CONSTRAINT_SINGLE_DIMENSION = 9, /* include/ilqgames/constraint/single_dimension_constraint.h:57-103 */
-  ILQG_COST_POLYLINE2_SIGNED_DISTANCE = 10 /* src/polyline2_signed_distance_cost.cpp:52-126: idx = (xidx, yidx),
+  ILQG_COST_POLYLINE2_SIGNED_DISTANCE = 10, /* src/polyline2_signed_distance_cost.cpp:52-126: idx = (xidx, yidx),
                                               value = nominal, ORIENTED = oriented_same_as_polyline, weight unused */
+  ILQG_COST_QUADRATIC_DIFFERENCE = 11 /* src/quadratic_difference_cost.cpp:51-91 with two dimension pairs:
+                                         idx = (dims1[0], dims1[1], dims2[0], dims2[1]) */
 } ilqg_cost_kind;
 
 /* Where a term sits inside PlayerCost::Quadraticize (src/player_cost.cpp:194-215):

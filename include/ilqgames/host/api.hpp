@@ -259,6 +259,21 @@ class Polyline2SignedDistanceCost : public TimeInvariantCost {
   const bool oriented_same_as_polyline_;
 };
 
+// include/ilqgames/cost/quadratic_difference_cost.h:55-75 — 0.5 w |x[dims1] - x[dims2]|^2; the device carries the
+// two-pair form the reference's examples use (a position against a position).
+class QuadraticDifferenceCost : public TimeInvariantCost {
+ public:
+  QuadraticDifferenceCost(float weight, const std::vector<Dimension>& dims1, const std::vector<Dimension>& dims2,
+                          const std::string& name = "")
+      : TimeInvariantCost(weight, name), dims1_(dims1), dims2_(dims2) {
+    CHECK_EQ(dims1_.size(), dims2_.size());
+  }
+  bool Describe(host::TermDescription* out) const override;
+
+ private:
+  const std::vector<Dimension> dims1_, dims2_;
+};
+
 // include/ilqgames/cost/final_time_cost.h:55-88 — another cost, switched on from `threshold_time` (relative to the
 // start of the window) onwards; zero value and derivatives before.
 class FinalTimeCost : public Cost {

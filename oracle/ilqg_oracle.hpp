@@ -647,6 +647,14 @@ S EvaluateTerm(const Problem<S>& p, int ti, const S* v, int dim) {
       const S cost = val - std::hypot(dx, dy);
       return oriented ? cost : -cost;
     }
+    case ILQG_COST_QUADRATIC_DIFFERENCE: {  // src/quadratic_difference_cost.cpp:51-59
+      S total = 0;
+      for (int ii = 0; ii < 2; ii++) {
+        const S diff = v[c.idx[ii]] - v[c.idx[2 + ii]];
+        total += diff * diff;
+      }
+      return S(0.5) * w * total;
+    }
     case ILQG_COST_POLYLINE2_SIGNED_DISTANCE: {  // src/polyline2_signed_distance_cost.cpp:52-65
       S cx, cy, ssd;
       bool is_vertex, is_endpoint;
@@ -809,6 +817,15 @@ void QuadraticizeTerm(const Problem<S>& p, int ti, double t, const S* v, int dim
       H(x1, y2) -= hxy; H(y2, x1) -= hxy;
       H(x2, y1) -= hxy; H(y1, x2) -= hxy;
       H(x2, y2) += hxy; H(y2, x2) += hxy;
+      return;
+    }
+    case ILQG_COST_QUADRATIC_DIFFERENCE: {  // src/quadratic_difference_cost.cpp:61-91
+      for (int ii = 0; ii < 2; ii++) {
+        const int d1 = c.idx[ii], d2 = c.idx[2 + ii];
+        const S dx = w * (v[d1] - v[d2]);
+        H(d1, d1) += w; H(d2, d2) += w; H(d1, d2) += -w; H(d2, d1) += -w;
+        G[d1] += dx; G[d2] += -dx;
+      }
       return;
     }
     case ILQG_COST_POLYLINE2_SIGNED_DISTANCE: {  // src/polyline2_signed_distance_cost.cpp:67-126

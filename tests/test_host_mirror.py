@@ -35,6 +35,7 @@ EXAMPLES = [
     ("ThreePlayerOvertakingExample", "three_player_overtaking_example", examples.three_player_overtaking),
     ("TwoPlayerCollisionExample", "two_player_collision_example", examples.two_player_collision),
     ("OnePlayerReachabilityExample", "one_player_reachability_example", examples.one_player_reachability),
+    ("DubinsOriginExample", "dubins_origin_example", examples.dubins_origin),
 ]
 
 
