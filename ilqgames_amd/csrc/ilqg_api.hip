@@ -117,7 +117,9 @@ __global__ void rollout_kernel(DevProblem p, RolloutBatchArgs<T> g) {
                    g.xs + b * Tn * n,     g.us + b * Tn * m};
   bool dubins = false;
   for (int i = 0; i < p.N; i++) dubins = dubins || p.sub_kind[i] == ILQG_DYN_DUBINS_CAR;
-  if (p.sub_kind[0] == ILQG_DYN_UNICYCLE_4D_DISTURBED)
+  if (p.sub_kind[0] == ILQG_DYN_AIR_3D_EVADER)
+    rollout_instance<T, 0, 0, false, false, true>(p, a, sm, threadIdx.x);
+  else if (p.sub_kind[0] == ILQG_DYN_UNICYCLE_4D_DISTURBED)
     rollout_instance<T, 0, 0, true>(p, a, sm, threadIdx.x);
   else if (dubins)
     rollout_instance<T, 0, 0, false, true>(p, a, sm, threadIdx.x);
@@ -303,7 +305,7 @@ bool build_pairs(const ilqg_pair* pairs, int npairs, const int* udim, int N, Pai
 // Supported (n, N, m_i) instantiations.  n=14/16/15/24: BASELINE configs 2-5;
 // (4,2,2): config 1 (TwoPlayerUnicycle4D); (2,2,1): test_lq_solver's point mass;
 // (6,3,2): synthetic parity cases.
-#define ILQG_FOR_DIMS(X) X(14, 3, 2) X(16, 3, 2) X(15, 3, 2) X(24, 4, 2) X(18, 3, 2) X(12, 2, 2) X(10, 2, 2) X(4, 2, 2) X(6, 2, 1) X(3, 1, 1) X(2, 2, 1) X(6, 3, 2) X(2, 1, 2)
+#define ILQG_FOR_DIMS(X) X(14, 3, 2) X(16, 3, 2) X(15, 3, 2) X(24, 4, 2) X(18, 3, 2) X(12, 2, 2) X(10, 2, 2) X(4, 2, 2) X(6, 2, 1) X(3, 2, 1) X(3, 1, 1) X(2, 2, 1) X(6, 3, 2) X(2, 1, 2)
 
 template <typename T, int NX, int NP, int MU>
 ilqg_status launch_lq(const ilqg_dims* d, const PairTable& pt, const void* A, const void* Bm, const void* Q,
@@ -636,15 +638,22 @@ ilqg_status ilqg_problem_create(const ilqg_problem_desc* desc, ilqg_problem** ou
     const ilqg_subsystem& sub = desc->subsystems[i];
     const int want_x = (sub.kind == ILQG_DYN_UNICYCLE_4D || sub.kind == ILQG_DYN_UNICYCLE_4D_DISTURBED) ? 4
                        : sub.kind == ILQG_DYN_CAR_5D ? 5 : sub.kind == ILQG_DYN_CAR_6D ? 6
-                       : sub.kind == ILQG_DYN_PLANAR_DISTURBANCE ? 0 : sub.kind == ILQG_DYN_DUBINS_CAR ? 3 : -1;
-    const int want_u = sub.kind == ILQG_DYN_DUBINS_CAR ? 1 : 2;
+                       : sub.kind == ILQG_DYN_PLANAR_DISTURBANCE ? 0 : sub.kind == ILQG_DYN_DUBINS_CAR ? 3
+                       : sub.kind == ILQG_DYN_AIR_3D_EVADER ? 3 : sub.kind == ILQG_DYN_AIR_3D_PURSUER ? 0 : -1;
+    const bool one_control = sub.kind == ILQG_DYN_DUBINS_CAR || sub.kind == ILQG_DYN_AIR_3D_EVADER ||
+                             sub.kind == ILQG_DYN_AIR_3D_PURSUER;
+    const int want_u = one_control ? 1 : 2;
     // TwoPlayerUnicycle4D is exactly the pair (disturbed unicycle, disturbance) and nothing else
-    const bool pair_ok = (sub.kind != ILQG_DYN_UNICYCLE_4D_DISTURBED && sub.kind != ILQG_DYN_PLANAR_DISTURBANCE) ||
+    const bool paired = sub.kind == ILQG_DYN_UNICYCLE_4D_DISTURBED || sub.kind == ILQG_DYN_PLANAR_DISTURBANCE ||
+                        sub.kind == ILQG_DYN_AIR_3D_EVADER || sub.kind == ILQG_DYN_AIR_3D_PURSUER;
+    const bool pair_ok = !paired ||
                          (desc->num_players == 2 && desc->subsystems[0].kind == ILQG_DYN_UNICYCLE_4D_DISTURBED &&
-                          desc->subsystems[1].kind == ILQG_DYN_PLANAR_DISTURBANCE);
+                          desc->subsystems[1].kind == ILQG_DYN_PLANAR_DISTURBANCE) ||
+                         (desc->num_players == 2 && desc->subsystems[0].kind == ILQG_DYN_AIR_3D_EVADER &&
+                          desc->subsystems[1].kind == ILQG_DYN_AIR_3D_PURSUER);
     if (!pair_ok) {
       delete p;
-      return fail(ILQG_ERR_UNSUPPORTED, "the two-player unicycle kinds only occur as the pair (4, 5)");
+      return fail(ILQG_ERR_UNSUPPORTED, "the shared-state kinds only occur as the pairs (4, 5) and (7, 8)");
     }
     if (want_x < 0 || sub.xdim != want_x || sub.udim != want_u) {
       delete p;

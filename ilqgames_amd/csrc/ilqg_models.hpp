@@ -40,7 +40,12 @@ __device__ __forceinline__ bool is_unicycle(int kind) {
 
 template <typename T>
 __device__ __forceinline__ void sub_eval(int kind, T L, const T* x, T u0, T u1, T* xd, T d0 = T(0), T d1 = T(0)) {
-  if (kind == ILQG_DYN_DUBINS_CAR) {  // single_player_dubins_car.h:94-103: constant speed L, u = omega
+  if (kind == ILQG_DYN_AIR_3D_EVADER) {  // air_3d.h:112-125: L = evader speed, d0 = pursuer speed, u1 = its turn rate
+    xd[0] = -L + d0 * t_cos(x[2]) + u0 * x[1];
+    xd[1] = d0 * t_sin(x[2]) - u0 * x[0];
+    xd[2] = u1 - u0;
+    xd[3] = xd[4] = xd[5] = T(0);
+  } else if (kind == ILQG_DYN_DUBINS_CAR) {  // single_player_dubins_car.h:94-103: constant speed L, u = omega
     xd[0] = L * t_cos(x[2]);
     xd[1] = L * t_sin(x[2]);
     xd[2] = u0;
@@ -245,9 +250,25 @@ __device__ __forceinline__ void sub_integrate_lanes(int kind, T L, double interv
 // The trigonometry comes in as arguments: (sth, cth) = sincos(heading), (sphi, cphi) = sincos(steering
 // angle) for the car models — callers evaluate them for all subsystems at once, one sincos latency per
 // angle instead of a cos, a sin, a cos and a tan in sequence; tan(phi) is formed as sphi / cphi.
+// aux0 / aux1: only read by the Air3D rows (the evader's turn rate and the pursuer's speed).
 template <typename T>
 __device__ __forceinline__ void sub_linearize_trig(int kind, T L, double dt, const T* x, T sth, T cth, T sphi, T cphi,
-                                                   T* A, T* B, int ld) {
+                                                   T* A, T* B, int ld, T aux0 = T(0), T aux1 = T(0)) {
+  if (kind == ILQG_DYN_AIR_3D_EVADER) {  // air_3d.h:127-146
+    const T ctd = T(double(cth) * dt), std_ = T(double(sth) * dt);
+    A[0 + ld * 1] += T(double(aux0) * dt);
+    A[0 + ld * 2] -= aux1 * std_;
+    A[1 + ld * 0] -= T(double(aux0) * dt);
+    A[1 + ld * 2] += aux1 * ctd;
+    B[0] = T(double(x[1]) * dt);
+    B[1] = T(double(-x[0]) * dt);
+    B[2] = T(-dt);
+    return;
+  }
+  if (kind == ILQG_DYN_AIR_3D_PURSUER) {  // Bs[1](rtheta, omega2) = dt (:148): last row of the 3-state block before
+    B[-1] = T(dt);
+    return;
+  }
   if (kind == ILQG_DYN_PLANAR_DISTURBANCE) {
     // Bs[1](px, dx) = Bs[1](py, dy) = dt (two_player_unicycle_4d.h:135-136): rows of the 4-state block that
     // ends where this (empty) block begins
@@ -291,8 +312,7 @@ template <typename T>
 __device__ __forceinline__ void sub_linearize(int kind, T L, double dt, const T* x, T* A, T* B, int ld) {
   T sth, cth, sphi = T(0), cphi = T(1);
   t_sincos(x[2], &sth, &cth);
-  if (!is_unicycle(kind) && kind != ILQG_DYN_PLANAR_DISTURBANCE && kind != ILQG_DYN_DUBINS_CAR)
-    t_sincos(x[3], &sphi, &cphi);
+  if (kind == ILQG_DYN_CAR_5D || kind == ILQG_DYN_CAR_6D) t_sincos(x[3], &sphi, &cphi);
   sub_linearize_trig<T>(kind, L, dt, x, sth, cth, sphi, cphi, A, B, ld);
 }
 

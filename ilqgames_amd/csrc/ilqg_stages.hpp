@@ -51,7 +51,9 @@ __device__ __forceinline__ int progress_observe(int* flag) {
 // DIST: the dynamics may be TwoPlayerUnicycle4D (a disturbed unicycle row + a state-less disturbance row).
 // DUB: it may contain SinglePlayerDubinsCar rows.  Both are compile-time so that the common car / unicycle games
 // keep the integrator they had.
-template <typename T, int CN = 0, int CM = 0, bool DIST = false, bool DUB = false>
+// AIR: the dynamics are Air3D — its position rates depend on the position itself, so the stage-parallel integrator
+// does not apply and lane 0 runs the plain RK4.
+template <typename T, int CN = 0, int CM = 0, bool DIST = false, bool DUB = false, bool AIR = false>
 __device__ __forceinline__ void rollout_instance(const DevProblem& p, const RolloutArgs<T>& a, T* sm, int t,
                                                  int* ready = nullptr, long long* phacc = nullptr) {
   const int n = CN > 0 ? CN : p.n, m = CM > 0 ? CM : p.m, N = p.N, Tn = p.T;
@@ -143,7 +145,9 @@ __device__ __forceinline__ void rollout_instance(const DevProblem& p, const Roll
     ILQG_RPH(1);
     if (t < 64 && k + 1 < Tn) {  // whole first wave: the shuffles inside need every group lane live
       const T u0 = integ ? su[uo] : T(0), u1 = integ ? su[uo + 1] : T(0);
-      if constexpr (DIST) {
+      if constexpr (AIR) {
+        if (t == 0) sub_integrate<T>(kind, Lp, p.dt, xj, u0, u1, T(p.sub_param[1]));
+      } else if constexpr (DIST) {
         const bool dist = integ && kind == ILQG_DYN_UNICYCLE_4D_DISTURBED;  // the next player's (dx, dy)
         const T d0 = dist ? su[uo + 2] : T(0), d1 = dist ? su[uo + 3] : T(0);
         sub_integrate_lanes<T, true>(kind, Lp, p.dt, xj, u0, u1, q, t & ~7, d0, d1);
@@ -337,8 +341,14 @@ __device__ __forceinline__ void linquad_compute(const DevProblem& p, const QuadT
     const T sphi = shfl(sn, (t + N) & 63), cphi = shfl(cs, (t + N) & 63);
     if (t < N) {
       const int uo = tb.lc[LC_UOFF + t];
-      sub_linearize_trig<T>(tb.lc[LC_KIND + t], T(__int_as_float(tb.lc[LC_PARAM + t])), p.dt, sx + xo, sn, cs, sphi,
-                            cphi, sA + xo + n * xo, sB + xo + n * uo, n);
+      const int kind = tb.lc[LC_KIND + t];
+      T aux0 = T(0), aux1 = T(0);
+      if (kind == ILQG_DYN_AIR_3D_EVADER) {  // its own turn rate and the pursuer's speed (the next row's parameter)
+        aux0 = sx[n + uo];
+        aux1 = T(__int_as_float(tb.lc[LC_PARAM + t + 1]));
+      }
+      sub_linearize_trig<T>(kind, T(__int_as_float(tb.lc[LC_PARAM + t])), p.dt, sx + xo, sn, cs, sphi, cphi,
+                            sA + xo + n * xo, sB + xo + n * uo, n, aux0, aux1);
     }
   }
   // ---- one lane per cost term: value + derivative pattern (the expensive part, in parallel) ----

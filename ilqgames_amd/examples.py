@@ -424,6 +424,32 @@ def dubins_origin(T=100, dt=0.1):
     return s
 
 
+def air_3d(T=100, dt=0.1, rx0=4.0, ry0=3.0, rtheta0=math.pi / 4.0, ve=1.0, vp=1.0):
+    """Air3DExample — the two-aircraft pursuit-evasion game in relative coordinates (n=3, one turn rate per player):
+    the evader (player 1) maximises over time, the pursuer minimises over time, the signed distance to a disc of
+    radius 5; turn-rate box constraints on both.  src/air_3d_example.cpp:62-137 (its Polyline2SignedDistanceCost
+    calls pass (!kReach, "Target") / (kReach, "Target") into (nominal, oriented_same_as_polyline)); params
+    exec/air_3d_example/main.cpp:76-78,112-116."""
+    prm = SolverParams.default()
+    prm.max_backtracking_steps = 100
+    prm.initial_alpha_scaling = 0.1
+    prm.convergence_tolerance = 0.01
+    prm.expected_decrease_fraction = 0.1
+    s = ProblemSpec(T, dt, prm)
+    s.add_player(abi.DYN_AIR_3D_EVADER, ve, structure=abi.MAX)
+    s.add_player(abi.DYN_AIR_3D_PURSUER, vp, structure=abi.MIN)
+    for pl in range(2):
+        s.quadratic(pl, 0.1, -1, 0.0, control_of=pl)
+        s.single_dimension_constraint(pl, 0, 1.0, True, control_of=pl)
+        s.single_dimension_constraint(pl, 0, -1.0, False, control_of=pl)
+    circle = s.add_polyline(draw_circle((0.0, 0.0), 5.0, 10))
+    s.polyline2_signed_distance(0, circle, (0, 1), 0.0, True)
+    s.polyline2_signed_distance(1, circle, (0, 1), 1.0, True)
+    s.x0 = [rx0, ry0, float(np.float32(rtheta0))]
+    s.position_dims, s.heading_dims, s.speed_dims = [(0, 1)], [2], []
+    return s
+
+
 def skeleton(T=100, dt=0.1):
     """SkeletonExample — the reference's template problem: two Car5D (n=10) crossing paths, lane-centre, speed,
     control and proximity costs.  src/skeleton_example.cpp:60-185; params exec/skeleton_example/main.cpp:73-80,113-121."""
@@ -582,6 +608,7 @@ CONFIGS = {
     "two_player_reachability": two_player_reachability,
     "two_player_collision_avoidance_reachability": two_player_collision_avoidance_reachability,
     "skeleton": skeleton,
+    "air_3d": air_3d,
     "dubins_origin": dubins_origin,
     "one_player_reachability": one_player_reachability,
     "two_player_collision": two_player_collision,

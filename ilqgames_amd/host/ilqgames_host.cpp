@@ -31,6 +31,15 @@ const Dimension TwoPlayerUnicycle4D::kAIdx = 1;
 const Dimension TwoPlayerUnicycle4D::kNumU2Dims = 2;
 const Dimension TwoPlayerUnicycle4D::kDxIdx = 0;
 const Dimension TwoPlayerUnicycle4D::kDyIdx = 1;
+const Dimension Air3D::kNumXDims = 3;
+const Dimension Air3D::kRxIdx = 0;
+const Dimension Air3D::kRyIdx = 1;
+const Dimension Air3D::kRThetaIdx = 2;
+const PlayerIndex Air3D::kNumPlayers = 2;
+const Dimension Air3D::kNumU1Dims = 1;
+const Dimension Air3D::kOmega1Idx = 0;
+const Dimension Air3D::kNumU2Dims = 1;
+const Dimension Air3D::kOmega2Idx = 0;
 const Dimension SinglePlayerDubinsCar::kNumXDims = 3;
 const Dimension SinglePlayerDubinsCar::kPxIdx = 0;
 const Dimension SinglePlayerDubinsCar::kPyIdx = 1;
@@ -334,9 +343,15 @@ bool DescribeDynamics(const MultiPlayerIntegrableSystem& dynamics, ilqg_problem_
     d->subsystems[1] = ilqg_subsystem{ILQG_DYN_PLANAR_DISTURBANCE, 0, 2, 0.0f};
     return true;
   }
+  if (const auto* air = dynamic_cast<const Air3D*>(&dynamics)) {
+    d->num_players = 2;
+    d->subsystems[0] = ilqg_subsystem{ILQG_DYN_AIR_3D_EVADER, 3, 1, air->evader_speed_};
+    d->subsystems[1] = ilqg_subsystem{ILQG_DYN_AIR_3D_PURSUER, 0, 1, air->pursuer_speed_};
+    return true;
+  }
   const auto* dyn = dynamic_cast<const ConcatenatedDynamicalSystem*>(&dynamics);
   if (dyn == nullptr) {
-    *why = "dynamics are neither a ConcatenatedDynamicalSystem nor TwoPlayerUnicycle4D";
+    *why = "dynamics are neither a ConcatenatedDynamicalSystem nor TwoPlayerUnicycle4D / Air3D";
     return false;
   }
   const int N = dyn->NumPlayers();

@@ -120,8 +120,14 @@ typedef enum {
    * rates of the row before it (xdim 0, udim 2).  The two kinds only occur as this pair. */
   ILQG_DYN_UNICYCLE_4D_DISTURBED = 4,
   ILQG_DYN_PLANAR_DISTURBANCE = 5,
-  ILQG_DYN_DUBINS_CAR = 6 /* include/ilqgames/dynamics/single_player_dubins_car.h:57-120: x = (px, py, theta),
+  ILQG_DYN_DUBINS_CAR = 6, /* include/ilqgames/dynamics/single_player_dubins_car.h:57-120: x = (px, py, theta),
                              u = (omega), constant speed param0; xdim 3, udim 1 */
+  /* Air3D (include/ilqgames/dynamics/air_3d.h:64-157): the pursuer's pose relative to the evader, x = (rx, ry,
+   * rtheta), driven by the evader's turn rate (player 0) and the pursuer's (player 1).  Row pair like kinds 4/5:
+   * the evader row carries the state (xdim 3, udim 1, param0 = evader speed), the pursuer row none (xdim 0,
+   * udim 1, param0 = pursuer speed). */
+  ILQG_DYN_AIR_3D_EVADER = 7,
+  ILQG_DYN_AIR_3D_PURSUER = 8
 } ilqg_dyn_kind;
 
 /* One block of a ConcatenatedDynamicalSystem

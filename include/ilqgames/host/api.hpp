@@ -542,6 +542,24 @@ class TwoPlayerUnicycle4D : public MultiPlayerDynamicalSystem {
   static const Dimension kNumU2Dims, kDxIdx, kDyIdx;
 };
 
+// include/ilqgames/dynamics/air_3d.h:64-110 — the classic two-aircraft pursuit-evasion model in the evader's frame:
+// x = (rx, ry, rtheta), player 1 turns the evader, player 2 the pursuer.  On the device: the row pair
+// (ILQG_DYN_AIR_3D_EVADER, ILQG_DYN_AIR_3D_PURSUER).
+class Air3D : public MultiPlayerDynamicalSystem {
+ public:
+  Air3D(float evader_speed, float pursuer_speed)
+      : MultiPlayerDynamicalSystem(kNumXDims), evader_speed_(evader_speed), pursuer_speed_(pursuer_speed) {}
+  Dimension UDim(PlayerIndex player_idx) const override { return (player_idx == 0) ? kNumU1Dims : kNumU2Dims; }
+  PlayerIndex NumPlayers() const override { return kNumPlayers; }
+  std::vector<Dimension> PositionDimensions() const override { return {kRxIdx, kRyIdx}; }
+  const float evader_speed_;
+  const float pursuer_speed_;
+  static const Dimension kNumXDims, kRxIdx, kRyIdx, kRThetaIdx;
+  static const PlayerIndex kNumPlayers;
+  static const Dimension kNumU1Dims, kOmega1Idx;
+  static const Dimension kNumU2Dims, kOmega2Idx;
+};
+
 using SubsystemList = std::vector<std::shared_ptr<SinglePlayerDynamicalSystem>>;
 
 // include/ilqgames/dynamics/concatenated_dynamical_system.h:57-104

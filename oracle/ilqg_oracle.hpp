@@ -444,7 +444,7 @@ struct ALState {
 // single_player_unicycle_4d.h:90-100, single_player_car_5d.h:100-111,
 // single_player_car_6d.h:102-114.
 template <class S>
-void EvaluateSubsystem(const ilqg_subsystem& s, const S* x, const S* u, S* xdot) {
+void EvaluateSubsystem(const ilqg_subsystem& s, const S* x, const S* u, S* xdot, S next_param = S(0)) {
   const S L = S(s.param0);
   switch (s.kind) {
     case ILQG_DYN_UNICYCLE_4D:
@@ -460,6 +460,15 @@ void EvaluateSubsystem(const ilqg_subsystem& s, const S* x, const S* u, S* xdot)
       xdot[3] = u[1];
       break;
     case ILQG_DYN_PLANAR_DISTURBANCE:  // no state of its own
+      break;
+    case ILQG_DYN_AIR_3D_EVADER: {  // air_3d.h:112-125; u[1] = the pursuer's turn rate, next_param = its speed
+      const S ve = L, vp = next_param;
+      xdot[0] = -ve + vp * std::cos(x[2]) + u[0] * x[1];
+      xdot[1] = vp * std::sin(x[2]) - u[0] * x[0];
+      xdot[2] = u[1] - u[0];
+      break;
+    }
+    case ILQG_DYN_AIR_3D_PURSUER:  // no state of its own
       break;
     case ILQG_DYN_DUBINS_CAR:  // single_player_dubins_car.h:94-103
       xdot[0] = L * std::cos(x[2]);
@@ -489,7 +498,8 @@ template <class S>
 Vec<S> Evaluate(const Problem<S>& p, const Vec<S>& x, const Vec<S>& u) {
   Vec<S> xdot(p.n);
   for (int i = 0; i < p.N; i++)
-    EvaluateSubsystem(p.subs[i], x.data() + p.xoff[i], u.data() + p.uoff[i], xdot.data() + p.xoff[i]);
+    EvaluateSubsystem(p.subs[i], x.data() + p.xoff[i], u.data() + p.uoff[i], xdot.data() + p.xoff[i],
+                      i + 1 < p.N ? S(p.subs[i + 1].param0) : S(0));
   return xdot;
 }
 
@@ -538,12 +548,28 @@ void Linearize(const Problem<S>& p, const Vec<S>& x, const Vec<S>& u, Mat<S>* A,
   *B = Mat<S>(n, p.m);
   for (int i = 0; i < p.N; i++) {
     const int o = p.xoff[i], uo = p.uoff[i];
-    const S* xs = &x[o];
+    const S* xs = x.data() + o;
     const ilqg_subsystem& s = p.subs[i];
     if (s.kind == ILQG_DYN_PLANAR_DISTURBANCE) {  // two_player_unicycle_4d.h:135-136: Bs[1](px, dx) = Bs[1](py, dy) = dt
       const int po = p.xoff[i - 1];
       (*B)(po + 0, uo + 0) = S(dt);
       (*B)(po + 1, uo + 1) = S(dt);
+      continue;
+    }
+    if (s.kind == ILQG_DYN_AIR_3D_EVADER) {  // air_3d.h:127-149 (the pursuer's column: the next row)
+      const S vp = S(p.subs[i + 1].param0), w1 = u[uo];
+      const S ctheta = S(double(std::cos(xs[2])) * dt), stheta = S(double(std::sin(xs[2])) * dt);
+      (*A)(o + 0, o + 1) += S(double(w1) * dt);
+      (*A)(o + 0, o + 2) -= vp * stheta;
+      (*A)(o + 1, o + 0) -= S(double(w1) * dt);
+      (*A)(o + 1, o + 2) += vp * ctheta;
+      (*B)(o + 0, uo) = S(double(xs[1]) * dt);
+      (*B)(o + 1, uo) = S(double(-xs[0]) * dt);
+      (*B)(o + 2, uo) = S(-dt);
+      continue;
+    }
+    if (s.kind == ILQG_DYN_AIR_3D_PURSUER) {
+      (*B)(p.xoff[i - 1] + 2, uo) = S(dt);
       continue;
     }
     if (s.kind == ILQG_DYN_DUBINS_CAR) {  // single_player_dubins_car.h:105-117

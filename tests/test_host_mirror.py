@@ -36,6 +36,7 @@ EXAMPLES = [
     ("TwoPlayerCollisionExample", "two_player_collision_example", examples.two_player_collision),
     ("OnePlayerReachabilityExample", "one_player_reachability_example", examples.one_player_reachability),
     ("DubinsOriginExample", "dubins_origin_example", examples.dubins_origin),
+    ("Air3DExample", "air_3d_example", examples.air_3d),
 ]
 
 
