@@ -1,0 +1,98 @@
+"""Parity at BASELINE.json's full sizes, through properties that do not need the oracle to run 1024 games:
+ * a batch is a set of independent games — what instance b gets must not depend on the rest of the batch
+   (sub-batch and permutation invariance, bit for bit);
+ * the LQ Nash sweep is affine in (l, r, x0): gains P ignore them, alpha and delta_x scale with them;
+ * a random sample of the batch is compared with the oracle.
+Config 2: three-player intersection, n=14, T=100, fp64, 1024 instances; config 3's per-GPU share: fp32, 8192."""
+import numpy as np
+import pytest
+
+from ilqgames_amd import abi, examples
+from helpers import dims_of, random_lq_game, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    from ilqgames_amd import hip as h
+    return h
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _spec():
+    spec = examples.modified_three_player_intersection()
+    spec.params.initial_alpha_scaling = 0.1   # bench.py's workload
+    spec.params.expected_decrease_fraction = 0.001
+    return spec
+
+
+KEYS = ("xs", "us", "P", "alpha", "costs", "iters", "status")
+
+
+@pytest.mark.parametrize("dtype,B", [(abi.F64, 1024), (abi.F32, 8192)])
+def test_full_batch_instances_are_independent(hip, dtype, B):
+    spec = _spec()
+    K = 4
+    x0 = examples.jittered_x0(spec, B, seed=77)
+    prob = hip.Problem(spec, dtype)
+    full = {k: _np(v).copy() for k, v in prob.solve(x0, fixed_iters=K).items() if k in KEYS}
+    assert np.isfinite(full["xs"]).all() and np.isfinite(full["P"]).all()
+    assert np.all(full["iters"] == K) and set(full["status"].tolist()) <= {0, 1}
+    # a slice of the batch solved on its own
+    lo, hi = B // 3, B // 3 + 37
+    part = prob.solve(x0[lo:hi], fixed_iters=K)
+    for k in KEYS:
+        assert np.array_equal(_np(part[k]), full[k][lo:hi]), k
+    # the whole batch in another order
+    perm = np.random.default_rng(5).permutation(B)
+    shuf = prob.solve(x0[perm], fixed_iters=K)
+    for k in KEYS:
+        assert np.array_equal(_np(shuf[k]), full[k][perm]), k
+
+
+def test_full_batch_sample_matches_oracle_fp64(hip, oracle):
+    spec = _spec()
+    B, K = 1024, 4
+    x0 = examples.jittered_x0(spec, B, seed=77)
+    out = hip.Problem(spec, abi.F64).solve(x0, fixed_iters=K)
+    pick = np.random.default_rng(9).choice(B, 24, replace=False)
+    ref = oracle.OracleProblem(spec).solve(abi.F64, x0[pick], fixed_iters=K, merit_log_len=K, threads=8)
+    bt = np.nan_to_num(ref["log"][:, :, 3], nan=0.0).max(axis=1)
+    ok = np.where((bt <= 12) & (ref["status"] == 1))[0]  # well-conditioned line searches (test_gpu_parity._clean)
+    assert len(ok) >= 12
+    sel = pick[ok]
+    assert np.array_equal(_np(out["iters"])[sel], ref["iters"][ok])
+    assert rel_err(_np(out["xs"])[sel], ref["xs"][ok]) < 1e-7
+    assert rel_err(_np(out["P"])[sel], ref["P"][ok]) < 1e-6
+    assert rel_err(_np(out["alpha"])[sel], ref["alpha"][ok]) < 1e-6
+    assert rel_err(_np(out["costs"])[sel], ref["costs"][ok]) < 1e-8
+
+
+@pytest.mark.parametrize("open_loop", [False, True])
+def test_full_size_lq_sweep_is_affine_in_its_linear_terms_fp64(hip, open_loop):
+    """1024 random three-player games of the headline shape (n=14, m=2+2+2, T=100): scaling (l, r, x0) by c scales
+    alpha and delta_x by c and leaves P alone (to rounding: 1e-11); zero linear terms and x0 give zero alpha, dx."""
+    rng = np.random.default_rng(123)
+    n, ms, T, B = 14, [2, 2, 2], 100, 1024
+    g = random_lq_game(rng, n, ms, T, B)
+    d = dims_of(g, abi.F64, adaptive=not open_loop)
+    x0 = rng.standard_normal((B, n))
+
+    def run(c):
+        return [(_np(v) if v is not None else None) for v in
+                hip.lq_feedback(d, g["A"], g["Bm"], g["Q"], c * g["l"], g["R"], c * g["r"], g["pairs"], x0=c * x0,
+                                open_loop=open_loop)]
+    P1, a1, dx1 = run(1.0)
+    P3, a3, dx3 = run(-2.5)
+    P0, a0, dx0 = run(0.0)
+    assert np.isfinite(a1).all() and np.isfinite(dx1).all()
+    if not open_loop:
+        assert rel_err(P3, P1) < 1e-13 and rel_err(P0, P1) < 1e-13 and np.abs(P1).max() > 1e-3
+    assert rel_err(a3, -2.5 * a1) < 1e-11 and rel_err(dx3, -2.5 * dx1) < 1e-11
+    assert not a0.any() and not dx0.any()
