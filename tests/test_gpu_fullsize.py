@@ -96,3 +96,41 @@ def test_full_size_lq_sweep_is_affine_in_its_linear_terms_fp64(hip, open_loop):
         assert rel_err(P3, P1) < 1e-13 and rel_err(P0, P1) < 1e-13 and np.abs(P1).max() > 1e-3
     assert rel_err(a3, -2.5 * a1) < 1e-11 and rel_err(dx3, -2.5 * dx1) < 1e-11
     assert not a0.any() and not dx0.any()
+
+
+def test_full_batch_stage_outputs_have_the_reference_structure_fp64(hip):
+    """Linearisation and quadraticisation of 1024 solved trajectories: A is block diagonal over the players'
+    subsystems with B_i confined to player i's rows (ConcatenatedDynamicalSystem::Linearize,
+    src/concatenated_dynamical_system.cpp:86-107), every Q_i and R_ij is exactly symmetric (each cost adds H(x,y) and
+    H(y,x) from one value) with the regularisation on its diagonal, and the control blocks are those of the pair table."""
+    import torch
+    spec = _spec()
+    B = 1024
+    x0 = examples.jittered_x0(spec, B, seed=77)
+    prob = hip.Problem(spec, abi.F64)
+    out = prob.solve(x0, fixed_iters=2)
+    A, Bm = prob.linearize(out["xs"], out["us"])
+    n, m, N, T = prob.n, prob.m, prob.N, prob.T
+    A = A.reshape(B, T, n, n).transpose(2, 3)   # column-major blocks -> [row, col]
+    Bm = Bm.reshape(B, T, m, n).transpose(2, 3)
+    xoff = [spec.xoff(i) for i in range(N)] + [n]
+    uoff = np.concatenate([[0], np.cumsum(spec.udims)])
+    for i in range(N):
+        for j in range(N):
+            if i != j:
+                assert not A[:, :, xoff[i]:xoff[i + 1], xoff[j]:xoff[j + 1]].any()
+                assert not Bm[:, :, xoff[i]:xoff[i + 1], uoff[j]:uoff[j + 1]].any()
+    assert torch.all(torch.diagonal(A, dim1=2, dim2=3) == 1.0)  # (I + dt J): none of these models has J_kk != 0
+    del A, Bm
+    Q, l, R, r = prob.quadraticize(out["xs"], out["us"])
+    Q = Q.reshape(B, T, N, n, n)
+    assert torch.equal(Q, Q.transpose(3, 4))
+    assert torch.all(torch.diagonal(Q, dim1=3, dim2=4) >= 10.0)  # sigma_x = 10 plus convex terms' diagonals
+    off = 0
+    for (i, j) in prob.pairs:
+        mj = spec.udims[j]
+        blk = R[:, :, off:off + mj * mj].reshape(B, T, mj, mj)
+        assert torch.equal(blk, blk.transpose(2, 3))
+        assert torch.all(torch.diagonal(blk, dim1=2, dim2=3) >= 10.0)
+        off += mj * mj
+    assert off == prob.Rsz and torch.isfinite(l).all() and torch.isfinite(r).all()
