@@ -134,3 +134,43 @@ def test_full_batch_stage_outputs_have_the_reference_structure_fp64(hip):
         assert torch.all(torch.diagonal(blk, dim1=2, dim2=3) >= 10.0)
         off += mj * mj
     assert off == prob.Rsz and torch.isfinite(l).all() and torch.isfinite(r).all()
+
+
+def test_full_batch_receding_horizon_step_is_per_instance_fp64(hip):
+    """Config 5's batch (2048 plans): one receding-horizon step — integrate the state along the plan, re-anchor,
+    warm-started solve, splice — gives every instance what it gets in a 29-instance slice of the batch, bit for bit,
+    and the row bookkeeping obeys the reference's invariants for every instance."""
+    import torch
+    spec = examples.three_player_collision_avoidance_reachability()
+    spec.params.max_solver_iters = 3
+    B = 2048
+    x0 = examples.jittered_x0(spec, B, seed=31)
+    prob = hip.Problem(spec, abi.F64)
+
+    def step(x0_part):
+        b = x0_part.shape[0]
+        bufs = prob.alloc_solve_buffers(b)
+        x = torch.as_tensor(x0_part, dtype=torch.float64, device="cuda").clone()
+        prob.solve(x, bufs)
+        plan = prob.new_plan(b)
+        t0 = torch.zeros(b, dtype=torch.float64, device="cuda")
+        prob.solution_splice(plan, bufs, t0)
+        active = torch.ones(b, dtype=torch.int32, device="cuda")
+        prob.plan_integrate(plan, 0.0, 0.25, 0.6, x, active)
+        x0n, st0, first = prob.receding_horizon_sync(plan, x, 0.25, 0.25, bufs, active)
+        prob.solve_again(x0n, bufs, active=active)
+        conv = torch.ones(b, dtype=torch.int32, device="cuda")
+        prob.solution_splice(plan, bufs, st0, converged=conv, active=active)
+        return dict(x=_np(x), x0n=_np(x0n), st0=_np(st0), first=_np(first), active=_np(active), xs=_np(bufs["xs"]),
+                    P=_np(bufs["P"]), len=_np(plan["len"]), t0=_np(plan["t0"]), pxs=_np(plan["xs"]))
+    full = step(x0)
+    lo, hi = 700, 729
+    part = step(x0[lo:hi])
+    for k in full:
+        assert np.array_equal(part[k], full[k][lo:hi]), k
+    assert full["active"].all()
+    # SetUpNextRecedingHorizon's invariant (src/problem.cpp:123) and SolutionSplicer's row count (:100-103)
+    assert np.all(np.abs(0.25 + 0.25 - full["st0"]) <= spec.dt + 1e-9)
+    kept = np.minimum(np.floor(1e-4 + full["st0"] / spec.dt).astype(int), 5)
+    assert np.array_equal(full["len"], spec.T + kept)
+    assert np.all((full["first"] >= 0) & (full["first"] < spec.T))
