@@ -174,3 +174,24 @@ def test_full_batch_receding_horizon_step_is_per_instance_fp64(hip):
     kept = np.minimum(np.floor(1e-4 + full["st0"] / spec.dt).astype(int), 5)
     assert np.array_equal(full["len"], spec.T + kept)
     assert np.all((full["first"] >= 0) & (full["first"] < spec.T))
+
+
+def test_config4_full_batch_slice_is_reproduced_fp64(hip):
+    """Config 4 at full size (roundabout merging, n=24, N=4, T=150, open-loop sweep, 4096 instances): a 21-instance
+    slice solved on its own reproduces its share of the full batch bit for bit; everything finite."""
+    import torch
+    spec = examples.CONFIGS["roundabout_merging_T150"]()
+    assert spec.params.open_loop and spec.T == 150 and spec.n == 24
+    spec.params.initial_alpha_scaling = 0.1
+    spec.params.expected_decrease_fraction = 0.001
+    B, K = 4096, 2
+    x0 = examples.jittered_x0(spec, B, seed=13)
+    prob = hip.Problem(spec, abi.F64)
+    full = prob.solve(x0, fixed_iters=K)
+    lo, hi = 2000, 2021
+    keep = {k: full[k][lo:hi].clone() for k in KEYS}
+    assert torch.isfinite(full["xs"]).all() and torch.isfinite(full["alpha"]).all()
+    assert torch.all(full["iters"] == K) and not full["P"].any()  # open-loop strategies carry no gains
+    part = prob.solve(x0[lo:hi], fixed_iters=K)
+    for k in KEYS:
+        assert torch.equal(part[k], keep[k]), k
