@@ -13,6 +13,7 @@
 #include <ctime>
 #include <fstream>
 #include <sstream>
+#include <typeinfo>
 
 namespace ilqgames {
 
@@ -1243,6 +1244,88 @@ std::vector<std::shared_ptr<const SolverLog>> RecedingHorizonSimulator(Time fina
     if (logs.back()->WasConverged()) splicer.Splice(*logs.back());
   }
   return logs;
+}
+
+// ------------------------------------------------------------------------------------------
+// MinimallyInvasiveRecedingHorizonSimulator (src/minimally_invasive_receding_horizon_simulator.cpp:68-218):
+// two planners over one plant.  Both are re-solved at every replanning instant from the spliced plan; the
+// safety planner's answer is adopted when its P1 value is above the threshold (:201-204) or when it alone
+// converged (:205-206), otherwise the original planner's (if that one converged).
+// ------------------------------------------------------------------------------------------
+std::vector<ActiveProblem> MinimallyInvasiveRecedingHorizonSimulator(
+    Time final_time, Time planner_runtime, GameSolver* original, GameSolver* safety,
+    std::vector<std::shared_ptr<const SolverLog>>* original_logs,
+    std::vector<std::shared_ptr<const SolverLog>>* safety_logs) {
+  CHECK_NOTNULL(original);
+  CHECK_NOTNULL(safety);
+  CHECK_NOTNULL(original_logs);
+  CHECK_NOTNULL(safety_logs);
+  using Clock = std::chrono::system_clock;
+  const Time fixed_solve_time = host::Options().simulated_solve_time;
+  Problem& plan_a = original->GetProblem();
+  Problem& plan_b = safety->GetProblem();
+  CHECK(plan_a.InitialState().isApprox(plan_b.InitialState(), constants::kSmallNumber));
+  CHECK_NEAR(plan_a.InitialTime(), plan_b.InitialTime(), constants::kSmallNumber);
+  const MultiPlayerIntegrableSystem& plant = *plan_a.Dynamics();
+  {
+    const MultiPlayerIntegrableSystem& other = *plan_b.Dynamics();
+    CHECK(typeid(plant) == typeid(other));
+  }
+  original_logs->clear();
+  safety_logs->clear();
+
+  // one solver call, charged its wall-clock time (or the fixed simulated time of host::DeviceOptions)
+  const auto timed_solve = [&](GameSolver* solver, std::vector<std::shared_ptr<const SolverLog>>* logs, bool first) {
+    const auto call_time = Clock::now();
+    bool success = false;
+    logs->push_back(first ? solver->Solve(&success) : solver->Solve(&success, planner_runtime));
+    if (first) CHECK(success);
+    const Time elapsed = std::chrono::duration<Time>(Clock::now() - call_time).count();
+    return fixed_solve_time >= 0.0 ? fixed_solve_time : elapsed;
+  };
+  timed_solve(original, original_logs, true);
+  timed_solve(safety, safety_logs, true);
+
+  SolutionSplicer splicer(*original_logs->front());  // the original controller is the one that starts (:121-123)
+  std::vector<ActiveProblem> active = {ActiveProblem::ORIGINAL};
+  VectorXf x(plan_a.InitialState());
+  Time t = plan_a.InitialTime();
+  const Time kExtraTime = 0.25;
+  constexpr float kSafetyThreshold = -1.0;
+  while (true) {
+    t += kExtraTime;
+    if (t >= final_time || !splicer.ContainsTime(t + planner_runtime + time::kTimeStep)) break;
+    x = plant.Integrate(t - kExtraTime, t, x, splicer.CurrentOperatingPoint(), splicer.CurrentStrategies());
+
+    // both planners restart from the plan in force and from the active planner's initial state (:141-160)
+    const VectorXf anchor = (active.back() == ActiveProblem::ORIGINAL ? plan_a : plan_b).InitialState();
+    for (Problem* plan : {&plan_a, &plan_b}) {
+      plan->OverwriteSolution(splicer.CurrentOperatingPoint(), splicer.CurrentStrategies());
+      plan->ResetInitialState(anchor);
+    }
+    for (Problem* plan : {&plan_a, &plan_b}) plan->SetUpNextRecedingHorizon(x, t, planner_runtime);
+
+    const Time spent_a = timed_solve(original, original_logs, false);
+    CHECK_LE(spent_a, planner_runtime);
+    const Time spent_b = timed_solve(safety, safety_logs, false);
+    CHECK_LE(spent_b, planner_runtime);
+    const Time elapsed = std::max(spent_a, spent_b);
+    t += elapsed;
+    if (t >= final_time || !splicer.ContainsTime(t)) break;
+    x = plant.Integrate(t - elapsed, t, x, splicer.CurrentOperatingPoint(), splicer.CurrentStrategies());
+
+    const SolverLog& log_a = *original_logs->back();
+    const SolverLog& log_b = *safety_logs->back();
+    const float safety_value = log_b.TotalCosts().front();
+    if (safety_value > kSafetyThreshold || (log_b.WasConverged() && !log_a.WasConverged())) {
+      active.push_back(ActiveProblem::SAFETY);
+      splicer.Splice(log_b);
+    } else {
+      active.push_back(ActiveProblem::ORIGINAL);
+      if (log_a.WasConverged()) splicer.Splice(log_a);
+    }
+  }
+  return active;
 }
 
 // ------------------------------------------------------------------------------------------

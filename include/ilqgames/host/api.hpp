@@ -963,6 +963,15 @@ class SolutionSplicer {
 std::vector<std::shared_ptr<const SolverLog>> RecedingHorizonSimulator(Time final_time, Time planner_runtime,
                                                                        GameSolver* solver);
 
+// include/ilqgames/examples/minimally_invasive_receding_horizon_simulator.h:60-72: two planners (the original one
+// and a safety one, same dynamics type and initial condition) are re-solved at every replanning instant; the
+// returned vector says whose plan was spliced in after each pair of calls.
+enum ActiveProblem { ORIGINAL, SAFETY };
+std::vector<ActiveProblem> MinimallyInvasiveRecedingHorizonSimulator(
+    Time final_time, Time planner_runtime, GameSolver* original, GameSolver* safety,
+    std::vector<std::shared_ptr<const SolverLog>>* original_logs,
+    std::vector<std::shared_ptr<const SolverLog>>* safety_logs);
+
 namespace host {
 // RecedingHorizonSimulator for a batch of initial states: every instance shares the simulator's clock (0.25 s of
 // motion before each call, `simulated_solve_time` after it) and keeps its own spliced plan; plans, states and the

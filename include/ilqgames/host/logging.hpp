@@ -78,6 +78,8 @@ T* CheckNotNull(T* p, const char* expr, const char* file, int line) {
 #define CHECK_LE(a, b) ILQG_CHECK_OP(a, b, <=)
 #define CHECK_GT(a, b) ILQG_CHECK_OP(a, b, >)
 #define CHECK_GE(a, b) ILQG_CHECK_OP(a, b, >=)
+#define CHECK_NEAR(a, b, margin) \
+  CHECK(((a) > (b) ? (a) - (b) : (b) - (a)) <= (margin)) << "(" << (a) << " vs. " << (b) << ") "
 #define CHECK_NOTNULL(p) ::ilqgames::host::CheckNotNull((p), #p, __FILE__, __LINE__)
 #define DCHECK(cond) CHECK(cond)
 

@@ -304,6 +304,60 @@ def test_cpp_receding_horizon_simulator_matches_oracle(demo_out, oracle):
     assert ref["iters"][0, 1] == 1 and ref["ok"][0, 1] == 0
 
 
+def _parse_mi(path):
+    active, logs = None, []
+    for line in open(path):
+        tok = line.split()
+        if tok[0] == "active":
+            active = [int(v) for v in tok[1:]]
+        elif tok[0] == "calls":
+            calls = (int(tok[1]), int(tok[2]))
+        elif tok[0] == "t0":
+            logs.append(dict(t0=float(tok[1]), xs=[], us=[]))
+        elif tok[0] == "success":
+            logs[-1]["converged"], logs[-1]["iters"] = int(tok[3]), int(tok[5])
+        elif tok[0] == "costs":
+            logs[-1]["costs"] = [float(v) for v in tok[1:]]
+        elif tok[0] == "x":
+            logs[-1]["xs"].append([float(v) for v in tok[1:]])
+        elif tok[0] == "u":
+            logs[-1]["us"].append([float(v) for v in tok[1:]])
+    assert calls[0] == calls[1] and 2 * calls[0] == len(logs)
+    return active, logs[0::2], logs[1::2]
+
+
+@pytest.mark.gpu
+def test_cpp_minimally_invasive_simulator(demo_out):
+    """MinimallyInvasiveRecedingHorizonSimulator of the C++ mirror (src/minimally_invasive_receding_horizon_
+    simulator.cpp:68-218).  Same scene on both sides: the two planners see identical inputs at every call, so
+    their logs are identical, and the positive P1 value hands every decision to the safety planner.  Safety scene
+    with a P1 value below the threshold: every decision follows the rule of :201-214 applied to the logs, and
+    both branches' start times advance by 0.25 s of motion plus the 0.25 s charged per pair of calls."""
+    rh_first = _parse_rh(os.path.join(demo_out, "rh_sim.txt"))[0]
+    for variant in (0, 1):
+        active, logs_a, logs_b = _parse_mi(os.path.join(demo_out, "mi_sim_%d.txt" % variant))
+        assert len(logs_a) >= 4 and active[0] == 0
+        # one decision per completed pair of re-solves; the loop may end right after the last pair's solves
+        assert len(active) in (len(logs_a), len(logs_a) - 1), (len(active), len(logs_a))
+        assert np.array_equal(np.array(logs_a[0]["xs"]), np.array(rh_first["xs"]))  # the original planner's first solve
+        for r in range(1, len(logs_a)):
+            assert abs(logs_a[r]["t0"] - 0.5 * r) < 1e-5 and abs(logs_b[r]["t0"] - 0.5 * r) < 1e-5, (variant, r)
+            assert np.array_equal(np.array(logs_a[r]["xs"])[0], np.array(logs_b[r]["xs"])[0]), (variant, r)
+        for r in range(1, len(active)):
+            a, b = logs_a[r], logs_b[r]
+            want = 1 if (b["costs"][0] > -1.0 or (b["converged"] and not a["converged"])) else 0
+            assert active[r] == want, (variant, r, active, b["costs"][0], a["converged"], b["converged"])
+        if variant == 0:
+            assert all(v == 1 for v in active[1:])
+            for a, b in zip(logs_a, logs_b):
+                assert a["iters"] == b["iters"] and a["converged"] == b["converged"]
+                assert np.array_equal(np.array(a["xs"]), np.array(b["xs"]))
+                assert np.array_equal(np.array(a["us"]), np.array(b["us"]))
+        else:
+            assert all(b["costs"][0] < -1.0 for b in logs_b)
+            assert any(v == 0 for v in active[1:])
+
+
 @pytest.mark.gpu
 def test_cpp_two_player_unicycle_solve_matches_oracle(demo_out, oracle):
     """TwoPlayerUnicycle4D through the C++ mirror: its descriptor equals the python builder's, and five iLQ
