@@ -18,6 +18,7 @@ DYN_UNICYCLE_4D, DYN_CAR_5D, DYN_CAR_6D = 1, 2, 3
 DYN_UNICYCLE_4D_DISTURBED, DYN_PLANAR_DISTURBANCE = 4, 5  # the two rows of TwoPlayerUnicycle4D
 DYN_DUBINS_CAR = 6  # (px, py, theta), u = (omega), param0 = speed
 DYN_AIR_3D_EVADER, DYN_AIR_3D_PURSUER = 7, 8  # the two rows of Air3D (param0 = that aircraft's speed)
+DYN_POINT_MASS_2D = 9  # (px, py, vx, vy), u = (ax, ay)
 # ilqg_cost_kind
 (COST_QUADRATIC, COST_QUADRATIC_POLYLINE2, COST_SEMIQUADRATIC, COST_SEMIQUADRATIC_POLYLINE2,
  COST_PROXIMITY, COST_SIGNED_DISTANCE, COST_EXTREME_VALUE, CONSTRAINT_PROXIMITY,
@@ -112,7 +113,8 @@ class ProblemSpec:
     # --- dynamics (ConcatenatedDynamicalSystem subsystem list) ---
     def add_player(self, kind, param0=0.0, state_reg=0.0, control_reg=0.0, structure=SUM):
         xdim = {DYN_UNICYCLE_4D: 4, DYN_CAR_5D: 5, DYN_CAR_6D: 6, DYN_UNICYCLE_4D_DISTURBED: 4,
-                DYN_PLANAR_DISTURBANCE: 0, DYN_DUBINS_CAR: 3, DYN_AIR_3D_EVADER: 3, DYN_AIR_3D_PURSUER: 0}[kind]
+                DYN_PLANAR_DISTURBANCE: 0, DYN_DUBINS_CAR: 3, DYN_AIR_3D_EVADER: 3, DYN_AIR_3D_PURSUER: 0,
+                DYN_POINT_MASS_2D: 4}[kind]
         one_control = kind in (DYN_DUBINS_CAR, DYN_AIR_3D_EVADER, DYN_AIR_3D_PURSUER)
         self.subsystems.append((kind, xdim, 1 if one_control else 2, param0))
         self.player_costs.append((state_reg, control_reg, structure))

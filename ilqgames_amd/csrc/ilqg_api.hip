@@ -123,6 +123,8 @@ __global__ void rollout_kernel(DevProblem p, RolloutBatchArgs<T> g) {
     rollout_instance<T, 0, 0, true>(p, a, sm, threadIdx.x);
   else if (dubins)
     rollout_instance<T, 0, 0, false, true>(p, a, sm, threadIdx.x);
+  else if (p.sub_kind[0] == ILQG_DYN_POINT_MASS_2D)
+    rollout_instance<T, 0, 0, false, false, false, true>(p, a, sm, threadIdx.x);
   else
     rollout_instance<T>(p, a, sm, threadIdx.x);
 }
@@ -305,7 +307,7 @@ bool build_pairs(const ilqg_pair* pairs, int npairs, const int* udim, int N, Pai
 // Supported (n, N, m_i) instantiations.  n=14/16/15/24: BASELINE configs 2-5;
 // (4,2,2): config 1 (TwoPlayerUnicycle4D); (2,2,1): test_lq_solver's point mass;
 // (6,3,2): synthetic parity cases.
-#define ILQG_FOR_DIMS(X) X(14, 3, 2) X(16, 3, 2) X(15, 3, 2) X(24, 4, 2) X(18, 3, 2) X(12, 2, 2) X(10, 2, 2) X(4, 2, 2) X(6, 2, 1) X(3, 2, 1) X(3, 1, 1) X(2, 2, 1) X(6, 3, 2) X(2, 1, 2)
+#define ILQG_FOR_DIMS(X) X(14, 3, 2) X(16, 3, 2) X(15, 3, 2) X(24, 4, 2) X(18, 3, 2) X(12, 2, 2) X(10, 2, 2) X(4, 2, 2) X(6, 2, 1) X(3, 2, 1) X(3, 1, 1) X(2, 2, 1) X(6, 3, 2) X(2, 1, 2) X(8, 2, 2)
 
 template <typename T, int NX, int NP, int MU>
 ilqg_status launch_lq(const ilqg_dims* d, const PairTable& pt, const void* A, const void* Bm, const void* Q,
@@ -636,7 +638,8 @@ ilqg_status ilqg_problem_create(const ilqg_problem_desc* desc, ilqg_problem** ou
   d.uoff[0] = 0;
   for (int i = 0; i < d.N; i++) {
     const ilqg_subsystem& sub = desc->subsystems[i];
-    const int want_x = (sub.kind == ILQG_DYN_UNICYCLE_4D || sub.kind == ILQG_DYN_UNICYCLE_4D_DISTURBED) ? 4
+    const int want_x = (sub.kind == ILQG_DYN_UNICYCLE_4D || sub.kind == ILQG_DYN_UNICYCLE_4D_DISTURBED ||
+                        sub.kind == ILQG_DYN_POINT_MASS_2D) ? 4
                        : sub.kind == ILQG_DYN_CAR_5D ? 5 : sub.kind == ILQG_DYN_CAR_6D ? 6
                        : sub.kind == ILQG_DYN_PLANAR_DISTURBANCE ? 0 : sub.kind == ILQG_DYN_DUBINS_CAR ? 3
                        : sub.kind == ILQG_DYN_AIR_3D_EVADER ? 3 : sub.kind == ILQG_DYN_AIR_3D_PURSUER ? 0 : -1;
@@ -654,6 +657,10 @@ ilqg_status ilqg_problem_create(const ilqg_problem_desc* desc, ilqg_problem** ou
     if (!pair_ok) {
       delete p;
       return fail(ILQG_ERR_UNSUPPORTED, "the shared-state kinds only occur as the pairs (4, 5) and (7, 8)");
+    }
+    if ((sub.kind == ILQG_DYN_POINT_MASS_2D) != (desc->subsystems[0].kind == ILQG_DYN_POINT_MASS_2D)) {
+      delete p;
+      return fail(ILQG_ERR_UNSUPPORTED, "point masses (kind 9) only occur in games made of point masses");
     }
     if (want_x < 0 || sub.xdim != want_x || sub.udim != want_u) {
       delete p;

@@ -40,7 +40,13 @@ __device__ __forceinline__ bool is_unicycle(int kind) {
 
 template <typename T>
 __device__ __forceinline__ void sub_eval(int kind, T L, const T* x, T u0, T u1, T* xd, T d0 = T(0), T d1 = T(0)) {
-  if (kind == ILQG_DYN_AIR_3D_EVADER) {  // air_3d.h:112-125: L = evader speed, d0 = pursuer speed, u1 = its turn rate
+  if (kind == ILQG_DYN_POINT_MASS_2D) {  // single_player_point_mass_2d.h:90-99
+    xd[0] = x[2];
+    xd[1] = x[3];
+    xd[2] = u0;
+    xd[3] = u1;
+    xd[4] = xd[5] = T(0);
+  } else if (kind == ILQG_DYN_AIR_3D_EVADER) {  // air_3d.h:112-125: L = evader speed, d0 = pursuer speed, u1 = its turn rate
     xd[0] = -L + d0 * t_cos(x[2]) + u0 * x[1];
     xd[1] = d0 * t_sin(x[2]) - u0 * x[0];
     xd[2] = u1 - u0;
@@ -274,6 +280,13 @@ __device__ __forceinline__ void sub_linearize_trig(int kind, T L, double dt, con
     // ends where this (empty) block begins
     B[-4 + ld * 0] = T(dt);
     B[-3 + ld * 1] = T(dt);
+    return;
+  }
+  if (kind == ILQG_DYN_POINT_MASS_2D) {  // single_player_point_mass_2d.h:101-110
+    A[0 + ld * 2] += T(dt);
+    A[1 + ld * 3] += T(dt);
+    B[2 + ld * 0] = T(dt);
+    B[3 + ld * 1] = T(dt);
     return;
   }
   if (kind == ILQG_DYN_DUBINS_CAR) {  // single_player_dubins_car.h:105-117

@@ -377,7 +377,8 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const Q
     }
     __syncthreads();
     if (roll && wave == 0)
-      rollout_instance<T, NX, NP * MU, (NX == 4 && NP == 2), (MU == 1), (NX == 3 && NP == 2 && MU == 1)>(p, ra, sm_roll, lane, W > 1 ? &flags[0] : nullptr,
+      rollout_instance<T, NX, NP * MU, (NX == 4 && NP == 2), (MU == 1), (NX == 3 && NP == 2 && MU == 1),
+                       (NX == 4 * NP && MU == 2 && NP <= 2)>(p, ra, sm_roll, lane, W > 1 ? &flags[0] : nullptr,
                                        (kProfile && sa.prof) ? rph : nullptr);
     if (roll && W == 1) {
       __syncthreads();

@@ -53,7 +53,9 @@ __device__ __forceinline__ int progress_observe(int* flag) {
 // keep the integrator they had.
 // AIR: the dynamics are Air3D — its position rates depend on the position itself, so the stage-parallel integrator
 // does not apply and lane 0 runs the plain RK4.
-template <typename T, int CN = 0, int CM = 0, bool DIST = false, bool DUB = false, bool AIR = false>
+// PM: the game may be one of point masses (then every row is one): the plain RK4 again, one copy per lane of the
+// group — the right-hand side is two moves and there is no transcendental to take out of the chain.
+template <typename T, int CN = 0, int CM = 0, bool DIST = false, bool DUB = false, bool AIR = false, bool PM = false>
 __device__ __forceinline__ void rollout_instance(const DevProblem& p, const RolloutArgs<T>& a, T* sm, int t,
                                                  int* ready = nullptr, long long* phacc = nullptr) {
   const int n = CN > 0 ? CN : p.n, m = CM > 0 ? CM : p.m, N = p.N, Tn = p.T;
@@ -151,6 +153,8 @@ __device__ __forceinline__ void rollout_instance(const DevProblem& p, const Roll
         const bool dist = integ && kind == ILQG_DYN_UNICYCLE_4D_DISTURBED;  // the next player's (dx, dy)
         const T d0 = dist ? su[uo + 2] : T(0), d1 = dist ? su[uo + 3] : T(0);
         sub_integrate_lanes<T, true>(kind, Lp, p.dt, xj, u0, u1, q, t & ~7, d0, d1);
+      } else if (PM && p.sub_kind[0] == ILQG_DYN_POINT_MASS_2D) {
+        sub_integrate<T>(kind, Lp, p.dt, xj, u0, u1);
       } else {
         sub_integrate_lanes<T, false, DUB>(kind, Lp, p.dt, xj, u0, u1, q, t & ~7);
       }

@@ -450,6 +450,29 @@ def air_3d(T=100, dt=0.1, rx0=4.0, ry0=3.0, rtheta0=math.pi / 4.0, ve=1.0, vp=1.
     return s
 
 
+def modified_air_3d(T=100, dt=0.1, rx0=4.0, ry0=3.0, rtheta0=math.pi / 4.0, ve=1.0, vp=1.0):
+    """ModifiedAir3DExample — pursuit-evasion between two planar point masses (n=8): the evader is paid, the
+    pursuer charged, 1e6 times half the squared distance between them; quadratic acceleration costs.
+    src/modified_air_3d_example.cpp:82-160 (state regularisation 1, control regularisation 0, :117-118); params
+    exec/modified_air_3d_example/main.cpp:76-78,112-116."""
+    prm = SolverParams.default()
+    prm.max_backtracking_steps = 100
+    prm.initial_alpha_scaling = 0.1
+    prm.convergence_tolerance = 0.01
+    prm.expected_decrease_fraction = 0.1
+    s = ProblemSpec(T, dt, prm)
+    for pl in range(2):
+        s.add_player(abi.DYN_POINT_MASS_2D, 0.0, state_reg=1.0, control_reg=0.0)
+        s.quadratic(pl, 0.1, -1, 0.0, control_of=pl)
+    s.quadratic_difference(0, -1e6, (0, 1), (4, 5))
+    s.quadratic_difference(1, 1e6, (0, 1), (4, 5))
+    f = np.float32
+    s.x0 = [0.0, 0.0, float(f(ve)), 0.0, float(f(rx0)), float(f(ry0)), float(f(vp * math.cos(rtheta0))),
+            float(f(vp * math.sin(rtheta0)))]
+    s.position_dims, s.heading_dims, s.speed_dims = [(0, 1), (4, 5)], [], []
+    return s
+
+
 def skeleton(T=100, dt=0.1):
     """SkeletonExample — the reference's template problem: two Car5D (n=10) crossing paths, lane-centre, speed,
     control and proximity costs.  src/skeleton_example.cpp:60-185; params exec/skeleton_example/main.cpp:73-80,113-121."""
@@ -588,10 +611,13 @@ def jittered_x0(spec, batch, seed=0):
     for b in range(batch):
         rng = np.random.default_rng(seed + b)
         speeds = list(spec.speed_dims) + [None] * (len(spec.position_dims) - len(spec.speed_dims))
-        for (xi, yi), hi, vi in zip(spec.position_dims, spec.heading_dims, speeds):
+        headings = list(spec.heading_dims) + [None] * (len(spec.position_dims) - len(spec.heading_dims))
+        for (xi, yi), hi, vi in zip(spec.position_dims, headings, speeds):
             x0[b, xi] += rng.uniform(-1, 1)
             x0[b, yi] += rng.uniform(-1, 1)
-            x0[b, hi] += rng.uniform(-0.1, 0.1)
+            dh = rng.uniform(-0.1, 0.1)
+            if hi is not None:
+                x0[b, hi] += dh
             dv = rng.uniform(-0.5, 0.5)  # drawn even for a model without a speed state: same stream per instance
             if vi is not None:
                 x0[b, vi] += dv
@@ -609,6 +635,7 @@ CONFIGS = {
     "two_player_collision_avoidance_reachability": two_player_collision_avoidance_reachability,
     "skeleton": skeleton,
     "air_3d": air_3d,
+    "modified_air_3d": modified_air_3d,
     "dubins_origin": dubins_origin,
     "one_player_reachability": one_player_reachability,
     "two_player_collision": two_player_collision,

@@ -41,6 +41,14 @@ const Dimension Air3D::kNumU1Dims = 1;
 const Dimension Air3D::kOmega1Idx = 0;
 const Dimension Air3D::kNumU2Dims = 1;
 const Dimension Air3D::kOmega2Idx = 0;
+const Dimension SinglePlayerPointMass2D::kNumXDims = 4;
+const Dimension SinglePlayerPointMass2D::kPxIdx = 0;
+const Dimension SinglePlayerPointMass2D::kPyIdx = 1;
+const Dimension SinglePlayerPointMass2D::kVxIdx = 2;
+const Dimension SinglePlayerPointMass2D::kVyIdx = 3;
+const Dimension SinglePlayerPointMass2D::kNumUDims = 2;
+const Dimension SinglePlayerPointMass2D::kAxIdx = 0;
+const Dimension SinglePlayerPointMass2D::kAyIdx = 1;
 const Dimension SinglePlayerDubinsCar::kNumXDims = 3;
 const Dimension SinglePlayerDubinsCar::kPxIdx = 0;
 const Dimension SinglePlayerDubinsCar::kPyIdx = 1;

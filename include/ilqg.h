@@ -127,7 +127,10 @@ typedef enum {
    * the evader row carries the state (xdim 3, udim 1, param0 = evader speed), the pursuer row none (xdim 0,
    * udim 1, param0 = pursuer speed). */
   ILQG_DYN_AIR_3D_EVADER = 7,
-  ILQG_DYN_AIR_3D_PURSUER = 8
+  ILQG_DYN_AIR_3D_PURSUER = 8,
+  /* include/ilqgames/dynamics/single_player_point_mass_2d.h:55-110: x = (px, py, vx, vy), u = (ax, ay);
+   * xdim 4, udim 2.  Point masses only occur in games made of point masses. */
+  ILQG_DYN_POINT_MASS_2D = 9
 } ilqg_dyn_kind;
 
 /* One block of a ConcatenatedDynamicalSystem

@@ -459,6 +459,16 @@ class SinglePlayerDubinsCar : public SinglePlayerDynamicalSystem {
   const float v_;
 };
 
+// include/ilqgames/dynamics/single_player_point_mass_2d.h:55-86 — planar double integrator
+class SinglePlayerPointMass2D : public SinglePlayerDynamicalSystem {
+ public:
+  SinglePlayerPointMass2D() : SinglePlayerDynamicalSystem(kNumXDims, kNumUDims) {}
+  std::vector<Dimension> PositionDimensions() const override { return {kPxIdx, kPyIdx}; }
+  ilqg_subsystem Describe() const override { return ilqg_subsystem{ILQG_DYN_POINT_MASS_2D, xdim_, udim_, 0.0f}; }
+  static const Dimension kNumXDims, kPxIdx, kPyIdx, kVxIdx, kVyIdx;
+  static const Dimension kNumUDims, kAxIdx, kAyIdx;
+};
+
 // include/ilqgames/dynamics/single_player_car_5d.h:59-98
 class SinglePlayerCar5D : public SinglePlayerDynamicalSystem {
  public:

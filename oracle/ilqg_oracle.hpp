@@ -475,6 +475,12 @@ void EvaluateSubsystem(const ilqg_subsystem& s, const S* x, const S* u, S* xdot,
       xdot[1] = L * std::sin(x[2]);
       xdot[2] = u[0];
       break;
+    case ILQG_DYN_POINT_MASS_2D:  // single_player_point_mass_2d.h:90-99
+      xdot[0] = x[2];
+      xdot[1] = x[3];
+      xdot[2] = u[0];
+      xdot[3] = u[1];
+      break;
     case ILQG_DYN_CAR_5D:
       xdot[0] = x[4] * std::cos(x[2]);
       xdot[1] = x[4] * std::sin(x[2]);
@@ -570,6 +576,13 @@ void Linearize(const Problem<S>& p, const Vec<S>& x, const Vec<S>& u, Mat<S>* A,
     }
     if (s.kind == ILQG_DYN_AIR_3D_PURSUER) {
       (*B)(p.xoff[i - 1] + 2, uo) = S(dt);
+      continue;
+    }
+    if (s.kind == ILQG_DYN_POINT_MASS_2D) {  // single_player_point_mass_2d.h:101-110
+      (*A)(o + 0, o + 2) += S(dt);
+      (*A)(o + 1, o + 3) += S(dt);
+      (*B)(o + 2, uo + 0) = S(dt);
+      (*B)(o + 3, uo + 1) = S(dt);
       continue;
     }
     if (s.kind == ILQG_DYN_DUBINS_CAR) {  // single_player_dubins_car.h:105-117

@@ -35,7 +35,7 @@ def _solved(oracle, cfg, B, iters):
 
 @pytest.mark.parametrize("cfg", ["modified_three_player_intersection", "three_player_collision_avoidance_reachability",
                                  "two_player_unicycle_4d_scene", "roundabout_merging", "two_player_reachability",
-                                 "one_player_reachability", "air_3d"])
+                                 "one_player_reachability", "air_3d", "modified_air_3d"])
 @pytest.mark.parametrize("open_loop,euler", [(False, True), (True, True), (False, False)])
 def test_strategy_costs_match_oracle_fp64(hip, oracle, cfg, open_loop, euler):
     spec, op, x0, r = _solved(oracle, cfg, 3, 2)

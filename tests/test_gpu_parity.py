@@ -192,7 +192,7 @@ def _clean(ref, max_bt=12):
 @pytest.mark.parametrize("cfg", ["modified_three_player_intersection", "three_player_intersection",
                                  "three_player_collision_avoidance_reachability", "two_player_unicycle_4d_scene",
                                  "two_player_reachability", "skeleton", "three_player_overtaking",
-                                 "one_player_reachability", "dubins_origin", "air_3d"])
+                                 "one_player_reachability", "dubins_origin", "air_3d", "modified_air_3d"])
 def test_ilq_solve_matches_oracle_fp64(hip, oracle, cfg):
     """Whole iLQ loop, fp64, fixed iteration count.  Where the line search is well conditioned the
     device makes the oracle's accept/reject decisions, so trajectories, strategies and costs agree
@@ -202,7 +202,7 @@ def test_ilq_solve_matches_oracle_fp64(hip, oracle, cfg):
     spec.params.expected_decrease_fraction = 0.001
     # reachability's line search is noise-limited from iteration 2; so is the overtaking example's (steering-rate
     # weight 5e5 against O(1) costs)
-    B, K = 12, (1 if ("reachability" in cfg or "overtaking" in cfg or cfg == "air_3d") else 6)
+    B, K = 12, (1 if ("reachability" in cfg or "overtaking" in cfg or cfg.endswith("air_3d")) else 6)
     x0 = examples.jittered_x0(spec, B, seed=11)
     ref = oracle.OracleProblem(spec).solve(abi.F64, x0, fixed_iters=K, merit_log_len=K)
     out = hip.Problem(spec, abi.F64).solve(x0, fixed_iters=K)

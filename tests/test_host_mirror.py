@@ -37,6 +37,7 @@ EXAMPLES = [
     ("OnePlayerReachabilityExample", "one_player_reachability_example", examples.one_player_reachability),
     ("DubinsOriginExample", "dubins_origin_example", examples.dubins_origin),
     ("Air3DExample", "air_3d_example", examples.air_3d),
+    ("ModifiedAir3DExample", "modified_air_3d_example", examples.modified_air_3d),
 ]
 
 
