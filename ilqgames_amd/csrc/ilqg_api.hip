@@ -20,9 +20,24 @@
 
 using namespace ilqg;
 
-namespace {
-
+// The library is built from several translation units of this one file (__graft_entry__.build): one "main" unit
+// with the C ABI and every kernel that does not depend on the (n, N, m_i) instantiation, and one unit per entry of
+// ILQG_FOR_DIMS (compiled with -DILQG_PART_NX/NP/MU) that holds DimsLaunch<T, n, N, m_i> and the kernels it
+// launches — they compile in parallel.  Without those macros the file is a single self-contained unit.
+// This is the state the units share.
+namespace ilqg_shared __attribute__((visibility("hidden"))) {
+#if defined(ILQG_PART_NX)
+extern thread_local std::string g_err;
+extern long long* g_prof;
+#else
 thread_local std::string g_err;
+long long* g_prof = nullptr;  // set through ilqg_debug_set_profile_buffer
+#endif
+}  // namespace ilqg_shared
+using ilqg_shared::g_err;
+using ilqg_shared::g_prof;
+
+namespace {
 
 ilqg_status fail(ilqg_status s, const std::string& msg) {
   g_err = msg;
@@ -260,8 +275,7 @@ struct Scratch {  // grow-only device scratch for entry points without a workspa
     return ILQG_OK;
   }
 };
-thread_local Scratch g_scratch;
-long long* g_prof = nullptr;  // set through ilqg_debug_set_profile_buffer
+thread_local Scratch g_scratch;  // one per translation unit
 
 // Large dynamic-LDS launches: ask for the opt-in limit; a refusal is not fatal by itself (the launch
 // reports the real error if the size is unusable), so it must not poison the sticky error state.
@@ -309,10 +323,28 @@ bool build_pairs(const ilqg_pair* pairs, int npairs, const int* udim, int N, Pai
 // (6,3,2): synthetic parity cases.
 #define ILQG_FOR_DIMS(X) X(14, 3, 2) X(16, 3, 2) X(15, 3, 2) X(24, 4, 2) X(18, 3, 2) X(12, 2, 2) X(10, 2, 2) X(4, 2, 2) X(6, 2, 1) X(3, 2, 1) X(3, 1, 1) X(2, 2, 1) X(6, 3, 2) X(2, 1, 2) X(8, 2, 2)
 
+}  // namespace
+
+// Launchers of the kernels that are instantiated per (n, N, m_i).  Members are defined out of class (not inline),
+// so `extern template struct DimsLaunch<...>` in the main unit of a split build leaves their code — and the
+// kernels behind them — to the unit that instantiates them explicitly.
 template <typename T, int NX, int NP, int MU>
-ilqg_status launch_lq(const ilqg_dims* d, const PairTable& pt, const void* A, const void* Bm, const void* Q,
-                      const void* l, const void* R, const void* r, const void* x0, void* P, void* alpha, void* dx,
-                      hipStream_t stream) {
+struct __attribute__((visibility("hidden"))) DimsLaunch {
+  static ilqg_status lq(const ilqg_dims* d, const PairTable& pt, const void* A, const void* Bm, const void* Q,
+                        const void* l, const void* R, const void* r, const void* x0, void* P, void* alpha, void* dx,
+                        hipStream_t stream);
+  static ilqg_status lq_openloop(const ilqg_dims* d, const PairTable& pt, const void* A, const void* Bm,
+                                 const void* Q, const void* l, const void* R, const void* r, const void* x0, void* P,
+                                 void* alpha, void* dx, hipStream_t stream);
+  static ilqg_status solve(ilqg_problem* p, int32_t batch, const void* x0, void* xs, void* us, void* P, void* alpha,
+                           void* total_costs, int32_t* iters, int32_t* status, int32_t* converged, void* workspace,
+                           int32_t fixed_iters, int al_mode, int resume, const int32_t* active, hipStream_t stream);
+};
+
+template <typename T, int NX, int NP, int MU>
+ilqg_status DimsLaunch<T, NX, NP, MU>::lq(const ilqg_dims* d, const PairTable& pt, const void* A, const void* Bm,
+                                          const void* Q, const void* l, const void* R, const void* r, const void* x0,
+                                          void* P, void* alpha, void* dx, hipStream_t stream) {
   using C = LQCfg<T, NX, NP, MU>;
   LQBatchArgs<T> g;
   g.A = (const T*)A; g.Bm = (const T*)Bm; g.Q = (const T*)Q; g.l = (const T*)l;
@@ -342,9 +374,10 @@ ilqg_status launch_lq(const ilqg_dims* d, const PairTable& pt, const void* A, co
 }
 
 template <typename T, int NX, int NP, int MU>
-ilqg_status launch_lq_openloop(const ilqg_dims* d, const PairTable& pt, const void* A, const void* Bm, const void* Q,
-                               const void* l, const void* R, const void* r, const void* x0, void* P, void* alpha,
-                               void* dx, hipStream_t stream) {
+ilqg_status DimsLaunch<T, NX, NP, MU>::lq_openloop(const ilqg_dims* d, const PairTable& pt, const void* A,
+                                                   const void* Bm, const void* Q, const void* l, const void* R,
+                                                   const void* r, const void* x0, void* P, void* alpha, void* dx,
+                                                   hipStream_t stream) {
   using C = LQCfg<T, NX, NP, MU>;
   using O = OLCfg<T, NX, NP, MU>;
   LQBatchArgs<T> g;
@@ -366,6 +399,8 @@ ilqg_status launch_lq_openloop(const ilqg_dims* d, const PairTable& pt, const vo
   HIP_TRY(hipGetLastError());
   return ILQG_OK;
 }
+
+namespace {
 
 bool uniform_udim(const int32_t* udim, int N, int* mu) {
   for (int i = 1; i < N; i++)
@@ -421,10 +456,10 @@ static ilqg_status launch_linquad(const ilqg_problem* p, int32_t batch, const vo
 }
 
 template <typename T, int NX, int NP, int MU>
-static ilqg_status launch_solve(ilqg_problem* p, int32_t batch, const void* x0, void* xs, void* us, void* P,
-                                void* alpha, void* total_costs, int32_t* iters, int32_t* status, int32_t* converged,
-                                void* workspace, int32_t fixed_iters, int al_mode, int resume, const int32_t* active,
-                                hipStream_t stream) {
+ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, const void* x0, void* xs, void* us,
+                                             void* P, void* alpha, void* total_costs, int32_t* iters, int32_t* status,
+                                             int32_t* converged, void* workspace, int32_t fixed_iters, int al_mode,
+                                             int resume, const int32_t* active, hipStream_t stream) {
   using C = LQCfg<T, NX, NP, MU>;
   const DevProblem& d = p->dev;
   static_assert(OLCfg<T, NX, NP, MU>::ROW == ((NX * NX + NX + NP * MU * NX + NP * MU + NP * NX * NX + 2 * NP * NX + 3) & ~3), "ol_row_elems");
@@ -504,6 +539,19 @@ static ilqg_status launch_solve(ilqg_problem* p, int32_t batch, const void* x0, 
   return ILQG_OK;
 }
 
+#if defined(ILQG_PART_NX)
+// instantiation unit of a split build: this (n, N, m_i) in both precisions, nothing else
+template struct DimsLaunch<float, ILQG_PART_NX, ILQG_PART_NP, ILQG_PART_MU>;
+template struct DimsLaunch<double, ILQG_PART_NX, ILQG_PART_NP, ILQG_PART_MU>;
+#else
+#if defined(ILQG_SPLIT_BUILD)
+#define X(NX_, NP_, MU_)                                   \
+  extern template struct DimsLaunch<float, NX_, NP_, MU_>; \
+  extern template struct DimsLaunch<double, NX_, NP_, MU_>;
+ILQG_FOR_DIMS(X)
+#undef X
+#endif
+
 extern "C" {
 
 const char* ilqg_last_error(void) { return g_err.c_str(); }
@@ -579,8 +627,8 @@ ilqg_status ilqg_lq_feedback_batch(const ilqg_dims* d, const void* A, const void
 #define X(NX_, NP_, MU_)                                                                              \
   if (d->n == NX_ && d->num_players == NP_ && mu == MU_) {                                            \
     return d->dtype == ILQG_F32                                                                       \
-               ? launch_lq<float, NX_, NP_, MU_>(d, pt, A, Bm, Q, l, R, r, x0, P, alpha, dx, st)      \
-               : launch_lq<double, NX_, NP_, MU_>(d, pt, A, Bm, Q, l, R, r, x0, P, alpha, dx, st);    \
+               ? DimsLaunch<float, NX_, NP_, MU_>::lq(d, pt, A, Bm, Q, l, R, r, x0, P, alpha, dx, st)      \
+               : DimsLaunch<double, NX_, NP_, MU_>::lq(d, pt, A, Bm, Q, l, R, r, x0, P, alpha, dx, st);    \
   }
   ILQG_FOR_DIMS(X)
 #undef X
@@ -612,8 +660,8 @@ ilqg_status ilqg_lq_openloop_batch(const ilqg_dims* d, const void* A, const void
 #define X(NX_, NP_, MU_)                                                                                      \
   if (d->n == NX_ && d->num_players == NP_ && mu == MU_) {                                                    \
     return d->dtype == ILQG_F32                                                                               \
-               ? launch_lq_openloop<float, NX_, NP_, MU_>(d, pt, A, Bm, Q, l, R, r, x0, P, alpha, dx, st)     \
-               : launch_lq_openloop<double, NX_, NP_, MU_>(d, pt, A, Bm, Q, l, R, r, x0, P, alpha, dx, st);   \
+               ? DimsLaunch<float, NX_, NP_, MU_>::lq_openloop(d, pt, A, Bm, Q, l, R, r, x0, P, alpha, dx, st)     \
+               : DimsLaunch<double, NX_, NP_, MU_>::lq_openloop(d, pt, A, Bm, Q, l, R, r, x0, P, alpha, dx, st);   \
   }
   ILQG_FOR_DIMS(X)
 #undef X
@@ -1016,9 +1064,9 @@ static ilqg_status solve_impl(ilqg_problem* p, int32_t batch, const void* x0, vo
 #define X(NX_, NP_, MU_)                                                                                        \
   if (d.n == NX_ && d.N == NP_ && p->mu_uniform == MU_) {                                                       \
     return p->desc.dtype == ILQG_F32                                                                            \
-               ? launch_solve<float, NX_, NP_, MU_>(p, batch, x0, xs, us, P, alpha, total_costs, iters, status,  \
+               ? DimsLaunch<float, NX_, NP_, MU_>::solve(p, batch, x0, xs, us, P, alpha, total_costs, iters, status,  \
                                                     converged, workspace, fixed_iters, al_mode, resume, active, st)                      \
-               : launch_solve<double, NX_, NP_, MU_>(p, batch, x0, xs, us, P, alpha, total_costs, iters, status, \
+               : DimsLaunch<double, NX_, NP_, MU_>::solve(p, batch, x0, xs, us, P, alpha, total_costs, iters, status, \
                                                      converged, workspace, fixed_iters, al_mode, resume, active, st);                    \
   }
   ILQG_FOR_DIMS(X)
@@ -1282,3 +1330,4 @@ ilqg_status ilqg_solution_splice_batch(const ilqg_problem* p, int32_t batch, int
 }
 
 }  // extern "C"
+#endif  // !ILQG_PART_NX
