@@ -180,6 +180,26 @@ def test_stage_kernels_match_oracle(hip, oracle, cfg, dtype):
     assert np.array_equal(_np(te_d), te_o)
 
 
+def test_problem_create_rejects_dynamics_the_kernels_do_not_cover(hip):
+    """Descriptor validation of ilqg_problem_create: the shared-state kinds only occur as their row pairs, point
+    masses only among point masses; the refusal is an error status with a message, never a silent fallback."""
+    def spec_of(kinds):
+        s = abi.ProblemSpec(T=10)
+        for k in kinds:
+            s.add_player(k, 1.0)
+        for i in range(len(kinds)):
+            s.quadratic(i, 1.0, -1, 0.0, control_of=i)
+        s.x0 = np.zeros(s.n)
+        return s
+    for kinds in ((abi.DYN_POINT_MASS_2D, abi.DYN_UNICYCLE_4D), (abi.DYN_UNICYCLE_4D, abi.DYN_POINT_MASS_2D),
+                  (abi.DYN_AIR_3D_EVADER, abi.DYN_DUBINS_CAR), (abi.DYN_PLANAR_DISTURBANCE, abi.DYN_UNICYCLE_4D_DISTURBED)):
+        with pytest.raises(hip.IlqgError) as e:
+            hip.Problem(spec_of(kinds), abi.F64)
+        assert e.value.status == abi.ERR_UNSUPPORTED, kinds
+        assert str(e.value)
+    hip.Problem(spec_of((abi.DYN_POINT_MASS_2D, abi.DYN_POINT_MASS_2D)), abi.F64)  # the covered case builds
+
+
 def _clean(ref, max_bt=12):
     """Instances whose line search never went below step ~ alpha0 * 2^-12.  Deeper back-tracking
     means the Armijo test `last - merit >= frac*step*ED` is decided by the last bits of two
