@@ -223,6 +223,57 @@ __global__ void __launch_bounds__(64 * W, W) ilq_trial_kernel(DevProblem p, Solv
   trial_part_instance<T, NX, NP, MU, W>(p, tb, sa, b, sm);
 }
 
+// The same pass cut into three launches (ilqg_solve.hpp, TRIAL_ROLL / rows_part_instance / TRIAL_DECIDE), for
+// problems whose fused trial kernel fits fewer than three instances on a CU.
+template <typename T, int NX, int NP, int MU>
+__global__ void __launch_bounds__(64) ilq_roll_kernel(DevProblem p, SolveArgs<T> sa) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int b = blockIdx.x;
+  if (!sa.first) {
+    const WsLayout L(p.n, p.m, p.N, p.T, p.pairs.Rsz, p.pairs.rsz, sa.ol_row, p.num_constraints, sa.al_mode);
+    const int stage = reinterpret_cast<const SolveState<T>*>(sa.ws + size_t(b) * sa.ws_stride + L.state)->stage;
+    if (stage != ST_ROLLOUT) return;
+  } else if (sa.active && !sa.active[b]) {
+    const WsLayout L(p.n, p.m, p.N, p.T, p.pairs.Rsz, p.pairs.rsz, sa.ol_row, p.num_constraints, sa.al_mode);
+    if (threadIdx.x == 0)
+      reinterpret_cast<SolveState<T>*>(sa.ws + size_t(b) * sa.ws_stride + L.state)->stage = ST_DONE;
+    return;
+  }
+  const QuadTables<T> no_tables{};
+  trial_part_instance<T, NX, NP, MU, 1, TRIAL_ROLL>(p, no_tables, sa, b, reinterpret_cast<T*>(smem_raw));
+}
+
+constexpr int kRowsPerBlock = 5;  // rows of one instance per workgroup of the row kernel (amortises the table load)
+
+template <typename T, int NX, int NP, int MU>
+__global__ void __launch_bounds__(64) ilq_rows_kernel(DevProblem p, SolveArgs<T> sa) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int b = blockIdx.y;
+  {
+    const WsLayout L(p.n, p.m, p.N, p.T, p.pairs.Rsz, p.pairs.rsz, sa.ol_row, p.num_constraints, sa.al_mode);
+    const int stage = reinterpret_cast<const SolveState<T>*>(sa.ws + size_t(b) * sa.ws_stride + L.state)->stage;
+    if (stage != ST_ROLLOUT && stage != ST_QUAD) return;
+  }
+  const QuadTables<T> tb = quad_tables_load<T>(p, smem_raw);
+  T* sm = reinterpret_cast<T*>(smem_raw + quad_tables_bytes(p, sizeof(T)));
+  const int k0 = int(blockIdx.x) * kRowsPerBlock;
+  const int k1 = k0 + kRowsPerBlock < p.T ? k0 + kRowsPerBlock : p.T;
+  rows_part_instance<T, NX, NP, MU>(p, tb, sa, b, k0, k1, sm);
+}
+
+template <typename T, int NX, int NP, int MU>
+__global__ void __launch_bounds__(64) ilq_decide_kernel(DevProblem p, SolveArgs<T> sa) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int b = blockIdx.x;
+  {
+    const WsLayout L(p.n, p.m, p.N, p.T, p.pairs.Rsz, p.pairs.rsz, sa.ol_row, p.num_constraints, sa.al_mode);
+    const int stage = reinterpret_cast<const SolveState<T>*>(sa.ws + size_t(b) * sa.ws_stride + L.state)->stage;
+    if (stage != ST_ROLLOUT && stage != ST_QUAD) return;
+  }
+  const QuadTables<T> no_tables{};
+  trial_part_instance<T, NX, NP, MU, 1, TRIAL_DECIDE>(p, no_tables, sa, b, reinterpret_cast<T*>(smem_raw));
+}
+
 // Exit kernel: return path of ILQSolver::Solve / AugmentedLagrangianSolver bookkeeping for the instances
 // whose inner solve has ended (converged, out of iterations, or line search exhausted).
 template <typename T, int NX, int NP, int MU>
@@ -501,21 +552,62 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   // makes a free-running solve synchronous with respect to `stream`.
   auto k_exit = ilq_exit_kernel<T, NX, NP, MU>;
   const size_t lds_exit = quad_tables_bytes(d, sizeof(T)) + 64 * sizeof(T);
-  const bool counted = !(fixed_iters > 0 && !al_mode);
-  const long long cap = al_mode ? (long long)(sa.prm.max_solver_iters + 1) * (sa.prm.unconstrained_solver_max_iters + 2)
-                                : (long long)sa.prm.max_solver_iters + 2;
+  // Split passes where the fused trial kernel's LDS leaves a CU with fewer than three instances (n = 24); the
+  // host then counts every round, because an instance may ask for another pass (back-tracking) before its sweep.
+  // ILQG_SPLIT_TRIAL=0/1 overrides the choice (A/B measurements).
+  bool split = 3 * lds_trial > size_t(160) * 1024;
+  if (const char* e = getenv("ILQG_SPLIT_TRIAL")) split = e[0] == '1';
+  if (kProfile) split = false;  // the phase profile reads the fused kernel's counters
+  const bool counted = split || !(fixed_iters > 0 && !al_mode);
+  long long cap = al_mode ? (long long)(sa.prm.max_solver_iters + 1) * (sa.prm.unconstrained_solver_max_iters + 2)
+                          : (long long)sa.prm.max_solver_iters + 2;
+  if (split) cap = (cap + 2) * ((long long)sa.prm.max_backtracking_steps + 3);
+  auto k_roll = ilq_roll_kernel<T, NX, NP, MU>;
+  auto k_rows = ilq_rows_kernel<T, NX, NP, MU>;
+  auto k_decide = ilq_decide_kernel<T, NX, NP, MU>;
+  const size_t lds_roll = trial_phase_lds_bytes<T>(d, TRIAL_ROLL), lds_decide = trial_phase_lds_bytes<T>(d, TRIAL_DECIDE);
+  const size_t lds_rows = quad_tables_bytes(d, sizeof(T)) + trial_phase_quad_elems<T>(d, TRIAL_FUSED) * sizeof(T);
+  if (split) {
+    raise_lds_limit((const void*)k_roll, lds_roll);
+    raise_lds_limit((const void*)k_rows, lds_rows);
+    raise_lds_limit((const void*)k_decide, lds_decide);
+  }
   sa.first = resume ? 2 : 1;
+  int waiting_lq = 0, waiting_exit = 0;  // split passes: instances already through this iteration's line search
   for (long long round = 0;; round++) {
     if (counted) HIP_TRY(hipMemsetAsync(p->d_unfinished, 0, 4 * sizeof(int), stream));
-    hipLaunchKernelGGL(k_trial, dim3(batch), dim3(64 * W), lds_trial, stream, d, sa);
+    if (split) {
+      hipLaunchKernelGGL(k_roll, dim3(batch), dim3(64), lds_roll, stream, d, sa);
+      HIP_TRY(hipGetLastError());
+      sa.first = 0;
+      hipLaunchKernelGGL(k_rows, dim3((d.T + kRowsPerBlock - 1) / kRowsPerBlock, batch), dim3(64), lds_rows, stream, d, sa);
+      HIP_TRY(hipGetLastError());
+      hipLaunchKernelGGL(k_decide, dim3(batch), dim3(64), lds_decide, stream, d, sa);
+    } else {
+      hipLaunchKernelGGL(k_trial, dim3(batch), dim3(64 * W), lds_trial, stream, d, sa);
+    }
     HIP_TRY(hipGetLastError());
     sa.first = 0;
-    int want_lq = 1, want_exit = 0, restarted = 0;
+    int want_lq = 1, want_exit = 0, restarted = 0, again = 0;
     if (counted) {
       HIP_TRY(hipMemcpyAsync(p->h_unfinished, p->d_unfinished, 4 * sizeof(int), hipMemcpyDeviceToHost, stream));
       HIP_TRY(hipStreamSynchronize(stream));
       want_lq = p->h_unfinished[0];
       want_exit = p->h_unfinished[1];
+      again = p->h_unfinished[3];
+      if (split) {
+        // keep the batch in step: the sweep is launched once per iteration, when the last back-tracking instance
+        // has made up its mind (a sweep launch with a handful of instances costs a full sweep's latency)
+        waiting_lq += want_lq;
+        waiting_exit += want_exit;
+        if (again) {
+          if (round > cap) return fail(ILQG_ERR_HIP, "solve did not terminate within its iteration bound");
+          continue;
+        }
+        want_lq = waiting_lq;
+        want_exit = waiting_exit;
+        waiting_lq = waiting_exit = 0;
+      }
     } else if (round == fixed_iters) {
       want_lq = 0;
       want_exit = 1;

@@ -38,7 +38,7 @@ struct SolveArgs {
   ilqg_solver_params prm;
   long long* prof;      // optional [B][16] shader-clock cycles (diagnostics) or nullptr
   int first;            // trial kernel: 1 on the first launch of a solve (initialises the state)
-  int* unfinished;      // [3] instances left waiting for: an LQ sweep, the exit path, a restart (AL)
+  int* unfinished;      // [4] instances left waiting for: an LQ sweep, the exit path, a restart (AL), another pass
 };
 
 // Elements of one open-loop scratch row ([X|y|W|w|M|m|Q l], OLCfg::ROW) from run-time dimensions.
@@ -298,10 +298,83 @@ __device__ __forceinline__ void exit_part_instance(const DevProblem& p, const Qu
 
 // ---------------------------------------------------------------------------
 // Trial part.  Runs while the instance's stage is ROLLOUT or QUAD; W = wavefronts per instance.
+//
+// PHASE selects how much of one pass a kernel carries.  TRIAL_FUSED: everything, passes repeated inside the
+// launch until the instance wants a sweep or its exit path (the default).  For problems whose linearise /
+// quadraticise scratch leaves a CU with one or two instances (n = 24: 78 KB), the serial rollout of so few
+// resident instances is what the launch waits for; there the pass is cut into three launches instead —
+// TRIAL_ROLL (one wave per instance, LDS for the rollout only, so a CU holds many), the row kernel
+// (rows_part_instance: one workgroup per block of rows, every row of the batch in flight) and TRIAL_DECIDE
+// (reductions and the line-search decision) — and the host repeats them while instances ask for another pass.
 // ---------------------------------------------------------------------------
-template <typename T, int NX, int NP, int MU, int W>
+enum { TRIAL_FUSED = 0, TRIAL_ROLL = 1, TRIAL_DECIDE = 2 };
+
+// linearise / quadraticise scratch per wave of a trial-part kernel (TRIAL_DECIDE only needs the reductions' copy
+// of the per-row partials, TRIAL_ROLL nothing)
+template <typename T>
+__host__ __device__ inline size_t trial_phase_quad_elems(const DevProblem& p, int phase) {
+  if (phase == TRIAL_ROLL) return 0;
+  if (phase == TRIAL_DECIDE) return (size_t(p.T) * p.N * 2 + 8 + 3) & ~size_t(3);
+  return (quad_lds_elems(p.n, p.m, p.N, p.pairs.Rsz, p.pairs.rsz, p.num_terms) + 3) & ~size_t(3);
+}
+template <typename T>
+__host__ __device__ inline size_t trial_phase_lds_bytes(const DevProblem& p, int phase) {  // W = 1, no cost tables
+  const size_t re = (rollout_lds_elems(p.n, p.m) + 3) & ~size_t(3);
+  return (re + trial_phase_quad_elems<T>(p, phase)) * sizeof(T) + 16;
+}
+
+// What the rows of a pass are asked for, from the instance's state (the pass's rollout, if any, is done).
+template <typename T>
+__device__ __forceinline__ QuadArgs<T> trial_quad_args(const DevProblem& p, const InstanceBuffers<T>& ib,
+                                                       const SolveState<T>& s) {
+  const WsLayout& L = ib.L;
+  T* const w = ib.w;
+  const int qmode = s.qmode;
+  const int at = (qmode == Q_COSTS || qmode == Q_INIT) ? s.cur : 1 - s.cur;
+  QuadArgs<T> qa;
+  qa.xs = ib.XS(at);
+  qa.us = ib.US(at);
+  qa.lambdas = p.num_constraints > 0 ? w + L.lambdas : nullptr;
+  qa.mu = s.mu;
+  qa.t_extreme = ib.t_extreme();
+  qa.t_init = 0.0;
+  const bool lin = qmode != Q_COSTS, quad = qmode == Q_INIT || qmode == Q_TRIAL;
+  qa.A = lin ? w + L.A : nullptr;
+  qa.Bm = lin ? w + L.B : nullptr;
+  qa.Q = quad ? w + L.Q : nullptr;
+  qa.l = quad ? w + L.l : nullptr;
+  qa.R = quad ? w + L.R : nullptr;
+  qa.r = quad ? w + L.r : nullptr;
+  qa.merit_part = qmode == Q_TRIAL ? w + L.mpart : nullptr;
+  qa.cost_part = (qmode == Q_COSTS || qmode == Q_TRIAL || qmode == Q_LIN) ? w + L.cpart : nullptr;
+  qa.phacc = nullptr;
+  return qa;
+}
+
+// Row kernel of the split pass: rows [k0, k1) of instance b, one wave with its own scratch.
+template <typename T, int NX, int NP, int MU>
+__device__ __forceinline__ void rows_part_instance(const DevProblem& p, const QuadTables<T>& tb, const SolveArgs<T>& sa,
+                                                   int b, int k0, int k1, T* sm) {
+  const InstanceBuffers<T> ib(p, sa, b);
+  const SolveState<T> s = state_load<T>(ib.w, ib.L);
+  const QuadArgs<T> qa = trial_quad_args<T>(p, ib, s);
+  const int lane = threadIdx.x;
+  constexpr int n = NX, m = NP * MU;
+  T argv = linquad_load_arg<T>(qa, k0, n, m, lane);
+#pragma unroll 1
+  for (int k = k0; k < k1; k++) {
+    LinquadCarry<T> carry;
+    linquad_compute<T, NX, NP * MU, NP>(p, tb, qa, k, sm, lane, argv, carry);
+    const T argn = k + 1 < k1 ? linquad_load_arg<T>(qa, k + 1, n, m, lane) : T(0);
+    linquad_store<T, NX, NP * MU, NP>(p, qa, k, sm, lane, carry);
+    argv = argn;
+  }
+}
+
+template <typename T, int NX, int NP, int MU, int W, int PHASE = TRIAL_FUSED>
 __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const QuadTables<T>& tb,
                                                     const SolveArgs<T>& sa, int b, T* sm) {
+  static_assert(PHASE == TRIAL_FUSED || W == 1, "the split phases run one wave per instance");
   constexpr int n = NX, N = NP, m = NP * MU;
   const int Tn = p.T;
   const ilqg_solver_params& prm = sa.prm;
@@ -314,7 +387,7 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const Q
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
 
   const size_t re = (rollout_lds_elems(n, m) + 3) & ~size_t(3);
-  const size_t qe = (quad_lds_elems(n, m, N, p.pairs.Rsz, p.pairs.rsz, p.num_terms) + 3) & ~size_t(3);
+  const size_t qe = trial_phase_quad_elems<T>(p, PHASE);
   T* const sm_roll = sm;
   T* const sm_quad = sm + re + size_t(wave) * qe;
   T* const sm_quad0 = sm + re;  // wave 0's linquad scratch doubles as reduction scratch between passes
@@ -351,7 +424,7 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const Q
 #pragma unroll 1
   while (s.stage == ST_ROLLOUT || s.stage == ST_QUAD) {
     __syncthreads();  // pass boundary: global-memory hand-off between waves
-    const bool roll = s.stage == ST_ROLLOUT;
+    const bool roll = PHASE != TRIAL_DECIDE && s.stage == ST_ROLLOUT;  // TRIAL_DECIDE: the pass's rollout is behind it
     RolloutArgs<T> ra;
     if (roll) {
       // initial: from the warm start (:100-104); later: trial point of the line search (:309-342)
@@ -385,26 +458,12 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const Q
       if (t == 0) flags[0] = Tn;
       __syncthreads();
     }
+    if (PHASE == TRIAL_ROLL) break;  // state (cur, qmode) goes to memory below; the row kernel takes over
 
     // ---- linearise / quadraticise the trajectory: every wave claims rows as they become ready ----
     const int qmode = s.qmode;
-    const int at = (qmode == Q_COSTS || qmode == Q_INIT) ? s.cur : 1 - s.cur;
-    QuadArgs<T> qa;
-    qa.xs = ib.XS(at);
-    qa.us = ib.US(at);
-    qa.lambdas = p.num_constraints > 0 ? lambdas : nullptr;
-    qa.mu = s.mu;
-    qa.t_extreme = t_extreme;
-    qa.t_init = 0.0;
-    const bool lin = qmode != Q_COSTS, quad = qmode == Q_INIT || qmode == Q_TRIAL;
-    qa.A = lin ? w + L.A : nullptr;
-    qa.Bm = lin ? w + L.B : nullptr;
-    qa.Q = quad ? w + L.Q : nullptr;
-    qa.l = quad ? w + L.l : nullptr;
-    qa.R = quad ? w + L.R : nullptr;
-    qa.r = quad ? w + L.r : nullptr;
-    qa.merit_part = qmode == Q_TRIAL ? w + L.mpart : nullptr;
-    qa.cost_part = (qmode == Q_COSTS || qmode == Q_TRIAL || qmode == Q_LIN) ? w + L.cpart : nullptr;
+    if (PHASE == TRIAL_FUSED) {
+    QuadArgs<T> qa = trial_quad_args<T>(p, ib, s);
     qa.phacc = (kProfile && sa.prof) ? qph : nullptr;
     long long tq0 = (kProfile && sa.prof) ? clock64() : 0;
     // Claim rows as they become ready.  The next row's argument is requested before this row's stores
@@ -430,6 +489,7 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const Q
       if (kProfile && sa.prof) { tq0 = clock64(); qph[7] += 1; }
       k = kn;
       argv = argn;
+    }
     }
 
     // ---- reductions and the line-search decision (wave-uniform, identical on every wave) ----
@@ -473,9 +533,13 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const Q
         }
       }
     }
+    if (PHASE == TRIAL_DECIDE) break;  // another pass, if the instance needs one, is the host's to launch
   }
   state_store<T>(w, L, s);
-  if (t == 0) atomicAdd(sa.unfinished + (s.stage == ST_LQ ? 0 : 1), 1);  // wants a sweep / wants the exit path
+  if (PHASE == TRIAL_ROLL) return;
+  // wants a sweep / wants the exit path / (split passes only) wants another pass
+  if (t == 0)
+    atomicAdd(sa.unfinished + (s.stage == ST_LQ ? 0 : (s.stage == ST_ROLLOUT || s.stage == ST_QUAD) ? 3 : 1), 1);
   if (kProfile && t == 0 && sa.prof) sa.prof[size_t(b) * 96 + 1] += clock64() - pr_start;
   if (kProfile && t == 0 && sa.prof) {
 #pragma unroll
