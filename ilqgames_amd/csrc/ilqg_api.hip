@@ -228,7 +228,7 @@ __global__ void __launch_bounds__(64 * W, W) ilq_trial_kernel(DevProblem p, Solv
 template <typename T, int NX, int NP, int MU>
 __global__ void __launch_bounds__(64) ilq_roll_kernel(DevProblem p, SolveArgs<T> sa) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  const int b = blockIdx.x;
+  const int b = sa.ids ? sa.ids[blockIdx.x] : int(blockIdx.x);
   if (!sa.first) {
     const WsLayout L(p.n, p.m, p.N, p.T, p.pairs.Rsz, p.pairs.rsz, sa.ol_row, p.num_constraints, sa.al_mode);
     const int stage = reinterpret_cast<const SolveState<T>*>(sa.ws + size_t(b) * sa.ws_stride + L.state)->stage;
@@ -243,12 +243,15 @@ __global__ void __launch_bounds__(64) ilq_roll_kernel(DevProblem p, SolveArgs<T>
   trial_part_instance<T, NX, NP, MU, 1, TRIAL_ROLL>(p, no_tables, sa, b, reinterpret_cast<T*>(smem_raw));
 }
 
-constexpr int kRowsPerBlock = 5;  // rows of one instance per workgroup of the row kernel (amortises the table load)
+// rows of one instance per workgroup of the row kernel: five amortise the table load when the whole batch is in
+// flight; a round with a few back-tracking instances left takes one row per workgroup (latency is all that counts)
+constexpr int kRowsPerBlock = 5;
+constexpr int kFewInstances = 512;
 
 template <typename T, int NX, int NP, int MU>
 __global__ void __launch_bounds__(64) ilq_rows_kernel(DevProblem p, SolveArgs<T> sa) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  const int b = blockIdx.y;
+  const int b = sa.ids ? sa.ids[blockIdx.y] : int(blockIdx.y);
   {
     const WsLayout L(p.n, p.m, p.N, p.T, p.pairs.Rsz, p.pairs.rsz, sa.ol_row, p.num_constraints, sa.al_mode);
     const int stage = reinterpret_cast<const SolveState<T>*>(sa.ws + size_t(b) * sa.ws_stride + L.state)->stage;
@@ -256,15 +259,15 @@ __global__ void __launch_bounds__(64) ilq_rows_kernel(DevProblem p, SolveArgs<T>
   }
   const QuadTables<T> tb = quad_tables_load<T>(p, smem_raw);
   T* sm = reinterpret_cast<T*>(smem_raw + quad_tables_bytes(p, sizeof(T)));
-  const int k0 = int(blockIdx.x) * kRowsPerBlock;
-  const int k1 = k0 + kRowsPerBlock < p.T ? k0 + kRowsPerBlock : p.T;
+  const int k0 = int(blockIdx.x) * sa.rows_per_block;
+  const int k1 = k0 + sa.rows_per_block < p.T ? k0 + sa.rows_per_block : p.T;
   rows_part_instance<T, NX, NP, MU>(p, tb, sa, b, k0, k1, sm);
 }
 
 template <typename T, int NX, int NP, int MU>
 __global__ void __launch_bounds__(64) ilq_decide_kernel(DevProblem p, SolveArgs<T> sa) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  const int b = blockIdx.x;
+  const int b = sa.ids ? sa.ids[blockIdx.x] : int(blockIdx.x);
   {
     const WsLayout L(p.n, p.m, p.N, p.T, p.pairs.Rsz, p.pairs.rsz, sa.ol_row, p.num_constraints, sa.al_mode);
     const int stage = reinterpret_cast<const SolveState<T>*>(sa.ws + size_t(b) * sa.ws_stride + L.state)->stage;
@@ -481,6 +484,8 @@ struct ilqg_problem {
   int* d_cost_order = nullptr;
   int* d_unfinished = nullptr;  // instances still running after an LQ-kernel launch
   int* h_unfinished = nullptr;  // pinned host mirror
+  int* d_pass_ids = nullptr;    // split passes: two lists of instances that need another pass (this round's, the next's)
+  int pass_ids_capacity = 0;
   int mu_uniform = 0;
 };
 
@@ -530,6 +535,9 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
     HIP_TRY(hipHostMalloc(&p->h_unfinished, 4 * sizeof(int)));
   }
   sa.unfinished = p->d_unfinished;
+  sa.ids = nullptr;
+  sa.ids_next = nullptr;
+  sa.rows_per_block = kRowsPerBlock;
   constexpr int W = TrialWaves<T>::W;
   // LDS of the sweep kernel that will run: the open-loop sweep's own working set plus the slot the expected
   // decrease is handed over in (n = 24: 54 KB, three instances per CU; the feedback layout would take 85 KB)
@@ -567,6 +575,14 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   auto k_decide = ilq_decide_kernel<T, NX, NP, MU>;
   const size_t lds_roll = trial_phase_lds_bytes<T>(d, TRIAL_ROLL), lds_decide = trial_phase_lds_bytes<T>(d, TRIAL_DECIDE);
   const size_t lds_rows = quad_tables_bytes(d, sizeof(T)) + trial_phase_quad_elems<T>(d, TRIAL_FUSED) * sizeof(T);
+  if (split && p->pass_ids_capacity < batch) {
+    if (p->d_pass_ids) (void)hipFree(p->d_pass_ids);
+    p->d_pass_ids = nullptr;
+    p->pass_ids_capacity = 0;
+    HIP_TRY(hipMalloc(&p->d_pass_ids, size_t(2) * batch * sizeof(int)));
+    p->pass_ids_capacity = batch;
+  }
+  int round_instances = batch, list = 0;  // split passes: how many instances this round covers, which list is free
   if (split) {
     raise_lds_limit((const void*)k_roll, lds_roll);
     raise_lds_limit((const void*)k_rows, lds_rows);
@@ -577,12 +593,15 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   for (long long round = 0;; round++) {
     if (counted) HIP_TRY(hipMemsetAsync(p->d_unfinished, 0, 4 * sizeof(int), stream));
     if (split) {
-      hipLaunchKernelGGL(k_roll, dim3(batch), dim3(64), lds_roll, stream, d, sa);
+      sa.ids_next = p->d_pass_ids + size_t(list) * p->pass_ids_capacity;
+      sa.rows_per_block = round_instances < kFewInstances ? 1 : kRowsPerBlock;
+      hipLaunchKernelGGL(k_roll, dim3(round_instances), dim3(64), lds_roll, stream, d, sa);
       HIP_TRY(hipGetLastError());
       sa.first = 0;
-      hipLaunchKernelGGL(k_rows, dim3((d.T + kRowsPerBlock - 1) / kRowsPerBlock, batch), dim3(64), lds_rows, stream, d, sa);
+      hipLaunchKernelGGL(k_rows, dim3((d.T + sa.rows_per_block - 1) / sa.rows_per_block, round_instances), dim3(64),
+                         lds_rows, stream, d, sa);
       HIP_TRY(hipGetLastError());
-      hipLaunchKernelGGL(k_decide, dim3(batch), dim3(64), lds_decide, stream, d, sa);
+      hipLaunchKernelGGL(k_decide, dim3(round_instances), dim3(64), lds_decide, stream, d, sa);
     } else {
       hipLaunchKernelGGL(k_trial, dim3(batch), dim3(64 * W), lds_trial, stream, d, sa);
     }
@@ -600,10 +619,15 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
         // has made up its mind (a sweep launch with a handful of instances costs a full sweep's latency)
         waiting_lq += want_lq;
         waiting_exit += want_exit;
-        if (again) {
+        if (again) {  // the next round covers the listed instances only
           if (round > cap) return fail(ILQG_ERR_HIP, "solve did not terminate within its iteration bound");
+          sa.ids = sa.ids_next;
+          round_instances = again;
+          list ^= 1;
           continue;
         }
+        sa.ids = nullptr;
+        round_instances = batch;
         want_lq = waiting_lq;
         want_exit = waiting_exit;
         waiting_lq = waiting_exit = 0;
@@ -1065,6 +1089,7 @@ void ilqg_problem_destroy(ilqg_problem* p) {
   if (p->d_cost_order) (void)hipFree(p->d_cost_order);
   if (p->d_unfinished) (void)hipFree(p->d_unfinished);
   if (p->h_unfinished) (void)hipHostFree(p->h_unfinished);
+  if (p->d_pass_ids) (void)hipFree(p->d_pass_ids);
   delete p;
 }
 

@@ -39,6 +39,11 @@ struct SolveArgs {
   long long* prof;      // optional [B][16] shader-clock cycles (diagnostics) or nullptr
   int first;            // trial kernel: 1 on the first launch of a solve (initialises the state)
   int* unfinished;      // [4] instances left waiting for: an LQ sweep, the exit path, a restart (AL), another pass
+  // split passes only: the instances of this round (null: all of the batch, in order), where the decision kernel
+  // lists the ones that need another pass, and the rows of one instance a workgroup of the row kernel takes
+  const int* ids;
+  int* ids_next;
+  int rows_per_block;
 };
 
 // Elements of one open-loop scratch row ([X|y|W|w|M|m|Q l], OLCfg::ROW) from run-time dimensions.
@@ -538,8 +543,11 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const Q
   state_store<T>(w, L, s);
   if (PHASE == TRIAL_ROLL) return;
   // wants a sweep / wants the exit path / (split passes only) wants another pass
-  if (t == 0)
-    atomicAdd(sa.unfinished + (s.stage == ST_LQ ? 0 : (s.stage == ST_ROLLOUT || s.stage == ST_QUAD) ? 3 : 1), 1);
+  if (t == 0) {
+    const int slot = s.stage == ST_LQ ? 0 : (s.stage == ST_ROLLOUT || s.stage == ST_QUAD) ? 3 : 1;
+    const int at = atomicAdd(sa.unfinished + slot, 1);
+    if (PHASE == TRIAL_DECIDE && slot == 3 && sa.ids_next) sa.ids_next[at] = b;
+  }
   if (kProfile && t == 0 && sa.prof) sa.prof[size_t(b) * 96 + 1] += clock64() - pr_start;
   if (kProfile && t == 0 && sa.prof) {
 #pragma unroll
