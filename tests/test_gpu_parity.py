@@ -349,6 +349,33 @@ def test_augmented_lagrangian_solve_matches_oracle_fp64(hip, oracle):
     assert np.isfinite(_np(out["xs"])).all()
 
 
+@pytest.mark.parametrize("cfg,al,dtype", [("modified_three_player_intersection", False, abi.F64),
+                                          ("modified_three_player_intersection", False, abi.F32),
+                                          ("three_player_intersection", True, abi.F64),
+                                          ("roundabout_merging", False, abi.F64),
+                                          ("one_player_reachability", True, abi.F64)])
+def test_split_trial_pass_is_the_fused_kernel_bit_for_bit(hip, cfg, al, dtype, monkeypatch):
+    """The three-launch form of the trial pass (rollout / rows / decision kernels, chosen by LDS footprint or
+    ILQG_SPLIT_TRIAL) runs the same functions on the same data as the fused kernel: free-running solves — line
+    searches with back-tracking, convergence exits, the augmented-Lagrangian restarts — must come back identical
+    in every output, status word and iteration count."""
+    spec = examples.CONFIGS[cfg]()
+    spec.params.max_solver_iters = 12
+    spec.params.unconstrained_solver_max_iters = 4
+    B = 9
+    x0 = examples.jittered_x0(spec, B, seed=3)
+    outs = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("ILQG_SPLIT_TRIAL", mode)
+        out = hip.Problem(spec, dtype).solve(x0, augmented_lagrangian=al)
+        outs.append({k: _np(v).copy() for k, v in out.items() if hasattr(v, "shape") and k != "ws"})
+    fused, split = outs
+    assert set(fused) == set(split)
+    for k in fused:
+        assert np.array_equal(fused[k], split[k], equal_nan=True), k
+    assert fused["iters"].max() >= 2
+
+
 def test_augmented_lagrangian_single_player_dubins_fp64(hip, oracle):
     """OnePlayerReachabilityExample through AugmentedLagrangianSolver: one player, one control, two box constraints on
     it, a max-over-time cost — the N = 1, m = 1 corner of every kernel.  Log length, flags and costs must agree
