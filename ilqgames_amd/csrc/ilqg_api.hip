@@ -277,6 +277,41 @@ __global__ void __launch_bounds__(64) ilq_decide_kernel(DevProblem p, SolveArgs<
   trial_part_instance<T, NX, NP, MU, 1, TRIAL_DECIDE>(p, no_tables, sa, b, reinterpret_cast<T*>(smem_raw));
 }
 
+// Speculative line search of the listed instances (ilqg_solve.hpp): candidate j of list entry `slot`.
+template <typename T, int NX, int NP, int MU>
+__global__ void __launch_bounds__(64) ilq_probe_roll_kernel(DevProblem p, SolveArgs<T> sa) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  probe_roll_instance<T, NX, NP, MU>(p, sa, sa.ids[blockIdx.x], blockIdx.x, blockIdx.y, reinterpret_cast<T*>(smem_raw));
+}
+
+template <typename T, int NX, int NP, int MU>
+__global__ void __launch_bounds__(64) ilq_probe_rows_kernel(DevProblem p, SolveArgs<T> sa) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int slot = blockIdx.y / kProbeCandidates, j = blockIdx.y % kProbeCandidates;
+  const int b = sa.ids[slot];
+  {  // leave before the table load if this candidate is not wanted
+    const WsLayout L(p.n, p.m, p.N, p.T, p.pairs.Rsz, p.pairs.rsz, sa.ol_row, p.num_constraints, sa.al_mode);
+    const SolveState<T> s = state_load<T>(sa.ws + size_t(b) * sa.ws_stride, L);
+    if (!probe_wanted(sa, s, j)) return;
+  }
+  const QuadTables<T> tb = quad_tables_load<T>(p, smem_raw);
+  T* sm = reinterpret_cast<T*>(smem_raw + quad_tables_bytes(p, sizeof(T)));
+  const int k0 = int(blockIdx.x) * sa.rows_per_block;
+  const int k1 = k0 + sa.rows_per_block < p.T ? k0 + sa.rows_per_block : p.T;
+  probe_rows_instance<T, NX, NP, MU>(p, tb, sa, b, slot, j, k0, k1, sm);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(64) ilq_probe_merit_kernel(DevProblem p, SolveArgs<T> sa, int sm_elems) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  probe_merit_instance<T>(p, sa, sa.ids[blockIdx.x], blockIdx.x, blockIdx.y, reinterpret_cast<T*>(smem_raw), sm_elems);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(64) ilq_probe_pick_kernel(DevProblem p, SolveArgs<T> sa) {
+  probe_pick_instance<T>(p, sa, sa.ids[blockIdx.x], blockIdx.x);
+}
+
 // Exit kernel: return path of ILQSolver::Solve / AugmentedLagrangianSolver bookkeeping for the instances
 // whose inner solve has ended (converged, out of iterations, or line search exhausted).
 template <typename T, int NX, int NP, int MU>
@@ -486,6 +521,7 @@ struct ilqg_problem {
   int* h_unfinished = nullptr;  // pinned host mirror
   int* d_pass_ids = nullptr;    // split passes: two lists of instances that need another pass (this round's, the next's)
   int pass_ids_capacity = 0;
+  void* d_probe_pool = nullptr;  // speculative line search: kProbeSlots x kProbeCandidates trajectories + merit partials
   int mu_uniform = 0;
 };
 
@@ -538,6 +574,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   sa.ids = nullptr;
   sa.ids_next = nullptr;
   sa.rows_per_block = kRowsPerBlock;
+  sa.probe_pool = nullptr;
   constexpr int W = TrialWaves<T>::W;
   // LDS of the sweep kernel that will run: the open-loop sweep's own working set plus the slot the expected
   // decrease is handed over in (n = 24: 54 KB, three instances per CU; the feedback layout would take 85 KB)
@@ -582,11 +619,22 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
     HIP_TRY(hipMalloc(&p->d_pass_ids, size_t(2) * batch * sizeof(int)));
     p->pass_ids_capacity = batch;
   }
+  // ILQG_PROBE=0 switches the speculative line search off (A/B measurements)
+  const bool probe = split && sa.prm.linesearch && !(getenv("ILQG_PROBE") && getenv("ILQG_PROBE")[0] == '0');
+  if (probe && !p->d_probe_pool)
+    HIP_TRY(hipMalloc(&p->d_probe_pool,
+                      size_t(kProbeSlots) * kProbeCandidates * ProbeEntry(d.n, d.m, d.N, d.T).total * sizeof(T)));
+  sa.probe_pool = (T*)p->d_probe_pool;
+  auto k_proll = ilq_probe_roll_kernel<T, NX, NP, MU>;
+  auto k_prows = ilq_probe_rows_kernel<T, NX, NP, MU>;
+  const int decide_elems = int(trial_phase_quad_elems<T>(d, TRIAL_DECIDE));
   int round_instances = batch, list = 0;  // split passes: how many instances this round covers, which list is free
   if (split) {
     raise_lds_limit((const void*)k_roll, lds_roll);
     raise_lds_limit((const void*)k_rows, lds_rows);
     raise_lds_limit((const void*)k_decide, lds_decide);
+    raise_lds_limit((const void*)k_proll, lds_roll);
+    raise_lds_limit((const void*)k_prows, lds_rows);
   }
   sa.first = resume ? 2 : 1;
   int waiting_lq = 0, waiting_exit = 0;  // split passes: instances already through this iteration's line search
@@ -595,6 +643,19 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
     if (split) {
       sa.ids_next = p->d_pass_ids + size_t(list) * p->pass_ids_capacity;
       sa.rows_per_block = round_instances < kFewInstances ? 1 : kRowsPerBlock;
+      if (probe && sa.ids && round_instances <= kProbeSlots) {
+        // the listed instances' next step sizes side by side; their states move to the first acceptable one
+        hipLaunchKernelGGL(k_proll, dim3(round_instances, kProbeCandidates), dim3(64), lds_roll, stream, d, sa);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(k_prows, dim3((d.T + sa.rows_per_block - 1) / sa.rows_per_block,
+                                         round_instances * kProbeCandidates), dim3(64), lds_rows, stream, d, sa);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(ilq_probe_merit_kernel<T>, dim3(round_instances, kProbeCandidates), dim3(64),
+                           size_t(decide_elems) * sizeof(T), stream, d, sa, decide_elems);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(ilq_probe_pick_kernel<T>, dim3(round_instances), dim3(64), 0, stream, d, sa);
+        HIP_TRY(hipGetLastError());
+      }
       hipLaunchKernelGGL(k_roll, dim3(round_instances), dim3(64), lds_roll, stream, d, sa);
       HIP_TRY(hipGetLastError());
       sa.first = 0;
@@ -1090,6 +1151,7 @@ void ilqg_problem_destroy(ilqg_problem* p) {
   if (p->d_unfinished) (void)hipFree(p->d_unfinished);
   if (p->h_unfinished) (void)hipHostFree(p->h_unfinished);
   if (p->d_pass_ids) (void)hipFree(p->d_pass_ids);
+  if (p->d_probe_pool) (void)hipFree(p->d_probe_pool);
   delete p;
 }
 

@@ -44,6 +44,7 @@ struct SolveArgs {
   const int* ids;
   int* ids_next;
   int rows_per_block;
+  T* probe_pool;        // speculative line search: [slots][kProbeCandidates] entries of ProbeEntry::total elements
 };
 
 // Elements of one open-loop scratch row ([X|y|W|w|M|m|Q l], OLCfg::ROW) from run-time dimensions.
@@ -374,6 +375,146 @@ __device__ __forceinline__ void rows_part_instance(const DevProblem& p, const Qu
     linquad_store<T, NX, NP * MU, NP>(p, qa, k, sm, lane, carry);
     argv = argn;
   }
+}
+
+// ---------------------------------------------------------------------------
+// Speculative line search (split passes).  A back-tracking instance tries its step sizes one pass at a time, and a
+// pass of one instance costs the latency of a serial rollout however empty the chip is.  Given the sweep's
+// strategies the candidates are independent, so the next kProbeCandidates step sizes of every listed instance are
+// rolled out side by side into a small pool (trajectory + merit partials; the rows run in merit-only mode, nothing
+// else is stored), and the instance's step is moved to the first candidate CheckArmijoCondition accepts — with the
+// rejections counted as if they had been tried one by one.  The regular pass that follows evaluates that
+// candidate again with all outputs and accepts it: same arithmetic, same decisions, fewer rounds.
+// ---------------------------------------------------------------------------
+constexpr int kProbeCandidates = 8;
+constexpr int kProbeSlots = 256;  // instances of a round that can be probed (the pool's size)
+
+struct ProbeEntry {
+  size_t xs, us, mpart, merit, total;
+  __host__ __device__ ProbeEntry(int n, int m, int N, int T) {
+    auto al = [](size_t e) { return (e + 3) & ~size_t(3); };
+    xs = 0;
+    us = xs + al(size_t(T) * n);
+    mpart = us + al(size_t(T) * m);
+    merit = mpart + al(size_t(T) * N * 2);
+    total = merit + 4;
+  }
+};
+
+// Is instance state `s` in a line search that has already rejected a step, and is candidate j one the sequential
+// loop would reach (ILQSolver::ModifyLQStrategies gives up after max_backtracking_steps rejections)?
+template <typename T>
+__device__ __forceinline__ bool probe_wanted(const SolveArgs<T>& sa, const SolveState<T>& s, int j) {
+  return s.stage == ST_ROLLOUT && !s.initial && sa.prm.linesearch && s.bt > 0 &&
+         s.bt + j < sa.prm.max_backtracking_steps;
+}
+template <typename T>
+__device__ __forceinline__ T probe_step(const SolveArgs<T>& sa, const SolveState<T>& s, int j) {
+  T step = s.step;
+  for (int i = 0; i < j; i++) step *= T(sa.prm.geometric_alpha_scaling);  // the products the loop forms, in order
+  return step;
+}
+
+template <typename T, int NX, int NP, int MU>
+__device__ __forceinline__ void probe_roll_instance(const DevProblem& p, const SolveArgs<T>& sa, int b, int slot, int j,
+                                                    T* sm) {
+  const InstanceBuffers<T> ib(p, sa, b);
+  const SolveState<T> s = state_load<T>(ib.w, ib.L);
+  if (!probe_wanted(sa, s, j)) return;
+  const ProbeEntry E(p.n, p.m, p.N, p.T);
+  T* const e = sa.probe_pool + (size_t(slot) * kProbeCandidates + j) * E.total;
+  const int snew = 1 - s.sacc;
+  RolloutArgs<T> ra;
+  ra.x0 = ib.XS(s.cur);
+  ra.xs_ref = ib.XS(s.cur);
+  ra.us_ref = ib.US(s.cur);
+  ra.P = ib.PB(snew);
+  ra.alpha = ib.AL(snew);
+  ra.alpha_scale = probe_step(sa, s, j);
+  ra.xs = e + E.xs;
+  ra.us = e + E.us;
+  rollout_instance<T, NX, NP * MU, (NX == 4 && NP == 2), (MU == 1), (NX == 3 && NP == 2 && MU == 1),
+                   (NX == 4 * NP && MU == 2 && NP <= 2)>(p, ra, sm, int(threadIdx.x), nullptr, nullptr);
+}
+
+template <typename T, int NX, int NP, int MU>
+__device__ __forceinline__ void probe_rows_instance(const DevProblem& p, const QuadTables<T>& tb, const SolveArgs<T>& sa,
+                                                    int b, int slot, int j, int k0, int k1, T* sm) {
+  const InstanceBuffers<T> ib(p, sa, b);
+  const SolveState<T> s = state_load<T>(ib.w, ib.L);
+  if (!probe_wanted(sa, s, j)) return;
+  const ProbeEntry E(p.n, p.m, p.N, p.T);
+  T* const e = sa.probe_pool + (size_t(slot) * kProbeCandidates + j) * E.total;
+  QuadArgs<T> qa;
+  qa.xs = e + E.xs;
+  qa.us = e + E.us;
+  qa.lambdas = p.num_constraints > 0 ? ib.w + ib.L.lambdas : nullptr;
+  qa.mu = s.mu;
+  qa.t_extreme = ib.t_extreme();
+  qa.t_init = 0.0;
+  qa.A = qa.Bm = qa.Q = qa.l = qa.R = qa.r = nullptr;
+  qa.merit_part = e + E.mpart;
+  qa.cost_part = nullptr;
+  qa.phacc = nullptr;
+  const int lane = threadIdx.x;
+  constexpr int n = NX, m = NP * MU;
+  T argv = linquad_load_arg<T>(qa, k0, n, m, lane);
+#pragma unroll 1
+  for (int k = k0; k < k1; k++) {
+    LinquadCarry<T> carry;
+    linquad_compute<T, NX, NP * MU, NP>(p, tb, qa, k, sm, lane, argv, carry);
+    const T argn = k + 1 < k1 ? linquad_load_arg<T>(qa, k + 1, n, m, lane) : T(0);
+    linquad_store<T, NX, NP * MU, NP>(p, qa, k, sm, lane, carry);
+    argv = argn;
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ void probe_merit_instance(const DevProblem& p, const SolveArgs<T>& sa, int b, int slot, int j,
+                                                     T* sm, int sm_elems) {
+  const InstanceBuffers<T> ib(p, sa, b);
+  const SolveState<T> s = state_load<T>(ib.w, ib.L);
+  if (!probe_wanted(sa, s, j)) return;
+  const ProbeEntry E(p.n, p.m, p.N, p.T);
+  T* const e = sa.probe_pool + (size_t(slot) * kProbeCandidates + j) * E.total;
+  const T merit = uniform(merit_reduce<T>(p, e + E.mpart, sm, sm_elems));
+  if (threadIdx.x == 0) e[E.merit] = merit;
+}
+
+// The line-search bookkeeping of the candidates, in the order the loop would have met them
+// (CheckArmijoCondition :350-362, the back-tracking branch of ModifyLQStrategies :333-347).
+template <typename T>
+__device__ __forceinline__ void probe_pick_instance(const DevProblem& p, const SolveArgs<T>& sa, int b, int slot) {
+  const InstanceBuffers<T> ib(p, sa, b);
+  SolveState<T> s = state_load<T>(ib.w, ib.L);
+  if (!probe_wanted(sa, s, 0)) return;
+  const ilqg_solver_params& prm = sa.prm;
+  const ProbeEntry E(p.n, p.m, p.N, p.T);
+  const T* const e0 = sa.probe_pool + size_t(slot) * kProbeCandidates * E.total;
+  int tried = 0;
+  bool found = false;
+  T step = s.step, last_tried = s.step;
+  for (int j = 0; j < kProbeCandidates && s.bt + j < prm.max_backtracking_steps; j++) {
+    const T merit = e0[size_t(j) * E.total + E.merit];
+    const T scaled = T(prm.expected_decrease_fraction) * step * s.expected_decrease;
+    if (s.last_merit - merit >= scaled) {
+      found = true;
+      break;
+    }
+    tried++;
+    last_tried = step;
+    step *= T(prm.geometric_alpha_scaling);
+  }
+  s.bt += tried;
+  if (found || s.bt < prm.max_backtracking_steps) {
+    s.step = step;  // the accepted candidate, or the one after the last rejected
+  } else {          // :346-347 — out of back-tracking steps (the step stays the last one tried)
+    s.step = last_tried;
+    s.ok = 0;
+    s.stage = ST_INNER_DONE;
+    if (threadIdx.x == 0) atomicAdd(sa.unfinished + 1, 1);
+  }
+  state_store<T>(ib.w, ib.L, s);
 }
 
 template <typename T, int NX, int NP, int MU, int W, int PHASE = TRIAL_FUSED>
