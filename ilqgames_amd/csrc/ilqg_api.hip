@@ -604,15 +604,21 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   if (const char* e = getenv("ILQG_SPLIT_TRIAL")) split = e[0] == '1';
   if (kProfile) split = false;  // the phase profile reads the fused kernel's counters
   const bool counted = split || !(fixed_iters > 0 && !al_mode);
+  // Hand-off: whenever the host counts rounds anyway, the fused kernel keeps an instance only until its line
+  // search rejects a step; the back-tracking instances then go through split passes with the speculative line
+  // search (ILQG_HANDOFF=0 keeps every pass in the fused kernel).
+  const bool handoff = counted && !split && !kProfile && sa.prm.linesearch &&
+                       !(getenv("ILQG_HANDOFF") && getenv("ILQG_HANDOFF")[0] == '0');
+  const bool lists = split || handoff;
   long long cap = al_mode ? (long long)(sa.prm.max_solver_iters + 1) * (sa.prm.unconstrained_solver_max_iters + 2)
                           : (long long)sa.prm.max_solver_iters + 2;
-  if (split) cap = (cap + 2) * ((long long)sa.prm.max_backtracking_steps + 3);
+  if (split || counted) cap = (cap + 2) * ((long long)sa.prm.max_backtracking_steps + 3);
   auto k_roll = ilq_roll_kernel<T, NX, NP, MU>;
   auto k_rows = ilq_rows_kernel<T, NX, NP, MU>;
   auto k_decide = ilq_decide_kernel<T, NX, NP, MU>;
   const size_t lds_roll = trial_phase_lds_bytes<T>(d, TRIAL_ROLL), lds_decide = trial_phase_lds_bytes<T>(d, TRIAL_DECIDE);
   const size_t lds_rows = quad_tables_bytes(d, sizeof(T)) + trial_phase_quad_elems<T>(d, TRIAL_FUSED) * sizeof(T);
-  if (split && p->pass_ids_capacity < batch) {
+  if (lists && p->pass_ids_capacity < batch) {
     if (p->d_pass_ids) (void)hipFree(p->d_pass_ids);
     p->d_pass_ids = nullptr;
     p->pass_ids_capacity = 0;
@@ -620,7 +626,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
     p->pass_ids_capacity = batch;
   }
   // ILQG_PROBE=0 switches the speculative line search off (A/B measurements)
-  const bool probe = split && sa.prm.linesearch && !(getenv("ILQG_PROBE") && getenv("ILQG_PROBE")[0] == '0');
+  const bool probe = lists && sa.prm.linesearch && !(getenv("ILQG_PROBE") && getenv("ILQG_PROBE")[0] == '0');
   if (probe && !p->d_probe_pool)
     HIP_TRY(hipMalloc(&p->d_probe_pool,
                       size_t(kProbeSlots) * kProbeCandidates * ProbeEntry(d.n, d.m, d.N, d.T).total * sizeof(T)));
@@ -629,7 +635,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   auto k_prows = ilq_probe_rows_kernel<T, NX, NP, MU>;
   const int decide_elems = int(trial_phase_quad_elems<T>(d, TRIAL_DECIDE));
   int round_instances = batch, list = 0;  // split passes: how many instances this round covers, which list is free
-  if (split) {
+  if (lists) {
     raise_lds_limit((const void*)k_roll, lds_roll);
     raise_lds_limit((const void*)k_rows, lds_rows);
     raise_lds_limit((const void*)k_decide, lds_decide);
@@ -640,7 +646,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   int waiting_lq = 0, waiting_exit = 0;  // split passes: instances already through this iteration's line search
   for (long long round = 0;; round++) {
     if (counted) HIP_TRY(hipMemsetAsync(p->d_unfinished, 0, 4 * sizeof(int), stream));
-    if (split) {
+    if (split || sa.ids) {  // a split pass: the whole batch (split mode) or the listed back-tracking instances
       sa.ids_next = p->d_pass_ids + size_t(list) * p->pass_ids_capacity;
       sa.rows_per_block = round_instances < kFewInstances ? 1 : kRowsPerBlock;
       if (probe && sa.ids && round_instances <= kProbeSlots) {
@@ -664,6 +670,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
       HIP_TRY(hipGetLastError());
       hipLaunchKernelGGL(k_decide, dim3(round_instances), dim3(64), lds_decide, stream, d, sa);
     } else {
+      sa.ids_next = handoff ? p->d_pass_ids + size_t(list) * p->pass_ids_capacity : nullptr;
       hipLaunchKernelGGL(k_trial, dim3(batch), dim3(64 * W), lds_trial, stream, d, sa);
     }
     HIP_TRY(hipGetLastError());
@@ -675,7 +682,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
       want_lq = p->h_unfinished[0];
       want_exit = p->h_unfinished[1];
       again = p->h_unfinished[3];
-      if (split) {
+      if (lists) {
         // keep the batch in step: the sweep is launched once per iteration, when the last back-tracking instance
         // has made up its mind (a sweep launch with a handful of instances costs a full sweep's latency)
         waiting_lq += want_lq;

@@ -680,6 +680,9 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const Q
       }
     }
     if (PHASE == TRIAL_DECIDE) break;  // another pass, if the instance needs one, is the host's to launch
+    // hand-off (the host gave a list to fill): a rejected step leaves the fused kernel too — the rest of this line
+    // search goes through the split passes, where the next step sizes are probed side by side
+    if (PHASE == TRIAL_FUSED && sa.ids_next != nullptr && s.stage == ST_ROLLOUT && s.bt > 0) break;
   }
   state_store<T>(w, L, s);
   if (PHASE == TRIAL_ROLL) return;
@@ -687,7 +690,7 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const Q
   if (t == 0) {
     const int slot = s.stage == ST_LQ ? 0 : (s.stage == ST_ROLLOUT || s.stage == ST_QUAD) ? 3 : 1;
     const int at = atomicAdd(sa.unfinished + slot, 1);
-    if (PHASE == TRIAL_DECIDE && slot == 3 && sa.ids_next) sa.ids_next[at] = b;
+    if (slot == 3 && sa.ids_next) sa.ids_next[at] = b;
   }
   if (kProfile && t == 0 && sa.prof) sa.prof[size_t(b) * 96 + 1] += clock64() - pr_start;
   if (kProfile && t == 0 && sa.prof) {

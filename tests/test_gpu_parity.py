@@ -365,14 +365,19 @@ def test_split_trial_pass_is_the_fused_kernel_bit_for_bit(hip, cfg, al, dtype, m
     B = 9
     x0 = examples.jittered_x0(spec, B, seed=3)
     outs = []
-    for mode in ("0", "1"):
-        monkeypatch.setenv("ILQG_SPLIT_TRIAL", mode)
+    # every pass in the fused kernel / fused first pass, back-tracking handed to split passes with the speculative
+    # line search (the default for free-running solves) / split passes throughout / split passes without probing
+    for split, handoff, probe in (("0", "0", "1"), ("0", "1", "1"), ("1", "1", "1"), ("1", "1", "0")):
+        monkeypatch.setenv("ILQG_SPLIT_TRIAL", split)
+        monkeypatch.setenv("ILQG_HANDOFF", handoff)
+        monkeypatch.setenv("ILQG_PROBE", probe)
         out = hip.Problem(spec, dtype).solve(x0, augmented_lagrangian=al)
         outs.append({k: _np(v).copy() for k, v in out.items() if hasattr(v, "shape") and k != "ws"})
-    fused, split = outs
-    assert set(fused) == set(split)
-    for k in fused:
-        assert np.array_equal(fused[k], split[k], equal_nan=True), k
+    fused = outs[0]
+    for other in outs[1:]:
+        assert set(fused) == set(other)
+        for k in fused:
+            assert np.array_equal(fused[k], other[k], equal_nan=True), k
     assert fused["iters"].max() >= 2
 
 
