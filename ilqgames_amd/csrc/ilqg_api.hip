@@ -627,10 +627,6 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   }
   // ILQG_PROBE=0 switches the speculative line search off (A/B measurements)
   const bool probe = lists && sa.prm.linesearch && !(getenv("ILQG_PROBE") && getenv("ILQG_PROBE")[0] == '0');
-  if (probe && !p->d_probe_pool)
-    HIP_TRY(hipMalloc(&p->d_probe_pool,
-                      size_t(kProbeSlots) * kProbeCandidates * ProbeEntry(d.n, d.m, d.N, d.T).total * sizeof(T)));
-  sa.probe_pool = (T*)p->d_probe_pool;
   auto k_proll = ilq_probe_roll_kernel<T, NX, NP, MU>;
   auto k_prows = ilq_probe_rows_kernel<T, NX, NP, MU>;
   const int decide_elems = int(trial_phase_quad_elems<T>(d, TRIAL_DECIDE));
@@ -651,6 +647,10 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
       sa.rows_per_block = round_instances < kFewInstances ? 1 : kRowsPerBlock;
       if (probe && sa.ids && round_instances <= kProbeSlots) {
         // the listed instances' next step sizes side by side; their states move to the first acceptable one
+        if (!p->d_probe_pool)  // 40-100 MB: only problems whose line searches back-track ever need it
+          HIP_TRY(hipMalloc(&p->d_probe_pool,
+                            size_t(kProbeSlots) * kProbeCandidates * ProbeEntry(d.n, d.m, d.N, d.T).total * sizeof(T)));
+        sa.probe_pool = (T*)p->d_probe_pool;
         hipLaunchKernelGGL(k_proll, dim3(round_instances, kProbeCandidates), dim3(64), lds_roll, stream, d, sa);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(k_prows, dim3((d.T + sa.rows_per_block - 1) / sa.rows_per_block,
