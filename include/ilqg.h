@@ -240,7 +240,11 @@ typedef struct ilqg_problem ilqg_problem;
 
 /* Builds the device-side tables of one Problem (what Problem::Initialize +
  * ILQSolver::ILQSolver set up, include/ilqgames/solver/problem.h:66-73,
- * include/ilqgames/solver/ilq_solver.h:69-95). */
+ * include/ilqgames/solver/ilq_solver.h:69-95).
+ * A handle also owns the small device buffers its solves coordinate through (round counters, the lists of
+ * back-tracking instances, the line-search probe pool): like the reference's solver objects it serves one
+ * solve at a time — concurrent solves need one handle each (the read-only entry points, e.g. rollout /
+ * linearize / quadraticize / strategy costs, may share one). */
 ilqg_status ilqg_problem_create(const ilqg_problem_desc* desc, ilqg_problem** out);
 void ilqg_problem_destroy(ilqg_problem* p);
 
