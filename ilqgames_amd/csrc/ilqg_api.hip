@@ -287,7 +287,7 @@ __global__ void __launch_bounds__(64) ilq_probe_roll_kernel(DevProblem p, SolveA
 template <typename T, int NX, int NP, int MU>
 __global__ void __launch_bounds__(64) ilq_probe_rows_kernel(DevProblem p, SolveArgs<T> sa) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  const int slot = blockIdx.y / kProbeCandidates, j = blockIdx.y % kProbeCandidates;
+  const int slot = blockIdx.y / sa.probe_k, j = blockIdx.y % sa.probe_k;
   const int b = sa.ids[slot];
   {  // leave before the table load if this candidate is not wanted
     const WsLayout L(p.n, p.m, p.N, p.T, p.pairs.Rsz, p.pairs.rsz, sa.ol_row, p.num_constraints, sa.al_mode);
@@ -521,7 +521,7 @@ struct ilqg_problem {
   int* h_unfinished = nullptr;  // pinned host mirror
   int* d_pass_ids = nullptr;    // split passes: two lists of instances that need another pass (this round's, the next's)
   int pass_ids_capacity = 0;
-  void* d_probe_pool = nullptr;  // speculative line search: kProbeSlots x kProbeCandidates trajectories + merit partials
+  void* d_probe_pool = nullptr;  // speculative line search: kProbeEntries trajectories + merit partials
   int mu_uniform = 0;
 };
 
@@ -575,6 +575,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   sa.ids_next = nullptr;
   sa.rows_per_block = kRowsPerBlock;
   sa.probe_pool = nullptr;
+  sa.probe_k = 0;
   constexpr int W = TrialWaves<T>::W;
   // LDS of the sweep kernel that will run: the open-loop sweep's own working set plus the slot the expected
   // decrease is handed over in (n = 24: 54 KB, three instances per CU; the feedback layout would take 85 KB)
@@ -631,6 +632,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   auto k_prows = ilq_probe_rows_kernel<T, NX, NP, MU>;
   const int decide_elems = int(trial_phase_quad_elems<T>(d, TRIAL_DECIDE));
   int round_instances = batch, list = 0;  // split passes: how many instances this round covers, which list is free
+  int tail_rounds = 0;                    // rounds since the whole batch was last in one
   if (lists) {
     raise_lds_limit((const void*)k_roll, lds_roll);
     raise_lds_limit((const void*)k_rows, lds_rows);
@@ -645,18 +647,26 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
     if (split || sa.ids) {  // a split pass: the whole batch (split mode) or the listed back-tracking instances
       sa.ids_next = p->d_pass_ids + size_t(list) * p->pass_ids_capacity;
       sa.rows_per_block = round_instances < kFewInstances ? 1 : kRowsPerBlock;
-      if (probe && sa.ids && round_instances <= kProbeSlots) {
+      // Step sizes probed per listed instance: as many as the pool holds for a list this long, doubling from two
+      // over the first rounds of a tail (most line searches that back-track at all end within a step or two; the
+      // ones that do not are the ones worth eight candidates a round).
+      int probe_k = sa.ids ? kProbeEntries / round_instances : 0;
+      if (probe_k > kProbeCandidates) probe_k = kProbeCandidates;
+      if (tail_rounds < 3 && probe_k > (2 << tail_rounds)) probe_k = 2 << tail_rounds;
+      if (sa.ids) tail_rounds++;
+      if (probe && probe_k >= 2) {
         // the listed instances' next step sizes side by side; their states move to the first acceptable one
-        if (!p->d_probe_pool)  // 40-100 MB: only problems whose line searches back-track ever need it
+        if (!p->d_probe_pool)  // 85-200 MB: only problems whose line searches back-track ever need it
           HIP_TRY(hipMalloc(&p->d_probe_pool,
-                            size_t(kProbeSlots) * kProbeCandidates * ProbeEntry(d.n, d.m, d.N, d.T).total * sizeof(T)));
+                            size_t(kProbeEntries) * ProbeEntry(d.n, d.m, d.N, d.T).total * sizeof(T)));
         sa.probe_pool = (T*)p->d_probe_pool;
-        hipLaunchKernelGGL(k_proll, dim3(round_instances, kProbeCandidates), dim3(64), lds_roll, stream, d, sa);
+        sa.probe_k = probe_k;
+        hipLaunchKernelGGL(k_proll, dim3(round_instances, probe_k), dim3(64), lds_roll, stream, d, sa);
         HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(k_prows, dim3((d.T + sa.rows_per_block - 1) / sa.rows_per_block,
-                                         round_instances * kProbeCandidates), dim3(64), lds_rows, stream, d, sa);
+        hipLaunchKernelGGL(k_prows, dim3((d.T + sa.rows_per_block - 1) / sa.rows_per_block, round_instances * probe_k),
+                           dim3(64), lds_rows, stream, d, sa);
         HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(ilq_probe_merit_kernel<T>, dim3(round_instances, kProbeCandidates), dim3(64),
+        hipLaunchKernelGGL(ilq_probe_merit_kernel<T>, dim3(round_instances, probe_k), dim3(64),
                            size_t(decide_elems) * sizeof(T), stream, d, sa, decide_elems);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(ilq_probe_pick_kernel<T>, dim3(round_instances), dim3(64), 0, stream, d, sa);
@@ -696,6 +706,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
         }
         sa.ids = nullptr;
         round_instances = batch;
+        tail_rounds = 0;
         want_lq = waiting_lq;
         want_exit = waiting_exit;
         waiting_lq = waiting_exit = 0;

@@ -44,7 +44,8 @@ struct SolveArgs {
   const int* ids;
   int* ids_next;
   int rows_per_block;
-  T* probe_pool;        // speculative line search: [slots][kProbeCandidates] entries of ProbeEntry::total elements
+  T* probe_pool;        // speculative line search: [listed instances][probe_k] entries of ProbeEntry::total elements
+  int probe_k;          // step sizes probed per instance this round (<= kProbeCandidates)
 };
 
 // Elements of one open-loop scratch row ([X|y|W|w|M|m|Q l], OLCfg::ROW) from run-time dimensions.
@@ -386,8 +387,8 @@ __device__ __forceinline__ void rows_part_instance(const DevProblem& p, const Qu
 // rejections counted as if they had been tried one by one.  The regular pass that follows evaluates that
 // candidate again with all outputs and accepts it: same arithmetic, same decisions, fewer rounds.
 // ---------------------------------------------------------------------------
-constexpr int kProbeCandidates = 8;
-constexpr int kProbeSlots = 256;  // instances of a round that can be probed (the pool's size)
+constexpr int kProbeCandidates = 8;             // most step sizes probed per instance and round
+constexpr int kProbeEntries = 8 * 512;          // pool size: candidates of all listed instances of one round
 
 struct ProbeEntry {
   size_t xs, us, mpart, merit, total;
@@ -422,7 +423,7 @@ __device__ __forceinline__ void probe_roll_instance(const DevProblem& p, const S
   const SolveState<T> s = state_load<T>(ib.w, ib.L);
   if (!probe_wanted(sa, s, j)) return;
   const ProbeEntry E(p.n, p.m, p.N, p.T);
-  T* const e = sa.probe_pool + (size_t(slot) * kProbeCandidates + j) * E.total;
+  T* const e = sa.probe_pool + (size_t(slot) * sa.probe_k + j) * E.total;
   const int snew = 1 - s.sacc;
   RolloutArgs<T> ra;
   ra.x0 = ib.XS(s.cur);
@@ -444,7 +445,7 @@ __device__ __forceinline__ void probe_rows_instance(const DevProblem& p, const Q
   const SolveState<T> s = state_load<T>(ib.w, ib.L);
   if (!probe_wanted(sa, s, j)) return;
   const ProbeEntry E(p.n, p.m, p.N, p.T);
-  T* const e = sa.probe_pool + (size_t(slot) * kProbeCandidates + j) * E.total;
+  T* const e = sa.probe_pool + (size_t(slot) * sa.probe_k + j) * E.total;
   QuadArgs<T> qa;
   qa.xs = e + E.xs;
   qa.us = e + E.us;
@@ -476,7 +477,7 @@ __device__ __forceinline__ void probe_merit_instance(const DevProblem& p, const 
   const SolveState<T> s = state_load<T>(ib.w, ib.L);
   if (!probe_wanted(sa, s, j)) return;
   const ProbeEntry E(p.n, p.m, p.N, p.T);
-  T* const e = sa.probe_pool + (size_t(slot) * kProbeCandidates + j) * E.total;
+  T* const e = sa.probe_pool + (size_t(slot) * sa.probe_k + j) * E.total;
   const T merit = uniform(merit_reduce<T>(p, e + E.mpart, sm, sm_elems));
   if (threadIdx.x == 0) e[E.merit] = merit;
 }
@@ -490,11 +491,11 @@ __device__ __forceinline__ void probe_pick_instance(const DevProblem& p, const S
   if (!probe_wanted(sa, s, 0)) return;
   const ilqg_solver_params& prm = sa.prm;
   const ProbeEntry E(p.n, p.m, p.N, p.T);
-  const T* const e0 = sa.probe_pool + size_t(slot) * kProbeCandidates * E.total;
+  const T* const e0 = sa.probe_pool + size_t(slot) * sa.probe_k * E.total;
   int tried = 0;
   bool found = false;
   T step = s.step, last_tried = s.step;
-  for (int j = 0; j < kProbeCandidates && s.bt + j < prm.max_backtracking_steps; j++) {
+  for (int j = 0; j < sa.probe_k && s.bt + j < prm.max_backtracking_steps; j++) {
     const T merit = e0[size_t(j) * E.total + E.merit];
     const T scaled = T(prm.expected_decrease_fraction) * step * s.expected_decrease;
     if (s.last_merit - merit >= scaled) {
