@@ -604,7 +604,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   bool split = 3 * lds_trial > size_t(160) * 1024;
   if (const char* e = getenv("ILQG_SPLIT_TRIAL")) split = e[0] == '1';
   if (kProfile) split = false;  // the phase profile reads the fused kernel's counters
-  const bool counted = split || !(fixed_iters > 0 && !al_mode);
+  const bool counted = split || !(fixed_iters > 0 && !al_mode) || getenv("ILQG_COUNTED") != nullptr;
   // Hand-off: whenever the host counts rounds anyway, the fused kernel keeps an instance only until its line
   // search rejects a step; the back-tracking instances then go through split passes with the speculative line
   // search (ILQG_HANDOFF=0 keeps every pass in the fused kernel).
