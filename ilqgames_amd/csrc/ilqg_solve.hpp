@@ -507,8 +507,19 @@ __device__ __forceinline__ void probe_pick_instance(const DevProblem& p, const S
     step *= T(prm.geometric_alpha_scaling);
   }
   s.bt += tried;
-  if (found || s.bt < prm.max_backtracking_steps) {
-    s.step = step;  // the accepted candidate, or the one after the last rejected
+  if (found) {
+    // The candidate's trajectory is the one the pass's rollout would produce (same function, same inputs): hand it
+    // over instead of integrating it again, and enter the pass at its row stage.
+    s.step = step;
+    const T* const e = e0 + size_t(tried) * E.total;
+    T* const xs_dst = ib.XS(1 - s.cur);
+    T* const us_dst = ib.US(1 - s.cur);
+    for (int i = threadIdx.x; i < p.T * p.n; i += blockDim.x) xs_dst[i] = e[E.xs + i];
+    for (int i = threadIdx.x; i < p.T * p.m; i += blockDim.x) us_dst[i] = e[E.us + i];
+    s.qmode = Q_TRIAL;
+    s.stage = ST_QUAD;
+  } else if (s.bt < prm.max_backtracking_steps) {
+    s.step = step;  // the one after the last rejected
   } else {          // :346-347 — out of back-tracking steps (the step stays the last one tried)
     s.step = last_tried;
     s.ok = 0;
