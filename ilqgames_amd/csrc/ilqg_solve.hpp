@@ -56,7 +56,9 @@ __host__ __device__ inline int ol_row_elems(int n, int m, int N) {
 // Loop state of one instance's ILQSolver::Solve (the locals of src/ilq_solver.cpp:76-172 plus the
 // AugmentedLagrangianSolver bookkeeping).  It lives in registers inside a kernel and in the
 // workspace between the trial kernel and the LQ kernel.
-enum { ST_ROLLOUT = 0, ST_QUAD = 1, ST_LQ = 2, ST_INNER_DONE = 3, ST_DONE = 4 };
+// ST_PROBE: ST_ROLLOUT for an instance whose last probe rejected every candidate — it skips the regular pass of
+// its round (which would try one more step size at the price of a rollout) and is probed again in the next one.
+enum { ST_ROLLOUT = 0, ST_QUAD = 1, ST_LQ = 2, ST_INNER_DONE = 3, ST_DONE = 4, ST_PROBE = 5 };
 enum { Q_COSTS = 0, Q_INIT = 1, Q_TRIAL = 2, Q_LIN = 3 };
 template <typename T>
 struct SolveState {
@@ -406,7 +408,7 @@ struct ProbeEntry {
 // loop would reach (ILQSolver::ModifyLQStrategies gives up after max_backtracking_steps rejections)?
 template <typename T>
 __device__ __forceinline__ bool probe_wanted(const SolveArgs<T>& sa, const SolveState<T>& s, int j) {
-  return s.stage == ST_ROLLOUT && !s.initial && sa.prm.linesearch && s.bt > 0 &&
+  return (s.stage == ST_ROLLOUT || s.stage == ST_PROBE) && !s.initial && sa.prm.linesearch && s.bt > 0 &&
          s.bt + j < sa.prm.max_backtracking_steps;
 }
 template <typename T>
@@ -519,7 +521,9 @@ __device__ __forceinline__ void probe_pick_instance(const DevProblem& p, const S
     s.qmode = Q_TRIAL;
     s.stage = ST_QUAD;
   } else if (s.bt < prm.max_backtracking_steps) {
-    s.step = step;  // the one after the last rejected
+    s.step = step;  // the one after the last rejected: probed from there in the next round
+    s.stage = ST_PROBE;
+    if (threadIdx.x == 0 && sa.ids_next) sa.ids_next[atomicAdd(sa.unfinished + 3, 1)] = b;
   } else {          // :346-347 — out of back-tracking steps (the step stays the last one tried)
     s.step = last_tried;
     s.ok = 0;
