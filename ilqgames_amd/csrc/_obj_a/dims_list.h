@@ -1,0 +1,1 @@
+#define ILQG_FOR_DIMS(X) X(14, 3, 2)

@@ -15,6 +15,7 @@
 #include "ilqg_models.hpp"
 #include "ilqg_nash.hpp"
 #include "ilqg_receding.hpp"
+#include "ilqg_rowprog.hpp"
 #include "ilqg_solve.hpp"
 #include "ilqg_stages.hpp"
 
@@ -152,16 +153,8 @@ struct QuadBatchArgs {
   const int* active;
 };
 
-// grid = (ceil(T / kStepsPerBlock), B): every (instance, time step) is independent here; a block
-// takes a few consecutive steps so that staging the cost tables into LDS is amortised.
-constexpr int kStepsPerBlock = 4;
 template <typename T>
-__global__ void linquad_kernel(DevProblem p, QuadBatchArgs<T> g) {
-  extern __shared__ __align__(16) unsigned char smem_raw[];
-  const size_t b = blockIdx.y;
-  if (g.active && !g.active[b]) return;
-  const QuadTables<T> tb = quad_tables_load<T>(p, smem_raw);
-  T* sm = reinterpret_cast<T*>(smem_raw + quad_tables_bytes(p, sizeof(T)));
+__device__ __forceinline__ QuadArgs<T> quad_args_of(const DevProblem& p, const QuadBatchArgs<T>& g, size_t b) {
   const size_t Tn = p.T, n = p.n, m = p.m, N = p.N;
   QuadArgs<T> a;
   a.xs = g.xs + b * Tn * n;
@@ -178,8 +171,37 @@ __global__ void linquad_kernel(DevProblem p, QuadBatchArgs<T> g) {
   a.r = g.r ? g.r + b * Tn * p.pairs.rsz : nullptr;
   a.merit_part = g.merit_part ? g.merit_part + b * Tn * N * 2 : nullptr;
   a.cost_part = g.cost_part ? g.cost_part + b * Tn * N : nullptr;
+  return a;
+}
+
+// grid = (ceil(T / kStepsPerBlock), B): every (instance, time step) is independent here; a block
+// takes a few consecutive steps so that staging the cost tables into LDS is amortised.
+constexpr int kStepsPerBlock = 4;
+template <typename T>
+__global__ void linquad_kernel(DevProblem p, QuadBatchArgs<T> g) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const size_t b = blockIdx.y;
+  if (g.active && !g.active[b]) return;
+  const QuadTables<T> tb = quad_tables_load<T>(p, smem_raw);
+  T* sm = reinterpret_cast<T*>(smem_raw + quad_tables_bytes(p, sizeof(T)));
+  const QuadArgs<T> a = quad_args_of<T>(p, g, b);
   const int k0 = int(blockIdx.x) * kStepsPerBlock;
   for (int k = k0; k < k0 + kStepsPerBlock && k < p.T; k++) linquad_step<T>(p, tb, a, k, sm, threadIdx.x);
+}
+
+// The lane-per-time-step form of the same stage (ilqg_rows.hpp): grid = (ceil(T / CW), B), one wavefront takes CW
+// consecutive rows of one instance.
+template <typename T, int NX, int NP, int MU>
+__global__ void __launch_bounds__(64) rows_kernel(DevProblem p, QuadBatchArgs<T> g, int cw) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const size_t b = blockIdx.y;
+  if (g.active && !g.active[b]) return;
+  const short* maps = rows_maps_load(p, smem_raw);
+  T* sm = reinterpret_cast<T*>(smem_raw + rows_maps_bytes(p));
+  const QuadArgs<T> a = quad_args_of<T>(p, g, b);
+  const int k0 = int(blockIdx.x) * cw;
+  const int nrows = p.T - k0 < cw ? p.T - k0 : cw;
+  rows_chunk<T, NX, NP * MU, NP>(p, maps, a, k0, nrows, cw, sm, int(threadIdx.x));
 }
 
 template <typename T>
@@ -189,10 +211,10 @@ __global__ void costs_reduce_kernel(DevProblem p, const T* cost_part, T* costs, 
   costs_reduce<T>(p, cost_part + b * p.T * p.N, costs + b * p.N, t_extreme ? t_extreme + b * p.N : nullptr);
 }
 
-// Wavefronts per instance in the trial kernel.  fp64 keeps the 256-register budget (two waves per
-// SIMD at the headline batch of 1024 instances on 1024 SIMDs); fp32 takes four.
+// Wavefronts per instance in the trial kernel: wave 0 integrates, the others take the chunks of rows it has
+// produced (ilqg_solve.hpp).  One row wave keeps up with the integration; each more costs a row scratch of LDS.
 #ifndef ILQG_TRIAL_WAVES_F32
-#define ILQG_TRIAL_WAVES_F32 4
+#define ILQG_TRIAL_WAVES_F32 2
 #endif
 #ifndef ILQG_TRIAL_WAVES_F64
 #define ILQG_TRIAL_WAVES_F64 2
@@ -218,9 +240,9 @@ __global__ void __launch_bounds__(64 * W, W) ilq_trial_kernel(DevProblem p, Solv
       reinterpret_cast<SolveState<T>*>(sa.ws + size_t(b) * sa.ws_stride + L.state)->stage = ST_DONE;
     return;
   }
-  const QuadTables<T> tb = quad_tables_load<T>(p, smem_raw);
-  T* sm = reinterpret_cast<T*>(smem_raw + quad_tables_bytes(p, sizeof(T)));
-  trial_part_instance<T, NX, NP, MU, W>(p, tb, sa, b, sm);
+  const short* maps = rows_maps_load(p, smem_raw);
+  T* sm = reinterpret_cast<T*>(smem_raw + rows_maps_bytes(p));
+  trial_part_instance<T, NX, NP, MU, W>(p, maps, sa, b, sm);
 }
 
 // The same pass cut into three launches (ilqg_solve.hpp, TRIAL_ROLL / rows_part_instance / TRIAL_DECIDE), for
@@ -239,14 +261,8 @@ __global__ void __launch_bounds__(64) ilq_roll_kernel(DevProblem p, SolveArgs<T>
       reinterpret_cast<SolveState<T>*>(sa.ws + size_t(b) * sa.ws_stride + L.state)->stage = ST_DONE;
     return;
   }
-  const QuadTables<T> no_tables{};
-  trial_part_instance<T, NX, NP, MU, 1, TRIAL_ROLL>(p, no_tables, sa, b, reinterpret_cast<T*>(smem_raw));
+  trial_part_instance<T, NX, NP, MU, 1, TRIAL_ROLL>(p, nullptr, sa, b, reinterpret_cast<T*>(smem_raw));
 }
-
-// rows of one instance per workgroup of the row kernel: five amortise the table load when the whole batch is in
-// flight; a round with a few back-tracking instances left takes one row per workgroup (latency is all that counts)
-constexpr int kRowsPerBlock = 5;
-constexpr int kFewInstances = 512;
 
 template <typename T, int NX, int NP, int MU>
 __global__ void __launch_bounds__(64) ilq_rows_kernel(DevProblem p, SolveArgs<T> sa) {
@@ -257,11 +273,9 @@ __global__ void __launch_bounds__(64) ilq_rows_kernel(DevProblem p, SolveArgs<T>
     const int stage = reinterpret_cast<const SolveState<T>*>(sa.ws + size_t(b) * sa.ws_stride + L.state)->stage;
     if (stage != ST_ROLLOUT && stage != ST_QUAD) return;
   }
-  const QuadTables<T> tb = quad_tables_load<T>(p, smem_raw);
-  T* sm = reinterpret_cast<T*>(smem_raw + quad_tables_bytes(p, sizeof(T)));
-  const int k0 = int(blockIdx.x) * sa.rows_per_block;
-  const int k1 = k0 + sa.rows_per_block < p.T ? k0 + sa.rows_per_block : p.T;
-  rows_part_instance<T, NX, NP, MU>(p, tb, sa, b, k0, k1, sm);
+  const short* maps = rows_maps_load(p, smem_raw);
+  T* sm = reinterpret_cast<T*>(smem_raw + rows_maps_bytes(p));
+  rows_part_instance<T, NX, NP, MU>(p, maps, sa, b, int(blockIdx.x), sm);
 }
 
 template <typename T, int NX, int NP, int MU>
@@ -273,8 +287,7 @@ __global__ void __launch_bounds__(64) ilq_decide_kernel(DevProblem p, SolveArgs<
     const int stage = reinterpret_cast<const SolveState<T>*>(sa.ws + size_t(b) * sa.ws_stride + L.state)->stage;
     if (stage != ST_ROLLOUT && stage != ST_QUAD) return;
   }
-  const QuadTables<T> no_tables{};
-  trial_part_instance<T, NX, NP, MU, 1, TRIAL_DECIDE>(p, no_tables, sa, b, reinterpret_cast<T*>(smem_raw));
+  trial_part_instance<T, NX, NP, MU, 1, TRIAL_DECIDE>(p, nullptr, sa, b, reinterpret_cast<T*>(smem_raw));
 }
 
 // Speculative line search of the listed instances (ilqg_solve.hpp): candidate j of list entry `slot`.
@@ -294,11 +307,9 @@ __global__ void __launch_bounds__(64) ilq_probe_rows_kernel(DevProblem p, SolveA
     const SolveState<T> s = state_load<T>(sa.ws + size_t(b) * sa.ws_stride, L);
     if (!probe_wanted(sa, s, j)) return;
   }
-  const QuadTables<T> tb = quad_tables_load<T>(p, smem_raw);
-  T* sm = reinterpret_cast<T*>(smem_raw + quad_tables_bytes(p, sizeof(T)));
-  const int k0 = int(blockIdx.x) * sa.rows_per_block;
-  const int k1 = k0 + sa.rows_per_block < p.T ? k0 + sa.rows_per_block : p.T;
-  probe_rows_instance<T, NX, NP, MU>(p, tb, sa, b, slot, j, k0, k1, sm);
+  const short* maps = rows_maps_load(p, smem_raw);
+  T* sm = reinterpret_cast<T*>(smem_raw + rows_maps_bytes(p));
+  probe_rows_instance<T, NX, NP, MU>(p, maps, sa, b, slot, j, int(blockIdx.x), sm);
 }
 
 template <typename T>
@@ -410,7 +421,11 @@ bool build_pairs(const ilqg_pair* pairs, int npairs, const int* udim, int N, Pai
 // Supported (n, N, m_i) instantiations.  n=14/16/15/24: BASELINE configs 2-5;
 // (4,2,2): config 1 (TwoPlayerUnicycle4D); (2,2,1): test_lq_solver's point mass;
 // (6,3,2): synthetic parity cases.
+#if defined(ILQG_DIMS_HEADER)
+#include ILQG_DIMS_HEADER  // experiment builds: a generated subset of the list below (__graft_entry__.build_hip_library)
+#else
 #define ILQG_FOR_DIMS(X) X(14, 3, 2) X(16, 3, 2) X(15, 3, 2) X(24, 4, 2) X(18, 3, 2) X(12, 2, 2) X(10, 2, 2) X(4, 2, 2) X(6, 2, 1) X(3, 2, 1) X(3, 1, 1) X(2, 2, 1) X(6, 3, 2) X(2, 1, 2) X(8, 2, 2)
+#endif
 
 }  // namespace
 
@@ -428,7 +443,24 @@ struct __attribute__((visibility("hidden"))) DimsLaunch {
   static ilqg_status solve(ilqg_problem* p, int32_t batch, const void* x0, void* xs, void* us, void* P, void* alpha,
                            void* total_costs, int32_t* iters, int32_t* status, int32_t* converged, void* workspace,
                            int32_t fixed_iters, int al_mode, int resume, const int32_t* active, hipStream_t stream);
+  // pointers in QuadBatchArgs' order: xs us lambdas mu t_extreme A Bm Q l R r merit_part cost_part active
+  static ilqg_status rows(const DevProblem& d, int32_t batch, const void* const* ptrs, hipStream_t stream);
 };
+
+template <typename T, int NX, int NP, int MU>
+ilqg_status DimsLaunch<T, NX, NP, MU>::rows(const DevProblem& d, int32_t batch, const void* const* q,
+                                            hipStream_t stream) {
+  const QuadBatchArgs<T> g{(const T*)q[0], (const T*)q[1], (const T*)q[2], (const T*)q[3], (const int*)q[4], (T*)q[5],
+                           (T*)q[6], (T*)q[7], (T*)q[8], (T*)q[9], (T*)q[10], (T*)q[11], (T*)q[12], (const int*)q[13]};
+  // the widest chunk that leaves a CU three workgroups of this kernel
+  const int cw = rows_chunk_width(d.n, d.m, d.rp_pslots, d.rp_lslots, sizeof(T), size_t(48) * 1024);
+  const size_t lds = rows_maps_bytes(d) + rows_lds_elems(d.n, d.m, d.rp_pslots, d.rp_lslots, cw) * sizeof(T);
+  auto kern = rows_kernel<T, NX, NP, MU>;
+  raise_lds_limit((const void*)kern, lds);
+  hipLaunchKernelGGL(kern, dim3((d.T + cw - 1) / cw, batch), dim3(64), lds, stream, d, g, cw);
+  HIP_TRY(hipGetLastError());
+  return ILQG_OK;
+}
 
 template <typename T, int NX, int NP, int MU>
 ilqg_status DimsLaunch<T, NX, NP, MU>::lq(const ilqg_dims* d, const PairTable& pt, const void* A, const void* Bm,
@@ -517,6 +549,7 @@ struct ilqg_problem {
   float* d_segs_f = nullptr;
   double* d_segs_d = nullptr;
   int* d_cost_order = nullptr;
+  int* d_row_prog = nullptr;
   int* d_unfinished = nullptr;  // instances still running after an LQ-kernel launch
   int* h_unfinished = nullptr;  // pinned host mirror
   int* d_pass_ids = nullptr;    // split passes: two lists of instances that need another pass (this round's, the next's)
@@ -530,22 +563,7 @@ struct ilqg_problem {
 static ilqg_status launch_linquad(const ilqg_problem* p, int32_t batch, const void* xs, const void* us,
                                   const void* lambdas, const void* mu, const int32_t* t_extreme, void* A, void* Bm,
                                   void* Q, void* l, void* R, void* r, void* merit_part, void* cost_part,
-                                  const int32_t* active, void* stream) {
-  const DevProblem& d = p->dev;
-#define CALL(TY_)                                                                                                 \
-  [&]() -> ilqg_status {                                                                                        \
-    QuadBatchArgs<TY_> g{(const TY_*)xs, (const TY_*)us, (const TY_*)lambdas, (const TY_*)mu, t_extreme, (TY_*)A, (TY_*)Bm,   \
-                       (TY_*)Q, (TY_*)l, (TY_*)R, (TY_*)r, (TY_*)merit_part, (TY_*)cost_part, active};                      \
-    const size_t lds = quad_lds_elems(d.n, d.m, d.N, d.pairs.Rsz, d.pairs.rsz, d.num_terms) * sizeof(TY_) +       \
-                       quad_tables_bytes(d, sizeof(TY_));                                                         \
-    hipLaunchKernelGGL(linquad_kernel<TY_>, dim3((d.T + kStepsPerBlock - 1) / kStepsPerBlock, batch), dim3(64),  \
-                       lds, (hipStream_t)stream, d, g);                                                           \
-    HIP_TRY(hipGetLastError());                                                                                 \
-    return ILQG_OK;                                                                                             \
-  }()
-  return DT_DISPATCH(p, CALL);
-#undef CALL
-}
+                                  const int32_t* active, void* stream);
 
 template <typename T, int NX, int NP, int MU>
 ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, const void* x0, void* xs, void* us,
@@ -573,7 +591,6 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   sa.unfinished = p->d_unfinished;
   sa.ids = nullptr;
   sa.ids_next = nullptr;
-  sa.rows_per_block = kRowsPerBlock;
   sa.probe_pool = nullptr;
   sa.probe_k = 0;
   constexpr int W = TrialWaves<T>::W;
@@ -582,7 +599,15 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   size_t lq_elems = (C::USE_MFMA && !p->desc.params.open_loop) ? PWCfg<T, NX, NP, MU>::LDS_ELEMS : C::LDS_ELEMS;
   if (p->desc.params.open_loop) lq_elems = OLCfg<T, NX, NP, MU>::LDS_ELEMS + 4;
   const size_t lds_lq = lq_elems * sizeof(T);
-  const size_t lds_trial = trial_lds_bytes<T>(d, W);
+  // Rows per chunk of the row stage: the widest whose scratch lets a CU hold four instances of the fused trial kernel
+  // (the headline batch is four instances per CU); the split row kernels get the same width.
+  {
+    const size_t fixed = rows_maps_bytes(d) + ((rollout_lds_elems(d.n, d.m) + 3) & ~size_t(3)) * sizeof(T) + 16;
+    const size_t per_instance = size_t(160) * 1024 / 4;
+    const size_t budget = per_instance > fixed ? (per_instance - fixed) / trial_row_waves(W) : 0;
+    sa.rows_cw = rows_chunk_width(d.n, d.m, d.rp_pslots, d.rp_lslots, sizeof(T), budget);
+  }
+  const size_t lds_trial = trial_lds_bytes<T>(d, W, sa.rows_cw);
   auto k_trial = ilq_trial_kernel<T, NX, NP, MU, W>;
   const bool pw = C::USE_MFMA && !p->desc.params.open_loop;  // one wave per player (MFMA feedback sweep)
   auto k_lq = pw ? ilq_lq_kernel<T, NX, NP, MU, (C::USE_MFMA ? LQ_PLAYER_WAVES : LQ_VALU_FEEDBACK)>
@@ -617,8 +642,9 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   auto k_roll = ilq_roll_kernel<T, NX, NP, MU>;
   auto k_rows = ilq_rows_kernel<T, NX, NP, MU>;
   auto k_decide = ilq_decide_kernel<T, NX, NP, MU>;
-  const size_t lds_roll = trial_phase_lds_bytes<T>(d, TRIAL_ROLL), lds_decide = trial_phase_lds_bytes<T>(d, TRIAL_DECIDE);
-  const size_t lds_rows = quad_tables_bytes(d, sizeof(T)) + trial_phase_quad_elems<T>(d, TRIAL_FUSED) * sizeof(T);
+  const size_t lds_roll = trial_phase_lds_bytes<T>(d, TRIAL_ROLL, sa.rows_cw),
+               lds_decide = trial_phase_lds_bytes<T>(d, TRIAL_DECIDE, sa.rows_cw);
+  const size_t lds_rows = rows_maps_bytes(d) + trial_rows_elems(d, sa.rows_cw) * sizeof(T);
   if (lists && p->pass_ids_capacity < batch) {
     if (p->d_pass_ids) (void)hipFree(p->d_pass_ids);
     p->d_pass_ids = nullptr;
@@ -630,7 +656,8 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   const bool probe = lists && sa.prm.linesearch && !(getenv("ILQG_PROBE") && getenv("ILQG_PROBE")[0] == '0');
   auto k_proll = ilq_probe_roll_kernel<T, NX, NP, MU>;
   auto k_prows = ilq_probe_rows_kernel<T, NX, NP, MU>;
-  const int decide_elems = int(trial_phase_quad_elems<T>(d, TRIAL_DECIDE));
+  const int decide_elems = int(trial_phase_quad_elems<T>(d, TRIAL_DECIDE, sa.rows_cw));
+  const int row_chunks = (d.T + sa.rows_cw - 1) / sa.rows_cw;  // workgroups per instance of the row kernels
   int round_instances = batch, list = 0;  // split passes: how many instances this round covers, which list is free
   int tail_rounds = 0;                    // rounds since the whole batch was last in one
   if (lists) {
@@ -646,7 +673,6 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
     if (counted) HIP_TRY(hipMemsetAsync(p->d_unfinished, 0, 4 * sizeof(int), stream));
     if (split || sa.ids) {  // a split pass: the whole batch (split mode) or the listed back-tracking instances
       sa.ids_next = p->d_pass_ids + size_t(list) * p->pass_ids_capacity;
-      sa.rows_per_block = round_instances < kFewInstances ? 1 : kRowsPerBlock;
       // Step sizes probed per listed instance: as many as the pool holds for a list this long, doubling from two
       // over the first rounds of a tail (most line searches that back-track at all end within a step or two; the
       // ones that do not are the ones worth eight candidates a round).
@@ -663,7 +689,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
         sa.probe_k = probe_k;
         hipLaunchKernelGGL(k_proll, dim3(round_instances, probe_k), dim3(64), lds_roll, stream, d, sa);
         HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(k_prows, dim3((d.T + sa.rows_per_block - 1) / sa.rows_per_block, round_instances * probe_k),
+        hipLaunchKernelGGL(k_prows, dim3(row_chunks, round_instances * probe_k),
                            dim3(64), lds_rows, stream, d, sa);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(ilq_probe_merit_kernel<T>, dim3(round_instances, probe_k), dim3(64),
@@ -675,7 +701,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
       hipLaunchKernelGGL(k_roll, dim3(round_instances), dim3(64), lds_roll, stream, d, sa);
       HIP_TRY(hipGetLastError());
       sa.first = 0;
-      hipLaunchKernelGGL(k_rows, dim3((d.T + sa.rows_per_block - 1) / sa.rows_per_block, round_instances), dim3(64),
+      hipLaunchKernelGGL(k_rows, dim3(row_chunks, round_instances), dim3(64),
                          lds_rows, stream, d, sa);
       HIP_TRY(hipGetLastError());
       hipLaunchKernelGGL(k_decide, dim3(round_instances), dim3(64), lds_decide, stream, d, sa);
@@ -746,6 +772,38 @@ template struct DimsLaunch<double, ILQG_PART_NX, ILQG_PART_NP, ILQG_PART_MU>;
 ILQG_FOR_DIMS(X)
 #undef X
 #endif
+
+static ilqg_status launch_linquad(const ilqg_problem* p, int32_t batch, const void* xs, const void* us,
+                                  const void* lambdas, const void* mu, const int32_t* t_extreme, void* A, void* Bm,
+                                  void* Q, void* l, void* R, void* r, void* merit_part, void* cost_part,
+                                  const int32_t* active, void* stream) {
+  const DevProblem& d = p->dev;
+  // the lane-per-time-step kernel where this (n, N, m_i) is instantiated (ILQG_OLD_ROWS=1: A/B against the
+  // term-per-lane kernel, which also serves shapes outside the list)
+  if (p->mu_uniform && getenv("ILQG_OLD_ROWS") == nullptr) {
+    const void* const ptrs[14] = {xs, us, lambdas, mu, t_extreme, A, Bm, Q, l, R, r, merit_part, cost_part, active};
+#define X(NX_, NP_, MU_)                                                                          \
+  if (d.n == NX_ && d.N == NP_ && p->mu_uniform == MU_)                                           \
+    return p->desc.dtype == ILQG_F32                                                              \
+               ? DimsLaunch<float, NX_, NP_, MU_>::rows(d, batch, ptrs, (hipStream_t)stream)      \
+               : DimsLaunch<double, NX_, NP_, MU_>::rows(d, batch, ptrs, (hipStream_t)stream);
+    ILQG_FOR_DIMS(X)
+#undef X
+  }
+#define CALL(TY_)                                                                                                 \
+  [&]() -> ilqg_status {                                                                                        \
+    QuadBatchArgs<TY_> g{(const TY_*)xs, (const TY_*)us, (const TY_*)lambdas, (const TY_*)mu, t_extreme, (TY_*)A, (TY_*)Bm,   \
+                       (TY_*)Q, (TY_*)l, (TY_*)R, (TY_*)r, (TY_*)merit_part, (TY_*)cost_part, active};                      \
+    const size_t lds = quad_lds_elems(d.n, d.m, d.N, d.pairs.Rsz, d.pairs.rsz, d.num_terms) * sizeof(TY_) +       \
+                       quad_tables_bytes(d, sizeof(TY_));                                                         \
+    hipLaunchKernelGGL(linquad_kernel<TY_>, dim3((d.T + kStepsPerBlock - 1) / kStepsPerBlock, batch), dim3(64),  \
+                       lds, (hipStream_t)stream, d, g);                                                           \
+    HIP_TRY(hipGetLastError());                                                                                 \
+    return ILQG_OK;                                                                                             \
+  }()
+  return DT_DISPATCH(p, CALL);
+#undef CALL
+}
 
 extern "C" {
 
@@ -1140,6 +1198,25 @@ ilqg_status ilqg_problem_create(const ilqg_problem_desc* desc, ilqg_problem** ou
   if (e == hipSuccess) e = hipMemcpy(p->d_cost_order, order.data(), sizeof(int) * order.size(), hipMemcpyHostToDevice);
   // the term table is uploaded last: it carries the scatter rounds computed above
   if (e == hipSuccess) e = hipMemcpy(p->d_terms, dt.data(), sizeof(DevTerm) * dt.size(), hipMemcpyHostToDevice);
+  RowProgramHost rph;
+  {
+    std::string rerr;
+    if (!build_row_program(d, dt, desc->polyline_offsets, &rph, &rerr)) {
+      ilqg_problem_destroy(p);
+      return fail(ILQG_ERR_UNSUPPORTED, rerr);
+    }
+  }
+  if (e == hipSuccess) e = hipMalloc(&p->d_row_prog, sizeof(int) * rph.words.size());
+  if (e == hipSuccess) e = hipMemcpy(p->d_row_prog, rph.words.data(), sizeof(int) * rph.words.size(), hipMemcpyHostToDevice);
+  d.row_prog = p->d_row_prog;
+  d.row_prog_words = int(rph.words.size());
+  d.rp_pslots = rph.num_pslots;
+  d.rp_lslots = rph.max_lslots;
+  d.rp_maps_off = rph.maps_off;
+  d.rp_maps_words = rph.maps_words;
+  if (getenv("ILQG_DEBUG_ROWPROG"))
+    std::fprintf(stderr, "row program: n=%d N=%d terms=%d words=%d persistent slots=%d pass-local slots=%d tables=%zu B\n", d.n,
+                 d.N, d.num_terms, d.row_prog_words, d.rp_pslots, d.rp_lslots, quad_tables_bytes(d, 8));
   if (e != hipSuccess) {
     ilqg_problem_destroy(p);
     return fail(ILQG_ERR_HIP, std::string("problem tables: ") + hipGetErrorString(e));
@@ -1166,6 +1243,7 @@ void ilqg_problem_destroy(ilqg_problem* p) {
   if (p->d_segs_f) (void)hipFree(p->d_segs_f);
   if (p->d_segs_d) (void)hipFree(p->d_segs_d);
   if (p->d_cost_order) (void)hipFree(p->d_cost_order);
+  if (p->d_row_prog) (void)hipFree(p->d_row_prog);
   if (p->d_unfinished) (void)hipFree(p->d_unfinished);
   if (p->h_unfinished) (void)hipHostFree(p->h_unfinished);
   if (p->d_pass_ids) (void)hipFree(p->d_pass_ids);

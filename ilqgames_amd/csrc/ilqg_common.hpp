@@ -94,6 +94,11 @@ struct DevProblem {
   int cq_tab[kMaxClosestQueries][4];
   int cq_items[kMaxClosestItems][2];
   PairTable pairs;
+  // Row program of the lane-per-time-step quadraticisation stage (ilqg_rows.hpp; built by build_row_program)
+  const int* row_prog;
+  int row_prog_words;
+  int rp_pslots, rp_lslots;  // persistent / most pass-local slots: sizes the stage's LDS
+  int rp_maps_off, rp_maps_words;  // the program's word -> slot maps (copied into LDS by every workgroup)
 };
 
 constexpr int kSegStride = 21;

@@ -421,10 +421,16 @@ constexpr int kClosestStride = 12;  // LDS image of a Closest<T>: cx cy ssd is_v
 // Polyline2::ClosestPoint, src/polyline2.cpp:105-174 — linear scan over the 1..15 segments of a
 // lane; the "shortcut" sign rule at interior vertices and the 1e-4 endpoint rule are reproduced.
 // Segments (and the shortcut segments of interior vertices) are precomputed LineSegment2 objects.
-template <typename T>
+// UNIFORM: `poly` is the same on every lane (the lane-per-time-step stage): the scan's bounds are pinned to scalar
+// registers so that its loop is a scalar branch.
+template <typename T, bool UNIFORM = false>
 __device__ __forceinline__ Closest<T> polyline_closest(const QuadTables<T>& tb, int poly, T qx, T qy) {
-  const int first = tb.poly_off[poly] - poly;  // segments before this polyline
-  const int nseg = tb.poly_off[poly + 1] - tb.poly_off[poly] - 1;
+  int first = tb.poly_off[poly] - poly;  // segments before this polyline
+  int nseg = tb.poly_off[poly + 1] - tb.poly_off[poly] - 1;
+  if constexpr (UNIFORM) {
+    first = __builtin_amdgcn_readfirstlane(first);
+    nseg = __builtin_amdgcn_readfirstlane(nseg);
+  }
   const T* base = tb.segs + size_t(first) * kSegStride;
   Closest<T> out;
   T best = dinf<T>();
@@ -550,9 +556,10 @@ __device__ __forceinline__ T constraint_mu(T lambda, T g, T mu) {
   return (g <= T(1e-4f) && t_abs(lambda) <= T(1e-4f)) ? T(0) : mu;
 }
 
-template <typename T>
-__device__ __forceinline__ T term_evaluate_leaf(const QuadTables<T>& tb, int ti, const T* v, int dim) {
-  const DevTerm c = tb.terms[ti];
+// `v` is anything indexable that yields the argument vector's entries: a pointer (LDS / global row) or the
+// transposed-row accessor of the lane-per-time-step stage (ilqg_rows.hpp).
+template <typename T, typename V>
+__device__ __forceinline__ T term_evaluate_leaf_of(const QuadTables<T>& tb, const DevTerm& c, const V& v, int dim) {
   const T w = T(c.weight), val = T(c.value);
   const bool oriented = c.flags & ILQG_FLAG_ORIENTED;
   switch (c.kind) {
@@ -616,15 +623,20 @@ __device__ __forceinline__ T term_evaluate_leaf(const QuadTables<T>& tb, int ti,
   }
   return T(0);
 }
+template <typename T, typename V>
+__device__ __forceinline__ T term_evaluate_leaf(const QuadTables<T>& tb, int ti, const V& v, int dim) {
+  const DevTerm c = tb.terms[ti];
+  return term_evaluate_leaf_of<T, V>(tb, c, v, dim);
+}
 
 // ExtremeValueCost::ExtremeCost, src/extreme_value_cost.cpp:66-85: index of the active child.
-template <typename T>
-__device__ __forceinline__ int extreme_child(const QuadTables<T>& tb, const DevTerm& c, const T* v, int dim, T* value_out) {
+template <typename T, typename V>
+__device__ __forceinline__ int extreme_child(const QuadTables<T>& tb, const DevTerm& c, const V& v, int dim, T* value_out) {
   const bool is_min = c.flags & ILQG_FLAG_IS_MIN;
   T ext = is_min ? dinf<T>() : -dinf<T>();
   int best = c.child_begin;
   for (int q = 0; q < c.child_count; q++) {
-    const T value = term_evaluate_leaf(tb, c.child_begin + q, v, dim);
+    const T value = term_evaluate_leaf<T, V>(tb, c.child_begin + q, v, dim);
     if ((is_min && value < ext) || (!is_min && value > ext)) {
       ext = value;
       best = c.child_begin + q;
@@ -673,9 +685,12 @@ struct TermOut {
 
 // Cost::Evaluate + Cost::Quadraticize of one LEAF term in one pass (the polyline closest-point
 // search is shared).  `lambda`, `mu`: augmented-Lagrangian state of a constraint term.
-template <typename T>
-__device__ __forceinline__ void term_compute_leaf(const QuadTables<T>& tb, const DevTerm& c, const T* v, T lambda,
-                                                  T mu, TermOut<T>* o, const T* sclo = nullptr) {
+// `pre`: the closest point of this term's polyline to its position, when the caller already has it.  HAVE_PRE: the
+// caller always has it (the polyline searches are compiled out of this function).
+template <typename T, typename V, bool HAVE_PRE = false>
+__device__ __forceinline__ void term_compute_leaf(const QuadTables<T>& tb, const DevTerm& c, const V& v, T lambda,
+                                                  T mu, TermOut<T>* o, const T* sclo = nullptr,
+                                                  const Closest<T>* pre = nullptr) {
   const T w = T(c.weight), val = T(c.value);
   const bool oriented = c.flags & ILQG_FLAG_ORIENTED;
   o->pattern = PAT_NONE;
@@ -713,8 +728,14 @@ __device__ __forceinline__ void term_compute_leaf(const QuadTables<T>& tb, const
     case ILQG_COST_SEMIQUADRATIC_POLYLINE2: {  // src/semiquadratic_polyline2_cost.cpp:52-142
       const bool semi = c.kind == ILQG_COST_SEMIQUADRATIC_POLYLINE2;
       const T px = v[c.idx[0]], py = v[c.idx[1]];
-      const Closest<T> cl = (sclo != nullptr && c.cq >= 0) ? closest_load<T>(sclo + kClosestStride * c.cq)
-                                                           : polyline_closest<T>(tb, c.polyline, px, py);
+      Closest<T> cl;
+      if constexpr (HAVE_PRE) {
+        cl = *pre;
+      } else {
+        cl = pre != nullptr ? *pre
+             : (sclo != nullptr && c.cq >= 0) ? closest_load<T>(sclo + kClosestStride * c.cq)
+                                              : polyline_closest<T>(tb, c.polyline, px, py);
+      }
       T dx, dy;
       if (semi) {
         const T sst = sgn(val) * val * val;
@@ -760,7 +781,8 @@ __device__ __forceinline__ void term_compute_leaf(const QuadTables<T>& tb, const
     }
     case ILQG_COST_POLYLINE2_SIGNED_DISTANCE: {  // src/polyline2_signed_distance_cost.cpp:52-126
       const T px = v[c.idx[0]], py = v[c.idx[1]];
-      const Closest<T> cl = polyline_closest<T>(tb, c.polyline, px, py);
+      Closest<T> cl;
+      if constexpr (HAVE_PRE) cl = *pre; else cl = polyline_closest<T>(tb, c.polyline, px, py);
       const T ssd = oriented ? cl.ssd : -cl.ssd;
       const T sign = sgn(ssd);
       const T distance = t_sqrt(t_abs(ssd));
@@ -839,18 +861,18 @@ __device__ __forceinline__ void term_compute_leaf(const QuadTables<T>& tb, const
 }
 
 // Top-level term: ExtremeValueCost dispatches to its active child (src/extreme_value_cost.cpp:51-85).
-template <typename T>
-__device__ __forceinline__ void term_compute(const QuadTables<T>& tb, const DevTerm& c, const T* v, T lambda, T mu,
+template <typename T, typename V>
+__device__ __forceinline__ void term_compute(const QuadTables<T>& tb, const DevTerm& c, const V& v, T lambda, T mu,
                                              TermOut<T>* o, const T* sclo = nullptr) {
   if (c.kind == ILQG_COST_EXTREME_VALUE) {
     T value;
-    const int best = extreme_child(tb, c, v, c.arg_dim, &value);
+    const int best = extreme_child<T, V>(tb, c, v, c.arg_dim, &value);
     const DevTerm child = tb.terms[best];
-    term_compute_leaf<T>(tb, child, v, lambda, mu, o);
+    term_compute_leaf<T, V>(tb, child, v, lambda, mu, o);
     o->value = value;
     return;
   }
-  term_compute_leaf<T>(tb, c, v, lambda, mu, o, sclo);
+  term_compute_leaf<T, V>(tb, c, v, lambda, mu, o, sclo);
 }
 
 // Scatter one term's contribution into its LDS tiles (H column-major with leading dim ld).

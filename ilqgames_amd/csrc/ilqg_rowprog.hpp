@@ -1,0 +1,333 @@
+// ilqg_rowprog.hpp — host side of the lane-per-time-step quadraticisation stage: compiles a problem's dynamics and
+// cost list into the "row program" ilqg_rows.hpp executes (passes, ops, slot lists, word -> slot maps).
+//
+// A slot is one word of the per-row image [A | B | Q_i | l_i | R_ij | r_ij] that some term (or a Jacobian) can
+// write; every other word of the image is a constant (0, 1, +-dt, a regularisation weight).  The constants are the
+// persistent slots; everything a pass accumulates (the Jacobian entries; the touched entries of one player's Q_i and
+// l_i, the diagonals and touched entries of its R_ij, its touched r_ij entries) is pass-local and its LDS is re-used
+// by the next pass.  Accumulation order is PlayerCost::Quadraticize's (src/player_cost.cpp:194-225): per player
+// state costs, control costs, state constraints, control constraints, each in table order.
+#pragma once
+
+#include <cstring>
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "ilqg_rows.hpp"
+
+namespace ilqg {
+
+struct RowProgramHost {
+  std::vector<int> words;  // the device image
+  int num_pslots = 0, max_lslots = 0, maps_off = 0, maps_words = 0;
+};
+
+// `poly_off`: the problem's polyline offsets (points), host copy.
+inline bool build_row_program(const DevProblem& d, const std::vector<DevTerm>& dt, const int* poly_off,
+                              RowProgramHost* out, std::string* err) {
+  const int n = d.n, m = d.m, N = d.N;
+  const PairTable& pt = d.pairs;
+  auto fbits = [](float v) { int b; std::memcpy(&b, &v, sizeof(b)); return b; };
+  std::vector<int> pinit;  // init records of the persistent slots
+  auto new_pslot = [&](int code, float value) {
+    pinit.push_back(code);
+    pinit.push_back(fbits(value));
+    return int(pinit.size()) / RINIT_WORDS - 1;
+  };
+  const int S_ZERO = new_pslot(RI_VALUE, 0.0f), S_ONE = new_pslot(RI_VALUE, 1.0f), S_DT = new_pslot(RI_DT, 0.0f),
+            S_NDT = new_pslot(RI_NEG_DT, 0.0f);
+  if (S_ZERO != kRowSlotZero) { *err = "row program: slot 0 must be the zero constant"; return false; }
+  std::vector<int> S_SREG(N);
+  for (int i = 0; i < N; i++) S_SREG[i] = new_pslot(RI_VALUE, d.state_reg[i]);
+  const int NPS = int(pinit.size()) / RINIT_WORDS;
+
+  auto pair_of = [&](int i, int j) {
+    for (int q = 0; q < pt.npairs; q++)
+      if (pt.pi[q] == i && pt.pj[q] == j) return q;
+    return -1;
+  };
+  // ---- the entries a leaf term adds to: (is_hessian, a, b) in rows_scatter's order ----
+  struct Entry { bool h; int a, b; };
+  auto leaf_entries = [&](const DevTerm& c, int dim, std::vector<Entry>* e) {
+    const int pat = term_pattern_of(c.kind, c.idx[0]);
+    if (pat == PAT_SINGLE) {
+      e->push_back({false, c.idx[0], 0});
+      e->push_back({true, c.idx[0], c.idx[0]});
+    } else if (pat == PAT_PAIR2) {
+      const int x = c.idx[0], y = c.idx[1];
+      e->push_back({false, x, 0}); e->push_back({false, y, 0});
+      e->push_back({true, x, x}); e->push_back({true, y, y}); e->push_back({true, x, y}); e->push_back({true, y, x});
+    } else if (pat == PAT_PAIR4) {
+      const int x1 = c.idx[0], y1 = c.idx[1], x2 = c.idx[2], y2 = c.idx[3];
+      e->push_back({false, x1, 0}); e->push_back({false, x2, 0}); e->push_back({false, y1, 0}); e->push_back({false, y2, 0});
+      const int hh[16][2] = {{x1, x1}, {x1, x2}, {x2, x1}, {x2, x2}, {y1, y1}, {y1, y2}, {y2, y1}, {y2, y2},
+                             {x1, y1}, {y1, x1}, {x1, y2}, {y2, x1}, {x2, y1}, {y1, x2}, {x2, y2}, {y2, x2}};
+      for (auto& q : hh) e->push_back({true, q[0], q[1]});
+    } else if (pat == PAT_ALL) {
+      for (int i = 0; i < dim; i++) e->push_back({false, i, 0});
+      for (int i = 0; i < dim; i++) e->push_back({true, i, i});
+    }
+  };
+  auto on_state = [&](const DevTerm& c) {
+    return c.role == ILQG_ROLE_STATE_COST || c.role == ILQG_ROLE_STATE_CONSTRAINT || c.role == ILQG_ROLE_CHILD;
+  };
+
+  // ---- tables ----
+  std::vector<int> passes, ops, sids, linit, regions, merit;
+  std::vector<short> maps;
+  int max_lslots = 0;
+  auto emit_op = [&](int mode, int sid_begin, int nsid, int aux, const DevTerm& c, const DevTerm& owner, int poly_first,
+                     int pattern_or_nseg) {
+    // `owner`: the top-level term whose role / player / constraint slot / first step apply (c itself, or the
+    // ExtremeValueCost c is a child of)
+    int o[ROP_WORDS] = {0};
+    o[RO_MODE] = mode; o[RO_SID] = sid_begin; o[RO_NSID] = nsid; o[RO_AUX] = aux;
+    o[RO_KIND] = c.kind; o[RO_ROLE] = owner.role; o[RO_PLAYER] = owner.player;
+    o[RO_FLAGS] = c.flags | (owner.flags & ILQG_FLAG_IS_MIN);
+    for (int q = 0; q < 4; q++) o[RO_IDX0 + q] = c.idx[q];
+    o[RO_WEIGHT] = fbits(c.weight); o[RO_VALUE] = fbits(c.value); o[RO_POLY_FIRST] = poly_first;
+    o[RO_SLOT] = owner.slot; o[RO_ARG_OFF] = owner.arg_off; o[RO_ARG_DIM] = owner.arg_dim; o[RO_K_START] = owner.k_start;
+    o[RO_PATTERN_NSEG] = pattern_or_nseg;
+    ops.insert(ops.end(), o, o + ROP_WORDS);
+  };
+  auto add_region = [&](int arr, int words, int offs, const std::vector<short>& map) {
+    regions.push_back(arr); regions.push_back(words); regions.push_back(offs); regions.push_back(int(maps.size()));
+    maps.insert(maps.end(), map.begin(), map.end());
+    if (maps.size() & 1) maps.push_back(0);
+  };
+  auto add_linit = [&](int code, float value) { linit.push_back(code); linit.push_back(fbits(value)); };
+
+  // pass 0: the Jacobians
+  {
+    std::vector<short> mapA(size_t(n) * n, short(S_ZERO)), mapB(size_t(n) * m, short(S_ZERO));
+    for (int i = 0; i < n; i++) mapA[i + n * i] = short(S_ONE);
+    const int op_begin = int(ops.size()) / ROP_WORDS, li_begin = int(linit.size()) / RINIT_WORDS;
+    int nl = 0;
+    for (int s = 0; s < N; s++) {
+      const int kind = d.sub_kind[s], xo = d.xoff[s], uo = d.uoff[s];
+      std::vector<std::pair<int, int>> av, bv;  // computed entries, in the order rows_chunk's Jacobian op writes them
+      auto A = [&](int r, int c) -> short& { return mapA[(xo + r) + n * (xo + c)]; };
+      auto B = [&](int r, int c) -> short& { return mapB[(xo + r) + n * (uo + c)]; };
+      if (kind == ILQG_DYN_UNICYCLE_4D || kind == ILQG_DYN_UNICYCLE_4D_DISTURBED) {
+        av = {{0, 2}, {0, 3}, {1, 2}, {1, 3}};
+        B(2, 0) = short(S_DT); B(3, 1) = short(S_DT);
+      } else if (kind == ILQG_DYN_CAR_5D || kind == ILQG_DYN_CAR_6D) {
+        av = {{0, 2}, {0, 4}, {1, 2}, {1, 4}, {2, 3}, {2, 4}};
+        if (kind == ILQG_DYN_CAR_5D) { B(3, 0) = short(S_DT); B(4, 1) = short(S_DT); }
+        else { A(4, 5) = short(S_DT); B(3, 0) = short(S_DT); B(5, 1) = short(S_DT); }
+      } else if (kind == ILQG_DYN_DUBINS_CAR) {
+        av = {{0, 2}, {1, 2}};
+        B(2, 0) = short(S_DT);
+      } else if (kind == ILQG_DYN_POINT_MASS_2D) {
+        A(0, 2) = short(S_DT); A(1, 3) = short(S_DT); B(2, 0) = short(S_DT); B(3, 1) = short(S_DT);
+      } else if (kind == ILQG_DYN_AIR_3D_EVADER) {
+        av = {{0, 1}, {0, 2}, {1, 0}, {1, 2}};
+        bv = {{0, 0}, {1, 0}};
+        B(2, 0) = short(S_NDT);
+      } else if (kind == ILQG_DYN_AIR_3D_PURSUER) {
+        B(-1, 0) = short(S_DT);
+      } else if (kind == ILQG_DYN_PLANAR_DISTURBANCE) {
+        B(-4, 0) = short(S_DT); B(-3, 1) = short(S_DT);
+      } else {
+        *err = "row program: unknown subsystem kind";
+        return false;
+      }
+      DevTerm j{};
+      j.kind = kind;
+      j.idx[0] = xo; j.idx[1] = uo;
+      j.weight = d.sub_param[s];
+      j.value = s + 1 < N ? d.sub_param[s + 1] : 0.0f;  // Air3D: the pursuer's speed enters the evader's rows
+      emit_op(ROP_JACOBIAN, int(sids.size()), int(av.size() + bv.size()), s, j, j, 0, 0);
+      for (auto& rc : av) {
+        A(rc.first, rc.second) = short(NPS + nl);
+        sids.push_back(NPS + nl);
+        add_linit(RI_VALUE, 0.0f);
+        nl++;
+      }
+      for (auto& rc : bv) {
+        B(rc.first, rc.second) = short(NPS + nl);
+        sids.push_back(NPS + nl);
+        add_linit(RI_VALUE, 0.0f);
+        nl++;
+      }
+    }
+    const int reg_begin = int(regions.size()) / RREG_WORDS;
+    add_region(RA_A, n * n, 0, mapA);
+    add_region(RA_B, n * m, 0, mapB);
+    passes.insert(passes.end(), {op_begin, int(ops.size()) / ROP_WORDS, reg_begin, int(regions.size()) / RREG_WORDS,
+                                 li_begin, nl, RPASS_JACOBIANS, 0});
+    if (nl > max_lslots) max_lslots = nl;
+  }
+
+  // passes 1..N: the players
+  merit.assign(size_t(N) * RMERIT_WORDS, 0);
+  for (int i = 0; i < N; i++) {
+    std::map<int, int> q_slot;                  // word of Q_i (a + n * b) -> pass-local slot
+    std::map<int, int> l_slot;                  // d
+    std::map<std::pair<int, int>, int> R_slot;  // (pair, a + mj * b)
+    std::map<std::pair<int, int>, int> r_slot;  // (pair, d)
+    const int op_begin = int(ops.size()) / ROP_WORDS, li_begin = int(linit.size()) / RINIT_WORDS;
+    int nl = 0;
+    // sigma_u on the diagonal of every control block of this player (player_cost.cpp:70-74)
+    for (int q = 0; q < pt.npairs; q++) {
+      if (pt.pi[q] != i) continue;
+      const int mj = d.udim[pt.pj[q]];
+      for (int a = 0; a < mj; a++) {
+        R_slot[{q, a + mj * a}] = nl++;
+        add_linit(RI_CREG | (i << 8) | ((pt.from_cost[q] ? 1 : 0) << 16), d.control_reg[i]);
+      }
+    }
+    bool ok = true;
+    // slot ids of one leaf's entries, in rows_scatter's order
+    auto leaf_sids = [&](const DevTerm& leaf, const DevTerm& owner) {
+      const int begin = int(sids.size());
+      std::vector<Entry> le;
+      leaf_entries(leaf, owner.arg_dim, &le);
+      const bool st = on_state(owner);
+      const int q = st ? -1 : pair_of(owner.player, owner.arg);
+      const int mj = st ? 0 : d.udim[owner.arg];
+      if (!st && q < 0) { ok = false; return begin; }
+      for (auto& e : le) {
+        const int lim = st ? n : mj;
+        if (e.a < 0 || e.a >= lim || (e.h && (e.b < 0 || e.b >= lim))) { ok = false; return begin; }
+        int* slot;
+        float init = 0.0f;
+        if (st && e.h) {
+          const int w = e.a + n * e.b;
+          if (!q_slot.count(w)) q_slot[w] = -1;
+          slot = &q_slot[w];
+          init = e.a == e.b ? d.state_reg[i] : 0.0f;
+        } else if (st) {
+          if (!l_slot.count(e.a)) l_slot[e.a] = -1;
+          slot = &l_slot[e.a];
+        } else if (e.h) {
+          if (!R_slot.count({q, e.a + mj * e.b})) R_slot[{q, e.a + mj * e.b}] = -1;
+          slot = &R_slot[{q, e.a + mj * e.b}];
+        } else {
+          if (!r_slot.count({q, e.a})) r_slot[{q, e.a}] = -1;
+          slot = &r_slot[{q, e.a}];
+        }
+        if (*slot < 0) {
+          *slot = nl++;
+          add_linit(RI_VALUE, init);
+        }
+        sids.push_back(NPS + *slot);
+      }
+      // rows_scatter reads all of a leaf's slots before it writes any of them
+      for (size_t x = begin; x < sids.size(); x++)
+        for (size_t y = x + 1; y < sids.size(); y++)
+          if (sids[x] == sids[y]) { ok = false; return begin; }
+      return begin;
+    };
+    int closest_key[4] = {-1, -1, -1, -1};  // (polyline, x index, y index, argument offset) of the pass's last CLOSEST op
+    auto want_closest = [&](const DevTerm& leaf, const DevTerm& owner) {
+      if (!term_is_polyline(leaf.kind)) return;
+      const int key[4] = {leaf.polyline, leaf.idx[0], leaf.idx[1], owner.arg_off};
+      if (std::memcmp(key, closest_key, sizeof(key)) == 0) return;
+      std::memcpy(closest_key, key, sizeof(key));
+      if (leaf.polyline < 0 || leaf.polyline >= d.num_polylines) { ok = false; return; }
+      const int first = poly_off[leaf.polyline] - leaf.polyline;  // segments before this polyline
+      const int nseg = poly_off[leaf.polyline + 1] - poly_off[leaf.polyline] - 1;
+      if (nseg < 1) { ok = false; return; }
+      emit_op(ROP_CLOSEST, 0, 0, 0, leaf, owner, first, nseg);
+    };
+    for (int role = 0; role < 4 && ok; role++)
+      for (int ti = 0; ti < d.num_terms && ok; ti++) {
+        const DevTerm& c = dt[ti];
+        if (c.player != i || c.role != role) continue;
+        if (c.kind == ILQG_COST_EXTREME_VALUE) {
+          if (c.child_count < 1 || c.child_count > 255) { *err = "row program: bad ExtremeValueCost"; return false; }
+          for (int q = 0; q < c.child_count; q++) {
+            const DevTerm& ch = dt[c.child_begin + q];
+            want_closest(ch, c);
+            emit_op(ROP_EXT_EVAL, 0, 0, q, ch, c, 0, term_pattern_of(ch.kind, ch.idx[0]));
+          }
+          for (int q = 0; q < c.child_count; q++) {
+            const DevTerm& ch = dt[c.child_begin + q];
+            want_closest(ch, c);
+            const int b0 = leaf_sids(ch, c);
+            emit_op(ROP_EXT_APPLY, b0, int(sids.size()) - b0, q, ch, c, 0, term_pattern_of(ch.kind, ch.idx[0]));
+          }
+        } else {
+          want_closest(c, c);
+          const int b0 = leaf_sids(c, c);
+          emit_op(ROP_TERM, b0, int(sids.size()) - b0, 0, c, c, 0, term_pattern_of(c.kind, c.idx[0]));
+        }
+      }
+    if (!ok) { *err = "row program: a term's indices are out of range or not distinct"; return false; }
+    // what this pass writes: Q_i, l_i and the R / r blocks of this player's control pairs
+    const int reg_begin = int(regions.size()) / RREG_WORDS;
+    {
+      std::vector<short> mapQ(size_t(n) * n, short(S_ZERO));
+      for (int e = 0; e < n; e++) mapQ[e + n * e] = short(S_SREG[i]);
+      for (auto& kv : q_slot) mapQ[kv.first] = short(NPS + kv.second);
+      add_region(RA_Q, n * n, i * n * n, mapQ);
+      std::vector<short> mapl((size_t)n, (short)S_ZERO);
+      for (auto& kv : l_slot) mapl[kv.first] = short(NPS + kv.second);
+      add_region(RA_L, n, i * n, mapl);
+      for (int q = 0; q < pt.npairs; q++) {
+        if (pt.pi[q] != i) continue;
+        const int mj = d.udim[pt.pj[q]];
+        std::vector<short> mapR((size_t)mj * mj, (short)S_ZERO), mapr((size_t)mj, (short)S_ZERO);
+        for (auto& kv : R_slot)
+          if (kv.first.first == q) mapR[kv.first.second] = short(NPS + kv.second);
+        for (auto& kv : r_slot)
+          if (kv.first.first == q) mapr[kv.first.second] = short(NPS + kv.second);
+        add_region(RA_R, mj * mj, pt.roff[q], mapR);
+        add_region(RA_r, mj, pt.rgoff[q], mapr);
+      }
+    }
+    // merit lists: |l_i|^2 over the touched entries (ascending d), |r_ii|^2 over all of the player's own controls
+    {
+      const int lb = int(sids.size());
+      for (auto& kv : l_slot) sids.push_back(NPS + kv.second);  // std::map: ascending d
+      const int rb = int(sids.size());
+      const int q = pt.pii[i], mi = d.udim[i];
+      for (int a = 0; a < mi; a++) sids.push_back(r_slot.count({q, a}) ? NPS + r_slot[{q, a}] : kRowSlotZero);
+      int* md = merit.data() + size_t(i) * RMERIT_WORDS;
+      md[0] = lb; md[1] = int(l_slot.size()); md[2] = rb; md[3] = mi;
+    }
+    passes.insert(passes.end(), {op_begin, int(ops.size()) / ROP_WORDS, reg_begin, int(regions.size()) / RREG_WORDS,
+                                 li_begin, nl, RPASS_PLAYER, i});
+    if (nl > max_lslots) max_lslots = nl;
+  }
+  if (NPS + max_lslots > 32000) { *err = "row program: too many slots"; return false; }
+
+  // ---- flatten ----
+  std::vector<int>& w = out->words;
+  w.assign(RP_HEADER, 0);
+  auto put = [&](const std::vector<int>& v) {
+    const int at = int(w.size());
+    w.insert(w.end(), v.begin(), v.end());
+    if (v.empty()) w.push_back(0);
+    return at;
+  };
+  w[RP_NUM_PASSES] = int(passes.size()) / RPASS_WORDS;
+  w[RP_NUM_PSLOTS] = NPS;
+  w[RP_MAX_LSLOTS] = max_lslots;
+  w[RP_OFF_PASS] = put(passes);
+  w[RP_OFF_OPS] = put(ops);
+  w[RP_OFF_SIDS] = put(sids);
+  w[RP_OFF_PINIT] = put(pinit);
+  w[RP_OFF_LINIT] = put(linit);
+  w[RP_OFF_REGIONS] = put(regions);
+  w[RP_OFF_MERIT] = put(merit);
+  while (w.size() & 3) w.push_back(0);
+  w[RP_OFF_MAPS] = int(w.size());
+  for (size_t e = 0; e < maps.size(); e += 2) {
+    const unsigned lo = (unsigned short)maps[e], hi = (unsigned short)(e + 1 < maps.size() ? maps[e + 1] : 0);
+    w.push_back(int(lo | (hi << 16)));
+  }
+  w[RP_MAPS_WORDS] = int(w.size()) - w[RP_OFF_MAPS];
+  while (w.size() & 3) w.push_back(0);
+  w[RP_WORDS] = int(w.size());
+  out->num_pslots = NPS;
+  out->max_lslots = max_lslots;
+  out->maps_off = w[RP_OFF_MAPS];
+  out->maps_words = w[RP_MAPS_WORDS];
+  return true;
+}
+
+}  // namespace ilqg

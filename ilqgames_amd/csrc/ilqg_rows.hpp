@@ -1,0 +1,564 @@
+// ilqg_rows.hpp — linearise + quadraticise with ONE LANE PER TIME STEP (gfx950).
+//
+// Computes, for a chunk of consecutive time steps ("rows") of one game instance, what
+//   ILQSolver::ComputeLinearization (src/ilq_solver.cpp:437-455),
+//   ILQSolver::ComputeCostQuadraticization (:471-490) -> PlayerCost::Quadraticize (src/player_cost.cpp:194-225),
+//   the per-step pieces of ILQSolver::MeritFunction (:400-435) and ILQSolver::TotalCosts (:220-257)
+// compute, one row at a time, in the reference.
+//
+// Mapping.  The rows of a trajectory are independent of each other and run the SAME cost list, so lane r of the
+// wavefront takes row k0 + r and the wave walks the cost list once for all of them: the term being evaluated, its
+// kind, indices, weights and the polyline segments are wave-uniform — they are read through the scalar data cache
+// (s_load from the row program in constant memory) and live in scalar registers, branches on them are scalar
+// branches — and no lane diverges from its neighbours except where a cost is inactive at its row.  A lane meets the
+// terms of a player in PlayerCost::Quadraticize's order, so every Hessian / gradient entry is accumulated in the
+// reference's order by construction.  (The first design of this stage gave a lane to each cost TERM of one row:
+// ~1000 instructions and ~16 k cycles per row, every cost kind's branch executed once per row whatever the number of
+// lanes in it.)
+//
+// The images [A | B | Q_i | l_i | R_ij | r_ij] of 64 rows do not fit the LDS, but cost Hessians are sparse: the host
+// lists the image words any term (or a Jacobian) can touch — "slots" — and a lane accumulates its row's slots in
+// LDS, acc[slot][lane].  Writing a row out is then a gather: every lane owns fixed words of the row's image, looks up
+// "which slot (or constant) is my word" once per chunk, and the wave streams the dense rows with full-width stores.
+// The work is cut into passes (the Jacobians, then one per player) so that the slots of one player's
+// Q_i, l_i, R_i*, r_i* are all that is live at a time.  The "row program" (passes, ops, slot lists, word maps) is built
+// by ilqg_problem_create (ilqg_rowprog.hpp).
+#pragma once
+
+#include "ilqg_common.hpp"
+#include "ilqg_models.hpp"
+
+#ifndef ILQG_PROFILE2
+#define ILQG_PROFILE2 0  // diagnostic: per-op phase stamps instead of the per-pass ones
+#endif
+
+namespace ilqg {
+
+// Loads through this pointer type are scalar loads whenever the address is wave-uniform (the constant address
+// space: the program is written by the host before any kernel runs).
+typedef const __attribute__((address_space(4))) int* rp_cptr;
+template <typename T> struct ConstPtr;
+template <> struct ConstPtr<float> { typedef const __attribute__((address_space(4))) float* type; };
+template <> struct ConstPtr<double> { typedef const __attribute__((address_space(4))) double* type; };
+
+// ---- row program: a flat int32 buffer; header words give the offsets of its tables ----
+enum {
+  RP_NUM_PASSES = 0, RP_NUM_PSLOTS, RP_MAX_LSLOTS, RP_OFF_PASS, RP_OFF_OPS, RP_OFF_SIDS, RP_OFF_PINIT, RP_OFF_LINIT,
+  RP_OFF_REGIONS, RP_OFF_MAPS, RP_MAPS_WORDS, RP_OFF_MERIT, RP_WORDS, RP_HEADER = 16
+};
+enum { RPASS_WORDS = 8, ROP_WORDS = 20, RREG_WORDS = 4, RMERIT_WORDS = 4, RINIT_WORDS = 2 };
+// An op is self-contained: [mode, first slot id, slot ids, aux | the fields of the term it evaluates].
+//   TERM       one top-level cost / constraint
+//   EXT_EVAL   child `aux` of an ExtremeValueCost: its value competes for the extreme (no derivatives yet)
+//   EXT_APPLY  the same child again: the lanes whose extreme it is take its derivatives
+//   JACOBIAN   one subsystem's Linearize (kind = dynamics kind, idx0 / idx1 = its state / control offsets,
+//              weight / value = its parameter and the next subsystem's)
+//   CLOSEST    Polyline2::ClosestPoint of (x[idx0], x[idx1]) to the polyline whose segments start at `poly_first`
+//              (`poly_nseg` of them); the polyline terms that follow read the result
+// An ExtremeValueCost becomes EXT_EVAL x children, EXT_APPLY x children; role / player / constraint slot / first
+// active step of those ops are the parent's.
+enum { ROP_TERM = 0, ROP_EXT_EVAL = 1, ROP_EXT_APPLY = 2, ROP_JACOBIAN = 3, ROP_CLOSEST = 4 };
+enum {
+  RO_MODE = 0, RO_SID, RO_NSID, RO_AUX, RO_KIND, RO_ROLE, RO_PLAYER, RO_FLAGS, RO_IDX0, RO_IDX1, RO_IDX2, RO_IDX3,
+  RO_WEIGHT, RO_VALUE, RO_POLY_FIRST, RO_SLOT, RO_ARG_OFF, RO_ARG_DIM, RO_K_START, RO_PATTERN_NSEG
+};
+// how a slot starts a chunk (persistent slots) or a pass (pass-local slots): [kind | player << 8 | from_cost << 16,
+// value (float bits)]; RI_CREG is the value only where the reference would have created the control block
+enum { RI_VALUE = 0, RI_DT = 2, RI_NEG_DT = 3, RI_CREG = 5 };
+enum { RA_A = 0, RA_B = 1, RA_Q = 2, RA_L = 3, RA_R = 4, RA_r = 5 };
+enum { RPASS_JACOBIANS = 0, RPASS_PLAYER = 1 };
+constexpr int kRowSlotZero = 0;  // persistent slot 0 is always the constant zero
+
+// The transposed argument image of a chunk: entry e of row r at arg[e * cw + r].
+template <typename T>
+struct RowArg {
+  const T* base;  // &arg[first entry * cw + this lane's row]
+  int stride;
+  __device__ __forceinline__ T operator[](int i) const { return base[i * stride]; }
+};
+
+// LDS of one wave of this stage: [arg (n + m) x cw | acc (persistent + pass-local slots) x (cw + 1)], and the word
+// maps, shared by the waves of a workgroup
+__host__ __device__ inline size_t rows_lds_elems(int n, int m, int num_pslots, int max_lslots, int cw) {
+  return size_t(n + m) * cw + size_t(num_pslots + max_lslots) * (cw + 1);
+}
+// Largest chunk width (64, 32 or 16 rows) whose scratch fits `budget` bytes.
+__host__ __device__ inline int rows_chunk_width(int n, int m, int num_pslots, int max_lslots, size_t elem, size_t budget) {
+  for (int cw = 64; cw > 16; cw >>= 1)
+    if (rows_lds_elems(n, m, num_pslots, max_lslots, cw) * elem <= budget) return cw;
+  return 16;
+}
+
+// Largest vector width (elements) that keeps every row's block of `unit`-element granularity 16 / 8 / 4-byte aligned.
+template <typename T>
+constexpr int rows_vec_width(int unit) {
+  constexpr int full = 16 / int(sizeof(T));
+  return (unit % full == 0) ? full : ((unit % 2 == 0 && full >= 2) ? 2 : 1);
+}
+
+template <typename T, int VW> struct RowVec;
+template <typename T> struct RowVec<T, 1> { typedef T type; };
+template <typename T> struct RowVec<T, 2> { typedef T type __attribute__((ext_vector_type(2))); };
+template <typename T> struct RowVec<T, 4> { typedef T type __attribute__((ext_vector_type(4))); };
+
+// Streams rows [0, nrows) of one output block: W words per row at g0 + r * stride, word w of a row from
+// acc[map[w]][r].  Every lane fetches the slots of its words once; the LDS reads of RB rows are issued together, then
+// their stores (one exposed LDS round trip per RB rows instead of one per store).
+template <typename T, int W, int VW>
+__device__ __forceinline__ void rows_writeout(T* g0, size_t stride, const short* map, const T* acc, int cws, int nrows,
+                                              int lane) {
+  constexpr int NST = (W + 64 * VW - 1) / (64 * VW);
+  constexpr int RB = (NST * VW <= 4) ? 4 : 2;
+  typedef typename RowVec<T, VW>::type vec;
+  int off[NST][VW];
+#pragma unroll
+  for (int j = 0; j < NST; j++)
+#pragma unroll
+    for (int q = 0; q < VW; q++) {
+      const int w = (j * 64 + lane) * VW + q;
+      off[j][q] = (w < W ? int(map[w]) : kRowSlotZero) * cws;
+    }
+#pragma unroll 1
+  for (int r0 = 0; r0 < nrows; r0 += RB) {
+    T val[RB][NST][VW];
+#pragma unroll
+    for (int rr = 0; rr < RB; rr++) {
+      const int r = r0 + rr < nrows ? r0 + rr : nrows - 1;
+#pragma unroll
+      for (int j = 0; j < NST; j++)
+#pragma unroll
+        for (int q = 0; q < VW; q++) val[rr][j][q] = acc[off[j][q] + r];
+    }
+#pragma unroll
+    for (int rr = 0; rr < RB; rr++) {
+      if (r0 + rr < nrows) {
+        T* g = g0 + size_t(r0 + rr) * stride;
+#pragma unroll
+        for (int j = 0; j < NST; j++) {
+          const int w0 = (j * 64 + lane) * VW;
+          if (w0 < W) {
+            if constexpr (VW == 1) {
+              g[w0] = val[rr][j][0];
+            } else {
+              vec v;
+#pragma unroll
+              for (int q = 0; q < VW; q++) v[q] = val[rr][j][q];
+              *reinterpret_cast<vec*>(g + w0) = v;
+            }
+          }
+        }
+      }
+    }
+  }
+}
+// The same for a block of at most 64 words whose size is only known at run time (l_i, R_ij, r_ij).
+template <typename T>
+__device__ __forceinline__ void rows_writeout_small(T* g0, size_t stride, int W, const short* map, const T* acc, int cws,
+                                                    int nrows, int lane) {
+  constexpr int RB = 8;
+  const int off = (lane < W ? int(map[lane]) : kRowSlotZero) * cws;
+#pragma unroll 1
+  for (int r0 = 0; r0 < nrows; r0 += RB) {
+    T val[RB];
+#pragma unroll
+    for (int rr = 0; rr < RB; rr++) val[rr] = acc[off + (r0 + rr < nrows ? r0 + rr : nrows - 1)];
+#pragma unroll
+    for (int rr = 0; rr < RB; rr++)
+      if (r0 + rr < nrows && lane < W) g0[size_t(r0 + rr) * stride + lane] = val[rr];
+  }
+}
+
+// Adds one term's contribution to this lane's slots.  `sid` (scalar memory) lists the slots in the order of the
+// term's pattern:
+//   SINGLE  G(d), H(d,d)
+//   PAIR2   G(x), G(y), H(x,x), H(y,y), H(x,y), H(y,x)
+//   PAIR4   G(x1), G(x2), G(y1), G(y2), then the sixteen H entries in term_scatter's order
+//   ALL     G(0..dim-1), H(0,0)..H(dim-1,dim-1)
+// (term_scatter in ilqg_models.hpp is the row-image form of the same sums.)
+// The slots of one leaf are distinct (build_row_program checks), so the read-modify-writes of a term do not depend
+// on each other: all reads, then all adds, then all writes — one LDS round trip per term instead of one per entry.
+template <typename T, typename V>
+__device__ __forceinline__ void rows_scatter(int pattern, const TermOut<T>& o, rp_cptr sid, int nsid, T* col, int cws,
+                                             const V& v, bool want_h) {
+  if (pattern == PAT_SINGLE) {
+    T* const p0 = col + sid[0] * cws;
+    T* const p1 = col + sid[1] * cws;
+    const T a0 = *p0, a1 = *p1;
+    *p0 = a0 + o.gx;
+    if (want_h) *p1 = a1 + o.hxx;
+  } else if (pattern == PAT_PAIR2) {
+    T* pp[6];
+    T av[6];
+#pragma unroll
+    for (int e = 0; e < 6; e++) pp[e] = col + sid[e] * cws;
+#pragma unroll
+    for (int e = 0; e < 6; e++) av[e] = *pp[e];
+    *pp[0] = av[0] + o.gx;
+    *pp[1] = av[1] + o.gy;
+    if (want_h) {
+      *pp[2] = av[2] + o.hxx;
+      *pp[3] = av[3] + o.hyy;
+      *pp[4] = av[4] + o.hxy;
+      *pp[5] = av[5] + o.hxy;
+    }
+  } else if (pattern == PAT_PAIR4) {
+    {
+      T* pp[4];
+      T av[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) pp[e] = col + sid[e] * cws;
+#pragma unroll
+      for (int e = 0; e < 4; e++) av[e] = *pp[e];
+      *pp[0] = av[0] + o.gx;
+      *pp[1] = av[1] - o.gx;
+      *pp[2] = av[2] + o.gy;
+      *pp[3] = av[3] - o.gy;
+    }
+    if (want_h) {
+      T* pp[16];
+      T av[16];
+#pragma unroll
+      for (int e = 0; e < 16; e++) pp[e] = col + sid[4 + e] * cws;
+#pragma unroll
+      for (int e = 0; e < 16; e++) av[e] = *pp[e];
+      const T add[16] = {o.hxx, -o.hxx, -o.hxx, o.hxx, o.hyy, -o.hyy, -o.hyy, o.hyy,
+                         o.hxy, o.hxy, -o.hxy, -o.hxy, -o.hxy, -o.hxy, o.hxy, o.hxy};
+#pragma unroll
+      for (int e = 0; e < 16; e++) *pp[e] = av[e] + add[e];
+    }
+  } else if (pattern == PAT_ALL) {
+    const int dim = nsid >> 1;
+    for (int i = 0; i < dim; i++) {
+      col[sid[i] * cws] += o.gx * (v[i] - o.gy);
+      if (want_h) col[sid[dim + i] * cws] += o.gx;
+    }
+  }
+}
+
+// The scatter pattern a cost kind produces when it is active (term_compute_leaf), known without evaluating it.
+__host__ __device__ inline int term_pattern_of(int kind, int idx0) {
+  switch (kind) {
+    case ILQG_COST_QUADRATIC: return idx0 >= 0 ? PAT_SINGLE : PAT_ALL;
+    case ILQG_COST_SEMIQUADRATIC:
+    case ILQG_CONSTRAINT_SINGLE_DIMENSION: return PAT_SINGLE;
+    case ILQG_COST_QUADRATIC_POLYLINE2:
+    case ILQG_COST_SEMIQUADRATIC_POLYLINE2:
+    case ILQG_COST_POLYLINE2_SIGNED_DISTANCE: return PAT_PAIR2;
+    case ILQG_COST_PROXIMITY:
+    case ILQG_COST_SIGNED_DISTANCE:
+    case ILQG_COST_QUADRATIC_DIFFERENCE:
+    case ILQG_CONSTRAINT_PROXIMITY: return PAT_PAIR4;
+  }
+  return PAT_NONE;
+}
+__host__ __device__ inline bool term_is_polyline(int kind) {
+  return kind == ILQG_COST_QUADRATIC_POLYLINE2 || kind == ILQG_COST_SEMIQUADRATIC_POLYLINE2 ||
+         kind == ILQG_COST_POLYLINE2_SIGNED_DISTANCE;
+}
+
+// Polyline2::ClosestPoint (src/polyline2.cpp:105-174) with the segment table in scalar memory: the same scan as
+// polyline_closest (ilqg_models.hpp), every lane its own query point against the same segments.
+template <typename T>
+__device__ __forceinline__ Seg<T> load_seg_const(typename ConstPtr<T>::type s) {
+  Seg<T> o;
+  o.p1x = s[0]; o.p1y = s[1]; o.p2x = s[2]; o.p2y = s[3]; o.len = s[4]; o.ux = s[5]; o.uy = s[6];
+  return o;
+}
+template <typename T>
+__device__ __forceinline__ Closest<T> polyline_closest_rows(typename ConstPtr<T>::type segs, int first, int nseg, T qx,
+                                                            T qy) {
+  typename ConstPtr<T>::type base = segs + first * kSegStride;
+  Closest<T> out;
+  T best = dinf<T>();
+  out.cx = T(0);
+  out.cy = T(0);
+  out.is_vertex = false;
+  out.seg = load_seg_const<T>(base);
+#pragma unroll 1
+  for (int c = 0; c < nseg; c++) {
+    const Seg<T> s = load_seg_const<T>(base + c * kSegStride);
+    T px, py, cur;
+    bool se;
+    seg_closest(s, qx, qy, &px, &py, &se, &cur);
+    if (t_abs(cur) < t_abs(best)) {
+      const bool at2 = (px == s.p2x && py == s.p2y);
+      const bool at1 = (px == s.p1x && py == s.p1y);
+      if (se && (c > 0 || at2) && (c < nseg - 1 || at1)) {
+        // the "shortcut" segment of the vertex (both candidates are scalar data; the lane picks)
+        const Seg<T> s1 = load_seg_const<T>(base + c * kSegStride + 7), s2 = load_seg_const<T>(base + c * kSegStride + 14);
+        Seg<T> sc;
+        sc.p1x = at1 ? s1.p1x : s2.p1x; sc.p1y = at1 ? s1.p1y : s2.p1y;
+        sc.ux = at1 ? s1.ux : s2.ux; sc.uy = at1 ? s1.uy : s2.uy;
+        cur *= seg_side(sc, qx, qy) ? sgn(cur) : -sgn(cur);
+      }
+      best = cur;
+      out.cx = px;
+      out.cy = py;
+      out.is_vertex = se;
+      out.seg = s;
+    }
+  }
+  out.ssd = best;
+  const Seg<T> s0 = load_seg_const<T>(base), sl = load_seg_const<T>(base + (nseg - 1) * kSegStride);
+  const T ax = out.cx - s0.p1x, ay = out.cy - s0.p1y;
+  const T bx = out.cx - sl.p2x, by = out.cy - sl.p2y;
+  out.is_endpoint = (ax * ax + ay * ay < T(1e-4f)) || (bx * bx + by * by < T(1e-4f));
+  return out;
+}
+
+// One chunk: rows [k0, k0 + nrows), nrows <= cw, executed by ONE wavefront (`lane` of 64) with its own LDS `sm`
+// (rows_lds_elems for this cw: 64, 32 or 16).  `maps` is the workgroup's LDS copy of the program's word maps
+// (rows_maps_load).  What is produced follows QuadArgs: A / Bm (null: skip the Jacobians), Q / l / R / r (null: not
+// written; derivatives are still accumulated when merit_part is set), merit_part, cost_part.
+template <typename T, int CN, int CM, int CNP>
+__device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* maps, const QuadArgs<T>& a, int k0,
+                                           int nrows, int cw, T* sm, int lane) {
+  constexpr int NA = CN + CM;
+  const int cws = cw + 1;
+  T* const arg = sm;
+  T* const acc = sm + NA * cw;
+  const rp_cptr rp = (rp_cptr)p.row_prog;
+  const typename ConstPtr<T>::type segs = (typename ConstPtr<T>::type)problem_segs<T>(p);
+  const int num_passes = rp[RP_NUM_PASSES], NPS = rp[RP_NUM_PSLOTS];
+  const rp_cptr passes = rp + rp[RP_OFF_PASS];
+  const rp_cptr ops = rp + rp[RP_OFF_OPS];
+  const rp_cptr sids = rp + rp[RP_OFF_SIDS];
+  const rp_cptr pinit = rp + rp[RP_OFF_PINIT];
+  const rp_cptr linit = rp + rp[RP_OFF_LINIT];
+  const rp_cptr regions = rp + rp[RP_OFF_REGIONS];
+  const rp_cptr merit = rp + rp[RP_OFF_MERIT];
+  const bool quad_out = a.Q != nullptr;
+  const bool do_quad = quad_out || a.merit_part != nullptr;
+  const bool want_cost = a.cost_part != nullptr;
+  const PairTable& pt = p.pairs;
+  // phase profile (scripts/stage_bench.py): [0] staging + slot init, [1] Jacobian ops, [2] cost ops, [3] write-out
+  long long qc0 = (kProfile && a.phacc) ? clock64() : 0, qc1;
+#define ILQG_QPH(i) do { if (kProfile && a.phacc) { __builtin_amdgcn_sched_barrier(0); qc1 = clock64(); __builtin_amdgcn_sched_barrier(0); a.phacc[i] += qc1 - qc0; qc0 = qc1; } } while (0)
+
+  // ---- the chunk's (x, u) rows, transposed: global reads are contiguous, a lane later reads down its column ----
+  {
+    const T* gx = a.xs + size_t(k0) * CN;
+    for (int i = lane; i < cw * CN; i += 64) {
+      const int r = i / CN, e = i - r * CN;
+      const int rs = r < nrows ? r : nrows - 1;  // lanes past the chunk's end repeat its last row (results unused)
+      arg[e * cw + r] = gx[rs * CN + e];
+    }
+    const T* gu = a.us + size_t(k0) * CM;
+    for (int i = lane; i < cw * CM; i += 64) {
+      const int r = i / CM, e = i - r * CM;
+      const int rs = r < nrows ? r : nrows - 1;
+      arg[(CN + e) * cw + r] = gu[rs * CM + e];
+    }
+  }
+  lds_sync(true);
+
+  const bool rowlane = lane < cw;          // lanes that own a row (cw < 64: the others only help to write out)
+  const bool valid = lane < nrows;
+  const int row = k0 + (valid ? lane : nrows - 1);
+  T* const col = acc + (rowlane ? lane : 0);
+  // PlayerCost::Quadraticize vs QuadraticizeControlCosts (src/ilq_solver.cpp:483-487): bit i = player i is
+  // quadraticised in full at this lane's row
+  unsigned full = 0;
+#pragma unroll
+  for (int i = 0; i < CNP; i++) {
+    const bool f = p.structure[i] == ILQG_SUM || (a.t_extreme ? a.t_extreme[i] == row : row == 0);
+    full |= (f ? 1u : 0u) << i;
+  }
+  const double tt = double(row) * p.dt;
+  const int tidx = int(static_cast<size_t>((tt - a.t_init) / p.dt));  // relative_time_tracker.h:69-72
+  auto init_value = [&](rp_cptr rec) -> T {
+    const int code = rec[0];
+    const T val = T(__int_as_float(rec[1]));
+    const int kind = code & 255, pl = (code >> 8) & 255;
+    if (kind == RI_DT) return T(p.dt);
+    if (kind == RI_NEG_DT) return T(-p.dt);
+    if (kind == RI_CREG)  // sigma_u I on a control block the reference would have created (player_cost.cpp:70-74)
+      return (((full >> pl) & 1u) || ((code >> 16) & 1)) ? val : T(0);
+    return val;  // 0, 1, sigma_x (player_cost.cpp:196)
+  };
+  if (rowlane)
+    for (int s = 0; s < NPS; s++) col[s * cws] = init_value(pinit + s * RINIT_WORDS);
+  Closest<T> cc;  // result of the pass's last CLOSEST op
+  cc.cx = cc.cy = cc.ssd = T(0);
+  cc.is_vertex = cc.is_endpoint = false;
+  cc.seg = Seg<T>{T(0), T(0), T(0), T(0), T(1), T(1), T(0)};
+  ILQG_QPH(0);
+
+#pragma unroll 1
+  for (int ps = 0; ps < num_passes; ps++) {
+    const rp_cptr pr = passes + ps * RPASS_WORDS;
+    const int op_begin = pr[0], op_end = pr[1], reg_begin = pr[2], reg_end = pr[3], li_begin = pr[4], li_count = pr[5];
+    const int pkind = pr[6], player = pr[7];
+    if (pkind == RPASS_JACOBIANS && a.A == nullptr) continue;
+    if (pkind == RPASS_PLAYER && !do_quad && !want_cost) continue;
+    T ctot = T(0);  // PlayerCost::Evaluate of this pass's player at this lane's row
+    T ext_value = T(0);  // ExtremeValueCost in flight: its value and active child at this lane's row
+    int ext_best = 0;
+    if (rowlane) {
+      for (int s = 0; s < li_count; s++) col[(NPS + s) * cws] = init_value(linit + (li_begin + s) * RINIT_WORDS);
+#pragma unroll 1
+      for (int op = op_begin; op < op_end; op++) {
+        const rp_cptr od = ops + op * ROP_WORDS;
+        const int mode = od[RO_MODE];
+        const rp_cptr sid = sids + od[RO_SID];
+        const int nsid = od[RO_NSID], aux = od[RO_AUX];
+        DevTerm c;
+        c.kind = od[RO_KIND]; c.role = od[RO_ROLE]; c.player = od[RO_PLAYER]; c.flags = od[RO_FLAGS];
+        c.idx[0] = od[RO_IDX0]; c.idx[1] = od[RO_IDX1]; c.idx[2] = od[RO_IDX2]; c.idx[3] = od[RO_IDX3];
+        c.weight = __int_as_float(od[RO_WEIGHT]); c.value = __int_as_float(od[RO_VALUE]);
+        c.polyline = 0; c.slot = od[RO_SLOT]; c.arg_off = od[RO_ARG_OFF]; c.arg_dim = od[RO_ARG_DIM];
+        c.k_start = od[RO_K_START];
+        c.arg = 0; c.child_begin = 0; c.child_count = 0; c.round = 0; c.tile_h = 0; c.tile_g = 0; c.ld = 0; c.cq = -1;
+        if (mode == ROP_JACOBIAN) {
+          // ---- ConcatenatedDynamicalSystem::Linearize, one subsystem (src/concatenated_dynamical_system.cpp:86-107).
+          // Same expressions as sub_linearize_trig (ilqg_models.hpp), which documents the reference lines; the
+          // entries go to the slots the program lists in this order.
+          const int kind = c.kind, xo = c.idx[0], uo = c.idx[1];
+          const T L = T(c.weight);
+          const RowArg<T> x{arg + xo * cw + lane, cw};
+          auto put = [&](int e, T val) { if (e < nsid) col[sid[e] * cws] = val; };
+          if (kind == ILQG_DYN_POINT_MASS_2D || kind == ILQG_DYN_PLANAR_DISTURBANCE || kind == ILQG_DYN_AIR_3D_PURSUER)
+            continue;  // constants only
+          T sth, cth;
+          t_sincos(x[2], &sth, &cth);
+          const T ct = T(double(cth) * p.dt), st = T(double(sth) * p.dt);
+          if (kind == ILQG_DYN_AIR_3D_EVADER) {  // air_3d.h:127-146
+            const T own = arg[(CN + uo) * cw + lane];  // its own turn rate; c.value = the pursuer's speed
+            put(0, T(double(own) * p.dt));             // A(0,1)
+            put(1, T(0) - T(c.value) * st);            // A(0,2)
+            put(2, T(0) - T(double(own) * p.dt));      // A(1,0)
+            put(3, T(c.value) * ct);                   // A(1,2)
+            put(4, T(double(x[1]) * p.dt));            // B(0,0)
+            put(5, T(double(-x[0]) * p.dt));           // B(1,0)
+          } else if (kind == ILQG_DYN_DUBINS_CAR) {  // single_player_dubins_car.h:105-117
+            put(0, T(0) + -L * st);  // A(0,2)
+            put(1, T(0) + L * ct);   // A(1,2)
+          } else {
+            const bool uni = is_unicycle(kind);
+            const T v = x[uni ? 3 : 4];
+            put(0, T(0) + -v * st);  // A(0,2)
+            put(1, ct);              // A(0,v)
+            put(2, v * ct);          // A(1,2)
+            put(3, st);              // A(1,v)
+            if (!uni) {
+              T sphi, cphi;
+              t_sincos(x[3], &sphi, &cphi);
+              const T tphi = sphi / cphi;
+              put(4, T(double(x[4]) * p.dt / double(L * cphi * cphi)));  // A(2,3)
+              put(5, T(double(tphi) * p.dt / double(L)));               // A(2,4)
+            }
+          }
+          continue;
+        }
+        const RowArg<T> v{arg + c.arg_off * cw + lane, cw};
+        if (mode == ROP_CLOSEST) {
+          cc = polyline_closest_rows<T>(segs, od[RO_POLY_FIRST], od[RO_PATTERN_NSEG], v[c.idx[0]], v[c.idx[1]]);
+          continue;
+        }
+#if ILQG_PROFILE2
+        ILQG_QPH(1);
+#endif
+        const bool is_cost = c.role == ILQG_ROLE_STATE_COST || c.role == ILQG_ROLE_CONTROL_COST;
+        const bool live = row >= c.k_start;  // FinalTimeCost: nothing before its threshold
+        const bool deriv = do_quad && live && (((full >> c.player) & 1u) || c.role == ILQG_ROLE_CONTROL_COST);
+        const bool need = deriv || (want_cost && is_cost && live);
+        if (!__any(need)) continue;
+        const T lambda = (c.slot >= 0 && a.lambdas) ? a.lambdas[c.slot * p.T + tidx] : T(0);
+#if ILQG_PROFILE2
+        ILQG_QPH(2);
+#endif
+        TermOut<T> o;
+        term_compute_leaf<T, RowArg<T>, true>(QuadTables<T>{}, c, v, lambda, a.mu, &o, nullptr, &cc);
+#if ILQG_PROFILE2
+        ILQG_QPH(3);
+#endif
+        bool act = deriv && o.pattern != PAT_NONE;
+        if (mode == ROP_EXT_EVAL) {
+          // ExtremeValueCost::ExtremeCost (src/extreme_value_cost.cpp:66-85): the first strict improvement wins
+          const bool is_min = c.flags & ILQG_FLAG_IS_MIN;
+          if (aux == 0 || (is_min && o.value < ext_value) || (!is_min && o.value > ext_value)) {
+            ext_value = o.value;
+            ext_best = aux;
+          }
+          continue;
+        }
+        if (mode == ROP_EXT_APPLY) {
+          if (aux == 0 && is_cost && live) ctot += ext_value;
+          act = act && ext_best == aux;
+        } else if (is_cost && live) {
+          ctot += o.value;
+        }
+        if (act) rows_scatter<T>(od[RO_PATTERN_NSEG], o, sid, nsid, col, cws, v, quad_out);
+#if ILQG_PROFILE2
+        ILQG_QPH(4);
+#endif
+      }
+      if (pkind == RPASS_PLAYER && valid) {
+        if (want_cost) a.cost_part[size_t(row) * CNP + player] = ctot;
+        if (a.merit_part) {
+          // pieces of ILQSolver::MeritFunction (:419-430): |r_ii|^2 and |l_i|^2 of this lane's row.  Entries no term
+          // touches are exact zeros, so the sums over the touched slots (in index order) are the reference's sums.
+          const rp_cptr md = merit + player * RMERIT_WORDS;
+          const rp_cptr ls = sids + md[0];
+          const rp_cptr rs = sids + md[2];
+          const int lcnt = md[1], rcnt = md[3];
+          T s1 = T(0), s2 = T(0);
+          for (int d = 0; d < rcnt; d++) {
+            const T rv = col[rs[d] * cws];
+            s1 += rv * rv;
+          }
+          for (int d = 0; d < lcnt; d++) {
+            const T lv = col[ls[d] * cws];
+            s2 += lv * lv;
+          }
+          a.merit_part[(size_t(row) * CNP + player) * 2 + 0] = s1;
+          a.merit_part[(size_t(row) * CNP + player) * 2 + 1] = s2;
+        }
+      }
+    }
+    lds_sync(true);  // the slots of this pass are complete: rows are written out by all lanes
+#if !ILQG_PROFILE2
+    if (pkind == RPASS_JACOBIANS) ILQG_QPH(1); else ILQG_QPH(2);
+#else
+    ILQG_QPH(0);
+#endif
+    for (int rg = reg_begin; rg < reg_end; rg++) {
+      const rp_cptr rd = regions + rg * RREG_WORDS;
+      const int arr = rd[0], words = rd[1], offs = rd[2];
+      const short* const map = maps + rd[3];
+      if (arr == RA_A) {
+        if (a.A) rows_writeout<T, CN * CN, rows_vec_width<T>(CN * CN)>(a.A + size_t(k0) * CN * CN, CN * CN, map, acc, cws, nrows, lane);
+      } else if (arr == RA_B) {
+        if (a.Bm) rows_writeout<T, CN * CM, rows_vec_width<T>(CN * CM)>(a.Bm + size_t(k0) * CN * CM, CN * CM, map, acc, cws, nrows, lane);
+      } else if (arr == RA_Q) {
+        if (a.Q) rows_writeout<T, CN * CN, rows_vec_width<T>(CN * CN)>(a.Q + size_t(k0) * CNP * CN * CN + offs, size_t(CNP) * CN * CN, map, acc, cws, nrows, lane);
+      } else if (arr == RA_L) {
+        if (a.l) rows_writeout_small<T>(a.l + size_t(k0) * CNP * CN + offs, CNP * CN, words, map, acc, cws, nrows, lane);
+      } else if (arr == RA_R) {
+        if (a.R) rows_writeout_small<T>(a.R + size_t(k0) * pt.Rsz + offs, pt.Rsz, words, map, acc, cws, nrows, lane);
+      } else {
+        if (a.r) rows_writeout_small<T>(a.r + size_t(k0) * pt.rsz + offs, pt.rsz, words, map, acc, cws, nrows, lane);
+      }
+    }
+    lds_sync(true);  // pass-local slots are re-initialised by the next pass
+#if !ILQG_PROFILE2
+    ILQG_QPH(3);
+#else
+    ILQG_QPH(5);
+#endif
+  }
+#undef ILQG_QPH
+}
+
+// The word maps of the row program, copied into LDS once per workgroup (every thread calls, then syncs): the
+// write-out reads them with a per-lane index.
+__host__ __device__ inline size_t rows_maps_bytes(const DevProblem& p) { return (size_t(p.rp_maps_words) * 4 + 15) & ~size_t(15); }
+__device__ __forceinline__ const short* rows_maps_load(const DevProblem& p, void* region) {
+  int* dst = reinterpret_cast<int*>(region);
+  const int* src = p.row_prog + p.rp_maps_off;
+  for (int e = threadIdx.x; e < p.rp_maps_words; e += blockDim.x) dst[e] = src[e];
+  __syncthreads();
+  return reinterpret_cast<const short*>(dst);
+}
+
+}  // namespace ilqg

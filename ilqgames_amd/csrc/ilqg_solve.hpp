@@ -43,7 +43,7 @@ struct SolveArgs {
   // lists the ones that need another pass, and the rows of one instance a workgroup of the row kernel takes
   const int* ids;
   int* ids_next;
-  int rows_per_block;
+  int rows_cw;          // rows per chunk of the row stage (ilqg_rows.hpp): 64, 32 or 16, chosen by the launcher
   T* probe_pool;        // speculative line search: [listed instances][probe_k] entries of ProbeEntry::total elements
   int probe_k;          // step sizes probed per instance this round (<= kProbeCandidates)
 };
@@ -176,12 +176,22 @@ __device__ __forceinline__ int solve_max_iters(const SolveArgs<T>& sa) {
                             : (sa.al_mode ? sa.prm.unconstrained_solver_max_iters : sa.prm.max_solver_iters);
 }
 
-// LDS of the trial kernel: [cost tables | rollout scratch | W x linquad scratch | 4 ints]
+// Row waves of a fused trial kernel of W wavefronts: wave 0 integrates, the others take the chunks of rows as they
+// become ready (a single-wave workgroup does both, one after the other).
+__host__ __device__ inline int trial_row_waves(int waves) { return waves > 1 ? waves - 1 : 1; }
+// scratch of one row wave (ilqg_rows.hpp, `cw` rows per chunk); also holds the per-row partials of the reductions
+// between passes
+__host__ __device__ inline size_t trial_rows_elems(const DevProblem& p, int cw) {
+  size_t e = rows_lds_elems(p.n, p.m, p.rp_pslots, p.rp_lslots, cw);
+  const size_t red = size_t(p.T) * p.N * 2 + 8;
+  if (e < red) e = red;
+  return (e + 3) & ~size_t(3);
+}
+// LDS of the trial kernel: [word maps | rollout scratch | row waves x row scratch | 4 ints]
 template <typename T>
-__host__ __device__ inline size_t trial_lds_bytes(const DevProblem& p, int waves) {
+__host__ __device__ inline size_t trial_lds_bytes(const DevProblem& p, int waves, int cw) {
   const size_t re = (rollout_lds_elems(p.n, p.m) + 3) & ~size_t(3);
-  const size_t qe = (quad_lds_elems(p.n, p.m, p.N, p.pairs.Rsz, p.pairs.rsz, p.num_terms) + 3) & ~size_t(3);
-  return quad_tables_bytes(p, sizeof(T)) + (re + size_t(waves) * qe) * sizeof(T) + 16;
+  return rows_maps_bytes(p) + (re + size_t(trial_row_waves(waves)) * trial_rows_elems(p, cw)) * sizeof(T) + 16;
 }
 
 // ---------------------------------------------------------------------------
@@ -321,15 +331,15 @@ enum { TRIAL_FUSED = 0, TRIAL_ROLL = 1, TRIAL_DECIDE = 2 };
 // linearise / quadraticise scratch per wave of a trial-part kernel (TRIAL_DECIDE only needs the reductions' copy
 // of the per-row partials, TRIAL_ROLL nothing)
 template <typename T>
-__host__ __device__ inline size_t trial_phase_quad_elems(const DevProblem& p, int phase) {
+__host__ __device__ inline size_t trial_phase_quad_elems(const DevProblem& p, int phase, int cw) {
   if (phase == TRIAL_ROLL) return 0;
   if (phase == TRIAL_DECIDE) return (size_t(p.T) * p.N * 2 + 8 + 3) & ~size_t(3);
-  return (quad_lds_elems(p.n, p.m, p.N, p.pairs.Rsz, p.pairs.rsz, p.num_terms) + 3) & ~size_t(3);
+  return trial_rows_elems(p, cw);
 }
 template <typename T>
-__host__ __device__ inline size_t trial_phase_lds_bytes(const DevProblem& p, int phase) {  // W = 1, no cost tables
+__host__ __device__ inline size_t trial_phase_lds_bytes(const DevProblem& p, int phase, int cw) {  // W = 1, no word maps
   const size_t re = (rollout_lds_elems(p.n, p.m) + 3) & ~size_t(3);
-  return (re + trial_phase_quad_elems<T>(p, phase)) * sizeof(T) + 16;
+  return (re + trial_phase_quad_elems<T>(p, phase, cw)) * sizeof(T) + 16;
 }
 
 // What the rows of a pass are asked for, from the instance's state (the pass's rollout, if any, is done).
@@ -360,24 +370,16 @@ __device__ __forceinline__ QuadArgs<T> trial_quad_args(const DevProblem& p, cons
   return qa;
 }
 
-// Row kernel of the split pass: rows [k0, k1) of instance b, one wave with its own scratch.
+// Row kernel of the split pass: one chunk of rows of instance b, one wave with its own scratch.
 template <typename T, int NX, int NP, int MU>
-__device__ __forceinline__ void rows_part_instance(const DevProblem& p, const QuadTables<T>& tb, const SolveArgs<T>& sa,
-                                                   int b, int k0, int k1, T* sm) {
+__device__ __forceinline__ void rows_part_instance(const DevProblem& p, const short* maps, const SolveArgs<T>& sa,
+                                                   int b, int chunk, T* sm) {
   const InstanceBuffers<T> ib(p, sa, b);
   const SolveState<T> s = state_load<T>(ib.w, ib.L);
   const QuadArgs<T> qa = trial_quad_args<T>(p, ib, s);
-  const int lane = threadIdx.x;
-  constexpr int n = NX, m = NP * MU;
-  T argv = linquad_load_arg<T>(qa, k0, n, m, lane);
-#pragma unroll 1
-  for (int k = k0; k < k1; k++) {
-    LinquadCarry<T> carry;
-    linquad_compute<T, NX, NP * MU, NP>(p, tb, qa, k, sm, lane, argv, carry);
-    const T argn = k + 1 < k1 ? linquad_load_arg<T>(qa, k + 1, n, m, lane) : T(0);
-    linquad_store<T, NX, NP * MU, NP>(p, qa, k, sm, lane, carry);
-    argv = argn;
-  }
+  const int k0 = chunk * sa.rows_cw;
+  const int nrows = p.T - k0 < sa.rows_cw ? p.T - k0 : sa.rows_cw;
+  rows_chunk<T, NX, NP * MU, NP>(p, maps, qa, k0, nrows, sa.rows_cw, sm, int(threadIdx.x));
 }
 
 // ---------------------------------------------------------------------------
@@ -441,8 +443,8 @@ __device__ __forceinline__ void probe_roll_instance(const DevProblem& p, const S
 }
 
 template <typename T, int NX, int NP, int MU>
-__device__ __forceinline__ void probe_rows_instance(const DevProblem& p, const QuadTables<T>& tb, const SolveArgs<T>& sa,
-                                                    int b, int slot, int j, int k0, int k1, T* sm) {
+__device__ __forceinline__ void probe_rows_instance(const DevProblem& p, const short* maps, const SolveArgs<T>& sa,
+                                                    int b, int slot, int j, int chunk, T* sm) {
   const InstanceBuffers<T> ib(p, sa, b);
   const SolveState<T> s = state_load<T>(ib.w, ib.L);
   if (!probe_wanted(sa, s, j)) return;
@@ -459,17 +461,9 @@ __device__ __forceinline__ void probe_rows_instance(const DevProblem& p, const Q
   qa.merit_part = e + E.mpart;
   qa.cost_part = nullptr;
   qa.phacc = nullptr;
-  const int lane = threadIdx.x;
-  constexpr int n = NX, m = NP * MU;
-  T argv = linquad_load_arg<T>(qa, k0, n, m, lane);
-#pragma unroll 1
-  for (int k = k0; k < k1; k++) {
-    LinquadCarry<T> carry;
-    linquad_compute<T, NX, NP * MU, NP>(p, tb, qa, k, sm, lane, argv, carry);
-    const T argn = k + 1 < k1 ? linquad_load_arg<T>(qa, k + 1, n, m, lane) : T(0);
-    linquad_store<T, NX, NP * MU, NP>(p, qa, k, sm, lane, carry);
-    argv = argn;
-  }
+  const int k0 = chunk * sa.rows_cw;
+  const int nrows = p.T - k0 < sa.rows_cw ? p.T - k0 : sa.rows_cw;
+  rows_chunk<T, NX, NP * MU, NP>(p, maps, qa, k0, nrows, sa.rows_cw, sm, int(threadIdx.x));
 }
 
 template <typename T>
@@ -534,7 +528,7 @@ __device__ __forceinline__ void probe_pick_instance(const DevProblem& p, const S
 }
 
 template <typename T, int NX, int NP, int MU, int W, int PHASE = TRIAL_FUSED>
-__device__ __forceinline__ void trial_part_instance(const DevProblem& p, const QuadTables<T>& tb,
+__device__ __forceinline__ void trial_part_instance(const DevProblem& p, const short* maps,
                                                     const SolveArgs<T>& sa, int b, T* sm) {
   static_assert(PHASE == TRIAL_FUSED || W == 1, "the split phases run one wave per instance");
   constexpr int n = NX, N = NP, m = NP * MU;
@@ -549,11 +543,13 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const Q
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
 
   const size_t re = (rollout_lds_elems(n, m) + 3) & ~size_t(3);
-  const size_t qe = trial_phase_quad_elems<T>(p, PHASE);
+  const size_t qe = trial_phase_quad_elems<T>(p, PHASE, sa.rows_cw);
+  constexpr int RW = W > 1 ? W - 1 : 1;     // row waves: all but the integrating wave 0
+  const int rwave = W > 1 ? wave - 1 : 0;   // this wave's row scratch (-1: wave 0 of a multi-wave workgroup has none)
   T* const sm_roll = sm;
-  T* const sm_quad = sm + re + size_t(wave) * qe;
-  T* const sm_quad0 = sm + re;  // wave 0's linquad scratch doubles as reduction scratch between passes
-  int* const flags = reinterpret_cast<int*>(sm + re + size_t(W) * qe);  // [0] rows ready, [1] next row to claim
+  T* const sm_quad = sm + re + size_t(rwave < 0 ? 0 : rwave) * qe;
+  T* const sm_quad0 = sm + re;  // the first row wave's scratch doubles as reduction scratch between passes
+  int* const flags = reinterpret_cast<int*>(sm + re + size_t(RW) * qe);  // [0] rows ready, [1] next chunk to claim
 
   SolveState<T> s;
   if (sa.first) {
@@ -628,29 +624,24 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const Q
     QuadArgs<T> qa = trial_quad_args<T>(p, ib, s);
     qa.phacc = (kProfile && sa.prof) ? qph : nullptr;
     long long tq0 = (kProfile && sa.prof) ? clock64() : 0;
-    // Claim rows as they become ready.  The next row's argument is requested before this row's stores
-    // are issued (see linquad_compute / linquad_store).
-    auto claim = [&]() {
-      int k = 0;
-      if (lane == 0) k = atomicAdd(&flags[1], 1);
-      k = __builtin_amdgcn_readfirstlane(k);
-      if (k < Tn)
-        while (progress_observe(&flags[0]) <= k) __builtin_amdgcn_s_sleep(8);
-      return k;
-    };
-    int k = claim();
-    T argv = k < Tn ? linquad_load_arg<T>(qa, k, n, m, lane) : T(0);
+    // Chunks of sa.rows_cw rows are claimed in order and processed once the rollout has published their last row.
+    if (rwave >= 0) {
+      const int cw = sa.rows_cw;
+      const int nchunks = (Tn + cw - 1) / cw;
+      auto claim = [&]() {
+        int c = 0;
+        if (lane == 0) c = atomicAdd(&flags[1], 1);
+        return __builtin_amdgcn_readfirstlane(c);
+      };
 #pragma unroll 1
-    while (k < Tn) {
-      if (kProfile && sa.prof) { const long long tq1 = clock64(); qph[6] += tq1 - tq0; }
-      LinquadCarry<T> carry;
-      linquad_compute<T, NX, NP * MU, NP>(p, tb, qa, k, sm_quad, lane, argv, carry);
-      const int kn = claim();
-      const T argn = kn < Tn ? linquad_load_arg<T>(qa, kn, n, m, lane) : T(0);
-      linquad_store<T, NX, NP * MU, NP>(p, qa, k, sm_quad, lane, carry);
-      if (kProfile && sa.prof) { tq0 = clock64(); qph[7] += 1; }
-      k = kn;
-      argv = argn;
+      for (int c = claim(); c < nchunks; c = claim()) {
+        const int k0 = c * cw;
+        const int nrows = Tn - k0 < cw ? Tn - k0 : cw;
+        while (progress_observe(&flags[0]) < k0 + nrows) __builtin_amdgcn_s_sleep(8);
+        if (kProfile && sa.prof) { const long long tq1 = clock64(); qph[6] += tq1 - tq0; }
+        rows_chunk<T, NX, NP * MU, NP>(p, maps, qa, k0, nrows, cw, sm_quad, lane);
+        if (kProfile && sa.prof) { tq0 = clock64(); qph[7] += 1; }
+      }
     }
     }
 

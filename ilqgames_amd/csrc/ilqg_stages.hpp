@@ -654,3 +654,5 @@ __device__ __forceinline__ void costs_reduce(const DevProblem& p, const T* cost_
 }
 
 }  // namespace ilqg
+
+#include "ilqg_rows.hpp"

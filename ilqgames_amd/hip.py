@@ -11,7 +11,8 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libilqg_hip.so")
+# ILQG_HIP_LIB: an alternative build of the same library (profile / experiment builds of scripts/devbuild.py)
+LIB_PATH = os.environ.get("ILQG_HIP_LIB") or os.path.join(_HERE, "libilqg_hip.so")
 _LIB = None
 
 EXPORTS = [

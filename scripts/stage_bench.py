@@ -56,8 +56,8 @@ for wv in range(3):
 
 for wv in range(2):
     q = pm[64 + 8 * wv: 72 + 8 * wv]
-    steps = max(q[7], 1.0)
-    print("  trial wave %d: %.0f linquad steps over 5 launches; cycles/step: load+init %.0f | linearize %.0f | terms %.0f | rounds %.0f | merit+cost %.0f | writeout %.0f | claim/wait %.0f" %
-          (wv, q[7], q[0] / steps, q[1] / steps, q[2] / steps, q[3] / steps, q[4] / steps, q[5] / steps, q[6] / steps))
+    chunks = max(q[7], 1.0)
+    print("  trial wave %d: %.0f row chunks over 5 launches; cycles/chunk: staging+init %.0f | jacobians %.0f | cost terms %.0f | write-out %.0f | merit %.0f | claim/wait %.0f" %
+          (wv, q[7], q[0] / chunks, q[1] / chunks, q[2] / chunks, q[3] / chunks, q[4] / chunks, q[6] / chunks))
 q = pm[88:92] / 500.0
 print("  rollout (cycles/step, 5 rollouts x 100 steps): publish+dx %.0f | u = u_ref - P dx - alpha %.0f | RK4 %.0f | commit prefetch %.0f" % tuple(q))
