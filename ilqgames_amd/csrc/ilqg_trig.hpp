@@ -8,8 +8,8 @@
 // minimax polynomials on [-pi/4, pi/4] (coefficients: the published fdlibm / msun kernels, k_sin.c, k_cos.c,
 // k_sindf.c, k_cosdf.c).  Arguments beyond kTrigFastLimit fall back to the library (wave-uniform test), so the
 // functions are total.  Accuracy: <= 2 ulp of the correctly rounded value on the fast path (scripts/ubench/trig_lat.hip
-// prints the worst disagreement with libm) — the same order as the difference between the device libm and the
-// host libm the oracle runs on, and ten orders of magnitude inside the parity bar.
+// prints the worst disagreement with libm) — the same order as the difference between the device libm and a host
+// libm, and ten orders of magnitude inside the parity bar.
 #pragma once
 
 #include <hip/hip_runtime.h>
