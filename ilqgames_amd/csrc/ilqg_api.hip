@@ -636,6 +636,13 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   const bool handoff = counted && !split && !kProfile && sa.prm.linesearch &&
                        !(getenv("ILQG_HANDOFF") && getenv("ILQG_HANDOFF")[0] == '0');
   const bool lists = split || handoff;
+  // The sweep's forward pass runs in the fused trial kernel that follows it, beside the rollout, whenever that is the
+  // kernel that follows (split passes and the open-loop sweep keep it in the sweep's kernel).
+  sa.defer_forward = (!split && !p->desc.params.open_loop) ? 1 : 0;
+  {
+    constexpr size_t fwd_elems = 4 * 2 * ((NX * NX + C::SCR + 3) & ~3) + NX + 8;
+    if (trial_rows_elems(d, sa.rows_cw) < fwd_elems + 8) sa.defer_forward = 0;
+  }
   long long cap = al_mode ? (long long)(sa.prm.max_solver_iters + 1) * (sa.prm.unconstrained_solver_max_iters + 2)
                           : (long long)sa.prm.max_solver_iters + 2;
   if (split || counted) cap = (cap + 2) * ((long long)sa.prm.max_backtracking_steps + 3);

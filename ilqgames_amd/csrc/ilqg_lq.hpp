@@ -36,6 +36,8 @@ struct LQArgs {
   int T_steps;
   int adaptive;
   int symmetric = 0;                // 1: every Q_i and R_ij is exactly symmetric (what the quadraticisation stage writes)
+  int defer_forward = 0;            // 1: leave the scratch rows for a forward pass that runs elsewhere (the solve's
+                                    //    trial kernel runs it beside the next rollout): no dx, no expected decrease here
   long long* ph = nullptr;          // optional: 8 shader-clock accumulators per instance (phase profile)
 };
 
@@ -331,7 +333,7 @@ __device__ __forceinline__ void lq_forward_pass_body(const LQArgs<T>& a, T* sm, 
 
 template <typename T, int NX, int NP, int MU>
 __device__ __forceinline__ void lq_forward_pass(const LQArgs<T>& a, T* sm, int t) {
-  if (a.dx == nullptr && a.ed_out == nullptr) return;
+  if ((a.dx == nullptr && a.ed_out == nullptr) || a.defer_forward) return;
   __syncthreads();  // scratch rows were written to global memory by other lanes during the sweep
   lq_forward_pass_body<T, NX, NP, MU>(a, sm, t);
 }
@@ -348,7 +350,7 @@ __device__ __forceinline__ void lq_feedback_instance(const LQArgs<T>& a, const P
   const int pi = zl ? t / NX : 0;
   const int pc = zl ? t % NX : 0;
   const int Tn = a.T_steps;
-  const bool want_fwd = a.dx != nullptr || a.ed_out != nullptr;
+  const bool want_fwd = a.dx != nullptr || a.ed_out != nullptr || a.defer_forward != 0;
   constexpr int SCR = C::SCR;
 
   T *sB, *sA, *sQ, *sl, *sR, *sr;  // views into the image of the step being processed
@@ -687,7 +689,7 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
   const int lane = t & 63, g = lane >> 4, j = lane & 15;
   const int Tn = a.T_steps;
   const PairRegs<NP> pr(pt);
-  const bool want_fwd = a.dx != nullptr || a.ed_out != nullptr;
+  const bool want_fwd = a.dx != nullptr || a.ed_out != nullptr || a.defer_forward != 0;
   constexpr int SCR = C::SCR;
   const vec zero4 = {T(0), T(0), T(0), T(0)};
   constexpr int RS = TL::row(0, 1) - TL::row(0, 0);  // row step between accumulator registers
@@ -820,25 +822,39 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
     // LDS, lane c < M + NX takes column c of [B | A] and the MU dot products over the state (sequential sums,
     // as the reference's).  Saves 8 of the step's MFMA and the matrix pipe is shared by the three resident waves.
     const vec Bd = ldD(tB);
+    // column `lane` of [B | A], requested while the matrix pipe forms G (lanes past the last column re-read column 0);
+    // columns of a padded tile start 16-byte aligned, so the reads pair up
+    T ba[NX];
+    {
+      const T* colp = lane < M ? tB + LD * lane : tA + LD * (lane < M + NX ? lane - M : 0);
+#pragma unroll
+      for (int kk = 0; kk < NX; kk++) ba[kk] = colp[kk];
+    }
     const vec G = tile_xty<T>(Zd, Bd, zero4);  // Z_w^T B
+    // this player's MU columns of G go through LDS interleaved, [row][aa], so that a lane reads the MU entries of a
+    // row with one instruction
     if (j / MU == w) {
 #pragma unroll
-      for (int r = 0; r < 4; r++) sGw[(j - w * MU) * 16 + row0 + RS * r] = G[r];
+      for (int r = 0; r < 4; r++) sGw[(row0 + RS * r) * MU + (j - w * MU)] = G[r];
     }
     lds_sync(true);
-    if (lane < M + NX) {
-      const T* colp = lane < M ? tB + LD * lane : tA + LD * (lane - M);
+    {
+      T gv[NX][MU];
+#pragma unroll
+      for (int kk = 0; kk < NX; kk++)
+#pragma unroll
+        for (int aa = 0; aa < MU; aa++) gv[kk][aa] = sGw[kk * MU + aa];
       T acc[MU];
 #pragma unroll
       for (int aa = 0; aa < MU; aa++) acc[aa] = T(0);
 #pragma unroll
-      for (int kk = 0; kk < NX; kk++) {
-        const T v = colp[kk];
+      for (int kk = 0; kk < NX; kk++)
 #pragma unroll
-        for (int aa = 0; aa < MU; aa++) acc[aa] += sGw[aa * 16 + kk] * v;
+        for (int aa = 0; aa < MU; aa++) acc[aa] += gv[kk][aa] * ba[kk];
+      if (lane < M + NX) {
+#pragma unroll
+        for (int aa = 0; aa < MU; aa++) sSY[(w * MU + aa) + M * lane] = acc[aa];
       }
-#pragma unroll
-      for (int aa = 0; aa < MU; aa++) sSY[(w * MU + aa) + M * lane] = acc[aa];
     }
     if (lane < MU) {  // y_zeta = B_w^T zeta_w + r_ww (:154-157)
       const int tt = w * MU + lane;
@@ -906,6 +922,7 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
 #pragma unroll
         for (int r = 0; r < M; r++) {
           sAl[r] = x[r];
+          if constexpr (SPARE) sPt[r + LD * JB] = x[r];  // [P | alpha]: F = A - B [P | alpha] then carries beta = -B alpha
           a.alpha[size_t(k) * M + r] = x[r];
         }
       }
@@ -919,22 +936,36 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
     vec nBT = ldDT(tB);  // B^T
 #pragma unroll
     for (int r = 0; r < 4; r++) nBT[r] = -nBT[r];
-    const vec Fd = tile_xty_blocks<T, kblock_mask<T>(0, M)>(nBT, Pd, ldD(tA));  // rows >= M of -B^T are zero
-    {
+    const vec Fraw = tile_xty_blocks<T, kblock_mask<T>(0, M)>(nBT, Pd, ldD(tA));  // rows >= M of -B^T are zero
+    vec Fd, BetaD, zetaD;  // F proper; beta / zeta_w down the vector column, zero elsewhere
+    if constexpr (SPARE) {
+      // column JB of the padded A is zero and column JB of the P tile holds alpha: Fraw = [F | beta]
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        Fd[r] = Fraw[r] * mCols;
+        BetaD[r] = Fraw[r] * mVecCol;
+        zetaD[r] = sZw[row0 + RS * r] * mVecCol;
+      }
+      if (want_fwd && w == 0 && j == JB) {
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          if (row0 + RS * r < NX) a.scratch[size_t(k) * SCR + NP * (NX + 1) + row0 + RS * r] = Fraw[r];
+      }
+    } else {
+      Fd = Fraw;
       T s = T(0);  // one entry of beta per lane (rows >= NX of the padded B are zero)
 #pragma unroll
       for (int q = 0; q < M; q++) s -= tB[(lane & 15) + LD * q] * sAl[q];
       if (lane < 16) sBw[lane] = s;
-    }
-    lds_sync(true);
-    vec BetaD, zetaD;  // beta / zeta_w down the vector column, zero elsewhere
+      lds_sync(true);
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-      BetaD[r] = sBw[row0 + RS * r] * mVecCol;
-      zetaD[r] = sZw[row0 + RS * r] * mVecCol;
+      for (int r = 0; r < 4; r++) {
+        BetaD[r] = sBw[row0 + RS * r] * mVecCol;
+        zetaD[r] = sZw[row0 + RS * r] * mVecCol;
+      }
+      if (want_fwd && w == 0 && lane < NX) a.scratch[size_t(k) * SCR + NP * (NX + 1) + lane] = sBw[lane];
     }
     if (want_fwd && w == 0) {
-      if (lane < NX) a.scratch[size_t(k) * SCR + NP * (NX + 1) + lane] = sBw[lane];
       if (lane < NP) {
         // alpha_i^T R_ii r_ii, evaluated (alpha^T R) r like Eigen (ilq_solver.cpp:384-386)
         int ro_ii = 0, rg_ii = 0;
@@ -973,7 +1004,7 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
       const T* Rij = sR + ro_wj;
       T pb[MU];
 #pragma unroll
-      for (int b = 0; b < MU; b++) pb[b] = sPt[(jj * MU + b) + LD * j];  // zero for j >= NX
+      for (int b = 0; b < MU; b++) pb[b] = sPt[(jj * MU + b) + LD * j] * mCols;  // column NX of the tile holds alpha
       vec Pj, Hd, Htd;
 #pragma unroll
       for (int r = 0; r < 4; r++) {
@@ -987,7 +1018,7 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
           h += Rij[ac + MU * b] * pb[b];
           ht += Rij[b + MU * ac] * pb[b];
         }
-        Pj[r] = Pd[r] * mk;
+        Pj[r] = Pd[r] * (mk * mCols);
         Hd[r] = h * mk;
         Htd[r] = ht * mk;
       }
@@ -1073,7 +1104,7 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
     for (int i = 0; i < 10; i++) a.ph[16 * w + i] += phacc[i];
   }
 
-  if (want_fwd) {
+  if (want_fwd && !a.defer_forward) {
     __syncthreads();  // scratch rows written by all waves
     if (w == 0) lq_forward_pass_body<T, NX, NP, MU, 64, W::LDS_ELEMS>(a, sm, lane);
   }

@@ -7,6 +7,7 @@
 #pragma once
 
 #include "ilqg_common.hpp"
+#include "ilqg_trig.hpp"
 
 namespace ilqg {
 
@@ -246,6 +247,98 @@ __device__ __forceinline__ void sub_integrate_lanes(int kind, T L, double interv
   x[1] = py;
 #pragma unroll
   for (int e = 2; e < 6; e++) x[e] = up[e];
+}
+
+// The RK4 (2 sub-steps) of one subsystem with ONE STAGE PER LANE and the stage values in closed form.
+// Lanes base..base+7 form the group; lane q = 4 s + j evaluates stage j of sub-step s.  What makes this possible:
+// the steering angle (or the unicycle's heading), the speed and the acceleration are driven by inputs that are
+// constant over the step, so RK4's stage values of these components are polynomials in h with known coefficients —
+//   phi_q = phi_0 + c_q h omega,  c = (0, 1/2, 1/2, 1, 1, 3/2, 3/2, 2)
+//   Car6D: v at stage j of a sub-step from (v_s, a_s):  v_s + alpha_j h a_s + beta_j h^2 jerk,
+//          alpha = (0, 1/2, 1/2, 1), beta = (0, 0, 1/4, 1/2);  v_{s+1} = v_s + h a_s + h^2 jerk / 2
+// — every lane forms its own stage's values with two or three FMAs instead of walking the stages in sequence.  The
+// heading's stage derivative k_q = h (v_q / L) tan(phi_q) is then one tan per lane; the eight k go through LDS, every
+// lane forms the heading at its stage from them; one sincos per lane gives the position rates, which go through LDS
+// once more for the two RK4 combinations.  Two libm latencies and two LDS exchanges per step; the expressions are
+// RK4's up to the order of the roundings (a few ulp per step).  All 8 lanes return the new state in x[].
+// `gth` is LDS scratch of 64 + 128 elements (this wave's); any_car: some group of the wave holds a car model.
+template <typename T, bool DIST = false, bool DUB = false>
+__device__ __forceinline__ void sub_integrate_stages(int kind, T L, double interval, T* x, T u0, T u1, int q, int lane,
+                                                     T* gth, bool any_car, T d0 = T(0), T d1 = T(0)) {
+  const T h = T(interval / 2.0);
+  const T six = T(6.0), rsix = T(1.0) / T(6.0), rL = T(1.0) / L;
+  const bool dubins = DUB && kind == ILQG_DYN_DUBINS_CAR;
+  const bool car = DIST ? false : (kind == ILQG_DYN_CAR_5D || kind == ILQG_DYN_CAR_6D);
+  const bool car6 = car && kind == ILQG_DYN_CAR_6D;
+  const int j = q & 3;
+  const bool s1 = q >= 4;
+  const T aj = j == 0 ? T(0) : (j == 3 ? T(1) : T(0.5));
+  const T cq = aj + (s1 ? T(1) : T(0));
+  // ---- the input-driven components at this lane's stage and at the end of the step ----
+  const T ang0 = car ? x[3] : x[2];
+  const T hk = h * u0;
+  const T ang_q = __builtin_fma(cq, hk, ang0);
+  const T ang_end = __builtin_fma(T(2), hk, ang0);
+  const T v0 = car ? x[4] : x[3];
+  const T hj = h * u1;  // Car6D: h jerk; otherwise h a
+  T v_q, v_end, a_end = T(0);
+  {
+    const T a0 = x[5];
+    const T a_1 = a0 + hj;
+    const T v_1 = __builtin_fma(T(0.5) * h, hj, __builtin_fma(h, a0, v0));
+    const T vb = s1 ? v_1 : v0, ab = s1 ? a_1 : a0;
+    const T bj = j == 2 ? T(0.25) : (j == 3 ? T(0.5) : T(0));
+    const T v6_q = __builtin_fma(bj * h, hj, __builtin_fma(aj * h, ab, vb));
+    const T v6_end = __builtin_fma(T(0.5) * h, hj, __builtin_fma(h, a_1, v_1));
+    const T v5_q = __builtin_fma(cq, hj, v0), v5_end = __builtin_fma(T(2), hj, v0);
+    v_q = car6 ? v6_q : v5_q;
+    v_end = car6 ? v6_end : v5_end;
+    a_end = __builtin_fma(T(2), hj, a0);
+    if (dubins) v_q = L;
+  }
+  // ---- heading at this lane's stage ----
+  T th_q = ang_q, th_end = ang_end;
+  if (any_car) {  // wave-uniform
+    const T kth = car ? h * (div_by(v_q, L, rL) * fast_tan(ang_q)) : T(0);
+    gth[lane] = kth;
+    lds_sync(true);
+    const T* g = gth + (lane & ~7);
+    const T k0 = g[0], k1 = g[1], k2 = g[2], k3 = g[3], k4 = g[4], k5 = g[5], k6 = g[6], k7 = g[7];
+    const T kprev = gth[lane > 0 ? lane - 1 : 0];  // the previous stage's derivative (unused by stage 0: aj = 0)
+    const T th1 = x[2] + div_by(k0 + T(2) * (k1 + k2) + k3, six, rsix);
+    const T th2 = th1 + div_by(k4 + T(2) * (k5 + k6) + k7, six, rsix);
+    const T thb = s1 ? th1 : x[2];
+    th_q = car ? __builtin_fma(aj, kprev, thb) : ang_q;
+    th_end = car ? th2 : ang_end;
+  }
+  // ---- position rates of this lane's stage, then the two RK4 combinations ----
+  T sn, cs;
+  fast_sincos(th_q, &sn, &cs);
+  const T kx = DIST ? h * (v_q * cs + d0) : h * (v_q * cs);
+  const T ky = DIST ? h * (v_q * sn + d1) : h * (v_q * sn);
+  T* gxy = gth + 64;
+  gxy[2 * lane] = kx;
+  gxy[2 * lane + 1] = ky;
+  lds_sync(true);
+  const T* gq = gxy + 2 * (lane & ~7);
+  T px = x[0], py = x[1];
+#pragma unroll
+  for (int s = 0; s < 2; s++) {
+    const T a1 = gq[8 * s + 0], b1 = gq[8 * s + 1], a2 = gq[8 * s + 2], b2 = gq[8 * s + 3];
+    const T a3 = gq[8 * s + 4], b3 = gq[8 * s + 5], a4 = gq[8 * s + 6], b4 = gq[8 * s + 7];
+    px += div_by(a1 + T(2) * (a2 + a3) + a4, six, rsix);
+    py += div_by(b1 + T(2) * (b2 + b3) + b4, six, rsix);
+  }
+  x[0] = px;
+  x[1] = py;
+  x[2] = th_end;
+  if (car) {
+    x[3] = ang_end;
+    x[4] = v_end;
+    if (car6) x[5] = a_end;
+  } else if (!dubins) {
+    x[3] = v_end;
+  }
 }
 
 // Per-model Jacobian entries added on top of (I, 0)

@@ -90,6 +90,8 @@ inline bool build_row_program(const DevProblem& d, const std::vector<DevTerm>& d
     o[RO_WEIGHT] = fbits(c.weight); o[RO_VALUE] = fbits(c.value); o[RO_POLY_FIRST] = poly_first;
     o[RO_SLOT] = owner.slot; o[RO_ARG_OFF] = owner.arg_off; o[RO_ARG_DIM] = owner.arg_dim; o[RO_K_START] = owner.k_start;
     o[RO_PATTERN_NSEG] = pattern_or_nseg;
+    for (int e = 0; e < ROP_INLINE_SIDS; e++)  // the op's first slot ids ride in its record (they are already listed)
+      o[ROP_FIELDS + e] = (e < nsid && size_t(sid_begin + e) < sids.size()) ? sids[sid_begin + e] : 0;
     ops.insert(ops.end(), o, o + ROP_WORDS);
   };
   auto add_region = [&](int arr, int words, int offs, const std::vector<short>& map) {
@@ -139,7 +141,7 @@ inline bool build_row_program(const DevProblem& d, const std::vector<DevTerm>& d
       j.idx[0] = xo; j.idx[1] = uo;
       j.weight = d.sub_param[s];
       j.value = s + 1 < N ? d.sub_param[s + 1] : 0.0f;  // Air3D: the pursuer's speed enters the evader's rows
-      emit_op(ROP_JACOBIAN, int(sids.size()), int(av.size() + bv.size()), s, j, j, 0, 0);
+      const int sid_begin = int(sids.size());
       for (auto& rc : av) {
         A(rc.first, rc.second) = short(NPS + nl);
         sids.push_back(NPS + nl);
@@ -152,6 +154,7 @@ inline bool build_row_program(const DevProblem& d, const std::vector<DevTerm>& d
         add_linit(RI_VALUE, 0.0f);
         nl++;
       }
+      emit_op(ROP_JACOBIAN, sid_begin, int(av.size() + bv.size()), s, j, j, 0, 0);
     }
     const int reg_begin = int(regions.size()) / RREG_WORDS;
     add_region(RA_A, n * n, 0, mapA);

@@ -46,8 +46,10 @@ enum {
   RP_NUM_PASSES = 0, RP_NUM_PSLOTS, RP_MAX_LSLOTS, RP_OFF_PASS, RP_OFF_OPS, RP_OFF_SIDS, RP_OFF_PINIT, RP_OFF_LINIT,
   RP_OFF_REGIONS, RP_OFF_MAPS, RP_MAPS_WORDS, RP_OFF_MERIT, RP_WORDS, RP_HEADER = 16
 };
-enum { RPASS_WORDS = 8, ROP_WORDS = 20, RREG_WORDS = 4, RMERIT_WORDS = 4, RINIT_WORDS = 2 };
-// An op is self-contained: [mode, first slot id, slot ids, aux | the fields of the term it evaluates].
+enum { RPASS_WORDS = 8, ROP_FIELDS = 20, ROP_INLINE_SIDS = 20, ROP_WORDS = 40, RREG_WORDS = 4, RMERIT_WORDS = 4, RINIT_WORDS = 2 };
+// An op is self-contained: [mode, first slot id, slot ids, aux | the fields of the term it evaluates | its first
+// ROP_INLINE_SIDS slot ids] — one batch of scalar loads per op (a PAT_ALL term on a wide vector reads the rest of its
+// slot ids from the list at RO_SID).
 //   TERM       one top-level cost / constraint
 //   EXT_EVAL   child `aux` of an ExtremeValueCost: its value competes for the extreme (no derivatives yet)
 //   EXT_APPLY  the same child again: the lanes whose extreme it is take its derivatives
@@ -400,8 +402,8 @@ __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* map
       for (int op = op_begin; op < op_end; op++) {
         const rp_cptr od = ops + op * ROP_WORDS;
         const int mode = od[RO_MODE];
-        const rp_cptr sid = sids + od[RO_SID];
         const int nsid = od[RO_NSID], aux = od[RO_AUX];
+        const rp_cptr sid = nsid <= ROP_INLINE_SIDS ? od + ROP_FIELDS : sids + od[RO_SID];
         DevTerm c;
         c.kind = od[RO_KIND]; c.role = od[RO_ROLE]; c.player = od[RO_PLAYER]; c.flags = od[RO_FLAGS];
         c.idx[0] = od[RO_IDX0]; c.idx[1] = od[RO_IDX1]; c.idx[2] = od[RO_IDX2]; c.idx[3] = od[RO_IDX3];

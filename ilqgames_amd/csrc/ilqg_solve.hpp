@@ -43,6 +43,7 @@ struct SolveArgs {
   // lists the ones that need another pass, and the rows of one instance a workgroup of the row kernel takes
   const int* ids;
   int* ids_next;
+  int defer_forward;    // 1: the sweep's forward pass / ExpectedDecrease runs in the next trial pass, beside the rollout
   int rows_cw;          // rows per chunk of the row stage (ilqg_rows.hpp): 64, 32 or 16, chosen by the launcher
   T* probe_pool;        // speculative line search: [listed instances][probe_k] entries of ProbeEntry::total elements
   int probe_k;          // step sizes probed per instance this round (<= kProbeCandidates)
@@ -63,7 +64,9 @@ enum { Q_COSTS = 0, Q_INIT = 1, Q_TRIAL = 2, Q_LIN = 3 };
 template <typename T>
 struct SolveState {
   int stage, qmode, initial, cur, sacc, num_iterations, bt, accepted_iters;
-  int has_converged, ok, logged, inner_calls, al_success, pad0, pad1, pad2;
+  int has_converged, ok, logged, inner_calls, al_success;
+  int ed_pending;  // the sweep left its scratch rows: ExpectedDecrease is formed by the next trial pass (forward pass)
+  int pad1, pad2;
   T acc_scale, step, last_merit, expected_decrease, max_err, mu;
 };
 constexpr int kStateElems = 32;  // >= sizeof(SolveState<T>) / sizeof(T) for float and double
@@ -138,7 +141,8 @@ __device__ __forceinline__ SolveState<T> state_load(const T* w, const WsLayout& 
   s.sacc = uniform(s.sacc); s.num_iterations = uniform(s.num_iterations); s.bt = uniform(s.bt);
   s.accepted_iters = uniform(s.accepted_iters); s.has_converged = uniform(s.has_converged); s.ok = uniform(s.ok);
   s.logged = uniform(s.logged); s.inner_calls = uniform(s.inner_calls); s.al_success = uniform(s.al_success);
-  s.pad0 = s.pad1 = s.pad2 = 0;
+  s.ed_pending = uniform(s.ed_pending);
+  s.pad1 = s.pad2 = 0;
   s.acc_scale = uniform(s.acc_scale); s.step = uniform(s.step); s.last_merit = uniform(s.last_merit);
   s.expected_decrease = uniform(s.expected_decrease); s.max_err = uniform(s.max_err); s.mu = uniform(s.mu);
   return s;
@@ -550,6 +554,7 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const s
   T* const sm_quad = sm + re + size_t(rwave < 0 ? 0 : rwave) * qe;
   T* const sm_quad0 = sm + re;  // the first row wave's scratch doubles as reduction scratch between passes
   int* const flags = reinterpret_cast<int*>(sm + re + size_t(RW) * qe);  // [0] rows ready, [1] next chunk to claim
+  T* const ed_slot = reinterpret_cast<T*>(flags + 2);  // deferred ExpectedDecrease, from the first row wave to everyone
 
   SolveState<T> s;
   if (sa.first) {
@@ -564,7 +569,7 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const s
     }
     s.stage = ST_ROLLOUT; s.qmode = Q_COSTS; s.initial = 1; s.cur = 0; s.sacc = 0;
     s.num_iterations = 0; s.bt = 0; s.accepted_iters = 0; s.has_converged = 0; s.ok = 1;
-    s.logged = 0; s.inner_calls = 0; s.al_success = 1; s.pad0 = s.pad1 = s.pad2 = 0;
+    s.logged = 0; s.inner_calls = 0; s.al_success = 1; s.ed_pending = 0; s.pad1 = s.pad2 = 0;
     // first == 2: the solver object has been called before on this workspace and its
     // last_merit_function_value_ (ilq_solver.h:189) is still what the previous call left
     const T carried = (sa.first == 2) ? state_load<T>(w, L).last_merit : dinf<T>();
@@ -624,7 +629,20 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const s
     QuadArgs<T> qa = trial_quad_args<T>(p, ib, s);
     qa.phacc = (kProfile && sa.prof) ? qph : nullptr;
     long long tq0 = (kProfile && sa.prof) ? clock64() : 0;
-    // Chunks of sa.rows_cw rows are claimed in order and processed once the rollout has published their last row.
+    // The sweep's forward pass (delta_xs, src/lq_feedback_solver.cpp:217-241) and ILQSolver::ExpectedDecrease
+    // (:364-398), deferred to here: the first row wave runs them from the sweep's scratch rows while wave 0
+    // integrates, before its first chunk overwrites the linearisation they read.
+    if (s.ed_pending && rwave == 0) {
+      LQArgs<T> fa{};
+      fa.A = w + L.A;
+      fa.scratch = w + L.lqscr;
+      fa.x0 = nullptr;
+      fa.dx = nullptr;
+      fa.ed_out = ed_slot;
+      fa.T_steps = Tn;
+      constexpr int FWD_LDSE = 4 * 2 * ((NX * NX + LQCfg<T, NX, NP, MU>::SCR + 3) & ~3) + NX + 8;
+      lq_forward_pass_body<T, NX, NP, MU, 64, FWD_LDSE>(fa, sm_quad, lane);
+    }
     if (rwave >= 0) {
       const int cw = sa.rows_cw;
       const int nchunks = (Tn + cw - 1) / cw;
@@ -645,6 +663,12 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const s
     }
     }
 
+    if (PHASE == TRIAL_FUSED && s.ed_pending) {
+      __syncthreads();
+      s.expected_decrease = uniform(*ed_slot);
+      s.ed_pending = 0;
+      __syncthreads();
+    }
     // ---- reductions and the line-search decision (wave-uniform, identical on every wave) ----
     if (qmode == Q_COSTS) {
       costs_reduce<T>(p, w + L.cpart, costs, t_extreme, sm_quad0, int(qe));
@@ -738,12 +762,14 @@ __device__ __forceinline__ void lq_part_instance(const DevProblem& p, const Solv
   la.x0 = nullptr;
   la.P = sacc ? sa.P + size_t(b) * Tn * p.m * p.n : w + L.P1;  // strategy buffer 1 - sacc
   la.alpha = sacc ? sa.alpha + size_t(b) * Tn * p.m : w + L.al1;
-  la.dx = w + L.dx;
+  const bool defer = sa.defer_forward && KIND != LQ_OPEN_LOOP;
+  la.dx = defer ? nullptr : w + L.dx;
+  la.defer_forward = defer ? 1 : 0;
   la.scratch = w + L.lqscr;
   // where the sweep leaves the expected decrease: an LDS slot that is free once it ends (feedback sweeps), or
   // one past the open-loop sweep's own working set (the launch reserves it)
   constexpr int ed_slot = (KIND == LQ_OPEN_LOOP) ? OLCfg<T, NX, NP, MU>::LDS_ELEMS : LQCfg<T, NX, NP, MU>::oX;
-  la.ed_out = sm + ed_slot;
+  la.ed_out = defer ? nullptr : sm + ed_slot;
   la.T_steps = Tn;
   la.adaptive = 1;
   la.symmetric = 1;  // linquad_compute writes H(x,y) and H(y,x) from the same value
@@ -757,7 +783,10 @@ __device__ __forceinline__ void lq_part_instance(const DevProblem& p, const Solv
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    st->expected_decrease = sm[ed_slot];
+    if (defer)
+      st->ed_pending = 1;
+    else
+      st->expected_decrease = sm[ed_slot];
     st->num_iterations += 1;
     st->step = T(sa.prm.initial_alpha_scaling);
     st->bt = 0;

@@ -30,8 +30,9 @@ struct RolloutArgs {
 
 // [x | dx | u] + two staged [P | alpha | u_ref | x_ref] blocks (the one in use, the one the DMA is filling)
 __host__ __device__ inline int rollout_stage_elems(int n, int m) { return (m * n + 2 * m + n + 3) & ~3; }
+constexpr int kRolloutGatherElems = 192;  // sub_integrate_stages: 64 heading rates + 64 (x, y) position-rate pairs
 __host__ __device__ inline int rollout_lds_elems(int n, int m) {
-  return ((2 * n + m + 3) & ~3) + 2 * rollout_stage_elems(n, m);
+  return ((2 * n + m + 3) & ~3) + 2 * rollout_stage_elems(n, m) + kRolloutGatherElems;
 }
 
 // Workgroup-scope publish / observe of a progress counter in LDS.  Waves of one workgroup share the
@@ -92,30 +93,33 @@ __device__ __forceinline__ void rollout_instance(const DevProblem& p, const Roll
 #pragma unroll
     for (int e = 0; e < 6; e++) xj[e] = (e < xd) ? a.x0[xo + e] : T(0);
   }
+  T* const gth = stg + 2 * WP;  // exchange scratch of the stage-parallel integrator
+  const bool any_car = __any(integ && (kind == ILQG_DYN_CAR_5D || kind == ILQG_DYN_CAR_6D));
   issue(0, 0);
-  dma_wait();
-  lds_sync(true);
   long long rc0 = (kProfile && phacc) ? clock64() : 0, rc1;
 #define ILQG_RPH(i) do { if (kProfile && phacc) { __builtin_amdgcn_sched_barrier(0); rc1 = clock64(); __builtin_amdgcn_sched_barrier(0); phacc[i] += rc1 - rc0; rc0 = rc1; } } while (0)
 #pragma unroll 1
   for (int k = 0; k < Tn; k++) {
-    // rows < k were stored at least one integration ago: the release finds nothing left to wait for,
-    // and it sits in front of the prefetch so it never waits on fresh loads either
+    // Block k of [P | alpha | u_ref | x_ref] was requested a whole step ago, and the rows of step k - 1 were stored
+    // then too: this wait finds nothing in flight, and with it the release below is free.
+    dma_wait();
     if (ready) progress_publish(ready, k);
-    if (k + 1 < Tn) issue(k + 1, (k + 1) & 1);
     const T* sP = stg + (k & 1) * WP;  // [m*n] gains of this step
     const T* sal = sP + m * n;         // [m]
     const T* sur = sal + m;            // [m] u_ref
     const T* sxr = sur + m;            // [n] x_ref
-    if (integ && q == 0) {
+    {
+      // every lane of a group holds the group's state: lane q publishes entry q (one LDS round trip for the row)
+      T mine = xj[0];
 #pragma unroll
-      for (int e = 0; e < 6; e++)
-        if (e < xd) {
-          sdx[xo + e] = xj[e] - sxr[xo + e];
-          a.xs[size_t(k) * n + xo + e] = xj[e];
-        }
+      for (int e = 1; e < 6; e++) mine = (q == e) ? xj[e] : mine;
+      if (integ && q < xd) {
+        sdx[xo + q] = mine - sxr[xo + q];
+        a.xs[size_t(k) * n + xo + q] = mine;
+      }
     }
     lds_sync(NT <= 64);
+    if (k + 1 < Tn) issue(k + 1, (k + 1) & 1);  // into the block step k - 1 read: a whole step to land
     ILQG_RPH(0);
     if (t < m) {
       T s = T(0);
@@ -145,24 +149,21 @@ __device__ __forceinline__ void rollout_instance(const DevProblem& p, const Roll
     }
     lds_sync(NT <= 64);
     ILQG_RPH(1);
-    if (t < 64 && k + 1 < Tn) {  // whole first wave: the shuffles inside need every group lane live
+    if (t < 64 && k + 1 < Tn) {  // whole first wave: the exchanges inside need every group lane live
       const T u0 = integ ? su[uo] : T(0), u1 = integ ? su[uo + 1] : T(0);
       if constexpr (AIR) {
-        if (t == 0) sub_integrate<T>(kind, Lp, p.dt, xj, u0, u1, T(p.sub_param[1]));
+        if (grp == 0) sub_integrate<T>(kind, Lp, p.dt, xj, u0, u1, T(p.sub_param[1]));  // every lane of the group keeps the state
       } else if constexpr (DIST) {
         const bool dist = integ && kind == ILQG_DYN_UNICYCLE_4D_DISTURBED;  // the next player's (dx, dy)
         const T d0 = dist ? su[uo + 2] : T(0), d1 = dist ? su[uo + 3] : T(0);
-        sub_integrate_lanes<T, true>(kind, Lp, p.dt, xj, u0, u1, q, t & ~7, d0, d1);
+        sub_integrate_stages<T, true>(kind, Lp, p.dt, xj, u0, u1, q, t, gth, false, d0, d1);
       } else if (PM && p.sub_kind[0] == ILQG_DYN_POINT_MASS_2D) {
         sub_integrate<T>(kind, Lp, p.dt, xj, u0, u1);
       } else {
-        sub_integrate_lanes<T, false, DUB>(kind, Lp, p.dt, xj, u0, u1, q, t & ~7);
+        sub_integrate_stages<T, false, DUB>(kind, Lp, p.dt, xj, u0, u1, q, t, gth, any_car);
       }
     }
     ILQG_RPH(2);
-    dma_wait();  // next block landed (this step's row stores are long retired by now)
-    lds_sync(NT <= 64);
-    ILQG_RPH(3);
   }
 #undef ILQG_RPH
   if (ready) progress_publish(ready, Tn);
