@@ -13,7 +13,7 @@ F32, F64 = 0, 1
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_NO_DEVICE = 0, 1, 2, 3, 4
 
 # ilqg_dyn_kind
-ABI_VERSION = 2  # ILQG_ABI_VERSION of include/ilqg.h these mirrors were written against
+ABI_VERSION = 3  # ILQG_ABI_VERSION of include/ilqg.h these mirrors were written against
 DYN_UNICYCLE_4D, DYN_CAR_5D, DYN_CAR_6D = 1, 2, 3
 DYN_UNICYCLE_4D_DISTURBED, DYN_PLANAR_DISTURBANCE = 4, 5  # the two rows of TwoPlayerUnicycle4D
 DYN_DUBINS_CAR = 6  # (px, py, theta), u = (omega), param0 = speed
@@ -38,7 +38,18 @@ class Pair(C.Structure):
 class Dims(C.Structure):
     _fields_ = [("n", C.c_int32), ("num_players", C.c_int32), ("udim", C.c_int32 * MAX_PLAYERS),
                 ("T", C.c_int32), ("batch", C.c_int32), ("dtype", C.c_int32),
-                ("adaptive_regularization", C.c_int32)]
+                ("adaptive_regularization", C.c_int32), ("sweep_formulation", C.c_int32)]
+
+
+CHOICE_AUTO, CHOICE_OFF, CHOICE_ON = 0, 1, 2
+
+
+class SolveOptions(C.Structure):
+    """ilqg_solve_options (include/ilqg.h)."""
+    _fields_ = [("fixed_iters", C.c_int32), ("augmented_lagrangian", C.c_int32), ("resume", C.c_int32),
+                ("reserved0", C.c_int32), ("active", C.c_void_p), ("forced_steps", C.c_void_p),
+                ("split_trial", C.c_int32), ("handoff", C.c_int32), ("probe", C.c_int32), ("counted", C.c_int32),
+                ("reserved", C.c_int32 * 6)]
 
 
 class Subsystem(C.Structure):

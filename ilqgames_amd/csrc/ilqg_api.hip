@@ -174,22 +174,7 @@ __device__ __forceinline__ QuadArgs<T> quad_args_of(const DevProblem& p, const Q
   return a;
 }
 
-// grid = (ceil(T / kStepsPerBlock), B): every (instance, time step) is independent here; a block
-// takes a few consecutive steps so that staging the cost tables into LDS is amortised.
-constexpr int kStepsPerBlock = 4;
-template <typename T>
-__global__ void linquad_kernel(DevProblem p, QuadBatchArgs<T> g) {
-  extern __shared__ __align__(16) unsigned char smem_raw[];
-  const size_t b = blockIdx.y;
-  if (g.active && !g.active[b]) return;
-  const QuadTables<T> tb = quad_tables_load<T>(p, smem_raw);
-  T* sm = reinterpret_cast<T*>(smem_raw + quad_tables_bytes(p, sizeof(T)));
-  const QuadArgs<T> a = quad_args_of<T>(p, g, b);
-  const int k0 = int(blockIdx.x) * kStepsPerBlock;
-  for (int k = k0; k < k0 + kStepsPerBlock && k < p.T; k++) linquad_step<T>(p, tb, a, k, sm, threadIdx.x);
-}
-
-// The lane-per-time-step form of the same stage (ilqg_rows.hpp): grid = (ceil(T / CW), B), one wavefront takes CW
+// Linearise / quadraticise / cost stage on its own (ilqg_rows.hpp): grid = (ceil(T / cw), B), one wavefront takes cw
 // consecutive rows of one instance.
 template <typename T, int NX, int NP, int MU>
 __global__ void __launch_bounds__(64) rows_kernel(DevProblem p, QuadBatchArgs<T> g, int cw) {
@@ -202,6 +187,36 @@ __global__ void __launch_bounds__(64) rows_kernel(DevProblem p, QuadBatchArgs<T>
   const int k0 = int(blockIdx.x) * cw;
   const int nrows = p.T - k0 < cw ? p.T - k0 : cw;
   rows_chunk<T, NX, NP * MU, NP>(p, maps, a, k0, nrows, cw, sm, int(threadIdx.x));
+}
+
+// ilqg_solve_state_batch: the loop state of every instance out of the workspace
+template <typename T>
+__global__ void solve_state_kernel(const T* ws, size_t ws_stride, size_t state_off, int batch, T* last_merit,
+                                   T* expected_decrease, T* step, int* backtracks) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  const SolveState<T>* s = reinterpret_cast<const SolveState<T>*>(ws + size_t(b) * ws_stride + state_off);
+  if (last_merit) last_merit[b] = s->last_merit;
+  if (expected_decrease) expected_decrease[b] = s->expected_decrease;
+  if (step) step[b] = s->acc_scale;
+  if (backtracks) backtracks[b] = s->bt;
+}
+
+// What follows the per-instance blocks in a solve's workspace: two lists of instance ids (this round's back-tracking
+// instances, the next round's) and the pool of the speculative line search.
+struct WsTail {
+  size_t ids_off, pool_off, total;
+  int pool_entries;
+};
+inline WsTail ws_tail(const DevProblem& d, int batch, size_t elem, int ol_row) {
+  auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
+  const WsLayout L(d.n, d.m, d.N, d.T, d.pairs.Rsz, d.pairs.rsz, ol_row, d.num_constraints, 1);
+  WsTail t;
+  t.ids_off = up(size_t(L.total) * elem * size_t(batch));
+  t.pool_off = up(t.ids_off + size_t(2) * batch * sizeof(int));
+  t.pool_entries = batch * 8 < kProbeEntries ? batch * 8 : kProbeEntries;
+  t.total = up(t.pool_off + size_t(t.pool_entries) * ProbeEntry(d.n, d.m, d.N, d.T).total * elem);
+  return t;
 }
 
 template <typename T>
@@ -442,7 +457,7 @@ struct __attribute__((visibility("hidden"))) DimsLaunch {
                                  void* alpha, void* dx, hipStream_t stream);
   static ilqg_status solve(ilqg_problem* p, int32_t batch, const void* x0, void* xs, void* us, void* P, void* alpha,
                            void* total_costs, int32_t* iters, int32_t* status, int32_t* converged, void* workspace,
-                           int32_t fixed_iters, int al_mode, int resume, const int32_t* active, hipStream_t stream);
+                           const ilqg_solve_options& opt, hipStream_t stream);
   // pointers in QuadBatchArgs' order: xs us lambdas mu t_extreme A Bm Q l R r merit_part cost_part active
   static ilqg_status rows(const DevProblem& d, int32_t batch, const void* const* ptrs, hipStream_t stream);
 };
@@ -482,10 +497,10 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::lq(const ilqg_dims* d, const PairTable& p
   g.adaptive = d->adaptive_regularization;
   g.batch = d->batch;
   g.force_valu = 0;
-  const bool use_pw = C::USE_MFMA && getenv("ILQG_FORCE_VALU") == nullptr;
+  // ilqg_dims::sweep_formulation = ILQG_CHOICE_OFF selects the VALU/LDS formulation where the MFMA one is the default
+  const bool valu = C::USE_MFMA && d->sweep_formulation == ILQG_CHOICE_OFF;
+  const bool use_pw = C::USE_MFMA && !valu;
   const size_t lds = size_t(use_pw ? PWCfg<T, NX, NP, MU>::LDS_ELEMS : C::LDS_ELEMS) * sizeof(T);
-  // ILQG_FORCE_VALU=1 selects the VALU/LDS formulation where the MFMA one is the default (A/B profiling)
-  const bool valu = C::USE_MFMA && getenv("ILQG_FORCE_VALU") != nullptr;
   auto kern = valu ? lq_feedback_kernel<T, NX, NP, MU, true> : lq_feedback_kernel<T, NX, NP, MU, false>;
   const int nt = valu ? LQFeedbackThreads<T, NX, NP, MU, true>::NT : LQFeedbackThreads<T, NX, NP, MU, false>::NT;
   raise_lds_limit((const void*)kern, lds);
@@ -552,9 +567,6 @@ struct ilqg_problem {
   int* d_row_prog = nullptr;
   int* d_unfinished = nullptr;  // instances still running after an LQ-kernel launch
   int* h_unfinished = nullptr;  // pinned host mirror
-  int* d_pass_ids = nullptr;    // split passes: two lists of instances that need another pass (this round's, the next's)
-  int pass_ids_capacity = 0;
-  void* d_probe_pool = nullptr;  // speculative line search: kProbeEntries trajectories + merit partials
   int mu_uniform = 0;
 };
 
@@ -568,10 +580,14 @@ static ilqg_status launch_linquad(const ilqg_problem* p, int32_t batch, const vo
 template <typename T, int NX, int NP, int MU>
 ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, const void* x0, void* xs, void* us,
                                              void* P, void* alpha, void* total_costs, int32_t* iters, int32_t* status,
-                                             int32_t* converged, void* workspace, int32_t fixed_iters, int al_mode,
-                                             int resume, const int32_t* active, hipStream_t stream) {
+                                             int32_t* converged, void* workspace, const ilqg_solve_options& opt,
+                                             hipStream_t stream) {
   using C = LQCfg<T, NX, NP, MU>;
   const DevProblem& d = p->dev;
+  const int32_t fixed_iters = opt.fixed_iters;
+  const int al_mode = opt.augmented_lagrangian ? 1 : 0, resume = opt.resume ? 1 : 0;
+  const int32_t* const active = opt.active;
+  auto choice = [](int32_t c, bool automatic) { return c == ILQG_CHOICE_ON ? true : (c == ILQG_CHOICE_OFF ? false : automatic); };
   static_assert(OLCfg<T, NX, NP, MU>::ROW == ((NX * NX + NX + NP * MU * NX + NP * MU + NP * NX * NX + 2 * NP * NX + 3) & ~3), "ol_row_elems");
   const int ol_row = p->desc.params.open_loop ? ol_row_elems(d.n, d.m, d.N) : 0;
   const WsLayout L(d.n, d.m, d.N, d.T, d.pairs.Rsz, d.pairs.rsz, ol_row, d.num_constraints, al_mode);
@@ -584,11 +600,12 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   sa.prm = p->desc.params;
   sa.active = active;
   sa.prof = g_prof;
-  if (!p->d_unfinished) {
-    HIP_TRY(hipMalloc(&p->d_unfinished, 4 * sizeof(int)));
-    HIP_TRY(hipHostMalloc(&p->h_unfinished, 4 * sizeof(int)));
-  }
+  sa.forced_steps = (const T*)opt.forced_steps;
   sa.unfinished = p->d_unfinished;
+  // the tail of the workspace: the two lists of back-tracking instances and the line-search probe pool
+  const WsTail tail = ws_tail(d, batch, sizeof(T), ol_row);
+  int* const pass_ids = reinterpret_cast<int*>(static_cast<char*>(workspace) + tail.ids_off);
+  T* const probe_pool = reinterpret_cast<T*>(static_cast<char*>(workspace) + tail.pool_off);
   sa.ids = nullptr;
   sa.ids_next = nullptr;
   sa.probe_pool = nullptr;
@@ -626,15 +643,24 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   // Split passes where the fused trial kernel's LDS leaves a CU with fewer than three instances (n = 24); the
   // host then counts every round, because an instance may ask for another pass (back-tracking) before its sweep.
   // ILQG_SPLIT_TRIAL=0/1 overrides the choice (A/B measurements).
-  bool split = 3 * lds_trial > size_t(160) * 1024;
-  if (const char* e = getenv("ILQG_SPLIT_TRIAL")) split = e[0] == '1';
-  if (kProfile) split = false;  // the phase profile reads the fused kernel's counters
-  const bool counted = split || !(fixed_iters > 0 && !al_mode) || getenv("ILQG_COUNTED") != nullptr;
+  // Split passes: where the fused kernel cannot keep four instances on a CU, and for batches that are several times
+  // what it keeps resident when the split integration kernel (a quarter of the registers, 4 KB of LDS) gains from
+  // the co-residency — measured: n = 24, B = 4096: 65 k vs 39 k it/s; n = 14 fp32, B = 8192: 1.81 M vs
+  // 1.61 M; n = 14 fp64, B = 8192: 1.02 M vs 1.08 M (the fused kernel stays).
+  int num_cus = 256;
+  {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) num_cus = prop.multiProcessorCount;
+  }
+  const bool big_batch = size_t(batch) >= size_t(8) * num_cus;
+  bool split = choice(opt.split_trial, 4 * lds_trial > size_t(160) * 1024 || (big_batch && (sizeof(T) == 4 || NX > 16)));
+  if (kProfile || opt.forced_steps) split = false;  // the phase profile reads the fused kernel's counters
+  const bool counted = !opt.forced_steps && (split || !(fixed_iters > 0 && !al_mode) || choice(opt.counted, false));
   // Hand-off: whenever the host counts rounds anyway, the fused kernel keeps an instance only until its line
   // search rejects a step; the back-tracking instances then go through split passes with the speculative line
   // search (ILQG_HANDOFF=0 keeps every pass in the fused kernel).
-  const bool handoff = counted && !split && !kProfile && sa.prm.linesearch &&
-                       !(getenv("ILQG_HANDOFF") && getenv("ILQG_HANDOFF")[0] == '0');
+  const bool handoff = counted && !split && !kProfile && sa.prm.linesearch && choice(opt.handoff, true);
   const bool lists = split || handoff;
   // The sweep's forward pass runs in the fused trial kernel that follows it, beside the rollout, whenever that is the
   // kernel that follows (split passes and the open-loop sweep keep it in the sweep's kernel).
@@ -652,15 +678,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   const size_t lds_roll = trial_phase_lds_bytes<T>(d, TRIAL_ROLL, sa.rows_cw),
                lds_decide = trial_phase_lds_bytes<T>(d, TRIAL_DECIDE, sa.rows_cw);
   const size_t lds_rows = rows_maps_bytes(d) + trial_rows_elems(d, sa.rows_cw) * sizeof(T);
-  if (lists && p->pass_ids_capacity < batch) {
-    if (p->d_pass_ids) (void)hipFree(p->d_pass_ids);
-    p->d_pass_ids = nullptr;
-    p->pass_ids_capacity = 0;
-    HIP_TRY(hipMalloc(&p->d_pass_ids, size_t(2) * batch * sizeof(int)));
-    p->pass_ids_capacity = batch;
-  }
-  // ILQG_PROBE=0 switches the speculative line search off (A/B measurements)
-  const bool probe = lists && sa.prm.linesearch && !(getenv("ILQG_PROBE") && getenv("ILQG_PROBE")[0] == '0');
+  const bool probe = lists && sa.prm.linesearch && choice(opt.probe, true);
   auto k_proll = ilq_probe_roll_kernel<T, NX, NP, MU>;
   auto k_prows = ilq_probe_rows_kernel<T, NX, NP, MU>;
   const int decide_elems = int(trial_phase_quad_elems<T>(d, TRIAL_DECIDE, sa.rows_cw));
@@ -679,20 +697,17 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   for (long long round = 0;; round++) {
     if (counted) HIP_TRY(hipMemsetAsync(p->d_unfinished, 0, 4 * sizeof(int), stream));
     if (split || sa.ids) {  // a split pass: the whole batch (split mode) or the listed back-tracking instances
-      sa.ids_next = p->d_pass_ids + size_t(list) * p->pass_ids_capacity;
+      sa.ids_next = pass_ids + size_t(list) * batch;
       // Step sizes probed per listed instance: as many as the pool holds for a list this long, doubling from two
       // over the first rounds of a tail (most line searches that back-track at all end within a step or two; the
       // ones that do not are the ones worth eight candidates a round).
-      int probe_k = sa.ids ? kProbeEntries / round_instances : 0;
+      int probe_k = sa.ids ? tail.pool_entries / round_instances : 0;
       if (probe_k > kProbeCandidates) probe_k = kProbeCandidates;
       if (tail_rounds < 3 && probe_k > (2 << tail_rounds)) probe_k = 2 << tail_rounds;
       if (sa.ids) tail_rounds++;
       if (probe && probe_k >= 2) {
         // the listed instances' next step sizes side by side; their states move to the first acceptable one
-        if (!p->d_probe_pool)  // 85-200 MB: only problems whose line searches back-track ever need it
-          HIP_TRY(hipMalloc(&p->d_probe_pool,
-                            size_t(kProbeEntries) * ProbeEntry(d.n, d.m, d.N, d.T).total * sizeof(T)));
-        sa.probe_pool = (T*)p->d_probe_pool;
+        sa.probe_pool = probe_pool;
         sa.probe_k = probe_k;
         hipLaunchKernelGGL(k_proll, dim3(round_instances, probe_k), dim3(64), lds_roll, stream, d, sa);
         HIP_TRY(hipGetLastError());
@@ -713,7 +728,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
       HIP_TRY(hipGetLastError());
       hipLaunchKernelGGL(k_decide, dim3(round_instances), dim3(64), lds_decide, stream, d, sa);
     } else {
-      sa.ids_next = handoff ? p->d_pass_ids + size_t(list) * p->pass_ids_capacity : nullptr;
+      sa.ids_next = handoff ? pass_ids + size_t(list) * batch : nullptr;
       hipLaunchKernelGGL(k_trial, dim3(batch), dim3(64 * W), lds_trial, stream, d, sa);
     }
     HIP_TRY(hipGetLastError());
@@ -785,31 +800,16 @@ static ilqg_status launch_linquad(const ilqg_problem* p, int32_t batch, const vo
                                   void* Q, void* l, void* R, void* r, void* merit_part, void* cost_part,
                                   const int32_t* active, void* stream) {
   const DevProblem& d = p->dev;
-  // the lane-per-time-step kernel where this (n, N, m_i) is instantiated (ILQG_OLD_ROWS=1: A/B against the
-  // term-per-lane kernel, which also serves shapes outside the list)
-  if (p->mu_uniform && getenv("ILQG_OLD_ROWS") == nullptr) {
-    const void* const ptrs[14] = {xs, us, lambdas, mu, t_extreme, A, Bm, Q, l, R, r, merit_part, cost_part, active};
+  if (!p->mu_uniform) return fail(ILQG_ERR_UNSUPPORTED, "non-uniform control dimensions");
+  const void* const ptrs[14] = {xs, us, lambdas, mu, t_extreme, A, Bm, Q, l, R, r, merit_part, cost_part, active};
 #define X(NX_, NP_, MU_)                                                                          \
   if (d.n == NX_ && d.N == NP_ && p->mu_uniform == MU_)                                           \
     return p->desc.dtype == ILQG_F32                                                              \
                ? DimsLaunch<float, NX_, NP_, MU_>::rows(d, batch, ptrs, (hipStream_t)stream)      \
                : DimsLaunch<double, NX_, NP_, MU_>::rows(d, batch, ptrs, (hipStream_t)stream);
-    ILQG_FOR_DIMS(X)
+  ILQG_FOR_DIMS(X)
 #undef X
-  }
-#define CALL(TY_)                                                                                                 \
-  [&]() -> ilqg_status {                                                                                        \
-    QuadBatchArgs<TY_> g{(const TY_*)xs, (const TY_*)us, (const TY_*)lambdas, (const TY_*)mu, t_extreme, (TY_*)A, (TY_*)Bm,   \
-                       (TY_*)Q, (TY_*)l, (TY_*)R, (TY_*)r, (TY_*)merit_part, (TY_*)cost_part, active};                      \
-    const size_t lds = quad_lds_elems(d.n, d.m, d.N, d.pairs.Rsz, d.pairs.rsz, d.num_terms) * sizeof(TY_) +       \
-                       quad_tables_bytes(d, sizeof(TY_));                                                         \
-    hipLaunchKernelGGL(linquad_kernel<TY_>, dim3((d.T + kStepsPerBlock - 1) / kStepsPerBlock, batch), dim3(64),  \
-                       lds, (hipStream_t)stream, d, g);                                                           \
-    HIP_TRY(hipGetLastError());                                                                                 \
-    return ILQG_OK;                                                                                             \
-  }()
-  return DT_DISPATCH(p, CALL);
-#undef CALL
+  return fail(ILQG_ERR_UNSUPPORTED, "no device kernel instantiated for this problem's dimensions");
 }
 
 extern "C" {
@@ -838,8 +838,10 @@ int32_t ilqg_abi_version(void) { return ILQG_ABI_VERSION; }
 ilqg_status ilqg_device_info(char* name_out, int32_t name_len, int32_t* num_cus) {
   ilqg_status s = check_device();
   if (s != ILQG_OK) return s;
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
   hipDeviceProp_t prop;
-  HIP_TRY(hipGetDeviceProperties(&prop, 0));
+  HIP_TRY(hipGetDeviceProperties(&prop, dev));
   if (name_out && name_len > 0) {
     std::snprintf(name_out, name_len, "%s (%s)", prop.name, prop.gcnArchName);
   }
@@ -1023,123 +1025,13 @@ ilqg_status ilqg_problem_create(const ilqg_problem_desc* desc, ilqg_problem** ou
     if (t.constraint_slot >= 0 && t.constraint_slot + 1 > nc) nc = t.constraint_slot + 1;
   }
   d.num_constraints = nc;
-  // ---- metadata of the term-parallel quadraticisation: tiles, argument slices, scatter rounds ----
-  {
-    const int nn = d.n;
-    auto pair_of = [&](int i, int j) {
-      for (int q = 0; q < d.pairs.npairs; q++)
-        if (d.pairs.pi[q] == i && d.pairs.pj[q] == j) return q;
-      return -1;
-    };
-    for (int ti = 0; ti < desc->num_terms; ti++) {
-      DevTerm& o = dt[ti];
-      const bool on_state = o.role == ILQG_ROLE_STATE_COST || o.role == ILQG_ROLE_STATE_CONSTRAINT ||
-                            o.role == ILQG_ROLE_CHILD;
-      if (on_state) {
-        o.tile_h = o.player * nn * nn;
-        o.tile_g = d.N * nn * nn + o.player * nn;
-        o.ld = nn;
-        o.arg_off = 0;
-        o.arg_dim = nn;
-      } else {
-        const int q = pair_of(o.player, o.arg);
-        const int mj = d.udim[o.arg];
-        o.tile_h = d.N * nn * nn + d.N * nn + d.pairs.roff[q];
-        o.tile_g = d.N * nn * nn + d.N * nn + d.pairs.Rsz + d.pairs.rgoff[q];
-        o.ld = mj;
-        o.arg_off = nn + d.uoff[o.arg];
-        o.arg_dim = mj;
-      }
-      o.round = 0;
-    }
-    // indices a term may touch inside its tile (children count for their parent)
-    auto touched = [&](int ti, std::vector<int>* idx) {
-      idx->clear();
-      auto add_leaf = [&](const DevTerm& c) {
-        switch (c.kind) {
-          case ILQG_COST_QUADRATIC:
-            if (c.idx[0] < 0) for (int e = 0; e < dt[ti].arg_dim; e++) idx->push_back(e);
-            else idx->push_back(c.idx[0]);
-            break;
-          case ILQG_COST_SEMIQUADRATIC:
-          case ILQG_CONSTRAINT_SINGLE_DIMENSION: idx->push_back(c.idx[0]); break;
-          case ILQG_COST_QUADRATIC_POLYLINE2:
-          case ILQG_COST_POLYLINE2_SIGNED_DISTANCE:
-          case ILQG_COST_SEMIQUADRATIC_POLYLINE2: idx->push_back(c.idx[0]); idx->push_back(c.idx[1]); break;
-          default: for (int e = 0; e < 4; e++) idx->push_back(c.idx[e]); break;
-        }
-      };
-      if (dt[ti].kind == ILQG_COST_EXTREME_VALUE)
-        for (int q = 0; q < dt[ti].child_count; q++) add_leaf(dt[dt[ti].child_begin + q]);
-      else
-        add_leaf(dt[ti]);
-    };
-    // accumulation order of PlayerCost::Quadraticize: per player, roles 0..3, table order within a role
-    std::vector<int> order;
-    for (int i = 0; i < d.N; i++)
-      for (int role = 0; role < 4; role++)
-        for (int ti = 0; ti < desc->num_terms; ti++)
-          if (dt[ti].player == i && dt[ti].role == role) order.push_back(ti);
-    int max_round = 0;
-    std::vector<int> ia, ib;
-    for (size_t a2 = 0; a2 < order.size(); a2++) {
-      const int ta = order[a2];
-      touched(ta, &ia);
-      int rnd = 0;
-      for (size_t b2 = 0; b2 < a2; b2++) {
-        const int tb = order[b2];
-        if (dt[tb].tile_h != dt[ta].tile_h) continue;
-        touched(tb, &ib);
-        bool hit = false;
-        for (int x : ia) for (int y : ib) hit = hit || (x == y);
-        if (hit && dt[tb].round + 1 > rnd) rnd = dt[tb].round + 1;
-      }
-      dt[ta].round = rnd;
-      if (rnd > max_round) max_round = rnd;
-    }
-    d.num_rounds = max_round + 1;
-    // shared closest-point queries of the top-level polyline terms on the state
-    d.num_cq = 0;
-    d.num_cq_items = 0;
-    for (int ti = 0; ti < desc->num_terms; ti++) dt[ti].cq = -1;
-    bool fits = true;
-    int cq_key[kMaxClosestQueries][3];
-    for (int ti = 0; ti < desc->num_terms && fits; ti++) {
-      DevTerm& o = dt[ti];
-      const bool poly_kind = o.kind == ILQG_COST_QUADRATIC_POLYLINE2 || o.kind == ILQG_COST_SEMIQUADRATIC_POLYLINE2;
-      if (!poly_kind || o.role == ILQG_ROLE_CHILD || o.arg_off != 0 || o.polyline < 0) continue;
-      int q = -1;
-      for (int e = 0; e < d.num_cq; e++)
-        if (cq_key[e][0] == o.polyline && cq_key[e][1] == o.idx[0] && cq_key[e][2] == o.idx[1]) q = e;
-      if (q < 0) {
-        const int nseg = desc->polyline_offsets[o.polyline + 1] - desc->polyline_offsets[o.polyline] - 1;
-        if (d.num_cq == kMaxClosestQueries || d.num_cq_items + nseg > kMaxClosestItems || nseg > 255 || nseg < 1 ||
-            o.idx[0] > 255 || o.idx[1] > 255) {
-          fits = false;
-          break;
-        }
-        q = d.num_cq++;
-        cq_key[q][0] = o.polyline;
-        cq_key[q][1] = o.idx[0];
-        cq_key[q][2] = o.idx[1];
-        const int first_seg = desc->polyline_offsets[o.polyline] - o.polyline;  // segments before this polyline
-        d.cq_tab[q][0] = d.num_cq_items;
-        d.cq_tab[q][1] = nseg;
-        d.cq_tab[q][2] = first_seg;
-        d.cq_tab[q][3] = 0;
-        for (int c = 0; c < nseg; c++) {
-          d.cq_items[d.num_cq_items][0] = first_seg + c;
-          d.cq_items[d.num_cq_items][1] = o.idx[0] | (o.idx[1] << 8) | (c << 16) | (nseg << 24);
-          d.num_cq_items++;
-        }
-      }
-      o.cq = q;
-    }
-    if (!fits || getenv("ILQG_NO_SHARED_CLOSEST") != nullptr) {  // too many distinct searches for one wave (or A/B switch): every term searches on its own
-      d.num_cq = 0;
-      d.num_cq_items = 0;
-      for (int ti = 0; ti < desc->num_terms; ti++) dt[ti].cq = -1;
-    }
+  // ---- where each term's argument vector sits inside a row's [x | u] ----
+  for (int ti = 0; ti < desc->num_terms; ti++) {
+    DevTerm& o = dt[ti];
+    const bool on_state = o.role == ILQG_ROLE_STATE_COST || o.role == ILQG_ROLE_STATE_CONSTRAINT ||
+                          o.role == ILQG_ROLE_CHILD;
+    o.arg_off = on_state ? 0 : d.n + d.uoff[o.arg];
+    o.arg_dim = on_state ? d.n : d.udim[o.arg];
   }
   p->terms_host.assign(desc->terms, desc->terms + desc->num_terms);
   const int npts = desc->num_polylines ? desc->polyline_offsets[desc->num_polylines] : 0;
@@ -1203,8 +1095,10 @@ ilqg_status ilqg_problem_create(const ilqg_problem_desc* desc, ilqg_problem** ou
     e = hipMemcpy(p->d_segs_d, segs_d.data(), sizeof(double) * segs_d.size(), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMalloc(&p->d_cost_order, sizeof(int) * order.size());
   if (e == hipSuccess) e = hipMemcpy(p->d_cost_order, order.data(), sizeof(int) * order.size(), hipMemcpyHostToDevice);
-  // the term table is uploaded last: it carries the scatter rounds computed above
+  // the term table is uploaded last: it carries the argument offsets computed above
   if (e == hipSuccess) e = hipMemcpy(p->d_terms, dt.data(), sizeof(DevTerm) * dt.size(), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMalloc(&p->d_unfinished, 4 * sizeof(int));
+  if (e == hipSuccess) e = hipHostMalloc(&p->h_unfinished, 4 * sizeof(int));
   RowProgramHost rph;
   {
     std::string rerr;
@@ -1221,9 +1115,6 @@ ilqg_status ilqg_problem_create(const ilqg_problem_desc* desc, ilqg_problem** ou
   d.rp_lslots = rph.max_lslots;
   d.rp_maps_off = rph.maps_off;
   d.rp_maps_words = rph.maps_words;
-  if (getenv("ILQG_DEBUG_ROWPROG"))
-    std::fprintf(stderr, "row program: n=%d N=%d terms=%d words=%d persistent slots=%d pass-local slots=%d tables=%zu B\n", d.n,
-                 d.N, d.num_terms, d.row_prog_words, d.rp_pslots, d.rp_lslots, quad_tables_bytes(d, 8));
   if (e != hipSuccess) {
     ilqg_problem_destroy(p);
     return fail(ILQG_ERR_HIP, std::string("problem tables: ") + hipGetErrorString(e));
@@ -1253,8 +1144,6 @@ void ilqg_problem_destroy(ilqg_problem* p) {
   if (p->d_row_prog) (void)hipFree(p->d_row_prog);
   if (p->d_unfinished) (void)hipFree(p->d_unfinished);
   if (p->h_unfinished) (void)hipHostFree(p->h_unfinished);
-  if (p->d_pass_ids) (void)hipFree(p->d_pass_ids);
-  if (p->d_probe_pool) (void)hipFree(p->d_probe_pool);
   delete p;
 }
 
@@ -1268,9 +1157,8 @@ ilqg_status ilqg_problem_pairs(const ilqg_problem* p, ilqg_pair* pairs_host, int
 ilqg_status ilqg_workspace_bytes(const ilqg_problem* p, int32_t batch, uint64_t* bytes) {
   if (!p || !bytes) return fail(ILQG_ERR_INVALID, "null argument");
   const DevProblem& d = p->dev;
-  const WsLayout L(d.n, d.m, d.N, d.T, d.pairs.Rsz, d.pairs.rsz, p->desc.params.open_loop ? ol_row_elems(d.n, d.m, d.N) : 0,
-                   d.num_constraints, 1);
-  *bytes = uint64_t(L.total) * (p->desc.dtype == ILQG_F32 ? 4 : 8) * uint64_t(batch > 0 ? batch : 0);
+  const size_t elem = p->desc.dtype == ILQG_F32 ? 4 : 8;
+  *bytes = ws_tail(d, batch > 0 ? batch : 0, elem, p->desc.params.open_loop ? ol_row_elems(d.n, d.m, d.N) : 0).total;
   return ILQG_OK;
 }
 
@@ -1333,13 +1221,23 @@ ilqg_status ilqg_total_costs_batch(const ilqg_problem* p, int32_t batch, const v
 #undef CALL
 }
 
-static ilqg_status solve_impl(ilqg_problem* p, int32_t batch, const void* x0, void* xs, void* us, void* P,
-                              void* alpha, void* total_costs, int32_t* iters, int32_t* status, int32_t* converged,
-                              void* workspace, int32_t fixed_iters, int al_mode, int resume, const int32_t* active,
-                              void* stream) {
-  if (!p || !x0 || !xs || !us || !P || !alpha || !total_costs || !iters || !status || !converged || !workspace)
+void ilqg_default_solve_options(ilqg_solve_options* o) {
+  if (!o) return;
+  std::memset(o, 0, sizeof(*o));  // reference semantics, every scheduling choice ILQG_CHOICE_AUTO
+}
+
+ilqg_status ilqg_solve_batch_ex(ilqg_problem* p, int32_t batch, const void* x0, void* xs, void* us, void* P,
+                                void* alpha, void* total_costs, int32_t* iters, int32_t* status, int32_t* converged,
+                                void* workspace, const ilqg_solve_options* options, void* stream) {
+  if (!p || !x0 || !xs || !us || !P || !alpha || !total_costs || !iters || !status || !converged || !workspace || !options)
     return fail(ILQG_ERR_INVALID, "null argument");
   if (batch <= 0) return ILQG_OK;
+  const ilqg_solve_options& o = *options;
+  if (o.fixed_iters < 0) return fail(ILQG_ERR_INVALID, "fixed_iters must not be negative");
+  if (o.forced_steps && (o.fixed_iters <= 0 || o.augmented_lagrangian))
+    return fail(ILQG_ERR_INVALID, "forced_steps needs fixed_iters > 0 and no augmented-Lagrangian loop");
+  for (int32_t c : {o.split_trial, o.handoff, o.probe, o.counted})
+    if (c < ILQG_CHOICE_AUTO || c > ILQG_CHOICE_ON) return fail(ILQG_ERR_INVALID, "scheduling choices are ilqg_choice values");
   const DevProblem& d = p->dev;
   if (!p->mu_uniform) return fail(ILQG_ERR_UNSUPPORTED, "non-uniform control dimensions");
   hipStream_t st = (hipStream_t)stream;
@@ -1347,9 +1245,9 @@ static ilqg_status solve_impl(ilqg_problem* p, int32_t batch, const void* x0, vo
   if (d.n == NX_ && d.N == NP_ && p->mu_uniform == MU_) {                                                       \
     return p->desc.dtype == ILQG_F32                                                                            \
                ? DimsLaunch<float, NX_, NP_, MU_>::solve(p, batch, x0, xs, us, P, alpha, total_costs, iters, status,  \
-                                                    converged, workspace, fixed_iters, al_mode, resume, active, st)                      \
+                                                         converged, workspace, o, st)                            \
                : DimsLaunch<double, NX_, NP_, MU_>::solve(p, batch, x0, xs, us, P, alpha, total_costs, iters, status, \
-                                                     converged, workspace, fixed_iters, al_mode, resume, active, st);                    \
+                                                          converged, workspace, o, st);                          \
   }
   ILQG_FOR_DIMS(X)
 #undef X
@@ -1359,22 +1257,51 @@ static ilqg_status solve_impl(ilqg_problem* p, int32_t batch, const void* x0, vo
 ilqg_status ilqg_ilq_solve_batch(ilqg_problem* p, int32_t batch, const void* x0, void* xs, void* us, void* P,
                                  void* alpha, void* total_costs, int32_t* iters, int32_t* status, int32_t* converged,
                                  void* workspace, int32_t fixed_iters, void* stream) {
-  return solve_impl(p, batch, x0, xs, us, P, alpha, total_costs, iters, status, converged, workspace, fixed_iters, 0,
-                    0, nullptr, stream);
+  ilqg_solve_options o;
+  ilqg_default_solve_options(&o);
+  o.fixed_iters = fixed_iters;
+  return ilqg_solve_batch_ex(p, batch, x0, xs, us, P, alpha, total_costs, iters, status, converged, workspace, &o, stream);
 }
 
 ilqg_status ilqg_al_solve_batch(ilqg_problem* p, int32_t batch, const void* x0, void* xs, void* us, void* P,
                                 void* alpha, void* total_costs, int32_t* iters, int32_t* status, int32_t* converged,
                                 void* workspace, void* stream) {
-  return solve_impl(p, batch, x0, xs, us, P, alpha, total_costs, iters, status, converged, workspace, 0, 1, 0, nullptr, stream);
+  ilqg_solve_options o;
+  ilqg_default_solve_options(&o);
+  o.augmented_lagrangian = 1;
+  return ilqg_solve_batch_ex(p, batch, x0, xs, us, P, alpha, total_costs, iters, status, converged, workspace, &o, stream);
 }
 
 ilqg_status ilqg_solve_again_batch(ilqg_problem* p, int32_t batch, const void* x0, void* xs, void* us, void* P,
                                    void* alpha, void* total_costs, int32_t* iters, int32_t* status,
                                    int32_t* converged, void* workspace, int32_t augmented_lagrangian,
                                    const int32_t* active, void* stream) {
-  return solve_impl(p, batch, x0, xs, us, P, alpha, total_costs, iters, status, converged, workspace, 0,
-                    augmented_lagrangian ? 1 : 0, 1, active, stream);
+  ilqg_solve_options o;
+  ilqg_default_solve_options(&o);
+  o.augmented_lagrangian = augmented_lagrangian ? 1 : 0;
+  o.resume = 1;
+  o.active = active;
+  return ilqg_solve_batch_ex(p, batch, x0, xs, us, P, alpha, total_costs, iters, status, converged, workspace, &o, stream);
+}
+
+ilqg_status ilqg_solve_state_batch(const ilqg_problem* p, int32_t batch, const void* workspace,
+                                   int32_t augmented_lagrangian, void* last_merit, void* expected_decrease,
+                                   void* step, int32_t* backtracks, void* stream) {
+  if (!p || !workspace) return fail(ILQG_ERR_INVALID, "null argument");
+  if (batch <= 0) return ILQG_OK;
+  const DevProblem& d = p->dev;
+  const int ol_row = p->desc.params.open_loop ? ol_row_elems(d.n, d.m, d.N) : 0;
+  const WsLayout L(d.n, d.m, d.N, d.T, d.pairs.Rsz, d.pairs.rsz, ol_row, d.num_constraints, augmented_lagrangian ? 1 : 0);
+#define CALL(TY_)                                                                                                  \
+  [&]() -> ilqg_status {                                                                                         \
+    hipLaunchKernelGGL(solve_state_kernel<TY_>, dim3((batch + 63) / 64), dim3(64), 0, (hipStream_t)stream,        \
+                       (const TY_*)workspace, L.total, L.state, batch, (TY_*)last_merit, (TY_*)expected_decrease,   \
+                       (TY_*)step, backtracks);                                                                    \
+    HIP_TRY(hipGetLastError());                                                                                  \
+    return ILQG_OK;                                                                                              \
+  }()
+  return DT_DISPATCH(p, CALL);
+#undef CALL
 }
 
 ilqg_status ilqg_receding_horizon_shift_batch(const ilqg_problem* p, int32_t batch, const void* x0, double t0,

@@ -29,8 +29,6 @@ constexpr int kMaxT = 256;
 #define ILQG_PROFILE 0
 #endif
 constexpr bool kProfile = ILQG_PROFILE != 0;
-constexpr int kMaxClosestQueries = 8;   // distinct (polyline, x index, y index) among the polyline terms
-constexpr int kMaxClosestItems = 64;    // their segments, one lane each
 
 // (i,j) control-block table of one problem (QuadraticCostApproximation::control keys).
 struct PairTable {
@@ -48,16 +46,9 @@ struct DevTerm {
   int idx[4];
   float weight, value;
   int flags, polyline, child_begin, child_count, slot;
-  // filled by ilqg_problem_create for the term-parallel quadraticisation stage:
-  int round;     // scatter round: terms of one round touch disjoint tile entries, and a term's
-                 // round is later than that of every earlier term sharing an entry, so each
-                 // Hessian/gradient entry is accumulated in the reference's order
-  int tile_h;    // offset of the Hessian tile inside the [Q|l|R|r] image
-  int tile_g;    // offset of the gradient vector inside the same image
-  int ld;        // leading dimension of the Hessian tile
-  int arg_off;   // offset of the argument vector inside the [x|u] image
+  // filled by ilqg_problem_create:
+  int arg_off;   // offset of the argument vector inside a row's [x | u]
   int arg_dim;   // its length
-  int cq;        // index of the shared closest-point query of a polyline term, or -1
   int k_start;   // FinalTimeCost: first time step the term is active at (0 = always)
 };
 
@@ -85,14 +76,6 @@ struct DevProblem {
   const int* cost_order;
   int cost_order_stride;
   int num_constraints;
-  int num_rounds;
-  // Shared Polyline2::ClosestPoint work of the polyline terms, flattened so that a lane needs one table
-  // read: query q = (first item, segments, first segment of the polyline in the segment table, 0);
-  // item = (segment-table index, xi | yi << 8 | segment << 16 | segments << 24).  num_cq = 0 disables the
-  // pre-pass (terms search on their own).
-  int num_cq, num_cq_items;
-  int cq_tab[kMaxClosestQueries][4];
-  int cq_items[kMaxClosestItems][2];
   PairTable pairs;
   // Row program of the lane-per-time-step quadraticisation stage (ilqg_rows.hpp; built by build_row_program)
   const int* row_prog;

@@ -111,18 +111,6 @@ template <typename T> __device__ __forceinline__ void t_sincos(T x, T* s, T* c);
 template <> __device__ __forceinline__ void t_sincos<float>(float x, float* s, float* c) { sincosf(x, s, c); }
 template <> __device__ __forceinline__ void t_sincos<double>(double x, double* s, double* c) { sincos(x, s, c); }
 
-// The same RK4 (2 sub-steps) as sub_integrate, restructured for the wavefront: the 8 stage
-// evaluations of one subsystem are spread over 8 lanes (`q` = this lane's stage, lanes
-// base..base+7 form the group) so that every transcendental leaves the dependent chain.
-//   1. the trig-free "upper" components (phi, v, a — or theta, v for the unicycle) are integrated
-//      redundantly by all 8 lanes, recording the 8 stage values;
-//   2. lane q evaluates tan(phi_q) — one tan latency for all 8 stages;
-//   3. the theta chain (arithmetic only) is run redundantly from the 8 shuffled tangents;
-//   4. lane q evaluates sincos(theta_q) — one sincos latency for all 8 stages;
-//   5. px, py are accumulated from the 8 shuffled stage derivatives.
-// Every floating-point expression is the one sub_integrate evaluates, component by component, so
-// the result is the sequential RK4's; only the schedule differs (24 serial libm calls -> 2).
-// All 8 lanes return the full new state in x[].
 // x / c for a divisor c that is fixed across many divisions (6, the axle length): q = x * (1/c) corrected by
 // one residual step — q' = q + (x - q c) (1/c), both through FMA — which is the correctly rounded quotient
 // (Markstein) at a third of the instructions of the IEEE division sequence; the RK4 has 22 of them per step.
@@ -136,117 +124,6 @@ __device__ __forceinline__ float div_by(float x, float c, float rc) {
   const float q = x * rc;
   const float r = __builtin_fmaf(-q, c, x);
   return __builtin_fmaf(r, rc, q);
-}
-
-// DIST: the problem may contain the disturbed unicycle; (d0, d1) are then the other player's controls (zero
-// for every other kind) and enter the position rates.  Compiled out otherwise.
-// DUB: the problem may contain the one-control Dubins car (constant speed L); compiled out otherwise, like DIST.
-template <typename T, bool DIST = false, bool DUB = false>
-__device__ __forceinline__ void sub_integrate_lanes(int kind, T L, double interval, T* x, T u0, T u1, int q,
-                                                    int base, T d0 = T(0), T d1 = T(0)) {
-  const T h = T(interval / 2.0);
-  const T six = T(6.0), rsix = T(1.0) / T(6.0), rL = T(1.0) / L;
-  const bool dubins = DUB && kind == ILQG_DYN_DUBINS_CAR;  // the unicycle's path with a constant speed L
-  const bool car = DIST ? false : (kind != ILQG_DYN_UNICYCLE_4D && !dubins);  // DIST problems hold unicycle rows only
-  const int vi = car ? 4 : 3;
-  // ---- 1. upper components, all stages ----
-  T up[6];  // working copy; lower components are left untouched here
-#pragma unroll
-  for (int e = 0; e < 6; e++) up[e] = x[e];
-  // v at the 8 stage points (the theta chain reads them with constant indices), and THIS lane's stage values
-  // picked as they are produced — a select chain over an 8-entry array is turned into a stack array with a
-  // per-lane index by the compiler, i.e. scratch stores and a dependent scratch load in the serial loop.
-  T v_s[8];
-  T my_ang = T(0), my_v = T(0);
-  auto pick = [&](int idx, T ang, T v_state) {
-    const T v = dubins ? L : v_state;
-    v_s[idx] = v;
-    my_ang = (q == idx) ? ang : my_ang;
-    my_v = (q == idx) ? v : my_v;
-  };
-  auto upper_f = [&](const T* xx, T* xd) {
-#pragma unroll
-    for (int e = 0; e < 6; e++) xd[e] = T(0);
-    if (!car) {
-      xd[2] = u0;
-      xd[3] = dubins ? T(0) : u1;
-    } else {
-      xd[3] = u0;
-      if (kind == ILQG_DYN_CAR_5D) {
-        xd[4] = u1;
-      } else {
-        xd[4] = xx[5];
-        xd[5] = u1;
-      }
-    }
-  };
-  const int ai = car ? 3 : 2;
-#pragma unroll
-  for (int s = 0; s < 2; s++) {
-    T k1[6], k2[6], k3[6], k4[6], xt[6];
-    pick(4 * s + 0, up[ai], up[vi]);
-    upper_f(up, k1);
-#pragma unroll
-    for (int e = 2; e < 6; e++) { k1[e] = h * k1[e]; xt[e] = up[e] + T(0.5) * k1[e]; }
-    pick(4 * s + 1, xt[ai], xt[vi]);
-    upper_f(xt, k2);
-#pragma unroll
-    for (int e = 2; e < 6; e++) { k2[e] = h * k2[e]; xt[e] = up[e] + T(0.5) * k2[e]; }
-    pick(4 * s + 2, xt[ai], xt[vi]);
-    upper_f(xt, k3);
-#pragma unroll
-    for (int e = 2; e < 6; e++) { k3[e] = h * k3[e]; xt[e] = up[e] + k3[e]; }
-    pick(4 * s + 3, xt[ai], xt[vi]);
-    upper_f(xt, k4);
-#pragma unroll
-    for (int e = 2; e < 6; e++) {
-      k4[e] = h * k4[e];
-      up[e] += div_by(k1[e] + T(2.0) * (k2[e] + k3[e]) + k4[e], six, rsix);
-    }
-  }
-  // ---- 2./3. theta at the 8 stage points ----
-  T my_th = my_ang;  // unicycle: the angle integrated above is the heading itself
-  if (car) {
-    const T tq = t_tan(my_ang);
-    T tan_s[8];
-#pragma unroll
-    for (int e = 0; e < 8; e++) tan_s[e] = shfl(tq, base + e);
-    T th = x[2];
-    auto pick_th = [&](int idx, T v) { my_th = (q == idx) ? v : my_th; };
-#pragma unroll
-    for (int s = 0; s < 2; s++) {
-      const T k1 = h * (div_by(v_s[4 * s + 0], L, rL) * tan_s[4 * s + 0]);
-      pick_th(4 * s + 0, th);
-      pick_th(4 * s + 1, th + T(0.5) * k1);
-      const T k2 = h * (div_by(v_s[4 * s + 1], L, rL) * tan_s[4 * s + 1]);
-      pick_th(4 * s + 2, th + T(0.5) * k2);
-      const T k3 = h * (div_by(v_s[4 * s + 2], L, rL) * tan_s[4 * s + 2]);
-      pick_th(4 * s + 3, th + k3);
-      const T k4 = h * (div_by(v_s[4 * s + 3], L, rL) * tan_s[4 * s + 3]);
-      th += div_by(k1 + T(2.0) * (k2 + k3) + k4, six, rsix);
-    }
-    up[2] = th;
-  }
-  // ---- 4. one sincos per lane ----
-  T sn, cs;
-  t_sincos(my_th, &sn, &cs);
-  const T kxq = DIST ? h * (my_v * cs + d0) : h * (my_v * cs);
-  const T kyq = DIST ? h * (my_v * sn + d1) : h * (my_v * sn);
-  // ---- 5. positions ----
-  T px = x[0], py = x[1];
-#pragma unroll
-  for (int s = 0; s < 2; s++) {
-    const T a1 = shfl(kxq, base + 4 * s + 0), a2 = shfl(kxq, base + 4 * s + 1);
-    const T a3 = shfl(kxq, base + 4 * s + 2), a4 = shfl(kxq, base + 4 * s + 3);
-    const T b1 = shfl(kyq, base + 4 * s + 0), b2 = shfl(kyq, base + 4 * s + 1);
-    const T b3 = shfl(kyq, base + 4 * s + 2), b4 = shfl(kyq, base + 4 * s + 3);
-    px += div_by(a1 + T(2.0) * (a2 + a3) + a4, six, rsix);
-    py += div_by(b1 + T(2.0) * (b2 + b3) + b4, six, rsix);
-  }
-  x[0] = px;
-  x[1] = py;
-#pragma unroll
-  for (int e = 2; e < 6; e++) x[e] = up[e];
 }
 
 // The RK4 (2 sub-steps) of one subsystem with ONE STAGE PER LANE and the stage values in closed form.
@@ -341,87 +218,6 @@ __device__ __forceinline__ void sub_integrate_stages(int kind, T L, double inter
   }
 }
 
-// Per-model Jacobian entries added on top of (I, 0)
-// (single_player_unicycle_4d.h:102-116, single_player_car_5d.h:113-133,
-//  single_player_car_6d.h:116-138; mixed float*double products kept).
-// A: pointer to the (o,o) corner of a column-major matrix with leading dim ld;
-// B: pointer to the (o,uo) corner, same ld.
-// The trigonometry comes in as arguments: (sth, cth) = sincos(heading), (sphi, cphi) = sincos(steering
-// angle) for the car models — callers evaluate them for all subsystems at once, one sincos latency per
-// angle instead of a cos, a sin, a cos and a tan in sequence; tan(phi) is formed as sphi / cphi.
-// aux0 / aux1: only read by the Air3D rows (the evader's turn rate and the pursuer's speed).
-template <typename T>
-__device__ __forceinline__ void sub_linearize_trig(int kind, T L, double dt, const T* x, T sth, T cth, T sphi, T cphi,
-                                                   T* A, T* B, int ld, T aux0 = T(0), T aux1 = T(0)) {
-  if (kind == ILQG_DYN_AIR_3D_EVADER) {  // air_3d.h:127-146
-    const T ctd = T(double(cth) * dt), std_ = T(double(sth) * dt);
-    A[0 + ld * 1] += T(double(aux0) * dt);
-    A[0 + ld * 2] -= aux1 * std_;
-    A[1 + ld * 0] -= T(double(aux0) * dt);
-    A[1 + ld * 2] += aux1 * ctd;
-    B[0] = T(double(x[1]) * dt);
-    B[1] = T(double(-x[0]) * dt);
-    B[2] = T(-dt);
-    return;
-  }
-  if (kind == ILQG_DYN_AIR_3D_PURSUER) {  // Bs[1](rtheta, omega2) = dt (:148): last row of the 3-state block before
-    B[-1] = T(dt);
-    return;
-  }
-  if (kind == ILQG_DYN_PLANAR_DISTURBANCE) {
-    // Bs[1](px, dx) = Bs[1](py, dy) = dt (two_player_unicycle_4d.h:135-136): rows of the 4-state block that
-    // ends where this (empty) block begins
-    B[-4 + ld * 0] = T(dt);
-    B[-3 + ld * 1] = T(dt);
-    return;
-  }
-  if (kind == ILQG_DYN_POINT_MASS_2D) {  // single_player_point_mass_2d.h:101-110
-    A[0 + ld * 2] += T(dt);
-    A[1 + ld * 3] += T(dt);
-    B[2 + ld * 0] = T(dt);
-    B[3 + ld * 1] = T(dt);
-    return;
-  }
-  if (kind == ILQG_DYN_DUBINS_CAR) {  // single_player_dubins_car.h:105-117
-    const T ctd = T(double(cth) * dt), std_ = T(double(sth) * dt);
-    A[0 + ld * 2] += -L * std_;
-    A[1 + ld * 2] += L * ctd;
-    B[2 + ld * 0] = T(dt);
-    return;
-  }
-  const int v = is_unicycle(kind) ? 3 : 4;
-  const T ct = T(double(cth) * dt);
-  const T st = T(double(sth) * dt);
-  A[0 + ld * 2] += -x[v] * st;
-  A[0 + ld * v] += ct;
-  A[1 + ld * 2] += x[v] * ct;
-  A[1 + ld * v] += st;
-  if (is_unicycle(kind)) {
-    B[2 + ld * 0] = T(dt);
-    B[3 + ld * 1] = T(dt);
-  } else {
-    const T tphi = sphi / cphi;
-    A[2 + ld * 3] += T(double(x[4]) * dt / double(L * cphi * cphi));
-    A[2 + ld * 4] += T(double(tphi) * dt / double(L));
-    if (kind == ILQG_DYN_CAR_5D) {
-      B[3 + ld * 0] = T(dt);
-      B[4 + ld * 1] = T(dt);
-    } else {
-      A[4 + ld * 5] += T(dt);
-      B[3 + ld * 0] = T(dt);
-      B[5 + ld * 1] = T(dt);
-    }
-  }
-}
-
-template <typename T>
-__device__ __forceinline__ void sub_linearize(int kind, T L, double dt, const T* x, T* A, T* B, int ld) {
-  T sth, cth, sphi = T(0), cphi = T(1);
-  t_sincos(x[2], &sth, &cth);
-  if (kind == ILQG_DYN_CAR_5D || kind == ILQG_DYN_CAR_6D) t_sincos(x[3], &sphi, &cphi);
-  sub_linearize_trig<T>(kind, L, dt, x, sth, cth, sphi, cphi, A, B, ld);
-}
-
 // ---------------------------------------------------------------------------
 // Geometry
 // ---------------------------------------------------------------------------
@@ -506,10 +302,8 @@ enum {
   LC_UDIM = LC_UOFF + kMaxPlayers + 1, LC_PARAM = LC_UDIM + kMaxPlayers, LC_SREG = LC_PARAM + kMaxPlayers,
   LC_CREG = LC_SREG + kMaxPlayers, LC_STRUCT = LC_CREG + kMaxPlayers, LC_PI = LC_STRUCT + kMaxPlayers,
   LC_PJ = LC_PI + kMaxPairs, LC_ROFF = LC_PJ + kMaxPairs, LC_RGOFF = LC_ROFF + kMaxPairs,
-  LC_FROMCOST = LC_RGOFF + kMaxPairs, LC_PII = LC_FROMCOST + kMaxPairs, LC_CQTAB = LC_PII + kMaxPlayers,
-  LC_CQITEMS = LC_CQTAB + 4 * kMaxClosestQueries, LC_COUNT = (LC_CQITEMS + 2 * kMaxClosestItems + 3) & ~3
+  LC_FROMCOST = LC_RGOFF + kMaxPairs, LC_PII = LC_FROMCOST + kMaxPairs, LC_COUNT = (LC_PII + kMaxPlayers + 3) & ~3
 };
-constexpr int kClosestStride = 12;  // LDS image of a Closest<T>: cx cy ssd is_vertex is_endpoint seg[7]
 
 // Polyline2::ClosestPoint, src/polyline2.cpp:105-174 — linear scan over the 1..15 segments of a
 // lane; the "shortcut" sign rule at interior vertices and the 1e-4 endpoint rule are reproduced.
@@ -557,86 +351,6 @@ __device__ __forceinline__ Closest<T> polyline_closest(const QuadTables<T>& tb, 
   const T bx = out.cx - sl.p2x, by = out.cy - sl.p2y;
   out.is_endpoint = (ax * ax + ay * ay < T(1e-4f)) || (bx * bx + by * by < T(1e-4f));
   return out;
-}
-
-// The same search, shared and lane-parallel.  Several terms of a player (lane centre, left and right
-// boundary) ask for the closest point of the same polyline to the same position, and a lane with k
-// segments makes every other lane of the wave wait k iterations.  closest_items evaluates ONE segment per
-// lane for every distinct query; closest_select lets one lane per query pick the winner exactly as the
-// sequential scan does (strictly smaller |signed squared distance| wins, so the first minimum is kept;
-// the shortcut-sign rule only flips the sign of a candidate, never its magnitude) and leaves a Closest<T>
-// image in LDS for the terms to read.
-template <typename T>
-__device__ __forceinline__ void closest_items(const QuadTables<T>& tb, int num_items, const T* sx, T* sitem, int t) {
-  if (t >= num_items) return;
-  const int seg_index = tb.lc[LC_CQITEMS + 2 * t], packed = tb.lc[LC_CQITEMS + 2 * t + 1];
-  const int c = (packed >> 16) & 255, nseg = (packed >> 24) & 255;
-  const T qx = sx[packed & 255], qy = sx[(packed >> 8) & 255];
-  const T* sb = tb.segs + size_t(seg_index) * kSegStride;
-  const Seg<T> s = load_seg<T>(sb);
-  T px, py, cur;
-  bool se;
-  seg_closest(s, qx, qy, &px, &py, &se, &cur);
-  const bool at2 = (px == s.p2x && py == s.p2y);
-  const bool at1 = (px == s.p1x && py == s.p1y);
-  if (se && (c > 0 || at2) && (c < nseg - 1 || at1)) {
-    const Seg<T> sc = load_seg<T>(sb + (at1 ? 7 : 14));
-    cur *= seg_side(sc, qx, qy) ? sgn(cur) : -sgn(cur);
-  }
-  sitem[4 * t + 0] = px;
-  sitem[4 * t + 1] = py;
-  sitem[4 * t + 2] = cur;
-  sitem[4 * t + 3] = se ? T(1) : T(0);
-}
-
-template <typename T>
-__device__ __forceinline__ void closest_select(const QuadTables<T>& tb, int num_cq, const T* sitem, T* sclo, int t) {
-  if (t >= num_cq) return;
-  const int first_item = tb.lc[LC_CQTAB + 4 * t], nseg = tb.lc[LC_CQTAB + 4 * t + 1];
-  const T* base = tb.segs + size_t(tb.lc[LC_CQTAB + 4 * t + 2]) * kSegStride;
-  T best = dinf<T>();
-  int bi = 0;
-  for (int c0 = 0; c0 < nseg; c0 += 8) {  // candidates eight at a time: the LDS reads overlap
-    T cur[8];
-#pragma unroll
-    for (int u = 0; u < 8; u++) cur[u] = sitem[4 * (first_item + (c0 + u < nseg ? c0 + u : nseg - 1)) + 2];
-#pragma unroll
-    for (int u = 0; u < 8; u++)
-      if (c0 + u < nseg && t_abs(cur[u]) < t_abs(best)) {
-        best = cur[u];
-        bi = c0 + u;
-      }
-  }
-  const T* it = sitem + 4 * (first_item + bi);
-  const T* sg = base + size_t(bi) * kSegStride;
-  const T* sl = base + size_t(nseg - 1) * kSegStride;
-  const T cx = it[0], cy = it[1], sev = it[3];
-  const T s0x = base[0], s0y = base[1], slx = sl[2], sly = sl[3];
-  T sgv[7];
-#pragma unroll
-  for (int e = 0; e < 7; e++) sgv[e] = sg[e];
-  T* o = sclo + kClosestStride * t;
-  o[0] = cx;
-  o[1] = cy;
-  o[2] = best;
-  o[3] = sev;
-  const T ax = cx - s0x, ay = cy - s0y;
-  const T bx = cx - slx, by = cy - sly;
-  o[4] = ((ax * ax + ay * ay < T(1e-4f)) || (bx * bx + by * by < T(1e-4f))) ? T(1) : T(0);
-#pragma unroll
-  for (int e = 0; e < 7; e++) o[5 + e] = sgv[e];
-}
-
-template <typename T>
-__device__ __forceinline__ Closest<T> closest_load(const T* o) {
-  Closest<T> c;
-  c.cx = o[0];
-  c.cy = o[1];
-  c.ssd = o[2];
-  c.is_vertex = o[3] != T(0);
-  c.is_endpoint = o[4] != T(0);
-  c.seg = load_seg<T>(o + 5);
-  return c;
 }
 
 // ---------------------------------------------------------------------------
@@ -782,8 +496,7 @@ struct TermOut {
 // caller always has it (the polyline searches are compiled out of this function).
 template <typename T, typename V, bool HAVE_PRE = false>
 __device__ __forceinline__ void term_compute_leaf(const QuadTables<T>& tb, const DevTerm& c, const V& v, T lambda,
-                                                  T mu, TermOut<T>* o, const T* sclo = nullptr,
-                                                  const Closest<T>* pre = nullptr) {
+                                                  T mu, TermOut<T>* o, const Closest<T>* pre = nullptr) {
   const T w = T(c.weight), val = T(c.value);
   const bool oriented = c.flags & ILQG_FLAG_ORIENTED;
   o->pattern = PAT_NONE;
@@ -825,9 +538,7 @@ __device__ __forceinline__ void term_compute_leaf(const QuadTables<T>& tb, const
       if constexpr (HAVE_PRE) {
         cl = *pre;
       } else {
-        cl = pre != nullptr ? *pre
-             : (sclo != nullptr && c.cq >= 0) ? closest_load<T>(sclo + kClosestStride * c.cq)
-                                              : polyline_closest<T>(tb, c.polyline, px, py);
+        cl = pre != nullptr ? *pre : polyline_closest<T>(tb, c.polyline, px, py);
       }
       T dx, dy;
       if (semi) {
@@ -949,51 +660,6 @@ __device__ __forceinline__ void term_compute_leaf(const QuadTables<T>& tb, const
       o->gx = dx;
       o->hxx = ddx;
       return;
-    }
-  }
-}
-
-// Top-level term: ExtremeValueCost dispatches to its active child (src/extreme_value_cost.cpp:51-85).
-template <typename T, typename V>
-__device__ __forceinline__ void term_compute(const QuadTables<T>& tb, const DevTerm& c, const V& v, T lambda, T mu,
-                                             TermOut<T>* o, const T* sclo = nullptr) {
-  if (c.kind == ILQG_COST_EXTREME_VALUE) {
-    T value;
-    const int best = extreme_child<T, V>(tb, c, v, c.arg_dim, &value);
-    const DevTerm child = tb.terms[best];
-    term_compute_leaf<T, V>(tb, child, v, lambda, mu, o);
-    o->value = value;
-    return;
-  }
-  term_compute_leaf<T, V>(tb, c, v, lambda, mu, o, sclo);
-}
-
-// Scatter one term's contribution into its LDS tiles (H column-major with leading dim ld).
-template <typename T>
-__device__ __forceinline__ void term_scatter(const TermOut<T>& o, const T* v, int dim, T* H, int ld, T* G) {
-  if (o.pattern == PAT_SINGLE) {
-    G[o.i0] += o.gx;
-    H[o.i0 + ld * o.i0] += o.hxx;
-  } else if (o.pattern == PAT_PAIR2) {
-    G[o.i0] += o.gx;
-    G[o.i1] += o.gy;
-    H[o.i0 + ld * o.i0] += o.hxx;
-    H[o.i1 + ld * o.i1] += o.hyy;
-    H[o.i0 + ld * o.i1] += o.hxy;
-    H[o.i1 + ld * o.i0] += o.hxy;
-  } else if (o.pattern == PAT_PAIR4) {
-    const int x1 = o.i0, y1 = o.i1, x2 = o.i2, y2 = o.i3;
-    G[x1] += o.gx; G[x2] -= o.gx; G[y1] += o.gy; G[y2] -= o.gy;
-    H[x1 + ld * x1] += o.hxx; H[x1 + ld * x2] -= o.hxx; H[x2 + ld * x1] -= o.hxx; H[x2 + ld * x2] += o.hxx;
-    H[y1 + ld * y1] += o.hyy; H[y1 + ld * y2] -= o.hyy; H[y2 + ld * y1] -= o.hyy; H[y2 + ld * y2] += o.hyy;
-    H[x1 + ld * y1] += o.hxy; H[y1 + ld * x1] += o.hxy;
-    H[x1 + ld * y2] -= o.hxy; H[y2 + ld * x1] -= o.hxy;
-    H[x2 + ld * y1] -= o.hxy; H[y1 + ld * x2] -= o.hxy;
-    H[x2 + ld * y2] += o.hxy; H[y2 + ld * x2] += o.hxy;
-  } else if (o.pattern == PAT_ALL) {
-    for (int i = 0; i < dim; i++) {
-      G[i] += o.gx * (v[i] - o.gy);
-      H[i + ld * i] = H[i + ld * i] + o.gx;
     }
   }
 }

@@ -174,9 +174,10 @@ __device__ __forceinline__ void rows_writeout_small(T* g0, size_t stride, int W,
 // term's pattern:
 //   SINGLE  G(d), H(d,d)
 //   PAIR2   G(x), G(y), H(x,x), H(y,y), H(x,y), H(y,x)
-//   PAIR4   G(x1), G(x2), G(y1), G(y2), then the sixteen H entries in term_scatter's order
+//   PAIR4   G(x1), G(x2), G(y1), G(y2), then H(x1,x1) (x1,x2) (x2,x1) (x2,x2), the same four for y, then
+//           H(x1,y1) (y1,x1) (x1,y2) (y2,x1) (x2,y1) (y1,x2) (x2,y2) (y2,x2)  — with s = (+,+,-,-) over (x1,y1,x2,y2):
+//           G[p] += s_p g_type(p), H(p,q) += s_p s_q h_type(p),type(q)
 //   ALL     G(0..dim-1), H(0,0)..H(dim-1,dim-1)
-// (term_scatter in ilqg_models.hpp is the row-image form of the same sums.)
 // The slots of one leaf are distinct (build_row_program checks), so the read-modify-writes of a term do not depend
 // on each other: all reads, then all adds, then all writes — one LDS round trip per term instead of one per entry.
 template <typename T, typename V>
@@ -410,11 +411,13 @@ __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* map
         c.weight = __int_as_float(od[RO_WEIGHT]); c.value = __int_as_float(od[RO_VALUE]);
         c.polyline = 0; c.slot = od[RO_SLOT]; c.arg_off = od[RO_ARG_OFF]; c.arg_dim = od[RO_ARG_DIM];
         c.k_start = od[RO_K_START];
-        c.arg = 0; c.child_begin = 0; c.child_count = 0; c.round = 0; c.tile_h = 0; c.tile_g = 0; c.ld = 0; c.cq = -1;
+        c.arg = 0; c.child_begin = 0; c.child_count = 0;
         if (mode == ROP_JACOBIAN) {
-          // ---- ConcatenatedDynamicalSystem::Linearize, one subsystem (src/concatenated_dynamical_system.cpp:86-107).
-          // Same expressions as sub_linearize_trig (ilqg_models.hpp), which documents the reference lines; the
-          // entries go to the slots the program lists in this order.
+          // ---- ConcatenatedDynamicalSystem::Linearize, one subsystem (src/concatenated_dynamical_system.cpp:86-107):
+          // the entries each model's Linearize adds to (I, 0) — single_player_unicycle_4d.h:102-116,
+          // single_player_car_5d.h:113-133, single_player_car_6d.h:116-138 (mixed float * double products kept),
+          // single_player_dubins_car.h:105-117, air_3d.h:127-148 — go to the slots the program lists in this order;
+          // the constant entries (dt, -dt, the identity) are in the word maps.
           const int kind = c.kind, xo = c.idx[0], uo = c.idx[1];
           const T L = T(c.weight);
           const RowArg<T> x{arg + xo * cw + lane, cw};
@@ -470,7 +473,7 @@ __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* map
         ILQG_QPH(2);
 #endif
         TermOut<T> o;
-        term_compute_leaf<T, RowArg<T>, true>(QuadTables<T>{}, c, v, lambda, a.mu, &o, nullptr, &cc);
+        term_compute_leaf<T, RowArg<T>, true>(QuadTables<T>{}, c, v, lambda, a.mu, &o, &cc);
 #if ILQG_PROFILE2
         ILQG_QPH(3);
 #endif

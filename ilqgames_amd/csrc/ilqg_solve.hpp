@@ -43,6 +43,7 @@ struct SolveArgs {
   // lists the ones that need another pass, and the rows of one instance a workgroup of the row kernel takes
   const int* ids;
   int* ids_next;
+  const T* forced_steps;  // [B][fixed_iters] or null: test mode, iteration q of instance b takes this step, no Armijo test
   int defer_forward;    // 1: the sweep's forward pass / ExpectedDecrease runs in the next trial pass, beside the rollout
   int rows_cw;          // rows per chunk of the row stage (ilqg_rows.hpp): 64, 32 or 16, chosen by the launcher
   T* probe_pool;        // speculative line search: [listed instances][probe_k] entries of ProbeEntry::total elements
@@ -682,7 +683,7 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const s
       if (qmode == Q_TRIAL) {
         const T merit = uniform(merit_reduce<T>(p, w + L.mpart, sm_quad0, int(qe)));
         const T scaled = T(prm.expected_decrease_fraction) * s.step * s.expected_decrease;
-        accepted = (s.last_merit - merit >= scaled);  // CheckArmijoCondition :350-362
+        accepted = (s.last_merit - merit >= scaled) || sa.forced_steps != nullptr;  // CheckArmijoCondition :350-362
         if (accepted) {
           const T diff = s.last_merit - merit;
           s.has_converged =
@@ -788,7 +789,8 @@ __device__ __forceinline__ void lq_part_instance(const DevProblem& p, const Solv
     else
       st->expected_decrease = sm[ed_slot];
     st->num_iterations += 1;
-    st->step = T(sa.prm.initial_alpha_scaling);
+    st->step = sa.forced_steps ? sa.forced_steps[size_t(b) * sa.fixed_iters + (st->num_iterations - 1)]
+                               : T(sa.prm.initial_alpha_scaling);
     st->bt = 0;
     st->stage = ST_ROLLOUT;
     if (kProfile && sa.prof) sa.prof[size_t(b) * 96 + 2] += clock64() - pr_start;

@@ -11,7 +11,7 @@ namespace ilqg {
 // ---------------------------------------------------------------------------
 // Rollout — ILQSolver::CurrentOperatingPoint (src/ilq_solver.cpp:174-206).
 // Eight lanes per subsystem run the RK4 (2 sub-steps) with one stage each, so the 24 serial
-// sin/cos/tan of a step collapse to two libm latencies (sub_integrate_lanes); lanes rho < m
+// sin/cos/tan of a step collapse to two (sub_integrate_stages); lanes rho < m
 // evaluate u_rho = u_ref - P[rho,:] dx - s*alpha (Strategy::operator(), strategy.h:73-76)
 // against dx broadcast through LDS.  The step's (P, alpha, u_ref, x_ref) block is
 // prefetched one step ahead so the only exposed latency is the dependent chain.
@@ -170,15 +170,9 @@ __device__ __forceinline__ void rollout_instance(const DevProblem& p, const Roll
 }
 
 // ---------------------------------------------------------------------------
-// Linearise + quadraticise one time step of one instance:
-//   ILQSolver::ComputeLinearization (src/ilq_solver.cpp:437-455),
-//   ILQSolver::ComputeCostQuadraticization (:471-490) -> PlayerCost::Quadraticize
-//   (src/player_cost.cpp:194-225), plus the per-step pieces of MeritFunction
-//   (:400-435) and TotalCosts (:220-257).
-// The step's [A | B | Q | l | R | r] image is assembled in LDS (lane i < N walks
-// player i's cost list in the reference's accumulation order and scatters <= 16
-// entries per term), then streamed out with fully coalesced stores — the stage's
-// cost is the ~n^2 N words it has to write.
+// Cost tables in LDS for the kernels that walk a player's cost list with a lane-varying index (strategy
+// costs / Nash checks, the multiplier update of the exit path).  The linearise + quadraticise stage itself is
+// ilqg_rows.hpp (one lane per time step, tables in scalar memory).
 // ---------------------------------------------------------------------------
 // Bytes of LDS the cost tables take (terms, precomputed segments, polyline offsets, cost order).
 __host__ __device__ inline size_t quad_tables_bytes(const DevProblem& p, size_t elem) {
@@ -226,8 +220,6 @@ __device__ __forceinline__ QuadTables<T> quad_tables_load(const DevProblem& p, v
     lc[LC_RGOFF + t] = p.pairs.rgoff[t];
     lc[LC_FROMCOST + t] = p.pairs.from_cost[t];
   }
-  for (int e = t; e < 4 * kMaxClosestQueries; e += NT) lc[LC_CQTAB + e] = p.cq_tab[e / 4][e % 4];
-  for (int e = t; e < 2 * kMaxClosestItems; e += NT) lc[LC_CQITEMS + e] = p.cq_items[e / 2][e % 2];
   __syncthreads();
   QuadTables<T> tb;
   tb.terms = reinterpret_cast<const DevTerm*>(terms_i);
@@ -252,306 +244,6 @@ struct QuadArgs {
   T* cost_part;        // [T][N] PlayerCost::Evaluate or nullptr
   long long* phacc = nullptr;  // optional phase profile accumulators (registers of the caller)
 };
-
-__host__ __device__ inline int quad_lds_elems(int n, int m, int N, int Rsz, int rsz, int num_terms) {
-  // + the shared closest-point pre-pass: 4 scalars per segment item, a Closest image per query
-  return n + m + n * n + n * m + N * n * n + N * n + Rsz + rsz + num_terms + 4 * kMaxClosestItems +
-         kClosestStride * kMaxClosestQueries;
-}
-
-// Executed by ONE wavefront (lane t of 64) with its own LDS scratch `sm`, so several waves of a
-// workgroup can take different time steps of the same instance concurrently.
-//
-// The step comes in three pieces so that a caller looping over steps can request the NEXT step's
-// argument before it issues THIS step's stores: vmcnt retires in order, so a load queued behind 8 KB of
-// stores would not be usable until they have all drained.
-template <typename T>
-struct LinquadCarry {
-  T ms1, ms2, ctot;  // merit pieces and PlayerCost::Evaluate of this lane's player (lanes < N)
-};
-
-// Element t of the step's [x | u] row (0 for lanes beyond n + m).
-template <typename T>
-__device__ __forceinline__ T linquad_load_arg(const QuadArgs<T>& a, int k, int n, int m, int t) {
-  T argv = T(0);
-  if (t < n)
-    argv = a.xs[size_t(k) * n + t];
-  else if (t < n + m)
-    argv = a.us[size_t(k) * m + (t - n)];
-  return argv;
-}
-
-template <typename T, int CN = 0, int CM = 0, int CNP = 0>
-__device__ __forceinline__ void linquad_compute(const DevProblem& p, const QuadTables<T>& tb, const QuadArgs<T>& a,
-                                                int k, T* sm, int t, T argv, LinquadCarry<T>& carry) {
-  const int n = CN > 0 ? CN : p.n, m = CM > 0 ? CM : p.m, N = CNP > 0 ? CNP : p.N;
-  constexpr int NT = 64;
-  const PairTable& pt = p.pairs;
-  T* sx = sm;  // [x | u] argument image
-  T* sA = sx + n + m;
-  T* sB = sA + n * n;
-  T* sQ = sB + n * m;  // [Q | l | R | r] tile image, same element order as the global arrays
-  T* sl = sQ + N * n * n;
-  T* sR = sl + N * n;
-  T* sr = sR + pt.Rsz;
-  const bool do_quad = a.Q != nullptr || a.merit_part != nullptr;
-  long long qc0 = (kProfile && a.phacc) ? clock64() : 0, qc1;
-#define ILQG_QPH(i) do { if (kProfile && a.phacc) { __builtin_amdgcn_sched_barrier(0); qc1 = clock64(); __builtin_amdgcn_sched_barrier(0); a.phacc[i] += qc1 - qc0; qc0 = qc1; } } while (0)
-  // ---- load the argument, initialise the tiles ----
-  // The (x, u) row was requested by the caller (argv); the tile image is cleared while that load is in
-  // flight (16-byte LDS writes where the image is 16-byte aligned and even-sized).
-  // PlayerCost::Quadraticize vs QuadraticizeControlCosts (src/ilq_solver.cpp:483-487)
-  auto is_full = [&](int i) {
-    return tb.lc[LC_STRUCT + i] == ILQG_SUM || (a.t_extreme ? a.t_extreme[i] == k : k == 0);
-  };
-  {
-    const int z0 = a.A ? 0 : n * n + n * m;  // clear [A | B] only when linearising
-    const int z1 = do_quad ? n * n + n * m + N * n * n + N * n + pt.Rsz + pt.rsz : n * n + n * m;
-    T* zb = sA;
-    if (((n + m) & 1) == 0 && (z0 & 1) == 0 && (z1 & 1) == 0) {
-      typedef T pair2 __attribute__((ext_vector_type(2)));
-      const pair2 zz = {T(0), T(0)};
-      for (int e = z0 + 2 * t; e < z1; e += 2 * NT) *reinterpret_cast<pair2*>(zb + e) = zz;
-    } else {
-      for (int e = z0 + t; e < z1; e += NT) zb[e] = T(0);
-    }
-  }
-  if (t < n + m) sx[t] = argv;
-  lds_sync(NT <= 64);
-  if (t < n) {
-    if (a.A) sA[t * (n + 1)] = T(1);  // LinearDynamicsApproximation starts from (I, 0)
-    if (do_quad)
-      for (int i = 0; i < N; i++)
-        sQ[i * n * n + t * (n + 1)] = T(__int_as_float(tb.lc[LC_SREG + i]));  // sigma_x I (player_cost.cpp:196)
-  }
-  if (do_quad && t < pt.npairs) {
-    // sigma_u I on every control block the reference would have created (player_cost.cpp:70-74)
-    const int i = tb.lc[LC_PI + t];
-    if (is_full(i) || tb.lc[LC_FROMCOST + t]) {
-      const int mj = tb.lc[LC_UDIM + tb.lc[LC_PJ + t]];
-      const int ro = tb.lc[LC_ROFF + t];
-      const T creg = T(__int_as_float(tb.lc[LC_CREG + i]));
-      for (int d = 0; d < mj; d++) sR[ro + d + mj * d] = creg;
-    }
-  }
-  lds_sync(NT <= 64);
-  ILQG_QPH(0);
-  if (a.A) {
-    // lanes [0, N): heading of subsystem t; lanes [N, 2N): steering angle of subsystem t - N.  One
-    // sincos for the whole wave, then the steering pair hops N lanes down.
-    const int sub = t < N ? t : (t < 2 * N ? t - N : 0);
-    const int xo = tb.lc[LC_XOFF + sub];
-    T sn, cs;
-    t_sincos(sx[xo + (t < N ? 2 : 3)], &sn, &cs);
-    const T sphi = shfl(sn, (t + N) & 63), cphi = shfl(cs, (t + N) & 63);
-    if (t < N) {
-      const int uo = tb.lc[LC_UOFF + t];
-      const int kind = tb.lc[LC_KIND + t];
-      T aux0 = T(0), aux1 = T(0);
-      if (kind == ILQG_DYN_AIR_3D_EVADER) {  // its own turn rate and the pursuer's speed (the next row's parameter)
-        aux0 = sx[n + uo];
-        aux1 = T(__int_as_float(tb.lc[LC_PARAM + t + 1]));
-      }
-      sub_linearize_trig<T>(kind, T(__int_as_float(tb.lc[LC_PARAM + t])), p.dt, sx + xo, sn, cs, sphi, cphi,
-                            sA + xo + n * xo, sB + xo + n * uo, n, aux0, aux1);
-    }
-  }
-  // ---- one lane per cost term: value + derivative pattern (the expensive part, in parallel) ----
-  const double tt = double(k) * p.dt;
-  const int tidx = int(static_cast<size_t>((tt - a.t_init) / p.dt));  // relative_time_tracker.h:69-72
-  T* svals = sr + pt.rsz;  // [num_terms] term values for TotalCosts
-  // ---- shared Polyline2::ClosestPoint searches: one lane per (query, segment), one lane per query ----
-  T* sitem = svals + p.num_terms;
-  T* sclo = sitem + 4 * kMaxClosestItems;
-  const bool shared_closest = p.num_cq > 0;
-  if (shared_closest) {
-    closest_items<T>(tb, p.num_cq_items, sx, sitem, t);
-    lds_sync(NT <= 64);
-    closest_select<T>(tb, p.num_cq, sitem, sclo, t);
-    lds_sync(NT <= 64);
-  }
-  ILQG_QPH(1);
-  for (int base = 0; base < p.num_terms; base += NT) {
-    const int ti = base + t;
-    DevTerm c;
-    TermOut<T> o;
-    o.pattern = PAT_NONE;
-    o.value = T(0);
-    bool live = false;
-    if (ti < p.num_terms) {
-      c = tb.terms[ti];
-      live = c.role != ILQG_ROLE_CHILD && k >= c.k_start;  // FinalTimeCost: nothing before its threshold
-      if (live) {
-        const bool is_cost = c.role == ILQG_ROLE_STATE_COST || c.role == ILQG_ROLE_CONTROL_COST;
-        const bool deriv = do_quad && (is_full(c.player) || c.role == ILQG_ROLE_CONTROL_COST);
-        if (deriv || (a.cost_part && is_cost)) {
-          const T lambda = (c.slot >= 0 && a.lambdas) ? a.lambdas[c.slot * p.T + tidx] : T(0);
-          term_compute<T>(tb, c, sx + c.arg_off, lambda, a.mu, &o, shared_closest ? sclo : nullptr);
-          if (!deriv) o.pattern = PAT_NONE;
-        }
-      }
-      if (a.cost_part) svals[ti] = o.value;
-    }
-    ILQG_QPH(2);
-    // ---- scatter in rounds: within a round no two terms touch the same entry ----
-    if (do_quad) {
-      for (int r = 0; r < p.num_rounds; r++) {
-        lds_sync(NT <= 64);
-        if (live && c.round == r && o.pattern != PAT_NONE)
-          term_scatter<T>(o, sx + c.arg_off, c.arg_dim, sQ + c.tile_h, c.ld, sQ + c.tile_g);
-      }
-    }
-  }
-  lds_sync(NT <= 64);
-  ILQG_QPH(3);
-  // Values first, stores last: a register that feeds a global store cannot be rewritten until the store
-  // has drained (the compiler waits vmcnt(0) for it), so every store of the step is issued in one
-  // burst at the very end, from registers nothing else needs.
-  T ms1 = T(0), ms2 = T(0), ctot = T(0);
-  if (t < N) {
-    const int i = t;
-    if (a.merit_part) {  // pieces of ILQSolver::MeritFunction (:419-430)
-      const int rg = tb.lc[LC_RGOFF + tb.lc[LC_PII + i]], ud = tb.lc[LC_UDIM + i];
-      T s1 = T(0), s2 = T(0);
-      for (int d = 0; d < ud; d++) s1 += sr[rg + d] * sr[rg + d];
-      if constexpr (CN > 0) {
-        T lv[CN];  // loads first, then the sequential sum (same order as the reference)
-#pragma unroll
-        for (int d = 0; d < CN; d++) lv[d] = sl[i * CN + d];
-#pragma unroll
-        for (int d = 0; d < CN; d++) s2 += lv[d] * lv[d];
-      } else {
-        for (int d = 0; d < n; d++) s2 += sl[i * n + d] * sl[i * n + d];
-      }
-      ms1 = s1;
-      ms2 = s2;
-    }
-    if (a.cost_part) {  // PlayerCost::Evaluate, src/player_cost.cpp:128-144 (state costs, then control costs)
-      // Same left-to-right sum as the reference; indices and values are fetched eight at a time so the
-      // LDS round trips overlap instead of chaining (index -> value -> add).
-      T total = T(0);
-      const int* ord = tb.order + i * p.cost_order_stride;
-      const int cnt = ord[0];
-      for (int q0 = 0; q0 < cnt; q0 += 8) {
-        int idx[8];
-        T val[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) idx[u] = ord[1 + ((q0 + u < cnt) ? q0 + u : cnt - 1)];
-#pragma unroll
-        for (int u = 0; u < 8; u++) val[u] = svals[idx[u]];
-#pragma unroll
-        for (int u = 0; u < 8; u++)
-          if (q0 + u < cnt) total += val[u];
-      }
-      ctot = total;
-    }
-  }
-  carry.ms1 = ms1;
-  carry.ms2 = ms2;
-  carry.ctot = ctot;
-  ILQG_QPH(4);
-#undef ILQG_QPH
-}
-
-template <typename T, int CN = 0, int CM = 0, int CNP = 0>
-__device__ __forceinline__ void linquad_store(const DevProblem& p, const QuadArgs<T>& a, int k, T* sm, int t,
-                                              const LinquadCarry<T>& carry) {
-  const int n = CN > 0 ? CN : p.n, m = CM > 0 ? CM : p.m, N = CNP > 0 ? CNP : p.N;
-  constexpr int NT = 64;
-  const PairTable& pt = p.pairs;
-  T* sx = sm;
-  T* sA = sx + n + m;
-  T* sB = sA + n * n;
-  T* sQ = sB + n * m;
-  T* sl = sQ + N * n * n;
-  T* sR = sl + N * n;
-  T* sr = sR + pt.Rsz;
-  const T ms1 = carry.ms1, ms2 = carry.ms2, ctot = carry.ctot;
-  long long qc0 = (kProfile && a.phacc) ? clock64() : 0, qc1;
-#define ILQG_QPH(i) do { if (kProfile && a.phacc) { __builtin_amdgcn_sched_barrier(0); qc1 = clock64(); __builtin_amdgcn_sched_barrier(0); a.phacc[i] += qc1 - qc0; qc0 = qc1; } } while (0)
-  // ---- coalesced write-out: the whole image is read into registers, then stored in one burst ----
-  typedef T pair2 __attribute__((ext_vector_type(2)));
-  bool burst = false;
-  if constexpr (CN > 0 && CM > 0 && CNP > 0) {
-    constexpr int cA = CN * CN, cB = CN * CM, cQ = CNP * CN * CN, cl = CNP * CN;
-    constexpr bool even = (cA % 2 == 0) && (cB % 2 == 0) && (cQ % 2 == 0) && (cl % 2 == 0) && ((CN + CM) % 2 == 0);
-    constexpr int UA = (cA / 2 + NT - 1) / NT, UB = (cB / 2 + NT - 1) / NT, UQ = (cQ / 2 + NT - 1) / NT,
-                  UL = (cl / 2 + NT - 1) / NT;
-    if (even && UA + UB + UQ + UL <= 12 && (pt.Rsz & 1) == 0 && (pt.rsz & 1) == 0 && pt.Rsz <= 2 * NT &&
-        pt.rsz <= 2 * NT && a.A != nullptr && a.Q != nullptr) {
-      burst = true;
-      pair2 rA[UA], rB[UB], rQ[UQ], rl[UL], rR = {T(0), T(0)}, rr = {T(0), T(0)};
-#pragma unroll
-      for (int u = 0; u < UA; u++)
-        if (2 * (t + NT * u) < cA) rA[u] = *reinterpret_cast<const pair2*>(sA + 2 * (t + NT * u));
-#pragma unroll
-      for (int u = 0; u < UB; u++)
-        if (2 * (t + NT * u) < cB) rB[u] = *reinterpret_cast<const pair2*>(sB + 2 * (t + NT * u));
-#pragma unroll
-      for (int u = 0; u < UQ; u++)
-        if (2 * (t + NT * u) < cQ) rQ[u] = *reinterpret_cast<const pair2*>(sQ + 2 * (t + NT * u));
-#pragma unroll
-      for (int u = 0; u < UL; u++)
-        if (2 * (t + NT * u) < cl) rl[u] = *reinterpret_cast<const pair2*>(sl + 2 * (t + NT * u));
-      if (2 * t < pt.Rsz) rR = *reinterpret_cast<const pair2*>(sR + 2 * t);
-      if (2 * t < pt.rsz) rr = *reinterpret_cast<const pair2*>(sr + 2 * t);
-      T* gA = a.A + size_t(k) * cA;
-      T* gB = a.Bm + size_t(k) * cB;
-      T* gQ = a.Q + size_t(k) * cQ;
-      T* gl = a.l + size_t(k) * cl;
-      T* gR = a.R + size_t(k) * pt.Rsz;
-      T* gr = a.r + size_t(k) * pt.rsz;
-#pragma unroll
-      for (int u = 0; u < UA; u++)
-        if (2 * (t + NT * u) < cA) *reinterpret_cast<pair2*>(gA + 2 * (t + NT * u)) = rA[u];
-#pragma unroll
-      for (int u = 0; u < UB; u++)
-        if (2 * (t + NT * u) < cB) *reinterpret_cast<pair2*>(gB + 2 * (t + NT * u)) = rB[u];
-#pragma unroll
-      for (int u = 0; u < UQ; u++)
-        if (2 * (t + NT * u) < cQ) *reinterpret_cast<pair2*>(gQ + 2 * (t + NT * u)) = rQ[u];
-#pragma unroll
-      for (int u = 0; u < UL; u++)
-        if (2 * (t + NT * u) < cl) *reinterpret_cast<pair2*>(gl + 2 * (t + NT * u)) = rl[u];
-      if (2 * t < pt.Rsz) *reinterpret_cast<pair2*>(gR + 2 * t) = rR;
-      if (2 * t < pt.rsz) *reinterpret_cast<pair2*>(gr + 2 * t) = rr;
-    }
-  }
-  if (!burst) {
-    auto copy_out = [&](T* dst, const T* src, int count) {
-      for (int e = t; e < count; e += NT) dst[e] = src[e];
-    };
-    if (a.A) {
-      copy_out(a.A + size_t(k) * n * n, sA, n * n);
-      copy_out(a.Bm + size_t(k) * n * m, sB, n * m);
-    }
-    if (a.Q) {
-      copy_out(a.Q + size_t(k) * N * n * n, sQ, N * n * n);
-      copy_out(a.l + size_t(k) * N * n, sl, N * n);
-      copy_out(a.R + size_t(k) * pt.Rsz, sR, pt.Rsz);
-      copy_out(a.r + size_t(k) * pt.rsz, sr, pt.rsz);
-    }
-  }
-  if (t < N) {
-    if (a.merit_part) {
-      a.merit_part[(size_t(k) * N + t) * 2 + 0] = ms1;
-      a.merit_part[(size_t(k) * N + t) * 2 + 1] = ms2;
-    }
-    if (a.cost_part) a.cost_part[size_t(k) * N + t] = ctot;
-  }
-  lds_sync(NT <= 64);
-  ILQG_QPH(5);
-#undef ILQG_QPH
-}
-
-template <typename T, int CN = 0, int CM = 0, int CNP = 0>
-__device__ __forceinline__ void linquad_step(const DevProblem& p, const QuadTables<T>& tb, const QuadArgs<T>& a, int k,
-                                             T* sm, int t) {
-  const int n = CN > 0 ? CN : p.n, m = CM > 0 ? CM : p.m;
-  LinquadCarry<T> carry;
-  linquad_compute<T, CN, CM, CNP>(p, tb, a, k, sm, t, linquad_load_arg<T>(a, k, n, m, t), carry);
-  linquad_store<T, CN, CM, CNP>(p, a, k, sm, t, carry);
-}
 
 // Sequential left-to-right sum of `count` LDS values, eight loads in flight at a time (the adds keep
 // the reference's order; only the LDS latency overlaps).

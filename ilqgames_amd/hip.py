@@ -22,7 +22,7 @@ EXPORTS = [
     "ilqg_last_error", "ilqg_abi_version", "ilqg_device_info", "ilqg_selftest_mfma", "ilqg_al_solve_batch", "ilqg_plan_integrate_batch", "ilqg_receding_horizon_sync_batch",
     "ilqg_solution_splice_batch", "ilqg_solve_again_batch", "ilqg_strategy_costs_batch",
     "ilqg_check_local_nash_batch", "ilqg_check_sufficient_nash_batch",
-    "ilqg_receding_horizon_shift_batch",
+    "ilqg_receding_horizon_shift_batch", "ilqg_default_solve_options", "ilqg_solve_batch_ex", "ilqg_solve_state_batch",
 ]
 
 
@@ -194,24 +194,45 @@ class Problem:
                     converged=torch.zeros(batch, dtype=torch.int32, device="cuda"),
                     ws=torch.empty(self.workspace_bytes(batch), dtype=torch.uint8, device="cuda"))
 
-    def solve(self, x0, bufs=None, fixed_iters=0, augmented_lagrangian=False):
-        """ilqg_ilq_solve_batch (or ilqg_al_solve_batch). `bufs` (from alloc_solve_buffers) carries the
-        warm start in and the solution out; zero warm start if omitted."""
+    def solve(self, x0, bufs=None, fixed_iters=0, augmented_lagrangian=False, forced_steps=None, split_trial=None,
+              handoff=None, probe=None, counted=None, resume=False, active=None):
+        """ilqg_solve_batch_ex. `bufs` (from alloc_solve_buffers) carries the warm start in and the solution out; zero
+        warm start if omitted.  forced_steps [B][fixed_iters]: test mode, the given step sizes instead of the line
+        search.  split_trial / handoff / probe / counted: None = let the library choose, True / False = force the
+        schedule (same results either way)."""
         x0 = _dev(x0, self.dtype)
         B = x0.shape[0]
         if bufs is None:
             bufs = self.alloc_solve_buffers(B)
-        if augmented_lagrangian:
-            _check(lib().ilqg_al_solve_batch(self.h, B, _ptr(x0), _ptr(bufs["xs"]), _ptr(bufs["us"]),
-                                             _ptr(bufs["P"]), _ptr(bufs["alpha"]), _ptr(bufs["costs"]),
-                                             _ptr(bufs["iters"]), _ptr(bufs["status"]), _ptr(bufs["converged"]),
-                                             _ptr(bufs["ws"]), _stream()))
-            return bufs
-        _check(lib().ilqg_ilq_solve_batch(self.h, B, _ptr(x0), _ptr(bufs["xs"]), _ptr(bufs["us"]), _ptr(bufs["P"]),
-                                          _ptr(bufs["alpha"]), _ptr(bufs["costs"]), _ptr(bufs["iters"]),
-                                          _ptr(bufs["status"]), _ptr(bufs["converged"]), _ptr(bufs["ws"]),
-                                          int(fixed_iters), _stream()))
+        o = abi.SolveOptions()
+        lib().ilqg_default_solve_options(C.byref(o))
+        o.fixed_iters = int(fixed_iters)
+        o.augmented_lagrangian = 1 if augmented_lagrangian else 0
+        o.resume = 1 if resume else 0
+        o.active = None if active is None else active.data_ptr()
+        fs = None
+        if forced_steps is not None:
+            fs = _dev(forced_steps, self.dtype)
+            assert tuple(fs.shape) == (B, fixed_iters)
+            o.forced_steps = fs.data_ptr()
+        tri = lambda v: abi.CHOICE_AUTO if v is None else (abi.CHOICE_ON if v else abi.CHOICE_OFF)  # noqa: E731
+        o.split_trial, o.handoff, o.probe, o.counted = tri(split_trial), tri(handoff), tri(probe), tri(counted)
+        _check(lib().ilqg_solve_batch_ex(self.h, B, _ptr(x0), _ptr(bufs["xs"]), _ptr(bufs["us"]), _ptr(bufs["P"]),
+                                         _ptr(bufs["alpha"]), _ptr(bufs["costs"]), _ptr(bufs["iters"]),
+                                         _ptr(bufs["status"]), _ptr(bufs["converged"]), _ptr(bufs["ws"]), C.byref(o),
+                                         _stream()))
         return bufs
+
+    def solve_state(self, bufs, augmented_lagrangian=False):
+        """ilqg_solve_state_batch: dict(last_merit, expected_decrease, step, backtracks) of the last solve on bufs."""
+        import torch
+        B = bufs["iters"].shape[0]
+        out = dict(last_merit=self._empty(B), expected_decrease=self._empty(B), step=self._empty(B),
+                   backtracks=torch.zeros(B, dtype=torch.int32, device="cuda"))
+        _check(lib().ilqg_solve_state_batch(self.h, B, _ptr(bufs["ws"]), int(augmented_lagrangian),
+                                            _ptr(out["last_merit"]), _ptr(out["expected_decrease"]),
+                                            _ptr(out["step"]), _ptr(out["backtracks"]), _stream()))
+        return out
 
     def receding_horizon_shift(self, x0, t0, planner_runtime, plan_t0, bufs):
         """ilqg_receding_horizon_shift_batch: turns the solution in `bufs` (xs, us, P, alpha) into the warm start

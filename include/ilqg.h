@@ -68,7 +68,12 @@ typedef struct {
   int32_t batch;                  /* B independent instances              */
   int32_t dtype;                  /* ilqg_dtype                           */
   int32_t adaptive_regularization;/* Gershgorin step of lq_feedback_solver.cpp:163-176 */
+  int32_t sweep_formulation;      /* ilqg_choice: ILQG_CHOICE_OFF selects the VALU / LDS formulation of the feedback sweep
+                                     where the matrix-core one is the default (n <= 16); same results (A/B runs) */
 } ilqg_dims;
+
+/* A scheduling choice that does not change results: let the library decide, or force it off / on. */
+typedef enum { ILQG_CHOICE_AUTO = 0, ILQG_CHOICE_OFF = 1, ILQG_CHOICE_ON = 2 } ilqg_choice;
 
 /* ------------------------------------------------------------------------ *
  *  LQ Nash sweeps                                                          *
@@ -241,14 +246,15 @@ typedef struct ilqg_problem ilqg_problem;
 /* Builds the device-side tables of one Problem (what Problem::Initialize +
  * ILQSolver::ILQSolver set up, include/ilqgames/solver/problem.h:66-73,
  * include/ilqgames/solver/ilq_solver.h:69-95).
- * A handle also owns the small device buffers its solves coordinate through (round counters, the lists of
- * back-tracking instances, the line-search probe pool): like the reference's solver objects it serves one
- * solve at a time — concurrent solves need one handle each (the read-only entry points, e.g. rollout /
- * linearize / quadraticize / strategy costs, may share one). */
+ * A handle also owns the four round counters its solves report through (device + pinned host copy, allocated
+ * here): like the reference's solver objects it serves one solve at a time — concurrent solves need one handle
+ * each (the read-only entry points, e.g. rollout / linearize / quadraticize / strategy costs, may share one). */
 ilqg_status ilqg_problem_create(const ilqg_problem_desc* desc, ilqg_problem** out);
 void ilqg_problem_destroy(ilqg_problem* p);
 
-/* Bytes of device workspace ilqg_ilq_solve_batch needs for `batch` instances. */
+/* Bytes of device workspace a solve of `batch` instances needs: the per-instance iterates, linearisations and
+ * loop states, the lists of back-tracking instances and the pool of the speculative line search.  A solve
+ * allocates nothing. */
 ilqg_status ilqg_workspace_bytes(const ilqg_problem* p, int32_t batch, uint64_t* bytes);
 
 /* ------------------------------------------------------------------------ *
@@ -326,6 +332,42 @@ ilqg_status ilqg_ilq_solve_batch(ilqg_problem* p, int32_t batch, const void* x0,
                                  int32_t* status, int32_t* converged,
                                  void* workspace, int32_t fixed_iters,
                                  void* stream);
+
+/* Everything a solve call can be told beyond its buffers (ilqg_solve_batch_ex).  The scheduling choices select among
+ * device schedules of the SAME arithmetic (bit-identical results; they exist for measurements and tests).
+ * ilqg_default_solve_options fills the defaults: reference semantics, every choice ILQG_CHOICE_AUTO. */
+typedef struct {
+  int32_t fixed_iters;          /* > 0: exactly that many outer iterations per instance, convergence not tested   */
+  int32_t augmented_lagrangian; /* 1: AugmentedLagrangianSolver::Solve around the inner solves                     */
+  int32_t resume;               /* 1: GameSolver::Solve called again on the same solver object: the workspace
+                                      holds the previous call's state (last_merit_function_value_)               */
+  int32_t reserved0;
+  const int32_t* active;        /* [B] device int32 or NULL: instances with 0 are skipped, their buffers untouched  */
+  const void* forced_steps;     /* [B][fixed_iters] device (problem dtype) or NULL.  Test mode: iteration q of
+                                      instance b scales its strategies by forced_steps[b][q], integrates and
+                                      quadraticises once and ACCEPTS, whatever CheckArmijoCondition says — the
+                                      loop's only data-dependent branch is gone, so iterates can be compared one
+                                      by one with a CPU run given the same steps.  Needs fixed_iters > 0, no AL.   */
+  int32_t split_trial;          /* ilqg_choice: the trial pass as three launches (integrate / rows / decide)        */
+  int32_t handoff;              /* ilqg_choice: back-tracking instances leave the fused kernel for split passes     */
+  int32_t probe;                /* ilqg_choice: speculative line search over the next step sizes of listed instances */
+  int32_t counted;              /* ilqg_choice: host counts the rounds of a fixed-iteration solve as well           */
+  int32_t reserved[6];
+} ilqg_solve_options;
+void ilqg_default_solve_options(ilqg_solve_options* o);
+
+/* ilqg_ilq_solve_batch / ilqg_al_solve_batch / ilqg_solve_again_batch are this call with the matching options. */
+ilqg_status ilqg_solve_batch_ex(ilqg_problem* p, int32_t batch, const void* x0, void* xs, void* us, void* P,
+                                void* alpha, void* total_costs, int32_t* iters, int32_t* status, int32_t* converged,
+                                void* workspace, const ilqg_solve_options* options, void* stream);
+
+/* The loop state a solve left in its workspace, per instance (what ILQSolver keeps in members / locals):
+ * last_merit_function_value_ (ilq_solver.h:189), the last expected decrease (:303), the step size of the last
+ * trial and the number of steps that line search had rejected.  Outputs are device arrays [B] (problem dtype; int32
+ * for backtracks), any may be NULL.  `augmented_lagrangian` must be what the solve was called with. */
+ilqg_status ilqg_solve_state_batch(const ilqg_problem* p, int32_t batch, const void* workspace,
+                                   int32_t augmented_lagrangian, void* last_merit, void* expected_decrease,
+                                   void* step, int32_t* backtracks, void* stream);
 
 /* Replaces AugmentedLagrangianSolver::Solve (src/augmented_lagrangian_solver.cpp:72-210) with
  * max_runtime = infinity: inner ilqg_ilq_solve_batch calls capped at
@@ -457,7 +499,8 @@ ilqg_status ilqg_selftest_mfma(int32_t dtype, const void* X, const void* Y, cons
 const char* ilqg_last_error(void);
 
 /* Library / device introspection (used by the loader to fail loudly). */
-#define ILQG_ABI_VERSION 2 /* 2: ilqg_cost_term::first_step, dynamics kinds 4/5, cost kind 10, harness / check entries */
+#define ILQG_ABI_VERSION 3 /* 3: ilqg_solve_options / ilqg_solve_batch_ex / ilqg_solve_state_batch, ilqg_dims::sweep_formulation;
+                              the workspace holds every device buffer a solve uses */
 int32_t ilqg_abi_version(void);
 ilqg_status ilqg_device_info(char* name_out, int32_t name_len, int32_t* num_cus);
 

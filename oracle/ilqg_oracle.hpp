@@ -1386,13 +1386,17 @@ struct ILQState {
 
 // ILQSolver::Solve, :76-172, with ModifyLQStrategies :289-348 inlined.
 // `fixed_iters` > 0: run exactly that many outer iterations (ignore has_converged).
+// `forced_steps` (test mode, needs fixed_iters > 0): iteration q takes the step forced_steps[q] — the strategies are
+// scaled by it, the trajectory is rolled out and quadraticised ONCE and accepted whatever CheckArmijoCondition
+// says; merit / convergence bookkeeping as after an accepted step.  This removes the only data-dependent branch of
+// the loop, so that a device solve can be compared iterate by iterate.
 // If `raw` is non-null it receives the unscaled LQ strategies of the LAST LQ solve
 // (the object P_t / alpha_t parity is defined on).
 template <class S>
 bool SolveILQ(const Problem<S>& p, const Vec<S>& x0, Trajectory<S>* op_io, Strategies<S>* st_io,
               ILQState<S>* state, const ALState<S>* al, int fixed_iters, std::vector<IterLog<S>>* log,
               Vec<S>* final_costs, int* iters_out, int* converged_out, Strategies<S>* raw = nullptr,
-              int* logged_out = nullptr) {
+              int* logged_out = nullptr, const S* forced_steps = nullptr) {
   const ilqg_solver_params& prm = p.params;
   if ((int)state->t_extreme.size() != p.N) state->t_extreme.assign(p.N, 0);
   Trajectory<S> last_op = *op_io, cur_op = *op_io;
@@ -1431,14 +1435,22 @@ bool SolveILQ(const Problem<S>& p, const Vec<S>& x0, Trajectory<S>* op_io, Strat
       for (auto& a : strategies.alpha)
         for (auto& v : a) v *= s;
     };
-    scale(S(prm.initial_alpha_scaling));
+    const S first_step = forced_steps ? forced_steps[num_iterations - 1] : S(prm.initial_alpha_scaling);
+    scale(first_step);
     const Trajectory<S> last = cur_op;
-    S step = S(prm.initial_alpha_scaling);
+    S step = first_step;
     Rollout(p, last.xs[0], last, strategies, &cur_op);
     int backtracks = 0;
     S merit = std::numeric_limits<S>::quiet_NaN();
     bool accepted = !prm.linesearch;
-    if (prm.linesearch) {
+    if (forced_steps && prm.linesearch) {
+      ComputeQuadraticization(p, cur_op, state->t_extreme, al, &lq);
+      merit = MeritFromQuad(p, lq);
+      has_converged = (merit <= state->last_merit) &&
+                      std::abs(state->last_merit - merit) < S(prm.convergence_tolerance);
+      state->last_merit = merit;
+      accepted = true;
+    } else if (prm.linesearch) {
       for (int bb = 0; bb < prm.max_backtracking_steps; bb++) {
         ComputeQuadraticization(p, cur_op, state->t_extreme, al, &lq);  // MeritFunction :405
         merit = MeritFromQuad(p, lq);

@@ -234,7 +234,7 @@ void TotalCostsBatch(const OracleProblem* op, int batch, const void* xs, const v
 template <class S>
 void SolveBatch(const OracleProblem* op, int batch, const void* x0, void* xs, void* us, void* P, void* alpha,
                 void* costs, int32_t* iters, int32_t* status, int32_t* converged, int fixed_iters, void* rawP,
-                void* rawAlpha, void* merit_log, int merit_log_len, int threads) {
+                void* rawAlpha, void* merit_log, int merit_log_len, int threads, const void* forced_steps = nullptr) {
   const Problem<S>& p = Get<S>(op);
   const int T = p.T, n = p.n, m = p.m, N = p.N;
 #pragma omp parallel for num_threads(threads) schedule(dynamic) if (threads > 1)
@@ -254,7 +254,8 @@ void SolveBatch(const OracleProblem* op, int batch, const void* x0, void* xs, vo
       S maxerr;
       ok = SolveAL(p, x0v, &tr, &st, &fc, &it, &maxerr, &conv);
     } else {
-      ok = SolveILQ(p, x0v, &tr, &st, &state, &al, fixed_iters, &log, &fc, &it, &conv, &raw);
+      const S* fs = (forced_steps && fixed_iters > 0) ? (const S*)forced_steps + size_t(b) * fixed_iters : nullptr;
+      ok = SolveILQ(p, x0v, &tr, &st, &state, &al, fixed_iters, &log, &fc, &it, &conv, &raw, (int*)nullptr, fs);
     }
     PackTraj(p, tr, (S*)xs + size_t(b) * T * n, (S*)us + size_t(b) * T * m);
     PackStrategies(p, st, (S*)P + size_t(b) * T * m * n, (S*)alpha + size_t(b) * T * m);
@@ -548,6 +549,14 @@ void oracle_ilq_solve(void* h, int dtype, int batch, const void* x0, void* xs, v
                       void* rawP, void* rawAlpha, void* merit_log, int merit_log_len, int threads) {
   DISPATCH(dtype, SolveBatch, (OracleProblem*)h, batch, x0, xs, us, P, alpha, costs, iters, status, converged,
            fixed_iters, rawP, rawAlpha, merit_log, merit_log_len, threads);
+}
+
+// The same with per-iteration step sizes supplied by the caller ([batch][fixed_iters]) instead of the line search.
+void oracle_ilq_solve_forced(void* h, int dtype, int batch, const void* x0, void* xs, void* us, void* P, void* alpha,
+                             void* costs, int32_t* iters, int32_t* status, int32_t* converged, int fixed_iters,
+                             const void* forced_steps, void* rawP, void* rawAlpha, void* merit_log, int merit_log_len) {
+  DISPATCH(dtype, SolveBatch, (OracleProblem*)h, batch, x0, xs, us, P, alpha, costs, iters, status, converged,
+           fixed_iters, rawP, rawAlpha, merit_log, merit_log_len, 1, forced_steps);
 }
 
 // Problem::SetUpNextRecedingHorizon for a batch of plans sharing one time base.

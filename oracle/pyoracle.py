@@ -123,8 +123,9 @@ class OracleProblem:
         return costs, te
 
     def solve(self, dtype, x0, xs=None, us=None, P=None, alpha=None, fixed_iters=0, merit_log_len=0, threads=1,
-              augmented_lagrangian=False):
+              augmented_lagrangian=False, forced_steps=None):
         """ILQSolver::Solve (or AugmentedLagrangianSolver::Solve) per instance.
+        forced_steps [B][fixed_iters]: every iteration takes the given step size instead of running the line search.
         Returns dict with final op/strategies/costs/iters/status."""
         if augmented_lagrangian:
             fixed_iters = -1
@@ -142,9 +143,16 @@ class OracleProblem:
         rawP = np.zeros_like(P)
         rawA = np.zeros_like(alpha)
         ml = np.zeros((B, merit_log_len, 4), dt) if merit_log_len else None
-        lib().oracle_ilq_solve(self.h, dtype, B, _p(x0), _p(xs), _p(us), _p(P), _p(alpha), _p(costs), _p(iters),
-                               _p(status), _p(conv), int(fixed_iters), _p(rawP), _p(rawA), _p(ml),
-                               int(merit_log_len), int(threads))
+        if forced_steps is not None:
+            fs = np.ascontiguousarray(forced_steps, dtype=dt)
+            assert fs.shape == (B, fixed_iters)
+            lib().oracle_ilq_solve_forced(self.h, dtype, B, _p(x0), _p(xs), _p(us), _p(P), _p(alpha), _p(costs),
+                                          _p(iters), _p(status), _p(conv), int(fixed_iters), _p(fs), _p(rawP),
+                                          _p(rawA), _p(ml), int(merit_log_len))
+        else:
+            lib().oracle_ilq_solve(self.h, dtype, B, _p(x0), _p(xs), _p(us), _p(P), _p(alpha), _p(costs), _p(iters),
+                                   _p(status), _p(conv), int(fixed_iters), _p(rawP), _p(rawA), _p(ml),
+                                   int(merit_log_len), int(threads))
         return dict(xs=xs, us=us, P=P, alpha=alpha, costs=costs, iters=iters, status=status, converged=conv,
                     rawP=rawP, rawAlpha=rawA, log=ml)
 

@@ -1,0 +1,123 @@
+"""GPU parity, every instance and every iterate: solves with FORCED step sizes.
+
+The whole-solve tests of test_gpu_parity.py can only compare instances whose line-search decisions agree between
+device and oracle (an Armijo test within rounding of its threshold flips a decision and sends the two runs down
+different paths).  Here the line search is taken out of the loop on both sides — iteration q of instance b scales its
+strategies by a given step size, rolls out, quadraticises and accepts (ilqg_solve_options::forced_steps, the oracle's
+SolveILQ(forced_steps)) — so that EVERY instance can be compared after EVERY iteration: operating point, raw
+strategies of the last LQ solve, merit, expected decrease, total costs.  The step sizes are the ones the reference's
+own line search accepted on that instance (a free-running oracle solve), shortened by a further 0.5^r, r mostly
+0..2 and 7 or 9 for a fifth of them: the depths a back-tracking search really ends at, and well beyond.
+
+What is left that can make two correct implementations disagree is conditioning: an LQ solution at a poor operating
+point can close the loop unstably, and a rollout then amplifies rounding differences by e^(lambda T) (the n = 16
+scene has an instance where 1e-16 becomes 1e+6 within one rollout); max-over-time players add the arg-max over
+time.  The test measures that amplification instead of guessing it: the fp64 oracle is run twice, the second time
+from x0 + 1e-12, and an (instance, iteration) pair is compared where the two oracle runs still agree to 1e-8, i.e.
+where the iteration amplifies a perturbation by less than 1e4.  There the fp64 device must match the fp64 oracle to
+1e-9 relative, the fp32 device the fp32 oracle to 2e-3 on the operating point and 1e-2 on P / alpha (fp32 round-off
+x that amplification x the conditioning of the Nash system).  Coverage is asserted: at least three
+quarters of the instances at the first iteration and 70 % of all (instance, iteration) pairs.
+"""
+import numpy as np
+import pytest
+
+from ilqgames_amd import abi, examples
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+K = 6  # iterations compared
+SCENES = [
+    "two_player_unicycle_4d_scene",                   # BASELINE config 1's dynamics (TwoPlayerUnicycle4D)
+    "modified_three_player_intersection",             # config 2 / 3 (n = 14)
+    "three_player_intersection",                      # config 2's n = 16 form (constraint terms at lambda = 0, mu = 10)
+    "roundabout_merging",                             # config 4 (n = 24, open-loop sweep)
+    "three_player_collision_avoidance_reachability",  # config 5 (max-over-time player, ExtremeValueCost)
+]
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    from ilqgames_amd import hip as h
+    return h
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _forced_steps(rng, free_log, alpha0):
+    """Accepted steps of the free-running oracle, each shortened by a further 0.5^r; an iteration the free run never
+    reached (converged, or its line search gave up) takes alpha0 / 256."""
+    acc = free_log[:, :K, 2].astype(np.float64)
+    acc = np.where(np.isfinite(acc) & (acc > 1e-6 * alpha0), acc, alpha0 / 256.0)
+    return acc * 0.5 ** rng.choice([0, 1, 2, 7, 9], p=[0.3, 0.3, 0.2, 0.1, 0.1], size=acc.shape)
+
+
+def _inst_err(a, b, keys):
+    return max(rel_err(a[ka], b[kb]) for ka, kb in keys)
+
+
+@pytest.mark.parametrize("scene", SCENES)
+@pytest.mark.parametrize("dtype", [abi.F64, abi.F32])
+def test_every_instance_matches_after_every_iteration(hip, oracle, scene, dtype):
+    spec = examples.CONFIGS[scene]()
+    B = 12
+    rng = np.random.default_rng(100 + SCENES.index(scene))
+    x0 = examples.jittered_x0(spec, B, seed=11)
+    op = oracle.OracleProblem(spec)
+    free = op.solve(abi.F64, x0, merit_log_len=K)
+    steps = _forced_steps(rng, free["log"], float(spec.params.initial_alpha_scaling))
+    assert steps.min() < 0.02 * steps.max(), "the forced steps should reach deep into a line search"
+    first = 0
+    x0_nudged = x0 + 1e-12 * rng.standard_normal(x0.shape)
+    prob = hip.Problem(spec, dtype)
+    f64 = dtype == abi.F64
+    tol_op, tol_st = (1e-9, 1e-9) if f64 else (2e-3, 1e-2)
+    amp_limit = 1e-8
+    compared = 0
+    for k in range(1, K + 1):
+        ref = op.solve(dtype, x0, fixed_iters=k, forced_steps=steps[:, :k], merit_log_len=k)
+        out = prob.solve(x0, fixed_iters=k, forced_steps=steps[:, :k])
+        st = prob.solve_state(out)
+        assert np.array_equal(_np(out["iters"]), ref["iters"]) and np.all(ref["iters"] == k)
+        assert np.all(_np(out["status"]) == 1) and np.all(ref["status"] == 1)
+        # how much this (instance, iteration) amplifies a 1e-12 nudge of x0, measured on the fp64 oracle
+        r64 = ref if f64 else op.solve(abi.F64, x0, fixed_iters=k, forced_steps=steps[:, :k])
+        r64n = op.solve(abi.F64, x0_nudged, fixed_iters=k, forced_steps=steps[:, :k])
+        merit_ref, ed_ref, step_ref = ref["log"][:, k - 1, 0], ref["log"][:, k - 1, 1], ref["log"][:, k - 1, 2]
+        dev = {q: _np(out[q]) for q in ("xs", "us", "P", "alpha", "costs")}
+        for b in range(B):  # every instance on its own scale: a batch-wide max-norm would hide the small ones
+            one = lambda d: {q: v[b] for q, v in d.items() if hasattr(v, "shape") and v.shape[:1] == (B,)}  # noqa: E731
+            amp = _inst_err(one(r64n), one(r64), (("xs", "xs"), ("us", "us"), ("rawP", "rawP"), ("alpha", "alpha")))
+            if not (amp <= amp_limit and np.isfinite(merit_ref[b])):
+                continue
+            compared += 1
+            first += k == 1
+            where = "%s k=%d instance %d (amplification of 1e-12: %.1e)" % (scene, k, b, amp)
+            assert rel_err(dev["xs"][b], ref["xs"][b]) < tol_op, where
+            # fp32: controls after a short step are ~1e-4, below what fp32 states of ~50 m resolve through u = -P dx;
+            # they are compared on the scale of a control (1), fp64 on their own
+            us_scale = float(np.max(np.abs(ref["us"][b]))) if f64 else max(1.0, float(np.max(np.abs(ref["us"][b]))))
+            assert float(np.max(np.abs(dev["us"][b] - ref["us"][b]))) < tol_op * max(us_scale, 1e-30), where
+            assert rel_err(dev["P"][b], ref["rawP"][b]) < tol_st, where
+            assert rel_err(dev["alpha"][b], ref["alpha"][b]) < tol_st, where
+            # a cost is a function of positions: its error is that of the trajectory, on the trajectory's scale
+            scale = max(1.0, float(np.max(np.abs(ref["xs"][b]))), float(np.max(np.abs(ref["costs"][b]))))
+            assert float(np.max(np.abs(dev["costs"][b] - ref["costs"][b]))) < tol_op * scale, where
+            assert abs(_np(st["last_merit"])[b] - merit_ref[b]) <= tol_op * max(1.0, abs(merit_ref[b])), where
+            assert abs(_np(st["expected_decrease"])[b] - ed_ref[b]) <= tol_st * max(1.0, abs(ed_ref[b])), where
+            assert abs(_np(st["step"])[b] - step_ref[b]) <= 1e-6 * step_ref[b], where
+    assert first >= 0.75 * B, "only %d of %d instances were well-conditioned at their first iteration" % (first, B)
+    assert compared >= 0.7 * B * K, "only %d of %d (instance, iteration) pairs were well-conditioned" % (compared, B * K)
+
+
+def test_forced_steps_are_rejected_where_they_make_no_sense(hip):
+    spec = examples.modified_three_player_intersection()
+    prob = hip.Problem(spec, abi.F64)
+    x0 = examples.jittered_x0(spec, 2, seed=0)
+    with pytest.raises(hip.IlqgError):
+        prob.solve(x0, fixed_iters=2, forced_steps=np.ones((2, 2)), augmented_lagrangian=True)

@@ -176,6 +176,57 @@ def test_full_batch_receding_horizon_step_is_per_instance_fp64(hip):
     assert np.all((full["first"] >= 0) & (full["first"] < spec.T))
 
 
+def test_config5_as_written_full_size_fp64(hip):
+    """BASELINE config 5 as written: ThreePlayerCollisionAvoidanceReachabilityExample, 2048 jittered instances,
+    AugmentedLagrangianSolver::Solve at every replanning instant, up to 200 solver calls (RecedingHorizonSimulator
+    with a fixed simulated solve time of 0.25 s, src/receding_horizon_simulator.cpp:64-137).  At this size the oracle
+    cannot follow (tests/test_gpu_receding.py compares 64 instances x 22 calls with it); here the size-independent
+    properties: an instance's run does not depend on the batch it is in — a slice holding the longest-running
+    instances reproduces, bit for bit, what they had after 40 calls inside the full batch —, nobody re-enters the
+    loop, everything stays finite, plan bookkeeping obeys the reference's invariants, and an instance is out after its
+    first call exactly when that solve reported failure (the reference's CHECK(success), :77).  (Measured: about 3 %
+    of the jittered instances pass their first solve — so does the oracle on a 64-instance sample, and the example's
+    own initial state is not among them under these parameters; the last survivor leaves the loop at call 149.)"""
+    import torch
+    spec = examples.three_player_collision_avoidance_reachability()
+    B, calls, probe_at = 2048, 200, 39
+    x0 = examples.jittered_x0(spec, B, seed=5)
+    prob = hip.Problem(spec, abi.F64)
+    trace, snap = [], {}
+
+    def on_record(r, info):
+        trace.append((int(info["active"].sum().item()), _np(info["bufs"]["status"]).copy() if r == 0 else None))
+        if r == probe_at:
+            snap.update(xs=info["bufs"]["xs"].clone(), P=info["bufs"]["P"].clone(), x=info["x_measured"].clone(),
+                        active=info["active"].clone())
+
+    out = prob.receding_horizon_simulate(x0, 1e9, 0.25, augmented_lagrangian=True, max_records=calls, on_record=on_record)
+    assert out["calls"] >= 100, "the loop should run for at least a hundred replanning instants"
+    nrec = _np(out["num_records"])
+    act = np.array([a for a, _ in trace])
+    assert np.all(np.diff(act) <= 0), "an instance re-entered the loop"
+    assert np.array_equal(nrec > 1, trace[0][1] == 1), "leaving after call 1 <=> the first solve failed"
+    assert nrec.max() >= 100 and (nrec > probe_at).sum() >= 4, "some instances keep replanning"
+    assert torch.isfinite(out["x"]).all() and torch.isfinite(out["plan"]["xs"]).all()
+    plen = _np(out["plan"]["len"])
+    assert np.all((plen >= spec.T) & (plen <= spec.T + 5))
+    # batch independence: the longest runners (and some instances that drop out at once) on their own, 40 calls
+    pick = np.unique(np.concatenate([np.argsort(-nrec)[:12], np.arange(40, 60)]))
+    snap2 = {}
+
+    def on_record2(r, info):
+        if r == probe_at:
+            snap2.update(xs=info["bufs"]["xs"].clone(), P=info["bufs"]["P"].clone(), x=info["x_measured"].clone(),
+                         active=info["active"].clone())
+
+    prob.receding_horizon_simulate(x0[pick], 1e9, 0.25, augmented_lagrangian=True, max_records=probe_at + 1,
+                                   on_record=on_record2)
+    assert torch.equal(snap2["active"], snap["active"][pick]) and snap2["active"].sum() >= 1
+    live = snap2["active"].bool()
+    for k in ("xs", "P", "x"):
+        assert torch.equal(snap2[k][live], snap[k][pick][live]), k
+
+
 def test_config4_full_batch_slice_is_reproduced_fp64(hip):
     """Config 4 at full size (roundabout merging, n=24, N=4, T=150, open-loop sweep, 4096 instances): a 21-instance
     slice solved on its own reproduces its share of the full batch bit for bit; everything finite."""

@@ -230,10 +230,18 @@ def test_ilq_solve_matches_oracle_fp64(hip, oracle, cfg):
     assert len(ok) >= 2, "test instances are all ill-conditioned"
     assert np.array_equal(_np(out["iters"])[ok], ref["iters"][ok])
     assert np.array_equal(_np(out["status"])[ok], ref["status"][ok])
-    agree = np.mean((_np(out["status"]) == ref["status"]) & (_np(out["iters"]) == ref["iters"]))
-    # SkeletonExample (no regularisation, proximity cost switching on mid-horizon): half of the jittered instances
-    # exhaust their line search within six iterations, at a depth where accept/reject is a rounding matter
-    assert agree >= (0.5 if cfg == "skeleton" else 0.75), "too many instances end differently (%.2f agree)" % agree
+    same = (_np(out["status"]) == ref["status"]) & (_np(out["iters"]) == ref["iters"])
+    agree = np.mean(same)
+    # Measured: every scene 1.00 except SkeletonExample 0.75 (no regularisation, proximity cost switching on
+    # mid-horizon: a quarter of the jittered instances exhaust their line search within six iterations) and
+    # DubinsOrigin 0.83.  Wherever the two runs end differently, a line search went past step alpha0 * 2^-12 or ran out
+    # of steps (status 0: the failing search is not logged) — the depth at which accept / reject is decided by the
+    # last bits of two ~1e5 merit values; the instance-by-instance comparison at forced steps is test_gpu_forced.py.
+    assert agree >= (0.75 if cfg in ("skeleton", "dubins_origin") else 0.9), "too many instances end differently (%.2f agree)" % agree
+    depth = np.nan_to_num(ref["log"][:, :, 3], nan=0.0).max(axis=1)
+    for b in np.where(~same)[0]:
+        assert depth[b] > 12 or ref["status"][b] == 0 or _np(out["status"])[b] == 0, \
+            "instance %d ends differently after a shallow line search (depth %d)" % (b, depth[b])
     assert rel_err(_np(out["xs"])[ok], ref["xs"][ok]) < 1e-7
     assert rel_err(_np(out["us"])[ok], ref["us"][ok]) < 1e-7
     assert rel_err(_np(out["P"])[ok], ref["P"][ok]) < 1e-6      # north_star: P_t, alpha_t within 1e-6 rel-err
@@ -354,9 +362,9 @@ def test_augmented_lagrangian_solve_matches_oracle_fp64(hip, oracle):
                                           ("three_player_intersection", True, abi.F64),
                                           ("roundabout_merging", False, abi.F64),
                                           ("one_player_reachability", True, abi.F64)])
-def test_split_trial_pass_is_the_fused_kernel_bit_for_bit(hip, cfg, al, dtype, monkeypatch):
-    """The three-launch form of the trial pass (rollout / rows / decision kernels, chosen by LDS footprint or
-    ILQG_SPLIT_TRIAL) runs the same functions on the same data as the fused kernel: free-running solves — line
+def test_split_trial_pass_is_the_fused_kernel_bit_for_bit(hip, cfg, al, dtype):
+    """The three-launch form of the trial pass (rollout / rows / decision kernels, chosen by problem size or by
+    ilqg_solve_options::split_trial) runs the same functions on the same data as the fused kernel: free-running solves — line
     searches with back-tracking, convergence exits, the augmented-Lagrangian restarts — must come back identical
     in every output, status word and iteration count."""
     spec = examples.CONFIGS[cfg]()
@@ -367,11 +375,8 @@ def test_split_trial_pass_is_the_fused_kernel_bit_for_bit(hip, cfg, al, dtype, m
     outs = []
     # every pass in the fused kernel / fused first pass, back-tracking handed to split passes with the speculative
     # line search (the default for free-running solves) / split passes throughout / split passes without probing
-    for split, handoff, probe in (("0", "0", "1"), ("0", "1", "1"), ("1", "1", "1"), ("1", "1", "0")):
-        monkeypatch.setenv("ILQG_SPLIT_TRIAL", split)
-        monkeypatch.setenv("ILQG_HANDOFF", handoff)
-        monkeypatch.setenv("ILQG_PROBE", probe)
-        out = hip.Problem(spec, dtype).solve(x0, augmented_lagrangian=al)
+    for split, handoff, probe in ((False, False, True), (False, True, True), (True, True, True), (True, True, False)):
+        out = hip.Problem(spec, dtype).solve(x0, augmented_lagrangian=al, split_trial=split, handoff=handoff, probe=probe)
         outs.append({k: _np(v).copy() for k, v in out.items() if hasattr(v, "shape") and k != "ws"})
     fused = outs[0]
     for other in outs[1:]:

@@ -212,22 +212,16 @@ def test_al_solve_again_matches_oracle_fp64(hip, oracle):
     assert (err < 1e-6).sum() >= max(1, len(g) // 2), err
 
 
-@pytest.mark.parametrize("name,al", [("modified_three_player_intersection", False), ("three_player_intersection", False)])
-def test_receding_horizon_simulate_matches_oracle_fp64(hip, oracle, name, al):
-    """RecedingHorizonSimulator with a fixed simulated solve time, 4 s of simulated time: every solver call of every
-    instance compared with the oracle's record (measured state, stitched initial state, plan start time, nearest
-    index, iterate count, flags, final operating point), then the final spliced plans."""
-    spec = examples.CONFIGS[name]()
-    spec.params.initial_alpha_scaling = 0.5
-    spec.params.expected_decrease_fraction = 0.01
-    spec.params.convergence_tolerance = 0.1
-    if name == "three_player_intersection":
-        spec.params.max_solver_iters = 60
-    B = 8
-    x0 = examples.jittered_x0(spec, B, seed=3)
-    x0[0] = spec.x0
+def _compare_simulation(hip, oracle, spec, x0, final_time, al, max_records):
+    """Runs RecedingHorizonSimulator on the oracle and on the device and compares every solver call of every instance
+    (measured state, stitched initial state, plan start time, nearest index, iterate count, flags, final operating
+    point) until a line-search decision falls the other way — which may only happen where the oracle's own line
+    search went deep enough to be decided by rounding — then the final spliced plans.  Returns (ref, device result,
+    instances that agree to the end, records matched)."""
+    B = x0.shape[0]
     op = oracle.OracleProblem(spec)
-    ref = op.receding_horizon_simulate(abi.F64, x0, 4.0, 0.25, augmented_lagrangian=al, max_records=16, threads=8)
+    ref = op.receding_horizon_simulate(abi.F64, x0, final_time, 0.25, augmented_lagrangian=al,
+                                       max_records=max_records, threads=8)
     prob = hip.Problem(spec, abi.F64)
     recs = []
 
@@ -239,7 +233,8 @@ def test_receding_horizon_simulate_matches_oracle_fp64(hip, oracle, name, al):
                          iters=_np(info["bufs"]["iters"]).copy(), status=_np(info["bufs"]["status"]).copy(),
                          converged=_np(info["bufs"]["converged"]).copy()))
 
-    out = prob.receding_horizon_simulate(x0, 4.0, 0.25, augmented_lagrangian=al, max_records=16, on_record=on_record)
+    out = prob.receding_horizon_simulate(x0, final_time, 0.25, augmented_lagrangian=al, max_records=max_records,
+                                         on_record=on_record)
     nrec = _np(out["num_records"])
     agree_all = matched = 0
     for b in range(B):
@@ -255,7 +250,9 @@ def test_receding_horizon_simulate_matches_oracle_fp64(hip, oracle, name, al):
             if not decisions or rel_err(d["xs"][b], ref["xs"][b, r]) > 1e-6:
                 # a decision fell the other way; what follows is a different run.  It may only happen where the
                 # oracle's own line search went deep enough to be decided by rounding (see _clean in test_gpu_parity)
-                assert ref["max_backtracks"][b, r] > 12, (b, r, ref["max_backtracks"][b, r])
+                # or ran out of steps (a failed search is not logged: status 0 on either side)
+                assert ref["max_backtracks"][b, r] > 12 or ref["ok"][b, r] == 0 or d["status"][b] == 0, \
+                    (b, r, ref["max_backtracks"][b, r])
                 full = False
                 break
             matched += 1
@@ -269,6 +266,24 @@ def test_receding_horizon_simulate_matches_oracle_fp64(hip, oracle, name, al):
             assert abs(_np(out["plan"]["t0"])[b] - ref["plan"]["t0"][b]) < 1e-9
             assert rel_err(_np(out["plan"]["xs"])[b, :L], ref["plan"]["xs"][b, :L]) < 1e-6
             assert rel_err(_np(out["x"])[b], ref["x"][b]) < 1e-6
+    return ref, out, agree_all, matched
+
+
+@pytest.mark.parametrize("name,al", [("modified_three_player_intersection", False), ("three_player_intersection", False)])
+def test_receding_horizon_simulate_matches_oracle_fp64(hip, oracle, name, al):
+    """RecedingHorizonSimulator with a fixed simulated solve time, 4 s of simulated time: every solver call of every
+    instance compared with the oracle's record, then the final spliced plans."""
+    spec = examples.CONFIGS[name]()
+    spec.params.initial_alpha_scaling = 0.5
+    spec.params.expected_decrease_fraction = 0.01
+    spec.params.convergence_tolerance = 0.1
+    if name == "three_player_intersection":
+        spec.params.max_solver_iters = 60
+    B = 8
+    x0 = examples.jittered_x0(spec, B, seed=3)
+    x0[0] = spec.x0
+    ref, out, agree_all, matched = _compare_simulation(hip, oracle, spec, x0, 4.0, al, 16)
+    nrec = _np(out["num_records"])
     assert agree_all >= 2 and matched >= 0.5 * ref["num_records"].sum(), (agree_all, matched, nrec, ref["num_records"])
     assert ref["num_records"].max() >= 6 and (ref["plan"]["len"] > spec.T).any()  # the loop ran and spliced
 
@@ -315,3 +330,32 @@ def test_receding_harness_kernels_fp32_match_fp32_oracle(hip, oracle):
         L = plan["len"][b]
         for key in ("xs", "us", "P", "alpha"):
             assert np.array_equal(_np(dplan[key])[b, :L], plan[key][b, :L]), (b, key)
+
+
+def test_config5_receding_horizon_with_the_augmented_lagrangian_solver_fp64(hip, oracle):
+    """BASELINE config 5 as written, at a batch the oracle can follow: ThreePlayerCollisionAvoidanceReachabilityExample
+    with the solver parameters of its receding-horizon main (alpha0 = 0.1, fraction 0.1, tolerance 0.01),
+    AugmentedLagrangianSolver::Solve at every replanning instant, 64 jittered instances, 11 s of simulated time
+    (the planning horizon is 10 s: 22 solver calls for an instance that stays in the loop), every call of every
+    instance against the oracle's RecedingHorizonSimulator (src/receding_horizon_simulator.cpp:64-137 around
+    src/augmented_lagrangian_solver.cpp:72-210).
+    The reference CHECKs success after its first solve (:77): an instance whose first solve reports failure leaves
+    the loop there, on both sides — that, not a defect, is why most jittered instances of this scene stop after
+    call 1 (the example's own x0, instance 0 here, is one that stays)."""
+    spec = examples.three_player_collision_avoidance_reachability()
+    B = 64
+    x0 = examples.jittered_x0(spec, B, seed=5)
+    x0[0] = spec.x0
+    ref, out, agree_all, matched = _compare_simulation(hip, oracle, spec, x0, 11.0, True, 24)
+    nrec = _np(out["num_records"])
+    assert ref["num_records"].max() >= 20, ref["num_records"]  # someone replans >= 20 times
+    # who stays in the loop after the first call is decided by the first solve's success flag, identically
+    stays_ref = ref["num_records"] > 1
+    stays_dev = nrec > 1
+    first_ok = ref["ok"][:, 0] == 1
+    assert np.array_equal(stays_ref, first_ok & stays_ref) and (stays_ref == stays_dev).mean() >= 0.9
+    # Measured: 40 of the 64 instances agree to the end, 42 of the 108 solver calls match before a decision falls the
+    # other way (every one of those at a line search deeper than 2^-12 or a failed one — asserted above): this
+    # scene's line search is noise-limited from its second iteration on (test_gpu_parity.py), and a receding-horizon
+    # run strings twenty of them together.  The per-iterate comparison of this scene is test_gpu_forced.py.
+    assert agree_all >= 0.5 * B and matched >= 0.3 * ref["num_records"].sum(), (agree_all, matched, nrec, ref["num_records"])
