@@ -199,7 +199,7 @@ __global__ void solve_state_kernel(const T* ws, size_t ws_stride, size_t state_o
   if (last_merit) last_merit[b] = s->last_merit;
   if (expected_decrease) expected_decrease[b] = s->expected_decrease;
   if (step) step[b] = s->acc_scale;
-  if (backtracks) backtracks[b] = s->bt;
+  if (backtracks) backtracks[b] = s->rejected;
 }
 
 // What follows the per-instance blocks in a solve's workspace: two lists of instance ids (this round's back-tracking
@@ -987,6 +987,7 @@ ilqg_status ilqg_problem_create(const ilqg_problem_desc* desc, ilqg_problem** ou
   }
   d.n = d.xoff[d.N];
   d.m = d.uoff[d.N];
+  d.sync_dist_dims = d.sub_kind[0] == ILQG_DYN_DUBINS_CAR ? 3 : d.sub_kind[0] == ILQG_DYN_UNICYCLE_4D_DISTURBED ? 4 : 2;
   // pair table in PlayerCost first-touch order: control costs, then control constraints
   std::vector<ilqg_pair> pairs;
   std::vector<int> from_cost;

@@ -76,6 +76,11 @@ struct DevProblem {
   const int* cost_order;
   int cost_order_stride;
   int num_constraints;
+  // MultiPlayerIntegrableSystem::DistanceBetween as Problem::SyncToExistingProblem uses it (src/problem.cpp:105-110):
+  // squared distance over the first sync_dist_dims entries of the state — the position of the first subsystem for
+  // the car / unicycle / point-mass models (their overrides) and Air3D, the first subsystem's whole state where the
+  // model inherits the default (SinglePlayerDubinsCar; TwoPlayerUnicycle4D: the whole state)
+  int sync_dist_dims;
   PairTable pairs;
   // Row program of the lane-per-time-step quadraticisation stage (ilqg_rows.hpp; built by build_row_program)
   const int* row_prog;

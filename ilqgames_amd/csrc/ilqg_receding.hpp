@@ -197,13 +197,17 @@ __global__ void __launch_bounds__(64) receding_sync_kernel(DevProblem p, Recedin
   PlanStepper<T> st{p, pl, sx, su, t};
   st.to_next_step(a.t);
   st.whole_steps(int_begin, int_end);
-  // nearest plan state by the first subsystem's position (concatenated_dynamical_system.cpp:109-113);
-  // std::min_element keeps the first minimum
+  // nearest plan state in the first subsystem's metric (concatenated_dynamical_system.cpp:109-113: its position for
+  // the car / unicycle / point-mass models, its whole state where the model inherits the default squared norm —
+  // DevProblem::sync_dist_dims); std::min_element keeps the first minimum
   T bestd = dinf<T>();
   int bestk = 0x7fffffff;
   for (int k = t; k < pl.len; k += 64) {
-    const T dx = sx[0] - pl.xs[size_t(k) * n + 0], dy = sx[1] - pl.xs[size_t(k) * n + 1];
-    const T d = dx * dx + dy * dy;
+    T d = T(0);
+    for (int e = 0; e < p.sync_dist_dims; e++) {
+      const T de = sx[e] - pl.xs[size_t(k) * n + e];
+      d += de * de;
+    }
     if (d < bestd) {
       bestd = d;
       bestk = k;

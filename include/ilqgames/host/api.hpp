@@ -923,6 +923,7 @@ class GameSolver {
   GameSolver(const std::shared_ptr<Problem>& problem, const SolverParams& params, bool augmented_lagrangian);
   virtual std::shared_ptr<SolverLog> CreateNewLog() const { return std::make_shared<SolverLog>(); }
   host::BatchResult SolveOne();  // Solve(): one instance; a repeated call continues this solver object's state
+  void RefreshDevice();          // (re)builds the device tables when the Problem / SolverParams no longer match them
   const std::shared_ptr<Problem> problem_;
   const SolverParams params_;
 

@@ -1639,11 +1639,14 @@ int RecedingHorizonShift(const Problem<S>& p, const RecedingHorizonTimes& tm, co
     x = Integrate(p, 0.0, p.dt, x, ApplyStrategies(p, *st, kk, x, op->xs[kk], op->us[kk]), false);
   // nearest plan state: ConcatenatedDynamicalSystem::DistanceBetween looks at the first subsystem only
   // (concatenated_dynamical_system.cpp:109-113); the car / unicycle models measure squared position distance
+  // — SinglePlayerDubinsCar inherits the default, the squared norm of its whole state (single_player_dynamical_system.h:69),
+  // and so does TwoPlayerUnicycle4D (multi_player_integrable_system.h:113)
+  const int dist_dims = p.subs[0].kind == ILQG_DYN_DUBINS_CAR ? 3 : p.subs[0].kind == ILQG_DYN_UNICYCLE_4D_DISTURBED ? 4 : 2;
   int first = 0;
   S best = std::numeric_limits<S>::infinity();
   for (int k = 0; k < T; k++) {
-    const S dx = x[0] - op->xs[k][0], dy = x[1] - op->xs[k][1];
-    const S d = dx * dx + dy * dy;
+    S d = 0;
+    for (int e = 0; e < dist_dims; e++) d += (x[e] - op->xs[k][e]) * (x[e] - op->xs[k][e]);
     if (d < best) {  // std::min_element keeps the first minimum
       best = d;
       first = k;
@@ -1769,11 +1772,13 @@ int SetUpNextRecedingHorizon(const Problem<S>& p, const Vec<S>& x0, double t0, d
   const RecedingHorizonTimes tm = RecedingHorizonTimesOf(t0, planner_runtime, pl->t0, p.dt);
   Vec<S> x = IntegrateToNextTimeStep(p, t0, x0, *pl);
   x = IntegrateSteps(p, size_t(tm.integrate_begin), size_t(tm.integrate_end), x, *pl);
+  // nearest plan state in the first subsystem's DistanceBetween (see RecedingHorizonShift above)
+  const int dist_dims = p.subs[0].kind == ILQG_DYN_DUBINS_CAR ? 3 : p.subs[0].kind == ILQG_DYN_UNICYCLE_4D_DISTURBED ? 4 : 2;
   int first = 0;
   S best = std::numeric_limits<S>::infinity();
   for (int k = 0; k < pl->len(); k++) {
-    const S dx = x[0] - pl->op.xs[k][0], dy = x[1] - pl->op.xs[k][1];
-    const S d = dx * dx + dy * dy;
+    S d = 0;
+    for (int e = 0; e < dist_dims; e++) d += (x[e] - pl->op.xs[k][e]) * (x[e] - pl->op.xs[k][e]);
     if (d < best) {
       best = d;
       first = k;

@@ -406,12 +406,14 @@ def test_augmented_lagrangian_single_player_dubins_fp64(hip, oracle):
     assert np.isfinite(_np(out["xs"])).all()
 
 
+@pytest.mark.parametrize("scene", ["modified_three_player_intersection", "dubins_origin"])
 @pytest.mark.parametrize("t0,runtime", [(0.33, 0.25), (0.0, 0.1), (1.07, 0.0), (2.5, 0.4)])
-def test_receding_horizon_shift_matches_oracle_fp64(hip, oracle, t0, runtime):
+def test_receding_horizon_shift_matches_oracle_fp64(hip, oracle, t0, runtime, scene):
     """Problem::SetUpNextRecedingHorizon on device vs the oracle's restatement: same nearest-state index, same
     shifted / zero-extended / re-propagated plan, same stitched initial state; then the warm-started solve from
-    it reproduces the oracle's."""
-    spec = examples.modified_three_player_intersection()
+    it reproduces the oracle's.  dubins_origin: an ego whose model inherits the default DistanceBetween (the squared
+    norm of its whole state, heading included — single_player_dynamical_system.h:69) instead of a position metric."""
+    spec = examples.CONFIGS[scene]()
     spec.params.initial_alpha_scaling = 0.5
     spec.params.expected_decrease_fraction = 0.001
     B = 6

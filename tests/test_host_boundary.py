@@ -134,3 +134,27 @@ def test_two_rank_sharding_and_gather_over_gloo(tmp_path):
     outs = [p.communicate(timeout=240)[0] for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
+
+
+def test_bench_two_rank_path_over_gloo():
+    """The code `bench.py --gpus N` executes for N > 1 — contiguous shards of the global batch, the gather of the
+    strategies to rank 0 through ilqgames_amd/sharding.py, max-over-ranks timing, one JSON line from rank 0 — launched
+    exactly as the driver launches it (torch.distributed.run, one process per rank), with the device solve replaced
+    by the CPU stand-in of `--backend stub` and gloo in place of RCCL.  The stand-in's strategy of global instance b
+    is b, and bench.py itself asserts on rank 0 that the gathered rows are 0 .. world * batch - 1 in order."""
+    import json
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "stub", "--steps", "2",
+           "--warmup", "1", "--batch", "5"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak"
+    assert out["value"] > 0 and abs(out["value"] * out["ms_per_step"] * 1e-3 * out["steps"] - 2 * 5 * 2) < 1e-6
