@@ -5,13 +5,14 @@
 //     W_i = R_ii^{-1} B_i^T, w_i = R_ii^{-1} r_ii                       (LDLT of R_ii, :119-126)
 //     Lambda = I + sum_i B_i W_i M_i[k+1]                               (:127-128)
 //     c = -sum_i B_i (W_i m_i[k+1] + w_i)                               (:134-139)
-//     X = Lambda^{-1} A, y = Lambda^{-1} c                              (Householder QR, :131,144,148)
+//     X = Lambda^{-1} A, y = Lambda^{-1} c                              (:131,144,148; here through the matrix
+//                                                                        inversion lemma: an m x m system)
 //     M_i[k] = Q_i + A^T M_i[k+1] X,   m_i[k] = l_i + A^T (m_i[k+1] + M_i[k+1] y)   (:141-150)
 //   forward, k = 0 .. T-2:
 //     x_{k+1} = Lambda_k^{-1} (A x_k + c_k) = X_k x_k + y_k             (:165)
 //     alpha_i,k = W_i,k (M_i[k+1] x_{k+1} + m_i[k+1]) + w_i,k           (:169-172);  P == 0
-// Mapping: lane (i,c) owns column c of player i's M_i update; the n x n system Lambda [X | y] = [A | c]
-// sits one column per lane in wave 0 (2n+1 columns) and reuses the feedback sweep's shuffle-free
+// Mapping: lane (i,c) owns column c of player i's M_i update; the m x m system K [Z | z] = [V A | V c] behind
+// Lambda^{-1} sits one column per lane in wave 0 (m + n + 1 columns) and reuses the feedback sweep's shuffle-free
 // Householder QR; the per-step blocks are staged by LDS-DMA exactly like the feedback sweep.  The
 // backward pass leaves one scratch row per step ([X|y|W|w|M|m|Q l]) for the forward pass.
 #pragma once
@@ -25,7 +26,7 @@ struct OLCfg {
   using C = LQCfg<T, NX, NP, MU>;
   static constexpr int M = NP * MU;
   static constexpr int NT = C::NT;
-  static_assert(2 * NX + 1 <= 64, "Lambda [X | y] = [A | c] must fit one wavefront");
+  static_assert(NP * MU + NX + 1 <= 64, "K [Z | z] = [V A | V c] must fit one wavefront");
   // scratch row (global), one per time step
   static constexpr int rX = 0;
   static constexpr int ry = rX + NX * NX;
@@ -219,32 +220,60 @@ __device__ __forceinline__ void lq_openloop_instance(const LQArgs<T>& a, const P
     }
     lds_sync(NT <= 64);
     PH(1);
-    // ---- Lambda [X | y] = [A | c], one column per lane (wave 0) ----
+    // ---- Lambda [X | y] = [A | c] through the matrix inversion lemma (wave 0) ----
+    // Lambda = I + B V with B = [B_0 .. B_{N-1}] (n x m) and V = [W_0 M_0; ..; W_{N-1} M_{N-1}] (m x n): a rank-m
+    // update of the identity, so  Lambda^{-1} = I - B K^{-1} V,  K = I_m + V B  (m x m), and
+    //     X = A - B Z,  y = c - B z,   K [Z | z] = [V A | V c].
+    // The reference factors the n x n Lambda by Householder QR (:131) and solves for n + 1 right-hand sides — 24
+    // dependent reflections per step at n = 24, which was half of this sweep; the m x m system (8 x 8) takes the
+    // same column-per-lane QR (M columns of K, then the NX + 1 right-hand sides).  Both are the solution of the same
+    // linear system; the parity tests compare with the QR oracle.
     if (t < 64) {
-      T col[NX], x[NX];
+      static_assert(M + NX + 1 <= 64, "K [Z | z] = [V A | V c] must fit one wavefront");
+      T col[M], x[M];
+#pragma unroll
+      for (int q = 0; q < M; q++) {
+        col[q] = T(0);
+        x[q] = T(0);
+      }
+      const bool isK = t < M, isA = t >= M && t < M + NX, isc = t == M + NX;
+      const int cidx = isA ? t - M : 0;
+      // this lane's vector v (a column of B, a column of A, or c = -B g), then V v
+      T cvec[NX];
 #pragma unroll
       for (int r = 0; r < NX; r++) {
         T v = T(0);
-        if (t < NX) {
-          v = (r == t) ? T(1) : T(0);
-#pragma unroll
-          for (int q = 0; q < M; q++) v += sB[r + NX * q] * sV[q + M * t];
-        } else if (t < 2 * NX) {
-          v = sA[r + NX * (t - NX)];
-        } else if (t == 2 * NX) {
+        if (isK) {
+          v = sB[r + NX * t];
+        } else if (isA) {
+          v = sA[r + NX * cidx];
+        } else if (isc) {
 #pragma unroll
           for (int q = 0; q < M; q++) v -= sB[r + NX * q] * sg[q];
         }
-        col[r] = v;
-        x[r] = T(0);
+        cvec[r] = v;
       }
-      qr_solve_columns<T, NX>(col, lane, x);
-      if (t >= NX && t < 2 * NX) {
 #pragma unroll
-        for (int r = 0; r < NX; r++) sX[r + NX * (t - NX)] = x[r];
-      } else if (t == 2 * NX) {
+      for (int r = 0; r < NX; r++) {
 #pragma unroll
-        for (int r = 0; r < NX; r++) sy[r] = x[r];
+        for (int q = 0; q < M; q++) col[q] += sV[q + M * r] * cvec[r];
+      }
+      if (isK) {
+#pragma unroll
+        for (int q = 0; q < M; q++) col[q] += (q == t) ? T(1) : T(0);
+      }
+      qr_solve_columns<T, M>(col, lane, x);
+      if (isA || isc) {
+#pragma unroll
+        for (int r = 0; r < NX; r++) {
+          T v = cvec[r];
+#pragma unroll
+          for (int q = 0; q < M; q++) v -= sB[r + NX * q] * x[q];
+          if (isA)
+            sX[r + NX * cidx] = v;
+          else
+            sy[r] = v;
+        }
       }
     }
     {  // W, w of this step -> scratch row k (forward pass)

@@ -16,7 +16,10 @@ time.  The test measures that amplification instead of guessing it: the fp64 ora
 from x0 + 1e-12, and an (instance, iteration) pair is compared where the two oracle runs still agree to 1e-8, i.e.
 where the iteration amplifies a perturbation by less than 1e4.  There the fp64 device must match the fp64 oracle to
 1e-9 relative, the fp32 device the fp32 oracle to 2e-3 on the operating point and 1e-2 on P / alpha (fp32 round-off
-x that amplification x the conditioning of the Nash system).  Coverage is asserted: at least three
+x that amplification x the conditioning of the Nash system).  The conditioning of the LQ solve in
+fp32 is measured the same way: a pair is skipped for fp32 where the fp32 oracle's own P / alpha are further than
+2e-3 from the fp64 oracle's (more than half of fp32's digits gone in the reference arithmetic itself; two correct
+fp32 implementations — Householder QR of Lambda and the m x m form of it alike — then differ by as much).  Coverage is asserted: at least three
 quarters of the instances at the first iteration and 70 % of all (instance, iteration) pairs.
 """
 import numpy as np
@@ -78,6 +81,7 @@ def test_every_instance_matches_after_every_iteration(hip, oracle, scene, dtype)
     f64 = dtype == abi.F64
     tol_op, tol_st = (1e-9, 1e-9) if f64 else (2e-3, 1e-2)
     amp_limit = 1e-8
+    lost32 = 2e-3
     compared = 0
     for k in range(1, K + 1):
         ref = op.solve(dtype, x0, fixed_iters=k, forced_steps=steps[:, :k], merit_log_len=k)
@@ -95,6 +99,8 @@ def test_every_instance_matches_after_every_iteration(hip, oracle, scene, dtype)
             amp = _inst_err(one(r64n), one(r64), (("xs", "xs"), ("us", "us"), ("rawP", "rawP"), ("alpha", "alpha")))
             if not (amp <= amp_limit and np.isfinite(merit_ref[b])):
                 continue
+            if not f64 and _inst_err(one(ref), one(r64), (("rawP", "rawP"), ("alpha", "alpha"))) > lost32:
+                continue  # the fp32 reference arithmetic itself has lost more than half its digits here
             compared += 1
             first += k == 1
             where = "%s k=%d instance %d (amplification of 1e-12: %.1e)" % (scene, k, b, amp)
