@@ -59,6 +59,7 @@ struct LQBatchArgs {
   const T *A, *Bm, *Q, *l, *R, *r, *x0;
   T *P, *alpha, *dx, *scratch;
   int T_steps, adaptive, batch, force_valu;
+  T* costates = nullptr;
 };
 
 template <typename T, int NX, int NP, int MU, bool FORCE_VALU>
@@ -89,7 +90,7 @@ lq_feedback_kernel(LQBatchArgs<T> g, PairTable pt) {
 }
 
 template <typename T, int NX, int NP, int MU>
-__global__ void __launch_bounds__((LQCfg<T, NX, NP, MU>::NT))
+__global__ void __launch_bounds__((OLCfg<T, NX, NP, MU>::NT))
 lq_openloop_kernel(LQBatchArgs<T> g, PairTable pt) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   T* sm = reinterpret_cast<T*>(smem_raw);
@@ -107,7 +108,8 @@ lq_openloop_kernel(LQBatchArgs<T> g, PairTable pt) {
   a.P = g.P + b * Tn * M * NX;
   a.alpha = g.alpha + b * Tn * M;
   a.dx = g.dx ? g.dx + b * Tn * NX : nullptr;
-  a.scratch = g.scratch + b * Tn * OLCfg<T, NX, NP, MU>::ROW;
+  a.scratch = g.scratch + b * Tn * (g.costates ? OLCfg<T, NX, NP, MU>::ROW_FAT : OLCfg<T, NX, NP, MU>::ROW);
+  a.costates = g.costates ? g.costates + b * Tn * NP * NX : nullptr;
   a.ed_out = nullptr;
   a.T_steps = g.T_steps;
   a.adaptive = 0;
@@ -356,7 +358,7 @@ __global__ void __launch_bounds__(64) ilq_exit_kernel(DevProblem p, SolveArgs<T>
 
 // LQ kernel: the Riccati sweep at the accepted operating point of every instance that asked for one.
 template <typename T, int NX, int NP, int MU, int KIND>
-__global__ void __launch_bounds__((KIND == LQ_PLAYER_WAVES ? 64 * NP : LQCfg<T, NX, NP, MU>::NT),
+__global__ void __launch_bounds__((KIND == LQ_VALU_FEEDBACK ? LQCfg<T, NX, NP, MU>::NT : 64 * NP),
                                   (KIND == LQ_PLAYER_WAVES ? NP : 1))
 ilq_lq_kernel(DevProblem p, SolveArgs<T> sa) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -454,7 +456,7 @@ struct __attribute__((visibility("hidden"))) DimsLaunch {
                         hipStream_t stream);
   static ilqg_status lq_openloop(const ilqg_dims* d, const PairTable& pt, const void* A, const void* Bm,
                                  const void* Q, const void* l, const void* R, const void* r, const void* x0, void* P,
-                                 void* alpha, void* dx, hipStream_t stream);
+                                 void* alpha, void* dx, void* costates, hipStream_t stream);
   static ilqg_status solve(ilqg_problem* p, int32_t batch, const void* x0, void* xs, void* us, void* P, void* alpha,
                            void* total_costs, int32_t* iters, int32_t* status, int32_t* converged, void* workspace,
                            const ilqg_solve_options& opt, hipStream_t stream);
@@ -513,14 +515,14 @@ template <typename T, int NX, int NP, int MU>
 ilqg_status DimsLaunch<T, NX, NP, MU>::lq_openloop(const ilqg_dims* d, const PairTable& pt, const void* A,
                                                    const void* Bm, const void* Q, const void* l, const void* R,
                                                    const void* r, const void* x0, void* P, void* alpha, void* dx,
-                                                   hipStream_t stream) {
-  using C = LQCfg<T, NX, NP, MU>;
+                                                   void* costates, hipStream_t stream) {
   using O = OLCfg<T, NX, NP, MU>;
   LQBatchArgs<T> g;
   g.A = (const T*)A; g.Bm = (const T*)Bm; g.Q = (const T*)Q; g.l = (const T*)l;
   g.R = (const T*)R; g.r = (const T*)r; g.x0 = (const T*)x0;
   g.P = (T*)P; g.alpha = (T*)alpha; g.dx = (T*)dx;
-  const size_t need = size_t(d->batch) * d->T * O::ROW * sizeof(T);
+  g.costates = (T*)costates;
+  const size_t need = size_t(d->batch) * d->T * (costates ? O::ROW_FAT : O::ROW) * sizeof(T);
   ilqg_status s = g_scratch.reserve(need);
   if (s != ILQG_OK) return s;
   g.scratch = (T*)g_scratch.ptr;
@@ -531,7 +533,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::lq_openloop(const ilqg_dims* d, const Pai
   const size_t lds = size_t(O::LDS_ELEMS) * sizeof(T);
   auto kern = lq_openloop_kernel<T, NX, NP, MU>;
   raise_lds_limit((const void*)kern, lds);
-  hipLaunchKernelGGL(kern, dim3(d->batch), dim3(C::NT), lds, stream, g, pt);
+  hipLaunchKernelGGL(kern, dim3(d->batch), dim3(O::NT), lds, stream, g, pt);
   HIP_TRY(hipGetLastError());
   return ILQG_OK;
 }
@@ -588,7 +590,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   const int al_mode = opt.augmented_lagrangian ? 1 : 0, resume = opt.resume ? 1 : 0;
   const int32_t* const active = opt.active;
   auto choice = [](int32_t c, bool automatic) { return c == ILQG_CHOICE_ON ? true : (c == ILQG_CHOICE_OFF ? false : automatic); };
-  static_assert(OLCfg<T, NX, NP, MU>::ROW == ((NX * NX + NX + NP * MU * NX + NP * MU + NP * NX * NX + 2 * NP * NX + 3) & ~3), "ol_row_elems");
+  static_assert(OLCfg<T, NX, NP, MU>::ROW == ((NX * NX + NX + NP * MU * NX + NP * MU + NP * NX + 3) & ~3), "ol_row_elems");
   const int ol_row = p->desc.params.open_loop ? ol_row_elems(d.n, d.m, d.N) : 0;
   const WsLayout L(d.n, d.m, d.N, d.T, d.pairs.Rsz, d.pairs.rsz, ol_row, d.num_constraints, al_mode);
   SolveArgs<T> sa;
@@ -630,7 +632,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   auto k_lq = pw ? ilq_lq_kernel<T, NX, NP, MU, (C::USE_MFMA ? LQ_PLAYER_WAVES : LQ_VALU_FEEDBACK)>
                  : (p->desc.params.open_loop ? ilq_lq_kernel<T, NX, NP, MU, LQ_OPEN_LOOP>
                                              : ilq_lq_kernel<T, NX, NP, MU, LQ_VALU_FEEDBACK>);
-  const int nt_lq = pw ? 64 * NP : C::NT;
+  const int nt_lq = (pw || p->desc.params.open_loop) ? 64 * NP : C::NT;
   raise_lds_limit((const void*)k_trial, lds_trial);
   raise_lds_limit((const void*)k_lq, lds_lq);
 
@@ -906,7 +908,7 @@ ilqg_status ilqg_lq_openloop_batch(const ilqg_dims* d, const void* A, const void
   if (d->num_players < 1 || d->num_players > ILQG_MAX_PLAYERS || d->n < 1 || d->n > ILQG_MAX_XDIM || d->T < 2 ||
       d->T > kMaxT || d->batch < 0)
     return fail(ILQG_ERR_INVALID, "bad dimensions");
-  if (costates) return fail(ILQG_ERR_UNSUPPORTED, "costates are not produced on device (ILQSolver ignores them)");
+  if (costates && !dx) return fail(ILQG_ERR_INVALID, "costates come with delta_xs (lq_open_loop_solver.cpp:83-84)");
   for (const void* ptr : {A, Bm, Q, l, R, r})
     if (reinterpret_cast<uintptr_t>(ptr) % 16 != 0) return fail(ILQG_ERR_INVALID, "array bases must be 16-byte aligned");
   PairTable pt;
@@ -922,8 +924,8 @@ ilqg_status ilqg_lq_openloop_batch(const ilqg_dims* d, const void* A, const void
 #define X(NX_, NP_, MU_)                                                                                      \
   if (d->n == NX_ && d->num_players == NP_ && mu == MU_) {                                                    \
     return d->dtype == ILQG_F32                                                                               \
-               ? DimsLaunch<float, NX_, NP_, MU_>::lq_openloop(d, pt, A, Bm, Q, l, R, r, x0, P, alpha, dx, st)     \
-               : DimsLaunch<double, NX_, NP_, MU_>::lq_openloop(d, pt, A, Bm, Q, l, R, r, x0, P, alpha, dx, st);   \
+               ? DimsLaunch<float, NX_, NP_, MU_>::lq_openloop(d, pt, A, Bm, Q, l, R, r, x0, P, alpha, dx, costates, st)     \
+               : DimsLaunch<double, NX_, NP_, MU_>::lq_openloop(d, pt, A, Bm, Q, l, R, r, x0, P, alpha, dx, costates, st);   \
   }
   ILQG_FOR_DIMS(X)
 #undef X

@@ -33,6 +33,7 @@ struct LQArgs {
   T *P, *alpha, *dx;                // [T][m*n], [T][m], [T][n] (dx may be nullptr)
   T* scratch;                       // [T][N*(n+1) + n] when dx/ed requested, else nullptr
   T* ed_out;                        // expected decrease (one scalar) or nullptr
+  T* costates = nullptr;            // [T][N][n] or nullptr (lq_solver.h:63-69)
   int T_steps;
   int adaptive;
   int symmetric = 0;                // 1: every Q_i and R_ij is exactly symmetric (what the quadraticisation stage writes)

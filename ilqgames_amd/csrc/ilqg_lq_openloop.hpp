@@ -1,66 +1,109 @@
-// ilqg_lq_openloop.hpp — open-loop LQ Nash sweep for ONE game instance per workgroup (gfx950).
+// ilqg_lq_openloop.hpp — open-loop LQ Nash sweep for ONE game instance per workgroup (gfx950), on the matrix cores.
 //
 // Computes what LQOpenLoopSolver::Solve computes (src/lq_open_loop_solver.cpp:73-195):
 //   backward, k = T-2 .. 0:
 //     W_i = R_ii^{-1} B_i^T, w_i = R_ii^{-1} r_ii                       (LDLT of R_ii, :119-126)
 //     Lambda = I + sum_i B_i W_i M_i[k+1]                               (:127-128)
 //     c = -sum_i B_i (W_i m_i[k+1] + w_i)                               (:134-139)
-//     X = Lambda^{-1} A, y = Lambda^{-1} c                              (:131,144,148; here through the matrix
-//                                                                        inversion lemma: an m x m system)
+//     X = Lambda^{-1} A, y = Lambda^{-1} c                              (:131,144,148)
 //     M_i[k] = Q_i + A^T M_i[k+1] X,   m_i[k] = l_i + A^T (m_i[k+1] + M_i[k+1] y)   (:141-150)
 //   forward, k = 0 .. T-2:
 //     x_{k+1} = Lambda_k^{-1} (A x_k + c_k) = X_k x_k + y_k             (:165)
 //     alpha_i,k = W_i,k (M_i[k+1] x_{k+1} + m_i[k+1]) + w_i,k           (:169-172);  P == 0
-// Mapping: lane (i,c) owns column c of player i's M_i update; the m x m system K [Z | z] = [V A | V c] behind
-// Lambda^{-1} sits one column per lane in wave 0 (m + n + 1 columns) and reuses the feedback sweep's shuffle-free
-// Householder QR; the per-step blocks are staged by LDS-DMA exactly like the feedback sweep.  The
-// backward pass leaves one scratch row per step ([X|y|W|w|M|m|Q l]) for the forward pass.
+//     costate_i,k = A_k^T (M_i[k+1] x_{k+1} + m_i[k+1])                 (:176; zero at k = T-1, :191)
+//
+// How it is laid out here.
+//   * Homogeneous coordinates.  With n' = n + 1 and
+//         Ma_i = [M_i m_i; 0 0],  Xa = [X y; 0 1],  Aa = [A 0; 0 1],  Qa_i = [Q_i l_i; 0 0]
+//     the two recursions are ONE matrix recursion  Ma_i[k] = Qa_i + Aa^T (Ma_i[k+1] Xa):  the vector parts ride in
+//     column n of products that are computed anyway.
+//   * One wavefront per player.  Wave i holds Ma_i (and its transpose) as 16 x 16 accumulator-layout tiles
+//     (ilqg_mfma.hpp; n' <= 32: a 2 x 2 block of tiles) and runs both products as chains of v_mfma_*_16x16x4; k blocks
+//     whose rows are identically zero are skipped at compile time.  The transpose for the next step goes through the
+//     wave's own LDS tile (write the result, read it back transposed) — the same tile the DMA engine fills with
+//     Q_i | l_i of the next step once it has been read.
+//   * Lambda^{-1} through the matrix inversion lemma.  Lambda = I + B V with B = [B_0 .. B_{N-1}] (n x m) and
+//     V = [W_0 M_0; ..] (m x n) is a rank-m update of the identity:
+//         Lambda^{-1} = I - B K^{-1} V,  K = I_m + V B          =>   X = A - B Z,  Z = K^{-1} (V A)
+//                                                                     y = -B K^{-1} g,  g_i = W_i m_i + w_i
+//     (y: c = -B g and V c = -(K - I) g, so K^{-1} V c = -g + K^{-1} g.)  The reference factors the n x n Lambda by
+//     Householder QR (:131); here the m x m system K [Z | z] = [V A | g] takes the column-per-lane Householder QR of
+//     the feedback sweep in wave 0 (m + n + 1 columns), everything around it is spread over the workgroup:
+//     [V_i | g_i] = R_ii^{-1} (B_i^T Ma_i + [0 | r_ii]) per wave (MFMA + LDL^T), [K | V A] one entry per thread,
+//     Xa = Aa - B [Z | z] per wave on the matrix cores (every wave needs Xa, so every wave computes it).
+//     Both forms solve the same linear system; the parity tests compare with the QR oracle.
+//   * The forward pass needs, per step, X, y, V = [W_i M_i[k+1]], g and (for the expected decrease) Q_i l_i:
+//     alpha_i,k = V_i x_{k+1} + g_i.  That is the scratch row the backward pass leaves (n^2 + n + m n + m + N n
+//     elements; M_i, m_i are appended only when costates are asked for).
 #pragma once
 
 #include "ilqg_lq.hpp"
 
 namespace ilqg {
 
+// Leading dimension of an accumulator-layout operand in LDS: lane (g, j) reads element [row(g, r)][j], so the 16
+// columns of a tile must fall on different banks.  fp64 (ds_read_b64, 64 banks, lanes 0-31 = g in {0, 1} per LDS
+// cycle): LD = 2 * odd puts the 16 columns on the even double-words and g on the odd ones.  fp32: LD odd.
+template <typename T>
+constexpr int pad_ld(int n) {
+  if (sizeof(T) == 8) {
+    int l = n;
+    while (l % 4 != 2) l++;
+    return l;
+  }
+  return n | 1;
+}
+
 template <typename T, int NX, int NP, int MU>
 struct OLCfg {
   using C = LQCfg<T, NX, NP, MU>;
   static constexpr int M = NP * MU;
-  static constexpr int NT = C::NT;
-  static_assert(NP * MU + NX + 1 <= 64, "K [Z | z] = [V A | V c] must fit one wavefront");
-  // scratch row (global), one per time step
+  static constexpr int NT = 64 * NP;  // one wavefront per player
+  static constexpr int NH = NX + 1;   // homogeneous dimension
+  static constexpr int NTL = (NH + 15) / 16;
+  static_assert(NH <= 32, "the homogeneous matrices are held as 2 x 2 tiles at most");
+  static_assert(M <= 16, "the rows of V must fit one tile");
+  static_assert(M + NX + 1 <= 64, "K [Z | z] = [V A | g] must fit one wavefront");
+  static constexpr int LD = pad_ld<T>(NH);
+  static constexpr int MAT = (NH * LD + 3) & ~3;  // one padded n' x n' matrix
+  static constexpr int LDZ = pad_ld<T>(M);
+  // scratch row (global), one per time step: [X | y | V | g | Q_i l_i]  (+ [M_i | m_i] when costates are wanted)
   static constexpr int rX = 0;
   static constexpr int ry = rX + NX * NX;
-  static constexpr int rW = ry + NX;
-  static constexpr int rw = rW + M * NX;
-  static constexpr int rM = rw + M;
-  static constexpr int rm = rM + NP * NX * NX;
-  static constexpr int rql = rm + NP * NX;
+  static constexpr int rV = ry + NX;
+  static constexpr int rg = rV + M * NX;
+  static constexpr int rql = rg + M;
   static constexpr int ROW = (rql + NP * NX + 3) & ~3;
-  // LDS (elements): DMA image(s), then working set.  Two images (DMA of step k-1 under step k) when that keeps
-  // the instance under ~48 KB; the n = 24 problems would take 92 KB and leave a CU with a single resident
-  // instance (two waves on four SIMDs), so they run single-buffered: a step there is ~40 us, the exposed DMA
-  // round trip ~1 us, and three instances per CU are worth far more than the overlap.
-  static constexpr int FS_ = ROW + NP * NX * NX + NP * NX + 4;
-  static constexpr bool DB = (2 * (C::IMG > FS_ ? C::IMG : FS_) + NP * NX * NX + 2 * NX * NX) * int(sizeof(T)) <= 48 * 1024;
-  static constexpr int NB = DB ? 2 : 1;
-  static constexpr int oM = NB * C::IMG;
-  static constexpr int om = oM + NP * NX * NX;
-  static constexpr int oW = om + NP * NX;
-  static constexpr int ow = oW + M * NX;
-  static constexpr int oV = ow + M;
-  static constexpr int og = oV + M * NX;
-  static constexpr int oX = og + M;
-  static constexpr int oy = oX + NX * NX;
-  static constexpr int oT = oy + NX;
-  static constexpr int LDS_BWD = oT + NP * NX;
-  // forward pass: overlays the backward working set — two staged scratch rows, then x, x+, it, alpha
-  static constexpr int FS = FS_;
-  static constexpr int fxs = NB * FS;
-  static constexpr int fT = fxs + 2 * NX;
-  static constexpr int fg = fT + NP * NX;
-  static constexpr int LDS_FWD = fg + M;
+  static constexpr int rM = ROW;
+  static constexpr int rm = rM + NP * NX * NX;
+  static constexpr int ROW_FAT = (rm + NP * NX + 3) & ~3;
+  // LDS (elements), backward pass.  The accumulator-layout reads of edge tiles touch (and discard) elements up to
+  // 31 rows / columns from a matrix base, so the padded matrices come last and SLACK elements follow them.
+  static constexpr int BIMG = ((NX * M + 3) & ~3) + C::RMAX + C::rMAX;  // [B | R | r] of one step (double-buffered)
+  static constexpr int oV = 0;                    // V (m x n, column-major)
+  static constexpr int og = oV + M * NX;          // g (m)
+  static constexpr int oKA = (og + M + 3) & ~3;   // [K | V A] (m x (m + n))
+  static constexpr int oBt = oKA + M * (M + NX);  // per player: B_i^T Ma_i bounce (mu x n')
+  static constexpr int oZs = (oBt + NP * MU * NH + 3) & ~3;  // [Z | z] (m x n', leading dimension LDZ)
+  static constexpr int oB = (oZs + LDZ * NH + 3) & ~3;       // two [B | R | r] images
+  static constexpr int oA = oB + 2 * BIMG;        // Aa
+  static constexpr int oZ = oA + MAT;             // per player: Qa_i image / transposition tile
+  static constexpr int SLACK = (32 + 32 * LD - MAT + 3) & ~3;
+  static constexpr int LDS_BWD = oZ + NP * MAT + (SLACK > 0 ? SLACK : 0);
+  static_assert(oZs + 16 + 32 * LDZ <= LDS_BWD && oB + 32 + NX * 32 <= LDS_BWD, "edge-tile reads stay inside the LDS");
+  // forward pass (wave 0; overlays the backward working set): two staged rows, x_k, x_{k+1}, alpha, it
+  static constexpr int fx = 2 * ROW;
+  static constexpr int fa = fx + 2 * NX;
+  static constexpr int fit = (fa + M + 3) & ~3;
+  static constexpr int LDS_FWD = fit + NX;
   static constexpr int LDS_ELEMS = LDS_FWD > LDS_BWD ? LDS_FWD : LDS_BWD;
 };
+
+// Elements of one open-loop scratch row from run-time dimensions (OLCfg::ROW / ROW_FAT).
+__host__ __device__ inline int ol_row_elems(int n, int m, int N, bool fat = false) {
+  const int slim = (n * n + n + m * n + m + N * n + 3) & ~3;
+  return fat ? ((slim + N * n * n + N * n + 3) & ~3) : slim;
+}
 
 // Solve R y = b for a small SPD block by LDL^T without pivoting (Eigen::LDLT at
 // src/lq_open_loop_solver.cpp:124-126; R_ii is diagonally dominant in every config).
@@ -93,60 +136,167 @@ __device__ __forceinline__ void ldlt_solve(const T* R /* MU x MU col-major */, T
     for (int k = i + 1; k < MU; k++) b[i] -= Lm[k][i] * b[k];
 }
 
-// a.scratch must hold T_steps rows of OLCfg::ROW elements.  a.P is written as zero (:96-102).
+// Accumulator layout of tile (a, b) of the matrix X with X[R][Cc] = mat[R + ld * Cc] (TR: mat[Cc + ld * R]) for
+// R < RL, Cc < CL and zero elsewhere.  `p` is mat plus this lane's offset (tile_lane_offset); every element is then
+// p[compile-time constant] — one address register per (matrix, orientation) instead of one per element, which is what
+// the step loop would otherwise keep live.  Elements outside [0, RL) x [0, CL) are READ (the address stays inside the
+// workgroup's LDS: OLCfg orders its regions for that) and replaced by zero; the range tests fold away for interior
+// tiles (a, b, RL, CL are compile-time constants at every call site).
+template <typename T, bool TR>
+__device__ __forceinline__ int tile_lane_offset(int ld, int g, int j) {
+  return TR ? j + ld * Tile<T>::row(g, 0) : Tile<T>::row(g, 0) + ld * j;
+}
+template <typename T, bool TR>
+__device__ __forceinline__ typename Tile<T>::vec ld_tile(const T* p, int ld, int a, int b, int RL, int CL, int g, int j) {
+  constexpr int RS = Tile<T>::row(0, 1) - Tile<T>::row(0, 0);
+  typename Tile<T>::vec v;
+  const bool cok = 16 * b + j < CL;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const bool rok = 16 * a + Tile<T>::row(g, r) < RL;
+    const T x = TR ? p[16 * b + ld * (16 * a + RS * r)] : p[16 * a + RS * r + ld * (16 * b)];
+    v[r] = (cok && rok) ? x : T(0);
+  }
+  return v;
+}
+
+// k blocks (of the two 16-row k tiles) that a contraction over KD rows has to visit
+template <typename T>
+constexpr int kd_mask(int KD, int c) {
+  const int rows = KD - 16 * c;
+  return rows <= 0 ? 0 : kblock_mask<T>(0, rows < 16 ? rows : 16);
+}
+
+// a.scratch must hold T_steps rows of OLCfg::ROW elements (ROW_FAT when a.costates).  a.P is written as zero (:96-102).
 template <typename T, int NX, int NP, int MU>
 __device__ __forceinline__ void lq_openloop_instance(const LQArgs<T>& a, const PairTable& pt, T* sm) {
   using C = LQCfg<T, NX, NP, MU>;
   using O = OLCfg<T, NX, NP, MU>;
-  constexpr int M = C::M, L = C::L, NT = C::NT, ROW = O::ROW;
+  using TL = Tile<T>;
+  using vec = typename TL::vec;
+  constexpr int M = O::M, NT = O::NT, NH = O::NH, NTL = O::NTL, LD = O::LD, LDZ = O::LDZ, MAT = O::MAT;
+  constexpr int S = int(sizeof(T));
+  constexpr int BOFF_R = (NX * M + 3) & ~3, BOFF_r = BOFF_R + C::RMAX;
   const int t = threadIdx.x;
-  const int lane = t & 63;
-  const bool zl = t < L;
-  const int pi = zl ? t / NX : 0;
-  const int pc = zl ? t % NX : 0;
+  const int w = t >> 6;  // wave = player
+  const int lane = t & 63, g = lane >> 4, j = lane & 15;
   const int Tn = a.T_steps;
+  const int ROWS = a.costates ? O::ROW_FAT : O::ROW;
   const PairRegs<NP> pr(pt);
-  T *sB, *sA, *sQ, *sl, *sR, *sr;
-  auto set_img = [&](int which) {
-    T* img = sm + which * C::IMG;
-    sB = img + C::oB; sA = img + C::oA; sQ = img + C::oQ; sl = img + C::ol; sR = img + C::oR; sr = img + C::or_;
-  };
-  T* sM = sm + O::oM;
-  T* smv = sm + O::om;
-  T* sW = sm + O::oW;
-  T* sw = sm + O::ow;
-  T* sV = sm + O::oV;
-  T* sg = sm + O::og;
-  T* sX = sm + O::oX;
-  T* sy = sm + O::oy;
-  T* sT = sm + O::oT;
-  auto row_of = [&](int k) { return a.scratch + size_t(k) * ROW; };
-  auto ro_ii = [&](int i) {
-    int v = 0;
+  const vec zero4 = {T(0), T(0), T(0), T(0)};
+  int ro_ww = 0, rg_ww = 0;  // this player's offsets in the R / r rows
 #pragma unroll
-    for (int e = 0; e < NP; e++) v = (i == e) ? pr.ro[e][e] : v;
-    return v;
-  };
-  auto rg_ii = [&](int i) {
-    int v = 0;
-#pragma unroll
-    for (int e = 0; e < NP; e++) v = (i == e) ? pr.rg[e][e] : v;
-    return v;
-  };
-  // store M_i, m_i (value functions AT step k) and Q_i l_i into scratch row k
-  auto store_value_row = [&](int k) {
-    T* row = row_of(k);
-    for (int e = t; e < NP * NX * NX; e += NT) row[O::rM + e] = sM[e];
-    for (int e = t; e < NP * NX; e += NT) row[O::rm + e] = smv[e];
-    if (zl) {
-      T s = T(0);
-#pragma unroll
-      for (int c = 0; c < NX; c++) s += sQ[pi * NX * NX + pc + NX * c] * sl[pi * NX + c];
-      row[O::rql + t] = s;
+  for (int e = 0; e < NP; e++) {
+    ro_ww = (w == e) ? pr.ro[e][e] : ro_ww;
+    rg_ww = (w == e) ? pr.rg[e][e] : rg_ww;
+  }
+  T* const sZ = sm + O::oZ + w * MAT;  // this wave's tile
+  T* const sAa = sm + O::oA;
+  T* const sV = sm + O::oV;
+  T* const sg = sm + O::og;
+  T* const sKA = sm + O::oKA;
+  T* const sZs = sm + O::oZs;
+  T* const sBt = sm + O::oBt + w * (MU * NH);
+  auto bimg = [&](int which) { return sm + O::oB + which * O::BIMG; };
+  auto row_of = [&](int k) { return a.scratch + size_t(k) * ROWS; };
+
+  // ---- DMA plumbing: columns of NX elements (contiguous in global memory) into padded columns of LD elements ----
+  // One wave moves `ncols` columns; piece p of the padded image is column p / PPC, offset p % PPC.
+  constexpr int PS = ((NX * S) % 16 == 0 && (LD * S) % 16 == 0) ? 16 : 4;  // DMA piece (bytes)
+  constexpr int PPC = LD * S / PS;                                          // pieces of a padded column
+  constexpr int VPC = NX * S / PS;                                          // of which carry data
+  auto dma_cols = [&](const T* src, T* dst, int ncols, int first_instr, int instr_step) {
+    const int total = ncols * PPC;
+    for (int h = first_instr; h * 64 < total; h += instr_step) {
+      const int p = h * 64 + lane;
+      const int c = p / PPC, inb = p % PPC;
+      if (p < total && inb < VPC) {
+        const char* s = reinterpret_cast<const char*>(src) + (c * NX * S + inb * PS);
+        char* d = reinterpret_cast<char*>(dst) + h * 64 * PS;  // wave-uniform; the hardware adds lane * PS
+        if constexpr (PS == 16)
+          __builtin_amdgcn_global_load_lds((glb_vptr)s, (lds_vptr)d, 16, 0, 0);
+        else
+          __builtin_amdgcn_global_load_lds((glb_vptr)s, (lds_vptr)d, 4, 0, 0);
+      }
     }
   };
+  // Q_i | l_i of step k into this wave's tile (columns 0..NX-1 and column NX)
+  auto issue_Q = [&](int k) {
+    dma_cols(a.Q + (size_t(k) * NP + w) * NX * NX, sZ, NX, 0, 1);
+    dma_cols(a.l + (size_t(k) * NP + w) * NX, sZ + LD * NX, 1, 0, 1);
+  };
+  // A of step k (the waves share the instructions)
+  auto issue_A = [&](int k) { dma_cols(a.A + size_t(k) * NX * NX, sAa, NX, w, NP); };
+  // [B | R | r] of step k into image `which`
+  auto issue_B = [&](int k, int which) {
+    T* img = bimg(which);
+    dma_g2l<NT, false>(a.Bm + size_t(k) * NX * M, img, NX * M * S, t);
+    dma_g2l<NT, false>(a.R + size_t(k) * pt.Rsz, img + BOFF_R, pt.Rsz * S, t);
+    dma_g2l<NT, false>(a.r + size_t(k) * pt.rsz, img + BOFF_r, pt.rsz * S, t);
+  };
 
-  // diagnostics (ILQG_PROFILE build): shader-clock cycles of thread 0 per phase, summed over the steps
+  // this lane's offsets into accumulator-layout operands (plain / transposed) for the three leading dimensions
+  const int oD = tile_lane_offset<T, false>(LD, g, j), oT = tile_lane_offset<T, true>(LD, g, j);
+  const int oDn = tile_lane_offset<T, false>(NX, g, j), oTn = tile_lane_offset<T, true>(NX, g, j);
+  const int oDz = tile_lane_offset<T, false>(LDZ, g, j);
+  constexpr int RS = TL::row(0, 1) - TL::row(0, 0);
+
+  // ---- block algebra on NTL x NTL tiles ----
+  struct Blk {
+    vec v[NTL][NTL];
+  };
+  auto load_blk = [&](const T* mat, bool transposed) {  // D(mat) / D(mat^T) of a padded n' x n' matrix
+    Blk o;
+#pragma unroll
+    for (int aa = 0; aa < NTL; aa++)
+#pragma unroll
+      for (int bb = 0; bb < NTL; bb++)
+        o.v[aa][bb] = transposed ? ld_tile<T, true>(mat + oT, LD, aa, bb, NH, NH, g, j) : ld_tile<T, false>(mat + oD, LD, aa, bb, NH, NH, g, j);
+    return o;
+  };
+  constexpr int KH0 = kd_mask<T>(NH, 0), KH1 = kd_mask<T>(NH, 1);  // contraction over n' rows
+  constexpr int KN0 = kd_mask<T>(NX, 0), KN1 = kd_mask<T>(NX, 1);  // over n rows
+  constexpr int KM0 = kd_mask<T>(M, 0);                            // over m rows
+
+  // ---- once per sweep: zero the tiles' padding, the homogeneous column of Aa ----
+  static_assert(O::oZ == O::oA + MAT, "Aa and the tiles are zeroed in one piece");
+  for (int e = t; e < NP * MAT + MAT; e += NT) sm[O::oA + e] = T(0);
+  lds_sync(NT <= 64);
+  if (t == 0) sAa[NX + LD * NX] = T(1);
+  lds_sync(NT <= 64);
+
+  // ---- terminal step (:105-108): Ma_i = Qa_i[T-1] ----
+  issue_Q(Tn - 1);
+  if (Tn >= 2) {
+    issue_A(Tn - 2);
+    issue_B(Tn - 2, (Tn - 2) & 1);
+    if (Tn >= 3) issue_B(Tn - 3, (Tn - 3) & 1);
+  }
+  dma_wait();
+  lds_sync(NT <= 64);
+  Blk Md = load_blk(sZ, false);  // D(Ma_i)
+  Blk MT = load_blk(sZ, true);   // D(Ma_i^T)
+  // Q_i l_i of a step (expected decrease, ilq_solver.cpp:392) -> scratch row, and M_i, m_i when costates are wanted;
+  // both read this wave's tile
+  auto store_row_from_tile = [&](int k, bool tile_holds_Q) {
+    T* row = row_of(k);
+    if (tile_holds_Q && lane < NX) {
+      T s = T(0);
+#pragma unroll
+      for (int c = 0; c < NX; c++) s += sZ[lane + LD * c] * sZ[c + LD * NX];
+      row[O::rql + w * NX + lane] = s;
+    }
+    if (!tile_holds_Q && a.costates) {
+      for (int e = lane; e < NX * NX; e += 64) row[O::rM + w * NX * NX + e] = sZ[(e % NX) + LD * (e / NX)];
+      if (lane < NX) row[O::rm + w * NX + lane] = sZ[lane + LD * NX];
+    }
+  };
+  store_row_from_tile(Tn - 1, true);
+  if (a.costates) store_row_from_tile(Tn - 1, false);  // M[T-1] = Q[T-1]: the tile holds both
+  lds_sync(true);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the tile has been read: the DMA engine may refill it
+  if (Tn >= 2) issue_Q(Tn - 2);
+
   long long ph_c = (kProfile && a.ph) ? clock64() : 0;
   auto PH = [&](int slot) {
     if (kProfile && a.ph && t == 0) {
@@ -155,305 +305,261 @@ __device__ __forceinline__ void lq_openloop_instance(const LQArgs<T>& a, const P
       ph_c = c;
     }
   };
-  // ---- terminal step (:105-108) ----
-  int cur = 0;
-  lq_stage_issue<T, NX, NP, MU>(a, pt, Tn - 1, sm, t);
-  dma_wait();
-  __syncthreads();
-  set_img(0);
-  for (int e = t; e < NP * NX * NX; e += NT) sM[e] = sQ[e];
-  for (int e = t; e < NP * NX; e += NT) smv[e] = sl[e];
-  lds_sync(NT <= 64);
-  store_value_row(Tn - 1);
-  if (O::DB) {
-    if (Tn >= 2) lq_stage_issue<T, NX, NP, MU>(a, pt, Tn - 2, sm + C::IMG, t);
-    dma_wait();
-    lds_sync(NT <= 64);
-    cur = 1;
-  } else {
-    lds_sync(NT <= 64);  // every read of the terminal image is done
-    if (Tn >= 2) lq_stage_issue<T, NX, NP, MU>(a, pt, Tn - 2, sm, t);
-    dma_wait();
-    lds_sync(NT <= 64);
-    cur = 0;
-  }
-  set_img(cur);
 
 #pragma unroll 1
   for (int k = Tn - 2; k >= 0; k--) {
-    if (O::DB && k > 0) lq_stage_issue<T, NX, NP, MU>(a, pt, k - 1, sm + (1 - cur) * C::IMG, t);
-    // ---- W_i = R_ii^{-1} B_i^T (column c by lane (i,c)), w_i = R_ii^{-1} r_ii ----
-    if (zl) {
-      T b[MU];
+    const T* img = bimg(k & 1);
+    const T* sB = img;
+    const T* sR = img + BOFF_R;
+    const T* sr = img + BOFF_r;
+    // ---- [V_i | g_i] = R_ii^{-1} (B_i^T Ma_i + [0 | r_ii]) ----
+    {
+      vec Bd[NTL];  // D(B_i): n x mu
 #pragma unroll
-      for (int aa = 0; aa < MU; aa++) b[aa] = sB[pc + NX * (pi * MU + aa)];
-      ldlt_solve<T, MU>(sR + ro_ii(pi), b);
+      for (int c = 0; c < NTL; c++) Bd[c] = ld_tile<T, false>(sB + NX * (w * MU) + oDn, NX, c, 0, NX, MU, g, j);
 #pragma unroll
-      for (int aa = 0; aa < MU; aa++) sW[(pi * MU + aa) + M * pc] = b[aa];
-    }
-    if (t < NP) {
-      T b[MU];
+      for (int bb = 0; bb < NTL; bb++) {
+        vec acc = tile_xty_blocks<T, KN0>(Bd[0], Md.v[0][bb], zero4);
+        if constexpr (NTL == 2) acc = tile_xty_blocks<T, KN1>(Bd[1], Md.v[1][bb], acc);
+        const int col = 16 * bb + j;
 #pragma unroll
-      for (int aa = 0; aa < MU; aa++) b[aa] = sr[rg_ii(t) + aa];
-      ldlt_solve<T, MU>(sR + ro_ii(t), b);
+        for (int r = 0; r < 4; r++) {
+          const int row = TL::row(g, r);
+          if (row < MU && col < NH) sBt[row + MU * col] = acc[r];
+        }
+      }
+      lds_sync(true);
+      if (lane < NH) {
+        T b[MU];
 #pragma unroll
-      for (int aa = 0; aa < MU; aa++) sw[t * MU + aa] = b[aa];
-    }
-    lds_sync(NT <= 64);
-    PH(0);
-    // ---- V_i = W_i M_i (column c), g = W_i m_i + w_i ----
-    if (zl) {
+        for (int aa = 0; aa < MU; aa++) b[aa] = sBt[aa + MU * lane] + (lane == NX ? sr[rg_ww + aa] : T(0));
+        ldlt_solve<T, MU>(sR + ro_ww, b);
 #pragma unroll
-      for (int aa = 0; aa < MU; aa++) {
-        T s = T(0);
-#pragma unroll
-        for (int r = 0; r < NX; r++) s += sW[(pi * MU + aa) + M * r] * sM[pi * NX * NX + r + NX * pc];
-        sV[(pi * MU + aa) + M * pc] = s;
+        for (int aa = 0; aa < MU; aa++) {
+          if (lane < NX)
+            sV[(w * MU + aa) + M * lane] = b[aa];
+          else
+            sg[w * MU + aa] = b[aa];
+        }
       }
     }
-    if (t < M) {
-      const int i = t / MU;
-      T s = T(0);
+    dma_wait();  // A, Q_i | l_i of this step (issued at the end of the previous one) have landed
+    lds_sync(NT <= 64);
+    PH(0);
+    static_assert(O::og == O::oV + M * NX && O::rg == O::rV + M * NX, "[V | g] is copied to the scratch row in one piece");
+    for (int e = t; e < M * NX + M; e += NT) row_of(k)[O::rV + e] = sV[e];
+    // ---- [K | V A] = [I + V B | V A], one entry per thread ----
+    for (int e = t; e < M * (M + NX); e += NT) {
+      const int q = e % M, c = e / M;
+      const T* colp = c < M ? sB + NX * c : sAa + LD * (c - M);
+      T s = (c == q) ? T(1) : T(0);
 #pragma unroll
-      for (int r = 0; r < NX; r++) s += sW[t + M * r] * smv[i * NX + r];
-      sg[t] = s + sw[t];
+      for (int r = 0; r < NX; r++) s += sV[q + M * r] * colp[r];
+      sKA[e] = s;
     }
     lds_sync(NT <= 64);
     PH(1);
-    // ---- Lambda [X | y] = [A | c] through the matrix inversion lemma (wave 0) ----
-    // Lambda = I + B V with B = [B_0 .. B_{N-1}] (n x m) and V = [W_0 M_0; ..; W_{N-1} M_{N-1}] (m x n): a rank-m
-    // update of the identity, so  Lambda^{-1} = I - B K^{-1} V,  K = I_m + V B  (m x m), and
-    //     X = A - B Z,  y = c - B z,   K [Z | z] = [V A | V c].
-    // The reference factors the n x n Lambda by Householder QR (:131) and solves for n + 1 right-hand sides — 24
-    // dependent reflections per step at n = 24, which was half of this sweep; the m x m system (8 x 8) takes the
-    // same column-per-lane QR (M columns of K, then the NX + 1 right-hand sides).  Both are the solution of the same
-    // linear system; the parity tests compare with the QR oracle.
-    if (t < 64) {
-      static_assert(M + NX + 1 <= 64, "K [Z | z] = [V A | V c] must fit one wavefront");
+    // ---- K [Z | z] = [V A | g] (wave 0, column per lane) ----
+    if (w == 0) {
       T col[M], x[M];
 #pragma unroll
       for (int q = 0; q < M; q++) {
-        col[q] = T(0);
+        col[q] = lane < M + NX ? sKA[q + M * (lane < M + NX ? lane : 0)] : (lane == M + NX ? sg[q] : T(0));
         x[q] = T(0);
       }
-      const bool isK = t < M, isA = t >= M && t < M + NX, isc = t == M + NX;
-      const int cidx = isA ? t - M : 0;
-      // this lane's vector v (a column of B, a column of A, or c = -B g), then V v
-      T cvec[NX];
-#pragma unroll
-      for (int r = 0; r < NX; r++) {
-        T v = T(0);
-        if (isK) {
-          v = sB[r + NX * t];
-        } else if (isA) {
-          v = sA[r + NX * cidx];
-        } else if (isc) {
-#pragma unroll
-          for (int q = 0; q < M; q++) v -= sB[r + NX * q] * sg[q];
-        }
-        cvec[r] = v;
-      }
-#pragma unroll
-      for (int r = 0; r < NX; r++) {
-#pragma unroll
-        for (int q = 0; q < M; q++) col[q] += sV[q + M * r] * cvec[r];
-      }
-      if (isK) {
-#pragma unroll
-        for (int q = 0; q < M; q++) col[q] += (q == t) ? T(1) : T(0);
-      }
       qr_solve_columns<T, M>(col, lane, x);
-      if (isA || isc) {
+      if (lane >= M && lane <= M + NX) {
 #pragma unroll
-        for (int r = 0; r < NX; r++) {
-          T v = cvec[r];
+        for (int q = 0; q < M; q++) sZs[q + LDZ * (lane - M)] = x[q];
+      }
+    }
+    lds_sync(NT <= 64);
+    PH(2);
+    // ---- Xa = Aa - B [Z | z]  (every wave) ----
+    Blk Xd;
+    {
+      vec nBT[NTL], Zd[NTL];  // D(-B^T) (m x n), D([Z | z]) (m x n')
 #pragma unroll
-          for (int q = 0; q < M; q++) v -= sB[r + NX * q] * x[q];
-          if (isA)
-            sX[r + NX * cidx] = v;
-          else
-            sy[r] = v;
+      for (int bb = 0; bb < NTL; bb++) {
+        nBT[bb] = ld_tile<T, true>(sB + oTn, NX, 0, bb, M, NX, g, j);
+#pragma unroll
+        for (int r = 0; r < 4; r++) nBT[bb][r] = -nBT[bb][r];
+        Zd[bb] = ld_tile<T, false>(sZs + oDz, LDZ, 0, bb, M, NH, g, j);
+      }
+#pragma unroll
+      for (int aa = 0; aa < NTL; aa++)
+#pragma unroll
+        for (int bb = 0; bb < NTL; bb++)
+          Xd.v[aa][bb] = tile_xty_blocks<T, KM0>(nBT[aa], Zd[bb], ld_tile<T, false>(sAa + oD, LD, aa, bb, NH, NH, g, j));
+    }
+    // X, y -> scratch row k (the waves share the tiles)
+    {
+      T* row = row_of(k);
+#pragma unroll
+      for (int aa = 0; aa < NTL; aa++)
+#pragma unroll
+        for (int bb = 0; bb < NTL; bb++)
+          if ((aa * NTL + bb) % NP == w) {
+            const int col = 16 * bb + j;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              const int rw = 16 * aa + TL::row(g, r);
+              if (rw < NX && col <= NX) row[(col < NX ? O::rX + NX * col : O::ry) + rw] = Xd.v[aa][bb][r];
+            }
+          }
+    }
+    // ---- W = Ma Xa;  Ma' = Qa + Aa^T W ----
+    Blk Wd;
+#pragma unroll
+    for (int aa = 0; aa < NTL; aa++)
+#pragma unroll
+      for (int bb = 0; bb < NTL; bb++) {
+        vec acc = tile_xty_blocks<T, KH0>(MT.v[0][aa], Xd.v[0][bb], zero4);
+        if constexpr (NTL == 2) acc = tile_xty_blocks<T, KH1>(MT.v[1][aa], Xd.v[1][bb], acc);
+        Wd.v[aa][bb] = acc;
+      }
+    store_row_from_tile(k, true);  // Q_i l_i
+#pragma unroll
+    for (int aa = 0; aa < NTL; aa++)
+#pragma unroll
+      for (int bb = 0; bb < NTL; bb++) {
+        vec acc = ld_tile<T, false>(sZ + oD, LD, aa, bb, NH, NH, g, j);  // D(Qa_i)
+        acc = tile_xty_blocks<T, KN0>(ld_tile<T, false>(sAa + oD, LD, 0, aa, NH, NH, g, j), Wd.v[0][bb], acc);
+        if constexpr (NTL == 2) acc = tile_xty_blocks<T, KN1>(ld_tile<T, false>(sAa + oD, LD, 1, aa, NH, NH, g, j), Wd.v[1][bb], acc);
+        Md.v[aa][bb] = acc;
+      }
+    PH(3);
+    // transpose through this wave's tile: write D(Ma'), read D(Ma'^T)
+    lds_sync(true);  // every read of Qa_i is done
+#pragma unroll
+    for (int aa = 0; aa < NTL; aa++)
+#pragma unroll
+      for (int bb = 0; bb < NTL; bb++) {
+        const int col = 16 * bb + j;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int rw = 16 * aa + TL::row(g, r);
+          if (rw < NH && col < NH) sZ[oD + 16 * aa + RS * r + LD * (16 * bb)] = Md.v[aa][bb][r];
         }
       }
-    }
-    {  // W, w of this step -> scratch row k (forward pass)
-      T* row = row_of(k);
-      for (int e = t; e < M * NX; e += NT) row[O::rW + e] = sW[e];
-      if (t < M) row[O::rw + t] = sw[t];
-    }
-    lds_sync(NT <= 64);
-    {  // X, y -> scratch row k, from LDS so that the stores are contiguous (a lane owns a COLUMN of X: stored
-       // from its registers, every store instruction would touch one cache line per lane)
-      T* row = row_of(k);
-      for (int e = t; e < NX * NX; e += NT) row[O::rX + e] = sX[e];
-      if (t < NX) row[O::ry + t] = sy[t];
-    }
-    PH(2);
-    // ---- M_i[:,c] = Q_i[:,c] + A^T (M_i X[:,c]);  t_i = m_i + M_i y ----
-    T mn[NX];
-    T tv = T(0);
-    if (zl) {
-      T xc[NX], u[NX];
-#pragma unroll
-      for (int kk = 0; kk < NX; kk++) xc[kk] = sX[kk + NX * pc];
-#pragma unroll
-      for (int r = 0; r < NX; r++) {
-        T s = T(0);
-#pragma unroll
-        for (int kk = 0; kk < NX; kk++) s += sM[pi * NX * NX + r + NX * kk] * xc[kk];
-        u[r] = s;
-      }
-#pragma unroll
-      for (int r = 0; r < NX; r++) {
-        T s = T(0);
-#pragma unroll
-        for (int kk = 0; kk < NX; kk++) s += sA[kk + NX * r] * u[kk];
-        mn[r] = sQ[pi * NX * NX + r + NX * pc] + s;
-      }
-      T s = T(0);
-#pragma unroll
-      for (int kk = 0; kk < NX; kk++) s += sM[pi * NX * NX + pc + NX * kk] * sy[kk];
-      tv = smv[pi * NX + pc] + s;
-    }
-    lds_sync(NT <= 64);
-    if (zl) {
-#pragma unroll
-      for (int r = 0; r < NX; r++) sM[pi * NX * NX + r + NX * pc] = mn[r];
-      sT[t] = tv;
-    }
-    lds_sync(NT <= 64);
-    if (zl) {
-      T s = T(0);
-#pragma unroll
-      for (int kk = 0; kk < NX; kk++) s += sA[kk + NX * pc] * sT[pi * NX + kk];
-      smv[t] = sl[t] + s;
-    }
-    lds_sync(NT <= 64);
-    PH(3);
-    store_value_row(k);
+    lds_sync(true);
+    MT = load_blk(sZ, true);
+    if (a.costates) store_row_from_tile(k, false);
+    lds_sync(true);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the tile has been read: the DMA engine may refill it
+    if (k > 0) issue_Q(k - 1);
+    lds_sync(NT <= 64);  // every wave is done with Aa (and with V, [K | V A], [Z | z])
+    if (k > 0) issue_A(k - 1);
+    if (k > 1) issue_B(k - 2, k & 1);  // this step's image is free again; B of step k - 1 is already in the other one
     PH(4);
-    if (O::DB) {
-      dma_wait();
-      lds_sync(NT <= 64);
-      cur = 1 - cur;
-      set_img(cur);
-    } else {
-      lds_sync(NT <= 64);  // the image is free: refill it in place
-      if (k > 0) lq_stage_issue<T, NX, NP, MU>(a, pt, k - 1, sm, t);
-      dma_wait();
-      lds_sync(NT <= 64);
-    }
-    PH(5);
   }
 
-  // ---- forward pass (:156-192) ----
-  __syncthreads();  // scratch rows were written by other lanes
-  T* f0 = sm;               // staged [row k | M,m of row k+1]  (overlays the backward working set)
-  T* sx = sm + O::fxs;      // x_k
-  T* sxn = sx + NX;         // x_{k+1}
-  sT = sm + O::fT;
-  sg = sm + O::fg;
-  constexpr int FS = O::FS;
-  constexpr int S = int(sizeof(T));
-  auto stage = [&](int k, int which) {
-    T* dst = f0 + which * FS;
-    dma_g2l<NT, false>(row_of(k), dst, (O::rM) * S, t);                                  // X, y, W, w
-    dma_g2l<NT, false>(row_of(k) + O::rql, dst + O::rql, NP * NX * S, t);                // Q_i l_i of step k
-    dma_g2l<NT, false>(row_of(k + 1) + O::rM, dst + ROW, (NP * NX * NX + NP * NX) * S, t);  // M, m at k+1
-  };
-  if (t < NX) sx[t] = a.x0 ? a.x0[t] : T(0);
+  // ---- forward pass (:156-192), wave 0 ----
   for (int e = t; e < M * NX; e += NT)
     for (int k = 0; k < Tn; k++) a.P[size_t(k) * M * NX + e] = T(0);  // open loop: P stays zero
+  __syncthreads();  // scratch rows were written by other waves
+  if (w != 0) return;
+  constexpr int ROW = O::ROW;
+  T* const sx = sm + O::fx;    // x_k
+  T* const sxn = sx + NX;      // x_{k+1}
+  T* const sal = sm + O::fa;   // alpha_k
+  T* const sit = sm + O::fit;  // M_i[k+1] x_{k+1} + m_i[k+1] (costates)
+  auto stage = [&](int k, int which) { dma_g2l<64, false>(row_of(k), sm + which * ROW, ROW * S, lane); };
+  if (lane < NX) sx[lane] = a.x0 ? a.x0[lane] : T(0);
   T ed = T(0);
-  cur = 0;
+  int cur = 0;
   if (Tn >= 2) stage(0, 0);
   dma_wait();
-  lds_sync(NT <= 64);
+  lds_sync(true);
 #pragma unroll 1
   for (int k = 0; k < Tn - 1; k++) {
-    if (O::DB && k + 2 < Tn) stage(k + 1, 1 - cur);
-    const T* fr = f0 + cur * FS;
-    if (a.dx && t < NX) a.dx[size_t(k) * NX + t] = sx[t];
-    if (t < NX) {
-      T s = fr[O::ry + t];
+    if (k + 2 < Tn) stage(k + 1, 1 - cur);
+    const T* fr = sm + cur * ROW;
+    if (a.dx && lane < NX) a.dx[size_t(k) * NX + lane] = sx[lane];
+    if (lane < NX) {
+      T s = fr[O::ry + lane];
 #pragma unroll
-      for (int c = 0; c < NX; c++) s += fr[O::rX + t + NX * c] * sx[c];
-      sxn[t] = s;
+      for (int c = 0; c < NX; c++) s += fr[O::rX + lane + NX * c] * sx[c];
+      sxn[lane] = s;
     }
-    lds_sync(NT <= 64);
-    if (zl) {  // it_i = M_i[k+1] x_{k+1} + m_i[k+1]
-      T s = fr[ROW + NP * NX * NX + t];
+    lds_sync(true);
+    if (lane < M) {
+      T s = fr[O::rg + lane];
 #pragma unroll
-      for (int c = 0; c < NX; c++) s += fr[ROW + pi * NX * NX + pc + NX * c] * sxn[c];
-      sT[t] = s;
+      for (int c = 0; c < NX; c++) s += fr[O::rV + lane + M * c] * sxn[c];
+      a.alpha[size_t(k) * M + lane] = s;
+      sal[lane] = s;
     }
-    lds_sync(NT <= 64);
-    T al = T(0);
-    if (t < M) {
-      const int i = t / MU;
-      T s = T(0);
-#pragma unroll
-      for (int r = 0; r < NX; r++) s += fr[O::rW + t + M * r] * sT[i * NX + r];
-      al = s + fr[O::rw + t];
-      a.alpha[size_t(k) * M + t] = al;
-      sg[t] = al;
+    if (a.costates) {  // A_k^T (M_i[k+1] x_{k+1} + m_i[k+1]) (:176)
+      const T* nrow = row_of(k + 1);
+      const T* Ak = a.A + size_t(k) * NX * NX;
+#pragma unroll 1
+      for (int i = 0; i < NP; i++) {
+        if (lane < NX) {
+          T s = nrow[O::rm + i * NX + lane];
+          for (int c = 0; c < NX; c++) s += nrow[O::rM + i * NX * NX + lane + NX * c] * sxn[c];
+          sit[lane] = s;
+        }
+        lds_sync(true);
+        if (lane < NX) {
+          T s = T(0);
+          for (int r = 0; r < NX; r++) s += Ak[r + NX * lane] * sit[r];
+          a.costates[(size_t(k) * NP + i) * NX + lane] = s;
+        }
+        lds_sync(true);
+      }
     }
     if (a.ed_out) {  // ILQSolver::ExpectedDecrease (ilq_solver.cpp:364-398) for this step
-      lds_sync(NT <= 64);
-      if (t < 64) {
-        T st = T(0), ct = T(0);
-        if (t < NP) {
-          const T* Rg = a.R + size_t(k) * pt.Rsz + ro_ii(t);
-          const T* rg = a.r + size_t(k) * pt.rsz + rg_ii(t);
+      lds_sync(true);
+      T st = T(0), ct = T(0);
+      if (lane < NP) {
+        int ro = 0, rg = 0;
 #pragma unroll
-          for (int c = 0; c < MU; c++) {
-            T aR = T(0);
-#pragma unroll
-            for (int b = 0; b < MU; b++) aR += sg[t * MU + b] * Rg[b + MU * c];
-            ct += aR * rg[c];
-          }
-          if (k > 0) {
-#pragma unroll
-            for (int c = 0; c < NX; c++) st += sx[c] * fr[O::rql + t * NX + c];
-          }
+        for (int e = 0; e < NP; e++) {
+          ro = (lane == e) ? pr.ro[e][e] : ro;
+          rg = (lane == e) ? pr.rg[e][e] : rg;
         }
+        const T* Rg = a.R + size_t(k) * pt.Rsz + ro;
+        const T* rgp = a.r + size_t(k) * pt.rsz + rg;
 #pragma unroll
-        for (int i = 0; i < NP; i++) {
-          ed -= shfl(ct, i);
-          if (k > 0) ed -= shfl(st, i);
+        for (int c = 0; c < MU; c++) {
+          T aR = T(0);
+#pragma unroll
+          for (int b = 0; b < MU; b++) aR += sal[lane * MU + b] * Rg[b + MU * c];
+          ct += aR * rgp[c];
+        }
+        if (k > 0) {
+#pragma unroll
+          for (int c = 0; c < NX; c++) st += sx[c] * fr[O::rql + lane * NX + c];
         }
       }
+#pragma unroll
+      for (int i = 0; i < NP; i++) {
+        ed -= shfl(ct, i);
+        if (k > 0) ed -= shfl(st, i);
+      }
     }
-    lds_sync(NT <= 64);
-    if (t < NX) sx[t] = sxn[t];
-    if (O::DB) {
-      dma_wait();
-      lds_sync(NT <= 64);
-      cur = 1 - cur;
-    } else {
-      lds_sync(NT <= 64);  // staged row consumed: refill in place
-      if (k + 2 < Tn) stage(k + 1, 0);
-      dma_wait();
-      lds_sync(NT <= 64);
-    }
+    lds_sync(true);
+    if (lane < NX) sx[lane] = sxn[lane];
+    dma_wait();
+    lds_sync(true);
+    cur = 1 - cur;
   }
-  PH(6);
-  if (a.dx && t < NX) a.dx[size_t(Tn - 1) * NX + t] = sx[t];  // :188-192
-  if (t < M) a.alpha[size_t(Tn - 1) * M + t] = T(0);
+  if (a.dx && lane < NX) a.dx[size_t(Tn - 1) * NX + lane] = sx[lane];  // :188-192
+  if (lane < M) a.alpha[size_t(Tn - 1) * M + lane] = T(0);
+  if (a.costates)
+    for (int e = lane; e < NP * NX; e += 64) a.costates[size_t(Tn - 1) * NP * NX + e] = T(0);
   if (a.ed_out) {
     // step T-1: alpha = 0; state term delta_x^T Q l
-    __syncthreads();
-    if (t < 64) {
-      T st = T(0);
-      if (t < NP && Tn > 1) {
-        const T* ql = row_of(Tn - 1) + O::rql;
+    T st = T(0);
+    if (lane < NP && Tn > 1) {
+      const T* ql = row_of(Tn - 1) + O::rql;
 #pragma unroll
-        for (int c = 0; c < NX; c++) st += sx[c] * ql[t * NX + c];
-      }
-#pragma unroll
-      for (int i = 0; i < NP; i++) ed -= shfl(st, i);
+      for (int c = 0; c < NX; c++) st += sx[c] * ql[lane * NX + c];
     }
-    if (t == 0) *a.ed_out = ed;
+#pragma unroll
+    for (int i = 0; i < NP; i++) ed -= shfl(st, i);
+    if (lane == 0) *a.ed_out = ed;
   }
 }
 

@@ -50,10 +50,6 @@ struct SolveArgs {
   int probe_k;          // step sizes probed per instance this round (<= kProbeCandidates)
 };
 
-// Elements of one open-loop scratch row ([X|y|W|w|M|m|Q l], OLCfg::ROW) from run-time dimensions.
-__host__ __device__ inline int ol_row_elems(int n, int m, int N) {
-  return (n * n + n + m * n + m + N * n * n + N * n + N * n + 3) & ~3;
-}
 
 // Loop state of one instance's ILQSolver::Solve (the locals of src/ilq_solver.cpp:76-172 plus the
 // AugmentedLagrangianSolver bookkeeping).  It lives in registers inside a kernel and in the
@@ -743,7 +739,7 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const s
 // LQ part: the Riccati sweep of one instance whose stage is LQ.  Kept free of everything else (the
 // exit path lives in the trial kernel) so that the sweep's registers are all it has to hold.
 // PW: the workgroup has one wave per player and runs the player-parallel MFMA feedback sweep;
-// otherwise LQCfg::NT threads run the open-loop sweep or the VALU feedback sweep.
+// likewise the open-loop sweep (ilqg_lq_openloop.hpp); otherwise LQCfg::NT threads run the VALU feedback sweep.
 // ---------------------------------------------------------------------------
 // KIND: which sweep this kernel instantiation carries (one each, so that the register allocation of one does not
 // pay for the others): LQ_VALU_FEEDBACK, LQ_PLAYER_WAVES (PW above) or LQ_OPEN_LOOP.
