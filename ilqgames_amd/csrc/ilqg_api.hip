@@ -90,7 +90,7 @@ lq_feedback_kernel(LQBatchArgs<T> g, PairTable pt) {
 }
 
 template <typename T, int NX, int NP, int MU>
-__global__ void __launch_bounds__((OLCfg<T, NX, NP, MU>::NT))
+__global__ void __launch_bounds__((OLCfg<T, NX, NP, MU>::NT), 3)  // three instances per CU (see ilqg_lq_openloop.hpp)
 lq_openloop_kernel(LQBatchArgs<T> g, PairTable pt) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   T* sm = reinterpret_cast<T*>(smem_raw);
@@ -358,8 +358,8 @@ __global__ void __launch_bounds__(64) ilq_exit_kernel(DevProblem p, SolveArgs<T>
 
 // LQ kernel: the Riccati sweep at the accepted operating point of every instance that asked for one.
 template <typename T, int NX, int NP, int MU, int KIND>
-__global__ void __launch_bounds__((KIND == LQ_VALU_FEEDBACK ? LQCfg<T, NX, NP, MU>::NT : 64 * NP),
-                                  (KIND == LQ_PLAYER_WAVES ? NP : 1))
+__global__ void __launch_bounds__((KIND == LQ_VALU_FEEDBACK ? LQCfg<T, NX, NP, MU>::NT : (KIND == LQ_OPEN_LOOP ? OLCfg<T, NX, NP, MU>::NT : 64 * NP)),
+                                  (KIND == LQ_PLAYER_WAVES ? NP : (KIND == LQ_OPEN_LOOP ? 3 : 1)))
 ilq_lq_kernel(DevProblem p, SolveArgs<T> sa) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int b = blockIdx.x;
@@ -590,7 +590,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   const int al_mode = opt.augmented_lagrangian ? 1 : 0, resume = opt.resume ? 1 : 0;
   const int32_t* const active = opt.active;
   auto choice = [](int32_t c, bool automatic) { return c == ILQG_CHOICE_ON ? true : (c == ILQG_CHOICE_OFF ? false : automatic); };
-  static_assert(OLCfg<T, NX, NP, MU>::ROW == ((NX * NX + NX + NP * MU * NX + NP * MU + NP * NX + 3) & ~3), "ol_row_elems");
+  static_assert(OLCfg<T, NX, NP, MU>::ROW == ol_row_elems(NX, NP * MU, NP) && OLCfg<T, NX, NP, MU>::ROW_FAT == ol_row_elems(NX, NP * MU, NP, true), "ol_row_elems");
   const int ol_row = p->desc.params.open_loop ? ol_row_elems(d.n, d.m, d.N) : 0;
   const WsLayout L(d.n, d.m, d.N, d.T, d.pairs.Rsz, d.pairs.rsz, ol_row, d.num_constraints, al_mode);
   SolveArgs<T> sa;
@@ -632,7 +632,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   auto k_lq = pw ? ilq_lq_kernel<T, NX, NP, MU, (C::USE_MFMA ? LQ_PLAYER_WAVES : LQ_VALU_FEEDBACK)>
                  : (p->desc.params.open_loop ? ilq_lq_kernel<T, NX, NP, MU, LQ_OPEN_LOOP>
                                              : ilq_lq_kernel<T, NX, NP, MU, LQ_VALU_FEEDBACK>);
-  const int nt_lq = (pw || p->desc.params.open_loop) ? 64 * NP : C::NT;
+  const int nt_lq = p->desc.params.open_loop ? OLCfg<T, NX, NP, MU>::NT : (pw ? 64 * NP : C::NT);
   raise_lds_limit((const void*)k_trial, lds_trial);
   raise_lds_limit((const void*)k_lq, lds_lq);
 

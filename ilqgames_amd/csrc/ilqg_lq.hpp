@@ -253,6 +253,54 @@ __device__ __forceinline__ void lu_solve_columns(T (&col)[M], int lane, T (&x)[M
   }
 }
 
+// Gaussian elimination with PARTIAL PIVOTING in the same column-per-lane layout, for systems that carry no
+// diagonal-dominance guarantee (the m x m system of the open-loop sweep).  Lane k holds column k of S, i.e. the whole
+// pivot column of step k: it picks the row, the choice is broadcast (wave-uniform), and every lane swaps the two rows of
+// its own column with selects.  Backward stable in practice like the Householder QR the reference uses for these
+// systems; per step one reciprocal instead of a square root and two divisions.
+template <typename T, int M>
+__device__ __forceinline__ void lu_pp_solve_columns(T (&col)[M], int lane, T (&x)[M]) {
+#pragma unroll
+  for (int k = 0; k + 1 < M; k++) {
+    int p = k;
+    T best = col[k] < T(0) ? -col[k] : col[k];
+#pragma unroll
+    for (int i = k + 1; i < M; i++) {
+      const T v = col[i] < T(0) ? -col[i] : col[i];
+      const bool gt = v > best;
+      best = gt ? v : best;
+      p = gt ? i : p;
+    }
+    p = __builtin_amdgcn_readlane(p, k);
+    const T ck = col[k];
+    T cp = ck;
+#pragma unroll
+    for (int i = k + 1; i < M; i++) {
+      const bool sel = (i == p);
+      cp = sel ? col[i] : cp;
+      col[i] = sel ? ck : col[i];
+    }
+    col[k] = cp;
+    const T rinv = fast_recip(col[k]);
+    T f[M];
+#pragma unroll
+    for (int i = k + 1; i < M; i++) f[i] = bcast(col[i] * rinv, k);
+#pragma unroll
+    for (int i = k + 1; i < M; i++) col[i] -= f[i] * col[k];
+  }
+  T diag = T(1);
+#pragma unroll
+  for (int i = 0; i < M; i++) diag = (lane == i) ? col[i] : diag;
+  const T dinv = fast_recip(diag);
+#pragma unroll
+  for (int i = M - 1; i >= 0; i--) {
+    T s = col[i];
+#pragma unroll
+    for (int k2 = i + 1; k2 < M; k2++) s -= bcast(col[i], k2) * x[k2];
+    x[i] = s * bcast(dinv, i);
+  }
+}
+
 // Forward pass of the sweep: delta_xs (src/lq_feedback_solver.cpp:217-241 — no feedback term) and
 // ILQSolver::ExpectedDecrease (src/ilq_solver.cpp:364-398) from the per-step scratch rows.
 // A_{k+1} and scratch row k+1 are DMA'd into the idle image while step k is computed.

@@ -18,7 +18,7 @@
 //     the two recursions are ONE matrix recursion  Ma_i[k] = Qa_i + Aa^T (Ma_i[k+1] Xa):  the vector parts ride in
 //     column n of products that are computed anyway.
 //   * One wavefront per player.  Wave i holds Ma_i (and its transpose) as 16 x 16 accumulator-layout tiles
-//     (ilqg_mfma.hpp; n' <= 32: a 2 x 2 block of tiles) and runs both products as chains of v_mfma_*_16x16x4; k blocks
+//     (ilqg_mfma.hpp; n' <= 32: a 2 x 2 block of tiles) and runs its products as chains of v_mfma_*_16x16x4; k blocks
 //     whose rows are identically zero are skipped at compile time.  The transpose for the next step goes through the
 //     wave's own LDS tile (write the result, read it back transposed) — the same tile the DMA engine fills with
 //     Q_i | l_i of the next step once it has been read.
@@ -27,14 +27,19 @@
 //         Lambda^{-1} = I - B K^{-1} V,  K = I_m + V B          =>   X = A - B Z,  Z = K^{-1} (V A)
 //                                                                     y = -B K^{-1} g,  g_i = W_i m_i + w_i
 //     (y: c = -B g and V c = -(K - I) g, so K^{-1} V c = -g + K^{-1} g.)  The reference factors the n x n Lambda by
-//     Householder QR (:131); here the m x m system K [Z | z] = [V A | g] takes the column-per-lane Householder QR of
-//     the feedback sweep in wave 0 (m + n + 1 columns), everything around it is spread over the workgroup:
-//     [V_i | g_i] = R_ii^{-1} (B_i^T Ma_i + [0 | r_ii]) per wave (MFMA + LDL^T), [K | V A] one entry per thread,
-//     Xa = Aa - B [Z | z] per wave on the matrix cores (every wave needs Xa, so every wave computes it).
-//     Both forms solve the same linear system; the parity tests compare with the QR oracle.
-//   * The forward pass needs, per step, X, y, V = [W_i M_i[k+1]], g and (for the expected decrease) Q_i l_i:
-//     alpha_i,k = V_i x_{k+1} + g_i.  That is the scratch row the backward pass leaves (n^2 + n + m n + m + N n
-//     elements; M_i, m_i are appended only when costates are asked for).
+//     Householder QR (:131); here the m x m system K [Z | z] = [V A | g] is solved by Gaussian elimination with partial
+//     pivoting, one column per lane (m + n + 1 columns), in wave 0.  Both forms solve the same linear system; the
+//     parity tests compare with the QR oracle.
+//   * A step has two workgroup barriers:  [V_i | g_i] = R_ii^{-1} (B_i^T Ma_i + [0 | r_ii]) (MFMA + LDL^T) and this
+//     player's rows of [K | V A]; barrier; elimination (wave 0); barrier; Xa = Aa - [B; 0] [Z | z] (every wave needs
+//     it, so every wave computes it), W = Ma Xa, Ma' = Qa + Aa^T W, transpose.  The elimination is a dependent chain of
+//     ~5k cycles during which three waves of the instance wait: the kernel is sized (registers, LDS) for three
+//     instances per CU so that other instances' products fill the fp64 pipes meanwhile.  (Hoisting the Zt-independent
+//     part of the products in front of the solve — Ma' = G - H Zt — was measured and dropped: fp64 MFMA runs at the
+//     vector fp64 rate on gfx950, the extra products cost what the overlap saves.)
+//   * The forward pass needs, per step, X, y, V = [W_i M_i[k+1]], g and (for the expected decrease) R_ii r_ii and
+//     Q_i l_i:  alpha_i,k = V_i x_{k+1} + g_i.  That is the scratch row the backward pass leaves (n^2 + n + m n + 2 m
+//     + N n elements; M_i, m_i are appended only when costates are asked for).
 #pragma once
 
 #include "ilqg_lq.hpp"
@@ -67,12 +72,13 @@ struct OLCfg {
   static constexpr int LD = pad_ld<T>(NH);
   static constexpr int MAT = (NH * LD + 3) & ~3;  // one padded n' x n' matrix
   static constexpr int LDZ = pad_ld<T>(M);
-  // scratch row (global), one per time step: [X | y | V | g | Q_i l_i]  (+ [M_i | m_i] when costates are wanted)
+  // scratch row (global), one per time step: [X | y | V | g | R_ii r_ii | Q_i l_i]  (+ [M_i | m_i] for costates)
   static constexpr int rX = 0;
   static constexpr int ry = rX + NX * NX;
   static constexpr int rV = ry + NX;
   static constexpr int rg = rV + M * NX;
-  static constexpr int rql = rg + M;
+  static constexpr int rRr = rg + M;
+  static constexpr int rql = rRr + M;
   static constexpr int ROW = (rql + NP * NX + 3) & ~3;
   static constexpr int rM = ROW;
   static constexpr int rm = rM + NP * NX * NX;
@@ -82,16 +88,17 @@ struct OLCfg {
   static constexpr int BIMG = ((NX * M + 3) & ~3) + C::RMAX + C::rMAX;  // [B | R | r] of one step (double-buffered)
   static constexpr int oV = 0;                    // V (m x n, column-major)
   static constexpr int og = oV + M * NX;          // g (m)
-  static constexpr int oKA = (og + M + 3) & ~3;   // [K | V A] (m x (m + n))
+  static constexpr int oRr = og + M;              // R_ii r_ii (m)
+  static constexpr int oKA = (oRr + M + 3) & ~3;  // [K | V A] (m x (m + n))
   static constexpr int oBt = oKA + M * (M + NX);  // per player: B_i^T Ma_i bounce (mu x n')
   static constexpr int oZs = (oBt + NP * MU * NH + 3) & ~3;  // [Z | z] (m x n', leading dimension LDZ)
   static constexpr int oB = (oZs + LDZ * NH + 3) & ~3;       // two [B | R | r] images
-  static constexpr int oA = oB + 2 * BIMG;        // Aa
-  static constexpr int oZ = oA + MAT;             // per player: Qa_i image / transposition tile
+  static constexpr int oA = oB + 2 * BIMG;        // two Aa images
+  static constexpr int oZ = oA + 2 * MAT;         // per player: Qa_i image / transposition tile
   static constexpr int SLACK = (32 + 32 * LD - MAT + 3) & ~3;
   static constexpr int LDS_BWD = oZ + NP * MAT + (SLACK > 0 ? SLACK : 0);
   static_assert(oZs + 16 + 32 * LDZ <= LDS_BWD && oB + 32 + NX * 32 <= LDS_BWD, "edge-tile reads stay inside the LDS");
-  // forward pass (wave 0; overlays the backward working set): two staged rows, x_k, x_{k+1}, alpha, it
+  // forward pass (one wave; overlays the backward working set): two staged rows, x_k, x_{k+1}, alpha, it
   static constexpr int fx = 2 * ROW;
   static constexpr int fa = fx + 2 * NX;
   static constexpr int fit = (fa + M + 3) & ~3;
@@ -100,8 +107,8 @@ struct OLCfg {
 };
 
 // Elements of one open-loop scratch row from run-time dimensions (OLCfg::ROW / ROW_FAT).
-__host__ __device__ inline int ol_row_elems(int n, int m, int N, bool fat = false) {
-  const int slim = (n * n + n + m * n + m + N * n + 3) & ~3;
+__host__ __device__ constexpr int ol_row_elems(int n, int m, int N, bool fat = false) {
+  const int slim = (n * n + n + m * n + 2 * m + N * n + 3) & ~3;
   return fat ? ((slim + N * n * n + N * n + 3) & ~3) : slim;
 }
 
@@ -109,19 +116,20 @@ __host__ __device__ inline int ol_row_elems(int n, int m, int N, bool fat = fals
 // src/lq_open_loop_solver.cpp:124-126; R_ii is diagonally dominant in every config).
 template <typename T, int MU>
 __device__ __forceinline__ void ldlt_solve(const T* R /* MU x MU col-major */, T (&b)[MU]) {
-  T Lm[MU][MU], D[MU];
+  T Lm[MU][MU], D[MU], Dinv[MU];  // one reciprocal per pivot (fast_recip: within an ulp of the quotient)
 #pragma unroll
   for (int jx = 0; jx < MU; jx++) {
     T dj = R[jx + MU * jx];
 #pragma unroll
     for (int k = 0; k < jx; k++) dj -= Lm[jx][k] * Lm[jx][k] * D[k];
     D[jx] = dj;
+    Dinv[jx] = fast_recip(dj);
 #pragma unroll
     for (int i = jx + 1; i < MU; i++) {
       T s = R[i + MU * jx];
 #pragma unroll
       for (int k = 0; k < jx; k++) s -= Lm[i][k] * Lm[jx][k] * D[k];
-      Lm[i][jx] = s / dj;
+      Lm[i][jx] = s * Dinv[jx];
     }
   }
 #pragma unroll
@@ -129,7 +137,7 @@ __device__ __forceinline__ void ldlt_solve(const T* R /* MU x MU col-major */, T
 #pragma unroll
     for (int k = 0; k < i; k++) b[i] -= Lm[i][k] * b[k];
 #pragma unroll
-  for (int i = 0; i < MU; i++) b[i] /= D[i];
+  for (int i = 0; i < MU; i++) b[i] *= Dinv[i];
 #pragma unroll
   for (int i = MU - 1; i >= 0; i--)
 #pragma unroll
@@ -168,6 +176,7 @@ constexpr int kd_mask(int KD, int c) {
 }
 
 // a.scratch must hold T_steps rows of OLCfg::ROW elements (ROW_FAT when a.costates).  a.P is written as zero (:96-102).
+// Executed by a workgroup of OLCfg::NT threads (one wave per player).
 template <typename T, int NX, int NP, int MU>
 __device__ __forceinline__ void lq_openloop_instance(const LQArgs<T>& a, const PairTable& pt, T* sm) {
   using C = LQCfg<T, NX, NP, MU>;
@@ -179,6 +188,7 @@ __device__ __forceinline__ void lq_openloop_instance(const LQArgs<T>& a, const P
   constexpr int BOFF_R = (NX * M + 3) & ~3, BOFF_r = BOFF_R + C::RMAX;
   const int t = threadIdx.x;
   const int w = t >> 6;  // wave = player
+  const int wp = w;
   const int lane = t & 63, g = lane >> 4, j = lane & 15;
   const int Tn = a.T_steps;
   const int ROWS = a.costates ? O::ROW_FAT : O::ROW;
@@ -187,53 +197,69 @@ __device__ __forceinline__ void lq_openloop_instance(const LQArgs<T>& a, const P
   int ro_ww = 0, rg_ww = 0;  // this player's offsets in the R / r rows
 #pragma unroll
   for (int e = 0; e < NP; e++) {
-    ro_ww = (w == e) ? pr.ro[e][e] : ro_ww;
-    rg_ww = (w == e) ? pr.rg[e][e] : rg_ww;
+    ro_ww = (wp == e) ? pr.ro[e][e] : ro_ww;
+    rg_ww = (wp == e) ? pr.rg[e][e] : rg_ww;
   }
-  T* const sZ = sm + O::oZ + w * MAT;  // this wave's tile
-  T* const sAa = sm + O::oA;
+  T* const sZ = sm + O::oZ + wp * MAT;  // this player's tile
   T* const sV = sm + O::oV;
   T* const sg = sm + O::og;
+  T* const sRr = sm + O::oRr;
   T* const sKA = sm + O::oKA;
   T* const sZs = sm + O::oZs;
-  T* const sBt = sm + O::oBt + w * (MU * NH);
+  T* const sBt = sm + O::oBt + wp * (MU * NH);
   auto bimg = [&](int which) { return sm + O::oB + which * O::BIMG; };
+  auto aimg = [&](int which) { return sm + O::oA + which * MAT; };
   auto row_of = [&](int k) { return a.scratch + size_t(k) * ROWS; };
 
   // ---- DMA plumbing: columns of NX elements (contiguous in global memory) into padded columns of LD elements ----
-  // One wave moves `ncols` columns; piece p of the padded image is column p / PPC, offset p % PPC.
+  // Piece p of the padded image is column p / PPC, offset p % PPC; one wave moves a whole matrix.
   constexpr int PS = ((NX * S) % 16 == 0 && (LD * S) % 16 == 0) ? 16 : 4;  // DMA piece (bytes)
   constexpr int PPC = LD * S / PS;                                          // pieces of a padded column
   constexpr int VPC = NX * S / PS;                                          // of which carry data
-  auto dma_cols = [&](const T* src, T* dst, int ncols, int first_instr, int instr_step) {
-    const int total = ncols * PPC;
-    for (int h = first_instr; h * 64 < total; h += instr_step) {
-      const int p = h * 64 + lane;
-      const int c = p / PPC, inb = p % PPC;
-      if (p < total && inb < VPC) {
-        const char* s = reinterpret_cast<const char*>(src) + (c * NX * S + inb * PS);
-        char* d = reinterpret_cast<char*>(dst) + h * 64 * PS;  // wave-uniform; the hardware adds lane * PS
-        if constexpr (PS == 16)
-          __builtin_amdgcn_global_load_lds((glb_vptr)s, (lds_vptr)d, 16, 0, 0);
-        else
-          __builtin_amdgcn_global_load_lds((glb_vptr)s, (lds_vptr)d, 4, 0, 0);
-      }
-    }
+  // The per-lane source offsets are the same every step: worked out once (the division stays out of the step loop).
+  constexpr int WI = (NX * PPC + 63) / 64;  // DMA instructions of an NX-column image
+  int plan[WI];                              // byte offset of this lane's piece of instruction h in the source, or -1
+#pragma unroll
+  for (int h = 0; h < WI; h++) {
+    const int p = h * 64 + lane;
+    const int c = p / PPC, inb = p % PPC;
+    plan[h] = (p < NX * PPC && inb < VPC) ? c * NX * S + inb * PS : -1;
+  }
+  auto dma_piece = [&](const char* s, char* d) {  // d is wave-uniform; the hardware adds lane * PS
+    if constexpr (PS == 16)
+      __builtin_amdgcn_global_load_lds((glb_vptr)s, (lds_vptr)d, 16, 0, 0);
+    else
+      __builtin_amdgcn_global_load_lds((glb_vptr)s, (lds_vptr)d, 4, 0, 0);
   };
-  // Q_i | l_i of step k into this wave's tile (columns 0..NX-1 and column NX)
+  auto dma_matrix = [&](const T* src, T* dst) {  // NX columns
+#pragma unroll
+    for (int h = 0; h < WI; h++)
+      if (plan[h] >= 0) dma_piece(reinterpret_cast<const char*>(src) + plan[h], reinterpret_cast<char*>(dst) + h * 64 * PS);
+  };
+  auto dma_column = [&](const T* src, T* dst) {  // one column
+    static_assert(VPC <= 64, "a column is one DMA instruction");
+    if (lane < VPC) dma_piece(reinterpret_cast<const char*>(src) + lane * PS, reinterpret_cast<char*>(dst));
+  };
+  // player wave: Q_i | l_i of step k into its tile (columns 0..NX-1 and column NX)
   auto issue_Q = [&](int k) {
-    dma_cols(a.Q + (size_t(k) * NP + w) * NX * NX, sZ, NX, 0, 1);
-    dma_cols(a.l + (size_t(k) * NP + w) * NX, sZ + LD * NX, 1, 0, 1);
+    dma_matrix(a.Q + (size_t(k) * NP + wp) * NX * NX, sZ);
+    dma_column(a.l + (size_t(k) * NP + wp) * NX, sZ + LD * NX);
   };
-  // A of step k (the waves share the instructions)
-  auto issue_A = [&](int k) { dma_cols(a.A + size_t(k) * NX * NX, sAa, NX, w, NP); };
-  // [B | R | r] of step k into image `which`
-  auto issue_B = [&](int k, int which) {
-    T* img = bimg(which);
-    dma_g2l<NT, false>(a.Bm + size_t(k) * NX * M, img, NX * M * S, t);
-    dma_g2l<NT, false>(a.R + size_t(k) * pt.Rsz, img + BOFF_R, pt.Rsz * S, t);
-    dma_g2l<NT, false>(a.r + size_t(k) * pt.rsz, img + BOFF_r, pt.rsz * S, t);
+  // A and [B | R | r] of step k into the images of its parity; the waves share the instructions.
+  auto dma_matrix_shared = [&](const T* src, T* dst) {
+#pragma unroll
+    for (int h = 0; h < WI; h++)
+      if (h % NP == wp && plan[h] >= 0) dma_piece(reinterpret_cast<const char*>(src) + plan[h], reinterpret_cast<char*>(dst) + h * 64 * PS);
   };
+  auto issue_shared = [&](int k) {
+    dma_matrix_shared(a.A + size_t(k) * NX * NX, aimg(k & 1));
+    T* img = bimg(k & 1);
+    const int tp = wp * 64 + lane;
+    dma_g2l<64 * NP, false>(a.Bm + size_t(k) * NX * M, img, NX * M * S, tp);
+    dma_g2l<64 * NP, false>(a.R + size_t(k) * pt.Rsz, img + BOFF_R, pt.Rsz * S, tp);
+    dma_g2l<64 * NP, false>(a.r + size_t(k) * pt.rsz, img + BOFF_r, pt.rsz * S, tp);
+  };
+  auto lds_drain = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
 
   // this lane's offsets into accumulator-layout operands (plain / transposed) for the three leading dimensions
   const int oD = tile_lane_offset<T, false>(LD, g, j), oT = tile_lane_offset<T, true>(LD, g, j);
@@ -258,24 +284,18 @@ __device__ __forceinline__ void lq_openloop_instance(const LQArgs<T>& a, const P
   constexpr int KN0 = kd_mask<T>(NX, 0), KN1 = kd_mask<T>(NX, 1);  // over n rows
   constexpr int KM0 = kd_mask<T>(M, 0);                            // over m rows
 
-  // ---- once per sweep: zero the tiles' padding, the homogeneous column of Aa ----
-  static_assert(O::oZ == O::oA + MAT, "Aa and the tiles are zeroed in one piece");
-  for (int e = t; e < NP * MAT + MAT; e += NT) sm[O::oA + e] = T(0);
-  lds_sync(NT <= 64);
-  if (t == 0) sAa[NX + LD * NX] = T(1);
-  lds_sync(NT <= 64);
+  // ---- once per sweep: zero the tiles' padding, the homogeneous column of both Aa images ----
+  static_assert(O::oZ == O::oA + 2 * MAT, "the Aa images and the tiles are zeroed in one piece");
+  for (int e = t; e < (NP + 2) * MAT; e += NT) sm[O::oA + e] = T(0);
+  lds_sync(false);
+  if (t < 2) aimg(t)[NX + LD * NX] = T(1);
+  lds_sync(false);
 
   // ---- terminal step (:105-108): Ma_i = Qa_i[T-1] ----
   issue_Q(Tn - 1);
-  if (Tn >= 2) {
-    issue_A(Tn - 2);
-    issue_B(Tn - 2, (Tn - 2) & 1);
-    if (Tn >= 3) issue_B(Tn - 3, (Tn - 3) & 1);
-  }
+  if (Tn >= 2) issue_shared(Tn - 2);
   dma_wait();
-  lds_sync(NT <= 64);
-  Blk Md = load_blk(sZ, false);  // D(Ma_i)
-  Blk MT = load_blk(sZ, true);   // D(Ma_i^T)
+  lds_sync(false);
   // Q_i l_i of a step (expected decrease, ilq_solver.cpp:392) -> scratch row, and M_i, m_i when costates are wanted;
   // both read this wave's tile
   auto store_row_from_tile = [&](int k, bool tile_holds_Q) {
@@ -284,18 +304,13 @@ __device__ __forceinline__ void lq_openloop_instance(const LQArgs<T>& a, const P
       T s = T(0);
 #pragma unroll
       for (int c = 0; c < NX; c++) s += sZ[lane + LD * c] * sZ[c + LD * NX];
-      row[O::rql + w * NX + lane] = s;
+      row[O::rql + wp * NX + lane] = s;
     }
     if (!tile_holds_Q && a.costates) {
-      for (int e = lane; e < NX * NX; e += 64) row[O::rM + w * NX * NX + e] = sZ[(e % NX) + LD * (e / NX)];
-      if (lane < NX) row[O::rm + w * NX + lane] = sZ[lane + LD * NX];
+      for (int e = lane; e < NX * NX; e += 64) row[O::rM + wp * NX * NX + e] = sZ[(e % NX) + LD * (e / NX)];
+      if (lane < NX) row[O::rm + wp * NX + lane] = sZ[lane + LD * NX];
     }
   };
-  store_row_from_tile(Tn - 1, true);
-  if (a.costates) store_row_from_tile(Tn - 1, false);  // M[T-1] = Q[T-1]: the tile holds both
-  lds_sync(true);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the tile has been read: the DMA engine may refill it
-  if (Tn >= 2) issue_Q(Tn - 2);
 
   long long ph_c = (kProfile && a.ph) ? clock64() : 0;
   auto PH = [&](int slot) {
@@ -306,13 +321,22 @@ __device__ __forceinline__ void lq_openloop_instance(const LQArgs<T>& a, const P
     }
   };
 
+  Blk Md = load_blk(sZ, false);  // D(Ma_i)
+  Blk MT = load_blk(sZ, true);   // D(Ma_i^T)
+  store_row_from_tile(Tn - 1, true);
+  if (a.costates) store_row_from_tile(Tn - 1, false);  // M[T-1] = Q[T-1]: the tile holds both
+  lds_sync(true);
+  lds_drain();  // the tile has been read: the DMA engine may refill it
+  if (Tn >= 2) issue_Q(Tn - 2);
 #pragma unroll 1
   for (int k = Tn - 2; k >= 0; k--) {
-    const T* img = bimg(k & 1);
-    const T* sB = img;
-    const T* sR = img + BOFF_R;
-    const T* sr = img + BOFF_r;
-    // ---- [V_i | g_i] = R_ii^{-1} (B_i^T Ma_i + [0 | r_ii]) ----
+    const T* sB = bimg(k & 1);
+    const T* sR = sB + BOFF_R;
+    const T* sr = sB + BOFF_r;
+    const T* sAa = aimg(k & 1);
+    // the images of the other parity were last read in step k + 1
+    if (k > 0) issue_shared(k - 1);
+    // ---- [V_i | g_i] = R_ii^{-1} (B_i^T Ma_i + [0 | r_ii]),  R_ii r_ii ----
     {
       vec Bd[NTL];  // D(B_i): n x mu
 #pragma unroll
@@ -341,24 +365,26 @@ __device__ __forceinline__ void lq_openloop_instance(const LQArgs<T>& a, const P
           else
             sg[w * MU + aa] = b[aa];
         }
+      } else if (lane < NH + MU) {
+        const int aa = lane - NH;
+        T s = T(0);
+#pragma unroll
+        for (int c = 0; c < MU; c++) s += sR[ro_ww + aa + MU * c] * sr[rg_ww + c];
+        sRr[w * MU + aa] = s;
+      }
+      lds_sync(true);
+      // this player's rows of [K | V A] = [I + V B | V A]
+      for (int e = lane; e < MU * (M + NX); e += 64) {
+        const int q = w * MU + e % MU, c = e / MU;
+        const T* colp = c < M ? sB + NX * c : sAa + LD * (c - M);
+        T s = (c == q) ? T(1) : T(0);
+#pragma unroll
+        for (int r = 0; r < NX; r++) s += sV[q + M * r] * colp[r];
+        sKA[q + M * c] = s;
       }
     }
-    dma_wait();  // A, Q_i | l_i of this step (issued at the end of the previous one) have landed
-    lds_sync(NT <= 64);
+    lds_sync(NT <= 64);  // barrier 1: [K | V A], g complete
     PH(0);
-    static_assert(O::og == O::oV + M * NX && O::rg == O::rV + M * NX, "[V | g] is copied to the scratch row in one piece");
-    for (int e = t; e < M * NX + M; e += NT) row_of(k)[O::rV + e] = sV[e];
-    // ---- [K | V A] = [I + V B | V A], one entry per thread ----
-    for (int e = t; e < M * (M + NX); e += NT) {
-      const int q = e % M, c = e / M;
-      const T* colp = c < M ? sB + NX * c : sAa + LD * (c - M);
-      T s = (c == q) ? T(1) : T(0);
-#pragma unroll
-      for (int r = 0; r < NX; r++) s += sV[q + M * r] * colp[r];
-      sKA[e] = s;
-    }
-    lds_sync(NT <= 64);
-    PH(1);
     // ---- K [Z | z] = [V A | g] (wave 0, column per lane) ----
     if (w == 0) {
       T col[M], x[M];
@@ -367,15 +393,22 @@ __device__ __forceinline__ void lq_openloop_instance(const LQArgs<T>& a, const P
         col[q] = lane < M + NX ? sKA[q + M * (lane < M + NX ? lane : 0)] : (lane == M + NX ? sg[q] : T(0));
         x[q] = T(0);
       }
-      qr_solve_columns<T, M>(col, lane, x);
+      {  // [V | g | R_ii r_ii] -> scratch row k (forward pass)
+        static_assert(O::og == O::oV + M * NX && O::oRr == O::og + M && O::rg == O::rV + M * NX && O::rRr == O::rg + M,
+                      "[V | g | R r] is copied to the scratch row in one piece");
+        T* row = row_of(k);
+        for (int e = lane; e < M * NX + 2 * M; e += 64) row[O::rV + e] = sV[e];
+      }
+      lu_pp_solve_columns<T, M>(col, lane, x);
       if (lane >= M && lane <= M + NX) {
 #pragma unroll
         for (int q = 0; q < M; q++) sZs[q + LDZ * (lane - M)] = x[q];
       }
     }
-    lds_sync(NT <= 64);
+    PH(1);
+    lds_sync(NT <= 64);  // barrier 2: [Z | z] published
     PH(2);
-    // ---- Xa = Aa - B [Z | z]  (every wave) ----
+    // ---- Xa = Aa - Bt Zt  (every wave) ----
     Blk Xd;
     {
       vec nBT[NTL], Zd[NTL];  // D(-B^T) (m x n), D([Z | z]) (m x n')
@@ -392,7 +425,20 @@ __device__ __forceinline__ void lq_openloop_instance(const LQArgs<T>& a, const P
         for (int bb = 0; bb < NTL; bb++)
           Xd.v[aa][bb] = tile_xty_blocks<T, KM0>(nBT[aa], Zd[bb], ld_tile<T, false>(sAa + oD, LD, aa, bb, NH, NH, g, j));
     }
-    // X, y -> scratch row k (the waves share the tiles)
+    // ---- W = Ma Xa ----
+    Blk Wd;
+#pragma unroll
+    for (int aa = 0; aa < NTL; aa++)
+#pragma unroll
+      for (int bb = 0; bb < NTL; bb++) {
+        vec acc = tile_xty_blocks<T, KH0>(MT.v[0][aa], Xd.v[0][bb], zero4);
+        if constexpr (NTL == 2) acc = tile_xty_blocks<T, KH1>(MT.v[1][aa], Xd.v[1][bb], acc);
+        Wd.v[aa][bb] = acc;
+      }
+    dma_wait();  // Q_i | l_i of this step (issued at the end of the previous one) has landed in the tile, and this
+                 // wave's share of the next step's A, [B | R | r] (visible to the others after the next barrier)
+    // X, y -> scratch row k (the waves share the tiles), Q_i l_i.  Stored after the wait above, so that the stores have a
+    // whole step to drain before the next one.
     {
       T* row = row_of(k);
 #pragma unroll
@@ -408,17 +454,8 @@ __device__ __forceinline__ void lq_openloop_instance(const LQArgs<T>& a, const P
             }
           }
     }
-    // ---- W = Ma Xa;  Ma' = Qa + Aa^T W ----
-    Blk Wd;
-#pragma unroll
-    for (int aa = 0; aa < NTL; aa++)
-#pragma unroll
-      for (int bb = 0; bb < NTL; bb++) {
-        vec acc = tile_xty_blocks<T, KH0>(MT.v[0][aa], Xd.v[0][bb], zero4);
-        if constexpr (NTL == 2) acc = tile_xty_blocks<T, KH1>(MT.v[1][aa], Xd.v[1][bb], acc);
-        Wd.v[aa][bb] = acc;
-      }
-    store_row_from_tile(k, true);  // Q_i l_i
+    store_row_from_tile(k, true);
+    // ---- Ma' = Qa + Aa^T W ----
 #pragma unroll
     for (int aa = 0; aa < NTL; aa++)
 #pragma unroll
@@ -446,11 +483,8 @@ __device__ __forceinline__ void lq_openloop_instance(const LQArgs<T>& a, const P
     MT = load_blk(sZ, true);
     if (a.costates) store_row_from_tile(k, false);
     lds_sync(true);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the tile has been read: the DMA engine may refill it
+    lds_drain();  // the tile has been read: the DMA engine may refill it
     if (k > 0) issue_Q(k - 1);
-    lds_sync(NT <= 64);  // every wave is done with Aa (and with V, [K | V A], [Z | z])
-    if (k > 0) issue_A(k - 1);
-    if (k > 1) issue_B(k - 2, k & 1);  // this step's image is free again; B of step k - 1 is already in the other one
     PH(4);
   }
 
@@ -513,21 +547,9 @@ __device__ __forceinline__ void lq_openloop_instance(const LQArgs<T>& a, const P
       lds_sync(true);
       T st = T(0), ct = T(0);
       if (lane < NP) {
-        int ro = 0, rg = 0;
+        // alpha_i^T R_ii r_ii with R_ii r_ii from the backward pass (the reference forms (alpha^T R) r, :384-386)
 #pragma unroll
-        for (int e = 0; e < NP; e++) {
-          ro = (lane == e) ? pr.ro[e][e] : ro;
-          rg = (lane == e) ? pr.rg[e][e] : rg;
-        }
-        const T* Rg = a.R + size_t(k) * pt.Rsz + ro;
-        const T* rgp = a.r + size_t(k) * pt.rsz + rg;
-#pragma unroll
-        for (int c = 0; c < MU; c++) {
-          T aR = T(0);
-#pragma unroll
-          for (int b = 0; b < MU; b++) aR += sal[lane * MU + b] * Rg[b + MU * c];
-          ct += aR * rgp[c];
-        }
+        for (int c = 0; c < MU; c++) ct += sal[lane * MU + c] * fr[O::rRr + lane * MU + c];
         if (k > 0) {
 #pragma unroll
           for (int c = 0; c < NX; c++) st += sx[c] * fr[O::rql + lane * NX + c];

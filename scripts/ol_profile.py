@@ -21,6 +21,6 @@ hip.lib().ilqg_debug_set_profile_buffer(None)
 pm = prof.double().mean(0).cpu().numpy()
 steps = K * (spec.T - 1)
 q = pm[8:16] / steps
-print("lq kernel cycles/launch %.0f ; per step: W,w %.0f | V,g %.0f | Lambda+QR %.0f | M update %.0f | store row %.0f | stage next %.0f | forward pass (per step) %.0f" %
-      (pm[2] / K, q[0], q[1], q[2], q[3], q[4], q[5], q[6]))
+print("lq kernel cycles/launch %.0f ; per step (wave 0): V, g, [K | V A] to barrier 1 %.0f | elimination %.0f | barrier 2 %.0f | Xa, W, Ma' %.0f | transpose, DMA issue %.0f" %
+      (pm[2] / K, q[0], q[1], q[2], q[3], q[4]))
 print("trial kernel cycles/launch %.0f" % (pm[1] / (K + 1)))
