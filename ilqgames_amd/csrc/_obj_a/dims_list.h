@@ -1,1 +1,1 @@
-#define ILQG_FOR_DIMS(X) X(24, 4, 2)
+#define ILQG_FOR_DIMS(X) X(14, 3, 2)

@@ -12,6 +12,7 @@
 #include "ilqg_common.hpp"
 #include "ilqg_lq.hpp"
 #include "ilqg_lq_openloop.hpp"
+#include "ilqg_costates.hpp"
 #include "ilqg_models.hpp"
 #include "ilqg_nash.hpp"
 #include "ilqg_receding.hpp"
@@ -875,7 +876,7 @@ ilqg_status ilqg_lq_feedback_batch(const ilqg_dims* d, const void* A, const void
   if (d->num_players < 1 || d->num_players > ILQG_MAX_PLAYERS || d->n < 1 || d->n > ILQG_MAX_XDIM || d->T < 1 ||
       d->T > kMaxT || d->batch < 0)
     return fail(ILQG_ERR_INVALID, "bad dimensions");
-  if (costates) return fail(ILQG_ERR_UNSUPPORTED, "costates are not produced on device (ILQSolver ignores them)");
+  if (costates && !dx) return fail(ILQG_ERR_INVALID, "costates come with delta_xs (lq_feedback_solver.cpp:77-78)");
   for (const void* ptr : {A, Bm, Q, l, R, r})
     if (reinterpret_cast<uintptr_t>(ptr) % 16 != 0) return fail(ILQG_ERR_INVALID, "array bases must be 16-byte aligned");
   PairTable pt;
@@ -888,11 +889,44 @@ ilqg_status ilqg_lq_feedback_batch(const ilqg_dims* d, const void* A, const void
   if (s != ILQG_OK) return s;
   if (d->batch == 0) return ILQG_OK;
   hipStream_t st = (hipStream_t)stream;
+  const size_t elem = d->dtype == ILQG_F32 ? 4 : 8;
+  const int N = d->num_players;
+  int m = 0;
+  for (int i = 0; i < N; i++) m += d->udim[i];
+  // costates: Z_i, zeta_i of every step (this translation unit's scratch; the sweep's launcher has its own)
+  if (costates) {
+    s = g_scratch.reserve(size_t(d->batch) * costates_scratch_elems(d->n, N, d->T) * elem);
+    if (s != ILQG_OK) return s;
+  }
+  auto finish = [&](ilqg_status launched) -> ilqg_status {
+    if (launched != ILQG_OK || !costates) return launched;
+    CostateDims cd;
+    cd.n = d->n; cd.N = N; cd.m = m; cd.T = d->T;
+    cd.uoff[0] = 0;
+    for (int i = 0; i < N; i++) cd.uoff[i + 1] = cd.uoff[i] + d->udim[i];
+    const size_t lds = costates_lds_elems(d->n, N) * elem;
+    void* zs = g_scratch.ptr;
+    if (d->dtype == ILQG_F32) {
+      auto kern = lq_feedback_costates_kernel<float>;
+      raise_lds_limit((const void*)kern, lds);
+      hipLaunchKernelGGL(kern, dim3(d->batch), dim3(256), lds, st, cd, pt, (const float*)A, (const float*)Bm,
+                         (const float*)Q, (const float*)l, (const float*)R, (const float*)r, (const float*)P,
+                         (const float*)alpha, (const float*)dx, (float*)zs, (float*)costates);
+    } else {
+      auto kern = lq_feedback_costates_kernel<double>;
+      raise_lds_limit((const void*)kern, lds);
+      hipLaunchKernelGGL(kern, dim3(d->batch), dim3(256), lds, st, cd, pt, (const double*)A, (const double*)Bm,
+                         (const double*)Q, (const double*)l, (const double*)R, (const double*)r, (const double*)P,
+                         (const double*)alpha, (const double*)dx, (double*)zs, (double*)costates);
+    }
+    HIP_TRY(hipGetLastError());
+    return ILQG_OK;
+  };
 #define X(NX_, NP_, MU_)                                                                              \
   if (d->n == NX_ && d->num_players == NP_ && mu == MU_) {                                            \
-    return d->dtype == ILQG_F32                                                                       \
+    return finish(d->dtype == ILQG_F32                                                                \
                ? DimsLaunch<float, NX_, NP_, MU_>::lq(d, pt, A, Bm, Q, l, R, r, x0, P, alpha, dx, st)      \
-               : DimsLaunch<double, NX_, NP_, MU_>::lq(d, pt, A, Bm, Q, l, R, r, x0, P, alpha, dx, st);    \
+               : DimsLaunch<double, NX_, NP_, MU_>::lq(d, pt, A, Bm, Q, l, R, r, x0, P, alpha, dx, st));   \
   }
   ILQG_FOR_DIMS(X)
 #undef X

@@ -96,8 +96,9 @@ def selftest_mfma(dtype, X, Y, Cm):
     return out.cpu().numpy().T
 
 
-def lq_feedback(dims, A, Bm, Q, l, R, r, pairs, x0=None, want_dx=True, open_loop=False):
-    """ilqg_lq_feedback_batch / ilqg_lq_openloop_batch on device tensors (numpy inputs are uploaded)."""
+def lq_feedback(dims, A, Bm, Q, l, R, r, pairs, x0=None, want_dx=True, open_loop=False, want_costates=False):
+    """ilqg_lq_feedback_batch / ilqg_lq_openloop_batch on device tensors (numpy inputs are uploaded).
+    Returns (P, alpha, dx) or, with want_costates, (P, alpha, dx, costates [B][T][N][n])."""
     import torch
     dt = dims.dtype
     B, T, n, N = dims.batch, dims.T, dims.n, dims.num_players
@@ -105,12 +106,13 @@ def lq_feedback(dims, A, Bm, Q, l, R, r, pairs, x0=None, want_dx=True, open_loop
     A, Bm, Q, l, R, r, x0 = [_dev(v, dt) for v in (A, Bm, Q, l, R, r, x0)]
     P = torch.empty((B, T, m * n), dtype=torch_dtype(dt), device="cuda")
     alpha = torch.empty((B, T, m), dtype=torch_dtype(dt), device="cuda")
-    dx = torch.empty((B, T, n), dtype=torch_dtype(dt), device="cuda") if want_dx else None
+    dx = torch.empty((B, T, n), dtype=torch_dtype(dt), device="cuda") if (want_dx or want_costates) else None
+    co = torch.empty((B, T, N, n), dtype=torch_dtype(dt), device="cuda") if want_costates else None
     fn = lib().ilqg_lq_openloop_batch if open_loop else lib().ilqg_lq_feedback_batch
     _check(fn(C.byref(dims), _ptr(A), _ptr(Bm), _ptr(Q), _ptr(l), _ptr(R), _ptr(r),
                                         abi.make_pairs(pairs), len(pairs), _ptr(x0), _ptr(P), _ptr(alpha), _ptr(dx),
-                                        None, _stream()))
-    return P, alpha, dx
+                                        _ptr(co), _stream()))
+    return (P, alpha, dx, co) if want_costates else (P, alpha, dx)
 
 
 class Problem:

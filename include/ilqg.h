@@ -92,7 +92,8 @@ typedef enum { ILQG_CHOICE_AUTO = 0, ILQG_CHOICE_OFF = 1, ILQG_CHOICE_ON = 2 } i
  *  P      [B][T][m*n]            stacked gains, rows of player i at sum_{p<i} m_p
  *  alpha  [B][T][m]
  *  dx     [B][T][n] or NULL      delta_xs (forward pass, lq_feedback_solver.cpp:217-241)
- *  costates [B][T][N][n] or NULL
+ *  costates [B][T][N][n] or NULL  -Z_i[k+1] dx_k - zeta_i[k+1], zero at T-1 (lq_feedback_solver.cpp:223-227);
+ *                                needs dx (the reference CHECKs the pair, :77-78): ILQG_ERR_INVALID otherwise
  *  Entry T-1 of P/alpha is written as zero (strategy.h:64-70; loop starts at T-2).
  */
 ilqg_status ilqg_lq_feedback_batch(const ilqg_dims* d, const void* A,
@@ -103,7 +104,8 @@ ilqg_status ilqg_lq_feedback_batch(const ilqg_dims* d, const void* A,
                                    void* dx, void* costates, void* stream);
 
 /* Replaces LQOpenLoopSolver::Solve (src/lq_open_loop_solver.cpp:73-195).
- * Same inputs; P is written as zero, alpha/dx/costates as the reference. */
+ * Same inputs; P is written as zero, alpha/dx as the reference; costates [B][T][N][n] or NULL:
+ * A_k^T (M_i[k+1] x_{k+1} + m_i[k+1]), zero at T-1 (:171-176, :191), dx required with it (:83-84). */
 ilqg_status ilqg_lq_openloop_batch(const ilqg_dims* d, const void* A,
                                    const void* Bm, const void* Q, const void* l,
                                    const void* R, const void* r,

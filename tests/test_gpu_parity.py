@@ -90,6 +90,50 @@ def test_lq_openloop_matches_oracle_random(hip, oracle, dims, dtype):
     assert rel_err(_np(dx), dxr) < tol
 
 
+@pytest.mark.parametrize("open_loop", [False, True])
+@pytest.mark.parametrize("dtype", [abi.F64, abi.F32])
+@pytest.mark.parametrize("dims", [(4, 2, 2), (14, 3, 2), (24, 4, 2)])
+def test_lq_costates_match_oracle(hip, oracle, dims, dtype, open_loop):
+    """The costates output of both LQ entry points (lq_solver.h:63-69): -Z_i[k+1] dx_k - zeta_i[k+1] for the feedback
+    solver (lq_feedback_solver.cpp:223-227), A_k^T (M_i[k+1] x_{k+1} + m_i[k+1]) for the open-loop one
+    (lq_open_loop_solver.cpp:171-176); zero at the last step in both."""
+    n, N, mu = dims
+    rng = np.random.default_rng(11 * n + N + (1 if open_loop else 0))
+    T, B = 16, 3
+    g = random_lq_game(rng, n, [mu] * N, T, B)
+    g["A"] = np.asarray(g["A"])
+    d = dims_of(g, dtype)
+    x0 = rng.standard_normal((B, n))
+    _, ar, dxr, cor = oracle.lq_solve(d, g["A"], g["Bm"], g["Q"], g["l"], g["R"], g["r"], g["pairs"], x0=x0,
+                                      open_loop=open_loop, want_costates=True)
+    _, alpha, dx, co = hip.lq_feedback(d, g["A"], g["Bm"], g["Q"], g["l"], g["R"], g["r"], g["pairs"], x0=x0,
+                                       open_loop=open_loop, want_costates=True)
+    tol = 1e-8 if dtype == abi.F64 else 5e-3
+    assert rel_err(_np(alpha), ar) < tol and rel_err(_np(dx), dxr) < tol
+    assert np.all(_np(co)[:, -1] == 0) and np.all(cor[:, -1] == 0)
+    assert np.max(np.abs(cor)) > 0
+    assert rel_err(_np(co), cor) < tol
+
+
+def test_lq_costates_need_delta_xs(hip):
+    """Both reference solvers CHECK that delta_xs and costates come together (lq_feedback_solver.cpp:77-78,
+    lq_open_loop_solver.cpp:83-84); the C ABI returns ILQG_ERR_INVALID."""
+    import ctypes as C
+    import torch
+    rng = np.random.default_rng(3)
+    g = random_lq_game(rng, 4, [2, 2], 6, 1)
+    d = dims_of(g, abi.F64)
+    dev = lambda v: torch.as_tensor(np.asarray(v), dtype=torch.float64, device="cuda").contiguous()  # noqa: E731
+    arrs = [dev(g[k]) for k in ("A", "Bm", "Q", "l", "R", "r")]
+    P = torch.empty((1, 6, 16), dtype=torch.float64, device="cuda")
+    al = torch.empty((1, 6, 4), dtype=torch.float64, device="cuda")
+    co = torch.empty((1, 6, 2, 4), dtype=torch.float64, device="cuda")
+    for fn in (hip.lib().ilqg_lq_feedback_batch, hip.lib().ilqg_lq_openloop_batch):
+        rc = fn(C.byref(d), *[C.c_void_p(a.data_ptr()) for a in arrs], abi.make_pairs(g["pairs"]), len(g["pairs"]),
+                None, C.c_void_p(P.data_ptr()), C.c_void_p(al.data_ptr()), None, C.c_void_p(co.data_ptr()), None)
+        assert rc == abi.ERR_INVALID
+
+
 def test_ilq_solve_open_loop_matches_oracle_fp64(hip, oracle):
     """BASELINE config 4: roundabout merging (n=24, 4 players) with SolverParams::open_loop, fp64."""
     spec = examples.roundabout_merging(open_loop=True)
