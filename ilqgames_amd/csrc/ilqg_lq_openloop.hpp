@@ -29,7 +29,7 @@
 //     (y: c = -B g and V c = -(K - I) g, so K^{-1} V c = -g + K^{-1} g.)  The reference factors the n x n Lambda by
 //     Householder QR (:131); here the m x m system K [Z | z] = [V A | g] is solved by Gaussian elimination with partial
 //     pivoting, one column per lane (m + n + 1 columns), in wave 0.  Both forms solve the same linear system; the
-//     parity tests compare with the QR oracle.
+//     parity tests compare with the reference arithmetic (QR).
 //   * A step has two workgroup barriers:  [V_i | g_i] = R_ii^{-1} (B_i^T Ma_i + [0 | r_ii]) (MFMA + LDL^T) and this
 //     player's rows of [K | V A]; barrier; elimination (wave 0); barrier; Xa = Aa - [B; 0] [Z | z] (every wave needs
 //     it, so every wave computes it), W = Ma Xa, Ma' = Qa + Aa^T W, transpose.  The elimination is a dependent chain of
@@ -334,8 +334,6 @@ __device__ __forceinline__ void lq_openloop_instance(const LQArgs<T>& a, const P
     const T* sR = sB + BOFF_R;
     const T* sr = sB + BOFF_r;
     const T* sAa = aimg(k & 1);
-    // the images of the other parity were last read in step k + 1
-    if (k > 0) issue_shared(k - 1);
     // ---- [V_i | g_i] = R_ii^{-1} (B_i^T Ma_i + [0 | r_ii]),  R_ii r_ii ----
     {
       vec Bd[NTL];  // D(B_i): n x mu
@@ -385,6 +383,9 @@ __device__ __forceinline__ void lq_openloop_instance(const LQArgs<T>& a, const P
     }
     lds_sync(NT <= 64);  // barrier 1: [K | V A], g complete
     PH(0);
+    // Every wave has left step k + 1 behind: the images of the other parity (last read there) are free for the next
+    // step's A, [B | R | r].  The loads are waited for in front of barrier 2, which publishes them to the other waves.
+    if (k > 0) issue_shared(k - 1);
     // ---- K [Z | z] = [V A | g] (wave 0, column per lane) ----
     if (w == 0) {
       T col[M], x[M];
@@ -406,7 +407,9 @@ __device__ __forceinline__ void lq_openloop_instance(const LQArgs<T>& a, const P
       }
     }
     PH(1);
-    lds_sync(NT <= 64);  // barrier 2: [Z | z] published
+    dma_wait();  // this wave's share of the next step's images, and Q_i | l_i of this step (issued at the end of the
+                 // previous one) in its tile
+    lds_sync(NT <= 64);  // barrier 2: [Z | z] and the next step's images published
     PH(2);
     // ---- Xa = Aa - Bt Zt  (every wave) ----
     Blk Xd;
@@ -435,10 +438,8 @@ __device__ __forceinline__ void lq_openloop_instance(const LQArgs<T>& a, const P
         if constexpr (NTL == 2) acc = tile_xty_blocks<T, KH1>(MT.v[1][aa], Xd.v[1][bb], acc);
         Wd.v[aa][bb] = acc;
       }
-    dma_wait();  // Q_i | l_i of this step (issued at the end of the previous one) has landed in the tile, and this
-                 // wave's share of the next step's A, [B | R | r] (visible to the others after the next barrier)
-    // X, y -> scratch row k (the waves share the tiles), Q_i l_i.  Stored after the wait above, so that the stores have a
-    // whole step to drain before the next one.
+    // X, y -> scratch row k (the waves share the tiles), Q_i l_i.  Stored after this step's wait for the DMA, so that the
+    // stores have a whole step to drain before the next one.
     {
       T* row = row_of(k);
 #pragma unroll

@@ -1476,7 +1476,11 @@ std::vector<Strategy> LQSolver::SolveOnDevice(
       }
     }
   }
-  DeviceBuffer dA, dB, dQ, dl, dR, dr, dx0, dP, dalpha, ddx;
+  // the reference CHECKs that delta_xs and costates come together (lq_feedback_solver.cpp:77-78,
+  // lq_open_loop_solver.cpp:83-84)
+  if (delta_xs) CHECK_NOTNULL(costates);
+  if (costates) CHECK_NOTNULL(delta_xs);
+  DeviceBuffer dA, dB, dQ, dl, dR, dr, dx0, dP, dalpha, ddx, dco;
   Upload(&dA, A, dtype);
   Upload(&dB, Bm, dtype);
   Upload(&dQ, Q, dtype);
@@ -1487,11 +1491,12 @@ std::vector<Strategy> LQSolver::SolveOnDevice(
   dP.Reserve(T * m * n * ElemBytes(dtype));
   dalpha.Reserve(T * m * ElemBytes(dtype));
   ddx.Reserve(T * n * ElemBytes(dtype));
+  if (costates != nullptr) dco.Reserve(T * N * n * ElemBytes(dtype));
 
   auto fn = open_loop ? ilqg_lq_openloop_batch : ilqg_lq_feedback_batch;
   const ilqg_status s = fn(&d, dA.get(), dB.get(), dQ.get(), dl.get(), dR.get(), dr.get(), pairs.data(),
                            static_cast<int32_t>(pairs.size()), dx0.get(), dP.get(), dalpha.get(), ddx.get(),
-                           /*costates=*/nullptr, nullptr);
+                           costates != nullptr ? dco.get() : nullptr, nullptr);
   // dimension mismatches / a missing R_ii abort in the reference (glog CHECK); same here
   CHECK_EQ(s, ILQG_OK) << ilqg_last_error();
   HipCheck(hipDeviceSynchronize(), "lq solve");
@@ -1511,9 +1516,12 @@ std::vector<Strategy> LQSolver::SolveOnDevice(
     delta_xs->assign(T, VectorXf::Zero(n));
     for (int k = 0; k < T; k++) std::memcpy((*delta_xs)[k].data(), &dxs[k * n], n * sizeof(float));
   }
-  // Costates are not produced on the device: ILQSolver discards them (src/ilq_solver.cpp:382-385,
-  // 419-422), so callers get correctly shaped zeros.
-  if (costates != nullptr) costates->assign(T, std::vector<VectorXf>(N, VectorXf::Zero(n)));
+  if (costates != nullptr) {  // [T][N][n] (lq_feedback_solver.cpp:83-92)
+    const std::vector<float> co = Download(dco, T * N * n, dtype);
+    costates->assign(T, std::vector<VectorXf>(N, VectorXf::Zero(n)));
+    for (int k = 0; k < T; k++)
+      for (int i = 0; i < N; i++) std::memcpy((*costates)[k][i].data(), &co[(k * N + i) * n], n * sizeof(float));
+  }
   return strategies;
 }
 

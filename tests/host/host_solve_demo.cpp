@@ -232,7 +232,8 @@ void RunLqGame(const std::string& outdir, bool open_loop) {
   else
     solver.reset(new LQFeedbackSolver(dynamics, T));
   std::vector<VectorXf> delta_xs;
-  const std::vector<Strategy> strategies = solver->Solve(lin, quad, x0, &delta_xs);
+  std::vector<std::vector<VectorXf>> costates;  // the reference CHECKs that the two come together
+  const std::vector<Strategy> strategies = solver->Solve(lin, quad, x0, &delta_xs, &costates);
 
   std::ofstream os(outdir + (open_loop ? "/lq_openloop.txt" : "/lq_feedback.txt"));
   os << std::setprecision(9) << "dims " << n << " " << N << " " << mi << " " << T << "\nx0 " << x0 << "\n";
@@ -259,6 +260,7 @@ void RunLqGame(const std::string& outdir, bool open_loop) {
       os << "\nalpha " << strategies[p].alphas[k] << "\n";
     }
     os << "dx " << delta_xs[k] << "\n";
+    for (int p = 0; p < N; p++) os << "costate " << costates[k][p] << "\n";
   }
 }
 

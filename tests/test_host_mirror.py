@@ -427,7 +427,8 @@ def test_cpp_lq_solvers_match_oracle(demo_out, oracle, open_loop):
     l = d["l"].reshape(1, T, N, n)
     R = d["R"].reshape(1, T, len(pairs) * mi * mi)
     r = d["r"].reshape(1, T, len(pairs) * mi)
-    P, alpha, dx, _ = oracle.lq_solve(dims, A, Bm, Q, l, R, r, pairs, x0=d["x0"].reshape(1, n), open_loop=open_loop)
+    P, alpha, dx, co = oracle.lq_solve(dims, A, Bm, Q, l, R, r, pairs, x0=d["x0"].reshape(1, n), open_loop=open_loop,
+                                       want_costates=True)
     # C++ side printed per-player (m_i x n) gains; restack to the (m x n) column-major layout
     gotP = d["P"].reshape(T, N, n, mi).transpose(0, 2, 1, 3).reshape(T, n * m)
     gotA = d["alpha"].reshape(T, m)
@@ -435,7 +436,8 @@ def test_cpp_lq_solvers_match_oracle(demo_out, oracle, open_loop):
     assert np.max(np.abs(gotP - P[0])) < tol * max(1.0, np.max(np.abs(P)))
     assert np.max(np.abs(gotA - alpha[0])) < tol * max(1.0, np.max(np.abs(alpha)))
     assert np.max(np.abs(d["dx"] - dx[0])) < tol * max(1.0, np.max(np.abs(dx)))
-    assert np.max(np.abs(gotA)) > 1e-3
+    assert np.max(np.abs(d["costate"].reshape(T, N, n) - co[0])) < tol * max(1.0, np.max(np.abs(co)))
+    assert np.max(np.abs(gotA)) > 1e-3 and np.max(np.abs(co)) > 1e-3
 
 
 @pytest.mark.gpu
