@@ -128,8 +128,19 @@ typedef const __attribute__((address_space(1))) void* glb_vptr;
 // Copies `nbytes` (a multiple of 4) from global `g` to LDS `l` with the workgroup's NT threads.
 // The LDS destination of one instruction is wave-uniform base + lane * width, i.e. the LDS image is
 // the global image.  WIDE = 16-byte pieces (both addresses 16-byte aligned), else 4-byte pieces.
+// A wave-uniform pointer, pinned to scalar registers.  The DMA sources below are "uniform base + 32-bit lane offset";
+// left to itself the compiler folds the lane offset into a loop-invariant 64-bit per-lane address per stream and keeps
+// it in VGPRs across the step loops (two registers each — in the sweeps they were what spilled).
+template <class P>
+__device__ __forceinline__ P* uniform_ptr(P* p) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane(unsigned(v)), hi = __builtin_amdgcn_readfirstlane(unsigned(v >> 32));
+  return reinterpret_cast<P*>((static_cast<unsigned long long>(hi) << 32) | lo);
+}
+
 template <int NT, bool WIDE>
-__device__ __forceinline__ void dma_g2l(const void* g, void* l, int nbytes, int t) {
+__device__ __forceinline__ void dma_g2l(const void* g_, void* l, int nbytes, int t) {
+  const void* g = uniform_ptr(g_);
   constexpr int BPL = WIDE ? 16 : 4;
   const int wbase = (t & ~63) * BPL;  // this wave's slice of each NT*BPL chunk
   const int lane = t & 63;
@@ -137,9 +148,9 @@ __device__ __forceinline__ void dma_g2l(const void* g, void* l, int nbytes, int 
     const int my = off + wbase + lane * BPL;
     if (my < nbytes) {
       if constexpr (WIDE)
-        __builtin_amdgcn_global_load_lds((glb_vptr)((const char*)g + my), (lds_vptr)((char*)l + off + wbase), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_vptr)((const char*)g + unsigned(my)), (lds_vptr)((char*)l + off + wbase), 16, 0, 0);
       else
-        __builtin_amdgcn_global_load_lds((glb_vptr)((const char*)g + my), (lds_vptr)((char*)l + off + wbase), 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_vptr)((const char*)g + unsigned(my)), (lds_vptr)((char*)l + off + wbase), 4, 0, 0);
     }
   }
 }

@@ -706,14 +706,17 @@ struct PWCfg {
 // DMA of an (nrows x ncols) column-major matrix with leading dimension NX into a zero-padded 16 x 16
 // tile, executed by ONE wave.  Lane `lane` of instruction h moves piece 64*h + lane of the tile.
 template <typename T, int NX, int LD, int PS, int WI>
-__device__ __forceinline__ void dma_tile(const T* g, T* tile, int nrows, int ncols, int lane) {
+__device__ __forceinline__ void dma_tile(const T* g_, T* tile, int nrows, int ncols, int lane) {
+  const T* g = uniform_ptr(g_);
   constexpr int COLB = LD * int(sizeof(T));  // bytes of a padded column
 #pragma unroll
   for (int h = 0; h < WI; h++) {
     const int pos = (64 * h + lane) * PS;  // byte position inside the padded tile
     const int c = pos / COLB, inb = pos % COLB;
     if (c < ncols && inb + PS <= nrows * int(sizeof(T))) {
-      const char* src = reinterpret_cast<const char*>(g) + c * NX * int(sizeof(T)) + inb;
+      // unsigned: a wave-uniform base plus a zero-extended 32-bit lane offset (the scalar-base addressing mode; a signed
+      // offset makes the compiler keep a 64-bit per-lane address per instruction live across the step loop)
+      const char* src = reinterpret_cast<const char*>(g) + unsigned(c * NX * int(sizeof(T)) + inb);
       char* dst = reinterpret_cast<char*>(tile) + 64 * h * PS;  // wave-uniform; the hardware adds lane * PS
       if constexpr (PS == 16)
         __builtin_amdgcn_global_load_lds((glb_vptr)src, (lds_vptr)dst, 16, 0, 0);
@@ -760,6 +763,12 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
   // 0/1 multipliers instead of selects (all masked quantities are finite)
   const T mCols = (j < NX) ? T(1) : T(0);      // a proper state column
   const T mVecCol = (j == (SPARE ? JB : w)) ? T(1) : T(0);
+  // SPARE: zeta_w rides in column JB of the Z_w tile (rows < NX), so every product with Z_w carries the matching
+  // product with zeta_w: row JB of G = Z_w^T B is zeta_w^T B (y_zeta), column JB of Z_w' = F^T [..] + C_w is the new
+  // zeta_w once column JB of C_w holds its additive terms.  Register rJ of lane group gJ holds row JB.
+  constexpr int gJ = sizeof(T) == 8 ? JB % 4 : JB / 4, rJ = sizeof(T) == 8 ? JB / 4 : JB % 4;
+  static_assert(!SPARE || TL::row(gJ, rJ) == JB, "accumulator-layout position of row JB");
+  const T mZcols = SPARE ? mCols + mVecCol : mCols;  // the columns of the Z_w tile that are kept
 
   // this player's offsets in the R / r rows (wave-uniform selects on a register table)
   int ro_ww = 0, rg_ww = 0;
@@ -840,7 +849,16 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
   const bool sym = a.symmetric != 0;
   vec Zd = ldD(tQ);
   vec Yd = sym ? Zd : ldDT(tQ);
-  if (lane < NX) sZw[lane] = sl[w * NX + lane];
+  if constexpr (SPARE) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int row = row0 + RS * r;
+      Zd[r] += (row < NX ? sl[w * NX + (row < NX ? row : 0)] : T(0)) * mVecCol;  // column JB of the padded Q tile is zero
+    }
+    if (sym) Yd = Zd;
+  } else {
+    if (lane < NX) sZw[lane] = sl[w * NX + lane];
+  }
   stash_ql(Tn - 1);
   for (int e = t; e < M * NX; e += NT) a.P[size_t(Tn - 1) * M * NX + e] = T(0);
   if (t < M) a.alpha[size_t(Tn - 1) * M + t] = T(0);
@@ -854,7 +872,7 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
   int cur = 1;
   set_img(1);
 
-  long long phacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // phase profile, kept in registers until the sweep ends
+  long long phacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // phase profile, kept in registers until the sweep ends
 #pragma unroll 1
   for (int k = Tn - 2; k >= 0; k--) {
     long long pc0 = (kProfile && a.ph) ? clock64() : 0, pc1;
@@ -885,8 +903,13 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
     if (j / MU == w) {
 #pragma unroll
       for (int r = 0; r < 4; r++) sGw[(row0 + RS * r) * MU + (j - w * MU)] = G[r];
+      if constexpr (SPARE) {
+        // y_zeta = B_w^T zeta_w + r_ww (:154-157): row JB of G (zeta_w rides in column JB of the Z_w tile)
+        if (g == gJ) sYz[j] = G[rJ] + sr[rg_ww + (j - w * MU)];
+      }
     }
     lds_sync(true);
+    ILQG_PH(12);
     {
       T gv[NX][MU];
 #pragma unroll
@@ -901,11 +924,17 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
 #pragma unroll
         for (int aa = 0; aa < MU; aa++) acc[aa] += gv[kk][aa] * ba[kk];
       if (lane < M + NX) {
+        // + R_ww on this player's diagonal block of S (:148-150)
+        const bool diag = lane / MU == w;
+        const int b = lane - w * MU;
 #pragma unroll
-        for (int aa = 0; aa < MU; aa++) sSY[(w * MU + aa) + M * lane] = acc[aa];
+        for (int aa = 0; aa < MU; aa++)
+          sSY[(w * MU + aa) + M * lane] = acc[aa] + (diag ? sR[ro_ww + aa + MU * (diag ? b : 0)] : T(0));
       }
     }
-    if (lane < MU) {  // y_zeta = B_w^T zeta_w + r_ww (:154-157)
+    ILQG_PH(13);
+    if constexpr (SPARE) {
+    } else if (lane < MU) {
       const int tt = w * MU + lane;
       T s = T(0);
 #pragma unroll
@@ -917,8 +946,10 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
     ILQG_PH(7);
     if (NP > 1 && w != 0) {  // while wave 0 solves: next step's image and this step's Q_i l_i
       if (k > 0) stage(k - 1, 1 - cur, w - 1, HELPERS);
+      ILQG_PH(14);
       stash_ql(k);
       if (w == 1) stash_ql_of(k, 0);
+      ILQG_PH(15);
     }
 
     // ---- wave 0: column `lane` of [S | Y]: + R_ii, Gershgorin (:163-176), then the M x M solve (:180) ----
@@ -934,16 +965,6 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
         x[r] = T(0);
       }
       {
-        const int pj = isS ? lane / MU : 0, b = lane % MU;
-        int ro_ii = 0;
-#pragma unroll
-        for (int e = 0; e < NP; e++) ro_ii = (pj == e) ? pr.ro[e][e] : ro_ii;
-        const T* Rii = sR + ro_ii;
-#pragma unroll
-        for (int r = 0; r < M; r++) {
-          const T rv = Rii[(r % MU) + MU * b];
-          col[r] = col[r] + ((isS && r / MU == pj) ? rv : T(0));
-        }
         // Gershgorin (columns are independent, so lane-parallel reproduces the sequential loop)
         T l1 = T(0), diag = T(0);
 #pragma unroll
@@ -957,28 +978,35 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
 #pragma unroll
         for (int r = 0; r < M; r++) col[r] = col[r] + ((r == lane) ? bump : T(0));
       }
+      ILQG_PH(10);
       if (a.adaptive)
         lu_solve_columns<T, M>(col, lane, x);
       else
         qr_solve_columns<T, M>(col, lane, x);
+      ILQG_PH(11);
       if (lane >= M && lane < M + NX) {
 #pragma unroll
-        for (int r = 0; r < M; r++) {
-          sPt[r + LD * (lane - M)] = x[r];
-          a.P[size_t(k) * M * NX + r + M * (lane - M)] = x[r];
-        }
+        for (int r = 0; r < M; r++) sPt[r + LD * (lane - M)] = x[r];
       } else if (lane == M + NX) {
 #pragma unroll
         for (int r = 0; r < M; r++) {
           sAl[r] = x[r];
           if constexpr (SPARE) sPt[r + LD * JB] = x[r];  // [P | alpha]: F = A - B [P | alpha] then carries beta = -B alpha
-          a.alpha[size_t(k) * M + r] = x[r];
         }
       }
     }
     ILQG_PH(2);
     lds_sync(false);  // (P, alpha) published
     ILQG_PH(8);
+    // the strategies go to global memory from the last wave (wave 0 is the one the others wait for)
+    if (w == NP - 1) {
+      if (lane < NX) {
+#pragma unroll
+        for (int r = 0; r < M; r++) uniform_ptr(a.P + size_t(k) * M * NX)[unsigned(r + M * lane)] = sPt[r + LD * lane];
+      } else if (lane < NX + M) {
+        uniform_ptr(a.alpha + size_t(k) * M)[unsigned(lane - NX)] = sAl[lane - NX];
+      }
+    }
 
     // ---- F = A - B P (:189-194), beta = -B alpha; every wave needs them, so every wave computes them ----
     const vec Pd = ldD(sPt);
@@ -993,7 +1021,7 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
       for (int r = 0; r < 4; r++) {
         Fd[r] = Fraw[r] * mCols;
         BetaD[r] = Fraw[r] * mVecCol;
-        zetaD[r] = sZw[row0 + RS * r] * mVecCol;
+        zetaD[r] = Zd[r] * mVecCol;
       }
       if (want_fwd && w == 0 && j == JB) {
 #pragma unroll
@@ -1039,6 +1067,39 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
     // ---- Z_w <- F^T Z_w F + Q_w + sum_jj P_jj^T R_w,jj P_jj  (:198-212), both layouts ----
     vec Cd = ldD(tQ);
     vec CTd = sym ? Cd : ldDT(tQ);
+    if constexpr (SPARE) {
+      // column JB of C_w: l_w + sum_jj P_jj^T (R_w,jj alpha_jj - r_w,jj)   (:198-201, 206-212), so that column JB of
+      // Z_w' = F^T [..] + C_w is the new zeta_w.  The sum is [P | alpha]^T q with q = (R_w,jj alpha_jj - r_w,jj) stacked:
+      // one product over the M rows of P with q in column JB of the right operand.  Every lane forms q for its own rows.
+      vec Qy;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = row0 + RS * r;          // a row of P: player jj = row / MU, control aa = row % MU
+        const bool in = row < M;
+        const int rowc = in ? row : 0;
+        const int jj = rowc / MU, aa = rowc % MU;
+        int qw = -1, ro_wj = 0, rg_wj = 0;
+#pragma unroll
+        for (int e = 0; e < NP; e++)
+#pragma unroll
+          for (int f = 0; f < NP; f++)
+            if (w == e && jj == f) {
+              qw = pr.q[e][f];
+              ro_wj = pr.ro[e][f];
+              rg_wj = pr.rg[e][f];
+            }
+        T ww = -sr[rg_wj + aa];
+#pragma unroll
+        for (int b = 0; b < MU; b++) ww += sR[ro_wj + aa + MU * b] * sAl[jj * MU + b];
+        Qy[r] = (in && qw >= 0) ? ww * mVecCol : T(0);
+        const int srow = row < NX ? row : 0;
+        Cd[r] += (row < NX ? sl[w * NX + srow] : T(0)) * mVecCol;
+      }
+      vec Pm;  // P proper: column JB of the tile holds alpha
+#pragma unroll
+      for (int r = 0; r < 4; r++) Pm[r] = Pd[r] * mCols;
+      Cd = tile_xty_blocks<T, kblock_mask<T>(0, M)>(Pm, Qy, Cd);
+    }
     static_for<NP>([&](auto JJ) {  // jj is a compile-time constant: it selects the k blocks of the product
       constexpr int jj = decltype(JJ)::value;
       // + P_jj^T R_w,jj P_jj (and its transpose): H = R P_jj and H' = R^T P_jj sit in rows
@@ -1090,10 +1151,7 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
       if (!sym) Yd = tile_xty<T>(Wm, Fd, CTd);  // (Z_w F)^T F + C_w^T
       const vec Zx = tile_xty<T>(Fd, Wz, Cd);   // F^T [Z_w F | zeta_w + Z_w beta] + C_w
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        Zd[r] = Zx[r] * mCols;
-        FT[r] = Zx[r];
-      }
+      for (int r = 0; r < 4; r++) Zd[r] = Zx[r] * mZcols;  // [Z_w' | F^T (zeta_w + Z_w beta)]
       if (sym) Yd = Zd;
     } else {
       const vec Wd = tile_xty<T>(Yd, Fd, zero4);     // Z_w F
@@ -1107,7 +1165,8 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
       FT = tile_xty<T>(Fd, TD, zero4);  // column w = F^T (zeta_w + Z_w beta)
     }
     ILQG_PH(4);
-    if (j == (SPARE ? JB : w)) {  // the reads of the old zeta (zetaD) precede this by data dependence
+    if constexpr (!SPARE) {
+    if (j == w) {  // the reads of the old zeta (zetaD) precede this by data dependence
 #pragma unroll
       for (int r = 0; r < 4; r++)
         if (row0 + RS * r < NX) sZw[row0 + RS * r] = FT[r];  // F^T (zeta_w + Z_w beta)
@@ -1139,6 +1198,7 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
       }
       sZw[lane] = zn;
     }
+    }
     ILQG_PH(5);
     dma_wait();
     ILQG_PH(9);
@@ -1150,7 +1210,7 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
 #undef ILQG_PH
   if (kProfile && a.ph && lane == 0) {  // wave w's row of the profile: a.ph[16 * w + i]
 #pragma unroll
-    for (int i = 0; i < 10; i++) a.ph[16 * w + i] += phacc[i];
+    for (int i = 0; i < 16; i++) a.ph[16 * w + i] += phacc[i];
   }
 
   if (want_fwd && !a.defer_forward) {

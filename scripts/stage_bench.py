@@ -50,9 +50,10 @@ print("  per launch: trial %.0f  lq sweep %.0f" % (pm[1] / 5, pm[2] / 4))
 hip.lib().ilqg_debug_set_profile_buffer(None)
 
 for wv in range(3):
-    q = pm[8 + 16 * wv: 8 + 16 * wv + 10] / 396
+    q = pm[8 + 16 * wv: 8 + 16 * wv + 16] / 396
     print("  wave %d (cycles/step): issue+ql %.0f | G,SY %.0f | bar1 %.0f | solve %.0f | bar2 %.0f | F,beta %.0f | players %.0f | zeta %.0f | dmawait %.0f | bar3 %.0f   sum %.0f" %
           (wv, q[0], q[1], q[7], q[2], q[8], q[3], q[4], q[5], q[9], q[6], q.sum()))
+    print("     detail: G + LDS bounce %.0f | [S|Y] rows %.0f | y_zeta %.0f || solve: load + Gershgorin %.0f | elimination %.0f | stores %.0f || helpers: stage %.0f | stash Q l %.0f" % (q[12], q[13], q[1], q[10], q[11], q[2], q[14], q[15]))
 
 for wv in range(2):
     q = pm[64 + 8 * wv: 72 + 8 * wv]

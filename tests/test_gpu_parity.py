@@ -276,12 +276,18 @@ def test_ilq_solve_matches_oracle_fp64(hip, oracle, cfg):
     assert np.array_equal(_np(out["status"])[ok], ref["status"][ok])
     same = (_np(out["status"]) == ref["status"]) & (_np(out["iters"]) == ref["iters"])
     agree = np.mean(same)
-    # Measured: every scene 1.00 except SkeletonExample 0.75 (no regularisation, proximity cost switching on
-    # mid-horizon: a quarter of the jittered instances exhaust their line search within six iterations) and
-    # DubinsOrigin 0.83.  Wherever the two runs end differently, a line search went past step alpha0 * 2^-12 or ran out
-    # of steps (status 0: the failing search is not logged) — the depth at which accept / reject is decided by the
-    # last bits of two ~1e5 merit values; the instance-by-instance comparison at forced steps is test_gpu_forced.py.
-    assert agree >= (0.75 if cfg in ("skeleton", "dubins_origin") else 0.9), "too many instances end differently (%.2f agree)" % agree
+    # How many instances CAN end the same way is measured, not guessed: the oracle is run again from x0 nudged by
+    # 1e-12; an instance whose two oracle runs end differently has a line search that is decided by rounding (deep
+    # back-tracking or a failing search: accept / reject hangs on the last bits of two ~1e5 merit values), and two
+    # correct implementations differ there as the oracle differs from itself.  Every scene is fully stable except
+    # SkeletonExample (no regularisation, proximity cost switching on mid-horizon) and DubinsOrigin.  The device may
+    # lose at most two more instances than the oracle loses against itself; the instance-by-instance comparison at
+    # forced steps is test_gpu_forced.py.
+    nudged = oracle.OracleProblem(spec).solve(abi.F64, x0 + 1e-12 * np.random.default_rng(5).standard_normal(x0.shape),
+                                              fixed_iters=K, merit_log_len=K)
+    stable = (nudged["status"] == ref["status"]) & (nudged["iters"] == ref["iters"])
+    assert np.mean(stable) >= 0.5, "the scene is too ill-conditioned to test (%.2f of the oracle's own runs agree)" % np.mean(stable)
+    assert agree >= np.mean(stable) - 2.0 / B, "too many instances end differently (%.2f agree, oracle vs itself %.2f)" % (agree, np.mean(stable))
     depth = np.nan_to_num(ref["log"][:, :, 3], nan=0.0).max(axis=1)
     for b in np.where(~same)[0]:
         assert depth[b] > 12 or ref["status"][b] == 0 or _np(out["status"])[b] == 0, \
