@@ -72,8 +72,10 @@ class HipBackend:
     def alloc(self, B):
         return self.prob.alloc_solve_buffers(B)
 
+    counted = None  # ilqg_solve_options::counted: None = the library's choice (an asynchronous launch sequence)
+
     def solve(self, x0, bufs, iters):
-        self.prob.solve(x0, bufs, fixed_iters=iters)
+        self.prob.solve(x0, bufs, fixed_iters=iters, counted=self.counted)
 
     def sync(self):
         self.torch.cuda.synchronize()
@@ -212,6 +214,12 @@ def main():
     backend.solve(x0_d, bufs, max(1, args.warmup))
     gather()
     backend.sync()
+    # A workload whose line searches back-track is run with ilqg_solve_options::counted: the host reads four counters
+    # per round and the back-tracking instances finish their line search in the speculative passes
+    # instead of serially inside the fused kernel.  Decided from the warm-up's own back-tracking count.
+    warm_bt = backend.mean_backtracks(bufs, int(bufs["iters"].sum().item())) if args.backend == "hip" else 0.0
+    if args.backend == "hip" and warm_bt > 0.25:
+        backend.counted = True
 
     # timed: exactly K iterations of every instance = K (LQ kernel, trial kernel) rounds after the
     # initial trial pass; all launches are enqueued back to back on the current stream
@@ -288,7 +296,10 @@ def main():
                                    "alpha0=0.1 frac=0.001 (exec/three_player_intersection/main.cpp:109-120; the n=14 "
                                    "example's own 1.0 / 0.9 fail the reference's line search at iteration 2: own_params)"
                                    % (args.config, n, N, T, B, args.dtype, args.steps),
-                       "parallelism": "instances sharded across %d GPU(s); RCCL gather of strategies" % world},
+                       "parallelism": "instances sharded across %d GPU(s); RCCL gather of strategies" % world,
+                       "launch_mode": ("host-counted rounds, speculative line search (warm-up back-tracked %.2f times per "
+                                       "iteration)" % warm_bt) if getattr(backend, "counted", None) else
+                                      "asynchronous launch sequence (no host round trips)"},
             "ms_per_solve_batch": kernel_s * 1e3,
             "gather_ms": gather_s * 1e3,
             "success_fraction": float(status.mean()),
