@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from ilqgames_amd import abi, examples
-from helpers import dims_of, load_golden_lq, random_lq_game, rel_err
+from helpers import oracle_with_stability, dims_of, load_golden_lq, random_lq_game, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -367,20 +367,20 @@ def test_ilq_solve_free_running_matches_oracle_fp64(hip, oracle):
     spec = examples.modified_three_player_intersection()
     B = 16
     x0 = examples.jittered_x0(spec, B, seed=3)
-    ref = oracle.OracleProblem(spec).solve(abi.F64, x0, merit_log_len=16)
+    ref, stable = oracle_with_stability(oracle.OracleProblem(spec), abi.F64, x0, keys=("iters", "status", "converged"),
+                                        merit_log_len=16)
     out = hip.Problem(spec, abi.F64).solve(x0)
-    # With the example's own expected_decrease_fraction = 0.9 the reference's line search fails
-    # early for most instances (status 0, last accepted iterate returned) — reproduced.  A FAILED
-    # line search walks through all 100 step sizes, so somewhere on the way the Armijo test is
-    # decided by rounding noise and a correct implementation may accept where another rejects;
-    # the comparison is therefore on the instances where both made the same final decision, and
-    # those must be the large majority.
-    same = np.where((_np(out["status"]) == ref["status"]) & (_np(out["iters"]) == ref["iters"]))[0]
-    assert len(same) >= 0.5 * B
-    bt = np.nan_to_num(ref["log"][:, :, 3], nan=0.0)
-    ok = np.array([b for b in same if bt[b].max() <= 12])
-    assert len(ok) >= 4
-    assert np.array_equal(_np(out["converged"])[ok], ref["converged"][ok])
+    # With the example's own expected_decrease_fraction = 0.9 the reference's line search fails early for most
+    # instances (status 0, last accepted iterate returned) — reproduced.  A FAILED line search walks through all 100
+    # step sizes, so somewhere on the way the Armijo test is decided by rounding noise and a correct implementation
+    # may accept where another rejects — as the oracle does against itself from a 1e-12 nudge of x0.  The comparison
+    # is on the instances whose outcome survives that nudge (helpers.oracle_with_stability): all of them but one must
+    # end the same way on the device, and every one that does must match to the parity bar.
+    same = (_np(out["status"]) == ref["status"]) & (_np(out["iters"]) == ref["iters"]) & \
+        (_np(out["converged"]) == ref["converged"])
+    assert stable.sum() >= 4, "the test instances are all decided by rounding"
+    assert (same & stable).sum() >= stable.sum() - 1, (same, stable)
+    ok = np.where(same & stable)[0]
     assert rel_err(_np(out["xs"])[ok], ref["xs"][ok]) < 1e-7
     assert rel_err(_np(out["P"])[ok], ref["P"][ok]) < 1e-6
     assert rel_err(_np(out["costs"])[ok], ref["costs"][ok]) < 1e-8
@@ -396,13 +396,16 @@ def test_augmented_lagrangian_solve_matches_oracle_fp64(hip, oracle):
     spec.params.unconstrained_solver_max_iters = 5
     B = 12
     x0 = examples.jittered_x0(spec, B, seed=21)
-    ref = oracle.OracleProblem(spec).solve(abi.F64, x0, augmented_lagrangian=True)
+    ref, stable = oracle_with_stability(oracle.OracleProblem(spec), abi.F64, x0, augmented_lagrangian=True)
     out = hip.Problem(spec, abi.F64).solve(x0, augmented_lagrangian=True)
-    same = np.where((_np(out["iters"]) == ref["iters"]) & (_np(out["status"]) == ref["status"]))[0]
-    assert len(same) >= 0.5 * B, (_np(out["iters"]), ref["iters"])
-    err = np.array([rel_err(_np(out["xs"])[b], ref["xs"][b]) for b in same])
-    good = same[err < 1e-6]
-    assert len(good) >= 0.5 * len(same), err
+    same = (_np(out["iters"]) == ref["iters"]) & (_np(out["status"]) == ref["status"])
+    # all but one of the instances whose outcome survives a 1e-12 nudge of x0 in the oracle itself end the same way on
+    # the device, and each of those matches to the parity bar
+    assert stable.sum() >= 3, "the test instances are all decided by rounding"
+    assert (same & stable).sum() >= stable.sum() - 1, (same, stable, _np(out["iters"]), ref["iters"])
+    good = np.where(same & stable)[0]
+    for b in good:
+        assert rel_err(_np(out["xs"])[b], ref["xs"][b]) < 1e-6, b
     assert rel_err(_np(out["costs"])[good], ref["costs"][good]) < 1e-6
     assert np.isfinite(_np(out["xs"])).all()
 
@@ -445,14 +448,15 @@ def test_augmented_lagrangian_single_player_dubins_fp64(hip, oracle):
     spec.params.unconstrained_solver_max_iters = 5
     B = 8
     x0 = examples.jittered_x0(spec, B, seed=21)
-    ref = oracle.OracleProblem(spec).solve(abi.F64, x0, augmented_lagrangian=True)
+    ref, stable = oracle_with_stability(oracle.OracleProblem(spec), abi.F64, x0, keys=("iters", "status", "converged"),
+                                        augmented_lagrangian=True)
     out = hip.Problem(spec, abi.F64).solve(x0, augmented_lagrangian=True)
     same = (_np(out["iters"]) == ref["iters"]) & (_np(out["status"]) == ref["status"]) & \
         (_np(out["converged"]) == ref["converged"])
-    assert same.sum() >= B // 2, (_np(out["iters"]), ref["iters"], _np(out["status"]), ref["status"])
-    g = np.where(same)[0]
-    err = np.array([rel_err(_np(out["xs"])[b], ref["xs"][b]) for b in g])
-    assert (err < 1e-6).sum() >= max(1, len(g) // 2), err
+    assert stable.sum() >= 2, "the test instances are all decided by rounding"
+    assert (same & stable).sum() >= stable.sum() - 1, (same, stable, _np(out["iters"]), ref["iters"])
+    for b in np.where(same & stable)[0]:
+        assert rel_err(_np(out["xs"])[b], ref["xs"][b]) < 1e-6, b
     assert np.isfinite(_np(out["xs"])).all()
 
 
