@@ -221,7 +221,7 @@ def _compare_simulation(hip, oracle, spec, x0, final_time, al, max_records, self
     B = x0.shape[0]
     op = oracle.OracleProblem(spec)
     ref = op.receding_horizon_simulate(abi.F64, x0, final_time, 0.25, augmented_lagrangian=al,
-                                       max_records=max_records, threads=8)
+                                       max_records=max_records, threads=32)
     prob = hip.Problem(spec, abi.F64)
     recs = []
 
@@ -275,7 +275,7 @@ def _compare_simulation(hip, oracle, spec, x0, final_time, al, max_records, self
     # on the same instances: the yardstick the callers hold the device against.
     S = B if self_subset is None else min(B, self_subset)
     again = op.receding_horizon_simulate(abi.F64, x0[:S] + 1e-12 * np.random.default_rng(77).standard_normal((S, x0.shape[1])),
-                                         final_time, 0.25, augmented_lagrangian=al, max_records=max_records, threads=8)
+                                         final_time, 0.25, augmented_lagrangian=al, max_records=max_records, threads=32)
     self_all = self_matched = 0
     for b in range(S):
         R, R2 = int(ref["num_records"][b]), int(again["num_records"][b])
