@@ -12,6 +12,7 @@
 #include "ilqg_common.hpp"
 #include "ilqg_lq.hpp"
 #include "ilqg_lq_openloop.hpp"
+#include "ilqg_lq_feedback2.hpp"
 #include "ilqg_costates.hpp"
 #include "ilqg_models.hpp"
 #include "ilqg_nash.hpp"
@@ -65,7 +66,7 @@ struct LQBatchArgs {
 
 template <typename T, int NX, int NP, int MU, bool FORCE_VALU>
 __global__ void __launch_bounds__((LQFeedbackThreads<T, NX, NP, MU, FORCE_VALU>::NT),
-                                  (LQFeedbackThreads<T, NX, NP, MU, FORCE_VALU>::PLAYER_WAVES ? NP : 1))
+                                  (LQFeedbackThreads<T, NX, NP, MU, FORCE_VALU>::PLAYER_WAVES ? (NX <= 16 ? NP : 2) : 1))
 lq_feedback_kernel(LQBatchArgs<T> g, PairTable pt) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   T* sm = reinterpret_cast<T*>(smem_raw);
@@ -360,7 +361,7 @@ __global__ void __launch_bounds__(64) ilq_exit_kernel(DevProblem p, SolveArgs<T>
 // LQ kernel: the Riccati sweep at the accepted operating point of every instance that asked for one.
 template <typename T, int NX, int NP, int MU, int KIND>
 __global__ void __launch_bounds__((KIND == LQ_VALU_FEEDBACK ? LQCfg<T, NX, NP, MU>::NT : (KIND == LQ_OPEN_LOOP ? OLCfg<T, NX, NP, MU>::NT : 64 * NP)),
-                                  (KIND == LQ_PLAYER_WAVES ? NP : (KIND == LQ_OPEN_LOOP ? 3 : 1)))
+                                  (KIND == LQ_PLAYER_WAVES ? (NX <= 16 ? NP : 2) : (KIND == LQ_OPEN_LOOP ? 3 : 1)))
 ilq_lq_kernel(DevProblem p, SolveArgs<T> sa) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int b = blockIdx.x;
@@ -503,7 +504,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::lq(const ilqg_dims* d, const PairTable& p
   // ilqg_dims::sweep_formulation = ILQG_CHOICE_OFF selects the VALU/LDS formulation where the MFMA one is the default
   const bool valu = C::USE_MFMA && d->sweep_formulation == ILQG_CHOICE_OFF;
   const bool use_pw = C::USE_MFMA && !valu;
-  const size_t lds = size_t(use_pw ? PWCfg<T, NX, NP, MU>::LDS_ELEMS : C::LDS_ELEMS) * sizeof(T);
+  const size_t lds = size_t(use_pw ? MfmaSweepLds<T, NX, NP, MU>::ELEMS : C::LDS_ELEMS) * sizeof(T);
   auto kern = valu ? lq_feedback_kernel<T, NX, NP, MU, true> : lq_feedback_kernel<T, NX, NP, MU, false>;
   const int nt = valu ? LQFeedbackThreads<T, NX, NP, MU, true>::NT : LQFeedbackThreads<T, NX, NP, MU, false>::NT;
   raise_lds_limit((const void*)kern, lds);
@@ -616,7 +617,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   constexpr int W = TrialWaves<T>::W;
   // LDS of the sweep kernel that will run: the open-loop sweep's own working set plus the slot the expected
   // decrease is handed over in (n = 24: 54 KB, three instances per CU; the feedback layout would take 85 KB)
-  size_t lq_elems = (C::USE_MFMA && !p->desc.params.open_loop) ? PWCfg<T, NX, NP, MU>::LDS_ELEMS : C::LDS_ELEMS;
+  size_t lq_elems = (C::USE_MFMA && !p->desc.params.open_loop) ? MfmaSweepLds<T, NX, NP, MU>::ELEMS + (C::MFMA_ONE_TILE ? 0 : 4) : C::LDS_ELEMS;
   if (p->desc.params.open_loop) lq_elems = OLCfg<T, NX, NP, MU>::LDS_ELEMS + 4;
   const size_t lds_lq = lq_elems * sizeof(T);
   // Rows per chunk of the row stage: the widest whose scratch lets a CU hold four instances of the fused trial kernel

@@ -71,7 +71,10 @@ struct LQCfg {
   static constexpr int oYz = oZeta + NP * NX;
   static constexpr int oX = oYz + M;
   // MFMA variant (NX <= 16): transpose scratch (16 x 17) and a 16-vector
-  static constexpr bool USE_MFMA = NX <= 16 && NP * NX <= 64;
+  // a player-parallel sweep on the matrix cores exists: one 16 x 16 tile per value function (n <= 16,
+  // lq_feedback_instance_mfma_pw below) or a 2 x 2 block of them (n <= 31, ilqg_lq_feedback2.hpp)
+  static constexpr bool USE_MFMA = (NX <= 16 && NP * NX <= 64) || (NX > 16 && NX <= 31 && M <= 16 && M + NX + 1 <= 64);
+  static constexpr bool MFMA_ONE_TILE = NX <= 16;
   static constexpr int oTr = oX + NX;
   static constexpr int oTv = oTr + 16 * 17;
   static constexpr int oSY = oTv + 16;  // [S | Y] bounce buffer of the MFMA variant: M x 32, column-major
@@ -1226,10 +1229,22 @@ struct LQFeedbackThreads {
   static constexpr int NT = PLAYER_WAVES ? 64 * NP : LQCfg<T, NX, NP, MU>::NT;
 };
 
+template <typename T, int NX, int NP, int MU>
+__device__ __forceinline__ void lq_feedback_instance_mfma_pw2(const LQArgs<T>& a, const PairTable& pt, T* sm);  // ilqg_lq_feedback2.hpp
+
+// The matrix-core sweep of this shape (LQCfg::USE_MFMA).
+template <typename T, int NX, int NP, int MU>
+__device__ __forceinline__ void lq_feedback_instance_mfma(const LQArgs<T>& a, const PairTable& pt, T* sm) {
+  if constexpr (LQCfg<T, NX, NP, MU>::MFMA_ONE_TILE)
+    lq_feedback_instance_mfma_pw<T, NX, NP, MU>(a, pt, sm);
+  else
+    lq_feedback_instance_mfma_pw2<T, NX, NP, MU>(a, pt, sm);
+}
+
 template <typename T, int NX, int NP, int MU, bool FORCE_VALU = false>
 __device__ __forceinline__ void lq_feedback_dispatch(const LQArgs<T>& a, const PairTable& pt, T* sm) {
   if constexpr (LQCfg<T, NX, NP, MU>::USE_MFMA && !FORCE_VALU) {
-    lq_feedback_instance_mfma_pw<T, NX, NP, MU>(a, pt, sm);
+    lq_feedback_instance_mfma<T, NX, NP, MU>(a, pt, sm);
   } else {
     lq_feedback_instance<T, NX, NP, MU>(a, pt, sm);
   }

@@ -17,6 +17,7 @@
 
 #include "ilqg_lq.hpp"
 #include "ilqg_lq_openloop.hpp"
+#include "ilqg_lq_feedback2.hpp"
 #include "ilqg_stages.hpp"
 
 namespace ilqg {
@@ -769,14 +770,16 @@ __device__ __forceinline__ void lq_part_instance(const DevProblem& p, const Solv
   la.scratch = w + L.lqscr;
   // where the sweep leaves the expected decrease: an LDS slot that is free once it ends (feedback sweeps), or
   // one past the open-loop sweep's own working set (the launch reserves it)
-  constexpr int ed_slot = (KIND == LQ_OPEN_LOOP) ? OLCfg<T, NX, NP, MU>::LDS_ELEMS : LQCfg<T, NX, NP, MU>::oX;
+  constexpr int ed_slot = (KIND == LQ_OPEN_LOOP) ? OLCfg<T, NX, NP, MU>::LDS_ELEMS
+                          : (KIND == LQ_PLAYER_WAVES && !LQCfg<T, NX, NP, MU>::MFMA_ONE_TILE) ? FB2Cfg<T, NX, NP, MU>::LDS_ELEMS
+                                                                                              : LQCfg<T, NX, NP, MU>::oX;
   la.ed_out = defer ? nullptr : sm + ed_slot;
   la.T_steps = Tn;
   la.adaptive = 1;
   la.symmetric = 1;  // linquad_compute writes H(x,y) and H(y,x) from the same value
   la.ph = (kProfile && sa.prof) ? sa.prof + size_t(b) * 96 + 8 : nullptr;
   if constexpr (KIND == LQ_PLAYER_WAVES) {
-    lq_feedback_instance_mfma_pw<T, NX, NP, MU>(la, p.pairs, sm);
+    lq_feedback_instance_mfma<T, NX, NP, MU>(la, p.pairs, sm);
   } else if constexpr (KIND == LQ_OPEN_LOOP) {
     lq_openloop_instance<T, NX, NP, MU>(la, p.pairs, sm);  // SolverParams::open_loop (ilq_solver.h:76-81)
   } else {
