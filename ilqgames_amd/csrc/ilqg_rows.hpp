@@ -180,8 +180,20 @@ __device__ __forceinline__ void rows_writeout_small(T* g0, size_t stride, int W,
 //   ALL     G(0..dim-1), H(0,0)..H(dim-1,dim-1)
 // The slots of one leaf are distinct (build_row_program checks), so the read-modify-writes of a term do not depend
 // on each other: all reads, then all adds, then all writes — one LDS round trip per term instead of one per entry.
-template <typename T, typename V>
-__device__ __forceinline__ void rows_scatter(int pattern, const TermOut<T>& o, rp_cptr sid, int nsid, T* col, int cws,
+// Where an op's slot ids are read from: the op's own descriptor words, held one word per lane in a vector register and
+// read through v_readlane (the index is wave-uniform), or — ops with more ids than fit inline — the program's id table
+// in scalar memory.
+struct SidsInline {
+  int words, base;
+  __device__ __forceinline__ int operator[](int e) const { return __builtin_amdgcn_readlane(words, base + e); }
+};
+struct SidsTable {
+  rp_cptr ptr;
+  __device__ __forceinline__ int operator[](int e) const { return ptr[e]; }
+};
+
+template <typename T, typename V, typename SID>
+__device__ __forceinline__ void rows_scatter(int pattern, const TermOut<T>& o, const SID& sid, int nsid, T* col, int cws,
                                              const V& v, bool want_h) {
   if (pattern == PAT_SINGLE) {
     T* const p0 = col + sid[0] * cws;
@@ -355,10 +367,13 @@ __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* map
   }
   lds_sync(true);
 
-  const bool rowlane = lane < cw;          // lanes that own a row (cw < 64: the others only help to write out)
+  // Every lane runs the op loop (an op's descriptor is read one word per lane, so all 64 must be live): the lanes past
+  // the chunk width (cw < 64) repeat lane 0's arguments and accumulate into the padding column nobody reads.
+  const bool rowlane = lane < cw;
   const bool valid = lane < nrows;
   const int row = k0 + (valid ? lane : nrows - 1);
-  T* const col = acc + (rowlane ? lane : 0);
+  const int rl = rowlane ? lane : 0;
+  T* const col = acc + (rowlane ? lane : cw);
   // PlayerCost::Quadraticize vs QuadraticizeControlCosts (src/ilq_solver.cpp:483-487): bit i = player i is
   // quadraticised in full at this lane's row
   unsigned full = 0;
@@ -379,8 +394,7 @@ __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* map
       return (((full >> pl) & 1u) || ((code >> 16) & 1)) ? val : T(0);
     return val;  // 0, 1, sigma_x (player_cost.cpp:196)
   };
-  if (rowlane)
-    for (int s = 0; s < NPS; s++) col[s * cws] = init_value(pinit + s * RINIT_WORDS);
+  for (int s = 0; s < NPS; s++) col[s * cws] = init_value(pinit + s * RINIT_WORDS);
   Closest<T> cc;  // result of the pass's last CLOSEST op
   cc.cx = cc.cy = cc.ssd = T(0);
   cc.is_vertex = cc.is_endpoint = false;
@@ -397,20 +411,30 @@ __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* map
     T ctot = T(0);  // PlayerCost::Evaluate of this pass's player at this lane's row
     T ext_value = T(0);  // ExtremeValueCost in flight: its value and active child at this lane's row
     int ext_best = 0;
-    if (rowlane) {
+    {
       for (int s = 0; s < li_count; s++) col[(NPS + s) * cws] = init_value(linit + (li_begin + s) * RINIT_WORDS);
+      // An op's descriptor (ROP_WORDS words) is fetched as ONE vector load, word w by lane w, one op ahead, and its
+      // fields are read out through v_readlane: scalar loads of the descriptor count on lgkmcnt together with the LDS
+      // traffic of the op before and return out of order, so every decode drained the accumulators' read-modify-writes
+      // and then waited a scalar-cache round trip.
+      static_assert(ROP_WORDS <= 64, "an op descriptor is one word per lane");
+      const int* const opsv = reinterpret_cast<const int*>(p.row_prog) + rp[RP_OFF_OPS];
+      int next_words = (lane < ROP_WORDS && op_begin < op_end) ? opsv[op_begin * ROP_WORDS + lane] : 0;
 #pragma unroll 1
       for (int op = op_begin; op < op_end; op++) {
-        const rp_cptr od = ops + op * ROP_WORDS;
-        const int mode = od[RO_MODE];
-        const int nsid = od[RO_NSID], aux = od[RO_AUX];
-        const rp_cptr sid = nsid <= ROP_INLINE_SIDS ? od + ROP_FIELDS : sids + od[RO_SID];
+        const int words = next_words;
+        if (op + 1 < op_end) next_words = lane < ROP_WORDS ? opsv[(op + 1) * ROP_WORDS + lane] : 0;
+        auto od = [&](int f) { return __builtin_amdgcn_readlane(words, f); };
+        const int mode = od(RO_MODE);
+        const int nsid = od(RO_NSID), aux = od(RO_AUX);
+        const bool sid_inline = nsid <= ROP_INLINE_SIDS;
+        const SidsInline sid{words, ROP_FIELDS};
         DevTerm c;
-        c.kind = od[RO_KIND]; c.role = od[RO_ROLE]; c.player = od[RO_PLAYER]; c.flags = od[RO_FLAGS];
-        c.idx[0] = od[RO_IDX0]; c.idx[1] = od[RO_IDX1]; c.idx[2] = od[RO_IDX2]; c.idx[3] = od[RO_IDX3];
-        c.weight = __int_as_float(od[RO_WEIGHT]); c.value = __int_as_float(od[RO_VALUE]);
-        c.polyline = 0; c.slot = od[RO_SLOT]; c.arg_off = od[RO_ARG_OFF]; c.arg_dim = od[RO_ARG_DIM];
-        c.k_start = od[RO_K_START];
+        c.kind = od(RO_KIND); c.role = od(RO_ROLE); c.player = od(RO_PLAYER); c.flags = od(RO_FLAGS);
+        c.idx[0] = od(RO_IDX0); c.idx[1] = od(RO_IDX1); c.idx[2] = od(RO_IDX2); c.idx[3] = od(RO_IDX3);
+        c.weight = __int_as_float(od(RO_WEIGHT)); c.value = __int_as_float(od(RO_VALUE));
+        c.polyline = 0; c.slot = od(RO_SLOT); c.arg_off = od(RO_ARG_OFF); c.arg_dim = od(RO_ARG_DIM);
+        c.k_start = od(RO_K_START);
         c.arg = 0; c.child_begin = 0; c.child_count = 0;
         if (mode == ROP_JACOBIAN) {
           // ---- ConcatenatedDynamicalSystem::Linearize, one subsystem (src/concatenated_dynamical_system.cpp:86-107):
@@ -420,7 +444,7 @@ __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* map
           // the constant entries (dt, -dt, the identity) are in the word maps.
           const int kind = c.kind, xo = c.idx[0], uo = c.idx[1];
           const T L = T(c.weight);
-          const RowArg<T> x{arg + xo * cw + lane, cw};
+          const RowArg<T> x{arg + xo * cw + rl, cw};
           auto put = [&](int e, T val) { if (e < nsid) col[sid[e] * cws] = val; };
           if (kind == ILQG_DYN_POINT_MASS_2D || kind == ILQG_DYN_PLANAR_DISTURBANCE || kind == ILQG_DYN_AIR_3D_PURSUER)
             continue;  // constants only
@@ -428,7 +452,7 @@ __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* map
           t_sincos(x[2], &sth, &cth);
           const T ct = T(double(cth) * p.dt), st = T(double(sth) * p.dt);
           if (kind == ILQG_DYN_AIR_3D_EVADER) {  // air_3d.h:127-146
-            const T own = arg[(CN + uo) * cw + lane];  // its own turn rate; c.value = the pursuer's speed
+            const T own = arg[(CN + uo) * cw + rl];  // its own turn rate; c.value = the pursuer's speed
             put(0, T(double(own) * p.dt));             // A(0,1)
             put(1, T(0) - T(c.value) * st);            // A(0,2)
             put(2, T(0) - T(double(own) * p.dt));      // A(1,0)
@@ -455,9 +479,9 @@ __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* map
           }
           continue;
         }
-        const RowArg<T> v{arg + c.arg_off * cw + lane, cw};
+        const RowArg<T> v{arg + c.arg_off * cw + rl, cw};
         if (mode == ROP_CLOSEST) {
-          cc = polyline_closest_rows<T>(segs, od[RO_POLY_FIRST], od[RO_PATTERN_NSEG], v[c.idx[0]], v[c.idx[1]]);
+          cc = polyline_closest_rows<T>(segs, od(RO_POLY_FIRST), od(RO_PATTERN_NSEG), v[c.idx[0]], v[c.idx[1]]);
           continue;
         }
 #if ILQG_PROFILE2
@@ -493,7 +517,12 @@ __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* map
         } else if (is_cost && live) {
           ctot += o.value;
         }
-        if (act) rows_scatter<T>(od[RO_PATTERN_NSEG], o, sid, nsid, col, cws, v, quad_out);
+        if (act) {
+          if (sid_inline)
+            rows_scatter<T>(od(RO_PATTERN_NSEG), o, sid, nsid, col, cws, v, quad_out);
+          else
+            rows_scatter<T>(od(RO_PATTERN_NSEG), o, SidsTable{sids + od(RO_SID)}, nsid, col, cws, v, quad_out);
+        }
 #if ILQG_PROFILE2
         ILQG_QPH(4);
 #endif
