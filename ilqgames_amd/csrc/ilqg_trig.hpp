@@ -7,7 +7,8 @@
 // reduction is the two-constant Cody-Waite form (exact products through FMA) and the kernels are the classical
 // minimax polynomials on [-pi/4, pi/4] (coefficients: the published fdlibm / msun kernels, k_sin.c, k_cos.c,
 // k_sindf.c, k_cosdf.c).  Arguments beyond kTrigFastLimit fall back to the library (wave-uniform test), so the
-// functions are total.  Accuracy: <= 2 ulp of the correctly rounded value on the fast path (scripts/ubench/trig_lat.hip
+// functions are total.  Accuracy on the fast path: sine / cosine <= 1.5 ulp, tangent <= 3 ulp of the correctly rounded value
+// (tests/host/trig_check.cpp checks it on the host over the whole range; scripts/ubench/trig_lat.hip
 // prints the worst disagreement with libm) — the same order as the difference between the device libm and a host
 // libm, and ten orders of magnitude inside the parity bar.
 #pragma once

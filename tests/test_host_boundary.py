@@ -158,3 +158,16 @@ def test_bench_two_rank_path_over_gloo():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak"
     assert out["value"] > 0 and abs(out["value"] * out["ms_per_step"] * 1e-3 * out["steps"] - 2 * 5 * 2) < 1e-6
+
+
+def test_fast_trig_of_the_rollout_is_within_its_documented_error(tmp_path):
+    """csrc/ilqg_trig.hpp is __host__ __device__: tests/host/trig_check.cpp compiles it for the host (plain g++ against
+    the HIP headers) and compares sine / cosine / tangent with the C library in long double over the whole fast-path
+    range, dense around the multiples of pi/2 — <= 2 ulp (tangent 3) or the program exits non-zero."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "trig_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                           os.path.join(root, "tests", "host", "trig_check.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "double:" in out.stdout and "float:" in out.stdout
