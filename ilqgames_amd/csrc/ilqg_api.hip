@@ -670,7 +670,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   // kernel that follows (split passes and the open-loop sweep keep it in the sweep's kernel).
   sa.defer_forward = (!split && !p->desc.params.open_loop) ? 1 : 0;
   {
-    constexpr size_t fwd_elems = 4 * 2 * ((NX * NX + C::SCR + 3) & ~3) + NX + 8;
+    constexpr size_t fwd_elems = 4 * 2 * ((NX * NX + C::SCR + 3) & ~3) + 2 * NX + 8;
     if (trial_rows_elems(d, sa.rows_cw) < fwd_elems + 8) sa.defer_forward = 0;
   }
   long long cap = al_mode ? (long long)(sa.prm.max_solver_iters + 1) * (sa.prm.unconstrained_solver_max_iters + 2)

@@ -29,6 +29,18 @@ constexpr int kMaxT = 256;
 #define ILQG_PROFILE 0
 #endif
 constexpr bool kProfile = ILQG_PROFILE != 0;
+// Timeline stamps (-DILQG_TIMELINE=1, scripts/timeline.py): a handful of wall-clock stamps per instance and launch, each
+// stored at once by one lane (nothing is kept live across the hot loops, unlike the phase profile): slot i of instance
+// b at prof[b * 96 + 32 + i], in 10 ns units of the constant-rate counter.
+#ifndef ILQG_TIMELINE
+#define ILQG_TIMELINE 0
+#endif
+constexpr bool kTimeline = ILQG_TIMELINE != 0;
+__device__ __forceinline__ void tl_stamp(long long* prof, int b, int slot, bool who) {
+  if constexpr (kTimeline) {
+    if (prof && who) prof[size_t(b) * 96 + 32 + slot] = wall_clock64();
+  }
+}
 
 // (i,j) control-block table of one problem (QuadraticCostApproximation::control keys).
 struct PairTable {

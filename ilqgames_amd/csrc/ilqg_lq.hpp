@@ -40,6 +40,8 @@ struct LQArgs {
   int defer_forward = 0;            // 1: leave the scratch rows for a forward pass that runs elsewhere (the solve's
                                     //    trial kernel runs it beside the next rollout): no dx, no expected decrease here
   long long* ph = nullptr;          // optional: 8 shader-clock accumulators per instance (phase profile)
+  long long* tl = nullptr;          // optional: timeline stamps (ilqg_common.hpp, -DILQG_TIMELINE=1)
+  int tl_b = 0;
 };
 
 template <typename T, int NX, int NP, int MU>
@@ -312,9 +314,114 @@ __device__ __forceinline__ void lu_pp_solve_columns(T (&col)[M], int lane, T (&x
 // One step is a 14-FMA chain (~300 cycles), far shorter than the global-load latency of its operands, so
 // A_k and scratch row k are staged G steps at a time into two LDS groups: the DMA of group g+1 runs
 // while group g is computed and only one wait per group is exposed.
+// Single-wave form of the forward pass (the one the MFMA sweeps and the solve's trial kernel run).  What the step costs
+// is one LDS exchange of delta_x and one NX-term FMA chain, so everything else is taken off that chain:
+//   * the [A_k | scratch row k] images of the next G steps travel global -> registers -> LDS (plain loads issued a whole
+//     group ahead; an LDS-DMA here made the compiler wait for the queue before every step's LDS reads, it cannot tell
+//     the DMA's destination from the image being read);
+//   * a step's operands (row t of A_k, delta_x_k, Q_i l_i) are requested together and waited for once;
+//   * delta_x is double-buffered in LDS: one wave-level sync per step;
+//   * ExpectedDecrease takes its terms from lanes 0 .. NP-1 through v_readlane, in the reference's order, beside the chain.
+template <typename T, int NX, int NP, int MU, int LDSE>
+__device__ __forceinline__ void lq_forward_pass_wave(const LQArgs<T>& a, T* sm, int t) {
+  using C = LQCfg<T, NX, NP, MU>;
+  constexpr int SCR = C::SCR;
+  constexpr int FSLOT = (NX * NX + SCR + 3) & ~3;
+  constexpr int GFIT = (LDSE - 2 * NX - 4) / (2 * FSLOT);
+  constexpr int G = GFIT < 1 ? 1 : (GFIT > 4 ? 4 : GFIT);
+  static_assert(2 * G * FSLOT + 2 * NX <= LDSE, "forward-pass staging does not fit the LDS it is given");
+  constexpr int ROW = NX * NX + SCR;           // elements of one step's image
+  constexpr int PER = (ROW + 63) / 64;         // loads per lane and step
+  const int Tn = a.T_steps;
+  T* sX = sm + 2 * G * FSLOT;                  // delta_x, two buffers of NX
+  const T* gA = uniform_ptr(a.A);
+  const T* gS = uniform_ptr(a.scratch);
+  T pre[G][PER];
+  auto fetch_group = [&](int grp) {
+#pragma unroll
+    for (int s = 0; s < G; s++) {
+      const int k = grp * G + s;
+#pragma unroll
+      for (int q = 0; q < PER; q++) {
+        const int e = q * 64 + t;
+        const bool inA = e < NX * NX;
+        const T* src = inA ? gA + (size_t(k) * NX * NX + e) : gS + (size_t(k) * SCR + (e - NX * NX));
+        pre[s][q] = (k < Tn && e < ROW) ? *src : T(0);
+      }
+    }
+  };
+  auto commit_group = [&](int which) {
+#pragma unroll
+    for (int s = 0; s < G; s++)
+#pragma unroll
+      for (int q = 0; q < PER; q++) {
+        const int e = q * 64 + t;
+        if (e < ROW) sm[(which * G + s) * FSLOT + e] = pre[s][q];
+      }
+  };
+  fetch_group(0);
+  if (t < NX) sX[t] = a.x0 ? a.x0[t] : T(0);
+  commit_group(0);
+  const int ngroups = (Tn + G - 1) / G;
+  if (ngroups > 1) fetch_group(1);
+  lds_sync(true);
+  T ed = T(0);
+  int cur = 0, xb = 0;
+#pragma unroll 1
+  for (int grp = 0; grp < ngroups; grp++) {
+#pragma unroll 1
+    for (int s = 0; s < G; s++) {
+      const int k = grp * G + s;
+      if (k >= Tn) break;
+      const T* fA = sm + (cur * G + s) * FSLOT;
+      const T* fS = fA + NX * NX;  // [ql (N*n) | ctrl (N) | beta (n)]
+      const T* x = sX + xb * NX;
+      const int tr = t < NX ? t : 0, tp = t < NP ? t : 0;
+      T xv[NX], av[NX], qv[NX];
+#pragma unroll
+      for (int c = 0; c < NX; c++) xv[c] = x[c];
+#pragma unroll
+      for (int c = 0; c < NX; c++) av[c] = fA[tr + NX * c];
+#pragma unroll
+      for (int c = 0; c < NX; c++) qv[c] = fS[tp * NX + c];
+      const T ct = fS[NP * NX + tp];
+      const T beta = fS[NP * (NX + 1) + tr];  // beta_k = -B alpha_k
+      if (a.dx && t < NX) a.dx[size_t(k) * NX + t] = xv[tr];
+      T xn = T(0), st = T(0);
+#pragma unroll
+      for (int c = 0; c < NX; c++) {
+        xn += av[c] * xv[c];
+        st += xv[c] * qv[c];
+      }
+      xn += beta;
+      if (t < NX) sX[(1 - xb) * NX + t] = xn;
+      if (a.ed_out) {
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+          ed -= bcast(ct, i);
+          if (k > 0) ed -= bcast(st, i);
+        }
+      }
+      xb = 1 - xb;
+      lds_sync(true);
+    }
+    if (grp + 1 < ngroups) {
+      commit_group(1 - cur);  // waits for the loads issued a group ago
+      if (grp + 2 < ngroups) fetch_group(grp + 2);
+      lds_sync(true);
+    }
+    cur = 1 - cur;
+  }
+  if (a.ed_out && t == 0) *a.ed_out = ed;
+}
+
 template <typename T, int NX, int NP, int MU, int NT = LQCfg<T, NX, NP, MU>::NT, int LDSE = LQCfg<T, NX, NP, MU>::LDS_ELEMS>
 __device__ __forceinline__ void lq_forward_pass_body(const LQArgs<T>& a, T* sm, int t) {
   using C = LQCfg<T, NX, NP, MU>;
+  if constexpr (NT == 64) {
+    lq_forward_pass_wave<T, NX, NP, MU, LDSE>(a, sm, t);
+    return;
+  }
   constexpr int SCR = C::SCR, S = int(sizeof(T));
   constexpr int FSLOT = (NX * NX + SCR + 3) & ~3;
   constexpr int GFIT = (LDSE - NX - 4) / (2 * FSLOT);
@@ -876,6 +983,10 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
   set_img(1);
 
   long long phacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // phase profile, kept in registers until the sweep ends
+  tl_stamp(a.tl, a.tl_b, 17, t == 0);
+  if (kTimeline && a.tl && lane == 0 && w < 4)  // where this wave sits: HW_ID | XCC_ID << 32
+    a.tl[size_t(a.tl_b) * 96 + 32 + 24 + w] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
+                                              ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
 #pragma unroll 1
   for (int k = Tn - 2; k >= 0; k--) {
     long long pc0 = (kProfile && a.ph) ? clock64() : 0, pc1;
@@ -1211,6 +1322,7 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
     ILQG_PH(6);
   }
 #undef ILQG_PH
+  tl_stamp(a.tl, a.tl_b, 18, t == 0);
   if (kProfile && a.ph && lane == 0) {  // wave w's row of the profile: a.ph[16 * w + i]
 #pragma unroll
     for (int i = 0; i < 16; i++) a.ph[16 * w + i] += phacc[i];

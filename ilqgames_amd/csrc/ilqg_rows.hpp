@@ -366,6 +366,7 @@ __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* map
     }
   }
   lds_sync(true);
+  tl_stamp(a.tl, a.tl_b, 40, lane == 0);
 
   // Every lane runs the op loop (an op's descriptor is read one word per lane, so all 64 must be live): the lanes past
   // the chunk width (cw < 64) repeat lane 0's arguments and accumulate into the padding column nobody reads.
@@ -395,6 +396,7 @@ __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* map
     return val;  // 0, 1, sigma_x (player_cost.cpp:196)
   };
   for (int s = 0; s < NPS; s++) col[s * cws] = init_value(pinit + s * RINIT_WORDS);
+  tl_stamp(a.tl, a.tl_b, 41, lane == 0);
   Closest<T> cc;  // result of the pass's last CLOSEST op
   cc.cx = cc.cy = cc.ssd = T(0);
   cc.is_vertex = cc.is_endpoint = false;
@@ -551,6 +553,7 @@ __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* map
       }
     }
     lds_sync(true);  // the slots of this pass are complete: rows are written out by all lanes
+    tl_stamp(a.tl, a.tl_b, 42 + 2 * (ps < 4 ? ps : 4), lane == 0);
 #if !ILQG_PROFILE2
     if (pkind == RPASS_JACOBIANS) ILQG_QPH(1); else ILQG_QPH(2);
 #else
@@ -575,6 +578,7 @@ __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* map
       }
     }
     lds_sync(true);  // pass-local slots are re-initialised by the next pass
+    tl_stamp(a.tl, a.tl_b, 43 + 2 * (ps < 4 ? ps : 4), lane == 0);
 #if !ILQG_PROFILE2
     ILQG_QPH(3);
 #else

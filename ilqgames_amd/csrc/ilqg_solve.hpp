@@ -581,6 +581,7 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const s
     s = state_load<T>(w, L);
   }
   const int max_iters = solve_max_iters(sa);
+  tl_stamp(sa.prof, b, 0, t == 0);
   const long long pr_start = clock64();
   long long qph[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // linquad phase profile of this wave (diagnostics)
   long long rph[4] = {0, 0, 0, 0};              // rollout phase profile (wave 0)
@@ -613,10 +614,12 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const s
       flags[1] = 0;
     }
     __syncthreads();
+    tl_stamp(sa.prof, b, 1, t == 0);
     if (roll && wave == 0)
       rollout_instance<T, NX, NP * MU, (NX == 4 && NP == 2), (MU == 1), (NX == 3 && NP == 2 && MU == 1),
                        (NX == 4 * NP && MU == 2 && NP <= 2)>(p, ra, sm_roll, lane, W > 1 ? &flags[0] : nullptr,
-                                       (kProfile && sa.prof) ? rph : nullptr);
+                                       (kProfile && sa.prof) ? rph : nullptr, kTimeline ? sa.prof : nullptr, b);
+    tl_stamp(sa.prof, b, 2, t == 0);
     if (roll && W == 1) {
       __syncthreads();
       if (t == 0) flags[0] = Tn;
@@ -629,6 +632,8 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const s
     if (PHASE == TRIAL_FUSED) {
     QuadArgs<T> qa = trial_quad_args<T>(p, ib, s);
     qa.phacc = (kProfile && sa.prof) ? qph : nullptr;
+    qa.tl = kTimeline ? sa.prof : nullptr;
+    qa.tl_b = b;
     long long tq0 = (kProfile && sa.prof) ? clock64() : 0;
     // The sweep's forward pass (delta_xs, src/lq_feedback_solver.cpp:217-241) and ILQSolver::ExpectedDecrease
     // (:364-398), deferred to here: the first row wave runs them from the sweep's scratch rows while wave 0
@@ -641,9 +646,10 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const s
       fa.dx = nullptr;
       fa.ed_out = ed_slot;
       fa.T_steps = Tn;
-      constexpr int FWD_LDSE = 4 * 2 * ((NX * NX + LQCfg<T, NX, NP, MU>::SCR + 3) & ~3) + NX + 8;
+      constexpr int FWD_LDSE = 4 * 2 * ((NX * NX + LQCfg<T, NX, NP, MU>::SCR + 3) & ~3) + 2 * NX + 8;
       lq_forward_pass_body<T, NX, NP, MU, 64, FWD_LDSE>(fa, sm_quad, lane);
     }
+    tl_stamp(sa.prof, b, 3, rwave == 0 && lane == 0);
     if (rwave >= 0) {
       const int cw = sa.rows_cw;
       const int nchunks = (Tn + cw - 1) / cw;
@@ -652,13 +658,18 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const s
         if (lane == 0) c = atomicAdd(&flags[1], 1);
         return __builtin_amdgcn_readfirstlane(c);
       };
+      // The chunk that is not full comes FIRST: its rows are ready that much earlier in the rollout, so the row wave
+      // starts sooner and the full chunks — which have to wait for the integration anyway — follow back to back.
+      const int rem = Tn % cw;
 #pragma unroll 1
       for (int c = claim(); c < nchunks; c = claim()) {
-        const int k0 = c * cw;
-        const int nrows = Tn - k0 < cw ? Tn - k0 : cw;
+        const int k0 = rem == 0 ? c * cw : (c == 0 ? 0 : rem + (c - 1) * cw);
+        const int nrows = (rem != 0 && c == 0) ? rem : cw;
         while (progress_observe(&flags[0]) < k0 + nrows) __builtin_amdgcn_s_sleep(8);
         if (kProfile && sa.prof) { const long long tq1 = clock64(); qph[6] += tq1 - tq0; }
+        tl_stamp(sa.prof, b, 4 + 2 * (c < 3 ? c : 3), lane == 0);
         rows_chunk<T, NX, NP * MU, NP>(p, maps, qa, k0, nrows, cw, sm_quad, lane);
+        tl_stamp(sa.prof, b, 5 + 2 * (c < 3 ? c : 3), lane == 0);
         if (kProfile && sa.prof) { tq0 = clock64(); qph[7] += 1; }
       }
     }
@@ -671,6 +682,7 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const s
       __syncthreads();
     }
     // ---- reductions and the line-search decision (wave-uniform, identical on every wave) ----
+    tl_stamp(sa.prof, b, 12, t == 0);
     if (qmode == Q_COSTS) {
       costs_reduce<T>(p, w + L.cpart, costs, t_extreme, sm_quad0, int(qe));
       s.qmode = Q_INIT;
@@ -718,6 +730,7 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const s
     if (PHASE == TRIAL_FUSED && sa.ids_next != nullptr && s.stage == ST_ROLLOUT && s.bt > 0) break;
   }
   state_store<T>(w, L, s);
+  tl_stamp(sa.prof, b, 13, t == 0);
   if (PHASE == TRIAL_ROLL) return;
   // wants a sweep / wants the exit path / (split passes only) wants another pass
   if (t == 0) {
@@ -778,6 +791,9 @@ __device__ __forceinline__ void lq_part_instance(const DevProblem& p, const Solv
   la.adaptive = 1;
   la.symmetric = 1;  // linquad_compute writes H(x,y) and H(y,x) from the same value
   la.ph = (kProfile && sa.prof) ? sa.prof + size_t(b) * 96 + 8 : nullptr;
+  la.tl = kTimeline ? sa.prof : nullptr;
+  la.tl_b = b;
+  tl_stamp(sa.prof, b, 16, threadIdx.x == 0);
   if constexpr (KIND == LQ_PLAYER_WAVES) {
     lq_feedback_instance_mfma<T, NX, NP, MU>(la, p.pairs, sm);
   } else if constexpr (KIND == LQ_OPEN_LOOP) {
@@ -786,6 +802,7 @@ __device__ __forceinline__ void lq_part_instance(const DevProblem& p, const Solv
     lq_feedback_instance<T, NX, NP, MU>(la, p.pairs, sm);
   }
   __syncthreads();
+  tl_stamp(sa.prof, b, 19, threadIdx.x == 0);
   if (threadIdx.x == 0) {
     if (defer)
       st->ed_pending = 1;

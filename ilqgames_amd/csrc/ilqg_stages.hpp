@@ -58,7 +58,8 @@ __device__ __forceinline__ int progress_observe(int* flag) {
 // group — the right-hand side is two moves and there is no transcendental to take out of the chain.
 template <typename T, int CN = 0, int CM = 0, bool DIST = false, bool DUB = false, bool AIR = false, bool PM = false>
 __device__ __forceinline__ void rollout_instance(const DevProblem& p, const RolloutArgs<T>& a, T* sm, int t,
-                                                 int* ready = nullptr, long long* phacc = nullptr) {
+                                                 int* ready = nullptr, long long* phacc = nullptr,
+                                                 long long* tl = nullptr, int tl_b = 0) {
   const int n = CN > 0 ? CN : p.n, m = CM > 0 ? CM : p.m, N = p.N, Tn = p.T;
   constexpr int NT = 64;
   T* sx = sm;       // [n] current state
@@ -103,6 +104,7 @@ __device__ __forceinline__ void rollout_instance(const DevProblem& p, const Roll
     // Block k of [P | alpha | u_ref | x_ref] was requested a whole step ago, and the rows of step k - 1 were stored
     // then too: this wait finds nothing in flight, and with it the release below is free.
     dma_wait();
+    if (kTimeline && (k & 31) == 0) tl_stamp(tl, tl_b, 20 + (k >> 5), t == 0);
     if (ready) progress_publish(ready, k);
     const T* sP = stg + (k & 1) * WP;  // [m*n] gains of this step
     const T* sal = sP + m * n;         // [m]
@@ -243,6 +245,8 @@ struct QuadArgs {
   T* merit_part;       // [T][N][2] = (|r_ii|^2, |l_i|^2) or nullptr
   T* cost_part;        // [T][N] PlayerCost::Evaluate or nullptr
   long long* phacc = nullptr;  // optional phase profile accumulators (registers of the caller)
+  long long* tl = nullptr;     // optional timeline stamps (ilqg_common.hpp, -DILQG_TIMELINE=1): slots 40.. of instance tl_b
+  int tl_b = 0;
 };
 
 // Sequential left-to-right sum of `count` LDS values, eight loads in flight at a time (the adds keep
