@@ -668,6 +668,9 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   const bool lists = split || handoff;
   // The sweep's forward pass runs in the fused trial kernel that follows it, beside the rollout, whenever that is the
   // kernel that follows (split passes and the open-loop sweep keep it in the sweep's kernel).
+  // Compact rows between the row stage and the one-tile player-parallel sweep (ilqg_common.hpp): what the row stage
+  // writes and the sweep reads per time step shrinks from N (n^2 + n) + ... words to the ones a cost term can touch.
+  sa.compact = (pw && C::MFMA_ONE_TILE && d.rp_compact_w > 0 && choice(opt.compact_rows, true)) ? 1 : 0;
   sa.defer_forward = (!split && !p->desc.params.open_loop) ? 1 : 0;
   {
     constexpr size_t fwd_elems = 4 * 2 * ((NX * NX + C::SCR + 3) & ~3) + 2 * NX + 8;
@@ -1024,7 +1027,7 @@ ilqg_status ilqg_problem_create(const ilqg_problem_desc* desc, ilqg_problem** ou
   }
   d.n = d.xoff[d.N];
   d.m = d.uoff[d.N];
-  d.sync_dist_dims = d.sub_kind[0] == ILQG_DYN_DUBINS_CAR ? 3 : d.sub_kind[0] == ILQG_DYN_UNICYCLE_4D_DISTURBED ? 4 : 2;
+  d.sync_dist_dims = d.sub_kind[0] == ILQG_DYN_DUBINS_CAR ? 3 : 2;  // two_player_unicycle_4d.h:141-147 overrides with (px, py) too
   // pair table in PlayerCost first-touch order: control costs, then control constraints
   std::vector<ilqg_pair> pairs;
   std::vector<int> from_cost;
@@ -1153,6 +1156,8 @@ ilqg_status ilqg_problem_create(const ilqg_problem_desc* desc, ilqg_problem** ou
   d.rp_lslots = rph.max_lslots;
   d.rp_maps_off = rph.maps_off;
   d.rp_maps_words = rph.maps_words;
+  d.rp_compact_off = rph.compact_off;
+  d.rp_compact_w = rph.compact_w;
   if (e != hipSuccess) {
     ilqg_problem_destroy(p);
     return fail(ILQG_ERR_HIP, std::string("problem tables: ") + hipGetErrorString(e));

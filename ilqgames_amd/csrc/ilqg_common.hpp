@@ -90,8 +90,8 @@ struct DevProblem {
   int num_constraints;
   // MultiPlayerIntegrableSystem::DistanceBetween as Problem::SyncToExistingProblem uses it (src/problem.cpp:105-110):
   // squared distance over the first sync_dist_dims entries of the state — the position of the first subsystem for
-  // the car / unicycle / point-mass models (their overrides) and Air3D, the first subsystem's whole state where the
-  // model inherits the default (SinglePlayerDubinsCar; TwoPlayerUnicycle4D: the whole state)
+  // the car / unicycle / point-mass models and TwoPlayerUnicycle4D (their overrides: two_player_unicycle_4d.h:141-147)
+  // and Air3D, the first subsystem's whole state where the model inherits the default (SinglePlayerDubinsCar only)
   int sync_dist_dims;
   PairTable pairs;
   // Row program of the lane-per-time-step quadraticisation stage (ilqg_rows.hpp; built by build_row_program)
@@ -99,7 +99,18 @@ struct DevProblem {
   int row_prog_words;
   int rp_pslots, rp_lslots;  // persistent / most pass-local slots: sizes the stage's LDS
   int rp_maps_off, rp_maps_words;  // the program's word -> slot maps (copied into LDS by every workgroup)
+  int rp_compact_off, rp_compact_w;  // compact rows (ilqg_rows.hpp): the block's offset in row_prog, words per row (0: none)
 };
+
+// arrays of a time step's image, as the row program's regions and the compact rows name them
+enum { RA_A = 0, RA_B = 1, RA_Q = 2, RA_L = 3, RA_R = 4, RA_r = 5 };
+// Compact rows (the solve's own interchange between this stage and the one-tile sweep, ilqg_lq.hpp): of a time step's
+// [Q_i | l_i | R_ij | r_ij] only the words some term can touch vary — a player pass's pass-local slots — so the stage
+// writes those, pass after pass ("compact row" of RC_W words), and the sweep scatters them over a constant background
+// in its LDS image.  Block at RP_OFF_COMPACT: [RC_W, RC_NBG, base of player 0 .. N-1 | destination of each word |
+// (destination, value) of each non-zero constant].  A destination is array << 24 | offset inside the array's row.
+enum { RC_W = 0, RC_NBG = 1, RC_BASE = 2 };
+constexpr int kCompactMaxWords = 192;  // three words per lane of the scattering wave
 
 constexpr int kSegStride = 21;
 

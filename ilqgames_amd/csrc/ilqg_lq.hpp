@@ -40,6 +40,8 @@ struct LQArgs {
   int defer_forward = 0;            // 1: leave the scratch rows for a forward pass that runs elsewhere (the solve's
                                     //    trial kernel runs it beside the next rollout): no dx, no expected decrease here
   long long* ph = nullptr;          // optional: 8 shader-clock accumulators per instance (phase profile)
+  const T* compact = nullptr;       // [T][compact_tab[RC_W]] compact rows of [Q | l | R | r] (ilqg_common.hpp) instead of the
+  const int* compact_tab = nullptr; // dense arrays: the one-tile player-parallel sweep only; compact_tab = the row program's block
   long long* tl = nullptr;          // optional: timeline stamps (ilqg_common.hpp, -DILQG_TIMELINE=1)
   int tl_b = 0;
 };
@@ -805,7 +807,9 @@ struct PWCfg {
   static constexpr int oSY = oYz + 16;          // [S | Y] bounce: M x 32, column-major
   static constexpr int oVec = oSY + M * 32;     // per player: beta strip (16) and zeta strip (16)
   static constexpr int oG = oVec + 2 * NP * 16;  // per player: its MU columns of G = Z^T B, 16 entries each
-  static constexpr int ELEMS_PW = oG + NP * MU * 16;
+  static constexpr int oSB = oG + NP * MU * 16;  // compact rows: two staging rows (the DMA's landing place, one step ahead)
+  static constexpr int oCD = oSB + 2 * kCompactMaxWords;  // ... and where each word of a row goes in an image (ints)
+  static constexpr int ELEMS_PW = oCD + kCompactMaxWords;
   // the forward pass reuses the LDS with the single-wave layout
   static constexpr int LDS_ELEMS = ELEMS_PW > C::LDS_ELEMS ? ELEMS_PW : C::LDS_ELEMS;
   // DMA piece: 16 bytes when every column of the source and of the padded tile starts 16-byte aligned, else 4
@@ -931,6 +935,57 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
     }
   };
 
+  // Compact rows (LQArgs::compact): the dense A, B tiles are DMA'd as above; the touched words of [Q | l | R | r] arrive as
+  // one short row that a wave scatters over the image's constant background (written once, below).  The row of step
+  // k - 2 is DMA'd into a staging row while step k runs and scattered into the image of step k - 1 ... one step later.
+  const bool cmp = a.compact != nullptr;
+  T* const sSB = sm + W::oSB;
+  auto cdecode = [&](int code) -> int {  // array << 24 | offset in the array's row  ->  offset inside an image
+    const int arr = code >> 24, off = code & 0xffffff;
+    if (arr == RA_Q) {
+      const int i = off / (NX * NX), wd = off - i * NX * NX;
+      const int col = wd / NX, row = wd - col * NX;
+      return W::oTQ + i * W::TILE + row + LD * col;
+    }
+    return (arr == RA_L ? W::oVl : (arr == RA_R ? W::oVR : W::oVr)) + off;
+  };
+  const int CWD = cmp ? a.compact_tab[RC_W] : 0;
+  int* const sCD = reinterpret_cast<int*>(sm + W::oCD);  // where each word of a compact row goes in an image (-1: none);
+                                                         // kept in LDS: the sweep has no registers to spare
+  auto stage_c = [&](int k, int which, int slot, int nslots) {
+    T* dst = sm + which * W::IMG;
+#pragma unroll
+    for (int job = 0; job < 4; job++) {
+      if (job % nslots != slot) continue;
+      if (job == 0) {
+        dma_tile<T, NX, W::LD, W::PS, W::WAVE_INSTRS>(a.A + size_t(k) * NX * NX, dst + W::oTA, NX, NX, lane);
+      } else if (job == 1) {
+        dma_tile<T, NX, W::LD, W::PS, W::WAVE_INSTRS>(a.Bm + size_t(k) * NX * M, dst + W::oTB, NX, M, lane);
+      } else if (job == 2) {
+        const T* row = sSB + (k & 1) * kCompactMaxWords;
+        T v[3];
+        int cd[3];
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+          cd[q] = sCD[lane + 64 * q];
+          v[q] = row[lane + 64 * q];
+        }
+#pragma unroll
+        for (int q = 0; q < 3; q++)
+          if (cd[q] >= 0) dst[cd[q]] = v[q];
+      } else if (k >= 1) {
+        dma_g2l<64, false>(a.compact + size_t(k - 1) * CWD, sSB + ((k - 1) & 1) * kCompactMaxWords, CWD * S, lane);
+      }
+    }
+  };
+  // the same for a step whose compact row is not staged yet (before the loop): straight from global memory
+  auto stage_c_sync = [&](int k, int which) {
+    T* dst = sm + which * W::IMG;
+    if (w == 0) dma_tile<T, NX, W::LD, W::PS, W::WAVE_INSTRS>(a.A + size_t(k) * NX * NX, dst + W::oTA, NX, NX, lane);
+    if (w == NP - 1) dma_tile<T, NX, W::LD, W::PS, W::WAVE_INSTRS>(a.Bm + size_t(k) * NX * M, dst + W::oTB, NX, M, lane);
+    for (int c = t; c < CWD; c += NT) dst[cdecode(a.compact_tab[RC_BASE + NP + c])] = a.compact[size_t(k) * CWD + c];
+  };
+
   // (Q_i l_i) of the staged step -> scratch, for ExpectedDecrease
   auto stash_ql_of = [&](int k, int i) {
     if (want_fwd && lane < NX) {
@@ -948,8 +1003,24 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
   for (int e = t; e < W::ELEMS_PW; e += NT) sm[e] = T(0);
   __syncthreads();
 
+  if (cmp) {
+    for (int c = t; c < kCompactMaxWords; c += NT) sCD[c] = c < CWD ? cdecode(a.compact_tab[RC_BASE + NP + c]) : -1;
+  }
+  if (cmp) {  // the images' constants that are not zero (untouched diagonal entries of Q_i: sigma_x)
+    const int nbg = a.compact_tab[RC_NBG];
+    const int* bg = a.compact_tab + RC_BASE + NP + CWD;
+    for (int e = t; e < nbg; e += NT) {
+      const int off = cdecode(bg[2 * e]);
+      const T v = T(__int_as_float(bg[2 * e + 1]));
+      sm[off] = v;
+      sm[W::IMG + off] = v;
+    }
+  }
   // ---- terminal step: Z_w = Q_w[T-1], zeta_w = l_w[T-1]  (:102-105) ----
-  stage(Tn - 1, 0, w, NP);
+  if (cmp)
+    stage_c_sync(Tn - 1, 0);
+  else
+    stage(Tn - 1, 0, w, NP);
   dma_wait();
   __syncthreads();
   set_img(0);
@@ -976,7 +1047,15 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
     if (t < NP) a.scratch[size_t(Tn - 1) * SCR + NP * NX + t] = T(0);
     if (t < NX) a.scratch[size_t(Tn - 1) * SCR + NP * (NX + 1) + t] = T(0);
   }
-  if (Tn >= 2) stage(Tn - 2, 1, w, NP);
+  if (Tn >= 2) {
+    if (cmp) {
+      stage_c_sync(Tn - 2, 1);
+      if (Tn >= 3 && w == 0)  // the first step's helpers scatter row T-3: it has to be staged by then
+        dma_g2l<64, false>(a.compact + size_t(Tn - 3) * CWD, sSB + ((Tn - 3) & 1) * kCompactMaxWords, CWD * S, lane);
+    } else {
+      stage(Tn - 2, 1, w, NP);
+    }
+  }
   dma_wait();
   __syncthreads();
   int cur = 1;
@@ -992,7 +1071,12 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
     long long pc0 = (kProfile && a.ph) ? clock64() : 0, pc1;
 #define ILQG_PH(i) do { if (kProfile && a.ph) { __builtin_amdgcn_sched_barrier(0); pc1 = clock64(); __builtin_amdgcn_sched_barrier(0); phacc[i] += pc1 - pc0; pc0 = pc1; } } while (0)
     if (NP == 1) {
-      if (k > 0) stage(k - 1, 1 - cur, 0, 1);
+      if (k > 0) {
+        if (cmp)
+          stage_c(k - 1, 1 - cur, 0, 1);
+        else
+          stage(k - 1, 1 - cur, 0, 1);
+      }
       stash_ql(k);
     }
     ILQG_PH(0);
@@ -1059,7 +1143,12 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
     lds_sync(false);  // [S | Y] and y_zeta complete (LDS only: no wait on the DMA or on global stores)
     ILQG_PH(7);
     if (NP > 1 && w != 0) {  // while wave 0 solves: next step's image and this step's Q_i l_i
-      if (k > 0) stage(k - 1, 1 - cur, w - 1, HELPERS);
+      if (k > 0) {
+        if (cmp)
+          stage_c(k - 1, 1 - cur, w - 1, HELPERS);
+        else
+          stage(k - 1, 1 - cur, w - 1, HELPERS);
+      }
       ILQG_PH(14);
       stash_ql(k);
       if (w == 1) stash_ql_of(k, 0);

@@ -198,8 +198,8 @@ __global__ void __launch_bounds__(64) receding_sync_kernel(DevProblem p, Recedin
   st.to_next_step(a.t);
   st.whole_steps(int_begin, int_end);
   // nearest plan state in the first subsystem's metric (concatenated_dynamical_system.cpp:109-113: its position for
-  // the car / unicycle / point-mass models, its whole state where the model inherits the default squared norm —
-  // DevProblem::sync_dist_dims); std::min_element keeps the first minimum
+  // the car / unicycle / point-mass models and TwoPlayerUnicycle4D, its whole state where the model inherits the default
+  // squared norm (SinglePlayerDubinsCar) — DevProblem::sync_dist_dims); std::min_element keeps the first minimum
   T bestd = dinf<T>();
   int bestk = 0x7fffffff;
   for (int k = t; k < pl.len; k += 64) {

@@ -22,6 +22,7 @@ namespace ilqg {
 struct RowProgramHost {
   std::vector<int> words;  // the device image
   int num_pslots = 0, max_lslots = 0, maps_off = 0, maps_words = 0;
+  int compact_off = 0, compact_w = 0;  // the compact-row block (ilqg_rows.hpp: RP_OFF_COMPACT) and its row length
 };
 
 // `poly_off`: the problem's polyline offsets (points), host copy.
@@ -165,6 +166,8 @@ inline bool build_row_program(const DevProblem& d, const std::vector<DevTerm>& d
   }
 
   // passes 1..N: the players
+  std::vector<int> cbase, cdst, cbg;  // compact rows (ilqg_rows.hpp)
+  bool compact_ok = true;
   merit.assign(size_t(N) * RMERIT_WORDS, 0);
   for (int i = 0; i < N; i++) {
     std::map<int, int> q_slot;                  // word of Q_i (a + n * b) -> pass-local slot
@@ -295,6 +298,30 @@ inline bool build_row_program(const DevProblem& d, const std::vector<DevTerm>& d
     passes.insert(passes.end(), {op_begin, int(ops.size()) / ROP_WORDS, reg_begin, int(regions.size()) / RREG_WORDS,
                                  li_begin, nl, RPASS_PLAYER, i});
     if (nl > max_lslots) max_lslots = nl;
+    // compact row: this pass's local slots in slot order; where each lands in the dense arrays
+    {
+      const int base = int(cdst.size());
+      cbase.push_back(base);
+      cdst.resize(size_t(base) + nl, -1);
+      for (int rg = reg_begin; rg < int(regions.size()) / RREG_WORDS; rg++) {
+        const int arr = regions[rg * RREG_WORDS + 0], words = regions[rg * RREG_WORDS + 1], offs = regions[rg * RREG_WORDS + 2];
+        const int mo = regions[rg * RREG_WORDS + 3];
+        for (int wd = 0; wd < words; wd++) {
+          const int slot = maps[size_t(mo) + wd];
+          if (slot >= NPS) {
+            if (cdst[size_t(base) + slot - NPS] >= 0) compact_ok = false;  // a slot feeds one word
+            cdst[size_t(base) + slot - NPS] = (arr << 24) | (offs + wd);
+          } else if (slot != S_ZERO) {
+            float v = 0.0f;
+            std::memcpy(&v, &pinit[size_t(slot) * RINIT_WORDS + 1], sizeof(v));
+            if ((pinit[size_t(slot) * RINIT_WORDS] & 255) != RI_VALUE) compact_ok = false;
+            if (v != 0.0f) { cbg.push_back((arr << 24) | (offs + wd)); cbg.push_back(fbits(v)); }
+          }
+        }
+      }
+      for (int e = base; e < int(cdst.size()); e++)
+        if (cdst[e] < 0) compact_ok = false;
+    }
   }
   if (NPS + max_lslots > 32000) { *err = "row program: too many slots"; return false; }
 
@@ -317,6 +344,20 @@ inline bool build_row_program(const DevProblem& d, const std::vector<DevTerm>& d
   w[RP_OFF_LINIT] = put(linit);
   w[RP_OFF_REGIONS] = put(regions);
   w[RP_OFF_MERIT] = put(merit);
+  {
+    if (cdst.size() > size_t(kCompactMaxWords) || cdst.size() >= (1u << 24)) compact_ok = false;
+    std::vector<int> blk;
+    blk.push_back(compact_ok ? int(cdst.size()) : 0);
+    blk.push_back(compact_ok ? int(cbg.size()) / 2 : 0);
+    for (int i = 0; i < N; i++) blk.push_back(i < int(cbase.size()) ? cbase[i] : 0);
+    if (compact_ok) {
+      blk.insert(blk.end(), cdst.begin(), cdst.end());
+      blk.insert(blk.end(), cbg.begin(), cbg.end());
+    }
+    w[RP_OFF_COMPACT] = put(blk);
+    out->compact_off = w[RP_OFF_COMPACT];
+    out->compact_w = blk[0];
+  }
   while (w.size() & 3) w.push_back(0);
   w[RP_OFF_MAPS] = int(w.size());
   for (size_t e = 0; e < maps.size(); e += 2) {

@@ -44,7 +44,7 @@ template <> struct ConstPtr<double> { typedef const __attribute__((address_space
 // ---- row program: a flat int32 buffer; header words give the offsets of its tables ----
 enum {
   RP_NUM_PASSES = 0, RP_NUM_PSLOTS, RP_MAX_LSLOTS, RP_OFF_PASS, RP_OFF_OPS, RP_OFF_SIDS, RP_OFF_PINIT, RP_OFF_LINIT,
-  RP_OFF_REGIONS, RP_OFF_MAPS, RP_MAPS_WORDS, RP_OFF_MERIT, RP_WORDS, RP_HEADER = 16
+  RP_OFF_REGIONS, RP_OFF_MAPS, RP_MAPS_WORDS, RP_OFF_MERIT, RP_WORDS, RP_OFF_COMPACT, RP_HEADER = 16
 };
 enum { RPASS_WORDS = 8, ROP_FIELDS = 20, ROP_INLINE_SIDS = 20, ROP_WORDS = 40, RREG_WORDS = 4, RMERIT_WORDS = 4, RINIT_WORDS = 2 };
 // An op is self-contained: [mode, first slot id, slot ids, aux | the fields of the term it evaluates | its first
@@ -67,7 +67,6 @@ enum {
 // how a slot starts a chunk (persistent slots) or a pass (pass-local slots): [kind | player << 8 | from_cost << 16,
 // value (float bits)]; RI_CREG is the value only where the reference would have created the control block
 enum { RI_VALUE = 0, RI_DT = 2, RI_NEG_DT = 3, RI_CREG = 5 };
-enum { RA_A = 0, RA_B = 1, RA_Q = 2, RA_L = 3, RA_R = 4, RA_r = 5 };
 enum { RPASS_JACOBIANS = 0, RPASS_PLAYER = 1 };
 constexpr int kRowSlotZero = 0;  // persistent slot 0 is always the constant zero
 
@@ -342,7 +341,7 @@ __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* map
   const rp_cptr linit = rp + rp[RP_OFF_LINIT];
   const rp_cptr regions = rp + rp[RP_OFF_REGIONS];
   const rp_cptr merit = rp + rp[RP_OFF_MERIT];
-  const bool quad_out = a.Q != nullptr;
+  const bool quad_out = a.Q != nullptr || a.compact != nullptr;
   const bool do_quad = quad_out || a.merit_part != nullptr;
   const bool want_cost = a.cost_part != nullptr;
   const PairTable& pt = p.pairs;
@@ -351,19 +350,31 @@ __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* map
 #define ILQG_QPH(i) do { if (kProfile && a.phacc) { __builtin_amdgcn_sched_barrier(0); qc1 = clock64(); __builtin_amdgcn_sched_barrier(0); a.phacc[i] += qc1 - qc0; qc0 = qc1; } } while (0)
 
   // ---- the chunk's (x, u) rows, transposed: global reads are contiguous, a lane later reads down its column ----
+  // (loads in batches of eight ahead of their LDS stores: one exposed global latency per batch instead of one per element)
   {
-    const T* gx = a.xs + size_t(k0) * CN;
-    for (int i = lane; i < cw * CN; i += 64) {
-      const int r = i / CN, e = i - r * CN;
-      const int rs = r < nrows ? r : nrows - 1;  // lanes past the chunk's end repeat its last row (results unused)
-      arg[e * cw + r] = gx[rs * CN + e];
-    }
-    const T* gu = a.us + size_t(k0) * CM;
-    for (int i = lane; i < cw * CM; i += 64) {
-      const int r = i / CM, e = i - r * CM;
-      const int rs = r < nrows ? r : nrows - 1;
-      arg[(CN + e) * cw + r] = gu[rs * CM + e];
-    }
+    auto stage_rows = [&](const T* g, int dim, int first) {
+      constexpr int UN = 8;
+      const int total = cw * dim;
+      for (int i0 = 0; i0 < total; i0 += 64 * UN) {
+        T v[UN];
+        int dst[UN];
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+          const int i = i0 + u * 64 + lane;
+          const bool in = i < total;
+          const int ic = in ? i : 0;
+          const int r = ic / dim, e = ic - r * dim;
+          const int rs = r < nrows ? r : nrows - 1;  // lanes past the chunk's end repeat its last row (results unused)
+          dst[u] = in ? (first + e) * cw + r : -1;
+          v[u] = g[rs * dim + e];
+        }
+#pragma unroll
+        for (int u = 0; u < UN; u++)
+          if (dst[u] >= 0) arg[dst[u]] = v[u];
+      }
+    };
+    stage_rows(a.xs + size_t(k0) * CN, CN, 0);
+    stage_rows(a.us + size_t(k0) * CM, CM, CN);
   }
   lds_sync(true);
   tl_stamp(a.tl, a.tl_b, 40, lane == 0);
@@ -575,6 +586,26 @@ __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* map
         if (a.R) rows_writeout_small<T>(a.R + size_t(k0) * pt.Rsz + offs, pt.Rsz, words, map, acc, cws, nrows, lane);
       } else {
         if (a.r) rows_writeout_small<T>(a.r + size_t(k0) * pt.rsz + offs, pt.rsz, words, map, acc, cws, nrows, lane);
+      }
+    }
+    if (pkind == RPASS_PLAYER && a.compact) {
+      // compact row: this pass's local slots, in slot order, at the pass's base (lane = slot, loop = row)
+      const rp_cptr cb = rp + rp[RP_OFF_COMPACT];
+      const int CWD = cb[RC_W], base = cb[RC_BASE + player];
+      T* const g0 = a.compact + size_t(k0) * CWD + base;
+      constexpr int RB = 8;
+      for (int s0 = 0; s0 < li_count; s0 += 64) {
+        const bool in = s0 + lane < li_count;
+        const int off = (NPS + (in ? s0 + lane : 0)) * cws;
+#pragma unroll 1
+        for (int r0 = 0; r0 < nrows; r0 += RB) {
+          T val[RB];
+#pragma unroll
+          for (int rr = 0; rr < RB; rr++) val[rr] = acc[off + (r0 + rr < nrows ? r0 + rr : nrows - 1)];
+#pragma unroll
+          for (int rr = 0; rr < RB; rr++)
+            if (r0 + rr < nrows && in) g0[size_t(r0 + rr) * CWD + s0 + lane] = val[rr];
+        }
       }
     }
     lds_sync(true);  // pass-local slots are re-initialised by the next pass

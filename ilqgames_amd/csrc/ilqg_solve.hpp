@@ -46,6 +46,8 @@ struct SolveArgs {
   int* ids_next;
   const T* forced_steps;  // [B][fixed_iters] or null: test mode, iteration q of instance b takes this step, no Armijo test
   int defer_forward;    // 1: the sweep's forward pass / ExpectedDecrease runs in the next trial pass, beside the rollout
+  int compact;          // 1: [Q | l | R | r] travel from the row stage to the sweep as compact rows (ilqg_rows.hpp), kept
+                        //    where the dense Q array would be
   int rows_cw;          // rows per chunk of the row stage (ilqg_rows.hpp): 64, 32 or 16, chosen by the launcher
   T* probe_pool;        // speculative line search: [listed instances][probe_k] entries of ProbeEntry::total elements
   int probe_k;          // step sizes probed per instance this round (<= kProbeCandidates)
@@ -349,7 +351,7 @@ __host__ __device__ inline size_t trial_phase_lds_bytes(const DevProblem& p, int
 // What the rows of a pass are asked for, from the instance's state (the pass's rollout, if any, is done).
 template <typename T>
 __device__ __forceinline__ QuadArgs<T> trial_quad_args(const DevProblem& p, const InstanceBuffers<T>& ib,
-                                                       const SolveState<T>& s) {
+                                                       const SolveState<T>& s, bool compact) {
   const WsLayout& L = ib.L;
   T* const w = ib.w;
   const int qmode = s.qmode;
@@ -364,10 +366,11 @@ __device__ __forceinline__ QuadArgs<T> trial_quad_args(const DevProblem& p, cons
   const bool lin = qmode != Q_COSTS, quad = qmode == Q_INIT || qmode == Q_TRIAL;
   qa.A = lin ? w + L.A : nullptr;
   qa.Bm = lin ? w + L.B : nullptr;
-  qa.Q = quad ? w + L.Q : nullptr;
-  qa.l = quad ? w + L.l : nullptr;
-  qa.R = quad ? w + L.R : nullptr;
-  qa.r = quad ? w + L.r : nullptr;
+  qa.Q = (quad && !compact) ? w + L.Q : nullptr;
+  qa.l = (quad && !compact) ? w + L.l : nullptr;
+  qa.R = (quad && !compact) ? w + L.R : nullptr;
+  qa.r = (quad && !compact) ? w + L.r : nullptr;
+  qa.compact = (quad && compact) ? w + L.Q : nullptr;  // the dense Q array's space
   qa.merit_part = qmode == Q_TRIAL ? w + L.mpart : nullptr;
   qa.cost_part = (qmode == Q_COSTS || qmode == Q_TRIAL || qmode == Q_LIN) ? w + L.cpart : nullptr;
   qa.phacc = nullptr;
@@ -380,7 +383,7 @@ __device__ __forceinline__ void rows_part_instance(const DevProblem& p, const sh
                                                    int b, int chunk, T* sm) {
   const InstanceBuffers<T> ib(p, sa, b);
   const SolveState<T> s = state_load<T>(ib.w, ib.L);
-  const QuadArgs<T> qa = trial_quad_args<T>(p, ib, s);
+  const QuadArgs<T> qa = trial_quad_args<T>(p, ib, s, sa.compact != 0);
   const int k0 = chunk * sa.rows_cw;
   const int nrows = p.T - k0 < sa.rows_cw ? p.T - k0 : sa.rows_cw;
   rows_chunk<T, NX, NP * MU, NP>(p, maps, qa, k0, nrows, sa.rows_cw, sm, int(threadIdx.x));
@@ -630,7 +633,7 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const s
     // ---- linearise / quadraticise the trajectory: every wave claims rows as they become ready ----
     const int qmode = s.qmode;
     if (PHASE == TRIAL_FUSED) {
-    QuadArgs<T> qa = trial_quad_args<T>(p, ib, s);
+    QuadArgs<T> qa = trial_quad_args<T>(p, ib, s, sa.compact != 0);
     qa.phacc = (kProfile && sa.prof) ? qph : nullptr;
     qa.tl = kTimeline ? sa.prof : nullptr;
     qa.tl_b = b;
@@ -692,8 +695,11 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const s
       s.stage = (s.num_iterations < max_iters) ? ST_LQ : ST_INNER_DONE;
     } else {
       bool accepted = true;
+      bool costs_ready = false;  // the cost totals were reduced beside the merit value and wait in LDS
       if (qmode == Q_TRIAL) {
-        const T merit = uniform(merit_reduce<T>(p, w + L.mpart, sm_quad0, int(qe)));
+        T merit_v = T(0);
+        costs_ready = merit_costs_reduce<T>(p, w + L.mpart, w + L.cpart, t_extreme, sm_quad0, int(qe), &merit_v);
+        const T merit = costs_ready ? uniform(merit_v) : uniform(merit_reduce<T>(p, w + L.mpart, sm_quad0, int(qe)));
         const T scaled = T(prm.expected_decrease_fraction) * s.step * s.expected_decrease;
         accepted = (s.last_merit - merit >= scaled) || sa.forced_steps != nullptr;  // CheckArmijoCondition :350-362
         if (accepted) {
@@ -710,7 +716,10 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const s
         s.sacc = 1 - s.sacc;
         s.acc_scale = s.step;
         s.accepted_iters++;
-        costs_reduce<T>(p, w + L.cpart, costs, t_extreme, sm_quad0, int(qe));  // TotalCosts of the accepted iterate (:158)
+        if (costs_ready)  // TotalCosts of the accepted iterate (:158)
+          costs_commit<T>(p, sm_quad0, costs, t_extreme);
+        else
+          costs_reduce<T>(p, w + L.cpart, costs, t_extreme, sm_quad0, int(qe));
         s.stage = (s.num_iterations < max_iters && (sa.fixed_iters > 0 || !s.has_converged)) ? ST_LQ : ST_INNER_DONE;
       } else {
         s.bt++;
@@ -790,6 +799,10 @@ __device__ __forceinline__ void lq_part_instance(const DevProblem& p, const Solv
   la.T_steps = Tn;
   la.adaptive = 1;
   la.symmetric = 1;  // linquad_compute writes H(x,y) and H(y,x) from the same value
+  if (sa.compact && KIND == LQ_PLAYER_WAVES) {
+    la.compact = w + L.Q;
+    la.compact_tab = p.row_prog + p.rp_compact_off;
+  }
   la.ph = (kProfile && sa.prof) ? sa.prof + size_t(b) * 96 + 8 : nullptr;
   la.tl = kTimeline ? sa.prof : nullptr;
   la.tl_b = b;

@@ -242,6 +242,8 @@ struct QuadArgs {
   double t_init;
   T *A, *Bm;           // [T][n*n], [T][n*m] or nullptr (skip linearisation)
   T *Q, *l, *R, *r;    // or nullptr (skip quadraticisation outputs)
+  T* compact = nullptr;  // [T][rp_compact_w] or nullptr: the touched words of [Q | l | R | r] only (ilqg_rows.hpp), instead
+                         // of the dense arrays
   T* merit_part;       // [T][N][2] = (|r_ii|^2, |l_i|^2) or nullptr
   T* cost_part;        // [T][N] PlayerCost::Evaluate or nullptr
   long long* phacc = nullptr;  // optional phase profile accumulators (registers of the caller)
@@ -253,13 +255,26 @@ struct QuadArgs {
 // the reference's order; only the LDS latency overlaps).
 template <typename T, typename F>
 __device__ __forceinline__ void lds_ordered_visit(const T* v, int count, F&& visit) {
+  // software-pipelined: the loads of the next eight are in flight while this eight is added (the chain of dependent
+  // adds is what the reduction costs; an LDS round trip per batch on top of it doubled that)
+  constexpr int U = 8;
   int e = 0;
-  for (; e + 8 <= count; e += 8) {
-    T x[8];
+  if (count >= U) {
+    T x[U];
 #pragma unroll
-    for (int u = 0; u < 8; u++) x[u] = v[e + u];
+    for (int u = 0; u < U; u++) x[u] = v[u];
+    for (; e + 2 * U <= count; e += U) {
+      T y[U];
 #pragma unroll
-    for (int u = 0; u < 8; u++) visit(e + u, x[u]);
+      for (int u = 0; u < U; u++) y[u] = v[e + U + u];
+#pragma unroll
+      for (int u = 0; u < U; u++) visit(e + u, x[u]);
+#pragma unroll
+      for (int u = 0; u < U; u++) x[u] = y[u];
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) visit(e + u, x[u]);
+    e += U;
   }
   for (; e < count; e++) visit(e, v[e]);
 }
@@ -301,6 +316,74 @@ __device__ __forceinline__ T merit_reduce(const DevProblem& p, const T* merit_pa
   const T v = sm[0];
   __syncthreads();
   return v;
+}
+
+// Both reductions of an accepted-or-not line-search trial in one go: the merit value (merit_reduce) on the first lane
+// of the workgroup and, beside it on another wave (when there is one), the per-player cost totals of costs_reduce, held
+// back in LDS until the caller knows whether the trial is accepted (costs_commit).  One staging of both partial arrays,
+// one pair of workgroup barriers.  Returns false (nothing done) when the partials do not fit `sm`.
+template <typename T>
+__device__ __forceinline__ bool merit_costs_reduce(const DevProblem& p, const T* merit_part, const T* cost_part,
+                                                   const int* t_extreme, T* sm, int sm_elems, T* merit_out) {
+  const int cm = p.T * p.N * 2, cc = p.T * p.N;
+  if (cm + cc + 2 * kMaxPlayers + 4 > sm_elems) return false;
+  __syncthreads();  // partials were written to global memory by other lanes
+  T* const smc = sm + cm;
+  T* const res = smc + cc;  // [merit | cost_i ... | t_extreme_i (as T) ...]
+  for (int e = threadIdx.x; e < cm; e += blockDim.x) sm[e] = merit_part[e];
+  for (int e = threadIdx.x; e < cc; e += blockDim.x) smc[e] = cost_part[e];
+  __syncthreads();
+  const int cw0 = blockDim.x > 64 ? 64 : 0;  // first lane of the cost reduction: the second wave when there is one
+  if (threadIdx.x == 0) {
+    T merit = T(0);
+    const int skip = p.N * 2;  // the |l_i|^2 terms of k = 0 do not enter (:421)
+    lds_ordered_visit<T>(sm, cm, [&](int e, T x) {
+      if ((e & 1) == 0 || e >= skip) merit += x;
+    });
+    res[0] = T(0.5) * merit;
+  }
+  const int i = int(threadIdx.x) - cw0;
+  if (i >= 0 && i < p.N) {
+    const int st = p.structure[i];
+    T c = st == ILQG_SUM ? T(0) : (st == ILQG_MAX ? -dinf<T>() : dinf<T>());
+    int te = t_extreme ? t_extreme[i] : 0;
+    auto visit = [&](int k, T v) {
+      if (st == ILQG_SUM)
+        c += v;
+      else if (st == ILQG_MAX && v > c) {
+        c = v;
+        te = k;
+      } else if (st == ILQG_MIN && v < c) {
+        c = v;
+        te = k;
+      }
+    };
+    int k = 0;
+    for (; k + 8 <= p.T; k += 8) {
+      T x[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) x[u] = smc[(k + u) * p.N + i];
+#pragma unroll
+      for (int u = 0; u < 8; u++) visit(k + u, x[u]);
+    }
+    for (; k < p.T; k++) visit(k, smc[k * p.N + i]);
+    res[1 + i] = c;
+    res[1 + kMaxPlayers + i] = T(te);
+  }
+  __syncthreads();
+  *merit_out = res[0];
+  return true;
+}
+// The cost totals merit_costs_reduce left in `sm`, written out (TotalCosts of an accepted iterate).
+template <typename T>
+__device__ __forceinline__ void costs_commit(const DevProblem& p, const T* sm, T* costs_out, int* t_extreme) {
+  const T* const res = sm + p.T * p.N * 3;
+  const int i = threadIdx.x;
+  if (i < p.N) {
+    costs_out[i] = res[1 + i];
+    if (t_extreme) t_extreme[i] = int(res[1 + kMaxPlayers + i]);
+  }
+  __syncthreads();
 }
 
 // ILQSolver::TotalCosts reduction (:220-257): sum / max / min over time per player, and

@@ -354,7 +354,8 @@ typedef struct {
   int32_t handoff;              /* ilqg_choice: back-tracking instances leave the fused kernel for split passes     */
   int32_t probe;                /* ilqg_choice: speculative line search over the next step sizes of listed instances */
   int32_t counted;              /* ilqg_choice: host counts the rounds of a fixed-iteration solve as well           */
-  int32_t reserved[6];
+  int32_t compact_rows;         /* ilqg_choice: the row stage hands the sweep only the touched words of [Q|l|R|r]   */
+  int32_t reserved[5];
 } ilqg_solve_options;
 void ilqg_default_solve_options(ilqg_solve_options* o);
 

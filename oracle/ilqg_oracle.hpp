@@ -1639,9 +1639,9 @@ int RecedingHorizonShift(const Problem<S>& p, const RecedingHorizonTimes& tm, co
     x = Integrate(p, 0.0, p.dt, x, ApplyStrategies(p, *st, kk, x, op->xs[kk], op->us[kk]), false);
   // nearest plan state: ConcatenatedDynamicalSystem::DistanceBetween looks at the first subsystem only
   // (concatenated_dynamical_system.cpp:109-113); the car / unicycle models measure squared position distance
-  // — SinglePlayerDubinsCar inherits the default, the squared norm of its whole state (single_player_dynamical_system.h:69),
-  // and so does TwoPlayerUnicycle4D (multi_player_integrable_system.h:113)
-  const int dist_dims = p.subs[0].kind == ILQG_DYN_DUBINS_CAR ? 3 : p.subs[0].kind == ILQG_DYN_UNICYCLE_4D_DISTURBED ? 4 : 2;
+  // (TwoPlayerUnicycle4D overrides it the same way: px, py only, two_player_unicycle_4d.h:141-147) — SinglePlayerDubinsCar
+  // alone inherits the default, the squared norm of its whole state (single_player_dynamical_system.h:69)
+  const int dist_dims = p.subs[0].kind == ILQG_DYN_DUBINS_CAR ? 3 : 2;
   int first = 0;
   S best = std::numeric_limits<S>::infinity();
   for (int k = 0; k < T; k++) {
@@ -1773,7 +1773,7 @@ int SetUpNextRecedingHorizon(const Problem<S>& p, const Vec<S>& x0, double t0, d
   Vec<S> x = IntegrateToNextTimeStep(p, t0, x0, *pl);
   x = IntegrateSteps(p, size_t(tm.integrate_begin), size_t(tm.integrate_end), x, *pl);
   // nearest plan state in the first subsystem's DistanceBetween (see RecedingHorizonShift above)
-  const int dist_dims = p.subs[0].kind == ILQG_DYN_DUBINS_CAR ? 3 : p.subs[0].kind == ILQG_DYN_UNICYCLE_4D_DISTURBED ? 4 : 2;
+  const int dist_dims = p.subs[0].kind == ILQG_DYN_DUBINS_CAR ? 3 : 2;
   int first = 0;
   S best = std::numeric_limits<S>::infinity();
   for (int k = 0; k < pl->len(); k++) {

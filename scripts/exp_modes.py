@@ -17,6 +17,7 @@ ap.add_argument("--dtype", default="f64")
 ap.add_argument("--config", default="modified_three_player_intersection")
 ap.add_argument("--split", type=int, default=-1, help="-1 auto, 0 fused, 1 split passes")
 ap.add_argument("--iters", type=int, default=6)
+ap.add_argument("--compact", type=int, default=-1, help="-1 auto, 0 dense rows, 1 compact rows")
 ap.add_argument("--reps", type=int, default=3)
 a = ap.parse_args()
 dtype = abi.F64 if a.dtype == "f64" else abi.F32
@@ -28,12 +29,13 @@ prob = hip.Problem(spec, dtype)
 x0 = torch.as_tensor(examples.jittered_x0(spec, a.batch, seed=0), dtype=hip.torch_dtype(dtype), device="cuda")
 bufs = prob.alloc_solve_buffers(a.batch)
 split = None if a.split < 0 else bool(a.split)
+compact = None if a.compact < 0 else bool(a.compact)
 
 
 def run():
     for k in ("xs", "us", "P", "alpha"):
         bufs[k].zero_()
-    prob.solve(x0, bufs, fixed_iters=a.iters, split_trial=split)
+    prob.solve(x0, bufs, fixed_iters=a.iters, split_trial=split, compact_rows=compact)
 
 
 run()
@@ -44,11 +46,11 @@ for _ in range(a.reps):
     for k in ("xs", "us", "P", "alpha"):
         bufs[k].zero_()
     e0.record()
-    prob.solve(x0, bufs, fixed_iters=a.iters, split_trial=split)
+    prob.solve(x0, bufs, fixed_iters=a.iters, split_trial=split, compact_rows=compact)
     e1.record()
     torch.cuda.synchronize()
     ts.append(e0.elapsed_time(e1))
 ts.sort()
 ms = ts[len(ts) // 2]
-print("batch %d %s split=%s iters=%d: %.3f ms per solve, %.3f ms per iteration of the batch, %.3f M it/s" %
-      (a.batch, a.dtype, a.split, a.iters, ms, ms / a.iters, a.batch * a.iters / ms / 1e3))
+print("batch %d %s split=%s compact=%s iters=%d: %.3f ms per solve, %.3f ms per iteration of the batch, %.3f M it/s" %
+      (a.batch, a.dtype, a.split, a.compact, a.iters, ms, ms / a.iters, a.batch * a.iters / ms / 1e3))

@@ -5,7 +5,7 @@ set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=/tmp/ilqg_regs_$1_$2_$3
 mkdir -p $OUT
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -I$ROOT/include -DILQG_PART_NX=$1 -DILQG_PART_NP=$2 -DILQG_PART_MU=$3 \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form=1 -I$ROOT/include -DILQG_PART_NX=$1 -DILQG_PART_NP=$2 -DILQG_PART_MU=$3 \
   -Wno-unused-function --cuda-device-only -S $ROOT/ilqgames_amd/csrc/ilqg_api.hip -o $OUT/dev.s
 python3 - "$OUT/dev.s" "${4:-.}" <<'PY'
 import re, sys
