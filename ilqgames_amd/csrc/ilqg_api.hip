@@ -649,8 +649,8 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   // ILQG_SPLIT_TRIAL=0/1 overrides the choice (A/B measurements).
   // Split passes: where the fused kernel cannot keep four instances on a CU, and for batches that are several times
   // what it keeps resident when the split integration kernel (a quarter of the registers, 4 KB of LDS) gains from
-  // the co-residency — measured: n = 24, B = 4096: 65 k vs 39 k it/s; n = 14 fp32, B = 8192: 1.81 M vs
-  // 1.61 M; n = 14 fp64, B = 8192: 1.02 M vs 1.08 M (the fused kernel stays).
+  // the co-residency — measured: n = 24, B = 4096: 65 k vs 39 k it/s.  For n <= 16 the fused kernel stays
+  // (round 3, with compact rows: n = 14 fp32, B = 8192: 1.97 M fused vs 1.79 M split; fp64: 1.34 M vs 1.27 M).
   int num_cus = 256;
   {
     int dev = 0;
@@ -658,7 +658,9 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) num_cus = prop.multiProcessorCount;
   }
   const bool big_batch = size_t(batch) >= size_t(8) * num_cus;
-  bool split = choice(opt.split_trial, 4 * lds_trial > size_t(160) * 1024 || (big_batch && (sizeof(T) == 4 || NX > 16)));
+  // the whole batch resident at once (four instances per CU): fair issue arbitration among the co-resident instances
+  sa.prio_div = (batch > num_cus && batch <= 4 * num_cus) ? num_cus : 0;
+  bool split = choice(opt.split_trial, 4 * lds_trial > size_t(160) * 1024 || (big_batch && NX > 16));
   if (kProfile || opt.forced_steps) split = false;  // the phase profile reads the fused kernel's counters
   const bool counted = !opt.forced_steps && (split || !(fixed_iters > 0 && !al_mode) || choice(opt.counted, false));
   // Hand-off: whenever the host counts rounds anyway, the fused kernel keeps an instance only until its line

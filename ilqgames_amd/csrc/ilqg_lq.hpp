@@ -42,6 +42,7 @@ struct LQArgs {
   long long* ph = nullptr;          // optional: 8 shader-clock accumulators per instance (phase profile)
   const T* compact = nullptr;       // [T][compact_tab[RC_W]] compact rows of [Q | l | R | r] (ilqg_common.hpp) instead of the
   const int* compact_tab = nullptr; // dense arrays: the one-tile player-parallel sweep only; compact_tab = the row program's block
+  int prio_div = 0;                 // > 0: rotate the wave priority every step, phase = blockIdx.x / prio_div (see the sweep)
   long long* tl = nullptr;          // optional: timeline stamps (ilqg_common.hpp, -DILQG_TIMELINE=1)
   int tl_b = 0;
 };
@@ -1068,6 +1069,18 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
                                               ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
 #pragma unroll 1
   for (int k = Tn - 2; k >= 0; k--) {
+    if (a.prio_div > 0) {
+      // Issue arbitration among the instances that share a CU is by priority, then AGE: left alone the workgroup that
+      // arrived first runs at the speed of a lone instance and the last one pays for it — and the launch ends when the
+      // last one does (measured, B = 1024 fp64: finishing times 356 / 386 / 428 / 465 us in arrival order).  Rotating
+      // the user priority with the step index shares the delay out: every instance ends within 10 us of 430 us.
+      // Only when the whole batch is resident at once (prio_div = CUs: blocks b, b + CUs, ... share a CU).
+      const int pr = (k + int(blockIdx.x) / a.prio_div) & 3;
+      if (pr == 0) __builtin_amdgcn_s_setprio(0);
+      else if (pr == 1) __builtin_amdgcn_s_setprio(1);
+      else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+      else __builtin_amdgcn_s_setprio(3);
+    }
     long long pc0 = (kProfile && a.ph) ? clock64() : 0, pc1;
 #define ILQG_PH(i) do { if (kProfile && a.ph) { __builtin_amdgcn_sched_barrier(0); pc1 = clock64(); __builtin_amdgcn_sched_barrier(0); phacc[i] += pc1 - pc0; pc0 = pc1; } } while (0)
     if (NP == 1) {
@@ -1411,6 +1424,7 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
     ILQG_PH(6);
   }
 #undef ILQG_PH
+  if (a.prio_div > 0) __builtin_amdgcn_s_setprio(0);
   tl_stamp(a.tl, a.tl_b, 18, t == 0);
   if (kProfile && a.ph && lane == 0) {  // wave w's row of the profile: a.ph[16 * w + i]
 #pragma unroll

@@ -46,6 +46,8 @@ struct SolveArgs {
   int* ids_next;
   const T* forced_steps;  // [B][fixed_iters] or null: test mode, iteration q of instance b takes this step, no Armijo test
   int defer_forward;    // 1: the sweep's forward pass / ExpectedDecrease runs in the next trial pass, beside the rollout
+  int prio_div;         // > 0: the batch is resident at once on this many CUs: the kernels rotate their wave priorities so
+                        //      that the instances sharing a CU finish together (ilqg_lq.hpp)
   int compact;          // 1: [Q | l | R | r] travel from the row stage to the sweep as compact rows (ilqg_rows.hpp), kept
                         //    where the dense Q array would be
   int rows_cw;          // rows per chunk of the row stage (ilqg_rows.hpp): 64, 32 or 16, chosen by the launcher
@@ -799,6 +801,7 @@ __device__ __forceinline__ void lq_part_instance(const DevProblem& p, const Solv
   la.T_steps = Tn;
   la.adaptive = 1;
   la.symmetric = 1;  // linquad_compute writes H(x,y) and H(y,x) from the same value
+  la.prio_div = KIND == LQ_PLAYER_WAVES ? sa.prio_div : 0;
   if (sa.compact && KIND == LQ_PLAYER_WAVES) {
     la.compact = w + L.Q;
     la.compact_tab = p.row_prog + p.rp_compact_off;
