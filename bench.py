@@ -29,7 +29,11 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
-FP64_PEAK_TFLOPS = 78.6  # dense fp64 (vector = matrix on this part), MI355X_MICROARCH.md
+# Dense fp64 rate, DERIVED (the guide lists no fp64 figure): half of its fp32 vector peak of 157.3 TFLOP/s, i.e.
+# 32 flop/clk/SIMD — what scripts/ubench/mfma_lat.hip measures for v_mfma_f64_16x16x4_f64 (64 cycles per 2048 flop)
+# and for dependent-free v_fma_f64 streams on this part.
+FP32_PEAK_TFLOPS = 157.3
+FP64_PEAK_TFLOPS = FP32_PEAK_TFLOPS / 2
 
 
 def algorithmic_bytes_per_iteration(n, m, N, T, pairs_m, elem, backtracks=0.0):
@@ -42,6 +46,18 @@ def algorithmic_bytes_per_iteration(n, m, N, T, pairs_m, elem, backtracks=0.0):
     base = elem * T * (2 * (W_lin + W_quad) + 2 * W_strat + 2 * W_op + n)
     extra = elem * T * (W_quad + W_strat + 2 * W_op)
     return base + backtracks * extra
+
+
+def sweep_flops_executed_per_step(n, m, N, open_loop):
+    """What the device sweep EXECUTES per time step (tile products on 16 x 16 x 4 matrix instructions, 2048 flop each,
+    padding included), as opposed to the reference's dense count below.  Open loop (csrc/ilqg_lq_openloop.hpp, n <= 31):
+    60 matrix instructions per player wave + the m x m elimination with n + 1 right-hand sides (inversion lemma
+    instead of the reference's n x n QR).  Feedback, n <= 16 (csrc/ilqg_lq.hpp): 17 per player wave + the m x m
+    elimination."""
+    elim = (2.0 / 3.0) * m ** 3 + 2.0 * m * m * (n + 1)
+    if open_loop:
+        return N * 60 * 2048 + elim
+    return N * 17 * 2048 + elim
 
 
 def sweep_flops_per_step(n, m, N, open_loop):
@@ -126,40 +142,55 @@ class StubBackend:
         return 0.0
 
 
-def _cpu_worker(args):
-    """One process of the all-core CPU baseline: its own oracle instance, one thread (no shared allocator)."""
-    cfg, dtype, seed, S, steps = args
-    from ilqgames_amd import examples
-    from oracle import pyoracle
-    spec = _bench_spec(examples, cfg)
-    x0 = examples.jittered_x0(spec, S, seed=seed)
-    op = pyoracle.OracleProblem(spec)
-    op.solve(dtype, x0[:1], fixed_iters=1)
-    t0 = time.perf_counter()
-    ref = op.solve(dtype, x0, fixed_iters=steps, threads=1)
-    return int(ref["iters"].sum()), time.perf_counter() - t0
+HEADLINE_CONFIG = "modified_three_player_intersection"
+# shorthands for BASELINE.json's configurations: (config, dtype, instances per GPU, default steps)
+BASELINE_CONFIGS = {
+    2: (HEADLINE_CONFIG, "f64", 1024, 20),
+    3: (HEADLINE_CONFIG, "f32", 8192, 10),
+    4: ("roundabout_merging_T150", "f64", 4096, 4),
+    5: ("three_player_collision_avoidance_reachability", "f64", 2048, 5),
+}
 
 
-def _bench_spec(examples, config):
-    # Workload.  The n=14 example's own line-search fraction (0.9) makes the REFERENCE's line search
-    # fail at iteration 2 (tests/test_gpu_parity.py::test_ilq_solve_free_running...), so throughput
-    # is measured with the line-search parameters of exec/three_player_intersection/main.cpp:109-120
-    # (alpha0 = 0.1, fraction 0.001) at a fixed iteration count, as SURVEY.md §8(d) prescribes.
+def _bench_spec(examples, config, linesearch="auto"):
+    """The workload's problem.  Every configuration runs with ITS OWN solver parameters (the ones its exec/*/main.cpp
+    sets; ilqgames_amd/examples.py restates them) except the default one under --linesearch auto: the n = 14 example's
+    own line-search fraction (0.9) makes the REFERENCE's line search fail at iteration 2
+    (tests/test_gpu_parity.py::test_ilq_solve_free_running...), so its throughput is measured with the line-search
+    parameters of exec/three_player_intersection/main.cpp:109-120 (alpha0 = 0.1, fraction 0.001) at a fixed iteration
+    count.  --linesearch headline applies those to any configuration, --linesearch own never does.
+    Returns (spec, description of the parameters in use)."""
     spec = examples.CONFIGS[config]()
-    spec.params.initial_alpha_scaling = 0.1
-    spec.params.expected_decrease_fraction = 0.001
-    spec.params.max_backtracking_steps = 100
-    return spec
+    use_headline = linesearch == "headline" or (linesearch == "auto" and config == HEADLINE_CONFIG)
+    if use_headline:
+        spec.params.initial_alpha_scaling = 0.1
+        spec.params.expected_decrease_fraction = 0.001
+        spec.params.max_backtracking_steps = 100
+        src = "exec/three_player_intersection/main.cpp:109-120" + (
+            "; the n=14 example's own 1.0 / 0.9 fail the reference's line search at iteration 2: own_params"
+            if config == HEADLINE_CONFIG else "; --linesearch headline")
+    else:
+        src = "the example's own parameters (ilqgames_amd/examples.py restates its exec/*/main.cpp)"
+    desc = "alpha0=%g frac=%g tol=%g backtracks<=%d (%s)" % (
+        spec.params.initial_alpha_scaling, spec.params.expected_decrease_fraction, spec.params.convergence_tolerance,
+        spec.params.max_backtracking_steps, src)
+    return spec, desc
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None, help="outer iterations in one timed solve (default 20)")
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=1024, help="instances per GPU")
-    ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
-    ap.add_argument("--config", default="modified_three_player_intersection")
+    ap.add_argument("--batch", type=int, default=None, help="instances per GPU (default 1024)")
+    ap.add_argument("--dtype", choices=["f64", "f32"], default=None)
+    ap.add_argument("--config", default=None)
+    ap.add_argument("--baseline-config", type=int, choices=sorted(BASELINE_CONFIGS), default=None,
+                    help="BASELINE.json configuration number: sets --config / --dtype / --batch (/ --steps) to that "
+                         "configuration's per-GPU form, e.g. 3 = fp32, 8192 instances per GPU")
+    ap.add_argument("--linesearch", choices=["auto", "own", "headline"], default="auto",
+                    help="solver parameters: the configuration's own, or the headline's (see _bench_spec)")
+    ap.add_argument("--repeats", type=int, default=5, help="timed repetitions of the K-step solve; the median is reported")
     ap.add_argument("--backend", choices=["hip", "stub"], default="hip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true",
@@ -167,6 +198,11 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=64,
                     help="instances in one run of the CPU baseline sample (64 x 20 iterations ~ 1.3 s on one host thread)")
     args = ap.parse_args()
+    base = BASELINE_CONFIGS[args.baseline_config or 2]
+    args.config = args.config or base[0]
+    args.dtype = args.dtype or base[1]
+    args.batch = args.batch or base[2]
+    args.steps = args.steps or (base[3] if args.baseline_config else 20)
 
     import torch
     from ilqgames_amd import abi, examples, sharding
@@ -177,7 +213,7 @@ def main():
     distributed = world > 1
     dtype = abi.F64 if args.dtype == "f64" else abi.F32
     elem = 8 if dtype == abi.F64 else 4
-    spec = _bench_spec(examples, args.config)
+    spec, params_desc = _bench_spec(examples, args.config, args.linesearch)
     backend = (HipBackend if args.backend == "hip" else StubBackend)(spec, dtype, local_rank)
     if distributed:
         import torch.distributed as dist
@@ -222,32 +258,38 @@ def main():
         backend.counted = True
 
     # timed: exactly K iterations of every instance = K (LQ kernel, trial kernel) rounds after the
-    # initial trial pass; all launches are enqueued back to back on the current stream
-    reset()
-    if distributed:
-        dist.barrier()
-    backend.sync()
-    ev = backend.events()
-    t0 = time.perf_counter()
-    if ev:
-        ev[0].record()
-    backend.solve(x0_d, bufs, args.steps)
-    if ev:
-        ev[1].record()
-    gathered = gather()
-    if ev:
-        ev[2].record()
-    if distributed:
-        dist.barrier()
-    backend.sync()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    kernel_s = ev[0].elapsed_time(ev[1]) * 1e-3 if ev else elapsed
-    gather_s = ev[1].elapsed_time(ev[2]) * 1e-3 if ev else 0.0
-    if distributed:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=backend.device())
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    # initial trial pass; all launches are enqueued back to back on the current stream.  The region is repeated
+    # `--repeats` times (each bracketed by barrier + synchronize, max over ranks); the MEDIAN repetition is reported.
+    reps = []
+    for _ in range(max(1, args.repeats)):
+        reset()
+        if distributed:
+            dist.barrier()
+        backend.sync()
+        ev = backend.events()
+        t0 = time.perf_counter()
+        if ev:
+            ev[0].record()
+        backend.solve(x0_d, bufs, args.steps)
+        if ev:
+            ev[1].record()
+        gathered = gather()
+        if ev:
+            ev[2].record()
+        if distributed:
+            dist.barrier()
+        backend.sync()
+        t1 = time.perf_counter()
+        el = t1 - t0
+        ks = ev[0].elapsed_time(ev[1]) * 1e-3 if ev else el
+        gs = ev[1].elapsed_time(ev[2]) * 1e-3 if ev else 0.0
+        if distributed:
+            tt = torch.tensor([el], dtype=torch.float64, device=backend.device())
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        reps.append((el, ks, gs))
+    reps_sorted = sorted(reps)
+    elapsed, kernel_s, gather_s = reps_sorted[len(reps_sorted) // 2]
 
     iters = bufs["iters"].cpu().numpy()
     status = bufs["status"].cpu().numpy()
@@ -268,6 +310,7 @@ def main():
         pairs_m = [spec.udims[j] for _, j in pairs]
         mean_bt = backend.mean_backtracks(bufs, local_iters)
         bytes_iter = algorithmic_bytes_per_iteration(n, m, N, T, pairs_m, elem, backtracks=mean_bt)
+        bytes_iter_b0 = algorithmic_bytes_per_iteration(n, m, N, T, pairs_m, elem, backtracks=0.0)
         value = total_iters / elapsed
         # Roofline of the hot path on this rank.  One outer iteration of the batch is one round of two
         # kernels (ilq_lq_kernel: Riccati sweep; ilq_trial_kernel: rollout + linearise/quadraticise +
@@ -275,6 +318,7 @@ def main():
         # with HIP events over the K rounds (profiles/: the two kernels' rocprofv3 averages add up to it).
         launch_bytes = bytes_iter * local_iters
         achieved = launch_bytes / kernel_s / 1e9
+        achieved_b0 = bytes_iter_b0 * local_iters / kernel_s / 1e9
         # HBM traffic per round: bench.py cannot run rocprofv3 on itself, so this figure is READ from the committed
         # medians of the PMC passes scripts/profile.sh collects on this workload (profiles/traffic.json), and labelled so
         traffic, traffic_source = None, None
@@ -286,20 +330,22 @@ def main():
                 traffic_source = "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE medians, %s)" % ent.get("collected", "this round")
         except (OSError, ValueError, KeyError):
             pass
-        flops_round = sweep_flops_per_step(n, m, N, bool(spec.params.open_loop)) * T * B
+        open_loop = bool(spec.params.open_loop)
+        flops_round = sweep_flops_per_step(n, m, N, open_loop) * T * B
+        flops_exec_round = sweep_flops_executed_per_step(n, m, N, open_loop) * T * B
+        peak_tf = FP64_PEAK_TFLOPS if elem == 8 else FP32_PEAK_TFLOPS
         out = {
             "metric": "iLQ iterations/sec (batch)", "value": value, "unit": "instance-iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "%s n=%d N=%d T=%d batch=%d/GPU %s, fixed %d outer iterations, "
-                                   "alpha0=0.1 frac=0.001 (exec/three_player_intersection/main.cpp:109-120; the n=14 "
-                                   "example's own 1.0 / 0.9 fail the reference's line search at iteration 2: own_params)"
-                                   % (args.config, n, N, T, B, args.dtype, args.steps),
+            "config": {"workload": "%s n=%d N=%d T=%d batch=%d/GPU %s, fixed %d outer iterations, %s"
+                                   % (args.config, n, N, T, B, args.dtype, args.steps, params_desc),
                        "parallelism": "instances sharded across %d GPU(s); RCCL gather of strategies" % world,
                        "launch_mode": ("host-counted rounds, speculative line search (warm-up back-tracked %.2f times per "
                                        "iteration)" % warm_bt) if getattr(backend, "counted", None) else
                                       "asynchronous launch sequence (no host round trips)"},
+            "repeats": {"count": len(reps), "reported": "median", "ms_per_step_all": [r[0] / args.steps * 1e3 for r in reps]},
             "ms_per_solve_batch": kernel_s * 1e3,
             "gather_ms": gather_s * 1e3,
             "success_fraction": float(status.mean()),
@@ -310,8 +356,17 @@ def main():
                          "launch_ms": kernel_s * 1e3 / max(1, args.steps),
                          "algorithmic_bytes_per_launch": launch_bytes / max(1, args.steps),
                          "bytes_per_iteration_per_instance": bytes_iter,
-                         "flop": {"sweep_tflops": flops_round * args.steps / kernel_s / 1e12, "peak_tflops": FP64_PEAK_TFLOPS if elem == 8 else 2 * FP64_PEAK_TFLOPS,
-                                  "note": "LQ sweep flops only (SURVEY.md 8d) over the whole round time"}},
+                         # the same fraction counting NO rejected line-search trial (SURVEY.md 8(d)'s b = 0 figure): `frac`
+                         # above adds s*T*[W_quad + W_strat + 2 W_op] per rejected trial, mean_backtracks of them per iteration
+                         "frac_b0": achieved_b0 / HBM_PEAK_GBS, "bytes_per_iteration_per_instance_b0": bytes_iter_b0,
+                         "flop": {"sweep_tflops": flops_round * args.steps / kernel_s / 1e12,
+                                  "sweep_tflops_executed": flops_exec_round * args.steps / kernel_s / 1e12,
+                                  "peak_tflops": peak_tf,
+                                  "frac_executed": flops_exec_round * args.steps / kernel_s / 1e12 / peak_tf,
+                                  "note": "LQ sweep only, over the whole round time: `sweep_tflops` counts the reference's dense "
+                                          "flops (SURVEY.md 8d), `sweep_tflops_executed` what the device sweep issues on the matrix "
+                                          "cores (16x16x4 tiles, padding included; open loop: inversion lemma instead of the n x n QR); "
+                                          "peak = fp32 vector peak of MI355X_MICROARCH.md, halved for fp64 (derived, see bench.py)"}},
         }
         if args.backend == "hip" and world == 1 and not args.no_latency:
             out["latency"] = latency_figures(backend, examples, abi, args, x0_d)
@@ -329,7 +384,7 @@ def latency_figures(backend, examples, abi, args, x0_d):
     outside the timed region — on a workload that does converge: the bench's game with alpha0 = 0.5 (fraction 0.001,
     tolerance 1.0): ~400 accepted iterations."""
     import torch
-    spec = _bench_spec(examples, args.config)
+    spec, _ = _bench_spec(examples, args.config, args.linesearch)
     spec.params.initial_alpha_scaling = 0.5
     prob = backend.hip.Problem(spec, abi.F64 if args.dtype == "f64" else abi.F32)
     lb = prob.alloc_solve_buffers(1)
@@ -375,9 +430,9 @@ def own_params_figure(backend, examples, abi, args, x0_d):
 def cpu_baseline(args, spec, x0, dtype, abi, latency):
     """The oracle (a port: the reference binary cannot be built here, Eigen3 / glog / gflags absent) timed on this
     box's host cores on a bounded sample of the same workload: one thread — the reference's execution model — as the
-    median of five runs in fp32 (the reference's arithmetic) and in fp64, and every core as independent single-thread
-    processes (no shared allocator)."""
-    from concurrent.futures import ProcessPoolExecutor
+    median of five runs in fp32 (the reference's arithmetic) and in fp64, and every core with OpenMP over the
+    instances (oracle/oracle_capi.cpp, dynamic schedule), sized for >= 1 s of work per thread."""
+    from ilqgames_amd import examples
     from oracle import pyoracle
     S = min(args.cpu_sample, x0.shape[0])
     op = pyoracle.OracleProblem(spec)
@@ -391,18 +446,21 @@ def cpu_baseline(args, spec, x0, dtype, abi, latency):
             runs.append(int(ref["iters"].sum()) / (time.perf_counter() - c0))
         res[name] = sorted(runs)[2]
     ncpu = os.cpu_count() or 1
-    per = 8
-    all_cores = None
+    # every core: instances per thread = what one thread does in ~1.2 s at the rate just measured
+    per = max(4, int(1.2 * res[args.dtype] / max(1, args.steps)) + 1)
+    n_all = min(ncpu * per, 65536)
+    all_cores, all_wall = None, None
     try:
-        with ProcessPoolExecutor(max_workers=ncpu) as pool:
-            t0 = time.perf_counter()
-            parts = list(pool.map(_cpu_worker, [(args.config, dtype, 17 + w, per, args.steps) for w in range(ncpu)]))
-            wall = time.perf_counter() - t0
-        # throughput of the slowest-finishing set: total iterations over the longest worker's solve time
-        all_cores = sum(p[0] for p in parts) / max(p[1] for p in parts)
-        del wall
-    except Exception as e:  # a box that cannot fork that many workers still reports the single-thread figure
-        all_cores = None
+        xa = examples.jittered_x0(spec, n_all, seed=17)
+        op.solve(dtype, xa[:ncpu], fixed_iters=1, threads=ncpu)  # spins the thread team up
+        runs = []
+        for _ in range(3):
+            c0 = time.perf_counter()
+            ref = op.solve(dtype, xa, fixed_iters=args.steps, threads=ncpu)
+            w_ = time.perf_counter() - c0
+            runs.append((int(ref["iters"].sum()) / w_, w_))
+        all_cores, all_wall = sorted(runs)[1]
+    except Exception as e:  # the single-thread figure stands on its own
         sys.stderr.write("all-core CPU baseline skipped: %r\n" % (e,))
     out = {"value": res[args.dtype], "unit": "instance-iterations/s", "cores": 1, "kind": "port",
            "value_f32": res["f32"], "value_f64": res["f64"],
@@ -410,9 +468,10 @@ def cpu_baseline(args, spec, x0, dtype, abi, latency):
                      "reference's execution model; the reference binary itself cannot be built here (Eigen3/glog/gflags absent)"
                      % (S, args.steps),
            "value_all_cores": all_cores, "cores_all": ncpu,
-           "sample_all_cores": "%d single-thread processes x %d instances x %d iterations (%s)" % (ncpu, per, args.steps, args.dtype)}
+           "sample_all_cores": "median of 3 runs: OpenMP over %d instances (%d per thread) x %d iterations on %d threads, %s, "
+                               "%.2f s per run" % (n_all, per, args.steps, ncpu, args.dtype, all_wall or 0.0)}
     if latency is not None:
-        s2 = _bench_spec(__import__("ilqgames_amd.examples", fromlist=["x"]), args.config)
+        s2, _ = _bench_spec(examples, args.config, args.linesearch)
         s2.params.initial_alpha_scaling = 0.5
         c0 = time.perf_counter()
         one = pyoracle.OracleProblem(s2).solve(dtype, x0[:1])

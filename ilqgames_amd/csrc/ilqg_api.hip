@@ -29,16 +29,25 @@ using namespace ilqg;
 // launches — they compile in parallel.  Without those macros the file is a single self-contained unit.
 // This is the state the units share.
 namespace ilqg_shared __attribute__((visibility("hidden"))) {
+// g_prof: the diagnostic builds' buffer (-DILQG_PROFILE=1 / -DILQG_TIMELINE=1: ilqg_debug_set_profile_buffer exists only
+// there); the product library has neither the symbol nor the global.
+#define ILQG_DIAGNOSTIC_BUILD (ILQG_PROFILE || ILQG_TIMELINE)
 #if defined(ILQG_PART_NX)
 extern thread_local std::string g_err;
+#if ILQG_DIAGNOSTIC_BUILD
 extern long long* g_prof;
+#endif
 #else
 thread_local std::string g_err;
+#if ILQG_DIAGNOSTIC_BUILD
 long long* g_prof = nullptr;  // set through ilqg_debug_set_profile_buffer
+#endif
 #endif
 }  // namespace ilqg_shared
 using ilqg_shared::g_err;
+#if ILQG_DIAGNOSTIC_BUILD
 using ilqg_shared::g_prof;
+#endif
 
 namespace {
 
@@ -52,6 +61,47 @@ ilqg_status fail(ilqg_status s, const std::string& msg) {
     if (e_ != hipSuccess)                                                               \
       return fail(ILQG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));     \
   } while (0)
+
+}  // namespace
+
+// Device scratch of the stand-alone entry points that take no workspace argument (ilqg_lq_*_batch with delta_x /
+// costates, ilqg_total_costs_batch, the equilibrium checks).  The caller may hand the library a buffer of its own
+// (ilqg_set_scratch): then nothing is allocated here and a call that needs more fails with the size it needs.  Without
+// one the library keeps a grow-only allocation per calling thread.  (The solves never use it: ilqg_workspace_bytes.)
+namespace ilqg_shared __attribute__((visibility("hidden"))) {
+struct ScratchState {
+  void* ptr = nullptr;
+  size_t bytes = 0;
+  bool caller_owned = false;
+};
+#if defined(ILQG_PART_NX)
+extern thread_local ScratchState g_scratch_state;
+#else
+thread_local ScratchState g_scratch_state;  // one per calling thread, shared by the library's translation units
+#endif
+}  // namespace ilqg_shared
+
+namespace {
+struct Scratch {  // this unit's view of the shared state
+  void*& ptr = ilqg_shared::g_scratch_state.ptr;
+  ilqg_status reserve(size_t need) {
+    ilqg_shared::ScratchState& st = ilqg_shared::g_scratch_state;
+    if (need <= st.bytes) return ILQG_OK;
+    if (st.caller_owned)
+      return fail(ILQG_ERR_INVALID, "the scratch buffer given to ilqg_set_scratch is too small: this call needs " +
+                                        std::to_string(need) + " bytes");
+    if (st.ptr) (void)hipFree(st.ptr);
+    st.ptr = nullptr;
+    st.bytes = 0;
+    HIP_TRY(hipMalloc(&st.ptr, need));
+    st.bytes = need;
+    return ILQG_OK;
+  }
+};
+}  // namespace
+
+namespace {
+
 
 // ------------------------------------------------------------------------------------
 // Kernels — one workgroup per game instance
@@ -381,20 +431,6 @@ __global__ void mfma_selftest_kernel(const T* X, const T* Y, const T* C, T* out)
 // ------------------------------------------------------------------------------------
 // Host side
 // ------------------------------------------------------------------------------------
-struct Scratch {  // grow-only device scratch for entry points without a workspace argument
-  void* ptr = nullptr;
-  size_t bytes = 0;
-  ilqg_status reserve(size_t need) {
-    if (need <= bytes) return ILQG_OK;
-    if (ptr) (void)hipFree(ptr);
-    ptr = nullptr;
-    bytes = 0;
-    HIP_TRY(hipMalloc(&ptr, need));
-    bytes = need;
-    return ILQG_OK;
-  }
-};
-thread_local Scratch g_scratch;  // one per translation unit
 
 // Large dynamic-LDS launches: ask for the opt-in limit; a refusal is not fatal by itself (the launch
 // reports the real error if the size is unusable), so it must not poison the sticky error state.
@@ -493,9 +529,9 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::lq(const ilqg_dims* d, const PairTable& p
   g.scratch = nullptr;
   if (dx) {
     const size_t need = size_t(d->batch) * d->T * (NP * (NX + 1) + NX) * sizeof(T);
-    ilqg_status s = g_scratch.reserve(need);
+    ilqg_status s = Scratch().reserve(need);
     if (s != ILQG_OK) return s;
-    g.scratch = (T*)g_scratch.ptr;
+    g.scratch = (T*)ilqg_shared::g_scratch_state.ptr;
   }
   g.T_steps = d->T;
   g.adaptive = d->adaptive_regularization;
@@ -525,9 +561,9 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::lq_openloop(const ilqg_dims* d, const Pai
   g.P = (T*)P; g.alpha = (T*)alpha; g.dx = (T*)dx;
   g.costates = (T*)costates;
   const size_t need = size_t(d->batch) * d->T * (costates ? O::ROW_FAT : O::ROW) * sizeof(T);
-  ilqg_status s = g_scratch.reserve(need);
+  ilqg_status s = Scratch().reserve(need);
   if (s != ILQG_OK) return s;
-  g.scratch = (T*)g_scratch.ptr;
+  g.scratch = (T*)ilqg_shared::g_scratch_state.ptr;
   g.T_steps = d->T;
   g.adaptive = 0;
   g.batch = d->batch;
@@ -603,11 +639,18 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   sa.ws = (T*)workspace; sa.ws_stride = L.total; sa.fixed_iters = fixed_iters; sa.batch = batch;
   sa.prm = p->desc.params;
   sa.active = active;
+#if ILQG_DIAGNOSTIC_BUILD
   sa.prof = g_prof;
+#else
+  sa.prof = nullptr;
+#endif
   sa.forced_steps = (const T*)opt.forced_steps;
   sa.unfinished = p->d_unfinished;
   // the tail of the workspace: the two lists of back-tracking instances and the line-search probe pool
   const WsTail tail = ws_tail(d, batch, sizeof(T), ol_row);
+  // ws_tail places the lists behind the augmented-Lagrangian layout (the larger one): whatever al_mode this solve runs in
+  if (WsLayout(d.n, d.m, d.N, d.T, d.pairs.Rsz, d.pairs.rsz, ol_row, d.num_constraints, 1).total < L.total)
+    return fail(ILQG_ERR_INVALID, "workspace layout: the tail offset does not cover this solve's per-instance blocks");
   int* const pass_ids = reinterpret_cast<int*>(static_cast<char*>(workspace) + tail.ids_off);
   T* const probe_pool = reinterpret_cast<T*>(static_cast<char*>(workspace) + tail.pool_off);
   sa.ids = nullptr;
@@ -825,8 +868,19 @@ extern "C" {
 
 const char* ilqg_last_error(void) { return g_err.c_str(); }
 
+ilqg_status ilqg_set_scratch(void* device_buffer, size_t bytes) {
+  ilqg_shared::ScratchState& st = ilqg_shared::g_scratch_state;
+  if (st.ptr && !st.caller_owned) (void)hipFree(st.ptr);
+  st.ptr = device_buffer;
+  st.bytes = device_buffer ? bytes : 0;
+  st.caller_owned = device_buffer != nullptr;
+  return ILQG_OK;
+}
+
 // Diagnostics: device buffer [B][8] of int64 receiving per-stage shader-clock cycles of the next solves.
+#if ILQG_DIAGNOSTIC_BUILD
 void ilqg_debug_set_profile_buffer(void* buf) { g_prof = (long long*)buf; }
+#endif
 
 // out = X^T Y + C for 16x16 column-major device matrices, through the MFMA accumulator-layout
 // path the LQ sweep uses (tests pin the register layouts with asymmetric inputs).
@@ -901,7 +955,7 @@ ilqg_status ilqg_lq_feedback_batch(const ilqg_dims* d, const void* A, const void
   for (int i = 0; i < N; i++) m += d->udim[i];
   // costates: Z_i, zeta_i of every step (this translation unit's scratch; the sweep's launcher has its own)
   if (costates) {
-    s = g_scratch.reserve(size_t(d->batch) * costates_scratch_elems(d->n, N, d->T) * elem);
+    s = Scratch().reserve(size_t(d->batch) * costates_scratch_elems(d->n, N, d->T) * elem);
     if (s != ILQG_OK) return s;
   }
   auto finish = [&](ilqg_status launched) -> ilqg_status {
@@ -911,7 +965,7 @@ ilqg_status ilqg_lq_feedback_batch(const ilqg_dims* d, const void* A, const void
     cd.uoff[0] = 0;
     for (int i = 0; i < N; i++) cd.uoff[i + 1] = cd.uoff[i] + d->udim[i];
     const size_t lds = costates_lds_elems(d->n, N) * elem;
-    void* zs = g_scratch.ptr;
+    void* zs = ilqg_shared::g_scratch_state.ptr;
     if (d->dtype == ILQG_F32) {
       auto kern = lq_feedback_costates_kernel<float>;
       raise_lds_limit((const void*)kern, lds);
@@ -1250,15 +1304,15 @@ ilqg_status ilqg_total_costs_batch(const ilqg_problem* p, int32_t batch, const v
   if (batch <= 0) return ILQG_OK;
   const DevProblem& d = p->dev;
   const size_t esz = p->desc.dtype == ILQG_F32 ? 4 : 8;
-  ilqg_status s = g_scratch.reserve(size_t(batch) * d.T * d.N * esz);
+  ilqg_status s = Scratch().reserve(size_t(batch) * d.T * d.N * esz);
   if (s != ILQG_OK) return s;
   s = launch_linquad(p, batch, xs, us, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                     nullptr, nullptr, g_scratch.ptr, active, stream);
+                     nullptr, nullptr, ilqg_shared::g_scratch_state.ptr, active, stream);
   if (s != ILQG_OK) return s;
 #define CALL(TY_)                                                                                             \
   [&]() -> ilqg_status {                                                                                    \
     hipLaunchKernelGGL(costs_reduce_kernel<TY_>, dim3(batch), dim3(64), 0, (hipStream_t)stream, d,            \
-                       (const TY_*)g_scratch.ptr, (TY_*)costs, t_extreme, active);                              \
+                       (const TY_*)ilqg_shared::g_scratch_state.ptr, (TY_*)costs, t_extreme, active);                              \
     HIP_TRY(hipGetLastError());                                                                             \
     return ILQG_OK;                                                                                         \
   }()
@@ -1432,16 +1486,16 @@ ilqg_status ilqg_check_local_nash_batch(const ilqg_problem* p, int32_t batch, co
   const int moves = 1 + 2 * d.m * (d.T - 1);
   if (moves > 65535) return fail(ILQG_ERR_UNSUPPORTED, "too many perturbations for one launch");
   const size_t esz = p->desc.dtype == ILQG_F32 ? 4 : 8;
-  ilqg_status s = g_scratch.reserve(size_t(moves) * batch * d.N * esz);
+  ilqg_status s = Scratch().reserve(size_t(moves) * batch * d.N * esz);
   if (s != ILQG_OK) return s;
   // the reference switches the integrator to one-step Euler for this check (check_local_nash_equilibrium.cpp:75-79)
-  s = launch_strategy_costs(p, batch, x0, xs, us, P, alpha, max_perturbation, open_loop ? 1 : 0, 1, moves, g_scratch.ptr,
+  s = launch_strategy_costs(p, batch, x0, xs, us, P, alpha, max_perturbation, open_loop ? 1 : 0, 1, moves, ilqg_shared::g_scratch_state.ptr,
                             stream);
   if (s != ILQG_OK) return s;
 #define CALL(TY_)                                                                                                  \
   [&]() -> ilqg_status {                                                                                         \
     hipLaunchKernelGGL(nash_verdict_kernel<TY_>, dim3(batch), dim3(64), 0, (hipStream_t)stream, d,                 \
-                       (const TY_*)g_scratch.ptr, moves, batch, is_nash, (TY_*)margin);                            \
+                       (const TY_*)ilqg_shared::g_scratch_state.ptr, moves, batch, is_nash, (TY_*)margin);                            \
     HIP_TRY(hipGetLastError());                                                                                  \
     return ILQG_OK;                                                                                              \
   }()
@@ -1463,13 +1517,13 @@ ilqg_status ilqg_check_sufficient_nash_batch(const ilqg_problem* p, int32_t batc
   int chunk = int((size_t(256) << 20) / per_inst);
   if (chunk < 1) chunk = 1;
   if (chunk > batch) chunk = batch;
-  ilqg_status s = g_scratch.reserve(per_inst * chunk);
+  ilqg_status s = Scratch().reserve(per_inst * chunk);
   if (s != ILQG_OK) return s;
   hipLaunchKernelGGL(fill_int_kernel<int>, dim3((batch + 255) / 256), dim3(256), 0, (hipStream_t)stream, is_psd, 1, batch);
   HIP_TRY(hipGetLastError());
   for (int b0 = 0; b0 < batch; b0 += chunk) {
     const int nb = (batch - b0 < chunk) ? batch - b0 : chunk;
-    char* base = (char*)g_scratch.ptr;
+    char* base = (char*)ilqg_shared::g_scratch_state.ptr;
     char* Q = base;
     char* l = Q + size_t(nb) * d.T * d.N * d.n * d.n * esz;
     char* R = l + size_t(nb) * d.T * d.N * d.n * esz;

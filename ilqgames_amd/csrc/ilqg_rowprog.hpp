@@ -324,6 +324,10 @@ inline bool build_row_program(const DevProblem& d, const std::vector<DevTerm>& d
     }
   }
   if (NPS + max_lslots > 32000) { *err = "row program: too many slots"; return false; }
+  // rows_writeout_small streams l_i, R_ij, r_ij with one word per lane
+  for (int q = 0; q < pt.npairs; q++)
+    if (d.udim[pt.pj[q]] * d.udim[pt.pj[q]] > 64) { *err = "row program: a control block of more than 64 words"; return false; }
+  if (n > 64) { *err = "row program: more than 64 states"; return false; }
 
   // ---- flatten ----
   std::vector<int>& w = out->words;

@@ -643,6 +643,8 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const s
     // The sweep's forward pass (delta_xs, src/lq_feedback_solver.cpp:217-241) and ILQSolver::ExpectedDecrease
     // (:364-398), deferred to here: the first row wave runs them from the sweep's scratch rows while wave 0
     // integrates, before its first chunk overwrites the linearisation they read.
+    static_assert(W <= 2, "the deferred forward pass reads the linearisation on the first row wave while no other row wave "
+                          "may overwrite it yet: with more than one row wave set defer_forward = 0 or hold them back");
     if (s.ed_pending && rwave == 0) {
       LQArgs<T> fa{};
       fa.A = w + L.A;

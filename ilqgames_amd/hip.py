@@ -23,6 +23,7 @@ EXPORTS = [
     "ilqg_solution_splice_batch", "ilqg_solve_again_batch", "ilqg_strategy_costs_batch",
     "ilqg_check_local_nash_batch", "ilqg_check_sufficient_nash_batch",
     "ilqg_receding_horizon_shift_batch", "ilqg_default_solve_options", "ilqg_solve_batch_ex", "ilqg_solve_state_batch",
+    "ilqg_set_scratch",
 ]
 
 

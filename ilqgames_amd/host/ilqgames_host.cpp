@@ -537,10 +537,28 @@ size_t ElemBytes(ilqg_dtype dtype) { return dtype == ILQG_F32 ? 4 : 8; }
 // The bytes a device handle was built from: the POD part of the descriptor (pointers cleared) and the arrays it
 // points into.  Two descriptions with equal fingerprints build identical device tables.
 static std::string Fingerprint(const ProblemDescription& d) {
-  ilqg_problem_desc pod = d.desc;
-  pod.terms = nullptr;
-  pod.polyline_offsets = nullptr;
-  pod.polyline_points = nullptr;
+  // Field by field into zeroed storage: the struct has padding (after num_terms, num_polylines, T, dtype) whose bytes
+  // a plain copy leaves unspecified — a spurious mismatch would rebuild the device handle and drop the solver state
+  // carried between Solve() calls.
+  ilqg_problem_desc pod;
+  std::memset(&pod, 0, sizeof(pod));
+  pod.num_players = d.desc.num_players;
+  for (int i = 0; i < ILQG_MAX_PLAYERS; i++) {
+    pod.subsystems[i].kind = d.desc.subsystems[i].kind;
+    pod.subsystems[i].xdim = d.desc.subsystems[i].xdim;
+    pod.subsystems[i].udim = d.desc.subsystems[i].udim;
+    pod.subsystems[i].param0 = d.desc.subsystems[i].param0;
+    pod.player_costs[i].state_regularization = d.desc.player_costs[i].state_regularization;
+    pod.player_costs[i].control_regularization = d.desc.player_costs[i].control_regularization;
+    pod.player_costs[i].structure = d.desc.player_costs[i].structure;
+  }
+  pod.num_terms = d.desc.num_terms;
+  pod.num_polylines = d.desc.num_polylines;
+  pod.T = d.desc.T;
+  pod.dt = d.desc.dt;
+  pod.dtype = d.desc.dtype;
+  std::memcpy(&pod.params, &d.desc.params, sizeof(pod.params));  // 4-byte fields only: no padding
+  static_assert(sizeof(ilqg_solver_params) % 4 == 0 && sizeof(ilqg_cost_term) == 16 * 4, "packed 4-byte fields");
   std::string f(reinterpret_cast<const char*>(&pod), sizeof(pod));
   f.append(reinterpret_cast<const char*>(d.terms.data()), d.terms.size() * sizeof(ilqg_cost_term));
   f.append(reinterpret_cast<const char*>(d.polyline_offsets.data()), d.polyline_offsets.size() * sizeof(int32_t));
@@ -1387,7 +1405,11 @@ GameSolver::~GameSolver() {}
 // The device tables are built on the first Solve() and rebuilt when the Problem's costs / weights / polylines or the
 // SolverParams no longer flatten to what they were built from (a rebuilt handle starts like a new solver object).
 void GameSolver::RefreshDevice() {
-  if (device_ && !device_->Matches(*problem_, params_)) device_.reset();
+  if (device_ && !device_->Matches(*problem_, params_)) {
+    LOG(INFO) << "GameSolver: the problem or its SolverParams changed since the device tables were built; rebuilding "
+                 "them (the solver state carried between Solve() calls starts afresh).";
+    device_.reset();
+  }
   if (!device_) device_.reset(new host::DeviceSolve(*problem_, params_));
 }
 

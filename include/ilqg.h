@@ -30,6 +30,7 @@
 #ifndef ILQG_H_
 #define ILQG_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -280,7 +281,10 @@ ilqg_status ilqg_rollout_batch(const ilqg_problem* p, int32_t batch,
 
 /* Replaces ILQSolver::ComputeLinearization (src/ilq_solver.cpp:437-455) ->
  * ConcatenatedDynamicalSystem::Linearize (src/concatenated_dynamical_system.cpp:86-107).
- *  A [B][T][n*n], Bm [B][T][n*m]. */
+ *  A [B][T][n*n], Bm [B][T][n*m].
+ * The stage entry points (this one, ilqg_quadraticize_batch, ilqg_total_costs_batch, ilqg_rollout_batch) run the same
+ * compile-time-dimensioned kernels as the solves: a problem whose (n, N, m_i) is not among the library's
+ * instantiations, or whose players' control dimensions differ, gets ILQG_ERR_UNSUPPORTED here too. */
 ilqg_status ilqg_linearize_batch(const ilqg_problem* p, int32_t batch,
                                  const void* xs, const void* us, void* A,
                                  void* Bm, const int32_t* active, void* stream);
@@ -500,6 +504,14 @@ ilqg_status ilqg_selftest_mfma(int32_t dtype, const void* X, const void* Y, cons
 
 /* Last HIP / validation error text of the calling thread. */
 const char* ilqg_last_error(void);
+
+/* Scratch of the stand-alone stage entry points that take no workspace argument (ilqg_lq_feedback_batch /
+ * ilqg_lq_openloop_batch when delta_x or costates are asked for, ilqg_total_costs_batch, ilqg_check_*_nash_batch):
+ * by default the library keeps one grow-only device allocation per calling thread for them.  A caller that owns all
+ * device memory hands a buffer of its own here (per calling thread; NULL returns to the default): nothing is
+ * allocated afterwards, and a call that needs more than `bytes` fails with ILQG_ERR_INVALID and the size it needs in
+ * ilqg_last_error().  The solves (ilqg_*_solve_batch*) never touch this scratch: their memory is the workspace. */
+ilqg_status ilqg_set_scratch(void* device_buffer, size_t bytes);
 
 /* Library / device introspection (used by the loader to fail loudly). */
 #define ILQG_ABI_VERSION 3 /* 3: ilqg_solve_options / ilqg_solve_batch_ex / ilqg_solve_state_batch, ilqg_dims::sweep_formulation;
