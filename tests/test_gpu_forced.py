@@ -20,7 +20,8 @@ x that amplification x the conditioning of the Nash system).  The 
 fp32 is measured the same way: a pair is skipped for fp32 where the fp32 oracle's own P / alpha are further than
 2e-3 from the fp64 oracle's (more than half of fp32's digits gone in the reference arithmetic itself; two correct
 fp32 implementations — Householder QR of Lambda and the m x m form of it alike — then differ by as much).  Coverage is asserted: at least three
-quarters of the instances at the first iteration and 70 % of all (instance, iteration) pairs.
+quarters of the instances at the first iteration and 70 % of all (instance, iteration) pairs, and the number of pairs
+compared may not fall below the committed figure of tests/golden/forced_coverage.json (the skipped pairs are printed).
 """
 import numpy as np
 import pytest
@@ -64,9 +65,8 @@ def _inst_err(a, b, keys):
     return max(rel_err(a[ka], b[kb]) for ka, kb in keys)
 
 
-@pytest.mark.parametrize("scene", SCENES)
-@pytest.mark.parametrize("dtype", [abi.F64, abi.F32])
-def test_every_instance_matches_after_every_iteration(hip, oracle, scene, dtype):
+def forced_case(oracle, scene):
+    """Inputs of one scene: (spec, B, x0, oracle problem, forced steps, nudged x0).  Oracle only (CPU)."""
     spec = examples.CONFIGS[scene]()
     B = 12
     rng = np.random.default_rng(100 + SCENES.index(scene))
@@ -74,15 +74,47 @@ def test_every_instance_matches_after_every_iteration(hip, oracle, scene, dtype)
     op = oracle.OracleProblem(spec)
     free = op.solve(abi.F64, x0, merit_log_len=K)
     steps = _forced_steps(rng, free["log"], float(spec.params.initial_alpha_scaling))
+    x0_nudged = x0 + 1e-12 * rng.standard_normal(x0.shape)
+    return spec, B, x0, op, steps, x0_nudged
+
+
+def conditioning(op, x0, x0_nudged, steps, k, dtype, ref, B):
+    """Which instances are compared after iteration k (see the module docstring), from oracle runs alone:
+    returns (mask [B], amplification [B])."""
+    f64 = dtype == abi.F64
+    amp_limit, lost32 = 1e-8, 2e-3
+    r64 = ref if f64 else op.solve(abi.F64, x0, fixed_iters=k, forced_steps=steps[:, :k])
+    r64n = op.solve(abi.F64, x0_nudged, fixed_iters=k, forced_steps=steps[:, :k])
+    merit_ref = ref["log"][:, k - 1, 0]
+    mask, amps = np.zeros(B, dtype=bool), np.zeros(B)
+    for b in range(B):
+        one = lambda d: {q: v[b] for q, v in d.items() if hasattr(v, "shape") and v.shape[:1] == (B,)}  # noqa: E731
+        amp = _inst_err(one(r64n), one(r64), (("xs", "xs"), ("us", "us"), ("rawP", "rawP"), ("alpha", "alpha")))
+        amps[b] = amp
+        ok = amp <= amp_limit and np.isfinite(merit_ref[b])
+        if ok and not f64 and _inst_err(one(ref), one(r64), (("rawP", "rawP"), ("alpha", "alpha"))) > lost32:
+            ok = False  # the fp32 reference arithmetic itself has lost more than half its digits here
+        mask[b] = ok
+    return mask, amps
+
+
+def committed_coverage():
+    import json
+    import os
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "forced_coverage.json")))
+
+
+@pytest.mark.parametrize("scene", SCENES)
+@pytest.mark.parametrize("dtype", [abi.F64, abi.F32])
+def test_every_instance_matches_after_every_iteration(hip, oracle, scene, dtype):
+    spec, B, x0, op, steps, x0_nudged = forced_case(oracle, scene)
     assert steps.min() < 0.02 * steps.max(), "the forced steps should reach deep into a line search"
     first = 0
-    x0_nudged = x0 + 1e-12 * rng.standard_normal(x0.shape)
     prob = hip.Problem(spec, dtype)
     f64 = dtype == abi.F64
     tol_op, tol_st = (1e-9, 1e-9) if f64 else (2e-3, 1e-2)
-    amp_limit = 1e-8
-    lost32 = 2e-3
     compared = 0
+    skipped = []
     for k in range(1, K + 1):
         ref = op.solve(dtype, x0, fixed_iters=k, forced_steps=steps[:, :k], merit_log_len=k)
         out = prob.solve(x0, fixed_iters=k, forced_steps=steps[:, :k])
@@ -90,17 +122,14 @@ def test_every_instance_matches_after_every_iteration(hip, oracle, scene, dtype)
         assert np.array_equal(_np(out["iters"]), ref["iters"]) and np.all(ref["iters"] == k)
         assert np.all(_np(out["status"]) == 1) and np.all(ref["status"] == 1)
         # how much this (instance, iteration) amplifies a 1e-12 nudge of x0, measured on the fp64 oracle
-        r64 = ref if f64 else op.solve(abi.F64, x0, fixed_iters=k, forced_steps=steps[:, :k])
-        r64n = op.solve(abi.F64, x0_nudged, fixed_iters=k, forced_steps=steps[:, :k])
+        mask, amps = conditioning(op, x0, x0_nudged, steps, k, dtype, ref, B)
         merit_ref, ed_ref, step_ref = ref["log"][:, k - 1, 0], ref["log"][:, k - 1, 1], ref["log"][:, k - 1, 2]
         dev = {q: _np(out[q]) for q in ("xs", "us", "P", "alpha", "costs")}
         for b in range(B):  # every instance on its own scale: a batch-wide max-norm would hide the small ones
-            one = lambda d: {q: v[b] for q, v in d.items() if hasattr(v, "shape") and v.shape[:1] == (B,)}  # noqa: E731
-            amp = _inst_err(one(r64n), one(r64), (("xs", "xs"), ("us", "us"), ("rawP", "rawP"), ("alpha", "alpha")))
-            if not (amp <= amp_limit and np.isfinite(merit_ref[b])):
+            amp = amps[b]
+            if not mask[b]:
+                skipped.append((k, b))
                 continue
-            if not f64 and _inst_err(one(ref), one(r64), (("rawP", "rawP"), ("alpha", "alpha"))) > lost32:
-                continue  # the fp32 reference arithmetic itself has lost more than half its digits here
             compared += 1
             first += k == 1
             where = "%s k=%d instance %d (amplification of 1e-12: %.1e)" % (scene, k, b, amp)
@@ -117,6 +146,15 @@ def test_every_instance_matches_after_every_iteration(hip, oracle, scene, dtype)
             assert abs(_np(st["last_merit"])[b] - merit_ref[b]) <= tol_op * max(1.0, abs(merit_ref[b])), where
             assert abs(_np(st["expected_decrease"])[b] - ed_ref[b]) <= tol_st * max(1.0, abs(ed_ref[b])), where
             assert abs(_np(st["step"])[b] - step_ref[b]) <= 1e-6 * step_ref[b], where
+    # Coverage: printed (pytest -s / the captured output of a failure), held against the committed figure — the mask
+    # comes from oracle runs alone (tests/golden/make_forced_coverage.py computes it on the CPU), so a pair that drops
+    # out is a change of the oracle or of the scene, not of the device; two pairs of slack for a host whose libm /
+    # vectorisation moves a borderline amplification across 1e-8.
+    want = committed_coverage()["%s:%s" % (scene, "f64" if f64 else "f32")]
+    print("forced-step coverage %s %s: compared %d of %d (instance, iteration) pairs (committed: %d); skipped (k, instance): %s"
+          % (scene, "f64" if f64 else "f32", compared, B * K, want["compared"], skipped))
+    assert compared >= want["compared"] - 2, "coverage fell from the committed %d to %d pairs; skipped: %s" % (
+        want["compared"], compared, skipped)
     assert first >= 0.75 * B, "only %d of %d instances were well-conditioned at their first iteration" % (first, B)
     assert compared >= 0.7 * B * K, "only %d of %d (instance, iteration) pairs were well-conditioned" % (compared, B * K)
 
