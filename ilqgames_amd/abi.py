@@ -49,7 +49,7 @@ class SolveOptions(C.Structure):
     _fields_ = [("fixed_iters", C.c_int32), ("augmented_lagrangian", C.c_int32), ("resume", C.c_int32),
                 ("reserved0", C.c_int32), ("active", C.c_void_p), ("forced_steps", C.c_void_p),
                 ("split_trial", C.c_int32), ("handoff", C.c_int32), ("probe", C.c_int32), ("counted", C.c_int32),
-                ("compact_rows", C.c_int32), ("reserved", C.c_int32 * 5)]
+                ("compact_rows", C.c_int32), ("round_bursts", C.c_int32), ("reserved", C.c_int32 * 4)]
 
 
 class Subsystem(C.Structure):

@@ -746,7 +746,28 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   }
   sa.first = resume ? 2 : 1;
   int waiting_lq = 0, waiting_exit = 0;  // split passes: instances already through this iteration's line search
+  // Free-running solves: the kernels select their instances by the stage each one is in, so a round launched for
+  // nobody is harmless — the host therefore enqueues BURSTS of whole rounds (trial, exit, sweep) and reads the
+  // counters back once per burst instead of once per round (a read-back is a stream synchronisation: ~20-30 us against
+  // a ~0.45 ms round of a single instance).  The burst doubles up to eight rounds while no instance is back-tracking
+  // and falls back to one as soon as one is (those go through the probing passes, which need the lists every round).
+  const bool bursts = counted && !split && !kProfile && choice(opt.round_bursts, true);
+  int burst = 1;
   for (long long round = 0;; round++) {
+    if (bursts && !sa.ids) {
+      for (int q = 1; q < burst; q++) {  // rounds without a read-back
+        HIP_TRY(hipMemsetAsync(p->d_unfinished, 0, 4 * sizeof(int), stream));
+        sa.ids_next = handoff ? pass_ids + size_t(list) * batch : nullptr;
+        hipLaunchKernelGGL(k_trial, dim3(batch), dim3(64 * W), lds_trial, stream, d, sa);
+        HIP_TRY(hipGetLastError());
+        sa.first = 0;
+        hipLaunchKernelGGL(k_exit, dim3(batch), dim3(64), lds_exit, stream, d, sa);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(k_lq, dim3(batch), dim3(nt_lq), lds_lq, stream, d, sa);
+        HIP_TRY(hipGetLastError());
+        round++;
+      }
+    }
     if (counted) HIP_TRY(hipMemsetAsync(p->d_unfinished, 0, 4 * sizeof(int), stream));
     if (split || sa.ids) {  // a split pass: the whole batch (split mode) or the listed back-tracking instances
       sa.ids_next = pass_ids + size_t(list) * batch;
@@ -798,6 +819,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
         waiting_lq += want_lq;
         waiting_exit += want_exit;
         if (again) {  // the next round covers the listed instances only
+          burst = 1;
           if (round > cap) return fail(ILQG_ERR_HIP, "solve did not terminate within its iteration bound");
           sa.ids = sa.ids_next;
           round_instances = again;
@@ -811,6 +833,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
         want_exit = waiting_exit;
         waiting_lq = waiting_exit = 0;
       }
+      if (bursts) burst = again ? 1 : (burst < 8 ? burst * 2 : 8);
     } else if (round == fixed_iters) {
       want_lq = 0;
       want_exit = 1;

@@ -198,7 +198,7 @@ class Problem:
                     ws=torch.empty(self.workspace_bytes(batch), dtype=torch.uint8, device="cuda"))
 
     def solve(self, x0, bufs=None, fixed_iters=0, augmented_lagrangian=False, forced_steps=None, split_trial=None,
-              handoff=None, probe=None, counted=None, resume=False, active=None, compact_rows=None):
+              handoff=None, probe=None, counted=None, resume=False, active=None, compact_rows=None, round_bursts=None):
         """ilqg_solve_batch_ex. `bufs` (from alloc_solve_buffers) carries the warm start in and the solution out; zero
         warm start if omitted.  forced_steps [B][fixed_iters]: test mode, the given step sizes instead of the line
         search.  split_trial / handoff / probe / counted / compact_rows: None = let the library choose, True / False = force the
@@ -221,6 +221,7 @@ class Problem:
         tri = lambda v: abi.CHOICE_AUTO if v is None else (abi.CHOICE_ON if v else abi.CHOICE_OFF)  # noqa: E731
         o.split_trial, o.handoff, o.probe, o.counted = tri(split_trial), tri(handoff), tri(probe), tri(counted)
         o.compact_rows = tri(compact_rows)
+        o.round_bursts = tri(round_bursts)
         _check(lib().ilqg_solve_batch_ex(self.h, B, _ptr(x0), _ptr(bufs["xs"]), _ptr(bufs["us"]), _ptr(bufs["P"]),
                                          _ptr(bufs["alpha"]), _ptr(bufs["costs"]), _ptr(bufs["iters"]),
                                          _ptr(bufs["status"]), _ptr(bufs["converged"]), _ptr(bufs["ws"]), C.byref(o),

@@ -359,7 +359,8 @@ typedef struct {
   int32_t probe;                /* ilqg_choice: speculative line search over the next step sizes of listed instances */
   int32_t counted;              /* ilqg_choice: host counts the rounds of a fixed-iteration solve as well           */
   int32_t compact_rows;         /* ilqg_choice: the row stage hands the sweep only the touched words of [Q|l|R|r]   */
-  int32_t reserved[5];
+  int32_t round_bursts;         /* ilqg_choice: free-running solves read their counters back once per burst of rounds */
+  int32_t reserved[4];
 } ilqg_solve_options;
 void ilqg_default_solve_options(ilqg_solve_options* o);
 
