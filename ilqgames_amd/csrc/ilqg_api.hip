@@ -74,18 +74,21 @@ struct ScratchState {
   size_t bytes = 0;
   bool caller_owned = false;
 };
-#if defined(ILQG_PART_NX)
-extern thread_local ScratchState g_scratch_state;
-#else
-thread_local ScratchState g_scratch_state;  // one per calling thread, shared by the library's translation units
+// One per calling thread, shared by the library's translation units — through an accessor: an `extern thread_local` of a
+// constant-initialised class type makes the other units call a TLS init function that the defining unit never emits.
+ScratchState& scratch_state();
+#if !defined(ILQG_PART_NX)
+ScratchState& scratch_state() {
+  static thread_local ScratchState st;
+  return st;
+}
 #endif
 }  // namespace ilqg_shared
 
 namespace {
 struct Scratch {  // this unit's view of the shared state
-  void*& ptr = ilqg_shared::g_scratch_state.ptr;
   ilqg_status reserve(size_t need) {
-    ilqg_shared::ScratchState& st = ilqg_shared::g_scratch_state;
+    ilqg_shared::ScratchState& st = ilqg_shared::scratch_state();
     if (need <= st.bytes) return ILQG_OK;
     if (st.caller_owned)
       return fail(ILQG_ERR_INVALID, "the scratch buffer given to ilqg_set_scratch is too small: this call needs " +
@@ -294,9 +297,10 @@ struct TrialWaves {
 };
 
 // Trial kernel: rollout + linearise/quadraticise + line-search decision (ilqg_solve.hpp).  The second
-// launch-bound argument is the number of waves per SIMD the register allocation must allow.
+// launch-bound argument is the number of waves per SIMD the register allocation must allow (fp32: three, i.e. 168
+// registers — six instances per CU at large batches; the fp32 kernel sits within a few registers of that either way).
 template <typename T, int NX, int NP, int MU, int W>
-__global__ void __launch_bounds__(64 * W, W) ilq_trial_kernel(DevProblem p, SolveArgs<T> sa) {
+__global__ void __launch_bounds__(64 * W, (sizeof(T) == 4 && W == 2) ? 3 : W) ilq_trial_kernel(DevProblem p, SolveArgs<T> sa) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int b = blockIdx.x;
   if (!sa.first) {  // instances that are done (or waiting for the LQ kernel) leave without touching LDS
@@ -531,7 +535,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::lq(const ilqg_dims* d, const PairTable& p
     const size_t need = size_t(d->batch) * d->T * (NP * (NX + 1) + NX) * sizeof(T);
     ilqg_status s = Scratch().reserve(need);
     if (s != ILQG_OK) return s;
-    g.scratch = (T*)ilqg_shared::g_scratch_state.ptr;
+    g.scratch = (T*)ilqg_shared::scratch_state().ptr;
   }
   g.T_steps = d->T;
   g.adaptive = d->adaptive_regularization;
@@ -563,7 +567,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::lq_openloop(const ilqg_dims* d, const Pai
   const size_t need = size_t(d->batch) * d->T * (costates ? O::ROW_FAT : O::ROW) * sizeof(T);
   ilqg_status s = Scratch().reserve(need);
   if (s != ILQG_OK) return s;
-  g.scratch = (T*)ilqg_shared::g_scratch_state.ptr;
+  g.scratch = (T*)ilqg_shared::scratch_state().ptr;
   g.T_steps = d->T;
   g.adaptive = 0;
   g.batch = d->batch;
@@ -892,7 +896,7 @@ extern "C" {
 const char* ilqg_last_error(void) { return g_err.c_str(); }
 
 ilqg_status ilqg_set_scratch(void* device_buffer, size_t bytes) {
-  ilqg_shared::ScratchState& st = ilqg_shared::g_scratch_state;
+  ilqg_shared::ScratchState& st = ilqg_shared::scratch_state();
   if (st.ptr && !st.caller_owned) (void)hipFree(st.ptr);
   st.ptr = device_buffer;
   st.bytes = device_buffer ? bytes : 0;
@@ -988,7 +992,7 @@ ilqg_status ilqg_lq_feedback_batch(const ilqg_dims* d, const void* A, const void
     cd.uoff[0] = 0;
     for (int i = 0; i < N; i++) cd.uoff[i + 1] = cd.uoff[i] + d->udim[i];
     const size_t lds = costates_lds_elems(d->n, N) * elem;
-    void* zs = ilqg_shared::g_scratch_state.ptr;
+    void* zs = ilqg_shared::scratch_state().ptr;
     if (d->dtype == ILQG_F32) {
       auto kern = lq_feedback_costates_kernel<float>;
       raise_lds_limit((const void*)kern, lds);
@@ -1330,12 +1334,12 @@ ilqg_status ilqg_total_costs_batch(const ilqg_problem* p, int32_t batch, const v
   ilqg_status s = Scratch().reserve(size_t(batch) * d.T * d.N * esz);
   if (s != ILQG_OK) return s;
   s = launch_linquad(p, batch, xs, us, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                     nullptr, nullptr, ilqg_shared::g_scratch_state.ptr, active, stream);
+                     nullptr, nullptr, ilqg_shared::scratch_state().ptr, active, stream);
   if (s != ILQG_OK) return s;
 #define CALL(TY_)                                                                                             \
   [&]() -> ilqg_status {                                                                                    \
     hipLaunchKernelGGL(costs_reduce_kernel<TY_>, dim3(batch), dim3(64), 0, (hipStream_t)stream, d,            \
-                       (const TY_*)ilqg_shared::g_scratch_state.ptr, (TY_*)costs, t_extreme, active);                              \
+                       (const TY_*)ilqg_shared::scratch_state().ptr, (TY_*)costs, t_extreme, active);                              \
     HIP_TRY(hipGetLastError());                                                                             \
     return ILQG_OK;                                                                                         \
   }()
@@ -1512,13 +1516,13 @@ ilqg_status ilqg_check_local_nash_batch(const ilqg_problem* p, int32_t batch, co
   ilqg_status s = Scratch().reserve(size_t(moves) * batch * d.N * esz);
   if (s != ILQG_OK) return s;
   // the reference switches the integrator to one-step Euler for this check (check_local_nash_equilibrium.cpp:75-79)
-  s = launch_strategy_costs(p, batch, x0, xs, us, P, alpha, max_perturbation, open_loop ? 1 : 0, 1, moves, ilqg_shared::g_scratch_state.ptr,
+  s = launch_strategy_costs(p, batch, x0, xs, us, P, alpha, max_perturbation, open_loop ? 1 : 0, 1, moves, ilqg_shared::scratch_state().ptr,
                             stream);
   if (s != ILQG_OK) return s;
 #define CALL(TY_)                                                                                                  \
   [&]() -> ilqg_status {                                                                                         \
     hipLaunchKernelGGL(nash_verdict_kernel<TY_>, dim3(batch), dim3(64), 0, (hipStream_t)stream, d,                 \
-                       (const TY_*)ilqg_shared::g_scratch_state.ptr, moves, batch, is_nash, (TY_*)margin);                            \
+                       (const TY_*)ilqg_shared::scratch_state().ptr, moves, batch, is_nash, (TY_*)margin);                            \
     HIP_TRY(hipGetLastError());                                                                                  \
     return ILQG_OK;                                                                                              \
   }()
@@ -1546,7 +1550,7 @@ ilqg_status ilqg_check_sufficient_nash_batch(const ilqg_problem* p, int32_t batc
   HIP_TRY(hipGetLastError());
   for (int b0 = 0; b0 < batch; b0 += chunk) {
     const int nb = (batch - b0 < chunk) ? batch - b0 : chunk;
-    char* base = (char*)ilqg_shared::g_scratch_state.ptr;
+    char* base = (char*)ilqg_shared::scratch_state().ptr;
     char* Q = base;
     char* l = Q + size_t(nb) * d.T * d.N * d.n * d.n * esz;
     char* R = l + size_t(nb) * d.T * d.N * d.n * esz;

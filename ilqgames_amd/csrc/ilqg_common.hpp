@@ -104,12 +104,15 @@ struct DevProblem {
 
 // arrays of a time step's image, as the row program's regions and the compact rows name them
 enum { RA_A = 0, RA_B = 1, RA_Q = 2, RA_L = 3, RA_R = 4, RA_r = 5 };
-// Compact rows (the solve's own interchange between this stage and the one-tile sweep, ilqg_lq.hpp): of a time step's
-// [Q_i | l_i | R_ij | r_ij] only the words some term can touch vary — a player pass's pass-local slots — so the stage
-// writes those, pass after pass ("compact row" of RC_W words), and the sweep scatters them over a constant background
-// in its LDS image.  Block at RP_OFF_COMPACT: [RC_W, RC_NBG, base of player 0 .. N-1 | destination of each word |
-// (destination, value) of each non-zero constant].  A destination is array << 24 | offset inside the array's row.
+// Compact rows (the solve's own interchange between the row stage, ilqg_rows.hpp, and the one-tile sweep + forward pass,
+// ilqg_lq.hpp): of a time step's [A | B | Q_i | l_i | R_ij | r_ij] only the words a Jacobian or a cost term can touch vary
+// — the pass-local slots of the row program's passes — so the stage writes those, pass after pass ("compact row" of
+// RC_W words), and the consumers scatter them over a constant background in their LDS images.  Block at RP_OFF_COMPACT:
+// [RC_W, RC_NBG, base of the Jacobian pass, of player 0 .. N-1 | destination of each word | (destination, kind, value)
+// of each non-zero constant].  A destination is array << 24 | offset inside the array's row; a constant's kind is
+// RC_LITERAL (the float `value`), RC_DT or RC_NEG_DT (the time step, in the problem's precision).
 enum { RC_W = 0, RC_NBG = 1, RC_BASE = 2 };
+enum { RC_LITERAL = 0, RC_DT = 1, RC_NEG_DT = 2, RC_BG_WORDS = 3 };
 constexpr int kCompactMaxWords = 192;  // three words per lane of the scattering wave
 
 constexpr int kSegStride = 21;
@@ -117,6 +120,15 @@ constexpr int kSegStride = 21;
 template <typename T> __device__ __forceinline__ const T* problem_segs(const DevProblem& p);
 template <> __device__ __forceinline__ const float* problem_segs<float>(const DevProblem& p) { return p.segs_f; }
 template <> __device__ __forceinline__ const double* problem_segs<double>(const DevProblem& p) { return p.segs_d; }
+
+// user priority 0..3 of the calling wave (s_setprio takes an immediate)
+__device__ __forceinline__ void set_wave_prio(int pr) {
+  pr &= 3;
+  if (pr == 0) __builtin_amdgcn_s_setprio(0);
+  else if (pr == 1) __builtin_amdgcn_s_setprio(1);
+  else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+  else __builtin_amdgcn_s_setprio(3);
+}
 
 template <typename T>
 __device__ __forceinline__ T sgn(T x) {

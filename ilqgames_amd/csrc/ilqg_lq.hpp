@@ -42,6 +42,7 @@ struct LQArgs {
   long long* ph = nullptr;          // optional: 8 shader-clock accumulators per instance (phase profile)
   const T* compact = nullptr;       // [T][compact_tab[RC_W]] compact rows of [Q | l | R | r] (ilqg_common.hpp) instead of the
   const int* compact_tab = nullptr; // dense arrays: the one-tile player-parallel sweep only; compact_tab = the row program's block
+  double dt = 0.0;                  // the time step (a constant of the compact rows' background)
   int prio_div = 0;                 // > 0: rotate the wave priority every step, phase = blockIdx.x / prio_div (see the sweep)
   long long* tl = nullptr;          // optional: timeline stamps (ilqg_common.hpp, -DILQG_TIMELINE=1)
   int tl_b = 0;
@@ -325,7 +326,9 @@ __device__ __forceinline__ void lu_pp_solve_columns(T (&col)[M], int lane, T (&x
 //   * a step's operands (row t of A_k, delta_x_k, Q_i l_i) are requested together and waited for once;
 //   * delta_x is double-buffered in LDS: one wave-level sync per step;
 //   * ExpectedDecrease takes its terms from lanes 0 .. NP-1 through v_readlane, in the reference's order, beside the chain.
-template <typename T, int NX, int NP, int MU, int LDSE>
+// CMP: A_k comes from compact rows (LQArgs::compact) — compile-time, so that each form holds only its own prefetch
+// registers (the trial kernel that hosts this pass is at its register limit in both precisions).
+template <typename T, int NX, int NP, int MU, int LDSE, bool CMP>
 __device__ __forceinline__ void lq_forward_pass_wave(const LQArgs<T>& a, T* sm, int t) {
   using C = LQCfg<T, NX, NP, MU>;
   constexpr int SCR = C::SCR;
@@ -335,32 +338,76 @@ __device__ __forceinline__ void lq_forward_pass_wave(const LQArgs<T>& a, T* sm, 
   static_assert(2 * G * FSLOT + 2 * NX <= LDSE, "forward-pass staging does not fit the LDS it is given");
   constexpr int ROW = NX * NX + SCR;           // elements of one step's image
   constexpr int PER = (ROW + 63) / 64;         // loads per lane and step
+  constexpr int SQ = (SCR + 63) / 64;          // ... of which the scratch row's, when A comes from compact rows
   const int Tn = a.T_steps;
   T* sX = sm + 2 * G * FSLOT;                  // delta_x, two buffers of NX
   const T* gA = uniform_ptr(a.A);
   const T* gS = uniform_ptr(a.scratch);
-  T pre[G][PER];
+  // Compact rows (LQArgs::compact): A_k is a constant background — written into every staging slot once — plus the
+  // Jacobian pass's words of the step's compact row (lane = word; the words that belong to B are skipped).
+  constexpr bool cmp = CMP;
+  const T* gC = uniform_ptr(a.compact);
+  const int CWD = cmp ? a.compact_tab[RC_W] : 0;
+  int nJ = 0, cbase = 0, cdstA = -1;
+  if (cmp) {
+    constexpr int NPB = NP + 1;  // bases: the Jacobian pass, then the players
+    cbase = a.compact_tab[RC_BASE];
+    nJ = a.compact_tab[RC_BASE + 1] - cbase;
+    if (nJ > 64) nJ = 64;  // (the Jacobian pass of these games has 2 .. 6 words per subsystem)
+    if (t < nJ) {
+      const int code = a.compact_tab[RC_BASE + NPB + cbase + t];
+      cdstA = (code >> 24) == RA_A ? (code & 0xffffff) : -1;
+    }
+    for (int e = t; e < 2 * G * FSLOT; e += 64) sm[e] = T(0);
+    lds_sync(true);
+    const int nbg = a.compact_tab[RC_NBG];
+    const int* bg = a.compact_tab + RC_BASE + NPB + CWD;
+    for (int e = t; e < nbg; e += 64) {
+      const int code = bg[RC_BG_WORDS * e], kind = bg[RC_BG_WORDS * e + 1];
+      if ((code >> 24) != RA_A) continue;
+      const T v = kind == RC_DT ? T(a.dt) : (kind == RC_NEG_DT ? T(-a.dt) : T(__int_as_float(bg[RC_BG_WORDS * e + 2])));
+      for (int sl = 0; sl < 2 * G; sl++) sm[sl * FSLOT + (code & 0xffffff)] = v;
+    }
+    lds_sync(true);
+  }
+  T pre[G][CMP ? 1 + SQ : PER];
   auto fetch_group = [&](int grp) {
 #pragma unroll
     for (int s = 0; s < G; s++) {
       const int k = grp * G + s;
+      if constexpr (cmp) {
+        // [0]: this lane's word of the Jacobian pass, [1]: its word of the scratch row
+        pre[s][0] = (k < Tn && t < nJ) ? gC[size_t(k) * CWD + cbase + t] : T(0);
 #pragma unroll
-      for (int q = 0; q < PER; q++) {
-        const int e = q * 64 + t;
-        const bool inA = e < NX * NX;
-        const T* src = inA ? gA + (size_t(k) * NX * NX + e) : gS + (size_t(k) * SCR + (e - NX * NX));
-        pre[s][q] = (k < Tn && e < ROW) ? *src : T(0);
+        for (int q = 0; q < SQ; q++) pre[s][1 + q] = (k < Tn && q * 64 + t < SCR) ? gS[size_t(k) * SCR + q * 64 + t] : T(0);
+      } else {
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+          const int e = q * 64 + t;
+          const bool inA = e < NX * NX;
+          const T* src = inA ? gA + (size_t(k) * NX * NX + e) : gS + (size_t(k) * SCR + (e - NX * NX));
+          pre[s][q] = (k < Tn && e < ROW) ? *src : T(0);
+        }
       }
     }
   };
   auto commit_group = [&](int which) {
 #pragma unroll
-    for (int s = 0; s < G; s++)
+    for (int s = 0; s < G; s++) {
+      if constexpr (cmp) {
+        T* slot = sm + (which * G + s) * FSLOT;
+        if (cdstA >= 0) slot[cdstA] = pre[s][0];
 #pragma unroll
-      for (int q = 0; q < PER; q++) {
-        const int e = q * 64 + t;
-        if (e < ROW) sm[(which * G + s) * FSLOT + e] = pre[s][q];
+        for (int q = 0; q < SQ; q++)
+          if (q * 64 + t < SCR) slot[NX * NX + q * 64 + t] = pre[s][1 + q];
+      } else {
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+          const int e = q * 64 + t;
+          if (e < ROW) sm[(which * G + s) * FSLOT + e] = pre[s][q];
+        }
       }
+    }
   };
   fetch_group(0);
   if (t < NX) sX[t] = a.x0 ? a.x0[t] : T(0);
@@ -422,7 +469,10 @@ template <typename T, int NX, int NP, int MU, int NT = LQCfg<T, NX, NP, MU>::NT,
 __device__ __forceinline__ void lq_forward_pass_body(const LQArgs<T>& a, T* sm, int t) {
   using C = LQCfg<T, NX, NP, MU>;
   if constexpr (NT == 64) {
-    lq_forward_pass_wave<T, NX, NP, MU, LDSE>(a, sm, t);
+    if (a.compact)
+      lq_forward_pass_wave<T, NX, NP, MU, LDSE, true>(a, sm, t);
+    else
+      lq_forward_pass_wave<T, NX, NP, MU, LDSE, false>(a, sm, t);
     return;
   }
   constexpr int SCR = C::SCR, S = int(sizeof(T));
@@ -936,8 +986,8 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
     }
   };
 
-  // Compact rows (LQArgs::compact): the dense A, B tiles are DMA'd as above; the touched words of [Q | l | R | r] arrive as
-  // one short row that a wave scatters over the image's constant background (written once, below).  The row of step
+  // Compact rows (LQArgs::compact): nothing dense is read; the touched words of [A | B | Q | l | R | r] arrive as one
+  // short row that a wave scatters over the image's constant background (written once, below).  The row of step
   // k - 2 is DMA'd into a staging row while step k runs and scattered into the image of step k - 1 ... one step later.
   const bool cmp = a.compact != nullptr;
   T* const sSB = sm + W::oSB;
@@ -948,6 +998,10 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
       const int col = wd / NX, row = wd - col * NX;
       return W::oTQ + i * W::TILE + row + LD * col;
     }
+    if (arr == RA_A || arr == RA_B) {
+      const int col = off / NX, row = off - col * NX;
+      return (arr == RA_A ? W::oTA : W::oTB) + row + LD * col;
+    }
     return (arr == RA_L ? W::oVl : (arr == RA_R ? W::oVR : W::oVr)) + off;
   };
   const int CWD = cmp ? a.compact_tab[RC_W] : 0;
@@ -956,13 +1010,9 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
   auto stage_c = [&](int k, int which, int slot, int nslots) {
     T* dst = sm + which * W::IMG;
 #pragma unroll
-    for (int job = 0; job < 4; job++) {
+    for (int job = 2; job < 4; job++) {
       if (job % nslots != slot) continue;
-      if (job == 0) {
-        dma_tile<T, NX, W::LD, W::PS, W::WAVE_INSTRS>(a.A + size_t(k) * NX * NX, dst + W::oTA, NX, NX, lane);
-      } else if (job == 1) {
-        dma_tile<T, NX, W::LD, W::PS, W::WAVE_INSTRS>(a.Bm + size_t(k) * NX * M, dst + W::oTB, NX, M, lane);
-      } else if (job == 2) {
+      if (job == 2) {
         const T* row = sSB + (k & 1) * kCompactMaxWords;
         T v[3];
         int cd[3];
@@ -982,9 +1032,7 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
   // the same for a step whose compact row is not staged yet (before the loop): straight from global memory
   auto stage_c_sync = [&](int k, int which) {
     T* dst = sm + which * W::IMG;
-    if (w == 0) dma_tile<T, NX, W::LD, W::PS, W::WAVE_INSTRS>(a.A + size_t(k) * NX * NX, dst + W::oTA, NX, NX, lane);
-    if (w == NP - 1) dma_tile<T, NX, W::LD, W::PS, W::WAVE_INSTRS>(a.Bm + size_t(k) * NX * M, dst + W::oTB, NX, M, lane);
-    for (int c = t; c < CWD; c += NT) dst[cdecode(a.compact_tab[RC_BASE + NP + c])] = a.compact[size_t(k) * CWD + c];
+    for (int c = t; c < CWD; c += NT) dst[cdecode(a.compact_tab[RC_BASE + NP + 1 + c])] = a.compact[size_t(k) * CWD + c];
   };
 
   // (Q_i l_i) of the staged step -> scratch, for ExpectedDecrease
@@ -1005,14 +1053,15 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
   __syncthreads();
 
   if (cmp) {
-    for (int c = t; c < kCompactMaxWords; c += NT) sCD[c] = c < CWD ? cdecode(a.compact_tab[RC_BASE + NP + c]) : -1;
+    for (int c = t; c < kCompactMaxWords; c += NT) sCD[c] = c < CWD ? cdecode(a.compact_tab[RC_BASE + NP + 1 + c]) : -1;
   }
-  if (cmp) {  // the images' constants that are not zero (untouched diagonal entries of Q_i: sigma_x)
+  if (cmp) {  // the images' constants that are not zero (the identity and the dt entries of A, B; untouched diagonal entries of Q_i)
     const int nbg = a.compact_tab[RC_NBG];
-    const int* bg = a.compact_tab + RC_BASE + NP + CWD;
+    const int* bg = a.compact_tab + RC_BASE + NP + 1 + CWD;
     for (int e = t; e < nbg; e += NT) {
-      const int off = cdecode(bg[2 * e]);
-      const T v = T(__int_as_float(bg[2 * e + 1]));
+      const int off = cdecode(bg[RC_BG_WORDS * e]);
+      const int kind = bg[RC_BG_WORDS * e + 1];
+      const T v = kind == RC_DT ? T(a.dt) : (kind == RC_NEG_DT ? T(-a.dt) : T(__int_as_float(bg[RC_BG_WORDS * e + 2])));
       sm[off] = v;
       sm[W::IMG + off] = v;
     }
@@ -1075,11 +1124,7 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
       // last one does (measured, B = 1024 fp64: finishing times 356 / 386 / 428 / 465 us in arrival order).  Rotating
       // the user priority with the step index shares the delay out: every instance ends within 10 us of 430 us.
       // Only when the whole batch is resident at once (prio_div = CUs: blocks b, b + CUs, ... share a CU).
-      const int pr = (k + int(blockIdx.x) / a.prio_div) & 3;
-      if (pr == 0) __builtin_amdgcn_s_setprio(0);
-      else if (pr == 1) __builtin_amdgcn_s_setprio(1);
-      else if (pr == 2) __builtin_amdgcn_s_setprio(2);
-      else __builtin_amdgcn_s_setprio(3);
+      set_wave_prio(k + int(blockIdx.x) / a.prio_div);
     }
     long long pc0 = (kProfile && a.ph) ? clock64() : 0, pc1;
 #define ILQG_PH(i) do { if (kProfile && a.ph) { __builtin_amdgcn_sched_barrier(0); pc1 = clock64(); __builtin_amdgcn_sched_barrier(0); phacc[i] += pc1 - pc0; pc0 = pc1; } } while (0)

@@ -102,6 +102,40 @@ inline bool build_row_program(const DevProblem& d, const std::vector<DevTerm>& d
   };
   auto add_linit = [&](int code, float value) { linit.push_back(code); linit.push_back(fbits(value)); };
 
+  // Compact rows (ilqg_common.hpp): a pass's local slots in slot order, where each lands in the dense arrays, and the
+  // constants around them.
+  std::vector<int> cbase, cdst, cbg;
+  bool compact_ok = true;
+  auto collect_compact = [&](int reg_begin, int nl) {
+    const int base = int(cdst.size());
+    cbase.push_back(base);
+    cdst.resize(size_t(base) + nl, -1);
+    for (int rg = reg_begin; rg < int(regions.size()) / RREG_WORDS; rg++) {
+      const int arr = regions[rg * RREG_WORDS + 0], words = regions[rg * RREG_WORDS + 1], offs = regions[rg * RREG_WORDS + 2];
+      const int mo = regions[rg * RREG_WORDS + 3];
+      for (int wd = 0; wd < words; wd++) {
+        const int slot = maps[size_t(mo) + wd];
+        if (slot >= NPS) {
+          if (cdst[size_t(base) + slot - NPS] >= 0) compact_ok = false;  // a slot feeds one word
+          cdst[size_t(base) + slot - NPS] = (arr << 24) | (offs + wd);
+        } else if (slot != S_ZERO) {
+          const int kind = pinit[size_t(slot) * RINIT_WORDS] & 255;
+          float v = 0.0f;
+          std::memcpy(&v, &pinit[size_t(slot) * RINIT_WORDS + 1], sizeof(v));
+          const int ck = kind == RI_VALUE ? RC_LITERAL : (kind == RI_DT ? RC_DT : (kind == RI_NEG_DT ? RC_NEG_DT : -1));
+          if (ck < 0) compact_ok = false;
+          if (ck != RC_LITERAL || v != 0.0f) {
+            cbg.push_back((arr << 24) | (offs + wd));
+            cbg.push_back(ck);
+            cbg.push_back(fbits(v));
+          }
+        }
+      }
+    }
+    for (int e = base; e < int(cdst.size()); e++)
+      if (cdst[e] < 0) compact_ok = false;
+  };
+
   // pass 0: the Jacobians
   {
     std::vector<short> mapA(size_t(n) * n, short(S_ZERO)), mapB(size_t(n) * m, short(S_ZERO));
@@ -163,11 +197,10 @@ inline bool build_row_program(const DevProblem& d, const std::vector<DevTerm>& d
     passes.insert(passes.end(), {op_begin, int(ops.size()) / ROP_WORDS, reg_begin, int(regions.size()) / RREG_WORDS,
                                  li_begin, nl, RPASS_JACOBIANS, 0});
     if (nl > max_lslots) max_lslots = nl;
+    collect_compact(reg_begin, nl);
   }
 
   // passes 1..N: the players
-  std::vector<int> cbase, cdst, cbg;  // compact rows (ilqg_rows.hpp)
-  bool compact_ok = true;
   merit.assign(size_t(N) * RMERIT_WORDS, 0);
   for (int i = 0; i < N; i++) {
     std::map<int, int> q_slot;                  // word of Q_i (a + n * b) -> pass-local slot
@@ -298,30 +331,7 @@ inline bool build_row_program(const DevProblem& d, const std::vector<DevTerm>& d
     passes.insert(passes.end(), {op_begin, int(ops.size()) / ROP_WORDS, reg_begin, int(regions.size()) / RREG_WORDS,
                                  li_begin, nl, RPASS_PLAYER, i});
     if (nl > max_lslots) max_lslots = nl;
-    // compact row: this pass's local slots in slot order; where each lands in the dense arrays
-    {
-      const int base = int(cdst.size());
-      cbase.push_back(base);
-      cdst.resize(size_t(base) + nl, -1);
-      for (int rg = reg_begin; rg < int(regions.size()) / RREG_WORDS; rg++) {
-        const int arr = regions[rg * RREG_WORDS + 0], words = regions[rg * RREG_WORDS + 1], offs = regions[rg * RREG_WORDS + 2];
-        const int mo = regions[rg * RREG_WORDS + 3];
-        for (int wd = 0; wd < words; wd++) {
-          const int slot = maps[size_t(mo) + wd];
-          if (slot >= NPS) {
-            if (cdst[size_t(base) + slot - NPS] >= 0) compact_ok = false;  // a slot feeds one word
-            cdst[size_t(base) + slot - NPS] = (arr << 24) | (offs + wd);
-          } else if (slot != S_ZERO) {
-            float v = 0.0f;
-            std::memcpy(&v, &pinit[size_t(slot) * RINIT_WORDS + 1], sizeof(v));
-            if ((pinit[size_t(slot) * RINIT_WORDS] & 255) != RI_VALUE) compact_ok = false;
-            if (v != 0.0f) { cbg.push_back((arr << 24) | (offs + wd)); cbg.push_back(fbits(v)); }
-          }
-        }
-      }
-      for (int e = base; e < int(cdst.size()); e++)
-        if (cdst[e] < 0) compact_ok = false;
-    }
+    collect_compact(reg_begin, nl);
   }
   if (NPS + max_lslots > 32000) { *err = "row program: too many slots"; return false; }
   // rows_writeout_small streams l_i, R_ij, r_ij with one word per lane
@@ -352,8 +362,8 @@ inline bool build_row_program(const DevProblem& d, const std::vector<DevTerm>& d
     if (cdst.size() > size_t(kCompactMaxWords) || cdst.size() >= (1u << 24)) compact_ok = false;
     std::vector<int> blk;
     blk.push_back(compact_ok ? int(cdst.size()) : 0);
-    blk.push_back(compact_ok ? int(cbg.size()) / 2 : 0);
-    for (int i = 0; i < N; i++) blk.push_back(i < int(cbase.size()) ? cbase[i] : 0);
+    blk.push_back(compact_ok ? int(cbg.size()) / RC_BG_WORDS : 0);
+    for (int i = 0; i < N + 1; i++) blk.push_back(i < int(cbase.size()) ? cbase[i] : 0);  // Jacobian pass, players
     if (compact_ok) {
       blk.insert(blk.end(), cdst.begin(), cdst.end());
       blk.insert(blk.end(), cbg.begin(), cbg.end());

@@ -341,7 +341,7 @@ __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* map
   const rp_cptr linit = rp + rp[RP_OFF_LINIT];
   const rp_cptr regions = rp + rp[RP_OFF_REGIONS];
   const rp_cptr merit = rp + rp[RP_OFF_MERIT];
-  const bool quad_out = a.Q != nullptr || a.compact != nullptr;
+  const bool quad_out = a.Q != nullptr || (a.compact != nullptr && a.compact_quad);
   const bool do_quad = quad_out || a.merit_part != nullptr;
   const bool want_cost = a.cost_part != nullptr;
   const PairTable& pt = p.pairs;
@@ -419,7 +419,7 @@ __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* map
     const rp_cptr pr = passes + ps * RPASS_WORDS;
     const int op_begin = pr[0], op_end = pr[1], reg_begin = pr[2], reg_end = pr[3], li_begin = pr[4], li_count = pr[5];
     const int pkind = pr[6], player = pr[7];
-    if (pkind == RPASS_JACOBIANS && a.A == nullptr) continue;
+    if (pkind == RPASS_JACOBIANS && a.A == nullptr && !(a.compact && a.compact_lin)) continue;
     if (pkind == RPASS_PLAYER && !do_quad && !want_cost) continue;
     T ctot = T(0);  // PlayerCost::Evaluate of this pass's player at this lane's row
     T ext_value = T(0);  // ExtremeValueCost in flight: its value and active child at this lane's row
@@ -588,10 +588,10 @@ __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* map
         if (a.r) rows_writeout_small<T>(a.r + size_t(k0) * pt.rsz + offs, pt.rsz, words, map, acc, cws, nrows, lane);
       }
     }
-    if (pkind == RPASS_PLAYER && a.compact) {
+    if (a.compact && (pkind == RPASS_PLAYER ? a.compact_quad : a.compact_lin)) {
       // compact row: this pass's local slots, in slot order, at the pass's base (lane = slot, loop = row)
       const rp_cptr cb = rp + rp[RP_OFF_COMPACT];
-      const int CWD = cb[RC_W], base = cb[RC_BASE + player];
+      const int CWD = cb[RC_W], base = cb[RC_BASE + (pkind == RPASS_PLAYER ? 1 + player : 0)];
       T* const g0 = a.compact + size_t(k0) * CWD + base;
       constexpr int RB = 8;
       for (int s0 = 0; s0 < li_count; s0 += 64) {

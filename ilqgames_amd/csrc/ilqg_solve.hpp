@@ -366,13 +366,15 @@ __device__ __forceinline__ QuadArgs<T> trial_quad_args(const DevProblem& p, cons
   qa.t_extreme = ib.t_extreme();
   qa.t_init = 0.0;
   const bool lin = qmode != Q_COSTS, quad = qmode == Q_INIT || qmode == Q_TRIAL;
-  qa.A = lin ? w + L.A : nullptr;
-  qa.Bm = lin ? w + L.B : nullptr;
+  qa.A = (lin && !compact) ? w + L.A : nullptr;
+  qa.Bm = (lin && !compact) ? w + L.B : nullptr;
   qa.Q = (quad && !compact) ? w + L.Q : nullptr;
   qa.l = (quad && !compact) ? w + L.l : nullptr;
   qa.R = (quad && !compact) ? w + L.R : nullptr;
   qa.r = (quad && !compact) ? w + L.r : nullptr;
-  qa.compact = (quad && compact) ? w + L.Q : nullptr;  // the dense Q array's space
+  qa.compact = ((lin || quad) && compact) ? w + L.Q : nullptr;  // the dense Q array's space
+  qa.compact_lin = lin && compact;
+  qa.compact_quad = quad && compact;
   qa.merit_part = qmode == Q_TRIAL ? w + L.mpart : nullptr;
   qa.cost_part = (qmode == Q_COSTS || qmode == Q_TRIAL || qmode == Q_LIN) ? w + L.cpart : nullptr;
   qa.phacc = nullptr;
@@ -653,6 +655,11 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const s
       fa.dx = nullptr;
       fa.ed_out = ed_slot;
       fa.T_steps = Tn;
+      if (sa.compact) {
+        fa.compact = w + L.Q;
+        fa.compact_tab = p.row_prog + p.rp_compact_off;
+        fa.dt = p.dt;
+      }
       constexpr int FWD_LDSE = 4 * 2 * ((NX * NX + LQCfg<T, NX, NP, MU>::SCR + 3) & ~3) + 2 * NX + 8;
       lq_forward_pass_body<T, NX, NP, MU, 64, FWD_LDSE>(fa, sm_quad, lane);
     }
@@ -807,6 +814,7 @@ __device__ __forceinline__ void lq_part_instance(const DevProblem& p, const Solv
   if (sa.compact && KIND == LQ_PLAYER_WAVES) {
     la.compact = w + L.Q;
     la.compact_tab = p.row_prog + p.rp_compact_off;
+    la.dt = p.dt;
   }
   la.ph = (kProfile && sa.prof) ? sa.prof + size_t(b) * 96 + 8 : nullptr;
   la.tl = kTimeline ? sa.prof : nullptr;

@@ -242,8 +242,8 @@ struct QuadArgs {
   double t_init;
   T *A, *Bm;           // [T][n*n], [T][n*m] or nullptr (skip linearisation)
   T *Q, *l, *R, *r;    // or nullptr (skip quadraticisation outputs)
-  T* compact = nullptr;  // [T][rp_compact_w] or nullptr: the touched words of [Q | l | R | r] only (ilqg_rows.hpp), instead
-                         // of the dense arrays
+  T* compact = nullptr;  // [T][rp_compact_w] or nullptr: compact rows (ilqg_common.hpp) instead of the dense arrays —
+  bool compact_lin = false, compact_quad = false;  // ... of the linearisation (A, Bm) / of the quadraticisation (Q, l, R, r)
   T* merit_part;       // [T][N][2] = (|r_ii|^2, |l_i|^2) or nullptr
   T* cost_part;        // [T][N] PlayerCost::Evaluate or nullptr
   long long* phacc = nullptr;  // optional phase profile accumulators (registers of the caller)

@@ -33,6 +33,17 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
 
 
+def test_library_has_no_dangling_internal_symbol():
+    """Every undefined symbol of libilqg_hip.so must come from a library it links (HIP runtime, libstdc++, libc, libm,
+    libgcc).  An undefined symbol of the library's OWN namespaces is a call through a null pointer at run time: the
+    hidden-visibility units resolve it to address 0 at link time without a word (this happened with an `extern
+    thread_local` of a constant-initialised class type, whose TLS init function no unit emits)."""
+    from ilqgames_amd import hip
+    out = subprocess.check_output(["nm", "-C", "--undefined-only", hip.LIB_PATH], text=True)
+    own = [line.split(None, 1)[-1].strip() for line in out.splitlines() if "ilqg" in line]
+    assert not own, own
+
+
 def test_struct_layouts_match_the_c_header():
     """Compile a tiny C program against include/ilqg.h and compare sizeof/offsetof with ctypes."""
     from ilqgames_amd import abi
