@@ -1198,6 +1198,7 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
       sYz[tt] = s + sr[rg_ww + lane];
     }
     ILQG_PH(1);
+    if (cmp) dma_wait();  // the compact row requested a step ago has landed (see the end of the step)
     lds_sync(false);  // [S | Y] and y_zeta complete (LDS only: no wait on the DMA or on global stores)
     ILQG_PH(7);
     if (NP > 1 && w != 0) {  // while wave 0 solves: next step's image and this step's Q_i l_i
@@ -1461,9 +1462,15 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
     }
     }
     ILQG_PH(5);
-    dma_wait();
-    ILQG_PH(9);
-    lds_sync(false);  // next image complete; everyone is done with P / alpha / this image
+    if (!cmp) {
+      dma_wait();
+      ILQG_PH(9);
+      lds_sync(false);  // next image complete (the DMA fills it directly); everyone is done with P / alpha / this image
+    }
+    // Compact rows: no barrier here.  The next image was completed by LDS stores (the scatter) in front of this step's
+    // second barrier; P / alpha, the [S | Y] bounce and this image are next written behind the NEXT step's first
+    // barrier, which every wave reaches only after its last read of them; the staged compact row is waited for in front
+    // of that barrier by the wave that requested it.
     cur = 1 - cur;
     set_img(cur);
     ILQG_PH(6);
