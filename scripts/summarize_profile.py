@@ -54,6 +54,50 @@ for name, db in (("FETCH_SIZE", "pmc_fetch/bench_results.db"), ("WRITE_SIZE", "p
         sel = [r for r in sel if r[2] > 0.2 * top]  # drops the one-workgroup dispatches of the latency figure
         out.append("| %s | %s | %d | %.1f | %d |" % (nm[:80], sel[0][1], len(sel), statistics.median(r[2] for r in sel),
                                                     statistics.median(r[3] for r in sel)))
+# wave-level SQ counters (own pass): per kernel, medians over the batch launches
+sqdb = "pmc_sq/bench_results.db"
+if os.path.exists(os.path.join(src, sqdb)):
+    cols, rows = q(sqdb, "select kernel_name, counter_name, value, duration from counters_collection "
+                         "where kernel_name like '%ilq%' order by start")
+    names = sorted(set(r[0] for r in rows))
+    ctrs = ["SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY",
+            "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS"]
+    out.append("\n## rocprofv3 --pmc " + " ".join(ctrs) + " (own pass): medians per kernel over the batch launches; the "
+               "WAIT / ACTIVE counters as a share of SQ_WAVE_CYCLES (all in quad-cycles)\n\n| kernel | waves | busy cycles | "
+               "wave cycles | waiting (s_waitcnt / barrier) | issue-stalled | executing any | of which VALU | LDS |\n|---|---|---|---|---|---|---|---|---|")
+    for nm in names:
+        med = {}
+        for c in ctrs:
+            vals = [r[2] for r in rows if r[0] == nm and r[1] == c]
+            if vals:
+                top = max(vals)
+                vals = [v for v in vals if v > 0.2 * top] or vals
+                med[c] = statistics.median(vals)
+        if "SQ_WAVE_CYCLES" not in med or med["SQ_WAVE_CYCLES"] <= 0:
+            continue
+        wc = med["SQ_WAVE_CYCLES"]
+        sh = lambda c: "%.0f %%" % (100.0 * med.get(c, 0.0) / wc)  # noqa: E731
+        out.append("| %s | %.0f | %.3g | %.3g | %s | %s | %s | %s | %s |" % (nm[:80], med.get("SQ_WAVES", 0), med.get("SQ_BUSY_CYCLES", 0), wc,
+                   sh("SQ_WAIT_ANY"), sh("SQ_WAIT_INST_ANY"), sh("SQ_ACTIVE_INST_ANY"), sh("SQ_ACTIVE_INST_VALU"), sh("SQ_ACTIVE_INST_LDS")))
+# HBM traffic per round for bench.py's roofline block: 2 x FETCH_SIZE (profiles/r03_counter_calibration.md: the counter
+# reports half of the bytes read) + WRITE_SIZE, summed over the kernels of one round (sweep + trial kernels)
+try:
+    tr = {}
+    for cname, db in (("FETCH_SIZE", "pmc_fetch/bench_results.db"), ("WRITE_SIZE", "pmc_write/bench_results.db")):
+        cols, rows = q(db, "select kernel_name, counter_name, value, duration from counters_collection where kernel_name like '%ilq%' order by start")
+        for nm in sorted(set(r[0] for r in rows)):
+            if "exit" in nm or "probe" in nm:
+                continue
+            sel = [r for r in rows if r[0] == nm]
+            top = max(r[2] for r in sel)
+            sel = [r for r in sel if r[2] > 0.2 * top]
+            short = nm.split("(")[0].split("::")[-1].split("<")[0]
+            tr.setdefault(short, {})[cname] = statistics.median(r[2] for r in sel) * 1024.0
+    total = sum(2.0 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0) for v in tr.values())
+    out.append("\n## HBM traffic per round (2 x FETCH_SIZE + WRITE_SIZE over the round's kernels, profiles/r03_counter_calibration.md)\n\n```json\n%s\n```"
+               % json.dumps({"bytes_per_round": total, "per_kernel_bytes": tr}, indent=1))
+except Exception as e:  # a pass that did not run leaves the section out
+    out.append("\n(traffic per round not computed: %r)" % (e,))
 for f in ("bench_plain.log",):
     p = os.path.join(src, f)
     if os.path.exists(p):
