@@ -423,3 +423,23 @@ def test_config5_receding_horizon_simulation_fp32_device_against_fp32_oracle(hip
     # the device stays with the fp32 oracle about as long as the fp32 oracle stays with itself
     assert self_all[0] >= self_all[1] - 3 and self_matched[0] >= 0.6 * self_matched[1], (agree_all, matched, self_all, self_matched)
     assert agree_all >= 0.4 * B
+
+
+def test_two_player_unicycle_4d_nearest_plan_state_is_by_position(hip):
+    """The device's SyncToExistingProblem on TwoPlayerUnicycle4D measures distance in (px, py) only
+    (two_player_unicycle_4d.h:141-147): the plan of tests/test_oracle_receding.py's twin test, where the position
+    metric picks row 10 and the whole-state norm would pick row 3.  The expected index is the reference's rule."""
+    import torch
+    spec = examples.two_player_unicycle_4d_scene()
+    prob = hip.Problem(spec, abi.F64)
+    T, n, m = spec.T, prob.n, prob.m
+    bufs = prob.alloc_solve_buffers(1)
+    xs = np.zeros((1, T, n))
+    xs[0, :, 0] = 0.05 * np.arange(T)
+    xs[0, 3, 2] = 1.0
+    bufs["xs"].copy_(torch.from_numpy(xs))
+    for k in ("us", "P", "alpha"):
+        bufs[k].zero_()
+    x = np.array([[0.5, 0.0, 1.0, 0.0]])
+    _, first, _ = prob.receding_horizon_shift(x, 0.0, 0.0, 0.0, bufs)
+    assert int(_np(first)[0]) == 10

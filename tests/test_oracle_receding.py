@@ -179,3 +179,30 @@ def test_jacobi_min_eigenvalue_matches_numpy(oracle):
             assert abs(oracle.min_eigenvalue(a) - np.linalg.eigvalsh(a)[0]) < 1e-10 * max(1.0, np.abs(a).max())
     g = rng.standard_normal((8, 3))
     assert abs(oracle.min_eigenvalue(g @ g.T)) < 1e-12  # rank-deficient PSD: smallest eigenvalue 0
+
+
+def test_nearest_plan_state_of_two_player_unicycle_4d_is_by_position(oracle):
+    """TwoPlayerUnicycle4D overrides DistanceBetween with the squared distance of (px, py) only
+    (include/ilqgames/dynamics/two_player_unicycle_4d.h:141-147) — it does NOT inherit the whole-state default of
+    multi_player_integrable_system.h:113.  Problem::SyncToExistingProblem (src/problem.cpp:105-110) therefore picks the
+    plan state nearest in position.  The plan below is built so that the two metrics disagree: the state nearest in
+    position (row 10) has a heading 1 rad away from the measured one, while row 3 matches the heading exactly and
+    is 0.35 m away — position says 10, the whole-state norm would say 3.  (The expected index comes from the
+    reference's rule, not from the device: tests/test_gpu_receding.py holds the device to the oracle.)"""
+    spec = examples.two_player_unicycle_4d_scene()
+    op = oracle.OracleProblem(spec)
+    T, n, m = spec.T, op.n, op.m
+    assert n == 4
+    xs = np.zeros((1, T, n))
+    xs[0, :, 0] = 0.05 * np.arange(T)   # px: 5 cm per row
+    # v = 0 everywhere and zero controls / gains: whatever SetUpNextRecedingHorizon integrates, the state stays put
+    xs[0, 3, 2] = 1.0                   # heading of row 3 only
+    us = np.zeros((1, T, m))
+    P = np.zeros((1, T, m * n))
+    alpha = np.zeros((1, T, m))
+    x = np.array([[0.5, 0.0, 1.0, 0.0]])  # on row 10's position, with row 3's heading
+    out = op.receding_horizon_shift(abi.F64, x, 0.0, 0.0, 0.0, xs, us, P, alpha)
+    d_pos = (xs[0, :, 0] - 0.5) ** 2 + xs[0, :, 1] ** 2
+    d_all = d_pos + (xs[0, :, 2] - 1.0) ** 2 + xs[0, :, 3] ** 2
+    assert int(np.argmin(d_pos)) == 10 and int(np.argmin(d_all)) == 3  # the construction
+    assert int(out["first_step"][0]) == 10
