@@ -4,6 +4,12 @@
 #include <ilqgames/host/api.hpp>
 
 #include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+
+#include <arpa/inet.h>
+#include <netinet/in.h>
+#include <sys/socket.h>
+#include <unistd.h>
 
 #include <sys/stat.h>
 #include <sys/types.h>
@@ -573,6 +579,132 @@ static void CheckSupportedParams(const SolverParams& params) {
       << "SolverParams::reset_problem / reset_lambdas / reset_mu = false are not supported by the device solve";
 }
 
+// ---------------------------------------------------------------------------------------------
+// Several GPUs: sharding rule, rendezvous, RCCL communicator
+// ---------------------------------------------------------------------------------------------
+void InstanceRange(size_t total, int rank, int world, size_t* lo, size_t* hi) {
+  CHECK_GT(world, 0);
+  CHECK(rank >= 0 && rank < world);
+  const size_t base = total / world, extra = total % world;
+  *lo = size_t(rank) * base + std::min<size_t>(rank, extra);
+  *hi = *lo + base + (size_t(rank) < extra ? 1 : 0);
+}
+
+ShardInfo ShardFromEnvironment() {
+  ShardInfo s;
+  auto env_int = [](const char* name, int fallback) {
+    const char* v = std::getenv(name);
+    return (v != nullptr && *v != 0) ? std::atoi(v) : fallback;
+  };
+  s.rank = env_int("RANK", 0);
+  s.world = env_int("WORLD_SIZE", 1);
+  s.local_rank = env_int("LOCAL_RANK", s.rank);
+  if (const char* a = std::getenv("MASTER_ADDR")) s.master_addr = a;
+  const int master_port = env_int("MASTER_PORT", 0);
+  s.port = env_int("ILQG_RENDEZVOUS_PORT", master_port > 0 ? master_port + 1 : 29517);
+  CHECK(s.world >= 1 && s.rank >= 0 && s.rank < s.world) << "RANK / WORLD_SIZE: " << s.rank << " / " << s.world;
+  return s;
+}
+
+namespace {
+void SendAll(int fd, const void* p, size_t n) {
+  const char* c = static_cast<const char*>(p);
+  while (n > 0) {
+    const ssize_t w = ::send(fd, c, n, 0);
+    CHECK_GT(w, 0) << "rendezvous send: " << std::strerror(errno);
+    c += w;
+    n -= size_t(w);
+  }
+}
+void RecvAll(int fd, void* p, size_t n) {
+  char* c = static_cast<char*>(p);
+  while (n > 0) {
+    const ssize_t r = ::recv(fd, c, n, 0);
+    CHECK_GT(r, 0) << "rendezvous recv: " << std::strerror(errno);
+    c += r;
+    n -= size_t(r);
+  }
+}
+}  // namespace
+
+void RendezvousBroadcast(const ShardInfo& info, void* token, size_t bytes) {
+  if (info.world <= 1) return;
+  sockaddr_in addr{};
+  addr.sin_family = AF_INET;
+  addr.sin_port = htons(uint16_t(info.port));
+  if (info.rank == 0) {
+    const int srv = ::socket(AF_INET, SOCK_STREAM, 0);
+    CHECK_GE(srv, 0) << std::strerror(errno);
+    const int one = 1;
+    ::setsockopt(srv, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
+    addr.sin_addr.s_addr = htonl(INADDR_ANY);
+    CHECK_EQ(::bind(srv, reinterpret_cast<sockaddr*>(&addr), sizeof(addr)), 0)
+        << "rendezvous bind to port " << info.port << ": " << std::strerror(errno);
+    CHECK_EQ(::listen(srv, info.world), 0) << std::strerror(errno);
+    for (int r = 1; r < info.world; r++) {
+      const int fd = ::accept(srv, nullptr, nullptr);
+      CHECK_GE(fd, 0) << std::strerror(errno);
+      SendAll(fd, token, bytes);
+      ::close(fd);
+    }
+    ::close(srv);
+  } else {
+    CHECK_EQ(::inet_pton(AF_INET, info.master_addr.c_str(), &addr.sin_addr), 1)
+        << "MASTER_ADDR must be a dotted IPv4 address, got " << info.master_addr;
+    int fd = -1;
+    for (int attempt = 0; attempt < 600; attempt++) {  // rank 0 may not be listening yet: retry for ~60 s
+      fd = ::socket(AF_INET, SOCK_STREAM, 0);
+      CHECK_GE(fd, 0) << std::strerror(errno);
+      if (::connect(fd, reinterpret_cast<sockaddr*>(&addr), sizeof(addr)) == 0) break;
+      ::close(fd);
+      fd = -1;
+      ::usleep(100000);
+    }
+    CHECK_GE(fd, 0) << "rendezvous: no answer from " << info.master_addr << ":" << info.port;
+    RecvAll(fd, token, bytes);
+    ::close(fd);
+  }
+}
+
+#define NCCL_CHECK(expr)                                                        \
+  do {                                                                          \
+    const ncclResult_t r_ = (expr);                                             \
+    CHECK(r_ == ncclSuccess) << #expr << ": " << ncclGetErrorString(r_);        \
+  } while (0)
+
+ShardContext::ShardContext(const ShardInfo& info) : info_(info) {
+  int count = 0;
+  HipCheck(hipGetDeviceCount(&count), "hipGetDeviceCount");
+  CHECK_GT(count, 0) << "no HIP device visible";
+  HipCheck(hipSetDevice(info.local_rank % count), "hipSetDevice");
+  hipStream_t st = nullptr;
+  HipCheck(hipStreamCreate(&st), "hipStreamCreate");
+  stream_ = st;
+  if (info.world > 1) {
+    ncclUniqueId id;
+    if (info.rank == 0) NCCL_CHECK(ncclGetUniqueId(&id));
+    RendezvousBroadcast(info, &id, sizeof(id));
+    ncclComm_t comm = nullptr;
+    NCCL_CHECK(ncclCommInitRank(&comm, info.world, id, info.rank));
+    comm_ = comm;
+  }
+}
+
+ShardContext::~ShardContext() {
+  if (comm_ != nullptr) (void)ncclCommDestroy(static_cast<ncclComm_t>(comm_));
+  if (stream_ != nullptr) (void)hipStreamDestroy(static_cast<hipStream_t>(stream_));
+}
+
+void ShardContext::AllGather(const void* send, void* recv, size_t bytes_per_rank) const {
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  if (info_.world <= 1) {
+    HipCheck(hipMemcpyAsync(recv, send, bytes_per_rank, hipMemcpyDeviceToDevice, st), "D2D");
+  } else {
+    NCCL_CHECK(ncclAllGather(send, recv, bytes_per_rank, ncclChar, static_cast<ncclComm_t>(comm_), st));
+  }
+  HipCheck(hipStreamSynchronize(st), "all-gather");
+}
+
 class DeviceSolve {
  public:
   DeviceSolve(const Problem& problem, const SolverParams& params) : dtype_(Options().dtype) {
@@ -600,10 +732,12 @@ class DeviceSolve {
     return Options().dtype == dtype_ && Fingerprint(now) == fingerprint_;
   }
 
+  // `shard` (with `total` > 0): x0s is this rank's block of a sharded batch of `total` instances; after the solve the
+  // per-instance results of every rank are all-gathered on the device and the BatchResult covers the whole batch.
   BatchResult Run(const std::vector<VectorXf>& x0s, const OperatingPoint& warm_op,
                   const std::vector<Strategy>& warm_strategies, bool augmented_lagrangian,
-                  bool repeat_single = false) {
-    const size_t B = x0s.size();
+                  bool repeat_single = false, const ShardContext* shard = nullptr, size_t total = 0) {
+    size_t B = x0s.size();
     CHECK_GT(B, 0);
     const auto start = Clock::now();
     // pack the warm start once, replicate per instance
@@ -664,13 +798,73 @@ class DeviceSolve {
     CHECK_EQ(s, ILQG_OK) << ilqg_last_error();
     HipCheck(hipDeviceSynchronize(), "solve");
 
-    xs = Download(d_xs_, xs.size(), dtype_);
-    us = Download(d_us_, us.size(), dtype_);
-    P = Download(d_P_, P.size(), dtype_);
-    alpha = Download(d_alpha_, alpha.size(), dtype_);
-    const std::vector<float> costs = Download(d_costs_, B * N_, dtype_);
-    const std::vector<int32_t> iters = DownloadInts(d_iters_, B), status = DownloadInts(d_status_, B),
-                               conv = DownloadInts(d_conv_, B);
+    std::vector<float> costs;
+    std::vector<int32_t> iters, status, conv;
+    if (shard != nullptr && total > 0) {
+      // The one exchange step of a sharded solve: every rank's block of every result array, all-gathered on the
+      // device (blocks differ by at most one instance: padded to the largest for the collective, trimmed here).
+      const int world = shard->Info().world;
+      size_t mx = 0;
+      for (int r = 0; r < world; r++) {
+        size_t lo, hi;
+        InstanceRange(total, r, world, &lo, &hi);
+        mx = std::max(mx, hi - lo);
+      }
+      const size_t es = ElemBytes(dtype_);
+      auto gather_f = [&](DeviceBuffer& local, size_t per_instance) {
+        const size_t blk = mx * per_instance * es;
+        DeviceBuffer padded;  // the local block, padded to the common size (the solve's own buffer holds B instances)
+        HipCheck(hipMemset(padded.Reserve(blk), 0, blk), "memset");
+        HipCheck(hipMemcpy(padded.get(), local.get(), B * per_instance * es, hipMemcpyDeviceToDevice), "D2D");
+        DeviceBuffer all;
+        shard->AllGather(padded.get(), all.Reserve(blk * world), blk);
+        std::vector<float> out;
+        out.reserve(total * per_instance);
+        for (int r = 0; r < world; r++) {
+          size_t lo, hi;
+          InstanceRange(total, r, world, &lo, &hi);
+          DeviceBuffer view;  // Download() reads from the start of a buffer: copy the rank's valid rows to one
+          HipCheck(hipMemcpy(view.Reserve((hi - lo) * per_instance * es), static_cast<char*>(all.get()) + size_t(r) * blk,
+                             (hi - lo) * per_instance * es, hipMemcpyDeviceToDevice), "D2D");
+          const std::vector<float> part = Download(view, (hi - lo) * per_instance, dtype_);
+          out.insert(out.end(), part.begin(), part.end());
+        }
+        return out;
+      };
+      auto gather_i = [&](DeviceBuffer& local) {
+        const size_t blk = mx * 4;
+        DeviceBuffer padded, all;
+        HipCheck(hipMemset(padded.Reserve(blk), 0, blk), "memset");
+        HipCheck(hipMemcpy(padded.get(), local.get(), B * 4, hipMemcpyDeviceToDevice), "D2D");
+        shard->AllGather(padded.get(), all.Reserve(blk * world), blk);
+        std::vector<int32_t> host(mx * world), out;
+        HipCheck(hipMemcpy(host.data(), all.get(), blk * world, hipMemcpyDeviceToHost), "D2H");
+        for (int r = 0; r < world; r++) {
+          size_t lo, hi;
+          InstanceRange(total, r, world, &lo, &hi);
+          out.insert(out.end(), host.begin() + r * mx, host.begin() + r * mx + (hi - lo));
+        }
+        return out;
+      };
+      xs = gather_f(d_xs_, size_t(T_) * n_);
+      us = gather_f(d_us_, size_t(T_) * m_);
+      P = gather_f(d_P_, size_t(T_) * m_ * n_);
+      alpha = gather_f(d_alpha_, size_t(T_) * m_);
+      costs = gather_f(d_costs_, N_);
+      iters = gather_i(d_iters_);
+      status = gather_i(d_status_);
+      conv = gather_i(d_conv_);
+      B = total;
+    } else {
+      xs = Download(d_xs_, xs.size(), dtype_);
+      us = Download(d_us_, us.size(), dtype_);
+      P = Download(d_P_, P.size(), dtype_);
+      alpha = Download(d_alpha_, alpha.size(), dtype_);
+      costs = Download(d_costs_, B * N_, dtype_);
+      iters = DownloadInts(d_iters_, B);
+      status = DownloadInts(d_status_, B);
+      conv = DownloadInts(d_conv_, B);
+    }
     const Time elapsed = std::chrono::duration<Time>(Clock::now() - start).count();
 
     BatchResult result;
@@ -1416,6 +1610,16 @@ void GameSolver::RefreshDevice() {
 host::BatchResult GameSolver::SolveBatch(const std::vector<VectorXf>& x0s) {
   RefreshDevice();
   return device_->Run(x0s, problem_->CurrentOperatingPoint(), problem_->CurrentStrategies(), augmented_lagrangian_);
+}
+
+host::BatchResult GameSolver::SolveBatchSharded(const std::vector<VectorXf>& x0s, const host::ShardContext& shard) {
+  RefreshDevice();
+  size_t lo, hi;
+  host::InstanceRange(x0s.size(), shard.Info().rank, shard.Info().world, &lo, &hi);
+  CHECK_GT(hi, lo) << "a sharded batch needs at least one instance per rank";
+  const std::vector<VectorXf> mine(x0s.begin() + lo, x0s.begin() + hi);
+  return device_->Run(mine, problem_->CurrentOperatingPoint(), problem_->CurrentStrategies(), augmented_lagrangian_,
+                      /*repeat_single=*/false, &shard, x0s.size());
 }
 
 host::BatchResult GameSolver::SolveOne() {

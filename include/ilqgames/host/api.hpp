@@ -852,6 +852,44 @@ struct BatchResult {
   std::vector<bool> success;
 };
 
+// ---- several GPUs: one process per GPU, instances sharded, one RCCL all-gather of the results ----
+// Game instances share nothing, so a batch is cut into contiguous blocks, block r to rank r; the first total % world
+// ranks take one instance more (the same rule as ilqgames_amd/sharding.py::instance_range).
+void InstanceRange(size_t total, int rank, int world, size_t* lo, size_t* hi);
+
+// Where this process stands among the processes of a job, as the launcher's environment says (the convention of
+// torch.distributed.run / mpirun wrappers): RANK, WORLD_SIZE, LOCAL_RANK, MASTER_ADDR; the rendezvous port is
+// ILQG_RENDEZVOUS_PORT, else MASTER_PORT + 1 (MASTER_PORT itself may be held by the launcher), else 29517.
+struct ShardInfo {
+  int rank = 0, world = 1, local_rank = 0;
+  std::string master_addr = "127.0.0.1";
+  int port = 29517;
+};
+ShardInfo ShardFromEnvironment();
+
+// The communicator of a sharded job.  Construction binds the process to GPU `local_rank` (hipSetDevice — the C ABI
+// of include/ilqg.h works on the calling thread's current device, one process per GPU) and builds the RCCL communicator:
+// rank 0 creates the ncclUniqueId and hands it to the other ranks over a TCP connection to master_addr:port.
+class ShardContext {
+ public:
+  explicit ShardContext(const ShardInfo& info);
+  ~ShardContext();
+  ShardContext(const ShardContext&) = delete;
+  ShardContext& operator=(const ShardContext&) = delete;
+  const ShardInfo& Info() const { return info_; }
+  // all-gather of `bytes_per_rank` bytes per rank, device buffers (RCCL over xGMI; world == 1: a device copy)
+  void AllGather(const void* send, void* recv, size_t bytes_per_rank) const;
+
+ private:
+  ShardInfo info_;
+  void* comm_ = nullptr;    // ncclComm_t
+  void* stream_ = nullptr;  // hipStream_t the collectives run on
+};
+
+// The rendezvous alone (no GPU, no RCCL): rank 0 sends `bytes` of `token` to every other rank, which receives them
+// into `token`.  Used by ShardContext for the ncclUniqueId; exported for the CPU test of the bootstrap.
+void RendezvousBroadcast(const ShardInfo& info, void* token, size_t bytes);
+
 }  // namespace host
 
 // ---------------------------------------------------------------------------------------------
@@ -916,6 +954,10 @@ class GameSolver {
   // Batched form of Solve(): one instance per entry of x0s, all sharing the Problem definition and
   // its current operating point / strategies as warm start.  This is the call that fills the GPU.
   host::BatchResult SolveBatch(const std::vector<VectorXf>& x0s);
+  // The same over several GPUs: every rank passes the SAME global list; rank r solves its block
+  // (host::InstanceRange) on its GPU, the per-instance results (operating points, strategies, costs, flags) are
+  // all-gathered with RCCL, and every rank returns the BatchResult of the whole batch, in the order of x0s.
+  host::BatchResult SolveBatchSharded(const std::vector<VectorXf>& x0s, const host::ShardContext& shard);
   const SolverParams& Params() const { return params_; }
   bool IsAugmentedLagrangian() const { return augmented_lagrangian_; }
 

@@ -453,3 +453,53 @@ def test_cpp_lq_solver_properties_like_the_reference_suite():
     print(res.stdout)
     assert res.returncode == 0, res.stdout + res.stderr
     assert res.stdout.count("PASS") == 4
+
+
+def _shard_exe():
+    exe = os.path.join(BIN, "shard_check")
+    if not os.path.exists(exe):
+        entry.build_host()
+    return exe
+
+
+def test_cpp_instance_range_is_the_sharding_rule():
+    """host::InstanceRange (the cut GameSolver::SolveBatchSharded uses) against ilqgames_amd/sharding.py::instance_range
+    (the cut bench.py uses): contiguous blocks, the first total % world ranks one instance longer."""
+    from ilqgames_amd import sharding
+    lines = subprocess.check_output([_shard_exe(), "range"], text=True, timeout=60).strip().splitlines()
+    assert len(lines) == 6 * (1 + 2 + 3 + 8)
+    for line in lines:
+        total, world, rank, lo, hi = (int(v) for v in line.split())
+        assert (lo, hi) == sharding.instance_range(total, rank, world), line
+
+
+def test_cpp_two_process_rendezvous_and_blocks():
+    """The bootstrap of the native multi-GPU entry on the CPU: two processes, RANK / WORLD_SIZE / ILQG_RENDEZVOUS_PORT
+    from the environment (host::ShardFromEnvironment), rank 0 hands a 128-byte token — where ShardContext hands the
+    ncclUniqueId — to rank 1 over TCP (host::RendezvousBroadcast), each prints its block of a 10-instance batch.  (The RCCL
+    communicator and the all-gather themselves need GPUs: `shard_check solve`, tests below, runs them on a world of one.)"""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   ILQG_RENDEZVOUS_PORT=str(port))
+        procs.append(subprocess.Popen([_shard_exe(), "rendezvous"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=120)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+    assert outs[0].strip() == "rank 0 of 2 token ncclUniqueId-stand-in:0123456789abcdef block 0 5"
+    assert outs[1].strip() == "rank 1 of 2 token ncclUniqueId-stand-in:0123456789abcdef block 5 10"
+
+
+@pytest.mark.gpu
+def test_cpp_solve_batch_sharded_on_a_world_of_one_equals_solve_batch():
+    """GameSolver::SolveBatchSharded through ShardContext on one GPU: the block is the whole batch, the gather a
+    device copy — every instance's operating point and gains must equal SolveBatch's bit for bit."""
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    res = subprocess.run([_shard_exe(), "solve"], env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "largest difference between SolveBatch and SolveBatchSharded 0" in res.stdout, res.stdout
