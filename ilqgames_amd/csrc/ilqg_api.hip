@@ -413,9 +413,13 @@ __global__ void __launch_bounds__(64) ilq_exit_kernel(DevProblem p, SolveArgs<T>
 }
 
 // LQ kernel: the Riccati sweep at the accepted operating point of every instance that asked for one.
+// KIND LQ_PLAYER_WAVES_PACKED is LQ_PLAYER_WAVES compiled for four waves per SIMD (128 registers): the fp32 one-tile
+// sweep is three registers over that by itself, and at batches of many instances per CU a fifth resident instance is
+// worth more than the two spilled registers cost (n = 14 fp32, B = 8192: 2.15 M vs 2.04 M it/s; B = 1024, where only
+// four instances per CU exist: 1.81 M vs 1.85 M — so the launcher picks it for large batches only).
 template <typename T, int NX, int NP, int MU, int KIND>
-__global__ void __launch_bounds__((KIND == LQ_VALU_FEEDBACK ? LQCfg<T, NX, NP, MU>::NT : (KIND == LQ_OPEN_LOOP ? OLCfg<T, NX, NP, MU>::NT : 64 * NP)),
-                                  (KIND == LQ_PLAYER_WAVES ? (NX <= 16 ? NP : 2) : (KIND == LQ_OPEN_LOOP ? 3 : 1)))
+__global__ void __launch_bounds__((KIND == LQ_VALU_FEEDBACK ? LQCfg<T, NX, NP, MU>::NT : ((KIND == LQ_OPEN_LOOP || KIND == LQ_OPEN_LOOP_COMPACT) ? OLCfg<T, NX, NP, MU>::NT : 64 * NP)),
+                                  (KIND == LQ_PLAYER_WAVES_PACKED ? 4 : KIND == LQ_PLAYER_WAVES ? (NX <= 16 ? NP : 2) : ((KIND == LQ_OPEN_LOOP || KIND == LQ_OPEN_LOOP_COMPACT) ? 3 : 1)))
 ilq_lq_kernel(DevProblem p, SolveArgs<T> sa) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int b = blockIdx.x;
@@ -424,7 +428,7 @@ ilq_lq_kernel(DevProblem p, SolveArgs<T> sa) {
     const int stage = reinterpret_cast<const SolveState<T>*>(sa.ws + size_t(b) * sa.ws_stride + L.state)->stage;
     if (stage != ST_LQ) return;
   }
-  lq_part_instance<T, NX, NP, MU, KIND>(p, sa, b, reinterpret_cast<T*>(smem_raw));
+  lq_part_instance<T, NX, NP, MU, (KIND == LQ_PLAYER_WAVES_PACKED ? LQ_PLAYER_WAVES : KIND)>(p, sa, b, reinterpret_cast<T*>(smem_raw));
 }
 
 template <typename T>
@@ -678,8 +682,16 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   const size_t lds_trial = trial_lds_bytes<T>(d, W, sa.rows_cw);
   auto k_trial = ilq_trial_kernel<T, NX, NP, MU, W>;
   const bool pw = C::USE_MFMA && !p->desc.params.open_loop;  // one wave per player (MFMA feedback sweep)
-  auto k_lq = pw ? ilq_lq_kernel<T, NX, NP, MU, (C::USE_MFMA ? LQ_PLAYER_WAVES : LQ_VALU_FEEDBACK)>
-                 : (p->desc.params.open_loop ? ilq_lq_kernel<T, NX, NP, MU, LQ_OPEN_LOOP>
+  // Compact rows (ilqg_common.hpp) between the row stage and the sweep: the one-tile player-parallel sweep and the
+  // open-loop sweep read them; the other sweeps take the dense arrays.
+  const bool compact_on = d.rp_compact_w > 0 && choice(opt.compact_rows, true);
+  const bool ol_compact = p->desc.params.open_loop && compact_on;
+  // fp32, one-tile sweep of three player waves, many instances per CU: the 128-register build (see ilq_lq_kernel)
+  constexpr bool has_packed = sizeof(T) == 4 && C::USE_MFMA && C::MFMA_ONE_TILE && NP == 3;
+  const bool packed = has_packed && pw && size_t(batch) >= size_t(5) * 256;
+  auto k_lq = packed ? ilq_lq_kernel<T, NX, NP, MU, (has_packed ? LQ_PLAYER_WAVES_PACKED : LQ_VALU_FEEDBACK)>
+            : pw ? ilq_lq_kernel<T, NX, NP, MU, (C::USE_MFMA ? LQ_PLAYER_WAVES : LQ_VALU_FEEDBACK)>
+                 : (p->desc.params.open_loop ? (ol_compact ? ilq_lq_kernel<T, NX, NP, MU, LQ_OPEN_LOOP_COMPACT> : ilq_lq_kernel<T, NX, NP, MU, LQ_OPEN_LOOP>)
                                              : ilq_lq_kernel<T, NX, NP, MU, LQ_VALU_FEEDBACK>);
   const int nt_lq = p->desc.params.open_loop ? OLCfg<T, NX, NP, MU>::NT : (pw ? 64 * NP : C::NT);
   raise_lds_limit((const void*)k_trial, lds_trial);
@@ -719,7 +731,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   // kernel that follows (split passes and the open-loop sweep keep it in the sweep's kernel).
   // Compact rows between the row stage and the one-tile player-parallel sweep (ilqg_common.hpp): what the row stage
   // writes and the sweep reads per time step shrinks from N (n^2 + n) + ... words to the ones a cost term can touch.
-  sa.compact = (pw && C::MFMA_ONE_TILE && d.rp_compact_w > 0 && choice(opt.compact_rows, true)) ? 1 : 0;
+  sa.compact = ((pw && C::MFMA_ONE_TILE && compact_on) || ol_compact) ? 1 : 0;
   sa.defer_forward = (!split && !p->desc.params.open_loop) ? 1 : 0;
   {
     constexpr size_t fwd_elems = 4 * 2 * ((NX * NX + C::SCR + 3) & ~3) + 2 * NX + 8;

@@ -113,7 +113,8 @@ enum { RA_A = 0, RA_B = 1, RA_Q = 2, RA_L = 3, RA_R = 4, RA_r = 5 };
 // RC_LITERAL (the float `value`), RC_DT or RC_NEG_DT (the time step, in the problem's precision).
 enum { RC_W = 0, RC_NBG = 1, RC_BASE = 2 };
 enum { RC_LITERAL = 0, RC_DT = 1, RC_NEG_DT = 2, RC_BG_WORDS = 3 };
-constexpr int kCompactMaxWords = 192;  // three words per lane of the scattering wave
+constexpr int kCompactMaxWords = 256;  // four words per lane of a scattering wave (roundabout, n = 24, N = 4: 192)
+constexpr int kCompactMaxBg = 128;     // non-zero constants an LDS copy of the background list holds (open-loop sweep)
 
 constexpr int kSegStride = 21;
 

@@ -1014,15 +1014,16 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
       if (job % nslots != slot) continue;
       if (job == 2) {
         const T* row = sSB + (k & 1) * kCompactMaxWords;
-        T v[3];
-        int cd[3];
+        constexpr int WPL = kCompactMaxWords / 64;  // words per lane
+        T v[WPL];
+        int cd[WPL];
 #pragma unroll
-        for (int q = 0; q < 3; q++) {
+        for (int q = 0; q < WPL; q++) {
           cd[q] = sCD[lane + 64 * q];
           v[q] = row[lane + 64 * q];
         }
 #pragma unroll
-        for (int q = 0; q < 3; q++)
+        for (int q = 0; q < WPL; q++)
           if (cd[q] >= 0) dst[cd[q]] = v[q];
       } else if (k >= 1) {
         dma_g2l<64, false>(a.compact + size_t(k - 1) * CWD, sSB + ((k - 1) & 1) * kCompactMaxWords, CWD * S, lane);

@@ -96,7 +96,14 @@ struct OLCfg {
   static constexpr int oA = oB + 2 * BIMG;        // two Aa images
   static constexpr int oZ = oA + 2 * MAT;         // per player: Qa_i image / transposition tile
   static constexpr int SLACK = (32 + 32 * LD - MAT + 3) & ~3;
-  static constexpr int LDS_BWD = oZ + NP * MAT + (SLACK > 0 ? SLACK : 0);
+  static constexpr int LDS_BWD0 = oZ + NP * MAT + (SLACK > 0 ? SLACK : 0);
+  // compact rows (ilqg_common.hpp): two staging rows, the destination of each word (ints), the non-zero constants of
+  // the players' tiles (destination ints + values)
+  static constexpr int oSB = LDS_BWD0;
+  static constexpr int oCD = oSB + 2 * kCompactMaxWords;
+  static constexpr int oBGc = oCD + kCompactMaxWords;
+  static constexpr int oBGv = oBGc + kCompactMaxBg;
+  static constexpr int LDS_BWD = oBGv + kCompactMaxBg;
   static_assert(oZs + 16 + 32 * LDZ <= LDS_BWD && oB + 32 + NX * 32 <= LDS_BWD, "edge-tile reads stay inside the LDS");
   // forward pass (one wave; overlays the backward working set): two staged rows, x_k, x_{k+1}, alpha, it
   static constexpr int fx = 2 * ROW;
@@ -177,7 +184,11 @@ constexpr int kd_mask(int KD, int c) {
 
 // a.scratch must hold T_steps rows of OLCfg::ROW elements (ROW_FAT when a.costates).  a.P is written as zero (:96-102).
 // Executed by a workgroup of OLCfg::NT threads (one wave per player).
-template <typename T, int NX, int NP, int MU>
+// CMP: the step's [A | B | Q_i | l_i | R | r] come from compact rows (LQArgs::compact, ilqg_common.hpp) instead of the
+// dense arrays: the row of step k - 2 is DMA'd into a staging row during step k; behind barrier 1 of step k - 1 all
+// waves scatter its shared words (A, B, R, r) into the images of that parity — whose constants were written once —
+// and at the end of step k - 1 every player wave clears its tile and scatters its own Q_i | l_i words into it.
+template <typename T, int NX, int NP, int MU, bool CMP = false>
 __device__ __forceinline__ void lq_openloop_instance(const LQArgs<T>& a, const PairTable& pt, T* sm) {
   using C = LQCfg<T, NX, NP, MU>;
   using O = OLCfg<T, NX, NP, MU>;
@@ -261,6 +272,53 @@ __device__ __forceinline__ void lq_openloop_instance(const LQArgs<T>& a, const P
   };
   auto lds_drain = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
 
+  // ---- compact rows (CMP) ----
+  // A word's destination: space << 16 | offset; space 0 = the A image, 1 = the [B | R | r] image, 2 + i = player i's tile.
+  T* const sSB = sm + O::oSB;
+  int* const sCD = reinterpret_cast<int*>(sm + O::oCD);
+  int* const sBGc = reinterpret_cast<int*>(sm + O::oBGc);
+  T* const sBGv = sm + O::oBGv;
+  const int CWD = CMP ? a.compact_tab[RC_W] : 0;
+  int nbg_tile = 0;  // entries of (sBGc, sBGv): the tiles' non-zero constants
+  auto cdecode = [&](int code) -> int {
+    const int arr = code >> 24, off = code & 0xffffff;
+    if (arr == RA_A) return (0 << 16) | ((off % NX) + LD * (off / NX));
+    if (arr == RA_B) return (1 << 16) | off;
+    if (arr == RA_R) return (1 << 16) | (BOFF_R + off);
+    if (arr == RA_r) return (1 << 16) | (BOFF_r + off);
+    if (arr == RA_Q) {
+      const int i = off / (NX * NX), wd = off - i * NX * NX;
+      return ((2 + i) << 16) | ((wd % NX) + LD * (wd / NX));
+    }
+    const int i = off / NX;  // RA_L
+    return ((2 + i) << 16) | ((off - i * NX) + LD * NX);
+  };
+  auto crow_dma = [&](int k) {  // compact row k -> its staging row, all waves share the pieces
+    dma_g2l<64 * NP, false>(a.compact + size_t(k) * CWD, sSB + (k & 1) * kCompactMaxWords, CWD * S, wp * 64 + lane);
+  };
+  // the shared words (A, B, R, r) of staged row k into the images of its parity: every thread its words
+  auto scatter_shared = [&](int k) {
+    const T* row = sSB + (k & 1) * kCompactMaxWords;
+    for (int c = t; c < CWD; c += NT) {
+      const int code = sCD[c], sp = code >> 16, off = code & 0xffff;
+      const T v = row[c];
+      if (sp == 0) aimg(k & 1)[off] = v;
+      if (sp == 1) bimg(k & 1)[off] = v;
+    }
+  };
+  // this wave's tile <- Qa_i of staged row k: cleared, its constants, its words
+  auto fill_tile = [&](int k) {
+    for (int e = lane; e < MAT; e += 64) sZ[e] = T(0);
+    lds_sync(true);
+    for (int e = lane; e < nbg_tile; e += 64)
+      if ((sBGc[e] >> 16) == 2 + wp) sZ[sBGc[e] & 0xffff] = sBGv[e];
+    const T* row = sSB + (k & 1) * kCompactMaxWords;
+    for (int c = lane; c < CWD; c += 64) {
+      const int code = sCD[c];
+      if ((code >> 16) == 2 + wp) sZ[code & 0xffff] = row[c];
+    }
+  };
+
   // this lane's offsets into accumulator-layout operands (plain / transposed) for the three leading dimensions
   const int oD = tile_lane_offset<T, false>(LD, g, j), oT = tile_lane_offset<T, true>(LD, g, j);
   const int oDn = tile_lane_offset<T, false>(NX, g, j), oTn = tile_lane_offset<T, true>(NX, g, j);
@@ -287,14 +345,51 @@ __device__ __forceinline__ void lq_openloop_instance(const LQArgs<T>& a, const P
   // ---- once per sweep: zero the tiles' padding, the homogeneous column of both Aa images ----
   static_assert(O::oZ == O::oA + 2 * MAT, "the Aa images and the tiles are zeroed in one piece");
   for (int e = t; e < (NP + 2) * MAT; e += NT) sm[O::oA + e] = T(0);
+  if constexpr (CMP) {
+    for (int e = t; e < 2 * O::BIMG; e += NT) sm[O::oB + e] = T(0);
+    for (int c = t; c < kCompactMaxWords; c += NT) sCD[c] = c < CWD ? cdecode(a.compact_tab[RC_BASE + NP + 1 + c]) : -1;
+  }
   lds_sync(false);
   if (t < 2) aimg(t)[NX + LD * NX] = T(1);
+  if constexpr (CMP) {
+    // the constants: those of A and B go into both images once; those of the tiles into the LDS list fill_tile reads
+    const int nbg = a.compact_tab[RC_NBG];
+    const int* bg = a.compact_tab + RC_BASE + NP + 1 + CWD;
+    int nt = 0;
+    for (int e = 0; e < nbg; e++) {  // every thread walks the (short) list: the tile entries keep their list order
+      const int code = cdecode(bg[RC_BG_WORDS * e]), kind = bg[RC_BG_WORDS * e + 1];
+      const T v = kind == RC_DT ? T(a.dt) : (kind == RC_NEG_DT ? T(-a.dt) : T(__int_as_float(bg[RC_BG_WORDS * e + 2])));
+      const int sp = code >> 16, off = code & 0xffff;
+      if (sp == 0 && t < 2) aimg(t)[off] = v;
+      if (sp == 1 && t < 2) bimg(t)[off] = v;
+      if (sp >= 2) {
+        if (t == 0 && nt < kCompactMaxBg) {
+          sBGc[nt] = code;
+          sBGv[nt] = v;
+        }
+        nt++;
+      }
+    }
+    nbg_tile = nt < kCompactMaxBg ? nt : kCompactMaxBg;
+  }
   lds_sync(false);
 
   // ---- terminal step (:105-108): Ma_i = Qa_i[T-1] ----
-  issue_Q(Tn - 1);
-  if (Tn >= 2) issue_shared(Tn - 2);
-  dma_wait();
+  if constexpr (CMP) {
+    crow_dma(Tn - 1);
+    if (Tn >= 2) crow_dma(Tn - 2);
+    dma_wait();
+    lds_sync(false);
+    fill_tile(Tn - 1);
+    if (Tn >= 2) scatter_shared(Tn - 2);
+    lds_sync(false);
+    if (Tn >= 3) crow_dma(Tn - 3);  // into row T-1's staging row, whose words have all been placed
+    dma_wait();
+  } else {
+    issue_Q(Tn - 1);
+    if (Tn >= 2) issue_shared(Tn - 2);
+    dma_wait();
+  }
   lds_sync(false);
   // Q_i l_i of a step (expected decrease, ilq_solver.cpp:392) -> scratch row, and M_i, m_i when costates are wanted;
   // both read this wave's tile
@@ -327,7 +422,12 @@ __device__ __forceinline__ void lq_openloop_instance(const LQArgs<T>& a, const P
   if (a.costates) store_row_from_tile(Tn - 1, false);  // M[T-1] = Q[T-1]: the tile holds both
   lds_sync(true);
   lds_drain();  // the tile has been read: the DMA engine may refill it
-  if (Tn >= 2) issue_Q(Tn - 2);
+  if (Tn >= 2) {
+    if constexpr (CMP)
+      fill_tile(Tn - 2);
+    else
+      issue_Q(Tn - 2);
+  }
 #pragma unroll 1
   for (int k = Tn - 2; k >= 0; k--) {
     const T* sB = bimg(k & 1);
@@ -385,7 +485,12 @@ __device__ __forceinline__ void lq_openloop_instance(const LQArgs<T>& a, const P
     PH(0);
     // Every wave has left step k + 1 behind: the images of the other parity (last read there) are free for the next
     // step's A, [B | R | r].  The loads are waited for in front of barrier 2, which publishes them to the other waves.
-    if (k > 0) issue_shared(k - 1);
+    if constexpr (CMP) {
+      if (k > 0) scatter_shared(k - 1);  // staged a step ago (or before the loop), published by barrier 2 there
+      if (k > 1) crow_dma(k - 2);        // into row k's staging row: its last word was placed at the end of step k + 1
+    } else {
+      if (k > 0) issue_shared(k - 1);
+    }
     // ---- K [Z | z] = [V A | g] (wave 0, column per lane) ----
     if (w == 0) {
       T col[M], x[M];
@@ -485,7 +590,12 @@ __device__ __forceinline__ void lq_openloop_instance(const LQArgs<T>& a, const P
     if (a.costates) store_row_from_tile(k, false);
     lds_sync(true);
     lds_drain();  // the tile has been read: the DMA engine may refill it
-    if (k > 0) issue_Q(k - 1);
+    if (k > 0) {
+      if constexpr (CMP)
+        fill_tile(k - 1);
+      else
+        issue_Q(k - 1);
+    }
     PH(4);
   }
 

@@ -777,7 +777,8 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const s
 // ---------------------------------------------------------------------------
 // KIND: which sweep this kernel instantiation carries (one each, so that the register allocation of one does not
 // pay for the others): LQ_VALU_FEEDBACK, LQ_PLAYER_WAVES (PW above) or LQ_OPEN_LOOP.
-enum { LQ_VALU_FEEDBACK = 0, LQ_PLAYER_WAVES = 1, LQ_OPEN_LOOP = 2 };
+enum { LQ_VALU_FEEDBACK = 0, LQ_PLAYER_WAVES = 1, LQ_OPEN_LOOP = 2, LQ_PLAYER_WAVES_PACKED = 3, LQ_OPEN_LOOP_COMPACT = 4 };
+// _PACKED: ilqg_api.hip; _COMPACT: the open-loop sweep reading compact rows (its own instantiation: register budget)
 template <typename T, int NX, int NP, int MU, int KIND>
 __device__ __forceinline__ void lq_part_instance(const DevProblem& p, const SolveArgs<T>& sa, int b, T* sm) {
   const int Tn = p.T;
@@ -797,13 +798,14 @@ __device__ __forceinline__ void lq_part_instance(const DevProblem& p, const Solv
   la.x0 = nullptr;
   la.P = sacc ? sa.P + size_t(b) * Tn * p.m * p.n : w + L.P1;  // strategy buffer 1 - sacc
   la.alpha = sacc ? sa.alpha + size_t(b) * Tn * p.m : w + L.al1;
-  const bool defer = sa.defer_forward && KIND != LQ_OPEN_LOOP;
+  constexpr bool kOL = KIND == LQ_OPEN_LOOP || KIND == LQ_OPEN_LOOP_COMPACT;
+  const bool defer = sa.defer_forward && !kOL;
   la.dx = defer ? nullptr : w + L.dx;
   la.defer_forward = defer ? 1 : 0;
   la.scratch = w + L.lqscr;
   // where the sweep leaves the expected decrease: an LDS slot that is free once it ends (feedback sweeps), or
   // one past the open-loop sweep's own working set (the launch reserves it)
-  constexpr int ed_slot = (KIND == LQ_OPEN_LOOP) ? OLCfg<T, NX, NP, MU>::LDS_ELEMS
+  constexpr int ed_slot = kOL ? OLCfg<T, NX, NP, MU>::LDS_ELEMS
                           : (KIND == LQ_PLAYER_WAVES && !LQCfg<T, NX, NP, MU>::MFMA_ONE_TILE) ? FB2Cfg<T, NX, NP, MU>::LDS_ELEMS
                                                                                               : LQCfg<T, NX, NP, MU>::oX;
   la.ed_out = defer ? nullptr : sm + ed_slot;
@@ -811,7 +813,7 @@ __device__ __forceinline__ void lq_part_instance(const DevProblem& p, const Solv
   la.adaptive = 1;
   la.symmetric = 1;  // linquad_compute writes H(x,y) and H(y,x) from the same value
   la.prio_div = KIND == LQ_PLAYER_WAVES ? sa.prio_div : 0;
-  if (sa.compact && KIND == LQ_PLAYER_WAVES) {
+  if (sa.compact && (KIND == LQ_PLAYER_WAVES || KIND == LQ_OPEN_LOOP_COMPACT)) {
     la.compact = w + L.Q;
     la.compact_tab = p.row_prog + p.rp_compact_off;
     la.dt = p.dt;
@@ -824,6 +826,8 @@ __device__ __forceinline__ void lq_part_instance(const DevProblem& p, const Solv
     lq_feedback_instance_mfma<T, NX, NP, MU>(la, p.pairs, sm);
   } else if constexpr (KIND == LQ_OPEN_LOOP) {
     lq_openloop_instance<T, NX, NP, MU>(la, p.pairs, sm);  // SolverParams::open_loop (ilq_solver.h:76-81)
+  } else if constexpr (KIND == LQ_OPEN_LOOP_COMPACT) {
+    lq_openloop_instance<T, NX, NP, MU, true>(la, p.pairs, sm);
   } else {
     lq_feedback_instance<T, NX, NP, MU>(la, p.pairs, sm);
   }
