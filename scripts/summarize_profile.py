@@ -1,5 +1,6 @@
 """Turns the rocprofv3 databases of scripts/profile.sh into the text summaries kept under profiles/."""
 import json
+import re
 import os
 import sqlite3
 import sys
@@ -91,7 +92,8 @@ try:
             sel = [r for r in rows if r[0] == nm]
             top = max(r[2] for r in sel)
             sel = [r for r in sel if r[2] > 0.2 * top]
-            short = nm.split("(")[0].split("::")[-1].split("<")[0]
+            mm = re.search(r"(ilq_\w+?_kernel)", nm)
+            short = mm.group(1) if mm else nm[:40]
             tr.setdefault(short, {})[cname] = statistics.median(r[2] for r in sel) * 1024.0
     total = sum(2.0 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0) for v in tr.values())
     out.append("\n## HBM traffic per round (2 x FETCH_SIZE + WRITE_SIZE over the round's kernels, profiles/r03_counter_calibration.md)\n\n```json\n%s\n```"
