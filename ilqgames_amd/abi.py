@@ -25,6 +25,13 @@ DYN_POINT_MASS_2D = 9  # (px, py, vx, vy), u = (ax, ay)
  CONSTRAINT_SINGLE_DIMENSION) = range(1, 10)
 COST_POLYLINE2_SIGNED_DISTANCE = 10
 COST_QUADRATIC_DIFFERENCE = 11
+COST_ORIENTATION = 12
+COST_QUADRATIC_NORM = 13
+COST_SEMIQUADRATIC_NORM = 14
+COST_RELATIVE_DISTANCE = 15
+COST_LOCALLY_CONVEX_PROXIMITY = 16
+COST_CURVATURE = 17
+CONSTRAINT_POLYLINE2_SIGNED_DISTANCE = 18
 # ilqg_cost_role
 ROLE_STATE_COST, ROLE_CONTROL_COST, ROLE_STATE_CONSTRAINT, ROLE_CONTROL_CONSTRAINT, ROLE_CHILD = range(5)
 FLAG_ORIENTED, FLAG_IS_MIN = 1, 2
@@ -201,6 +208,40 @@ class ProblemSpec:
 
     def quadratic_difference(self, player, weight, dims1, dims2):
         return self._term(COST_QUADRATIC_DIFFERENCE, ROLE_STATE_COST, player, -1, tuple(dims1) + tuple(dims2), weight)
+
+    # --- the rest of the reference's cost / constraint zoo that fits the device's scatter patterns ---
+    def orientation(self, player, weight, dim, nominal=0.0):
+        """OrientationCost (src/orientation_cost.cpp:50-80)."""
+        return self._term(COST_ORIENTATION, ROLE_STATE_COST, player, -1, (dim,), weight, nominal)
+
+    def quadratic_norm(self, player, weight, dims, nominal=0.0, control_of=None):
+        """QuadraticNormCost (src/quadratic_norm_cost.cpp:50-94)."""
+        role, arg = (ROLE_STATE_COST, -1) if control_of is None else (ROLE_CONTROL_COST, control_of)
+        return self._term(COST_QUADRATIC_NORM, role, player, arg, tuple(dims), weight, nominal)
+
+    def semiquadratic_norm(self, player, weight, dims, threshold, oriented_right, control_of=None):
+        """SemiquadraticNormCost (src/semiquadratic_norm_cost.cpp:50-99)."""
+        role, arg = (ROLE_STATE_COST, -1) if control_of is None else (ROLE_CONTROL_COST, control_of)
+        return self._term(COST_SEMIQUADRATIC_NORM, role, player, arg, tuple(dims), weight, threshold,
+                          FLAG_ORIENTED if oriented_right else 0)
+
+    def relative_distance(self, player, weight, xy1, xy2):
+        """RelativeDistanceCost (src/relative_distance_cost.cpp:50-104)."""
+        return self._term(COST_RELATIVE_DISTANCE, ROLE_STATE_COST, player, -1, tuple(xy1) + tuple(xy2), weight)
+
+    def locally_convex_proximity(self, player, weight, xy1, xy2, threshold):
+        """LocallyConvexProximityCost (src/locally_convex_proximity_cost.cpp:50-108)."""
+        return self._term(COST_LOCALLY_CONVEX_PROXIMITY, ROLE_STATE_COST, player, -1, tuple(xy1) + tuple(xy2), weight,
+                          threshold)
+
+    def curvature(self, player, weight, omega_idx, v_idx):
+        """CurvatureCost (src/curvature_cost.cpp:50-86)."""
+        return self._term(COST_CURVATURE, ROLE_STATE_COST, player, -1, (omega_idx, v_idx), weight)
+
+    def polyline2_signed_distance_constraint(self, player, polyline, xy, threshold, keep_left):
+        """Polyline2SignedDistanceConstraint (src/polyline2_signed_distance_constraint.cpp:52-144)."""
+        return self._term(CONSTRAINT_POLYLINE2_SIGNED_DISTANCE, ROLE_STATE_CONSTRAINT, player, -1, xy, 1.0, threshold,
+                          FLAG_ORIENTED if keep_left else 0, polyline, constraint=True)
 
     def extreme_value(self, player, children, is_min):
         """children: list of callables(role) -> term index, created contiguously as CHILD terms."""

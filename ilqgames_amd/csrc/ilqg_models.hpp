@@ -363,6 +363,14 @@ __device__ __forceinline__ T constraint_mu(T lambda, T g, T mu) {
   return (g <= T(1e-4f) && t_abs(lambda) <= T(1e-4f)) ? T(0) : mu;
 }
 
+// OrientationCost's wrapped heading error, src/orientation_cost.cpp:54-55: the difference is taken in the argument's
+// precision, pi is added and the remainder taken in double (M_PI is a double there).
+template <typename T>
+__device__ __forceinline__ T orientation_difference(T angle, T nominal) {
+  const double kPi = 3.14159265358979323846;
+  return T(fmod(double(angle - nominal) + kPi, kPi * 2.0) - kPi);
+}
+
 // `v` is anything indexable that yields the argument vector's entries: a pointer (LDS / global row) or the
 // transposed-row accessor of the lane-per-time-step stage (ilqg_rows.hpp).
 template <typename T, typename V>
@@ -427,6 +435,37 @@ __device__ __forceinline__ T term_evaluate_leaf_of(const QuadTables<T>& tb, cons
     }
     case ILQG_CONSTRAINT_SINGLE_DIMENSION:  // single_dimension_constraint.h:68-70
       return oriented ? v[c.idx[0]] - val : val - v[c.idx[0]];
+    case ILQG_COST_ORIENTATION: {  // src/orientation_cost.cpp:50-58
+      const T diff = orientation_difference<T>(v[c.idx[0]], val);
+      return T(0.5) * w * diff * diff;
+    }
+    case ILQG_COST_QUADRATIC_NORM: {  // src/quadratic_norm_cost.cpp:52-57
+      const T diff = t_hypot(v[c.idx[0]], v[c.idx[1]]) - val;
+      return T(0.5) * w * diff * diff;
+    }
+    case ILQG_COST_SEMIQUADRATIC_NORM: {  // src/semiquadratic_norm_cost.cpp:52-59
+      const T diff = t_hypot(v[c.idx[0]], v[c.idx[1]]) - val;
+      if ((diff > T(0) && oriented) || (diff < T(0) && !oriented)) return T(0.5) * w * diff * diff;
+      return T(0);
+    }
+    case ILQG_COST_RELATIVE_DISTANCE:  // src/relative_distance_cost.cpp:48-54
+      return w * t_hypot(v[c.idx[0]] - v[c.idx[2]], v[c.idx[1]] - v[c.idx[3]]);
+    case ILQG_COST_LOCALLY_CONVEX_PROXIMITY: {  // src/locally_convex_proximity_cost.cpp:50-60
+      const T dx = v[c.idx[0]] - v[c.idx[2]], dy = v[c.idx[1]] - v[c.idx[3]];
+      if (dx * dx >= val * val || dy * dy >= val * val) return T(0);
+      const T ax = val - t_abs(dx), ay = val - t_abs(dy);
+      const T sx = ax * ax, sy = ay * ay;
+      return T(0.5) * w * (sy < sx ? sy : sx);
+    }
+    case ILQG_COST_CURVATURE: {  // src/curvature_cost.cpp:50-53
+      const T curvature = v[c.idx[0]] / v[c.idx[1]];
+      return T(0.5) * w * curvature * curvature;
+    }
+    case ILQG_CONSTRAINT_POLYLINE2_SIGNED_DISTANCE: {  // src/polyline2_signed_distance_constraint.cpp:57-69
+      const Closest<T> cl = polyline_closest<T>(tb, c.polyline, v[c.idx[0]], v[c.idx[1]]);
+      const T value = sgn(cl.ssd) * t_sqrt(t_abs(cl.ssd)) - val;
+      return oriented ? value : -value;
+    }
   }
   return T(0);
 }
@@ -659,6 +698,103 @@ __device__ __forceinline__ void term_compute_leaf(const QuadTables<T>& tb, const
       o->pattern = PAT_SINGLE;
       o->gx = dx;
       o->hxx = ddx;
+      return;
+    }
+    case ILQG_COST_ORIENTATION: {  // src/orientation_cost.cpp:50-80
+      const T diff = orientation_difference<T>(v[c.idx[0]], val);
+      o->value = T(0.5) * w * diff * diff;
+      o->pattern = PAT_SINGLE;
+      o->gx = w * diff;
+      o->hxx = w;
+      return;
+    }
+    case ILQG_COST_QUADRATIC_NORM:        // src/quadratic_norm_cost.cpp:52-94
+    case ILQG_COST_SEMIQUADRATIC_NORM: {  // src/semiquadratic_norm_cost.cpp:52-99
+      const bool semi = c.kind == ILQG_COST_SEMIQUADRATIC_NORM;
+      const T x = v[c.idx[0]], y = v[c.idx[1]];
+      const T hyp = t_hypot(x, y);
+      const T diff = hyp - val;
+      if (!semi || (diff > T(0) && oriented) || (diff < T(0) && !oriented)) o->value = T(0.5) * w * diff * diff;
+      if (semi && ((hyp > val && !oriented) || (hyp < val && oriented))) return;
+      // the norm of the derivatives: hypot and norm * norm^2 in the one-sided cost, sqrt(x^2 + y^2) and norm * (x^2 +
+      // y^2) in the two-sided one (quadratic_norm_cost.cpp:75-77, semiquadratic_norm_cost.cpp:75, 81-82)
+      const T norm_sq_q = x * x + y * y;
+      const T norm = semi ? hyp : t_sqrt(norm_sq_q);
+      const T norm3 = norm * (semi ? norm * norm : norm_sq_q);
+      o->pattern = PAT_PAIR2;
+      o->gx = -w * x * (T(-1) + val / norm);
+      o->gy = -w * y * (T(-1) + val / norm);
+      o->hxx = w - (val * y * y * w) / norm3;
+      o->hyy = w - (val * x * x * w) / norm3;
+      o->hxy = val * x * y * w / norm3;
+      return;
+    }
+    case ILQG_COST_RELATIVE_DISTANCE: {  // src/relative_distance_cost.cpp:48-104
+      const T ex = v[c.idx[0]] - v[c.idx[2]], ey = v[c.idx[1]] - v[c.idx[3]];
+      const T dist = t_hypot(ex, ey);
+      o->value = w * dist;
+      const T dist3 = dist * dist * dist;
+      o->pattern = PAT_PAIR4;
+      o->gx = w * ex / dist;
+      o->gy = w * ey / dist;
+      o->hxx = w * ey * ey / dist3;
+      o->hyy = w * ex * ex / dist3;
+      o->hxy = -w * ex * ey / dist3;
+      return;
+    }
+    case ILQG_COST_LOCALLY_CONVEX_PROXIMITY: {  // src/locally_convex_proximity_cost.cpp:50-108
+      const T dx = v[c.idx[0]] - v[c.idx[2]], dy = v[c.idx[1]] - v[c.idx[3]];
+      if (dx * dx >= val * val || dy * dy >= val * val) return;
+      const T ax = val - t_abs(dx), ay = val - t_abs(dy);
+      const T sx = ax * ax, sy = ay * ay;
+      o->value = T(0.5) * w * (sy < sx ? sy : sx);
+      o->pattern = PAT_PAIR4;  // one axis only: the other one's entries get an exact +-0
+      if (sx < sy) {
+        o->gx = -w * ax; o->hxx = w;
+      } else {
+        o->gy = -w * ay; o->hyy = w;
+      }
+      return;
+    }
+    case ILQG_COST_CURVATURE: {  // src/curvature_cost.cpp:50-86: idx = (omega, v)
+      const T omega = v[c.idx[0]], vel = v[c.idx[1]];
+      const T curvature = omega / vel;
+      o->value = T(0.5) * w * curvature * curvature;
+      const T one_over_vsq = T(1) / (vel * vel);
+      const T weight_over_vsq = w * one_over_vsq;
+      const T weight_omega_over_vsq = omega * weight_over_vsq;
+      o->pattern = PAT_PAIR2;
+      o->gx = weight_omega_over_vsq;
+      o->gy = -weight_omega_over_vsq * omega / vel;
+      o->hxx = weight_over_vsq;
+      o->hxy = T(-2) * weight_omega_over_vsq / vel;
+      o->hyy = T(3) * weight_omega_over_vsq * omega * one_over_vsq;
+      return;
+    }
+    case ILQG_CONSTRAINT_POLYLINE2_SIGNED_DISTANCE: {  // src/polyline2_signed_distance_constraint.cpp:57-144
+      const T x = v[c.idx[0]], y = v[c.idx[1]];
+      Closest<T> cl;
+      if constexpr (HAVE_PRE) cl = *pre; else cl = polyline_closest<T>(tb, c.polyline, x, y);
+      const T s = sgn(cl.ssd);
+      const T sign = oriented ? T(1) : T(-1);
+      const T sd = s * t_sqrt(t_abs(cl.ssd));
+      const T g = oriented ? sd - val : val - sd;
+      o->value = g;
+      T dx = sign * cl.seg.uy, ddx = T(0), dy = -sign * cl.seg.ux, ddy = T(0), dxdy = T(0);
+      if (cl.is_vertex) {
+        const T px = cl.cx, py = cl.cy;
+        const T rx = x - px, ry = y - py;
+        const T d_sq = rx * rx + ry * ry;
+        const T d = t_sqrt(d_sq);
+        dx = sign * s * rx / d;
+        ddx = sign * s * (d_sq - px * px - x * x + T(2) * px * x) / (d_sq * d);
+        dxdy = -sign * s * rx * ry / (d_sq * d);
+        dy = sign * s * ry / d;
+        ddy = sign * s * (d_sq - py * py - y * y + T(2) * py * y) / (d_sq * d);
+      }
+      modify_derivatives(lambda, mu, g, &dx, &ddx, &dy, &ddy, &dxdy);
+      o->pattern = PAT_PAIR2;
+      o->gx = dx; o->gy = dy; o->hxx = ddx; o->hyy = ddy; o->hxy = dxdy;
       return;
     }
   }

@@ -254,20 +254,27 @@ __host__ __device__ inline int term_pattern_of(int kind, int idx0) {
   switch (kind) {
     case ILQG_COST_QUADRATIC: return idx0 >= 0 ? PAT_SINGLE : PAT_ALL;
     case ILQG_COST_SEMIQUADRATIC:
+    case ILQG_COST_ORIENTATION:
     case ILQG_CONSTRAINT_SINGLE_DIMENSION: return PAT_SINGLE;
     case ILQG_COST_QUADRATIC_POLYLINE2:
     case ILQG_COST_SEMIQUADRATIC_POLYLINE2:
-    case ILQG_COST_POLYLINE2_SIGNED_DISTANCE: return PAT_PAIR2;
+    case ILQG_COST_POLYLINE2_SIGNED_DISTANCE:
+    case ILQG_COST_QUADRATIC_NORM:
+    case ILQG_COST_SEMIQUADRATIC_NORM:
+    case ILQG_COST_CURVATURE:
+    case ILQG_CONSTRAINT_POLYLINE2_SIGNED_DISTANCE: return PAT_PAIR2;
     case ILQG_COST_PROXIMITY:
     case ILQG_COST_SIGNED_DISTANCE:
     case ILQG_COST_QUADRATIC_DIFFERENCE:
+    case ILQG_COST_RELATIVE_DISTANCE:
+    case ILQG_COST_LOCALLY_CONVEX_PROXIMITY:
     case ILQG_CONSTRAINT_PROXIMITY: return PAT_PAIR4;
   }
   return PAT_NONE;
 }
 __host__ __device__ inline bool term_is_polyline(int kind) {
   return kind == ILQG_COST_QUADRATIC_POLYLINE2 || kind == ILQG_COST_SEMIQUADRATIC_POLYLINE2 ||
-         kind == ILQG_COST_POLYLINE2_SIGNED_DISTANCE;
+         kind == ILQG_COST_POLYLINE2_SIGNED_DISTANCE || kind == ILQG_CONSTRAINT_POLYLINE2_SIGNED_DISTANCE;
 }
 
 // Polyline2::ClosestPoint (src/polyline2.cpp:105-174) with the segment table in scalar memory: the same scan as

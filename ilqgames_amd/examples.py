@@ -604,6 +604,53 @@ def two_player_unicycle_4d_scene(T=100, dt=0.1):
     return s
 
 
+def cost_zoo_scene(T=100, dt=0.1):
+    """A test scene, NOT a reference example: the two crossing Car5D of the skeleton example (n=10) carrying the cost
+    and constraint kinds no reference example in CONFIGS uses — OrientationCost, QuadraticNormCost,
+    SemiquadraticNormCost (on a state pair and on a control pair), RelativeDistanceCost, LocallyConvexProximityCost,
+    CurvatureCost and Polyline2SignedDistanceConstraint — so that every stage kernel and the whole solve are compared
+    with the restatement on them.  CurvatureCost reads (phi, v) here: the reference pairs it with a yaw-rate state
+    (Unicycle5D / Car7D); only its (omega_idx, v_idx) pattern matters to the kernels."""
+    prm = SolverParams.default()
+    prm.max_backtracking_steps = 100
+    prm.initial_alpha_scaling = 0.1
+    prm.convergence_tolerance = 0.01
+    prm.expected_decrease_fraction = 0.001
+    s = ProblemSpec(T, dt, prm)
+    for _ in range(2):
+        s.add_player(DYN_CAR_5D, 4.0)
+    X, Y, H, PHI, V = [0, 5], [1, 6], [2, 7], [3, 8], [4, 9]
+    for i in range(2):
+        s.quadratic(i, 25.0, 0, 0.0, control_of=i)  # omega
+        s.quadratic(i, 15.0, 1, 0.0, control_of=i)  # acceleration
+        s.semiquadratic_norm(i, 40.0, (0, 1), 1.5, True, control_of=i)  # (QuadraticNormCost is singular at u = 0)
+    s.quadratic(0, 10.0, V[0], 8.0)
+    s.quadratic(1, 10.0, V[1], 8.0)
+    lane1 = s.add_polyline([(0.0, -1000.0), (0.0, 1000.0)])
+    lane2 = s.add_polyline([(-5.0, 1000.0), (-5.0, 5.0), (0.0, 0.0), (995.0, 0.0)])
+    wall = s.add_polyline([(3.0, -1000.0), (3.0, -10.0), (0.2, 0.0), (3.0, 10.0), (3.0, 1000.0)])  # bulges into lane 1
+    s.quadratic_polyline2(0, 25.0, lane1, (X[0], Y[0]))
+    s.quadratic_polyline2(1, 25.0, lane2, (X[1], Y[1]))
+    s.orientation(0, 5.0, H[0], float(np.float32(np.pi / 2)))
+    s.orientation(1, 2.0, H[1], -1.0)
+    s.quadratic_norm(0, 0.5, (X[0], Y[0]), 40.0)          # stay on a circle of radius 40 about the origin
+    s.semiquadratic_norm(1, 0.5, (X[1], Y[1]), 45.0, True)  # and the other car inside radius 45
+    s.semiquadratic_norm(1, 0.5, (X[1], Y[1]), 2.0, False)  # but not at the origin
+    s.relative_distance(1, 1.0, (X[1], Y[1]), (X[0], Y[0]))
+    for i in range(2):
+        s.locally_convex_proximity(i, 50.0, (X[i], Y[i]), (X[1 - i], Y[1 - i]), 6.0)
+        s.curvature(i, 20.0, PHI[i], V[i])
+    s.polyline2_signed_distance_constraint(0, wall, (X[0], Y[0]), -0.5, True)
+    s.polyline2_signed_distance_constraint(1, lane1, (X[1], Y[1]), -60.0, False)
+    f = np.float32
+    x0 = np.zeros(10)
+    x0[[X[0], Y[0], H[0], V[0]]] = [0.0, -30.0, float(f(np.pi / 2)), 4.0]
+    x0[[X[1], Y[1], H[1], V[1]]] = [-5.0, 30.0, float(f(-np.pi / 2)), 3.0]
+    s.x0 = x0
+    s.position_dims, s.heading_dims, s.speed_dims = list(zip(X, Y)), H, V
+    return s
+
+
 def jittered_x0(spec, batch, seed=0):
     """Per-instance initial states of SURVEY.md §8(d): U(-1,1) m on px,py, U(-0.1,0.1) rad
     heading, U(-0.5,0.5) m/s speed; instance b uses numpy default_rng(seed + b)."""
@@ -634,6 +681,7 @@ CONFIGS = {
     "two_player_reachability": two_player_reachability,
     "two_player_collision_avoidance_reachability": two_player_collision_avoidance_reachability,
     "skeleton": skeleton,
+    "cost_zoo_scene": cost_zoo_scene,
     "air_3d": air_3d,
     "modified_air_3d": modified_air_3d,
     "dubins_origin": dubins_origin,

@@ -223,6 +223,32 @@ bool QuadraticDifferenceCost::Describe(host::TermDescription* out) const {
   FillTerm(out, ILQG_COST_QUADRATIC_DIFFERENCE, weight_, 0.0f, 0, {dims1_[0], dims1_[1], dims2_[0], dims2_[1]});
   return true;
 }
+bool OrientationCost::Describe(host::TermDescription* out) const {
+  FillTerm(out, ILQG_COST_ORIENTATION, weight_, nominal_, 0, {dim_});
+  return true;
+}
+bool QuadraticNormCost::Describe(host::TermDescription* out) const {
+  FillTerm(out, ILQG_COST_QUADRATIC_NORM, weight_, nominal_, 0, {dim1_, dim2_});
+  return true;
+}
+bool SemiquadraticNormCost::Describe(host::TermDescription* out) const {
+  FillTerm(out, ILQG_COST_SEMIQUADRATIC_NORM, weight_, threshold_, oriented_right_ ? ILQG_FLAG_ORIENTED : 0,
+           {dim1_, dim2_});
+  return true;
+}
+bool RelativeDistanceCost::Describe(host::TermDescription* out) const {
+  FillTerm(out, ILQG_COST_RELATIVE_DISTANCE, weight_, 0.0f, 0,
+           {dims1_.first, dims1_.second, dims2_.first, dims2_.second});
+  return true;
+}
+bool LocallyConvexProximityCost::Describe(host::TermDescription* out) const {
+  FillTerm(out, ILQG_COST_LOCALLY_CONVEX_PROXIMITY, weight_, threshold_, 0, {xidx1_, yidx1_, xidx2_, yidx2_});
+  return true;
+}
+bool CurvatureCost::Describe(host::TermDescription* out) const {
+  FillTerm(out, ILQG_COST_CURVATURE, weight_, 0.0f, 0, {omega_idx_, v_idx_});
+  return true;
+}
 bool FinalTimeCost::Describe(host::TermDescription* out) const {
   if (!cost_->Describe(out) || out->term.kind == ILQG_COST_EXTREME_VALUE) return false;
   // the first step whose time ILQSolver hands to Evaluate / Quadraticize (RelativeTime(kk) = kk * kTimeStep,
@@ -244,6 +270,12 @@ bool ProximityConstraint::Describe(host::TermDescription* out) const {
 }
 bool SingleDimensionConstraint::Describe(host::TermDescription* out) const {
   FillTerm(out, ILQG_CONSTRAINT_SINGLE_DIMENSION, 1.0f, threshold_, keep_below_ ? ILQG_FLAG_ORIENTED : 0, {dim_});
+  return true;
+}
+bool Polyline2SignedDistanceConstraint::Describe(host::TermDescription* out) const {
+  FillTerm(out, ILQG_CONSTRAINT_POLYLINE2_SIGNED_DISTANCE, 1.0f, threshold_, keep_left_ ? ILQG_FLAG_ORIENTED : 0,
+           {xidx_, yidx_});
+  out->polyline = &polyline_;
   return true;
 }
 

@@ -163,8 +163,20 @@ typedef enum {
   ILQG_CONSTRAINT_SINGLE_DIMENSION = 9, /* include/ilqgames/constraint/single_dimension_constraint.h:57-103 */
   ILQG_COST_POLYLINE2_SIGNED_DISTANCE = 10, /* src/polyline2_signed_distance_cost.cpp:52-126: idx = (xidx, yidx),
                                               value = nominal, ORIENTED = oriented_same_as_polyline, weight unused */
-  ILQG_COST_QUADRATIC_DIFFERENCE = 11 /* src/quadratic_difference_cost.cpp:51-91 with two dimension pairs:
+  ILQG_COST_QUADRATIC_DIFFERENCE = 11, /* src/quadratic_difference_cost.cpp:51-91 with two dimension pairs:
                                          idx = (dims1[0], dims1[1], dims2[0], dims2[1]) */
+  ILQG_COST_ORIENTATION = 12,        /* src/orientation_cost.cpp:50-80: idx[0] = heading dimension, value = nominal;
+                                        0.5 w wrap(x - nominal)^2 with the difference wrapped into [-pi, pi) */
+  ILQG_COST_QUADRATIC_NORM = 13,     /* src/quadratic_norm_cost.cpp:50-94: idx = (dim1, dim2), value = nominal;
+                                        0.5 w (|(x[dim1], x[dim2])| - nominal)^2 */
+  ILQG_COST_SEMIQUADRATIC_NORM = 14, /* src/semiquadratic_norm_cost.cpp:50-99: the one-sided form; value = threshold,
+                                        ORIENTED = oriented_right */
+  ILQG_COST_RELATIVE_DISTANCE = 15,  /* src/relative_distance_cost.cpp:50-104: idx = (x1, y1, x2, y2); w |p1 - p2| */
+  ILQG_COST_LOCALLY_CONVEX_PROXIMITY = 16, /* src/locally_convex_proximity_cost.cpp:50-108: idx = (x1, y1, x2, y2),
+                                        value = threshold; 0.5 w min((thr - |dx|)^2, (thr - |dy|)^2) inside the box */
+  ILQG_COST_CURVATURE = 17,          /* src/curvature_cost.cpp:50-86: idx = (omega index, v index); 0.5 w (omega / v)^2 */
+  ILQG_CONSTRAINT_POLYLINE2_SIGNED_DISTANCE = 18 /* src/polyline2_signed_distance_constraint.cpp:52-144: idx = (x, y),
+                                        polyline, value = threshold, ORIENTED = keep_left */
 } ilqg_cost_kind;
 
 /* Where a term sits inside PlayerCost::Quadraticize (src/player_cost.cpp:194-215):

@@ -274,6 +274,93 @@ class QuadraticDifferenceCost : public TimeInvariantCost {
   const std::vector<Dimension> dims1_, dims2_;
 };
 
+// include/ilqgames/cost/orientation_cost.h:55-82 — 0.5 w d^2 with d the heading error wrapped into [-pi, pi).
+class OrientationCost : public TimeInvariantCost {
+ public:
+  OrientationCost(float weight, Dimension dim, float nominal = 0.0, const std::string& name = "")
+      : TimeInvariantCost(weight, name), dim_(dim), nominal_(nominal) {
+    CHECK_GE(dim_, 0);
+  }
+  bool Describe(host::TermDescription* out) const override;
+
+ private:
+  const Dimension dim_;
+  const float nominal_;
+};
+
+// include/ilqgames/cost/quadratic_norm_cost.h:56-88 — 0.5 w (|(x[d1], x[d2])| - nominal)^2
+class QuadraticNormCost : public TimeInvariantCost {
+ public:
+  QuadraticNormCost(float weight, const std::pair<Dimension, Dimension>& dims, float nominal = 0.0,
+                    const std::string& name = "")
+      : TimeInvariantCost(weight, name), dim1_(dims.first), dim2_(dims.second), nominal_(nominal) {
+    CHECK_GE(dim1_, 0);
+    CHECK_GE(dim2_, 0);
+  }
+  bool Describe(host::TermDescription* out) const override;
+
+ private:
+  const Dimension dim1_, dim2_;
+  const float nominal_;
+};
+
+// include/ilqgames/cost/semiquadratic_norm_cost.h:57-93 — the one-sided version of QuadraticNormCost.
+class SemiquadraticNormCost : public TimeInvariantCost {
+ public:
+  SemiquadraticNormCost(float weight, const std::pair<Dimension, Dimension>& dims, float threshold,
+                        bool oriented_right, const std::string& name = "")
+      : TimeInvariantCost(weight, name), dim1_(dims.first), dim2_(dims.second), threshold_(threshold),
+        oriented_right_(oriented_right) {
+    CHECK_GE(dim1_, 0);
+    CHECK_GE(dim2_, 0);
+  }
+  bool Describe(host::TermDescription* out) const override;
+
+ private:
+  const Dimension dim1_, dim2_;
+  const float threshold_;
+  const bool oriented_right_;
+};
+
+// include/ilqgames/cost/relative_distance_cost.h:55-78 — w |p1 - p2| (not squared).
+class RelativeDistanceCost : public TimeInvariantCost {
+ public:
+  RelativeDistanceCost(float weight, const std::pair<Dimension, Dimension>& dims1,
+                       const std::pair<Dimension, Dimension>& dims2, const std::string& name = "")
+      : TimeInvariantCost(weight, name), dims1_(dims1), dims2_(dims2) {}
+  bool Describe(host::TermDescription* out) const override;
+
+ private:
+  const std::pair<Dimension, Dimension> dims1_, dims2_;
+};
+
+// include/ilqgames/cost/locally_convex_proximity_cost.h:54-86 — 0.5 w min((thr - |dx|)^2, (thr - |dy|)^2) inside the
+// square |dx|, |dy| < thr around the other player.
+class LocallyConvexProximityCost : public TimeInvariantCost {
+ public:
+  LocallyConvexProximityCost(float weight, const std::pair<Dimension, Dimension>& position_idxs1,
+                             const std::pair<Dimension, Dimension>& position_idxs2, float threshold,
+                             const std::string& name = "")
+      : TimeInvariantCost(weight, name), threshold_(threshold), xidx1_(position_idxs1.first),
+        yidx1_(position_idxs1.second), xidx2_(position_idxs2.first), yidx2_(position_idxs2.second) {}
+  bool Describe(host::TermDescription* out) const override;
+
+ private:
+  const float threshold_;
+  const Dimension xidx1_, yidx1_, xidx2_, yidx2_;
+};
+
+// include/ilqgames/cost/curvature_cost.h:53-74 — 0.5 w (omega / v)^2
+class CurvatureCost : public TimeInvariantCost {
+ public:
+  CurvatureCost(float weight, Dimension omega_idx, Dimension v_idx, const std::string& name = "")
+      : TimeInvariantCost(weight, name), omega_idx_(omega_idx), v_idx_(v_idx) {}
+  bool Describe(host::TermDescription* out) const override;
+
+ private:
+  const Dimension omega_idx_, v_idx_;
+};
+
 // include/ilqgames/cost/final_time_cost.h:55-88 — another cost, switched on from `threshold_time` (relative to the
 // start of the window) onwards; zero value and derivatives before.
 class FinalTimeCost : public Cost {
@@ -353,14 +440,15 @@ class SingleDimensionConstraint : public TimeInvariantConstraint {
   bool keep_below_;
 };
 
-// include/ilqgames/constraint/polyline2_signed_distance_constraint.h:57-91 — constructible so
-// problem definitions that build one compile; it has no device kernel yet (Describe() is false).
+// include/ilqgames/constraint/polyline2_signed_distance_constraint.h:57-91 — g = signed distance to the polyline
+// minus a threshold, <= 0 when keep_left and >= 0 otherwise.
 class Polyline2SignedDistanceConstraint : public TimeInvariantConstraint {
  public:
   Polyline2SignedDistanceConstraint(const Polyline2& polyline, const std::pair<Dimension, Dimension>& dims,
                                     float threshold, bool keep_left, const std::string& name = "")
       : TimeInvariantConstraint(false, name), polyline_(polyline), xidx_(dims.first), yidx_(dims.second),
         threshold_(threshold), keep_left_(keep_left) {}
+  bool Describe(host::TermDescription* out) const override;
 
  private:
   Polyline2 polyline_;

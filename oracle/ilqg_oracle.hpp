@@ -702,6 +702,38 @@ S EvaluateTerm(const Problem<S>& p, int ti, const S* v, int dim) {
       if (!oriented) ssd *= S(-1);
       return sgn(ssd) * std::sqrt(std::abs(ssd)) - val;
     }
+    case ILQG_COST_ORIENTATION: {  // src/orientation_cost.cpp:50-58 (the wrap is computed in double there)
+      const S diff = S(std::fmod(double(v[c.idx[0]] - val) + M_PI, M_PI * 2.0) - M_PI);
+      return S(0.5) * w * diff * diff;
+    }
+    case ILQG_COST_QUADRATIC_NORM: {  // src/quadratic_norm_cost.cpp:50-57
+      const S diff = std::hypot(v[c.idx[0]], v[c.idx[1]]) - val;
+      return S(0.5) * w * diff * diff;
+    }
+    case ILQG_COST_SEMIQUADRATIC_NORM: {  // src/semiquadratic_norm_cost.cpp:50-59
+      const S diff = std::hypot(v[c.idx[0]], v[c.idx[1]]) - val;
+      if ((diff > S(0) && oriented) || (diff < S(0) && !oriented)) return S(0.5) * w * diff * diff;
+      return S(0);
+    }
+    case ILQG_COST_RELATIVE_DISTANCE: {  // src/relative_distance_cost.cpp:50-54
+      return w * std::hypot(v[c.idx[0]] - v[c.idx[2]], v[c.idx[1]] - v[c.idx[3]]);
+    }
+    case ILQG_COST_LOCALLY_CONVEX_PROXIMITY: {  // src/locally_convex_proximity_cost.cpp:50-60
+      const S dx = v[c.idx[0]] - v[c.idx[2]], dy = v[c.idx[1]] - v[c.idx[3]];
+      if (dx * dx >= val * val || dy * dy >= val * val) return S(0);
+      const S delta_x = val - std::abs(dx), delta_y = val - std::abs(dy);
+      return S(0.5) * w * std::min(delta_x * delta_x, delta_y * delta_y);
+    }
+    case ILQG_COST_CURVATURE: {  // src/curvature_cost.cpp:50-53, curvature_cost.h: omega / v
+      const S curvature = v[c.idx[0]] / v[c.idx[1]];
+      return S(0.5) * w * curvature * curvature;
+    }
+    case ILQG_CONSTRAINT_POLYLINE2_SIGNED_DISTANCE: {  // src/polyline2_signed_distance_constraint.cpp:52-63
+      S cx, cy, ssd;
+      p.polylines[c.polyline].ClosestPoint(v[c.idx[0]], v[c.idx[1]], &cx, &cy, nullptr, nullptr, &ssd, nullptr);
+      const S value = sgn(ssd) * std::sqrt(std::abs(ssd)) - val;
+      return oriented ? value : -value;
+    }
     case ILQG_COST_EXTREME_VALUE: {  // src/extreme_value_cost.cpp:51-85
       const bool is_min = c.flags & ILQG_FLAG_IS_MIN;
       S ext = is_min ? std::numeric_limits<S>::infinity() : -std::numeric_limits<S>::infinity();
@@ -951,6 +983,103 @@ void QuadraticizeTerm(const Problem<S>& p, int ti, double t, const S* v, int dim
       ModifyDerivatives(lambda, mu, g, &dx, &ddx);
       G[d] += dx;
       H(d, d) += ddx;
+      return;
+    }
+    case ILQG_COST_ORIENTATION: {  // src/orientation_cost.cpp:60-80
+      const int d = c.idx[0];
+      const S diff = S(std::fmod(double(v[d] - val) + M_PI, M_PI * 2.0) - M_PI);
+      G[d] += w * diff;
+      H(d, d) += w;
+      return;
+    }
+    case ILQG_COST_QUADRATIC_NORM:        // src/quadratic_norm_cost.cpp:59-94
+    case ILQG_COST_SEMIQUADRATIC_NORM: {  // src/semiquadratic_norm_cost.cpp:61-99
+      const int d1 = c.idx[0], d2 = c.idx[1];
+      const S x = v[d1], y = v[d2];
+      const bool semi = c.kind == ILQG_COST_SEMIQUADRATIC_NORM;
+      const S norm_sq = x * x + y * y;
+      const S norm = semi ? std::hypot(x, y) : std::sqrt(norm_sq);
+      if (semi && ((norm > val && !oriented) || (norm < val && oriented))) return;
+      const S norm3 = semi ? norm * (norm * norm) : norm * norm_sq;
+      const S dx = -w * x * (S(-1) + val / norm), dy = -w * y * (S(-1) + val / norm);
+      const S ddx = w - (val * y * y * w) / norm3, ddy = w - (val * x * x * w) / norm3;
+      const S dxdy = val * x * y * w / norm3;
+      G[d1] += dx; G[d2] += dy;
+      H(d1, d1) += ddx; H(d2, d2) += ddy; H(d1, d2) += dxdy; H(d2, d1) += dxdy;
+      return;
+    }
+    case ILQG_COST_RELATIVE_DISTANCE: {  // src/relative_distance_cost.cpp:56-104
+      const int x1 = c.idx[0], y1 = c.idx[1], x2 = c.idx[2], y2 = c.idx[3];
+      const S ex = v[x1] - v[x2], ey = v[y1] - v[y2];
+      const S dist = std::hypot(ex, ey);
+      const S dist3 = dist * dist * dist;
+      const S ddx = w * ey * ey / dist3, ddy = w * ex * ex / dist3, dxdy = -w * ex * ey / dist3;
+      H(x1, x1) += ddx; H(x1, y1) += dxdy; H(y1, x1) += dxdy; H(y1, y1) += ddy;
+      H(x2, x2) += ddx; H(x2, y2) += dxdy; H(y2, x2) += dxdy; H(y2, y2) += ddy;
+      H(x1, x2) -= ddx; H(x1, y2) -= dxdy; H(y1, x2) -= dxdy; H(y1, y2) -= ddy;
+      H(x2, x1) -= ddx; H(x2, y1) -= dxdy; H(y2, x1) -= dxdy; H(y2, y1) -= ddy;
+      const S dx = w * ex / dist, dy = w * ey / dist;
+      G[x1] += dx; G[y1] += dy; G[x2] -= dx; G[y2] -= dy;
+      return;
+    }
+    case ILQG_COST_LOCALLY_CONVEX_PROXIMITY: {  // src/locally_convex_proximity_cost.cpp:62-108
+      const int x1 = c.idx[0], y1 = c.idx[1], x2 = c.idx[2], y2 = c.idx[3];
+      const S dx = v[x1] - v[x2], dy = v[y1] - v[y2];
+      if (dx * dx >= val * val || dy * dy >= val * val) return;
+      const S delta_x = val - std::abs(dx), delta_y = val - std::abs(dy);
+      if (delta_x * delta_x < delta_y * delta_y) {  // as written there: the gradient carries no sign(dx)
+        const S dx1 = -w * delta_x;
+        G[x1] += dx1; G[x2] -= dx1;
+        H(x1, x1) += w; H(x2, x2) += w; H(x1, x2) -= w; H(x2, x1) -= w;
+      } else {
+        const S dy1 = -w * delta_y;
+        G[y1] += dy1; G[y2] -= dy1;
+        H(y1, y1) += w; H(y2, y2) += w; H(y1, y2) -= w; H(y2, y1) -= w;
+      }
+      return;
+    }
+    case ILQG_COST_CURVATURE: {  // src/curvature_cost.cpp:55-86
+      const int oi = c.idx[0], vi = c.idx[1];
+      const S vel = v[vi], omega = v[oi];
+      const S one_over_vsq = S(1) / (vel * vel);
+      const S weight_over_vsq = w * one_over_vsq;
+      const S weight_omega_over_vsq = omega * weight_over_vsq;
+      G[oi] += weight_omega_over_vsq;
+      G[vi] += -weight_omega_over_vsq * omega / vel;
+      H(oi, oi) += weight_over_vsq;
+      H(oi, vi) += S(-2) * weight_omega_over_vsq / vel;
+      H(vi, oi) += S(-2) * weight_omega_over_vsq / vel;
+      H(vi, vi) += S(3) * weight_omega_over_vsq * omega * one_over_vsq;
+      return;
+    }
+    case ILQG_CONSTRAINT_POLYLINE2_SIGNED_DISTANCE: {  // src/polyline2_signed_distance_constraint.cpp:65-144
+      const int xi = c.idx[0], yi = c.idx[1];
+      const S x = v[xi], y = v[yi];
+      S cx, cy, ssd;
+      bool is_vertex;
+      Segment2<S> seg;
+      p.polylines[c.polyline].ClosestPoint(x, y, &cx, &cy, &is_vertex, &seg, &ssd, nullptr);
+      const S s = sgn(ssd);
+      const S sign = oriented ? S(1) : S(-1);
+      const S sd = sgn(ssd) * std::sqrt(std::abs(ssd));
+      const S g = oriented ? sd - val : val - sd;
+      S dx = sign * seg.uy, ddx = 0, dy = -sign * seg.ux, ddy = 0, dxdy = 0;
+      if (is_vertex) {
+        const S px = cx, py = cy;
+        const S rx = x - px, ry = y - py;
+        const S d_sq = rx * rx + ry * ry;
+        const S d = std::sqrt(d_sq);
+        dx = sign * s * rx / d;
+        ddx = sign * s * (d_sq - px * px - x * x + S(2) * px * x) / (d_sq * d);
+        dxdy = -sign * s * rx * ry / (d_sq * d);
+        dy = sign * s * ry / d;
+        ddy = sign * s * (d_sq - py * py - y * y + S(2) * py * y) / (d_sq * d);
+      }
+      const S lambda = al ? al->lambda(c.constraint_slot, t) : S(0);
+      const S mu = al ? al->mu : S(10);
+      ModifyDerivatives(lambda, mu, g, &dx, &ddx, &dy, &ddy, &dxdy);
+      G[xi] += dx; G[yi] += dy;
+      H(xi, xi) += ddx; H(xi, yi) += dxdy; H(yi, xi) += dxdy; H(yi, yi) += ddy;
       return;
     }
   }

@@ -256,7 +256,8 @@ def _clean(ref, max_bt=12):
 @pytest.mark.parametrize("cfg", ["modified_three_player_intersection", "three_player_intersection",
                                  "three_player_collision_avoidance_reachability", "two_player_unicycle_4d_scene",
                                  "two_player_reachability", "skeleton", "three_player_overtaking",
-                                 "one_player_reachability", "dubins_origin", "air_3d", "modified_air_3d"])
+                                 "one_player_reachability", "dubins_origin", "air_3d", "modified_air_3d",
+                                 "cost_zoo_scene"])
 def test_ilq_solve_matches_oracle_fp64(hip, oracle, cfg):
     """Whole iLQ loop, fp64, fixed iteration count.  Where the line search is well conditioned the
     device makes the oracle's accept/reject decisions, so trajectories, strategies and costs agree
@@ -414,7 +415,8 @@ def test_augmented_lagrangian_solve_matches_oracle_fp64(hip, oracle):
                                           ("modified_three_player_intersection", False, abi.F32),
                                           ("three_player_intersection", True, abi.F64),
                                           ("roundabout_merging", False, abi.F64),
-                                          ("one_player_reachability", True, abi.F64)])
+                                          ("one_player_reachability", True, abi.F64),
+                                          ("cost_zoo_scene", True, abi.F64), ("cost_zoo_scene", False, abi.F32)])
 def test_split_trial_pass_is_the_fused_kernel_bit_for_bit(hip, cfg, al, dtype):
     """The three-launch form of the trial pass (rollout / rows / decision kernels, chosen by problem size or by
     ilqg_solve_options::split_trial) runs the same functions on the same data as the fused kernel: free-running solves — line
@@ -437,6 +439,26 @@ def test_split_trial_pass_is_the_fused_kernel_bit_for_bit(hip, cfg, al, dtype):
         for k in fused:
             assert np.array_equal(fused[k], other[k], equal_nan=True), k
     assert fused["iters"].max() >= 2
+
+
+def test_augmented_lagrangian_with_a_polyline_constraint_fp64(hip, oracle):
+    """Polyline2SignedDistanceConstraint through AugmentedLagrangianSolver (examples.cost_zoo_scene: a wall that bulges
+    into player 1's lane makes the constraint active mid-horizon, next to the other cost kinds of that scene)."""
+    spec = examples.cost_zoo_scene()
+    spec.params.max_solver_iters = 30
+    spec.params.unconstrained_solver_max_iters = 5
+    B = 12
+    x0 = examples.jittered_x0(spec, B, seed=21)
+    ref, stable = oracle_with_stability(oracle.OracleProblem(spec), abi.F64, x0, augmented_lagrangian=True)
+    out = hip.Problem(spec, abi.F64).solve(x0, augmented_lagrangian=True)
+    same = (_np(out["iters"]) == ref["iters"]) & (_np(out["status"]) == ref["status"])
+    assert stable.sum() >= 3, "the test instances are all decided by rounding"
+    assert (same & stable).sum() >= stable.sum() - 1, (same, stable, _np(out["iters"]), ref["iters"])
+    good = np.where(same & stable)[0]
+    for b in good:
+        assert rel_err(_np(out["xs"])[b], ref["xs"][b]) < 1e-6, b
+    assert rel_err(_np(out["costs"])[good], ref["costs"][good]) < 1e-6
+    assert np.isfinite(_np(out["xs"])).all()
 
 
 def test_augmented_lagrangian_single_player_dubins_fp64(hip, oracle):

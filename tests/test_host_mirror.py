@@ -154,6 +154,26 @@ def test_reference_example_source_compiles_unchanged_and_flattens_like_examples_
     assert got.num_constraints == want.num_constraints
 
 
+def test_cpp_cost_zoo_scene_flattens_like_examples_py(tmp_path):
+    """The mirrored classes of the kinds no reference example uses (OrientationCost, QuadraticNormCost,
+    SemiquadraticNormCost, RelativeDistanceCost, LocallyConvexProximityCost, CurvatureCost,
+    Polyline2SignedDistanceConstraint): tests/host/zoo_scene.h builds examples.cost_zoo_scene through them."""
+    entry.build_host()
+    exe = str(tmp_path / "dump_zoo")
+    _compile(exe, [os.path.join(ROOT, "tests", "host", "dump_example.cpp")],
+             ['-DEXAMPLE_HEADER="zoo_scene.h"', "-DEXAMPLE_CLASS=CostZooScene", "-I" + os.path.join(ROOT, "tests", "host")])
+    got = abi.ProblemSpec.from_dump(subprocess.check_output([exe], text=True))
+    want = examples.cost_zoo_scene()
+    g, w = got.canonical(), want.canonical()
+    for key in ("subsystems", "player_costs", "pairs", "T", "dt"):
+        assert g[key] == w[key], key
+    assert set(g["groups"]) == set(w["groups"])
+    for key in w["groups"]:
+        assert g["groups"][key] == w["groups"][key], key
+    np.testing.assert_allclose(np.array(got.x0, np.float32), np.array(want.x0, np.float32), rtol=1e-6, atol=1e-6)
+    assert got.num_constraints == want.num_constraints == 2
+
+
 # ------------------------------------------------------------------------------------------------
 # GPU: the C++ mirror end to end (Problem -> descriptor -> C ABI -> kernels -> SolverLog)
 # ------------------------------------------------------------------------------------------------
