@@ -19,6 +19,9 @@ DYN_UNICYCLE_4D_DISTURBED, DYN_PLANAR_DISTURBANCE = 4, 5  # the two rows of TwoP
 DYN_DUBINS_CAR = 6  # (px, py, theta), u = (omega), param0 = speed
 DYN_AIR_3D_EVADER, DYN_AIR_3D_PURSUER = 7, 8  # the two rows of Air3D (param0 = that aircraft's speed)
 DYN_POINT_MASS_2D = 9  # (px, py, vx, vy), u = (ax, ay)
+DYN_UNICYCLE_5D = 10  # (px, py, theta, v, s), u = (omega, a)
+DYN_CAR_7D = 11  # (px, py, theta, phi, v, kappa, s), u = (omega, a), param0 = inter-axle distance
+DYN_DELAYED_DUBINS_CAR = 12  # (px, py, theta, omega), u = (alpha), param0 = speed
 # ilqg_cost_kind
 (COST_QUADRATIC, COST_QUADRATIC_POLYLINE2, COST_SEMIQUADRATIC, COST_SEMIQUADRATIC_POLYLINE2,
  COST_PROXIMITY, COST_SIGNED_DISTANCE, COST_EXTREME_VALUE, CONSTRAINT_PROXIMITY,
@@ -132,8 +135,8 @@ class ProblemSpec:
     def add_player(self, kind, param0=0.0, state_reg=0.0, control_reg=0.0, structure=SUM):
         xdim = {DYN_UNICYCLE_4D: 4, DYN_CAR_5D: 5, DYN_CAR_6D: 6, DYN_UNICYCLE_4D_DISTURBED: 4,
                 DYN_PLANAR_DISTURBANCE: 0, DYN_DUBINS_CAR: 3, DYN_AIR_3D_EVADER: 3, DYN_AIR_3D_PURSUER: 0,
-                DYN_POINT_MASS_2D: 4}[kind]
-        one_control = kind in (DYN_DUBINS_CAR, DYN_AIR_3D_EVADER, DYN_AIR_3D_PURSUER)
+                DYN_POINT_MASS_2D: 4, DYN_UNICYCLE_5D: 5, DYN_CAR_7D: 7, DYN_DELAYED_DUBINS_CAR: 4}[kind]
+        one_control = kind in (DYN_DUBINS_CAR, DYN_AIR_3D_EVADER, DYN_AIR_3D_PURSUER, DYN_DELAYED_DUBINS_CAR)
         self.subsystems.append((kind, xdim, 1 if one_control else 2, param0))
         self.player_costs.append((state_reg, control_reg, structure))
         return len(self.subsystems) - 1
@@ -324,7 +327,8 @@ class ProblemSpec:
             if t["role"] == ROLE_CHILD:
                 continue
             groups.setdefault((t["player"], t["role"]), []).append(term_key(t))
-        subs = [(k, xd, ud, f32(p0) if k in (DYN_CAR_5D, DYN_CAR_6D, DYN_DUBINS_CAR, DYN_AIR_3D_EVADER, DYN_AIR_3D_PURSUER) else 0.0)
+        subs = [(k, xd, ud, f32(p0) if k in (DYN_CAR_5D, DYN_CAR_6D, DYN_DUBINS_CAR, DYN_AIR_3D_EVADER, DYN_AIR_3D_PURSUER, DYN_CAR_7D,
+                                         DYN_DELAYED_DUBINS_CAR) else 0.0)
                 for k, xd, ud, p0 in self.subsystems]
         pcs = [(f32(a), f32(b), c) for a, b, c in self.player_costs]
         return dict(T=self.T, dt=self.dt, subsystems=subs, player_costs=pcs, groups=groups, pairs=self.pairs())

@@ -188,9 +188,14 @@ __global__ void rollout_kernel(DevProblem p, RolloutBatchArgs<T> g) {
   RolloutArgs<T> a{g.x0 + b * n,          g.xs_ref + b * Tn * n, g.us_ref + b * Tn * m, g.P + b * Tn * m * n,
                    g.alpha + b * Tn * m,  g.alpha_scale ? g.alpha_scale[b] : T(1),
                    g.xs + b * Tn * n,     g.us + b * Tn * m};
-  bool dubins = false;
-  for (int i = 0; i < p.N; i++) dubins = dubins || p.sub_kind[i] == ILQG_DYN_DUBINS_CAR;
-  if (p.sub_kind[0] == ILQG_DYN_AIR_3D_EVADER)
+  bool dubins = false, plain = false;
+  for (int i = 0; i < p.N; i++) {
+    dubins = dubins || p.sub_kind[i] == ILQG_DYN_DUBINS_CAR;
+    plain = plain || is_plain_rk4_kind(p.sub_kind[i]);
+  }
+  if (plain)
+    rollout_instance<T, 0, 0, false, false, false, false, true>(p, a, sm, threadIdx.x);
+  else if (p.sub_kind[0] == ILQG_DYN_AIR_3D_EVADER)
     rollout_instance<T, 0, 0, false, false, true>(p, a, sm, threadIdx.x);
   else if (p.sub_kind[0] == ILQG_DYN_UNICYCLE_4D_DISTURBED)
     rollout_instance<T, 0, 0, true>(p, a, sm, threadIdx.x);
@@ -487,7 +492,7 @@ bool build_pairs(const ilqg_pair* pairs, int npairs, const int* udim, int N, Pai
 #if defined(ILQG_DIMS_HEADER)
 #include ILQG_DIMS_HEADER  // experiment builds: a generated subset of the list below (__graft_entry__.build_hip_library)
 #else
-#define ILQG_FOR_DIMS(X) X(14, 3, 2) X(16, 3, 2) X(15, 3, 2) X(24, 4, 2) X(18, 3, 2) X(12, 2, 2) X(10, 2, 2) X(4, 2, 2) X(6, 2, 1) X(3, 2, 1) X(3, 1, 1) X(2, 2, 1) X(6, 3, 2) X(2, 1, 2) X(8, 2, 2)
+#define ILQG_FOR_DIMS(X) X(14, 3, 2) X(16, 3, 2) X(15, 3, 2) X(24, 4, 2) X(18, 3, 2) X(12, 2, 2) X(10, 2, 2) X(4, 2, 2) X(6, 2, 1) X(3, 2, 1) X(3, 1, 1) X(2, 2, 1) X(6, 3, 2) X(2, 1, 2) X(8, 2, 2) X(17, 3, 2) X(8, 2, 1)
 #endif
 
 }  // namespace
@@ -1084,12 +1089,13 @@ ilqg_status ilqg_problem_create(const ilqg_problem_desc* desc, ilqg_problem** ou
   for (int i = 0; i < d.N; i++) {
     const ilqg_subsystem& sub = desc->subsystems[i];
     const int want_x = (sub.kind == ILQG_DYN_UNICYCLE_4D || sub.kind == ILQG_DYN_UNICYCLE_4D_DISTURBED ||
-                        sub.kind == ILQG_DYN_POINT_MASS_2D) ? 4
+                        sub.kind == ILQG_DYN_POINT_MASS_2D || sub.kind == ILQG_DYN_DELAYED_DUBINS_CAR) ? 4
+                       : sub.kind == ILQG_DYN_UNICYCLE_5D ? 5 : sub.kind == ILQG_DYN_CAR_7D ? 7
                        : sub.kind == ILQG_DYN_CAR_5D ? 5 : sub.kind == ILQG_DYN_CAR_6D ? 6
                        : sub.kind == ILQG_DYN_PLANAR_DISTURBANCE ? 0 : sub.kind == ILQG_DYN_DUBINS_CAR ? 3
                        : sub.kind == ILQG_DYN_AIR_3D_EVADER ? 3 : sub.kind == ILQG_DYN_AIR_3D_PURSUER ? 0 : -1;
     const bool one_control = sub.kind == ILQG_DYN_DUBINS_CAR || sub.kind == ILQG_DYN_AIR_3D_EVADER ||
-                             sub.kind == ILQG_DYN_AIR_3D_PURSUER;
+                             sub.kind == ILQG_DYN_AIR_3D_PURSUER || sub.kind == ILQG_DYN_DELAYED_DUBINS_CAR;
     const int want_u = one_control ? 1 : 2;
     // TwoPlayerUnicycle4D is exactly the pair (disturbed unicycle, disturbance) and nothing else
     const bool paired = sub.kind == ILQG_DYN_UNICYCLE_4D_DISTURBED || sub.kind == ILQG_DYN_PLANAR_DISTURBANCE ||
@@ -1122,7 +1128,19 @@ ilqg_status ilqg_problem_create(const ilqg_problem_desc* desc, ilqg_problem** ou
   }
   d.n = d.xoff[d.N];
   d.m = d.uoff[d.N];
-  d.sync_dist_dims = d.sub_kind[0] == ILQG_DYN_DUBINS_CAR ? 3 : 2;  // two_player_unicycle_4d.h:141-147 overrides with (px, py) too
+  {
+    bool plain = false;
+    for (int i = 0; i < d.N; i++) plain = plain || is_plain_rk4_kind(d.sub_kind[i]);
+    if (plain && !dims_use_plain_rk4(d.n, d.N, d.udim[0])) {
+      delete p;
+      return fail(ILQG_ERR_UNSUPPORTED,
+                  "Unicycle5D / Car7D / DelayedDubinsCar rows need an instantiation that carries the plain RK4 "
+                  "(dims_use_plain_rk4, csrc/ilqg_stages.hpp)");
+    }
+  }
+  // DistanceBetween of the first subsystem: (px, py) where the model overrides it (two_player_unicycle_4d.h:141-147
+  // too), the whole block where it does not (the two Dubins cars: single_player_dynamical_system.h:69-71)
+  d.sync_dist_dims = d.sub_kind[0] == ILQG_DYN_DUBINS_CAR ? 3 : (d.sub_kind[0] == ILQG_DYN_DELAYED_DUBINS_CAR ? 4 : 2);
   // pair table in PlayerCost first-touch order: control costs, then control constraints
   std::vector<ilqg_pair> pairs;
   std::vector<int> from_cost;

@@ -107,6 +107,69 @@ __device__ __forceinline__ void sub_integrate(int kind, T L, double interval, T*
   }
 }
 
+// The models outside the stage-per-lane integrator's closed forms — SinglePlayerUnicycle5D (unicycle_5d.h:92-103),
+// SinglePlayerCar7D (car_7d.h:104-120), SinglePlayerDelayedDubinsCar (delayed_dubins_car.h:103-113) — and any other
+// kind through sub_eval: blocks of up to 8 states, the plain RK4 of MultiPlayerDynamicalSystem::Integrate.
+constexpr int kSubStatesMax = 8;
+__host__ __device__ inline bool is_plain_rk4_kind(int kind) {
+  return kind == ILQG_DYN_UNICYCLE_5D || kind == ILQG_DYN_CAR_7D || kind == ILQG_DYN_DELAYED_DUBINS_CAR;
+}
+template <typename T>
+__device__ __forceinline__ void sub_eval8(int kind, T L, const T* x, T u0, T u1, T* xd, T d0 = T(0), T d1 = T(0)) {
+  if (kind == ILQG_DYN_UNICYCLE_5D) {
+    xd[0] = x[3] * t_cos(x[2]);
+    xd[1] = x[3] * t_sin(x[2]);
+    xd[2] = u0;
+    xd[3] = u1;
+    xd[4] = x[3];
+    xd[5] = xd[6] = xd[7] = T(0);
+  } else if (kind == ILQG_DYN_CAR_7D) {
+    xd[0] = x[4] * t_cos(x[2]);
+    xd[1] = x[4] * t_sin(x[2]);
+    xd[2] = (x[4] / L) * t_tan(x[3]);
+    xd[3] = u0;
+    xd[4] = u1;
+    const T sec_phi = T(1.0 / double(t_cos(x[3])));  // a float made from a double quotient there (car_7d.h:115)
+    xd[5] = u0 * sec_phi * sec_phi / L;
+    xd[6] = x[4];
+    xd[7] = T(0);
+  } else if (kind == ILQG_DYN_DELAYED_DUBINS_CAR) {
+    xd[0] = L * t_cos(x[2]);
+    xd[1] = L * t_sin(x[2]);
+    xd[2] = x[3];
+    xd[3] = u0;
+    xd[4] = xd[5] = xd[6] = xd[7] = T(0);
+  } else {
+    sub_eval<T>(kind, L, x, u0, u1, xd, d0, d1);
+    xd[6] = xd[7] = T(0);
+  }
+}
+template <typename T>
+__device__ __forceinline__ void sub_integrate8(int kind, T L, double interval, T* x, T u0, T u1, T d0 = T(0),
+                                               T d1 = T(0)) {
+  constexpr int XS = kSubStatesMax;
+  const T h = T(interval / 2.0);
+#pragma unroll 1
+  for (int s = 0; s < 2; s++) {
+    T k1[XS], k2[XS], k3[XS], k4[XS], xt[XS];
+    sub_eval8(kind, L, x, u0, u1, k1, d0, d1);
+#pragma unroll
+    for (int i = 0; i < XS; i++) { k1[i] = h * k1[i]; xt[i] = x[i] + T(0.5) * k1[i]; }
+    sub_eval8(kind, L, xt, u0, u1, k2, d0, d1);
+#pragma unroll
+    for (int i = 0; i < XS; i++) { k2[i] = h * k2[i]; xt[i] = x[i] + T(0.5) * k2[i]; }
+    sub_eval8(kind, L, xt, u0, u1, k3, d0, d1);
+#pragma unroll
+    for (int i = 0; i < XS; i++) { k3[i] = h * k3[i]; xt[i] = x[i] + k3[i]; }
+    sub_eval8(kind, L, xt, u0, u1, k4, d0, d1);
+#pragma unroll
+    for (int i = 0; i < XS; i++) {
+      k4[i] = h * k4[i];
+      x[i] += (k1[i] + T(2.0) * (k2[i] + k3[i]) + k4[i]) / T(6.0);
+    }
+  }
+}
+
 template <typename T> __device__ __forceinline__ void t_sincos(T x, T* s, T* c);
 template <> __device__ __forceinline__ void t_sincos<float>(float x, float* s, float* c) { sincosf(x, s, c); }
 template <> __device__ __forceinline__ void t_sincos<double>(double x, double* s, double* c) { sincos(x, s, c); }

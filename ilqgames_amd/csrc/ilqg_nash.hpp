@@ -60,16 +60,16 @@ __global__ void __launch_bounds__(64) strategy_costs_kernel(DevProblem p, Strate
     __syncthreads();
     if (t < N) {  // dynamics.Integrate(t, dt, x, us) (:85)
       const int xo = p.xoff[t], uo = p.uoff[t], xd = p.xoff[t + 1] - xo;
-      T xj[6], f[6];
-      for (int e = 0; e < 6; e++) xj[e] = e < xd ? sx[xo + e] : T(0);
+      T xj[kSubStatesMax], f[kSubStatesMax];
+      for (int e = 0; e < kSubStatesMax; e++) xj[e] = e < xd ? sx[xo + e] : T(0);
       const bool dist = p.sub_kind[t] == ILQG_DYN_UNICYCLE_4D_DISTURBED;
       const bool air = p.sub_kind[t] == ILQG_DYN_AIR_3D_EVADER;  // d0 carries the pursuer's speed there
       const T d0 = dist ? sx[n + uo + 2] : (air ? T(p.sub_param[t + 1]) : T(0)), d1 = dist ? sx[n + uo + 3] : T(0);
       if (a.euler) {  // multi_player_dynamical_system.cpp:57-58
-        sub_eval<T>(p.sub_kind[t], T(p.sub_param[t]), xj, sx[n + uo], sx[n + uo + 1], f, d0, d1);
-        for (int e = 0; e < 6; e++) xj[e] += T(p.dt) * f[e];
+        sub_eval8<T>(p.sub_kind[t], T(p.sub_param[t]), xj, sx[n + uo], sx[n + uo + 1], f, d0, d1);
+        for (int e = 0; e < kSubStatesMax; e++) xj[e] += T(p.dt) * f[e];
       } else {
-        sub_integrate<T>(p.sub_kind[t], T(p.sub_param[t]), p.dt, xj, sx[n + uo], sx[n + uo + 1], d0, d1);
+        sub_integrate8<T>(p.sub_kind[t], T(p.sub_param[t]), p.dt, xj, sx[n + uo], sx[n + uo + 1], d0, d1);
       }
       for (int e = 0; e < xd; e++) snx[xo + e] = xj[e];
     }

@@ -55,11 +55,11 @@ struct PlanStepper {
   __device__ __forceinline__ void integrate(double interval) {
     if (t < p.N) {
       const int xo = p.xoff[t], uo = p.uoff[t], xd = p.xoff[t + 1] - xo;
-      T xj[6];
-      for (int e = 0; e < 6; e++) xj[e] = e < xd ? sx[xo + e] : T(0);
+      T xj[kSubStatesMax];
+      for (int e = 0; e < kSubStatesMax; e++) xj[e] = e < xd ? sx[xo + e] : T(0);
       const bool dist = p.sub_kind[t] == ILQG_DYN_UNICYCLE_4D_DISTURBED;  // the next player's (dx, dy)
       const bool air = p.sub_kind[t] == ILQG_DYN_AIR_3D_EVADER;           // the next row's parameter: pursuer speed
-      sub_integrate<T>(p.sub_kind[t], T(p.sub_param[t]), interval, xj, su[uo], su[uo + 1],
+      sub_integrate8<T>(p.sub_kind[t], T(p.sub_param[t]), interval, xj, su[uo], su[uo + 1],
                        dist ? su[uo + 2] : (air ? T(p.sub_param[t + 1]) : T(0)), dist ? su[uo + 3] : T(0));
       for (int e = 0; e < xd; e++) sx[xo + e] = xj[e];
     }

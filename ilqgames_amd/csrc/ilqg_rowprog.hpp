@@ -147,16 +147,23 @@ inline bool build_row_program(const DevProblem& d, const std::vector<DevTerm>& d
       std::vector<std::pair<int, int>> av, bv;  // computed entries, in the order rows_chunk's Jacobian op writes them
       auto A = [&](int r, int c) -> short& { return mapA[(xo + r) + n * (xo + c)]; };
       auto B = [&](int r, int c) -> short& { return mapB[(xo + r) + n * (uo + c)]; };
-      if (kind == ILQG_DYN_UNICYCLE_4D || kind == ILQG_DYN_UNICYCLE_4D_DISTURBED) {
+      if (kind == ILQG_DYN_UNICYCLE_4D || kind == ILQG_DYN_UNICYCLE_4D_DISTURBED || kind == ILQG_DYN_UNICYCLE_5D) {
         av = {{0, 2}, {0, 3}, {1, 2}, {1, 3}};
         B(2, 0) = short(S_DT); B(3, 1) = short(S_DT);
-      } else if (kind == ILQG_DYN_CAR_5D || kind == ILQG_DYN_CAR_6D) {
+        if (kind == ILQG_DYN_UNICYCLE_5D) A(4, 3) = short(S_DT);
+      } else if (kind == ILQG_DYN_CAR_5D || kind == ILQG_DYN_CAR_6D || kind == ILQG_DYN_CAR_7D) {
         av = {{0, 2}, {0, 4}, {1, 2}, {1, 4}, {2, 3}, {2, 4}};
         if (kind == ILQG_DYN_CAR_5D) { B(3, 0) = short(S_DT); B(4, 1) = short(S_DT); }
-        else { A(4, 5) = short(S_DT); B(3, 0) = short(S_DT); B(5, 1) = short(S_DT); }
-      } else if (kind == ILQG_DYN_DUBINS_CAR) {
+        else if (kind == ILQG_DYN_CAR_6D) { A(4, 5) = short(S_DT); B(3, 0) = short(S_DT); B(5, 1) = short(S_DT); }
+        else {  // the curvature row: A(kappa, phi) and B(kappa, omega) are computed
+          av.push_back({5, 3});
+          bv = {{5, 0}};
+          A(6, 4) = short(S_DT); B(3, 0) = short(S_DT); B(4, 1) = short(S_DT);
+        }
+      } else if (kind == ILQG_DYN_DUBINS_CAR || kind == ILQG_DYN_DELAYED_DUBINS_CAR) {
         av = {{0, 2}, {1, 2}};
-        B(2, 0) = short(S_DT);
+        if (kind == ILQG_DYN_DUBINS_CAR) B(2, 0) = short(S_DT);
+        else { A(2, 3) = short(S_DT); B(3, 0) = short(S_DT); }
       } else if (kind == ILQG_DYN_POINT_MASS_2D) {
         A(0, 2) = short(S_DT); A(1, 3) = short(S_DT); B(2, 0) = short(S_DT); B(3, 1) = short(S_DT);
       } else if (kind == ILQG_DYN_AIR_3D_EVADER) {

@@ -479,11 +479,12 @@ __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* map
             put(3, T(c.value) * ct);                   // A(1,2)
             put(4, T(double(x[1]) * p.dt));            // B(0,0)
             put(5, T(double(-x[0]) * p.dt));           // B(1,0)
-          } else if (kind == ILQG_DYN_DUBINS_CAR) {  // single_player_dubins_car.h:105-117
+          } else if (kind == ILQG_DYN_DUBINS_CAR || kind == ILQG_DYN_DELAYED_DUBINS_CAR) {
+            // single_player_dubins_car.h:105-117, single_player_delayed_dubins_car.h:115-127
             put(0, T(0) + -L * st);  // A(0,2)
             put(1, T(0) + L * ct);   // A(1,2)
           } else {
-            const bool uni = is_unicycle(kind);
+            const bool uni = is_unicycle(kind) || kind == ILQG_DYN_UNICYCLE_5D;  // single_player_unicycle_5d.h:105-122
             const T v = x[uni ? 3 : 4];
             put(0, T(0) + -v * st);  // A(0,2)
             put(1, ct);              // A(0,v)
@@ -495,6 +496,12 @@ __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* map
               const T tphi = sphi / cphi;
               put(4, T(double(x[4]) * p.dt / double(L * cphi * cphi)));  // A(2,3)
               put(5, T(double(tphi) * p.dt / double(L)));               // A(2,4)
+              if (kind == ILQG_DYN_CAR_7D) {  // single_player_car_7d.h:141-151: the curvature row, all-double products
+                const T own = arg[(CN + uo) * cw + rl];  // omega
+                const T den = cphi * cphi * L;
+                put(6, T(2.0 * p.dt * double(own) * double(tphi) / double(den)));  // A(5,3)
+                put(7, T(p.dt / double(den)));                                     // B(5,0)
+              }
             }
           }
           continue;

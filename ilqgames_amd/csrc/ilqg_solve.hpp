@@ -254,7 +254,8 @@ __device__ __forceinline__ void solve_exit_path(const DevProblem& p, const QuadT
             const bool on_state = c.role == ILQG_ROLE_STATE_CONSTRAINT;
             for (int k = 0; k < Tn; k++) {
               const T* v = on_state ? xs0 + size_t(k) * n : us0 + size_t(k) * m + p.uoff[c.arg];
-              const T err = term_evaluate_leaf<T>(tb, ti, v, c.arg_dim);
+              // FinalTimeConstraint::Evaluate (constraint/final_time_constraint.h:66-70): 0 before its threshold
+              const T err = k < c.k_start ? T(0) : term_evaluate_leaf<T>(tb, ti, v, c.arg_dim);
               my_err = err > my_err ? err : my_err;
               // Constraint::IncrementLambda (constraint.h:98-102) at TimeIndex(t0 + dt*float(k))
               const double tt = 0.0 + p.dt * double(float(k));
@@ -450,7 +451,8 @@ __device__ __forceinline__ void probe_roll_instance(const DevProblem& p, const S
   ra.xs = e + E.xs;
   ra.us = e + E.us;
   rollout_instance<T, NX, NP * MU, (NX == 4 && NP == 2), (MU == 1), (NX == 3 && NP == 2 && MU == 1),
-                   (NX == 4 * NP && MU == 2 && NP <= 2)>(p, ra, sm, int(threadIdx.x), nullptr, nullptr);
+                   (NX == 4 * NP && MU == 2 && NP <= 2), dims_use_plain_rk4(NX, NP, MU)>(p, ra, sm, int(threadIdx.x),
+                                                                                         nullptr, nullptr);
 }
 
 template <typename T, int NX, int NP, int MU>
@@ -624,7 +626,8 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const s
     tl_stamp(sa.prof, b, 1, t == 0);
     if (roll && wave == 0)
       rollout_instance<T, NX, NP * MU, (NX == 4 && NP == 2), (MU == 1), (NX == 3 && NP == 2 && MU == 1),
-                       (NX == 4 * NP && MU == 2 && NP <= 2)>(p, ra, sm_roll, lane, W > 1 ? &flags[0] : nullptr,
+                       (NX == 4 * NP && MU == 2 && NP <= 2), dims_use_plain_rk4(NX, NP, MU)>(
+                                       p, ra, sm_roll, lane, W > 1 ? &flags[0] : nullptr,
                                        (kProfile && sa.prof) ? rph : nullptr, kTimeline ? sa.prof : nullptr, b);
     tl_stamp(sa.prof, b, 2, t == 0);
     if (roll && W == 1) {

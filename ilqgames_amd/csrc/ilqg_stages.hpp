@@ -56,7 +56,14 @@ __device__ __forceinline__ int progress_observe(int* flag) {
 // does not apply and lane 0 runs the plain RK4.
 // PM: the game may be one of point masses (then every row is one): the plain RK4 again, one copy per lane of the
 // group — the right-hand side is two moves and there is no transcendental to take out of the chain.
-template <typename T, int CN = 0, int CM = 0, bool DIST = false, bool DUB = false, bool AIR = false, bool PM = false>
+// GEN: the game may contain the models the stage-parallel integrator has no closed forms for (Unicycle5D, Car7D,
+// DelayedDubinsCar; blocks of up to 8 states): every row then takes the plain RK4, one copy per lane of its group.
+// The instantiations that may hold such games, by dimension:
+__host__ __device__ constexpr bool dims_use_plain_rk4(int nx, int np, int mu) {
+  return (nx == 17 && np == 3 && mu == 2) || (nx == 8 && np == 2 && mu == 1);
+}
+template <typename T, int CN = 0, int CM = 0, bool DIST = false, bool DUB = false, bool AIR = false, bool PM = false,
+          bool GEN = false>
 __device__ __forceinline__ void rollout_instance(const DevProblem& p, const RolloutArgs<T>& a, T* sm, int t,
                                                  int* ready = nullptr, long long* phacc = nullptr,
                                                  long long* tl = nullptr, int tl_b = 0) {
@@ -78,13 +85,14 @@ __device__ __forceinline__ void rollout_instance(const DevProblem& p, const Roll
     dma_g2l<NT, false>(a.xs_ref + size_t(k) * n, d + m * n + 2 * m, n * S, t);
   };
   // lane group g = t / 8 integrates subsystem g; lane q = t % 8 owns RK4 stage q of that group
-  T xj[6];
+  constexpr int XS = GEN ? kSubStatesMax : 6;
+  T xj[XS];
   const int grp = t >> 3, q = t & 7;
   const bool integ = grp < N && t < 64;
   int kind = ILQG_DYN_UNICYCLE_4D, xo = 0, uo = 0, xd = 0;
   T Lp = T(1);
 #pragma unroll
-  for (int e = 0; e < 6; e++) xj[e] = T(0);
+  for (int e = 0; e < XS; e++) xj[e] = T(0);
   if (integ) {
     kind = p.sub_kind[grp];
     xo = p.xoff[grp];
@@ -92,7 +100,7 @@ __device__ __forceinline__ void rollout_instance(const DevProblem& p, const Roll
     xd = p.xoff[grp + 1] - xo;
     Lp = T(p.sub_param[grp]);
 #pragma unroll
-    for (int e = 0; e < 6; e++) xj[e] = (e < xd) ? a.x0[xo + e] : T(0);
+    for (int e = 0; e < XS; e++) xj[e] = (e < xd) ? a.x0[xo + e] : T(0);
   }
   T* const gth = stg + 2 * WP;  // exchange scratch of the stage-parallel integrator
   const bool any_car = __any(integ && (kind == ILQG_DYN_CAR_5D || kind == ILQG_DYN_CAR_6D));
@@ -114,7 +122,7 @@ __device__ __forceinline__ void rollout_instance(const DevProblem& p, const Roll
       // every lane of a group holds the group's state: lane q publishes entry q (one LDS round trip for the row)
       T mine = xj[0];
 #pragma unroll
-      for (int e = 1; e < 6; e++) mine = (q == e) ? xj[e] : mine;
+      for (int e = 1; e < XS; e++) mine = (q == e) ? xj[e] : mine;
       if (integ && q < xd) {
         sdx[xo + q] = mine - sxr[xo + q];
         a.xs[size_t(k) * n + xo + q] = mine;
@@ -153,7 +161,9 @@ __device__ __forceinline__ void rollout_instance(const DevProblem& p, const Roll
     ILQG_RPH(1);
     if (t < 64 && k + 1 < Tn) {  // whole first wave: the exchanges inside need every group lane live
       const T u0 = integ ? su[uo] : T(0), u1 = integ ? su[uo + 1] : T(0);
-      if constexpr (AIR) {
+      if constexpr (GEN) {
+        if (integ) sub_integrate8<T>(kind, Lp, p.dt, xj, u0, u1);
+      } else if constexpr (AIR) {
         if (grp == 0) sub_integrate<T>(kind, Lp, p.dt, xj, u0, u1, T(p.sub_param[1]));  // every lane of the group keeps the state
       } else if constexpr (DIST) {
         const bool dist = integ && kind == ILQG_DYN_UNICYCLE_4D_DISTURBED;  // the next player's (dx, dy)

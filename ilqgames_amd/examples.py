@@ -608,7 +608,7 @@ def cost_zoo_scene(T=100, dt=0.1):
     """A test scene, NOT a reference example: the two crossing Car5D of the skeleton example (n=10) carrying the cost
     and constraint kinds no reference example in CONFIGS uses — OrientationCost, QuadraticNormCost,
     SemiquadraticNormCost (on a state pair and on a control pair), RelativeDistanceCost, LocallyConvexProximityCost,
-    CurvatureCost and Polyline2SignedDistanceConstraint — so that every stage kernel and the whole solve are compared
+    CurvatureCost, Polyline2SignedDistanceConstraint and FinalTimeConstraint — so that every stage kernel and the whole solve are compared
     with the restatement on them.  CurvatureCost reads (phi, v) here: the reference pairs it with a yaw-rate state
     (Unicycle5D / Car7D); only its (omega_idx, v_idx) pattern matters to the kernels."""
     prm = SolverParams.default()
@@ -641,13 +641,78 @@ def cost_zoo_scene(T=100, dt=0.1):
         s.locally_convex_proximity(i, 50.0, (X[i], Y[i]), (X[1 - i], Y[1 - i]), 6.0)
         s.curvature(i, 20.0, PHI[i], V[i])
     s.polyline2_signed_distance_constraint(0, wall, (X[0], Y[0]), -0.5, True)
-    s.polyline2_signed_distance_constraint(1, lane1, (X[1], Y[1]), -60.0, False)
+    # FinalTimeConstraint: from 4 s on player 2 must be within 4 m of lane 1's left side (it starts 5 m away)
+    s.final_time(4.0, s.polyline2_signed_distance_constraint(1, lane1, (X[1], Y[1]), -4.0, False))
     f = np.float32
     x0 = np.zeros(10)
     x0[[X[0], Y[0], H[0], V[0]]] = [0.0, -30.0, float(f(np.pi / 2)), 4.0]
     x0[[X[1], Y[1], H[1], V[1]]] = [-5.0, 30.0, float(f(-np.pi / 2)), 3.0]
     s.x0 = x0
     s.position_dims, s.heading_dims, s.speed_dims = list(zip(X, Y)), H, V
+    return s
+
+
+def dynamics_zoo_scene(T=100, dt=0.1):
+    """A test scene, NOT a reference example: the single-player models no reference example uses — one Car7D and two
+    Unicycle5D (n = 17) — on the crossing lanes of the skeleton example, with costs on the states only these models
+    have (curvature kappa, path length s)."""
+    prm = SolverParams.default()
+    prm.max_backtracking_steps = 100
+    prm.initial_alpha_scaling = 0.1
+    prm.convergence_tolerance = 0.01
+    prm.expected_decrease_fraction = 0.001
+    s = ProblemSpec(T, dt, prm)
+    s.add_player(abi.DYN_CAR_7D, 4.0)
+    s.add_player(abi.DYN_UNICYCLE_5D)
+    s.add_player(abi.DYN_UNICYCLE_5D)
+    X, Y, H, V = [0, 7, 12], [1, 8, 13], [2, 9, 14], [4, 10, 15]
+    KAPPA, S = 5, [6, 11, 16]
+    for i in range(3):
+        s.quadratic(i, 25.0, 0, 0.0, control_of=i)  # omega
+        s.quadratic(i, 15.0, 1, 0.0, control_of=i)  # acceleration
+        s.quadratic(i, 10.0, V[i], 6.0)
+        s.quadratic(i, 0.02, S[i], 50.0)           # path length driven towards 50 m
+    s.quadratic(0, 30.0, KAPPA, 0.0)
+    lane1 = s.add_polyline([(0.0, -1000.0), (0.0, 1000.0)])
+    lane2 = s.add_polyline([(-5.0, 1000.0), (-5.0, 5.0), (0.0, 0.0), (995.0, 0.0)])
+    lane3 = s.add_polyline([(-1000.0, 8.0), (1000.0, 8.0)])
+    for i, lane in enumerate((lane1, lane2, lane3)):
+        s.quadratic_polyline2(i, 25.0, lane, (X[i], Y[i]))
+    for i in range(3):
+        for j in range(3):
+            if i != j:
+                s.proximity(i, 100.0, (X[i], Y[i]), (X[j], Y[j]), 6.0)
+    f = np.float32
+    x0 = np.zeros(17)
+    x0[[X[0], Y[0], H[0], V[0]]] = [0.0, -30.0, float(f(np.pi / 2)), 4.0]
+    x0[[X[1], Y[1], H[1], V[1]]] = [-5.0, 30.0, float(f(-np.pi / 2)), 3.0]
+    x0[[X[2], Y[2], H[2], V[2]]] = [-25.0, 8.0, 0.0, 5.0]
+    s.x0 = x0
+    s.position_dims, s.heading_dims, s.speed_dims = list(zip(X, Y)), H, V
+    return s
+
+
+def delayed_dubins_scene(T=100, dt=0.1):
+    """A test scene, NOT a reference example: two SinglePlayerDelayedDubinsCar (n = 8, one control each) — the game
+    of DubinsOriginExample (src/dubins_origin_example.cpp) with the turn rate as a state: player 1 is drawn to the
+    origin, player 2 to player 1."""
+    prm = SolverParams.default()
+    prm.max_backtracking_steps = 100
+    prm.initial_alpha_scaling = 0.1
+    prm.convergence_tolerance = 0.01
+    prm.expected_decrease_fraction = 0.001
+    s = ProblemSpec(T, dt, prm)
+    for _ in range(2):
+        s.add_player(abi.DYN_DELAYED_DUBINS_CAR, 1.0)
+    X, Y, H, W = [0, 4], [1, 5], [2, 6], [3, 7]
+    for i in range(2):
+        s.quadratic(i, 1.0, 0, 0.0, control_of=i)
+        s.quadratic(i, 2.0, W[i], 0.0)
+    s.quadratic(0, 1.0, X[0], 0.0)
+    s.quadratic(0, 1.0, Y[0], 0.0)
+    s.quadratic_difference(1, 1.0, (X[1], Y[1]), (X[0], Y[0]))
+    s.x0 = [2.0, 1.0, float(np.float32(np.pi / 2)), 0.0, -1.0, -2.0, 0.3, 0.1]
+    s.position_dims, s.heading_dims, s.speed_dims = list(zip(X, Y)), H, []
     return s
 
 
@@ -682,6 +747,8 @@ CONFIGS = {
     "two_player_collision_avoidance_reachability": two_player_collision_avoidance_reachability,
     "skeleton": skeleton,
     "cost_zoo_scene": cost_zoo_scene,
+    "dynamics_zoo_scene": dynamics_zoo_scene,
+    "delayed_dubins_scene": delayed_dubins_scene,
     "air_3d": air_3d,
     "modified_air_3d": modified_air_3d,
     "dubins_origin": dubins_origin,

@@ -80,6 +80,34 @@ const Dimension SinglePlayerCar5D::kNumUDims = 2;
 const Dimension SinglePlayerCar5D::kOmegaIdx = 0;
 const Dimension SinglePlayerCar5D::kAIdx = 1;
 
+// src/single_player_unicycle_5d.cpp:53-64, src/single_player_car_7d.cpp:60-74, src/single_player_delayed_dubins_car.cpp:53-62
+const Dimension SinglePlayerUnicycle5D::kNumXDims = 5;
+const Dimension SinglePlayerUnicycle5D::kPxIdx = 0;
+const Dimension SinglePlayerUnicycle5D::kPyIdx = 1;
+const Dimension SinglePlayerUnicycle5D::kThetaIdx = 2;
+const Dimension SinglePlayerUnicycle5D::kVIdx = 3;
+const Dimension SinglePlayerUnicycle5D::kSIdx = 4;
+const Dimension SinglePlayerUnicycle5D::kNumUDims = 2;
+const Dimension SinglePlayerUnicycle5D::kOmegaIdx = 0;
+const Dimension SinglePlayerUnicycle5D::kAIdx = 1;
+const Dimension SinglePlayerCar7D::kNumXDims = 7;
+const Dimension SinglePlayerCar7D::kPxIdx = 0;
+const Dimension SinglePlayerCar7D::kPyIdx = 1;
+const Dimension SinglePlayerCar7D::kThetaIdx = 2;
+const Dimension SinglePlayerCar7D::kPhiIdx = 3;
+const Dimension SinglePlayerCar7D::kVIdx = 4;
+const Dimension SinglePlayerCar7D::kKappaIdx = 5;
+const Dimension SinglePlayerCar7D::kSIdx = 6;
+const Dimension SinglePlayerCar7D::kNumUDims = 2;
+const Dimension SinglePlayerCar7D::kOmegaIdx = 0;
+const Dimension SinglePlayerCar7D::kAIdx = 1;
+const Dimension SinglePlayerDelayedDubinsCar::kNumXDims = 4;
+const Dimension SinglePlayerDelayedDubinsCar::kPxIdx = 0;
+const Dimension SinglePlayerDelayedDubinsCar::kPyIdx = 1;
+const Dimension SinglePlayerDelayedDubinsCar::kThetaIdx = 2;
+const Dimension SinglePlayerDelayedDubinsCar::kOmegaIdx = 3;
+const Dimension SinglePlayerDelayedDubinsCar::kNumUDims = 1;
+const Dimension SinglePlayerDelayedDubinsCar::kAlphaIdx = 0;
 const Dimension SinglePlayerCar6D::kNumXDims = 6;
 const Dimension SinglePlayerCar6D::kPxIdx = 0;
 const Dimension SinglePlayerCar6D::kPyIdx = 1;
@@ -254,6 +282,13 @@ bool FinalTimeCost::Describe(host::TermDescription* out) const {
   // the first step whose time ILQSolver hands to Evaluate / Quadraticize (RelativeTime(kk) = kk * kTimeStep,
   // src/ilq_solver.cpp:236,475) passes `t >= threshold_time` (final_time_cost.h:67,75)
   int first = 0;
+  while (static_cast<Time>(first) * time::kTimeStep < threshold_time_) first++;
+  out->term.first_step = first;
+  return true;
+}
+bool FinalTimeConstraint::Describe(host::TermDescription* out) const {
+  if (!constraint_->Describe(out)) return false;
+  int first = 0;  // as FinalTimeCost: the first step whose time passes `t >= initial_time + threshold_time` (final_time_constraint.h:67,75)
   while (static_cast<Time>(first) * time::kTimeStep < threshold_time_) first++;
   out->term.first_step = first;
   return true;

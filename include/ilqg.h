@@ -138,7 +138,16 @@ typedef enum {
   ILQG_DYN_AIR_3D_PURSUER = 8,
   /* include/ilqgames/dynamics/single_player_point_mass_2d.h:55-110: x = (px, py, vx, vy), u = (ax, ay);
    * xdim 4, udim 2.  Point masses only occur in games made of point masses. */
-  ILQG_DYN_POINT_MASS_2D = 9
+  ILQG_DYN_POINT_MASS_2D = 9,
+  /* The rest of the reference's single-player models.  They run on the plain RK4 (one lane walks the four stages of
+   * a block) instead of the stage-per-lane integrator of kinds 1-3 and 6, in the instantiations that list them
+   * (dims_use_plain_rk4 in csrc/ilqg_stages.hpp). */
+  ILQG_DYN_UNICYCLE_5D = 10, /* include/ilqgames/dynamics/single_player_unicycle_5d.h:55-135: x = (px, py, theta, v, s),
+                                u = (omega, a); s = path length; xdim 5, udim 2 */
+  ILQG_DYN_CAR_7D = 11,      /* include/ilqgames/dynamics/single_player_car_7d.h:61-170: x = (px, py, theta, phi, v,
+                                kappa, s), u = (omega, a), param0 = inter-axle distance; xdim 7, udim 2 */
+  ILQG_DYN_DELAYED_DUBINS_CAR = 12 /* include/ilqgames/dynamics/single_player_delayed_dubins_car.h:57-129: x = (px, py,
+                                theta, omega), u = (alpha), constant speed param0; xdim 4, udim 1 */
 } ilqg_dyn_kind;
 
 /* One block of a ConcatenatedDynamicalSystem

@@ -457,6 +457,19 @@ class Polyline2SignedDistanceConstraint : public TimeInvariantConstraint {
   bool keep_left_;
 };
 
+// include/ilqgames/constraint/final_time_constraint.h:55-90 — another constraint, switched on from `threshold_time`
+// (relative to the start of the window) onwards: g = 0 and no derivatives before.
+class FinalTimeConstraint : public Constraint {
+ public:
+  FinalTimeConstraint(const std::shared_ptr<Constraint>& constraint, Time threshold_time)
+      : Constraint(*CHECK_NOTNULL(constraint.get())), constraint_(constraint), threshold_time_(threshold_time) {}
+  bool Describe(host::TermDescription* out) const override;
+
+ private:
+  const std::shared_ptr<Constraint> constraint_;
+  const Time threshold_time_;
+};
+
 // ---------------------------------------------------------------------------------------------
 // PlayerCost (include/ilqgames/cost/player_cost.h:60-170)
 // ---------------------------------------------------------------------------------------------
@@ -587,6 +600,45 @@ class SinglePlayerCar6D : public SinglePlayerDynamicalSystem {
 
  private:
   const float inter_axle_distance_;
+};
+
+// include/ilqgames/dynamics/single_player_unicycle_5d.h:55-88 — the unicycle with a path-length state.
+class SinglePlayerUnicycle5D : public SinglePlayerDynamicalSystem {
+ public:
+  SinglePlayerUnicycle5D() : SinglePlayerDynamicalSystem(kNumXDims, kNumUDims) {}
+  std::vector<Dimension> PositionDimensions() const override { return {kPxIdx, kPyIdx}; }
+  ilqg_subsystem Describe() const override { return ilqg_subsystem{ILQG_DYN_UNICYCLE_5D, xdim_, udim_, 0.0f}; }
+  static const Dimension kNumXDims, kPxIdx, kPyIdx, kThetaIdx, kVIdx, kSIdx;
+  static const Dimension kNumUDims, kOmegaIdx, kAIdx;
+};
+
+// include/ilqgames/dynamics/single_player_car_7d.h:61-100 — Car5D with curvature and path-length states.
+class SinglePlayerCar7D : public SinglePlayerDynamicalSystem {
+ public:
+  SinglePlayerCar7D(float inter_axle_distance)
+      : SinglePlayerDynamicalSystem(kNumXDims, kNumUDims), inter_axle_distance_(inter_axle_distance) {}
+  std::vector<Dimension> PositionDimensions() const override { return {kPxIdx, kPyIdx}; }
+  ilqg_subsystem Describe() const override {
+    return ilqg_subsystem{ILQG_DYN_CAR_7D, xdim_, udim_, inter_axle_distance_};
+  }
+  static const Dimension kNumXDims, kPxIdx, kPyIdx, kThetaIdx, kPhiIdx, kVIdx, kKappaIdx, kSIdx;
+  static const Dimension kNumUDims, kOmegaIdx, kAIdx;
+
+ private:
+  const float inter_axle_distance_;
+};
+
+// include/ilqgames/dynamics/single_player_delayed_dubins_car.h:57-99 — constant speed, the turn rate is a state.
+class SinglePlayerDelayedDubinsCar : public SinglePlayerDynamicalSystem {
+ public:
+  SinglePlayerDelayedDubinsCar(float v) : SinglePlayerDynamicalSystem(kNumXDims, kNumUDims), v_(v) { CHECK_GT(v_, 0.0); }
+  std::vector<Dimension> PositionDimensions() const override { return {kPxIdx, kPyIdx}; }
+  ilqg_subsystem Describe() const override { return ilqg_subsystem{ILQG_DYN_DELAYED_DUBINS_CAR, xdim_, udim_, v_}; }
+  static const Dimension kNumXDims, kPxIdx, kPyIdx, kThetaIdx, kOmegaIdx;
+  static const Dimension kNumUDims, kAlphaIdx;
+
+ private:
+  const float v_;
 };
 
 // include/ilqgames/dynamics/multi_player_integrable_system.h:57-140 (shape queries only; the

@@ -496,6 +496,30 @@ void EvaluateSubsystem(const ilqg_subsystem& s, const S* x, const S* u, S* xdot,
       xdot[4] = x[5];
       xdot[5] = u[1];
       break;
+    case ILQG_DYN_UNICYCLE_5D:  // single_player_unicycle_5d.h:92-103
+      xdot[0] = x[3] * std::cos(x[2]);
+      xdot[1] = x[3] * std::sin(x[2]);
+      xdot[2] = u[0];
+      xdot[3] = u[1];
+      xdot[4] = x[3];
+      break;
+    case ILQG_DYN_CAR_7D: {  // single_player_car_7d.h:104-120 (sec_phi is a float made from a double quotient there)
+      xdot[0] = x[4] * std::cos(x[2]);
+      xdot[1] = x[4] * std::sin(x[2]);
+      xdot[2] = (x[4] / L) * std::tan(x[3]);
+      xdot[3] = u[0];
+      xdot[4] = u[1];
+      const S sec_phi = S(1.0 / double(std::cos(x[3])));
+      xdot[5] = u[0] * sec_phi * sec_phi / L;
+      xdot[6] = x[4];
+      break;
+    }
+    case ILQG_DYN_DELAYED_DUBINS_CAR:  // single_player_delayed_dubins_car.h:103-113
+      xdot[0] = L * std::cos(x[2]);
+      xdot[1] = L * std::sin(x[2]);
+      xdot[2] = x[3];
+      xdot[3] = u[0];
+      break;
   }
 }
 
@@ -593,7 +617,17 @@ void Linearize(const Problem<S>& p, const Vec<S>& x, const Vec<S>& u, Mat<S>* A,
       (*B)(o + 2, uo + 0) = S(dt);
       continue;
     }
-    const bool unicycle = s.kind == ILQG_DYN_UNICYCLE_4D || s.kind == ILQG_DYN_UNICYCLE_4D_DISTURBED;
+    if (s.kind == ILQG_DYN_DELAYED_DUBINS_CAR) {  // single_player_delayed_dubins_car.h:115-127
+      const S v = S(s.param0);
+      const S ctheta = S(double(std::cos(xs[2])) * dt), stheta = S(double(std::sin(xs[2])) * dt);
+      (*A)(o + 0, o + 2) += -v * stheta;
+      (*A)(o + 1, o + 2) += v * ctheta;
+      (*A)(o + 2, o + 3) += S(dt);
+      (*B)(o + 3, uo + 0) = S(dt);
+      continue;
+    }
+    const bool unicycle = s.kind == ILQG_DYN_UNICYCLE_4D || s.kind == ILQG_DYN_UNICYCLE_4D_DISTURBED ||
+                          s.kind == ILQG_DYN_UNICYCLE_5D;
     const int vidx = unicycle ? 3 : 4;
     const S ctheta = S(double(std::cos(xs[2])) * dt);
     const S stheta = S(double(std::sin(xs[2])) * dt);
@@ -604,6 +638,7 @@ void Linearize(const Problem<S>& p, const Vec<S>& x, const Vec<S>& u, Mat<S>* A,
     if (unicycle) {
       (*B)(o + 2, uo + 0) = S(dt);
       (*B)(o + 3, uo + 1) = S(dt);
+      if (s.kind == ILQG_DYN_UNICYCLE_5D) (*A)(o + 4, o + 3) += S(dt);  // single_player_unicycle_5d.h:117
     } else {
       const S L = S(s.param0);
       const S cphi = std::cos(xs[3]);
@@ -613,6 +648,13 @@ void Linearize(const Problem<S>& p, const Vec<S>& x, const Vec<S>& u, Mat<S>* A,
       if (s.kind == ILQG_DYN_CAR_5D) {
         (*B)(o + 3, uo + 0) = S(dt);
         (*B)(o + 4, uo + 1) = S(dt);
+      } else if (s.kind == ILQG_DYN_CAR_7D) {  // single_player_car_7d.h:122-152: the all-double products of the
+        const S den = cphi * cphi * L;         // curvature row narrow once, at the store
+        (*A)(o + 5, o + 3) += S(2.0 * dt * double(u[uo]) * double(tphi) / double(den));
+        (*A)(o + 6, o + 4) += S(dt);
+        (*B)(o + 3, uo + 0) = S(dt);
+        (*B)(o + 4, uo + 1) = S(dt);
+        (*B)(o + 5, uo + 0) = S(dt / double(den));
       } else {
         (*A)(o + 4, o + 5) += S(dt);
         (*B)(o + 3, uo + 0) = S(dt);
@@ -1658,7 +1700,9 @@ bool SolveAL(const Problem<S>& p, const Vec<S>& x0, Trajectory<S>* op_io, Strate
             for (size_t ti = 0; ti < p.terms.size(); ti++) {
               const ilqg_cost_term& c = p.terms[ti];
               if (c.player != i || c.role != role) continue;
-              const S err = (role == ILQG_ROLE_STATE_CONSTRAINT)
+              // FinalTimeConstraint::Evaluate (constraint/final_time_constraint.h:66-70): 0 before its threshold
+              const S err = k < c.first_step ? S(0)
+                            : (role == ILQG_ROLE_STATE_CONSTRAINT)
                                 ? EvaluateTerm(p, (int)ti, res_op.xs[k].data(), p.n)
                                 : EvaluateTerm(p, (int)ti, &res_op.us[k][p.uoff[c.arg]], p.udim(c.arg));
               max_err = std::max(max_err, err);
@@ -1770,7 +1814,7 @@ int RecedingHorizonShift(const Problem<S>& p, const RecedingHorizonTimes& tm, co
   // (concatenated_dynamical_system.cpp:109-113); the car / unicycle models measure squared position distance
   // (TwoPlayerUnicycle4D overrides it the same way: px, py only, two_player_unicycle_4d.h:141-147) — SinglePlayerDubinsCar
   // alone inherits the default, the squared norm of its whole state (single_player_dynamical_system.h:69)
-  const int dist_dims = p.subs[0].kind == ILQG_DYN_DUBINS_CAR ? 3 : 2;
+  const int dist_dims = p.subs[0].kind == ILQG_DYN_DUBINS_CAR ? 3 : (p.subs[0].kind == ILQG_DYN_DELAYED_DUBINS_CAR ? 4 : 2);
   int first = 0;
   S best = std::numeric_limits<S>::infinity();
   for (int k = 0; k < T; k++) {
@@ -1902,7 +1946,7 @@ int SetUpNextRecedingHorizon(const Problem<S>& p, const Vec<S>& x0, double t0, d
   Vec<S> x = IntegrateToNextTimeStep(p, t0, x0, *pl);
   x = IntegrateSteps(p, size_t(tm.integrate_begin), size_t(tm.integrate_end), x, *pl);
   // nearest plan state in the first subsystem's DistanceBetween (see RecedingHorizonShift above)
-  const int dist_dims = p.subs[0].kind == ILQG_DYN_DUBINS_CAR ? 3 : 2;
+  const int dist_dims = p.subs[0].kind == ILQG_DYN_DUBINS_CAR ? 3 : (p.subs[0].kind == ILQG_DYN_DELAYED_DUBINS_CAR ? 4 : 2);
   int first = 0;
   S best = std::numeric_limits<S>::infinity();
   for (int k = 0; k < pl->len(); k++) {

@@ -1,5 +1,5 @@
-// Test scene written against the mirrored reference API (include/ilqgames/host/api.hpp): the same game as
-// ilqgames_amd/examples.py::cost_zoo_scene, term for term and in the same order, so that tests/test_host_mirror.py can
+// Test scenes written against the mirrored reference API (include/ilqgames/host/api.hpp): the same games as
+// ilqgames_amd/examples.py::cost_zoo_scene / dynamics_zoo_scene / delayed_dubins_scene, term for term and in the same order, so that tests/test_host_mirror.py can
 // check that the C++ classes of the cost / constraint kinds no reference example uses flatten to the descriptor the
 // Python builders produce.  Not a reference example.
 #pragma once
@@ -57,11 +57,92 @@ class CostZooScene : public TopDownRenderableProblem {
       player_costs_[ii].AddStateCost(std::make_shared<CurvatureCost>(20.0f, 5 * ii + Car::kPhiIdx, 5 * ii + Car::kVIdx, "curvature"));
     }
     player_costs_[0].AddStateConstraint(std::make_shared<Polyline2SignedDistanceConstraint>(wall, xy(0), -0.5f, true, "wall"));
-    player_costs_[1].AddStateConstraint(std::make_shared<Polyline2SignedDistanceConstraint>(lane1, xy(1), -60.0f, false, "far side"));
+    player_costs_[1].AddStateConstraint(std::make_shared<FinalTimeConstraint>(
+        std::make_shared<Polyline2SignedDistanceConstraint>(lane1, xy(1), -4.0f, false, "far side"), 4.0f));
   }
   std::vector<float> Xs(const VectorXf& x) const override { return {x(0), x(5)}; }
   std::vector<float> Ys(const VectorXf& x) const override { return {x(1), x(6)}; }
   std::vector<float> Thetas(const VectorXf& x) const override { return {x(2), x(7)}; }
+};
+
+// ilqgames_amd/examples.py::dynamics_zoo_scene — SinglePlayerCar7D and two SinglePlayerUnicycle5D.
+class DynamicsZooScene : public TopDownRenderableProblem {
+ public:
+  using Car = SinglePlayerCar7D;
+  using Uni = SinglePlayerUnicycle5D;
+  void ConstructDynamics() override {
+    dynamics_.reset(new ConcatenatedDynamicalSystem(
+        {std::make_shared<Car>(4.0f), std::make_shared<Uni>(), std::make_shared<Uni>()}));
+  }
+  void ConstructInitialState() override {
+    x0_ = VectorXf::Zero(dynamics_->XDim());
+    x0_(Car::kPyIdx) = -30.0f;
+    x0_(Car::kThetaIdx) = static_cast<float>(M_PI_2);
+    x0_(Car::kVIdx) = 4.0f;
+    x0_(7 + Uni::kPxIdx) = -5.0f;
+    x0_(7 + Uni::kPyIdx) = 30.0f;
+    x0_(7 + Uni::kThetaIdx) = static_cast<float>(-M_PI_2);
+    x0_(7 + Uni::kVIdx) = 3.0f;
+    x0_(12 + Uni::kPxIdx) = -25.0f;
+    x0_(12 + Uni::kPyIdx) = 8.0f;
+    x0_(12 + Uni::kVIdx) = 5.0f;
+  }
+  void ConstructPlayerCosts() override {
+    for (const char* name : {"car", "unicycle1", "unicycle2"}) player_costs_.emplace_back(name);
+    const Dimension base[3] = {0, 7, 12};
+    const Dimension v[3] = {Car::kVIdx, 7 + Uni::kVIdx, 12 + Uni::kVIdx};
+    const Dimension s[3] = {Car::kSIdx, 7 + Uni::kSIdx, 12 + Uni::kSIdx};
+    const auto xy = [&](PlayerIndex ii) { return std::make_pair(Dimension(base[ii]), Dimension(base[ii] + 1)); };
+    for (PlayerIndex ii = 0; ii < 3; ii++) {
+      PlayerCost& cost = player_costs_[ii];
+      cost.AddControlCost(ii, std::make_shared<QuadraticCost>(25.0f, 0, 0.0f, "steer"));
+      cost.AddControlCost(ii, std::make_shared<QuadraticCost>(15.0f, 1, 0.0f, "accelerate"));
+      cost.AddStateCost(std::make_shared<QuadraticCost>(10.0f, v[ii], 6.0f, "cruise"));
+      cost.AddStateCost(std::make_shared<QuadraticCost>(0.02f, s[ii], 50.0f, "path length"));
+    }
+    player_costs_[0].AddStateCost(std::make_shared<QuadraticCost>(30.0f, Car::kKappaIdx, 0.0f, "curvature"));
+    const Polyline2 lanes[3] = {
+        Polyline2({Point2(0.0, -1000.0), Point2(0.0, 1000.0)}),
+        Polyline2({Point2(-5.0, 1000.0), Point2(-5.0, 5.0), Point2(0.0, 0.0), Point2(995.0, 0.0)}),
+        Polyline2({Point2(-1000.0, 8.0), Point2(1000.0, 8.0)})};
+    for (PlayerIndex ii = 0; ii < 3; ii++)
+      player_costs_[ii].AddStateCost(std::make_shared<QuadraticPolyline2Cost>(25.0f, lanes[ii], xy(ii), "lane"));
+    for (PlayerIndex ii = 0; ii < 3; ii++)
+      for (PlayerIndex jj = 0; jj < 3; jj++)
+        if (ii != jj) player_costs_[ii].AddStateCost(std::make_shared<ProximityCost>(100.0f, xy(ii), xy(jj), 6.0f, "gap"));
+  }
+  std::vector<float> Xs(const VectorXf& x) const override { return {x(0), x(7), x(12)}; }
+  std::vector<float> Ys(const VectorXf& x) const override { return {x(1), x(8), x(13)}; }
+  std::vector<float> Thetas(const VectorXf& x) const override { return {x(2), x(9), x(14)}; }
+};
+
+// ilqgames_amd/examples.py::delayed_dubins_scene — two SinglePlayerDelayedDubinsCar.
+class DelayedDubinsScene : public TopDownRenderableProblem {
+ public:
+  using Car = SinglePlayerDelayedDubinsCar;
+  void ConstructDynamics() override {
+    dynamics_.reset(new ConcatenatedDynamicalSystem({std::make_shared<Car>(1.0f), std::make_shared<Car>(1.0f)}));
+  }
+  void ConstructInitialState() override {
+    x0_ = VectorXf::Zero(dynamics_->XDim());
+    const float x0[8] = {2.0f, 1.0f, static_cast<float>(M_PI_2), 0.0f, -1.0f, -2.0f, 0.3f, 0.1f};
+    for (int i = 0; i < 8; i++) x0_(i) = x0[i];
+  }
+  void ConstructPlayerCosts() override {
+    player_costs_.emplace_back("p1");
+    player_costs_.emplace_back("p2");
+    for (PlayerIndex ii = 0; ii < 2; ii++) {
+      player_costs_[ii].AddControlCost(ii, std::make_shared<QuadraticCost>(1.0f, Car::kAlphaIdx, 0.0f, "turn"));
+      player_costs_[ii].AddStateCost(std::make_shared<QuadraticCost>(2.0f, 4 * ii + Car::kOmegaIdx, 0.0f, "turn rate"));
+    }
+    player_costs_[0].AddStateCost(std::make_shared<QuadraticCost>(1.0f, Car::kPxIdx, 0.0f, "x"));
+    player_costs_[0].AddStateCost(std::make_shared<QuadraticCost>(1.0f, Car::kPyIdx, 0.0f, "y"));
+    player_costs_[1].AddStateCost(std::make_shared<QuadraticDifferenceCost>(
+        1.0f, std::vector<Dimension>{4 + Car::kPxIdx, 4 + Car::kPyIdx}, std::vector<Dimension>{Car::kPxIdx, Car::kPyIdx}, "chase"));
+  }
+  std::vector<float> Xs(const VectorXf& x) const override { return {x(0), x(4)}; }
+  std::vector<float> Ys(const VectorXf& x) const override { return {x(1), x(5)}; }
+  std::vector<float> Thetas(const VectorXf& x) const override { return {x(2), x(6)}; }
 };
 
 }  // namespace ilqgames

@@ -52,7 +52,7 @@ def test_lq_feedback_matches_reference_python_golden(hip, name):
 
 
 @pytest.mark.parametrize("dims", [(14, 3, 2), (16, 3, 2), (15, 3, 2), (24, 4, 2), (18, 3, 2), (10, 2, 2), (6, 3, 2),
-                                  (4, 2, 2), (6, 2, 1), (3, 2, 1), (3, 1, 1), (2, 2, 1)])
+                                  (4, 2, 2), (6, 2, 1), (3, 2, 1), (3, 1, 1), (2, 2, 1), (17, 3, 2), (8, 2, 1)])
 @pytest.mark.parametrize("dtype", [abi.F64, abi.F32])
 def test_lq_feedback_matches_oracle_random(hip, oracle, dims, dtype):
     n, N, mu = dims
@@ -69,7 +69,8 @@ def test_lq_feedback_matches_oracle_random(hip, oracle, dims, dtype):
     assert rel_err(_np(dx), dxr) < tol
 
 
-@pytest.mark.parametrize("dims", [(14, 3, 2), (16, 3, 2), (24, 4, 2), (18, 3, 2), (10, 2, 2), (6, 3, 2), (2, 2, 1)])
+@pytest.mark.parametrize("dims", [(14, 3, 2), (16, 3, 2), (24, 4, 2), (18, 3, 2), (10, 2, 2), (6, 3, 2), (2, 2, 1),
+                                  (17, 3, 2), (8, 2, 1)])
 @pytest.mark.parametrize("dtype", [abi.F64, abi.F32])
 def test_lq_openloop_matches_oracle_random(hip, oracle, dims, dtype):
     """ilqg_lq_openloop_batch vs the oracle's LQOpenLoopSolver restatement (alpha, delta_xs; P == 0)."""
@@ -257,7 +258,7 @@ def _clean(ref, max_bt=12):
                                  "three_player_collision_avoidance_reachability", "two_player_unicycle_4d_scene",
                                  "two_player_reachability", "skeleton", "three_player_overtaking",
                                  "one_player_reachability", "dubins_origin", "air_3d", "modified_air_3d",
-                                 "cost_zoo_scene"])
+                                 "cost_zoo_scene", "dynamics_zoo_scene", "delayed_dubins_scene"])
 def test_ilq_solve_matches_oracle_fp64(hip, oracle, cfg):
     """Whole iLQ loop, fp64, fixed iteration count.  Where the line search is well conditioned the
     device makes the oracle's accept/reject decisions, so trajectories, strategies and costs agree
@@ -449,7 +450,10 @@ def test_augmented_lagrangian_with_a_polyline_constraint_fp64(hip, oracle):
     spec.params.unconstrained_solver_max_iters = 5
     B = 12
     x0 = examples.jittered_x0(spec, B, seed=21)
-    ref, stable = oracle_with_stability(oracle.OracleProblem(spec), abi.F64, x0, augmented_lagrangian=True)
+    # thirty chained inner solves that each end in a failed line search: three nudged oracle runs pick the instances
+    # whose trajectories are reproducible at all (one run calls instance 3 stable, which then differs from itself by
+    # 2e-4 under another 1e-13 nudge)
+    ref, stable = oracle_with_stability(oracle.OracleProblem(spec), abi.F64, x0, draws=3, augmented_lagrangian=True)
     out = hip.Problem(spec, abi.F64).solve(x0, augmented_lagrangian=True)
     same = (_np(out["iters"]) == ref["iters"]) & (_np(out["status"]) == ref["status"])
     assert stable.sum() >= 3, "the test instances are all decided by rounding"
@@ -482,13 +486,14 @@ def test_augmented_lagrangian_single_player_dubins_fp64(hip, oracle):
     assert np.isfinite(_np(out["xs"])).all()
 
 
-@pytest.mark.parametrize("scene", ["modified_three_player_intersection", "dubins_origin"])
+@pytest.mark.parametrize("scene", ["modified_three_player_intersection", "dubins_origin", "delayed_dubins_scene"])
 @pytest.mark.parametrize("t0,runtime", [(0.33, 0.25), (0.0, 0.1), (1.07, 0.0), (2.5, 0.4)])
 def test_receding_horizon_shift_matches_oracle_fp64(hip, oracle, t0, runtime, scene):
     """Problem::SetUpNextRecedingHorizon on device vs the oracle's restatement: same nearest-state index, same
     shifted / zero-extended / re-propagated plan, same stitched initial state; then the warm-started solve from
     it reproduces the oracle's.  dubins_origin: an ego whose model inherits the default DistanceBetween (the squared
-    norm of its whole state, heading included — single_player_dynamical_system.h:69) instead of a position metric."""
+    norm of its whole state, heading included — single_player_dynamical_system.h:69) instead of a position metric;
+    delayed_dubins_scene: the same with four states, through the plain-RK4 integrator."""
     spec = examples.CONFIGS[scene]()
     spec.params.initial_alpha_scaling = 0.5
     spec.params.expected_decrease_fraction = 0.001

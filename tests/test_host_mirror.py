@@ -154,16 +154,20 @@ def test_reference_example_source_compiles_unchanged_and_flattens_like_examples_
     assert got.num_constraints == want.num_constraints
 
 
-def test_cpp_cost_zoo_scene_flattens_like_examples_py(tmp_path):
-    """The mirrored classes of the kinds no reference example uses (OrientationCost, QuadraticNormCost,
-    SemiquadraticNormCost, RelativeDistanceCost, LocallyConvexProximityCost, CurvatureCost,
-    Polyline2SignedDistanceConstraint): tests/host/zoo_scene.h builds examples.cost_zoo_scene through them."""
+@pytest.mark.parametrize("cls,builder,nc", [("CostZooScene", examples.cost_zoo_scene, 2),
+                                            ("DynamicsZooScene", examples.dynamics_zoo_scene, 0),
+                                            ("DelayedDubinsScene", examples.delayed_dubins_scene, 0)])
+def test_cpp_zoo_scenes_flatten_like_examples_py(tmp_path, cls, builder, nc):
+    """The mirrored classes no reference example uses — the costs OrientationCost, QuadraticNormCost,
+    SemiquadraticNormCost, RelativeDistanceCost, LocallyConvexProximityCost, CurvatureCost, the constraint
+    Polyline2SignedDistanceConstraint, the models SinglePlayerCar7D, SinglePlayerUnicycle5D,
+    SinglePlayerDelayedDubinsCar: tests/host/zoo_scene.h builds the scenes of examples.py through them."""
     entry.build_host()
     exe = str(tmp_path / "dump_zoo")
     _compile(exe, [os.path.join(ROOT, "tests", "host", "dump_example.cpp")],
-             ['-DEXAMPLE_HEADER="zoo_scene.h"', "-DEXAMPLE_CLASS=CostZooScene", "-I" + os.path.join(ROOT, "tests", "host")])
+             ['-DEXAMPLE_HEADER="zoo_scene.h"', "-DEXAMPLE_CLASS=" + cls, "-I" + os.path.join(ROOT, "tests", "host")])
     got = abi.ProblemSpec.from_dump(subprocess.check_output([exe], text=True))
-    want = examples.cost_zoo_scene()
+    want = builder()
     g, w = got.canonical(), want.canonical()
     for key in ("subsystems", "player_costs", "pairs", "T", "dt"):
         assert g[key] == w[key], key
@@ -171,7 +175,7 @@ def test_cpp_cost_zoo_scene_flattens_like_examples_py(tmp_path):
     for key in w["groups"]:
         assert g["groups"][key] == w["groups"][key], key
     np.testing.assert_allclose(np.array(got.x0, np.float32), np.array(want.x0, np.float32), rtol=1e-6, atol=1e-6)
-    assert got.num_constraints == want.num_constraints == 2
+    assert got.num_constraints == want.num_constraints == nc
 
 
 # ------------------------------------------------------------------------------------------------

@@ -62,7 +62,10 @@ def _dyn_spec(kinds):
                                    (DYN_UNICYCLE_4D, DYN_CAR_5D), (DYN_CAR_6D, DYN_CAR_6D, DYN_UNICYCLE_4D),
                                    (abi.DYN_UNICYCLE_4D_DISTURBED, abi.DYN_PLANAR_DISTURBANCE), (abi.DYN_DUBINS_CAR,),
                                    (abi.DYN_DUBINS_CAR, DYN_CAR_5D), (abi.DYN_AIR_3D_EVADER, abi.DYN_AIR_3D_PURSUER),
-                                   (abi.DYN_POINT_MASS_2D, abi.DYN_POINT_MASS_2D)])
+                                   (abi.DYN_POINT_MASS_2D, abi.DYN_POINT_MASS_2D),
+                                   # test_linearization.cpp:120-131,149-155: Car7D, Unicycle5D, DelayedDubinsCar
+                                   (abi.DYN_CAR_7D,), (abi.DYN_UNICYCLE_5D,), (abi.DYN_DELAYED_DUBINS_CAR,),
+                                   (abi.DYN_CAR_7D, abi.DYN_UNICYCLE_5D, abi.DYN_UNICYCLE_5D)])
 def test_linearization_matches_finite_differences(oracle, kinds):
     """test_linearization.cpp:71-100: A = I + dt df/dx, B_i = dt df/du_i against forward differences
     (h = 1e-3, tolerance 1e-2 there; the fp64 oracle meets 1e-5)."""
