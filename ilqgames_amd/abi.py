@@ -13,7 +13,7 @@ F32, F64 = 0, 1
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_NO_DEVICE = 0, 1, 2, 3, 4
 
 # ilqg_dyn_kind
-ABI_VERSION = 3  # ILQG_ABI_VERSION of include/ilqg.h these mirrors were written against
+ABI_VERSION = 4  # ILQG_ABI_VERSION of include/ilqg.h these mirrors were written against
 DYN_UNICYCLE_4D, DYN_CAR_5D, DYN_CAR_6D = 1, 2, 3
 DYN_UNICYCLE_4D_DISTURBED, DYN_PLANAR_DISTURBANCE = 4, 5  # the two rows of TwoPlayerUnicycle4D
 DYN_DUBINS_CAR = 6  # (px, py, theta), u = (omega), param0 = speed
@@ -35,6 +35,8 @@ COST_RELATIVE_DISTANCE = 15
 COST_LOCALLY_CONVEX_PROXIMITY = 16
 COST_CURVATURE = 17
 CONSTRAINT_POLYLINE2_SIGNED_DISTANCE = 18
+COST_NOMINAL_PATH_LENGTH = 19  # time-dependent: quadratic about k * dt * speed
+COST_ROUTE_PROGRESS = 20       # time-dependent: quadratic about the polyline point at pos0 + k * dt * speed
 # ilqg_cost_role
 ROLE_STATE_COST, ROLE_CONTROL_COST, ROLE_STATE_CONSTRAINT, ROLE_CONTROL_CONSTRAINT, ROLE_CHILD = range(5)
 FLAG_ORIENTED, FLAG_IS_MIN = 1, 2
@@ -68,7 +70,8 @@ class Subsystem(C.Structure):
 
 class CostTerm(C.Structure):
     _fields_ = [("kind", C.c_int32), ("role", C.c_int32), ("player", C.c_int32), ("arg", C.c_int32),
-                ("idx", C.c_int32 * 4), ("weight", C.c_float), ("value", C.c_float), ("flags", C.c_int32),
+                ("idx", C.c_int32 * 4), ("weight", C.c_float), ("value", C.c_float), ("value2", C.c_float),
+                ("flags", C.c_int32),
                 ("polyline", C.c_int32), ("child_begin", C.c_int32), ("child_count", C.c_int32),
                 ("constraint_slot", C.c_int32), ("first_step", C.c_int32)]
 
@@ -161,7 +164,7 @@ class ProblemSpec:
         return len(self.polylines) - 1
 
     def _term(self, kind, role, player, arg=-1, idx=(0, 0, 0, 0), weight=1.0, value=0.0, flags=0,
-              polyline=-1, child_begin=0, child_count=0, constraint=False, first_step=0):
+              polyline=-1, child_begin=0, child_count=0, constraint=False, first_step=0, value2=0.0):
         idx = tuple(idx) + (0,) * (4 - len(idx))
         slot = -1
         if constraint:
@@ -169,7 +172,7 @@ class ProblemSpec:
             self._num_constraints += 1
         self.terms.append(dict(kind=kind, role=role, player=player, arg=arg, idx=idx, weight=weight,
                                value=value, flags=flags, polyline=polyline, child_begin=child_begin,
-                               child_count=child_count, constraint_slot=slot, first_step=first_step))
+                               child_count=child_count, constraint_slot=slot, first_step=first_step, value2=value2))
         return len(self.terms) - 1
 
     def final_time(self, threshold_time, term):
@@ -246,6 +249,15 @@ class ProblemSpec:
         return self._term(CONSTRAINT_POLYLINE2_SIGNED_DISTANCE, ROLE_STATE_CONSTRAINT, player, -1, xy, 1.0, threshold,
                           FLAG_ORIENTED if keep_left else 0, polyline, constraint=True)
 
+    def nominal_path_length(self, player, weight, dim, nominal_speed):
+        """NominalPathLengthCost (src/nominal_path_length_cost.cpp:50-78)."""
+        return self._term(COST_NOMINAL_PATH_LENGTH, ROLE_STATE_COST, player, -1, (dim,), weight, nominal_speed)
+
+    def route_progress(self, player, weight, nominal_speed, polyline, xy, initial_route_pos=0.0):
+        """RouteProgressCost (src/route_progress_cost.cpp:52-110)."""
+        return self._term(COST_ROUTE_PROGRESS, ROLE_STATE_COST, player, -1, xy, weight, nominal_speed, 0, polyline,
+                          value2=initial_route_pos)
+
     def extreme_value(self, player, children, is_min):
         """children: list of callables(role) -> term index, created contiguously as CHILD terms."""
         begin = len(self.terms)
@@ -290,7 +302,8 @@ class ProblemSpec:
                                        idx=tuple(int(a) for a in v[4:8]), weight=float(v[8]), value=float(v[9]),
                                        flags=int(v[10]), polyline=int(v[11]), child_begin=int(v[12]),
                                        child_count=int(v[13]), constraint_slot=int(v[14]),
-                                       first_step=int(v[15]) if len(v) > 15 else 0))
+                                       first_step=int(v[15]) if len(v) > 15 else 0,
+                                       value2=float(v[16]) if len(v) > 16 else 0.0))
                 if int(v[14]) >= 0:
                     spec._num_constraints = max(spec._num_constraints, int(v[14]) + 1)
             elif tok[0] == "polyline":
@@ -320,7 +333,7 @@ class ProblemSpec:
                 if t["polyline"] >= 0 else None
             kids = tuple(term_key(self.terms[c]) for c in range(t["child_begin"], t["child_begin"] + t["child_count"]))
             return (t["kind"], t["arg"], tuple(t["idx"]), f32(t["weight"]), f32(t["value"]), t["flags"], poly, kids,
-                    t.get("first_step", 0))
+                    t.get("first_step", 0), f32(t.get("value2", 0.0)))
 
         groups = {}
         for t in self.terms:
@@ -358,6 +371,7 @@ class ProblemSpec:
                       "child_count", "constraint_slot"):
                 setattr(ct, k, t[k])
             ct.first_step = t.get("first_step", 0)
+            ct.value2 = t.get("value2", 0.0)
             for a in range(4):
                 ct.idx[a] = t["idx"][a]
         d.num_terms = len(self.terms)

@@ -616,6 +616,8 @@ struct ilqg_problem {
   float* d_poly_pts = nullptr;
   float* d_segs_f = nullptr;
   double* d_segs_d = nullptr;
+  double* d_tnom_f = nullptr;
+  double* d_tnom_d = nullptr;
   int* d_cost_order = nullptr;
   int* d_row_prog = nullptr;
   int* d_unfinished = nullptr;  // instances still running after an LQ-kernel launch
@@ -1225,6 +1227,53 @@ ilqg_status ilqg_problem_create(const ilqg_problem_desc* desc, ilqg_problem** ou
     }
   }
   d.total_segs = int(segs_f.size() / kSegStride);
+  // Per-step nominals of the time-dependent costs, one table per such term and geometry precision (doubles: the
+  // path-length nominal is a double product in the reference, nominal_path_length_cost.cpp:53; the route point is a
+  // pair of the geometry's scalars, exact in double).  t = RelativeTime(k) = double(k) * dt (relative_time_tracker.h:
+  // 63-65); the route position is a float (a scalar of the geometry) made from a double expression
+  // (route_progress_cost.cpp:57-59) and Polyline2::PointAt walks the cumulative lengths (src/polyline2.cpp:68-103).
+  std::vector<double> tnom_f, tnom_d;
+  {
+    int ntab = 0;
+    for (int ti = 0; ti < desc->num_terms; ti++) {
+      DevTerm& o = dt[ti];
+      if (!term_is_time_dependent(o.kind)) continue;
+      const bool route = o.kind == ILQG_COST_ROUTE_PROGRESS;
+      if (o.role != ILQG_ROLE_STATE_COST || (route && (o.polyline < 0 || o.polyline >= desc->num_polylines))) {
+        ilqg_problem_destroy(p);
+        return fail(ILQG_ERR_INVALID, "a time-dependent cost must be a top-level state cost (with a polyline, for "
+                                      "RouteProgressCost)");
+      }
+      const int src_poly = o.polyline;
+      auto point_at = [&](const auto& segs, auto route_pos, double* px, double* py) {
+        using S = decltype(route_pos);
+        const int first = desc->polyline_offsets[src_poly] - src_poly;
+        const int nseg = desc->polyline_offsets[src_poly + 1] - desc->polyline_offsets[src_poly] - 1;
+        std::vector<S> cumulative(1, S(0));
+        for (int c = 0; c < nseg; c++) cumulative.push_back(cumulative.back() + segs[size_t(first + c) * kSegStride + 4]);
+        auto upper = std::upper_bound(cumulative.begin(), cumulative.end(), route_pos);
+        if (upper == cumulative.end()) upper--;
+        upper--;
+        const size_t idx = size_t(upper - cumulative.begin());
+        const S remaining = route_pos - cumulative[idx];
+        const S* sg = &segs[size_t(first + idx) * kSegStride];
+        *px = double(S(sg[0] + remaining * sg[5]));
+        *py = double(S(sg[1] + remaining * sg[6]));
+      };
+      for (int k = 0; k < d.T; k++) {
+        const double t = double(k) * d.dt;
+        double f0 = t * double(o.value), f1 = 0.0, d0 = f0, d1 = 0.0;
+        if (route) {
+          const double pos = double(desc->terms[ti].value2) + (t - 0.0) * double(o.value);
+          point_at(segs_f, float(pos), &f0, &f1);
+          point_at(segs_d, double(pos), &d0, &d1);
+        }
+        tnom_f.push_back(f0); tnom_f.push_back(f1);
+        tnom_d.push_back(d0); tnom_d.push_back(d1);
+      }
+      o.polyline = ntab++;  // from here on: the term's table
+    }
+  }
   // TotalCosts summation order per player: state costs then control costs, table order
   int maxc = 0;
   for (int i = 0; i < d.N; i++) {
@@ -1247,6 +1296,14 @@ ilqg_status ilqg_problem_create(const ilqg_problem_desc* desc, ilqg_problem** ou
   if (e == hipSuccess) e = hipMalloc(&p->d_segs_d, sizeof(double) * (segs_d.size() + 1));
   if (e == hipSuccess && !segs_d.empty())
     e = hipMemcpy(p->d_segs_d, segs_d.data(), sizeof(double) * segs_d.size(), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMalloc(&p->d_tnom_f, sizeof(double) * (tnom_f.size() + 2));
+  if (e == hipSuccess && !tnom_f.empty())
+    e = hipMemcpy(p->d_tnom_f, tnom_f.data(), sizeof(double) * tnom_f.size(), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMalloc(&p->d_tnom_d, sizeof(double) * (tnom_d.size() + 2));
+  if (e == hipSuccess && !tnom_d.empty())
+    e = hipMemcpy(p->d_tnom_d, tnom_d.data(), sizeof(double) * tnom_d.size(), hipMemcpyHostToDevice);
+  d.time_nominal_f = p->d_tnom_f;
+  d.time_nominal_d = p->d_tnom_d;
   if (e == hipSuccess) e = hipMalloc(&p->d_cost_order, sizeof(int) * order.size());
   if (e == hipSuccess) e = hipMemcpy(p->d_cost_order, order.data(), sizeof(int) * order.size(), hipMemcpyHostToDevice);
   // the term table is uploaded last: it carries the argument offsets computed above
@@ -1296,6 +1353,8 @@ void ilqg_problem_destroy(ilqg_problem* p) {
   if (p->d_poly_pts) (void)hipFree(p->d_poly_pts);
   if (p->d_segs_f) (void)hipFree(p->d_segs_f);
   if (p->d_segs_d) (void)hipFree(p->d_segs_d);
+  if (p->d_tnom_f) (void)hipFree(p->d_tnom_f);
+  if (p->d_tnom_d) (void)hipFree(p->d_tnom_d);
   if (p->d_cost_order) (void)hipFree(p->d_cost_order);
   if (p->d_row_prog) (void)hipFree(p->d_row_prog);
   if (p->d_unfinished) (void)hipFree(p->d_unfinished);

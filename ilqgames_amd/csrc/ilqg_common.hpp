@@ -84,6 +84,11 @@ struct DevProblem {
   const float* segs_f;
   const double* segs_d;
   int total_segs;
+  // Per-step nominals of the time-dependent costs (NominalPathLengthCost: t_k * speed; RouteProgressCost: the route
+  // point at pos0 + t_k * speed), [table][T][2] doubles, one copy per geometry precision; DevTerm::polyline of such a
+  // term is its table.  Tabulated by ilqg_problem_create.
+  const double* time_nominal_f;
+  const double* time_nominal_d;
   // TotalCosts summation order: per player [count, term indices...] (state costs, then control costs)
   const int* cost_order;
   int cost_order_stride;
@@ -121,6 +126,9 @@ constexpr int kSegStride = 21;
 template <typename T> __device__ __forceinline__ const T* problem_segs(const DevProblem& p);
 template <> __device__ __forceinline__ const float* problem_segs<float>(const DevProblem& p) { return p.segs_f; }
 template <> __device__ __forceinline__ const double* problem_segs<double>(const DevProblem& p) { return p.segs_d; }
+template <typename T> __device__ __forceinline__ const double* problem_time_nominal(const DevProblem& p);
+template <> __device__ __forceinline__ const double* problem_time_nominal<float>(const DevProblem& p) { return p.time_nominal_f; }
+template <> __device__ __forceinline__ const double* problem_time_nominal<double>(const DevProblem& p) { return p.time_nominal_d; }
 
 // user priority 0..3 of the calling wave (s_setprio takes an immediate)
 __device__ __forceinline__ void set_wave_prio(int pr) {

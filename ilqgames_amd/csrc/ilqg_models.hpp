@@ -359,7 +359,13 @@ struct QuadTables {
   // kernel-argument copy with a per-lane index is a global load (and `rgoff[pii[i]]` a chain of two);
   // from LDS it is a 64-cycle read.  Layout: LC_* offsets below, floats stored as their bit patterns.
   const int* lc;
+  // The per-step nominals of the time-dependent costs (DevProblem::time_nominal of this precision), [table][T][2].
+  const double* tnom;
+  int tnom_T;
 };
+__host__ __device__ inline bool term_is_time_dependent(int kind) {
+  return kind == ILQG_COST_NOMINAL_PATH_LENGTH || kind == ILQG_COST_ROUTE_PROGRESS;
+}
 enum {
   LC_KIND = 0, LC_XOFF = LC_KIND + kMaxPlayers, LC_UOFF = LC_XOFF + kMaxPlayers + 1,
   LC_UDIM = LC_UOFF + kMaxPlayers + 1, LC_PARAM = LC_UDIM + kMaxPlayers, LC_SREG = LC_PARAM + kMaxPlayers,
@@ -436,11 +442,23 @@ __device__ __forceinline__ T orientation_difference(T angle, T nominal) {
 
 // `v` is anything indexable that yields the argument vector's entries: a pointer (LDS / global row) or the
 // transposed-row accessor of the lane-per-time-step stage (ilqg_rows.hpp).
+// `step`: the time step the term is evaluated at (the time-dependent kinds read their nominal of that step).
 template <typename T, typename V>
-__device__ __forceinline__ T term_evaluate_leaf_of(const QuadTables<T>& tb, const DevTerm& c, const V& v, int dim) {
+__device__ __forceinline__ T term_evaluate_leaf_of(const QuadTables<T>& tb, const DevTerm& c, const V& v, int dim,
+                                                   int step = 0) {
   const T w = T(c.weight), val = T(c.value);
   const bool oriented = c.flags & ILQG_FLAG_ORIENTED;
   switch (c.kind) {
+    case ILQG_COST_NOMINAL_PATH_LENGTH: {  // src/nominal_path_length_cost.cpp:50-56
+      const double nom = tb.tnom[(size_t(c.polyline) * tb.tnom_T + step) * 2];
+      const T delta = T(double(v[c.idx[0]]) - nom);
+      return T(0.5) * w * delta * delta;
+    }
+    case ILQG_COST_ROUTE_PROGRESS: {  // src/route_progress_cost.cpp:52-64
+      const double* nom = tb.tnom + (size_t(c.polyline) * tb.tnom_T + step) * 2;
+      const T dx = v[c.idx[0]] - T(nom[0]), dy = v[c.idx[1]] - T(nom[1]);
+      return T(0.5) * w * (dx * dx + dy * dy);
+    }
     case ILQG_COST_QUADRATIC: {  // src/quadratic_cost.cpp:51-63
       if (c.idx[0] >= 0) {
         const T d = v[c.idx[0]] - val;
@@ -533,9 +551,9 @@ __device__ __forceinline__ T term_evaluate_leaf_of(const QuadTables<T>& tb, cons
   return T(0);
 }
 template <typename T, typename V>
-__device__ __forceinline__ T term_evaluate_leaf(const QuadTables<T>& tb, int ti, const V& v, int dim) {
+__device__ __forceinline__ T term_evaluate_leaf(const QuadTables<T>& tb, int ti, const V& v, int dim, int step = 0) {
   const DevTerm c = tb.terms[ti];
-  return term_evaluate_leaf_of<T, V>(tb, c, v, dim);
+  return term_evaluate_leaf_of<T, V>(tb, c, v, dim, step);
 }
 
 // ExtremeValueCost::ExtremeCost, src/extreme_value_cost.cpp:66-85: index of the active child.
@@ -596,9 +614,11 @@ struct TermOut {
 // search is shared).  `lambda`, `mu`: augmented-Lagrangian state of a constraint term.
 // `pre`: the closest point of this term's polyline to its position, when the caller already has it.  HAVE_PRE: the
 // caller always has it (the polyline searches are compiled out of this function).
+// `tnom`: this step's nominal pair of a time-dependent term (term_is_time_dependent).
 template <typename T, typename V, bool HAVE_PRE = false>
 __device__ __forceinline__ void term_compute_leaf(const QuadTables<T>& tb, const DevTerm& c, const V& v, T lambda,
-                                                  T mu, TermOut<T>* o, const Closest<T>* pre = nullptr) {
+                                                  T mu, TermOut<T>* o, const Closest<T>* pre = nullptr,
+                                                  const double* tnom = nullptr) {
   const T w = T(c.weight), val = T(c.value);
   const bool oriented = c.flags & ILQG_FLAG_ORIENTED;
   o->pattern = PAT_NONE;
@@ -606,6 +626,21 @@ __device__ __forceinline__ void term_compute_leaf(const QuadTables<T>& tb, const
   o->i0 = c.idx[0]; o->i1 = c.idx[1]; o->i2 = c.idx[2]; o->i3 = c.idx[3];
   o->gx = o->gy = o->hxx = o->hyy = o->hxy = T(0);
   switch (c.kind) {
+    case ILQG_COST_NOMINAL_PATH_LENGTH: {  // src/nominal_path_length_cost.cpp:50-78
+      const T delta = T(double(v[c.idx[0]]) - tnom[0]);
+      o->value = T(0.5) * w * delta * delta;
+      o->pattern = PAT_SINGLE;
+      o->gx = w * delta;
+      o->hxx = w;
+      return;
+    }
+    case ILQG_COST_ROUTE_PROGRESS: {  // src/route_progress_cost.cpp:52-110
+      const T dx = v[c.idx[0]] - T(tnom[0]), dy = v[c.idx[1]] - T(tnom[1]);
+      o->value = T(0.5) * w * (dx * dx + dy * dy);
+      o->pattern = PAT_PAIR2;
+      o->gx = w * dx; o->gy = w * dy; o->hxx = w; o->hyy = w;
+      return;
+    }
     case ILQG_COST_QUADRATIC: {  // src/quadratic_cost.cpp:51-94
       if (c.idx[0] >= 0) {
         const T d = v[c.idx[0]] - val;

@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(64) strategy_costs_kernel(DevProblem p, Strate
         if (c.kind == ILQG_COST_EXTREME_VALUE)
           (void)extreme_child<T>(tb, c, at + c.arg_off, c.arg_dim, &value);
         else
-          value = term_evaluate_leaf<T>(tb, ti, at + c.arg_off, c.arg_dim);
+          value = term_evaluate_leaf<T>(tb, ti, at + c.arg_off, c.arg_dim, at_step);
       }
       sval[ti] = value;
     }

@@ -299,7 +299,8 @@ inline bool build_row_program(const DevProblem& d, const std::vector<DevTerm>& d
         } else {
           want_closest(c, c);
           const int b0 = leaf_sids(c, c);
-          emit_op(ROP_TERM, b0, int(sids.size()) - b0, 0, c, c, 0, term_pattern_of(c.kind, c.idx[0]));
+          emit_op(ROP_TERM, b0, int(sids.size()) - b0, 0, c, c, term_is_time_dependent(c.kind) ? c.polyline : 0,
+                  term_pattern_of(c.kind, c.idx[0]));
         }
       }
     if (!ok) { *err = "row program: a term's indices are out of range or not distinct"; return false; }

@@ -255,6 +255,7 @@ __host__ __device__ inline int term_pattern_of(int kind, int idx0) {
     case ILQG_COST_QUADRATIC: return idx0 >= 0 ? PAT_SINGLE : PAT_ALL;
     case ILQG_COST_SEMIQUADRATIC:
     case ILQG_COST_ORIENTATION:
+    case ILQG_COST_NOMINAL_PATH_LENGTH:
     case ILQG_CONSTRAINT_SINGLE_DIMENSION: return PAT_SINGLE;
     case ILQG_COST_QUADRATIC_POLYLINE2:
     case ILQG_COST_SEMIQUADRATIC_POLYLINE2:
@@ -262,6 +263,7 @@ __host__ __device__ inline int term_pattern_of(int kind, int idx0) {
     case ILQG_COST_QUADRATIC_NORM:
     case ILQG_COST_SEMIQUADRATIC_NORM:
     case ILQG_COST_CURVATURE:
+    case ILQG_COST_ROUTE_PROGRESS:
     case ILQG_CONSTRAINT_POLYLINE2_SIGNED_DISTANCE: return PAT_PAIR2;
     case ILQG_COST_PROXIMITY:
     case ILQG_COST_SIGNED_DISTANCE:
@@ -524,7 +526,13 @@ __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* map
         ILQG_QPH(2);
 #endif
         TermOut<T> o;
-        term_compute_leaf<T, RowArg<T>, true>(QuadTables<T>{}, c, v, lambda, a.mu, &o, &cc);
+        double tnom[2] = {0.0, 0.0};
+        if (term_is_time_dependent(c.kind)) {  // this row's nominal; the op's RO_POLY_FIRST field is the term's table
+          const double* tn = problem_time_nominal<T>(p) + (size_t(od(RO_POLY_FIRST)) * p.T + row) * 2;
+          tnom[0] = tn[0];
+          tnom[1] = tn[1];
+        }
+        term_compute_leaf<T, RowArg<T>, true>(QuadTables<T>{}, c, v, lambda, a.mu, &o, &cc, tnom);
 #if ILQG_PROFILE2
         ILQG_QPH(3);
 #endif

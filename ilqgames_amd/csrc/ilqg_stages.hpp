@@ -239,6 +239,8 @@ __device__ __forceinline__ QuadTables<T> quad_tables_load(const DevProblem& p, v
   tb.poly_off = poff;
   tb.order = order;
   tb.lc = lc;
+  tb.tnom = problem_time_nominal<T>(p);
+  tb.tnom_T = p.T;
   return tb;
 }
 

@@ -655,7 +655,7 @@ def cost_zoo_scene(T=100, dt=0.1):
 def dynamics_zoo_scene(T=100, dt=0.1):
     """A test scene, NOT a reference example: the single-player models no reference example uses — one Car7D and two
     Unicycle5D (n = 17) — on the crossing lanes of the skeleton example, with costs on the states only these models
-    have (curvature kappa, path length s)."""
+    have (curvature kappa, path length s) and the two time-dependent costs (NominalPathLengthCost, RouteProgressCost)."""
     prm = SolverParams.default()
     prm.max_backtracking_steps = 100
     prm.initial_alpha_scaling = 0.1
@@ -673,11 +673,14 @@ def dynamics_zoo_scene(T=100, dt=0.1):
         s.quadratic(i, 10.0, V[i], 6.0)
         s.quadratic(i, 0.02, S[i], 50.0)           # path length driven towards 50 m
     s.quadratic(0, 30.0, KAPPA, 0.0)
+    s.nominal_path_length(1, 0.5, S[1], 5.0)        # the time-dependent costs: path length 5 m/s * t ...
     lane1 = s.add_polyline([(0.0, -1000.0), (0.0, 1000.0)])
     lane2 = s.add_polyline([(-5.0, 1000.0), (-5.0, 5.0), (0.0, 0.0), (995.0, 0.0)])
     lane3 = s.add_polyline([(-1000.0, 8.0), (1000.0, 8.0)])
     for i, lane in enumerate((lane1, lane2, lane3)):
         s.quadratic_polyline2(i, 25.0, lane, (X[i], Y[i]))
+    s.route_progress(0, 2.0, 6.0, lane1, (X[0], Y[0]), 970.0)   # ... and a point moving up lane 1 at 6 m/s from y = -30
+    s.route_progress(1, 1.0, 4.0, lane2, (X[1], Y[1]), 968.0)   # (lane 2's corner at route position 995 is passed)
     for i in range(3):
         for j in range(3):
             if i != j:

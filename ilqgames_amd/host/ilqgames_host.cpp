@@ -277,6 +277,16 @@ bool CurvatureCost::Describe(host::TermDescription* out) const {
   FillTerm(out, ILQG_COST_CURVATURE, weight_, 0.0f, 0, {omega_idx_, v_idx_});
   return true;
 }
+bool NominalPathLengthCost::Describe(host::TermDescription* out) const {
+  FillTerm(out, ILQG_COST_NOMINAL_PATH_LENGTH, weight_, nominal_speed_, 0, {dimension_});
+  return true;
+}
+bool RouteProgressCost::Describe(host::TermDescription* out) const {
+  FillTerm(out, ILQG_COST_ROUTE_PROGRESS, weight_, nominal_speed_, 0, {xidx_, yidx_});
+  out->term.value2 = initial_route_pos_;
+  out->polyline = &polyline_;
+  return true;
+}
 bool FinalTimeCost::Describe(host::TermDescription* out) const {
   if (!cost_->Describe(out) || out->term.kind == ILQG_COST_EXTREME_VALUE) return false;
   // the first step whose time ILQSolver hands to Evaluate / Quadraticize (RelativeTime(kk) = kk * kTimeStep,
@@ -532,7 +542,7 @@ std::string DumpDescription(const ProblemDescription& description) {
     os << "term " << t.kind << " " << t.role << " " << t.player << " " << t.arg << " " << t.idx[0] << " " << t.idx[1]
        << " " << t.idx[2] << " " << t.idx[3] << " " << t.weight << " " << t.value << " " << t.flags << " "
        << t.polyline << " " << t.child_begin << " " << t.child_count << " " << t.constraint_slot << " " << t.first_step
-       << "\n";
+       << " " << t.value2 << "\n";
   for (int q = 0; q < d.num_polylines; q++) {
     os << "polyline";
     for (int p = description.polyline_offsets[q]; p < description.polyline_offsets[q + 1]; p++)
@@ -631,7 +641,7 @@ static std::string Fingerprint(const ProblemDescription& d) {
   pod.dt = d.desc.dt;
   pod.dtype = d.desc.dtype;
   std::memcpy(&pod.params, &d.desc.params, sizeof(pod.params));  // 4-byte fields only: no padding
-  static_assert(sizeof(ilqg_solver_params) % 4 == 0 && sizeof(ilqg_cost_term) == 16 * 4, "packed 4-byte fields");
+  static_assert(sizeof(ilqg_solver_params) % 4 == 0 && sizeof(ilqg_cost_term) == 17 * 4, "packed 4-byte fields");
   std::string f(reinterpret_cast<const char*>(&pod), sizeof(pod));
   f.append(reinterpret_cast<const char*>(d.terms.data()), d.terms.size() * sizeof(ilqg_cost_term));
   f.append(reinterpret_cast<const char*>(d.polyline_offsets.data()), d.polyline_offsets.size() * sizeof(int32_t));

@@ -184,8 +184,17 @@ typedef enum {
   ILQG_COST_LOCALLY_CONVEX_PROXIMITY = 16, /* src/locally_convex_proximity_cost.cpp:50-108: idx = (x1, y1, x2, y2),
                                         value = threshold; 0.5 w min((thr - |dx|)^2, (thr - |dy|)^2) inside the box */
   ILQG_COST_CURVATURE = 17,          /* src/curvature_cost.cpp:50-86: idx = (omega index, v index); 0.5 w (omega / v)^2 */
-  ILQG_CONSTRAINT_POLYLINE2_SIGNED_DISTANCE = 18 /* src/polyline2_signed_distance_constraint.cpp:52-144: idx = (x, y),
+  ILQG_CONSTRAINT_POLYLINE2_SIGNED_DISTANCE = 18, /* src/polyline2_signed_distance_constraint.cpp:52-144: idx = (x, y),
                                         polyline, value = threshold, ORIENTED = keep_left */
+  /* The two costs that depend on time.  ILQSolver hands them the time RELATIVE to the start of the window
+   * (src/ilq_solver.cpp:186,236: RelativeTime(kk) = kk * dt), so each is a quadratic about a per-step nominal that
+   * ilqg_problem_create tabulates.  RouteProgressCost subtracts RelativeTimeTracker's initial time from that
+   * relative time (src/route_progress_cost.cpp:58), which is 0 until a receding-horizon step resets it: the tables
+   * are those of a first solve. */
+  ILQG_COST_NOMINAL_PATH_LENGTH = 19, /* src/nominal_path_length_cost.cpp:50-78: idx[0] = dimension, value =
+                                        nominal speed; 0.5 w (x[dim] - t * speed)^2 */
+  ILQG_COST_ROUTE_PROGRESS = 20      /* src/route_progress_cost.cpp:52-110: idx = (x, y), polyline, value = nominal
+                                        speed, value2 = initial route position; 0.5 w |p - PointAt(pos0 + t speed)|^2 */
 } ilqg_cost_kind;
 
 /* Where a term sits inside PlayerCost::Quadraticize (src/player_cost.cpp:194-215):
@@ -212,6 +221,7 @@ typedef struct {
                           CONSTRAINT_PROXIMITY: (x1, y1, x2, y2)                */
   float weight;        /* Cost::weight_                                        */
   float value;         /* nominal_ or threshold_                               */
+  float value2;        /* ROUTE_PROGRESS: initial_route_pos_; else 0            */
   int32_t flags;       /* ILQG_FLAG_*                                          */
   int32_t polyline;    /* index into the polyline table or -1                  */
   int32_t child_begin; /* EXTREME_VALUE: first child term index                */
@@ -536,7 +546,8 @@ const char* ilqg_last_error(void);
 ilqg_status ilqg_set_scratch(void* device_buffer, size_t bytes);
 
 /* Library / device introspection (used by the loader to fail loudly). */
-#define ILQG_ABI_VERSION 3 /* 3: ilqg_solve_options / ilqg_solve_batch_ex / ilqg_solve_state_batch, ilqg_dims::sweep_formulation;
+#define ILQG_ABI_VERSION 4 /* 4: ilqg_cost_term::value2, cost kinds 12-20, dynamics kinds 10-12;
+                              3: ilqg_solve_options / ilqg_solve_batch_ex / ilqg_solve_state_batch, ilqg_dims::sweep_formulation;
                               the workspace holds every device buffer a solve uses */
 int32_t ilqg_abi_version(void);
 ilqg_status ilqg_device_info(char* name_out, int32_t name_len, int32_t* num_cus);

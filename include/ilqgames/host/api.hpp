@@ -361,6 +361,36 @@ class CurvatureCost : public TimeInvariantCost {
   const Dimension omega_idx_, v_idx_;
 };
 
+// include/ilqgames/cost/nominal_path_length_cost.h:54-77 — 0.5 w (x[dim] - t nominal_speed)^2, t the time the solver
+// hands to the cost (relative to the start of the window, src/ilq_solver.cpp:186,236).
+class NominalPathLengthCost : public Cost {
+ public:
+  NominalPathLengthCost(float weight, Dimension dim, float nominal_speed, const std::string& name = "")
+      : Cost(weight, name), dimension_(dim), nominal_speed_(nominal_speed) {}
+  bool Describe(host::TermDescription* out) const override;
+
+ private:
+  const Dimension dimension_;
+  const float nominal_speed_;
+};
+
+// include/ilqgames/cost/route_progress_cost.h:55-96 — 0.5 w |p - route(initial_route_pos + t nominal_speed)|^2
+class RouteProgressCost : public Cost {
+ public:
+  RouteProgressCost(float weight, float nominal_speed, const Polyline2& polyline,
+                    const std::pair<Dimension, Dimension>& position_idxs, const std::string& name = "",
+                    float initial_route_pos = 0.0)
+      : Cost(weight, name), nominal_speed_(nominal_speed), polyline_(polyline), xidx_(position_idxs.first),
+        yidx_(position_idxs.second), initial_route_pos_(initial_route_pos) {}
+  bool Describe(host::TermDescription* out) const override;
+
+ private:
+  const float nominal_speed_;
+  const Polyline2 polyline_;
+  const Dimension xidx_, yidx_;
+  const float initial_route_pos_;
+};
+
 // include/ilqgames/cost/final_time_cost.h:55-88 — another cost, switched on from `threshold_time` (relative to the
 // start of the window) onwards; zero value and derivatives before.
 class FinalTimeCost : public Cost {

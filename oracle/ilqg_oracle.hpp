@@ -260,6 +260,18 @@ struct Polyline2 {  // src/polyline2.cpp:52-63
       segs.emplace_back(S(pts[2 * (i - 1)]), S(pts[2 * (i - 1) + 1]), S(pts[2 * i]),
                         S(pts[2 * i + 1]));
   }
+  // src/polyline2.cpp:68-103 (the cumulative lengths of the constructor, :52-63, formed on the way)
+  void PointAt(S route_pos, S* px, S* py) const {
+    std::vector<S> cumulative(1, S(0));
+    for (const auto& s : segs) cumulative.push_back(cumulative.back() + s.length);
+    auto upper = std::upper_bound(cumulative.begin(), cumulative.end(), route_pos);
+    if (upper == cumulative.end()) upper--;  // off the end of the route: the reference warns and clamps
+    upper--;
+    const size_t idx = size_t(upper - cumulative.begin());
+    const S remaining = route_pos - cumulative[idx];
+    *px = segs[idx].p1x + remaining * segs[idx].ux;
+    *py = segs[idx].p1y + remaining * segs[idx].uy;
+  }
   // src/polyline2.cpp:105-174
   void ClosestPoint(S qx, S qy, S* cx, S* cy, bool* is_vertex, Segment2<S>* segment,
                     S* signed_sq, bool* is_endpoint) const {
@@ -674,13 +686,45 @@ inline S ConstraintMu(S lambda, S g, S mu) {
   return mu;
 }
 
-// Cost::Evaluate for every in-scope kind.
+// The per-step nominal of the two time-dependent costs at step k (t = RelativeTime(k) = double(k) * dt, Time = double;
+// relative_time_tracker.h:63-65): NominalPathLengthCost's t * nominal_speed (a double product of a double and a
+// float, nominal_path_length_cost.cpp:53) and RouteProgressCost's route point (the route position is a float made from
+// that double expression, route_progress_cost.cpp:57-59, RelativeTimeTracker's initial time = 0).
+// Returned as doubles: the path-length nominal IS a double there; the route point is an S pair (exact in double).
 template <class S>
-S EvaluateTerm(const Problem<S>& p, int ti, const S* v, int dim) {
+inline void TimeNominal(const Problem<S>& p, const ilqg_cost_term& c, int k, double* nx, double* ny) {
+  const double t = double(k) * p.dt;
+  if (c.kind == ILQG_COST_NOMINAL_PATH_LENGTH) {
+    *nx = t * double(c.value);
+    *ny = 0.0;
+  } else {
+    const S route_pos = S(double(c.value2) + (t - 0.0) * double(c.value));
+    S px, py;
+    p.polylines[c.polyline].PointAt(route_pos, &px, &py);
+    *nx = double(px);
+    *ny = double(py);
+  }
+}
+
+// Cost::Evaluate for every in-scope kind.  `step`: the time step the term is evaluated at (the time-dependent kinds).
+template <class S>
+S EvaluateTerm(const Problem<S>& p, int ti, const S* v, int dim, int step = 0) {
   const ilqg_cost_term& c = p.terms[ti];
   const S w = S(c.weight), val = S(c.value);
   const bool oriented = c.flags & ILQG_FLAG_ORIENTED;
   switch (c.kind) {
+    case ILQG_COST_NOMINAL_PATH_LENGTH: {  // src/nominal_path_length_cost.cpp:50-56
+      double nom, unused;
+      TimeNominal(p, c, step, &nom, &unused);
+      const S delta = S(double(v[c.idx[0]]) - nom);
+      return S(0.5) * w * delta * delta;
+    }
+    case ILQG_COST_ROUTE_PROGRESS: {  // src/route_progress_cost.cpp:52-64
+      double px, py;
+      TimeNominal(p, c, step, &px, &py);
+      const S dx = v[c.idx[0]] - S(px), dy = v[c.idx[1]] - S(py);
+      return S(0.5) * w * (dx * dx + dy * dy);
+    }
     case ILQG_COST_QUADRATIC: {  // src/quadratic_cost.cpp:51-63
       if (c.idx[0] >= 0) {
         const S delta = v[c.idx[0]] - val;
@@ -827,6 +871,26 @@ void QuadraticizeTerm(const Problem<S>& p, int ti, double t, const S* v, int dim
   Mat<S>& H = *hess;
   Vec<S>& G = *grad;
   switch (c.kind) {
+    case ILQG_COST_NOMINAL_PATH_LENGTH: {  // src/nominal_path_length_cost.cpp:58-76
+      double nom, unused;
+      TimeNominal(p, c, int(std::llround(t / p.dt)), &nom, &unused);
+      const S delta = S(double(v[c.idx[0]]) - nom);
+      G[c.idx[0]] += w * delta;
+      H(c.idx[0], c.idx[0]) += w;
+      return;
+    }
+    case ILQG_COST_ROUTE_PROGRESS: {  // src/route_progress_cost.cpp:66-108
+      double px, py;
+      TimeNominal(p, c, int(std::llround(t / p.dt)), &px, &py);
+      const int xi = c.idx[0], yi = c.idx[1];
+      G[xi] += w * (v[xi] - S(px));
+      G[yi] += w * (v[yi] - S(py));
+      H(xi, xi) += w;
+      H(yi, yi) += w;
+      H(xi, yi) += S(0);
+      H(yi, xi) += S(0);
+      return;
+    }
     case ILQG_COST_QUADRATIC: {  // src/quadratic_cost.cpp:65-94
       if (c.idx[0] >= 0) {
         const int d = c.idx[0];
@@ -1191,12 +1255,12 @@ S EvaluatePlayer(const Problem<S>& p, int i, const Vec<S>& x, const Vec<S>& u, i
   const int nt = (int)p.terms.size();
   for (int ti = 0; ti < nt; ti++)
     if (p.terms[ti].player == i && p.terms[ti].role == ILQG_ROLE_STATE_COST && k_state >= p.terms[ti].first_step)
-      total += EvaluateTerm(p, ti, x.data(), p.n);
+      total += EvaluateTerm(p, ti, x.data(), p.n, k_state);
   for (int ti = 0; ti < nt; ti++)
     if (p.terms[ti].player == i && p.terms[ti].role == ILQG_ROLE_CONTROL_COST &&
         k_control >= p.terms[ti].first_step) {
       const int j = p.terms[ti].arg;
-      total += EvaluateTerm(p, ti, &u[p.uoff[j]], p.udim(j));
+      total += EvaluateTerm(p, ti, &u[p.uoff[j]], p.udim(j), k_control);
     }
   return total;
 }

@@ -672,10 +672,11 @@ void oracle_dynamics(void* h, int dtype, const double* x, const double* u, doubl
 // augmented-Lagrangian value of every constraint of the player
 // (Constraint::EvaluateAugmentedLagrangian, constraint.h:83-87) with lambda/mu given.
 double oracle_player_value(void* h, int player, const double* x, const double* u, int include_constraints,
-                           double lambda, double mu) {
+                           double lambda, double mu, int step) {
   const auto& p = *((OracleProblem*)h)->pd;
   Vec<double> xv(x, x + p.n), uv(u, u + p.m);
-  double v = EvaluatePlayer(p, player, xv, uv);
+  // step < 0: "late enough for every FinalTimeCost"; otherwise the time step the costs are evaluated at
+  double v = step < 0 ? EvaluatePlayer(p, player, xv, uv) : EvaluatePlayer(p, player, xv, uv, step, step);
   if (include_constraints)
     for (size_t ti = 0; ti < p.terms.size(); ti++) {
       const auto& t = p.terms[ti];

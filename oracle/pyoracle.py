@@ -290,11 +290,11 @@ class OracleProblem:
         lib().oracle_dynamics(self.h, dtype, _p(x), _p(u), _p(xdot), _p(xn), int(euler))
         return xdot, xn
 
-    def player_value(self, player, x, u, include_constraints=False, lam=0.0, mu=10.0):
+    def player_value(self, player, x, u, include_constraints=False, lam=0.0, mu=10.0, step=-1):
         x = np.ascontiguousarray(x, np.float64)
         u = np.ascontiguousarray(u, np.float64)
         return lib().oracle_player_value(self.h, int(player), _p(x), _p(u), int(include_constraints),
-                                         C.c_double(lam), C.c_double(mu))
+                                         C.c_double(lam), C.c_double(mu), int(step))
 
 
 def polyline_closest_point(pts, q, dtype=abi.F32):

@@ -101,12 +101,15 @@ class DynamicsZooScene : public TopDownRenderableProblem {
       cost.AddStateCost(std::make_shared<QuadraticCost>(0.02f, s[ii], 50.0f, "path length"));
     }
     player_costs_[0].AddStateCost(std::make_shared<QuadraticCost>(30.0f, Car::kKappaIdx, 0.0f, "curvature"));
+    player_costs_[1].AddStateCost(std::make_shared<NominalPathLengthCost>(0.5f, s[1], 5.0f, "on schedule"));
     const Polyline2 lanes[3] = {
         Polyline2({Point2(0.0, -1000.0), Point2(0.0, 1000.0)}),
         Polyline2({Point2(-5.0, 1000.0), Point2(-5.0, 5.0), Point2(0.0, 0.0), Point2(995.0, 0.0)}),
         Polyline2({Point2(-1000.0, 8.0), Point2(1000.0, 8.0)})};
     for (PlayerIndex ii = 0; ii < 3; ii++)
       player_costs_[ii].AddStateCost(std::make_shared<QuadraticPolyline2Cost>(25.0f, lanes[ii], xy(ii), "lane"));
+    player_costs_[0].AddStateCost(std::make_shared<RouteProgressCost>(2.0f, 6.0f, lanes[0], xy(0), "progress", 970.0f));
+    player_costs_[1].AddStateCost(std::make_shared<RouteProgressCost>(1.0f, 4.0f, lanes[1], xy(1), "progress", 968.0f));
     for (PlayerIndex ii = 0; ii < 3; ii++)
       for (PlayerIndex jj = 0; jj < 3; jj++)
         if (ii != jj) player_costs_[ii].AddStateCost(std::make_shared<ProximityCost>(100.0f, xy(ii), xy(jj), 6.0f, "gap"));

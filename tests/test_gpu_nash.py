@@ -35,14 +35,19 @@ def _solved(oracle, cfg, B, iters):
 
 @pytest.mark.parametrize("cfg", ["modified_three_player_intersection", "three_player_collision_avoidance_reachability",
                                  "two_player_unicycle_4d_scene", "roundabout_merging", "two_player_reachability",
-                                 "one_player_reachability", "air_3d", "modified_air_3d"])
+                                 "one_player_reachability", "air_3d", "modified_air_3d",
+                                 # the kinds no reference example uses (time-dependent costs, Car7D / Unicycle5D /
+                                 # DelayedDubinsCar on the plain RK4, the norm / orientation / curvature costs)
+                                 "cost_zoo_scene", "dynamics_zoo_scene", "delayed_dubins_scene"])
 @pytest.mark.parametrize("open_loop,euler", [(False, True), (True, True), (False, False)])
 def test_strategy_costs_match_oracle_fp64(hip, oracle, cfg, open_loop, euler):
     spec, op, x0, r = _solved(oracle, cfg, 3, 2)
     ref = op.strategy_costs(abi.F64, x0, r["xs"], r["us"], r["P"], r["alpha"], open_loop=open_loop, euler=euler)
     out = hip.Problem(spec, abi.F64).strategy_costs(x0, r["xs"], r["us"], r["P"], r["alpha"], open_loop=open_loop,
                                                     euler=euler)
-    fin = np.isfinite(ref).all(axis=1)  # an Euler replay of an unstable closed loop can overflow (Air3D does)
+    # a replay of an unstable closed loop can overflow (Air3D's Euler replay does) or run away to 1e20+ (one instance of
+    # dynamics_zoo_scene after two iterations): a diverging trajectory amplifies rounding without bound, nothing to compare
+    fin = np.isfinite(ref).all(axis=1) & (np.abs(np.nan_to_num(ref)).max(axis=1) < 1e12)
     assert fin.any()
     assert rel_err(_np(out)[fin], ref[fin]) < 1e-10
 

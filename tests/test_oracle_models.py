@@ -215,6 +215,11 @@ COST_BUILDERS = {
         0, s.add_polyline([(-2.0, -2.0), (0.5, 1.0), (2.0, 2.0)]), (0, 1), 10.0, True),
     "polyline2_signed_distance_constraint_right": lambda s: s.polyline2_signed_distance_constraint(
         0, s.add_polyline(LANE), (0, 1), -0.5, False),
+    # the time-dependent costs (test_quadraticization.cpp:241-263), evaluated at step 1 below
+    "nominal_path_length": lambda s: s.nominal_path_length(0, 1.0, 0, 1.0),
+    "route_progress": lambda s: s.route_progress(0, 1.0, 0.1, s.add_polyline([(-2.0, -2.0), (0.5, 1.0), (2.0, 2.0)]),
+                                                 (0, 1)),
+    "route_progress_from_2m": lambda s: s.route_progress(0, 3.0, 20.0, s.add_polyline(LANE), (0, 1), 2.0),
 }
 
 
@@ -259,7 +264,7 @@ def test_quadraticization_matches_numerical_derivatives(oracle, name):
         g = l[0, 1, 0]
 
         def val(xx):
-            return op.player_value(0, xx, u, include_constraints=is_constraint, lam=lam, mu=mu)
+            return op.player_value(0, xx, u, include_constraints=is_constraint, lam=lam, mu=mu, step=1)
         h = 1e-5
         gn = np.zeros(n)
         Hn = np.zeros((n, n))
