@@ -37,6 +37,7 @@ COST_CURVATURE = 17
 CONSTRAINT_POLYLINE2_SIGNED_DISTANCE = 18
 COST_NOMINAL_PATH_LENGTH = 19  # time-dependent: quadratic about k * dt * speed
 COST_ROUTE_PROGRESS = 20       # time-dependent: quadratic about the polyline point at pos0 + k * dt * speed
+COST_WEIGHTED_CONVEX_PROXIMITY = 21  # idx = (x1, y1, x2, y2), idx_extra = (v1, v2)
 # ilqg_cost_role
 ROLE_STATE_COST, ROLE_CONTROL_COST, ROLE_STATE_CONSTRAINT, ROLE_CONTROL_CONSTRAINT, ROLE_CHILD = range(5)
 FLAG_ORIENTED, FLAG_IS_MIN = 1, 2
@@ -70,7 +71,8 @@ class Subsystem(C.Structure):
 
 class CostTerm(C.Structure):
     _fields_ = [("kind", C.c_int32), ("role", C.c_int32), ("player", C.c_int32), ("arg", C.c_int32),
-                ("idx", C.c_int32 * 4), ("weight", C.c_float), ("value", C.c_float), ("value2", C.c_float),
+                ("idx", C.c_int32 * 4), ("idx_extra", C.c_int32 * 2), ("weight", C.c_float), ("value", C.c_float),
+                ("value2", C.c_float),
                 ("flags", C.c_int32),
                 ("polyline", C.c_int32), ("child_begin", C.c_int32), ("child_count", C.c_int32),
                 ("constraint_slot", C.c_int32), ("first_step", C.c_int32)]
@@ -164,7 +166,8 @@ class ProblemSpec:
         return len(self.polylines) - 1
 
     def _term(self, kind, role, player, arg=-1, idx=(0, 0, 0, 0), weight=1.0, value=0.0, flags=0,
-              polyline=-1, child_begin=0, child_count=0, constraint=False, first_step=0, value2=0.0):
+              polyline=-1, child_begin=0, child_count=0, constraint=False, first_step=0, value2=0.0,
+              idx_extra=(0, 0)):
         idx = tuple(idx) + (0,) * (4 - len(idx))
         slot = -1
         if constraint:
@@ -172,7 +175,8 @@ class ProblemSpec:
             self._num_constraints += 1
         self.terms.append(dict(kind=kind, role=role, player=player, arg=arg, idx=idx, weight=weight,
                                value=value, flags=flags, polyline=polyline, child_begin=child_begin,
-                               child_count=child_count, constraint_slot=slot, first_step=first_step, value2=value2))
+                               child_count=child_count, constraint_slot=slot, first_step=first_step, value2=value2,
+                               idx_extra=tuple(idx_extra)))
         return len(self.terms) - 1
 
     def final_time(self, threshold_time, term):
@@ -258,6 +262,11 @@ class ProblemSpec:
         return self._term(COST_ROUTE_PROGRESS, ROLE_STATE_COST, player, -1, xy, weight, nominal_speed, 0, polyline,
                           value2=initial_route_pos)
 
+    def weighted_convex_proximity(self, player, weight, xy1, xy2, vidx1, vidx2, threshold):
+        """WeightedConvexProximityCost (src/weighted_convex_proximity_cost.cpp:50-158)."""
+        return self._term(COST_WEIGHTED_CONVEX_PROXIMITY, ROLE_STATE_COST, player, -1, tuple(xy1) + tuple(xy2), weight,
+                          threshold, idx_extra=(vidx1, vidx2))
+
     def extreme_value(self, player, children, is_min):
         """children: list of callables(role) -> term index, created contiguously as CHILD terms."""
         begin = len(self.terms)
@@ -303,7 +312,8 @@ class ProblemSpec:
                                        flags=int(v[10]), polyline=int(v[11]), child_begin=int(v[12]),
                                        child_count=int(v[13]), constraint_slot=int(v[14]),
                                        first_step=int(v[15]) if len(v) > 15 else 0,
-                                       value2=float(v[16]) if len(v) > 16 else 0.0))
+                                       value2=float(v[16]) if len(v) > 16 else 0.0,
+                                       idx_extra=(int(v[17]), int(v[18])) if len(v) > 18 else (0, 0)))
                 if int(v[14]) >= 0:
                     spec._num_constraints = max(spec._num_constraints, int(v[14]) + 1)
             elif tok[0] == "polyline":
@@ -333,7 +343,7 @@ class ProblemSpec:
                 if t["polyline"] >= 0 else None
             kids = tuple(term_key(self.terms[c]) for c in range(t["child_begin"], t["child_begin"] + t["child_count"]))
             return (t["kind"], t["arg"], tuple(t["idx"]), f32(t["weight"]), f32(t["value"]), t["flags"], poly, kids,
-                    t.get("first_step", 0), f32(t.get("value2", 0.0)))
+                    t.get("first_step", 0), f32(t.get("value2", 0.0)), tuple(t.get("idx_extra", (0, 0))))
 
         groups = {}
         for t in self.terms:
@@ -372,6 +382,8 @@ class ProblemSpec:
                 setattr(ct, k, t[k])
             ct.first_step = t.get("first_step", 0)
             ct.value2 = t.get("value2", 0.0)
+            for a in range(2):
+                ct.idx_extra[a] = t.get("idx_extra", (0, 0))[a]
             for a in range(4):
                 ct.idx[a] = t["idx"][a]
         d.num_terms = len(self.terms)

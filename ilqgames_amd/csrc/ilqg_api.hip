@@ -1178,6 +1178,15 @@ ilqg_status ilqg_problem_create(const ilqg_problem_desc* desc, ilqg_problem** ou
     o.weight = t.weight; o.value = t.value; o.flags = t.flags; o.polyline = t.polyline;
     o.child_begin = t.child_begin; o.child_count = t.child_count; o.slot = t.constraint_slot;
     o.k_start = t.first_step;
+    if (t.kind == ILQG_COST_WEIGHTED_CONVEX_PROXIMITY) {  // its two speed indices ride in `polyline` (wcp_indices)
+      if (t.role != ILQG_ROLE_STATE_COST || t.idx_extra[0] < 0 || t.idx_extra[0] >= d.n || t.idx_extra[1] < 0 ||
+          t.idx_extra[1] >= d.n) {
+        delete p;
+        return fail(ILQG_ERR_INVALID, "WeightedConvexProximityCost must be a top-level state cost with speed indices "
+                                      "inside the state");
+      }
+      o.polyline = t.idx_extra[0] | (t.idx_extra[1] << 16);
+    }
     if (t.constraint_slot >= 0 && t.constraint_slot + 1 > nc) nc = t.constraint_slot + 1;
   }
   d.num_constraints = nc;

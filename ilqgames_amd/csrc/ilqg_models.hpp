@@ -363,6 +363,48 @@ struct QuadTables {
   const double* tnom;
   int tnom_T;
 };
+// WeightedConvexProximityCost touches more entries than one pattern holds: the row program evaluates it as four ops —
+// the cost kind itself (the position block: the relative-position pattern, and the value) and three internal kinds
+// that only exist inside row programs: the speed block (PAIR2 over (v1, v2)) and the position x speed blocks of the
+// two axes (CROSS4; only the active axis contributes).  Every op re-derives the few scalars it needs from the six
+// state entries; where the indices that are not part of its own pattern travel is wcp_indices().
+enum { ILQG_INTERNAL_WCP_SPEED = 101, ILQG_INTERNAL_WCP_CROSS_X = 102, ILQG_INTERNAL_WCP_CROSS_Y = 103 };
+__host__ __device__ inline bool term_is_wcp(int kind) {
+  return kind == ILQG_COST_WEIGHTED_CONVEX_PROXIMITY || (kind >= ILQG_INTERNAL_WCP_SPEED && kind <= ILQG_INTERNAL_WCP_CROSS_Y);
+}
+// (x1, y1, x2, y2, v1, v2) of the op's term; the op's own pattern indices are idx[], the others ride in 16-bit halves
+// of `polyline` (and of idx[2], idx[3] for the speed block, whose pattern uses two indices).
+struct WcpIdx { int x1, y1, x2, y2, v1, v2; };  // scalars, not an array: the kernels keep them in (scalar) registers
+__host__ __device__ inline WcpIdx wcp_indices(const DevTerm& c) {
+  const int lo = c.polyline & 0xffff, hi = (c.polyline >> 16) & 0xffff;
+  WcpIdx ix;
+  if (c.kind == ILQG_COST_WEIGHTED_CONVEX_PROXIMITY) {
+    ix.x1 = c.idx[0]; ix.y1 = c.idx[1]; ix.x2 = c.idx[2]; ix.y2 = c.idx[3]; ix.v1 = lo; ix.v2 = hi;
+  } else if (c.kind == ILQG_INTERNAL_WCP_SPEED) {
+    ix.v1 = c.idx[0]; ix.v2 = c.idx[1];
+    ix.x1 = c.idx[2] & 0xffff; ix.y1 = (c.idx[2] >> 16) & 0xffff; ix.x2 = c.idx[3] & 0xffff; ix.y2 = (c.idx[3] >> 16) & 0xffff;
+  } else if (c.kind == ILQG_INTERNAL_WCP_CROSS_X) {
+    ix.x1 = c.idx[0]; ix.x2 = c.idx[1]; ix.v1 = c.idx[2]; ix.v2 = c.idx[3]; ix.y1 = lo; ix.y2 = hi;
+  } else {
+    ix.y1 = c.idx[0]; ix.y2 = c.idx[1]; ix.v1 = c.idx[2]; ix.v2 = c.idx[3]; ix.x1 = lo; ix.x2 = hi;
+  }
+  return ix;
+}
+// The sub-op `which` (0 = the cost kind, else an internal kind) of the term whose indices are ix.
+__host__ inline DevTerm wcp_sub_term(const DevTerm& c, const WcpIdx& ix, int which) {
+  DevTerm o = c;
+  o.kind = which == 0 ? int(ILQG_COST_WEIGHTED_CONVEX_PROXIMITY) : which;
+  if (which == 0) {
+    o.idx[0] = ix.x1; o.idx[1] = ix.y1; o.idx[2] = ix.x2; o.idx[3] = ix.y2; o.polyline = ix.v1 | (ix.v2 << 16);
+  } else if (which == ILQG_INTERNAL_WCP_SPEED) {
+    o.idx[0] = ix.v1; o.idx[1] = ix.v2; o.idx[2] = ix.x1 | (ix.y1 << 16); o.idx[3] = ix.x2 | (ix.y2 << 16); o.polyline = 0;
+  } else if (which == ILQG_INTERNAL_WCP_CROSS_X) {
+    o.idx[0] = ix.x1; o.idx[1] = ix.x2; o.idx[2] = ix.v1; o.idx[3] = ix.v2; o.polyline = ix.y1 | (ix.y2 << 16);
+  } else {
+    o.idx[0] = ix.y1; o.idx[1] = ix.y2; o.idx[2] = ix.v1; o.idx[3] = ix.v2; o.polyline = ix.x1 | (ix.x2 << 16);
+  }
+  return o;
+}
 __host__ __device__ inline bool term_is_time_dependent(int kind) {
   return kind == ILQG_COST_NOMINAL_PATH_LENGTH || kind == ILQG_COST_ROUTE_PROGRESS;
 }
@@ -542,6 +584,16 @@ __device__ __forceinline__ T term_evaluate_leaf_of(const QuadTables<T>& tb, cons
       const T curvature = v[c.idx[0]] / v[c.idx[1]];
       return T(0.5) * w * curvature * curvature;
     }
+    case ILQG_COST_WEIGHTED_CONVEX_PROXIMITY: {  // src/weighted_convex_proximity_cost.cpp:50-61
+      const WcpIdx ix = wcp_indices(c);
+      const T dx = v[ix.x1] - v[ix.x2], dy = v[ix.y1] - v[ix.y2];
+      const T v1 = v[ix.v1], v2 = v[ix.v2];
+      const T vv = v1 * v1 + v2 * v2;
+      if (dx * dx >= val * val || dy * dy >= val * val) return T(0);
+      const T ax = val - t_abs(dx), ay = val - t_abs(dy);
+      const T sx = ax * ax, sy = ay * ay;
+      return T(0.5) * w * vv * (sy < sx ? sy : sx);
+    }
     case ILQG_CONSTRAINT_POLYLINE2_SIGNED_DISTANCE: {  // src/polyline2_signed_distance_constraint.cpp:57-69
       const Closest<T> cl = polyline_closest<T>(tb, c.polyline, v[c.idx[0]], v[c.idx[1]]);
       const T value = sgn(cl.ssd) * t_sqrt(t_abs(cl.ssd)) - val;
@@ -600,7 +652,10 @@ __device__ __forceinline__ void modify_derivatives(T lambda, T mu_in, T g, T* dx
 //                          ProximityConstraint: with s = (+,+,-,-) over (x1,y1,x2,y2),
 //                          G[p] += s_p g_type(p),  H(p,q) += s_p s_q h_type(p),type(q)
 //   ALL:                   QuadraticCost with dimension < 0: G[i] += w (v[i]-nominal), H(i,i) += w
-enum { PAT_NONE = 0, PAT_SINGLE = 1, PAT_PAIR2 = 2, PAT_PAIR4 = 3, PAT_ALL = 4 };
+//   CROSS4 (p1,p2,v1,v2):  the position x speed block of WeightedConvexProximityCost, no gradient part:
+//                          H(p1,v1) += hxx, H(p1,v2) += hyy, H(p2,v1) -= hxx, H(p2,v2) -= hyy, and the transposed four
+enum { PAT_NONE = 0, PAT_SINGLE = 1, PAT_PAIR2 = 2, PAT_PAIR4 = 3, PAT_ALL = 4, PAT_CROSS4 = 5 };
+
 
 template <typename T>
 struct TermOut {
@@ -851,6 +906,36 @@ __device__ __forceinline__ void term_compute_leaf(const QuadTables<T>& tb, const
         o->gx = -w * ax; o->hxx = w;
       } else {
         o->gy = -w * ay; o->hyy = w;
+      }
+      return;
+    }
+    case ILQG_COST_WEIGHTED_CONVEX_PROXIMITY:  // src/weighted_convex_proximity_cost.cpp:50-158, as written there
+    case ILQG_INTERNAL_WCP_SPEED:
+    case ILQG_INTERNAL_WCP_CROSS_X:
+    case ILQG_INTERNAL_WCP_CROSS_Y: {
+      const WcpIdx ix = wcp_indices(c);
+      const T dx = v[ix.x1] - v[ix.x2], dy = v[ix.y1] - v[ix.y2];
+      const T v1 = v[ix.v1], v2 = v[ix.v2];
+      const T vv = v1 * v1 + v2 * v2;
+      if (dx * dx >= val * val || dy * dy >= val * val) return;
+      const T ax = val - t_abs(dx), ay = val - t_abs(dy);
+      const T sx = ax * ax, sy = ay * ay;
+      const bool x_active = sx < sy;
+      const T delta = x_active ? ax : ay, d = x_active ? dx : dy;
+      if (c.kind == ILQG_COST_WEIGHTED_CONVEX_PROXIMITY) {
+        o->value = T(0.5) * w * vv * (sy < sx ? sy : sx);
+        o->pattern = PAT_PAIR4;  // one axis only: the other one's entries get an exact +-0
+        if (x_active) { o->gx = -w * delta * vv; o->hxx = w; } else { o->gy = -w * delta * vv; o->hyy = w; }
+      } else if (c.kind == ILQG_INTERNAL_WCP_SPEED) {
+        o->pattern = PAT_PAIR2;
+        o->gx = -w * v1 * delta * delta;
+        o->gy = -w * v2 * delta * delta;
+        o->hxx = w * delta * delta;
+        o->hyy = o->hxx;
+      } else if (x_active == (c.kind == ILQG_INTERNAL_WCP_CROSS_X)) {
+        o->pattern = PAT_CROSS4;
+        o->hxx = T(-2.0) * w * v1 * sgn(d);
+        o->hyy = T(-2.0) * w * v2 * sgn(d);
       }
       return;
     }

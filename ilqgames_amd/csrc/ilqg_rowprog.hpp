@@ -69,6 +69,10 @@ inline bool build_row_program(const DevProblem& d, const std::vector<DevTerm>& d
     } else if (pat == PAT_ALL) {
       for (int i = 0; i < dim; i++) e->push_back({false, i, 0});
       for (int i = 0; i < dim; i++) e->push_back({true, i, i});
+    } else if (pat == PAT_CROSS4) {
+      const int p1 = c.idx[0], p2 = c.idx[1], v1 = c.idx[2], v2 = c.idx[3];
+      const int hh[8][2] = {{p1, v1}, {p1, v2}, {p2, v1}, {p2, v2}, {v1, p1}, {v1, p2}, {v2, p1}, {v2, p2}};
+      for (auto& q : hh) e->push_back({true, q[0], q[1]});
     }
   };
   auto on_state = [&](const DevTerm& c) {
@@ -295,6 +299,18 @@ inline bool build_row_program(const DevProblem& d, const std::vector<DevTerm>& d
             want_closest(ch, c);
             const int b0 = leaf_sids(ch, c);
             emit_op(ROP_EXT_APPLY, b0, int(sids.size()) - b0, q, ch, c, 0, term_pattern_of(ch.kind, ch.idx[0]));
+          }
+        } else if (c.kind == ILQG_COST_WEIGHTED_CONVEX_PROXIMITY) {
+          // four ops (ilqg_models.hpp): the position block carries the value, then the speed block and the two
+          // position x speed blocks
+          const WcpIdx ix = wcp_indices(c);
+          for (int e : {ix.x1, ix.y1, ix.x2, ix.y2, ix.v1, ix.v2})
+            if (e < 0 || e >= n) ok = false;
+          const int which[4] = {0, ILQG_INTERNAL_WCP_SPEED, ILQG_INTERNAL_WCP_CROSS_X, ILQG_INTERNAL_WCP_CROSS_Y};
+          for (int q = 0; q < 4 && ok; q++) {
+            const DevTerm sub = wcp_sub_term(c, ix, which[q]);
+            const int b0 = leaf_sids(sub, c);
+            emit_op(ROP_TERM, b0, int(sids.size()) - b0, 0, sub, c, sub.polyline, term_pattern_of(sub.kind, sub.idx[0]));
           }
         } else {
           want_closest(c, c);

@@ -246,6 +246,17 @@ __device__ __forceinline__ void rows_scatter(int pattern, const TermOut<T>& o, c
       col[sid[i] * cws] += o.gx * (v[i] - o.gy);
       if (want_h) col[sid[dim + i] * cws] += o.gx;
     }
+  } else if (pattern == PAT_CROSS4 && want_h) {
+    //   H(p1,v1) (p1,v2) (p2,v1) (p2,v2) (v1,p1) (v1,p2) (v2,p1) (v2,p2)
+    T* pp[8];
+    T av[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) pp[e] = col + sid[e] * cws;
+#pragma unroll
+    for (int e = 0; e < 8; e++) av[e] = *pp[e];
+    const T add[8] = {o.hxx, o.hyy, -o.hxx, -o.hyy, o.hxx, -o.hxx, o.hyy, -o.hyy};
+#pragma unroll
+    for (int e = 0; e < 8; e++) *pp[e] = av[e] + add[e];
   }
 }
 
@@ -270,7 +281,11 @@ __host__ __device__ inline int term_pattern_of(int kind, int idx0) {
     case ILQG_COST_QUADRATIC_DIFFERENCE:
     case ILQG_COST_RELATIVE_DISTANCE:
     case ILQG_COST_LOCALLY_CONVEX_PROXIMITY:
+    case ILQG_COST_WEIGHTED_CONVEX_PROXIMITY:
     case ILQG_CONSTRAINT_PROXIMITY: return PAT_PAIR4;
+    case ILQG_INTERNAL_WCP_SPEED: return PAT_PAIR2;
+    case ILQG_INTERNAL_WCP_CROSS_X:
+    case ILQG_INTERNAL_WCP_CROSS_Y: return PAT_CROSS4;
   }
   return PAT_NONE;
 }
@@ -455,7 +470,7 @@ __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* map
         c.kind = od(RO_KIND); c.role = od(RO_ROLE); c.player = od(RO_PLAYER); c.flags = od(RO_FLAGS);
         c.idx[0] = od(RO_IDX0); c.idx[1] = od(RO_IDX1); c.idx[2] = od(RO_IDX2); c.idx[3] = od(RO_IDX3);
         c.weight = __int_as_float(od(RO_WEIGHT)); c.value = __int_as_float(od(RO_VALUE));
-        c.polyline = 0; c.slot = od(RO_SLOT); c.arg_off = od(RO_ARG_OFF); c.arg_dim = od(RO_ARG_DIM);
+        c.polyline = od(RO_POLY_FIRST); c.slot = od(RO_SLOT); c.arg_off = od(RO_ARG_OFF); c.arg_dim = od(RO_ARG_DIM);
         c.k_start = od(RO_K_START);
         c.arg = 0; c.child_begin = 0; c.child_count = 0;
         if (mode == ROP_JACOBIAN) {

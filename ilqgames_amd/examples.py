@@ -652,6 +652,20 @@ def cost_zoo_scene(T=100, dt=0.1):
     return s
 
 
+def weighted_proximity_scene(T=100, dt=0.1):
+    """A test scene, NOT a reference example: the skeleton example's two Car5D with WeightedConvexProximityCost in
+    place of its ProximityCost.  That cost's Quadraticize is not the derivative of its Evaluate in the reference
+    (src/weighted_convex_proximity_cost.cpp:91-98: the speed gradient has the opposite sign), so an iLQ solve that
+    leans on it goes nowhere in particular; the scene exists for the stage kernels and the cost evaluation, which are
+    compared with the restatement wherever the cost is active."""
+    s = skeleton(T, dt)
+    s.terms = [t for t in s.terms if t["kind"] != abi.COST_PROXIMITY]
+    X, Y, V = [0, 5], [1, 6], [4, 9]
+    for i in range(2):
+        s.weighted_convex_proximity(i, 0.02, (X[i], Y[i]), (X[1 - i], Y[1 - i]), V[i], V[1 - i], 40.0)
+    return s
+
+
 def dynamics_zoo_scene(T=100, dt=0.1):
     """A test scene, NOT a reference example: the single-player models no reference example uses — one Car7D and two
     Unicycle5D (n = 17) — on the crossing lanes of the skeleton example, with costs on the states only these models
@@ -750,6 +764,7 @@ CONFIGS = {
     "two_player_collision_avoidance_reachability": two_player_collision_avoidance_reachability,
     "skeleton": skeleton,
     "cost_zoo_scene": cost_zoo_scene,
+    "weighted_proximity_scene": weighted_proximity_scene,
     "dynamics_zoo_scene": dynamics_zoo_scene,
     "delayed_dubins_scene": delayed_dubins_scene,
     "air_3d": air_3d,

@@ -273,6 +273,12 @@ bool LocallyConvexProximityCost::Describe(host::TermDescription* out) const {
   FillTerm(out, ILQG_COST_LOCALLY_CONVEX_PROXIMITY, weight_, threshold_, 0, {xidx1_, yidx1_, xidx2_, yidx2_});
   return true;
 }
+bool WeightedConvexProximityCost::Describe(host::TermDescription* out) const {
+  FillTerm(out, ILQG_COST_WEIGHTED_CONVEX_PROXIMITY, weight_, threshold_, 0, {xidx1_, yidx1_, xidx2_, yidx2_});
+  out->term.idx_extra[0] = vidx1_;
+  out->term.idx_extra[1] = vidx2_;
+  return true;
+}
 bool CurvatureCost::Describe(host::TermDescription* out) const {
   FillTerm(out, ILQG_COST_CURVATURE, weight_, 0.0f, 0, {omega_idx_, v_idx_});
   return true;
@@ -542,7 +548,7 @@ std::string DumpDescription(const ProblemDescription& description) {
     os << "term " << t.kind << " " << t.role << " " << t.player << " " << t.arg << " " << t.idx[0] << " " << t.idx[1]
        << " " << t.idx[2] << " " << t.idx[3] << " " << t.weight << " " << t.value << " " << t.flags << " "
        << t.polyline << " " << t.child_begin << " " << t.child_count << " " << t.constraint_slot << " " << t.first_step
-       << " " << t.value2 << "\n";
+       << " " << t.value2 << " " << t.idx_extra[0] << " " << t.idx_extra[1] << "\n";
   for (int q = 0; q < d.num_polylines; q++) {
     os << "polyline";
     for (int p = description.polyline_offsets[q]; p < description.polyline_offsets[q + 1]; p++)
@@ -641,7 +647,7 @@ static std::string Fingerprint(const ProblemDescription& d) {
   pod.dt = d.desc.dt;
   pod.dtype = d.desc.dtype;
   std::memcpy(&pod.params, &d.desc.params, sizeof(pod.params));  // 4-byte fields only: no padding
-  static_assert(sizeof(ilqg_solver_params) % 4 == 0 && sizeof(ilqg_cost_term) == 17 * 4, "packed 4-byte fields");
+  static_assert(sizeof(ilqg_solver_params) % 4 == 0 && sizeof(ilqg_cost_term) == 19 * 4, "packed 4-byte fields");
   std::string f(reinterpret_cast<const char*>(&pod), sizeof(pod));
   f.append(reinterpret_cast<const char*>(d.terms.data()), d.terms.size() * sizeof(ilqg_cost_term));
   f.append(reinterpret_cast<const char*>(d.polyline_offsets.data()), d.polyline_offsets.size() * sizeof(int32_t));

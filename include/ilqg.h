@@ -193,8 +193,11 @@ typedef enum {
    * are those of a first solve. */
   ILQG_COST_NOMINAL_PATH_LENGTH = 19, /* src/nominal_path_length_cost.cpp:50-78: idx[0] = dimension, value =
                                         nominal speed; 0.5 w (x[dim] - t * speed)^2 */
-  ILQG_COST_ROUTE_PROGRESS = 20      /* src/route_progress_cost.cpp:52-110: idx = (x, y), polyline, value = nominal
+  ILQG_COST_ROUTE_PROGRESS = 20,     /* src/route_progress_cost.cpp:52-110: idx = (x, y), polyline, value = nominal
                                         speed, value2 = initial route position; 0.5 w |p - PointAt(pos0 + t speed)|^2 */
+  ILQG_COST_WEIGHTED_CONVEX_PROXIMITY = 21 /* src/weighted_convex_proximity_cost.cpp:50-158: idx = (x1, y1, x2, y2),
+                                        idx_extra = (v1, v2), value = threshold; LOCALLY_CONVEX_PROXIMITY scaled by
+                                        v1^2 + v2^2, derivatives as written there.  Top-level state cost only. */
 } ilqg_cost_kind;
 
 /* Where a term sits inside PlayerCost::Quadraticize (src/player_cost.cpp:194-215):
@@ -219,6 +222,7 @@ typedef struct {
   int32_t idx[4];      /* QUADRATIC/SEMIQUADRATIC/SINGLE_DIM: idx[0]=dimension (-1 = all dims);
                           *_POLYLINE2: (xidx, yidx); PROXIMITY/SIGNED_DISTANCE/
                           CONSTRAINT_PROXIMITY: (x1, y1, x2, y2)                */
+  int32_t idx_extra[2]; /* WEIGHTED_CONVEX_PROXIMITY: (v1, v2); else 0          */
   float weight;        /* Cost::weight_                                        */
   float value;         /* nominal_ or threshold_                               */
   float value2;        /* ROUTE_PROGRESS: initial_route_pos_; else 0            */
@@ -546,7 +550,7 @@ const char* ilqg_last_error(void);
 ilqg_status ilqg_set_scratch(void* device_buffer, size_t bytes);
 
 /* Library / device introspection (used by the loader to fail loudly). */
-#define ILQG_ABI_VERSION 4 /* 4: ilqg_cost_term::value2, cost kinds 12-20, dynamics kinds 10-12;
+#define ILQG_ABI_VERSION 4 /* 4: ilqg_cost_term::idx_extra / value2, cost kinds 12-21, dynamics kinds 10-12;
                               3: ilqg_solve_options / ilqg_solve_batch_ex / ilqg_solve_state_batch, ilqg_dims::sweep_formulation;
                               the workspace holds every device buffer a solve uses */
 int32_t ilqg_abi_version(void);

@@ -350,6 +350,23 @@ class LocallyConvexProximityCost : public TimeInvariantCost {
   const Dimension xidx1_, yidx1_, xidx2_, yidx2_;
 };
 
+// include/ilqgames/cost/weighted_convex_proximity_cost.h:54-92 — LocallyConvexProximityCost scaled by v1^2 + v2^2.
+class WeightedConvexProximityCost : public TimeInvariantCost {
+ public:
+  WeightedConvexProximityCost(float weight, const std::pair<Dimension, Dimension>& position_idxs1,
+                              const std::pair<Dimension, Dimension>& position_idxs2, Dimension vidx1, Dimension vidx2,
+                              float threshold, const std::string& name = "")
+      : TimeInvariantCost(weight, name), threshold_(threshold), xidx1_(position_idxs1.first),
+        yidx1_(position_idxs1.second), vidx1_(vidx1), xidx2_(position_idxs2.first), yidx2_(position_idxs2.second),
+        vidx2_(vidx2) {}
+  bool Describe(host::TermDescription* out) const override;
+
+ private:
+  const float threshold_;
+  const Dimension xidx1_, yidx1_, vidx1_;
+  const Dimension xidx2_, yidx2_, vidx2_;
+};
+
 // include/ilqgames/cost/curvature_cost.h:53-74 — 0.5 w (omega / v)^2
 class CurvatureCost : public TimeInvariantCost {
  public:

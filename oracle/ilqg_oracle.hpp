@@ -810,6 +810,14 @@ S EvaluateTerm(const Problem<S>& p, int ti, const S* v, int dim, int step = 0) {
       const S delta_x = val - std::abs(dx), delta_y = val - std::abs(dy);
       return S(0.5) * w * std::min(delta_x * delta_x, delta_y * delta_y);
     }
+    case ILQG_COST_WEIGHTED_CONVEX_PROXIMITY: {  // src/weighted_convex_proximity_cost.cpp:50-61
+      const S dx = v[c.idx[0]] - v[c.idx[2]], dy = v[c.idx[1]] - v[c.idx[3]];
+      const S v1 = v[c.idx_extra[0]], v2 = v[c.idx_extra[1]];
+      const S vv = v1 * v1 + v2 * v2;
+      if (dx * dx >= val * val || dy * dy >= val * val) return S(0);
+      const S delta_x = val - std::abs(dx), delta_y = val - std::abs(dy);
+      return S(0.5) * w * vv * std::min(delta_x * delta_x, delta_y * delta_y);
+    }
     case ILQG_COST_CURVATURE: {  // src/curvature_cost.cpp:50-53, curvature_cost.h: omega / v
       const S curvature = v[c.idx[0]] / v[c.idx[1]];
       return S(0.5) * w * curvature * curvature;
@@ -1142,6 +1150,27 @@ void QuadraticizeTerm(const Problem<S>& p, int ti, double t, const S* v, int dim
         G[y1] += dy1; G[y2] -= dy1;
         H(y1, y1) += w; H(y2, y2) += w; H(y1, y2) -= w; H(y2, y1) -= w;
       }
+      return;
+    }
+    case ILQG_COST_WEIGHTED_CONVEX_PROXIMITY: {  // src/weighted_convex_proximity_cost.cpp:63-158, as written there
+      const int x1 = c.idx[0], y1 = c.idx[1], x2 = c.idx[2], y2 = c.idx[3], i1 = c.idx_extra[0], i2 = c.idx_extra[1];
+      const S dx = v[x1] - v[x2], dy = v[y1] - v[y2];
+      const S v1 = v[i1], v2 = v[i2];
+      const S vv = v1 * v1 + v2 * v2;
+      if (dx * dx >= val * val || dy * dy >= val * val) return;
+      const S delta_x = val - std::abs(dx), delta_y = val - std::abs(dy);
+      const bool is_x_active = delta_x * delta_x < delta_y * delta_y;
+      const int p1 = is_x_active ? x1 : y1, p2 = is_x_active ? x2 : y2;  // the two branches differ in the axis only
+      const S delta = is_x_active ? delta_x : delta_y, d = is_x_active ? dx : dy;
+      const S dp1 = -w * delta * vv;
+      const S dv1 = -w * v1 * delta * delta, dv2 = -w * v2 * delta * delta;
+      const S ddp1 = w, ddv1 = w * delta * delta, ddv2 = ddv1, dv1dv2 = S(0);
+      const S dp1dv1 = S(-2.0) * w * v1 * sgn(d), dp1dv2 = S(-2.0) * w * v2 * sgn(d);
+      H(p1, p1) += ddp1; H(p1, p2) -= ddp1; H(p2, p1) -= ddp1; H(p2, p2) += ddp1;
+      H(p1, i1) += dp1dv1; H(p1, i2) += dp1dv2; H(p2, i1) -= dp1dv1; H(p2, i2) -= dp1dv2;
+      H(i1, p1) += dp1dv1; H(i1, p2) -= dp1dv1; H(i1, i1) += ddv1; H(i1, i2) += dv1dv2;
+      H(i2, p1) += dp1dv2; H(i2, p2) -= dp1dv2; H(i2, i1) += dv1dv2; H(i2, i2) += ddv2;
+      G[p1] += dp1; G[p2] -= dp1; G[i1] += dv1; G[i2] += dv2;
       return;
     }
     case ILQG_COST_CURVATURE: {  // src/curvature_cost.cpp:55-86

@@ -38,16 +38,25 @@ def _solved(oracle, cfg, B, iters):
                                  "one_player_reachability", "air_3d", "modified_air_3d",
                                  # the kinds no reference example uses (time-dependent costs, Car7D / Unicycle5D /
                                  # DelayedDubinsCar on the plain RK4, the norm / orientation / curvature costs)
-                                 "cost_zoo_scene", "dynamics_zoo_scene", "delayed_dubins_scene"])
+                                 "cost_zoo_scene", "dynamics_zoo_scene", "delayed_dubins_scene", "weighted_proximity_scene"])
 @pytest.mark.parametrize("open_loop,euler", [(False, True), (True, True), (False, False)])
 def test_strategy_costs_match_oracle_fp64(hip, oracle, cfg, open_loop, euler):
     spec, op, x0, r = _solved(oracle, cfg, 3, 2)
     ref = op.strategy_costs(abi.F64, x0, r["xs"], r["us"], r["P"], r["alpha"], open_loop=open_loop, euler=euler)
     out = hip.Problem(spec, abi.F64).strategy_costs(x0, r["xs"], r["us"], r["P"], r["alpha"], open_loop=open_loop,
                                                     euler=euler)
-    # a replay of an unstable closed loop can overflow (Air3D's Euler replay does) or run away to 1e20+ (one instance of
-    # dynamics_zoo_scene after two iterations): a diverging trajectory amplifies rounding without bound, nothing to compare
-    fin = np.isfinite(ref).all(axis=1) & (np.abs(np.nan_to_num(ref)).max(axis=1) < 1e12)
+    # A replay of an unstable closed loop can overflow (Air3D's Euler replay does), run away to 1e20+ (one instance of
+    # dynamics_zoo_scene after two iterations) or merely amplify rounding by ten orders of magnitude (one of
+    # cost_zoo_scene): nothing to compare there.  Which instances those are is measured — the oracle replays from x0
+    # nudged by 1e-12 and must reproduce its own costs to 1e-9.
+    nudged = op.strategy_costs(abi.F64, x0 + 1e-12 * np.random.default_rng(9).standard_normal(x0.shape), r["xs"], r["us"],
+                               r["P"], r["alpha"], open_loop=open_loop, euler=euler)
+    with np.errstate(invalid="ignore", over="ignore"):
+        fin = np.isfinite(ref).all(axis=1) & np.isfinite(nudged).all(axis=1)
+        fin &= np.nan_to_num(np.abs(nudged - ref) / np.maximum(np.abs(ref), 1e-30), nan=1.0).max(axis=1) < 1e-9
+        # ... and a trajectory that has left the scene by ten orders of magnitude evaluates sines and cosines of
+        # arguments ~1e11, where two correct libms already differ
+        fin &= np.abs(np.nan_to_num(ref)).max(axis=1) < 1e12
     assert fin.any()
     assert rel_err(_np(out)[fin], ref[fin]) < 1e-10
 

@@ -155,11 +155,13 @@ def test_reference_example_source_compiles_unchanged_and_flattens_like_examples_
 
 
 @pytest.mark.parametrize("cls,builder,nc", [("CostZooScene", examples.cost_zoo_scene, 2),
+                                            ("WeightedProximityScene", examples.weighted_proximity_scene, 0),
                                             ("DynamicsZooScene", examples.dynamics_zoo_scene, 0),
                                             ("DelayedDubinsScene", examples.delayed_dubins_scene, 0)])
 def test_cpp_zoo_scenes_flatten_like_examples_py(tmp_path, cls, builder, nc):
     """The mirrored classes no reference example uses — the costs OrientationCost, QuadraticNormCost,
-    SemiquadraticNormCost, RelativeDistanceCost, LocallyConvexProximityCost, CurvatureCost, the constraint
+    SemiquadraticNormCost, RelativeDistanceCost, LocallyConvexProximityCost, WeightedConvexProximityCost, CurvatureCost,
+    NominalPathLengthCost, RouteProgressCost, the constraints FinalTimeConstraint and
     Polyline2SignedDistanceConstraint, the models SinglePlayerCar7D, SinglePlayerUnicycle5D,
     SinglePlayerDelayedDubinsCar: tests/host/zoo_scene.h builds the scenes of examples.py through them."""
     entry.build_host()

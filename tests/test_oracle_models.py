@@ -290,6 +290,54 @@ def test_quadraticization_matches_numerical_derivatives(oracle, name):
     assert checked >= (3 if "flipped" in name else 8), "too few regular points for %s" % name  # flipped: vertices only
 
 
+def test_weighted_convex_proximity_is_the_reference_as_written(oracle):
+    """WeightedConvexProximityCost: the reference's own test runs it with threshold 0, i.e. never active
+    (test_quadraticization.cpp:275-278), and its Quadraticize is not the derivative of its Evaluate (the speed gradient
+    has the opposite sign, the position Hessian lacks the v1^2 + v2^2 factor: weighted_convex_proximity_cost.cpp:91-98),
+    so the finite-difference test cannot apply.  What is pinned is the restatement against those lines, term by term,
+    in numpy: value, gradient and Hessian at points inside and outside the box, both axes active."""
+    w, thr = 2.0, 3.0
+    x1, y1, x2, y2, i1, i2 = 0, 1, 5, 6, 4, 9
+    spec = _cost_spec(lambda s: s.weighted_convex_proximity(0, w, (x1, y1), (x2, y2), i1, i2, thr))
+    op = oracle.OracleProblem(spec)
+    n, T = spec.n, spec.T
+    rng = np.random.default_rng(3)
+    seen = set()
+    for _ in range(40):
+        x = rng.uniform(-3, 3, n)
+        x[x2], x[y2] = x[x1] - rng.uniform(-3.5, 3.5), x[y1] - rng.uniform(-3.5, 3.5)
+        u = np.zeros(spec.m)
+        Q, l, _, _ = op.quadraticize(abi.F64, np.tile(x, (1, T, 1)), np.tile(u, (1, T, 1)), None, None,
+                                     np.zeros((1, 2), np.int32))
+        H, g = Q[0, 1, 0].reshape(n, n, order="F"), l[0, 1, 0]
+        dx, dy = x[x1] - x[x2], x[y1] - x[y2]
+        v1, v2 = x[i1], x[i2]
+        vv = v1 * v1 + v2 * v2
+        He, ge, value = np.zeros((n, n)), np.zeros(n), 0.0
+        if dx * dx < thr * thr and dy * dy < thr * thr:
+            ax, ay = thr - abs(dx), thr - abs(dy)
+            value = 0.5 * w * vv * min(ax * ax, ay * ay)
+            xa = ax * ax < ay * ay
+            p1, p2, delta, d = (x1, x2, ax, dx) if xa else (y1, y2, ay, dy)
+            dp1, dv1, dv2 = -w * delta * vv, -w * v1 * delta * delta, -w * v2 * delta * delta
+            a, b2 = -2.0 * w * v1 * np.sign(d), -2.0 * w * v2 * np.sign(d)
+            for (r, c2, val) in ((p1, p1, w), (p1, p2, -w), (p2, p1, -w), (p2, p2, w), (p1, i1, a), (p1, i2, b2), (p2, i1, -a),
+                                 (p2, i2, -b2), (i1, p1, a), (i1, p2, -a), (i1, i1, w * delta * delta), (i2, p1, b2),
+                                 (i2, p2, -b2), (i2, i2, w * delta * delta)):
+                He[r, c2] += val
+            ge[p1] += dp1
+            ge[p2] -= dp1
+            ge[i1] += dv1
+            ge[i2] += dv2
+            seen.add("x" if xa else "y")
+        else:
+            seen.add("outside")
+        assert np.allclose(H, He, rtol=1e-13, atol=1e-13) and np.allclose(g, ge, rtol=1e-13, atol=1e-13)
+        base = op.player_value(0, np.zeros(n), u)
+        assert abs(op.player_value(0, x, u) - base - value) < 1e-12 * max(1.0, value)
+    assert seen == {"x", "y", "outside"}
+
+
 def test_quadratic_and_semiquadratic_known_answers(oracle):
     """test_quadratic_cost.cpp:51-122 and test_semiquadratic_cost.cpp:53-118 with their own numbers: weight 5 on
     dimension 3, threshold 1, input (0.5, 0.75, 1.5, 2.0, 2.5 | zeros); all-dimensions form; gradient / Hessian
