@@ -243,6 +243,21 @@ def test_problem_create_rejects_dynamics_the_kernels_do_not_cover(hip):
         assert e.value.status == abi.ERR_UNSUPPORTED, kinds
         assert str(e.value)
     hip.Problem(spec_of((abi.DYN_POINT_MASS_2D, abi.DYN_POINT_MASS_2D)), abi.F64)  # the covered case builds
+    # the plain-RK4 models only build in the instantiations that carry that integrator: (10,2,2) exists, without it
+    with pytest.raises(hip.IlqgError) as e:
+        hip.Problem(spec_of((abi.DYN_UNICYCLE_5D, abi.DYN_UNICYCLE_5D)), abi.F64)
+    assert e.value.status == abi.ERR_UNSUPPORTED and "plain RK4" in str(e.value)
+    # a time-dependent cost anywhere but among a player's state costs; speed indices outside the state
+    s = spec_of((abi.DYN_CAR_5D, abi.DYN_CAR_5D))
+    s.terms.append(dict(s.terms[0], kind=abi.COST_NOMINAL_PATH_LENGTH, idx=(0, 0, 0, 0)))  # a copy of a control cost
+    with pytest.raises(hip.IlqgError) as e:
+        hip.Problem(s, abi.F64)
+    assert e.value.status == abi.ERR_INVALID
+    s = spec_of((abi.DYN_CAR_5D, abi.DYN_CAR_5D))
+    s.weighted_convex_proximity(0, 1.0, (0, 1), (5, 6), 4, 10, 3.0)  # n = 10: index 10 is past the state
+    with pytest.raises(hip.IlqgError) as e:
+        hip.Problem(s, abi.F64)
+    assert e.value.status == abi.ERR_INVALID
 
 
 def _clean(ref, max_bt=12):
