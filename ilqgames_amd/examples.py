@@ -758,6 +758,9 @@ CONFIGS = {
     "three_player_intersection": three_player_intersection,
     "roundabout_merging": roundabout_merging,
     "roundabout_merging_T150": lambda: roundabout_merging(T=150),  # BASELINE.json config 4 (n=24, T=150, open loop)
+    # the same game on the feedback solver, as the reference's own main runs it (exec/roundabout_merging_example/main.cpp
+    # leaves SolverParams::open_loop at its default): the 2 x 2-tile feedback sweep
+    "roundabout_merging_feedback": lambda: roundabout_merging(open_loop=False),
     "three_player_collision_avoidance_reachability": three_player_collision_avoidance_reachability,
     "two_player_unicycle_4d_scene": two_player_unicycle_4d_scene,
     "two_player_reachability": two_player_reachability,

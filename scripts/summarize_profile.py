@@ -52,7 +52,7 @@ for name, db in (("FETCH_SIZE", "pmc_fetch/bench_results.db"), ("WRITE_SIZE", "p
     for nm in sorted(set(r[0] for r in rows)):
         sel = [r for r in rows if r[0] == nm]
         top = max(r[2] for r in sel)
-        sel = [r for r in sel if r[2] > 0.2 * top]  # drops the one-workgroup dispatches of the latency figure
+        sel = [r for r in sel if r[2] > 0.2 * top] or sel  # drops the one-workgroup dispatches of the latency figure
         out.append("| %s | %s | %d | %.1f | %d |" % (nm[:80], sel[0][1], len(sel), statistics.median(r[2] for r in sel),
                                                     statistics.median(r[3] for r in sel)))
 # wave-level SQ counters (own pass): per kernel, medians over the batch launches
