@@ -276,7 +276,10 @@ inline WsTail ws_tail(const DevProblem& d, int batch, size_t elem, int ol_row) {
   WsTail t;
   t.ids_off = up(size_t(L.total) * elem * size_t(batch));
   t.pool_off = up(t.ids_off + size_t(2) * batch * sizeof(int));
+  // eight candidates per instance up to kProbeEntries, and never fewer than two full rounds' worth for a single
+  // instance (a lone instance in a failing line search walks through all its step sizes: 32 a round, not 8)
   t.pool_entries = batch * 8 < kProbeEntries ? batch * 8 : kProbeEntries;
+  if (t.pool_entries < 2 * kProbeCandidates) t.pool_entries = 2 * kProbeCandidates;
   t.total = up(t.pool_off + size_t(t.pool_entries) * ProbeEntry(d.n, d.m, d.N, d.T).total * elem);
   return t;
 }
@@ -796,10 +799,11 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
       sa.ids_next = pass_ids + size_t(list) * batch;
       // Step sizes probed per listed instance: as many as the pool holds for a list this long, doubling from two
       // over the first rounds of a tail (most line searches that back-track at all end within a step or two; the
-      // ones that do not are the ones worth eight candidates a round).
+      // ones that do not are mostly on their way through all max_backtracking_steps of a failing search, and a round
+      // for the few instances left costs the latency of its launches whatever it probes: 2, 4, 8, 16, 32).
       int probe_k = sa.ids ? tail.pool_entries / round_instances : 0;
       if (probe_k > kProbeCandidates) probe_k = kProbeCandidates;
-      if (tail_rounds < 3 && probe_k > (2 << tail_rounds)) probe_k = 2 << tail_rounds;
+      if (tail_rounds < 5 && probe_k > (2 << tail_rounds)) probe_k = 2 << tail_rounds;
       if (sa.ids) tail_rounds++;
       if (probe && probe_k >= 2) {
         // the listed instances' next step sizes side by side; their states move to the first acceptable one

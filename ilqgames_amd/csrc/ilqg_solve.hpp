@@ -403,7 +403,7 @@ __device__ __forceinline__ void rows_part_instance(const DevProblem& p, const sh
 // rejections counted as if they had been tried one by one.  The regular pass that follows evaluates that
 // candidate again with all outputs and accepts it: same arithmetic, same decisions, fewer rounds.
 // ---------------------------------------------------------------------------
-constexpr int kProbeCandidates = 8;             // most step sizes probed per instance and round
+constexpr int kProbeCandidates = 32;            // most step sizes probed per instance and round
 constexpr int kProbeEntries = 8 * 512;          // pool size: candidates of all listed instances of one round
 
 struct ProbeEntry {
