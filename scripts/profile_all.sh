@@ -15,8 +15,8 @@ run headline_f64_b1024 "--steps 10 --warmup 2 --repeats 1 --no-cpu-baseline --no
 run headline_f32_b1024 "--steps 10 --warmup 2 --repeats 1 --dtype f32 --no-cpu-baseline --no-latency"
 run headline_f64_b8192 "--steps 10 --warmup 2 --repeats 1 --batch 8192 --no-cpu-baseline --no-latency"
 run config3_f32_b8192 "--baseline-config 3 --warmup 2 --repeats 1 --no-cpu-baseline --no-latency"
-run config4_roundabout_T150_f64_b4096 "--baseline-config 4 --warmup 1 --repeats 1 --no-cpu-baseline --no-latency"
-run config5_reachability_f64_b2048 "--baseline-config 5 --warmup 1 --repeats 1 --no-cpu-baseline --no-latency"
+run config4_roundabout_T150_f64_b4096 "--baseline-config 4 --warmup 3 --repeats 1 --no-cpu-baseline --no-latency"
+run config5_reachability_f64_b2048 "--baseline-config 5 --warmup 3 --repeats 1 --no-cpu-baseline --no-latency"
 # beside the BASELINE configurations: the n = 16 constrained form of config 2 (the example BASELINE.json names) and the
 # n = 24 game on the feedback sweep
 run config2_n16_constrained_f64_b1024 "--config three_player_intersection --steps 6 --warmup 3 --repeats 1 --no-cpu-baseline --no-latency"

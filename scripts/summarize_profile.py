@@ -91,7 +91,7 @@ try:
                 continue
             sel = [r for r in rows if r[0] == nm]
             top = max(r[2] for r in sel)
-            sel = [r for r in sel if r[2] > 0.2 * top]
+            sel = [r for r in sel if r[2] > 0.2 * top] or sel
             mm = re.search(r"(ilq_\w+?_kernel)", nm)
             short = mm.group(1) if mm else nm[:40]
             tr.setdefault(short, {})[cname] = statistics.median(r[2] for r in sel) * 1024.0
