@@ -97,6 +97,15 @@ def selftest_mfma(dtype, X, Y, Cm):
     return out.cpu().numpy().T
 
 
+def set_scratch(buffer=None):
+    """ilqg_set_scratch: hand the stand-alone entry points a caller-owned device buffer (a torch tensor; None returns
+    to the library's own grow-only allocation).  The caller keeps the tensor alive while it is installed."""
+    if buffer is None:
+        _check(lib().ilqg_set_scratch(None, C.c_size_t(0)))
+    else:
+        _check(lib().ilqg_set_scratch(C.c_void_p(buffer.data_ptr()), C.c_size_t(buffer.numel() * buffer.element_size())))
+
+
 def lq_feedback(dims, A, Bm, Q, l, R, r, pairs, x0=None, want_dx=True, open_loop=False, want_costates=False):
     """ilqg_lq_feedback_batch / ilqg_lq_openloop_batch on device tensors (numpy inputs are uploaded).
     Returns (P, alpha, dx) or, with want_costates, (P, alpha, dx, costates [B][T][N][n])."""

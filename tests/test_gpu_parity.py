@@ -69,6 +69,39 @@ def test_lq_feedback_matches_oracle_random(hip, oracle, dims, dtype):
     assert rel_err(_np(dx), dxr) < tol
 
 
+def test_stand_alone_entry_points_run_in_caller_owned_scratch(hip, oracle):
+    """ilqg_set_scratch: with a caller's buffer installed the stand-alone sweep (delta_x and costates asked for, which
+    is what needs scratch) computes what it computes in the library's own allocation; a buffer that is too small is
+    refused with the size that is needed, never grown behind the caller's back; NULL returns to the default."""
+    import torch
+    n, N, mu = 14, 3, 2
+    rng = np.random.default_rng(5)
+    T, B = 25, 5
+    g = random_lq_game(rng, n, [mu] * N, T, B)
+    d = dims_of(g, abi.F64, adaptive=True)
+    x0 = rng.standard_normal((B, n))
+    args = (d, g["A"], g["Bm"], g["Q"], g["l"], g["R"], g["r"], g["pairs"])
+    ref = [_np(v).copy() for v in hip.lq_feedback(*args, x0=x0, want_costates=True)]
+    big = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+    small = torch.empty(256, dtype=torch.uint8, device="cuda")
+    try:
+        hip.set_scratch(big)
+        big.fill_(0xAB)
+        out = [_np(v).copy() for v in hip.lq_feedback(*args, x0=x0, want_costates=True)]
+        for a, b in zip(out, ref):
+            assert np.array_equal(a, b)
+        assert (big != 0xAB).any()  # the sweep really worked in the caller's buffer
+        hip.set_scratch(small)
+        with pytest.raises(hip.IlqgError) as e:
+            hip.lq_feedback(*args, x0=x0, want_costates=True)
+        assert e.value.status == abi.ERR_INVALID and any(ch.isdigit() for ch in str(e.value))
+    finally:
+        hip.set_scratch(None)
+    out = [_np(v).copy() for v in hip.lq_feedback(*args, x0=x0, want_costates=True)]
+    for a, b in zip(out, ref):
+        assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("dims", [(14, 3, 2), (16, 3, 2), (24, 4, 2), (18, 3, 2), (10, 2, 2), (6, 3, 2), (2, 2, 1),
                                   (17, 3, 2), (8, 2, 1)])
 @pytest.mark.parametrize("dtype", [abi.F64, abi.F32])
