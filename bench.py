@@ -48,6 +48,21 @@ def algorithmic_bytes_per_iteration(n, m, N, T, pairs_m, elem, backtracks=0.0):
     return base + backtracks * extra
 
 
+def csrc_sha16():
+    """Identity of the kernels a figure was collected on: sha256 over the sources of libilqg_hip.so (csrc/*.hip, *.hpp in
+    name order and the C ABI header), first 16 hex digits.  profiles/traffic.json entries carry the value of the build
+    their PMC passes ran on (scripts/summarize_profile.py prints it); a `traffic` figure is only quoted on a match."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "ilqgames_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    h.update(open(os.path.join(ROOT, "include", "ilqg.h"), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def sweep_flops_executed_per_step(n, m, N, open_loop):
     """What the device sweep EXECUTES per time step (tile products on 16 x 16 x 4 matrix instructions, 2048 flop each,
     padding included), as opposed to the reference's dense count below.  Open loop (csrc/ilqg_lq_openloop.hpp, n <= 31):
@@ -195,6 +210,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true",
                     help="skip the single-instance ms/solve figure (profiling runs: keeps the kernel statistics to the batch)")
+    ap.add_argument("--no-second-workload", action="store_true",
+                    help="skip the back-tracking workload reported beside the headline (three_player_intersection, n = 16)")
     ap.add_argument("--cpu-sample", type=int, default=64,
                     help="instances in one run of the CPU baseline sample (64 x 20 iterations ~ 1.3 s on one host thread)")
     args = ap.parse_args()
@@ -321,13 +338,20 @@ def main():
         achieved_b0 = bytes_iter_b0 * local_iters / kernel_s / 1e9
         # HBM traffic per round: bench.py cannot run rocprofv3 on itself, so this figure is READ from the committed
         # medians of the PMC passes scripts/profile.sh collects on this workload (profiles/traffic.json), and labelled so
+        # — and only when they were collected on THESE kernels: an entry is stamped with the hash of the kernel sources
+        # of the build it was measured on (csrc_sha16), a figure from any other build is not quoted (null)
         traffic, traffic_source = None, None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
             ent = tj.get("%s:%s:%d" % (args.config, args.dtype, B))
-            if ent:
+            sha = csrc_sha16()
+            if ent and ent.get("csrc_sha16") == sha:
                 traffic = ent["bytes_per_round"]
-                traffic_source = "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE medians, %s)" % ent.get("collected", "this round")
+                traffic_source = "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE medians, %s, kernels %s)" % (
+                    ent.get("collected", "this round"), sha)
+            elif ent:
+                traffic_source = "not quoted: profiles/traffic.json holds a figure collected on kernels %s, this build is %s" % (
+                    ent.get("csrc_sha16", "(unstamped)"), sha)
         except (OSError, ValueError, KeyError):
             pass
         open_loop = bool(spec.params.open_loop)
@@ -350,14 +374,17 @@ def main():
             "gather_ms": gather_s * 1e3,
             "success_fraction": float(status.mean()),
             "mean_backtracks": mean_bt,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+            # achieved / frac count NO rejected line-search trial (SURVEY.md 8(d)'s b = 0 bytes per accepted iteration):
+            # a rejected trial is work the path did, not bytes the workload asked for.  The figure that adds
+            # s*T*[W_quad + W_strat + 2 W_op] per rejected trial is kept under `with_rejected_trials`.
+            "roofline": {"bound": "hbm", "achieved": achieved_b0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved_b0 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "with_rejected_trials": {"achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
+                                                  "mean_backtracks": mean_bt},
                          "kernel": "ilq_lq_kernel + ilq_trial_kernel (one round = one outer iteration of the batch)",
                          "launch_ms": kernel_s * 1e3 / max(1, args.steps),
-                         "algorithmic_bytes_per_launch": launch_bytes / max(1, args.steps),
-                         "bytes_per_iteration_per_instance": bytes_iter,
-                         # the same fraction counting NO rejected line-search trial (SURVEY.md 8(d)'s b = 0 figure): `frac`
-                         # above adds s*T*[W_quad + W_strat + 2 W_op] per rejected trial, mean_backtracks of them per iteration
+                         "algorithmic_bytes_per_launch": bytes_iter_b0 * local_iters / max(1, args.steps),
+                         "bytes_per_iteration_per_instance": bytes_iter_b0,
                          "frac_b0": achieved_b0 / HBM_PEAK_GBS, "bytes_per_iteration_per_instance_b0": bytes_iter_b0,
                          "flop": {"sweep_tflops": flops_round * args.steps / kernel_s / 1e12,
                                   "sweep_tflops_executed": flops_exec_round * args.steps / kernel_s / 1e12,
@@ -371,6 +398,8 @@ def main():
         if args.backend == "hip" and world == 1 and not args.no_latency:
             out["latency"] = latency_figures(backend, examples, abi, args, x0_d)
             out["own_params"] = own_params_figure(backend, examples, abi, args, x0_d)
+            if args.config == HEADLINE_CONFIG and not args.no_second_workload:
+                out["second_workload"] = backtracking_workload(examples, abi, args, local_rank)
         if args.backend == "hip" and not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, spec, x0, dtype, abi, out.get("latency"))
         print(json.dumps(out))
@@ -402,6 +431,55 @@ def latency_figures(backend, examples, abi, args, x0_d):
     return {"ms_per_solve": sorted(lat)[1] * 1e3, "iterations": it, "ms_per_iteration": sorted(lat)[1] * 1e3 / max(1, it),
             "converged": int(lb["converged"][0].item()), "success": int(lb["status"][0].item()), "instances": 1,
             "mode": "free-running to convergence_tolerance = 1.0, alpha0 = 0.5, fraction 0.001, zero warm start"}
+
+
+def backtracking_workload(examples, abi, args, local_rank, steps=6, warmup=3):
+    """A second reported workload beside the headline, so that the path every line search that back-tracks goes through
+    has a driver-visible number: ThreePlayerIntersectionExample (the n = 16 example BASELINE.json's config 2 names, its
+    constraints as augmented-Lagrangian terms at their initial multipliers), its own solver parameters
+    (exec/three_player_intersection/main.cpp:109-120), the headline's batch and precision, `steps` outer iterations —
+    the launch mode chosen from the warm-up exactly as for the headline.  Median of three timed solves."""
+    import torch
+    cfg = "three_player_intersection"
+    spec, params_desc = _bench_spec(examples, cfg, "own")
+    dtype = abi.F64 if args.dtype == "f64" else abi.F32
+    elem = 8 if dtype == abi.F64 else 4
+    be = HipBackend(spec, dtype, local_rank)
+    B = args.batch
+    x0 = torch.as_tensor(examples.jittered_x0(spec, B, seed=0), dtype=be.tdtype, device="cuda")
+    bufs = be.alloc(B)
+
+    def reset():
+        for k in ("xs", "us", "P", "alpha"):
+            bufs[k].zero_()
+    reset()
+    be.solve(x0, bufs, warmup)
+    be.sync()
+    warm_bt = be.mean_backtracks(bufs, int(bufs["iters"].sum().item()))
+    if warm_bt > 0.25:
+        be.counted = True
+    runs = []
+    for _ in range(3):
+        reset()
+        be.sync()
+        ev = be.events()
+        ev[0].record()
+        be.solve(x0, bufs, steps)
+        ev[1].record()
+        be.sync()
+        runs.append(ev[0].elapsed_time(ev[1]) * 1e-3)
+    kernel_s = sorted(runs)[1]
+    iters = int(bufs["iters"].sum().item())
+    n, m, N, T = spec.n, spec.m, len(spec.subsystems), spec.T
+    pairs_m = [spec.udims[j] for _, j in be.prob.pairs]
+    b0 = algorithmic_bytes_per_iteration(n, m, N, T, pairs_m, elem, backtracks=0.0)
+    return {"workload": "%s n=%d N=%d T=%d batch=%d %s, fixed %d outer iterations, %s" % (cfg, n, N, T, B, args.dtype, steps, params_desc),
+            "value": iters / kernel_s, "unit": "instance-iterations/s", "ms_per_step": kernel_s / steps * 1e3,
+            "mean_backtracks": be.mean_backtracks(bufs, iters), "success_fraction": float(bufs["status"].float().mean().item()),
+            "launch_mode": "host-counted rounds, speculative line search" if be.counted else "asynchronous launch sequence",
+            "roofline": {"bound": "hbm", "achieved": b0 * iters / kernel_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": b0 * iters / kernel_s / 1e9 / HBM_PEAK_GBS, "bytes_per_iteration_per_instance": b0,
+                         "note": "b = 0 bytes per accepted iteration (SURVEY.md 8d); rejected trials are not counted as useful bytes"}}
 
 
 def own_params_figure(backend, examples, abi, args, x0_d):

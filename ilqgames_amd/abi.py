@@ -13,7 +13,7 @@ F32, F64 = 0, 1
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_NO_DEVICE = 0, 1, 2, 3, 4
 
 # ilqg_dyn_kind
-ABI_VERSION = 4  # ILQG_ABI_VERSION of include/ilqg.h these mirrors were written against
+ABI_VERSION = 5  # ILQG_ABI_VERSION of include/ilqg.h these mirrors were written against
 DYN_UNICYCLE_4D, DYN_CAR_5D, DYN_CAR_6D = 1, 2, 3
 DYN_UNICYCLE_4D_DISTURBED, DYN_PLANAR_DISTURBANCE = 4, 5  # the two rows of TwoPlayerUnicycle4D
 DYN_DUBINS_CAR = 6  # (px, py, theta), u = (omega), param0 = speed
@@ -55,6 +55,13 @@ class Dims(C.Structure):
 
 
 CHOICE_AUTO, CHOICE_OFF, CHOICE_ON = 0, 1, 2
+SWEEP_GENERIC = 3  # ilqg_dims::sweep_formulation: the run-time-dimensioned sweeps
+
+
+class IterateLog(C.Structure):
+    """ilqg_iterate_log (include/ilqg.h): device arrays [B][capacity][...] + count [B]."""
+    _fields_ = [("xs", C.c_void_p), ("us", C.c_void_p), ("costs", C.c_void_p), ("P", C.c_void_p),
+                ("alpha", C.c_void_p), ("count", C.c_void_p), ("capacity", C.c_int32)]
 
 
 class SolveOptions(C.Structure):
@@ -62,7 +69,9 @@ class SolveOptions(C.Structure):
     _fields_ = [("fixed_iters", C.c_int32), ("augmented_lagrangian", C.c_int32), ("resume", C.c_int32),
                 ("reserved0", C.c_int32), ("active", C.c_void_p), ("forced_steps", C.c_void_p),
                 ("split_trial", C.c_int32), ("handoff", C.c_int32), ("probe", C.c_int32), ("counted", C.c_int32),
-                ("compact_rows", C.c_int32), ("round_bursts", C.c_int32), ("reserved", C.c_int32 * 4)]
+                ("compact_rows", C.c_int32), ("round_bursts", C.c_int32), ("generic_kernels", C.c_int32),
+                ("reserved", C.c_int32 * 3),
+                ("iterate_log", C.POINTER(IterateLog)), ("max_runtime", C.c_double)]
 
 
 class Subsystem(C.Structure):

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cmath>
+#include <chrono>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -13,6 +14,7 @@
 #include "ilqg_lq.hpp"
 #include "ilqg_lq_openloop.hpp"
 #include "ilqg_lq_feedback2.hpp"
+#include "ilqg_lq_generic.hpp"
 #include "ilqg_costates.hpp"
 #include "ilqg_models.hpp"
 #include "ilqg_nash.hpp"
@@ -171,6 +173,35 @@ lq_openloop_kernel(LQBatchArgs<T> g, PairTable pt) {
   lq_openloop_instance<T, NX, NP, MU>(a, pt, sm);
 }
 
+// The sweeps with run-time dimensions (ilqg_lq_generic.hpp): whatever has no specialised instantiation above.
+template <typename T>
+__global__ void __launch_bounds__(256) lq_generic_kernel(LQBatchArgs<T> g, GenDims d, PairTable pt, int open_loop,
+                                                         int scratch_row) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  T* sm = reinterpret_cast<T*>(smem_raw);
+  const size_t b = blockIdx.x, Tn = d.T, n = d.n, m = d.m, N = d.N;
+  GenLQArgs<T> a;
+  a.A = g.A + b * Tn * n * n;
+  a.Bm = g.Bm + b * Tn * n * m;
+  a.Q = g.Q + b * Tn * N * n * n;
+  a.l = g.l + b * Tn * N * n;
+  a.R = g.R + b * Tn * pt.Rsz;
+  a.r = g.r + b * Tn * pt.rsz;
+  a.x0 = g.x0 ? g.x0 + b * n : nullptr;
+  a.P = g.P + b * Tn * m * n;
+  a.alpha = g.alpha + b * Tn * m;
+  a.dx = g.dx ? g.dx + b * Tn * n : nullptr;
+  a.costates = (open_loop && g.costates) ? g.costates + b * Tn * N * n : nullptr;
+  a.scratch = g.scratch ? g.scratch + b * Tn * size_t(scratch_row) : nullptr;
+  a.ed_out = nullptr;
+  a.adaptive = g.adaptive;
+  const ParDevice par;
+  if (open_loop)
+    lq_openloop_generic<T>(d, a, pt, sm, par);
+  else
+    lq_feedback_generic<T>(d, a, pt, sm, par);
+}
+
 template <typename T>
 struct RolloutBatchArgs {
   const T *x0, *xs_ref, *us_ref, *P, *alpha, *alpha_scale;
@@ -188,23 +219,7 @@ __global__ void rollout_kernel(DevProblem p, RolloutBatchArgs<T> g) {
   RolloutArgs<T> a{g.x0 + b * n,          g.xs_ref + b * Tn * n, g.us_ref + b * Tn * m, g.P + b * Tn * m * n,
                    g.alpha + b * Tn * m,  g.alpha_scale ? g.alpha_scale[b] : T(1),
                    g.xs + b * Tn * n,     g.us + b * Tn * m};
-  bool dubins = false, plain = false;
-  for (int i = 0; i < p.N; i++) {
-    dubins = dubins || p.sub_kind[i] == ILQG_DYN_DUBINS_CAR;
-    plain = plain || is_plain_rk4_kind(p.sub_kind[i]);
-  }
-  if (plain)
-    rollout_instance<T, 0, 0, false, false, false, false, true>(p, a, sm, threadIdx.x);
-  else if (p.sub_kind[0] == ILQG_DYN_AIR_3D_EVADER)
-    rollout_instance<T, 0, 0, false, false, true>(p, a, sm, threadIdx.x);
-  else if (p.sub_kind[0] == ILQG_DYN_UNICYCLE_4D_DISTURBED)
-    rollout_instance<T, 0, 0, true>(p, a, sm, threadIdx.x);
-  else if (dubins)
-    rollout_instance<T, 0, 0, false, true>(p, a, sm, threadIdx.x);
-  else if (p.sub_kind[0] == ILQG_DYN_POINT_MASS_2D)
-    rollout_instance<T, 0, 0, false, false, false, true>(p, a, sm, threadIdx.x);
-  else
-    rollout_instance<T>(p, a, sm, threadIdx.x);
+  rollout_instance_rt<T>(p, a, sm, threadIdx.x);
 }
 
 template <typename T>
@@ -404,6 +419,16 @@ __global__ void __launch_bounds__(64) ilq_probe_pick_kernel(DevProblem p, SolveA
   probe_pick_instance<T>(p, sa, sa.ids[blockIdx.x], blockIdx.x);
 }
 
+// Iterate log and anytime exit (ilqg_solve.hpp): only launched by solves that ask for them.
+template <typename T>
+__global__ void __launch_bounds__(256) ilq_log_kernel(DevProblem p, SolveArgs<T> sa, IterLog<T> lg) {
+  log_part_instance<T>(p, sa, lg, int(blockIdx.x));
+}
+template <typename T>
+__global__ void __launch_bounds__(64) ilq_deadline_kernel(DevProblem p, SolveArgs<T> sa) {
+  deadline_part_instance<T>(p, sa, int(blockIdx.x));
+}
+
 // Exit kernel: return path of ILQSolver::Solve / AugmentedLagrangianSolver bookkeeping for the instances
 // whose inner solve has ended (converged, out of iterations, or line search exhausted).
 template <typename T, int NX, int NP, int MU>
@@ -437,6 +462,19 @@ ilq_lq_kernel(DevProblem p, SolveArgs<T> sa) {
     if (stage != ST_LQ) return;
   }
   lq_part_instance<T, NX, NP, MU, (KIND == LQ_PLAYER_WAVES_PACKED ? LQ_PLAYER_WAVES : KIND)>(p, sa, b, reinterpret_cast<T*>(smem_raw));
+}
+
+// The sweep of the run-time-dimensioned solve path (lq_part_generic, ilqg_solve.hpp).
+template <typename T>
+__global__ void __launch_bounds__(256) gen_lq_kernel(DevProblem p, SolveArgs<T> sa) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int b = blockIdx.x;
+  {
+    const WsLayout L(p.n, p.m, p.N, p.T, p.pairs.Rsz, p.pairs.rsz, sa.ol_row, p.num_constraints, sa.al_mode);
+    const int stage = reinterpret_cast<const SolveState<T>*>(sa.ws + size_t(b) * sa.ws_stride + L.state)->stage;
+    if (stage != ST_LQ) return;
+  }
+  lq_part_generic<T>(p, sa, b, reinterpret_cast<T*>(smem_raw));
 }
 
 template <typename T>
@@ -626,6 +664,25 @@ struct ilqg_problem {
   int* d_unfinished = nullptr;  // instances still running after an LQ-kernel launch
   int* h_unfinished = nullptr;  // pinned host mirror
   int mu_uniform = 0;
+  bool has_route_progress = false;  // a RouteProgressCost term: its tables are a first solve's (initial time 0)
+  bool generic = false;  // no specialised instantiation holds this problem: every entry point runs the run-time-dimensioned kernels
+  // LoopTimer of the solver object (include/ilqgames/utils/loop_timer.h:60-98, src/loop_timer.cpp:55-92): the last ten
+  // iteration times, kept across solves as the reference's member is; only solves with a max_runtime feed and read it
+  double loop_times[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  int loop_count = 0, loop_next = 0;
+  void loop_add(double seconds) {
+    loop_times[loop_next] = seconds;
+    loop_next = (loop_next + 1) % 10;
+    if (loop_count < 10) loop_count++;
+  }
+  double loop_upper_bound() const {  // mean + 3 sigma (unbiased), 0.02 s until two samples exist
+    if (loop_count < 2) return 0.02;
+    double mean = 0.0, var = 0.0;
+    for (int i = 0; i < loop_count; i++) mean += loop_times[i];
+    mean /= loop_count;
+    for (int i = 0; i < loop_count; i++) var += (loop_times[i] - mean) * (loop_times[i] - mean);
+    return mean + 3.0 * std::sqrt(var / (loop_count - 1));
+  }
 };
 
 #define DT_DISPATCH(p, CALL) ((p)->desc.dtype == ILQG_F32 ? CALL(float) : CALL(double))
@@ -694,7 +751,10 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   const bool pw = C::USE_MFMA && !p->desc.params.open_loop;  // one wave per player (MFMA feedback sweep)
   // Compact rows (ilqg_common.hpp) between the row stage and the sweep: the one-tile player-parallel sweep and the
   // open-loop sweep read them; the other sweeps take the dense arrays.
-  const bool compact_on = d.rp_compact_w > 0 && choice(opt.compact_rows, true);
+  // ... and only when the [T][rp_compact_w] rows fit the space they are kept in: the dense Q, l, R, r arrays up to the
+  // sweep's scratch rows (a small or densely coupled problem's row carries the A and B words too)
+  const bool compact_on = d.rp_compact_w > 0 && size_t(d.T) * size_t(d.rp_compact_w) <= L.lqscr - L.Q &&
+                          choice(opt.compact_rows, true);
   const bool ol_compact = p->desc.params.open_loop && compact_on;
   // fp32, one-tile sweep of three player waves, many instances per CU: the 128-register build (see ilq_lq_kernel)
   constexpr bool has_packed = sizeof(T) == 4 && C::USE_MFMA && C::MFMA_ONE_TILE && NP == 3;
@@ -777,8 +837,32 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   // counters back once per burst instead of once per round (a read-back is a stream synchronisation: ~20-30 us against
   // a ~0.45 ms round of a single instance).  The burst doubles up to eight rounds while no instance is back-tracking
   // and falls back to one as soon as one is (those go through the probing passes, which need the lists every round).
-  const bool bursts = counted && !split && !kProfile && choice(opt.round_bursts, true);
+  // the anytime exit (ilqg_solve_options::max_runtime): the host's clock is read where the batch is about to start an
+  // iteration, so rounds are not batched into bursts; the augmented-Lagrangian solver gives each inner solve of a
+  // constrained problem max_runtime / max_solver_iters (src/augmented_lagrangian_solver.cpp:85-88)
+  const bool timed = opt.max_runtime > 0.0 && counted;
+  const double budget = !timed ? 0.0 : ((al_mode && d.num_constraints > 0) ? opt.max_runtime / double(sa.prm.max_solver_iters) : opt.max_runtime);
+  auto wall = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double inner_elapsed = 0.0, tic = 0.0;
+  bool iteration_open = false;
+  const bool bursts = counted && !split && !kProfile && !timed && choice(opt.round_bursts, true);
   int burst = 1;
+  // the iterate log (ilqg_solve_options::iterate_log): copied in front of every exit / sweep launch
+  IterLog<T> lg{};
+  const bool logging = opt.iterate_log != nullptr;
+  if (logging) {
+    const ilqg_iterate_log& il = *opt.iterate_log;
+    if (!il.xs || !il.us || !il.costs || !il.count || il.capacity < 1)
+      return fail(ILQG_ERR_INVALID, "iterate log: xs, us, costs, count and a capacity of at least one are required");
+    lg = IterLog<T>{(T*)il.xs, (T*)il.us, (T*)il.costs, (T*)il.P, (T*)il.alpha, il.count, il.capacity};
+    HIP_TRY(hipMemsetAsync(il.count, 0, sizeof(int) * size_t(batch), stream));
+  }
+  auto log_iterates = [&]() -> ilqg_status {
+    if (!logging) return ILQG_OK;
+    hipLaunchKernelGGL(ilq_log_kernel<T>, dim3(batch), dim3(256), 0, stream, d, sa, lg);
+    HIP_TRY(hipGetLastError());
+    return ILQG_OK;
+  };
   for (long long round = 0;; round++) {
     if (bursts && !sa.ids) {
       for (int q = 1; q < burst; q++) {  // rounds without a read-back
@@ -787,6 +871,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
         hipLaunchKernelGGL(k_trial, dim3(batch), dim3(64 * W), lds_trial, stream, d, sa);
         HIP_TRY(hipGetLastError());
         sa.first = 0;
+        if (log_iterates() != ILQG_OK) return ILQG_ERR_HIP;
         hipLaunchKernelGGL(k_exit, dim3(batch), dim3(64), lds_exit, stream, d, sa);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(k_lq, dim3(batch), dim3(nt_lq), lds_lq, stream, d, sa);
@@ -865,6 +950,22 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
       want_lq = 0;
       want_exit = 1;
     }
+    if (timed && want_lq) {
+      // the loop condition of src/ilq_solver.cpp:123-124 for the iteration the batch is about to start
+      const double now = wall();
+      if (iteration_open) {
+        p->loop_add(now - tic);
+        inner_elapsed += now - tic;
+        iteration_open = false;
+      }
+      if (!(inner_elapsed < budget - p->loop_upper_bound())) {
+        hipLaunchKernelGGL(ilq_deadline_kernel<T>, dim3(batch), dim3(64), 0, stream, d, sa);
+        HIP_TRY(hipGetLastError());
+        want_exit = 1;
+        want_lq = 0;
+      }
+    }
+    if ((want_exit || want_lq) && log_iterates() != ILQG_OK) return ILQG_ERR_HIP;
     if (want_exit) {
       hipLaunchKernelGGL(k_exit, dim3(batch), dim3(64), lds_exit, stream, d, sa);
       HIP_TRY(hipGetLastError());
@@ -872,9 +973,14 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
         HIP_TRY(hipMemcpyAsync(p->h_unfinished, p->d_unfinished, 4 * sizeof(int), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         restarted = p->h_unfinished[2];
+        if (restarted) inner_elapsed = 0.0;  // the next inner solve's own budget
       }
     }
     if (want_lq) {
+      if (timed) {
+        tic = wall();
+        iteration_open = true;
+      }
       hipLaunchKernelGGL(k_lq, dim3(batch), dim3(nt_lq), lds_lq, stream, d, sa);
       HIP_TRY(hipGetLastError());
     }
@@ -902,8 +1008,10 @@ static ilqg_status launch_linquad(const ilqg_problem* p, int32_t batch, const vo
                                   void* Q, void* l, void* R, void* r, void* merit_part, void* cost_part,
                                   const int32_t* active, void* stream) {
   const DevProblem& d = p->dev;
-  if (!p->mu_uniform) return fail(ILQG_ERR_UNSUPPORTED, "non-uniform control dimensions");
   const void* const ptrs[14] = {xs, us, lambdas, mu, t_extreme, A, Bm, Q, l, R, r, merit_part, cost_part, active};
+  if (p->generic)  // the row stage with run-time dimensions (rows_chunk<T, 0, 0, 0>)
+    return p->desc.dtype == ILQG_F32 ? DimsLaunch<float, 0, 0, 0>::rows(d, batch, ptrs, (hipStream_t)stream)
+                                     : DimsLaunch<double, 0, 0, 0>::rows(d, batch, ptrs, (hipStream_t)stream);
 #define X(NX_, NP_, MU_)                                                                          \
   if (d.n == NX_ && d.N == NP_ && p->mu_uniform == MU_)                                           \
     return p->desc.dtype == ILQG_F32                                                              \
@@ -913,6 +1021,181 @@ static ilqg_status launch_linquad(const ilqg_problem* p, int32_t batch, const vo
 #undef X
   return fail(ILQG_ERR_UNSUPPORTED, "no device kernel instantiated for this problem's dimensions");
 }
+
+// LDS a CU can give one workgroup (gfx950: 160 KB)
+static constexpr size_t kLdsPerWorkgroup = size_t(160) * 1024;
+
+// The whole solve on the run-time-dimensioned kernels: the split trial pass (integrate / rows / decide, ilqg_solve.hpp)
+// over the whole batch every round, the host counting rounds; the sweeps of ilqg_lq_generic.hpp on dense rows.  No
+// hand-off, no probing, no compact rows: the correctness path of every shape without a specialised instantiation.
+template <typename T>
+static ilqg_status generic_solve(ilqg_problem* p, int32_t batch, const void* x0, void* xs, void* us, void* P, void* alpha,
+                                 void* total_costs, int32_t* iters, int32_t* status, int32_t* converged, void* workspace,
+                                 const ilqg_solve_options& opt, hipStream_t stream) {
+  const DevProblem& d = p->dev;
+  const int al_mode = opt.augmented_lagrangian ? 1 : 0, resume = opt.resume ? 1 : 0;
+  const int ol_row = p->desc.params.open_loop ? ol_row_elems(d.n, d.m, d.N) : 0;
+  const WsLayout L(d.n, d.m, d.N, d.T, d.pairs.Rsz, d.pairs.rsz, ol_row, d.num_constraints, al_mode);
+  SolveArgs<T> sa{};
+  sa.ol_row = ol_row;
+  sa.al_mode = al_mode;
+  sa.x0 = (const T*)x0; sa.xs = (T*)xs; sa.us = (T*)us; sa.P = (T*)P; sa.alpha = (T*)alpha;
+  sa.total_costs = (T*)total_costs; sa.iters = iters; sa.status = status; sa.converged = converged;
+  sa.ws = (T*)workspace; sa.ws_stride = L.total; sa.fixed_iters = opt.fixed_iters; sa.batch = batch;
+  sa.prm = p->desc.params;
+  sa.active = opt.active;
+  sa.prof = nullptr;
+  sa.forced_steps = (const T*)opt.forced_steps;
+  sa.unfinished = p->d_unfinished;
+  sa.rows_cw = rows_chunk_width(d.n, d.m, d.rp_pslots, d.rp_lslots, sizeof(T), size_t(48) * 1024);
+  const size_t lds_roll = trial_phase_lds_bytes<T>(d, TRIAL_ROLL, sa.rows_cw),
+               lds_decide = trial_phase_lds_bytes<T>(d, TRIAL_DECIDE, sa.rows_cw);
+  const size_t lds_rows = rows_maps_bytes(d) + trial_rows_elems(d, sa.rows_cw) * sizeof(T);
+  const size_t lds_exit = quad_tables_bytes(d, sizeof(T)) + 64 * sizeof(T);
+  const size_t lds_lq = ((p->desc.params.open_loop ? gen_openloop_lds_elems(d.n, d.N, d.m) : gen_feedback_lds_elems(d.n, d.N, d.m)) + 4) * sizeof(T);
+  if (lds_lq > kLdsPerWorkgroup || lds_rows > kLdsPerWorkgroup)
+    return fail(ILQG_ERR_UNSUPPORTED, "the game does not fit a CU's LDS");
+  auto k_roll = ilq_roll_kernel<T, 0, 0, 0>;
+  auto k_rows = ilq_rows_kernel<T, 0, 0, 0>;
+  auto k_decide = ilq_decide_kernel<T, 0, 0, 0>;
+  auto k_exit = ilq_exit_kernel<T, 0, 0, 0>;
+  auto k_lq = gen_lq_kernel<T>;
+  raise_lds_limit((const void*)k_roll, lds_roll);
+  raise_lds_limit((const void*)k_rows, lds_rows);
+  raise_lds_limit((const void*)k_decide, lds_decide);
+  raise_lds_limit((const void*)k_exit, lds_exit);
+  raise_lds_limit((const void*)k_lq, lds_lq);
+  const int row_chunks = (d.T + sa.rows_cw - 1) / sa.rows_cw;
+  long long cap = al_mode ? (long long)(sa.prm.max_solver_iters + 1) * (sa.prm.unconstrained_solver_max_iters + 2)
+                          : (long long)(opt.fixed_iters > 0 ? opt.fixed_iters : sa.prm.max_solver_iters) + 2;
+  cap = (cap + 2) * ((long long)sa.prm.max_backtracking_steps + 3);
+  const bool timed = opt.max_runtime > 0.0;
+  const double budget = !timed ? 0.0 : ((al_mode && d.num_constraints > 0) ? opt.max_runtime / double(sa.prm.max_solver_iters) : opt.max_runtime);
+  auto wall = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double inner_elapsed = 0.0, tic = 0.0;
+  bool iteration_open = false;
+  IterLog<T> lg{};
+  const bool logging = opt.iterate_log != nullptr;
+  if (logging) {
+    const ilqg_iterate_log& il = *opt.iterate_log;
+    if (!il.xs || !il.us || !il.costs || !il.count || il.capacity < 1)
+      return fail(ILQG_ERR_INVALID, "iterate log: xs, us, costs, count and a capacity of at least one are required");
+    lg = IterLog<T>{(T*)il.xs, (T*)il.us, (T*)il.costs, (T*)il.P, (T*)il.alpha, il.count, il.capacity};
+    HIP_TRY(hipMemsetAsync(il.count, 0, sizeof(int) * size_t(batch), stream));
+  }
+  sa.first = resume ? 2 : 1;
+  int waiting_lq = 0, waiting_exit = 0;
+  for (long long round = 0;; round++) {
+    HIP_TRY(hipMemsetAsync(p->d_unfinished, 0, 4 * sizeof(int), stream));
+    hipLaunchKernelGGL(k_roll, dim3(batch), dim3(64), lds_roll, stream, d, sa);
+    HIP_TRY(hipGetLastError());
+    sa.first = 0;
+    hipLaunchKernelGGL(k_rows, dim3(row_chunks, batch), dim3(64), lds_rows, stream, d, sa);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_decide, dim3(batch), dim3(64), lds_decide, stream, d, sa);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(p->h_unfinished, p->d_unfinished, 4 * sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    waiting_lq += p->h_unfinished[0];
+    waiting_exit += p->h_unfinished[1];
+    if (round > cap) return fail(ILQG_ERR_HIP, "solve did not terminate within its iteration bound");
+    if (p->h_unfinished[3]) continue;  // some instances want another pass (initial quadraticisation, back-tracking)
+    int want_lq = waiting_lq, want_exit = waiting_exit, restarted = 0;
+    waiting_lq = waiting_exit = 0;
+    if (timed && want_lq) {  // the loop condition of src/ilq_solver.cpp:123-124 (see DimsLaunch::solve)
+      const double now = wall();
+      if (iteration_open) {
+        p->loop_add(now - tic);
+        inner_elapsed += now - tic;
+        iteration_open = false;
+      }
+      if (!(inner_elapsed < budget - p->loop_upper_bound())) {
+        hipLaunchKernelGGL(ilq_deadline_kernel<T>, dim3(batch), dim3(64), 0, stream, d, sa);
+        HIP_TRY(hipGetLastError());
+        want_exit = 1;
+        want_lq = 0;
+      }
+    }
+    if (logging && (want_exit || want_lq)) {
+      hipLaunchKernelGGL(ilq_log_kernel<T>, dim3(batch), dim3(256), 0, stream, d, sa, lg);
+      HIP_TRY(hipGetLastError());
+    }
+    if (want_exit) {
+      HIP_TRY(hipMemsetAsync(p->d_unfinished, 0, 4 * sizeof(int), stream));
+      hipLaunchKernelGGL(k_exit, dim3(batch), dim3(64), lds_exit, stream, d, sa);
+      HIP_TRY(hipGetLastError());
+      if (al_mode) {
+        HIP_TRY(hipMemcpyAsync(p->h_unfinished, p->d_unfinished, 4 * sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        restarted = p->h_unfinished[2];
+        if (restarted) inner_elapsed = 0.0;
+      }
+    }
+    if (want_lq) {
+      if (timed) {
+        tic = wall();
+        iteration_open = true;
+      }
+      hipLaunchKernelGGL(k_lq, dim3(batch), dim3(256), lds_lq, stream, d, sa);
+      HIP_TRY(hipGetLastError());
+    }
+    if (!want_lq && !restarted) break;
+  }
+  return ILQG_OK;
+}
+
+static GenDims gen_dims_of(int n, int N, const int32_t* udim, int T) {
+  GenDims g{};
+  g.n = n; g.N = N; g.T = T;
+  g.uoff[0] = 0;
+  for (int i = 0; i < N; i++) {
+    g.udim[i] = udim[i];
+    g.uoff[i + 1] = g.uoff[i] + udim[i];
+  }
+  g.m = g.uoff[N];
+  return g;
+}
+
+// ilqg_lq_feedback_batch / ilqg_lq_openloop_batch for a shape without a specialised instantiation (or when the caller
+// asks for these kernels: ilqg_dims::sweep_formulation = ILQG_SWEEP_GENERIC).
+template <typename T>
+static ilqg_status launch_lq_generic(const ilqg_dims* d, const PairTable& pt, bool open_loop, const void* A, const void* Bm,
+                                     const void* Q, const void* l, const void* R, const void* r, const void* x0, void* P,
+                                     void* alpha, void* dx, void* costates, hipStream_t stream) {
+  const GenDims gd = gen_dims_of(d->n, d->num_players, d->udim, d->T);
+  if (gd.m > ILQG_MAX_UDIM_TOTAL) return fail(ILQG_ERR_UNSUPPORTED, "more than ILQG_MAX_UDIM_TOTAL controls in total");
+  const size_t lds = (open_loop ? gen_openloop_lds_elems(gd.n, gd.N, gd.m) : gen_feedback_lds_elems(gd.n, gd.N, gd.m)) * sizeof(T);
+  if (lds > kLdsPerWorkgroup) return fail(ILQG_ERR_UNSUPPORTED, "the game's value functions do not fit a CU's LDS");
+  LQBatchArgs<T> g;
+  g.A = (const T*)A; g.Bm = (const T*)Bm; g.Q = (const T*)Q; g.l = (const T*)l;
+  g.R = (const T*)R; g.r = (const T*)r; g.x0 = (const T*)x0;
+  g.P = (T*)P; g.alpha = (T*)alpha; g.dx = (T*)dx;
+  g.costates = open_loop ? (T*)costates : nullptr;
+  g.scratch = nullptr;
+  const int row = open_loop ? gen_ol_row_elems(gd.n, gd.m, gd.N, costates != nullptr) : 0;
+  if (open_loop) {
+    const ilqg_status s = Scratch().reserve(size_t(d->batch) * d->T * size_t(row) * sizeof(T));
+    if (s != ILQG_OK) return s;
+    g.scratch = (T*)ilqg_shared::scratch_state().ptr;
+  }
+  g.T_steps = d->T;
+  g.adaptive = open_loop ? 0 : d->adaptive_regularization;
+  g.batch = d->batch;
+  g.force_valu = 0;
+  auto kern = lq_generic_kernel<T>;
+  raise_lds_limit((const void*)kern, lds);
+  hipLaunchKernelGGL(kern, dim3(d->batch), dim3(256), lds, stream, g, gd, pt, open_loop ? 1 : 0, row);
+  HIP_TRY(hipGetLastError());
+  return ILQG_OK;
+}
+
+// RouteProgressCost subtracts RelativeTimeTracker::initial_time_ from the time it is handed (src/route_progress_cost.cpp:
+// 58), which Problem::SetUpNextRecedingHorizon resets to the window's start (src/problem.cpp:120); the device tables
+// are tabulated once with initial time 0 (ilqg_problem_create).  Re-anchoring such a problem would silently diverge
+// from the reference after the first re-plan, so the receding-horizon entry points refuse it.
+static const char* const kRouteProgressReceding =
+    "receding horizon: the problem holds a RouteProgressCost, whose per-step nominals are tabulated for a first solve "
+    "(initial time 0) only";
 
 extern "C" {
 
@@ -983,9 +1266,10 @@ ilqg_status ilqg_lq_feedback_batch(const ilqg_dims* d, const void* A, const void
                                    const void* x0, void* P, void* alpha, void* dx, void* costates, void* stream) {
   if (!d || !A || !Bm || !Q || !l || !R || !r || !pairs_host || !P || !alpha)
     return fail(ILQG_ERR_INVALID, "null argument");
-  if (d->num_players < 1 || d->num_players > ILQG_MAX_PLAYERS || d->n < 1 || d->n > ILQG_MAX_XDIM || d->T < 1 ||
-      d->T > kMaxT || d->batch < 0)
+  if (d->num_players < 1 || d->n < 1 || d->T < 1 || d->T > kMaxT || d->batch < 0)
     return fail(ILQG_ERR_INVALID, "bad dimensions");
+  if (d->num_players > ILQG_MAX_PLAYERS || d->n > ILQG_MAX_XDIM)
+    return fail(ILQG_ERR_UNSUPPORTED, "more than ILQG_MAX_XDIM states or ILQG_MAX_PLAYERS players");
   if (costates && !dx) return fail(ILQG_ERR_INVALID, "costates come with delta_xs (lq_feedback_solver.cpp:77-78)");
   for (const void* ptr : {A, Bm, Q, l, R, r})
     if (reinterpret_cast<uintptr_t>(ptr) % 16 != 0) return fail(ILQG_ERR_INVALID, "array bases must be 16-byte aligned");
@@ -993,8 +1277,7 @@ ilqg_status ilqg_lq_feedback_batch(const ilqg_dims* d, const void* A, const void
   std::string err;
   if (!build_pairs(pairs_host, npairs, d->udim, d->num_players, &pt, &err)) return fail(ILQG_ERR_INVALID, err);
   int mu = 0;
-  if (!uniform_udim(d->udim, d->num_players, &mu))
-    return fail(ILQG_ERR_UNSUPPORTED, "device kernels need equal control dimensions for all players");
+  const bool uniform = uniform_udim(d->udim, d->num_players, &mu);  // the specialised sweeps: one m_i for all players
   ilqg_status s = check_device();
   if (s != ILQG_OK) return s;
   if (d->batch == 0) return ILQG_OK;
@@ -1033,15 +1316,17 @@ ilqg_status ilqg_lq_feedback_batch(const ilqg_dims* d, const void* A, const void
     return ILQG_OK;
   };
 #define X(NX_, NP_, MU_)                                                                              \
-  if (d->n == NX_ && d->num_players == NP_ && mu == MU_) {                                            \
+  if (uniform && d->sweep_formulation != ILQG_SWEEP_GENERIC && d->n == NX_ && d->num_players == NP_ && mu == MU_) { \
     return finish(d->dtype == ILQG_F32                                                                \
                ? DimsLaunch<float, NX_, NP_, MU_>::lq(d, pt, A, Bm, Q, l, R, r, x0, P, alpha, dx, st)      \
                : DimsLaunch<double, NX_, NP_, MU_>::lq(d, pt, A, Bm, Q, l, R, r, x0, P, alpha, dx, st));   \
   }
   ILQG_FOR_DIMS(X)
 #undef X
-  return fail(ILQG_ERR_UNSUPPORTED, "no device kernel instantiated for n=" + std::to_string(d->n) +
-                                        " N=" + std::to_string(d->num_players) + " m_i=" + std::to_string(mu));
+  // no specialised instantiation (or players with different control dimensions): the run-time-dimensioned sweep
+  return finish(d->dtype == ILQG_F32
+                    ? launch_lq_generic<float>(d, pt, false, A, Bm, Q, l, R, r, x0, P, alpha, dx, nullptr, st)
+                    : launch_lq_generic<double>(d, pt, false, A, Bm, Q, l, R, r, x0, P, alpha, dx, nullptr, st));
 }
 
 ilqg_status ilqg_lq_openloop_batch(const ilqg_dims* d, const void* A, const void* Bm, const void* Q, const void* l,
@@ -1049,9 +1334,10 @@ ilqg_status ilqg_lq_openloop_batch(const ilqg_dims* d, const void* A, const void
                                    const void* x0, void* P, void* alpha, void* dx, void* costates, void* stream) {
   if (!d || !A || !Bm || !Q || !l || !R || !r || !pairs_host || !P || !alpha)
     return fail(ILQG_ERR_INVALID, "null argument");
-  if (d->num_players < 1 || d->num_players > ILQG_MAX_PLAYERS || d->n < 1 || d->n > ILQG_MAX_XDIM || d->T < 2 ||
-      d->T > kMaxT || d->batch < 0)
+  if (d->num_players < 1 || d->n < 1 || d->T < 2 || d->T > kMaxT || d->batch < 0)
     return fail(ILQG_ERR_INVALID, "bad dimensions");
+  if (d->num_players > ILQG_MAX_PLAYERS || d->n > ILQG_MAX_XDIM)
+    return fail(ILQG_ERR_UNSUPPORTED, "more than ILQG_MAX_XDIM states or ILQG_MAX_PLAYERS players");
   if (costates && !dx) return fail(ILQG_ERR_INVALID, "costates come with delta_xs (lq_open_loop_solver.cpp:83-84)");
   for (const void* ptr : {A, Bm, Q, l, R, r})
     if (reinterpret_cast<uintptr_t>(ptr) % 16 != 0) return fail(ILQG_ERR_INVALID, "array bases must be 16-byte aligned");
@@ -1059,22 +1345,21 @@ ilqg_status ilqg_lq_openloop_batch(const ilqg_dims* d, const void* A, const void
   std::string err;
   if (!build_pairs(pairs_host, npairs, d->udim, d->num_players, &pt, &err)) return fail(ILQG_ERR_INVALID, err);
   int mu = 0;
-  if (!uniform_udim(d->udim, d->num_players, &mu))
-    return fail(ILQG_ERR_UNSUPPORTED, "device kernels need equal control dimensions for all players");
+  const bool uniform = uniform_udim(d->udim, d->num_players, &mu);
   ilqg_status s = check_device();
   if (s != ILQG_OK) return s;
   if (d->batch == 0) return ILQG_OK;
   hipStream_t st = (hipStream_t)stream;
 #define X(NX_, NP_, MU_)                                                                                      \
-  if (d->n == NX_ && d->num_players == NP_ && mu == MU_) {                                                    \
+  if (uniform && d->sweep_formulation != ILQG_SWEEP_GENERIC && d->n == NX_ && d->num_players == NP_ && mu == MU_) { \
     return d->dtype == ILQG_F32                                                                               \
                ? DimsLaunch<float, NX_, NP_, MU_>::lq_openloop(d, pt, A, Bm, Q, l, R, r, x0, P, alpha, dx, costates, st)     \
                : DimsLaunch<double, NX_, NP_, MU_>::lq_openloop(d, pt, A, Bm, Q, l, R, r, x0, P, alpha, dx, costates, st);   \
   }
   ILQG_FOR_DIMS(X)
 #undef X
-  return fail(ILQG_ERR_UNSUPPORTED, "no device kernel instantiated for n=" + std::to_string(d->n) +
-                                        " N=" + std::to_string(d->num_players) + " m_i=" + std::to_string(mu));
+  return d->dtype == ILQG_F32 ? launch_lq_generic<float>(d, pt, true, A, Bm, Q, l, R, r, x0, P, alpha, dx, costates, st)
+                              : launch_lq_generic<double>(d, pt, true, A, Bm, Q, l, R, r, x0, P, alpha, dx, costates, st);
 }
 
 ilqg_status ilqg_problem_create(const ilqg_problem_desc* desc, ilqg_problem** out) {
@@ -1137,12 +1422,10 @@ ilqg_status ilqg_problem_create(const ilqg_problem_desc* desc, ilqg_problem** ou
   {
     bool plain = false;
     for (int i = 0; i < d.N; i++) plain = plain || is_plain_rk4_kind(d.sub_kind[i]);
-    if (plain && !dims_use_plain_rk4(d.n, d.N, d.udim[0])) {
-      delete p;
-      return fail(ILQG_ERR_UNSUPPORTED,
-                  "Unicycle5D / Car7D / DelayedDubinsCar rows need an instantiation that carries the plain RK4 "
-                  "(dims_use_plain_rk4, csrc/ilqg_stages.hpp)");
-    }
+    // Unicycle5D / Car7D / DelayedDubinsCar rows need an instantiation that carries the plain RK4 (dims_use_plain_rk4,
+    // csrc/ilqg_stages.hpp); in any other shape they run on the run-time-dimensioned path, which picks its integrator
+    // from the models
+    if (plain && !dims_use_plain_rk4(d.n, d.N, d.udim[0])) p->generic = true;
   }
   // DistanceBetween of the first subsystem: (px, py) where the model overrides it (two_player_unicycle_4d.h:141-147
   // too), the whole block where it does not (the two Dubins cars: single_player_dynamical_system.h:69-71)
@@ -1258,6 +1541,19 @@ ilqg_status ilqg_problem_create(const ilqg_problem_desc* desc, ilqg_problem** ou
                                       "RouteProgressCost)");
       }
       const int src_poly = o.polyline;
+      if (route) {
+        // Polyline2::PointAt CHECKs its argument (src/polyline2.cpp:68-103): a route position that is negative at any
+        // step, or a polyline without a segment, is a programmer error there and ILQG_ERR_INVALID here
+        const int nseg_r = desc->polyline_offsets[src_poly + 1] - desc->polyline_offsets[src_poly] - 1;
+        const double pos_first = double(desc->terms[ti].value2);
+        const double pos_last = pos_first + double(d.T - 1) * d.dt * double(o.value);
+        if (nseg_r < 1 || !(pos_first >= 0.0) || !(pos_last >= 0.0)) {
+          ilqg_problem_destroy(p);
+          return fail(ILQG_ERR_INVALID, "RouteProgressCost: the route needs a segment and a route position that stays "
+                                        "non-negative over the horizon (initial_route_pos, nominal_speed)");
+        }
+        p->has_route_progress = true;
+      }
       auto point_at = [&](const auto& segs, auto route_pos, double* px, double* py) {
         using S = decltype(route_pos);
         const int first = desc->polyline_offsets[src_poly] - src_poly;
@@ -1354,7 +1650,18 @@ ilqg_status ilqg_problem_create(const ilqg_problem_desc* desc, ilqg_problem** ou
   p->desc.terms = nullptr;
   p->desc.polyline_offsets = nullptr;
   p->desc.polyline_points = nullptr;
-  uniform_udim(d.udim, d.N, &p->mu_uniform);
+  if (!uniform_udim(d.udim, d.N, &p->mu_uniform)) p->mu_uniform = 0;
+  {
+    bool instantiated = false;
+#define X(NX_, NP_, MU_) instantiated = instantiated || (d.n == NX_ && d.N == NP_ && p->mu_uniform == MU_);
+    ILQG_FOR_DIMS(X)
+#undef X
+    if (!instantiated) p->generic = true;
+  }
+  if (d.n > ILQG_MAX_XDIM || d.m > ILQG_MAX_UDIM_TOTAL) {
+    ilqg_problem_destroy(p);
+    return fail(ILQG_ERR_UNSUPPORTED, "more than ILQG_MAX_XDIM states or ILQG_MAX_UDIM_TOTAL controls");
+  }
   *out = p;
   return ILQG_OK;
 }
@@ -1464,11 +1771,18 @@ ilqg_status ilqg_solve_batch_ex(ilqg_problem* p, int32_t batch, const void* x0, 
   if (o.fixed_iters < 0) return fail(ILQG_ERR_INVALID, "fixed_iters must not be negative");
   if (o.forced_steps && (o.fixed_iters <= 0 || o.augmented_lagrangian))
     return fail(ILQG_ERR_INVALID, "forced_steps needs fixed_iters > 0 and no augmented-Lagrangian loop");
+  if (o.max_runtime > 0.0 && (o.fixed_iters > 0 || o.forced_steps))
+    return fail(ILQG_ERR_INVALID, "max_runtime needs a free-running solve (fixed_iters = 0, no forced steps)");
   for (int32_t c : {o.split_trial, o.handoff, o.probe, o.counted})
     if (c < ILQG_CHOICE_AUTO || c > ILQG_CHOICE_ON) return fail(ILQG_ERR_INVALID, "scheduling choices are ilqg_choice values");
   const DevProblem& d = p->dev;
-  if (!p->mu_uniform) return fail(ILQG_ERR_UNSUPPORTED, "non-uniform control dimensions");
   hipStream_t st = (hipStream_t)stream;
+  if (o.generic_kernels < ILQG_CHOICE_AUTO || o.generic_kernels > ILQG_CHOICE_ON)
+    return fail(ILQG_ERR_INVALID, "scheduling choices are ilqg_choice values");
+  if (p->generic || o.generic_kernels == ILQG_CHOICE_ON)
+    return p->desc.dtype == ILQG_F32
+               ? generic_solve<float>(p, batch, x0, xs, us, P, alpha, total_costs, iters, status, converged, workspace, o, st)
+               : generic_solve<double>(p, batch, x0, xs, us, P, alpha, total_costs, iters, status, converged, workspace, o, st);
 #define X(NX_, NP_, MU_)                                                                                        \
   if (d.n == NX_ && d.N == NP_ && p->mu_uniform == MU_) {                                                       \
     return p->desc.dtype == ILQG_F32                                                                            \
@@ -1537,6 +1851,7 @@ ilqg_status ilqg_receding_horizon_shift_batch(const ilqg_problem* p, int32_t bat
                                               void* alpha, void* x0_next, int32_t* first_step,
                                               double* new_plan_t0_host, void* stream) {
   if (!p || !x0 || !xs || !us || !P || !alpha || !x0_next || !first_step) return fail(ILQG_ERR_INVALID, "null argument");
+  if (p->has_route_progress) return fail(ILQG_ERR_UNSUPPORTED, kRouteProgressReceding);
   const DevProblem& d = p->dev;
   const double dt = d.dt, horizon = dt * d.T;
   // the reference's CHECKs (src/problem.cpp:68-70)
@@ -1720,6 +2035,7 @@ ilqg_status ilqg_receding_horizon_sync_batch(const ilqg_problem* p, int32_t batc
     return fail(ILQG_ERR_INVALID, "null argument");
   if (xs == plan_xs || us == plan_us || P == plan_P || alpha == plan_alpha)
     return fail(ILQG_ERR_INVALID, "the next solve's buffers must not alias the stored plan");
+  if (p->has_route_progress) return fail(ILQG_ERR_UNSUPPORTED, kRouteProgressReceding);
   if (batch <= 0) return ILQG_OK;
   const DevProblem& d = p->dev;
 #define CALL(TY_)                                                                                                  \

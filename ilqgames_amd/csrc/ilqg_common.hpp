@@ -14,14 +14,13 @@
 #include <stdint.h>
 
 #include "../../include/ilqg.h"
+#include "ilqg_pairs.hpp"  // kMaxPlayers, kMaxPairs, PairTable
 
 #include <type_traits>
 #include <utility>
 
 namespace ilqg {
 
-constexpr int kMaxPlayers = ILQG_MAX_PLAYERS;
-constexpr int kMaxPairs = 16;  // device kernels: at most NP*NP <= 16 control blocks
 constexpr int kMaxT = 256;
 // Phase-profile instrumentation (scripts/stage_bench.py) is compiled in only with -DILQG_PROFILE=1: the
 // accumulators are live across the hot loops and the kernels are register-bound.
@@ -41,17 +40,6 @@ __device__ __forceinline__ void tl_stamp(long long* prof, int b, int slot, bool 
     if (prof && who) prof[size_t(b) * 96 + 32 + slot] = wall_clock64();
   }
 }
-
-// (i,j) control-block table of one problem (QuadraticCostApproximation::control keys).
-struct PairTable {
-  int npairs;
-  int pi[kMaxPairs], pj[kMaxPairs];
-  int roff[kMaxPairs];   // offset of block p inside an R row (elements)
-  int rgoff[kMaxPairs];  // offset inside an r row
-  int from_cost[kMaxPairs];
-  int pii[kMaxPlayers];  // index of the (i,i) block
-  int Rsz, rsz;
-};
 
 struct DevTerm {
   int kind, role, player, arg;

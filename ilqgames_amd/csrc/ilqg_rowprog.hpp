@@ -384,6 +384,19 @@ inline bool build_row_program(const DevProblem& d, const std::vector<DevTerm>& d
   w[RP_OFF_MERIT] = put(merit);
   {
     if (cdst.size() > size_t(kCompactMaxWords) || cdst.size() >= (1u << 24)) compact_ok = false;
+    // what the compact rows' consumers hold: the open-loop sweep keeps the non-zero tile constants (those of Q_i, l_i)
+    // in an LDS list of kCompactMaxBg entries (ilqg_lq_openloop.hpp), the forward pass scatters the Jacobian pass with
+    // one word per lane (ilqg_lq.hpp) — a problem past either takes the dense rows instead of losing entries
+    {
+      int tile_constants = 0;
+      for (size_t e = 0; e + RC_BG_WORDS <= cbg.size(); e += RC_BG_WORDS) {
+        const int arr = cbg[e] >> 24;
+        if (arr == RA_Q || arr == RA_L) tile_constants++;
+      }
+      if (tile_constants > kCompactMaxBg) compact_ok = false;
+      const int jac_words = cbase.size() >= 2 ? cbase[1] - cbase[0] : int(cdst.size());
+      if (jac_words > 64) compact_ok = false;
+    }
     std::vector<int> blk;
     blk.push_back(compact_ok ? int(cdst.size()) : 0);
     blk.push_back(compact_ok ? int(cbg.size()) / RC_BG_WORDS : 0);

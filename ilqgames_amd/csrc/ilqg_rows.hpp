@@ -152,6 +152,15 @@ __device__ __forceinline__ void rows_writeout(T* g0, size_t stride, const short*
     }
   }
 }
+// A block of any size known at run time only (the run-time-dimensioned path, CN = 0 in rows_chunk): 64 words at a time.
+template <typename T>
+__device__ __forceinline__ void rows_writeout_small(T* g0, size_t stride, int W, const short* map, const T* acc, int cws,
+                                                    int nrows, int lane);
+template <typename T>
+__device__ __forceinline__ void rows_writeout_rt(T* g0, size_t stride, int W, const short* map, const T* acc, int cws,
+                                                 int nrows, int lane) {
+  for (int w0 = 0; w0 < W; w0 += 64) rows_writeout_small<T>(g0 + w0, stride, W - w0 < 64 ? W - w0 : 64, map + w0, acc, cws, nrows, lane);
+}
 // The same for a block of at most 64 words whose size is only known at run time (l_i, R_ij, r_ij).
 template <typename T>
 __device__ __forceinline__ void rows_writeout_small(T* g0, size_t stride, int W, const short* map, const T* acc, int cws,
@@ -348,10 +357,14 @@ __device__ __forceinline__ Closest<T> polyline_closest_rows(typename ConstPtr<T>
 // (rows_lds_elems for this cw: 64, 32 or 16).  `maps` is the workgroup's LDS copy of the program's word maps
 // (rows_maps_load).  What is produced follows QuadArgs: A / Bm (null: skip the Jacobians), Q / l / R / r (null: not
 // written; derivatives are still accumulated when merit_part is set), merit_part, cost_part.
-template <typename T, int CN, int CM, int CNP>
+// CN, CM, CNP: the problem's state / total control dimension / player count at compile time, or all 0 — the
+// run-time-dimensioned path (shapes without an instantiation): the same program, dimensions read from `p`.
+template <typename T, int CN_, int CM_, int CNP_>
 __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* maps, const QuadArgs<T>& a, int k0,
                                            int nrows, int cw, T* sm, int lane) {
-  constexpr int NA = CN + CM;
+  constexpr bool RT = CN_ == 0;
+  const int CN = RT ? p.n : CN_, CM = RT ? p.m : CM_, CNP = RT ? p.N : CNP_;
+  const int NA = CN + CM;
   const int cws = cw + 1;
   T* const arg = sm;
   T* const acc = sm + NA * cw;
@@ -612,11 +625,20 @@ __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* map
       const int arr = rd[0], words = rd[1], offs = rd[2];
       const short* const map = maps + rd[3];
       if (arr == RA_A) {
-        if (a.A) rows_writeout<T, CN * CN, rows_vec_width<T>(CN * CN)>(a.A + size_t(k0) * CN * CN, CN * CN, map, acc, cws, nrows, lane);
+        if (a.A) {
+          if constexpr (RT) rows_writeout_rt<T>(a.A + size_t(k0) * CN * CN, size_t(CN) * CN, CN * CN, map, acc, cws, nrows, lane);
+          else rows_writeout<T, CN_ * CN_, rows_vec_width<T>(CN_ * CN_)>(a.A + size_t(k0) * CN * CN, CN * CN, map, acc, cws, nrows, lane);
+        }
       } else if (arr == RA_B) {
-        if (a.Bm) rows_writeout<T, CN * CM, rows_vec_width<T>(CN * CM)>(a.Bm + size_t(k0) * CN * CM, CN * CM, map, acc, cws, nrows, lane);
+        if (a.Bm) {
+          if constexpr (RT) rows_writeout_rt<T>(a.Bm + size_t(k0) * CN * CM, size_t(CN) * CM, CN * CM, map, acc, cws, nrows, lane);
+          else rows_writeout<T, CN_ * CM_, rows_vec_width<T>(CN_ * CM_)>(a.Bm + size_t(k0) * CN * CM, CN * CM, map, acc, cws, nrows, lane);
+        }
       } else if (arr == RA_Q) {
-        if (a.Q) rows_writeout<T, CN * CN, rows_vec_width<T>(CN * CN)>(a.Q + size_t(k0) * CNP * CN * CN + offs, size_t(CNP) * CN * CN, map, acc, cws, nrows, lane);
+        if (a.Q) {
+          if constexpr (RT) rows_writeout_rt<T>(a.Q + size_t(k0) * CNP * CN * CN + offs, size_t(CNP) * CN * CN, CN * CN, map, acc, cws, nrows, lane);
+          else rows_writeout<T, CN_ * CN_, rows_vec_width<T>(CN_ * CN_)>(a.Q + size_t(k0) * CNP * CN * CN + offs, size_t(CNP) * CN * CN, map, acc, cws, nrows, lane);
+        }
       } else if (arr == RA_L) {
         if (a.l) rows_writeout_small<T>(a.l + size_t(k0) * CNP * CN + offs, CNP * CN, words, map, acc, cws, nrows, lane);
       } else if (arr == RA_R) {

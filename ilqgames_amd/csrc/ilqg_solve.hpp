@@ -18,6 +18,7 @@
 #include "ilqg_lq.hpp"
 #include "ilqg_lq_openloop.hpp"
 #include "ilqg_lq_feedback2.hpp"
+#include "ilqg_lq_generic.hpp"
 #include "ilqg_stages.hpp"
 
 namespace ilqg {
@@ -210,7 +211,7 @@ __host__ __device__ inline size_t trial_lds_bytes(const DevProblem& p, int waves
 template <typename T, int NX, int NP, int MU>
 __device__ __forceinline__ void solve_exit_path(const DevProblem& p, const QuadTables<T>& tb, const SolveArgs<T>& sa,
                                                 const InstanceBuffers<T>& ib, SolveState<T>& s, int b, T* sm) {
-  constexpr int n = NX, m = NP * MU;
+  const int n = NX > 0 ? NX : p.n, m = NX > 0 ? NP * MU : p.m;  // NX = 0: the run-time-dimensioned path
   const int Tn = p.T;
   const ilqg_solver_params& prm = sa.prm;
   const WsLayout& L = ib.L;
@@ -545,7 +546,8 @@ template <typename T, int NX, int NP, int MU, int W, int PHASE = TRIAL_FUSED>
 __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const short* maps,
                                                     const SolveArgs<T>& sa, int b, T* sm) {
   static_assert(PHASE == TRIAL_FUSED || W == 1, "the split phases run one wave per instance");
-  constexpr int n = NX, N = NP, m = NP * MU;
+  static_assert(NX > 0 || PHASE != TRIAL_FUSED, "the run-time-dimensioned path (NX = 0) runs the split passes");
+  const int n = NX > 0 ? NX : p.n, N = NX > 0 ? NP : p.N, m = NX > 0 ? NP * MU : p.m;
   const int Tn = p.T;
   const ilqg_solver_params& prm = sa.prm;
   const InstanceBuffers<T> ib(p, sa, b);
@@ -624,11 +626,15 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const s
     }
     __syncthreads();
     tl_stamp(sa.prof, b, 1, t == 0);
-    if (roll && wave == 0)
-      rollout_instance<T, NX, NP * MU, (NX == 4 && NP == 2), (MU == 1), (NX == 3 && NP == 2 && MU == 1),
-                       (NX == 4 * NP && MU == 2 && NP <= 2), dims_use_plain_rk4(NX, NP, MU)>(
-                                       p, ra, sm_roll, lane, W > 1 ? &flags[0] : nullptr,
-                                       (kProfile && sa.prof) ? rph : nullptr, kTimeline ? sa.prof : nullptr, b);
+    if (roll && wave == 0) {
+      if constexpr (NX > 0)
+        rollout_instance<T, NX, NP * MU, (NX == 4 && NP == 2), (MU == 1), (NX == 3 && NP == 2 && MU == 1),
+                         (NX == 4 * NP && MU == 2 && NP <= 2), dims_use_plain_rk4(NX, NP, MU)>(
+                                         p, ra, sm_roll, lane, W > 1 ? &flags[0] : nullptr,
+                                         (kProfile && sa.prof) ? rph : nullptr, kTimeline ? sa.prof : nullptr, b);
+      else
+        rollout_instance_rt<T>(p, ra, sm_roll, lane);
+    }
     tl_stamp(sa.prof, b, 2, t == 0);
     if (roll && W == 1) {
       __syncthreads();
@@ -639,7 +645,7 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const s
 
     // ---- linearise / quadraticise the trajectory: every wave claims rows as they become ready ----
     const int qmode = s.qmode;
-    if (PHASE == TRIAL_FUSED) {
+    if constexpr (PHASE == TRIAL_FUSED) {
     QuadArgs<T> qa = trial_quad_args<T>(p, ib, s, sa.compact != 0);
     qa.phacc = (kProfile && sa.prof) ? qph : nullptr;
     qa.tl = kTimeline ? sa.prof : nullptr;
@@ -773,6 +779,60 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const s
 }
 
 // ---------------------------------------------------------------------------
+// Iterate log (ilqg_iterate_log, include/ilqg.h): what SolverLog::AddSolverIterate deep-copies in the reference
+// (src/ilq_solver.cpp:111,164).  An instance shows an accepted iterate at a kernel boundary exactly when its stage is
+// LQ (the loop goes on) or INNER_DONE (it ends); iterate q of an inner solve goes to slot `logged so far` + q, so a
+// second visit of the same state (an instance that waits several rounds for the batch's sweep, or one whose line
+// search failed and still holds its last accepted iterate) rewrites the slot with the same values.
+// Executed by every thread of a workgroup, one workgroup per instance, launched in front of the exit / sweep kernels.
+// ---------------------------------------------------------------------------
+template <typename T>
+struct IterLog {
+  T *xs, *us, *costs, *P, *alpha;
+  int* count;
+  int capacity;
+};
+
+template <typename T>
+__device__ __forceinline__ void log_part_instance(const DevProblem& p, const SolveArgs<T>& sa, const IterLog<T>& lg, int b) {
+  const InstanceBuffers<T> ib(p, sa, b);
+  const SolveState<T> s = state_load<T>(ib.w, ib.L);
+  if (s.stage != ST_LQ && s.stage != ST_INNER_DONE) return;
+  const int slot = (sa.al_mode ? s.logged : 0) + s.accepted_iters;
+  const int t = threadIdx.x, nt = blockDim.x;
+  if (t == 0 && lg.count[b] < slot + 1) lg.count[b] = slot + 1;
+  if (slot >= lg.capacity) return;
+  const size_t Tn = p.T, n = p.n, m = p.m, N = p.N;
+  const size_t at = size_t(b) * lg.capacity + slot;
+  const T* xs = ib.XS(s.cur);
+  const T* us = ib.US(s.cur);
+  for (size_t e = t; e < Tn * n; e += nt) lg.xs[at * Tn * n + e] = xs[e];
+  for (size_t e = t; e < Tn * m; e += nt) lg.us[at * Tn * m + e] = us[e];
+  if (size_t(t) < N) lg.costs[at * N + t] = sa.total_costs[size_t(b) * N + t];
+  if (lg.P) {
+    const T* P = ib.PB(s.sacc);
+    for (size_t e = t; e < Tn * m * n; e += nt) lg.P[at * Tn * m * n + e] = P[e];
+  }
+  if (lg.alpha) {  // the strategies the reference logs carry the accepted step (ScaleAlphas is destructive, :66-72)
+    const T* al = ib.AL(s.sacc);
+    for (size_t e = t; e < Tn * m; e += nt) lg.alpha[at * Tn * m + e] = al[e] * s.acc_scale;
+  }
+}
+
+// The anytime exit of ILQSolver::Solve (src/ilq_solver.cpp:123-124): once the host's clock says the next iteration no
+// longer fits max_runtime, the instances that would start one (stage LQ) take the loop's normal exit instead — success
+// stays true, has_converged is whatever the last accepted step left.
+template <typename T>
+__device__ __forceinline__ void deadline_part_instance(const DevProblem& p, const SolveArgs<T>& sa, int b) {
+  const WsLayout L(p.n, p.m, p.N, p.T, p.pairs.Rsz, p.pairs.rsz, sa.ol_row, p.num_constraints, sa.al_mode);
+  SolveState<T>* const st = reinterpret_cast<SolveState<T>*>(sa.ws + size_t(b) * sa.ws_stride + L.state);
+  if (threadIdx.x == 0 && st->stage == ST_LQ) {
+    st->stage = ST_INNER_DONE;
+    atomicAdd(sa.unfinished + 1, 1);
+  }
+}
+
+// ---------------------------------------------------------------------------
 // LQ part: the Riccati sweep of one instance whose stage is LQ.  Kept free of everything else (the
 // exit path lives in the trial kernel) so that the sweep's registers are all it has to hold.
 // PW: the workgroup has one wave per player and runs the player-parallel MFMA feedback sweep;
@@ -847,6 +907,49 @@ __device__ __forceinline__ void lq_part_instance(const DevProblem& p, const Solv
     st->bt = 0;
     st->stage = ST_ROLLOUT;
     if (kProfile && sa.prof) sa.prof[size_t(b) * 96 + 2] += clock64() - pr_start;
+  }
+}
+
+// The LQ part on the run-time-dimensioned sweeps (ilqg_lq_generic.hpp): dense rows in, strategies and the expected
+// decrease out, no deferred forward pass.  One workgroup per instance whose stage is LQ.
+template <typename T>
+__device__ __forceinline__ void lq_part_generic(const DevProblem& p, const SolveArgs<T>& sa, int b, T* sm) {
+  const int Tn = p.T;
+  const WsLayout L(p.n, p.m, p.N, p.T, p.pairs.Rsz, p.pairs.rsz, sa.ol_row, p.num_constraints, sa.al_mode);
+  T* const w = sa.ws + size_t(b) * sa.ws_stride;
+  SolveState<T>* const st = reinterpret_cast<SolveState<T>*>(w + L.state);
+  const int sacc = __builtin_amdgcn_readfirstlane(st->sacc);
+  GenDims gd;
+  gd.n = p.n; gd.N = p.N; gd.m = p.m; gd.T = p.T;
+  for (int i = 0; i < kMaxPlayers; i++) {
+    gd.udim[i] = p.udim[i];
+    gd.uoff[i] = p.uoff[i];
+  }
+  gd.uoff[kMaxPlayers] = p.uoff[kMaxPlayers];
+  GenLQArgs<T> la;
+  la.A = w + L.A; la.Bm = w + L.B; la.Q = w + L.Q; la.l = w + L.l; la.R = w + L.R; la.r = w + L.r;
+  la.x0 = nullptr;
+  la.P = sacc ? sa.P + size_t(b) * Tn * p.m * p.n : w + L.P1;  // strategy buffer 1 - sacc
+  la.alpha = sacc ? sa.alpha + size_t(b) * Tn * p.m : w + L.al1;
+  la.dx = w + L.dx;
+  la.costates = nullptr;
+  la.scratch = w + L.lqscr;
+  // the expected decrease: one LDS slot past the sweep's own working set (the launch reserves it)
+  la.ed_out = sm + (sa.prm.open_loop ? gen_openloop_lds_elems(p.n, p.N, p.m) : gen_feedback_lds_elems(p.n, p.N, p.m));
+  la.adaptive = 1;
+  const ParDevice par;
+  if (sa.prm.open_loop)
+    lq_openloop_generic<T>(gd, la, p.pairs, sm, par);
+  else
+    lq_feedback_generic<T>(gd, la, p.pairs, sm, par);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    st->expected_decrease = *la.ed_out;
+    st->num_iterations += 1;
+    st->step = sa.forced_steps ? sa.forced_steps[size_t(b) * sa.fixed_iters + (st->num_iterations - 1)]
+                               : T(sa.prm.initial_alpha_scaling);
+    st->bt = 0;
+    st->stage = ST_ROLLOUT;
   }
 }
 

@@ -181,6 +181,30 @@ __device__ __forceinline__ void rollout_instance(const DevProblem& p, const Roll
   if (ready) progress_publish(ready, Tn);
 }
 
+// The rollout with run-time dimensions, the integrator picked from the problem's models at run time (what the
+// instantiated solves pick at compile time from their dimensions): the stand-alone rollout entry point and the
+// run-time-dimensioned solve path.
+template <typename T>
+__device__ __forceinline__ void rollout_instance_rt(const DevProblem& p, const RolloutArgs<T>& a, T* sm, int t) {
+  bool dubins = false, plain = false;
+  for (int i = 0; i < p.N; i++) {
+    dubins = dubins || p.sub_kind[i] == ILQG_DYN_DUBINS_CAR;
+    plain = plain || is_plain_rk4_kind(p.sub_kind[i]);
+  }
+  if (plain)
+    rollout_instance<T, 0, 0, false, false, false, false, true>(p, a, sm, t);
+  else if (p.sub_kind[0] == ILQG_DYN_AIR_3D_EVADER)
+    rollout_instance<T, 0, 0, false, false, true>(p, a, sm, t);
+  else if (p.sub_kind[0] == ILQG_DYN_UNICYCLE_4D_DISTURBED)
+    rollout_instance<T, 0, 0, true>(p, a, sm, t);
+  else if (dubins)
+    rollout_instance<T, 0, 0, false, true>(p, a, sm, t);
+  else if (p.sub_kind[0] == ILQG_DYN_POINT_MASS_2D)
+    rollout_instance<T, 0, 0, false, false, false, true>(p, a, sm, t);
+  else
+    rollout_instance<T>(p, a, sm, t);
+}
+
 // ---------------------------------------------------------------------------
 // Cost tables in LDS for the kernels that walk a player's cost list with a lane-varying index (strategy
 // costs / Nash checks, the multiplier update of the exit path).  The linearise + quadraticise stage itself is

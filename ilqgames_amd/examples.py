@@ -733,6 +733,75 @@ def delayed_dubins_scene(T=100, dt=0.1):
     return s
 
 
+def mixed_dubins_car_scene(T=100, dt=0.1, open_loop=False, constrained=False):
+    """A test scene, NOT a reference example: ConcatenatedDynamicalSystem({SinglePlayerDubinsCar, SinglePlayerCar5D})
+    — n = 3 + 5, control dimensions (1, 2): players with DIFFERENT control dimensions, which only the
+    run-time-dimensioned kernels run (src/concatenated_dynamical_system.cpp:52-66 and src/lq_feedback_solver.cpp:118-160
+    walk cumulative dimensions; the reference's test/test_linearization.cpp:200-260 concatenates mixed models too).
+    The Dubins car is drawn to a point while keeping clear of the car; the car follows a lane at a nominal speed."""
+    prm = SolverParams.default()
+    prm.max_backtracking_steps = 100
+    prm.initial_alpha_scaling = 0.1
+    prm.convergence_tolerance = 0.1
+    prm.expected_decrease_fraction = 0.001
+    prm.max_solver_iters = 40
+    prm.open_loop = 1 if open_loop else 0
+    s = ProblemSpec(T, dt, prm)
+    s.add_player(abi.DYN_DUBINS_CAR, 2.0, state_reg=10.0, control_reg=10.0)
+    s.add_player(abi.DYN_CAR_5D, 4.0, state_reg=10.0, control_reg=10.0)
+    DX, DY, DH = 0, 1, 2
+    CX, CY, CH, CPHI, CV = 3, 4, 5, 6, 7
+    lane = s.add_polyline([(-50.0, -2.0), (0.0, -2.0), (20.0, 2.0), (80.0, 2.0)])
+    s.quadratic(0, 2.0, DX, 12.0)
+    s.quadratic(0, 2.0, DY, 3.0)
+    s.proximity(0, 20.0, (DX, DY), (CX, CY), 4.0)
+    s.quadratic(0, 5.0, 0, 0.0, control_of=0)
+    s.quadratic_polyline2(1, 10.0, lane, (CX, CY))
+    s.quadratic(1, 4.0, CV, 6.0)
+    s.semiquadratic(1, 50.0, CPHI, 0.4, True)
+    s.proximity(1, 20.0, (CX, CY), (DX, DY), 4.0)
+    s.quadratic(1, 5.0, 0, 0.0, control_of=1)
+    s.quadratic(1, 2.0, 1, 0.0, control_of=1)
+    s.quadratic(1, 0.5, 0, 0.0, control_of=0)  # the car's cost sees the Dubins car's turn rate: an (1, 0) block
+    if constrained:
+        s.single_dimension_constraint(0, 0, 1.2, True, control_of=0)
+        s.single_dimension_constraint(1, CV, 8.0, True)
+        s.proximity_constraint(1, (CX, CY), (DX, DY), 2.0, False)
+    s.x0 = [0.0, 4.0, float(np.float32(-0.4)), -10.0, -2.0, 0.0, 0.0, 5.0]
+    s.position_dims, s.heading_dims, s.speed_dims = [(DX, DY), (CX, CY)], [DH, CH], [None, CV]
+    return s
+
+
+def three_unicycle_scene(T=60, dt=0.1, open_loop=False):
+    """A test scene, NOT a reference example: three SinglePlayerUnicycle4D (n = 12, N = 3, m_i = 2) — equal control
+    dimensions, but a shape the library holds no specialised instantiation of, and a horizon that is not the reference's
+    100 steps: the run-time-dimensioned kernels again."""
+    prm = SolverParams.default()
+    prm.max_backtracking_steps = 100
+    prm.initial_alpha_scaling = 0.1
+    prm.convergence_tolerance = 0.1
+    prm.expected_decrease_fraction = 0.001
+    prm.max_solver_iters = 30
+    prm.open_loop = 1 if open_loop else 0
+    s = ProblemSpec(T, dt, prm)
+    for _ in range(3):
+        s.add_player(abi.DYN_UNICYCLE_4D, 0.0, state_reg=10.0, control_reg=10.0)
+    X, Y, H, V = [0, 4, 8], [1, 5, 9], [2, 6, 10], [3, 7, 11]
+    goals = [(8.0, 0.0), (0.0, 8.0), (-6.0, -6.0)]
+    for i in range(3):
+        s.quadratic(i, 2.0, X[i], goals[i][0])
+        s.quadratic(i, 2.0, Y[i], goals[i][1])
+        s.quadratic(i, 1.0, V[i], 2.0)
+        for j in range(3):
+            if j != i:
+                s.proximity(i, 15.0, (X[i], Y[i]), (X[j], Y[j]), 3.0)
+        s.quadratic(i, 2.0, 0, 0.0, control_of=i)
+        s.quadratic(i, 2.0, 1, 0.0, control_of=i)
+    s.x0 = [-8.0, 0.5, 0.0, 2.0, 0.5, -8.0, float(np.float32(np.pi / 2)), 2.0, 6.0, 6.5, float(np.float32(-2.3)), 2.0]
+    s.position_dims, s.heading_dims, s.speed_dims = list(zip(X, Y)), H, V
+    return s
+
+
 def jittered_x0(spec, batch, seed=0):
     """Per-instance initial states of SURVEY.md §8(d): U(-1,1) m on px,py, U(-0.1,0.1) rad
     heading, U(-0.5,0.5) m/s speed; instance b uses numpy default_rng(seed + b)."""
@@ -770,6 +839,12 @@ CONFIGS = {
     "weighted_proximity_scene": weighted_proximity_scene,
     "dynamics_zoo_scene": dynamics_zoo_scene,
     "delayed_dubins_scene": delayed_dubins_scene,
+    # shapes without a specialised instantiation: the run-time-dimensioned kernels
+    "mixed_dubins_car_scene": mixed_dubins_car_scene,
+    "mixed_dubins_car_scene_open_loop": lambda: mixed_dubins_car_scene(open_loop=True),
+    "mixed_dubins_car_scene_constrained": lambda: mixed_dubins_car_scene(constrained=True),
+    "three_unicycle_scene": three_unicycle_scene,
+    "three_unicycle_scene_open_loop": lambda: three_unicycle_scene(open_loop=True),
     "air_3d": air_3d,
     "modified_air_3d": modified_air_3d,
     "dubins_origin": dubins_origin,

@@ -207,11 +207,14 @@ class Problem:
                     ws=torch.empty(self.workspace_bytes(batch), dtype=torch.uint8, device="cuda"))
 
     def solve(self, x0, bufs=None, fixed_iters=0, augmented_lagrangian=False, forced_steps=None, split_trial=None,
-              handoff=None, probe=None, counted=None, resume=False, active=None, compact_rows=None, round_bursts=None):
+              handoff=None, probe=None, counted=None, resume=False, active=None, compact_rows=None, round_bursts=None,
+              log_capacity=0, log_strategies=False, max_runtime=0.0, generic_kernels=None):
         """ilqg_solve_batch_ex. `bufs` (from alloc_solve_buffers) carries the warm start in and the solution out; zero
         warm start if omitted.  forced_steps [B][fixed_iters]: test mode, the given step sizes instead of the line
         search.  split_trial / handoff / probe / counted / compact_rows: None = let the library choose, True / False = force the
-        schedule (same results either way)."""
+        schedule (same results either way).  log_capacity > 0: every iterate of every instance is logged
+        (ilqg_iterate_log) into bufs["log"] = dict(xs, us, costs[, P, alpha], count).  max_runtime > 0: the anytime exit."""
+        import torch
         x0 = _dev(x0, self.dtype)
         B = x0.shape[0]
         if bufs is None:
@@ -231,6 +234,21 @@ class Problem:
         o.split_trial, o.handoff, o.probe, o.counted = tri(split_trial), tri(handoff), tri(probe), tri(counted)
         o.compact_rows = tri(compact_rows)
         o.round_bursts = tri(round_bursts)
+        o.generic_kernels = tri(generic_kernels)
+        o.max_runtime = float(max_runtime)
+        il = None
+        if log_capacity > 0:
+            cap = int(log_capacity)
+            log = dict(xs=self._empty(B, cap, self.T, self.n), us=self._empty(B, cap, self.T, self.m),
+                       costs=self._empty(B, cap, self.N), count=torch.zeros(B, dtype=torch.int32, device="cuda"))
+            if log_strategies:
+                log["P"] = self._empty(B, cap, self.T, self.m * self.n)
+                log["alpha"] = self._empty(B, cap, self.T, self.m)
+            il = abi.IterateLog(log["xs"].data_ptr(), log["us"].data_ptr(), log["costs"].data_ptr(),
+                                log["P"].data_ptr() if log_strategies else None,
+                                log["alpha"].data_ptr() if log_strategies else None, log["count"].data_ptr(), cap)
+            o.iterate_log = C.pointer(il)
+            bufs["log"] = log
         _check(lib().ilqg_solve_batch_ex(self.h, B, _ptr(x0), _ptr(bufs["xs"]), _ptr(bufs["us"]), _ptr(bufs["P"]),
                                          _ptr(bufs["alpha"]), _ptr(bufs["costs"]), _ptr(bufs["iters"]),
                                          _ptr(bufs["status"]), _ptr(bufs["converged"]), _ptr(bufs["ws"]), C.byref(o),

@@ -12,9 +12,12 @@
 #include <unistd.h>
 
 #include <sys/stat.h>
+#include <sys/time.h>
 #include <sys/types.h>
 
 #include <cerrno>
+#include <chrono>
+#include <cmath>
 #include <cstring>
 #include <ctime>
 #include <fstream>
@@ -690,50 +693,88 @@ ShardInfo ShardFromEnvironment() {
 }
 
 namespace {
-void SendAll(int fd, const void* p, size_t n) {
+// false = the peer went away (a stray connection must not take the process down: no SIGPIPE, no CHECK)
+bool SendAll(int fd, const void* p, size_t n) {
   const char* c = static_cast<const char*>(p);
   while (n > 0) {
-    const ssize_t w = ::send(fd, c, n, 0);
-    CHECK_GT(w, 0) << "rendezvous send: " << std::strerror(errno);
+    const ssize_t w = ::send(fd, c, n, MSG_NOSIGNAL);
+    if (w <= 0) return false;
     c += w;
     n -= size_t(w);
   }
+  return true;
 }
-void RecvAll(int fd, void* p, size_t n) {
+bool RecvAll(int fd, void* p, size_t n) {
   char* c = static_cast<char*>(p);
   while (n > 0) {
-    const ssize_t r = ::recv(fd, c, n, 0);
-    CHECK_GT(r, 0) << "rendezvous recv: " << std::strerror(errno);
+    const ssize_t r = ::recv(fd, c, n, 0);  // SO_RCVTIMEO bounds it
+    if (r <= 0) return false;
     c += r;
     n -= size_t(r);
   }
+  return true;
+}
+void SetTimeout(int fd, int seconds) {
+  timeval tv{};
+  tv.tv_sec = seconds;
+  ::setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
+  ::setsockopt(fd, SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof(tv));
+}
+// What a rank says before rank 0 hands it the token: who it is and a word only this job's ranks can form (the job's
+// launcher exports the same MASTER_PORT / WORLD_SIZE — and, if set, ILQG_RENDEZVOUS_SECRET — to every rank).
+struct Hello {
+  uint32_t magic, rank;
+  uint64_t nonce;
+};
+constexpr uint32_t kHelloMagic = 0x494c5147u;  // "ILQG"
+uint64_t JobNonce(const ShardInfo& info) {
+  std::string word = std::to_string(info.port) + ":" + std::to_string(info.world) + ":";
+  if (const char* secret = std::getenv("ILQG_RENDEZVOUS_SECRET")) word += secret;
+  uint64_t h = 1469598103934665603ull;  // FNV-1a
+  for (unsigned char ch : word) h = (h ^ ch) * 1099511628211ull;
+  return h;
 }
 }  // namespace
 
+// Rank 0 listens on MASTER_ADDR (not on every interface), answers only connections that identify themselves as a rank
+// of this job it has not served yet, and gives up after two minutes; a stray or half-open connection costs it a
+// ten-second read timeout, not the run.
 void RendezvousBroadcast(const ShardInfo& info, void* token, size_t bytes) {
   if (info.world <= 1) return;
   sockaddr_in addr{};
   addr.sin_family = AF_INET;
   addr.sin_port = htons(uint16_t(info.port));
+  CHECK_EQ(::inet_pton(AF_INET, info.master_addr.c_str(), &addr.sin_addr), 1)
+      << "MASTER_ADDR must be a dotted IPv4 address, got " << info.master_addr;
+  const uint64_t nonce = JobNonce(info);
   if (info.rank == 0) {
     const int srv = ::socket(AF_INET, SOCK_STREAM, 0);
     CHECK_GE(srv, 0) << std::strerror(errno);
     const int one = 1;
     ::setsockopt(srv, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
-    addr.sin_addr.s_addr = htonl(INADDR_ANY);
     CHECK_EQ(::bind(srv, reinterpret_cast<sockaddr*>(&addr), sizeof(addr)), 0)
-        << "rendezvous bind to port " << info.port << ": " << std::strerror(errno);
+        << "rendezvous bind to " << info.master_addr << ":" << info.port << ": " << std::strerror(errno);
     CHECK_EQ(::listen(srv, info.world), 0) << std::strerror(errno);
-    for (int r = 1; r < info.world; r++) {
+    SetTimeout(srv, 5);  // accept() wakes up to look at the clock
+    std::vector<bool> served(size_t(info.world), false);
+    int remaining = info.world - 1;
+    const auto give_up = std::chrono::steady_clock::now() + std::chrono::seconds(120);
+    while (remaining > 0) {
+      CHECK(std::chrono::steady_clock::now() < give_up) << "rendezvous: " << remaining << " rank(s) never connected";
       const int fd = ::accept(srv, nullptr, nullptr);
-      CHECK_GE(fd, 0) << std::strerror(errno);
-      SendAll(fd, token, bytes);
+      if (fd < 0) continue;  // timeout (or a connection that was reset before it was accepted)
+      SetTimeout(fd, 10);
+      Hello hello{};
+      const bool ok = RecvAll(fd, &hello, sizeof(hello)) && hello.magic == kHelloMagic && hello.nonce == nonce &&
+                      hello.rank >= 1 && hello.rank < uint32_t(info.world) && !served[hello.rank];
+      if (ok && SendAll(fd, token, bytes)) {
+        served[hello.rank] = true;
+        remaining--;
+      }
       ::close(fd);
     }
     ::close(srv);
   } else {
-    CHECK_EQ(::inet_pton(AF_INET, info.master_addr.c_str(), &addr.sin_addr), 1)
-        << "MASTER_ADDR must be a dotted IPv4 address, got " << info.master_addr;
     int fd = -1;
     for (int attempt = 0; attempt < 600; attempt++) {  // rank 0 may not be listening yet: retry for ~60 s
       fd = ::socket(AF_INET, SOCK_STREAM, 0);
@@ -744,7 +785,11 @@ void RendezvousBroadcast(const ShardInfo& info, void* token, size_t bytes) {
       ::usleep(100000);
     }
     CHECK_GE(fd, 0) << "rendezvous: no answer from " << info.master_addr << ":" << info.port;
-    RecvAll(fd, token, bytes);
+    SetTimeout(fd, 120);
+    const Hello hello{kHelloMagic, uint32_t(info.rank), nonce};
+    CHECK(SendAll(fd, &hello, sizeof(hello))) << "rendezvous send: " << std::strerror(errno);
+    CHECK(RecvAll(fd, token, bytes)) << "rendezvous: rank 0 did not answer (wrong job, or it gave up): "
+                                     << std::strerror(errno);
     ::close(fd);
   }
 }
@@ -817,9 +862,11 @@ class DeviceSolve {
 
   // `shard` (with `total` > 0): x0s is this rank's block of a sharded batch of `total` instances; after the solve the
   // per-instance results of every rank are all-gathered on the device and the BatchResult covers the whole batch.
+  // `max_runtime`: the reference's anytime budget (ilqg_solve_options::max_runtime), infinity = none.
   BatchResult Run(const std::vector<VectorXf>& x0s, const OperatingPoint& warm_op,
                   const std::vector<Strategy>& warm_strategies, bool augmented_lagrangian,
-                  bool repeat_single = false, const ShardContext* shard = nullptr, size_t total = 0) {
+                  bool repeat_single = false, const ShardContext* shard = nullptr, size_t total = 0,
+                  Time max_runtime = std::numeric_limits<Time>::infinity()) {
     size_t B = x0s.size();
     CHECK_GT(B, 0);
     const auto start = Clock::now();
@@ -862,22 +909,29 @@ class DeviceSolve {
     const bool again = repeat_single && B == 1 && solved_single_ && last_kind_ == augmented_lagrangian;
     solved_single_ = repeat_single && B == 1;
     last_kind_ = augmented_lagrangian;
-    ilqg_status s;
-    if (again)
-      s = ilqg_solve_again_batch(handle_, 1, d_x0_.get(), d_xs_.get(), d_us_.get(), d_P_.get(), d_alpha_.get(),
-                                 d_costs_.get(), static_cast<int32_t*>(d_iters_.get()),
-                                 static_cast<int32_t*>(d_status_.get()), static_cast<int32_t*>(d_conv_.get()),
-                                 d_workspace_.get(), augmented_lagrangian ? 1 : 0, nullptr, nullptr);
-    else if (augmented_lagrangian)
-      s = ilqg_al_solve_batch(handle_, static_cast<int32_t>(B), d_x0_.get(), d_xs_.get(), d_us_.get(), d_P_.get(),
-                              d_alpha_.get(), d_costs_.get(), static_cast<int32_t*>(d_iters_.get()),
-                              static_cast<int32_t*>(d_status_.get()), static_cast<int32_t*>(d_conv_.get()),
-                              d_workspace_.get(), nullptr);
-    else
-      s = ilqg_ilq_solve_batch(handle_, static_cast<int32_t>(B), d_x0_.get(), d_xs_.get(), d_us_.get(), d_P_.get(),
-                               d_alpha_.get(), d_costs_.get(), static_cast<int32_t*>(d_iters_.get()),
-                               static_cast<int32_t*>(d_status_.get()), static_cast<int32_t*>(d_conv_.get()),
-                               d_workspace_.get(), /*fixed_iters=*/0, nullptr);
+    ilqg_solve_options so;
+    ilqg_default_solve_options(&so);
+    so.augmented_lagrangian = augmented_lagrangian ? 1 : 0;
+    so.resume = again ? 1 : 0;
+    if (std::isfinite(max_runtime)) so.max_runtime = max_runtime > 0.0 ? max_runtime : 1e-9;
+    // GameSolver::Solve: every iterate of the solve goes into the log (the batched entries keep the final one)
+    const int log_cap = (repeat_single && B == 1 && shard == nullptr) ? Options().logged_iterates : 0;
+    ilqg_iterate_log il{};
+    if (log_cap > 0) {
+      const size_t es = ElemBytes(dtype_);
+      il.xs = d_log_xs_.Reserve(size_t(log_cap) * T_ * n_ * es);
+      il.us = d_log_us_.Reserve(size_t(log_cap) * T_ * m_ * es);
+      il.costs = d_log_costs_.Reserve(size_t(log_cap) * N_ * es);
+      il.P = d_log_P_.Reserve(size_t(log_cap) * T_ * m_ * n_ * es);
+      il.alpha = d_log_alpha_.Reserve(size_t(log_cap) * T_ * m_ * es);
+      il.count = static_cast<int32_t*>(d_log_count_.Reserve(4));
+      il.capacity = log_cap;
+      so.iterate_log = &il;
+    }
+    const ilqg_status s = ilqg_solve_batch_ex(
+        handle_, static_cast<int32_t>(B), d_x0_.get(), d_xs_.get(), d_us_.get(), d_P_.get(), d_alpha_.get(),
+        d_costs_.get(), static_cast<int32_t*>(d_iters_.get()), static_cast<int32_t*>(d_status_.get()),
+        static_cast<int32_t*>(d_conv_.get()), d_workspace_.get(), &so, nullptr);
     CHECK_EQ(s, ILQG_OK) << ilqg_last_error();
     HipCheck(hipDeviceSynchronize(), "solve");
 
@@ -950,25 +1004,52 @@ class DeviceSolve {
     }
     const Time elapsed = std::chrono::duration<Time>(Clock::now() - start).count();
 
-    BatchResult result;
-    for (size_t b = 0; b < B; b++) {
-      OperatingPoint op(warm_op);
-      std::vector<Strategy> strategies(warm_strategies);
+    // one logged iterate out of flat (instance-major) host arrays
+    auto unpack = [&](const std::vector<float>& fxs, const std::vector<float>& fus, const std::vector<float>& fP,
+                      const std::vector<float>& fal, size_t b, OperatingPoint* op, std::vector<Strategy>* strategies) {
       for (int k = 0; k < T_; k++) {
-        std::memcpy(op.xs[k].data(), &xs[(b * T_ + k) * n_], n_ * sizeof(float));
+        std::memcpy(op->xs[k].data(), &fxs[(b * T_ + k) * n_], n_ * sizeof(float));
         int row = 0;
         for (int i = 0; i < N_; i++) {
-          std::memcpy(op.us[k][i].data(), &us[(b * T_ + k) * m_ + row], udims_[i] * sizeof(float));
-          std::memcpy(strategies[i].alphas[k].data(), &alpha[(b * T_ + k) * m_ + row], udims_[i] * sizeof(float));
+          std::memcpy(op->us[k][i].data(), &fus[(b * T_ + k) * m_ + row], udims_[i] * sizeof(float));
+          std::memcpy((*strategies)[i].alphas[k].data(), &fal[(b * T_ + k) * m_ + row], udims_[i] * sizeof(float));
           for (int c = 0; c < n_; c++)
             for (int r = 0; r < udims_[i]; r++)
-              strategies[i].Ps[k](r, c) = P[((b * T_ + k) * n_ + c) * m_ + row + r];
+              (*strategies)[i].Ps[k](r, c) = fP[((b * T_ + k) * n_ + c) * m_ + row + r];
           row += udims_[i];
         }
       }
+    };
+    BatchResult result;
+    for (size_t b = 0; b < B; b++) {
       auto log = std::make_shared<SolverLog>();
-      log->AddSolverIterate(op, strategies, std::vector<float>(costs.begin() + b * N_, costs.begin() + (b + 1) * N_),
-                            elapsed, conv[b] != 0);
+      int logged = 0, produced = 0;
+      if (log_cap > 0) {
+        // the iterates the device copied (slot q = the q-th AddSolverIterate of the reference's log); cumulative
+        // run times are the call's wall time spread evenly — the device loop has no per-iteration host clock
+        produced = DownloadInts(d_log_count_, 1)[0];
+        logged = std::min(produced, log_cap);
+        const std::vector<float> lxs = Download(d_log_xs_, size_t(logged) * T_ * n_, dtype_);
+        const std::vector<float> lus = Download(d_log_us_, size_t(logged) * T_ * m_, dtype_);
+        const std::vector<float> lP = Download(d_log_P_, size_t(logged) * T_ * m_ * n_, dtype_);
+        const std::vector<float> lal = Download(d_log_alpha_, size_t(logged) * T_ * m_, dtype_);
+        const std::vector<float> lc = Download(d_log_costs_, size_t(logged) * N_, dtype_);
+        for (int q = 0; q < logged; q++) {
+          OperatingPoint op(warm_op);
+          std::vector<Strategy> strategies(warm_strategies);
+          unpack(lxs, lus, lP, lal, size_t(q), &op, &strategies);
+          const bool last = q + 1 == produced;
+          log->AddSolverIterate(op, strategies, std::vector<float>(lc.begin() + q * N_, lc.begin() + (q + 1) * N_),
+                                produced > 1 ? elapsed * q / (produced - 1) : elapsed, last && conv[b] != 0);
+        }
+      }
+      if (logged == 0 || logged < produced) {  // no log asked for, or it overflowed: the final iterate from the solve's outputs
+        OperatingPoint op(warm_op);
+        std::vector<Strategy> strategies(warm_strategies);
+        unpack(xs, us, P, alpha, b, &op, &strategies);
+        log->AddSolverIterate(op, strategies, std::vector<float>(costs.begin() + b * N_, costs.begin() + (b + 1) * N_),
+                              elapsed, conv[b] != 0);
+      }
       log->SetDeviceIterations(iters[b]);
       result.logs.push_back(log);
       result.success.push_back(status[b] != 0);
@@ -985,6 +1066,7 @@ class DeviceSolve {
   std::vector<int> udims_;
   bool solved_single_ = false, last_kind_ = false;
   DeviceBuffer d_x0_, d_xs_, d_us_, d_P_, d_alpha_, d_costs_, d_iters_, d_status_, d_conv_, d_workspace_;
+  DeviceBuffer d_log_xs_, d_log_us_, d_log_costs_, d_log_P_, d_log_alpha_, d_log_count_;
 };
 
 }  // namespace host
@@ -1208,6 +1290,17 @@ VectorXf MultiPlayerIntegrableSystem::Integrate(Time t0, Time t, const VectorXf&
 void Problem::SetUpNextRecedingHorizon(const VectorXf& x0, Time t0, Time planner_runtime) {
   using namespace host;
   CHECK(initialized_);
+  // RouteProgressCost subtracts the window's start time from the time it is handed (src/route_progress_cost.cpp:58,
+  // reset by src/problem.cpp:120); the device tabulates its per-step nominals once, for initial time 0
+  // (ilqg_problem_create), so a re-anchored problem would diverge from the reference: refused here as the C ABI's
+  // receding-horizon entry points refuse it.
+  for (const PlayerCost& pc : player_costs_)
+    for (const auto& cost : pc.StateCosts()) {
+      TermDescription td;
+      const bool known = cost->Describe(&td);
+      CHECK(!(known && td.term.kind == ILQG_COST_ROUTE_PROGRESS))
+          << "SetUpNextRecedingHorizon: RouteProgressCost is only supported in a first solve (initial time 0)";
+    }
   const ilqg_dtype dtype = Options().dtype;
   const int n = dynamics_->XDim(), m = dynamics_->TotalUDim(), N = dynamics_->NumPlayers();
   const int T = static_cast<int>(time::kNumTimeSteps);
@@ -1568,7 +1661,9 @@ std::vector<std::shared_ptr<const SolverLog>> RecedingHorizonSimulator(Time fina
     problem.OverwriteSolution(splicer.CurrentOperatingPoint(), splicer.CurrentStrategies());
     problem.SetUpNextRecedingHorizon(x, t, planner_runtime);
     const auto call_time = Clock::now();
-    logs.push_back(solver->Solve(&success, planner_runtime));
+    // a fixed simulated solve time asks for reproducible runs: no wall-clock budget inside the solve then either
+    logs.push_back(solver->Solve(&success, fixed_solve_time >= 0.0 ? std::numeric_limits<Time>::infinity()
+                                                                    : planner_runtime));
     Time elapsed = std::chrono::duration<Time>(Clock::now() - call_time).count();
     if (fixed_solve_time >= 0.0) elapsed = fixed_solve_time;  // deterministic runs (host::DeviceOptions)
     // receding_horizon_simulator.cpp:119 CHECKs elapsed <= planner_runtime, which the reference's anytime exit
@@ -1618,7 +1713,7 @@ std::vector<ActiveProblem> MinimallyInvasiveRecedingHorizonSimulator(
   const auto timed_solve = [&](GameSolver* solver, std::vector<std::shared_ptr<const SolverLog>>* logs, bool first) {
     const auto call_time = Clock::now();
     bool success = false;
-    logs->push_back(first ? solver->Solve(&success) : solver->Solve(&success, planner_runtime));
+    logs->push_back((first || fixed_solve_time >= 0.0) ? solver->Solve(&success) : solver->Solve(&success, planner_runtime));
     if (first) CHECK(success);
     const Time elapsed = std::chrono::duration<Time>(Clock::now() - call_time).count();
     return fixed_solve_time >= 0.0 ? fixed_solve_time : elapsed;
@@ -1705,26 +1800,26 @@ host::BatchResult GameSolver::SolveBatchSharded(const std::vector<VectorXf>& x0s
                       /*repeat_single=*/false, &shard, x0s.size());
 }
 
-host::BatchResult GameSolver::SolveOne() {
+host::BatchResult GameSolver::SolveOne(Time max_runtime) {
   RefreshDevice();
   return device_->Run({problem_->InitialState()}, problem_->CurrentOperatingPoint(), problem_->CurrentStrategies(),
-                      augmented_lagrangian_, /*repeat_single=*/true);
+                      augmented_lagrangian_, /*repeat_single=*/true, nullptr, 0, max_runtime);
 }
 
-// `max_runtime` (the reference's wall-clock anytime exit, src/ilq_solver.cpp:101-104) is not
-// reproduced: the loop runs on the device to its iteration bounds (SolverParams::max_solver_iters).  The
-// receding-horizon simulators below therefore treat a solve that overran its budget as one that returned AT its
-// deadline (the reference's would have, with an earlier iterate) instead of CHECK-failing on the clock.
+// `max_runtime` is the reference's wall-clock anytime exit (src/ilq_solver.cpp:123-124; per inner solve of a
+// constrained problem max_runtime / max_solver_iters, src/augmented_lagrangian_solver.cpp:85-88): the device loop
+// leaves at the first iteration boundary at which the host's clock says the next iteration no longer fits
+// (ilqg_solve_options::max_runtime).  Infinity (the default) runs to the iteration bounds.  The receding-horizon
+// simulators below still treat a solve that overran its budget as one that returned AT its deadline instead of
+// CHECK-failing on the clock: a round of the device loop cannot be interrupted.
 std::shared_ptr<SolverLog> ILQSolver::Solve(bool* success, Time max_runtime) {
-  (void)max_runtime;
-  host::BatchResult r = SolveOne();
+  host::BatchResult r = SolveOne(max_runtime);
   if (success != nullptr) *success = r.success[0];
   return r.logs[0];
 }
 
 std::shared_ptr<SolverLog> AugmentedLagrangianSolver::Solve(bool* success, Time max_runtime) {
-  (void)max_runtime;
-  host::BatchResult r = SolveOne();
+  host::BatchResult r = SolveOne(max_runtime);
   if (success != nullptr) *success = r.success[0];
   return r.logs[0];
 }

@@ -70,8 +70,11 @@ typedef struct {
   int32_t dtype;                  /* ilqg_dtype                           */
   int32_t adaptive_regularization;/* Gershgorin step of lq_feedback_solver.cpp:163-176 */
   int32_t sweep_formulation;      /* ilqg_choice: ILQG_CHOICE_OFF selects the VALU / LDS formulation of the feedback sweep
-                                     where the matrix-core one is the default (n <= 16); same results (A/B runs) */
+                                     where the matrix-core one is the default (n <= 16); ILQG_SWEEP_GENERIC the
+                                     run-time-dimensioned kernels every shape without a specialised instantiation runs
+                                     on anyway; same results (A/B runs) */
 } ilqg_dims;
+#define ILQG_SWEEP_GENERIC 3
 
 /* A scheduling choice that does not change results: let the library decide, or force it off / on. */
 typedef enum { ILQG_CHOICE_AUTO = 0, ILQG_CHOICE_OFF = 1, ILQG_CHOICE_ON = 2 } ilqg_choice;
@@ -96,6 +99,9 @@ typedef enum { ILQG_CHOICE_AUTO = 0, ILQG_CHOICE_OFF = 1, ILQG_CHOICE_ON = 2 } i
  *  costates [B][T][N][n] or NULL  -Z_i[k+1] dx_k - zeta_i[k+1], zero at T-1 (lq_feedback_solver.cpp:223-227);
  *                                needs dx (the reference CHECKs the pair, :77-78): ILQG_ERR_INVALID otherwise
  *  Entry T-1 of P/alpha is written as zero (strategy.h:64-70; loop starts at T-2).
+ *  Any dimensions within ILQG_MAX_XDIM / ILQG_MAX_PLAYERS / ILQG_MAX_UDIM_TOTAL run, players with different control
+ *  dimensions included (src/lq_feedback_solver.cpp:118-160 walks cumulative dimensions): the shapes of the reference's
+ *  examples have specialised kernels (matrix cores, LDS-DMA staging), everything else the run-time-dimensioned ones.
  */
 ilqg_status ilqg_lq_feedback_batch(const ilqg_dims* d, const void* A,
                                    const void* Bm, const void* Q, const void* l,
@@ -395,8 +401,33 @@ typedef struct {
   int32_t counted;              /* ilqg_choice: host counts the rounds of a fixed-iteration solve as well           */
   int32_t compact_rows;         /* ilqg_choice: the row stage hands the sweep only the touched words of [Q|l|R|r]   */
   int32_t round_bursts;         /* ilqg_choice: free-running solves read their counters back once per burst of rounds */
-  int32_t reserved[4];
+  int32_t generic_kernels;      /* ilqg_choice: ILQG_CHOICE_ON runs the run-time-dimensioned kernels (what every shape
+                                     without a specialised instantiation runs on) for this problem too */
+  int32_t reserved[3];
+  const struct ilqg_iterate_log* iterate_log; /* NULL, or where every logged iterate of the solve goes (below)          */
+  double max_runtime;           /* > 0: the anytime exit of ILQSolver::Solve (src/ilq_solver.cpp:123-124) on the host's
+                                     clock, seconds — once it has passed, instances leave the loop at their next
+                                     iteration boundary with success = 1 and the iterate they hold (a line search in
+                                     flight is finished first, as there).  <= 0: run to the iteration bounds.  Needs a
+                                     free-running solve (fixed_iters = 0, no forced steps); with the augmented-Lagrangian
+                                     loop the budget ends the inner solve in flight and the outer loop with it. */
 } ilqg_solve_options;
+
+/* What SolverLog::AddSolverIterate receives per iterate (include/ilqgames/utils/solver_log.h:65-74: the reference deep-
+ * copies operating point, strategies and total costs at src/ilq_solver.cpp:111 and :164).  On the device the copies are
+ * optional: a solve given a log writes iterate q of instance b — q = 0 is the initial rollout, then one per accepted
+ * step; with the augmented-Lagrangian loop the iterates of successive inner solves follow one another as in
+ * src/augmented_lagrangian_solver.cpp:94,185 — to slot q of that instance while q < capacity, and counts them.
+ * All arrays are device memory in the problem's dtype. */
+typedef struct ilqg_iterate_log {
+  void* xs;       /* [B][capacity][T][n]                                                         */
+  void* us;       /* [B][capacity][T][m]                                                         */
+  void* costs;    /* [B][capacity][N]     ILQSolver::TotalCosts of the iterate                    */
+  void* P;        /* [B][capacity][T][m*n] or NULL: the strategies the iterate was played with    */
+  void* alpha;    /* [B][capacity][T][m] or NULL (alpha carries the accepted step, as logged)     */
+  int32_t* count; /* [B] out: iterates the solve produced (may exceed capacity: those were dropped) */
+  int32_t capacity;
+} ilqg_iterate_log;
 void ilqg_default_solve_options(ilqg_solve_options* o);
 
 /* ilqg_ilq_solve_batch / ilqg_al_solve_batch / ilqg_solve_again_batch are this call with the matching options. */
@@ -550,7 +581,9 @@ const char* ilqg_last_error(void);
 ilqg_status ilqg_set_scratch(void* device_buffer, size_t bytes);
 
 /* Library / device introspection (used by the loader to fail loudly). */
-#define ILQG_ABI_VERSION 4 /* 4: ilqg_cost_term::idx_extra / value2, cost kinds 12-21, dynamics kinds 10-12;
+#define ILQG_ABI_VERSION 5 /* 5: ilqg_solve_options::iterate_log / max_runtime, run-time-dimensioned kernels behind every entry
+                              point (any n <= 32, N <= 8, m_i), the affine constraints (ilqg_problem_desc::dense_params);
+                              4: ilqg_cost_term::idx_extra / value2, cost kinds 12-21, dynamics kinds 10-12;
                               3: ilqg_solve_options / ilqg_solve_batch_ex / ilqg_solve_state_batch, ilqg_dims::sweep_formulation;
                               the workspace holds every device buffer a solve uses */
 int32_t ilqg_abi_version(void);

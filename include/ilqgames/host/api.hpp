@@ -1006,6 +1006,11 @@ struct DeviceOptions {
   // RecedingHorizonSimulator: time charged per solver call.  Negative = the wall clock, as the reference does
   // (src/receding_horizon_simulator.cpp:110-114); a fixed value makes runs reproducible.
   Time simulated_solve_time = -1.0;
+  // GameSolver::Solve keeps the iterates of the solve in its SolverLog as the reference does (src/ilq_solver.cpp:111,
+  // 164: one AddSolverIterate per accepted step) — copied on the device into an ilqg_iterate_log of this many
+  // slots per solve; iterates past it are dropped and the final one is appended.  0 = the final iterate only.
+  // SolveBatch logs the final iterate of each instance.
+  int logged_iterates = 64;
 };
 DeviceOptions& Options();
 
@@ -1151,7 +1156,7 @@ class GameSolver {
  protected:
   GameSolver(const std::shared_ptr<Problem>& problem, const SolverParams& params, bool augmented_lagrangian);
   virtual std::shared_ptr<SolverLog> CreateNewLog() const { return std::make_shared<SolverLog>(); }
-  host::BatchResult SolveOne();  // Solve(): one instance; a repeated call continues this solver object's state
+  host::BatchResult SolveOne(Time max_runtime = std::numeric_limits<Time>::infinity());  // Solve(): one instance; a repeated call continues this solver object's state
   void RefreshDevice();          // (re)builds the device tables when the Problem / SolverParams no longer match them
   const std::shared_ptr<Problem> problem_;
   const SolverParams params_;

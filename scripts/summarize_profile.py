@@ -96,8 +96,10 @@ try:
             short = mm.group(1) if mm else nm[:40]
             tr.setdefault(short, {})[cname] = statistics.median(r[2] for r in sel) * 1024.0
     total = sum(2.0 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0) for v in tr.values())
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench  # csrc_sha16: which kernels these passes ran on (profiles/traffic.json entries carry it)
     out.append("\n## HBM traffic per round (2 x FETCH_SIZE + WRITE_SIZE over the round's kernels, profiles/r03_counter_calibration.md)\n\n```json\n%s\n```"
-               % json.dumps({"bytes_per_round": total, "per_kernel_bytes": tr}, indent=1))
+               % json.dumps({"bytes_per_round": total, "per_kernel_bytes": tr, "csrc_sha16": bench.csrc_sha16()}, indent=1))
 except Exception as e:  # a pass that did not run leaves the section out
     out.append("\n(traffic per round not computed: %r)" % (e,))
 for f in ("bench_plain.log",):

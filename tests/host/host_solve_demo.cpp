@@ -4,6 +4,7 @@
 // AugmentedLagrangianSolver, and runs one LQ game through LQFeedbackSolver / LQOpenLoopSolver.
 // Everything is written to <outdir>/ as text; tests/test_host_mirror.py replays the same inputs
 // through the CPU oracle and compares.
+#include <cstdlib>
 #include <ilqgames/constraint/proximity_constraint.h>
 #include <ilqgames/cost/proximity_cost.h>
 #include <ilqgames/cost/quadratic_cost.h>
@@ -296,6 +297,36 @@ int main(int argc, char** argv) {
     std::ofstream os(outdir + "/ilq_single.txt");
     os << std::setprecision(9) << "x0 " << problem->InitialState() << "\n";
     WriteLog(os, *log, success);
+
+    // SolverLog on disk, from a log the device produced: every iterate of the solve (src/solver_log.cpp:113-171)
+    // and the SaveLogs form (last trajectory only, :208-240)
+    setenv("ILQGAMES_LOG_DIR", outdir.c_str(), 1);
+    CHECK(log->Save(false, "ilq_single_log"));
+    CHECK(SaveLogs(std::vector<std::shared_ptr<const SolverLog>>{log}, true, "ilq_single_last"));
+    std::ofstream(outdir + "/ilq_single_log_meta.txt") << "iterates " << log->NumIterates() << " device_iterations "
+                                                        << log->DeviceIterations() << "\n";
+
+    // the anytime exit (src/ilq_solver.cpp:123-124): a budget no iteration fits in returns iterate 0 with success
+    {
+      auto timed_problem = std::make_shared<MergeScene>(false);
+      timed_problem->Initialize();
+      ILQSolver timed(timed_problem, params);
+      bool timed_success = false;
+      const std::shared_ptr<SolverLog> timed_log = timed.Solve(&timed_success, 1e-6);
+      std::ofstream od(outdir + "/ilq_deadline.txt");
+      od << std::setprecision(9) << "x0 " << timed_problem->InitialState() << "\n";
+      od << "iterates " << timed_log->NumIterates() << "\n";
+      WriteLog(od, *timed_log, timed_success);
+      // ... and a generous one changes nothing
+      auto relaxed_problem = std::make_shared<MergeScene>(false);
+      relaxed_problem->Initialize();
+      ILQSolver relaxed(relaxed_problem, params);
+      bool relaxed_success = false;
+      const std::shared_ptr<SolverLog> relaxed_log = relaxed.Solve(&relaxed_success, 3600.0);
+      std::ofstream orx(outdir + "/ilq_relaxed.txt");
+      orx << std::setprecision(9) << "x0 " << relaxed_problem->InitialState() << "\n";
+      WriteLog(orx, *relaxed_log, relaxed_success);
+    }
 
     // receding horizon: adopt the solution, re-sync to a measured state 0.33 s into the plan
     {

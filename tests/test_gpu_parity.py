@@ -40,9 +40,11 @@ def test_mfma_tile_layout(hip, dtype):
                           Y.astype(np.float32 if dtype == abi.F32 else np.float64))
 
 
-@pytest.mark.parametrize("name", ["lq_feedback_unicycle.npz", "lq_feedback_pointmass.npz"])
+@pytest.mark.parametrize("name", ["lq_feedback_random.npz", "lq_feedback_unicycle.npz", "lq_feedback_pointmass.npz"])
 def test_lq_feedback_matches_reference_python_golden(hip, name):
-    """Device sweep vs the reference's own numpy solver (fixtures of tests/golden/make_golden.py)."""
+    """Device sweep vs the reference's own numpy solver (fixtures of tests/golden/make_golden.py) — every fixture:
+    lq_feedback_random.npz has n = 5 and control dimensions (2, 1, 2), a shape the run-time-dimensioned kernels take
+    (ilqg_lq_generic.hpp); the other two run on their specialised instantiations."""
     g = load_golden_lq(name)
     d = dims_of(g, abi.F64, adaptive=False)
     P, alpha, _ = hip.lq_feedback(d, g["A"], g["Bm"], g["Q"], g["l"], g["R"], g["r"], g["pairs"])
@@ -202,7 +204,7 @@ def test_lq_feedback_errors(hip):
     with pytest.raises(hip.IlqgError) as e:
         hip.lq_feedback(dims_of(g, abi.F64), g["A"], g["Bm"], g["Q"], g["l"], g["R"], g["r"], g["pairs"])
     assert e.value.status == abi.ERR_INVALID
-    g = random_lq_game(rng, 7, [2, 2], 5, 1)  # no kernel for n=7
+    g = random_lq_game(rng, 33, [2, 2], 5, 1)  # past ILQG_MAX_XDIM (any n <= 32 runs: tests/test_gpu_generic.py)
     with pytest.raises(hip.IlqgError) as e:
         hip.lq_feedback(dims_of(g, abi.F64), g["A"], g["Bm"], g["Q"], g["l"], g["R"], g["r"], g["pairs"])
     assert e.value.status == abi.ERR_UNSUPPORTED
@@ -276,10 +278,15 @@ def test_problem_create_rejects_dynamics_the_kernels_do_not_cover(hip):
         assert e.value.status == abi.ERR_UNSUPPORTED, kinds
         assert str(e.value)
     hip.Problem(spec_of((abi.DYN_POINT_MASS_2D, abi.DYN_POINT_MASS_2D)), abi.F64)  # the covered case builds
-    # the plain-RK4 models only build in the instantiations that carry that integrator: (10,2,2) exists, without it
-    with pytest.raises(hip.IlqgError) as e:
-        hip.Problem(spec_of((abi.DYN_UNICYCLE_5D, abi.DYN_UNICYCLE_5D)), abi.F64)
-    assert e.value.status == abi.ERR_UNSUPPORTED and "plain RK4" in str(e.value)
+    # the plain-RK4 models in a shape whose instantiation does not carry that integrator ((10,2,2) exists, without it)
+    # run on the run-time-dimensioned kernels, which pick the integrator from the models
+    s5 = spec_of((abi.DYN_UNICYCLE_5D, abi.DYN_UNICYCLE_5D))
+    p5 = hip.Problem(s5, abi.F64)
+    x0 = np.array([[0.0, 0.0, 0.3, 2.0, 0.0, 3.0, 1.0, -0.2, 1.5, 0.0]])
+    z = lambda *shape: np.zeros(shape)  # noqa: E731
+    us_ref = 0.1 * np.ones((1, 10, 4))
+    xs, _ = p5.rollout(x0, z(1, 10, 10), us_ref, z(1, 10, 40), z(1, 10, 4))
+    assert np.all(np.isfinite(_np(xs))) and abs(float(_np(xs)[0, -1, 0])) > 1.0  # it moved
     # a time-dependent cost anywhere but among a player's state costs; speed indices outside the state
     s = spec_of((abi.DYN_CAR_5D, abi.DYN_CAR_5D))
     s.terms.append(dict(s.terms[0], kind=abi.COST_NOMINAL_PATH_LENGTH, idx=(0, 0, 0, 0)))  # a copy of a control cost

@@ -272,6 +272,75 @@ def test_cpp_ilq_solver_single_solve_matches_oracle(demo_out, oracle):
 
 
 @pytest.mark.gpu
+def test_cpp_device_produced_solver_log_on_disk_matches_oracle_iterates(demo_out, oracle):
+    """SURVEY 8(f) item 3 end to end: the log of a solve that ran on the device — every iterate, copied by the device
+    into an ilqg_iterate_log — is written by SolverLog::Save in the reference's layout (src/solver_log.cpp:113-171:
+    <dir>/<experiment>/<iterate>/{t0,xs,u<i>,costs,cumulative_runtimes}.txt), read back from disk and compared with
+    the oracle's iterates: iterate 0 is the initial rollout (src/ilq_solver.cpp:100-112), iterate q the operating
+    point after q outer iterations.  The files hold six significant digits (Eigen's default stream precision)."""
+    got = _parse_log(os.path.join(demo_out, "ilq_single.txt"))
+    spec = abi.ProblemSpec.from_dump(open(os.path.join(demo_out, "scene.txt")).read())
+    O = oracle.OracleProblem(spec)
+    meta = open(os.path.join(demo_out, "ilq_single_log_meta.txt")).read().split()
+    iterates, device_iterations = int(meta[1]), int(meta[3])
+    assert iterates == device_iterations + 1 == got["iters"] + 1 and iterates >= 3
+    base = os.path.join(demo_out, "ilq_single_log")
+    assert sorted(os.listdir(base), key=int) == [str(q) for q in range(iterates)]
+    x0 = got["x0"][None, :]
+    udims = [sub[2] for sub in spec.subsystems]
+    for q in range(iterates):
+        d = os.path.join(base, str(q))
+        assert sorted(os.listdir(d)) == sorted(["t0.txt", "xs.txt", "costs.txt", "cumulative_runtimes.txt"] +
+                                               ["u%d.txt" % i for i in range(len(udims))])
+        if q == 0:  # the warm start (zero strategies about a zero operating point) played from x0
+            z = lambda *shape: np.zeros(shape)  # noqa: E731
+            xs, us = O.rollout(abi.F64, x0, z(1, spec.T, spec.n), z(1, spec.T, spec.m), z(1, spec.T, spec.m * spec.n),
+                               z(1, spec.T, spec.m))
+            costs, _ = O.total_costs(abi.F64, xs, us)
+        else:
+            ref = O.solve(abi.F64, x0, fixed_iters=q)
+            xs, us, costs = ref["xs"], ref["us"], ref["costs"]
+        scale = max(1.0, np.max(np.abs(xs)))
+        assert np.max(np.abs(np.loadtxt(os.path.join(d, "xs.txt")) - xs[0])) < 2e-5 * scale, q
+        off = 0
+        for i, mi in enumerate(udims):
+            ui = np.loadtxt(os.path.join(d, "u%d.txt" % i)).reshape(spec.T, mi)
+            assert np.max(np.abs(ui - us[0][:, off:off + mi])) < 2e-5 * max(1.0, np.max(np.abs(us))), (q, i)
+            off += mi
+        np.testing.assert_allclose(np.loadtxt(os.path.join(d, "costs.txt")), costs[0], rtol=2e-5)
+        assert float(open(os.path.join(d, "t0.txt")).read()) == 0.0
+    # the last iterate on disk is the solve's result; SaveLogs keeps only that one
+    last = os.path.join(demo_out, "ilq_single_last", "0")
+    assert os.listdir(last) == [str(iterates - 1)]
+    assert open(os.path.join(last, str(iterates - 1), "xs.txt")).read() == \
+        open(os.path.join(base, str(iterates - 1), "xs.txt")).read()
+    assert np.max(np.abs(np.loadtxt(os.path.join(base, str(iterates - 1), "xs.txt")) - got["xs"])) < \
+        2e-5 * max(1.0, np.max(np.abs(got["xs"])))
+
+
+@pytest.mark.gpu
+def test_cpp_solve_honours_max_runtime_like_the_reference_loop(demo_out, oracle):
+    """ILQSolver::Solve(success, max_runtime) (src/ilq_solver.cpp:123-124): with a budget no iteration fits in
+    (elapsed = 0 is not below 1e-6 - RuntimeUpperBound()) the loop body never runs — the log holds iterate 0, the
+    call reports success; with a generous budget the solve is the unbudgeted one."""
+    lines = open(os.path.join(demo_out, "ilq_deadline.txt")).read().splitlines()
+    assert lines[1].split() == ["iterates", "1"]
+    got = _parse_log(os.path.join(demo_out, "ilq_deadline.txt"))
+    assert got["success"] == 1 and got["converged"] == 0 and got["iters"] == 0
+    spec = abi.ProblemSpec.from_dump(open(os.path.join(demo_out, "scene.txt")).read())
+    O = oracle.OracleProblem(spec)
+    z = lambda *shape: np.zeros(shape)  # noqa: E731
+    xs, us = O.rollout(abi.F64, got["x0"][None, :], z(1, spec.T, spec.n), z(1, spec.T, spec.m),
+                       z(1, spec.T, spec.m * spec.n), z(1, spec.T, spec.m))
+    assert np.max(np.abs(got["xs"] - xs[0])) < 2e-4 * max(1.0, np.max(np.abs(xs)))
+    assert np.max(np.abs(got["alpha"])) == 0.0
+    relaxed = _parse_log(os.path.join(demo_out, "ilq_relaxed.txt"))
+    plain = _parse_log(os.path.join(demo_out, "ilq_single.txt"))
+    assert relaxed["iters"] == plain["iters"] and relaxed["success"] == plain["success"]
+    assert np.array_equal(relaxed["xs"], plain["xs"]) and np.array_equal(relaxed["alpha"], plain["alpha"])
+
+
+@pytest.mark.gpu
 def test_cpp_receding_horizon_resync_matches_oracle(demo_out, oracle):
     """Problem::SetUpNextRecedingHorizon through the C++ mirror (float containers, fp64 device) against the
     oracle's restatement applied to the same solved plan."""
