@@ -104,9 +104,13 @@ class HipBackend:
         return self.prob.alloc_solve_buffers(B)
 
     counted = None  # ilqg_solve_options::counted: None = the library's choice (an asynchronous launch sequence)
+    probe_first = 0  # ilqg_solve_options::probe_first: 0 = the library's choice
+    single_wave = None  # ilqg_solve_options::single_wave_sweep: None = the library's choice
+    split_trial = None  # ilqg_solve_options::split_trial: None = the library's choice
 
     def solve(self, x0, bufs, iters):
-        self.prob.solve(x0, bufs, fixed_iters=iters, counted=self.counted)
+        self.prob.solve(x0, bufs, fixed_iters=iters, counted=self.counted, probe_first=self.probe_first,
+                        single_wave_sweep=self.single_wave, split_trial=self.split_trial)
 
     def sync(self):
         self.torch.cuda.synchronize()
@@ -210,6 +214,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true",
                     help="skip the single-instance ms/solve figure (profiling runs: keeps the kernel statistics to the batch)")
+    ap.add_argument("--single-wave", choices=["auto", "on", "off"], default="auto",
+                    help="ilqg_solve_options::single_wave_sweep (A/B measurements)")
+    ap.add_argument("--split-trial", choices=["auto", "on", "off"], default="auto",
+                    help="ilqg_solve_options::split_trial (A/B measurements)")
+    ap.add_argument("--probe-first", type=int, default=0,
+                    help="ilqg_solve_options::probe_first (A/B measurements of the speculative line search's ramp)")
     ap.add_argument("--no-second-workload", action="store_true",
                     help="skip the back-tracking workload reported beside the headline (three_player_intersection, n = 16)")
     ap.add_argument("--cpu-sample", type=int, default=64,
@@ -232,6 +242,9 @@ def main():
     elem = 8 if dtype == abi.F64 else 4
     spec, params_desc = _bench_spec(examples, args.config, args.linesearch)
     backend = (HipBackend if args.backend == "hip" else StubBackend)(spec, dtype, local_rank)
+    backend.probe_first = args.probe_first
+    backend.single_wave = {"auto": None, "on": True, "off": False}[args.single_wave]
+    backend.split_trial = {"auto": None, "on": True, "off": False}[args.split_trial]
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -293,7 +293,7 @@ inline WsTail ws_tail(const DevProblem& d, int batch, size_t elem, int ol_row) {
   t.pool_off = up(t.ids_off + size_t(2) * batch * sizeof(int));
   // eight candidates per instance up to kProbeEntries, and never fewer than two full rounds' worth for a single
   // instance (a lone instance in a failing line search walks through all its step sizes: 32 a round, not 8)
-  t.pool_entries = batch * 8 < kProbeEntries ? batch * 8 : kProbeEntries;
+  t.pool_entries = batch * 16 < kProbeEntries ? batch * 16 : kProbeEntries;
   if (t.pool_entries < 2 * kProbeCandidates) t.pool_entries = 2 * kProbeCandidates;
   t.total = up(t.pool_off + size_t(t.pool_entries) * ProbeEntry(d.n, d.m, d.N, d.T).total * elem);
   return t;
@@ -450,9 +450,11 @@ __global__ void __launch_bounds__(64) ilq_exit_kernel(DevProblem p, SolveArgs<T>
 // sweep is three registers over that by itself, and at batches of many instances per CU a fifth resident instance is
 // worth more than the two spilled registers cost (n = 14 fp32, B = 8192: 2.15 M vs 2.04 M it/s; B = 1024, where only
 // four instances per CU exist: 1.81 M vs 1.85 M — so the launcher picks it for large batches only).
+// KIND LQ_SINGLE_WAVE: one wave per instance (ilqg_lq_feedback1w.hpp), compiled for as many waves per SIMD as its LDS
+// lets a CU hold instances (fp64: 20 KB -> eight per CU, two per SIMD; fp32: 10 KB -> sixteen, four per SIMD).
 template <typename T, int NX, int NP, int MU, int KIND>
-__global__ void __launch_bounds__((KIND == LQ_VALU_FEEDBACK ? LQCfg<T, NX, NP, MU>::NT : ((KIND == LQ_OPEN_LOOP || KIND == LQ_OPEN_LOOP_COMPACT) ? OLCfg<T, NX, NP, MU>::NT : 64 * NP)),
-                                  (KIND == LQ_PLAYER_WAVES_PACKED ? 4 : KIND == LQ_PLAYER_WAVES ? (NX <= 16 ? NP : 2) : ((KIND == LQ_OPEN_LOOP || KIND == LQ_OPEN_LOOP_COMPACT) ? 3 : 1)))
+__global__ void __launch_bounds__((KIND == LQ_SINGLE_WAVE ? 64 : KIND == LQ_VALU_FEEDBACK ? LQCfg<T, NX, NP, MU>::NT : ((KIND == LQ_OPEN_LOOP || KIND == LQ_OPEN_LOOP_COMPACT) ? OLCfg<T, NX, NP, MU>::NT : 64 * NP)),
+                                  (KIND == LQ_SINGLE_WAVE ? (sizeof(T) == 4 ? 4 : 2) : KIND == LQ_PLAYER_WAVES_PACKED ? 4 : KIND == LQ_PLAYER_WAVES ? (NX <= 16 ? NP : 2) : ((KIND == LQ_OPEN_LOOP || KIND == LQ_OPEN_LOOP_COMPACT) ? 3 : 1)))
 ilq_lq_kernel(DevProblem p, SolveArgs<T> sa) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int b = blockIdx.x;
@@ -737,7 +739,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   // decrease is handed over in (n = 24: 54 KB, three instances per CU; the feedback layout would take 85 KB)
   size_t lq_elems = (C::USE_MFMA && !p->desc.params.open_loop) ? MfmaSweepLds<T, NX, NP, MU>::ELEMS + (C::MFMA_ONE_TILE ? 0 : 4) : C::LDS_ELEMS;
   if (p->desc.params.open_loop) lq_elems = OLCfg<T, NX, NP, MU>::LDS_ELEMS + 4;
-  const size_t lds_lq = lq_elems * sizeof(T);
+  const size_t lds_lq_multi = lq_elems * sizeof(T);
   // Rows per chunk of the row stage: the widest whose scratch lets a CU hold four instances of the fused trial kernel
   // (the headline batch is four instances per CU); the split row kernels get the same width.
   {
@@ -759,13 +761,12 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   // fp32, one-tile sweep of three player waves, many instances per CU: the 128-register build (see ilq_lq_kernel)
   constexpr bool has_packed = sizeof(T) == 4 && C::USE_MFMA && C::MFMA_ONE_TILE && NP == 3;
   const bool packed = has_packed && pw && size_t(batch) >= size_t(5) * 256;
-  auto k_lq = packed ? ilq_lq_kernel<T, NX, NP, MU, (has_packed ? LQ_PLAYER_WAVES_PACKED : LQ_VALU_FEEDBACK)>
+  auto k_lq_multi = packed ? ilq_lq_kernel<T, NX, NP, MU, (has_packed ? LQ_PLAYER_WAVES_PACKED : LQ_VALU_FEEDBACK)>
             : pw ? ilq_lq_kernel<T, NX, NP, MU, (C::USE_MFMA ? LQ_PLAYER_WAVES : LQ_VALU_FEEDBACK)>
                  : (p->desc.params.open_loop ? (ol_compact ? ilq_lq_kernel<T, NX, NP, MU, LQ_OPEN_LOOP_COMPACT> : ilq_lq_kernel<T, NX, NP, MU, LQ_OPEN_LOOP>)
                                              : ilq_lq_kernel<T, NX, NP, MU, LQ_VALU_FEEDBACK>);
-  const int nt_lq = p->desc.params.open_loop ? OLCfg<T, NX, NP, MU>::NT : (pw ? 64 * NP : C::NT);
+  const int nt_lq_multi = p->desc.params.open_loop ? OLCfg<T, NX, NP, MU>::NT : (pw ? 64 * NP : C::NT);
   raise_lds_limit((const void*)k_trial, lds_trial);
-  raise_lds_limit((const void*)k_lq, lds_lq);
 
   // One round = trial kernel, then (for the instances that asked) the exit kernel and the LQ kernel.
   // The trial kernel counts what its instances wait for; with fixed_iters = K (no AL) the sequence is
@@ -807,6 +808,17 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
     constexpr size_t fwd_elems = 4 * 2 * ((NX * NX + C::SCR + 3) & ~3) + 2 * NX + 8;
     if (trial_rows_elems(d, sa.rows_cw) < fwd_elems + 8) sa.defer_forward = 0;
   }
+  // The throughput form of the one-tile feedback sweep — one wave per instance, twice the instances per CU
+  // (ilqg_lq_feedback1w.hpp) — for batches of many instances per CU; it reads compact rows and leaves the forward pass
+  // to the trial kernel.  ilqg_solve_options::single_wave_sweep overrides the choice (same results to rounding).
+  constexpr bool has_1w = W1Cfg<T, NX, NP, MU>::SUPPORTED && C::USE_MFMA && C::MFMA_ONE_TILE;
+  const bool single_wave = has_1w && pw && sa.compact && sa.defer_forward && !kProfile &&
+                           choice(opt.single_wave_sweep, big_batch);
+  auto k_lq = single_wave ? ilq_lq_kernel<T, NX, NP, MU, (has_1w ? LQ_SINGLE_WAVE : LQ_VALU_FEEDBACK)> : k_lq_multi;
+  const int nt_lq = single_wave ? 64 : nt_lq_multi;
+  const size_t lds_lq = single_wave ? size_t(W1Cfg<T, NX, NP, MU>::ELEMS) * sizeof(T) : lds_lq_multi;
+  if (single_wave) sa.prio_div = 0;
+  raise_lds_limit((const void*)k_lq, lds_lq);
   long long cap = al_mode ? (long long)(sa.prm.max_solver_iters + 1) * (sa.prm.unconstrained_solver_max_iters + 2)
                           : (long long)sa.prm.max_solver_iters + 2;
   if (split || counted) cap = (cap + 2) * ((long long)sa.prm.max_backtracking_steps + 3);
@@ -888,7 +900,23 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
       // for the few instances left costs the latency of its launches whatever it probes: 2, 4, 8, 16, 32).
       int probe_k = sa.ids ? tail.pool_entries / round_instances : 0;
       if (probe_k > kProbeCandidates) probe_k = kProbeCandidates;
-      if (tail_rounds < 5 && probe_k > (2 << tail_rounds)) probe_k = 2 << tail_rounds;
+      {
+        // the ramp: `first` candidates in a tail's first round, doubling per round (ilqg_solve_options::probe_first)
+        // The library's choice: as many candidates per instance as keep the round's rollouts within one filling of
+        // the chip (kProbeRoundBudget of them), between 2 and 32.  A short list is a few deep searches — the instances
+        // that back-track at all mostly go on for tens of steps (the n = 16 intersection: ~10 % of the batch, mean
+        // depth ~30) — and 32 at once ends them in a round or two (measured, B = 1024: 280 k -> 335 k it/s); a long list
+        // (config 4: ~40 % of 4096 instances, most done within a step or two) pays for every candidate it does not
+        // need (226 k it/s at 2, 193 k at 32).
+        int first = opt.probe_first;
+        if (first <= 0) {
+          first = kProbeRoundBudget / (round_instances > 0 ? round_instances : 1);
+          first = first < 2 ? 2 : (first > kProbeCandidates ? kProbeCandidates : first);
+        }
+        long long ramp = (long long)first << (tail_rounds < 8 ? tail_rounds : 8);
+        if (ramp < 2) ramp = 2;
+        if (probe_k > ramp) probe_k = int(ramp);
+      }
       if (sa.ids) tail_rounds++;
       if (probe && probe_k >= 2) {
         // the listed instances' next step sizes side by side; their states move to the first acceptable one
@@ -1773,6 +1801,9 @@ ilqg_status ilqg_solve_batch_ex(ilqg_problem* p, int32_t batch, const void* x0, 
     return fail(ILQG_ERR_INVALID, "forced_steps needs fixed_iters > 0 and no augmented-Lagrangian loop");
   if (o.max_runtime > 0.0 && (o.fixed_iters > 0 || o.forced_steps))
     return fail(ILQG_ERR_INVALID, "max_runtime needs a free-running solve (fixed_iters = 0, no forced steps)");
+  if (o.single_wave_sweep < ILQG_CHOICE_AUTO || o.single_wave_sweep > ILQG_CHOICE_ON)
+    return fail(ILQG_ERR_INVALID, "scheduling choices are ilqg_choice values");
+  if (o.probe_first < 0 || o.probe_first > 1024) return fail(ILQG_ERR_INVALID, "probe_first: 0 (the library's choice) or a count");
   for (int32_t c : {o.split_trial, o.handoff, o.probe, o.counted})
     if (c < ILQG_CHOICE_AUTO || c > ILQG_CHOICE_ON) return fail(ILQG_ERR_INVALID, "scheduling choices are ilqg_choice values");
   const DevProblem& d = p->dev;

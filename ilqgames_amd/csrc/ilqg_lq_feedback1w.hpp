@@ -1,0 +1,388 @@
+// ilqg_lq_feedback1w.hpp — the one-tile feedback sweep (n < 16) with ONE wavefront per game instance: the throughput form.
+//
+// The player-parallel sweep (lq_feedback_instance_mfma_pw, ilqg_lq.hpp) gives an instance one wave per player: the
+// shortest chain per step, which is what a batch of a few instances per CU needs — but every wave repeats what the
+// players share (F = A - B P, the operand loads), two waves idle through the m x m solve, each step costs two workgroup
+// barriers, and three waves of 168 registers with a double-buffered 36 KB image hold a CU to four instances whatever the
+// batch (B = 8192 ran at the per-instance rate of B = 1024: profiles/r03_headline_f64_b8192.md).  A batch of many
+// instances per CU does not need the short chain, it needs the fewest instructions per instance and as many instances
+// in flight as the LDS holds.  Here one wave walks the players one after the other:
+//   * the shared work is done once per step (about half the vector instructions of the three-wave form per instance);
+//   * the players' matrix-instruction chains are independent of each other and sit next to each other in the
+//     instruction stream, so the matrix pipe is fed from one wave;
+//   * no workgroup barrier at all — a wave's LDS operations execute in order;
+//   * one step image instead of two (the compact row of step k - 1 is scattered over it at the end of step k, out of a
+//     staging row the DMA engine filled during the step): 20 KB per instance in fp64, 10 KB in fp32 — eight / sixteen
+//     instances per CU, each with the register budget of two / four waves per SIMD.
+// Same recursion, same operand layouts, same order of operations per player as the player-parallel form (so the same
+// results to rounding; the forced-step parity tests run both).  Only what the solver's LQ part needs is built: compact
+// rows in (LQArgs::compact), symmetric costs, zeta riding in the spare tile column (n < 16), the forward pass deferred
+// to the next trial pass (scratch rows out).
+// Reference: LQFeedbackSolver::Solve, src/lq_feedback_solver.cpp:110-213.
+#pragma once
+
+#include "ilqg_lq.hpp"
+
+namespace ilqg {
+
+template <typename T, int NX, int NP, int MU>
+struct W1Cfg {
+  using C = LQCfg<T, NX, NP, MU>;
+  static constexpr int M = NP * MU;
+  static constexpr int LD = sizeof(T) == 8 ? 18 : 17;  // padded tile columns (bank-conflict-free accumulator-layout reads)
+  static constexpr int TILE = (16 * LD + 3) & ~3;
+  // the step image [tA | tB | tQ_0.. | l | R | r]
+  static constexpr int oTA = 0;
+  static constexpr int oTB = oTA + TILE;
+  static constexpr int oTQ = oTB + TILE;
+  static constexpr int oVl = oTQ + NP * TILE;
+  static constexpr int oVR = (oVl + NP * NX + 3) & ~3;
+  static constexpr int oVr = (oVR + C::RMAX + 3) & ~3;
+  static constexpr int IMG = (oVr + C::rMAX + 3) & ~3;
+  // intermediates
+  static constexpr int oPt = IMG;               // [P | alpha] as a padded tile
+  static constexpr int oAl = oPt + TILE;        // alpha (M, padded to 16)
+  static constexpr int oYz = oAl + 16;          // y_zeta (M, padded to 16)
+  static constexpr int oSY = oYz + 16;          // [S | Y]: M x 32, column-major
+  static constexpr int oG = oSY + M * 32;       // per player: its MU columns of G = Z^T B, interleaved [row][aa]
+  static constexpr int oSB = oG + NP * MU * 16;  // staging row of the compact rows (the DMA's landing place)
+  static constexpr int oCD = oSB + kCompactMaxWords;  // where each word of a compact row goes in the image (ints)
+  static constexpr int CD_ELEMS = (kCompactMaxWords * 4 + int(sizeof(T)) - 1) / int(sizeof(T));
+  static constexpr int ELEMS = (oCD + CD_ELEMS + 3) & ~3;
+  static constexpr bool SUPPORTED = NX < 16 && M <= 16 && C::NSOLVE <= 32 && NP <= 4;
+};
+
+template <typename T, int NX, int NP, int MU>
+__device__ __forceinline__ void lq_feedback_instance_mfma_1w(const LQArgs<T>& a, const PairTable& pt, T* sm) {
+  using C = LQCfg<T, NX, NP, MU>;
+  using W = W1Cfg<T, NX, NP, MU>;
+  using TL = Tile<T>;
+  using vec = typename TL::vec;
+  constexpr int M = C::M, S = int(sizeof(T)), LD = W::LD, SCR = C::SCR, JB = NX;
+  static_assert(W::SUPPORTED, "the single-wave sweep needs a spare tile column (n < 16) and a Nash system of <= 32 columns");
+  const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
+  const int Tn = a.T_steps;
+  const PairRegs<NP> pr(pt);
+  const vec zero4 = {T(0), T(0), T(0), T(0)};
+  constexpr int RS = TL::row(0, 1) - TL::row(0, 0);
+  const int row0 = TL::row(g, 0);
+  const int offD = row0 + LD * j;  // [row][col] of a padded tile
+  const int offT = j + LD * row0;  // its transpose
+  auto ldD = [&](const T* tile) {
+    vec v;
+#pragma unroll
+    for (int r = 0; r < 4; r++) v[r] = tile[offD + RS * r];
+    return v;
+  };
+  auto ldDT = [&](const T* tile) {
+    vec v;
+#pragma unroll
+    for (int r = 0; r < 4; r++) v[r] = tile[offT + LD * RS * r];
+    return v;
+  };
+  const T mCols = (j < NX) ? T(1) : T(0);    // a proper state column
+  const T mVecCol = (j == JB) ? T(1) : T(0);  // the column zeta / beta / alpha ride in
+  const T mZcols = mCols + mVecCol;
+  constexpr int gJ = sizeof(T) == 8 ? JB % 4 : JB / 4, rJ = sizeof(T) == 8 ? JB / 4 : JB % 4;
+  static_assert(TL::row(gJ, rJ) == JB, "accumulator-layout position of row JB");
+
+  T* const tA = sm + W::oTA;
+  T* const tB = sm + W::oTB;
+  T* const tQ0 = sm + W::oTQ;
+  T* const sl = sm + W::oVl;
+  T* const sR = sm + W::oVR;
+  T* const sr = sm + W::oVr;
+  T* const sPt = sm + W::oPt;
+  T* const sAl = sm + W::oAl;
+  T* const sYz = sm + W::oYz;
+  T* const sSY = sm + W::oSY;
+  T* const sG0 = sm + W::oG;
+  T* const sSB = sm + W::oSB;
+  int* const sCD = reinterpret_cast<int*>(sm + W::oCD);
+
+  // compact rows: array << 24 | offset in the array's row  ->  offset inside the image
+  auto cdecode = [&](int code) -> int {
+    const int arr = code >> 24, off = code & 0xffffff;
+    if (arr == RA_Q) {
+      const int i = off / (NX * NX), wd = off - i * NX * NX;
+      const int col = wd / NX, row = wd - col * NX;
+      return W::oTQ + i * W::TILE + row + LD * col;
+    }
+    if (arr == RA_A || arr == RA_B) {
+      const int col = off / NX, row = off - col * NX;
+      return (arr == RA_A ? W::oTA : W::oTB) + row + LD * col;
+    }
+    return (arr == RA_L ? W::oVl : (arr == RA_R ? W::oVR : W::oVr)) + off;
+  };
+  const int CWD = a.compact_tab[RC_W];
+  const int* const ctab = a.compact_tab + RC_BASE + NP + 1;  // destination of each word, then the constants
+  const T* const gC = uniform_ptr(a.compact);
+  // row k straight from global memory (before the loop), row by DMA into the staging row, staged row over the image
+  auto scatter_sync = [&](int k) {
+    for (int c = lane; c < CWD; c += 64) sm[cdecode(ctab[c])] = gC[size_t(k) * CWD + c];
+  };
+  auto request_row = [&](int k) { dma_g2l<64, false>(gC + size_t(k) * CWD, sSB, CWD * S, lane); };
+  auto scatter_staged = [&]() {
+    constexpr int WPL = kCompactMaxWords / 64;
+    T v[WPL];
+    int cd[WPL];
+#pragma unroll
+    for (int q = 0; q < WPL; q++) {
+      cd[q] = sCD[lane + 64 * q];
+      v[q] = sSB[lane + 64 * q];
+    }
+#pragma unroll
+    for (int q = 0; q < WPL; q++)
+      if (cd[q] >= 0) sm[cd[q]] = v[q];
+  };
+  // (Q_i l_i) of the image's step for ExpectedDecrease: lane group i takes player i, lane j of the group row j
+  auto stash_ql = [&](int k) {
+    if (g < NP && j < NX) {
+      const T* tQi = tQ0 + g * W::TILE;
+      T s = T(0);
+#pragma unroll
+      for (int c = 0; c < NX; c++) s += tQi[j + LD * c] * sl[g * NX + c];
+      a.scratch[size_t(k) * SCR + g * NX + j] = s;
+    }
+  };
+
+  // ---- zero the tile padding (and everything else the scatter does not write), once; the constants of the image ----
+  for (int e = lane; e < W::ELEMS; e += 64) sm[e] = T(0);
+  lds_sync(true);
+  for (int c = lane; c < kCompactMaxWords; c += 64) sCD[c] = c < CWD ? cdecode(ctab[c]) : -1;
+  {
+    const int nbg = a.compact_tab[RC_NBG];
+    const int* bg = ctab + CWD;
+    for (int e = lane; e < nbg; e += 64) {
+      const int off = cdecode(bg[RC_BG_WORDS * e]);
+      const int kind = bg[RC_BG_WORDS * e + 1];
+      sm[off] = kind == RC_DT ? T(a.dt) : (kind == RC_NEG_DT ? T(-a.dt) : T(__int_as_float(bg[RC_BG_WORDS * e + 2])));
+    }
+  }
+  lds_sync(true);
+
+  // ---- terminal step: Z_i = Q_i[T-1], zeta_i = l_i[T-1] (:102-105); zeta_i rides in column JB of the Z_i tile ----
+  scatter_sync(Tn - 1);
+  lds_sync(true);
+  vec Zd[NP];
+#pragma unroll
+  for (int w = 0; w < NP; w++) {
+    Zd[w] = ldD(tQ0 + w * W::TILE);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int row = row0 + RS * r;
+      Zd[w][r] += (row < NX ? sl[w * NX + (row < NX ? row : 0)] : T(0)) * mVecCol;
+    }
+  }
+  stash_ql(Tn - 1);
+  for (int e = lane; e < M * NX; e += 64) a.P[size_t(Tn - 1) * M * NX + e] = T(0);  // strategy.h:64-70
+  if (lane < M) a.alpha[size_t(Tn - 1) * M + lane] = T(0);
+  if (lane < NP) a.scratch[size_t(Tn - 1) * SCR + NP * NX + lane] = T(0);
+  if (lane < NX) a.scratch[size_t(Tn - 1) * SCR + NP * (NX + 1) + lane] = T(0);
+  lds_sync(true);
+  if (Tn >= 2) {
+    scatter_sync(Tn - 2);
+    if (Tn >= 3) request_row(Tn - 3);
+  }
+  lds_sync(true);
+
+#pragma unroll 1
+  for (int k = Tn - 2; k >= 0; k--) {
+    // ---- every player's MU rows of the stacked Nash system: (B_w^T Z_w) [B | A] (:128-157) ----
+    const vec Bd = ldD(tB);
+    T ba[NX];  // column `lane` of [B | A] (lanes past the last column re-read column 0)
+    {
+      const T* colp = lane < M ? tB + LD * lane : tA + LD * (lane < M + NX ? lane - M : 0);
+#pragma unroll
+      for (int kk = 0; kk < NX; kk++) ba[kk] = colp[kk];
+    }
+    vec G[NP];  // G_w = Z_w^T B: NP independent chains on the matrix pipe
+#pragma unroll
+    for (int w = 0; w < NP; w++) G[w] = tile_xty<T>(Zd[w], Bd, zero4);
+#pragma unroll
+    for (int w = 0; w < NP; w++) {
+      if (j / MU == w) {  // this player's MU columns of G_w, interleaved [row][aa]
+        T* const sGw = sG0 + w * MU * 16;
+#pragma unroll
+        for (int r = 0; r < 4; r++) sGw[(row0 + RS * r) * MU + (j - w * MU)] = G[w][r];
+        // y_zeta = B_w^T zeta_w + r_ww (:154-157): row JB of G_w (zeta_w rides in column JB of the Z_w tile)
+        if (g == gJ) sYz[j] = G[w][rJ] + sr[pr.rg[w][w] + (j - w * MU)];
+      }
+    }
+    lds_sync(true);
+#pragma unroll
+    for (int w = 0; w < NP; w++) {
+      const T* const sGw = sG0 + w * MU * 16;
+      T acc[MU];
+#pragma unroll
+      for (int aa = 0; aa < MU; aa++) acc[aa] = T(0);
+#pragma unroll
+      for (int kk = 0; kk < NX; kk++)
+#pragma unroll
+        for (int aa = 0; aa < MU; aa++) acc[aa] += sGw[kk * MU + aa] * ba[kk];
+      if (lane < M + NX) {
+        const bool diag = lane / MU == w;  // + R_ww on this player's diagonal block of S (:148-150)
+        const int b = lane - w * MU;
+#pragma unroll
+        for (int aa = 0; aa < MU; aa++)
+          sSY[(w * MU + aa) + M * lane] = acc[aa] + (diag ? sR[pr.ro[w][w] + aa + MU * (diag ? b : 0)] : T(0));
+      }
+    }
+    stash_ql(k);
+    lds_sync(true);
+
+    // ---- column `lane` of [S | Y]: Gershgorin (:163-176), then the M x M solve (:180) ----
+    {
+      T col[M], x[M];
+      const bool isS = lane < M;
+      const T* src = (lane < M + NX) ? sSY + M * lane : sYz;
+#pragma unroll
+      for (int r = 0; r < M; r++) {
+        col[r] = src[r];
+        x[r] = T(0);
+      }
+      {
+        T l1 = T(0), diag = T(0);
+#pragma unroll
+        for (int r = 0; r < M; r++) {
+          l1 += (col[r] < T(0) ? -col[r] : col[r]);
+          diag = (r == lane) ? col[r] : diag;
+        }
+        const T radius = l1 - (diag < T(0) ? -diag : diag);
+        const T eval_lo = diag - radius;
+        const T bump = (isS && a.adaptive && eval_lo < T(1e-3f)) ? radius + T(1e-3f) : T(0);
+#pragma unroll
+        for (int r = 0; r < M; r++) col[r] = col[r] + ((r == lane) ? bump : T(0));
+      }
+      if (a.adaptive)
+        lu_solve_columns<T, M>(col, lane, x);
+      else
+        qr_solve_columns<T, M>(col, lane, x);
+      if (lane >= M && lane < M + NX) {
+#pragma unroll
+        for (int r = 0; r < M; r++) sPt[r + LD * (lane - M)] = x[r];
+      } else if (lane == M + NX) {
+#pragma unroll
+        for (int r = 0; r < M; r++) {
+          sAl[r] = x[r];
+          sPt[r + LD * JB] = x[r];  // [P | alpha]: F = A - B [P | alpha] then carries beta = -B alpha
+        }
+      }
+    }
+    lds_sync(true);
+    if (lane < NX) {
+#pragma unroll
+      for (int r = 0; r < M; r++) uniform_ptr(a.P + size_t(k) * M * NX)[unsigned(r + M * lane)] = sPt[r + LD * lane];
+    } else if (lane < NX + M) {
+      uniform_ptr(a.alpha + size_t(k) * M)[unsigned(lane - NX)] = sAl[lane - NX];
+    }
+
+    // ---- F = A - B P (:189-194), beta = -B alpha: once for all players ----
+    const vec Pd = ldD(sPt);
+    vec nBT = ldDT(tB);
+#pragma unroll
+    for (int r = 0; r < 4; r++) nBT[r] = -nBT[r];
+    const vec Fraw = tile_xty_blocks<T, kblock_mask<T>(0, M)>(nBT, Pd, ldD(tA));  // = [F | beta]
+    vec Fd, Fx, Pm;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      Fd[r] = Fraw[r] * mCols;
+      Fx[r] = Fraw[r] * mZcols;  // F in the state columns, beta in column JB, zero elsewhere
+      Pm[r] = Pd[r] * mCols;     // P proper: column JB of the tile holds alpha
+    }
+    if (j == JB) {
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+        if (row0 + RS * r < NX) a.scratch[size_t(k) * SCR + NP * (NX + 1) + row0 + RS * r] = Fraw[r];
+    }
+    if (lane < NP) {  // alpha_i^T R_ii r_ii, evaluated (alpha^T R) r like Eigen (ilq_solver.cpp:384-386)
+      int ro_ii = 0, rg_ii = 0;
+#pragma unroll
+      for (int e = 0; e < NP; e++) {
+        ro_ii = (lane == e) ? pr.ro[e][e] : ro_ii;
+        rg_ii = (lane == e) ? pr.rg[e][e] : rg_ii;
+      }
+      T acc = T(0);
+#pragma unroll
+      for (int c = 0; c < MU; c++) {
+        T aR = T(0);
+#pragma unroll
+        for (int b = 0; b < MU; b++) aR += sAl[lane * MU + b] * sR[ro_ii + b + MU * c];
+        acc += aR * sr[rg_ii + c];
+      }
+      a.scratch[size_t(k) * SCR + NP * NX + lane] = acc;
+    }
+
+    // ---- Z_w <- F^T Z_w F + Q_w + sum_jj P_jj^T R_w,jj P_jj, zeta_w in column JB (:198-212), player after player ----
+    static_for<NP>([&](auto WW) {
+      constexpr int w = decltype(WW)::value;
+      vec Cd = ldD(tQ0 + w * W::TILE);
+      // column JB of C_w: l_w + sum_jj P_jj^T (R_w,jj alpha_jj - r_w,jj) as one product [P]^T q with
+      // q = (R_w,jj alpha_jj - r_w,jj) stacked in column JB of the right operand
+      vec Qy;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = row0 + RS * r;  // a row of P: player jj = row / MU, control aa = row % MU
+        const bool in = row < M;
+        const int rowc = in ? row : 0;
+        const int jj = rowc / MU, aa = rowc % MU;
+        int qw = -1, ro_wj = 0, rg_wj = 0;
+#pragma unroll
+        for (int f = 0; f < NP; f++)
+          if (jj == f) {
+            qw = pr.q[w][f];
+            ro_wj = pr.ro[w][f];
+            rg_wj = pr.rg[w][f];
+          }
+        T ww = -sr[rg_wj + aa];
+#pragma unroll
+        for (int b = 0; b < MU; b++) ww += sR[ro_wj + aa + MU * b] * sAl[jj * MU + b];
+        Qy[r] = (in && qw >= 0) ? ww * mVecCol : T(0);
+        const int srow = row < NX ? row : 0;
+        Cd[r] += (row < NX ? sl[w * NX + srow] : T(0)) * mVecCol;
+      }
+      Cd = tile_xty_blocks<T, kblock_mask<T>(0, M)>(Pm, Qy, Cd);
+      static_for<NP>([&](auto JJ) {
+        constexpr int jj = decltype(JJ)::value;
+        if (pr.q[w][jj] < 0) return;  // wave-uniform
+        const T* Rij = sR + pr.ro[w][jj];
+        T pb[MU];
+#pragma unroll
+        for (int b = 0; b < MU; b++) pb[b] = sPt[(jj * MU + b) + LD * j] * mCols;
+        vec Pj, Hd;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int aa = row0 + RS * r - jj * MU;
+          const bool in = aa >= 0 && aa < MU;
+          const int ac = in ? aa : 0;
+          const T mk = in ? T(1) : T(0);
+          T h = T(0);
+#pragma unroll
+          for (int b = 0; b < MU; b++) h += Rij[ac + MU * b] * pb[b];
+          Pj[r] = Pd[r] * (mk * mCols);
+          Hd[r] = h * mk;
+        }
+        Cd = tile_xty_blocks<T, kblock_mask<T>(jj * MU, jj * MU + MU)>(Pj, Hd, Cd);  // P_jj^T (R P_jj)
+      });
+      const vec Wd = tile_xty<T>(Zd[w], Fx, zero4);  // Z_w [F | beta] (Z_w symmetric: its own transpose)
+      vec Wz;
+#pragma unroll
+      for (int r = 0; r < 4; r++) Wz[r] = Wd[r] * mZcols + Zd[w][r] * mVecCol;  // column JB: zeta_w + Z_w beta
+      const vec Zx = tile_xty<T>(Fd, Wz, Cd);  // F^T [Z_w F | zeta_w + Z_w beta] + C_w
+#pragma unroll
+      for (int r = 0; r < 4; r++) Zd[w][r] = Zx[r] * mZcols;
+    });
+
+    // ---- the image of the next step: the staged compact row over this one, then the row after it requested ----
+    if (k >= 1) {
+      dma_wait();
+      lds_sync(true);
+      scatter_staged();
+      lds_sync(true);
+      if (k >= 2) request_row(k - 2);
+    }
+    lds_sync(true);
+  }
+}
+
+}  // namespace ilqg

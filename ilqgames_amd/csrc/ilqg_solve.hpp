@@ -18,6 +18,7 @@
 #include "ilqg_lq.hpp"
 #include "ilqg_lq_openloop.hpp"
 #include "ilqg_lq_feedback2.hpp"
+#include "ilqg_lq_feedback1w.hpp"
 #include "ilqg_lq_generic.hpp"
 #include "ilqg_stages.hpp"
 
@@ -405,7 +406,8 @@ __device__ __forceinline__ void rows_part_instance(const DevProblem& p, const sh
 // candidate again with all outputs and accepts it: same arithmetic, same decisions, fewer rounds.
 // ---------------------------------------------------------------------------
 constexpr int kProbeCandidates = 32;            // most step sizes probed per instance and round
-constexpr int kProbeEntries = 8 * 512;          // pool size: candidates of all listed instances of one round
+constexpr int kProbeEntries = 16384;            // pool size: candidates of all listed instances of one round
+constexpr int kProbeRoundBudget = 4096;         // rollouts the first probing round of a tail may hold (doubling after)
 
 struct ProbeEntry {
   size_t xs, us, mpart, merit, total;
@@ -840,7 +842,8 @@ __device__ __forceinline__ void deadline_part_instance(const DevProblem& p, cons
 // ---------------------------------------------------------------------------
 // KIND: which sweep this kernel instantiation carries (one each, so that the register allocation of one does not
 // pay for the others): LQ_VALU_FEEDBACK, LQ_PLAYER_WAVES (PW above) or LQ_OPEN_LOOP.
-enum { LQ_VALU_FEEDBACK = 0, LQ_PLAYER_WAVES = 1, LQ_OPEN_LOOP = 2, LQ_PLAYER_WAVES_PACKED = 3, LQ_OPEN_LOOP_COMPACT = 4 };
+enum { LQ_VALU_FEEDBACK = 0, LQ_PLAYER_WAVES = 1, LQ_OPEN_LOOP = 2, LQ_PLAYER_WAVES_PACKED = 3, LQ_OPEN_LOOP_COMPACT = 4,
+       LQ_SINGLE_WAVE = 5 };  // _SINGLE_WAVE: the one-tile feedback sweep with one wave per instance (ilqg_lq_feedback1w.hpp)
 // _PACKED: ilqg_api.hip; _COMPACT: the open-loop sweep reading compact rows (its own instantiation: register budget)
 template <typename T, int NX, int NP, int MU, int KIND>
 __device__ __forceinline__ void lq_part_instance(const DevProblem& p, const SolveArgs<T>& sa, int b, T* sm) {
@@ -876,7 +879,7 @@ __device__ __forceinline__ void lq_part_instance(const DevProblem& p, const Solv
   la.adaptive = 1;
   la.symmetric = 1;  // linquad_compute writes H(x,y) and H(y,x) from the same value
   la.prio_div = KIND == LQ_PLAYER_WAVES ? sa.prio_div : 0;
-  if (sa.compact && (KIND == LQ_PLAYER_WAVES || KIND == LQ_OPEN_LOOP_COMPACT)) {
+  if (sa.compact && (KIND == LQ_PLAYER_WAVES || KIND == LQ_OPEN_LOOP_COMPACT || KIND == LQ_SINGLE_WAVE)) {
     la.compact = w + L.Q;
     la.compact_tab = p.row_prog + p.rp_compact_off;
     la.dt = p.dt;
@@ -887,6 +890,9 @@ __device__ __forceinline__ void lq_part_instance(const DevProblem& p, const Solv
   tl_stamp(sa.prof, b, 16, threadIdx.x == 0);
   if constexpr (KIND == LQ_PLAYER_WAVES) {
     lq_feedback_instance_mfma<T, NX, NP, MU>(la, p.pairs, sm);
+  } else if constexpr (KIND == LQ_SINGLE_WAVE) {
+    // (the launcher only picks this kind with compact rows and the deferred forward pass: la.compact set, no ed_out)
+    if constexpr (W1Cfg<T, NX, NP, MU>::SUPPORTED) lq_feedback_instance_mfma_1w<T, NX, NP, MU>(la, p.pairs, sm);
   } else if constexpr (KIND == LQ_OPEN_LOOP) {
     lq_openloop_instance<T, NX, NP, MU>(la, p.pairs, sm);  // SolverParams::open_loop (ilq_solver.h:76-81)
   } else if constexpr (KIND == LQ_OPEN_LOOP_COMPACT) {

@@ -772,7 +772,7 @@ def mixed_dubins_car_scene(T=100, dt=0.1, open_loop=False, constrained=False):
     return s
 
 
-def three_unicycle_scene(T=60, dt=0.1, open_loop=False):
+def three_unicycle_scene(T=40, dt=0.1, open_loop=False):
     """A test scene, NOT a reference example: three SinglePlayerUnicycle4D (n = 12, N = 3, m_i = 2) — equal control
     dimensions, but a shape the library holds no specialised instantiation of, and a horizon that is not the reference's
     100 steps: the run-time-dimensioned kernels again."""

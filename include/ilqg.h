@@ -403,7 +403,12 @@ typedef struct {
   int32_t round_bursts;         /* ilqg_choice: free-running solves read their counters back once per burst of rounds */
   int32_t generic_kernels;      /* ilqg_choice: ILQG_CHOICE_ON runs the run-time-dimensioned kernels (what every shape
                                      without a specialised instantiation runs on) for this problem too */
-  int32_t reserved[3];
+  int32_t probe_first;          /* speculative line search: step sizes probed per listed instance in the first round of
+                                     a tail (doubling every round up to 32, as many as the pool holds); 0 = the library's
+                                     choice.  Same decisions whatever the value.                                       */
+  int32_t single_wave_sweep;    /* ilqg_choice: the one-tile feedback sweep with one wave per instance (twice the instances
+                                     per CU; the library picks it for batches of eight or more instances per CU)          */
+  int32_t reserved[1];
   const struct ilqg_iterate_log* iterate_log; /* NULL, or where every logged iterate of the solve goes (below)          */
   double max_runtime;           /* > 0: the anytime exit of ILQSolver::Solve (src/ilq_solver.cpp:123-124) on the host's
                                      clock, seconds — once it has passed, instances leave the loop at their next

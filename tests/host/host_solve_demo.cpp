@@ -298,13 +298,35 @@ int main(int argc, char** argv) {
     os << std::setprecision(9) << "x0 " << problem->InitialState() << "\n";
     WriteLog(os, *log, success);
 
-    // SolverLog on disk, from a log the device produced: every iterate of the solve (src/solver_log.cpp:113-171)
-    // and the SaveLogs form (last trajectory only, :208-240)
+    // SolverLog on disk, from logs the device produced: every iterate of a solve (src/solver_log.cpp:113-171) and the
+    // SaveLogs form (last trajectory only, :208-240).  The solve above gives up in its second iteration's line search
+    // (as the reference's does with these parameters): its log holds iterates 0 and 1.  A second solve with the
+    // intersection main's line-search parameters runs its six iterations.
     setenv("ILQGAMES_LOG_DIR", outdir.c_str(), 1);
     CHECK(log->Save(false, "ilq_single_log"));
-    CHECK(SaveLogs(std::vector<std::shared_ptr<const SolverLog>>{log}, true, "ilq_single_last"));
     std::ofstream(outdir + "/ilq_single_log_meta.txt") << "iterates " << log->NumIterates() << " device_iterations "
                                                         << log->DeviceIterations() << "\n";
+    {
+      SolverParams log_params = params;
+      log_params.max_solver_iters = 6;
+      log_params.initial_alpha_scaling = 0.1f;
+      log_params.expected_decrease_fraction = 0.001f;
+      auto logged_problem = std::make_shared<MergeScene>(false);
+      logged_problem->Initialize();
+      host::ProblemDescription logged_description;
+      CHECK(host::DescribeProblem(*logged_problem, log_params, ILQG_F64, &logged_description, &why)) << why;
+      std::ofstream(outdir + "/scene_logged.txt") << host::DumpDescription(logged_description);
+      ILQSolver logged_solver(logged_problem, log_params);
+      bool logged_success = false;
+      const std::shared_ptr<SolverLog> logged = logged_solver.Solve(&logged_success);
+      std::ofstream ol(outdir + "/ilq_logged.txt");
+      ol << std::setprecision(9) << "x0 " << logged_problem->InitialState() << "\n";
+      WriteLog(ol, *logged, logged_success);
+      CHECK(logged->Save(false, "ilq_logged_log"));
+      CHECK(SaveLogs(std::vector<std::shared_ptr<const SolverLog>>{logged}, true, "ilq_logged_last"));
+      std::ofstream(outdir + "/ilq_logged_log_meta.txt") << "iterates " << logged->NumIterates() << " device_iterations "
+                                                          << logged->DeviceIterations() << "\n";
+    }
 
     // the anytime exit (src/ilq_solver.cpp:123-124): a budget no iteration fits in returns iterate 0 with success
     {

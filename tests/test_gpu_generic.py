@@ -212,15 +212,20 @@ def test_free_running_solves_of_mixed_dimension_games_match_oracle(hip, oracle, 
     rng = np.random.default_rng(1)
     O = oracle.OracleProblem(spec)
     ref = O.solve(abi.F64, x0)
-    refn = O.solve(abi.F64, x0 + 1e-12 * rng.standard_normal(x0.shape))
+    # two nudges: the size of fp64 round-off in x0, and the size of the device-vs-oracle tolerance itself
+    nudged = [O.solve(abi.F64, x0 + e * rng.standard_normal(x0.shape)) for e in (1e-12, 1e-9)]
     out = hip.Problem(spec, abi.F64).solve(x0, log_capacity=int(spec.params.max_solver_iters) + 2)
-    robust = [b for b in range(B) if ref["iters"][b] == refn["iters"][b] and ref["status"][b] == refn["status"][b] and
-              rel_err(ref["xs"][b], refn["xs"][b]) < 1e-7]
+    robust = [b for b in range(B) if all(ref["iters"][b] == r["iters"][b] and ref["status"][b] == r["status"][b] and
+                                         ref["converged"][b] == r["converged"][b] and
+                                         rel_err(ref["xs"][b], r["xs"][b]) < 1e-6 for r in nudged)]
     assert len(robust) >= B // 2, "scene too ill-conditioned to compare free-running solves: %s" % robust
     for b in robust:
         assert _np(out["iters"])[b] == ref["iters"][b] and _np(out["status"])[b] == ref["status"][b], b
         assert _np(out["converged"])[b] == ref["converged"][b], b
-        assert rel_err(_np(out["xs"])[b], ref["xs"][b]) < 1e-6 and rel_err(_np(out["alpha"])[b], ref["alpha"][b]) < 1e-5, b
+        assert rel_err(_np(out["xs"])[b], ref["xs"][b]) < 1e-6, b
+        # alpha carries the last accepted step; at a converged iterate it is rounding noise (1e-13) whose step the two
+        # runs need not agree on: compared on the scale of the controls
+        assert np.max(np.abs(_np(out["alpha"])[b] - ref["alpha"][b])) < 1e-6 * max(1.0, np.max(np.abs(ref["us"][b]))), b
         np.testing.assert_allclose(_np(out["costs"])[b], ref["costs"][b], rtol=1e-6)
         # the iterate log of the run-time-dimensioned path: one entry per logged iterate, the last one = the result
         cnt = int(_np(out["log"]["count"])[b])

@@ -278,13 +278,19 @@ def test_cpp_device_produced_solver_log_on_disk_matches_oracle_iterates(demo_out
     <dir>/<experiment>/<iterate>/{t0,xs,u<i>,costs,cumulative_runtimes}.txt), read back from disk and compared with
     the oracle's iterates: iterate 0 is the initial rollout (src/ilq_solver.cpp:100-112), iterate q the operating
     point after q outer iterations.  The files hold six significant digits (Eigen's default stream precision)."""
-    got = _parse_log(os.path.join(demo_out, "ilq_single.txt"))
-    spec = abi.ProblemSpec.from_dump(open(os.path.join(demo_out, "scene.txt")).read())
-    O = oracle.OracleProblem(spec)
+    # a solve whose second line search gives up (src/ilq_solver.cpp:146-155 returns the log as it stands): iterates 0, 1
+    failed = _parse_log(os.path.join(demo_out, "ilq_single.txt"))
     meta = open(os.path.join(demo_out, "ilq_single_log_meta.txt")).read().split()
+    assert failed["success"] == 0 and int(meta[1]) == int(meta[3]) == failed["iters"] == 2
+    assert sorted(os.listdir(os.path.join(demo_out, "ilq_single_log"))) == ["0", "1"]
+    # a solve that runs its six iterations: iterates 0 .. 6
+    got = _parse_log(os.path.join(demo_out, "ilq_logged.txt"))
+    spec = abi.ProblemSpec.from_dump(open(os.path.join(demo_out, "scene_logged.txt")).read())
+    O = oracle.OracleProblem(spec)
+    meta = open(os.path.join(demo_out, "ilq_logged_log_meta.txt")).read().split()
     iterates, device_iterations = int(meta[1]), int(meta[3])
-    assert iterates == device_iterations + 1 == got["iters"] + 1 and iterates >= 3
-    base = os.path.join(demo_out, "ilq_single_log")
+    assert got["success"] == 1 and iterates == device_iterations + 1 == got["iters"] + 1 == 7
+    base = os.path.join(demo_out, "ilq_logged_log")
     assert sorted(os.listdir(base), key=int) == [str(q) for q in range(iterates)]
     x0 = got["x0"][None, :]
     udims = [sub[2] for sub in spec.subsystems]
@@ -310,7 +316,7 @@ def test_cpp_device_produced_solver_log_on_disk_matches_oracle_iterates(demo_out
         np.testing.assert_allclose(np.loadtxt(os.path.join(d, "costs.txt")), costs[0], rtol=2e-5)
         assert float(open(os.path.join(d, "t0.txt")).read()) == 0.0
     # the last iterate on disk is the solve's result; SaveLogs keeps only that one
-    last = os.path.join(demo_out, "ilq_single_last", "0")
+    last = os.path.join(demo_out, "ilq_logged_last", "0")
     assert os.listdir(last) == [str(iterates - 1)]
     assert open(os.path.join(last, str(iterates - 1), "xs.txt")).read() == \
         open(os.path.join(base, str(iterates - 1), "xs.txt")).read()
@@ -630,3 +636,29 @@ def test_cpp_solve_batch_sharded_on_a_world_of_one_equals_solve_batch():
     res = subprocess.run([_shard_exe(), "solve"], env=env, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "largest difference between SolveBatch and SolveBatchSharded 0" in res.stdout, res.stdout
+
+
+@pytest.mark.gpu
+def test_cpp_solve_batch_sharded_on_two_gpus_equals_solve_batch():
+    """The native multi-GPU entry on a world of TWO: two processes, one GPU each (host::ShardContext: hipSetDevice by
+    LOCAL_RANK, ncclUniqueId over the TCP rendezvous, ncclCommInitRank), every rank solves its block of the batch and one
+    ncclAllGather per result array gives each rank the whole BatchResult — which must equal SolveBatch's bit for bit on
+    both ranks.  Needs two visible GPUs: skipped on the one-GPU boxes this build has had (no scaling curve has been
+    measured), there so that the first multi-GPU lease runs the collective under a test, not under the bench."""
+    import socket
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible GPUs")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   ILQG_RENDEZVOUS_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([_shard_exe(), "solve"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert "rank %d of 2" % r in o and "largest difference between SolveBatch and SolveBatchSharded 0" in o, o
