@@ -38,9 +38,11 @@ CONSTRAINT_POLYLINE2_SIGNED_DISTANCE = 18
 COST_NOMINAL_PATH_LENGTH = 19  # time-dependent: quadratic about k * dt * speed
 COST_ROUTE_PROGRESS = 20       # time-dependent: quadratic about the polyline point at pos0 + k * dt * speed
 COST_WEIGHTED_CONVEX_PROXIMITY = 21  # idx = (x1, y1, x2, y2), idx_extra = (v1, v2)
+CONSTRAINT_AFFINE_SCALAR = 22  # g = a^T v - b over the whole argument vector; `polyline` = offset of [a | b] in dense_params
+CONSTRAINT_AFFINE_VECTOR = 23  # g = |A v - b|; `polyline` = offset of [A (column-major) | b]
 # ilqg_cost_role
 ROLE_STATE_COST, ROLE_CONTROL_COST, ROLE_STATE_CONSTRAINT, ROLE_CONTROL_CONSTRAINT, ROLE_CHILD = range(5)
-FLAG_ORIENTED, FLAG_IS_MIN = 1, 2
+FLAG_ORIENTED, FLAG_IS_MIN, FLAG_EQUALITY = 1, 2, 4
 SUM, MAX, MIN = 0, 1, 2
 
 
@@ -112,7 +114,8 @@ class ProblemDesc(C.Structure):
                 ("player_costs", PlayerCost * MAX_PLAYERS), ("num_terms", C.c_int32),
                 ("terms", C.POINTER(CostTerm)), ("num_polylines", C.c_int32),
                 ("polyline_offsets", C.POINTER(C.c_int32)), ("polyline_points", C.POINTER(C.c_float)),
-                ("T", C.c_int32), ("dt", C.c_double), ("dtype", C.c_int32), ("params", SolverParams)]
+                ("T", C.c_int32), ("dt", C.c_double), ("dtype", C.c_int32), ("params", SolverParams),
+                ("num_dense_params", C.c_int32), ("dense_params", C.POINTER(C.c_float))]
 
 
 def make_dims(n, udims, T, batch, dtype, adaptive_regularization=True):
@@ -144,6 +147,7 @@ class ProblemSpec:
         self.params = params or SolverParams.default()
         self.x0 = None
         self._num_constraints = 0
+        self.dense_params = []  # coefficients of the affine constraints (ilqg_problem_desc::dense_params)
 
     # --- dynamics (ConcatenatedDynamicalSystem subsystem list) ---
     def add_player(self, kind, param0=0.0, state_reg=0.0, control_reg=0.0, structure=SUM):
@@ -294,6 +298,31 @@ class ProblemSpec:
         return self._term(CONSTRAINT_SINGLE_DIMENSION, role, player, arg, (dim,), 1.0, threshold,
                           FLAG_ORIENTED if keep_below else 0, constraint=True)
 
+    def affine_scalar_constraint(self, player, a, b, is_equality=False, control_of=None):
+        """AffineScalarConstraint(a, b, is_equality) (constraint/affine_scalar_constraint.h:54-100): a^T v - b on the whole
+        state, or on the control vector of player `control_of`."""
+        role, arg = (ROLE_STATE_CONSTRAINT, -1) if control_of is None else (ROLE_CONTROL_CONSTRAINT, control_of)
+        dim = self.n if control_of is None else self.udims[control_of]
+        a = [float(v) for v in a]
+        assert len(a) == dim
+        off = len(self.dense_params)
+        self.dense_params += a + [float(b)]
+        return self._term(CONSTRAINT_AFFINE_SCALAR, role, player, arg, (0,), 1.0, 0.0,
+                          FLAG_EQUALITY if is_equality else 0, off, constraint=True)
+
+    def affine_vector_constraint(self, player, A, b, is_equality=False, control_of=None):
+        """AffineVectorConstraint(A, b, is_equality) (constraint/affine_vector_constraint.h:52-112), A square (its
+        Quadraticize CHECKs input.size() == b.size()): |A v - b|."""
+        import numpy as np
+        role, arg = (ROLE_STATE_CONSTRAINT, -1) if control_of is None else (ROLE_CONTROL_CONSTRAINT, control_of)
+        dim = self.n if control_of is None else self.udims[control_of]
+        A = np.asarray(A, dtype=np.float32)
+        assert A.shape == (dim, dim) and len(b) == dim
+        off = len(self.dense_params)
+        self.dense_params += [float(v) for v in A.T.reshape(-1)] + [float(v) for v in b]  # column-major
+        return self._term(CONSTRAINT_AFFINE_VECTOR, role, player, arg, (0,), 1.0, 0.0,
+                          FLAG_EQUALITY if is_equality else 0, off, constraint=True)
+
     @property
     def num_constraints(self):
         return self._num_constraints
@@ -333,6 +362,8 @@ class ProblemSpec:
                 spec.params = SolverParams(float(v[0]), int(v[1]), int(v[2]), float(v[3]), float(v[4]), int(v[5]),
                                            float(v[6]), int(v[7]), int(v[8]), float(v[9]), float(v[10]),
                                            float(v[11]), float(v[12]))
+            elif tok[0] == "dense":
+                spec.dense_params = [float(a) for a in tok[1:]]
             elif tok[0] == "x0":
                 spec.x0 = [float(a) for a in tok[1:]]
         spec.subsystems, spec.player_costs = subs, pcs
@@ -348,8 +379,13 @@ class ProblemSpec:
         def term_key(t):
             # polyline by content, to 6 significant digits: libm's cosf/sinf and a correctly rounded
             # double->float cos/sin may differ in the last bit of a vertex
-            poly = tuple((float('%.6g' % x), float('%.6g' % y)) for x, y in self.polylines[t["polyline"]]) \
-                if t["polyline"] >= 0 else None
+            if t["kind"] in (CONSTRAINT_AFFINE_SCALAR, CONSTRAINT_AFFINE_VECTOR):  # its coefficient block, by content
+                dim = self.n if t["arg"] < 0 else self.udims[t["arg"]]
+                cnt = dim + 1 if t["kind"] == CONSTRAINT_AFFINE_SCALAR else dim * dim + dim
+                poly = tuple(f32(v) for v in self.dense_params[t["polyline"]:t["polyline"] + cnt])
+            else:
+                poly = tuple((float('%.6g' % x), float('%.6g' % y)) for x, y in self.polylines[t["polyline"]]) \
+                    if t["polyline"] >= 0 else None
             kids = tuple(term_key(self.terms[c]) for c in range(t["child_begin"], t["child_begin"] + t["child_count"]))
             return (t["kind"], t["arg"], tuple(t["idx"]), f32(t["weight"]), f32(t["value"]), t["flags"], poly, kids,
                     t.get("first_step", 0), f32(t.get("value2", 0.0)), tuple(t.get("idx_extra", (0, 0))))
@@ -410,4 +446,7 @@ class ProblemSpec:
         d.polyline_points = pts_arr
         d.T, d.dt, d.dtype = self.T, self.dt, dtype
         d.params = self.params
-        return d, (terms, offs_arr, pts_arr)
+        dense_arr = (C.c_float * max(1, len(self.dense_params)))(*self.dense_params)
+        d.num_dense_params = len(self.dense_params)
+        d.dense_params = dense_arr
+        return d, (terms, offs_arr, pts_arr, dense_arr)

@@ -659,6 +659,8 @@ struct ilqg_problem {
   float* d_poly_pts = nullptr;
   float* d_segs_f = nullptr;
   double* d_segs_d = nullptr;
+  float* d_dense_f = nullptr;
+  double* d_dense_d = nullptr;
   double* d_tnom_f = nullptr;
   double* d_tnom_d = nullptr;
   int* d_cost_order = nullptr;
@@ -809,11 +811,13 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
     if (trial_rows_elems(d, sa.rows_cw) < fwd_elems + 8) sa.defer_forward = 0;
   }
   // The throughput form of the one-tile feedback sweep — one wave per instance, twice the instances per CU
-  // (ilqg_lq_feedback1w.hpp) — for batches of many instances per CU; it reads compact rows and leaves the forward pass
-  // to the trial kernel.  ilqg_solve_options::single_wave_sweep overrides the choice (same results to rounding).
+  // (ilqg_lq_feedback1w.hpp) — for batches of five or more instances per CU (measured, n = 14 fp64: B = 1024 1.47 M it/s
+  // player-parallel vs 1.11 M single-wave; 1280: 1.09 vs 1.10; 1536: 1.17 vs 1.25; 2048: 1.20 vs 1.45; 8192: 1.45 vs
+  // 1.68); it reads compact rows and leaves the forward pass to the trial kernel.
+  // ilqg_solve_options::single_wave_sweep overrides the choice (same results to rounding).
   constexpr bool has_1w = W1Cfg<T, NX, NP, MU>::SUPPORTED && C::USE_MFMA && C::MFMA_ONE_TILE;
   const bool single_wave = has_1w && pw && sa.compact && sa.defer_forward && !kProfile &&
-                           choice(opt.single_wave_sweep, big_batch);
+                           choice(opt.single_wave_sweep, size_t(batch) >= size_t(5) * num_cus);
   auto k_lq = single_wave ? ilq_lq_kernel<T, NX, NP, MU, (has_1w ? LQ_SINGLE_WAVE : LQ_VALU_FEEDBACK)> : k_lq_multi;
   const int nt_lq = single_wave ? 64 : nt_lq_multi;
   const size_t lds_lq = single_wave ? size_t(W1Cfg<T, NX, NP, MU>::ELEMS) * sizeof(T) : lds_lq_multi;
@@ -1513,6 +1517,42 @@ ilqg_status ilqg_problem_create(const ilqg_problem_desc* desc, ilqg_problem** ou
     o.arg_off = on_state ? 0 : d.n + d.uoff[o.arg];
     o.arg_dim = on_state ? d.n : d.udim[o.arg];
   }
+  // ---- coefficient blocks of the affine constraints, in both precisions (DevProblem::dense_f / dense_d) ----
+  std::vector<float> dense_f;
+  std::vector<double> dense_d;
+  for (int ti = 0; ti < desc->num_terms; ti++) {
+    DevTerm& o = dt[ti];
+    if (!term_is_affine(o.kind)) continue;
+    const int dim = o.arg_dim;
+    const bool vec = o.kind == ILQG_CONSTRAINT_AFFINE_VECTOR;
+    const long long count = vec ? (long long)dim * dim + dim : dim + 1;
+    const bool constraint_role = o.role == ILQG_ROLE_STATE_CONSTRAINT || o.role == ILQG_ROLE_CONTROL_CONSTRAINT;
+    if (!constraint_role || o.slot < 0 || desc->dense_params == nullptr || desc->terms[ti].polyline < 0 ||
+        (long long)desc->terms[ti].polyline + count > desc->num_dense_params) {
+      delete p;
+      return fail(ILQG_ERR_INVALID, "an affine constraint must be a state / control constraint with a multiplier slot "
+                                    "and a coefficient block inside ilqg_problem_desc::dense_params");
+    }
+    const float* src = desc->dense_params + desc->terms[ti].polyline;
+    o.polyline = int(dense_f.size());  // from here on: the offset of its block in the device tables
+    auto emit = [&](auto& out) {
+      using S = typename std::decay<decltype(out)>::type::value_type;
+      for (long long e = 0; e < count; e++) out.push_back(S(src[e]));
+      if (vec)  // ATA_ = A^T A, AAT_ = A A^T as the constructor forms them (affine_vector_constraint.h:60-61)
+        for (int which = 0; which < 2; which++)
+          for (int j = 0; j < dim; j++)
+            for (int i = 0; i < dim; i++) {
+              S acc = S(0);
+              for (int q = 0; q < dim; q++)
+                acc += which == 0 ? S(src[q + dim * i]) * S(src[q + dim * j]) : S(src[i + dim * q]) * S(src[j + dim * q]);
+              out.push_back(acc);
+            }
+    };
+    const size_t before = dense_f.size();
+    emit(dense_f);
+    emit(dense_d);
+    (void)before;
+  }
   p->terms_host.assign(desc->terms, desc->terms + desc->num_terms);
   const int npts = desc->num_polylines ? desc->polyline_offsets[desc->num_polylines] : 0;
   hipError_t e = hipMalloc(&p->d_terms, sizeof(DevTerm) * dt.size());
@@ -1641,6 +1681,14 @@ ilqg_status ilqg_problem_create(const ilqg_problem_desc* desc, ilqg_problem** ou
     e = hipMemcpy(p->d_tnom_d, tnom_d.data(), sizeof(double) * tnom_d.size(), hipMemcpyHostToDevice);
   d.time_nominal_f = p->d_tnom_f;
   d.time_nominal_d = p->d_tnom_d;
+  if (e == hipSuccess) e = hipMalloc(&p->d_dense_f, sizeof(float) * (dense_f.size() + 1));
+  if (e == hipSuccess && !dense_f.empty())
+    e = hipMemcpy(p->d_dense_f, dense_f.data(), sizeof(float) * dense_f.size(), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMalloc(&p->d_dense_d, sizeof(double) * (dense_d.size() + 1));
+  if (e == hipSuccess && !dense_d.empty())
+    e = hipMemcpy(p->d_dense_d, dense_d.data(), sizeof(double) * dense_d.size(), hipMemcpyHostToDevice);
+  d.dense_f = p->d_dense_f;
+  d.dense_d = p->d_dense_d;
   if (e == hipSuccess) e = hipMalloc(&p->d_cost_order, sizeof(int) * order.size());
   if (e == hipSuccess) e = hipMemcpy(p->d_cost_order, order.data(), sizeof(int) * order.size(), hipMemcpyHostToDevice);
   // the term table is uploaded last: it carries the argument offsets computed above
@@ -1678,6 +1726,7 @@ ilqg_status ilqg_problem_create(const ilqg_problem_desc* desc, ilqg_problem** ou
   p->desc.terms = nullptr;
   p->desc.polyline_offsets = nullptr;
   p->desc.polyline_points = nullptr;
+  p->desc.dense_params = nullptr;
   if (!uniform_udim(d.udim, d.N, &p->mu_uniform)) p->mu_uniform = 0;
   {
     bool instantiated = false;
@@ -1701,6 +1750,8 @@ void ilqg_problem_destroy(ilqg_problem* p) {
   if (p->d_poly_pts) (void)hipFree(p->d_poly_pts);
   if (p->d_segs_f) (void)hipFree(p->d_segs_f);
   if (p->d_segs_d) (void)hipFree(p->d_segs_d);
+  if (p->d_dense_f) (void)hipFree(p->d_dense_f);
+  if (p->d_dense_d) (void)hipFree(p->d_dense_d);
   if (p->d_tnom_f) (void)hipFree(p->d_tnom_f);
   if (p->d_tnom_d) (void)hipFree(p->d_tnom_d);
   if (p->d_cost_order) (void)hipFree(p->d_cost_order);

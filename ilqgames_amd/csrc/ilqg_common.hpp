@@ -77,6 +77,11 @@ struct DevProblem {
   // term is its table.  Tabulated by ilqg_problem_create.
   const double* time_nominal_f;
   const double* time_nominal_d;
+  // Coefficient blocks of the affine constraints, one copy per precision; DevTerm::polyline of such a term is its block's
+  // offset.  AffineScalarConstraint: [a (d) | b]; AffineVectorConstraint: [A (d x d, column-major) | b (d) | A^T A | A A^T]
+  // (the two products as its constructor forms them, affine_vector_constraint.h:60-61).  Built by ilqg_problem_create.
+  const float* dense_f;
+  const double* dense_d;
   // TotalCosts summation order: per player [count, term indices...] (state costs, then control costs)
   const int* cost_order;
   int cost_order_stride;
@@ -114,6 +119,9 @@ constexpr int kSegStride = 21;
 template <typename T> __device__ __forceinline__ const T* problem_segs(const DevProblem& p);
 template <> __device__ __forceinline__ const float* problem_segs<float>(const DevProblem& p) { return p.segs_f; }
 template <> __device__ __forceinline__ const double* problem_segs<double>(const DevProblem& p) { return p.segs_d; }
+template <typename T> __device__ __forceinline__ const T* problem_dense(const DevProblem& p);
+template <> __device__ __forceinline__ const float* problem_dense<float>(const DevProblem& p) { return p.dense_f; }
+template <> __device__ __forceinline__ const double* problem_dense<double>(const DevProblem& p) { return p.dense_d; }
 template <typename T> __device__ __forceinline__ const double* problem_time_nominal(const DevProblem& p);
 template <> __device__ __forceinline__ const double* problem_time_nominal<float>(const DevProblem& p) { return p.time_nominal_f; }
 template <> __device__ __forceinline__ const double* problem_time_nominal<double>(const DevProblem& p) { return p.time_nominal_d; }

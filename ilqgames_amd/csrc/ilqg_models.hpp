@@ -362,7 +362,36 @@ struct QuadTables {
   // The per-step nominals of the time-dependent costs (DevProblem::time_nominal of this precision), [table][T][2].
   const double* tnom;
   int tnom_T;
+  const T* dense = nullptr;  // coefficient blocks of the affine constraints (DevProblem::dense_f / dense_d)
 };
+__host__ __device__ inline bool term_is_affine(int kind) {
+  return kind == ILQG_CONSTRAINT_AFFINE_SCALAR || kind == ILQG_CONSTRAINT_AFFINE_VECTOR;
+}
+// Constraint::Mu(lambda, g) (constraint.h:112-117): the inactive-inequality gate; an equality constraint has none
+template <typename T>
+__device__ __forceinline__ T constraint_mu(T lambda, T g, T mu, bool is_equality) {
+  const T al = lambda < T(0) ? -lambda : lambda;
+  return (!is_equality && g <= T(1e-4f) && al <= T(1e-4f)) ? T(0) : mu;
+}
+// g of the two affine constraints from their coefficient block: a^T v - b (affine_scalar_constraint.h:63-66),
+// |A v - b| (affine_vector_constraint.h:70-73)
+template <typename T, typename V>
+__device__ __forceinline__ T affine_evaluate(int kind, const T* blk, const V& v, int dim) {
+  if (kind == ILQG_CONSTRAINT_AFFINE_SCALAR) {
+    T s = T(0);
+    for (int i = 0; i < dim; i++) s += blk[i] * v[i];
+    return s - blk[dim];
+  }
+  const T* b = blk + dim * dim;
+  T sq = T(0);
+  for (int i = 0; i < dim; i++) {
+    T dlt = T(0);
+    for (int j = 0; j < dim; j++) dlt += blk[i + dim * j] * v[j];
+    dlt -= b[i];
+    sq += dlt * dlt;
+  }
+  return t_sqrt(sq);
+}
 // WeightedConvexProximityCost touches more entries than one pattern holds: the row program evaluates it as four ops —
 // the cost kind itself (the position block: the relative-position pattern, and the value) and three internal kinds
 // that only exist inside row programs: the speed block (PAIR2 over (v1, v2)) and the position x speed blocks of the
@@ -599,6 +628,9 @@ __device__ __forceinline__ T term_evaluate_leaf_of(const QuadTables<T>& tb, cons
       const T value = sgn(cl.ssd) * t_sqrt(t_abs(cl.ssd)) - val;
       return oriented ? value : -value;
     }
+    case ILQG_CONSTRAINT_AFFINE_SCALAR:
+    case ILQG_CONSTRAINT_AFFINE_VECTOR:
+      return tb.dense ? affine_evaluate<T, V>(c.kind, tb.dense + c.polyline, v, dim) : T(0);
   }
   return T(0);
 }

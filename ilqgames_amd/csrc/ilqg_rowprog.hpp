@@ -52,6 +52,12 @@ inline bool build_row_program(const DevProblem& d, const std::vector<DevTerm>& d
   // ---- the entries a leaf term adds to: (is_hessian, a, b) in rows_scatter's order ----
   struct Entry { bool h; int a, b; };
   auto leaf_entries = [&](const DevTerm& c, int dim, std::vector<Entry>* e) {
+    if (term_is_affine(c.kind)) {  // dense: every gradient entry, every Hessian entry column by column (rows_affine)
+      for (int i = 0; i < dim; i++) e->push_back({false, i, 0});
+      for (int j = 0; j < dim; j++)
+        for (int i = 0; i < dim; i++) e->push_back({true, i, j});
+      return;
+    }
     const int pat = term_pattern_of(c.kind, c.idx[0]);
     if (pat == PAT_SINGLE) {
       e->push_back({false, c.idx[0], 0});
@@ -312,6 +318,15 @@ inline bool build_row_program(const DevProblem& d, const std::vector<DevTerm>& d
             const int b0 = leaf_sids(sub, c);
             emit_op(ROP_TERM, b0, int(sids.size()) - b0, 0, sub, c, sub.polyline, term_pattern_of(sub.kind, sub.idx[0]));
           }
+        } else if (term_is_affine(c.kind)) {
+          // G and H slots as any leaf's, then 2 d scratch slots that no output word reads (the vector constraint's
+          // temporaries; unmapped slots also keep such a problem off the compact rows, whose every slot feeds a word)
+          const int b0 = leaf_sids(c, c);
+          for (int q = 0; q < 2 * c.arg_dim; q++) {
+            sids.push_back(NPS + nl++);
+            add_linit(RI_VALUE, 0.0f);
+          }
+          emit_op(ROP_AFFINE, b0, int(sids.size()) - b0, 0, c, c, c.polyline, PAT_NONE);
         } else {
           want_closest(c, c);
           const int b0 = leaf_sids(c, c);

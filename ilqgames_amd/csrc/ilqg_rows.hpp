@@ -59,7 +59,10 @@ enum { RPASS_WORDS = 8, ROP_FIELDS = 20, ROP_INLINE_SIDS = 20, ROP_WORDS = 40, R
 //              (`poly_nseg` of them); the polyline terms that follow read the result
 // An ExtremeValueCost becomes EXT_EVAL x children, EXT_APPLY x children; role / player / constraint slot / first
 // active step of those ops are the parent's.
-enum { ROP_TERM = 0, ROP_EXT_EVAL = 1, ROP_EXT_APPLY = 2, ROP_JACOBIAN = 3, ROP_CLOSEST = 4 };
+//   AFFINE     an AffineScalarConstraint / AffineVectorConstraint: dense over its whole argument vector, evaluated and
+//              scattered by rows_affine from its coefficient block (`poly_first` = the block's offset); its slot ids are
+//              [G(0..d-1) | H(r, c) column-major (d^2) | 2 d scratch slots (the vector constraint's delta and A^T delta)]
+enum { ROP_TERM = 0, ROP_EXT_EVAL = 1, ROP_EXT_APPLY = 2, ROP_JACOBIAN = 3, ROP_CLOSEST = 4, ROP_AFFINE = 5 };
 enum {
   RO_MODE = 0, RO_SID, RO_NSID, RO_AUX, RO_KIND, RO_ROLE, RO_PLAYER, RO_FLAGS, RO_IDX0, RO_IDX1, RO_IDX2, RO_IDX3,
   RO_WEIGHT, RO_VALUE, RO_POLY_FIRST, RO_SLOT, RO_ARG_OFF, RO_ARG_DIM, RO_K_START, RO_PATTERN_NSEG
@@ -266,6 +269,63 @@ __device__ __forceinline__ void rows_scatter(int pattern, const TermOut<T>& o, c
     const T add[8] = {o.hxx, o.hyy, -o.hxx, -o.hyy, o.hxx, -o.hxx, o.hyy, -o.hyy};
 #pragma unroll
     for (int e = 0; e < 8; e++) *pp[e] = av[e] + add[e];
+  }
+}
+
+// The two affine constraints (constraint/affine_scalar_constraint.h:70-88, affine_vector_constraint.h:77-101): the
+// augmented-Lagrangian term's gradient and DENSE Hessian over the whole argument vector of this lane's row, added to the
+// op's slots.  `blk`: the constraint's coefficient block (uniform address); `v`: the row's argument vector; the vector
+// constraint keeps delta = A v - b and A^T delta in its 2 d scratch slots (LDS, this lane's column) instead of registers.
+template <typename T, typename V, typename SID>
+__device__ __forceinline__ void rows_affine(int kind, bool is_equality, const T* blk, int d, const SID& sid, T* col, int cws,
+                                            const V& v, T lambda, T mu, bool want_h) {
+  if (kind == ILQG_CONSTRAINT_AFFINE_SCALAR) {
+    const T b = blk[d];
+    T s = T(0);
+    for (int i = 0; i < d; i++) s += blk[i] * v[i];
+    const T mu_eff = constraint_mu<T>(lambda, s - b, mu, is_equality);
+    for (int i = 0; i < d; i++) {
+      // hess_of_sq_ = a a^T is a matrix of the reference's scalars: the product a_i a_j is rounded before it meets x
+      const T ai = blk[i];
+      T hx = T(0);
+      for (int j = 0; j < d; j++) {
+        const T aij = ai * blk[j];
+        hx += aij * v[j];
+        if (want_h) col[sid[d + i + d * j] * cws] += mu_eff * aij;
+      }
+      col[sid[i] * cws] += lambda * ai + mu_eff * (hx - b * ai);
+    }
+    return;
+  }
+  const T* const bb = blk + d * d;
+  const T* const ata = bb + d;
+  const T* const aat = ata + d * d;
+  T* const t_delta = col;  // scratch slot q of this lane: col[sid[d + d * d + q] * cws]
+  const int s0 = d + d * d;
+  T sq = T(0);
+  for (int i = 0; i < d; i++) {
+    T dlt = T(0);
+    for (int j = 0; j < d; j++) dlt += blk[i + d * j] * v[j];
+    dlt -= bb[i];
+    t_delta[sid[s0 + i] * cws] = dlt;
+    sq += dlt * dlt;
+  }
+  const T value = t_sqrt(sq);
+  for (int i = 0; i < d; i++) {  // A^T delta
+    T atd = T(0);
+    for (int j = 0; j < d; j++) atd += blk[j + d * i] * t_delta[sid[s0 + j] * cws];
+    t_delta[sid[s0 + d + i] * cws] = atd;
+  }
+  const T mu_eff = constraint_mu<T>(lambda, value, mu, is_equality);
+  const T lv = lambda / value;
+  for (int i = 0; i < d; i++) {
+    const T atd_i = t_delta[sid[s0 + d + i] * cws];
+    col[sid[i] * cws] += (mu_eff + lv) * atd_i;
+    if (want_h)
+      for (int j = 0; j < d; j++) {
+        const T atd_j = t_delta[sid[s0 + d + j] * cws];
+        col[sid[d + i + d * j] * cws] += lv * (aat[i + d * j] - atd_i * atd_j / (value * value)) + mu_eff * ata[i + d * j];
+      }
   }
 }
 
@@ -537,6 +597,17 @@ __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* map
           continue;
         }
         const RowArg<T> v{arg + c.arg_off * cw + rl, cw};
+        if (mode == ROP_AFFINE) {
+          // constraints are quadraticised with the player's full PlayerCost::Quadraticize only (:483-487), from their
+          // first active step on (FinalTimeConstraint)
+          const bool deriv = do_quad && row >= c.k_start && ((full >> c.player) & 1u);
+          if (!__any(deriv)) continue;
+          const T lambda = (c.slot >= 0 && a.lambdas) ? a.lambdas[c.slot * p.T + tidx] : T(0);
+          if (deriv)
+            rows_affine<T>(c.kind, (c.flags & ILQG_FLAG_EQUALITY) != 0, problem_dense<T>(p) + od(RO_POLY_FIRST), c.arg_dim,
+                           SidsTable{sids + od(RO_SID)}, col, cws, v, lambda, a.mu, quad_out);
+          continue;
+        }
         if (mode == ROP_CLOSEST) {
           cc = polyline_closest_rows<T>(segs, od(RO_POLY_FIRST), od(RO_PATTERN_NSEG), v[c.idx[0]], v[c.idx[1]]);
           continue;

@@ -263,7 +263,7 @@ __device__ __forceinline__ void solve_exit_path(const DevProblem& p, const QuadT
               const double tt = 0.0 + p.dt * double(float(k));
               const int tidx = int(static_cast<size_t>(tt / p.dt));
               const T nl = lambdas[cs * Tn + tidx] + s.mu * err;
-              lambdas[cs * Tn + tidx] = nl > T(0) ? nl : T(0);
+              lambdas[cs * Tn + tidx] = ((c.flags & ILQG_FLAG_EQUALITY) || nl > T(0)) ? nl : T(0);
             }
           }
           if (t < 64) {

@@ -265,6 +265,7 @@ __device__ __forceinline__ QuadTables<T> quad_tables_load(const DevProblem& p, v
   tb.lc = lc;
   tb.tnom = problem_time_nominal<T>(p);
   tb.tnom_T = p.T;
+  tb.dense = problem_dense<T>(p);
   return tb;
 }
 

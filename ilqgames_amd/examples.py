@@ -652,6 +652,53 @@ def cost_zoo_scene(T=100, dt=0.1):
     return s
 
 
+# coefficients of affine_constraint_scene (its C++ twin: tests/host/zoo_scene.h)
+AFFINE_A_U = [[1.0, 0.3], [-0.2, 1.0]]
+AFFINE_B_U = [0.05, 0.1]
+
+
+def affine_constraint_scene(T=100, dt=0.1):
+    """A test scene, NOT a reference example: two Car5D (n = 10) following crossing lanes with the reference's two
+    DENSE constraints (constraint/affine_scalar_constraint.h, affine_vector_constraint.h; its tests only run their
+    quadraticisation, test/test_quadraticization.cpp:305-316): player 1 stays behind a line in the (px1, px2) plane
+    (an inequality a^T x <= b on the whole state), player 2 keeps its heading tied to its speed (an EQUALITY
+    a^T x = b), and player 1's controls are held at A u = b by an AffineVectorConstraint on its control vector."""
+    prm = SolverParams.default()
+    prm.max_backtracking_steps = 100
+    prm.initial_alpha_scaling = 0.1
+    prm.convergence_tolerance = 0.01
+    prm.expected_decrease_fraction = 0.001
+    prm.max_solver_iters = 30
+    s = ProblemSpec(T, dt, prm)
+    for _ in range(2):
+        s.add_player(DYN_CAR_5D, 4.0, state_reg=1.0, control_reg=5.0)
+    X, Y, H, PHI, V = [0, 5], [1, 6], [2, 7], [3, 8], [4, 9]
+    lane1 = s.add_polyline([(0.0, -1000.0), (0.0, 1000.0)])
+    lane2 = s.add_polyline([(-1000.0, 2.0), (1000.0, 2.0)])
+    for i in range(2):
+        s.quadratic(i, 10.0, 0, 0.0, control_of=i)
+        s.quadratic(i, 5.0, 1, 0.0, control_of=i)
+        s.quadratic(i, 10.0, V[i], 6.0)
+    s.quadratic_polyline2(0, 25.0, lane1, (X[0], Y[0]))
+    s.quadratic_polyline2(1, 25.0, lane2, (X[1], Y[1]))
+    s.proximity(0, 30.0, (X[0], Y[0]), (X[1], Y[1]), 5.0)
+    s.proximity(1, 30.0, (X[1], Y[1]), (X[0], Y[0]), 5.0)
+    a1 = [0.0] * 10
+    a1[X[0]], a1[X[1]] = 1.0, -0.25
+    s.affine_scalar_constraint(0, a1, 6.0)                      # px1 - 0.25 px2 <= 6
+    a2 = [0.0] * 10
+    a2[H[1]], a2[V[1]] = 1.0, -0.01
+    s.affine_scalar_constraint(1, a2, -0.06, is_equality=True)  # theta2 = 0.01 v2 - 0.06
+    s.affine_vector_constraint(0, AFFINE_A_U, AFFINE_B_U, control_of=0)
+    f = np.float32
+    x0 = np.zeros(10)
+    x0[[X[0], Y[0], H[0], V[0]]] = [0.0, -25.0, float(f(np.pi / 2)), 5.0]
+    x0[[X[1], Y[1], H[1], V[1]]] = [-30.0, 2.0, 0.0, 5.0]
+    s.x0 = x0
+    s.position_dims, s.heading_dims, s.speed_dims = list(zip(X, Y)), H, V
+    return s
+
+
 def weighted_proximity_scene(T=100, dt=0.1):
     """A test scene, NOT a reference example: the skeleton example's two Car5D with WeightedConvexProximityCost in
     place of its ProximityCost.  That cost's Quadraticize is not the derivative of its Evaluate in the reference
@@ -837,6 +884,7 @@ CONFIGS = {
     "skeleton": skeleton,
     "cost_zoo_scene": cost_zoo_scene,
     "weighted_proximity_scene": weighted_proximity_scene,
+    "affine_constraint_scene": affine_constraint_scene,
     "dynamics_zoo_scene": dynamics_zoo_scene,
     "delayed_dubins_scene": delayed_dubins_scene,
     # shapes without a specialised instantiation: the run-time-dimensioned kernels

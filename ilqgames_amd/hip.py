@@ -141,6 +141,10 @@ class Problem:
         self.Rsz = sum(spec.udims[j] ** 2 for _, j in self.pairs)
         self.rsz = sum(spec.udims[j] for _, j in self.pairs)
         self._ws = None
+        # ilqg_solve_options::single_wave_sweep of every solve through this object that does not say otherwise (None =
+        # the library's choice, which depends on the batch size: tests that compare a slice with its batch bit for bit
+        # pin it)
+        self.single_wave_sweep = None
 
     def __del__(self):
         try:
@@ -236,7 +240,7 @@ class Problem:
         o.round_bursts = tri(round_bursts)
         o.generic_kernels = tri(generic_kernels)
         o.probe_first = int(probe_first)
-        o.single_wave_sweep = tri(single_wave_sweep)
+        o.single_wave_sweep = tri(self.single_wave_sweep if single_wave_sweep is None else single_wave_sweep)
         o.max_runtime = float(max_runtime)
         il = None
         if log_capacity > 0:
@@ -327,6 +331,8 @@ class Problem:
     def solve_again(self, x0, bufs, augmented_lagrangian=False, active=None):
         """ilqg_solve_again_batch: the next Solve() of the solver object whose previous call used bufs['ws']."""
         x0 = _dev(x0, self.dtype)
+        if self.single_wave_sweep is not None:  # a pinned schedule: the same call through the options struct
+            return self.solve(x0, bufs, augmented_lagrangian=augmented_lagrangian, resume=True, active=active)
         _check(lib().ilqg_solve_again_batch(self.h, x0.shape[0], _ptr(x0), _ptr(bufs["xs"]), _ptr(bufs["us"]),
                                             _ptr(bufs["P"]), _ptr(bufs["alpha"]), _ptr(bufs["costs"]),
                                             _ptr(bufs["iters"]), _ptr(bufs["status"]), _ptr(bufs["converged"]),

@@ -326,6 +326,20 @@ bool SingleDimensionConstraint::Describe(host::TermDescription* out) const {
   FillTerm(out, ILQG_CONSTRAINT_SINGLE_DIMENSION, 1.0f, threshold_, keep_below_ ? ILQG_FLAG_ORIENTED : 0, {dim_});
   return true;
 }
+bool AffineScalarConstraint::Describe(host::TermDescription* out) const {
+  FillTerm(out, ILQG_CONSTRAINT_AFFINE_SCALAR, 1.0f, 0.0f, IsEquality() ? ILQG_FLAG_EQUALITY : 0, {0});
+  out->dense.assign(a_.data(), a_.data() + a_.size());
+  out->dense.push_back(b_);
+  return true;
+}
+bool AffineVectorConstraint::Describe(host::TermDescription* out) const {
+  if (A_.rows() != A_.cols()) return false;  // the reference's Quadraticize only takes a square A
+  FillTerm(out, ILQG_CONSTRAINT_AFFINE_VECTOR, 1.0f, 0.0f, IsEquality() ? ILQG_FLAG_EQUALITY : 0, {0});
+  for (std::ptrdiff_t j = 0; j < A_.cols(); j++)  // column-major
+    for (std::ptrdiff_t i = 0; i < A_.rows(); i++) out->dense.push_back(A_(i, j));
+  out->dense.insert(out->dense.end(), b_.data(), b_.data() + b_.size());
+  return true;
+}
 bool Polyline2SignedDistanceConstraint::Describe(host::TermDescription* out) const {
   FillTerm(out, ILQG_CONSTRAINT_POLYLINE2_SIGNED_DISTANCE, 1.0f, threshold_, keep_left_ ? ILQG_FLAG_ORIENTED : 0,
            {xidx_, yidx_});
@@ -403,6 +417,10 @@ class Packer {
       td.term.child_count = static_cast<int>(out_->terms.size()) - begin;
     }
     if (td.polyline != nullptr) td.term.polyline = InternPolyline(*td.polyline);
+    if (!td.dense.empty()) {  // an affine constraint's coefficient block: `polyline` is its offset in the dense table
+      td.term.polyline = static_cast<int>(out_->dense_params.size());
+      out_->dense_params.insert(out_->dense_params.end(), td.dense.begin(), td.dense.end());
+    }
     td.term.role = role;
     td.term.player = player;
     td.term.arg = arg;
@@ -516,6 +534,8 @@ bool DescribeProblem(const Problem& problem, const SolverParams& params, ilqg_dt
   d.num_polylines = static_cast<int>(out->polyline_offsets.size()) - 1;
   d.polyline_offsets = out->polyline_offsets.data();
   d.polyline_points = out->polyline_points.data();
+  d.num_dense_params = static_cast<int>(out->dense_params.size());
+  d.dense_params = out->dense_params.empty() ? nullptr : out->dense_params.data();
   d.T = static_cast<int>(time::kNumTimeSteps);
   d.dt = time::kTimeStep;
   d.dtype = dtype;
@@ -556,6 +576,11 @@ std::string DumpDescription(const ProblemDescription& description) {
     os << "polyline";
     for (int p = description.polyline_offsets[q]; p < description.polyline_offsets[q + 1]; p++)
       os << " " << description.polyline_points[2 * p] << " " << description.polyline_points[2 * p + 1];
+    os << "\n";
+  }
+  if (!description.dense_params.empty()) {
+    os << "dense";
+    for (float v : description.dense_params) os << " " << v;
     os << "\n";
   }
   const ilqg_solver_params& sp = d.params;
@@ -655,6 +680,7 @@ static std::string Fingerprint(const ProblemDescription& d) {
   f.append(reinterpret_cast<const char*>(d.terms.data()), d.terms.size() * sizeof(ilqg_cost_term));
   f.append(reinterpret_cast<const char*>(d.polyline_offsets.data()), d.polyline_offsets.size() * sizeof(int32_t));
   f.append(reinterpret_cast<const char*>(d.polyline_points.data()), d.polyline_points.size() * sizeof(float));
+  f.append(reinterpret_cast<const char*>(d.dense_params.data()), d.dense_params.size() * sizeof(float));
   return f;
 }
 

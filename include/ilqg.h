@@ -201,9 +201,17 @@ typedef enum {
                                         nominal speed; 0.5 w (x[dim] - t * speed)^2 */
   ILQG_COST_ROUTE_PROGRESS = 20,     /* src/route_progress_cost.cpp:52-110: idx = (x, y), polyline, value = nominal
                                         speed, value2 = initial route position; 0.5 w |p - PointAt(pos0 + t speed)|^2 */
-  ILQG_COST_WEIGHTED_CONVEX_PROXIMITY = 21 /* src/weighted_convex_proximity_cost.cpp:50-158: idx = (x1, y1, x2, y2),
+  ILQG_COST_WEIGHTED_CONVEX_PROXIMITY = 21, /* src/weighted_convex_proximity_cost.cpp:50-158: idx = (x1, y1, x2, y2),
                                         idx_extra = (v1, v2), value = threshold; LOCALLY_CONVEX_PROXIMITY scaled by
                                         v1^2 + v2^2, derivatives as written there.  Top-level state cost only. */
+  /* The two constraints on the WHOLE argument vector (the state, or the control vector of player `arg`; d = its
+   * dimension): dense d x d Hessian blocks.  Their coefficients sit in ilqg_problem_desc::dense_params, the term's
+   * `polyline` field is the offset of its block there. */
+  ILQG_CONSTRAINT_AFFINE_SCALAR = 22, /* include/ilqgames/constraint/affine_scalar_constraint.h:54-100: g = a^T v - b;
+                                        block [a (d) | b] */
+  ILQG_CONSTRAINT_AFFINE_VECTOR = 23  /* include/ilqgames/constraint/affine_vector_constraint.h:52-112: g = |A v - b| with
+                                        a square A; block [A (d x d, column-major) | b (d)]; derivatives as written
+                                        there (its Hessian mixes A A^T and A^T A) */
 } ilqg_cost_kind;
 
 /* Where a term sits inside PlayerCost::Quadraticize (src/player_cost.cpp:194-215):
@@ -219,6 +227,9 @@ typedef enum {
 
 #define ILQG_FLAG_ORIENTED 1 /* oriented_right / keep_within / keep_below / less_is_positive */
 #define ILQG_FLAG_IS_MIN 2   /* ExtremeValueCost::is_min_ */
+#define ILQG_FLAG_EQUALITY 4 /* Constraint::is_equality_ (constraint.h:74-76,98-117): no inactive-constraint gate on mu, the
+                                multiplier is not clipped at zero.  The affine constraints take it; the reference's other
+                                constraints are inequalities by construction. */
 
 typedef struct {
   int32_t kind;        /* ilqg_cost_kind                                       */
@@ -281,6 +292,8 @@ typedef struct {
   double dt;                       /* time::kTimeStep     (types.h:135)      */
   int32_t dtype;                   /* ilqg_dtype of state/gain arithmetic    */
   ilqg_solver_params params;
+  int32_t num_dense_params;        /* coefficients of the affine constraints  */
+  const float* dense_params;       /* host array (may be NULL when there are none) */
 } ilqg_problem_desc;
 
 void ilqg_default_solver_params(ilqg_solver_params* p);
@@ -407,7 +420,7 @@ typedef struct {
                                      a tail (doubling every round up to 32, as many as the pool holds); 0 = the library's
                                      choice.  Same decisions whatever the value.                                       */
   int32_t single_wave_sweep;    /* ilqg_choice: the one-tile feedback sweep with one wave per instance (twice the instances
-                                     per CU; the library picks it for batches of eight or more instances per CU)          */
+                                     per CU; the library picks it for batches of five or more instances per CU)           */
   int32_t reserved[1];
   const struct ilqg_iterate_log* iterate_log; /* NULL, or where every logged iterate of the solve goes (below)          */
   double max_runtime;           /* > 0: the anytime exit of ILQSolver::Solve (src/ilq_solver.cpp:123-124) on the host's

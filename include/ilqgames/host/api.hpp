@@ -89,6 +89,7 @@ struct TermDescription {
   ilqg_cost_term term{};                            // kind, idx, weight, value, flags
   const Polyline2* polyline = nullptr;              // for *_POLYLINE2 kinds
   std::vector<std::shared_ptr<const Cost>> children;  // EXTREME_VALUE
+  std::vector<float> dense;                         // affine constraints: their coefficient block (ilqg.h)
 };
 }  // namespace host
 
@@ -485,6 +486,33 @@ class SingleDimensionConstraint : public TimeInvariantConstraint {
   Dimension dim_;
   float threshold_;
   bool keep_below_;
+};
+
+// include/ilqgames/constraint/affine_scalar_constraint.h:54-100 — g(x) = a^T x - b on the whole input vector.
+class AffineScalarConstraint : public TimeInvariantConstraint {
+ public:
+  AffineScalarConstraint(const VectorXf& a, float b, bool is_equality, const std::string& name = "")
+      : TimeInvariantConstraint(is_equality, name), a_(a), b_(b) {}
+  bool Describe(host::TermDescription* out) const override;
+
+ private:
+  const VectorXf a_;
+  const float b_;
+};
+
+// include/ilqgames/constraint/affine_vector_constraint.h:52-112 — g(x) = |A x - b|, A square (its Quadraticize CHECKs
+// input.size() == b.size()).
+class AffineVectorConstraint : public TimeInvariantConstraint {
+ public:
+  AffineVectorConstraint(const MatrixXf& A, const VectorXf& b, bool is_equality, const std::string& name = "")
+      : TimeInvariantConstraint(is_equality, name), A_(A), b_(b) {
+    CHECK_EQ(A_.rows(), b_.size());
+  }
+  bool Describe(host::TermDescription* out) const override;
+
+ private:
+  const MatrixXf A_;
+  const VectorXf b_;
 };
 
 // include/ilqgames/constraint/polyline2_signed_distance_constraint.h:57-91 — g = signed distance to the polyline
@@ -1022,6 +1050,7 @@ struct ProblemDescription {
   std::vector<float> polyline_points;
   std::vector<ilqg_pair> pairs;  // (i, j) control blocks in PlayerCost first-touch order
   int num_constraints = 0;
+  std::vector<float> dense_params;  // coefficient blocks of the affine constraints
 };
 
 // Walks Problem::Dynamics() and Problem::PlayerCosts() (after Initialize()) and fills the POD

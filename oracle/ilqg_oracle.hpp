@@ -335,8 +335,10 @@ struct Problem {
   int Rsz = 0, rsz = 0;
   int num_constraints = 0;
   ilqg_solver_params params;
+  std::vector<float> dense;  // coefficients of the affine constraints (ilqg_problem_desc::dense_params)
 
   explicit Problem(const ilqg_problem_desc& d) {
+    if (d.num_dense_params > 0 && d.dense_params) dense.assign(d.dense_params, d.dense_params + d.num_dense_params);
     N = d.num_players;
     T = d.T;
     dt = d.dt;
@@ -681,8 +683,8 @@ void Linearize(const Problem<S>& p, const Vec<S>& x, const Vec<S>& u, Mat<S>* A,
 // ---------------------------------------------------------------------------
 // Constraint::Mu(lambda, g), constraint.h:112-117
 template <class S>
-inline S ConstraintMu(S lambda, S g, S mu) {
-  if (g <= S(1e-4f) && std::abs(lambda) <= S(1e-4f)) return S(0);  // all in-scope constraints are inequalities
+inline S ConstraintMu(S lambda, S g, S mu, bool is_equality = false) {
+  if (!is_equality && g <= S(1e-4f) && std::abs(lambda) <= S(1e-4f)) return S(0);
   return mu;
 }
 
@@ -844,6 +846,24 @@ S EvaluateTerm(const Problem<S>& p, int ti, const S* v, int dim, int step = 0) {
     }
     case ILQG_CONSTRAINT_SINGLE_DIMENSION:  // single_dimension_constraint.h:68-70
       return oriented ? v[c.idx[0]] - val : val - v[c.idx[0]];
+    case ILQG_CONSTRAINT_AFFINE_SCALAR: {  // affine_scalar_constraint.h:63-66: a^T x - b
+      const float* a = p.dense.data() + c.polyline;
+      S s = S(0);
+      for (int i = 0; i < dim; i++) s += S(a[i]) * v[i];
+      return s - S(a[dim]);
+    }
+    case ILQG_CONSTRAINT_AFFINE_VECTOR: {  // affine_vector_constraint.h:70-73: |A x - b|
+      const float* A = p.dense.data() + c.polyline;
+      const float* b = A + dim * dim;
+      S sq = S(0);
+      for (int i = 0; i < dim; i++) {
+        S d = S(0);
+        for (int j = 0; j < dim; j++) d += S(A[i + dim * j]) * v[j];
+        d -= S(b[i]);
+        sq += d * d;
+      }
+      return std::sqrt(sq);
+    }
   }
   return S(0);
 }
@@ -1097,6 +1117,55 @@ void QuadraticizeTerm(const Problem<S>& p, int ti, double t, const S* v, int dim
       ModifyDerivatives(lambda, mu, g, &dx, &ddx);
       G[d] += dx;
       H(d, d) += ddx;
+      return;
+    }
+    case ILQG_CONSTRAINT_AFFINE_SCALAR: {  // affine_scalar_constraint.h:70-88
+      // grad += lambda a + mu (hess_of_sq x - b a), hess += mu hess_of_sq, hess_of_sq = a a^T formed in the
+      // constructor (a matrix of the reference's scalars: every product a_i a_j is rounded before it meets x)
+      const float* a = p.dense.data() + c.polyline;
+      const S b = S(a[dim]);
+      const S g = EvaluateTerm(p, ti, v, dim);
+      const S lambda = al ? al->lambda(c.constraint_slot, t) : S(0);
+      const S mu = ConstraintMu(lambda, g, al ? al->mu : S(10), (c.flags & ILQG_FLAG_EQUALITY) != 0);
+      for (int i = 0; i < dim; i++) {
+        S hx = S(0);
+        for (int j = 0; j < dim; j++) hx += S(S(a[i]) * S(a[j])) * v[j];
+        G[i] += lambda * S(a[i]) + mu * (hx - b * S(a[i]));
+        for (int j = 0; j < dim; j++) H(i, j) += mu * S(S(a[i]) * S(a[j]));
+      }
+      return;
+    }
+    case ILQG_CONSTRAINT_AFFINE_VECTOR: {  // affine_vector_constraint.h:77-101, as written there
+      const float* A = p.dense.data() + c.polyline;
+      const float* b = A + dim * dim;
+      Vec<S> delta(dim), atd(dim);
+      S sq = S(0);
+      for (int i = 0; i < dim; i++) {
+        S d = S(0);
+        for (int j = 0; j < dim; j++) d += S(A[i + dim * j]) * v[j];
+        delta[i] = d - S(b[i]);
+        sq += delta[i] * delta[i];
+      }
+      const S value = std::sqrt(sq);
+      for (int i = 0; i < dim; i++) {  // A^T delta
+        S d = S(0);
+        for (int j = 0; j < dim; j++) d += S(A[j + dim * i]) * delta[j];
+        atd[i] = d;
+      }
+      const S lambda = al ? al->lambda(c.constraint_slot, t) : S(0);
+      const S mu = ConstraintMu(lambda, value, al ? al->mu : S(10), (c.flags & ILQG_FLAG_EQUALITY) != 0);
+      const S lv = lambda / value;
+      for (int i = 0; i < dim; i++) {
+        G[i] += (mu + lv) * atd[i];
+        for (int j = 0; j < dim; j++) {
+          S ata = S(0), aat = S(0);  // ATA_ = A^T A, AAT_ = A A^T (constructor; :60-61)
+          for (int q = 0; q < dim; q++) {
+            ata += S(A[q + dim * i]) * S(A[q + dim * j]);
+            aat += S(A[i + dim * q]) * S(A[j + dim * q]);
+          }
+          H(i, j) += lv * (aat - atd[i] * atd[j] / (value * value)) + mu * ata;
+        }
+      }
       return;
     }
     case ILQG_COST_ORIENTATION: {  // src/orientation_cost.cpp:60-80
@@ -1800,7 +1869,7 @@ bool SolveAL(const Problem<S>& p, const Vec<S>& x0, Trajectory<S>* op_io, Strate
                                 : EvaluateTerm(p, (int)ti, &res_op.us[k][p.uoff[c.arg]], p.udim(c.arg));
               max_err = std::max(max_err, err);
               S& lam = al.lambda(c.constraint_slot, t);  // Constraint::IncrementLambda, constraint.h:98-102
-              lam = std::max(S(0), lam + al.mu * err);
+              lam = (c.flags & ILQG_FLAG_EQUALITY) ? lam + al.mu * err : std::max(S(0), lam + al.mu * err);
             }
         }
       al.mu *= S(p.params.geometric_mu_scaling);  // :143

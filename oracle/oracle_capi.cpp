@@ -137,6 +137,7 @@ struct OracleProblem {
   std::vector<ilqg_cost_term> terms;
   std::vector<int32_t> poly_off;
   std::vector<float> poly_pts;
+  std::vector<float> dense;
   ilqg_problem_desc desc;
   std::unique_ptr<Problem<float>> pf;
   std::unique_ptr<Problem<double>> pd;
@@ -504,6 +505,8 @@ void* oracle_problem_create(const ilqg_problem_desc* desc) {
   const int npts = desc->num_polylines ? desc->polyline_offsets[desc->num_polylines] : 0;
   op->poly_pts.assign(desc->polyline_points, desc->polyline_points + 2 * npts);
   op->desc = *desc;
+  op->dense.assign(desc->dense_params, desc->dense_params + (desc->dense_params ? desc->num_dense_params : 0));
+  op->desc.dense_params = op->dense.data();
   op->desc.terms = op->terms.data();
   op->desc.polyline_offsets = op->poly_off.data();
   op->desc.polyline_points = op->poly_pts.data();
@@ -688,7 +691,7 @@ double oracle_player_value(void* h, int player, const double* x, const double* u
         g = EvaluateTerm(p, (int)ti, &uv[p.uoff[t.arg]], p.udim(t.arg));
       else
         continue;
-      v += lambda * g + 0.5 * ConstraintMu(lambda, g, mu) * g * g;
+      v += lambda * g + 0.5 * ConstraintMu(lambda, g, mu, (t.flags & ILQG_FLAG_EQUALITY) != 0) * g * g;
     }
   return v;
 }

@@ -41,12 +41,17 @@ def test_full_batch_instances_are_independent(hip, dtype, B):
     K = 4
     x0 = examples.jittered_x0(spec, B, seed=77)
     prob = hip.Problem(spec, dtype)
+    # Which of its two one-tile feedback sweeps the library runs is a function of the batch size (the single-wave form
+    # from five instances per CU on, ilqg_solve_options::single_wave_sweep): two schedules of one recursion that agree to
+    # rounding, not bit for bit — so the slice is solved with the schedule the full batch ran.  Everything else the
+    # library decides from the batch size (split passes, hand-off, probing, priorities) is bit-identical by construction.
+    single = B >= 5 * hip.device_info()[1]
     full = {k: _np(v).copy() for k, v in prob.solve(x0, fixed_iters=K).items() if k in KEYS}
     assert np.isfinite(full["xs"]).all() and np.isfinite(full["P"]).all()
     assert np.all(full["iters"] == K) and set(full["status"].tolist()) <= {0, 1}
     # a slice of the batch solved on its own
     lo, hi = B // 3, B // 3 + 37
-    part = prob.solve(x0[lo:hi], fixed_iters=K)
+    part = prob.solve(x0[lo:hi], fixed_iters=K, single_wave_sweep=single)
     for k in KEYS:
         assert np.array_equal(_np(part[k]), full[k][lo:hi]), k
     # the whole batch in another order
@@ -146,6 +151,9 @@ def test_full_batch_receding_horizon_step_is_per_instance_fp64(hip):
     B = 2048
     x0 = examples.jittered_x0(spec, B, seed=31)
     prob = hip.Problem(spec, abi.F64)
+    # the sweep's schedule is a function of the batch size and the two schedules agree to rounding only: pinned to what
+    # the full batch runs by itself, for the slice too (test_full_batch_instances_are_independent)
+    prob.single_wave_sweep = B >= 5 * hip.device_info()[1]
 
     def step(x0_part):
         b = x0_part.shape[0]
@@ -192,6 +200,7 @@ def test_config5_as_written_full_size_fp64(hip):
     B, calls, probe_at = 2048, 200, 39
     x0 = examples.jittered_x0(spec, B, seed=5)
     prob = hip.Problem(spec, abi.F64)
+    prob.single_wave_sweep = B >= 5 * hip.device_info()[1]  # one schedule of the sweep for the batch and its slice
     trace, snap = [], {}
 
     def on_record(r, info):

@@ -1,5 +1,5 @@
 """GPU parity of the single-wave feedback sweep (ilqgames_amd/csrc/ilqg_lq_feedback1w.hpp): the throughput form the
-library picks for batches of eight or more instances per CU, forced here onto small batches
+library picks for batches of five or more instances per CU, forced here onto small batches
 (ilqg_solve_options::single_wave_sweep = ON).  Same recursion and the same order of operations per player as the
 player-parallel sweep, so: against the oracle after every forced-step iteration (1e-9 fp64, fp32 tolerances of
 test_gpu_forced.py), against the player-parallel sweep itself on a free-running solve (same line-search decisions), and

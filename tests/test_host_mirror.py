@@ -157,9 +157,8 @@ def test_reference_example_source_compiles_unchanged_and_flattens_like_examples_
 def test_every_reference_header_path_resolves_in_the_mirror(tmp_path):
     """A translation unit written for the reference keeps its #include lines: every header of the reference's
     include/ilqgames tree has a counterpart at the same path, except the GUI, the internal utilities no problem
-    definition includes, and the classes DESIGN.md section 6 lists as not built (flat systems, affine constraints)."""
-    not_mirrored = {"constraint/affine_scalar_constraint.h", "constraint/affine_vector_constraint.h",
-                    "dynamics/concatenated_flat_system.h", "dynamics/multi_player_flat_system.h",
+    definition includes, and the classes DESIGN.md section 6 lists as not built (the flat systems)."""
+    not_mirrored = {"dynamics/concatenated_flat_system.h", "dynamics/multi_player_flat_system.h",
                     "dynamics/single_player_flat_car_6d.h", "dynamics/single_player_flat_system.h",
                     "dynamics/single_player_flat_unicycle_4d.h", "examples/flat_roundabout_merging_example.h",
                     "examples/three_player_flat_intersection_example.h", "examples/three_player_flat_overtaking_example.h",

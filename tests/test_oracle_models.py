@@ -220,6 +220,12 @@ COST_BUILDERS = {
     "route_progress": lambda s: s.route_progress(0, 1.0, 0.1, s.add_polyline([(-2.0, -2.0), (0.5, 1.0), (2.0, 2.0)]),
                                                  (0, 1)),
     "route_progress_from_2m": lambda s: s.route_progress(0, 3.0, 20.0, s.add_polyline(LANE), (0, 1), 2.0),
+    # test_quadraticization.cpp:305-316: AffineScalarConstraint(LinSpaced(10, -1, 1), 0.5, false) and
+    # AffineVectorConstraint(10 * Random(10, 10), Random(10), false) — dense constraints on the whole input vector
+    "affine_scalar_constraint": lambda s: s.affine_scalar_constraint(0, np.linspace(-1.0, 1.0, 10), 0.5),
+    "affine_vector_constraint": lambda s: s.affine_vector_constraint(
+        0, 10.0 * np.random.default_rng(7).uniform(-1, 1, (10, 10)), np.random.default_rng(8).uniform(-1, 1, 10)),
+    "affine_scalar_constraint_equality": lambda s: s.affine_scalar_constraint(0, np.linspace(-1.0, 1.0, 10), 0.5, True),
 }
 
 
