@@ -654,7 +654,7 @@ def cost_zoo_scene(T=100, dt=0.1):
 
 # coefficients of affine_constraint_scene (its C++ twin: tests/host/zoo_scene.h)
 AFFINE_A_U = [[1.0, 0.3], [-0.2, 1.0]]
-AFFINE_B_U = [0.05, 0.1]
+AFFINE_B_U = [2.0, 3.0]
 
 
 def affine_constraint_scene(T=100, dt=0.1):
@@ -662,16 +662,18 @@ def affine_constraint_scene(T=100, dt=0.1):
     DENSE constraints (constraint/affine_scalar_constraint.h, affine_vector_constraint.h; its tests only run their
     quadraticisation, test/test_quadraticization.cpp:305-316): player 1 stays behind a line in the (px1, px2) plane
     (an inequality a^T x <= b on the whole state), player 2 keeps its heading tied to its speed (an EQUALITY
-    a^T x = b), and player 1's controls are held at A u = b by an AffineVectorConstraint on its control vector."""
+    a^T x = b), and player 1's controls are drawn to A u = b by an AffineVectorConstraint on its control vector (b
+    far enough from zero that |A u - b| stays away from its singularity at 0).  Convex costs and the regularisation
+    of the n = 14 example keep free-running solves of jittered instances well conditioned."""
     prm = SolverParams.default()
     prm.max_backtracking_steps = 100
     prm.initial_alpha_scaling = 0.1
-    prm.convergence_tolerance = 0.01
+    prm.convergence_tolerance = 0.1
     prm.expected_decrease_fraction = 0.001
     prm.max_solver_iters = 30
     s = ProblemSpec(T, dt, prm)
     for _ in range(2):
-        s.add_player(DYN_CAR_5D, 4.0, state_reg=1.0, control_reg=5.0)
+        s.add_player(DYN_CAR_5D, 4.0, state_reg=10.0, control_reg=10.0)
     X, Y, H, PHI, V = [0, 5], [1, 6], [2, 7], [3, 8], [4, 9]
     lane1 = s.add_polyline([(0.0, -1000.0), (0.0, 1000.0)])
     lane2 = s.add_polyline([(-1000.0, 2.0), (1000.0, 2.0)])
@@ -681,8 +683,6 @@ def affine_constraint_scene(T=100, dt=0.1):
         s.quadratic(i, 10.0, V[i], 6.0)
     s.quadratic_polyline2(0, 25.0, lane1, (X[0], Y[0]))
     s.quadratic_polyline2(1, 25.0, lane2, (X[1], Y[1]))
-    s.proximity(0, 30.0, (X[0], Y[0]), (X[1], Y[1]), 5.0)
-    s.proximity(1, 30.0, (X[1], Y[1]), (X[0], Y[0]), 5.0)
     a1 = [0.0] * 10
     a1[X[0]], a1[X[1]] = 1.0, -0.25
     s.affine_scalar_constraint(0, a1, 6.0)                      # px1 - 0.25 px2 <= 6

@@ -65,6 +65,55 @@ class CostZooScene : public TopDownRenderableProblem {
   std::vector<float> Thetas(const VectorXf& x) const override { return {x(2), x(7)}; }
 };
 
+// ilqgames_amd/examples.py::affine_constraint_scene — two Car5D with the reference's two dense constraints
+// (AffineScalarConstraint as an inequality and as an equality on the state, AffineVectorConstraint on a control vector).
+class AffineConstraintScene : public TopDownRenderableProblem {
+ public:
+  using Car = SinglePlayerCar5D;
+  void ConstructDynamics() override {
+    dynamics_.reset(new ConcatenatedDynamicalSystem({std::make_shared<Car>(4.0f), std::make_shared<Car>(4.0f)}));
+  }
+  void ConstructInitialState() override {
+    x0_ = VectorXf::Zero(dynamics_->XDim());
+    x0_(Car::kPyIdx) = -25.0f;
+    x0_(Car::kThetaIdx) = static_cast<float>(M_PI_2);
+    x0_(Car::kVIdx) = 5.0f;
+    x0_(5 + Car::kPxIdx) = -30.0f;
+    x0_(5 + Car::kPyIdx) = 2.0f;
+    x0_(5 + Car::kVIdx) = 5.0f;
+  }
+  void ConstructPlayerCosts() override {
+    player_costs_.emplace_back("car1", 10.0f, 10.0f);
+    player_costs_.emplace_back("car2", 10.0f, 10.0f);
+    const auto xy = [](PlayerIndex ii) { return std::make_pair(Dimension(5 * ii + Car::kPxIdx), Dimension(5 * ii + Car::kPyIdx)); };
+    const Polyline2 lane1({Point2(0.0, -1000.0), Point2(0.0, 1000.0)});
+    const Polyline2 lane2({Point2(-1000.0, 2.0), Point2(1000.0, 2.0)});
+    for (PlayerIndex ii = 0; ii < 2; ii++) {
+      PlayerCost& cost = player_costs_[ii];
+      cost.AddControlCost(ii, std::make_shared<QuadraticCost>(10.0f, Car::kOmegaIdx, 0.0f, "steer"));
+      cost.AddControlCost(ii, std::make_shared<QuadraticCost>(5.0f, Car::kAIdx, 0.0f, "accelerate"));
+      cost.AddStateCost(std::make_shared<QuadraticCost>(10.0f, 5 * ii + Car::kVIdx, 6.0f, "cruise"));
+    }
+    player_costs_[0].AddStateCost(std::make_shared<QuadraticPolyline2Cost>(25.0f, lane1, xy(0), "lane"));
+    player_costs_[1].AddStateCost(std::make_shared<QuadraticPolyline2Cost>(25.0f, lane2, xy(1), "lane"));
+    VectorXf a1 = VectorXf::Zero(10), a2 = VectorXf::Zero(10);
+    a1(Car::kPxIdx) = 1.0f;
+    a1(5 + Car::kPxIdx) = -0.25f;
+    a2(5 + Car::kThetaIdx) = 1.0f;
+    a2(5 + Car::kVIdx) = -0.01f;
+    player_costs_[0].AddStateConstraint(std::make_shared<AffineScalarConstraint>(a1, 6.0f, false, "behind the line"));
+    player_costs_[1].AddStateConstraint(std::make_shared<AffineScalarConstraint>(a2, -0.06f, true, "heading tied to speed"));
+    MatrixXf A = MatrixXf::Zero(2, 2);
+    A(0, 0) = 1.0f; A(0, 1) = 0.3f; A(1, 0) = -0.2f; A(1, 1) = 1.0f;
+    VectorXf b = VectorXf::Zero(2);
+    b(0) = 2.0f; b(1) = 3.0f;
+    player_costs_[0].AddControlConstraint(0, std::make_shared<AffineVectorConstraint>(A, b, false, "controls drawn to A u = b"));
+  }
+  std::vector<float> Xs(const VectorXf& x) const override { return {x(0), x(5)}; }
+  std::vector<float> Ys(const VectorXf& x) const override { return {x(1), x(6)}; }
+  std::vector<float> Thetas(const VectorXf& x) const override { return {x(2), x(7)}; }
+};
+
 // ilqgames_amd/examples.py::weighted_proximity_scene — the skeleton example with WeightedConvexProximityCost.
 class WeightedProximityScene : public TopDownRenderableProblem {
  public:

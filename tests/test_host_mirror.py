@@ -186,6 +186,7 @@ def test_every_reference_header_path_resolves_in_the_mirror(tmp_path):
 
 
 @pytest.mark.parametrize("cls,builder,nc", [("CostZooScene", examples.cost_zoo_scene, 2),
+                                            ("AffineConstraintScene", examples.affine_constraint_scene, 3),
                                             ("WeightedProximityScene", examples.weighted_proximity_scene, 0),
                                             ("DynamicsZooScene", examples.dynamics_zoo_scene, 0),
                                             ("DelayedDubinsScene", examples.delayed_dubins_scene, 0)])
