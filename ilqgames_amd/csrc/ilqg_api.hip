@@ -450,11 +450,14 @@ __global__ void __launch_bounds__(64) ilq_exit_kernel(DevProblem p, SolveArgs<T>
 // sweep is three registers over that by itself, and at batches of many instances per CU a fifth resident instance is
 // worth more than the two spilled registers cost (n = 14 fp32, B = 8192: 2.15 M vs 2.04 M it/s; B = 1024, where only
 // four instances per CU exist: 1.81 M vs 1.85 M — so the launcher picks it for large batches only).
+#ifndef ILQG_1W_WAVES_F64
+#define ILQG_1W_WAVES_F64 2
+#endif
 // KIND LQ_SINGLE_WAVE: one wave per instance (ilqg_lq_feedback1w.hpp), compiled for as many waves per SIMD as its LDS
 // lets a CU hold instances (fp64: 20 KB -> eight per CU, two per SIMD; fp32: 10 KB -> sixteen, four per SIMD).
 template <typename T, int NX, int NP, int MU, int KIND>
 __global__ void __launch_bounds__((KIND == LQ_SINGLE_WAVE ? 64 : KIND == LQ_VALU_FEEDBACK ? LQCfg<T, NX, NP, MU>::NT : ((KIND == LQ_OPEN_LOOP || KIND == LQ_OPEN_LOOP_COMPACT) ? OLCfg<T, NX, NP, MU>::NT : 64 * NP)),
-                                  (KIND == LQ_SINGLE_WAVE ? (sizeof(T) == 4 ? 4 : 2) : KIND == LQ_PLAYER_WAVES_PACKED ? 4 : KIND == LQ_PLAYER_WAVES ? (NX <= 16 ? NP : 2) : ((KIND == LQ_OPEN_LOOP || KIND == LQ_OPEN_LOOP_COMPACT) ? 3 : 1)))
+                                  (KIND == LQ_SINGLE_WAVE ? (sizeof(T) == 4 ? 4 : ILQG_1W_WAVES_F64) : KIND == LQ_PLAYER_WAVES_PACKED ? 4 : KIND == LQ_PLAYER_WAVES ? (NX <= 16 ? NP : 2) : ((KIND == LQ_OPEN_LOOP || KIND == LQ_OPEN_LOOP_COMPACT) ? 3 : 1)))
 ilq_lq_kernel(DevProblem p, SolveArgs<T> sa) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int b = blockIdx.x;
@@ -817,6 +820,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   // ilqg_solve_options::single_wave_sweep overrides the choice (same results to rounding).
   constexpr bool has_1w = W1Cfg<T, NX, NP, MU>::SUPPORTED && C::USE_MFMA && C::MFMA_ONE_TILE;
   const bool single_wave = has_1w && pw && sa.compact && sa.defer_forward && !kProfile &&
+                           d.rp_compact_w <= W1Cfg<T, NX, NP, MU>::kWords &&
                            choice(opt.single_wave_sweep, size_t(batch) >= size_t(5) * num_cus);
   auto k_lq = single_wave ? ilq_lq_kernel<T, NX, NP, MU, (has_1w ? LQ_SINGLE_WAVE : LQ_VALU_FEEDBACK)> : k_lq_multi;
   const int nt_lq = single_wave ? 64 : nt_lq_multi;

@@ -43,11 +43,18 @@ struct W1Cfg {
   static constexpr int oPt = IMG;               // [P | alpha] as a padded tile
   static constexpr int oAl = oPt + TILE;        // alpha (M, padded to 16)
   static constexpr int oYz = oAl + 16;          // y_zeta (M, padded to 16)
-  static constexpr int oSY = oYz + 16;          // [S | Y]: M x 32, column-major
-  static constexpr int oG = oSY + M * 32;       // per player: its MU columns of G = Z^T B, interleaved [row][aa]
-  static constexpr int oSB = oG + NP * MU * 16;  // staging row of the compact rows (the DMA's landing place)
-  static constexpr int oCD = oSB + kCompactMaxWords;  // where each word of a compact row goes in the image (ints)
-  static constexpr int CD_ELEMS = (kCompactMaxWords * 4 + int(sizeof(T)) - 1) / int(sizeof(T));
+  // [S | Y] (M x 32, column-major) shares the [P | alpha] tile's memory where it fits: the solve has its columns in
+  // registers before it writes P, and the next step's rows are written after the last read of P (one wave: its LDS
+  // operations execute in order)
+  static constexpr bool SY_IN_PT = M * 32 <= TILE;
+  static constexpr int oSY = SY_IN_PT ? oPt : oYz + 16;
+  static constexpr int oG = oYz + 16 + (SY_IN_PT ? 0 : M * 32);  // per player: its MU columns of G = Z^T B, interleaved [row][aa]
+  // compact rows of at most kWords words (three per lane of the scattering wave; the games with a spare tile column have
+  // 136 - 170): the staging row the DMA lands in, and where each of its words goes in the image (ints)
+  static constexpr int kWords = 192;
+  static constexpr int oSB = oG + NP * MU * 16;
+  static constexpr int oCD = oSB + kWords;
+  static constexpr int CD_ELEMS = (kWords * 4 + int(sizeof(T)) - 1) / int(sizeof(T));
   static constexpr int ELEMS = (oCD + CD_ELEMS + 3) & ~3;
   static constexpr bool SUPPORTED = NX < 16 && M <= 16 && C::NSOLVE <= 32 && NP <= 4;
 };
@@ -123,7 +130,7 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_1w(const LQArgs<T>& a,
   };
   auto request_row = [&](int k) { dma_g2l<64, false>(gC + size_t(k) * CWD, sSB, CWD * S, lane); };
   auto scatter_staged = [&]() {
-    constexpr int WPL = kCompactMaxWords / 64;
+    constexpr int WPL = W::kWords / 64;
     T v[WPL];
     int cd[WPL];
 #pragma unroll
@@ -149,7 +156,7 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_1w(const LQArgs<T>& a,
   // ---- zero the tile padding (and everything else the scatter does not write), once; the constants of the image ----
   for (int e = lane; e < W::ELEMS; e += 64) sm[e] = T(0);
   lds_sync(true);
-  for (int c = lane; c < kCompactMaxWords; c += 64) sCD[c] = c < CWD ? cdecode(ctab[c]) : -1;
+  for (int c = lane; c < W::kWords; c += 64) sCD[c] = c < CWD ? cdecode(ctab[c]) : -1;
   {
     const int nbg = a.compact_tab[RC_NBG];
     const int* bg = ctab + CWD;
@@ -232,6 +239,8 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_1w(const LQArgs<T>& a,
     lds_sync(true);
 
     // ---- column `lane` of [S | Y]: Gershgorin (:163-176), then the M x M solve (:180) ----
+    // (Measured and dropped: keeping the column in the registers of the lane that forms it, player after player — no LDS
+    // trip for the Nash system — holds M more values across the row products: 186 -> 256 VGPRs and 320 B of scratch.)
     {
       T col[M], x[M];
       const bool isS = lane < M;
