@@ -107,10 +107,12 @@ class HipBackend:
     probe_first = 0  # ilqg_solve_options::probe_first: 0 = the library's choice
     single_wave = None  # ilqg_solve_options::single_wave_sweep: None = the library's choice
     split_trial = None  # ilqg_solve_options::split_trial: None = the library's choice
+    adjoint = None      # ilqg_solve_options::adjoint_expected_decrease
 
     def solve(self, x0, bufs, iters):
         self.prob.solve(x0, bufs, fixed_iters=iters, counted=self.counted, probe_first=self.probe_first,
-                        single_wave_sweep=self.single_wave, split_trial=self.split_trial)
+                        single_wave_sweep=self.single_wave, split_trial=self.split_trial,
+                        adjoint_expected_decrease=self.adjoint)
 
     def sync(self):
         self.torch.cuda.synchronize()
@@ -216,6 +218,8 @@ def main():
                     help="skip the single-instance ms/solve figure (profiling runs: keeps the kernel statistics to the batch)")
     ap.add_argument("--single-wave", choices=["auto", "on", "off"], default="auto",
                     help="ilqg_solve_options::single_wave_sweep (A/B measurements)")
+    ap.add_argument("--adjoint", choices=["auto", "on", "off"], default="auto",
+                    help="ilqg_solve_options::adjoint_expected_decrease (A/B measurements)")
     ap.add_argument("--split-trial", choices=["auto", "on", "off"], default="auto",
                     help="ilqg_solve_options::split_trial (A/B measurements)")
     ap.add_argument("--probe-first", type=int, default=0,
@@ -245,6 +249,7 @@ def main():
     backend.probe_first = args.probe_first
     backend.single_wave = {"auto": None, "on": True, "off": False}[args.single_wave]
     backend.split_trial = {"auto": None, "on": True, "off": False}[args.split_trial]
+    backend.adjoint = {"auto": None, "on": True, "off": False}[args.adjoint]
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

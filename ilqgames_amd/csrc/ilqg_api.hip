@@ -343,8 +343,11 @@ __global__ void __launch_bounds__(64 * W, (sizeof(T) == 4 && W == 2) ? 3 : W) il
 
 // The same pass cut into three launches (ilqg_solve.hpp, TRIAL_ROLL / rows_part_instance / TRIAL_DECIDE), for
 // problems whose fused trial kernel fits fewer than three instances on a CU.
+#ifndef ILQG_ROLL_WAVES
+#define ILQG_ROLL_WAVES 1
+#endif
 template <typename T, int NX, int NP, int MU>
-__global__ void __launch_bounds__(64) ilq_roll_kernel(DevProblem p, SolveArgs<T> sa) {
+__global__ void __launch_bounds__(64, ILQG_ROLL_WAVES) ilq_roll_kernel(DevProblem p, SolveArgs<T> sa) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int b = sa.ids ? sa.ids[blockIdx.x] : int(blockIdx.x);
   if (!sa.first) {
@@ -819,13 +822,19 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   // 1.68); it reads compact rows and leaves the forward pass to the trial kernel.
   // ilqg_solve_options::single_wave_sweep overrides the choice (same results to rounding).
   constexpr bool has_1w = W1Cfg<T, NX, NP, MU>::SUPPORTED && C::USE_MFMA && C::MFMA_ONE_TILE;
-  const bool single_wave = has_1w && pw && sa.compact && sa.defer_forward && !kProfile &&
+  // Where the expected decrease of a single-wave sweep comes from: its own adjoint recursion, or — only possible with the
+  // fused trial kernel, whose row wave runs it — the deferred forward pass over the sweep's scratch rows.
+  const bool adjoint = choice(opt.adjoint_expected_decrease, sa.defer_forward == 0);
+  const bool single_wave = has_1w && pw && sa.compact && !kProfile && (adjoint || sa.defer_forward) &&
                            d.rp_compact_w <= W1Cfg<T, NX, NP, MU>::kWords &&
                            choice(opt.single_wave_sweep, size_t(batch) >= size_t(5) * num_cus);
   auto k_lq = single_wave ? ilq_lq_kernel<T, NX, NP, MU, (has_1w ? LQ_SINGLE_WAVE : LQ_VALU_FEEDBACK)> : k_lq_multi;
   const int nt_lq = single_wave ? 64 : nt_lq_multi;
-  const size_t lds_lq = single_wave ? size_t(W1Cfg<T, NX, NP, MU>::ELEMS) * sizeof(T) : lds_lq_multi;
-  if (single_wave) sa.prio_div = 0;
+  const size_t lds_lq = single_wave ? size_t(W1Cfg<T, NX, NP, MU>::ELEMS + 4) * sizeof(T) : lds_lq_multi;
+  if (single_wave) {
+    sa.prio_div = 0;
+    if (adjoint) sa.defer_forward = 0;  // the sweep forms the expected decrease itself: no forward pass anywhere
+  }
   raise_lds_limit((const void*)k_lq, lds_lq);
   long long cap = al_mode ? (long long)(sa.prm.max_solver_iters + 1) * (sa.prm.unconstrained_solver_max_iters + 2)
                           : (long long)sa.prm.max_solver_iters + 2;
@@ -1856,7 +1865,8 @@ ilqg_status ilqg_solve_batch_ex(ilqg_problem* p, int32_t batch, const void* x0, 
     return fail(ILQG_ERR_INVALID, "forced_steps needs fixed_iters > 0 and no augmented-Lagrangian loop");
   if (o.max_runtime > 0.0 && (o.fixed_iters > 0 || o.forced_steps))
     return fail(ILQG_ERR_INVALID, "max_runtime needs a free-running solve (fixed_iters = 0, no forced steps)");
-  if (o.single_wave_sweep < ILQG_CHOICE_AUTO || o.single_wave_sweep > ILQG_CHOICE_ON)
+  if (o.single_wave_sweep < ILQG_CHOICE_AUTO || o.single_wave_sweep > ILQG_CHOICE_ON ||
+      o.adjoint_expected_decrease < ILQG_CHOICE_AUTO || o.adjoint_expected_decrease > ILQG_CHOICE_ON)
     return fail(ILQG_ERR_INVALID, "scheduling choices are ilqg_choice values");
   if (o.probe_first < 0 || o.probe_first > 1024) return fail(ILQG_ERR_INVALID, "probe_first: 0 (the library's choice) or a count");
   for (int32_t c : {o.split_trial, o.handoff, o.probe, o.counted})

@@ -18,6 +18,15 @@
 // results to rounding; the forced-step parity tests run both).  Only what the solver's LQ part needs is built: compact
 // rows in (LQArgs::compact), symmetric costs, zeta riding in the spare tile column (n < 16), the forward pass deferred
 // to the next trial pass (scratch rows out).
+// ILQSolver::ExpectedDecrease (src/ilq_solver.cpp:364-398) without a forward pass.  The reference sums
+// -sum_k sum_i [alpha_i,k^T R_ii r_ii + [k > 0] dx_k^T Q_i l_i] over the delta_x of LQFeedbackSolver's forward pass
+// (dx_0 = 0, dx_{k+1} = A_k dx_k + beta_k, beta_k = -sum B_i alpha_i: lq_feedback_solver.cpp:217-241) — a recursion that
+// runs forwards in time, after a sweep that runs backwards.  With q_k = sum_i Q_i,k l_i,k and dx_k = sum_{j<k} A_{k-1} ..
+// A_{j+1} beta_j, the state part is  sum_k q_k^T dx_k = sum_j beta_j^T mu_{j+1},  mu_k = q_k + A_k^T mu_{k+1}, mu_T = 0:
+// an ADJOINT recursion that runs backwards, i.e. inside the sweep — one n-term product per lane and step more, no second
+// pass over the horizon, no scratch rows, no delta_x (which only ever feeds this sum).  Same value up to the order of
+// summation (the tests hold it to 1e-9 of the reference's order in fp64).  LQArgs::ed_out selects it; with
+// LQArgs::defer_forward the scratch rows of the trial kernel's forward pass are written instead.
 // Reference: LQFeedbackSolver::Solve, src/lq_feedback_solver.cpp:110-213.
 #pragma once
 
@@ -55,7 +64,10 @@ struct W1Cfg {
   static constexpr int oSB = oG + NP * MU * 16;
   static constexpr int oCD = oSB + kWords;
   static constexpr int CD_ELEMS = (kWords * 4 + int(sizeof(T)) - 1) / int(sizeof(T));
-  static constexpr int ELEMS = (oCD + CD_ELEMS + 3) & ~3;
+  // ExpectedDecrease by the adjoint recursion (below): Q_i l_i of every player (NP x 16), mu (two buffers of 16)
+  static constexpr int oQL = (oCD + CD_ELEMS + 3) & ~3;
+  static constexpr int oMu = oQL + NP * 16;
+  static constexpr int ELEMS = (oMu + 32 + 3) & ~3;
   static constexpr bool SUPPORTED = NX < 16 && M <= 16 && C::NSOLVE <= 32 && NP <= 4;
 };
 
@@ -106,6 +118,11 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_1w(const LQArgs<T>& a,
   T* const sG0 = sm + W::oG;
   T* const sSB = sm + W::oSB;
   int* const sCD = reinterpret_cast<int*>(sm + W::oCD);
+  T* const sQL = sm + W::oQL;
+  T* const sMu = sm + W::oMu;
+  const bool adj = a.ed_out != nullptr;  // ExpectedDecrease by the adjoint recursion, in this sweep
+  T ed = T(0);
+  int mub = 0;  // which half of sMu holds mu_{k+1}
 
   // compact rows: array << 24 | offset in the array's row  ->  offset inside the image
   auto cdecode = [&](int code) -> int {
@@ -149,7 +166,26 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_1w(const LQArgs<T>& a,
       T s = T(0);
 #pragma unroll
       for (int c = 0; c < NX; c++) s += tQi[j + LD * c] * sl[g * NX + c];
-      a.scratch[size_t(k) * SCR + g * NX + j] = s;
+      if (adj)
+        sQL[g * 16 + j] = s;
+      else
+        a.scratch[size_t(k) * SCR + g * NX + j] = s;
+    }
+  };
+  // mu <- q + A^T mu (q = sum_i Q_i l_i from sQL; A of the image; `first`: mu = q): lanes < NX, into the other half
+  auto adjoint_step = [&](bool first) {
+    if (lane < NX) {
+      T q = T(0);
+#pragma unroll
+      for (int i = 0; i < NP; i++) q += sQL[i * 16 + lane];
+      if (!first) {
+        const T* mu = sMu + mub * 16;
+        T s = T(0);
+#pragma unroll
+        for (int c = 0; c < NX; c++) s += tA[c + LD * lane] * mu[c];
+        q += s;
+      }
+      sMu[(1 - mub) * 16 + lane] = q;
     }
   };
 
@@ -184,8 +220,14 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_1w(const LQArgs<T>& a,
   stash_ql(Tn - 1);
   for (int e = lane; e < M * NX; e += 64) a.P[size_t(Tn - 1) * M * NX + e] = T(0);  // strategy.h:64-70
   if (lane < M) a.alpha[size_t(Tn - 1) * M + lane] = T(0);
-  if (lane < NP) a.scratch[size_t(Tn - 1) * SCR + NP * NX + lane] = T(0);
-  if (lane < NX) a.scratch[size_t(Tn - 1) * SCR + NP * (NX + 1) + lane] = T(0);
+  if (adj) {
+    lds_sync(true);
+    adjoint_step(true);  // mu_{T-1} = q_{T-1}
+    mub = 1 - mub;
+  } else {
+    if (lane < NP) a.scratch[size_t(Tn - 1) * SCR + NP * NX + lane] = T(0);
+    if (lane < NX) a.scratch[size_t(Tn - 1) * SCR + NP * (NX + 1) + lane] = T(0);
+  }
   lds_sync(true);
   if (Tn >= 2) {
     scatter_sync(Tn - 2);
@@ -299,11 +341,18 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_1w(const LQArgs<T>& a,
       Fx[r] = Fraw[r] * mZcols;  // F in the state columns, beta in column JB, zero elsewhere
       Pm[r] = Pd[r] * mCols;     // P proper: column JB of the tile holds alpha
     }
+    T bmu = T(0);  // adjoint mode: this lane's share of beta_k^T mu_{k+1} (beta = column JB of Fraw: lanes j == JB)
     if (j == JB) {
 #pragma unroll
       for (int r = 0; r < 4; r++)
-        if (row0 + RS * r < NX) a.scratch[size_t(k) * SCR + NP * (NX + 1) + row0 + RS * r] = Fraw[r];
+        if (row0 + RS * r < NX) {
+          if (adj)
+            bmu += Fraw[r] * sMu[mub * 16 + row0 + RS * r];
+          else
+            a.scratch[size_t(k) * SCR + NP * (NX + 1) + row0 + RS * r] = Fraw[r];
+        }
     }
+    T ctrl = T(0);
     if (lane < NP) {  // alpha_i^T R_ii r_ii, evaluated (alpha^T R) r like Eigen (ilq_solver.cpp:384-386)
       int ro_ii = 0, rg_ii = 0;
 #pragma unroll
@@ -319,7 +368,19 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_1w(const LQArgs<T>& a,
         for (int b = 0; b < MU; b++) aR += sAl[lane * MU + b] * sR[ro_ii + b + MU * c];
         acc += aR * sr[rg_ii + c];
       }
-      a.scratch[size_t(k) * SCR + NP * NX + lane] = acc;
+      if (adj)
+        ctrl = acc;
+      else
+        a.scratch[size_t(k) * SCR + NP * NX + lane] = acc;
+    }
+    if (adj) {
+      // ExpectedDecrease: the players' control terms of this step, then beta_k^T mu_{k+1}; then mu_k for the next step
+      // (every lane forms the same sums: LDS broadcasts, `ed` stays wave-uniform)
+#pragma unroll
+      for (int i = 0; i < NP; i++) ed -= bcast(ctrl, i);
+      ed -= (bcast(bmu, JB) + bcast(bmu, 16 + JB)) + (bcast(bmu, 32 + JB) + bcast(bmu, 48 + JB));
+      adjoint_step(false);  // (reads what was written before the solve's sync; its result is read a step from now)
+      mub = 1 - mub;
     }
 
     // ---- Z_w <- F^T Z_w F + Q_w + sum_jj P_jj^T R_w,jj P_jj, zeta_w in column JB (:198-212), player after player ----
@@ -392,6 +453,7 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_1w(const LQArgs<T>& a,
     }
     lds_sync(true);
   }
+  if (adj && lane == 0) *a.ed_out = ed;
 }
 
 }  // namespace ilqg

@@ -872,6 +872,7 @@ __device__ __forceinline__ void lq_part_instance(const DevProblem& p, const Solv
   // where the sweep leaves the expected decrease: an LDS slot that is free once it ends (feedback sweeps), or
   // one past the open-loop sweep's own working set (the launch reserves it)
   constexpr int ed_slot = kOL ? OLCfg<T, NX, NP, MU>::LDS_ELEMS
+                          : KIND == LQ_SINGLE_WAVE ? W1Cfg<T, NX, NP, MU>::ELEMS
                           : (KIND == LQ_PLAYER_WAVES && !LQCfg<T, NX, NP, MU>::MFMA_ONE_TILE) ? FB2Cfg<T, NX, NP, MU>::LDS_ELEMS
                                                                                               : LQCfg<T, NX, NP, MU>::oX;
   la.ed_out = defer ? nullptr : sm + ed_slot;
@@ -891,8 +892,12 @@ __device__ __forceinline__ void lq_part_instance(const DevProblem& p, const Solv
   if constexpr (KIND == LQ_PLAYER_WAVES) {
     lq_feedback_instance_mfma<T, NX, NP, MU>(la, p.pairs, sm);
   } else if constexpr (KIND == LQ_SINGLE_WAVE) {
-    // (the launcher only picks this kind with compact rows and the deferred forward pass: la.compact set, no ed_out)
-    if constexpr (W1Cfg<T, NX, NP, MU>::SUPPORTED) lq_feedback_instance_mfma_1w<T, NX, NP, MU>(la, p.pairs, sm);
+    // (the launcher only picks this kind with compact rows; the expected decrease comes out of the sweep itself — the
+    // adjoint recursion of ilqg_lq_feedback1w.hpp — unless the forward pass is deferred to the trial kernel)
+    if constexpr (W1Cfg<T, NX, NP, MU>::SUPPORTED) {
+      la.dx = nullptr;
+      lq_feedback_instance_mfma_1w<T, NX, NP, MU>(la, p.pairs, sm);
+    }
   } else if constexpr (KIND == LQ_OPEN_LOOP) {
     lq_openloop_instance<T, NX, NP, MU>(la, p.pairs, sm);  // SolverParams::open_loop (ilq_solver.h:76-81)
   } else if constexpr (KIND == LQ_OPEN_LOOP_COMPACT) {

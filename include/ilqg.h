@@ -421,7 +421,10 @@ typedef struct {
                                      choice.  Same decisions whatever the value.                                       */
   int32_t single_wave_sweep;    /* ilqg_choice: the one-tile feedback sweep with one wave per instance (twice the instances
                                      per CU; the library picks it for batches of five or more instances per CU)           */
-  int32_t reserved[1];
+  int32_t adjoint_expected_decrease; /* ilqg_choice: the single-wave sweep forms ILQSolver::ExpectedDecrease itself, by an
+                                     adjoint recursion inside the sweep, instead of leaving scratch rows for a forward pass
+                                     in the next trial pass (AUTO: where the trial pass is split and has no wave to spare
+                                     for one).  Same value up to the order of summation.                                */
   const struct ilqg_iterate_log* iterate_log; /* NULL, or where every logged iterate of the solve goes (below)          */
   double max_runtime;           /* > 0: the anytime exit of ILQSolver::Solve (src/ilq_solver.cpp:123-124) on the host's
                                      clock, seconds — once it has passed, instances leave the loop at their next
