@@ -292,7 +292,7 @@ inline WsTail ws_tail(const DevProblem& d, int batch, size_t elem, int ol_row) {
   t.ids_off = up(size_t(L.total) * elem * size_t(batch));
   t.pool_off = up(t.ids_off + size_t(2) * batch * sizeof(int));
   // eight candidates per instance up to kProbeEntries, and never fewer than two full rounds' worth for a single
-  // instance (a lone instance in a failing line search walks through all its step sizes: 32 a round, not 8)
+  // instance (a lone instance in a failing line search walks through all its step sizes: 128 a round, not 8)
   t.pool_entries = batch * 16 < kProbeEntries ? batch * 16 : kProbeEntries;
   if (t.pool_entries < 2 * kProbeCandidates) t.pool_entries = 2 * kProbeCandidates;
   t.total = up(t.pool_off + size_t(t.pool_entries) * ProbeEntry(d.n, d.m, d.N, d.T).total * elem);
@@ -344,10 +344,10 @@ __global__ void __launch_bounds__(64 * W, (sizeof(T) == 4 && W == 2) ? 3 : W) il
 // The same pass cut into three launches (ilqg_solve.hpp, TRIAL_ROLL / rows_part_instance / TRIAL_DECIDE), for
 // problems whose fused trial kernel fits fewer than three instances on a CU.
 #ifndef ILQG_ROLL_WAVES
-#define ILQG_ROLL_WAVES 1
+#define ILQG_ROLL_WAVES 4
 #endif
 template <typename T, int NX, int NP, int MU>
-__global__ void __launch_bounds__(64, ILQG_ROLL_WAVES) ilq_roll_kernel(DevProblem p, SolveArgs<T> sa) {
+__global__ void __launch_bounds__(64, sizeof(T) == 8 ? ILQG_ROLL_WAVES : 1) ilq_roll_kernel(DevProblem p, SolveArgs<T> sa) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int b = sa.ids ? sa.ids[blockIdx.x] : int(blockIdx.x);
   if (!sa.first) {
@@ -798,7 +798,15 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   const bool big_batch = size_t(batch) >= size_t(8) * num_cus;
   // the whole batch resident at once (four instances per CU): fair issue arbitration among the co-resident instances
   sa.prio_div = (batch > num_cus && batch <= 4 * num_cus) ? num_cus : 0;
-  bool split = choice(opt.split_trial, 4 * lds_trial > size_t(160) * 1024 || (big_batch && NX > 16));
+  // ... and wherever the single-wave sweep (below) will run: it takes its expected decrease from its own adjoint pass, so
+  // nothing is left for the fused kernel's row wave to overlap with the rollout, and the three split kernels each keep
+  // more instances on a CU than the fused one (measured, n = 14, B = 8192, LQ single-wave + adjoint: fp64 1.58 M it/s
+  // fused vs 1.65 M split, fp32 2.61 M vs 2.77 M; B = 2048 fp64 1.40 M vs 1.50 M).
+  constexpr bool has_1w = W1Cfg<T, NX, NP, MU>::SUPPORTED && C::USE_MFMA && C::MFMA_ONE_TILE;
+  const bool want_1w = has_1w && pw && compact_on && !kProfile && d.rp_compact_w <= W1Cfg<T, NX, NP, MU>::kWords &&
+                       choice(opt.single_wave_sweep, size_t(batch) >= size_t(5) * num_cus) &&
+                       opt.adjoint_expected_decrease != ILQG_CHOICE_OFF;
+  bool split = choice(opt.split_trial, 4 * lds_trial > size_t(160) * 1024 || (big_batch && NX > 16) || want_1w);
   if (kProfile || opt.forced_steps) split = false;  // the phase profile reads the fused kernel's counters
   const bool counted = !opt.forced_steps && (split || !(fixed_iters > 0 && !al_mode) || choice(opt.counted, false));
   // Hand-off: whenever the host counts rounds anyway, the fused kernel keeps an instance only until its line
@@ -821,7 +829,6 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   // player-parallel vs 1.11 M single-wave; 1280: 1.09 vs 1.10; 1536: 1.17 vs 1.25; 2048: 1.20 vs 1.45; 8192: 1.45 vs
   // 1.68); it reads compact rows and leaves the forward pass to the trial kernel.
   // ilqg_solve_options::single_wave_sweep overrides the choice (same results to rounding).
-  constexpr bool has_1w = W1Cfg<T, NX, NP, MU>::SUPPORTED && C::USE_MFMA && C::MFMA_ONE_TILE;
   // Where the expected decrease of a single-wave sweep comes from: its own adjoint recursion, or — only possible with the
   // fused trial kernel, whose row wave runs it — the deferred forward pass over the sweep's scratch rows.
   const bool adjoint = choice(opt.adjoint_expected_decrease, sa.defer_forward == 0);
@@ -914,13 +921,13 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
       // Step sizes probed per listed instance: as many as the pool holds for a list this long, doubling from two
       // over the first rounds of a tail (most line searches that back-track at all end within a step or two; the
       // ones that do not are mostly on their way through all max_backtracking_steps of a failing search, and a round
-      // for the few instances left costs the latency of its launches whatever it probes: 2, 4, 8, 16, 32).
+      // for the few instances left costs the latency of its launches whatever it probes: 2, 4, 8, 16, 32, ...).
       int probe_k = sa.ids ? tail.pool_entries / round_instances : 0;
       if (probe_k > kProbeCandidates) probe_k = kProbeCandidates;
       {
         // the ramp: `first` candidates in a tail's first round, doubling per round (ilqg_solve_options::probe_first)
         // The library's choice: as many candidates per instance as keep the round's rollouts within one filling of
-        // the chip (kProbeRoundBudget of them), between 2 and 32.  A short list is a few deep searches — the instances
+        // the chip (kProbeRoundBudget of them), between 2 and kProbeCandidates.  A short list is a few deep searches — the instances
         // that back-track at all mostly go on for tens of steps (the n = 16 intersection: ~10 % of the batch, mean
         // depth ~30) — and 32 at once ends them in a round or two (measured, B = 1024: 280 k -> 335 k it/s); a long list
         // (config 4: ~40 % of 4096 instances, most done within a step or two) pays for every candidate it does not

@@ -405,8 +405,10 @@ __device__ __forceinline__ void rows_part_instance(const DevProblem& p, const sh
 // rejections counted as if they had been tried one by one.  The regular pass that follows evaluates that
 // candidate again with all outputs and accepts it: same arithmetic, same decisions, fewer rounds.
 // ---------------------------------------------------------------------------
-constexpr int kProbeCandidates = 32;            // most step sizes probed per instance and round
-constexpr int kProbeEntries = 16384;            // pool size: candidates of all listed instances of one round
+constexpr int kProbeCandidates = 128;           // most step sizes probed per instance and round (a failing search walks
+                                                // through all max_backtracking_steps of them — 100 in the examples — and a
+                                                // round costs the latency of one rollout whatever it probes)
+constexpr int kProbeEntries = 32768;            // pool size: candidates of all listed instances of one round
 constexpr int kProbeRoundBudget = 4096;         // rollouts the first probing round of a tail may hold (doubling after)
 
 struct ProbeEntry {

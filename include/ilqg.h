@@ -417,7 +417,7 @@ typedef struct {
   int32_t generic_kernels;      /* ilqg_choice: ILQG_CHOICE_ON runs the run-time-dimensioned kernels (what every shape
                                      without a specialised instantiation runs on) for this problem too */
   int32_t probe_first;          /* speculative line search: step sizes probed per listed instance in the first round of
-                                     a tail (doubling every round up to 32, as many as the pool holds); 0 = the library's
+                                     a tail (doubling every round up to 128, as many as the pool holds); 0 = the library's
                                      choice.  Same decisions whatever the value.                                       */
   int32_t single_wave_sweep;    /* ilqg_choice: the one-tile feedback sweep with one wave per instance (twice the instances
                                      per CU; the library picks it for batches of five or more instances per CU)           */
