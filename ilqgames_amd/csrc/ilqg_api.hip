@@ -343,6 +343,9 @@ __global__ void __launch_bounds__(64 * W, (sizeof(T) == 4 && W == 2) ? 3 : W) il
 
 // The same pass cut into three launches (ilqg_solve.hpp, TRIAL_ROLL / rows_part_instance / TRIAL_DECIDE), for
 // problems whose fused trial kernel fits fewer than three instances on a CU.
+#ifndef ILQG_SPLIT_ROW_EXTRA_CHUNKS
+#define ILQG_SPLIT_ROW_EXTRA_CHUNKS 0
+#endif
 #ifndef ILQG_ROLL_WAVES
 #define ILQG_ROLL_WAVES 4
 #endif
@@ -808,6 +811,26 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
                        opt.adjoint_expected_decrease != ILQG_CHOICE_OFF;
   bool split = choice(opt.split_trial, 4 * lds_trial > size_t(160) * 1024 || (big_batch && NX > 16) || want_1w);
   if (kProfile || opt.forced_steps) split = false;  // the phase profile reads the fused kernel's counters
+  if (split) {
+    // The split row kernel is one wave per chunk with the chunk's scratch to itself, and its instances per CU are what
+    // the scratch leaves room for: chunks of equal width (T = 100: 2 x 50 rows, 28 KB, five per CU — not 64 + 36 at 36 KB
+    // and four), or one chunk more where that buys a second wave per SIMD.
+    const int base = (d.T + sa.rows_cw - 1) / sa.rows_cw;
+    int best_cw = sa.rows_cw;
+    double best = 0.0;
+    for (int chunks = base; chunks <= base + ILQG_SPLIT_ROW_EXTRA_CHUNKS && chunks <= d.T; chunks++) {
+      const int cw = (d.T + chunks - 1) / chunks;
+      const size_t lds = rows_maps_bytes(d) + trial_rows_elems(d, cw) * sizeof(T);
+      size_t per_cu = size_t(160) * 1024 / (lds + 512);
+      if (per_cu > 8) per_cu = 8;
+      const double score = double(per_cu) / double(chunks);
+      if (score > best * 1.05) {
+        best = score;
+        best_cw = cw;
+      }
+    }
+    sa.rows_cw = best_cw;
+  }
   const bool counted = !opt.forced_steps && (split || !(fixed_iters > 0 && !al_mode) || choice(opt.counted, false));
   // Hand-off: whenever the host counts rounds anyway, the fused kernel keeps an instance only until its line
   // search rejects a step; the back-tracking instances then go through split passes with the speculative line
@@ -881,7 +904,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   auto wall = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double inner_elapsed = 0.0, tic = 0.0;
   bool iteration_open = false;
-  const bool bursts = counted && !split && !kProfile && !timed && choice(opt.round_bursts, true);
+  const bool bursts = counted && !kProfile && !timed && choice(opt.round_bursts, true);
   int burst = 1;
   // the iterate log (ilqg_solve_options::iterate_log): copied in front of every exit / sweep launch
   IterLog<T> lg{};
@@ -901,10 +924,22 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   };
   for (long long round = 0;; round++) {
     if (bursts && !sa.ids) {
-      for (int q = 1; q < burst; q++) {  // rounds without a read-back
+      // a fixed-iteration solve knows its last round: no burst runs past it
+      const long long left = (fixed_iters > 0 && !al_mode) ? (long long)fixed_iters - round : (long long)burst;
+      for (int q = 1; q < burst && q <= left; q++) {  // rounds without a read-back
         HIP_TRY(hipMemsetAsync(p->d_unfinished, 0, 4 * sizeof(int), stream));
-        sa.ids_next = handoff ? pass_ids + size_t(list) * batch : nullptr;
-        hipLaunchKernelGGL(k_trial, dim3(batch), dim3(64 * W), lds_trial, stream, d, sa);
+        if (split) {  // the three-kernel form of the pass over the whole batch (no probing: nobody is listed)
+          sa.ids_next = pass_ids + size_t(list) * batch;
+          hipLaunchKernelGGL(k_roll, dim3(batch), dim3(64), lds_roll, stream, d, sa);
+          HIP_TRY(hipGetLastError());
+          sa.first = 0;
+          hipLaunchKernelGGL(k_rows, dim3(row_chunks, batch), dim3(64), lds_rows, stream, d, sa);
+          HIP_TRY(hipGetLastError());
+          hipLaunchKernelGGL(k_decide, dim3(batch), dim3(64), lds_decide, stream, d, sa);
+        } else {
+          sa.ids_next = handoff ? pass_ids + size_t(list) * batch : nullptr;
+          hipLaunchKernelGGL(k_trial, dim3(batch), dim3(64 * W), lds_trial, stream, d, sa);
+        }
         HIP_TRY(hipGetLastError());
         sa.first = 0;
         if (log_iterates() != ILQG_OK) return ILQG_ERR_HIP;
