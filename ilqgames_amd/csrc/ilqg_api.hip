@@ -820,7 +820,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
     double best = 0.0;
     for (int chunks = base; chunks <= base + ILQG_SPLIT_ROW_EXTRA_CHUNKS && chunks <= d.T; chunks++) {
       const int cw = (d.T + chunks - 1) / chunks;
-      const size_t lds = rows_maps_bytes(d) + trial_rows_elems(d, cw) * sizeof(T);
+      const size_t lds = rows_maps_bytes(d) + split_rows_elems(d, NX, cw) * sizeof(T);
       size_t per_cu = size_t(160) * 1024 / (lds + 512);
       if (per_cu > 8) per_cu = 8;
       const double score = double(per_cu) / double(chunks);
@@ -874,7 +874,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   auto k_decide = ilq_decide_kernel<T, NX, NP, MU>;
   const size_t lds_roll = trial_phase_lds_bytes<T>(d, TRIAL_ROLL, sa.rows_cw),
                lds_decide = trial_phase_lds_bytes<T>(d, TRIAL_DECIDE, sa.rows_cw);
-  const size_t lds_rows = rows_maps_bytes(d) + trial_rows_elems(d, sa.rows_cw) * sizeof(T);
+  const size_t lds_rows = rows_maps_bytes(d) + split_rows_elems(d, NX, sa.rows_cw) * sizeof(T);
   const bool probe = lists && sa.prm.linesearch && choice(opt.probe, true);
   auto k_proll = ilq_probe_roll_kernel<T, NX, NP, MU>;
   auto k_prows = ilq_probe_rows_kernel<T, NX, NP, MU>;

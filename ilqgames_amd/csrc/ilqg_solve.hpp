@@ -197,6 +197,12 @@ __host__ __device__ inline size_t trial_rows_elems(const DevProblem& p, int cw) 
   if (e < red) e = red;
   return (e + 3) & ~size_t(3);
 }
+// scratch of a workgroup of the split row kernels (ilq_rows_kernel, ilq_probe_rows_kernel): one chunk, the state rows in
+// registers where the shape allows it (`nx`: the instantiation's compile-time n, 0 for the run-time-dimensioned kernels)
+__host__ __device__ inline size_t split_rows_elems(const DevProblem& p, int nx, int cw) {
+  if (!rows_state_in_registers(nx)) return trial_rows_elems(p, cw);
+  return (rows_lds_elems_xreg(p.m, p.rp_pslots, p.rp_lslots, cw) + 3) & ~size_t(3);
+}
 // LDS of the trial kernel: [word maps | rollout scratch | row waves x row scratch | 4 ints]
 template <typename T>
 __host__ __device__ inline size_t trial_lds_bytes(const DevProblem& p, int waves, int cw) {
@@ -393,7 +399,7 @@ __device__ __forceinline__ void rows_part_instance(const DevProblem& p, const sh
   const QuadArgs<T> qa = trial_quad_args<T>(p, ib, s, sa.compact != 0);
   const int k0 = chunk * sa.rows_cw;
   const int nrows = p.T - k0 < sa.rows_cw ? p.T - k0 : sa.rows_cw;
-  rows_chunk<T, NX, NP * MU, NP>(p, maps, qa, k0, nrows, sa.rows_cw, sm, int(threadIdx.x));
+  rows_chunk<T, NX, NP * MU, NP, rows_state_in_registers(NX)>(p, maps, qa, k0, nrows, sa.rows_cw, sm, int(threadIdx.x));
 }
 
 // ---------------------------------------------------------------------------
@@ -481,7 +487,7 @@ __device__ __forceinline__ void probe_rows_instance(const DevProblem& p, const s
   qa.phacc = nullptr;
   const int k0 = chunk * sa.rows_cw;
   const int nrows = p.T - k0 < sa.rows_cw ? p.T - k0 : sa.rows_cw;
-  rows_chunk<T, NX, NP * MU, NP>(p, maps, qa, k0, nrows, sa.rows_cw, sm, int(threadIdx.x));
+  rows_chunk<T, NX, NP * MU, NP, rows_state_in_registers(NX)>(p, maps, qa, k0, nrows, sa.rows_cw, sm, int(threadIdx.x));
 }
 
 template <typename T>
