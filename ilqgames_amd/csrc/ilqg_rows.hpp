@@ -86,51 +86,50 @@ struct RowArg {
   __device__ __forceinline__ T operator[](int i) const { return base[i * stride]; }
 };
 
-// The same with the row's STATE held in registers (rows_chunk<..., XREG>: n <= 16, compile-time dimensions).  A term's
-// argument is the state or one player's control vector.  The controls stay in the transposed LDS image; of the state,
-// the (up to four) entries the term's descriptor names are picked out of this lane's register copy when the op is
-// decoded — wave-uniform register indices — and the accessor hands them out by index; any other entry (a cost over
-// the whole state vector, an affine constraint) is read from the trajectory in memory.
+// The same with the row's (x, u) held in registers (rows_chunk<..., XREG>: n, m <= 16, compile-time dimensions) and no
+// LDS image at all.  A term's argument is the state or one player's control vector; the (up to four) entries its
+// descriptor names — the first four, for a cost over the whole vector — are picked out of this lane's register copy
+// when the op is decoded (wave-uniform register indices) and the accessor hands them out by index; any other entry (a
+// cost over a long vector, an affine constraint) is read from the trajectory in memory.
 template <typename T>
 struct MixArg {
-  T a0, a1, a2, a3;   // state entries off + id0 .. off + id3 of this lane's row
+  T a0, a1, a2, a3;   // entries id0 .. id3 of the argument vector at this lane's row
   int id0, id1, id2, id3;
-  const T* ubase;     // in_u: &arg_u[first entry * cw + this lane's row]
-  int stride;
-  bool in_u;          // wave-uniform
-  const T* xg;        // &xs[this lane's row][off]
+  const T* g;         // the argument vector of this lane's row in memory
   __device__ __forceinline__ T operator[](int i) const {
-    if (in_u) return ubase[i * stride];
     if (i == id0) return a0;
     if (i == id1) return a1;
     if (i == id2) return a2;
     if (i == id3) return a3;
-    return xg[i];
+    return g[i];
   }
 };
-template <typename T> struct RowVec16 { typedef T type __attribute__((ext_vector_type(16))); };
+template <typename T, int W> struct RowVecN;
+template <typename T> struct RowVecN<T, 8> { typedef T type __attribute__((ext_vector_type(8))); };
+template <typename T> struct RowVecN<T, 16> { typedef T type __attribute__((ext_vector_type(16))); };
+constexpr int rows_vec_regs(int dim) { return dim <= 8 ? 8 : 16; }  // elements of the register copy of a dim-vector
 
 // The accessor of a term's argument vector (entries off .. of this lane's row; id0 .. id3: the entries the op names).
 // The register copy itself never goes into a struct: a vector inside a stack object is read back through scratch.
-template <typename T, bool XREG>
+template <typename T, bool XREG, int XW, int UW>
 __device__ __forceinline__ typename std::conditional<XREG, MixArg<T>, RowArg<T>>::type rows_make_arg(
-    typename RowVec16<T>::type xrow, const T* xg, const T* arg, int cw, int cn, int off, int rl, int id0, int id1, int id2,
-    int id3) {
+    typename RowVecN<T, XW>::type xrow, typename RowVecN<T, UW>::type urow, const T* xg, const T* ug, const T* arg, int cw,
+    int cn, int off, int rl, int id0, int id1, int id2, int id3) {
   if constexpr (XREG) {
     const bool in_u = off >= cn;
+    const int o = in_u ? off - cn : off;
+    if (id0 < 0) {  // a term over its whole argument vector walks it from the front
+      id0 = 0; id1 = 1; id2 = 2; id3 = 3;
+    }
     MixArg<T> m;
     m.id0 = id0; m.id1 = id1; m.id2 = id2; m.id3 = id3;
-    m.a0 = m.a1 = m.a2 = m.a3 = T(0);
-    if (!in_u) {
-      m.a0 = xrow[(off + (id0 < 0 ? 0 : id0)) & 15];
-      m.a1 = xrow[(off + (id1 < 0 ? 0 : id1)) & 15];
-      m.a2 = xrow[(off + (id2 < 0 ? 0 : id2)) & 15];
-      m.a3 = xrow[(off + (id3 < 0 ? 0 : id3)) & 15];
+    const int e0 = o + id0, e1 = o + (id1 < 0 ? 0 : id1), e2 = o + (id2 < 0 ? 0 : id2), e3 = o + (id3 < 0 ? 0 : id3);
+    if (in_u) {
+      m.a0 = urow[e0 & (UW - 1)]; m.a1 = urow[e1 & (UW - 1)]; m.a2 = urow[e2 & (UW - 1)]; m.a3 = urow[e3 & (UW - 1)];
+    } else {
+      m.a0 = xrow[e0 & (XW - 1)]; m.a1 = xrow[e1 & (XW - 1)]; m.a2 = xrow[e2 & (XW - 1)]; m.a3 = xrow[e3 & (XW - 1)];
     }
-    m.ubase = arg + (in_u ? off - cn : 0) * cw + rl;
-    m.stride = cw;
-    m.in_u = in_u;
-    m.xg = xg + off;
+    m.g = (in_u ? ug : xg) + o;
     return m;
   } else {
     return RowArg<T>{arg + off * cw + rl, cw};
@@ -142,10 +141,12 @@ __device__ __forceinline__ typename std::conditional<XREG, MixArg<T>, RowArg<T>>
 __host__ __device__ inline size_t rows_lds_elems(int n, int m, int num_pslots, int max_lslots, int cw) {
   return size_t(n + m) * cw + size_t(num_pslots + max_lslots) * (cw + 1);
 }
-// ... of the variant that keeps the state rows in registers (the split row kernels of the shapes with n <= 16)
-__host__ __device__ constexpr bool rows_state_in_registers(int cn) { return cn > 0 && cn <= 16 && ILQG_ROWS_XREG; }
-__host__ __device__ inline size_t rows_lds_elems_xreg(int m, int num_pslots, int max_lslots, int cw) {
-  return size_t(m) * cw + size_t(num_pslots + max_lslots) * (cw + 1);
+// ... of the variant that keeps the (x, u) rows in registers (the split row kernels of the shapes with n, m <= 16)
+__host__ __device__ constexpr bool rows_state_in_registers(int cn, int cm) {
+  return cn > 0 && cn <= 16 && cm <= 16 && ILQG_ROWS_XREG;
+}
+__host__ __device__ inline size_t rows_lds_elems_xreg(int num_pslots, int max_lslots, int cw) {
+  return size_t(num_pslots + max_lslots) * (cw + 1);
 }
 // Largest chunk width (64, 32 or 16 rows) whose scratch fits `budget` bytes.
 __host__ __device__ inline int rows_chunk_width(int n, int m, int num_pslots, int max_lslots, size_t elem, size_t budget) {
@@ -480,19 +481,18 @@ __device__ __forceinline__ Closest<T> polyline_closest_rows(typename ConstPtr<T>
 // written; derivatives are still accumulated when merit_part is set), merit_part, cost_part.
 // CN, CM, CNP: the problem's state / total control dimension / player count at compile time, or all 0 — the
 // run-time-dimensioned path (shapes without an instantiation): the same program, dimensions read from `p`.
-// XREG: the state row of this lane lives in registers (MixArg) and the LDS image holds the controls only
-// (rows_lds_elems_xreg) — a third less scratch per row, i.e. that many more chunks resident on a CU; n <= 16.
+// XREG: the (x, u) row of this lane lives in registers (MixArg) and there is no LDS image (rows_lds_elems_xreg) — a
+// third less scratch per row, i.e. that many more chunks resident on a CU; n, m <= 16.
 template <typename T, int CN_, int CM_, int CNP_, bool XREG = false>
 __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* maps, const QuadArgs<T>& a, int k0,
                                            int nrows, int cw, T* sm, int lane) {
   constexpr bool RT = CN_ == 0;
-  static_assert(!XREG || (CN_ > 0 && CN_ <= 16), "register-held state rows: compile-time n <= 16");
+  static_assert(!XREG || (CN_ > 0 && CN_ <= 16 && CM_ <= 16), "register-held rows: compile-time n, m <= 16");
   const int CN = RT ? p.n : CN_, CM = RT ? p.m : CM_, CNP = RT ? p.N : CNP_;
   const int NA = CN + CM;
   const int cws = cw + 1;
-  constexpr int UOFF = XREG ? 0 : CN_;  // first control entry of the LDS image (RT: CN below)
   T* const arg = sm;
-  T* const acc = sm + (XREG ? CM : NA) * cw;
+  T* const acc = sm + (XREG ? 0 : NA) * cw;
   typedef typename std::conditional<XREG, MixArg<T>, RowArg<T>>::type Arg;
   const rp_cptr rp = (rp_cptr)p.row_prog;
   const typename ConstPtr<T>::type segs = (typename ConstPtr<T>::type)problem_segs<T>(p);
@@ -536,17 +536,24 @@ __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* map
           if (dst[u] >= 0) arg[dst[u]] = v[u];
       }
     };
-    if constexpr (!XREG) stage_rows(a.xs + size_t(k0) * CN, CN, 0);
-    stage_rows(a.us + size_t(k0) * CM, CM, XREG ? 0 : CN);
+    if constexpr (!XREG) {
+      stage_rows(a.xs + size_t(k0) * CN, CN, 0);
+      stage_rows(a.us + size_t(k0) * CM, CM, CN);
+    }
   }
-  typename RowVec16<T>::type xrow = {};
-  const T* xg = a.xs;
+  constexpr int XW = rows_vec_regs(CN_), UW = rows_vec_regs(CM_);
+  typename RowVecN<T, XW>::type xrow = {};
+  typename RowVecN<T, UW>::type urow = {};
+  const T *xg = a.xs, *ug = a.us;
   if constexpr (XREG) {
     // this lane's state row (lanes past the chunk's end: its last row; lanes past the chunk width: lane 0's)
     const int r = lane < cw ? (lane < nrows ? lane : nrows - 1) : 0;
     xg = a.xs + size_t(k0 + r) * CN;
 #pragma unroll
     for (int e = 0; e < CN_; e++) xrow[e] = xg[e];
+    ug = a.us + size_t(k0 + r) * CM;
+#pragma unroll
+    for (int e = 0; e < CM_; e++) urow[e] = ug[e];
   }
   lds_sync(true);
   tl_stamp(a.tl, a.tl_b, 40, lane == 0);
@@ -629,9 +636,8 @@ __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* map
           // the constant entries (dt, -dt, the identity) are in the word maps.
           const int kind = c.kind, xo = c.idx[0], uo = c.idx[1];
           const T L = T(c.weight);
-          const Arg x = rows_make_arg<T, XREG>(xrow, xg, arg, cw, CN, xo, rl, 2, kind == ILQG_DYN_AIR_3D_EVADER ? 0 : 3,
+          const Arg x = rows_make_arg<T, XREG, XW, UW>(xrow, urow, xg, ug, arg, cw, CN, xo, rl, 2, kind == ILQG_DYN_AIR_3D_EVADER ? 0 : 3,
                                                    kind == ILQG_DYN_AIR_3D_EVADER ? 1 : 4, -1);
-          const int uimg = (RT ? CN : UOFF) + uo;  // this subsystem's first control in the LDS image
           auto put = [&](int e, T val) { if (e < nsid) col[sid[e] * cws] = val; };
           if (kind == ILQG_DYN_POINT_MASS_2D || kind == ILQG_DYN_PLANAR_DISTURBANCE || kind == ILQG_DYN_AIR_3D_PURSUER)
             continue;  // constants only
@@ -639,7 +645,7 @@ __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* map
           t_sincos(x[2], &sth, &cth);
           const T ct = T(double(cth) * p.dt), st = T(double(sth) * p.dt);
           if (kind == ILQG_DYN_AIR_3D_EVADER) {  // air_3d.h:127-146
-            const T own = arg[uimg * cw + rl];  // its own turn rate; c.value = the pursuer's speed
+            const T own = XREG ? T(urow[uo & (UW - 1)]) : arg[(CN + uo) * cw + rl];  // its own turn rate; c.value = the pursuer's speed
             put(0, T(double(own) * p.dt));             // A(0,1)
             put(1, T(0) - T(c.value) * st);            // A(0,2)
             put(2, T(0) - T(double(own) * p.dt));      // A(1,0)
@@ -664,7 +670,7 @@ __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* map
               put(4, T(double(x[4]) * p.dt / double(L * cphi * cphi)));  // A(2,3)
               put(5, T(double(tphi) * p.dt / double(L)));               // A(2,4)
               if (kind == ILQG_DYN_CAR_7D) {  // single_player_car_7d.h:141-151: the curvature row, all-double products
-                const T own = arg[uimg * cw + rl];  // omega
+                const T own = XREG ? T(urow[uo & (UW - 1)]) : arg[(CN + uo) * cw + rl];  // omega
                 const T den = cphi * cphi * L;
                 put(6, T(2.0 * p.dt * double(own) * double(tphi) / double(den)));  // A(5,3)
                 put(7, T(p.dt / double(den)));                                     // B(5,0)
@@ -673,7 +679,7 @@ __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* map
           }
           continue;
         }
-        const Arg v = rows_make_arg<T, XREG>(xrow, xg, arg, cw, CN, c.arg_off, rl, c.idx[0], c.idx[1], c.idx[2], c.idx[3]);
+        const Arg v = rows_make_arg<T, XREG, XW, UW>(xrow, urow, xg, ug, arg, cw, CN, c.arg_off, rl, c.idx[0], c.idx[1], c.idx[2], c.idx[3]);
         if (mode == ROP_AFFINE) {
           // constraints are quadraticised with the player's full PlayerCost::Quadraticize only (:483-487), from their
           // first active step on (FinalTimeConstraint)

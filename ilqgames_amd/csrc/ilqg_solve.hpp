@@ -200,8 +200,8 @@ __host__ __device__ inline size_t trial_rows_elems(const DevProblem& p, int cw) 
 // scratch of a workgroup of the split row kernels (ilq_rows_kernel, ilq_probe_rows_kernel): one chunk, the state rows in
 // registers where the shape allows it (`nx`: the instantiation's compile-time n, 0 for the run-time-dimensioned kernels)
 __host__ __device__ inline size_t split_rows_elems(const DevProblem& p, int nx, int cw) {
-  if (!rows_state_in_registers(nx)) return trial_rows_elems(p, cw);
-  return (rows_lds_elems_xreg(p.m, p.rp_pslots, p.rp_lslots, cw) + 3) & ~size_t(3);
+  if (!rows_state_in_registers(nx, p.m)) return trial_rows_elems(p, cw);
+  return (rows_lds_elems_xreg(p.rp_pslots, p.rp_lslots, cw) + 3) & ~size_t(3);
 }
 // LDS of the trial kernel: [word maps | rollout scratch | row waves x row scratch | 4 ints]
 template <typename T>
@@ -399,7 +399,7 @@ __device__ __forceinline__ void rows_part_instance(const DevProblem& p, const sh
   const QuadArgs<T> qa = trial_quad_args<T>(p, ib, s, sa.compact != 0);
   const int k0 = chunk * sa.rows_cw;
   const int nrows = p.T - k0 < sa.rows_cw ? p.T - k0 : sa.rows_cw;
-  rows_chunk<T, NX, NP * MU, NP, rows_state_in_registers(NX)>(p, maps, qa, k0, nrows, sa.rows_cw, sm, int(threadIdx.x));
+  rows_chunk<T, NX, NP * MU, NP, rows_state_in_registers(NX, NP * MU)>(p, maps, qa, k0, nrows, sa.rows_cw, sm, int(threadIdx.x));
 }
 
 // ---------------------------------------------------------------------------
@@ -487,7 +487,7 @@ __device__ __forceinline__ void probe_rows_instance(const DevProblem& p, const s
   qa.phacc = nullptr;
   const int k0 = chunk * sa.rows_cw;
   const int nrows = p.T - k0 < sa.rows_cw ? p.T - k0 : sa.rows_cw;
-  rows_chunk<T, NX, NP * MU, NP, rows_state_in_registers(NX)>(p, maps, qa, k0, nrows, sa.rows_cw, sm, int(threadIdx.x));
+  rows_chunk<T, NX, NP * MU, NP, rows_state_in_registers(NX, NP * MU)>(p, maps, qa, k0, nrows, sa.rows_cw, sm, int(threadIdx.x));
 }
 
 template <typename T>
