@@ -375,8 +375,9 @@ __global__ void __launch_bounds__(64) ilq_rows_kernel(DevProblem p, SolveArgs<T>
     const int stage = reinterpret_cast<const SolveState<T>*>(sa.ws + size_t(b) * sa.ws_stride + L.state)->stage;
     if (stage != ST_ROLLOUT && stage != ST_QUAD) return;
   }
-  const short* maps = rows_maps_load(p, smem_raw);
-  T* sm = reinterpret_cast<T*>(smem_raw + rows_maps_bytes(p));
+  // compact rows: nothing dense is written, so the word maps of the dense images are not needed (nor their LDS)
+  const short* maps = sa.compact ? nullptr : rows_maps_load(p, smem_raw);
+  T* sm = reinterpret_cast<T*>(smem_raw + (sa.compact ? 0 : rows_maps_bytes(p)));
   rows_part_instance<T, NX, NP, MU>(p, maps, sa, b, int(blockIdx.x), sm);
 }
 
@@ -409,8 +410,8 @@ __global__ void __launch_bounds__(64) ilq_probe_rows_kernel(DevProblem p, SolveA
     const SolveState<T> s = state_load<T>(sa.ws + size_t(b) * sa.ws_stride, L);
     if (!probe_wanted(sa, s, j)) return;
   }
-  const short* maps = rows_maps_load(p, smem_raw);
-  T* sm = reinterpret_cast<T*>(smem_raw + rows_maps_bytes(p));
+  const short* maps = sa.compact ? nullptr : rows_maps_load(p, smem_raw);  // merit only: no dense image either way
+  T* sm = reinterpret_cast<T*>(smem_raw + (sa.compact ? 0 : rows_maps_bytes(p)));
   probe_rows_instance<T, NX, NP, MU>(p, maps, sa, b, slot, j, int(blockIdx.x), sm);
 }
 
@@ -811,6 +812,8 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
                        opt.adjoint_expected_decrease != ILQG_CHOICE_OFF;
   bool split = choice(opt.split_trial, 4 * lds_trial > size_t(160) * 1024 || (big_batch && NX > 16) || want_1w);
   if (kProfile || opt.forced_steps) split = false;  // the phase profile reads the fused kernel's counters
+  sa.compact = ((pw && C::MFMA_ONE_TILE && compact_on) || ol_compact) ? 1 : 0;
+  const size_t split_maps_bytes = sa.compact ? 0 : rows_maps_bytes(d);  // the split row kernels' copy of the word maps
   if (split) {
     // The split row kernel is one wave per chunk with the chunk's scratch to itself, and its instances per CU are what
     // the scratch leaves room for: chunks of equal width (T = 100: 2 x 50 rows, 28 KB, five per CU — not 64 + 36 at 36 KB
@@ -820,8 +823,8 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
     double best = 0.0;
     for (int chunks = base; chunks <= base + ILQG_SPLIT_ROW_EXTRA_CHUNKS && chunks <= d.T; chunks++) {
       const int cw = (d.T + chunks - 1) / chunks;
-      const size_t lds = rows_maps_bytes(d) + split_rows_elems(d, NX, cw) * sizeof(T);
-      size_t per_cu = size_t(160) * 1024 / (lds + 512);
+      const size_t lds = split_maps_bytes + split_rows_elems(d, NX, cw) * sizeof(T);
+      size_t per_cu = size_t(160) * 1024 / (lds + 256);
       if (per_cu > 8) per_cu = 8;
       const double score = double(per_cu) / double(chunks);
       if (score > best * 1.05) {
@@ -841,7 +844,6 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   // kernel that follows (split passes and the open-loop sweep keep it in the sweep's kernel).
   // Compact rows between the row stage and the one-tile player-parallel sweep (ilqg_common.hpp): what the row stage
   // writes and the sweep reads per time step shrinks from N (n^2 + n) + ... words to the ones a cost term can touch.
-  sa.compact = ((pw && C::MFMA_ONE_TILE && compact_on) || ol_compact) ? 1 : 0;
   sa.defer_forward = (!split && !p->desc.params.open_loop) ? 1 : 0;
   {
     constexpr size_t fwd_elems = 4 * 2 * ((NX * NX + C::SCR + 3) & ~3) + 2 * NX + 8;
@@ -874,7 +876,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   auto k_decide = ilq_decide_kernel<T, NX, NP, MU>;
   const size_t lds_roll = trial_phase_lds_bytes<T>(d, TRIAL_ROLL, sa.rows_cw),
                lds_decide = trial_phase_lds_bytes<T>(d, TRIAL_DECIDE, sa.rows_cw);
-  const size_t lds_rows = rows_maps_bytes(d) + split_rows_elems(d, NX, sa.rows_cw) * sizeof(T);
+  const size_t lds_rows = split_maps_bytes + split_rows_elems(d, NX, sa.rows_cw) * sizeof(T);
   const bool probe = lists && sa.prm.linesearch && choice(opt.probe, true);
   auto k_proll = ilq_probe_roll_kernel<T, NX, NP, MU>;
   auto k_prows = ilq_probe_rows_kernel<T, NX, NP, MU>;
