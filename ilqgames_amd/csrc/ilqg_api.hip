@@ -352,6 +352,13 @@ __global__ void __launch_bounds__(64 * W, (sizeof(T) == 4 && W == 2) ? 3 : W) il
 template <typename T, int NX, int NP, int MU>
 __global__ void __launch_bounds__(64, sizeof(T) == 8 ? ILQG_ROLL_WAVES : 1) ilq_roll_kernel(DevProblem p, SolveArgs<T> sa) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
+  if constexpr (rollout_pairs(NX, NP, MU)) {  // two instances per wavefront: entries 2 x and 2 x + 1 of the round
+    const int i0 = 2 * int(blockIdx.x), i1 = i0 + 1;
+    const int b0 = sa.ids ? sa.ids[i0] : i0;
+    const int b1 = i1 < sa.round_count ? (sa.ids ? sa.ids[i1] : i1) : -1;
+    roll_pair_instances<T, NX, NP, MU>(p, sa, b0, b1, reinterpret_cast<T*>(smem_raw));
+    return;
+  }
   const int b = sa.ids ? sa.ids[blockIdx.x] : int(blockIdx.x);
   if (!sa.first) {
     const WsLayout L(p.n, p.m, p.N, p.T, p.pairs.Rsz, p.pairs.rsz, sa.ol_row, p.num_constraints, sa.al_mode);
@@ -395,9 +402,12 @@ __global__ void __launch_bounds__(64) ilq_decide_kernel(DevProblem p, SolveArgs<
 
 // Speculative line search of the listed instances (ilqg_solve.hpp): candidate j of list entry `slot`.
 template <typename T, int NX, int NP, int MU>
-__global__ void __launch_bounds__(64) ilq_probe_roll_kernel(DevProblem p, SolveArgs<T> sa) {
+__global__ void __launch_bounds__(64, sizeof(T) == 8 ? ILQG_ROLL_WAVES : 1) ilq_probe_roll_kernel(DevProblem p, SolveArgs<T> sa) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  probe_roll_instance<T, NX, NP, MU>(p, sa, sa.ids[blockIdx.x], blockIdx.x, blockIdx.y, reinterpret_cast<T*>(smem_raw));
+  if constexpr (rollout_pairs(NX, NP, MU))  // candidates 2 y and 2 y + 1 in the two halves of the wave
+    probe_roll_pair<T, NX, NP, MU>(p, sa, sa.ids[blockIdx.x], blockIdx.x, 2 * int(blockIdx.y), reinterpret_cast<T*>(smem_raw));
+  else
+    probe_roll_instance<T, NX, NP, MU>(p, sa, sa.ids[blockIdx.x], blockIdx.x, blockIdx.y, reinterpret_cast<T*>(smem_raw));
 }
 
 template <typename T, int NX, int NP, int MU>
@@ -877,6 +887,8 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   const size_t lds_roll = trial_phase_lds_bytes<T>(d, TRIAL_ROLL, sa.rows_cw),
                lds_decide = trial_phase_lds_bytes<T>(d, TRIAL_DECIDE, sa.rows_cw);
   const size_t lds_rows = split_maps_bytes + split_rows_elems(d, NX, sa.rows_cw) * sizeof(T);
+  constexpr bool pairs = rollout_pairs(NX, NP, MU);  // two rollouts per wavefront (ilqg_stages.hpp)
+  const size_t lds_proll = pairs ? size_t(rollout_pair_lds_elems(d.n, d.m)) * sizeof(T) + 16 : lds_roll;
   const bool probe = lists && sa.prm.linesearch && choice(opt.probe, true);
   auto k_proll = ilq_probe_roll_kernel<T, NX, NP, MU>;
   auto k_prows = ilq_probe_rows_kernel<T, NX, NP, MU>;
@@ -885,10 +897,10 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   int round_instances = batch, list = 0;  // split passes: how many instances this round covers, which list is free
   int tail_rounds = 0;                    // rounds since the whole batch was last in one
   if (lists) {
-    raise_lds_limit((const void*)k_roll, lds_roll);
+    raise_lds_limit((const void*)k_roll, lds_proll);
     raise_lds_limit((const void*)k_rows, lds_rows);
     raise_lds_limit((const void*)k_decide, lds_decide);
-    raise_lds_limit((const void*)k_proll, lds_roll);
+    raise_lds_limit((const void*)k_proll, lds_proll);
     raise_lds_limit((const void*)k_prows, lds_rows);
   }
   sa.first = resume ? 2 : 1;
@@ -932,7 +944,8 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
         HIP_TRY(hipMemsetAsync(p->d_unfinished, 0, 4 * sizeof(int), stream));
         if (split) {  // the three-kernel form of the pass over the whole batch (no probing: nobody is listed)
           sa.ids_next = pass_ids + size_t(list) * batch;
-          hipLaunchKernelGGL(k_roll, dim3(batch), dim3(64), lds_roll, stream, d, sa);
+          sa.round_count = batch;
+          hipLaunchKernelGGL(k_roll, dim3(pairs ? (batch + 1) / 2 : batch), dim3(64), lds_proll, stream, d, sa);
           HIP_TRY(hipGetLastError());
           sa.first = 0;
           hipLaunchKernelGGL(k_rows, dim3(row_chunks, batch), dim3(64), lds_rows, stream, d, sa);
@@ -983,7 +996,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
         // the listed instances' next step sizes side by side; their states move to the first acceptable one
         sa.probe_pool = probe_pool;
         sa.probe_k = probe_k;
-        hipLaunchKernelGGL(k_proll, dim3(round_instances, probe_k), dim3(64), lds_roll, stream, d, sa);
+        hipLaunchKernelGGL(k_proll, dim3(round_instances, pairs ? (probe_k + 1) / 2 : probe_k), dim3(64), lds_proll, stream, d, sa);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(k_prows, dim3(row_chunks, round_instances * probe_k),
                            dim3(64), lds_rows, stream, d, sa);
@@ -994,7 +1007,8 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
         hipLaunchKernelGGL(ilq_probe_pick_kernel<T>, dim3(round_instances), dim3(64), 0, stream, d, sa);
         HIP_TRY(hipGetLastError());
       }
-      hipLaunchKernelGGL(k_roll, dim3(round_instances), dim3(64), lds_roll, stream, d, sa);
+      sa.round_count = round_instances;
+      hipLaunchKernelGGL(k_roll, dim3(pairs ? (round_instances + 1) / 2 : round_instances), dim3(64), lds_proll, stream, d, sa);
       HIP_TRY(hipGetLastError());
       sa.first = 0;
       hipLaunchKernelGGL(k_rows, dim3(row_chunks, round_instances), dim3(64),

@@ -201,10 +201,12 @@ __device__ __forceinline__ float div_by(float x, float c, float rc) {
 // lane forms the heading at its stage from them; one sincos per lane gives the position rates, which go through LDS
 // once more for the two RK4 combinations.  Two libm latencies and two LDS exchanges per step; the expressions are
 // RK4's up to the order of the roundings (a few ulp per step).  All 8 lanes return the new state in x[].
-// `gth` is LDS scratch of 64 + 128 elements (this wave's); any_car: some group of the wave holds a car model.
+// `gth` is LDS scratch of 64 + 128 elements (this wave's); any_car: some group of the wave holds a car model;
+// `group`: the lanes of this trajectory (ilqg_trig.hpp: the library fall-back is decided over them).
 template <typename T, bool DIST = false, bool DUB = false>
 __device__ __forceinline__ void sub_integrate_stages(int kind, T L, double interval, T* x, T u0, T u1, int q, int lane,
-                                                     T* gth, bool any_car, T d0 = T(0), T d1 = T(0)) {
+                                                     T* gth, bool any_car, T d0 = T(0), T d1 = T(0),
+                                                     unsigned long long group = ~0ull) {
   const T h = T(interval / 2.0);
   const T six = T(6.0), rsix = T(1.0) / T(6.0), rL = T(1.0) / L;
   const bool dubins = DUB && kind == ILQG_DYN_DUBINS_CAR;
@@ -239,7 +241,7 @@ __device__ __forceinline__ void sub_integrate_stages(int kind, T L, double inter
   // ---- heading at this lane's stage ----
   T th_q = ang_q, th_end = ang_end;
   if (any_car) {  // wave-uniform
-    const T kth = car ? h * (div_by(v_q, L, rL) * fast_tan(ang_q)) : T(0);
+    const T kth = car ? h * (div_by(v_q, L, rL) * fast_tan(ang_q, group)) : T(0);
     gth[lane] = kth;
     lds_sync(true);
     const T* g = gth + (lane & ~7);
@@ -253,7 +255,7 @@ __device__ __forceinline__ void sub_integrate_stages(int kind, T L, double inter
   }
   // ---- position rates of this lane's stage, then the two RK4 combinations ----
   T sn, cs;
-  fast_sincos(th_q, &sn, &cs);
+  fast_sincos(th_q, &sn, &cs, group);
   const T kx = DIST ? h * (v_q * cs + d0) : h * (v_q * cs);
   const T ky = DIST ? h * (v_q * sn + d1) : h * (v_q * sn);
   T* gxy = gth + 64;

@@ -46,6 +46,7 @@ struct SolveArgs {
   // lists the ones that need another pass, and the rows of one instance a workgroup of the row kernel takes
   const int* ids;
   int* ids_next;
+  int round_count;      // instances this round's split kernels cover (the batch, or the length of `ids`)
   const T* forced_steps;  // [B][fixed_iters] or null: test mode, iteration q of instance b takes this step, no Armijo test
   int defer_forward;    // 1: the sweep's forward pass / ExpectedDecrease runs in the next trial pass, beside the rollout
   int prio_div;         // > 0: the batch is resident at once on this many CUs: the kernels rotate their wave priorities so
@@ -466,6 +467,31 @@ __device__ __forceinline__ void probe_roll_instance(const DevProblem& p, const S
                                                                                          nullptr, nullptr);
 }
 
+// Two candidates of one instance per wavefront (rollout_pair): j0 and j0 + 1 share the staged gains and references.
+template <typename T, int NX, int NP, int MU>
+__device__ __forceinline__ void probe_roll_pair(const DevProblem& p, const SolveArgs<T>& sa, int b, int slot, int j0, T* sm) {
+  const InstanceBuffers<T> ib(p, sa, b);
+  const SolveState<T> s = state_load<T>(ib.w, ib.L);
+  const bool w0 = probe_wanted(sa, s, j0), w1 = j0 + 1 < sa.probe_k && probe_wanted(sa, s, j0 + 1);
+  if (!w0 && !w1) return;
+  const ProbeEntry E(p.n, p.m, p.N, p.T);
+  const int snew = 1 - s.sacc;
+  RolloutArgs<T> ra[2];
+  for (int q = 0; q < 2; q++) {
+    const int j = (q == 0 ? w0 : w1) ? j0 + q : (w0 ? j0 : j0 + 1);  // an idle half repeats the other candidate
+    T* const e = sa.probe_pool + (size_t(slot) * sa.probe_k + j) * E.total;
+    ra[q].x0 = ib.XS(s.cur);
+    ra[q].xs_ref = ib.XS(s.cur);
+    ra[q].us_ref = ib.US(s.cur);
+    ra[q].P = ib.PB(snew);
+    ra[q].alpha = ib.AL(snew);
+    ra[q].alpha_scale = probe_step(sa, s, j);
+    ra[q].xs = e + E.xs;
+    ra[q].us = e + E.us;
+  }
+  rollout_pair<T, NX, NP * MU, (MU == 1)>(p, ra[0], ra[1], w0, w1, sm, int(threadIdx.x));
+}
+
 template <typename T, int NX, int NP, int MU>
 __device__ __forceinline__ void probe_rows_instance(const DevProblem& p, const short* maps, const SolveArgs<T>& sa,
                                                     int b, int slot, int j, int chunk, T* sm) {
@@ -552,6 +578,96 @@ __device__ __forceinline__ void probe_pick_instance(const DevProblem& p, const S
   state_store<T>(ib.w, ib.L, s);
 }
 
+// The state an instance enters a trial pass with: read back from its workspace, or — on the first launch of a solve
+// (sa.first) — initialised here together with what the solve starts from.  Executed by every thread of the workgroup.
+template <typename T>
+__device__ __forceinline__ SolveState<T> trial_state_begin(const DevProblem& p, const SolveArgs<T>& sa,
+                                                           const InstanceBuffers<T>& ib, int b, int n, int N, int m) {
+  const WsLayout& L = ib.L;
+  T* const w = ib.w;
+  const int Tn = p.T, t = threadIdx.x;
+  SolveState<T> s;
+  if (sa.first) {
+    int* const t_extreme = ib.t_extreme();
+    T* const lambdas = w + L.lambdas;  // Constraint::lambdas_, zero-initialised (types.h:128)
+    if (t < n) ib.xs0[t] = sa.x0[size_t(b) * n + t];  // xs[0] = x0 (src/ilq_solver.cpp:89-90)
+    if (t < N) t_extreme[t] = 0;  // PlayerCost::time_of_extreme_cost_ starts at 0 (player_cost.h:70)
+    for (int e = t; e < p.num_constraints * Tn; e += blockDim.x) lambdas[e] = T(0);
+    if (sa.al_mode) {  // Problem's stored solution (what OverwriteSolution maintains)
+      for (int e = t; e < Tn * n; e += blockDim.x) (w + L.wxs)[e] = ib.xs0[e];
+      for (int e = t; e < Tn * m; e += blockDim.x) (w + L.wus)[e] = ib.us0[e];
+      for (int e = t; e < Tn * m * n; e += blockDim.x) (w + L.wP)[e] = ib.P0[e];
+      for (int e = t; e < Tn * m; e += blockDim.x) (w + L.wal)[e] = ib.al0[e];
+    }
+    s.stage = ST_ROLLOUT; s.qmode = Q_COSTS; s.initial = 1; s.cur = 0; s.sacc = 0;
+    s.num_iterations = 0; s.bt = 0; s.accepted_iters = 0; s.has_converged = 0; s.ok = 1;
+    s.logged = 0; s.inner_calls = 0; s.al_success = 1; s.ed_pending = 0; s.rejected = 0; s.pad2 = 0;
+    // first == 2: the solver object has been called before on this workspace and its
+    // last_merit_function_value_ (ilq_solver.h:189) is still what the previous call left
+    const T carried = (sa.first == 2) ? state_load<T>(w, L).last_merit : dinf<T>();
+    s.acc_scale = T(1); s.step = T(1); s.last_merit = carried; s.expected_decrease = dinf<T>();
+    s.max_err = dinf<T>();
+    s.mu = T(10);  // Constraint::mu_ = kDefaultMu (src/constraint.cpp:61) — one per instance
+  } else {
+    s = state_load<T>(w, L);
+  }
+  return s;
+}
+
+// The rollout of a pass whose instance is in ST_ROLLOUT: its inputs and outputs, and what the state becomes with it.
+template <typename T>
+__device__ __forceinline__ void trial_rollout_args(const SolveArgs<T>& sa, const InstanceBuffers<T>& ib, int b, int n,
+                                                   SolveState<T>& s, RolloutArgs<T>& ra) {
+  // initial: from the warm start (:100-104); later: trial point of the line search (:309-342)
+  const int snew = 1 - s.sacc;
+  ra.x0 = s.initial ? sa.x0 + size_t(b) * n : ib.XS(s.cur);
+  ra.xs_ref = s.initial ? ib.XS(0) : ib.XS(s.cur);
+  ra.us_ref = s.initial ? ib.US(0) : ib.US(s.cur);
+  ra.P = s.initial ? ib.PB(0) : ib.PB(snew);
+  ra.alpha = s.initial ? ib.AL(0) : ib.AL(snew);
+  ra.alpha_scale = s.initial ? T(1) : s.step;
+  ra.xs = s.initial ? ib.XS(1) : ib.XS(1 - s.cur);
+  ra.us = s.initial ? ib.US(1) : ib.US(1 - s.cur);
+  if (s.initial) {
+    s.cur = 1;
+    s.qmode = Q_COSTS;  // TotalCosts (:107) before quadraticising (:116): costs set t_extreme
+  } else {
+    s.qmode = sa.prm.linesearch ? Q_TRIAL : Q_LIN;
+  }
+}
+
+// The rollout kernel of the split pass with TWO instances per wavefront (rollout_pair, ilqg_stages.hpp): what
+// trial_part_instance<..., TRIAL_ROLL> does for one — the state in, the pass's rollout, the state out — for b0 and b1
+// (b1 < 0: none) side by side.
+template <typename T, int NX, int NP, int MU>
+__device__ __forceinline__ void roll_pair_instances(const DevProblem& p, const SolveArgs<T>& sa, int b0, int b1, T* sm) {
+  constexpr int n = NX, N = NP, m = NP * MU;
+  const InstanceBuffers<T> ib0(p, sa, b0), ib1(p, sa, b1 < 0 ? b0 : b1);
+  SolveState<T> s0, s1;
+  RolloutArgs<T> r0, r1;
+  // an instance this pass is not for (not in ST_ROLLOUT, or switched off by the caller's mask on the first launch) is
+  // left alone, as ilq_roll_kernel leaves it
+  auto enter = [&](const InstanceBuffers<T>& ib, int b, SolveState<T>& s, RolloutArgs<T>& r) -> bool {
+    if (b < 0) return false;
+    if (!sa.first) {
+      if (reinterpret_cast<const SolveState<T>*>(ib.w + ib.L.state)->stage != ST_ROLLOUT) return false;
+    } else if (sa.active && !sa.active[b]) {
+      if (threadIdx.x == 0) reinterpret_cast<SolveState<T>*>(ib.w + ib.L.state)->stage = ST_DONE;
+      return false;
+    }
+    s = trial_state_begin<T>(p, sa, ib, b, n, N, m);
+    if (s.stage != ST_ROLLOUT) return false;
+    trial_rollout_args<T>(sa, ib, b, n, s, r);
+    return true;
+  };
+  const bool g0 = enter(ib0, b0, s0, r0), g1 = enter(ib1, b1, s1, r1);
+  if (!g0 && !g1) return;
+  __syncthreads();  // what the first launch wrote (xs[0]) is the rollout's to read
+  rollout_pair<T, NX, NP * MU, (MU == 1)>(p, g0 ? r0 : r1, g1 ? r1 : r0, g0, g1, sm, int(threadIdx.x));
+  if (g0) state_store<T>(ib0.w, ib0.L, s0);
+  if (g1) state_store<T>(ib1.w, ib1.L, s1);
+}
+
 template <typename T, int NX, int NP, int MU, int W, int PHASE = TRIAL_FUSED>
 __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const short* maps,
                                                     const SolveArgs<T>& sa, int b, T* sm) {
@@ -578,29 +694,7 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const s
   int* const flags = reinterpret_cast<int*>(sm + re + size_t(RW) * qe);  // [0] rows ready, [1] next chunk to claim
   T* const ed_slot = reinterpret_cast<T*>(flags + 2);  // deferred ExpectedDecrease, from the first row wave to everyone
 
-  SolveState<T> s;
-  if (sa.first) {
-    if (t < n) ib.xs0[t] = sa.x0[size_t(b) * n + t];  // xs[0] = x0 (src/ilq_solver.cpp:89-90)
-    if (t < N) t_extreme[t] = 0;  // PlayerCost::time_of_extreme_cost_ starts at 0 (player_cost.h:70)
-    for (int e = t; e < p.num_constraints * Tn; e += blockDim.x) lambdas[e] = T(0);
-    if (sa.al_mode) {  // Problem's stored solution (what OverwriteSolution maintains)
-      for (int e = t; e < Tn * n; e += blockDim.x) (w + L.wxs)[e] = ib.xs0[e];
-      for (int e = t; e < Tn * m; e += blockDim.x) (w + L.wus)[e] = ib.us0[e];
-      for (int e = t; e < Tn * m * n; e += blockDim.x) (w + L.wP)[e] = ib.P0[e];
-      for (int e = t; e < Tn * m; e += blockDim.x) (w + L.wal)[e] = ib.al0[e];
-    }
-    s.stage = ST_ROLLOUT; s.qmode = Q_COSTS; s.initial = 1; s.cur = 0; s.sacc = 0;
-    s.num_iterations = 0; s.bt = 0; s.accepted_iters = 0; s.has_converged = 0; s.ok = 1;
-    s.logged = 0; s.inner_calls = 0; s.al_success = 1; s.ed_pending = 0; s.rejected = 0; s.pad2 = 0;
-    // first == 2: the solver object has been called before on this workspace and its
-    // last_merit_function_value_ (ilq_solver.h:189) is still what the previous call left
-    const T carried = (sa.first == 2) ? state_load<T>(w, L).last_merit : dinf<T>();
-    s.acc_scale = T(1); s.step = T(1); s.last_merit = carried; s.expected_decrease = dinf<T>();
-    s.max_err = dinf<T>();
-    s.mu = T(10);  // Constraint::mu_ = kDefaultMu (src/constraint.cpp:61) — one per instance
-  } else {
-    s = state_load<T>(w, L);
-  }
+  SolveState<T> s = trial_state_begin<T>(p, sa, ib, b, n, N, m);
   const int max_iters = solve_max_iters(sa);
   tl_stamp(sa.prof, b, 0, t == 0);
   const long long pr_start = clock64();
@@ -612,24 +706,7 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const s
     __syncthreads();  // pass boundary: global-memory hand-off between waves
     const bool roll = PHASE != TRIAL_DECIDE && s.stage == ST_ROLLOUT;  // TRIAL_DECIDE: the pass's rollout is behind it
     RolloutArgs<T> ra;
-    if (roll) {
-      // initial: from the warm start (:100-104); later: trial point of the line search (:309-342)
-      const int snew = 1 - s.sacc;
-      ra.x0 = s.initial ? sa.x0 + size_t(b) * n : ib.XS(s.cur);
-      ra.xs_ref = s.initial ? ib.XS(0) : ib.XS(s.cur);
-      ra.us_ref = s.initial ? ib.US(0) : ib.US(s.cur);
-      ra.P = s.initial ? ib.PB(0) : ib.PB(snew);
-      ra.alpha = s.initial ? ib.AL(0) : ib.AL(snew);
-      ra.alpha_scale = s.initial ? T(1) : s.step;
-      ra.xs = s.initial ? ib.XS(1) : ib.XS(1 - s.cur);
-      ra.us = s.initial ? ib.US(1) : ib.US(1 - s.cur);
-      if (s.initial) {
-        s.cur = 1;
-        s.qmode = Q_COSTS;  // TotalCosts (:107) before quadraticising (:116): costs set t_extreme
-      } else {
-        s.qmode = prm.linesearch ? Q_TRIAL : Q_LIN;
-      }
-    }
+    if (roll) trial_rollout_args<T>(sa, ib, b, n, s, ra);
     if (t == 0) {
       flags[0] = roll ? 0 : Tn;
       flags[1] = 0;

@@ -6,6 +6,10 @@
 #include "ilqg_common.hpp"
 #include "ilqg_models.hpp"
 
+#ifndef ILQG_ROLLOUT_PAIRS
+#define ILQG_ROLLOUT_PAIRS 1  // two rollouts per wavefront in the split rollout kernels (0: one, for A/B measurements)
+#endif
+
 namespace ilqg {
 
 // ---------------------------------------------------------------------------
@@ -179,6 +183,144 @@ __device__ __forceinline__ void rollout_instance(const DevProblem& p, const Roll
   }
 #undef ILQG_RPH
   if (ready) progress_publish(ready, Tn);
+}
+
+// ---------------------------------------------------------------------------
+// Two rollouts per wavefront.  rollout_instance uses 8 lanes per subsystem and m lanes for the controls — 24 of 64 for
+// three players — and the split rollout kernel at four waves per SIMD is bound by the instructions it issues (~520 per
+// step, ~300 of them fp64), not by their latency: the second half of the wave takes a second trajectory through the same
+// instruction stream.  Lanes 0-31 integrate `a0`, lanes 32-63 `a1`: the same lane roles within each half (subsystem
+// g = (t & 31) / 8, stage q = t & 7, control lane (t & 31) < m), each half with its own [x | dx | u] and staged
+// [P | alpha | u_ref | x_ref] blocks in LDS, the same arithmetic per lane — a trajectory comes out bit for bit as
+// rollout_instance would produce it.  `act0` / `act1`: whether the half's trajectory is wanted (an idle half repeats
+// the other's inputs and stores nothing).  N <= 4, m <= 32; the integrators with their own lane layouts (Air3D, point
+// masses, the plain-RK4 models, the disturbed unicycle) stay on rollout_instance.
+// ---------------------------------------------------------------------------
+__host__ __device__ constexpr bool rollout_pairs(int nx, int np, int mu) {
+  return nx > 0 && np <= 4 && np * mu <= 32 && !(nx == 4 && np == 2) && !(nx == 3 && np == 2 && mu == 1) &&
+         !(nx == 4 * np && mu == 2 && np <= 2) && !dims_use_plain_rk4(nx, np, mu) && ILQG_ROLLOUT_PAIRS;
+}
+__host__ __device__ inline int rollout_pair_lds_elems(int n, int m) {
+  return 2 * ((2 * n + m + 3) & ~3) + 4 * rollout_stage_elems(n, m) + kRolloutGatherElems;
+}
+
+// one half's LDS-DMA: lanes 32 H .. 32 H + 31 move `nbytes` from g to l in 4-byte pieces (the hardware writes lane L's
+// piece at base + 4 L, so the upper half aims 128 bytes low)
+template <int H>
+__device__ __forceinline__ void dma_g2l_half(const void* g_, void* l, int nbytes, int tl) {
+  const void* g = uniform_ptr(g_);
+  for (int off = 0; off < nbytes; off += 128) {
+    const int my = off + tl * 4;
+    if (my < nbytes)
+      __builtin_amdgcn_global_load_lds((glb_vptr)((const char*)g + unsigned(my)), (lds_vptr)((char*)l + off - 128 * H), 4, 0, 0);
+  }
+}
+
+template <typename T, int CN, int CM, bool DUB>
+__device__ __forceinline__ void rollout_pair(const DevProblem& p, const RolloutArgs<T>& a0, const RolloutArgs<T>& a1,
+                                             bool act0, bool act1, T* sm, int t) {
+  static_assert(CN > 0 && CM > 0 && CM <= 32, "compile-time dimensions");
+  constexpr int n = CN, m = CM;
+  const int N = p.N, Tn = p.T;
+  const int h = t >> 5, tl = t & 31;
+  constexpr int S0 = (2 * n + m + 3) & ~3;
+  const int WP = rollout_stage_elems(n, m);
+  T* const sx = sm + h * S0;  // this half's [x | dx | u]
+  T* const sdx = sx + n;
+  T* const su = sdx + n;
+  T* const stg = sm + 2 * S0 + h * 2 * WP;  // this half's two staged blocks
+  T* const gth = sm + 2 * S0 + 4 * WP;      // the wave's exchange scratch (indexed by lane)
+  constexpr int S = int(sizeof(T));
+  const bool act = h ? act1 : act0;
+  auto issue = [&](int k, int buf) {
+    if (h == 0) {
+      T* d = sm + 2 * S0 + buf * WP;
+      dma_g2l_half<0>(a0.P + size_t(k) * m * n, d, m * n * S, tl);
+      dma_g2l_half<0>(a0.alpha + size_t(k) * m, d + m * n, m * S, tl);
+      dma_g2l_half<0>(a0.us_ref + size_t(k) * m, d + m * n + m, m * S, tl);
+      dma_g2l_half<0>(a0.xs_ref + size_t(k) * n, d + m * n + 2 * m, n * S, tl);
+      // The two arms must stay two instruction streams: the DMA's LDS base travels in M0 and has to be uniform, and an
+      // optimiser that sinks the arms' common tail into one block hands it a per-lane select of the two bases (seen
+      // in the ISA: v_readfirstlane of a VGPR base — the upper half's rows then land in the lower half's block).
+      // Distinct markers at the end of each arm leave nothing identical to sink.
+      asm volatile("; rollout_pair: lower half staged" ::: "memory");
+    } else {
+      T* d = sm + 2 * S0 + 2 * WP + buf * WP;
+      dma_g2l_half<1>(a1.P + size_t(k) * m * n, d, m * n * S, tl);
+      dma_g2l_half<1>(a1.alpha + size_t(k) * m, d + m * n, m * S, tl);
+      dma_g2l_half<1>(a1.us_ref + size_t(k) * m, d + m * n + m, m * S, tl);
+      dma_g2l_half<1>(a1.xs_ref + size_t(k) * n, d + m * n + 2 * m, n * S, tl);
+      asm volatile("; rollout_pair: upper half staged" ::: "memory");
+    }
+  };
+  constexpr int XS = 6;
+  T xj[XS];
+  const int grp = tl >> 3, q = t & 7;
+  const bool integ = grp < N;
+  int kind = ILQG_DYN_UNICYCLE_4D, xo = 0, uo = 0, xd = 0;
+  T Lp = T(1);
+  const T* const x0 = h ? a1.x0 : a0.x0;
+  T* const xs_out = h ? a1.xs : a0.xs;
+  T* const us_out = h ? a1.us : a0.us;
+  const T alpha_scale = h ? a1.alpha_scale : a0.alpha_scale;
+#pragma unroll
+  for (int e = 0; e < XS; e++) xj[e] = T(0);
+  if (integ) {
+    kind = p.sub_kind[grp];
+    xo = p.xoff[grp];
+    uo = p.uoff[grp];
+    xd = p.xoff[grp + 1] - xo;
+    Lp = T(p.sub_param[grp]);
+#pragma unroll
+    for (int e = 0; e < XS; e++) xj[e] = (e < xd) ? x0[xo + e] : T(0);
+  }
+  const bool any_car = __any(integ && (kind == ILQG_DYN_CAR_5D || kind == ILQG_DYN_CAR_6D));
+  issue(0, 0);
+#pragma unroll 1
+  for (int k = 0; k < Tn; k++) {
+    dma_wait();
+    const T* sP = stg + (k & 1) * WP;
+    const T* sal = sP + m * n;
+    const T* sur = sal + m;
+    const T* sxr = sur + m;
+    {
+      T mine = xj[0];
+#pragma unroll
+      for (int e = 1; e < XS; e++) mine = (q == e) ? xj[e] : mine;
+      if (integ && q < xd) {
+        sdx[xo + q] = mine - sxr[xo + q];
+        if (act) xs_out[size_t(k) * n + xo + q] = mine;
+      }
+    }
+    lds_sync(true);
+    if (k + 1 < Tn) issue(k + 1, (k + 1) & 1);
+    if (tl < m) {
+      T s = T(0);
+      constexpr int CH = 8;
+#pragma unroll
+      for (int c0 = 0; c0 < CN; c0 += CH) {
+        T pr[CH], dv[CH];
+#pragma unroll
+        for (int c = 0; c < CH; c++)
+          if (c0 + c < CN) {
+            pr[c] = sP[tl + m * (c0 + c)];
+            dv[c] = sdx[c0 + c];
+          }
+#pragma unroll
+        for (int c = 0; c < CH; c++)
+          if (c0 + c < CN) s += pr[c] * dv[c];
+      }
+      const T u = (sur[tl] - s) - alpha_scale * sal[tl];
+      su[tl] = u;
+      if (act) us_out[size_t(k) * m + tl] = u;
+    }
+    lds_sync(true);
+    if (k + 1 < Tn) {  // the whole wave: the exchanges inside need every group lane live
+      const T u0 = integ ? su[uo] : T(0), u1 = integ ? su[uo + 1] : T(0);
+      sub_integrate_stages<T, false, DUB>(kind, Lp, p.dt, xj, u0, u1, q, t, gth, any_car, T(0), T(0),
+                                          h ? 0xffffffff00000000ull : 0x00000000ffffffffull);
+    }
+  }
 }
 
 // The rollout with run-time dimensions, the integrator picked from the problem's models at run time (what the

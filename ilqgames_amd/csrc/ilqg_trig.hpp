@@ -6,8 +6,10 @@
 // (Payne-Hanek) behind a branch; headings and steering angles of a driving game are a few radians, so here the
 // reduction is the two-constant Cody-Waite form (exact products through FMA) and the kernels are the classical
 // minimax polynomials on [-pi/4, pi/4] (coefficients: the published fdlibm / msun kernels, k_sin.c, k_cos.c,
-// k_sindf.c, k_cosdf.c).  Arguments beyond kTrigFastLimit fall back to the library (wave-uniform test), so the
-// functions are total.  Accuracy on the fast path: sine / cosine <= 1.5 ulp, tangent <= 3 ulp of the correctly rounded value
+// k_sindf.c, k_cosdf.c).  Arguments beyond kTrigFastLimit fall back to the library, so the functions are total.  The test
+// is taken over a GROUP of lanes (`group`: a lane mask; by default the whole wavefront) — one branch for the group, and what
+// a lane computes depends on its group only: where two trajectories share a wavefront (rollout_pair) each passes its own
+// half, so neither sees the other's arguments.  Accuracy on the fast path: sine / cosine <= 1.5 ulp, tangent <= 3 ulp of the correctly rounded value
 // (tests/host/trig_check.cpp checks it on the host over the whole range; scripts/ubench/trig_lat.hip
 // prints the worst disagreement with libm) — the same order as the difference between the device libm and a host
 // libm, and ten orders of magnitude inside the parity bar.
@@ -78,18 +80,26 @@ __host__ __device__ __forceinline__ void fast_sincos_core(T x, T* s, T* c) {
   *c = ((n + 1) & 2) ? -cv : cv;
 }
 
-__host__ __device__ __forceinline__ void fast_sincos(double x, double* s, double* c) {
+// does any lane of `group` (all lanes: ~0) hold an argument the fast path does not take?  NaN goes to the library too
 #if defined(__HIP_DEVICE_COMPILE__)
-  if (__builtin_expect(__any(!(__builtin_fabs(x) <= kTrigFastLimit)), 0)) {  // wave-uniform; NaN goes to the library too
+__device__ __forceinline__ bool trig_group_any(bool mine, unsigned long long group) {
+  if (group == ~0ull) return __any(mine);
+  return (__ballot(mine) & group) != 0;
+}
+#endif
+
+__host__ __device__ __forceinline__ void fast_sincos(double x, double* s, double* c, unsigned long long group = ~0ull) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (__builtin_expect(trig_group_any(!(__builtin_fabs(x) <= kTrigFastLimit), group), 0)) {
     sincos(x, s, c);
     return;
   }
 #endif
   fast_sincos_core<double>(x, s, c);
 }
-__host__ __device__ __forceinline__ void fast_sincos(float x, float* s, float* c) {
+__host__ __device__ __forceinline__ void fast_sincos(float x, float* s, float* c, unsigned long long group = ~0ull) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  if (__builtin_expect(__any(!(__builtin_fabsf(x) <= kTrigFastLimitF)), 0)) {
+  if (__builtin_expect(trig_group_any(!(__builtin_fabsf(x) <= kTrigFastLimitF), group), 0)) {
     sincosf(x, s, c);
     return;
   }
@@ -128,15 +138,15 @@ __host__ __device__ __forceinline__ T fast_tan_core(T x) {
   const bool odd = n & 1;
   return trig_div(odd ? -cr : sr, odd ? sr : cr);
 }
-__host__ __device__ __forceinline__ double fast_tan(double x) {
+__host__ __device__ __forceinline__ double fast_tan(double x, unsigned long long group = ~0ull) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  if (__builtin_expect(__any(!(__builtin_fabs(x) <= kTrigFastLimit)), 0)) return tan(x);
+  if (__builtin_expect(trig_group_any(!(__builtin_fabs(x) <= kTrigFastLimit), group), 0)) return tan(x);
 #endif
   return fast_tan_core<double>(x);
 }
-__host__ __device__ __forceinline__ float fast_tan(float x) {
+__host__ __device__ __forceinline__ float fast_tan(float x, unsigned long long group = ~0ull) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  if (__builtin_expect(__any(!(__builtin_fabsf(x) <= kTrigFastLimitF)), 0)) return tanf(x);
+  if (__builtin_expect(trig_group_any(!(__builtin_fabsf(x) <= kTrigFastLimitF), group), 0)) return tanf(x);
 #endif
   return fast_tan_core<float>(x);
 }
