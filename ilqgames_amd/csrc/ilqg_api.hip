@@ -411,7 +411,7 @@ __global__ void __launch_bounds__(64, sizeof(T) == 8 ? ILQG_ROLL_WAVES : 1) ilq_
 }
 
 template <typename T, int NX, int NP, int MU>
-__global__ void __launch_bounds__(64) ilq_probe_rows_kernel(DevProblem p, SolveArgs<T> sa) {
+__global__ void __launch_bounds__(64, sizeof(T) == 8 ? 4 : 1) ilq_probe_rows_kernel(DevProblem p, SolveArgs<T> sa) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int slot = blockIdx.y / sa.probe_k, j = blockIdx.y % sa.probe_k;
   const int b = sa.ids[slot];
@@ -887,6 +887,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   const size_t lds_roll = trial_phase_lds_bytes<T>(d, TRIAL_ROLL, sa.rows_cw),
                lds_decide = trial_phase_lds_bytes<T>(d, TRIAL_DECIDE, sa.rows_cw);
   const size_t lds_rows = split_maps_bytes + split_rows_elems(d, NX, sa.rows_cw) * sizeof(T);
+  const size_t lds_prows = split_maps_bytes + probe_rows_elems(d, NX, sa.rows_cw) * sizeof(T);  // merit only
   constexpr bool pairs = rollout_pairs(NX, NP, MU);  // two rollouts per wavefront (ilqg_stages.hpp)
   const size_t lds_proll = pairs ? size_t(rollout_pair_lds_elems(d.n, d.m)) * sizeof(T) + 16 : lds_roll;
   const bool probe = lists && sa.prm.linesearch && choice(opt.probe, true);
@@ -901,7 +902,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
     raise_lds_limit((const void*)k_rows, lds_rows);
     raise_lds_limit((const void*)k_decide, lds_decide);
     raise_lds_limit((const void*)k_proll, lds_proll);
-    raise_lds_limit((const void*)k_prows, lds_rows);
+    raise_lds_limit((const void*)k_prows, lds_prows);
   }
   sa.first = resume ? 2 : 1;
   int waiting_lq = 0, waiting_exit = 0;  // split passes: instances already through this iteration's line search
@@ -999,7 +1000,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
         hipLaunchKernelGGL(k_proll, dim3(round_instances, pairs ? (probe_k + 1) / 2 : probe_k), dim3(64), lds_proll, stream, d, sa);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(k_prows, dim3(row_chunks, round_instances * probe_k),
-                           dim3(64), lds_rows, stream, d, sa);
+                           dim3(64), lds_prows, stream, d, sa);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(ilq_probe_merit_kernel<T>, dim3(round_instances, probe_k), dim3(64),
                            size_t(decide_elems) * sizeof(T), stream, d, sa, decide_elems);
@@ -1780,6 +1781,7 @@ ilqg_status ilqg_problem_create(const ilqg_problem_desc* desc, ilqg_problem** ou
   d.row_prog_words = int(rph.words.size());
   d.rp_pslots = rph.num_pslots;
   d.rp_lslots = rph.max_lslots;
+  d.rp_gslots = rph.max_gslots;
   d.rp_maps_off = rph.maps_off;
   d.rp_maps_words = rph.maps_words;
   d.rp_compact_off = rph.compact_off;

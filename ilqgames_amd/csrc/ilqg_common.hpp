@@ -96,6 +96,7 @@ struct DevProblem {
   const int* row_prog;
   int row_prog_words;
   int rp_pslots, rp_lslots;  // persistent / most pass-local slots: sizes the stage's LDS
+  int rp_gslots;             // most gradient slots of a pass (numbered first: a merit-only evaluation keeps only these)
   int rp_maps_off, rp_maps_words;  // the program's word -> slot maps (copied into LDS by every workgroup)
   int rp_compact_off, rp_compact_w;  // compact rows (ilqg_rows.hpp): the block's offset in row_prog, words per row (0: none)
 };

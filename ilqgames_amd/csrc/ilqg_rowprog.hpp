@@ -21,7 +21,7 @@ namespace ilqg {
 
 struct RowProgramHost {
   std::vector<int> words;  // the device image
-  int num_pslots = 0, max_lslots = 0, maps_off = 0, maps_words = 0;
+  int num_pslots = 0, max_lslots = 0, max_gslots = 0, maps_off = 0, maps_words = 0;
   int compact_off = 0, compact_w = 0;  // the compact-row block (ilqg_rows.hpp: RP_OFF_COMPACT) and its row length
 };
 
@@ -88,7 +88,7 @@ inline bool build_row_program(const DevProblem& d, const std::vector<DevTerm>& d
   // ---- tables ----
   std::vector<int> passes, ops, sids, linit, regions, merit;
   std::vector<short> maps;
-  int max_lslots = 0;
+  int max_lslots = 0, max_gslots = 0;
   auto emit_op = [&](int mode, int sid_begin, int nsid, int aux, const DevTerm& c, const DevTerm& owner, int poly_first,
                      int pattern_or_nseg) {
     // `owner`: the top-level term whose role / player / constraint slot / first step apply (c itself, or the
@@ -212,7 +212,7 @@ inline bool build_row_program(const DevProblem& d, const std::vector<DevTerm>& d
     add_region(RA_A, n * n, 0, mapA);
     add_region(RA_B, n * m, 0, mapB);
     passes.insert(passes.end(), {op_begin, int(ops.size()) / ROP_WORDS, reg_begin, int(regions.size()) / RREG_WORDS,
-                                 li_begin, nl, RPASS_JACOBIANS, 0});
+                                 li_begin, nl, RPASS_JACOBIANS, 0, 0});
     if (nl > max_lslots) max_lslots = nl;
     collect_compact(reg_begin, nl);
   }
@@ -225,6 +225,8 @@ inline bool build_row_program(const DevProblem& d, const std::vector<DevTerm>& d
     std::map<std::pair<int, int>, int> R_slot;  // (pair, a + mj * b)
     std::map<std::pair<int, int>, int> r_slot;  // (pair, d)
     const int op_begin = int(ops.size()) / ROP_WORDS, li_begin = int(linit.size()) / RINIT_WORDS;
+    const size_t sids_begin = sids.size();
+    std::vector<int> scratch_slots;  // an affine vector constraint's temporaries
     int nl = 0;
     // sigma_u on the diagonal of every control block of this player (player_cost.cpp:70-74)
     for (int q = 0; q < pt.npairs; q++) {
@@ -323,6 +325,7 @@ inline bool build_row_program(const DevProblem& d, const std::vector<DevTerm>& d
           // temporaries; unmapped slots also keep such a problem off the compact rows, whose every slot feeds a word)
           const int b0 = leaf_sids(c, c);
           for (int q = 0; q < 2 * c.arg_dim; q++) {
+            scratch_slots.push_back(nl);
             sids.push_back(NPS + nl++);
             add_linit(RI_VALUE, 0.0f);
           }
@@ -335,6 +338,36 @@ inline bool build_row_program(const DevProblem& d, const std::vector<DevTerm>& d
         }
       }
     if (!ok) { *err = "row program: a term's indices are out of range or not distinct"; return false; }
+    // Gradient slots first.  A merit-only evaluation (the speculative line search: rows_chunk<..., GRAD_ONLY>) touches the
+    // slots of l_i and r_ij — and an affine constraint's temporaries — only, so with those numbered [0, ng) its scratch is
+    // ng slots wide instead of nl.  The order in which anything is accumulated does not change: only the names do.
+    int ng = 0;
+    {
+      std::vector<int> perm((size_t)nl, -1);
+      std::vector<char> grad((size_t)nl, 0);
+      for (auto& kv : l_slot) grad[kv.second] = 1;
+      for (auto& kv : r_slot) grad[kv.second] = 1;
+      for (int sl : scratch_slots) grad[sl] = 1;
+      for (int o = 0; o < nl; o++)
+        if (grad[o]) perm[o] = ng++;
+      int nh = ng;
+      for (int o = 0; o < nl; o++)
+        if (!grad[o]) perm[o] = nh++;
+      auto re = [&](int sid) { return sid >= NPS ? NPS + perm[sid - NPS] : sid; };
+      for (auto& kv : q_slot) kv.second = perm[kv.second];
+      for (auto& kv : l_slot) kv.second = perm[kv.second];
+      for (auto& kv : R_slot) kv.second = perm[kv.second];
+      for (auto& kv : r_slot) kv.second = perm[kv.second];
+      for (size_t e = sids_begin; e < sids.size(); e++) sids[e] = re(sids[e]);
+      for (int op = op_begin; op < int(ops.size()) / ROP_WORDS; op++) {
+        int* o = ops.data() + size_t(op) * ROP_WORDS;
+        for (int e = 0; e < ROP_INLINE_SIDS && e < o[RO_NSID]; e++) o[ROP_FIELDS + e] = re(o[ROP_FIELDS + e]);
+      }
+      std::vector<int> li(linit.begin() + size_t(li_begin) * RINIT_WORDS, linit.end());
+      for (int o = 0; o < nl; o++)
+        for (int q = 0; q < RINIT_WORDS; q++) linit[(size_t(li_begin) + perm[o]) * RINIT_WORDS + q] = li[size_t(o) * RINIT_WORDS + q];
+    }
+    if (ng > max_gslots) max_gslots = ng;
     // what this pass writes: Q_i, l_i and the R / r blocks of this player's control pairs
     const int reg_begin = int(regions.size()) / RREG_WORDS;
     {
@@ -368,7 +401,7 @@ inline bool build_row_program(const DevProblem& d, const std::vector<DevTerm>& d
       md[0] = lb; md[1] = int(l_slot.size()); md[2] = rb; md[3] = mi;
     }
     passes.insert(passes.end(), {op_begin, int(ops.size()) / ROP_WORDS, reg_begin, int(regions.size()) / RREG_WORDS,
-                                 li_begin, nl, RPASS_PLAYER, i});
+                                 li_begin, nl, RPASS_PLAYER, i, ng});
     if (nl > max_lslots) max_lslots = nl;
     collect_compact(reg_begin, nl);
   }
@@ -435,6 +468,7 @@ inline bool build_row_program(const DevProblem& d, const std::vector<DevTerm>& d
   w[RP_WORDS] = int(w.size());
   out->num_pslots = NPS;
   out->max_lslots = max_lslots;
+  out->max_gslots = max_gslots;
   out->maps_off = w[RP_OFF_MAPS];
   out->maps_words = w[RP_MAPS_WORDS];
   return true;

@@ -51,7 +51,7 @@ enum {
   RP_NUM_PASSES = 0, RP_NUM_PSLOTS, RP_MAX_LSLOTS, RP_OFF_PASS, RP_OFF_OPS, RP_OFF_SIDS, RP_OFF_PINIT, RP_OFF_LINIT,
   RP_OFF_REGIONS, RP_OFF_MAPS, RP_MAPS_WORDS, RP_OFF_MERIT, RP_WORDS, RP_OFF_COMPACT, RP_HEADER = 16
 };
-enum { RPASS_WORDS = 8, ROP_FIELDS = 20, ROP_INLINE_SIDS = 20, ROP_WORDS = 40, RREG_WORDS = 4, RMERIT_WORDS = 4, RINIT_WORDS = 2 };
+enum { RPASS_WORDS = 9, ROP_FIELDS = 20, ROP_INLINE_SIDS = 20, ROP_WORDS = 40, RREG_WORDS = 4, RMERIT_WORDS = 4, RINIT_WORDS = 2 };
 // An op is self-contained: [mode, first slot id, slot ids, aux | the fields of the term it evaluates | its first
 // ROP_INLINE_SIDS slot ids] — one batch of scalar loads per op (a PAT_ALL term on a wide vector reads the rest of its
 // slot ids from the list at RO_SID).
@@ -147,6 +147,10 @@ __host__ __device__ constexpr bool rows_state_in_registers(int cn, int cm) {
 }
 __host__ __device__ inline size_t rows_lds_elems_xreg(int num_pslots, int max_lslots, int cw) {
   return size_t(num_pslots + max_lslots) * (cw + 1);
+}
+// ... and of a merit-only evaluation on top of that (rows_chunk<..., XREG, GRAD_ONLY>): gradient slots only
+__host__ __device__ inline size_t rows_lds_elems_grad(int num_pslots, int max_gslots, int cw) {
+  return size_t(num_pslots + max_gslots) * (cw + 1);
 }
 // Largest chunk width (64, 32 or 16 rows) whose scratch fits `budget` bytes.
 __host__ __device__ inline int rows_chunk_width(int n, int m, int num_pslots, int max_lslots, size_t elem, size_t budget) {
@@ -483,7 +487,10 @@ __device__ __forceinline__ Closest<T> polyline_closest_rows(typename ConstPtr<T>
 // run-time-dimensioned path (shapes without an instantiation): the same program, dimensions read from `p`.
 // XREG: the (x, u) row of this lane lives in registers (MixArg) and there is no LDS image (rows_lds_elems_xreg) — a
 // third less scratch per row, i.e. that many more chunks resident on a CU; n, m <= 16.
-template <typename T, int CN_, int CM_, int CNP_, bool XREG = false>
+// GRAD_ONLY: a merit-only evaluation (the probing passes of the line search: merit_part, nothing else): no Hessian
+// entry is formed or stored, and the scratch holds the persistent slots and each pass's gradient slots only — the row
+// program numbers those first (rows_lds_elems_grad).
+template <typename T, int CN_, int CM_, int CNP_, bool XREG = false, bool GRAD_ONLY = false>
 __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* maps, const QuadArgs<T>& a, int k0,
                                            int nrows, int cw, T* sm, int lane) {
   constexpr bool RT = CN_ == 0;
@@ -504,9 +511,9 @@ __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* map
   const rp_cptr linit = rp + rp[RP_OFF_LINIT];
   const rp_cptr regions = rp + rp[RP_OFF_REGIONS];
   const rp_cptr merit = rp + rp[RP_OFF_MERIT];
-  const bool quad_out = a.Q != nullptr || (a.compact != nullptr && a.compact_quad);
+  const bool quad_out = !GRAD_ONLY && (a.Q != nullptr || (a.compact != nullptr && a.compact_quad));
   const bool do_quad = quad_out || a.merit_part != nullptr;
-  const bool want_cost = a.cost_part != nullptr;
+  const bool want_cost = !GRAD_ONLY && a.cost_part != nullptr;
   const PairTable& pt = p.pairs;
   // phase profile (scripts/stage_bench.py): [0] staging + slot init, [1] Jacobian ops, [2] cost ops, [3] write-out
   long long qc0 = (kProfile && a.phacc) ? clock64() : 0, qc1;
@@ -598,13 +605,15 @@ __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* map
     const rp_cptr pr = passes + ps * RPASS_WORDS;
     const int op_begin = pr[0], op_end = pr[1], reg_begin = pr[2], reg_end = pr[3], li_begin = pr[4], li_count = pr[5];
     const int pkind = pr[6], player = pr[7];
+    if (GRAD_ONLY && pkind == RPASS_JACOBIANS) continue;
     if (pkind == RPASS_JACOBIANS && a.A == nullptr && !(a.compact && a.compact_lin)) continue;
     if (pkind == RPASS_PLAYER && !do_quad && !want_cost) continue;
     T ctot = T(0);  // PlayerCost::Evaluate of this pass's player at this lane's row
     T ext_value = T(0);  // ExtremeValueCost in flight: its value and active child at this lane's row
     int ext_best = 0;
     {
-      for (int s = 0; s < li_count; s++) col[(NPS + s) * cws] = init_value(linit + (li_begin + s) * RINIT_WORDS);
+      const int li_live = GRAD_ONLY ? pr[8] : li_count;  // GRAD_ONLY: the pass's gradient slots, numbered first
+      for (int s = 0; s < li_live; s++) col[(NPS + s) * cws] = init_value(linit + (li_begin + s) * RINIT_WORDS);
       // An op's descriptor (ROP_WORDS words) is fetched as ONE vector load, word w by lane w, one op ahead, and its
       // fields are read out through v_readlane: scalar loads of the descriptor count on lgkmcnt together with the LDS
       // traffic of the op before and return out of order, so every decode drained the accumulators' read-modify-writes
@@ -774,7 +783,7 @@ __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* map
 #else
     ILQG_QPH(0);
 #endif
-    for (int rg = reg_begin; rg < reg_end; rg++) {
+    for (int rg = reg_begin; rg < (GRAD_ONLY ? reg_begin : reg_end); rg++) {
       const rp_cptr rd = regions + rg * RREG_WORDS;
       const int arr = rd[0], words = rd[1], offs = rd[2];
       const short* const map = maps + rd[3];
@@ -801,7 +810,7 @@ __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* map
         if (a.r) rows_writeout_small<T>(a.r + size_t(k0) * pt.rsz + offs, pt.rsz, words, map, acc, cws, nrows, lane);
       }
     }
-    if (a.compact && (pkind == RPASS_PLAYER ? a.compact_quad : a.compact_lin)) {
+    if (!GRAD_ONLY && a.compact && (pkind == RPASS_PLAYER ? a.compact_quad : a.compact_lin)) {
       // compact row: this pass's local slots, in slot order, at the pass's base (lane = slot, loop = row)
       const rp_cptr cb = rp + rp[RP_OFF_COMPACT];
       const int CWD = cb[RC_W], base = cb[RC_BASE + (pkind == RPASS_PLAYER ? 1 + player : 0)];

@@ -204,6 +204,11 @@ __host__ __device__ inline size_t split_rows_elems(const DevProblem& p, int nx, 
   if (!rows_state_in_registers(nx, p.m)) return trial_rows_elems(p, cw);
   return (rows_lds_elems_xreg(p.rp_pslots, p.rp_lslots, cw) + 3) & ~size_t(3);
 }
+// ... and of a workgroup of the probing row kernel, which evaluates the merit function only (gradient slots)
+__host__ __device__ inline size_t probe_rows_elems(const DevProblem& p, int nx, int cw) {
+  const size_t image = rows_state_in_registers(nx, p.m) ? 0 : size_t(p.n + p.m) * cw;
+  return (image + rows_lds_elems_grad(p.rp_pslots, p.rp_gslots, cw) + 3) & ~size_t(3);
+}
 // LDS of the trial kernel: [word maps | rollout scratch | row waves x row scratch | 4 ints]
 template <typename T>
 __host__ __device__ inline size_t trial_lds_bytes(const DevProblem& p, int waves, int cw) {
@@ -513,7 +518,7 @@ __device__ __forceinline__ void probe_rows_instance(const DevProblem& p, const s
   qa.phacc = nullptr;
   const int k0 = chunk * sa.rows_cw;
   const int nrows = p.T - k0 < sa.rows_cw ? p.T - k0 : sa.rows_cw;
-  rows_chunk<T, NX, NP * MU, NP, rows_state_in_registers(NX, NP * MU)>(p, maps, qa, k0, nrows, sa.rows_cw, sm, int(threadIdx.x));
+  rows_chunk<T, NX, NP * MU, NP, rows_state_in_registers(NX, NP * MU), true>(p, maps, qa, k0, nrows, sa.rows_cw, sm, int(threadIdx.x));
 }
 
 template <typename T>
