@@ -982,7 +982,9 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
         // that back-track at all mostly go on for tens of steps (the n = 16 intersection: ~10 % of the batch, mean
         // depth ~30) — and 32 at once ends them in a round or two (measured, B = 1024: 280 k -> 335 k it/s); a long list
         // (config 4: ~40 % of 4096 instances, most done within a step or two) pays for every candidate it does not
-        // need (226 k it/s at 2, 193 k at 32).
+        // need (226 k it/s at 2, 193 k at 32).  Round 4, with two rollouts per wavefront and the gradient-only row pass: a
+        // budget of 8192 rollouts (config 5 / n = 16 constrained / config 4: 249 k / 483 k / 248 k it/s; 4096: 240 / 469 /
+        // 252; 16384: 261 / 483 / 236; 4096 growing fourfold per round: 245 / 457 / 251).
         int first = opt.probe_first;
         if (first <= 0) {
           first = kProbeRoundBudget / (round_instances > 0 ? round_instances : 1);

@@ -421,7 +421,8 @@ constexpr int kProbeCandidates = 128;           // most step sizes probed per in
                                                 // through all max_backtracking_steps of them — 100 in the examples — and a
                                                 // round costs the latency of one rollout whatever it probes)
 constexpr int kProbeEntries = 32768;            // pool size: candidates of all listed instances of one round
-constexpr int kProbeRoundBudget = 4096;         // rollouts the first probing round of a tail may hold (doubling after)
+constexpr int kProbeRoundBudget = 8192;         // rollouts the first probing round of a tail may hold (doubling after): what
+                                                // the chip integrates at once, two per wavefront at four waves per SIMD
 
 struct ProbeEntry {
   size_t xs, us, mpart, merit, total;
