@@ -617,3 +617,32 @@ def test_receding_horizon_shift_rejects_times_outside_the_plan(hip):
         prob.receding_horizon_shift(x0, -0.5, 0.1, 0.0, bufs)   # t0 before the plan (problem.cpp:70)
     with pytest.raises(hip.IlqgError):
         prob.receding_horizon_shift(x0, 9.95, 0.2, 0.0, bufs)   # t0 + runtime past the horizon (:69)
+
+
+@pytest.mark.parametrize("dtype", [abi.F64, abi.F32])
+def test_instances_sharing_a_wavefront_in_the_split_rollout_do_not_see_each_other(hip, dtype):
+    """The split rollout kernels integrate two trajectories per wavefront (rollout_pair, csrc/ilqg_stages.hpp): an
+    instance's result must not depend on who shares its wavefront.  The n = 16 intersection with its own line-search
+    parameters has instances whose rejected trial steps diverge (headings past the fast trigonometric range, where
+    the library fall-back differs in the last bits) next to instances that do not — the pairing that showed a
+    wavefront-wide fall-back vote changing the partner's last bits.  Every instance solved alone, in pairs in both
+    orders, and in the whole batch must give the same bits."""
+    spec = examples.CONFIGS["three_player_intersection"]()
+    spec.params.max_solver_iters = 4
+    B = 9
+    x0 = examples.jittered_x0(spec, B, seed=3)
+    keys = ("xs", "us", "P", "alpha", "costs", "iters", "status")
+
+    def solve(rows):
+        out = hip.Problem(spec, dtype).solve(x0[rows], split_trial=True, probe=False)
+        return {k: _np(out[k]).copy() for k in keys}
+    whole = solve(list(range(B)))
+    for i in range(B):
+        alone = solve([i])
+        for k in keys:
+            assert np.array_equal(alone[k][0], whole[k][i], equal_nan=True), (i, k)
+    for a, b in ((2, 3), (3, 2), (6, 7), (0, 8)):
+        pair = solve([a, b])
+        for k in keys:
+            assert np.array_equal(pair[k][0], whole[k][a], equal_nan=True), (a, b, k)
+            assert np.array_equal(pair[k][1], whole[k][b], equal_nan=True), (a, b, k)
