@@ -426,14 +426,9 @@ __global__ void __launch_bounds__(64, sizeof(T) == 8 ? 4 : 1) ilq_probe_rows_ker
 }
 
 template <typename T>
-__global__ void __launch_bounds__(64) ilq_probe_merit_kernel(DevProblem p, SolveArgs<T> sa, int sm_elems) {
-  extern __shared__ __align__(16) unsigned char smem_raw[];
-  probe_merit_instance<T>(p, sa, sa.ids[blockIdx.x], blockIdx.x, blockIdx.y, reinterpret_cast<T*>(smem_raw), sm_elems);
-}
-
-template <typename T>
 __global__ void __launch_bounds__(64) ilq_probe_pick_kernel(DevProblem p, SolveArgs<T> sa) {
-  probe_pick_instance<T>(p, sa, sa.ids[blockIdx.x], blockIdx.x);
+  __shared__ T merits[kProbeCandidates];  // the candidates' merit values, reduced here one lane per candidate
+  probe_pick_instance<T>(p, sa, sa.ids[blockIdx.x], blockIdx.x, merits);
 }
 
 // Iterate log and anytime exit (ilqg_solve.hpp): only launched by solves that ask for them.
@@ -1003,9 +998,6 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(k_prows, dim3(row_chunks, round_instances * probe_k),
                            dim3(64), lds_prows, stream, d, sa);
-        HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(ilq_probe_merit_kernel<T>, dim3(round_instances, probe_k), dim3(64),
-                           size_t(decide_elems) * sizeof(T), stream, d, sa, decide_elems);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(ilq_probe_pick_kernel<T>, dim3(round_instances), dim3(64), 0, stream, d, sa);
         HIP_TRY(hipGetLastError());

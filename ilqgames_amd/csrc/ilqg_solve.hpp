@@ -522,33 +522,46 @@ __device__ __forceinline__ void probe_rows_instance(const DevProblem& p, const s
   rows_chunk<T, NX, NP * MU, NP, rows_state_in_registers(NX, NP * MU), true>(p, maps, qa, k0, nrows, sa.rows_cw, sm, int(threadIdx.x));
 }
 
-template <typename T>
-__device__ __forceinline__ void probe_merit_instance(const DevProblem& p, const SolveArgs<T>& sa, int b, int slot, int j,
-                                                     T* sm, int sm_elems) {
-  const InstanceBuffers<T> ib(p, sa, b);
-  const SolveState<T> s = state_load<T>(ib.w, ib.L);
-  if (!probe_wanted(sa, s, j)) return;
-  const ProbeEntry E(p.n, p.m, p.N, p.T);
-  T* const e = sa.probe_pool + (size_t(slot) * sa.probe_k + j) * E.total;
-  const T merit = uniform(merit_reduce<T>(p, e + E.mpart, sm, sm_elems));
-  if (threadIdx.x == 0) e[E.merit] = merit;
-}
-
 // The line-search bookkeeping of the candidates, in the order the loop would have met them
 // (CheckArmijoCondition :350-362, the back-tracking branch of ModifyLQStrategies :333-347).
+// `merits` (LDS, kProbeCandidates elements): lane j forms candidate j's merit value first — the per-row partials of its
+// pool entry, summed in merit_reduce's order (one lane per candidate, not one workgroup: the sum is a serial chain either
+// way, and a probing round has thousands of them; round 3 had a kernel of its own for it).  Null: read from the entries.
 template <typename T>
-__device__ __forceinline__ void probe_pick_instance(const DevProblem& p, const SolveArgs<T>& sa, int b, int slot) {
+__device__ __forceinline__ void probe_pick_instance(const DevProblem& p, const SolveArgs<T>& sa, int b, int slot,
+                                                    T* merits = nullptr) {
   const InstanceBuffers<T> ib(p, sa, b);
   SolveState<T> s = state_load<T>(ib.w, ib.L);
   if (!probe_wanted(sa, s, 0)) return;
   const ilqg_solver_params& prm = sa.prm;
   const ProbeEntry E(p.n, p.m, p.N, p.T);
   const T* const e0 = sa.probe_pool + size_t(slot) * sa.probe_k * E.total;
+  if (merits) {
+    const int count = p.T * p.N * 2, skip = p.N * 2;  // the |l_i|^2 terms of k = 0 do not enter (:421)
+    for (int j = threadIdx.x; j < sa.probe_k; j += blockDim.x) {
+      if (s.bt + j >= prm.max_backtracking_steps) continue;
+      const T* const mp = e0 + size_t(j) * E.total + E.mpart;
+      T merit = T(0);
+      int e = 0;
+      for (; e < skip && e < count; e++)
+        if ((e & 1) == 0) merit += mp[e];
+      for (; e + 8 <= count; e += 8) {
+        T x[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) x[u] = mp[e + u];
+#pragma unroll
+        for (int u = 0; u < 8; u++) merit += x[u];
+      }
+      for (; e < count; e++) merit += mp[e];
+      merits[j] = T(0.5) * merit;
+    }
+    __syncthreads();
+  }
   int tried = 0;
   bool found = false;
   T step = s.step, last_tried = s.step;
   for (int j = 0; j < sa.probe_k && s.bt + j < prm.max_backtracking_steps; j++) {
-    const T merit = e0[size_t(j) * E.total + E.merit];
+    const T merit = merits ? merits[j] : e0[size_t(j) * E.total + E.merit];
     const T scaled = T(prm.expected_decrease_fraction) * step * s.expected_decrease;
     if (s.last_merit - merit >= scaled) {
       found = true;
