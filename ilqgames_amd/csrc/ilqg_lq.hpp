@@ -840,8 +840,11 @@ struct PWCfg {
   using C = LQCfg<T, NX, NP, MU>;
   static constexpr int M = NP * MU;
   // leading dimension of a padded tile: 16 would put every other column on the same LDS banks
-  // (8-way conflicts on accumulator-layout reads); 18 doubles / 17 floats spread them
-  static constexpr int LD = sizeof(T) == 8 ? 18 : 17;
+  // (8-way conflicts on accumulator-layout reads); an odd number of elements spreads them.  fp64 ran on 18 until round 4
+  // (16-byte DMA pieces for the dense tiles); with compact rows nothing is DMA'd into the tiles and 17 / 19 / 21 all
+  // measure 2.2 % faster on the headline batch (1.444 -> 1.476 M it/s; SQ_LDS_BANK_CONFLICT was 17 % of the LDS-active
+  // cycles, the LDS busy 59 % of the kernel) — the smallest it is.  The dense path pays with 4-byte DMA pieces.
+  static constexpr int LD = 17;
   static constexpr int TILE = (16 * LD + 3) & ~3;
   // one staged step: [tA | tB | tQ_0.. | l | R | r]
   static constexpr int oTA = 0;
