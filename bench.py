@@ -163,6 +163,30 @@ class StubBackend:
         return 0.0
 
 
+def launch_ranks_if_needed(gpus):
+    """`--gpus N` is the number of ranks of the job (one process per GPU).  Started by a launcher
+    (torch.distributed.run sets WORLD_SIZE) the two must agree — a mismatch is an error, not a silent one-GPU run.
+    Started bare with N > 1 (`python bench.py --gpus 8`), this process becomes the launcher: it re-executes itself
+    as N ranks under torch.distributed.run on a free local port and exits with the job's status."""
+    ws = os.environ.get("WORLD_SIZE")
+    if ws is not None:
+        if int(ws) != gpus:
+            sys.stderr.write("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks\n" % (gpus, ws))
+            sys.exit(2)
+        return
+    if gpus <= 1:
+        return
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd))
+
+
 HEADLINE_CONFIG = "modified_three_player_intersection"
 # shorthands for BASELINE.json's configurations: (config, dtype, instances per GPU, default steps)
 BASELINE_CONFIGS = {
@@ -234,6 +258,8 @@ def main():
     args.dtype = args.dtype or base[1]
     args.batch = args.batch or base[2]
     args.steps = args.steps or (base[3] if args.baseline_config else 20)
+
+    launch_ranks_if_needed(args.gpus)
 
     import torch
     from ilqgames_amd import abi, examples, sharding
@@ -334,10 +360,16 @@ def main():
         ti = torch.tensor([total_iters], dtype=torch.int64, device=backend.device())
         dist.all_reduce(ti)
         total_iters = int(ti.item())
-        if rank == 0 and args.backend == "stub":
-            # the stub's strategy of instance b is b: the gather must have put every block where it belongs
-            assert gathered is not None and gathered.shape[0] == total
-            assert torch.equal(gathered[:, 0], torch.arange(total, dtype=gathered.dtype))
+        assert dist.get_world_size() == world == args.gpus
+        if rank == 0:
+            # every rank's block arrived: N x batch rows of [P | alpha] on rank 0 (both backends)
+            assert gathered is not None and gathered.shape[0] == total == args.gpus * B, (
+                "gathered %s rows, expected %d" % (None if gathered is None else gathered.shape[0], total))
+            if args.backend == "stub":
+                # the stub's strategy of instance b is b: the gather must have put every block where it belongs
+                assert torch.equal(gathered[:, 0], torch.arange(total, dtype=gathered.dtype))
+            else:
+                assert bool(torch.isfinite(gathered).all())
 
     if rank == 0:
         n, m, N, T = spec.n, spec.m, len(spec.subsystems), spec.T
@@ -378,7 +410,7 @@ def main():
         peak_tf = FP64_PEAK_TFLOPS if elem == 8 else FP32_PEAK_TFLOPS
         out = {
             "metric": "iLQ iterations/sec (batch)", "value": value, "unit": "instance-iterations/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": dist.get_world_size() if distributed else 1, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "%s n=%d N=%d T=%d batch=%d/GPU %s, fixed %d outer iterations, %s"

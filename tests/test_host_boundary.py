@@ -171,6 +171,26 @@ def test_bench_two_rank_path_over_gloo():
     assert out["value"] > 0 and abs(out["value"] * out["ms_per_step"] * 1e-3 * out["steps"] - 2 * 5 * 2) < 1e-6
 
 
+def test_bench_gpus_flag_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (the form of the driver's N = 1 command with another N)
+    must run TWO ranks, not one rank that prints n_gpus = 1: bench.py re-executes itself under torch.distributed.run.
+    A launcher whose WORLD_SIZE disagrees with --gpus is an error."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "stub", "--steps", "2",
+           "--warmup", "1", "--batch", "3"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2
+    assert abs(out["value"] * out["ms_per_step"] * 1e-3 * out["steps"] - 2 * 3 * 2) < 1e-6
+    bad = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=bad)
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
+
+
 def test_fast_trig_of_the_rollout_is_within_its_documented_error(tmp_path):
     """csrc/ilqg_trig.hpp is __host__ __device__: tests/host/trig_check.cpp compiles it for the host (plain g++ against
     the HIP headers) and compares sine / cosine / tangent with the C library in long double over the whole fast-path
