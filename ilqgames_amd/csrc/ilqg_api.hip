@@ -702,6 +702,54 @@ struct ilqg_problem {
     for (int i = 0; i < loop_count; i++) var += (loop_times[i] - mean) * (loop_times[i] - mean);
     return mean + 3.0 * std::sqrt(var / (loop_count - 1));
   }
+  // AugmentedLagrangianSolver's own LoopTimer (solver/augmented_lagrangian_solver.h: `timer_`), over its outer iterations
+  double al_loop_times[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  int al_loop_count = 0, al_loop_next = 0;
+  void al_loop_add(double seconds) {
+    al_loop_times[al_loop_next] = seconds;
+    al_loop_next = (al_loop_next + 1) % 10;
+    if (al_loop_count < 10) al_loop_count++;
+  }
+  double al_loop_upper_bound() const {
+    if (al_loop_count < 2) return 0.02;
+    double mean = 0.0, var = 0.0;
+    for (int i = 0; i < al_loop_count; i++) mean += al_loop_times[i];
+    mean /= al_loop_count;
+    for (int i = 0; i < al_loop_count; i++) var += (al_loop_times[i] - mean) * (al_loop_times[i] - mean);
+    return mean + 3.0 * std::sqrt(var / (al_loop_count - 1));
+  }
+};
+
+// The outer loop's clock of AugmentedLagrangianSolver::Solve under a max_runtime (src/augmented_lagrangian_solver.cpp:
+// 104-110,193): `elapsed` starts at the first inner solve's ALLOWANCE (max_runtime / max_solver_iters, not the time it
+// took), every outer iteration adds its wall time, and another one starts only while
+// elapsed < max_runtime - timer_.RuntimeUpperBound().  A batch shares the clock: an "outer iteration" is the time from
+// one exit launch that restarted instances to the next exit launch.  before_exit() is called in front of every exit
+// launch and says whether instances whose inner solve has ended may still restart.
+struct AlOuterClock {
+  ilqg_problem* p;
+  bool on;
+  double max_runtime, elapsed, tic = 0.0;
+  bool open = false;
+  AlOuterClock(ilqg_problem* p_, bool on_, double max_runtime_, double first_allowance)
+      : p(p_), on(on_), max_runtime(max_runtime_), elapsed(first_allowance) {}
+  static double wall() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+  bool before_exit() {  // true: the outer loop is closed
+    if (!on) return false;
+    const double now = wall();
+    if (open) {
+      p->al_loop_add(now - tic);
+      elapsed += now - tic;
+      open = false;
+    }
+    return !(elapsed < max_runtime - p->al_loop_upper_bound());
+  }
+  void after_exit(int restarted) {
+    if (on && restarted && !open) {
+      tic = wall();
+      open = true;
+    }
+  }
 };
 
 #define DT_DISPATCH(p, CALL) ((p)->desc.dtype == ILQG_F32 ? CALL(float) : CALL(double))
@@ -725,7 +773,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   static_assert(OLCfg<T, NX, NP, MU>::ROW == ol_row_elems(NX, NP * MU, NP) && OLCfg<T, NX, NP, MU>::ROW_FAT == ol_row_elems(NX, NP * MU, NP, true), "ol_row_elems");
   const int ol_row = p->desc.params.open_loop ? ol_row_elems(d.n, d.m, d.N) : 0;
   const WsLayout L(d.n, d.m, d.N, d.T, d.pairs.Rsz, d.pairs.rsz, ol_row, d.num_constraints, al_mode);
-  SolveArgs<T> sa;
+  SolveArgs<T> sa{};
   sa.ol_row = ol_row;
   sa.al_mode = al_mode;
   sa.x0 = (const T*)x0; sa.xs = (T*)xs; sa.us = (T*)us; sa.P = (T*)P; sa.alpha = (T*)alpha;
@@ -914,6 +962,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   auto wall = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double inner_elapsed = 0.0, tic = 0.0;
   bool iteration_open = false;
+  AlOuterClock outer(p, timed && al_mode && d.num_constraints > 0, opt.max_runtime, budget);
   const bool bursts = counted && !kProfile && !timed && choice(opt.round_bursts, true);
   int burst = 1;
   // the iterate log (ilqg_solve_options::iterate_log): copied in front of every exit / sweep launch
@@ -1065,6 +1114,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
     }
     if ((want_exit || want_lq) && log_iterates() != ILQG_OK) return ILQG_ERR_HIP;
     if (want_exit) {
+      if (outer.before_exit()) sa.outer_closed = 1;  // out of time: inner solves that end now are the last ones
       hipLaunchKernelGGL(k_exit, dim3(batch), dim3(64), lds_exit, stream, d, sa);
       HIP_TRY(hipGetLastError());
       if (counted && al_mode) {
@@ -1072,6 +1122,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
         HIP_TRY(hipStreamSynchronize(stream));
         restarted = p->h_unfinished[2];
         if (restarted) inner_elapsed = 0.0;  // the next inner solve's own budget
+        outer.after_exit(restarted);
       }
     }
     if (want_lq) {
@@ -1172,6 +1223,7 @@ static ilqg_status generic_solve(ilqg_problem* p, int32_t batch, const void* x0,
   auto wall = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double inner_elapsed = 0.0, tic = 0.0;
   bool iteration_open = false;
+  AlOuterClock outer(p, timed && al_mode && d.num_constraints > 0, opt.max_runtime, budget);
   IterLog<T> lg{};
   const bool logging = opt.iterate_log != nullptr;
   if (logging) {
@@ -1220,6 +1272,7 @@ static ilqg_status generic_solve(ilqg_problem* p, int32_t batch, const void* x0,
     }
     if (want_exit) {
       HIP_TRY(hipMemsetAsync(p->d_unfinished, 0, 4 * sizeof(int), stream));
+      if (outer.before_exit()) sa.outer_closed = 1;
       hipLaunchKernelGGL(k_exit, dim3(batch), dim3(64), lds_exit, stream, d, sa);
       HIP_TRY(hipGetLastError());
       if (al_mode) {
@@ -1227,6 +1280,7 @@ static ilqg_status generic_solve(ilqg_problem* p, int32_t batch, const void* x0,
         HIP_TRY(hipStreamSynchronize(stream));
         restarted = p->h_unfinished[2];
         if (restarted) inner_elapsed = 0.0;
+        outer.after_exit(restarted);
       }
     }
     if (want_lq) {
@@ -1517,6 +1571,10 @@ ilqg_status ilqg_problem_create(const ilqg_problem_desc* desc, ilqg_problem** ou
   }
   d.n = d.xoff[d.N];
   d.m = d.uoff[d.N];
+  if (d.n > ILQG_MAX_XDIM || d.m > ILQG_MAX_UDIM_TOTAL) {  // before any table is sized by them
+    delete p;
+    return fail(ILQG_ERR_UNSUPPORTED, "more than ILQG_MAX_XDIM states or ILQG_MAX_UDIM_TOTAL controls");
+  }
   {
     bool plain = false;
     for (int i = 0; i < d.N; i++) plain = plain || is_plain_rk4_kind(d.sub_kind[i]);
@@ -1571,6 +1629,12 @@ ilqg_status ilqg_problem_create(const ilqg_problem_desc* desc, ilqg_problem** ou
                                       "inside the state");
       }
       o.polyline = t.idx_extra[0] | (t.idx_extra[1] << 16);
+    }
+    // Constraint::is_equality_ is only carried for the affine constraints (ilqg.h): on any other kind the multiplier
+    // update would drop its clip at zero while the mu gate stayed an inequality's
+    if ((t.flags & ILQG_FLAG_EQUALITY) && t.kind != ILQG_CONSTRAINT_AFFINE_SCALAR && t.kind != ILQG_CONSTRAINT_AFFINE_VECTOR) {
+      delete p;
+      return fail(ILQG_ERR_INVALID, "ILQG_FLAG_EQUALITY is only defined for the affine constraints");
     }
     if (t.constraint_slot >= 0 && t.constraint_slot + 1 > nc) nc = t.constraint_slot + 1;
   }
@@ -1801,10 +1865,6 @@ ilqg_status ilqg_problem_create(const ilqg_problem_desc* desc, ilqg_problem** ou
     ILQG_FOR_DIMS(X)
 #undef X
     if (!instantiated) p->generic = true;
-  }
-  if (d.n > ILQG_MAX_XDIM || d.m > ILQG_MAX_UDIM_TOTAL) {
-    ilqg_problem_destroy(p);
-    return fail(ILQG_ERR_UNSUPPORTED, "more than ILQG_MAX_XDIM states or ILQG_MAX_UDIM_TOTAL controls");
   }
   *out = p;
   return ILQG_OK;

@@ -56,6 +56,8 @@ struct SolveArgs {
   int rows_cw;          // rows per chunk of the row stage (ilqg_rows.hpp): 64, 32 or 16, chosen by the launcher
   T* probe_pool;        // speculative line search: [listed instances][probe_k] entries of ProbeEntry::total elements
   int probe_k;          // step sizes probed per instance this round (<= kProbeCandidates)
+  int outer_closed;     // 1: the augmented-Lagrangian outer loop is out of time (max_runtime): an inner solve that ends
+                        //    now ends the instance's solve instead of starting another (augmented_lagrangian_solver.cpp:107-110)
 };
 
 
@@ -257,7 +259,7 @@ __device__ __forceinline__ void solve_exit_path(const DevProblem& p, const QuadT
         }
         s.inner_calls++;
         if (p.num_constraints > 0 && s.logged < prm.max_solver_iters &&
-            s.max_err > T(prm.constraint_error_tolerance)) {
+            s.max_err > T(prm.constraint_error_tolerance) && !sa.outer_closed) {
           // ---- multiplier update at the final operating point (:116-140) ----
           T my_err = -dinf<T>();
           for (int cs = t; cs < p.num_constraints; cs += blockDim.x) {  // a thread per constraint slot, in strides

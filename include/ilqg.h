@@ -430,8 +430,12 @@ typedef struct {
                                      clock, seconds — once it has passed, instances leave the loop at their next
                                      iteration boundary with success = 1 and the iterate they hold (a line search in
                                      flight is finished first, as there).  <= 0: run to the iteration bounds.  Needs a
-                                     free-running solve (fixed_iters = 0, no forced steps); with the augmented-Lagrangian
-                                     loop the budget ends the inner solve in flight and the outer loop with it. */
+                                     free-running solve (fixed_iters = 0, no forced steps).  With the augmented-Lagrangian
+                                     loop (src/augmented_lagrangian_solver.cpp:85-110,193) every inner solve of a constrained
+                                     problem gets max_runtime / max_solver_iters, and the outer loop has its own clock: it
+                                     starts at that allowance, adds the wall time of every outer iteration (its own
+                                     LoopTimer, kept in the problem handle) and starts no further inner solve once
+                                     elapsed >= max_runtime - RuntimeUpperBound() — a batch shares the clock. */
 } ilqg_solve_options;
 
 /* What SolverLog::AddSolverIterate receives per iterate (include/ilqgames/utils/solver_log.h:65-74: the reference deep-

@@ -492,6 +492,37 @@ def test_augmented_lagrangian_solve_matches_oracle_fp64(hip, oracle):
     assert np.isfinite(_np(out["xs"])).all()
 
 
+def test_augmented_lagrangian_max_runtime_bounds_the_outer_loop(hip):
+    """AugmentedLagrangianSolver::Solve(success, max_runtime), src/augmented_lagrangian_solver.cpp:85-110: the first
+    inner solve gets max_runtime / max_solver_iters, `elapsed` STARTS at that allowance and the outer loop runs only
+    while elapsed < max_runtime - RuntimeUpperBound() (0.02 s until the loop timer holds two samples).  With a budget of
+    1 ms neither an inner iteration nor an outer iteration fits: one logged iterate (the initial operating point), no
+    restart — and success = 0 because the constraints are not met (:188-191).  A generous budget changes nothing."""
+    spec = examples.three_player_intersection()
+    spec.params.max_solver_iters = 30
+    spec.params.unconstrained_solver_max_iters = 5
+    x0 = examples.jittered_x0(spec, 6, seed=21)
+    prob = hip.Problem(spec, abi.F64)
+    tight = prob.solve(x0, augmented_lagrangian=True, max_runtime=1e-3)
+    assert np.array_equal(_np(tight["iters"]), np.ones(6, dtype=np.int32)), _np(tight["iters"])
+    assert not _np(tight["status"]).any()
+    plain = hip.Problem(spec, abi.F64).solve(x0, augmented_lagrangian=True)
+    relaxed = hip.Problem(spec, abi.F64).solve(x0, augmented_lagrangian=True, max_runtime=1e4)
+    assert np.array_equal(_np(relaxed["iters"]), _np(plain["iters"]))
+    assert np.array_equal(_np(relaxed["xs"]), _np(plain["xs"]))
+    assert _np(plain["iters"]).min() > 1
+
+
+def test_equality_flag_is_refused_on_non_affine_constraints(hip):
+    """ILQG_FLAG_EQUALITY (Constraint::is_equality_) is only carried for the affine constraints; on a proximity
+    constraint ilqg_problem_create refuses it instead of running an unclipped multiplier behind an inequality's gate."""
+    spec = examples.three_player_intersection()
+    t = next(t for t in spec.terms if t["constraint_slot"] >= 0)
+    t["flags"] |= abi.FLAG_EQUALITY
+    with pytest.raises(Exception, match="EQUALITY"):
+        hip.Problem(spec, abi.F64)
+
+
 @pytest.mark.parametrize("cfg,al,dtype", [("modified_three_player_intersection", False, abi.F64),
                                           ("modified_three_player_intersection", False, abi.F32),
                                           ("three_player_intersection", True, abi.F64),
