@@ -250,6 +250,8 @@ def main():
                     help="ilqg_solve_options::probe_first (A/B measurements of the speculative line search's ramp)")
     ap.add_argument("--no-second-workload", action="store_true",
                     help="skip the back-tracking workload reported beside the headline (three_player_intersection, n = 16)")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the `configs` block (BASELINE.json configurations 3, 4, 5 in their per-GPU form, ~40 s)")
     ap.add_argument("--cpu-sample", type=int, default=64,
                     help="instances in one run of the CPU baseline sample (64 x 20 iterations ~ 1.3 s on one host thread)")
     args = ap.parse_args()
@@ -450,6 +452,8 @@ def main():
             out["own_params"] = own_params_figure(backend, examples, abi, args, x0_d)
             if args.config == HEADLINE_CONFIG and not args.no_second_workload:
                 out["second_workload"] = backtracking_workload(examples, abi, args, local_rank)
+            if args.config == HEADLINE_CONFIG and args.baseline_config is None and not args.no_configs:
+                out["configs"] = baseline_configs_block(examples, abi, local_rank)
         if args.backend == "hip" and not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, spec, x0, dtype, abi, out.get("latency"))
         print(json.dumps(out))
@@ -483,19 +487,15 @@ def latency_figures(backend, examples, abi, args, x0_d):
             "mode": "free-running to convergence_tolerance = 1.0, alpha0 = 0.5, fraction 0.001, zero warm start"}
 
 
-def backtracking_workload(examples, abi, args, local_rank, steps=6, warmup=3):
-    """A second reported workload beside the headline, so that the path every line search that back-tracks goes through
-    has a driver-visible number: ThreePlayerIntersectionExample (the n = 16 example BASELINE.json's config 2 names, its
-    constraints as augmented-Lagrangian terms at their initial multipliers), its own solver parameters
-    (exec/three_player_intersection/main.cpp:109-120), the headline's batch and precision, `steps` outer iterations —
-    the launch mode chosen from the warm-up exactly as for the headline.  Median of three timed solves."""
+def timed_workload(examples, abi, cfg, dtype_name, B, steps, local_rank, warmup=3, reps=3, linesearch="own"):
+    """One more fixed-iteration workload timed like the headline (warm-up decides the launch mode, HIP events around
+    the solve, inputs resident in HBM, median of `reps`): its own solver parameters unless `linesearch` says otherwise.
+    Returns the per-workload block of the bench line."""
     import torch
-    cfg = "three_player_intersection"
-    spec, params_desc = _bench_spec(examples, cfg, "own")
-    dtype = abi.F64 if args.dtype == "f64" else abi.F32
+    spec, params_desc = _bench_spec(examples, cfg, linesearch)
+    dtype = abi.F64 if dtype_name == "f64" else abi.F32
     elem = 8 if dtype == abi.F64 else 4
     be = HipBackend(spec, dtype, local_rank)
-    B = args.batch
     x0 = torch.as_tensor(examples.jittered_x0(spec, B, seed=0), dtype=be.tdtype, device="cuda")
     bufs = be.alloc(B)
 
@@ -509,7 +509,7 @@ def backtracking_workload(examples, abi, args, local_rank, steps=6, warmup=3):
     if warm_bt > 0.25:
         be.counted = True
     runs = []
-    for _ in range(3):
+    for _ in range(reps):
         reset()
         be.sync()
         ev = be.events()
@@ -518,18 +518,99 @@ def backtracking_workload(examples, abi, args, local_rank, steps=6, warmup=3):
         ev[1].record()
         be.sync()
         runs.append(ev[0].elapsed_time(ev[1]) * 1e-3)
-    kernel_s = sorted(runs)[1]
+    kernel_s = sorted(runs)[len(runs) // 2]
     iters = int(bufs["iters"].sum().item())
     n, m, N, T = spec.n, spec.m, len(spec.subsystems), spec.T
     pairs_m = [spec.udims[j] for _, j in be.prob.pairs]
     b0 = algorithmic_bytes_per_iteration(n, m, N, T, pairs_m, elem, backtracks=0.0)
-    return {"workload": "%s n=%d N=%d T=%d batch=%d %s, fixed %d outer iterations, %s" % (cfg, n, N, T, B, args.dtype, steps, params_desc),
-            "value": iters / kernel_s, "unit": "instance-iterations/s", "ms_per_step": kernel_s / steps * 1e3,
-            "mean_backtracks": be.mean_backtracks(bufs, iters), "success_fraction": float(bufs["status"].float().mean().item()),
-            "launch_mode": "host-counted rounds, speculative line search" if be.counted else "asynchronous launch sequence",
-            "roofline": {"bound": "hbm", "achieved": b0 * iters / kernel_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": b0 * iters / kernel_s / 1e9 / HBM_PEAK_GBS, "bytes_per_iteration_per_instance": b0,
-                         "note": "b = 0 bytes per accepted iteration (SURVEY.md 8d); rejected trials are not counted as useful bytes"}}
+    out = {"workload": "%s n=%d N=%d T=%d batch=%d %s%s, fixed %d outer iterations, %s" % (
+               cfg, n, N, T, B, dtype_name, " open-loop" if spec.params.open_loop else "", steps, params_desc),
+           "value": iters / kernel_s, "unit": "instance-iterations/s", "ms_per_step": kernel_s / steps * 1e3,
+           "repeats": len(runs), "ms_per_step_all": [r / steps * 1e3 for r in runs],
+           "mean_backtracks": be.mean_backtracks(bufs, iters), "success_fraction": float(bufs["status"].float().mean().item()),
+           "launch_mode": "host-counted rounds, speculative line search" if be.counted else "asynchronous launch sequence",
+           "roofline": {"bound": "hbm", "achieved": b0 * iters / kernel_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": b0 * iters / kernel_s / 1e9 / HBM_PEAK_GBS, "bytes_per_iteration_per_instance": b0,
+                        "note": "b = 0 bytes per accepted iteration (SURVEY.md 8d); rejected trials are not counted as useful bytes"}}
+    del bufs, be
+    torch.cuda.empty_cache()
+    return out
+
+
+def backtracking_workload(examples, abi, args, local_rank, steps=6, warmup=3):
+    """A second reported workload beside the headline, so that the path every line search that back-tracks goes through
+    has a driver-visible number: ThreePlayerIntersectionExample (the n = 16 example BASELINE.json's config 2 names, its
+    constraints as augmented-Lagrangian terms at their initial multipliers), its own solver parameters
+    (exec/three_player_intersection/main.cpp:109-120), the headline's batch and precision, `steps` outer iterations —
+    the launch mode chosen from the warm-up exactly as for the headline.  Median of three timed solves."""
+    return timed_workload(examples, abi, "three_player_intersection", args.dtype, args.batch, steps, local_rank, warmup=warmup)
+
+
+def receding_horizon_workload(examples, abi, local_rank, batch=2048, replans=12, horizon_calls=200, max_solver_iters=50):
+    """BASELINE.json config 5 AS WRITTEN: the receding-horizon loop of src/receding_horizon_simulator.cpp:65-137 over
+    three_player_collision_avoidance_reachability with the augmented-Lagrangian solver, `batch` plans resident on the
+    device, every call after the first warm-started from the spliced plan.  The wall clock of the reference's loop is
+    replaced by a fixed simulated solve time sized so that `horizon_calls` (200) calls fit the horizon; the first
+    1 + `replans` of them are run and timed (a 200-call run is minutes; what a call costs does not change along it).
+    An instance whose first solve fails leaves the loop there, as the reference's CHECK(success) (:77) ends its run —
+    `active_after_first_call` says how many plans the replanning calls are really about."""
+    import torch
+    cfg = "three_player_collision_avoidance_reachability"
+    spec = examples.CONFIGS[cfg]()
+    spec.params.max_solver_iters = max_solver_iters
+    from ilqgames_amd import hip
+    torch.cuda.set_device(local_rank)
+    prob = hip.Problem(spec, abi.F64)
+    x0 = examples.jittered_x0(spec, batch, seed=1)
+    tick = 0.5 * spec.T * spec.dt / (horizon_calls + 8)
+    stamps, active, iterates = [], [], []
+
+    def on_record(r, info):
+        torch.cuda.synchronize()
+        stamps.append(time.perf_counter())
+        active.append(int(info["active"].sum().item()))
+        iterates.append(int((info["bufs"]["iters"] * info["active"]).sum().item()))
+
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = prob.receding_horizon_simulate(x0, final_time=1e9, planner_runtime=tick, extra_time=tick, solve_time=tick,
+                                         augmented_lagrangian=True, max_records=replans + 1, on_record=on_record)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    solves = int(out["num_records"].sum().item())
+    first_s = stamps[0] - t0 if stamps else wall
+    replan_s = (stamps[-1] - stamps[0]) if len(stamps) > 1 else 0.0
+    replan_solves = sum(active[1:])
+    res = {"workload": "%s n=%d N=%d T=%d batch=%d f64: RecedingHorizonSimulator loop, AugmentedLagrangianSolver, first call + %d "
+                       "warm-started replans of a %d-call horizon (simulated solve time %.4f s), max_solver_iters=%d"
+                       % (cfg, spec.n, len(spec.subsystems), spec.T, batch, out["calls"] - 1, horizon_calls, tick, max_solver_iters),
+           "calls": out["calls"], "instance_solves": solves, "seconds": wall,
+           "instance_solves_per_s": solves / wall, "unit": "warm-started instance-solves/s (first call included)",
+           "first_call_ms": first_s * 1e3, "ms_per_replan": (replan_s / max(1, out["calls"] - 1)) * 1e3,
+           "replan_instance_solves_per_s": (replan_solves / replan_s) if replan_s > 0 else None,
+           "active_after_first_call": active[1] if len(active) > 1 else (active[0] if active else 0),
+           "active_at_end": int(out["active"].sum().item()),
+           "logged_iterates_per_call": iterates}
+    del prob
+    torch.cuda.empty_cache()
+    return res
+
+
+def baseline_configs_block(examples, abi, local_rank):
+    """Every other BASELINE.json configuration in its per-GPU form, in the default bench line (`configs`)."""
+    out = {}
+    # config 3: fp32, 8192 instances per GPU (65536 over 8)
+    out["config3_f32_b8192"] = timed_workload(examples, abi, HEADLINE_CONFIG, "f32", 8192, 10, local_rank, linesearch="auto")
+    # the headline batch in fp32 and the headline shape at the large batch (the single-wave throughput schedule)
+    out["headline_f32_b1024"] = timed_workload(examples, abi, HEADLINE_CONFIG, "f32", 1024, 20, local_rank, linesearch="auto")
+    out["headline_f64_b8192"] = timed_workload(examples, abi, HEADLINE_CONFIG, "f64", 8192, 10, local_rank, linesearch="auto")
+    # config 4: roundabout merging, n = 24, N = 4, T = 150, open-loop sweep, 4096 instances, its own parameters
+    out["config4_roundabout_T150_openloop_b4096"] = timed_workload(examples, abi, "roundabout_merging_T150", "f64", 4096, 4, local_rank)
+    # config 5's scene as a fixed-iteration solve (what --baseline-config 5 times), then config 5 as written
+    out["config5_scene_fixed_iterations_b2048"] = timed_workload(examples, abi, "three_player_collision_avoidance_reachability",
+                                                                 "f64", 2048, 5, local_rank)
+    out["config5_receding_horizon_al_b2048"] = receding_horizon_workload(examples, abi, local_rank)
+    return out
 
 
 def own_params_figure(backend, examples, abi, args, x0_d):

@@ -149,6 +149,8 @@ __device__ __forceinline__ double bcast(double v, int l) {
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
   return __hiloint2double(hi, lo);
 }
+__device__ __forceinline__ float lq_abs(float x) { return __builtin_fabsf(x); }
+__device__ __forceinline__ double lq_abs(double x) { return __builtin_fabs(x); }
 __device__ __forceinline__ float lq_sqrt(float x) { return sqrtf(x); }
 __device__ __forceinline__ double lq_sqrt(double x) { return sqrt(x); }
 
@@ -240,25 +242,24 @@ __device__ __forceinline__ float fast_recip(float x) {
 
 template <typename T, int M>
 __device__ __forceinline__ void lu_solve_columns(T (&col)[M], int lane, T (&x)[M]) {
+  T dinv[M];  // 1 / U[k][k], wave-uniform: lane k forms the pivot's reciprocal for the multipliers anyway
 #pragma unroll
   for (int k = 0; k + 1 < M; k++) {
     const T rinv = fast_recip(col[k]);  // the pivot's reciprocal where it matters: on lane k
+    dinv[k] = bcast(rinv, k);
     T f[M];
 #pragma unroll
     for (int i = k + 1; i < M; i++) f[i] = bcast(col[i] * rinv, k);  // multipliers S[i][k] / S[k][k]
 #pragma unroll
     for (int i = k + 1; i < M; i++) col[i] -= f[i] * col[k];        // row_i -= f_i row_k, every column at once
   }
-  T diag = T(1);
-#pragma unroll
-  for (int i = 0; i < M; i++) diag = (lane == i) ? col[i] : diag;
-  const T dinv = fast_recip(diag);
+  dinv[M - 1] = bcast(fast_recip(col[M - 1]), M - 1);
 #pragma unroll
   for (int i = M - 1; i >= 0; i--) {
     T s = col[i];
 #pragma unroll
     for (int k2 = i + 1; k2 < M; k2++) s -= bcast(col[i], k2) * x[k2];
-    x[i] = s * bcast(dinv, i);
+    x[i] = s * dinv[i];
   }
 }
 
@@ -894,7 +895,10 @@ __device__ __forceinline__ void dma_tile(const T* g_, T* tile, int nrows, int nc
   }
 }
 
-template <typename T, int NX, int NP, int MU>
+// SOLVER: the instantiation the solve's sweep kernel runs (compact rows in, symmetric costs, regularised system, forward
+// pass deferred to the trial kernel) with those choices made at compile time: the dense staging, the QR solve and the
+// forward pass are not in its loop or its register allocation.
+template <typename T, int NX, int NP, int MU, bool SOLVER = false>
 __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a, const PairTable& pt, T* sm) {
   using C = LQCfg<T, NX, NP, MU>;
   using W = PWCfg<T, NX, NP, MU>;
@@ -909,7 +913,7 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
   const int lane = t & 63, g = lane >> 4, j = lane & 15;
   const int Tn = a.T_steps;
   const PairRegs<NP> pr(pt);
-  const bool want_fwd = a.dx != nullptr || a.ed_out != nullptr || a.defer_forward != 0;
+  const bool want_fwd = SOLVER || a.dx != nullptr || a.ed_out != nullptr || a.defer_forward != 0;
   constexpr int SCR = C::SCR;
   const vec zero4 = {T(0), T(0), T(0), T(0)};
   constexpr int RS = TL::row(0, 1) - TL::row(0, 0);  // row step between accumulator registers
@@ -992,7 +996,7 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
   // Compact rows (LQArgs::compact): nothing dense is read; the touched words of [A | B | Q | l | R | r] arrive as one
   // short row that a wave scatters over the image's constant background (written once, below).  The row of step
   // k - 2 is DMA'd into a staging row while step k runs and scattered into the image of step k - 1 ... one step later.
-  const bool cmp = a.compact != nullptr;
+  const bool cmp = SOLVER || a.compact != nullptr;
   T* const sSB = sm + W::oSB;
   auto cdecode = [&](int code) -> int {  // array << 24 | offset in the array's row  ->  offset inside an image
     const int arr = code >> 24, off = code & 0xffffff;
@@ -1029,6 +1033,9 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
         for (int q = 0; q < WPL; q++)
           if (cd[q] >= 0) dst[cd[q]] = v[q];
       } else if (k >= 1) {
+        if ((CWD * S) % 16 == 0)  // rows start 16-byte aligned: 16-byte pieces (a row is one or two instructions)
+          dma_g2l<64, true>(a.compact + size_t(k - 1) * CWD, sSB + ((k - 1) & 1) * kCompactMaxWords, CWD * S, lane);
+        else
         dma_g2l<64, false>(a.compact + size_t(k - 1) * CWD, sSB + ((k - 1) & 1) * kCompactMaxWords, CWD * S, lane);
       }
     }
@@ -1081,7 +1088,8 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
   // With symmetric costs Z_w is symmetric up to rounding, so Z_w^T (only ever used as the left factor of
   // W = Z_w F) is replaced by Z_w itself: two of the nine tile products of a step and the transposed loads
   // disappear.  The C ABI's general LQ entry (arbitrary Q, R) keeps both layouts.
-  const bool sym = a.symmetric != 0;
+  const bool sym = SOLVER || a.symmetric != 0;
+  const bool adaptive = SOLVER || a.adaptive != 0;
   vec Zd = ldD(tQ);
   vec Yd = sym ? Zd : ldDT(tQ);
   if constexpr (SPARE) {
@@ -1139,38 +1147,91 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
         else
           stage(k - 1, 1 - cur, 0, 1);
       }
+      if constexpr (!SOLVER)
       stash_ql(k);
     }
     ILQG_PH(0);
 
     // ---- this player's MU rows of the stacked Nash system: (B_w^T Z_w) [B | A] ----
-    // G = Z_w^T B on the matrix pipe; the MU x (M + NX) block G_w^T [B | A] that follows has two useful rows
-    // out of a 16 x 16 tile, so it is done by the vector unit instead: this player's MU columns of G go through
-    // LDS, lane c < M + NX takes column c of [B | A] and the MU dot products over the state (sequential sums,
-    // as the reference's).  Saves 8 of the step's MFMA and the matrix pipe is shared by the three resident waves.
+    // Only this player's MU columns of G = Z_w^T B are needed, and of the MU x (M + NX) block G_w^T [B | A] that follows
+    // two rows of a tile would be useful: neither is a job for the matrix pipe, which the SIMD's resident waves share
+    // (an fp64 matrix instruction holds it for 64 cycles).
     const vec Bd = ldD(tB);
-    // column `lane` of [B | A], requested while the matrix pipe forms G (lanes past the last column re-read column 0);
-    // columns of a padded tile start 16-byte aligned, so the reads pair up
-    T ba[NX];
-    {
+    constexpr bool kRowSums = MU == 2;  // the vector-unit forms below (rows_reduce4 packs (S, Y) x two controls)
+    T ba[kRowSums ? 1 : NX];
+    if constexpr (!kRowSums) {
+      // column `lane` of [B | A], requested while the matrix pipe forms G (lanes past the last column re-read column 0)
       const T* colp = lane < M ? tB + LD * lane : tA + LD * (lane < M + NX ? lane - M : 0);
 #pragma unroll
       for (int kk = 0; kk < NX; kk++) ba[kk] = colp[kk];
     }
-    const vec G = tile_xty<T>(Zd, Bd, zero4);  // Z_w^T B
-    // this player's MU columns of G go through LDS interleaved, [row][aa], so that a lane reads the MU entries of a
-    // row with one instruction
-    if (j / MU == w) {
+    if constexpr (SPARE && kRowSums) {
+      // G[:, w MU + aa] as two matrix-vector products: lane (g, j) multiplies its four rows of column j of the Z_w tile
+      // with B[row][w MU + aa] (read from the B tile: the address depends on g only) and the four lane rows are summed on
+      // the vector unit (v_permlane32_swap / v_permlane16_swap).  4 LDS reads + 8 FMA + 6 permlane / add instead of four
+      // matrix instructions.  zeta_w rides in column JB of the Z_w tile, so entry JB of the result is zeta_w^T B_w.
+      T p0 = T(0), p1 = T(0);
 #pragma unroll
-      for (int r = 0; r < 4; r++) sGw[(row0 + RS * r) * MU + (j - w * MU)] = G[r];
-      if constexpr (SPARE) {
-        // y_zeta = B_w^T zeta_w + r_ww (:154-157): row JB of G (zeta_w rides in column JB of the Z_w tile)
-        if (g == gJ) sYz[j] = G[rJ] + sr[rg_ww + (j - w * MU)];
+      for (int r = 0; r < 4; r++) {
+        const T* bp = tB + (row0 + RS * r) + LD * (w * MU);
+        p0 += Zd[r] * bp[0];
+        p1 += Zd[r] * bp[LD];
+      }
+      T sa, sb;
+      permlane32_swap(p0, p1, sa, sb);
+      const T tt = sa + sb;  // rows: p0(0+2), p0(1+3), p1(0+2), p1(1+3)
+      permlane16_swap(tt, tt, sa, sb);
+      const T gcol = sa + sb;  // rows 0, 1: G[j][w MU]; rows 2, 3: G[j][w MU + 1]
+      if ((g & 1) == 0) {
+        const int aa = g >> 1;
+        sGw[j * MU + aa] = gcol;  // interleaved [row][aa]: a lane reads the MU entries of a row with one instruction
+        // y_zeta = B_w^T zeta_w + r_ww (:154-157)
+        if (j == JB) sYz[w * MU + aa] = gcol + sr[rg_ww + aa];
+      }
+    } else {
+      const vec G = tile_xty<T>(Zd, Bd, zero4);  // Z_w^T B
+      if (j / MU == w) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) sGw[(row0 + RS * r) * MU + (j - w * MU)] = G[r];
+        if constexpr (SPARE) {
+          // y_zeta = B_w^T zeta_w + r_ww (:154-157): row JB of G (zeta_w rides in column JB of the Z_w tile)
+          if (g == gJ) sYz[j] = G[rJ] + sr[rg_ww + (j - w * MU)];
+        }
       }
     }
     lds_sync(true);
     ILQG_PH(12);
-    {
+    if constexpr (kRowSums) {
+      // Lane (g, c) takes the rows {row(g, r)} of the dot products G_w[:, aa]^T [B | A][:, c] for column c of the B tile
+      // AND of the A tile — the operands are the accumulator-layout registers Bd / Ad it holds anyway — and the four
+      // partial sums per lane (S / Y part x two controls) are reduced over the lane rows on the vector unit
+      // (rows_reduce4).  Four 16-byte LDS reads per lane instead of NX + NX / 2, 4-term FMA chains instead of NX-term.
+      const vec Ad2 = ldD(tA);
+      T pS[MU], pY[MU];
+#pragma unroll
+      for (int aa = 0; aa < MU; aa++) pS[aa] = pY[aa] = T(0);
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const T* gp = sGw + (row0 + RS * r) * MU;
+#pragma unroll
+        for (int aa = 0; aa < MU; aa++) {
+          const T gval = gp[aa];
+          pS[aa] += gval * Bd[r];
+          pY[aa] += gval * Ad2[r];
+        }
+      }
+      // rows after the reduction: 0 = S(aa 0), 1 = Y(aa 0), 2 = S(aa 1), 3 = Y(aa 1)
+      const T tot = rows_reduce4<T>(pS[0], pS[MU - 1], pY[0], pY[MU - 1]);
+      const int aa = g >> 1;
+      const bool isY = (g & 1) != 0;
+      const int c = isY ? M + j : j;  // column of [S | Y]
+      // + R_ww on this player's diagonal block of S (:148-150); every lane reads (a clamped address): no divergent region
+      const bool diag = !isY && j / MU == w;
+      const T rd = sR[ro_ww + aa + MU * (diag ? j - w * MU : 0)];
+      const T val = tot + (diag ? rd : T(0));
+      if (isY ? j < NX : j < M) sSY[(w * MU + aa) + M * c] = val;
+    } else {
+      // lane c < M + NX takes column c of [B | A] and the MU dot products over the state (sequential sums)
       T gv[NX][MU];
 #pragma unroll
       for (int kk = 0; kk < NX; kk++)
@@ -1213,8 +1274,11 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
           stage(k - 1, 1 - cur, w - 1, HELPERS);
       }
       ILQG_PH(14);
-      stash_ql(k);
-      if (w == 1) stash_ql_of(k, 0);
+      if constexpr (!SOLVER)
+      {
+        stash_ql(k);
+        if (w == 1) stash_ql_of(k, 0);
+      }
       ILQG_PH(15);
     }
 
@@ -1232,20 +1296,19 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
       }
       {
         // Gershgorin (columns are independent, so lane-parallel reproduces the sequential loop)
-        T l1 = T(0), diag = T(0);
+        // (|x| as a source modifier of the add; the diagonal entry re-read from LDS instead of a select chain)
+        T l1 = T(0);
 #pragma unroll
-        for (int r = 0; r < M; r++) {
-          l1 += (col[r] < T(0) ? -col[r] : col[r]);
-          diag = (r == lane) ? col[r] : diag;
-        }
-        const T radius = l1 - (diag < T(0) ? -diag : diag);
+        for (int r = 0; r < M; r++) l1 += lq_abs(col[r]);
+        const T diag = src[isS ? lane : 0];
+        const T radius = l1 - lq_abs(diag);
         const T eval_lo = diag - radius;
-        const T bump = (isS && a.adaptive && eval_lo < T(1e-3f)) ? radius + T(1e-3f) : T(0);
+        const T bump = (isS && adaptive && eval_lo < T(1e-3f)) ? radius + T(1e-3f) : T(0);
 #pragma unroll
         for (int r = 0; r < M; r++) col[r] = col[r] + ((r == lane) ? bump : T(0));
       }
       ILQG_PH(10);
-      if (a.adaptive)
+      if (adaptive)
         lu_solve_columns<T, M>(col, lane, x);
       else
         qr_solve_columns<T, M>(col, lane, x);
@@ -1266,11 +1329,18 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
     ILQG_PH(8);
     // the strategies go to global memory from the last wave (wave 0 is the one the others wait for)
     if (w == NP - 1) {
+      // explicit global address space: through a generic pointer these are FLAT stores, which count on the LDS counter
+      // too, and the compiler then waits for every LDS read before the store that follows it (six round trips in a row)
+      typedef __attribute__((address_space(1))) T gT;
       if (lane < NX) {
+        T pv[M];
 #pragma unroll
-        for (int r = 0; r < M; r++) uniform_ptr(a.P + size_t(k) * M * NX)[unsigned(r + M * lane)] = sPt[r + LD * lane];
+        for (int r = 0; r < M; r++) pv[r] = sPt[r + LD * lane];
+        gT* dst = (gT*)(uniform_ptr(a.P + size_t(k) * M * NX)) + unsigned(M * lane);
+#pragma unroll
+        for (int r = 0; r < M; r++) dst[r] = pv[r];
       } else if (lane < NX + M) {
-        uniform_ptr(a.alpha + size_t(k) * M)[unsigned(lane - NX)] = sAl[lane - NX];
+        ((gT*)(uniform_ptr(a.alpha + size_t(k) * M)))[unsigned(lane - NX)] = sAl[lane - NX];
       }
     }
 
@@ -1283,10 +1353,15 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
     vec Fd, BetaD, zetaD;  // F proper; beta / zeta_w down the vector column, zero elsewhere
     if constexpr (SPARE) {
       // column JB of the padded A is zero and column JB of the P tile holds alpha: Fraw = [F | beta]
+      constexpr bool kNoMasks = SOLVER;
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        Fd[r] = Fraw[r] * mCols;
-        BetaD[r] = Fraw[r] * mVecCol;
+        // kNoMasks: [F | beta] is used as it is on both sides of the products.  As a LEFT operand its column JB only
+        // produces ROW JB of the result, and row JB of a Z_w tile never reaches anything: every right operand it meets
+        // (B, [F | beta]) has a zero row JB (tile padding), and the recursion does not feed it back (the row is rebuilt
+        // from this step's operands).  Column 15 of every operand is zero by construction, so it needs no mask either.
+        Fd[r] = kNoMasks ? Fraw[r] : Fraw[r] * mCols;
+        BetaD[r] = kNoMasks ? T(0) : Fraw[r] * mVecCol;
         zetaD[r] = Zd[r] * mVecCol;
       }
       if (want_fwd && w == 0 && j == JB) {
@@ -1333,6 +1408,19 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
     // ---- Z_w <- F^T Z_w F + Q_w + sum_jj P_jj^T R_w,jj P_jj  (:198-212), both layouts ----
     vec Cd = ldD(tQ);
     vec CTd = sym ? Cd : ldDT(tQ);
+    if constexpr (SOLVER) {
+      // Q_w l_w for ExpectedDecrease from the tile this wave has just loaded: Q_w is symmetric, so entry j is
+      // sum_row Q_w[row][j] l_w[row] — every lane multiplies its four rows and the lane rows are summed on the vector
+      // unit (rows_allreduce).  Six LDS reads per player and step instead of 2 NX, and no helper wave's time.
+      T part = T(0);
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = row0 + RS * r;
+        part += Cd[r] * (row < NX ? sl[w * NX + (row < NX ? row : 0)] : T(0));
+      }
+      part = rows_allreduce<T>(part);
+      if (g == 0 && j < NX) a.scratch[size_t(k) * SCR + w * NX + j] = part;
+    }
     if constexpr (SPARE) {
       // column JB of C_w: l_w + sum_jj P_jj^T (R_w,jj alpha_jj - r_w,jj)   (:198-201, 206-212), so that column JB of
       // Z_w' = F^T [..] + C_w is the new zeta_w.  The sum is [P | alpha]^T q with q = (R_w,jj alpha_jj - r_w,jj) stacked:
@@ -1362,10 +1450,39 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
         Cd[r] += (row < NX ? sl[w * NX + srow] : T(0)) * mVecCol;
       }
       vec Pm;  // P proper: column JB of the tile holds alpha
+      if constexpr (SOLVER) {
+        Pm = Pd;  // a left operand: its column JB only produces row JB of the result (see [F | beta] above)
+      } else
 #pragma unroll
       for (int r = 0; r < 4; r++) Pm[r] = Pd[r] * mCols;
+      if constexpr (SOLVER) {
+        // + sum_jj P_jj^T (R_w,jj P_jj) in the SAME product: H = blockdiag(R_w,jj) P has the rows of P and lives in the
+        // state columns, q in column JB — one right operand [H | q], one chain over the M rows of P instead of one more
+        // matrix instruction per (w, jj) block.  (Symmetric costs: no transposed copy to keep.)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int row = row0 + RS * r;
+          const bool in = row < M;
+          const int rowc = in ? row : 0;
+          const int jj = rowc / MU, aa = rowc % MU;
+          int qw = -1, ro_wj = 0;
+#pragma unroll
+          for (int e = 0; e < NP; e++)
+#pragma unroll
+            for (int f = 0; f < NP; f++)
+              if (w == e && jj == f) {
+                qw = pr.q[e][f];
+                ro_wj = pr.ro[e][f];
+              }
+          T h = T(0);
+#pragma unroll
+          for (int b = 0; b < MU; b++) h += sR[ro_wj + aa + MU * b] * sPt[(jj * MU + b) + LD * j];
+          Qy[r] += (in && qw >= 0) ? h * mCols : T(0);
+        }
+      }
       Cd = tile_xty_blocks<T, kblock_mask<T>(0, M)>(Pm, Qy, Cd);
     }
+    if constexpr (!(SOLVER && SPARE))
     static_for<NP>([&](auto JJ) {  // jj is a compile-time constant: it selects the k blocks of the product
       constexpr int jj = decltype(JJ)::value;
       // + P_jj^T R_w,jj P_jj (and its transpose): H = R P_jj and H' = R^T P_jj sit in rows
@@ -1404,6 +1521,15 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
     });
     vec FT;
     if constexpr (SPARE) {
+      if constexpr (SOLVER) {
+        const vec Wd = tile_xty<T>(Yd, Fd, zero4);  // Z_w [F | beta]
+        vec Wz;
+#pragma unroll
+        for (int r = 0; r < 4; r++) Wz[r] = Wd[r] + zetaD[r];  // column JB: zeta_w + Z_w beta
+        Zd = tile_xty<T>(Fd, Wz, Cd);  // [Z_w' | F^T (zeta_w + Z_w beta)] + C_w; column 15 stays zero, row JB is never read
+        Yd = Zd;
+      } else
+      {
       vec Fx;  // [F | beta]: F is zero in column JB, beta is zero outside it
 #pragma unroll
       for (int r = 0; r < 4; r++) Fx[r] = Fd[r] + BetaD[r];
@@ -1419,6 +1545,7 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
 #pragma unroll
       for (int r = 0; r < 4; r++) Zd[r] = Zx[r] * mZcols;  // [Z_w' | F^T (zeta_w + Z_w beta)]
       if (sym) Yd = Zd;
+      }
     } else {
       const vec Wd = tile_xty<T>(Yd, Fd, zero4);     // Z_w F
       const vec ZB = tile_xty<T>(Yd, BetaD, zero4);  // column w = Z_w beta
@@ -1487,9 +1614,11 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
     for (int i = 0; i < 16; i++) a.ph[16 * w + i] += phacc[i];
   }
 
-  if (want_fwd && !a.defer_forward) {
-    __syncthreads();  // scratch rows written by all waves
-    if (w == 0) lq_forward_pass_body<T, NX, NP, MU, 64, W::LDS_ELEMS>(a, sm, lane);
+  if constexpr (!SOLVER) {
+    if (want_fwd && !a.defer_forward) {
+      __syncthreads();  // scratch rows written by all waves
+      if (w == 0) lq_forward_pass_body<T, NX, NP, MU, 64, W::LDS_ELEMS>(a, sm, lane);
+    }
   }
 }
 

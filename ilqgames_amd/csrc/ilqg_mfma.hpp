@@ -75,6 +75,55 @@ __device__ __forceinline__ typename Tile<T>::vec tile_xty_blocks(const typename 
   return c;
 }
 
+// ---- cross-row exchanges of a wavefront's four 16-lane rows on the vector unit (gfx950: v_permlane32_swap /
+// v_permlane16_swap; no LDS) ----
+// permlane32_swap(a, b): a' = [a.row0 a.row1 b.row0 b.row1], b' = [a.row2 a.row3 b.row2 b.row3]
+// permlane16_swap(a, b): a' = [a.row0 b.row0 a.row2 b.row2], b' = [a.row1 b.row1 a.row3 b.row3]
+// (lane maps printed by scripts/ubench/lds_probe.hip)
+__device__ __forceinline__ void permlane32_swap(float a, float b, float& ra, float& rb) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  ra = __uint_as_float(r[0]);
+  rb = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void permlane16_swap(float a, float b, float& ra, float& rb) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  ra = __uint_as_float(r[0]);
+  rb = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void permlane32_swap(double a, double b, double& ra, double& rb) {
+  const auto lo = __builtin_amdgcn_permlane32_swap(unsigned(__double2loint(a)), unsigned(__double2loint(b)), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap(unsigned(__double2hiint(a)), unsigned(__double2hiint(b)), false, false);
+  ra = __hiloint2double(int(hi[0]), int(lo[0]));
+  rb = __hiloint2double(int(hi[1]), int(lo[1]));
+}
+__device__ __forceinline__ void permlane16_swap(double a, double b, double& ra, double& rb) {
+  const auto lo = __builtin_amdgcn_permlane16_swap(unsigned(__double2loint(a)), unsigned(__double2loint(b)), false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap(unsigned(__double2hiint(a)), unsigned(__double2hiint(b)), false, false);
+  ra = __hiloint2double(int(hi[0]), int(lo[0]));
+  rb = __hiloint2double(int(hi[1]), int(lo[1]));
+}
+// Sum over the four rows of every lane column: all rows return (x.row0 + x.row2) + (x.row1 + x.row3).
+template <typename T>
+__device__ __forceinline__ T rows_allreduce(T x) {
+  T a, b;
+  permlane32_swap(x, x, a, b);
+  const T s = a + b;  // [x0 + x2, x1 + x3, x0 + x2, x1 + x3]
+  permlane16_swap(s, s, a, b);
+  return a + b;
+}
+// Four per-lane partial sums p0 .. p3 (each to be summed over the four rows) -> one register whose row q holds the
+// total of p_q', q' = (q >> 1) + 2 * (q & 1)... see the body: row 0 = sum p0, row 1 = sum p2, row 2 = sum p1, row 3 = sum p3.
+template <typename T>
+__device__ __forceinline__ T rows_reduce4(T p0, T p1, T p2, T p3) {
+  T a, b;
+  permlane32_swap(p0, p1, a, b);
+  const T t = a + b;  // rows: p0(0+2), p0(1+3), p1(0+2), p1(1+3)
+  permlane32_swap(p2, p3, a, b);
+  const T u = a + b;  // rows: p2(0+2), p2(1+3), p3(0+2), p3(1+3)
+  permlane16_swap(t, u, a, b);
+  return a + b;  // rows: p0, p2, p1, p3
+}
+
 // Self-test kernel body: given 16x16 column-major X, Y, C in global memory computes
 // out = X^T * Y + C through the D-layout path (one wavefront).
 template <typename T>

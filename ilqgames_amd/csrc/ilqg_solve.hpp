@@ -997,6 +997,12 @@ __device__ __forceinline__ void lq_part_instance(const DevProblem& p, const Solv
   la.tl_b = b;
   tl_stamp(sa.prof, b, 16, threadIdx.x == 0);
   if constexpr (KIND == LQ_PLAYER_WAVES) {
+    if constexpr (LQCfg<T, NX, NP, MU>::MFMA_ONE_TILE) {
+      if (la.compact != nullptr && defer)
+        lq_feedback_instance_mfma_pw<T, NX, NP, MU, true>(la, p.pairs, sm);
+      else
+        lq_feedback_instance_mfma<T, NX, NP, MU>(la, p.pairs, sm);
+    } else
     lq_feedback_instance_mfma<T, NX, NP, MU>(la, p.pairs, sm);
   } else if constexpr (KIND == LQ_SINGLE_WAVE) {
     // (the launcher only picks this kind with compact rows; the expected decrease comes out of the sweep itself — the

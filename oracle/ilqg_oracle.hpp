@@ -1725,11 +1725,18 @@ struct ILQState {
 // the loop, so that a device solve can be compared iterate by iterate.
 // If `raw` is non-null it receives the unscaled LQ strategies of the LAST LQ solve
 // (the object P_t / alpha_t parity is defined on).
+// One CheckArmijoCondition call (src/ilq_solver.cpp:350-362), for diagnosis: which inequality was tested with what.
+template <class S>
+struct ArmijoTrace {
+  int iteration, backtrack, accepted;
+  S step, last_merit, merit, expected_decrease, scaled;  // scaled = fraction * step * expected_decrease
+};
+
 template <class S>
 bool SolveILQ(const Problem<S>& p, const Vec<S>& x0, Trajectory<S>* op_io, Strategies<S>* st_io,
               ILQState<S>* state, const ALState<S>* al, int fixed_iters, std::vector<IterLog<S>>* log,
               Vec<S>* final_costs, int* iters_out, int* converged_out, Strategies<S>* raw = nullptr,
-              int* logged_out = nullptr, const S* forced_steps = nullptr) {
+              int* logged_out = nullptr, const S* forced_steps = nullptr, std::vector<ArmijoTrace<S>>* trace = nullptr) {
   const ilqg_solver_params& prm = p.params;
   if ((int)state->t_extreme.size() != p.N) state->t_extreme.assign(p.N, 0);
   Trajectory<S> last_op = *op_io, cur_op = *op_io;
@@ -1788,6 +1795,9 @@ bool SolveILQ(const Problem<S>& p, const Vec<S>& x0, Trajectory<S>* op_io, Strat
         ComputeQuadraticization(p, cur_op, state->t_extreme, al, &lq);  // MeritFunction :405
         merit = MeritFromQuad(p, lq);
         const S scaled = S(prm.expected_decrease_fraction) * step * state->expected_decrease;
+        if (trace)
+          trace->push_back({num_iterations, bb, (state->last_merit - merit >= scaled) ? 1 : 0, step, state->last_merit, merit,
+                            state->expected_decrease, scaled});
         if (state->last_merit - merit >= scaled) {  // CheckArmijoCondition :350-362
           has_converged = (merit <= state->last_merit) &&
                           std::abs(state->last_merit - merit) < S(prm.convergence_tolerance);

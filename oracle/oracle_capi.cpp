@@ -480,6 +480,35 @@ void NashBatch(const OracleProblem* op, int batch, const void* x0, const void* x
   }
 }
 
+// Diagnosis: ILQSolver::Solve of ONE instance (zero warm start) with every CheckArmijoCondition call recorded:
+// out [max_entries][8] doubles = (iteration, backtrack, accepted, step, last_merit, merit, expected_decrease, scaled).
+// Returns the number of calls made (entries beyond max_entries are dropped); *ok_out = the solve's success flag.
+template <class S>
+int ArmijoTraceOne(const OracleProblem* op, const void* x0, int max_entries, double* out, int* ok_out, int* iters_out) {
+  const Problem<S>& p = Get<S>(op);
+  Trajectory<S> tr;
+  Strategies<S> st;
+  std::vector<S> zx(size_t(p.T) * p.n, S(0)), zu(size_t(p.T) * p.m, S(0)), zP(size_t(p.T) * p.m * p.n, S(0)), za(size_t(p.T) * p.m, S(0));
+  UnpackTraj(p, p.T, zx.data(), zu.data(), &tr);
+  UnpackStrategies(p, p.T, zP.data(), za.data(), &st);
+  Vec<S> x0v((const S*)x0, (const S*)x0 + p.n);
+  ILQState<S> state;
+  ALState<S> al(p.num_constraints, p.T, p.dt);
+  std::vector<ArmijoTrace<S>> trace;
+  Vec<S> fc;
+  int it = 0, conv = 0;
+  const bool ok = SolveILQ(p, x0v, &tr, &st, &state, &al, 0, (std::vector<IterLog<S>>*)nullptr, &fc, &it, &conv,
+                           (Strategies<S>*)nullptr, (int*)nullptr, (const S*)nullptr, &trace);
+  for (size_t q = 0; q < trace.size() && (int)q < max_entries; q++) {
+    const ArmijoTrace<S>& t = trace[q];
+    double* o = out + 8 * q;
+    o[0] = t.iteration; o[1] = t.backtrack; o[2] = t.accepted; o[3] = double(t.step);
+    o[4] = double(t.last_merit); o[5] = double(t.merit); o[6] = double(t.expected_decrease); o[7] = double(t.scaled);
+  }
+  if (ok_out) *ok_out = ok ? 1 : 0;
+  if (iters_out) *iters_out = it;
+  return int(trace.size());
+}
 extern "C" {
 
 int oracle_lq_feedback(const ilqg_dims* d, const void* A, const void* Bm, const void* Q, const void* l,
@@ -552,6 +581,11 @@ void oracle_ilq_solve(void* h, int dtype, int batch, const void* x0, void* xs, v
                       void* rawP, void* rawAlpha, void* merit_log, int merit_log_len, int threads) {
   DISPATCH(dtype, SolveBatch, (OracleProblem*)h, batch, x0, xs, us, P, alpha, costs, iters, status, converged,
            fixed_iters, rawP, rawAlpha, merit_log, merit_log_len, threads);
+}
+
+int oracle_armijo_trace(void* h, int dtype, const void* x0, int max_entries, double* out, int* ok_out, int* iters_out) {
+  return dtype == 0 ? ArmijoTraceOne<float>((OracleProblem*)h, x0, max_entries, out, ok_out, iters_out)
+                    : ArmijoTraceOne<double>((OracleProblem*)h, x0, max_entries, out, ok_out, iters_out);
 }
 
 // The same with per-iteration step sizes supplied by the caller ([batch][fixed_iters]) instead of the line search.

@@ -449,8 +449,10 @@ def test_ilq_solve_free_running_matches_oracle_fp64(hip, oracle):
     spec = examples.modified_three_player_intersection()
     B = 16
     x0 = examples.jittered_x0(spec, B, seed=3)
+    # three draws: with one, instances 3 and 12 of this batch pass as stable although a second nudge of the same size
+    # flips them in the oracle itself (measured: 11 stable after one draw, 7 after two or three)
     ref, stable = oracle_with_stability(oracle.OracleProblem(spec), abi.F64, x0, keys=("iters", "status", "converged"),
-                                        merit_log_len=16)
+                                        merit_log_len=16, draws=3)
     out = hip.Problem(spec, abi.F64).solve(x0)
     # With the example's own expected_decrease_fraction = 0.9 the reference's line search fails early for most
     # instances (status 0, last accepted iterate returned) — reproduced.  A FAILED line search walks through all 100
