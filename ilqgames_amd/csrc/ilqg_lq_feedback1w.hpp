@@ -68,7 +68,7 @@ struct W1Cfg {
   static constexpr int oQL = (oCD + CD_ELEMS + 3) & ~3;
   static constexpr int oMu = oQL + NP * 16;
   static constexpr int ELEMS = (oMu + 32 + 3) & ~3;
-  static constexpr bool SUPPORTED = NX < 16 && M <= 16 && C::NSOLVE <= 32 && NP <= 4;
+  static constexpr bool SUPPORTED = NX < 16 && M <= 16 && C::NSOLVE <= 32 && NP <= 4 && MU == 2;  // (MU == 2: rows_reduce4)
 };
 
 template <typename T, int NX, int NP, int MU>
@@ -101,7 +101,7 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_1w(const LQArgs<T>& a,
   };
   const T mCols = (j < NX) ? T(1) : T(0);    // a proper state column
   const T mVecCol = (j == JB) ? T(1) : T(0);  // the column zeta / beta / alpha ride in
-  const T mZcols = mCols + mVecCol;
+  (void)mCols;
   constexpr int gJ = sizeof(T) == 8 ? JB % 4 : JB / 4, rJ = sizeof(T) == 8 ? JB / 4 : JB % 4;
   static_assert(TL::row(gJ, rJ) == JB, "accumulator-layout position of row JB");
 
@@ -238,46 +238,63 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_1w(const LQArgs<T>& a,
 #pragma unroll 1
   for (int k = Tn - 2; k >= 0; k--) {
     // ---- every player's MU rows of the stacked Nash system: (B_w^T Z_w) [B | A] (:128-157) ----
+    // As in the player-parallel form (ilqg_lq.hpp): only MU columns of G_w = Z_w^T B are used, so they are formed as
+    // matrix-vector products on the vector unit — lane (g, j) multiplies its four rows of column j of the Z_w tile with
+    // B[row][w MU + aa] and the lane rows are summed with v_permlane swaps — and the MU x (M + NX) block G_w^T [B | A]
+    // likewise from the accumulator-layout registers of the B and A tiles (rows_reduce4).  No matrix instruction here.
+    static_assert(MU == 2, "rows_reduce4 packs (S, Y) x two controls");
     const vec Bd = ldD(tB);
-    T ba[NX];  // column `lane` of [B | A] (lanes past the last column re-read column 0)
-    {
-      const T* colp = lane < M ? tB + LD * lane : tA + LD * (lane < M + NX ? lane - M : 0);
-#pragma unroll
-      for (int kk = 0; kk < NX; kk++) ba[kk] = colp[kk];
-    }
-    vec G[NP];  // G_w = Z_w^T B: NP independent chains on the matrix pipe
-#pragma unroll
-    for (int w = 0; w < NP; w++) G[w] = tile_xty<T>(Zd[w], Bd, zero4);
+    const vec Ad = ldD(tA);
 #pragma unroll
     for (int w = 0; w < NP; w++) {
-      if (j / MU == w) {  // this player's MU columns of G_w, interleaved [row][aa]
-        T* const sGw = sG0 + w * MU * 16;
+      T p0 = T(0), p1 = T(0);
 #pragma unroll
-        for (int r = 0; r < 4; r++) sGw[(row0 + RS * r) * MU + (j - w * MU)] = G[w][r];
-        // y_zeta = B_w^T zeta_w + r_ww (:154-157): row JB of G_w (zeta_w rides in column JB of the Z_w tile)
-        if (g == gJ) sYz[j] = G[w][rJ] + sr[pr.rg[w][w] + (j - w * MU)];
+      for (int r = 0; r < 4; r++) {
+        const T* bp = tB + (row0 + RS * r) + LD * (w * MU);
+        p0 += Zd[w][r] * bp[0];
+        p1 += Zd[w][r] * bp[LD];
+      }
+      T sa, sb;
+      permlane32_swap(p0, p1, sa, sb);
+      const T tt = sa + sb;
+      permlane16_swap(tt, tt, sa, sb);
+      const T gcol = sa + sb;  // rows 0, 1: G_w[j][w MU]; rows 2, 3: G_w[j][w MU + 1]
+      if ((g & 1) == 0) {
+        const int aa = g >> 1;
+        sG0[w * MU * 16 + j * MU + aa] = gcol;
+        // y_zeta = B_w^T zeta_w + r_ww (:154-157): zeta_w rides in column JB of the Z_w tile
+        if (j == JB) sYz[w * MU + aa] = gcol + sr[pr.rg[w][w] + aa];
       }
     }
     lds_sync(true);
+    {
+      const int aa = g >> 1;
+      const bool isY = (g & 1) != 0;
+      const int c = isY ? M + j : j;  // column of [S | Y]
 #pragma unroll
-    for (int w = 0; w < NP; w++) {
-      const T* const sGw = sG0 + w * MU * 16;
-      T acc[MU];
+      for (int w = 0; w < NP; w++) {
+        const T* const sGw = sG0 + w * MU * 16;
+        T pS[MU], pY[MU];
 #pragma unroll
-      for (int aa = 0; aa < MU; aa++) acc[aa] = T(0);
+        for (int q = 0; q < MU; q++) pS[q] = pY[q] = T(0);
 #pragma unroll
-      for (int kk = 0; kk < NX; kk++)
+        for (int r = 0; r < 4; r++) {
+          const T* gp = sGw + (row0 + RS * r) * MU;
 #pragma unroll
-        for (int aa = 0; aa < MU; aa++) acc[aa] += sGw[kk * MU + aa] * ba[kk];
-      if (lane < M + NX) {
-        const bool diag = lane / MU == w;  // + R_ww on this player's diagonal block of S (:148-150)
-        const int b = lane - w * MU;
-#pragma unroll
-        for (int aa = 0; aa < MU; aa++)
-          sSY[(w * MU + aa) + M * lane] = acc[aa] + (diag ? sR[pr.ro[w][w] + aa + MU * (diag ? b : 0)] : T(0));
+          for (int q = 0; q < MU; q++) {
+            const T gval = gp[q];
+            pS[q] += gval * Bd[r];
+            pY[q] += gval * Ad[r];
+          }
+        }
+        // rows after the reduction: 0 = S(aa 0), 1 = Y(aa 0), 2 = S(aa 1), 3 = Y(aa 1)
+        const T tot = rows_reduce4<T>(pS[0], pS[1], pY[0], pY[1]);
+        const bool diag = !isY && j / MU == w;  // + R_ww on this player's diagonal block of S (:148-150)
+        const T rd = sR[pr.ro[w][w] + aa + MU * (diag ? j - w * MU : 0)];
+        const T val = tot + (diag ? rd : T(0));
+        if (isY ? j < NX : j < M) sSY[(w * MU + aa) + M * c] = val;
       }
     }
-    stash_ql(k);
     lds_sync(true);
 
     // ---- column `lane` of [S | Y]: Gershgorin (:163-176), then the M x M solve (:180) ----
@@ -293,13 +310,11 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_1w(const LQArgs<T>& a,
         x[r] = T(0);
       }
       {
-        T l1 = T(0), diag = T(0);
+        T l1 = T(0);
 #pragma unroll
-        for (int r = 0; r < M; r++) {
-          l1 += (col[r] < T(0) ? -col[r] : col[r]);
-          diag = (r == lane) ? col[r] : diag;
-        }
-        const T radius = l1 - (diag < T(0) ? -diag : diag);
+        for (int r = 0; r < M; r++) l1 += lq_abs(col[r]);
+        const T diag = src[isS ? lane : 0];
+        const T radius = l1 - lq_abs(diag);
         const T eval_lo = diag - radius;
         const T bump = (isS && a.adaptive && eval_lo < T(1e-3f)) ? radius + T(1e-3f) : T(0);
 #pragma unroll
@@ -321,36 +336,38 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_1w(const LQArgs<T>& a,
       }
     }
     lds_sync(true);
-    if (lane < NX) {
+    {
+      // explicit global address space: through a generic pointer these are FLAT stores, which count on the LDS counter too
+      typedef __attribute__((address_space(1))) T gT;
+      if (lane < NX) {
+        T pv[M];
 #pragma unroll
-      for (int r = 0; r < M; r++) uniform_ptr(a.P + size_t(k) * M * NX)[unsigned(r + M * lane)] = sPt[r + LD * lane];
-    } else if (lane < NX + M) {
-      uniform_ptr(a.alpha + size_t(k) * M)[unsigned(lane - NX)] = sAl[lane - NX];
+        for (int r = 0; r < M; r++) pv[r] = sPt[r + LD * lane];
+        gT* dst = (gT*)(uniform_ptr(a.P + size_t(k) * M * NX)) + unsigned(M * lane);
+#pragma unroll
+        for (int r = 0; r < M; r++) dst[r] = pv[r];
+      } else if (lane < NX + M) {
+        ((gT*)(uniform_ptr(a.alpha + size_t(k) * M)))[unsigned(lane - NX)] = sAl[lane - NX];
+      }
     }
 
-    // ---- F = A - B P (:189-194), beta = -B alpha: once for all players ----
+    // ---- [F | beta] = A - B [P | alpha] (:189-194): once for all players.  Used unmasked on both sides of the products:
+    // as a left operand its column JB only produces row JB of the result, and row JB of a Z_w tile never reaches anything
+    // (every right operand it meets has a zero row JB: tile padding); column 15 of every operand is zero. ----
     const vec Pd = ldD(sPt);
     vec nBT = ldDT(tB);
 #pragma unroll
     for (int r = 0; r < 4; r++) nBT[r] = -nBT[r];
-    const vec Fraw = tile_xty_blocks<T, kblock_mask<T>(0, M)>(nBT, Pd, ldD(tA));  // = [F | beta]
-    vec Fd, Fx, Pm;
+    const vec Fd = tile_xty_blocks<T, kblock_mask<T>(0, M)>(nBT, Pd, Ad);
+    // mu_{k+1} by rows (adjoint mode): this lane's rows of it, for beta_k^T mu_{k+1} and A_k^T mu_{k+1}
+    T muv[4] = {T(0), T(0), T(0), T(0)};
+    if (adj) {
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-      Fd[r] = Fraw[r] * mCols;
-      Fx[r] = Fraw[r] * mZcols;  // F in the state columns, beta in column JB, zero elsewhere
-      Pm[r] = Pd[r] * mCols;     // P proper: column JB of the tile holds alpha
-    }
-    T bmu = T(0);  // adjoint mode: this lane's share of beta_k^T mu_{k+1} (beta = column JB of Fraw: lanes j == JB)
-    if (j == JB) {
+      for (int r = 0; r < 4; r++) muv[r] = sMu[mub * 16 + row0 + RS * r];  // entries >= NX are zero
+    } else if (j == JB) {
 #pragma unroll
       for (int r = 0; r < 4; r++)
-        if (row0 + RS * r < NX) {
-          if (adj)
-            bmu += Fraw[r] * sMu[mub * 16 + row0 + RS * r];
-          else
-            a.scratch[size_t(k) * SCR + NP * (NX + 1) + row0 + RS * r] = Fraw[r];
-        }
+        if (row0 + RS * r < NX) a.scratch[size_t(k) * SCR + NP * (NX + 1) + row0 + RS * r] = Fd[r];
     }
     T ctrl = T(0);
     if (lane < NP) {  // alpha_i^T R_ii r_ii, evaluated (alpha^T R) r like Eigen (ilq_solver.cpp:384-386)
@@ -374,21 +391,36 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_1w(const LQArgs<T>& a,
         a.scratch[size_t(k) * SCR + NP * NX + lane] = acc;
     }
     if (adj) {
-      // ExpectedDecrease: the players' control terms of this step, then beta_k^T mu_{k+1}; then mu_k for the next step
-      // (every lane forms the same sums: LDS broadcasts, `ed` stays wave-uniform)
+      // ExpectedDecrease: the players' control terms of this step, then beta_k^T mu_{k+1} (beta = column JB of [F | beta])
 #pragma unroll
       for (int i = 0; i < NP; i++) ed -= bcast(ctrl, i);
-      ed -= (bcast(bmu, JB) + bcast(bmu, 16 + JB)) + (bcast(bmu, 32 + JB) + bcast(bmu, 48 + JB));
-      adjoint_step(false);  // (reads what was written before the solve's sync; its result is read a step from now)
-      mub = 1 - mub;
+      T bm = T(0);
+#pragma unroll
+      for (int r = 0; r < 4; r++) bm += Fd[r] * muv[r];
+      ed -= bcast(rows_allreduce<T>(bm), JB);
     }
 
     // ---- Z_w <- F^T Z_w F + Q_w + sum_jj P_jj^T R_w,jj P_jj, zeta_w in column JB (:198-212), player after player ----
+    T qsum = T(0);  // adjoint mode: sum_w (Q_w l_w)[j], every lane row
     static_for<NP>([&](auto WW) {
       constexpr int w = decltype(WW)::value;
       vec Cd = ldD(tQ0 + w * W::TILE);
-      // column JB of C_w: l_w + sum_jj P_jj^T (R_w,jj alpha_jj - r_w,jj) as one product [P]^T q with
-      // q = (R_w,jj alpha_jj - r_w,jj) stacked in column JB of the right operand
+      {
+        // Q_w l_w for ExpectedDecrease from the tile just loaded: Q_w is symmetric, so entry j is sum_row Q_w[row][j] l_w[row]
+        T part = T(0);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int row = row0 + RS * r;
+          part += Cd[r] * (row < NX ? sl[w * NX + (row < NX ? row : 0)] : T(0));
+        }
+        part = rows_allreduce<T>(part);
+        if (adj)
+          qsum += part;
+        else if (g == 0 && j < NX)
+          a.scratch[size_t(k) * SCR + w * NX + j] = part;
+      }
+      // column JB of C_w: l_w + sum_jj P_jj^T (R_w,jj alpha_jj - r_w,jj), and the state columns' sum_jj P_jj^T (R_w,jj P_jj):
+      // ONE product [P]^T [H | q] over the M rows of P, H = blockdiag(R_w,jj) P in the state columns, q in column JB
       vec Qy;
 #pragma unroll
       for (int r = 0; r < 4; r++) {
@@ -404,44 +436,33 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_1w(const LQArgs<T>& a,
             ro_wj = pr.ro[w][f];
             rg_wj = pr.rg[w][f];
           }
-        T ww = -sr[rg_wj + aa];
+        T ww = -sr[rg_wj + aa], h = T(0);
 #pragma unroll
-        for (int b = 0; b < MU; b++) ww += sR[ro_wj + aa + MU * b] * sAl[jj * MU + b];
-        Qy[r] = (in && qw >= 0) ? ww * mVecCol : T(0);
+        for (int b = 0; b < MU; b++) {
+          const T rv = sR[ro_wj + aa + MU * b];
+          ww += rv * sAl[jj * MU + b];
+          h += rv * sPt[(jj * MU + b) + LD * j];
+        }
+        Qy[r] = (in && qw >= 0) ? ww * mVecCol + h * mCols : T(0);
         const int srow = row < NX ? row : 0;
         Cd[r] += (row < NX ? sl[w * NX + srow] : T(0)) * mVecCol;
       }
-      Cd = tile_xty_blocks<T, kblock_mask<T>(0, M)>(Pm, Qy, Cd);
-      static_for<NP>([&](auto JJ) {
-        constexpr int jj = decltype(JJ)::value;
-        if (pr.q[w][jj] < 0) return;  // wave-uniform
-        const T* Rij = sR + pr.ro[w][jj];
-        T pb[MU];
-#pragma unroll
-        for (int b = 0; b < MU; b++) pb[b] = sPt[(jj * MU + b) + LD * j] * mCols;
-        vec Pj, Hd;
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const int aa = row0 + RS * r - jj * MU;
-          const bool in = aa >= 0 && aa < MU;
-          const int ac = in ? aa : 0;
-          const T mk = in ? T(1) : T(0);
-          T h = T(0);
-#pragma unroll
-          for (int b = 0; b < MU; b++) h += Rij[ac + MU * b] * pb[b];
-          Pj[r] = Pd[r] * (mk * mCols);
-          Hd[r] = h * mk;
-        }
-        Cd = tile_xty_blocks<T, kblock_mask<T>(jj * MU, jj * MU + MU)>(Pj, Hd, Cd);  // P_jj^T (R P_jj)
-      });
-      const vec Wd = tile_xty<T>(Zd[w], Fx, zero4);  // Z_w [F | beta] (Z_w symmetric: its own transpose)
+      Cd = tile_xty_blocks<T, kblock_mask<T>(0, M)>(Pd, Qy, Cd);
+      const vec Wd = tile_xty<T>(Zd[w], Fd, zero4);  // Z_w [F | beta] (Z_w symmetric: its own transpose)
       vec Wz;
 #pragma unroll
-      for (int r = 0; r < 4; r++) Wz[r] = Wd[r] * mZcols + Zd[w][r] * mVecCol;  // column JB: zeta_w + Z_w beta
-      const vec Zx = tile_xty<T>(Fd, Wz, Cd);  // F^T [Z_w F | zeta_w + Z_w beta] + C_w
-#pragma unroll
-      for (int r = 0; r < 4; r++) Zd[w][r] = Zx[r] * mZcols;
+      for (int r = 0; r < 4; r++) Wz[r] = Wd[r] + Zd[w][r] * mVecCol;  // column JB: zeta_w + Z_w beta
+      Zd[w] = tile_xty<T>(Fd, Wz, Cd);  // [Z_w' | F^T (zeta_w + Z_w beta)] + C_w
     });
+    if (adj) {
+      // mu_k = q_k + A_k^T mu_{k+1} (A of this image, still in place): entry j = sum_row A[row][j] mu_{k+1}[row]
+      T am = T(0);
+#pragma unroll
+      for (int r = 0; r < 4; r++) am += Ad[r] * muv[r];
+      const T munew = qsum + rows_allreduce<T>(am);
+      if (g == 0 && j < NX) sMu[(1 - mub) * 16 + j] = munew;
+      mub = 1 - mub;
+    }
 
     // ---- the image of the next step: the staged compact row over this one, then the row after it requested ----
     if (k >= 1) {
