@@ -1165,28 +1165,46 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
 #pragma unroll
       for (int kk = 0; kk < NX; kk++) ba[kk] = colp[kk];
     }
-    if constexpr (SPARE && kRowSums) {
+    if constexpr (kRowSums) {
       // G[:, w MU + aa] as two matrix-vector products: lane (g, j) multiplies its four rows of column j of the Z_w tile
       // with B[row][w MU + aa] (read from the B tile: the address depends on g only) and the four lane rows are summed on
       // the vector unit (v_permlane32_swap / v_permlane16_swap).  4 LDS reads + 8 FMA + 6 permlane / add instead of four
-      // matrix instructions.  zeta_w rides in column JB of the Z_w tile, so entry JB of the result is zeta_w^T B_w.
-      T p0 = T(0), p1 = T(0);
+      // matrix instructions.  SPARE: zeta_w rides in column JB of the Z_w tile, so entry JB of the result is zeta_w^T B_w;
+      // otherwise (n = 16) zeta_w^T B_w is formed beside it from the same B entries and this lane's rows of zeta_w.
+      T p0 = T(0), p1 = T(0), z0 = T(0), z1 = T(0);
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const T* bp = tB + (row0 + RS * r) + LD * (w * MU);
-        p0 += Zd[r] * bp[0];
-        p1 += Zd[r] * bp[LD];
+        const T b0 = bp[0], b1 = bp[LD];
+        p0 += Zd[r] * b0;
+        p1 += Zd[r] * b1;
+        if constexpr (!SPARE) {
+          const T zr = sZw[row0 + RS * r];
+          z0 += zr * b0;
+          z1 += zr * b1;
+        }
       }
       T sa, sb;
       permlane32_swap(p0, p1, sa, sb);
       const T tt = sa + sb;  // rows: p0(0+2), p0(1+3), p1(0+2), p1(1+3)
       permlane16_swap(tt, tt, sa, sb);
       const T gcol = sa + sb;  // rows 0, 1: G[j][w MU]; rows 2, 3: G[j][w MU + 1]
+      T ycol = T(0);
+      if constexpr (!SPARE) {
+        permlane32_swap(z0, z1, sa, sb);
+        const T tz = sa + sb;
+        permlane16_swap(tz, tz, sa, sb);
+        ycol = sa + sb;  // rows 0, 1: zeta_w^T B[:, w MU]; rows 2, 3: zeta_w^T B[:, w MU + 1] (every lane of the row)
+      }
       if ((g & 1) == 0) {
         const int aa = g >> 1;
         sGw[j * MU + aa] = gcol;  // interleaved [row][aa]: a lane reads the MU entries of a row with one instruction
         // y_zeta = B_w^T zeta_w + r_ww (:154-157)
-        if (j == JB) sYz[w * MU + aa] = gcol + sr[rg_ww + aa];
+        if constexpr (SPARE) {
+          if (j == JB) sYz[w * MU + aa] = gcol + sr[rg_ww + aa];
+        } else {
+          if (j == 0) sYz[w * MU + aa] = ycol + sr[rg_ww + aa];
+        }
       }
     } else {
       const vec G = tile_xty<T>(Zd, Bd, zero4);  // Z_w^T B
@@ -1254,7 +1272,7 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
       }
     }
     ILQG_PH(13);
-    if constexpr (SPARE) {
+    if constexpr (SPARE || kRowSums) {
     } else if (lane < MU) {
       const int tt = w * MU + lane;
       T s = T(0);
@@ -1378,8 +1396,9 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
       lds_sync(true);
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        BetaD[r] = sBw[row0 + RS * r] * mVecCol;
-        zetaD[r] = sZw[row0 + RS * r] * mVecCol;
+        // kRowSums: this lane's rows of beta, unmasked, for the row-sum products below (BetaD stands in for them)
+        BetaD[r] = kRowSums ? sBw[row0 + RS * r] : sBw[row0 + RS * r] * mVecCol;
+        zetaD[r] = kRowSums ? T(0) : sZw[row0 + RS * r] * mVecCol;
       }
       if (want_fwd && w == 0 && lane < NX) a.scratch[size_t(k) * SCR + NP * (NX + 1) + lane] = sBw[lane];
     }
@@ -1519,7 +1538,7 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
       Cd = tile_xty_blocks<T, kblock_mask<T>(jj * MU, jj * MU + MU)>(Pj, Hd, Cd);  // P_jj^T (R P_jj)
       if (!sym) CTd = tile_xty_blocks<T, kblock_mask<T>(jj * MU, jj * MU + MU)>(Pj, Htd, CTd);  // (P_jj^T R P_jj)^T
     });
-    vec FT;
+    vec FT = zero4;
     if constexpr (SPARE) {
       if constexpr (SOLVER) {
         const vec Wd = tile_xty<T>(Yd, Fd, zero4);  // Z_w [F | beta]
@@ -1546,6 +1565,28 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
       for (int r = 0; r < 4; r++) Zd[r] = Zx[r] * mZcols;  // [Z_w' | F^T (zeta_w + Z_w beta)]
       if (sym) Yd = Zd;
       }
+    } else if constexpr (kRowSums) {
+      // n = 16: no spare tile column for the vector recursion, and a tile product per matrix-vector product (Z_w beta,
+      // F^T t) is sixteen times the work: both are row sums over the accumulator-layout registers instead.
+      //   (Z_w beta)[j] = sum_row Z_w^T[row][j] beta[row]  (Yd holds Z_w^T; Z_w itself when the costs are symmetric)
+      //   (F^T t)[j]    = sum_row F[row][j] t[row],  t = zeta_w + Z_w beta
+      // each 4 FMA per lane + rows_allreduce; t changes from "entry j on lane j" to "this lane's rows" through the
+      // player's beta strip in LDS (beta's rows are in registers by now).
+      const vec Wd = tile_xty<T>(Yd, Fd, zero4);  // Z_w F
+      T zb = T(0);
+#pragma unroll
+      for (int r = 0; r < 4; r++) zb += Yd[r] * BetaD[r];
+      zb = rows_allreduce<T>(zb);
+      const T tj = sZw[j] + zb;  // zeta_w + Z_w beta, entry j (every lane row)
+      if (!sym) Yd = tile_xty<T>(Wd, Fd, CTd);
+      Zd = tile_xty<T>(Fd, Wd, Cd);
+      if (sym) Yd = Zd;
+      if (g == 0) sBw[j] = tj;
+      lds_sync(true);
+      T ft = T(0);
+#pragma unroll
+      for (int r = 0; r < 4; r++) ft += Fd[r] * sBw[row0 + RS * r];
+      FT[0] = rows_allreduce<T>(ft);  // entry j of F^T (zeta_w + Z_w beta), every lane row
     } else {
       const vec Wd = tile_xty<T>(Yd, Fd, zero4);     // Z_w F
       const vec ZB = tile_xty<T>(Yd, BetaD, zero4);  // column w = Z_w beta
@@ -1559,14 +1600,16 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
     }
     ILQG_PH(4);
     if constexpr (!SPARE) {
+    if constexpr (!kRowSums) {
     if (j == w) {  // the reads of the old zeta (zetaD) precede this by data dependence
 #pragma unroll
       for (int r = 0; r < 4; r++)
         if (row0 + RS * r < NX) sZw[row0 + RS * r] = FT[r];  // F^T (zeta_w + Z_w beta)
     }
     lds_sync(true);
+    }
     if (lane < NX) {  // + l_w + sum_jj P_jj^T (R_w,jj alpha_jj - r_w,jj)   (:198-201, 206-212)
-      T zn = sZw[lane] + sl[w * NX + lane];
+      T zn = (kRowSums ? FT[0] : sZw[lane]) + sl[w * NX + lane];
 #pragma unroll
       for (int jj = 0; jj < NP; jj++) {
         int qw = -1, ro_wj = 0, rg_wj = 0;
