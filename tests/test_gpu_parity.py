@@ -480,7 +480,8 @@ def test_augmented_lagrangian_solve_matches_oracle_fp64(hip, oracle):
     spec.params.unconstrained_solver_max_iters = 5
     B = 12
     x0 = examples.jittered_x0(spec, B, seed=21)
-    ref, stable = oracle_with_stability(oracle.OracleProblem(spec), abi.F64, x0, augmented_lagrangian=True)
+    # (three draws: with one, instance 9 passes as stable although another 1e-12 nudge moves it in the oracle itself)
+    ref, stable = oracle_with_stability(oracle.OracleProblem(spec), abi.F64, x0, augmented_lagrangian=True, draws=3)
     out = hip.Problem(spec, abi.F64).solve(x0, augmented_lagrangian=True)
     same = (_np(out["iters"]) == ref["iters"]) & (_np(out["status"]) == ref["status"])
     # all but one of the instances whose outcome survives a 1e-12 nudge of x0 in the oracle itself end the same way on
