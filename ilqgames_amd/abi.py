@@ -13,7 +13,7 @@ F32, F64 = 0, 1
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_NO_DEVICE = 0, 1, 2, 3, 4
 
 # ilqg_dyn_kind
-ABI_VERSION = 5  # ILQG_ABI_VERSION of include/ilqg.h these mirrors were written against
+ABI_VERSION = 6  # ILQG_ABI_VERSION of include/ilqg.h these mirrors were written against
 DYN_UNICYCLE_4D, DYN_CAR_5D, DYN_CAR_6D = 1, 2, 3
 DYN_UNICYCLE_4D_DISTURBED, DYN_PLANAR_DISTURBANCE = 4, 5  # the two rows of TwoPlayerUnicycle4D
 DYN_DUBINS_CAR = 6  # (px, py, theta), u = (omega), param0 = speed
@@ -43,6 +43,9 @@ CONSTRAINT_AFFINE_VECTOR = 23  # g = |A v - b|; `polyline` = offset of [A (colum
 # ilqg_cost_role
 ROLE_STATE_COST, ROLE_CONTROL_COST, ROLE_STATE_CONSTRAINT, ROLE_CONTROL_CONSTRAINT, ROLE_CHILD = range(5)
 FLAG_ORIENTED, FLAG_IS_MIN, FLAG_EQUALITY = 1, 2, 4
+# ILQG_SCHEDULE_* (ilqg_problem_last_schedule)
+SCHEDULE_SINGLE_WAVE_SWEEP, SCHEDULE_ADJOINT_DECREASE, SCHEDULE_SPLIT_TRIAL, SCHEDULE_COMPACT_ROWS = 1, 2, 4, 8
+SCHEDULE_COUNTED, SCHEDULE_GENERIC, SCHEDULE_OPEN_LOOP = 16, 32, 64
 SUM, MAX, MIN = 0, 1, 2
 
 

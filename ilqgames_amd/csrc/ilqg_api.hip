@@ -427,7 +427,8 @@ __global__ void __launch_bounds__(64, sizeof(T) == 8 ? 4 : 1) ilq_probe_rows_ker
 
 template <typename T>
 __global__ void __launch_bounds__(64) ilq_probe_pick_kernel(DevProblem p, SolveArgs<T> sa) {
-  __shared__ T merits[kProbeCandidates];  // the candidates' merit values, reduced here one lane per candidate
+  // the candidates' merit values, reduced here one lane per candidate, and the staging the reduction reads through
+  __shared__ T merits[kProbeCandidates + kProbeStage * (kProbeCandidates + 1)];
   probe_pick_instance<T>(p, sa, sa.ids[blockIdx.x], blockIdx.x, merits);
 }
 
@@ -684,6 +685,7 @@ struct ilqg_problem {
   int* h_unfinished = nullptr;  // pinned host mirror
   int mu_uniform = 0;
   bool has_route_progress = false;  // a RouteProgressCost term: its tables are a first solve's (initial time 0)
+  int last_schedule = 0;  // ILQG_SCHEDULE_* of the last solve (ilqg_problem_last_schedule)
   bool generic = false;  // no specialised instantiation holds this problem: every entry point runs the run-time-dimensioned kernels
   // LoopTimer of the solver object (include/ilqgames/utils/loop_timer.h:60-98, src/loop_timer.cpp:55-92): the last ten
   // iteration times, kept across solves as the reference's member is; only solves with a max_runtime feed and read it
@@ -921,6 +923,9 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
     if (adjoint) sa.defer_forward = 0;  // the sweep forms the expected decrease itself: no forward pass anywhere
   }
   raise_lds_limit((const void*)k_lq, lds_lq);
+  p->last_schedule = (single_wave ? ILQG_SCHEDULE_SINGLE_WAVE_SWEEP : 0) | ((single_wave && adjoint) ? ILQG_SCHEDULE_ADJOINT_DECREASE : 0) |
+                     (split ? ILQG_SCHEDULE_SPLIT_TRIAL : 0) | (sa.compact ? ILQG_SCHEDULE_COMPACT_ROWS : 0) |
+                     (counted ? ILQG_SCHEDULE_COUNTED : 0) | (p->desc.params.open_loop ? ILQG_SCHEDULE_OPEN_LOOP : 0);
   long long cap = al_mode ? (long long)(sa.prm.max_solver_iters + 1) * (sa.prm.unconstrained_solver_max_iters + 2)
                           : (long long)sa.prm.max_solver_iters + 2;
   if (split || counted) cap = (cap + 2) * ((long long)sa.prm.max_backtracking_steps + 3);
@@ -1196,6 +1201,8 @@ static ilqg_status generic_solve(ilqg_problem* p, int32_t batch, const void* x0,
   sa.prof = nullptr;
   sa.forced_steps = (const T*)opt.forced_steps;
   sa.unfinished = p->d_unfinished;
+  p->last_schedule = ILQG_SCHEDULE_GENERIC | ILQG_SCHEDULE_SPLIT_TRIAL | ILQG_SCHEDULE_COUNTED |
+                     (p->desc.params.open_loop ? ILQG_SCHEDULE_OPEN_LOOP : 0);
   sa.rows_cw = rows_chunk_width(d.n, d.m, d.rp_pslots, d.rp_lslots, sizeof(T), size_t(48) * 1024);
   const size_t lds_roll = trial_phase_lds_bytes<T>(d, TRIAL_ROLL, sa.rows_cw),
                lds_decide = trial_phase_lds_bytes<T>(d, TRIAL_DECIDE, sa.rows_cw);
@@ -1382,6 +1389,12 @@ ilqg_status ilqg_selftest_mfma(int32_t dtype, const void* X, const void* Y, cons
   return ILQG_OK;
 }
 int32_t ilqg_abi_version(void) { return ILQG_ABI_VERSION; }
+
+ilqg_status ilqg_problem_last_schedule(const ilqg_problem* p, int32_t* schedule_out) {
+  if (!p || !schedule_out) return fail(ILQG_ERR_INVALID, "null argument");
+  *schedule_out = p->last_schedule;
+  return ILQG_OK;
+}
 
 ilqg_status ilqg_device_info(char* name_out, int32_t name_len, int32_t* num_cus) {
   ilqg_status s = check_device();

@@ -46,6 +46,11 @@ struct LQArgs {
   int prio_div = 0;                 // > 0: rotate the wave priority every step, phase = blockIdx.x / prio_div (see the sweep)
   long long* tl = nullptr;          // optional: timeline stamps (ilqg_common.hpp, -DILQG_TIMELINE=1)
   int tl_b = 0;
+  // > 0: A is block diagonal over `nsub` subsystems with state offsets xoff[0 .. nsub] and B_i is confined to the rows of
+  // subsystem i (what ConcatenatedDynamicalSystem::Linearize produces, src/concatenated_dynamical_system.cpp:86-107):
+  // the open-loop sweep then skips the matrix-instruction blocks that only meet structural zeros.  0: dense.
+  int nsub = 0;
+  int xoff[ILQG_MAX_PLAYERS + 1] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 template <typename T, int NX, int NP, int MU>

@@ -407,6 +407,27 @@ __device__ __forceinline__ void lq_openloop_instance(const LQArgs<T>& a, const P
     }
   };
 
+  // Structural zeros of block-diagonal dynamics (LQArgs::nsub): which k blocks of the two k tiles can be non-zero in
+  //   Aa^T W, output row tile aa: the rows of the subsystems that reach into rows [16 aa, 16 aa + 16)
+  // (wave-uniform; everything allowed when the caller gave no structure).
+  int mA[2][2] = {{15, 15}, {15, 15}};  // [k tile][aa]
+  if (a.nsub > 0) {
+#pragma unroll
+    for (int aa = 0; aa < 2; aa++) {
+      int lo = NX, hi = 0;
+#pragma unroll
+      for (int i = 0; i < NP; i++) {  // (compile-time indices: a run-time-indexed member would put the arguments in scratch)
+        const int x0 = a.xoff[i], x1 = a.xoff[i + 1];
+        if (i < a.nsub && x1 > 16 * aa && x0 < 16 * aa + 16) {
+          lo = x0 < lo ? x0 : lo;
+          hi = x1 > hi ? x1 : hi;
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 2; c++) mA[c][aa] = __builtin_amdgcn_readfirstlane(kblock_mask_rt<T>(c, lo, hi));
+    }
+  }
+
   long long ph_c = (kProfile && a.ph) ? clock64() : 0;
   auto PH = [&](int slot) {
     if (kProfile && a.ph && t == 0) {
@@ -416,6 +437,8 @@ __device__ __forceinline__ void lq_openloop_instance(const LQArgs<T>& a, const P
     }
   };
 
+  // (M_i of an open-loop Nash game is NOT symmetric — M_i = Q_i + A^T M_i Lambda^{-1} A with the other players' terms in
+  // Lambda — so both D(Ma_i) and D(Ma_i^T) are kept; replacing one by the other was tried in round 5 and is wrong.)
   Blk Md = load_blk(sZ, false);  // D(Ma_i)
   Blk MT = load_blk(sZ, true);   // D(Ma_i^T)
   store_row_from_tile(Tn - 1, true);
@@ -436,6 +459,31 @@ __device__ __forceinline__ void lq_openloop_instance(const LQArgs<T>& a, const P
     const T* sAa = aimg(k & 1);
     // ---- [V_i | g_i] = R_ii^{-1} (B_i^T Ma_i + [0 | r_ii]),  R_ii r_ii ----
     {
+      if constexpr (MU == 2 && NTL <= 2) {
+        // B_i^T Ma_i has MU = 2 rows: as a tile product fourteen of sixteen output rows are zeros.  Row sums instead
+        // (ilqg_mfma.hpp): lane (g, j) multiplies its rows of column j of every column tile of Ma_i with
+        // B_i[row][aa] (from the image: the address depends on g only), and the (aa, bb) partial sums are reduced over the
+        // four lane rows with v_permlane swaps — twelve matrix instructions less per step at n = 24.
+        T pp[2][2] = {{T(0), T(0)}, {T(0), T(0)}};  // [aa][bb]
+#pragma unroll
+        for (int c = 0; c < NTL; c++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const int row = 16 * c + TL::row(g, r);
+            const bool rok = row < NX;
+            const T* bp = sB + NX * (w * MU) + (rok ? row : 0);
+            const T b0 = rok ? bp[0] : T(0), b1 = rok ? bp[NX] : T(0);
+#pragma unroll
+            for (int bb = 0; bb < NTL; bb++) {
+              pp[0][bb] += Md.v[c][bb][r] * b0;
+              pp[1][bb] += Md.v[c][bb][r] * b1;
+            }
+          }
+        // rows after the reduction: 0 = (aa 0, bb 0), 1 = (aa 0, bb 1), 2 = (aa 1, bb 0), 3 = (aa 1, bb 1)
+        const T tot = rows_reduce4<T>(pp[0][0], pp[1][0], pp[0][1], pp[1][1]);
+        const int col = 16 * (g & 1) + j;
+        if (((g & 1) < NTL) && col < NH) sBt[(g >> 1) + MU * col] = tot;
+      } else {
       vec Bd[NTL];  // D(B_i): n x mu
 #pragma unroll
       for (int c = 0; c < NTL; c++) Bd[c] = ld_tile<T, false>(sB + NX * (w * MU) + oDn, NX, c, 0, NX, MU, g, j);
@@ -449,6 +497,7 @@ __device__ __forceinline__ void lq_openloop_instance(const LQArgs<T>& a, const P
           const int row = TL::row(g, r);
           if (row < MU && col < NH) sBt[row + MU * col] = acc[r];
         }
+      }
       }
       lds_sync(true);
       if (lane < NH) {
@@ -505,7 +554,20 @@ __device__ __forceinline__ void lq_openloop_instance(const LQArgs<T>& a, const P
         T* row = row_of(k);
         for (int e = lane; e < M * NX + 2 * M; e += 64) row[O::rV + e] = sV[e];
       }
-      lu_pp_solve_columns<T, M>(col, lane, x);
+      {
+        // Partial pivoting never exchanges rows of a matrix whose columns are strictly diagonally dominant (elimination
+        // keeps the property for every Schur complement), so for such a K the pivot searches and row exchanges — more
+        // than a third of the chain's instructions — are skipped and the result is the same to the last bit.
+        T l1 = T(0);
+#pragma unroll
+        for (int q = 0; q < M; q++) l1 += lq_abs(col[q]);
+        const T dg = lq_abs(sKA[(lane < M ? lane : 0) * (M + 1)]);
+        const bool dominant = __all(lane >= M || dg > l1 - dg);
+        if (dominant)
+          lu_solve_columns<T, M>(col, lane, x);
+        else
+          lu_pp_solve_columns<T, M>(col, lane, x);
+      }
       if (lane >= M && lane <= M + NX) {
 #pragma unroll
         for (int q = 0; q < M; q++) sZs[q + LDZ * (lane - M)] = x[q];
@@ -560,17 +622,35 @@ __device__ __forceinline__ void lq_openloop_instance(const LQArgs<T>& a, const P
             }
           }
     }
-    store_row_from_tile(k, true);
+    // Q_i l_i (expected decrease): with symmetric costs entry j is sum_row Q_i[row][j] l_i[row] — row sums of the D(Qa_i)
+    // tiles this update loads anyway (l_i is their column NX), reduced over the lane rows below; otherwise the row-by-
+    // row products from the tile
+    const bool ql_rows = a.symmetric != 0 && NTL <= 2;
+    if (!ql_rows) store_row_from_tile(k, true);
+    T qlp[2] = {T(0), T(0)};
     // ---- Ma' = Qa + Aa^T W ----
 #pragma unroll
     for (int aa = 0; aa < NTL; aa++)
 #pragma unroll
       for (int bb = 0; bb < NTL; bb++) {
         vec acc = ld_tile<T, false>(sZ + oD, LD, aa, bb, NH, NH, g, j);  // D(Qa_i)
-        acc = tile_xty_blocks<T, KN0>(ld_tile<T, false>(sAa + oD, LD, 0, aa, NH, NH, g, j), Wd.v[0][bb], acc);
-        if constexpr (NTL == 2) acc = tile_xty_blocks<T, KN1>(ld_tile<T, false>(sAa + oD, LD, 1, aa, NH, NH, g, j), Wd.v[1][bb], acc);
+        if (ql_rows) {
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const int row = 16 * aa + TL::row(g, r);
+            qlp[bb] += acc[r] * (row < NX ? sZ[(row < NX ? row : 0) + LD * NX] : T(0));
+          }
+        }
+        acc = tile_xty_blocks_rt<T, KN0>(ld_tile<T, false>(sAa + oD, LD, 0, aa, NH, NH, g, j), Wd.v[0][bb], acc, mA[0][aa]);
+        if constexpr (NTL == 2)
+          acc = tile_xty_blocks_rt<T, KN1>(ld_tile<T, false>(sAa + oD, LD, 1, aa, NH, NH, g, j), Wd.v[1][bb], acc, mA[1][aa]);
         Md.v[aa][bb] = acc;
       }
+    if (ql_rows) {
+      const T tot = rows_reduce4<T>(qlp[0], T(0), qlp[1], T(0));  // row 0: columns 0 .. 15, row 1: columns 16 ..
+      const int col = 16 * g + j;
+      if (g < NTL && col < NX) row_of(k)[O::rql + wp * NX + col] = tot;
+    }
     PH(3);
     // transpose through this wave's tile: write D(Ma'), read D(Ma'^T)
     lds_sync(true);  // every read of Qa_i is done

@@ -75,6 +75,29 @@ __device__ __forceinline__ typename Tile<T>::vec tile_xty_blocks(const typename 
   return c;
 }
 
+// The same with a run-time (wave-uniform) mask on top of the compile-time one: block structure known per problem, not per
+// instantiation (a scalar branch around a 64-cycle instruction).
+template <typename T, int MASK>
+__device__ __forceinline__ typename Tile<T>::vec tile_xty_blocks_rt(const typename Tile<T>::vec& xd,
+                                                                    const typename Tile<T>::vec& yd,
+                                                                    typename Tile<T>::vec c, int rt_mask) {
+#pragma unroll
+  for (int kb = 0; kb < 4; kb++)
+    if ((MASK & (1 << kb)) && (rt_mask & (1 << kb))) c = Tile<T>::mfma(xd[kb], yd[kb], c);
+  return c;
+}
+// k blocks of a 16-row k tile (rows 16 c ..) that hold a row in [lo, hi)
+template <typename T>
+__host__ __device__ inline int kblock_mask_rt(int c, int lo, int hi) {
+  int mask = 0;
+  for (int kb = 0; kb < 4; kb++)
+    for (int g = 0; g < 4; g++) {
+      const int row = 16 * c + Tile<T>::row(g, kb);
+      if (row >= lo && row < hi) mask |= 1 << kb;
+    }
+  return mask;
+}
+
 // ---- cross-row exchanges of a wavefront's four 16-lane rows on the vector unit (gfx950: v_permlane32_swap /
 // v_permlane16_swap; no LDS) ----
 // permlane32_swap(a, b): a' = [a.row0 a.row1 b.row0 b.row1], b' = [a.row2 a.row3 b.row2 b.row3]

@@ -422,6 +422,7 @@ __device__ __forceinline__ void rows_part_instance(const DevProblem& p, const sh
 constexpr int kProbeCandidates = 128;           // most step sizes probed per instance and round (a failing search walks
                                                 // through all max_backtracking_steps of them — 100 in the examples — and a
                                                 // round costs the latency of one rollout whatever it probes)
+constexpr int kProbeStage = 32;                 // partials per candidate the pick kernel stages at a time
 constexpr int kProbeEntries = 32768;            // pool size: candidates of all listed instances of one round
 constexpr int kProbeRoundBudget = 8192;         // rollouts the first probing round of a tail may hold (doubling after): what
                                                 // the chip integrates at once, two per wavefront at four waves per SIMD
@@ -539,24 +540,37 @@ __device__ __forceinline__ void probe_pick_instance(const DevProblem& p, const S
   const ProbeEntry E(p.n, p.m, p.N, p.T);
   const T* const e0 = sa.probe_pool + size_t(slot) * sa.probe_k * E.total;
   if (merits) {
+    // Candidate j's merit value = its per-row partials summed in merit_reduce's order, one lane per candidate (a serial
+    // chain either way).  The partials of one candidate are contiguous and the candidates' entries far apart, so a lane
+    // that walks its own entry issues one cache line per load and lane (measured: 69 us per probing round).  Instead
+    // the wave loads kProbeStage partials of every candidate at a time with contiguous half-wave reads, transposes them
+    // through LDS ([partial][candidate]: conflict-free for the summing lanes) and every lane adds its candidate's
+    // column in order.
+    T* const stage = merits + kProbeCandidates;  // [kProbeStage][kProbeCandidates + 1]
+    constexpr int LDJ = kProbeCandidates + 1;
     const int count = p.T * p.N * 2, skip = p.N * 2;  // the |l_i|^2 terms of k = 0 do not enter (:421)
-    for (int j = threadIdx.x; j < sa.probe_k; j += blockDim.x) {
-      if (s.bt + j >= prm.max_backtracking_steps) continue;
-      const T* const mp = e0 + size_t(j) * E.total + E.mpart;
-      T merit = T(0);
-      int e = 0;
-      for (; e < skip && e < count; e++)
-        if ((e & 1) == 0) merit += mp[e];
-      for (; e + 8 <= count; e += 8) {
-        T x[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) x[u] = mp[e + u];
-#pragma unroll
-        for (int u = 0; u < 8; u++) merit += x[u];
+    const int lane = threadIdx.x, half = lane >> 5, hl = lane & 31;
+    static_assert(kProbeStage == 32 && kProbeCandidates == 128, "two candidates per lane, a half-wave per candidate row");
+    T acc[2] = {T(0), T(0)};
+    const T* const mp0 = e0 + E.mpart;
+    for (int c0 = 0; c0 < count; c0 += kProbeStage) {
+      for (int jj = half; jj < sa.probe_k; jj += 2) {
+        const int e = c0 + hl;
+        stage[hl * LDJ + jj] = e < count ? mp0[size_t(jj) * E.total + e] : T(0);
       }
-      for (; e < count; e++) merit += mp[e];
-      merits[j] = T(0.5) * merit;
+      __syncthreads();
+#pragma unroll 4
+      for (int u = 0; u < kProbeStage; u++) {
+        const int e = c0 + u;
+        if (e >= count) break;
+        if (e < skip && (e & 1)) continue;  // wave-uniform
+        acc[0] += stage[u * LDJ + lane];
+        acc[1] += stage[u * LDJ + lane + 64];
+      }
+      __syncthreads();
     }
+    if (lane < sa.probe_k) merits[lane] = T(0.5) * acc[0];
+    if (lane + 64 < sa.probe_k) merits[lane + 64] = T(0.5) * acc[1];
     __syncthreads();
   }
   int tried = 0;
@@ -986,6 +1000,17 @@ __device__ __forceinline__ void lq_part_instance(const DevProblem& p, const Solv
   la.T_steps = Tn;
   la.adaptive = 1;
   la.symmetric = 1;  // linquad_compute writes H(x,y) and H(y,x) from the same value
+  if constexpr (kOL) {
+    // block-diagonal A (one block per subsystem): every player brings a state block of its own
+    bool blocks = true;
+#pragma unroll
+    for (int i = 0; i < NP; i++) blocks = blocks && p.xoff[i + 1] > p.xoff[i];
+    if (blocks) {
+      la.nsub = NP;
+#pragma unroll
+      for (int i = 0; i <= NP; i++) la.xoff[i] = p.xoff[i];
+    }
+  }
   la.prio_div = KIND == LQ_PLAYER_WAVES ? sa.prio_div : 0;
   if (sa.compact && (KIND == LQ_PLAYER_WAVES || KIND == LQ_OPEN_LOOP_COMPACT || KIND == LQ_SINGLE_WAVE)) {
     la.compact = w + L.Q;

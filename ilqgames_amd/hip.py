@@ -23,7 +23,7 @@ EXPORTS = [
     "ilqg_solution_splice_batch", "ilqg_solve_again_batch", "ilqg_strategy_costs_batch",
     "ilqg_check_local_nash_batch", "ilqg_check_sufficient_nash_batch",
     "ilqg_receding_horizon_shift_batch", "ilqg_default_solve_options", "ilqg_solve_batch_ex", "ilqg_solve_state_batch",
-    "ilqg_set_scratch",
+    "ilqg_set_scratch", "ilqg_problem_last_schedule",
 ]
 
 
@@ -272,6 +272,12 @@ class Problem:
                                             _ptr(out["last_merit"]), _ptr(out["expected_decrease"]),
                                             _ptr(out["step"]), _ptr(out["backtracks"]), _stream()))
         return out
+
+    def last_schedule(self):
+        """ilqg_problem_last_schedule: the ILQG_SCHEDULE_* bits of the last solve on this problem."""
+        v = C.c_int32(0)
+        _check(lib().ilqg_problem_last_schedule(self.h, C.byref(v)))
+        return v.value
 
     def receding_horizon_shift(self, x0, t0, planner_runtime, plan_t0, bufs):
         """ilqg_receding_horizon_shift_batch: turns the solution in `bufs` (xs, us, P, alpha) into the warm start

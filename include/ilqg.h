@@ -394,7 +394,12 @@ ilqg_status ilqg_ilq_solve_batch(ilqg_problem* p, int32_t batch, const void* x0,
                                  void* stream);
 
 /* Everything a solve call can be told beyond its buffers (ilqg_solve_batch_ex).  The scheduling choices select among
- * device schedules of the SAME arithmetic (bit-identical results; they exist for measurements and tests).
+ * device schedules of the SAME arithmetic: split_trial / handoff / probe / counted / compact_rows / round_bursts are
+ * bit-identical with each other; single_wave_sweep and adjoint_expected_decrease run the same recursion as a different
+ * instruction stream (sums in another order), i.e. the same results to rounding — and ILQG_CHOICE_AUTO picks them from
+ * the batch size (five or more instances per CU), so an instance's last bits, and with them a line-search decision that
+ * sits on a rounding threshold, can depend on the size of the batch it is solved in.  Pin the two choices (ON / OFF) for
+ * results that must not; ilqg_problem_last_schedule says what the last solve ran.
  * ilqg_default_solve_options fills the defaults: reference semantics, every choice ILQG_CHOICE_AUTO. */
 typedef struct {
   int32_t fixed_iters;          /* > 0: exactly that many outer iterations per instance, convergence not tested   */
@@ -467,6 +472,17 @@ ilqg_status ilqg_solve_batch_ex(ilqg_problem* p, int32_t batch, const void* x0, 
 ilqg_status ilqg_solve_state_batch(const ilqg_problem* p, int32_t batch, const void* workspace,
                                    int32_t augmented_lagrangian, void* last_merit, void* expected_decrease,
                                    void* step, int32_t* backtracks, void* stream);
+
+/* Which device schedule the problem's last solve ran (bits below), so that a caller can tell two runs apart whose results
+ * differ in the last bits because ILQG_CHOICE_AUTO chose differently for their batch sizes. */
+#define ILQG_SCHEDULE_SINGLE_WAVE_SWEEP 1   /* one wave per instance (else: one wave per player)                  */
+#define ILQG_SCHEDULE_ADJOINT_DECREASE 2    /* ExpectedDecrease by the sweep's adjoint recursion                  */
+#define ILQG_SCHEDULE_SPLIT_TRIAL 4         /* trial pass as rollout / rows / decision kernels                    */
+#define ILQG_SCHEDULE_COMPACT_ROWS 8        /* compact rows between the row stage and the sweep                   */
+#define ILQG_SCHEDULE_COUNTED 16            /* host-counted rounds (hand-off, speculative line search)            */
+#define ILQG_SCHEDULE_GENERIC 32            /* the run-time-dimensioned kernels                                   */
+#define ILQG_SCHEDULE_OPEN_LOOP 64          /* LQOpenLoopSolver's sweep                                           */
+ilqg_status ilqg_problem_last_schedule(const ilqg_problem* p, int32_t* schedule_out);
 
 /* Replaces AugmentedLagrangianSolver::Solve (src/augmented_lagrangian_solver.cpp:72-210) with
  * max_runtime = infinity: inner ilqg_ilq_solve_batch calls capped at
@@ -606,7 +622,8 @@ const char* ilqg_last_error(void);
 ilqg_status ilqg_set_scratch(void* device_buffer, size_t bytes);
 
 /* Library / device introspection (used by the loader to fail loudly). */
-#define ILQG_ABI_VERSION 5 /* 5: ilqg_solve_options::iterate_log / max_runtime, run-time-dimensioned kernels behind every entry
+#define ILQG_ABI_VERSION 6 /* 6: ilqg_problem_last_schedule;
+                              5: ilqg_solve_options::iterate_log / max_runtime, run-time-dimensioned kernels behind every entry
                               point (any n <= 32, N <= 8, m_i), the affine constraints (ilqg_problem_desc::dense_params);
                               4: ilqg_cost_term::idx_extra / value2, cost kinds 12-21, dynamics kinds 10-12;
                               3: ilqg_solve_options / ilqg_solve_batch_ex / ilqg_solve_state_batch, ilqg_dims::sweep_formulation;

@@ -80,3 +80,25 @@ def test_single_wave_sweep_at_config3_batch_is_batch_independent(hip):
     # and the two sweeps agree at that size to fp32 rounding through three iterations
     pw = prob.solve(x0[lo:lo + 37], fixed_iters=3, single_wave_sweep=False)
     assert rel_err(_np(pw["xs"]), _np(part["xs"])) < 2e-3
+
+
+def test_last_schedule_reports_what_auto_chose(hip):
+    """ilqg_problem_last_schedule: AUTO picks the single-wave sweep (with the adjoint expected decrease and the split
+    trial pass) from five instances per CU on, the player-parallel sweep below; pinned choices are reported as pinned."""
+    import torch
+    spec = examples.modified_three_player_intersection()
+    spec.params.expected_decrease_fraction = 0.001
+    spec.params.initial_alpha_scaling = 0.1
+    prob = hip.Problem(spec, abi.F64)
+    prob.solve(examples.jittered_x0(spec, 8, seed=1), fixed_iters=1)
+    torch.cuda.synchronize()
+    few = prob.last_schedule()
+    assert few & abi.SCHEDULE_COMPACT_ROWS and not few & abi.SCHEDULE_SINGLE_WAVE_SWEEP and not few & abi.SCHEDULE_OPEN_LOOP
+    cus = hip.device_info()[1]
+    prob.solve(examples.jittered_x0(spec, 5 * cus, seed=1), fixed_iters=1)
+    torch.cuda.synchronize()
+    many = prob.last_schedule()
+    assert many & abi.SCHEDULE_SINGLE_WAVE_SWEEP and many & abi.SCHEDULE_ADJOINT_DECREASE and many & abi.SCHEDULE_SPLIT_TRIAL
+    prob.solve(examples.jittered_x0(spec, 5 * cus, seed=1), fixed_iters=1, single_wave_sweep=False)
+    torch.cuda.synchronize()
+    assert not prob.last_schedule() & abi.SCHEDULE_SINGLE_WAVE_SWEEP
