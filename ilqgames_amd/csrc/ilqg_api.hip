@@ -426,9 +426,8 @@ __global__ void __launch_bounds__(64, sizeof(T) == 8 ? 4 : 1) ilq_probe_rows_ker
 }
 
 template <typename T>
-__global__ void __launch_bounds__(64) ilq_probe_pick_kernel(DevProblem p, SolveArgs<T> sa) {
-  // the candidates' merit values, reduced here one lane per candidate, and the staging the reduction reads through
-  __shared__ T merits[kProbeCandidates + kProbeStage * (kProbeCandidates + 1)];
+__global__ void __launch_bounds__(kProbeCandidates) ilq_probe_pick_kernel(DevProblem p, SolveArgs<T> sa) {
+  __shared__ T merits[kProbeCandidates];  // the candidates' merit values, reduced here one lane per candidate
   probe_pick_instance<T>(p, sa, sa.ids[blockIdx.x], blockIdx.x, merits);
 }
 
@@ -1053,7 +1052,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
         hipLaunchKernelGGL(k_prows, dim3(row_chunks, round_instances * probe_k),
                            dim3(64), lds_prows, stream, d, sa);
         HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(ilq_probe_pick_kernel<T>, dim3(round_instances), dim3(64), 0, stream, d, sa);
+        hipLaunchKernelGGL(ilq_probe_pick_kernel<T>, dim3(round_instances), dim3(kProbeCandidates), 0, stream, d, sa);
         HIP_TRY(hipGetLastError());
       }
       sa.round_count = round_instances;

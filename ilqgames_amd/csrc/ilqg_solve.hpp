@@ -422,7 +422,7 @@ __device__ __forceinline__ void rows_part_instance(const DevProblem& p, const sh
 constexpr int kProbeCandidates = 128;           // most step sizes probed per instance and round (a failing search walks
                                                 // through all max_backtracking_steps of them — 100 in the examples — and a
                                                 // round costs the latency of one rollout whatever it probes)
-constexpr int kProbeStage = 32;                 // partials per candidate the pick kernel stages at a time
+constexpr int kProbeStage = 16;                 // partials per candidate the pick kernel's loads run ahead of its additions
 constexpr int kProbeEntries = 32768;            // pool size: candidates of all listed instances of one round
 constexpr int kProbeRoundBudget = 8192;         // rollouts the first probing round of a tail may hold (doubling after): what
                                                 // the chip integrates at once, two per wavefront at four waves per SIMD
@@ -541,36 +541,39 @@ __device__ __forceinline__ void probe_pick_instance(const DevProblem& p, const S
   const T* const e0 = sa.probe_pool + size_t(slot) * sa.probe_k * E.total;
   if (merits) {
     // Candidate j's merit value = its per-row partials summed in merit_reduce's order, one lane per candidate (a serial
-    // chain either way).  The partials of one candidate are contiguous and the candidates' entries far apart, so a lane
-    // that walks its own entry issues one cache line per load and lane (measured: 69 us per probing round).  Instead
-    // the wave loads kProbeStage partials of every candidate at a time with contiguous half-wave reads, transposes them
-    // through LDS ([partial][candidate]: conflict-free for the summing lanes) and every lane adds its candidate's
-    // column in order.
-    T* const stage = merits + kProbeCandidates;  // [kProbeStage][kProbeCandidates + 1]
-    constexpr int LDJ = kProbeCandidates + 1;
+    // chain either way; the candidates' entries are far apart, so every load of a lane is a cache line of its own).  What
+    // it costs is the round trips, so the loads run a block of kProbeStage partials ahead of the additions.
+    // (Measured and dropped in round 5: transposing the partials through LDS with contiguous half-wave reads — the
+    // staging loop's own round trips made the kernel three times slower.)
     const int count = p.T * p.N * 2, skip = p.N * 2;  // the |l_i|^2 terms of k = 0 do not enter (:421)
-    const int lane = threadIdx.x, half = lane >> 5, hl = lane & 31;
-    static_assert(kProbeStage == 32 && kProbeCandidates == 128, "two candidates per lane, a half-wave per candidate row");
-    T acc[2] = {T(0), T(0)};
-    const T* const mp0 = e0 + E.mpart;
-    for (int c0 = 0; c0 < count; c0 += kProbeStage) {
-      for (int jj = half; jj < sa.probe_k; jj += 2) {
-        const int e = c0 + hl;
-        stage[hl * LDJ + jj] = e < count ? mp0[size_t(jj) * E.total + e] : T(0);
+    for (int j = threadIdx.x; j < sa.probe_k; j += blockDim.x) {
+      if (s.bt + j >= prm.max_backtracking_steps) continue;
+      const T* const mp = e0 + size_t(j) * E.total + E.mpart;
+      T merit = T(0);
+      int e = 0;
+      for (; e < skip && e < count; e++)
+        if ((e & 1) == 0) merit += mp[e];
+      T x[kProbeStage], y[kProbeStage];
+      if (e + kProbeStage <= count) {
+#pragma unroll
+        for (int u = 0; u < kProbeStage; u++) x[u] = mp[e + u];
       }
-      __syncthreads();
-#pragma unroll 4
-      for (int u = 0; u < kProbeStage; u++) {
-        const int e = c0 + u;
-        if (e >= count) break;
-        if (e < skip && (e & 1)) continue;  // wave-uniform
-        acc[0] += stage[u * LDJ + lane];
-        acc[1] += stage[u * LDJ + lane + 64];
+      for (; e + kProbeStage <= count; e += kProbeStage) {
+        const bool more = e + 2 * kProbeStage <= count;
+        if (more) {
+#pragma unroll
+          for (int u = 0; u < kProbeStage; u++) y[u] = mp[e + kProbeStage + u];
+        }
+#pragma unroll
+        for (int u = 0; u < kProbeStage; u++) merit += x[u];
+        if (more) {
+#pragma unroll
+          for (int u = 0; u < kProbeStage; u++) x[u] = y[u];
+        }
       }
-      __syncthreads();
+      for (; e < count; e++) merit += mp[e];
+      merits[j] = T(0.5) * merit;
     }
-    if (lane < sa.probe_k) merits[lane] = T(0.5) * acc[0];
-    if (lane + 64 < sa.probe_k) merits[lane + 64] = T(0.5) * acc[1];
     __syncthreads();
   }
   int tried = 0;
