@@ -746,8 +746,11 @@ void SetTimeout(int fd, int seconds) {
   ::setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
   ::setsockopt(fd, SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof(tv));
 }
-// What a rank says before rank 0 hands it the token: who it is and a word only this job's ranks can form (the job's
-// launcher exports the same MASTER_PORT / WORLD_SIZE — and, if set, ILQG_RENDEZVOUS_SECRET — to every rank).
+// What a rank says before rank 0 hands it the token: who it is and a word this job's ranks form (the job's launcher
+// exports the same MASTER_PORT / WORLD_SIZE — and, if set, ILQG_RENDEZVOUS_SECRET — to every rank).  Without the secret
+// the word is a function of port and world size only: it keeps ranks of DIFFERENT jobs apart (a stray connection is
+// turned away), it does not authenticate — anyone who can reach the port can compute it.  Set ILQG_RENDEZVOUS_SECRET
+// (any string, the same for all ranks) where the rendezvous port is reachable by others.
 struct Hello {
   uint32_t magic, rank;
   uint64_t nonce;
