@@ -2,7 +2,7 @@
 # The rocprofv3 evidence of a round, one pass per BASELINE config bench.py reports (run on the GPU box via gpurun):
 #   gpurun -- 'bash scripts/profile_all.sh r02'
 # leaves gpurun_out/profiles/<tag>_*.md; copy the ones to be judged into profiles/.
-TAG=${1:-r04}
+TAG=${1:-r05}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $ROOT/gpurun_out/profiles
 run() {  # name, bench args
