@@ -1215,6 +1215,18 @@ static ilqg_status generic_solve(ilqg_problem* p, int32_t batch, const void* x0,
   auto k_decide = ilq_decide_kernel<T, 0, 0, 0>;
   auto k_exit = ilq_exit_kernel<T, 0, 0, 0>;
   auto k_lq = gen_lq_kernel<T>;
+  // Back-tracking instances are listed and their next step sizes probed side by side, as in the specialised solve
+  // (DimsLaunch::solve): without it a single failing line search of 100 steps costs the whole batch 100 serial passes
+  // (round 5: mixed_dubins_car_scene, B = 1024: 76 passes per iteration, 42 k it/s).
+  auto k_proll = ilq_probe_roll_kernel<T, 0, 0, 0>;
+  auto k_prows = ilq_probe_rows_kernel<T, 0, 0, 0>;
+  const size_t lds_prows = rows_maps_bytes(d) + probe_rows_elems(d, 0, sa.rows_cw) * sizeof(T);
+  const WsTail tail = ws_tail(d, batch, sizeof(T), ol_row);
+  int* const pass_ids = reinterpret_cast<int*>(static_cast<char*>(workspace) + tail.ids_off);
+  T* const probe_pool = reinterpret_cast<T*>(static_cast<char*>(workspace) + tail.pool_off);
+  const bool probe = !opt.forced_steps && sa.prm.linesearch && opt.probe != ILQG_CHOICE_OFF;
+  raise_lds_limit((const void*)k_proll, lds_roll);
+  raise_lds_limit((const void*)k_prows, lds_prows);
   raise_lds_limit((const void*)k_roll, lds_roll);
   raise_lds_limit((const void*)k_rows, lds_rows);
   raise_lds_limit((const void*)k_decide, lds_decide);
@@ -1240,22 +1252,60 @@ static ilqg_status generic_solve(ilqg_problem* p, int32_t batch, const void* x0,
     HIP_TRY(hipMemsetAsync(il.count, 0, sizeof(int) * size_t(batch), stream));
   }
   sa.first = resume ? 2 : 1;
+  sa.ids = nullptr;
+  sa.ids_next = nullptr;
   int waiting_lq = 0, waiting_exit = 0;
+  int round_instances = batch, list = 0, tail_rounds = 0;
   for (long long round = 0;; round++) {
     HIP_TRY(hipMemsetAsync(p->d_unfinished, 0, 4 * sizeof(int), stream));
-    hipLaunchKernelGGL(k_roll, dim3(batch), dim3(64), lds_roll, stream, d, sa);
+    sa.ids_next = pass_ids + size_t(list) * batch;
+    if (sa.ids && probe) {
+      // step sizes probed per listed instance this round: what the pool holds for a list this long, ramping up over the
+      // rounds of a tail from a budget of kProbeRoundBudget rollouts (the rule of DimsLaunch::solve)
+      int probe_k = tail.pool_entries / round_instances;
+      if (probe_k > kProbeCandidates) probe_k = kProbeCandidates;
+      int first = opt.probe_first;
+      if (first <= 0) {
+        first = kProbeRoundBudget / round_instances;
+        first = first < 2 ? 2 : (first > kProbeCandidates ? kProbeCandidates : first);
+      }
+      long long ramp = (long long)first << (tail_rounds < 8 ? tail_rounds : 8);
+      if (ramp < 2) ramp = 2;
+      if (probe_k > ramp) probe_k = int(ramp);
+      tail_rounds++;
+      if (probe_k >= 2) {
+        sa.probe_pool = probe_pool;
+        sa.probe_k = probe_k;
+        hipLaunchKernelGGL(k_proll, dim3(round_instances, probe_k), dim3(64), lds_roll, stream, d, sa);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(k_prows, dim3(row_chunks, round_instances * probe_k), dim3(64), lds_prows, stream, d, sa);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(ilq_probe_pick_kernel<T>, dim3(round_instances), dim3(kProbeCandidates), 0, stream, d, sa);
+        HIP_TRY(hipGetLastError());
+      }
+    }
+    sa.round_count = round_instances;
+    hipLaunchKernelGGL(k_roll, dim3(round_instances), dim3(64), lds_roll, stream, d, sa);
     HIP_TRY(hipGetLastError());
     sa.first = 0;
-    hipLaunchKernelGGL(k_rows, dim3(row_chunks, batch), dim3(64), lds_rows, stream, d, sa);
+    hipLaunchKernelGGL(k_rows, dim3(row_chunks, round_instances), dim3(64), lds_rows, stream, d, sa);
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k_decide, dim3(batch), dim3(64), lds_decide, stream, d, sa);
+    hipLaunchKernelGGL(k_decide, dim3(round_instances), dim3(64), lds_decide, stream, d, sa);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(p->h_unfinished, p->d_unfinished, 4 * sizeof(int), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     waiting_lq += p->h_unfinished[0];
     waiting_exit += p->h_unfinished[1];
     if (round > cap) return fail(ILQG_ERR_HIP, "solve did not terminate within its iteration bound");
-    if (p->h_unfinished[3]) continue;  // some instances want another pass (initial quadraticisation, back-tracking)
+    if (p->h_unfinished[3]) {  // some instances want another pass (initial quadraticisation, back-tracking): they are listed
+      sa.ids = sa.ids_next;
+      round_instances = p->h_unfinished[3];
+      list ^= 1;
+      continue;
+    }
+    sa.ids = nullptr;
+    round_instances = batch;
+    tail_rounds = 0;
     int want_lq = waiting_lq, want_exit = waiting_exit, restarted = 0;
     waiting_lq = waiting_exit = 0;
     if (timed && want_lq) {  // the loop condition of src/ilq_solver.cpp:123-124 (see DimsLaunch::solve)

@@ -471,9 +471,12 @@ __device__ __forceinline__ void probe_roll_instance(const DevProblem& p, const S
   ra.alpha_scale = probe_step(sa, s, j);
   ra.xs = e + E.xs;
   ra.us = e + E.us;
-  rollout_instance<T, NX, NP * MU, (NX == 4 && NP == 2), (MU == 1), (NX == 3 && NP == 2 && MU == 1),
-                   (NX == 4 * NP && MU == 2 && NP <= 2), dims_use_plain_rk4(NX, NP, MU)>(p, ra, sm, int(threadIdx.x),
-                                                                                         nullptr, nullptr);
+  if constexpr (NX > 0)
+    rollout_instance<T, NX, NP * MU, (NX == 4 && NP == 2), (MU == 1), (NX == 3 && NP == 2 && MU == 1),
+                     (NX == 4 * NP && MU == 2 && NP <= 2), dims_use_plain_rk4(NX, NP, MU)>(p, ra, sm, int(threadIdx.x),
+                                                                                           nullptr, nullptr);
+  else
+    rollout_instance_rt<T>(p, ra, sm, int(threadIdx.x));  // the run-time-dimensioned path picks its integrator from the models
 }
 
 // Two candidates of one instance per wavefront (rollout_pair): j0 and j0 + 1 share the staged gains and references.

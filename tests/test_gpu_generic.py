@@ -252,3 +252,23 @@ def test_augmented_lagrangian_solve_of_a_mixed_dimension_game_matches_oracle(hip
         assert _np(out["iters"])[b] == ref["iters"][b] and _np(out["status"])[b] == ref["status"][b], b
         assert rel_err(_np(out["xs"])[b], ref["xs"][b]) < 1e-6, b
         np.testing.assert_allclose(_np(out["costs"])[b], ref["costs"][b], rtol=1e-6)
+
+
+@pytest.mark.parametrize("cfg", ["mixed_dubins_car_scene", "three_unicycle_scene", "mixed_dubins_car_scene_open_loop"])
+def test_speculative_line_search_on_the_run_time_dimensioned_path_changes_nothing(hip, cfg):
+    """The run-time-dimensioned solve lists its back-tracking instances and probes their next step sizes side by side
+    (round 5: a failing 100-step line search of one instance used to cost the whole batch 100 serial passes).  Same
+    arithmetic, same decisions: free-running and fixed-iteration solves come back bit for bit as without probing."""
+    import torch
+    spec = examples.CONFIGS[cfg]()
+    x0 = examples.jittered_x0(spec, 96, seed=0)
+    for kw in (dict(), dict(fixed_iters=5)):
+        a = hip.Problem(spec, abi.F64).solve(x0, probe=False, **kw)
+        b = hip.Problem(spec, abi.F64).solve(x0, probe=True, **kw)
+        torch.cuda.synchronize()
+        for k in ("iters", "status", "converged", "xs", "us", "P", "alpha", "costs"):
+            assert torch.equal(a[k], b[k]), (cfg, kw, k)
+    prob = hip.Problem(spec, abi.F64)
+    prob.solve(x0[:4], fixed_iters=1)
+    torch.cuda.synchronize()
+    assert prob.last_schedule() & abi.SCHEDULE_GENERIC  # the scene really runs on the run-time-dimensioned kernels
