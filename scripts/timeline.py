@@ -86,4 +86,4 @@ order = np.argsort(tl[:, 16])
 q = B // 4
 print("  loop us by launch order quartile:", " ".join("%.0f" % np.mean(loop[order[i * q:(i + 1) * q]]) for i in range(4)))
 print("  loop us by block index quartile:", " ".join("%.0f" % np.mean(loop[i * q:(i + 1) * q]) for i in range(4)))
-np.save(os.path.join(R, "gpurun_out", "r3c", "tl_raw.npy"), prof.cpu().numpy())
+os.makedirs(os.path.join(R, "gpurun_out", "tl"), exist_ok=True); np.save(os.path.join(R, "gpurun_out", "tl", "tl_raw.npy"), prof.cpu().numpy())
