@@ -320,10 +320,15 @@ struct TrialWaves {
 };
 
 // Trial kernel: rollout + linearise/quadraticise + line-search decision (ilqg_solve.hpp).  The second
-// launch-bound argument is the number of waves per SIMD the register allocation must allow (fp32: three, i.e. 168
-// registers — six instances per CU at large batches; the fp32 kernel sits within a few registers of that either way).
+// launch-bound argument is the number of waves per SIMD the register allocation must allow.  fp32 was compiled for
+// three (168 registers: six instances per CU) until round 5; since the large batches of the one-tile shapes run the
+// split pass, the fused kernel serves four instances per CU at most there, and the full register file is worth 1.6 %
+// at the headline batch in fp32 (2.105 -> 2.140 M it/s).  -DILQG_TRIAL_OCCUPANCY_F32=3 restores the old build.
+#ifndef ILQG_TRIAL_OCCUPANCY_F32
+#define ILQG_TRIAL_OCCUPANCY_F32 2
+#endif
 template <typename T, int NX, int NP, int MU, int W>
-__global__ void __launch_bounds__(64 * W, (sizeof(T) == 4 && W == 2) ? 3 : W) ilq_trial_kernel(DevProblem p, SolveArgs<T> sa) {
+__global__ void __launch_bounds__(64 * W, (sizeof(T) == 4 && W == 2) ? ILQG_TRIAL_OCCUPANCY_F32 : W) ilq_trial_kernel(DevProblem p, SolveArgs<T> sa) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int b = blockIdx.x;
   if (!sa.first) {  // instances that are done (or waiting for the LQ kernel) leave without touching LDS
