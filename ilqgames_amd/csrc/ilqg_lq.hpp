@@ -968,6 +968,7 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
   };
   T* sPt = sm + W::oPt;
   T* sAl = sm + W::oAl;
+  const T* const sAlr = SPARE ? sm + W::oPt + LD * JB : sAl;  // where alpha is read from (SPARE: column JB of the [P | alpha] tile)
   T* sYz = sm + W::oYz;
   T* sSY = sm + W::oSY;
   T* sBw = sm + W::oVec + w * 16;         // this player's beta, entries NX..15 zero
@@ -1338,14 +1339,21 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
       else
         qr_solve_columns<T, M>(col, lane, x);
       ILQG_PH(11);
-      if (lane >= M && lane < M + NX) {
+      if constexpr (SPARE) {
+        // [P | alpha] in one piece: column lane - M of the tile, alpha in column NX = JB (F = A - B [P | alpha] then
+        // carries beta = -B alpha); alpha is read from there too (sAlr) — one divergent region and M stores less on the
+        // solving wave's way to the barrier
+        if (lane >= M && lane <= M + NX) {
 #pragma unroll
-        for (int r = 0; r < M; r++) sPt[r + LD * (lane - M)] = x[r];
-      } else if (lane == M + NX) {
+          for (int r = 0; r < M; r++) sPt[r + LD * (lane - M)] = x[r];
+        }
+      } else {
+        if (lane >= M && lane < M + NX) {
 #pragma unroll
-        for (int r = 0; r < M; r++) {
-          sAl[r] = x[r];
-          if constexpr (SPARE) sPt[r + LD * JB] = x[r];  // [P | alpha]: F = A - B [P | alpha] then carries beta = -B alpha
+          for (int r = 0; r < M; r++) sPt[r + LD * (lane - M)] = x[r];
+        } else if (lane == M + NX) {
+#pragma unroll
+          for (int r = 0; r < M; r++) sAl[r] = x[r];
         }
       }
     }
@@ -1365,7 +1373,7 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
 #pragma unroll
         for (int r = 0; r < M; r++) dst[r] = pv[r];
       } else if (lane < NX + M) {
-        ((gT*)(uniform_ptr(a.alpha + size_t(k) * M)))[unsigned(lane - NX)] = sAl[lane - NX];
+        ((gT*)(uniform_ptr(a.alpha + size_t(k) * M)))[unsigned(lane - NX)] = sAlr[lane - NX];
       }
     }
 
@@ -1423,7 +1431,7 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
         for (int c = 0; c < MU; c++) {
           T aR = T(0);
 #pragma unroll
-          for (int b = 0; b < MU; b++) aR += sAl[lane * MU + b] * sR[ro_ii + b + MU * c];
+          for (int b = 0; b < MU; b++) aR += sAlr[lane * MU + b] * sR[ro_ii + b + MU * c];
           acc += aR * sr[rg_ii + c];
         }
         a.scratch[size_t(k) * SCR + NP * NX + lane] = acc;
@@ -1470,7 +1478,7 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
             }
         T ww = -sr[rg_wj + aa];
 #pragma unroll
-        for (int b = 0; b < MU; b++) ww += sR[ro_wj + aa + MU * b] * sAl[jj * MU + b];
+        for (int b = 0; b < MU; b++) ww += sR[ro_wj + aa + MU * b] * sAlr[jj * MU + b];
         Qy[r] = (in && qw >= 0) ? ww * mVecCol : T(0);
         const int srow = row < NX ? row : 0;
         Cd[r] += (row < NX ? sl[w * NX + srow] : T(0)) * mVecCol;
@@ -1634,7 +1642,7 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_pw(const LQArgs<T>& a,
         for (int aa = 0; aa < MU; aa++) {
           T ww = T(0);
 #pragma unroll
-          for (int b = 0; b < MU; b++) ww += Rij[aa + MU * b] * sAl[jj * MU + b];
+          for (int b = 0; b < MU; b++) ww += Rij[aa + MU * b] * sAlr[jj * MU + b];
           add += sPt[(jj * MU + aa) + LD * lane] * (ww - rij[aa]);
         }
         zn += add;

@@ -112,7 +112,7 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_1w(const LQArgs<T>& a,
   T* const sR = sm + W::oVR;
   T* const sr = sm + W::oVr;
   T* const sPt = sm + W::oPt;
-  T* const sAl = sm + W::oAl;
+  const T* const sAl = sm + W::oPt + LD * JB;  // alpha: column JB of the [P | alpha] tile
   T* const sYz = sm + W::oYz;
   T* const sSY = sm + W::oSY;
   T* const sG0 = sm + W::oG;
@@ -324,15 +324,11 @@ __device__ __forceinline__ void lq_feedback_instance_mfma_1w(const LQArgs<T>& a,
         lu_solve_columns<T, M>(col, lane, x);
       else
         qr_solve_columns<T, M>(col, lane, x);
-      if (lane >= M && lane < M + NX) {
+      // [P | alpha] in one piece: column lane - M of the tile, alpha in column NX = JB (F = A - B [P | alpha] then carries
+      // beta = -B alpha); alpha is read from there too (sAl below)
+      if (lane >= M && lane <= M + NX) {
 #pragma unroll
         for (int r = 0; r < M; r++) sPt[r + LD * (lane - M)] = x[r];
-      } else if (lane == M + NX) {
-#pragma unroll
-        for (int r = 0; r < M; r++) {
-          sAl[r] = x[r];
-          sPt[r + LD * JB] = x[r];  // [P | alpha]: F = A - B [P | alpha] then carries beta = -B alpha
-        }
       }
     }
     lds_sync(true);
