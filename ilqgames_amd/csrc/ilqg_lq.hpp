@@ -830,7 +830,14 @@ __device__ __forceinline__ void lq_feedback_instance(const LQArgs<T>& a, const P
 // and the last link are per player and independent of each other, so each wave keeps ITS Z_i / Z_i^T
 // in registers and produces its MU rows of [S | Y] and its own Z_i', zeta_i'.  Only the small solve is
 // serial (wave 0, column per lane).  Three workgroup barriers per step: [S|Y] complete,
-// (P, alpha) published, image swap.
+// (P, alpha) published, image swap (two with compact rows).
+//
+// Round 5: an fp64 matrix instruction holds the SIMD's vector pipe for 64 cycles and the LDS executes
+// one instruction per ~3-4 cycles per CU, so with three waves per SIMD the sweep was bound by the instructions it
+// issues.  Everything that is a matrix-VECTOR product or has two useful rows — the player's columns of G = Z_w^T B,
+// its rows of [S | Y], Q_w l_w, for n = 16 also Z_w beta and F^T t — is a row sum over the accumulator-layout registers
+// (v_permlane32_swap / v_permlane16_swap reductions, ilqg_mfma.hpp) instead of a tile product or an LDS gather; the
+// matrix cores keep F (2), the C terms (2), Z_w F (4) and F^T W (4).
 //
 // Staging: A, B and every Q_i are DMA'd (global_load_lds with a per-lane gather address) straight into
 // zero-padded 16 x 16 LDS tiles, so every accumulator-layout operand is read with one per-lane base
