@@ -860,7 +860,10 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   }
   const bool big_batch = size_t(batch) >= size_t(8) * num_cus;
   // the whole batch resident at once (four instances per CU): fair issue arbitration among the co-resident instances
-  sa.prio_div = (batch > num_cus && batch <= 4 * num_cus) ? num_cus : 0;
+#ifndef ILQG_PRIO_ROTATION
+#define ILQG_PRIO_ROTATION 1
+#endif
+  sa.prio_div = (ILQG_PRIO_ROTATION && batch > num_cus && batch <= 4 * num_cus) ? num_cus : 0;
   // ... and wherever the single-wave sweep (below) will run: it takes its expected decrease from its own adjoint pass, so
   // nothing is left for the fused kernel's row wave to overlap with the rollout, and the three split kernels each keep
   // more instances on a CU than the fused one (measured, n = 14, B = 8192, LQ single-wave + adjoint: fp64 1.58 M it/s

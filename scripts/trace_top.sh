@@ -1,3 +1,4 @@
+# Top kernels of one bench.py configuration under rocprofv3 --kernel-trace --stats (GPU box): bash scripts/trace_top.sh "--dtype f32"
 # usage: trace.sh "<bench args>"  -> prints top kernels
 cd $GRAFT_REPO_ROOT; ROOT=$GRAFT_REPO_ROOT
 rm -rf gpurun_out/prof_t; mkdir -p gpurun_out/prof_t
