@@ -347,12 +347,15 @@ __device__ __forceinline__ void lq_forward_pass_wave(const LQArgs<T>& a, T* sm, 
   constexpr int SQ = (SCR + 63) / 64;          // ... of which the scratch row's, when A comes from compact rows
   const int Tn = a.T_steps;
   T* sX = sm + 2 * G * FSLOT;                  // delta_x, two buffers of NX
-  const T* gA = uniform_ptr(a.A);
-  const T* gS = uniform_ptr(a.scratch);
+  // explicit global address space: through generic pointers the prefetch loads below are FLAT loads, which count on the
+  // LDS counter too — every wait for a step's LDS operands then also waited for the group being prefetched
+  typedef const __attribute__((address_space(1))) T gcT;
+  const gcT* gA = (const gcT*)uniform_ptr(a.A);
+  const gcT* gS = (const gcT*)uniform_ptr(a.scratch);
   // Compact rows (LQArgs::compact): A_k is a constant background — written into every staging slot once — plus the
   // Jacobian pass's words of the step's compact row (lane = word; the words that belong to B are skipped).
   constexpr bool cmp = CMP;
-  const T* gC = uniform_ptr(a.compact);
+  const gcT* gC = (const gcT*)uniform_ptr(a.compact);
   const int CWD = cmp ? a.compact_tab[RC_W] : 0;
   int nJ = 0, cbase = 0, cdstA = -1;
   if (cmp) {
@@ -391,7 +394,7 @@ __device__ __forceinline__ void lq_forward_pass_wave(const LQArgs<T>& a, T* sm, 
         for (int q = 0; q < PER; q++) {
           const int e = q * 64 + t;
           const bool inA = e < NX * NX;
-          const T* src = inA ? gA + (size_t(k) * NX * NX + e) : gS + (size_t(k) * SCR + (e - NX * NX));
+          const gcT* src = inA ? gA + (size_t(k) * NX * NX + e) : gS + (size_t(k) * SCR + (e - NX * NX));
           pre[s][q] = (k < Tn && e < ROW) ? *src : T(0);
         }
       }
