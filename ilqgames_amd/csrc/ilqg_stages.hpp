@@ -133,8 +133,9 @@ __device__ __forceinline__ void rollout_instance(const DevProblem& p, const Roll
       }
     }
     lds_sync(NT <= 64);
-    if (k + 1 < Tn) issue(k + 1, (k + 1) & 1);  // into the block step k - 1 read: a whole step to land
     ILQG_RPH(0);
+    // (Measured and dropped, round 5: four lanes per control, each a quarter of the dot product, DPP quad sums —
+    // -0.3 % on the headline: the chain is not what this phase costs.)
     if (t < m) {
       T s = T(0);
       if constexpr (CN > 0) {
@@ -163,6 +164,10 @@ __device__ __forceinline__ void rollout_instance(const DevProblem& p, const Roll
     }
     lds_sync(NT <= 64);
     ILQG_RPH(1);
+    // the next block's DMA (into the block step k - 1 read) is requested here, behind the controls — it still has most of
+    // a step to land, and its dozen address / M0 instructions are off the chain publish -> u -> integrate (round 5:
+    // +0.7 % on the headline; it used to follow the publication barrier)
+    if (k + 1 < Tn) issue(k + 1, (k + 1) & 1);
     if (t < 64 && k + 1 < Tn) {  // whole first wave: the exchanges inside need every group lane live
       const T u0 = integ ? su[uo] : T(0), u1 = integ ? su[uo + 1] : T(0);
       if constexpr (GEN) {
@@ -293,7 +298,6 @@ __device__ __forceinline__ void rollout_pair(const DevProblem& p, const RolloutA
       }
     }
     lds_sync(true);
-    if (k + 1 < Tn) issue(k + 1, (k + 1) & 1);
     if (tl < m) {
       T s = T(0);
       constexpr int CH = 8;
@@ -315,6 +319,7 @@ __device__ __forceinline__ void rollout_pair(const DevProblem& p, const RolloutA
       if (act) us_out[size_t(k) * m + tl] = u;
     }
     lds_sync(true);
+    if (k + 1 < Tn) issue(k + 1, (k + 1) & 1);  // behind the controls, as in rollout_instance
     if (k + 1 < Tn) {  // the whole wave: the exchanges inside need every group lane live
       const T u0 = integ ? su[uo] : T(0), u1 = integ ? su[uo + 1] : T(0);
       sub_integrate_stages<T, false, DUB>(kind, Lp, p.dt, xj, u0, u1, q, t, gth, any_car, T(0), T(0),
