@@ -535,10 +535,36 @@ __device__ __forceinline__ void lq_openloop_instance(const LQArgs<T>& a, const P
     // Every wave has left step k + 1 behind: the images of the other parity (last read there) are free for the next
     // step's A, [B | R | r].  The loads are waited for in front of barrier 2, which publishes them to the other waves.
     if constexpr (CMP) {
-      if (k > 0) scatter_shared(k - 1);  // staged a step ago (or before the loop), published by barrier 2 there
-      if (k > 1) crow_dma(k - 2);        // into row k's staging row: its last word was placed at the end of step k + 1
+      if constexpr (NP > 1) {
+        // by the waves that wait through the elimination: the solving wave goes straight to its columns
+        if (w != 0) {
+          if (k > 0) {  // staged a step ago (or before the loop), published by barrier 2 there
+            const T* row = sSB + ((k - 1) & 1) * kCompactMaxWords;
+            for (int c = t - 64; c < CWD; c += NT - 64) {
+              const int code = sCD[c], sp = code >> 16, off = code & 0xffff;
+              const T v = row[c];
+              if (sp == 0) aimg((k - 1) & 1)[off] = v;
+              if (sp == 1) bimg((k - 1) & 1)[off] = v;
+            }
+          }
+          if (k > 1)  // into row k's staging row: its last word was placed at the end of step k + 1
+            dma_g2l<64 * (NP - 1), false>(a.compact + size_t(k - 2) * CWD, sSB + ((k - 2) & 1) * kCompactMaxWords, CWD * S,
+                                          (wp - 1) * 64 + lane);
+        }
+      } else {
+        if (k > 0) scatter_shared(k - 1);
+        if (k > 1) crow_dma(k - 2);
+      }
     } else {
       if (k > 0) issue_shared(k - 1);
+    }
+    // [V | g | R_ii r_ii] -> scratch row k (forward pass): by the last wave, which waits through the elimination anyway
+    // (it was the solving wave's job until round 5: four LDS-read / store trips at the head of the step's longest chain)
+    if (w == (NP > 1 ? NP - 1 : 0)) {
+      static_assert(O::og == O::oV + M * NX && O::oRr == O::og + M && O::rg == O::rV + M * NX && O::rRr == O::rg + M,
+                    "[V | g | R r] is copied to the scratch row in one piece");
+      T* row = row_of(k);
+      for (int e = lane; e < M * NX + 2 * M; e += 64) row[O::rV + e] = sV[e];
     }
     // ---- K [Z | z] = [V A | g] (wave 0, column per lane) ----
     if (w == 0) {
@@ -547,12 +573,6 @@ __device__ __forceinline__ void lq_openloop_instance(const LQArgs<T>& a, const P
       for (int q = 0; q < M; q++) {
         col[q] = lane < M + NX ? sKA[q + M * (lane < M + NX ? lane : 0)] : (lane == M + NX ? sg[q] : T(0));
         x[q] = T(0);
-      }
-      {  // [V | g | R_ii r_ii] -> scratch row k (forward pass)
-        static_assert(O::og == O::oV + M * NX && O::oRr == O::og + M && O::rg == O::rV + M * NX && O::rRr == O::rg + M,
-                      "[V | g | R r] is copied to the scratch row in one piece");
-        T* row = row_of(k);
-        for (int e = lane; e < M * NX + 2 * M; e += 64) row[O::rV + e] = sV[e];
       }
       {
         // Partial pivoting never exchanges rows of a matrix whose columns are strictly diagonally dominant (elimination
