@@ -532,15 +532,19 @@ __device__ __forceinline__ void lq_openloop_instance(const LQArgs<T>& a, const P
     }
     lds_sync(NT <= 64);  // barrier 1: [K | V A], g complete
     PH(0);
+    // (Rotating the solving wave over the players, so that the elimination's vector instructions load the four SIMDs
+    // evenly, was measured in round 5: no difference — the sweep is not bound by the solving wave's SIMD.)
+    const int rel = wp;  // 0: solves this step; 1 .. NP-1: helpers
     // Every wave has left step k + 1 behind: the images of the other parity (last read there) are free for the next
     // step's A, [B | R | r].  The loads are waited for in front of barrier 2, which publishes them to the other waves.
     if constexpr (CMP) {
       if constexpr (NP > 1) {
         // by the waves that wait through the elimination: the solving wave goes straight to its columns
-        if (w != 0) {
+        if (rel != 0) {
+          const int ht = (rel - 1) * 64 + lane;  // thread index among the helpers
           if (k > 0) {  // staged a step ago (or before the loop), published by barrier 2 there
             const T* row = sSB + ((k - 1) & 1) * kCompactMaxWords;
-            for (int c = t - 64; c < CWD; c += NT - 64) {
+            for (int c = ht; c < CWD; c += NT - 64) {
               const int code = sCD[c], sp = code >> 16, off = code & 0xffff;
               const T v = row[c];
               if (sp == 0) aimg((k - 1) & 1)[off] = v;
@@ -549,7 +553,7 @@ __device__ __forceinline__ void lq_openloop_instance(const LQArgs<T>& a, const P
           }
           if (k > 1)  // into row k's staging row: its last word was placed at the end of step k + 1
             dma_g2l<64 * (NP - 1), false>(a.compact + size_t(k - 2) * CWD, sSB + ((k - 2) & 1) * kCompactMaxWords, CWD * S,
-                                          (wp - 1) * 64 + lane);
+                                          ht);
         }
       } else {
         if (k > 0) scatter_shared(k - 1);
@@ -560,14 +564,14 @@ __device__ __forceinline__ void lq_openloop_instance(const LQArgs<T>& a, const P
     }
     // [V | g | R_ii r_ii] -> scratch row k (forward pass): by the last wave, which waits through the elimination anyway
     // (it was the solving wave's job until round 5: four LDS-read / store trips at the head of the step's longest chain)
-    if (w == (NP > 1 ? NP - 1 : 0)) {
+    if (rel == NP - 1) {
       static_assert(O::og == O::oV + M * NX && O::oRr == O::og + M && O::rg == O::rV + M * NX && O::rRr == O::rg + M,
                     "[V | g | R r] is copied to the scratch row in one piece");
       T* row = row_of(k);
       for (int e = lane; e < M * NX + 2 * M; e += 64) row[O::rV + e] = sV[e];
     }
-    // ---- K [Z | z] = [V A | g] (wave 0, column per lane) ----
-    if (w == 0) {
+    // ---- K [Z | z] = [V A | g] (the step's solving wave, column per lane) ----
+    if (rel == 0) {
       T col[M], x[M];
 #pragma unroll
       for (int q = 0; q < M; q++) {
@@ -703,6 +707,119 @@ __device__ __forceinline__ void lq_openloop_instance(const LQArgs<T>& a, const P
   for (int e = t; e < M * NX; e += NT)
     for (int k = 0; k < Tn; k++) a.P[size_t(k) * M * NX + e] = T(0);  // open loop: P stays zero
   __syncthreads();  // scratch rows were written by other waves
+  // ---- forward pass, two stages (round 5; the one-wave step-by-step pass below stays for costates and for horizons whose
+  // state history does not fit the LDS).  The only sequential part is x_{k+1} = X_k x_k + y_k: stage 1 runs it alone (wave
+  // 0: the 2 x 32 lanes split each row's terms in two, X_k | y_k prefetched kFwdDepth steps ahead from the scratch rows
+  // into registers, x_k handed on through the LDS history) — about 300 cycles per step instead of the 6000 of the pass
+  // that also formed alpha, the expected decrease and the stores inside the chain.  Stage 2 is parallel over the steps
+  // and runs on all waves: alpha_k = V_k x_{k+1} + g_k, the expected-decrease terms, the stores.
+  constexpr int kFwdDepth = 4;
+  constexpr int FCH = (NX + 1) / 2;
+  T* const xh = sm;  // x_k, k = 0 .. T-1 (overlays the backward working set)
+  const int red_off = (Tn * NX + 3) & ~3;
+  if (!a.costates && red_off + NP <= O::LDS_ELEMS && NX <= 32) {
+    if (w == 0) {
+      const int h = lane >> 5, i = lane & 31, ii = i < NX ? i : 0, c0 = h * FCH;
+      if (lane < NX) xh[lane] = a.x0 ? a.x0[lane] : T(0);
+      T xb[kFwdDepth][FCH], yb[kFwdDepth];
+      auto fetch = [&](int k, T (&xs_)[FCH], T& y_) {
+        const T* row = row_of(k);
+#pragma unroll
+        for (int c = 0; c < FCH; c++) {
+          const int cc = c0 + c;
+          const T v = row[O::rX + ii + NX * (cc < NX ? cc : 0)];
+          xs_[c] = cc < NX ? v : T(0);
+        }
+        const T yv = row[O::ry + ii];
+        y_ = h == 0 ? yv : T(0);
+      };
+#pragma unroll
+      for (int d = 0; d < kFwdDepth; d++)
+        if (d < Tn - 1) fetch(d, xb[d], yb[d]);
+      lds_sync(true);
+#pragma unroll 1
+      for (int kb = 0; kb < Tn - 1; kb += kFwdDepth) {
+#pragma unroll
+        for (int d = 0; d < kFwdDepth; d++) {
+          const int k = kb + d;
+          if (k < Tn - 1) {
+            const T* xk = xh + k * NX;
+            T s0 = yb[d], s1 = T(0);
+#pragma unroll
+            for (int c = 0; c < FCH; c++) {
+              const int cc = c0 + c;
+              const T xv = xk[cc < NX ? cc : 0];
+              if (c & 1)
+                s1 += xb[d][c] * xv;
+              else
+                s0 += xb[d][c] * xv;
+            }
+            const T sh = s0 + s1;
+            T lo_, hi_;
+            permlane32_swap(sh, sh, lo_, hi_);  // [rows 0 1 | rows 0 1], [rows 2 3 | rows 2 3]
+            if (lane < NX) xh[(k + 1) * NX + lane] = lo_ + hi_;
+            if (k + kFwdDepth < Tn - 1) fetch(k + kFwdDepth, xb[d], yb[d]);
+            lds_sync(true);
+          }
+        }
+      }
+    }
+    __syncthreads();  // the state history is complete
+    T edp = T(0);
+    constexpr int SL = NT / M;  // steps per pass of the workgroup
+    const int ks = t / M, q = t % M;
+    if (ks < SL) {
+#pragma unroll 1
+      for (int k = ks; k < Tn - 1; k += SL) {
+        const T* row = row_of(k);
+        const T* xn = xh + (k + 1) * NX;
+        const T* xk = xh + k * NX;
+        T s0 = row[O::rg + q], s1 = T(0);
+#pragma unroll
+        for (int c = 0; c < NX; c++) {
+          if (c & 1)
+            s1 += row[O::rV + q + M * c] * xn[c];
+          else
+            s0 += row[O::rV + q + M * c] * xn[c];
+        }
+        const T al = s0 + s1;
+        a.alpha[size_t(k) * M + q] = al;
+        if (a.ed_out) {  // ILQSolver::ExpectedDecrease (ilq_solver.cpp:364-398): this lane's share of the step's terms
+          T e = al * row[O::rRr + q];  // alpha_i^T (R_ii r_ii), (:384-386)
+          if (k > 0) {
+#pragma unroll
+            for (int it = 0; it < (NP * NX + M - 1) / M; it++) {  // delta_x^T Q_i l_i (:392)
+              const int c = q + M * it;
+              if (c < NP * NX) e += xk[c % NX] * row[O::rql + c];
+            }
+          }
+          edp -= e;
+        }
+        if (a.dx) {
+          for (int c = q; c < NX; c += M) a.dx[size_t(k) * NX + c] = xk[c];
+        }
+      }
+    }
+    // step T-1 (:188-192): alpha = 0, the state term delta_x^T Q l
+    const T* xl = xh + (Tn - 1) * NX;
+    if (t < M) a.alpha[size_t(Tn - 1) * M + t] = T(0);
+    if (a.dx && t < NX) a.dx[size_t(Tn - 1) * NX + t] = xl[t];
+    if (a.ed_out) {
+      if (Tn > 1 && t < NP * NX) edp -= xl[t % NX] * row_of(Tn - 1)[O::rql + t];
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) edp += __shfl_xor(edp, off, 64);
+      T* const red = sm + red_off;
+      if (lane == 0) red[w] = edp;
+      __syncthreads();
+      if (t == 0) {
+        T tot = T(0);
+#pragma unroll
+        for (int e = 0; e < NP; e++) tot += red[e];
+        *a.ed_out = tot;
+      }
+    }
+    return;
+  }
   if (w != 0) return;
   constexpr int ROW = O::ROW;
   T* const sx = sm + O::fx;    // x_k
