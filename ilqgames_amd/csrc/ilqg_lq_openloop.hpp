@@ -185,9 +185,10 @@ constexpr int kd_mask(int KD, int c) {
 // a.scratch must hold T_steps rows of OLCfg::ROW elements (ROW_FAT when a.costates).  a.P is written as zero (:96-102).
 // Executed by a workgroup of OLCfg::NT threads (one wave per player).
 // CMP: the step's [A | B | Q_i | l_i | R | r] come from compact rows (LQArgs::compact, ilqg_common.hpp) instead of the
-// dense arrays: the row of step k - 2 is DMA'd into a staging row during step k; behind barrier 1 of step k - 1 all
-// waves scatter its shared words (A, B, R, r) into the images of that parity — whose constants were written once —
-// and at the end of step k - 1 every player wave clears its tile and scatters its own Q_i | l_i words into it.
+// dense arrays: the row of step k - 2 is DMA'd into a staging row behind barrier 2 of step k; behind barrier 1 of step
+// k - 1 the waves that wait for the elimination scatter its shared words (A, B, R, r) into the images of that parity —
+// whose constants were written once — and behind barrier 1 of step k - 2 they clear the players' tiles and scatter the
+// Q_i | l_i words into them.
 template <typename T, int NX, int NP, int MU, bool CMP = false>
 __device__ __forceinline__ void lq_openloop_instance(const LQArgs<T>& a, const PairTable& pt, T* sm) {
   using C = LQCfg<T, NX, NP, MU>;
@@ -306,16 +307,19 @@ __device__ __forceinline__ void lq_openloop_instance(const LQArgs<T>& a, const P
       if (sp == 1) bimg(k & 1)[off] = v;
     }
   };
-  // this wave's tile <- Qa_i of staged row k: cleared, its constants, its words
-  auto fill_tile = [&](int k) {
-    for (int e = lane; e < MAT; e += 64) sZ[e] = T(0);
+  // tiles lo .. hi <- Qa_i of staged row k: cleared, their constants, their words (one wave)
+  auto fill_tiles = [&](int k, int lo, int hi) {
+    T* const z0 = sm + O::oZ + lo * MAT;
+    for (int e = lane; e < (hi - lo + 1) * MAT; e += 64) z0[e] = T(0);
     lds_sync(true);
-    for (int e = lane; e < nbg_tile; e += 64)
-      if ((sBGc[e] >> 16) == 2 + wp) sZ[sBGc[e] & 0xffff] = sBGv[e];
+    for (int e = lane; e < nbg_tile; e += 64) {
+      const int code = sBGc[e], sp = (code >> 16) - 2;
+      if (sp >= lo && sp <= hi) sm[O::oZ + sp * MAT + (code & 0xffff)] = sBGv[e];
+    }
     const T* row = sSB + (k & 1) * kCompactMaxWords;
     for (int c = lane; c < CWD; c += 64) {
-      const int code = sCD[c];
-      if ((code >> 16) == 2 + wp) sZ[code & 0xffff] = row[c];
+      const int code = sCD[c], sp = (code >> 16) - 2;
+      if (sp >= lo && sp <= hi) sm[O::oZ + sp * MAT + (code & 0xffff)] = row[c];
     }
   };
 
@@ -380,7 +384,7 @@ __device__ __forceinline__ void lq_openloop_instance(const LQArgs<T>& a, const P
     if (Tn >= 2) crow_dma(Tn - 2);
     dma_wait();
     lds_sync(false);
-    fill_tile(Tn - 1);
+    fill_tiles(Tn - 1, wp, wp);
     if (Tn >= 2) scatter_shared(Tn - 2);
     lds_sync(false);
     if (Tn >= 3) crow_dma(Tn - 3);  // into row T-1's staging row, whose words have all been placed
@@ -445,11 +449,8 @@ __device__ __forceinline__ void lq_openloop_instance(const LQArgs<T>& a, const P
   if (a.costates) store_row_from_tile(Tn - 1, false);  // M[T-1] = Q[T-1]: the tile holds both
   lds_sync(true);
   lds_drain();  // the tile has been read: the DMA engine may refill it
-  if (Tn >= 2) {
-    if constexpr (CMP)
-      fill_tile(Tn - 2);
-    else
-      issue_Q(Tn - 2);
+  if constexpr (!CMP) {
+    if (Tn >= 2) issue_Q(Tn - 2);
   }
 #pragma unroll 1
   for (int k = Tn - 2; k >= 0; k--) {
@@ -530,19 +531,24 @@ __device__ __forceinline__ void lq_openloop_instance(const LQArgs<T>& a, const P
         sKA[q + M * c] = s;
       }
     }
+    if constexpr (CMP) dma_wait();  // this wave's pieces of compact row k - 1 (requested behind barrier 2 of step k + 1)
     lds_sync(NT <= 64);  // barrier 1: [K | V A], g complete
     PH(0);
     // (Rotating the solving wave over the players, so that the elimination's vector instructions load the four SIMDs
     // evenly, was measured in round 5: no difference — the sweep is not bound by the solving wave's SIMD.)
     const int rel = wp;  // 0: solves this step; 1 .. NP-1: helpers
     // Every wave has left step k + 1 behind: the images of the other parity (last read there) are free for the next
-    // step's A, [B | R | r].  The loads are waited for in front of barrier 2, which publishes them to the other waves.
+    // step's A, [B | R | r], and every tile has been read back transposed: free for Qa_i of this step.
     if constexpr (CMP) {
+      // By the waves that wait through the elimination (the solving wave goes straight to its columns): the shared words
+      // of row k - 1 (staged during step k + 1, waited for in front of barrier 1) into the images, and the tiles' words of
+      // row k — wave 1 fills the solving wave's tile too.  (Until round 5 every wave filled its own tile at the end of
+      // the previous step, on the way to barrier 1; here it costs the instance nothing.)  Row k - 2 goes into row k's
+      // staging row behind barrier 2, when the tiles' words have been taken out of it.
       if constexpr (NP > 1) {
-        // by the waves that wait through the elimination: the solving wave goes straight to its columns
         if (rel != 0) {
           const int ht = (rel - 1) * 64 + lane;  // thread index among the helpers
-          if (k > 0) {  // staged a step ago (or before the loop), published by barrier 2 there
+          if (k > 0) {
             const T* row = sSB + ((k - 1) & 1) * kCompactMaxWords;
             for (int c = ht; c < CWD; c += NT - 64) {
               const int code = sCD[c], sp = code >> 16, off = code & 0xffff;
@@ -551,13 +557,11 @@ __device__ __forceinline__ void lq_openloop_instance(const LQArgs<T>& a, const P
               if (sp == 1) bimg((k - 1) & 1)[off] = v;
             }
           }
-          if (k > 1)  // into row k's staging row: its last word was placed at the end of step k + 1
-            dma_g2l<64 * (NP - 1), false>(a.compact + size_t(k - 2) * CWD, sSB + ((k - 2) & 1) * kCompactMaxWords, CWD * S,
-                                          ht);
+          fill_tiles(k, rel == 1 ? 0 : wp, wp);
         }
       } else {
         if (k > 0) scatter_shared(k - 1);
-        if (k > 1) crow_dma(k - 2);
+        fill_tiles(k, 0, 0);
       }
     } else {
       if (k > 0) issue_shared(k - 1);
@@ -598,10 +602,13 @@ __device__ __forceinline__ void lq_openloop_instance(const LQArgs<T>& a, const P
       }
     }
     PH(1);
-    dma_wait();  // this wave's share of the next step's images, and Q_i | l_i of this step (issued at the end of the
-                 // previous one) in its tile
-    lds_sync(NT <= 64);  // barrier 2: [Z | z] and the next step's images published
+    dma_wait();  // dense arrays: this wave's share of the next step's images, and Q_i | l_i of this step (issued at the
+                 // end of the previous one) in its tile
+    lds_sync(NT <= 64);  // barrier 2: [Z | z], the next step's images and this step's tiles published
     PH(2);
+    if constexpr (CMP) {
+      if (k > 1) crow_dma(k - 2);  // into row k's staging row
+    }
     // ---- Xa = Aa - Bt Zt  (every wave) ----
     Blk Xd;
     {
@@ -694,11 +701,8 @@ __device__ __forceinline__ void lq_openloop_instance(const LQArgs<T>& a, const P
     if (a.costates) store_row_from_tile(k, false);
     lds_sync(true);
     lds_drain();  // the tile has been read: the DMA engine may refill it
-    if (k > 0) {
-      if constexpr (CMP)
-        fill_tile(k - 1);
-      else
-        issue_Q(k - 1);
+    if constexpr (!CMP) {
+      if (k > 0) issue_Q(k - 1);
     }
     PH(4);
   }
