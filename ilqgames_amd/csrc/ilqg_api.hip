@@ -406,8 +406,13 @@ __global__ void __launch_bounds__(64) ilq_decide_kernel(DevProblem p, SolveArgs<
 }
 
 // Speculative line search of the listed instances (ilqg_solve.hpp): candidate j of list entry `slot`.
-template <typename T, int NX, int NP, int MU>
-__global__ void __launch_bounds__(64, sizeof(T) == 8 ? ILQG_ROLL_WAVES : 1) ilq_probe_roll_kernel(DevProblem p, SolveArgs<T> sa) {
+// FAT (fp64): compiled for two waves per SIMD instead of ILQG_ROLL_WAVES — 256 registers, none spilled.  At four waves per
+// SIMD the paired fp64 rollout keeps 42 registers in scratch memory, reloaded inside the time-step chain: a round of a few
+// candidates, which costs the latency of one rollout however empty the chip is, runs a third faster without them (n = 16,
+// 6 instances x 128 candidates: 248 -> 166 us; the n = 16 constrained workload at B = 1024: 517 -> 533 k it/s); a round
+// that fills the chip wants the occupancy back (config 5's scene: 255 k it/s lean, 244 k fat).  The launcher picks.
+template <typename T, int NX, int NP, int MU, bool FAT = false>
+__global__ void __launch_bounds__(64, sizeof(T) == 8 ? (FAT ? 2 : ILQG_ROLL_WAVES) : 1) ilq_probe_roll_kernel(DevProblem p, SolveArgs<T> sa) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   if constexpr (rollout_pairs(NX, NP, MU))  // candidates 2 y and 2 y + 1 in the two halves of the wave
     probe_roll_pair<T, NX, NP, MU>(p, sa, sa.ids[blockIdx.x], blockIdx.x, 2 * int(blockIdx.y), reinterpret_cast<T*>(smem_raw));
@@ -947,6 +952,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   const size_t lds_proll = pairs ? size_t(rollout_pair_lds_elems(d.n, d.m)) * sizeof(T) + 16 : lds_roll;
   const bool probe = lists && sa.prm.linesearch && choice(opt.probe, true);
   auto k_proll = ilq_probe_roll_kernel<T, NX, NP, MU>;
+  auto k_proll_fat = ilq_probe_roll_kernel<T, NX, NP, MU, sizeof(T) == 8>;  // (fp32: the same kernel)
   auto k_prows = ilq_probe_rows_kernel<T, NX, NP, MU>;
   const int decide_elems = int(trial_phase_quad_elems<T>(d, TRIAL_DECIDE, sa.rows_cw));
   const int row_chunks = (d.T + sa.rows_cw - 1) / sa.rows_cw;  // workgroups per instance of the row kernels
@@ -957,6 +963,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
     raise_lds_limit((const void*)k_rows, lds_rows);
     raise_lds_limit((const void*)k_decide, lds_decide);
     raise_lds_limit((const void*)k_proll, lds_proll);
+    raise_lds_limit((const void*)k_proll_fat, lds_proll);
     raise_lds_limit((const void*)k_prows, lds_prows);
   }
   sa.first = resume ? 2 : 1;
@@ -1055,7 +1062,10 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
         // the listed instances' next step sizes side by side; their states move to the first acceptable one
         sa.probe_pool = probe_pool;
         sa.probe_k = probe_k;
-        hipLaunchKernelGGL(k_proll, dim3(round_instances, pairs ? (probe_k + 1) / 2 : probe_k), dim3(64), lds_proll, stream, d, sa);
+        const int proll_y = pairs ? (probe_k + 1) / 2 : probe_k;
+        // the register-rich build while every rollout of the round is resident at once at two waves per SIMD
+        const bool fat = (long long)round_instances * proll_y <= 8ll * num_cus;
+        hipLaunchKernelGGL(fat ? k_proll_fat : k_proll, dim3(round_instances, proll_y), dim3(64), lds_proll, stream, d, sa);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(k_prows, dim3(row_chunks, round_instances * probe_k),
                            dim3(64), lds_prows, stream, d, sa);
