@@ -23,7 +23,7 @@ __global__ void probe(unsigned* out, int spin) {
   __syncthreads();
 }
 
-static void run(int grid, int waves, int lds_bytes) {
+static void run(int grid, int waves, int lds_bytes, int working = 0) {  // working > 0: only waves < working count
   unsigned* d;
   const size_t n = size_t(grid) * waves * 2;
   hipMalloc(&d, n * 4);
@@ -46,6 +46,7 @@ static void run(int grid, int waves, int lds_bytes) {
     std::string pat;
     int per_simd[4] = {0, 0, 0, 0}, w0_simd[4] = {0, 0, 0, 0};
     for (auto& e : kv.second) {
+      if (working > 0 && e.first % waves >= working) continue;
       per_simd[e.second]++;
       if (e.first % waves == 0) w0_simd[e.second]++;
     }
@@ -69,5 +70,8 @@ int main() {
   run(1024, 3, 30272);
   run(512, 4, 80352);
   run(256, 8, 160000);
+  printf("-- the sweep's geometry with an idle fourth wave (only waves 0 .. 2 counted)\n");
+  run(1024, 4, 35072, 3);
+  run(1024, 4, 30272, 3);
   return 0;
 }
