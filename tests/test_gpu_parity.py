@@ -126,6 +126,29 @@ def test_lq_openloop_matches_oracle_random(hip, oracle, dims, dtype):
     assert rel_err(_np(dx), dxr) < tol
 
 
+@pytest.mark.parametrize("dims,T", [((24, 4, 2), 256), ((6, 3, 2), 256), ((2, 2, 1), 256), ((10, 2, 2), 256), ((14, 3, 2), 255)])
+def test_lq_openloop_long_horizons_match_oracle_fp64(hip, oracle, dims, T):
+    """The longest horizon the library takes (kMaxT = 256).  The open-loop sweep's forward pass has two forms
+    (csrc/ilqg_lq_openloop.hpp): the state recursion on one wave with alpha and the expected decrease parallel over the
+    steps, which keeps every x_k in LDS, and the step-by-step pass for shapes whose state history does not fit beside
+    nothing else (small working sets, long horizons).  The random games are not stable over hundreds of steps, so every
+    time step is compared at its own magnitude."""
+    n, N, mu = dims
+    rng = np.random.default_rng(13 * n + T)
+    B = 2
+    g = random_lq_game(rng, n, [mu] * N, T, B)
+    g["A"] = np.asarray(g["A"])
+    d = dims_of(g, abi.F64)
+    x0 = rng.standard_normal((B, n))
+    _, ar, dxr, _ = oracle.lq_solve(d, g["A"], g["Bm"], g["Q"], g["l"], g["R"], g["r"], g["pairs"], x0=x0, open_loop=True)
+    P, alpha, dx = hip.lq_feedback(d, g["A"], g["Bm"], g["Q"], g["l"], g["R"], g["r"], g["pairs"], x0=x0, open_loop=True)
+    assert np.all(_np(P) == 0)
+    for got, ref in ((_np(alpha), ar), (_np(dx), dxr)):
+        assert np.all(np.isfinite(got))
+        scale = np.maximum(np.max(np.abs(ref), axis=-1, keepdims=True), 1e-300)
+        assert np.max(np.abs(got - ref) / scale) < 1e-7
+
+
 @pytest.mark.parametrize("open_loop", [False, True])
 @pytest.mark.parametrize("dtype", [abi.F64, abi.F32])
 @pytest.mark.parametrize("dims", [(4, 2, 2), (14, 3, 2), (24, 4, 2)])
