@@ -235,6 +235,26 @@ def test_ilq_solve_open_loop_matches_oracle_fp64(hip, oracle, T):
     assert rel_err(_np(out["costs"])[ok], ref["costs"][ok]) < 1e-7
 
 
+@pytest.mark.parametrize("T", [2, 3, 4, 7])
+@pytest.mark.parametrize("cfg", ["roundabout_merging", "modified_three_player_intersection"])
+def test_ilq_solve_open_loop_short_horizons_match_oracle_fp64(hip, oracle, cfg, T):
+    """The open-loop sweep pipelines its compact rows two steps ahead (staging DMA behind barrier 2, the tiles filled by
+    the waiting waves behind barrier 1): the horizons at which the prologue and the steady state meet, n = 24 (2 x 2
+    tiles) and n = 14 (one tile), two iterations against the oracle."""
+    spec = examples.roundabout_merging(T=T, open_loop=True) if cfg == "roundabout_merging" else examples.CONFIGS[cfg](T=T)
+    spec.params.open_loop = 1
+    spec.params.expected_decrease_fraction = 0.001
+    B, K = 3, 2
+    x0 = examples.jittered_x0(spec, B, seed=2)
+    ref = oracle.OracleProblem(spec).solve(abi.F64, x0, fixed_iters=K)
+    out = hip.Problem(spec, abi.F64).solve(x0, fixed_iters=K)
+    assert np.array_equal(_np(out["iters"]), ref["iters"])
+    assert np.all(_np(out["P"]) == 0)
+    assert rel_err(_np(out["xs"]), ref["xs"]) < 1e-8
+    assert rel_err(_np(out["alpha"]), ref["alpha"]) < 1e-7
+    assert rel_err(_np(out["costs"]), ref["costs"]) < 1e-8
+
+
 def test_lq_feedback_partial_pairs_and_no_regularization(hip, oracle):
     """Only the (i,i) blocks plus one off-diagonal block; adaptive_regularization off."""
     rng = np.random.default_rng(5)
