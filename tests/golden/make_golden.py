@@ -14,6 +14,18 @@ Fixtures:
                            R_ii = I, R_ij = 0.1 I as test/test_lq_solver.cpp:227-248.
   lq_feedback_pointmass.npz test/test_lq_solver.cpp:143-186,227-264 fixture (nominal 0):
                            time-invariant TwoPlayerPointMass1D, T=100.
+  product_dynamics_n14.npz BASELINE configs 2 / 3: the headline's own 14-state system.  The reference's
+                           ProductMultiPlayerDynamicalSystem([Car5D(4.0, dt), Car5D(4.0, dt), Unicycle4D(dt)])
+                           (python/product_multiplayer_dynamical_system.py, car_5d.py:50-88, unicycle_4d.py)
+                           evaluated along two 100-step trajectories from the example's x0
+                           (src/modified_three_player_intersection_example.cpp:108-126): zero controls, and
+                           seeded random controls.  Stored per step: x, u, xdot = system(x, u) (the C++
+                           ConcatenatedDynamicalSystem::Evaluate, src/concatenated_dynamical_system.cpp:69-84) and
+                           (A, B_i) = linearize_discrete(x, u) = (I + dt J, dt dB_i) (the C++ ::Linearize, :86-107;
+                           the MULTI-player class discretises by Euler like the C++ — the single-system
+                           DynamicalSystem.linearize_discrete uses the zero-order hold and is not an oracle).
+                           The states advance by x += dt * xdot of the reference's own __call__, so the fixture
+                           holds nothing this repository computed.
 Index mapping: solve_lq_game(As[0:T-1], Bs[i][0:T-1], Qs[i][k]=Q_i[k+1]... )
 python's k-th Q is the state cost of time k+1 while the C++ sweep applies quad[k] at k and
 quad[T-1] as terminal; with time-INVARIANT or explicitly shifted inputs both agree:
@@ -120,7 +132,50 @@ def pointmass_game():
     save("lq_feedback_pointmass.npz", A, Bs, Q, l, R, Ps, alphas)
 
 
+def product_dynamics():
+    from car_5d import Car5D
+    from unicycle_4d import Unicycle4D
+    from product_multiplayer_dynamical_system import ProductMultiPlayerDynamicalSystem
+    T, dt, L = 100, 0.1, 4.0
+    system = ProductMultiPlayerDynamicalSystem([Car5D(L, dt), Car5D(L, dt), Unicycle4D(dt)], T=dt)
+    # src/modified_three_player_intersection_example.cpp:108-126 (headings are float32 constants there)
+    x0 = np.zeros((14, 1))
+    x0[[0, 1, 2, 4], 0] = [-2.0, -30.0, np.float32(np.pi / 2), 4.0]
+    x0[[5, 6, 7, 9], 0] = [-10.0, 45.0, np.float32(-np.pi / 2), 3.0]
+    x0[[10, 11, 12, 13], 0] = [-11.0, 16.0, 0.0, 1.25]
+    rng = np.random.default_rng(20261001)
+    out = {}
+    for name in ("zero", "random"):
+        x = x0.copy()
+        xs, us, xdots, As, Bs = [], [], [], [], [[], [], []]
+        for k in range(T):
+            if name == "zero":
+                u = [np.zeros((2, 1)) for _ in range(3)]
+            else:  # steering rate / acceleration (turn rate for the unicycle) of a size that bends the paths
+                u = [rng.uniform(-1.0, 1.0, (2, 1)) * np.array([[0.4], [2.0]]) for _ in range(3)]
+            xdot = system(x, u)
+            A, B = system.linearize_discrete(x, u)
+            xs.append(x.reshape(-1).copy())
+            us.append(np.concatenate([v.reshape(-1) for v in u]))
+            xdots.append(np.asarray(xdot).reshape(-1).copy())
+            As.append(np.array(A))
+            for i in range(3):
+                Bs[i].append(np.array(B[i]))
+            x = x + dt * xdot
+        out["xs_" + name] = np.stack(xs)
+        out["us_" + name] = np.stack(us)
+        out["xdot_" + name] = np.stack(xdots)
+        out["A_" + name] = np.stack(As)
+        for i in range(3):
+            out["B%d_%s" % (i, name)] = np.stack(Bs[i])
+    out["dt"] = np.float64(dt)
+    out["L"] = np.float64(L)
+    np.savez_compressed(os.path.join(HERE, "product_dynamics_n14.npz"), **out)
+    print("wrote product_dynamics_n14.npz", out["A_zero"].shape, out["B0_random"].shape)
+
+
 if __name__ == "__main__":
+    product_dynamics()
     random_game()
     unicycle_game()
     pointmass_game()

@@ -291,6 +291,28 @@ def _random_op(spec, rng, B):
     return x0, xs_ref, us_ref, P, alpha
 
 
+@pytest.mark.parametrize("dtype", [abi.F64, abi.F32])
+def test_linearize_headline_system_matches_reference_python_golden(hip, dtype):
+    """ilqg_linearize_batch on BASELINE config 2 / 3's own 14-state system against the (A, B_i) the reference's
+    python/product_multiplayer_dynamical_system.py produced (tests/golden/product_dynamics_n14.npz): the device
+    against a reference artefact directly, no oracle in between.  Both trajectories as one batch of two.
+    fp64 1e-12 absolute; fp32 (the reference's C++ arithmetic) 2e-6 relative to the largest entry."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "product_dynamics_n14.npz"))
+    spec = examples.modified_three_player_intersection()
+    hp = hip.Problem(spec, dtype)
+    xs = np.stack([g["xs_zero"], g["xs_random"]])
+    us = np.stack([g["us_zero"], g["us_random"]])
+    A_d, B_d = hp.linearize(xs, us)
+    A_d = _np(A_d).astype(np.float64).reshape(2, spec.T, 14, 14).transpose(0, 1, 3, 2)   # column-major blocks
+    B_d = _np(B_d).astype(np.float64).reshape(2, spec.T, 6, 14).transpose(0, 1, 3, 2)
+    tol = 1e-12 if dtype == abi.F64 else 2e-6 * 5.0
+    for b, traj in enumerate(("zero", "random")):
+        assert np.abs(A_d[b] - g["A_" + traj]).max() < tol
+        for i in range(3):
+            assert np.abs(B_d[b][:, :, 2 * i:2 * i + 2] - g["B%d_%s" % (i, traj)]).max() < tol
+
+
 @pytest.mark.parametrize("cfg", list(examples.CONFIGS))
 @pytest.mark.parametrize("dtype", [abi.F64, abi.F32])
 def test_stage_kernels_match_oracle(hip, oracle, cfg, dtype):

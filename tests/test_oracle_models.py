@@ -114,6 +114,43 @@ def test_two_player_unicycle_linearization_matches_reference_python_golden(oracl
     assert np.any(B[0, 0].reshape(4, 4, order="F")[0:2, 2:4] != 0)  # the disturbance enters the position rows
 
 
+def _product_golden():
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "product_dynamics_n14.npz"))
+
+
+@pytest.mark.parametrize("traj", ["zero", "random"])
+def test_headline_product_system_matches_reference_python_golden(oracle, traj):
+    """Rows a7 / a9 / a10 on BASELINE config 2 / 3's own 14-state system, pinned to a reference artefact:
+    ConcatenatedDynamicalSystem::Evaluate / ::Linearize (src/concatenated_dynamical_system.cpp:69-107) over
+    SinglePlayerCar5D (dynamics/single_player_car_5d.h:100-133) x 2 and SinglePlayerUnicycle4D
+    (single_player_unicycle_4d.h:90-116), against xdot and (A, B_i) of the reference's own
+    python/product_multiplayer_dynamical_system.py along two 100-step trajectories from the example's x0
+    (tests/golden/product_dynamics_n14.npz, generated by tests/golden/make_golden.py; fp64, 1e-12)."""
+    g = _product_golden()
+    spec = examples.modified_three_player_intersection()
+    assert spec.dt == float(g["dt"]) and spec.n == 14
+    op = oracle.OracleProblem(spec)
+    xs, us = g["xs_" + traj], g["us_" + traj]
+    T = xs.shape[0]
+    assert T == spec.T
+    assert np.array_equal(xs[0], spec.x0)  # the fixture starts at the example's own initial state
+    A, B = op.linearize(abi.F64, xs.reshape(1, T, 14), us.reshape(1, T, 6))
+    for k in range(T):
+        Ak = A[0, k].reshape(14, 14, order="F")
+        Bk = B[0, k].reshape(14, 6, order="F")
+        assert np.allclose(Ak, g["A_" + traj][k], rtol=0, atol=1e-12)
+        for i in range(3):
+            assert np.allclose(Bk[:, 2 * i:2 * i + 2], g["B%d_%s" % (i, traj)][k], rtol=0, atol=1e-12)
+        xdot, _ = op.dynamics(abi.F64, xs[k], us[k])
+        assert np.allclose(xdot, g["xdot_" + traj][k], rtol=1e-13, atol=1e-13)
+    # the structure the device path relies on (block-diagonal A, B_i confined to player i's rows) is the reference's
+    Ag = g["A_" + traj]
+    assert not Ag[:, 0:5, 5:].any() and not Ag[:, 5:10, 0:5].any() and not Ag[:, 5:10, 10:].any() and not Ag[:, 10:, 0:10].any()
+    assert not g["B0_" + traj][:, 5:, :].any() and not g["B2_" + traj][:, 0:10, :].any()
+    if traj == "random":  # the trajectory leaves the straight line: steering and heading Jacobian entries are exercised
+        assert np.abs(Ag[:, 2, 3]).max() > 1e-3 and np.abs(Ag[:, 0, 2]).max() > 1e-2
+
+
 def test_point_mass_known_answers(oracle):
     """SinglePlayerPointMass2D (single_player_point_mass_2d.h:90-110): xdot = (vx, vy, ax, ay); the discrete
     Jacobians are the constant double-integrator blocks, and RK4 is exact for it:
