@@ -178,13 +178,21 @@ def launch_ranks_if_needed(gpus):
         return
     import socket
     import subprocess
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    sys.exit(subprocess.call(cmd))
+    rc = 1
+    for attempt in range(3):
+        # the port is free when probed and re-bound by the launcher a moment later: a job that dies at once (somebody
+        # took the port in between) is started again on another one; a job that ran is not
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        t0 = time.time()
+        rc = subprocess.call(cmd)
+        if rc == 0 or time.time() - t0 > 20.0:
+            break
+    sys.exit(rc)
 
 
 HEADLINE_CONFIG = "modified_three_player_intersection"
@@ -356,6 +364,11 @@ def main():
 
     iters = bufs["iters"].cpu().numpy()
     status = bufs["status"].cpu().numpy()
+    # eight instances of the timed batch, kept for the parity figure (BASELINE.json's metric: "P_t rel-err vs CPU")
+    sample_ids = sorted(set(int(v) for v in np.linspace(0, B - 1, 8).round()))
+    timed_result = {"ids": sample_ids}
+    for k in ("P", "alpha", "costs", "xs", "iters"):
+        timed_result[k] = bufs[k][sample_ids].cpu().numpy()
     local_iters = int(iters.sum())
     total_iters = local_iters
     if distributed:
@@ -410,6 +423,12 @@ def main():
         flops_round = sweep_flops_per_step(n, m, N, open_loop) * T * B
         flops_exec_round = sweep_flops_executed_per_step(n, m, N, open_loop) * T * B
         peak_tf = FP64_PEAK_TFLOPS if elem == 8 else FP32_PEAK_TFLOPS
+        peak_measured = None
+        if args.backend == "hip":
+            try:
+                peak_measured = backend.hip.copy_bandwidth_gbs()
+            except Exception as e:  # the nominal figure stands on its own
+                sys.stderr.write("copy-bandwidth measurement skipped: %r\n" % (e,))
         out = {
             "metric": "iLQ iterations/sec (batch)", "value": value, "unit": "instance-iterations/s",
             "n_gpus": dist.get_world_size() if distributed else 1, "steps": args.steps, "warmup": args.warmup,
@@ -431,6 +450,11 @@ def main():
             # s*T*[W_quad + W_strat + 2 W_op] per rejected trial is kept under `with_rejected_trials`.
             "roofline": {"bound": "hbm", "achieved": achieved_b0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_b0 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         # the nominal 8 TB/s AND the box's measured copy bandwidth as denominators
+                         "peak_measured": peak_measured,
+                         "frac_of_measured": (achieved_b0 / peak_measured) if peak_measured else None,
+                         "peak_measured_source": "ilqg_copy_bandwidth (16-byte-per-lane streaming copy, 1 GiB each way, best of 10 "
+                                                 "launches, HIP events; read + write bytes counted)",
                          "with_rejected_trials": {"achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
                                                   "mean_backtracks": mean_bt},
                          "kernel": "ilq_lq_kernel + ilq_trial_kernel (one round = one outer iteration of the batch)",
@@ -456,6 +480,7 @@ def main():
                 out["configs"] = baseline_configs_block(examples, abi, local_rank)
         if args.backend == "hip" and not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, spec, x0, dtype, abi, out.get("latency"))
+            out["parity"] = parity_figure(args, spec, x0, dtype, abi, timed_result)
         print(json.dumps(out))
     if distributed:
         dist.barrier()
@@ -487,7 +512,7 @@ def latency_figures(backend, examples, abi, args, x0_d):
             "mode": "free-running to convergence_tolerance = 1.0, alpha0 = 0.5, fraction 0.001, zero warm start"}
 
 
-def timed_workload(examples, abi, cfg, dtype_name, B, steps, local_rank, warmup=3, reps=3, linesearch="own"):
+def timed_workload(examples, abi, cfg, dtype_name, B, steps, local_rank, warmup=3, reps=5, linesearch="own"):
     """One more fixed-iteration workload timed like the headline (warm-up decides the launch mode, HIP events around
     the solve, inputs resident in HBM, median of `reps`): its own solver parameters unless `linesearch` says otherwise.
     Returns the per-workload block of the bench line."""
@@ -542,34 +567,41 @@ def backtracking_workload(examples, abi, args, local_rank, steps=6, warmup=3):
     has a driver-visible number: ThreePlayerIntersectionExample (the n = 16 example BASELINE.json's config 2 names, its
     constraints as augmented-Lagrangian terms at their initial multipliers), its own solver parameters
     (exec/three_player_intersection/main.cpp:109-120), the headline's batch and precision, `steps` outer iterations —
-    the launch mode chosen from the warm-up exactly as for the headline.  Median of three timed solves."""
+    the launch mode chosen from the warm-up exactly as for the headline.  Median of five timed solves."""
     return timed_workload(examples, abi, "three_player_intersection", args.dtype, args.batch, steps, local_rank, warmup=warmup)
 
 
-def receding_horizon_workload(examples, abi, local_rank, batch=2048, replans=12, horizon_calls=200, max_solver_iters=50):
+def receding_horizon_workload(examples, abi, local_rank, batch=2048, replans=12, horizon_calls=200, max_solver_iters=50,
+                              dtype_name="f64", cpu=True):
     """BASELINE.json config 5 AS WRITTEN: the receding-horizon loop of src/receding_horizon_simulator.cpp:65-137 over
     three_player_collision_avoidance_reachability with the augmented-Lagrangian solver, `batch` plans resident on the
     device, every call after the first warm-started from the spliced plan.  The wall clock of the reference's loop is
     replaced by a fixed simulated solve time sized so that `horizon_calls` (200) calls fit the horizon; the first
     1 + `replans` of them are run and timed (a 200-call run is minutes; what a call costs does not change along it).
     An instance whose first solve fails leaves the loop there, as the reference's CHECK(success) (:77) ends its run —
-    `active_after_first_call` says how many plans the replanning calls are really about."""
+    `active_after_first_call` says how many plans the replanning calls are really about.
+    `cpu`: the CPU port (the oracle's restatement of the same loop) on the plans that survived the device's first call
+    — at most 64 of them — with one thread and with every usable core, first call and replans timed apart (two runs:
+    one record, then 1 + replans records), so that the device's replanning rate has its CPU figure beside it."""
     import torch
     cfg = "three_player_collision_avoidance_reachability"
     spec = examples.CONFIGS[cfg]()
     spec.params.max_solver_iters = max_solver_iters
     from ilqgames_amd import hip
     torch.cuda.set_device(local_rank)
-    prob = hip.Problem(spec, abi.F64)
+    dtype = abi.F64 if dtype_name == "f64" else abi.F32
+    prob = hip.Problem(spec, dtype)
     x0 = examples.jittered_x0(spec, batch, seed=1)
     tick = 0.5 * spec.T * spec.dt / (horizon_calls + 8)
-    stamps, active, iterates = [], [], []
+    stamps, active, iterates, active_masks = [], [], [], []
 
     def on_record(r, info):
         torch.cuda.synchronize()
         stamps.append(time.perf_counter())
         active.append(int(info["active"].sum().item()))
         iterates.append(int((info["bufs"]["iters"] * info["active"]).sum().item()))
+        if r <= 1:
+            active_masks.append(info["active"].cpu().numpy().astype(bool))
 
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -581,19 +613,53 @@ def receding_horizon_workload(examples, abi, local_rank, batch=2048, replans=12,
     first_s = stamps[0] - t0 if stamps else wall
     replan_s = (stamps[-1] - stamps[0]) if len(stamps) > 1 else 0.0
     replan_solves = sum(active[1:])
-    res = {"workload": "%s n=%d N=%d T=%d batch=%d f64: RecedingHorizonSimulator loop, AugmentedLagrangianSolver, first call + %d "
+    res = {"workload": "%s n=%d N=%d T=%d batch=%d %s: RecedingHorizonSimulator loop, AugmentedLagrangianSolver, first call + %d "
                        "warm-started replans of a %d-call horizon (simulated solve time %.4f s), max_solver_iters=%d"
-                       % (cfg, spec.n, len(spec.subsystems), spec.T, batch, out["calls"] - 1, horizon_calls, tick, max_solver_iters),
+                       % (cfg, spec.n, len(spec.subsystems), spec.T, batch, dtype_name, out["calls"] - 1, horizon_calls, tick,
+                          max_solver_iters),
+           "dtype": dtype_name,
            "calls": out["calls"], "instance_solves": solves, "seconds": wall,
            "instance_solves_per_s": solves / wall, "unit": "warm-started instance-solves/s (first call included)",
            "first_call_ms": first_s * 1e3, "ms_per_replan": (replan_s / max(1, out["calls"] - 1)) * 1e3,
            "replan_instance_solves_per_s": (replan_solves / replan_s) if replan_s > 0 else None,
+           "replan_logged_iterates_per_s": (sum(iterates[1:]) / replan_s) if replan_s > 0 else None,
            "active_after_first_call": active[1] if len(active) > 1 else (active[0] if active else 0),
            "active_at_end": int(out["active"].sum().item()),
            "logged_iterates_per_call": iterates}
     del prob
     torch.cuda.empty_cache()
+    if cpu and len(active_masks) > 1 and active_masks[1].any():
+        res["cpu_port"] = receding_horizon_cpu(spec, abi, dtype, x0[active_masks[1]][:64], tick, replans)
     return res
+
+
+def receding_horizon_cpu(spec, abi, dtype, x0_all, tick, replans):
+    """The CPU port of the same loop (oracle SimulateBatch: RecedingHorizonSimulator + AugmentedLagrangianSolver +
+    SolutionSplicer, same simulated solve time) on the given plans: one thread, then every usable core (OpenMP over the
+    plans).  Replanning time = (run with 1 + replans records) - (run with the first call only)."""
+    from oracle import pyoracle
+    op = pyoracle.OracleProblem(spec)
+    ncpu = usable_cpus()
+    out = {}
+    # bounded: a replanning call of ONE plan is ~0.3 s of CPU here (its failing line searches walk through all their
+    # step sizes, each a rollout and a quadraticisation), so one thread gets three plans and every core one plan each
+    for label, threads, plans in (("1_thread", 1, 3), ("all_cores", ncpu, ncpu)):
+        x0 = x0_all[:plans]
+        c0 = time.perf_counter()
+        op.receding_horizon_simulate(dtype, x0, 1e9, tick, extra_time=tick, solve_time=tick, augmented_lagrangian=True,
+                                     max_records=1, threads=threads)
+        c1 = time.perf_counter()
+        full = op.receding_horizon_simulate(dtype, x0, 1e9, tick, extra_time=tick, solve_time=tick, augmented_lagrangian=True,
+                                            max_records=replans + 1, threads=threads)
+        c2 = time.perf_counter()
+        rs = max(1e-9, (c2 - c1) - (c1 - c0))
+        nrec = full["num_records"]
+        out[label] = {"threads": threads, "plans": int(x0.shape[0]), "first_call_ms": (c1 - c0) * 1e3, "replans_s": rs,
+                      "ms_per_replan": rs / max(1, replans) * 1e3,
+                      "replan_instance_solves": int((nrec - 1).clip(min=0).sum()),
+                      "replan_instance_solves_per_s": float((nrec - 1).clip(min=0).sum()) / rs,
+                      "replan_logged_iterates_per_s": float(sum(int(full["iters"][b, 1:int(nrec[b])].sum()) for b in range(len(nrec)))) / rs}
+    return out
 
 
 def baseline_configs_block(examples, abi, local_rank):
@@ -610,6 +676,8 @@ def baseline_configs_block(examples, abi, local_rank):
     out["config5_scene_fixed_iterations_b2048"] = timed_workload(examples, abi, "three_player_collision_avoidance_reachability",
                                                                  "f64", 2048, 5, local_rank)
     out["config5_receding_horizon_al_b2048"] = receding_horizon_workload(examples, abi, local_rank)
+    # ... and in fp32, the reference's own arithmetic (include/ilqgames/utils/types.h:68-69), in which its x0 passes
+    out["config5_receding_horizon_al_b2048_f32"] = receding_horizon_workload(examples, abi, local_rank, dtype_name="f32")
     return out
 
 
@@ -634,6 +702,29 @@ def own_params_figure(backend, examples, abi, args, x0_d):
             "instance_iterations_per_s": float(it.sum()) / dt,
             "params": "alpha0=%g frac=%g tol=%g" % (spec.params.initial_alpha_scaling, spec.params.expected_decrease_fraction,
                                                    spec.params.convergence_tolerance)}
+
+
+def parity_figure(args, spec, x0, dtype, abi, timed):
+    """BASELINE.json's metric names "P_t rel-err vs CPU": the strategies, trajectory and total costs the TIMED batch ended
+    with (eight instances spread over it, after the `steps` fixed iterations just timed, line searches included) against
+    the CPU oracle run on the same initial states in the same precision.  The oracle is the checker here, nothing else."""
+    from oracle import pyoracle
+    ids = timed["ids"]
+    ref = pyoracle.OracleProblem(spec).solve(dtype, x0[ids], fixed_iters=args.steps, threads=1)
+
+    def rel(a, b):
+        return float(np.max(np.abs(np.asarray(a, np.float64) - b)) / max(1e-300, np.max(np.abs(b))))
+    same = [int(i) for i in range(len(ids)) if int(timed["iters"][i]) == int(ref["iters"][i])]
+    fig = {"instances": [int(i) for i in ids], "iterations": args.steps, "dtype": args.dtype,
+           "instances_with_equal_iteration_counts": len(same),
+           "against": "oracle/ilqg_oracle.hpp (CPU restatement of the reference, same precision, same x0, same fixed iteration count)"}
+    if same:
+        fig["rel_err_P"] = max(rel(timed["P"][i], ref["P"][i]) for i in same)
+        fig["rel_err_alpha"] = max(rel(timed["alpha"][i], ref["alpha"][i]) for i in same)
+        fig["rel_err_total_cost"] = max(rel(timed["costs"][i], ref["costs"][i]) for i in same)
+        fig["rel_err_xs"] = max(rel(timed["xs"][i], ref["xs"][i]) for i in same)
+        fig["max"] = max(fig["rel_err_P"], fig["rel_err_alpha"], fig["rel_err_total_cost"])
+    return fig
 
 
 def usable_cpus():

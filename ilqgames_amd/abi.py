@@ -13,7 +13,7 @@ F32, F64 = 0, 1
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_NO_DEVICE = 0, 1, 2, 3, 4
 
 # ilqg_dyn_kind
-ABI_VERSION = 6  # ILQG_ABI_VERSION of include/ilqg.h these mirrors were written against
+ABI_VERSION = 7  # ILQG_ABI_VERSION of include/ilqg.h these mirrors were written against
 DYN_UNICYCLE_4D, DYN_CAR_5D, DYN_CAR_6D = 1, 2, 3
 DYN_UNICYCLE_4D_DISTURBED, DYN_PLANAR_DISTURBANCE = 4, 5  # the two rows of TwoPlayerUnicycle4D
 DYN_DUBINS_CAR = 6  # (px, py, theta), u = (omega), param0 = speed
@@ -72,7 +72,7 @@ class IterateLog(C.Structure):
 class SolveOptions(C.Structure):
     """ilqg_solve_options (include/ilqg.h)."""
     _fields_ = [("fixed_iters", C.c_int32), ("augmented_lagrangian", C.c_int32), ("resume", C.c_int32),
-                ("reserved0", C.c_int32), ("active", C.c_void_p), ("forced_steps", C.c_void_p),
+                ("deterministic", C.c_int32), ("active", C.c_void_p), ("forced_steps", C.c_void_p),
                 ("split_trial", C.c_int32), ("handoff", C.c_int32), ("probe", C.c_int32), ("counted", C.c_int32),
                 ("compact_rows", C.c_int32), ("round_bursts", C.c_int32), ("generic_kernels", C.c_int32),
                 ("probe_first", C.c_int32), ("single_wave_sweep", C.c_int32), ("adjoint_expected_decrease", C.c_int32),

@@ -509,6 +509,23 @@ __global__ void mfma_selftest_kernel(const T* X, const T* Y, const T* C, T* out)
   mfma_selftest<T>(X, Y, C, out);
 }
 
+// The measured-bandwidth denominator of bench.py's roofline ("measure achievable BW on the box with a copy
+// kernel"): a grid-stride float4 copy, four independent 16-byte loads per lane in flight before the first store.
+typedef float copy_v4f __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) copy_bandwidth_kernel(copy_v4f* __restrict__ dst, const copy_v4f* __restrict__ src, size_t n16) {
+  const size_t stride = size_t(gridDim.x) * 256;
+  size_t i = size_t(blockIdx.x) * 256 + threadIdx.x;
+  for (; i + 3 * stride < n16; i += 4 * stride) {
+    const copy_v4f a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride),
+                 c = __builtin_nontemporal_load(src + i + 2 * stride), e = __builtin_nontemporal_load(src + i + 3 * stride);
+    __builtin_nontemporal_store(a, dst + i);
+    __builtin_nontemporal_store(b, dst + i + stride);
+    __builtin_nontemporal_store(c, dst + i + 2 * stride);
+    __builtin_nontemporal_store(e, dst + i + 3 * stride);
+  }
+  for (; i < n16; i += stride) dst[i] = src[i];
+}
+
 // ------------------------------------------------------------------------------------
 // Host side
 // ------------------------------------------------------------------------------------
@@ -734,31 +751,49 @@ struct ilqg_problem {
 // The outer loop's clock of AugmentedLagrangianSolver::Solve under a max_runtime (src/augmented_lagrangian_solver.cpp:
 // 104-110,193): `elapsed` starts at the first inner solve's ALLOWANCE (max_runtime / max_solver_iters, not the time it
 // took), every outer iteration adds its wall time, and another one starts only while
-// elapsed < max_runtime - timer_.RuntimeUpperBound().  A batch shares the clock: an "outer iteration" is the time from
-// one exit launch that restarted instances to the next exit launch.  before_exit() is called in front of every exit
-// launch and says whether instances whose inner solve has ended may still restart.
+// elapsed < max_runtime - timer_.RuntimeUpperBound().  A batch shares the clock.  It runs without a gap from the first
+// exit launch that restarted an instance until the solve returns — whoever is restarted or not at the launches in
+// between (round 5 re-armed it only when a launch restarted somebody: with staggered instances whole inner solves went
+// uncounted).  The LoopTimer's samples are outer-iteration durations: every restart-bearing exit launch opens an
+// interval, and each later exit launch (one exists only when some inner solve has ended) closes the oldest open one —
+// exact for a batch in lockstep, the inner-solve length of the earliest group when instances are staggered; never the
+// gap between two neighbouring rounds.  before_exit() is called in front of every exit launch and says whether instances
+// whose inner solve has ended may still restart.
 struct AlOuterClock {
   ilqg_problem* p;
   bool on;
-  double max_runtime, elapsed, tic = 0.0;
-  bool open = false;
+  double max_runtime, elapsed, last = 0.0;
+  bool running = false;
+  static constexpr int kOpen = 32;
+  double open_since[kOpen];
+  int open_head = 0, open_count = 0;
   AlOuterClock(ilqg_problem* p_, bool on_, double max_runtime_, double first_allowance)
       : p(p_), on(on_), max_runtime(max_runtime_), elapsed(first_allowance) {}
   static double wall() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
   bool before_exit() {  // true: the outer loop is closed
     if (!on) return false;
     const double now = wall();
-    if (open) {
-      p->al_loop_add(now - tic);
-      elapsed += now - tic;
-      open = false;
+    if (running) {
+      elapsed += now - last;
+      last = now;
+      if (open_count > 0) {
+        p->al_loop_add(now - open_since[open_head]);
+        open_head = (open_head + 1) % kOpen;
+        open_count--;
+      }
     }
     return !(elapsed < max_runtime - p->al_loop_upper_bound());
   }
   void after_exit(int restarted) {
-    if (on && restarted && !open) {
-      tic = wall();
-      open = true;
+    if (!on || !restarted) return;
+    const double now = wall();
+    if (!running) {
+      running = true;
+      last = now;
+    }
+    if (open_count < kOpen) {
+      open_since[(open_head + open_count) % kOpen] = now;
+      open_count++;
     }
   }
 };
@@ -875,7 +910,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   // fused vs 1.65 M split, fp32 2.61 M vs 2.77 M; B = 2048 fp64 1.40 M vs 1.50 M).
   constexpr bool has_1w = W1Cfg<T, NX, NP, MU>::SUPPORTED && C::USE_MFMA && C::MFMA_ONE_TILE;
   const bool want_1w = has_1w && pw && compact_on && !kProfile && d.rp_compact_w <= W1Cfg<T, NX, NP, MU>::kWords &&
-                       choice(opt.single_wave_sweep, size_t(batch) >= size_t(5) * num_cus) &&
+                       choice(opt.single_wave_sweep, !opt.deterministic && size_t(batch) >= size_t(5) * num_cus) &&
                        opt.adjoint_expected_decrease != ILQG_CHOICE_OFF;
   bool split = choice(opt.split_trial, 4 * lds_trial > size_t(160) * 1024 || (big_batch && NX > 16) || want_1w);
   if (kProfile || opt.forced_steps) split = false;  // the phase profile reads the fused kernel's counters
@@ -926,7 +961,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   const bool adjoint = choice(opt.adjoint_expected_decrease, sa.defer_forward == 0);
   const bool single_wave = has_1w && pw && sa.compact && !kProfile && (adjoint || sa.defer_forward) &&
                            d.rp_compact_w <= W1Cfg<T, NX, NP, MU>::kWords &&
-                           choice(opt.single_wave_sweep, size_t(batch) >= size_t(5) * num_cus);
+                           choice(opt.single_wave_sweep, !opt.deterministic && size_t(batch) >= size_t(5) * num_cus);
   auto k_lq = single_wave ? ilq_lq_kernel<T, NX, NP, MU, (has_1w ? LQ_SINGLE_WAVE : LQ_VALU_FEEDBACK)> : k_lq_multi;
   const int nt_lq = single_wave ? 64 : nt_lq_multi;
   const size_t lds_lq = single_wave ? size_t(W1Cfg<T, NX, NP, MU>::ELEMS + 4) * sizeof(T) : lds_lq_multi;
@@ -958,6 +993,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   const int row_chunks = (d.T + sa.rows_cw - 1) / sa.rows_cw;  // workgroups per instance of the row kernels
   int round_instances = batch, list = 0;  // split passes: how many instances this round covers, which list is free
   int tail_rounds = 0;                    // rounds since the whole batch was last in one
+  bool probed_in_tail = false;            // the current tail has launched a probing pass
   if (lists) {
     raise_lds_limit((const void*)k_roll, lds_proll);
     raise_lds_limit((const void*)k_rows, lds_rows);
@@ -1058,7 +1094,10 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
         if (probe_k > ramp) probe_k = int(ramp);
       }
       if (sa.ids) tail_rounds++;
+      // see generic_solve: instances in ST_PROBE are only picked up again by a probing launch
+      if (probe && sa.ids && probed_in_tail && probe_k < 2) return fail(ILQG_ERR_HIP, "a probing line-search tail lost its probe launch");
       if (probe && probe_k >= 2) {
+        probed_in_tail = true;
         // the listed instances' next step sizes side by side; their states move to the first acceptable one
         sa.probe_pool = probe_pool;
         sa.probe_k = probe_k;
@@ -1110,6 +1149,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
         sa.ids = nullptr;
         round_instances = batch;
         tail_rounds = 0;
+        probed_in_tail = false;
         want_lq = waiting_lq;
         want_exit = waiting_exit;
         waiting_lq = waiting_exit = 0;
@@ -1197,8 +1237,10 @@ static ilqg_status launch_linquad(const ilqg_problem* p, int32_t batch, const vo
 static constexpr size_t kLdsPerWorkgroup = size_t(160) * 1024;
 
 // The whole solve on the run-time-dimensioned kernels: the split trial pass (integrate / rows / decide, ilqg_solve.hpp)
-// over the whole batch every round, the host counting rounds; the sweeps of ilqg_lq_generic.hpp on dense rows.  No
-// hand-off, no probing, no compact rows: the correctness path of every shape without a specialised instantiation.
+// over the whole batch in a round without back-tracking instances, the host counting rounds; the sweeps of
+// ilqg_lq_generic.hpp on dense rows.  Instances whose step is rejected are listed and their next step sizes probed side
+// by side (round 5: the speculative line search of DimsLaunch::solve, bit-identical with probe = OFF).  No fused trial
+// kernel, no compact rows: the path of every shape without a specialised instantiation.
 template <typename T>
 static ilqg_status generic_solve(ilqg_problem* p, int32_t batch, const void* x0, void* xs, void* us, void* P, void* alpha,
                                  void* total_costs, int32_t* iters, int32_t* status, int32_t* converged, void* workspace,
@@ -1274,6 +1316,7 @@ static ilqg_status generic_solve(ilqg_problem* p, int32_t batch, const void* x0,
   sa.ids_next = nullptr;
   int waiting_lq = 0, waiting_exit = 0;
   int round_instances = batch, list = 0, tail_rounds = 0;
+  bool probed_in_tail = false;
   for (long long round = 0;; round++) {
     HIP_TRY(hipMemsetAsync(p->d_unfinished, 0, 4 * sizeof(int), stream));
     sa.ids_next = pass_ids + size_t(list) * batch;
@@ -1291,7 +1334,12 @@ static ilqg_status generic_solve(ilqg_problem* p, int32_t batch, const void* x0,
       if (ramp < 2) ramp = 2;
       if (probe_k > ramp) probe_k = int(ramp);
       tail_rounds++;
+      // an instance every candidate of which was rejected waits in ST_PROBE and is skipped by the regular pass: it is
+      // only picked up again by the next probing launch, so a tail that has probed must keep probing (the list only
+      // shrinks and the ramp only grows, so this cannot trigger; if it ever does, fail instead of dropping instances)
+      if (probed_in_tail && probe_k < 2) return fail(ILQG_ERR_HIP, "a probing line-search tail lost its probe launch");
       if (probe_k >= 2) {
+        probed_in_tail = true;
         sa.probe_pool = probe_pool;
         sa.probe_k = probe_k;
         hipLaunchKernelGGL(k_proll, dim3(round_instances, probe_k), dim3(64), lds_roll, stream, d, sa);
@@ -1324,6 +1372,7 @@ static ilqg_status generic_solve(ilqg_problem* p, int32_t batch, const void* x0,
     sa.ids = nullptr;
     round_instances = batch;
     tail_rounds = 0;
+    probed_in_tail = false;
     int want_lq = waiting_lq, want_exit = waiting_exit, restarted = 0;
     waiting_lq = waiting_exit = 0;
     if (timed && want_lq) {  // the loop condition of src/ilq_solver.cpp:123-124 (see DimsLaunch::solve)
@@ -1456,6 +1505,27 @@ ilqg_status ilqg_selftest_mfma(int32_t dtype, const void* X, const void* Y, cons
   return ILQG_OK;
 }
 int32_t ilqg_abi_version(void) { return ILQG_ABI_VERSION; }
+
+ilqg_status ilqg_copy_bandwidth(void* dst, const void* src, size_t bytes, void* stream) {
+  ilqg_status s = check_device();
+  if (s != ILQG_OK) return s;
+  if (!dst || !src || bytes < 16 || (bytes & 15) || (reinterpret_cast<uintptr_t>(dst) & 15) || (reinterpret_cast<uintptr_t>(src) & 15))
+    return fail(ILQG_ERR_INVALID, "ilqg_copy_bandwidth: 16-byte aligned buffers and a multiple of 16 bytes");
+  const size_t n16 = bytes / 16;
+  int num_cus = 256;
+  {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) num_cus = prop.multiProcessorCount;
+  }
+  // eight workgroups of 256 per CU, each lane four independent 16-byte pieces per trip (64 KB in flight per workgroup)
+  size_t blocks = (n16 + 1023) / 1024;
+  if (blocks > size_t(num_cus) * 8) blocks = size_t(num_cus) * 8;
+  hipLaunchKernelGGL(copy_bandwidth_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<copy_v4f*>(dst), reinterpret_cast<const copy_v4f*>(src), n16);
+  HIP_TRY(hipGetLastError());
+  return ILQG_OK;
+}
 
 ilqg_status ilqg_problem_last_schedule(const ilqg_problem* p, int32_t* schedule_out) {
   if (!p || !schedule_out) return fail(ILQG_ERR_INVALID, "null argument");

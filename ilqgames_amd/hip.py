@@ -23,7 +23,7 @@ EXPORTS = [
     "ilqg_solution_splice_batch", "ilqg_solve_again_batch", "ilqg_strategy_costs_batch",
     "ilqg_check_local_nash_batch", "ilqg_check_sufficient_nash_batch",
     "ilqg_receding_horizon_shift_batch", "ilqg_default_solve_options", "ilqg_solve_batch_ex", "ilqg_solve_state_batch",
-    "ilqg_set_scratch", "ilqg_problem_last_schedule",
+    "ilqg_set_scratch", "ilqg_problem_last_schedule", "ilqg_copy_bandwidth",
 ]
 
 
@@ -78,6 +78,29 @@ def _dev(a, dtype):
 def _stream():
     import torch
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def copy_bandwidth_gbs(nbytes=1 << 30, reps=10):
+    """Measured streaming-copy bandwidth of this GPU in GB/s (read + write bytes of ilqg_copy_bandwidth over HIP-event
+    time, best of `reps` launches after one warm-up): the roofline's measured denominator."""
+    import torch
+    nbytes = int(nbytes) & ~15
+    src = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    dst = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    src.fill_(1)
+    _check(lib().ilqg_copy_bandwidth(_ptr(dst), _ptr(src), C.c_size_t(nbytes), _stream()))
+    torch.cuda.synchronize()
+    best = None
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _check(lib().ilqg_copy_bandwidth(_ptr(dst), _ptr(src), C.c_size_t(nbytes), _stream()))
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)
+        best = ms if best is None or ms < best else best
+    assert bool((dst[:: max(1, nbytes // 4096)] == 1).all())
+    return 2.0 * nbytes / (best * 1e-3) / 1e9
 
 
 def device_info():
@@ -212,7 +235,8 @@ class Problem:
 
     def solve(self, x0, bufs=None, fixed_iters=0, augmented_lagrangian=False, forced_steps=None, split_trial=None,
               handoff=None, probe=None, counted=None, resume=False, active=None, compact_rows=None, round_bursts=None,
-              log_capacity=0, log_strategies=False, max_runtime=0.0, generic_kernels=None, probe_first=0, single_wave_sweep=None, adjoint_expected_decrease=None):
+              log_capacity=0, log_strategies=False, max_runtime=0.0, generic_kernels=None, probe_first=0, single_wave_sweep=None, adjoint_expected_decrease=None,
+              deterministic=False):
         """ilqg_solve_batch_ex. `bufs` (from alloc_solve_buffers) carries the warm start in and the solution out; zero
         warm start if omitted.  forced_steps [B][fixed_iters]: test mode, the given step sizes instead of the line
         search.  split_trial / handoff / probe / counted / compact_rows: None = let the library choose, True / False = force the
@@ -228,6 +252,7 @@ class Problem:
         o.fixed_iters = int(fixed_iters)
         o.augmented_lagrangian = 1 if augmented_lagrangian else 0
         o.resume = 1 if resume else 0
+        o.deterministic = 1 if deterministic else 0
         o.active = None if active is None else active.data_ptr()
         fs = None
         if forced_steps is not None:

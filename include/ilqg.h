@@ -398,15 +398,21 @@ ilqg_status ilqg_ilq_solve_batch(ilqg_problem* p, int32_t batch, const void* x0,
  * bit-identical with each other; single_wave_sweep and adjoint_expected_decrease run the same recursion as a different
  * instruction stream (sums in another order), i.e. the same results to rounding — and ILQG_CHOICE_AUTO picks them from
  * the batch size (five or more instances per CU), so an instance's last bits, and with them a line-search decision that
- * sits on a rounding threshold, can depend on the size of the batch it is solved in.  Pin the two choices (ON / OFF) for
- * results that must not; ilqg_problem_last_schedule says what the last solve ran.
+ * sits on a rounding threshold, can depend on the size of the batch it is solved in.  Set `deterministic` (or pin the two
+ * choices ON / OFF) for results that must not; ilqg_problem_last_schedule says what the last solve ran.
+ * single_wave_sweep = ON is a request: shapes the single-wave form is not built for (players with one control, n >= 16,
+ * compact rows wider than its staging row) run the player-parallel sweep, and ilqg_problem_last_schedule reports it.
  * ilqg_default_solve_options fills the defaults: reference semantics, every choice ILQG_CHOICE_AUTO. */
 typedef struct {
   int32_t fixed_iters;          /* > 0: exactly that many outer iterations per instance, convergence not tested   */
   int32_t augmented_lagrangian; /* 1: AugmentedLagrangianSolver::Solve around the inner solves                     */
   int32_t resume;               /* 1: GameSolver::Solve called again on the same solver object: the workspace
                                       holds the previous call's state (last_merit_function_value_)               */
-  int32_t reserved0;
+  int32_t deterministic;        /* 1: every ILQG_CHOICE_AUTO below resolves to a schedule that does not depend on the
+                                      batch size (the player-parallel sweep and its forward-pass expected decrease at
+                                      every batch): an instance's result is the same bits whatever batch it is solved in
+                                      (tests/test_gpu_single_wave.py).  Costs the large-batch throughput form.  (This
+                                      field was reserved0 = 0 up to ABI 6: same layout.)                              */
   const int32_t* active;        /* [B] device int32 or NULL: instances with 0 are skipped, their buffers untouched  */
   const void* forced_steps;     /* [B][fixed_iters] device (problem dtype) or NULL.  Test mode: iteration q of
                                       instance b scales its strategies by forced_steps[b][q], integrates and
@@ -610,6 +616,11 @@ ilqg_status ilqg_check_sufficient_nash_batch(const ilqg_problem* p, int32_t batc
  * MFMA accumulator-layout path the LQ sweep is built on (pins the gfx950 register layouts). */
 ilqg_status ilqg_selftest_mfma(int32_t dtype, const void* X, const void* Y, const void* C, void* out, void* stream);
 
+/* Diagnostics: a streaming 16-byte-per-lane copy of `bytes` (a multiple of 16; both buffers 16-byte aligned, device
+ * memory) on `stream` — the copy kernel SURVEY.md 8(d) asks the roofline's measured-bandwidth denominator to come from
+ * (bench.py times it with HIP events: 2 x bytes per launch / time). */
+ilqg_status ilqg_copy_bandwidth(void* dst, const void* src, size_t bytes, void* stream);
+
 /* Last HIP / validation error text of the calling thread. */
 const char* ilqg_last_error(void);
 
@@ -622,7 +633,8 @@ const char* ilqg_last_error(void);
 ilqg_status ilqg_set_scratch(void* device_buffer, size_t bytes);
 
 /* Library / device introspection (used by the loader to fail loudly). */
-#define ILQG_ABI_VERSION 6 /* 6: ilqg_problem_last_schedule;
+#define ILQG_ABI_VERSION 7 /* 7: ilqg_solve_options::deterministic (was reserved0), ilqg_copy_bandwidth;
+                              6: ilqg_problem_last_schedule;
                               5: ilqg_solve_options::iterate_log / max_runtime, run-time-dimensioned kernels behind every entry
                               point (any n <= 32, N <= 8, m_i), the affine constraints (ilqg_problem_desc::dense_params);
                               4: ilqg_cost_term::idx_extra / value2, cost kinds 12-21, dynamics kinds 10-12;

@@ -2,7 +2,7 @@
 # A/B of experiment builds (scripts/devbuild.py --tag T ...) on the GPU box: gpurun -- "PARITY_TAGS=\"t1 t2\" bash scripts/ab_variants.sh OUTDIR base t1 t2"
 # runs bench.py twice per tag (tag "base" = the product library), then scripts/quick_parity.py on the PARITY_TAGS.
 # usage: ab.sh OUTDIR tag1 tag2 ...   (tag "base" = product library); runs each twice, then quick parity on the last tag
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun (GRAFT_REPO_ROOT is unset)}" || exit 1
 O=gpurun_out/$1; shift; mkdir -p $O
 BA="${BENCH_ARGS:---no-cpu-baseline --no-latency --no-second-workload --repeats 5}"
 for rep in 1 2; do for tag in "$@"; do

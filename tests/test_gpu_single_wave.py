@@ -102,3 +102,35 @@ def test_last_schedule_reports_what_auto_chose(hip):
     prob.solve(examples.jittered_x0(spec, 5 * cus, seed=1), fixed_iters=1, single_wave_sweep=False)
     torch.cuda.synchronize()
     assert not prob.last_schedule() & abi.SCHEDULE_SINGLE_WAVE_SWEEP
+
+
+@pytest.mark.parametrize("dtype", [abi.F64, abi.F32])
+def test_deterministic_option_gives_the_same_bits_at_every_batch_size(hip, dtype):
+    """ilqg_solve_options::deterministic: no scheduling choice depends on the batch size, so the SAME 64 initial states
+    return the same bits solved alone, as rows of a 1024-instance batch and as rows of an 8192-instance batch (where
+    AUTO alone would switch to the single-wave sweep and its adjoint expected decrease) — free-running solves, line
+    searches included."""
+    import torch
+    spec = examples.modified_three_player_intersection()
+    spec.params.initial_alpha_scaling = 0.1
+    spec.params.expected_decrease_fraction = 0.001
+    spec.params.max_backtracking_steps = 100
+    spec.params.max_solver_iters = 6
+    x0 = examples.jittered_x0(spec, 8192, seed=5)
+    prob = hip.Problem(spec, dtype)
+    results = {}
+    for B in (64, 1024, 8192):
+        lo = 0 if B == 64 else 517
+        xb = x0[:B].copy()
+        xb[lo:lo + 64] = x0[:64]
+        out = prob.solve(xb, deterministic=True)
+        torch.cuda.synchronize()
+        assert not prob.last_schedule() & abi.SCHEDULE_SINGLE_WAVE_SWEEP
+        results[B] = {q: _np(out[q])[lo:lo + 64].copy() for q in ("xs", "us", "P", "alpha", "costs", "iters", "status", "converged")}
+    for B in (1024, 8192):
+        for q, v in results[64].items():
+            assert np.array_equal(v, results[B][q]), (B, q)
+    # without the option the large batch runs the other sweep (the reason the option exists)
+    prob.solve(x0, fixed_iters=1)
+    torch.cuda.synchronize()
+    assert prob.last_schedule() & abi.SCHEDULE_SINGLE_WAVE_SWEEP

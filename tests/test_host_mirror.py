@@ -423,17 +423,33 @@ def _compare_rh_run(oracle, spec, logs, tag, compare_us=False):
             assert np.max(np.abs(us - ref["us"][0, r])) < 5e-4 * max(1.0, np.max(np.abs(ref["us"][0, r]))), (tag, r)
     if div is not None:
         # the flags the device saw at the diverging call (or "gone" when it left the loop earlier than the oracle)
-        # must be an outcome the oracle itself reaches from a nudged x0
+        # must be an outcome the oracle itself reaches from a nudged x0 — counting only nudged runs that still agree
+        # with the reference run on every call before the divergence (a run that parted ways earlier says nothing
+        # about call `div`)
+        def outcome_at(num_records, iters, converged):
+            if num_records <= div:
+                return (False, -1, -1)  # left the loop before call `div`
+            return (True, int(iters[div]), int(converged[div]))
+
+        def agrees_before(run, num_records):
+            if min(num_records, R) < div:
+                return False
+            return all(int(run["iters"][0, r]) == int(ref["iters"][0, r]) and
+                       int(run["converged"][0, r]) == int(ref["converged"][0, r]) for r in range(div))
+
+        dev_outcome = outcome_at(len(logs), [g["iters"] for g in logs], [g["converged"] for g in logs])
+        ref_outcome = outcome_at(R, ref["iters"][0], ref["converged"][0])
+        assert dev_outcome != ref_outcome
         rng = np.random.default_rng(99)
-        outcomes = set()
-        for scale in (1e-12, 1e-12, 1e-12, 1e-12, 1e-11, 1e-11, 1e-10, 1e-10):
+        outcomes = {ref_outcome}
+        for scale in (1e-12, 1e-12, 1e-12, 1e-12, 1e-11, 1e-11, 1e-10, 1e-10, 1e-12, 1e-12, 1e-11, 1e-10):
             again = O.receding_horizon_simulate(abi.F64, (x0 + scale * rng.standard_normal(x0.shape))[None, :], 3.0, 0.25,
                                                 max_records=32)
             Ra = int(again["num_records"][0])
-            outcomes.add((Ra > div, int(again["iters"][0, min(div, Ra - 1)]), int(again["converged"][0, min(div, Ra - 1)])))
-        ref_outcome = (R > div, int(ref["iters"][0, min(div, R - 1)]), int(ref["converged"][0, min(div, R - 1)]))
-        assert len(outcomes | {ref_outcome}) > 1, (tag, "the device parts ways with the oracle at call", div,
-                                                    "where the oracle's own outcome is stable", ref_outcome)
+            if agrees_before(again, Ra):
+                outcomes.add(outcome_at(Ra, again["iters"][0], again["converged"][0]))
+        assert dev_outcome in outcomes, (tag, "the device parts ways with the oracle at call", div, "with", dev_outcome,
+                                         "which the oracle does not reach from nudged initial states:", sorted(outcomes))
     return upto, ref
 
 
