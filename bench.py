@@ -108,11 +108,12 @@ class HipBackend:
     single_wave = None  # ilqg_solve_options::single_wave_sweep: None = the library's choice
     split_trial = None  # ilqg_solve_options::split_trial: None = the library's choice
     adjoint = None      # ilqg_solve_options::adjoint_expected_decrease
+    static_rows = None  # ilqg_solve_options::static_rows
 
     def solve(self, x0, bufs, iters):
         self.prob.solve(x0, bufs, fixed_iters=iters, counted=self.counted, probe_first=self.probe_first,
                         single_wave_sweep=self.single_wave, split_trial=self.split_trial,
-                        adjoint_expected_decrease=self.adjoint)
+                        adjoint_expected_decrease=self.adjoint, static_rows=self.static_rows)
 
     def sync(self):
         self.torch.cuda.synchronize()
@@ -254,6 +255,8 @@ def main():
                     help="ilqg_solve_options::adjoint_expected_decrease (A/B measurements)")
     ap.add_argument("--split-trial", choices=["auto", "on", "off"], default="auto",
                     help="ilqg_solve_options::split_trial (A/B measurements)")
+    ap.add_argument("--static-rows", choices=["auto", "on", "off"], default="auto",
+                    help="ilqg_solve_options::static_rows (A/B measurements: straight-line row stage vs the interpreter)")
     ap.add_argument("--probe-first", type=int, default=0,
                     help="ilqg_solve_options::probe_first (A/B measurements of the speculative line search's ramp)")
     ap.add_argument("--no-second-workload", action="store_true",
@@ -286,6 +289,7 @@ def main():
     backend.single_wave = {"auto": None, "on": True, "off": False}[args.single_wave]
     backend.split_trial = {"auto": None, "on": True, "off": False}[args.split_trial]
     backend.adjoint = {"auto": None, "on": True, "off": False}[args.adjoint]
+    backend.static_rows = {"auto": None, "on": True, "off": False}[args.static_rows]
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -45,7 +45,7 @@ ROLE_STATE_COST, ROLE_CONTROL_COST, ROLE_STATE_CONSTRAINT, ROLE_CONTROL_CONSTRAI
 FLAG_ORIENTED, FLAG_IS_MIN, FLAG_EQUALITY = 1, 2, 4
 # ILQG_SCHEDULE_* (ilqg_problem_last_schedule)
 SCHEDULE_SINGLE_WAVE_SWEEP, SCHEDULE_ADJOINT_DECREASE, SCHEDULE_SPLIT_TRIAL, SCHEDULE_COMPACT_ROWS = 1, 2, 4, 8
-SCHEDULE_COUNTED, SCHEDULE_GENERIC, SCHEDULE_OPEN_LOOP = 16, 32, 64
+SCHEDULE_COUNTED, SCHEDULE_GENERIC, SCHEDULE_OPEN_LOOP, SCHEDULE_STATIC_ROWS = 16, 32, 64, 128
 SUM, MAX, MIN = 0, 1, 2
 
 
@@ -76,6 +76,7 @@ class SolveOptions(C.Structure):
                 ("split_trial", C.c_int32), ("handoff", C.c_int32), ("probe", C.c_int32), ("counted", C.c_int32),
                 ("compact_rows", C.c_int32), ("round_bursts", C.c_int32), ("generic_kernels", C.c_int32),
                 ("probe_first", C.c_int32), ("single_wave_sweep", C.c_int32), ("adjoint_expected_decrease", C.c_int32),
+                ("static_rows", C.c_int32), ("reserved1", C.c_int32),
                 ("iterate_log", C.POINTER(IterateLog)), ("max_runtime", C.c_double)]
 
 

@@ -20,6 +20,7 @@
 #include "ilqg_nash.hpp"
 #include "ilqg_receding.hpp"
 #include "ilqg_rowprog.hpp"
+#include "ilqg_rowprog_static.hpp"
 #include "ilqg_solve.hpp"
 #include "ilqg_stages.hpp"
 
@@ -327,7 +328,7 @@ struct TrialWaves {
 #ifndef ILQG_TRIAL_OCCUPANCY_F32
 #define ILQG_TRIAL_OCCUPANCY_F32 2
 #endif
-template <typename T, int NX, int NP, int MU, int W>
+template <typename T, int NX, int NP, int MU, int W, int PROGID = 0>
 __global__ void __launch_bounds__(64 * W, (sizeof(T) == 4 && W == 2) ? ILQG_TRIAL_OCCUPANCY_F32 : W) ilq_trial_kernel(DevProblem p, SolveArgs<T> sa) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int b = blockIdx.x;
@@ -343,7 +344,7 @@ __global__ void __launch_bounds__(64 * W, (sizeof(T) == 4 && W == 2) ? ILQG_TRIA
   }
   const short* maps = rows_maps_load(p, smem_raw);
   T* sm = reinterpret_cast<T*>(smem_raw + rows_maps_bytes(p));
-  trial_part_instance<T, NX, NP, MU, W>(p, maps, sa, b, sm);
+  trial_part_instance<T, NX, NP, MU, W, TRIAL_FUSED, PROGID>(p, maps, sa, b, sm);
 }
 
 // The same pass cut into three launches (ilqg_solve.hpp, TRIAL_ROLL / rows_part_instance / TRIAL_DECIDE), for
@@ -707,6 +708,8 @@ struct ilqg_problem {
   double* d_tnom_d = nullptr;
   int* d_cost_order = nullptr;
   int* d_row_prog = nullptr;
+  std::vector<int> row_prog_host;  // the program as built (ilqg_problem_row_program)
+  int static_prog = 0;             // id of the registered structure it matches (ilqg_rowprog_static.hpp), 0: none
   int* d_unfinished = nullptr;  // instances still running after an LQ-kernel launch
   int* h_unfinished = nullptr;  // pinned host mirror
   int mu_uniform = 0;
@@ -861,6 +864,19 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   }
   const size_t lds_trial = trial_lds_bytes<T>(d, W, sa.rows_cw);
   auto k_trial = ilq_trial_kernel<T, NX, NP, MU, W>;
+  // a registered row-program structure (ilqg_rowprog_static.hpp): the fused kernel whose row stage is straight-line
+  // code for it (compiled for chunks of ProgStatic::CW rows, state rows in registers) — same results, bit for bit
+  int static_prog = 0;
+  if (sa.rows_cw == 64 && opt.static_rows != ILQG_CHOICE_OFF) {
+#define X(ID_, NX_, NP_, MU_)                                                          \
+    if constexpr (NX_ == NX && NP_ == NP && MU_ == MU && rows_state_in_registers(NX, NP * MU)) \
+      if (p->static_prog == ID_) {                                                     \
+        k_trial = ilq_trial_kernel<T, NX, NP, MU, W, ID_>;                             \
+        static_prog = ID_;                                                             \
+      }
+    ILQG_STATIC_PROGS(X)
+#undef X
+  }
   const bool pw = C::USE_MFMA && !p->desc.params.open_loop;  // one wave per player (MFMA feedback sweep)
   // Compact rows (ilqg_common.hpp) between the row stage and the sweep: the one-tile player-parallel sweep and the
   // open-loop sweep read them; the other sweeps take the dense arrays.
@@ -972,7 +988,8 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   raise_lds_limit((const void*)k_lq, lds_lq);
   p->last_schedule = (single_wave ? ILQG_SCHEDULE_SINGLE_WAVE_SWEEP : 0) | ((single_wave && adjoint) ? ILQG_SCHEDULE_ADJOINT_DECREASE : 0) |
                      (split ? ILQG_SCHEDULE_SPLIT_TRIAL : 0) | (sa.compact ? ILQG_SCHEDULE_COMPACT_ROWS : 0) |
-                     (counted ? ILQG_SCHEDULE_COUNTED : 0) | (p->desc.params.open_loop ? ILQG_SCHEDULE_OPEN_LOOP : 0);
+                     (counted ? ILQG_SCHEDULE_COUNTED : 0) | (p->desc.params.open_loop ? ILQG_SCHEDULE_OPEN_LOOP : 0) |
+                     ((static_prog && !split) ? ILQG_SCHEDULE_STATIC_ROWS : 0);
   long long cap = al_mode ? (long long)(sa.prm.max_solver_iters + 1) * (sa.prm.unconstrained_solver_max_iters + 2)
                           : (long long)sa.prm.max_solver_iters + 2;
   if (split || counted) cap = (cap + 2) * ((long long)sa.prm.max_backtracking_steps + 3);
@@ -1527,6 +1544,18 @@ ilqg_status ilqg_copy_bandwidth(void* dst, const void* src, size_t bytes, void* 
   return ILQG_OK;
 }
 
+ilqg_status ilqg_problem_row_program(const ilqg_problem* p, int32_t* words_out, int32_t capacity, int32_t* num_words,
+                                     int32_t* static_id) {
+  if (!p || !num_words) return fail(ILQG_ERR_INVALID, "null argument");
+  *num_words = int32_t(p->row_prog_host.size());
+  if (static_id) *static_id = p->static_prog;
+  if (words_out) {
+    if (capacity < *num_words) return fail(ILQG_ERR_INVALID, "ilqg_problem_row_program: buffer too small");
+    std::memcpy(words_out, p->row_prog_host.data(), sizeof(int32_t) * p->row_prog_host.size());
+  }
+  return ILQG_OK;
+}
+
 ilqg_status ilqg_problem_last_schedule(const ilqg_problem* p, int32_t* schedule_out) {
   if (!p || !schedule_out) return fail(ILQG_ERR_INVALID, "null argument");
   *schedule_out = p->last_schedule;
@@ -1664,12 +1693,17 @@ ilqg_status ilqg_lq_openloop_batch(const ilqg_dims* d, const void* A, const void
                               : launch_lq_generic<double>(d, pt, true, A, Bm, Q, l, R, r, x0, P, alpha, dx, costates, st);
 }
 
-ilqg_status ilqg_problem_create(const ilqg_problem_desc* desc, ilqg_problem** out) {
+// `host_only`: everything ilqg_problem_create does on the host — validation, flattening, the row program and its match
+// against the registered structures — without touching a device; the handle then only serves ilqg_problem_row_program
+// and ilqg_problem_destroy (ilqg_row_program_build).
+static ilqg_status problem_create_impl(const ilqg_problem_desc* desc, ilqg_problem** out, bool host_only) {
   if (!desc || !out) return fail(ILQG_ERR_INVALID, "null argument");
   if (desc->num_players < 1 || desc->num_players > ILQG_MAX_PLAYERS) return fail(ILQG_ERR_INVALID, "bad player count");
   if (desc->T < 2 || desc->T > kMaxT) return fail(ILQG_ERR_INVALID, "bad horizon");
-  ilqg_status s = check_device();
-  if (s != ILQG_OK) return s;
+  if (!host_only) {
+    ilqg_status s = check_device();
+    if (s != ILQG_OK) return s;
+  }
   auto* p = new ilqg_problem;
   p->desc = *desc;
   DevProblem& d = p->dev;
@@ -1835,14 +1869,6 @@ ilqg_status ilqg_problem_create(const ilqg_problem_desc* desc, ilqg_problem** ou
   }
   p->terms_host.assign(desc->terms, desc->terms + desc->num_terms);
   const int npts = desc->num_polylines ? desc->polyline_offsets[desc->num_polylines] : 0;
-  hipError_t e = hipMalloc(&p->d_terms, sizeof(DevTerm) * dt.size());
-  if (e == hipSuccess) e = hipMemcpy(p->d_terms, dt.data(), sizeof(DevTerm) * dt.size(), hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMalloc(&p->d_poly_off, sizeof(int) * (desc->num_polylines + 1));
-  if (e == hipSuccess && desc->num_polylines)
-    e = hipMemcpy(p->d_poly_off, desc->polyline_offsets, sizeof(int) * (desc->num_polylines + 1), hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMalloc(&p->d_poly_pts, sizeof(float) * 2 * (npts > 0 ? npts : 1));
-  if (e == hipSuccess && npts)
-    e = hipMemcpy(p->d_poly_pts, desc->polyline_points, sizeof(float) * 2 * npts, hipMemcpyHostToDevice);
   // LineSegment2 objects of every polyline, in both precisions (line_segment2.h:55-62)
   std::vector<float> segs_f;
   std::vector<double> segs_d;
@@ -1947,6 +1973,46 @@ ilqg_status ilqg_problem_create(const ilqg_problem_desc* desc, ilqg_problem** ou
       for (int ti = 0; ti < desc->num_terms; ti++)
         if (dt[ti].player == i && dt[ti].role == role) o[1 + o[0]++] = ti;
   }
+  RowProgramHost rph;
+  {
+    std::string rerr;
+    if (!build_row_program(d, dt, desc->polyline_offsets, &rph, &rerr)) {
+      ilqg_problem_destroy(p);
+      return fail(ILQG_ERR_UNSUPPORTED, rerr);
+    }
+  }
+  d.row_prog_words = int(rph.words.size());
+  p->row_prog_host = rph.words;
+  {
+    // a registered structure (ilqg_rowprog_static.hpp)?  Word for word, parameters masked.
+    std::vector<int> masked = rph.words;
+    row_program_mask_parameters(&masked);
+#define X(ID_, NX_, NP_, MU_)                                                                                         \
+    if (p->static_prog == 0 && d.n == NX_ && d.N == NP_ && int(masked.size()) == StaticRowProg<ID_>::kWords &&         \
+        std::memcmp(masked.data(), StaticRowProg<ID_>::w, sizeof(int) * masked.size()) == 0)                          \
+      p->static_prog = ID_;
+    ILQG_STATIC_PROGS(X)
+#undef X
+  }
+  d.rp_pslots = rph.num_pslots;
+  d.rp_lslots = rph.max_lslots;
+  d.rp_gslots = rph.max_gslots;
+  d.rp_maps_off = rph.maps_off;
+  d.rp_maps_words = rph.maps_words;
+  d.rp_compact_off = rph.compact_off;
+  d.rp_compact_w = rph.compact_w;
+  if (host_only) {
+    *out = p;
+    return ILQG_OK;
+  }
+  // ---- device tables ----
+  hipError_t e = hipMalloc(&p->d_terms, sizeof(DevTerm) * dt.size());
+  if (e == hipSuccess) e = hipMalloc(&p->d_poly_off, sizeof(int) * (desc->num_polylines + 1));
+  if (e == hipSuccess && desc->num_polylines)
+    e = hipMemcpy(p->d_poly_off, desc->polyline_offsets, sizeof(int) * (desc->num_polylines + 1), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMalloc(&p->d_poly_pts, sizeof(float) * 2 * (npts > 0 ? npts : 1));
+  if (e == hipSuccess && npts)
+    e = hipMemcpy(p->d_poly_pts, desc->polyline_points, sizeof(float) * 2 * npts, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMalloc(&p->d_segs_f, sizeof(float) * (segs_f.size() + 1));
   if (e == hipSuccess && !segs_f.empty())
     e = hipMemcpy(p->d_segs_f, segs_f.data(), sizeof(float) * segs_f.size(), hipMemcpyHostToDevice);
@@ -1975,25 +2041,9 @@ ilqg_status ilqg_problem_create(const ilqg_problem_desc* desc, ilqg_problem** ou
   if (e == hipSuccess) e = hipMemcpy(p->d_terms, dt.data(), sizeof(DevTerm) * dt.size(), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMalloc(&p->d_unfinished, 4 * sizeof(int));
   if (e == hipSuccess) e = hipHostMalloc(&p->h_unfinished, 4 * sizeof(int));
-  RowProgramHost rph;
-  {
-    std::string rerr;
-    if (!build_row_program(d, dt, desc->polyline_offsets, &rph, &rerr)) {
-      ilqg_problem_destroy(p);
-      return fail(ILQG_ERR_UNSUPPORTED, rerr);
-    }
-  }
   if (e == hipSuccess) e = hipMalloc(&p->d_row_prog, sizeof(int) * rph.words.size());
   if (e == hipSuccess) e = hipMemcpy(p->d_row_prog, rph.words.data(), sizeof(int) * rph.words.size(), hipMemcpyHostToDevice);
   d.row_prog = p->d_row_prog;
-  d.row_prog_words = int(rph.words.size());
-  d.rp_pslots = rph.num_pslots;
-  d.rp_lslots = rph.max_lslots;
-  d.rp_gslots = rph.max_gslots;
-  d.rp_maps_off = rph.maps_off;
-  d.rp_maps_words = rph.maps_words;
-  d.rp_compact_off = rph.compact_off;
-  d.rp_compact_w = rph.compact_w;
   if (e != hipSuccess) {
     ilqg_problem_destroy(p);
     return fail(ILQG_ERR_HIP, std::string("problem tables: ") + hipGetErrorString(e));
@@ -2018,6 +2068,19 @@ ilqg_status ilqg_problem_create(const ilqg_problem_desc* desc, ilqg_problem** ou
   }
   *out = p;
   return ILQG_OK;
+}
+
+ilqg_status ilqg_problem_create(const ilqg_problem_desc* desc, ilqg_problem** out) { return problem_create_impl(desc, out, false); }
+
+ilqg_status ilqg_row_program_build(const ilqg_problem_desc* desc, int32_t* words_out, int32_t capacity, int32_t* num_words,
+                                   int32_t* static_id) {
+  if (!num_words) return fail(ILQG_ERR_INVALID, "null argument");
+  ilqg_problem* p = nullptr;
+  ilqg_status s = problem_create_impl(desc, &p, true);
+  if (s != ILQG_OK) return s;
+  s = ilqg_problem_row_program(p, words_out, capacity, num_words, static_id);
+  ilqg_problem_destroy(p);
+  return s;
 }
 
 void ilqg_problem_destroy(ilqg_problem* p) {

@@ -474,4 +474,25 @@ inline bool build_row_program(const DevProblem& d, const std::vector<DevTerm>& d
   return true;
 }
 
+// What a statically specialised row stage (ProgStatic<ID>, ilqg_rows.hpp) still reads at run time: the floating-point
+// parameters of the ops (weight, value), their polyline segment range / table offset, the initial values of the slots
+// and the literal constants of the compact rows' background.  Zeroing them leaves the STRUCTURE of the program: two
+// problems whose masked programs are equal word for word run the same straight-line code.
+inline void row_program_mask_parameters(std::vector<int>* words) {
+  std::vector<int>& w = *words;
+  if (w.size() < size_t(RP_HEADER)) return;
+  const int nops = (w[RP_OFF_SIDS] - w[RP_OFF_OPS]) / ROP_WORDS;
+  for (int op = 0; op < nops; op++) {
+    int* o = w.data() + w[RP_OFF_OPS] + size_t(op) * ROP_WORDS;
+    o[RO_WEIGHT] = 0; o[RO_VALUE] = 0; o[RO_POLY_FIRST] = 0;
+    if (o[RO_MODE] == ROP_CLOSEST) o[RO_PATTERN_NSEG] = 0;
+  }
+  for (int at = w[RP_OFF_PINIT] + 1; at < w[RP_OFF_LINIT]; at += RINIT_WORDS) w[at] = 0;
+  for (int at = w[RP_OFF_LINIT] + 1; at < w[RP_OFF_REGIONS]; at += RINIT_WORDS) w[at] = 0;
+  const int cb = w[RP_OFF_COMPACT], nplayers = w[RP_NUM_PASSES] - 1;
+  const int cw = w[cb + RC_W], nbg = w[cb + RC_NBG];
+  const int bg0 = cb + RC_BASE + (nplayers + 1) + cw;
+  for (int e = 0; e < nbg; e++) w[bg0 + e * RC_BG_WORDS + 2] = 0;
+}
+
 }  // namespace ilqg

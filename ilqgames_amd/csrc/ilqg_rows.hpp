@@ -26,6 +26,7 @@
 #pragma once
 
 #include <type_traits>
+#include <utility>
 
 #include "ilqg_common.hpp"
 #include "ilqg_models.hpp"
@@ -479,6 +480,67 @@ __device__ __forceinline__ Closest<T> polyline_closest_rows(typename ConstPtr<T>
   return out;
 }
 
+// ---- where a chunk reads its program from ----
+// ProgDynamic: the row program built by ilqg_problem_create, in scalar memory — the interpreter: one loop over the ops,
+// every field of an op read out of its descriptor at run time.
+// ProgStatic<ID>: the STRUCTURE of the program (passes, op modes, kinds, indices, flags, slot ids, merit lists, compact
+// bases: everything but floating-point parameters and polyline ranges) is a compile-time table (StaticRowProg<ID>,
+// ilqg_rowprog_static.hpp, generated from build_row_program's output for a known problem structure): the op loop is
+// unrolled into straight-line code with every kind switch folded, every slot an LDS immediate offset and every state
+// entry a direct register read.  The PARAMETERS (weights, nominal values, thresholds, regularisation, polyline segment
+// ranges) are still read from the run-time program, so any problem with the same structure — other weights, other lane
+// geometry — runs the same code.  ilqg_problem_create matches the program it built against the registered structures
+// word for word (parameters masked, row_program_mask_parameters); anything else runs the interpreter.  Both produce the
+// same bits: the same expressions in the same order on the same data (tests/test_gpu_parity.py).
+struct ProgDynamic { static constexpr bool STATIC = false; static constexpr int CW = 0; };
+template <int ID> struct StaticRowProg;  // { static constexpr int kWords, w[kWords]; } per registered structure
+template <int ID> struct ProgStatic {
+  static constexpr bool STATIC = true;
+  static constexpr int CW = 64;  // the chunk width the static code is compiled for (slot offsets are immediates)
+  typedef StaticRowProg<ID> S;
+};
+
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, E>(f);
+  }
+}
+
+// An op's descriptor.  field<F>(): a structural field (compile-time under ProgStatic); param<F>(): a parameter field
+// (always run time); sid(e): the e-th inline slot id.
+struct OpDynamic {
+  int words;  // the descriptor, word w in lane w
+  template <int F> __device__ __forceinline__ int field() const { return __builtin_amdgcn_readlane(words, F); }
+  template <int F> __device__ __forceinline__ int param() const { return __builtin_amdgcn_readlane(words, F); }
+  __device__ __forceinline__ SidsInline sids() const { return SidsInline{words, ROP_FIELDS}; }
+};
+template <class S, int OP>
+struct SidsStatic {
+  __device__ __forceinline__ constexpr int operator[](int e) const { return S::w[S::w[RP_OFF_OPS] + OP * ROP_WORDS + ROP_FIELDS + e]; }
+};
+template <class S, int OP>
+struct OpStatic {
+  rp_cptr rt;  // this op's descriptor in the run-time program (parameters)
+  template <int F> __device__ __forceinline__ constexpr int field() const {
+    constexpr int v = S::w[S::w[RP_OFF_OPS] + OP * ROP_WORDS + F];
+    return v;
+  }
+  template <int F> __device__ __forceinline__ int param() const { return rt[F]; }
+  __device__ __forceinline__ SidsStatic<S, OP> sids() const { return SidsStatic<S, OP>{}; }
+};
+struct PassDynamic {
+  int op_begin, op_end, reg_begin, reg_end, li_begin, li_count, pkind, player, li_grad;
+};
+template <class S, int PS>
+struct PassStatic {
+  static constexpr int b = S::w[RP_OFF_PASS] + PS * RPASS_WORDS;
+  static constexpr int op_begin = S::w[b + 0], op_end = S::w[b + 1], reg_begin = S::w[b + 2], reg_end = S::w[b + 3],
+                       li_begin = S::w[b + 4], li_count = S::w[b + 5], pkind = S::w[b + 6], player = S::w[b + 7],
+                       li_grad = S::w[b + 8];
+};
+
 // One chunk: rows [k0, k0 + nrows), nrows <= cw, executed by ONE wavefront (`lane` of 64) with its own LDS `sm`
 // (rows_lds_elems for this cw: 64, 32 or 16).  `maps` is the workgroup's LDS copy of the program's word maps
 // (rows_maps_load).  What is produced follows QuadArgs: A / Bm (null: skip the Jacobians), Q / l / R / r (null: not
@@ -490,27 +552,36 @@ __device__ __forceinline__ Closest<T> polyline_closest_rows(typename ConstPtr<T>
 // GRAD_ONLY: a merit-only evaluation (the probing passes of the line search: merit_part, nothing else): no Hessian
 // entry is formed or stored, and the scratch holds the persistent slots and each pass's gradient slots only — the row
 // program numbers those first (rows_lds_elems_grad).
-template <typename T, int CN_, int CM_, int CNP_, bool XREG = false, bool GRAD_ONLY = false>
+// PROG: ProgDynamic (the interpreter) or ProgStatic<ID> (straight-line code for a registered structure; cw must be
+// PROG::CW).
+template <typename T, int CN_, int CM_, int CNP_, bool XREG = false, bool GRAD_ONLY = false, class PROG = ProgDynamic>
 __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* maps, const QuadArgs<T>& a, int k0,
-                                           int nrows, int cw, T* sm, int lane) {
+                                           int nrows, int cw_arg, T* sm, int lane) {
   constexpr bool RT = CN_ == 0;
+  constexpr bool ST = PROG::STATIC;
   static_assert(!XREG || (CN_ > 0 && CN_ <= 16 && CM_ <= 16), "register-held rows: compile-time n, m <= 16");
   const int CN = RT ? p.n : CN_, CM = RT ? p.m : CM_, CNP = RT ? p.N : CNP_;
   const int NA = CN + CM;
+  const int cw = ST ? PROG::CW : cw_arg;
   const int cws = cw + 1;
   T* const arg = sm;
   T* const acc = sm + (XREG ? 0 : NA) * cw;
   typedef typename std::conditional<XREG, MixArg<T>, RowArg<T>>::type Arg;
   const rp_cptr rp = (rp_cptr)p.row_prog;
   const typename ConstPtr<T>::type segs = (typename ConstPtr<T>::type)problem_segs<T>(p);
-  const int num_passes = rp[RP_NUM_PASSES], NPS = rp[RP_NUM_PSLOTS];
-  const rp_cptr passes = rp + rp[RP_OFF_PASS];
-  const rp_cptr ops = rp + rp[RP_OFF_OPS];
-  const rp_cptr sids = rp + rp[RP_OFF_SIDS];
-  const rp_cptr pinit = rp + rp[RP_OFF_PINIT];
-  const rp_cptr linit = rp + rp[RP_OFF_LINIT];
-  const rp_cptr regions = rp + rp[RP_OFF_REGIONS];
-  const rp_cptr merit = rp + rp[RP_OFF_MERIT];
+  // table offsets: compile-time under ProgStatic (the run-time program has the same layout: it matched word for word)
+  auto hdr = [&](auto f) -> int {
+    if constexpr (ST) { constexpr int v = PROG::S::w[decltype(f)::value]; return v; } else return rp[decltype(f)::value];
+  };
+#define ILQG_RP_HDR(F) hdr(std::integral_constant<int, F>{})
+  const int num_passes = ILQG_RP_HDR(RP_NUM_PASSES), NPS = ILQG_RP_HDR(RP_NUM_PSLOTS);
+  const rp_cptr passes = rp + ILQG_RP_HDR(RP_OFF_PASS);
+  const rp_cptr ops = rp + ILQG_RP_HDR(RP_OFF_OPS);
+  const rp_cptr sids = rp + ILQG_RP_HDR(RP_OFF_SIDS);
+  const rp_cptr pinit = rp + ILQG_RP_HDR(RP_OFF_PINIT);
+  const rp_cptr linit = rp + ILQG_RP_HDR(RP_OFF_LINIT);
+  const rp_cptr regions = rp + ILQG_RP_HDR(RP_OFF_REGIONS);
+  const rp_cptr merit = rp + ILQG_RP_HDR(RP_OFF_MERIT);
   const bool quad_out = !GRAD_ONLY && (a.Q != nullptr || (a.compact != nullptr && a.compact_quad));
   const bool do_quad = quad_out || a.merit_part != nullptr;
   const bool want_cost = !GRAD_ONLY && a.cost_part != nullptr;
@@ -582,9 +653,8 @@ __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* map
   }
   const double tt = double(row) * p.dt;
   const int tidx = int(static_cast<size_t>((tt - a.t_init) / p.dt));  // relative_time_tracker.h:69-72
-  auto init_value = [&](rp_cptr rec) -> T {
-    const int code = rec[0];
-    const T val = T(__int_as_float(rec[1]));
+  auto init_value = [&](int code, int valbits) -> T {
+    const T val = T(__int_as_float(valbits));
     const int kind = code & 255, pl = (code >> 8) & 255;
     if (kind == RI_DT) return T(p.dt);
     if (kind == RI_NEG_DT) return T(-p.dt);
@@ -592,7 +662,15 @@ __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* map
       return (((full >> pl) & 1u) || ((code >> 16) & 1)) ? val : T(0);
     return val;  // 0, 1, sigma_x (player_cost.cpp:196)
   };
-  for (int s = 0; s < NPS; s++) col[s * cws] = init_value(pinit + s * RINIT_WORDS);
+  if constexpr (ST) {
+    static_for<0, PROG::S::w[RP_NUM_PSLOTS]>([&](auto sc) {
+      constexpr int s = decltype(sc)::value;
+      constexpr int code = PROG::S::w[PROG::S::w[RP_OFF_PINIT] + s * RINIT_WORDS];
+      col[s * cws] = init_value(code, pinit[s * RINIT_WORDS + 1]);
+    });
+  } else {
+    for (int s = 0; s < NPS; s++) col[s * cws] = init_value(pinit[s * RINIT_WORDS], pinit[s * RINIT_WORDS + 1]);
+  }
   tl_stamp(a.tl, a.tl_b, 41, lane == 0);
   Closest<T> cc;  // result of the pass's last CLOSEST op
   cc.cx = cc.cy = cc.ssd = T(0);
@@ -600,42 +678,46 @@ __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* map
   cc.seg = Seg<T>{T(0), T(0), T(0), T(0), T(1), T(1), T(0)};
   ILQG_QPH(0);
 
-#pragma unroll 1
-  for (int ps = 0; ps < num_passes; ps++) {
-    const rp_cptr pr = passes + ps * RPASS_WORDS;
-    const int op_begin = pr[0], op_end = pr[1], reg_begin = pr[2], reg_end = pr[3], li_begin = pr[4], li_count = pr[5];
-    const int pkind = pr[6], player = pr[7];
-    if (GRAD_ONLY && pkind == RPASS_JACOBIANS) continue;
-    if (pkind == RPASS_JACOBIANS && a.A == nullptr && !(a.compact && a.compact_lin)) continue;
-    if (pkind == RPASS_PLAYER && !do_quad && !want_cost) continue;
+  // ---- one pass: `pd` is a PassDynamic (run-time fields) or a PassStatic<S, PS> (compile-time fields) ----
+  auto run_pass = [&](auto pd, int ps) {
+    typedef decltype(pd) PD;
+    const int op_begin = pd.op_begin, op_end = pd.op_end, reg_begin = pd.reg_begin, reg_end = pd.reg_end,
+              li_begin = pd.li_begin, li_count = pd.li_count;
+    const int pkind = pd.pkind, player = pd.player;
+    if (GRAD_ONLY && pkind == RPASS_JACOBIANS) return;
+    if (pkind == RPASS_JACOBIANS && a.A == nullptr && !(a.compact && a.compact_lin)) return;
+    if (pkind == RPASS_PLAYER && !do_quad && !want_cost) return;
     T ctot = T(0);  // PlayerCost::Evaluate of this pass's player at this lane's row
     T ext_value = T(0);  // ExtremeValueCost in flight: its value and active child at this lane's row
     int ext_best = 0;
     {
-      const int li_live = GRAD_ONLY ? pr[8] : li_count;  // GRAD_ONLY: the pass's gradient slots, numbered first
-      for (int s = 0; s < li_live; s++) col[(NPS + s) * cws] = init_value(linit + (li_begin + s) * RINIT_WORDS);
-      // An op's descriptor (ROP_WORDS words) is fetched as ONE vector load, word w by lane w, one op ahead, and its
-      // fields are read out through v_readlane: scalar loads of the descriptor count on lgkmcnt together with the LDS
-      // traffic of the op before and return out of order, so every decode drained the accumulators' read-modify-writes
-      // and then waited a scalar-cache round trip.
-      static_assert(ROP_WORDS <= 64, "an op descriptor is one word per lane");
-      const int* const opsv = reinterpret_cast<const int*>(p.row_prog) + rp[RP_OFF_OPS];
-      int next_words = (lane < ROP_WORDS && op_begin < op_end) ? opsv[op_begin * ROP_WORDS + lane] : 0;
-#pragma unroll 1
-      for (int op = op_begin; op < op_end; op++) {
-        const int words = next_words;
-        if (op + 1 < op_end) next_words = lane < ROP_WORDS ? opsv[(op + 1) * ROP_WORDS + lane] : 0;
-        auto od = [&](int f) { return __builtin_amdgcn_readlane(words, f); };
-        const int mode = od(RO_MODE);
-        const int nsid = od(RO_NSID), aux = od(RO_AUX);
+      const int li_live = GRAD_ONLY ? pd.li_grad : li_count;  // GRAD_ONLY: the pass's gradient slots, numbered first
+      if constexpr (ST) {
+        static_for<0, (GRAD_ONLY ? PD::li_grad : PD::li_count)>([&](auto sc) {
+          constexpr int s = decltype(sc)::value;
+          constexpr int code = PROG::S::w[PROG::S::w[RP_OFF_LINIT] + (PD::li_begin + s) * RINIT_WORDS];
+          col[(PROG::S::w[RP_NUM_PSLOTS] + s) * cws] = init_value(code, linit[(PD::li_begin + s) * RINIT_WORDS + 1]);
+        });
+      } else {
+        for (int s = 0; s < li_live; s++)
+          col[(NPS + s) * cws] = init_value(linit[(li_begin + s) * RINIT_WORDS], linit[(li_begin + s) * RINIT_WORDS + 1]);
+      }
+      // ---- one op: `od` is an OpDynamic or an OpStatic<S, OP> ----
+      auto run_op = [&](auto od) {
+        const int mode = od.template field<RO_MODE>();
+        const int nsid = od.template field<RO_NSID>(), aux = od.template field<RO_AUX>();
         const bool sid_inline = nsid <= ROP_INLINE_SIDS;
-        const SidsInline sid{words, ROP_FIELDS};
+        const auto sid = od.sids();
         DevTerm c;
-        c.kind = od(RO_KIND); c.role = od(RO_ROLE); c.player = od(RO_PLAYER); c.flags = od(RO_FLAGS);
-        c.idx[0] = od(RO_IDX0); c.idx[1] = od(RO_IDX1); c.idx[2] = od(RO_IDX2); c.idx[3] = od(RO_IDX3);
-        c.weight = __int_as_float(od(RO_WEIGHT)); c.value = __int_as_float(od(RO_VALUE));
-        c.polyline = od(RO_POLY_FIRST); c.slot = od(RO_SLOT); c.arg_off = od(RO_ARG_OFF); c.arg_dim = od(RO_ARG_DIM);
-        c.k_start = od(RO_K_START);
+        c.kind = od.template field<RO_KIND>(); c.role = od.template field<RO_ROLE>(); c.player = od.template field<RO_PLAYER>();
+        c.flags = od.template field<RO_FLAGS>();
+        c.idx[0] = od.template field<RO_IDX0>(); c.idx[1] = od.template field<RO_IDX1>();
+        c.idx[2] = od.template field<RO_IDX2>(); c.idx[3] = od.template field<RO_IDX3>();
+        c.weight = __int_as_float(od.template param<RO_WEIGHT>()); c.value = __int_as_float(od.template param<RO_VALUE>());
+        c.slot = od.template field<RO_SLOT>(); c.arg_off = od.template field<RO_ARG_OFF>();
+        c.arg_dim = od.template field<RO_ARG_DIM>();
+        c.k_start = od.template field<RO_K_START>();
+        c.polyline = od.template param<RO_POLY_FIRST>();  // segment range / table offset / WeightedConvexProximity's packed indices
         c.arg = 0; c.child_begin = 0; c.child_count = 0;
         if (mode == ROP_JACOBIAN) {
           // ---- ConcatenatedDynamicalSystem::Linearize, one subsystem (src/concatenated_dynamical_system.cpp:86-107):
@@ -649,7 +731,7 @@ __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* map
                                                    kind == ILQG_DYN_AIR_3D_EVADER ? 1 : 4, -1);
           auto put = [&](int e, T val) { if (e < nsid) col[sid[e] * cws] = val; };
           if (kind == ILQG_DYN_POINT_MASS_2D || kind == ILQG_DYN_PLANAR_DISTURBANCE || kind == ILQG_DYN_AIR_3D_PURSUER)
-            continue;  // constants only
+            return;  // constants only
           T sth, cth;
           t_sincos(x[2], &sth, &cth);
           const T ct = T(double(cth) * p.dt), st = T(double(sth) * p.dt);
@@ -686,23 +768,23 @@ __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* map
               }
             }
           }
-          continue;
+          return;
         }
         const Arg v = rows_make_arg<T, XREG, XW, UW>(xrow, urow, xg, ug, arg, cw, CN, c.arg_off, rl, c.idx[0], c.idx[1], c.idx[2], c.idx[3]);
         if (mode == ROP_AFFINE) {
           // constraints are quadraticised with the player's full PlayerCost::Quadraticize only (:483-487), from their
           // first active step on (FinalTimeConstraint)
           const bool deriv = do_quad && row >= c.k_start && ((full >> c.player) & 1u);
-          if (!__any(deriv)) continue;
+          if (!__any(deriv)) return;
           const T lambda = (c.slot >= 0 && a.lambdas) ? a.lambdas[c.slot * p.T + tidx] : T(0);
           if (deriv)
-            rows_affine<T>(c.kind, (c.flags & ILQG_FLAG_EQUALITY) != 0, problem_dense<T>(p) + od(RO_POLY_FIRST), c.arg_dim,
-                           SidsTable{sids + od(RO_SID)}, col, cws, v, lambda, a.mu, quad_out);
-          continue;
+            rows_affine<T>(c.kind, (c.flags & ILQG_FLAG_EQUALITY) != 0, problem_dense<T>(p) + od.template param<RO_POLY_FIRST>(), c.arg_dim,
+                           SidsTable{sids + od.template field<RO_SID>()}, col, cws, v, lambda, a.mu, quad_out);
+          return;
         }
         if (mode == ROP_CLOSEST) {
-          cc = polyline_closest_rows<T>(segs, od(RO_POLY_FIRST), od(RO_PATTERN_NSEG), v[c.idx[0]], v[c.idx[1]]);
-          continue;
+          cc = polyline_closest_rows<T>(segs, od.template param<RO_POLY_FIRST>(), od.template param<RO_PATTERN_NSEG>(), v[c.idx[0]], v[c.idx[1]]);
+          return;
         }
 #if ILQG_PROFILE2
         ILQG_QPH(1);
@@ -711,7 +793,7 @@ __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* map
         const bool live = row >= c.k_start;  // FinalTimeCost: nothing before its threshold
         const bool deriv = do_quad && live && (((full >> c.player) & 1u) || c.role == ILQG_ROLE_CONTROL_COST);
         const bool need = deriv || (want_cost && is_cost && live);
-        if (!__any(need)) continue;
+        if (!__any(need)) return;
         const T lambda = (c.slot >= 0 && a.lambdas) ? a.lambdas[c.slot * p.T + tidx] : T(0);
 #if ILQG_PROFILE2
         ILQG_QPH(2);
@@ -719,7 +801,7 @@ __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* map
         TermOut<T> o;
         double tnom[2] = {0.0, 0.0};
         if (term_is_time_dependent(c.kind)) {  // this row's nominal; the op's RO_POLY_FIRST field is the term's table
-          const double* tn = problem_time_nominal<T>(p) + (size_t(od(RO_POLY_FIRST)) * p.T + row) * 2;
+          const double* tn = problem_time_nominal<T>(p) + (size_t(od.template param<RO_POLY_FIRST>()) * p.T + row) * 2;
           tnom[0] = tn[0];
           tnom[1] = tn[1];
         }
@@ -735,7 +817,7 @@ __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* map
             ext_value = o.value;
             ext_best = aux;
           }
-          continue;
+          return;
         }
         if (mode == ROP_EXT_APPLY) {
           if (aux == 0 && is_cost && live) ctot += ext_value;
@@ -745,31 +827,64 @@ __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* map
         }
         if (act) {
           if (sid_inline)
-            rows_scatter<T>(od(RO_PATTERN_NSEG), o, sid, nsid, col, cws, v, quad_out);
+            rows_scatter<T>(od.template field<RO_PATTERN_NSEG>(), o, sid, nsid, col, cws, v, quad_out);
           else
-            rows_scatter<T>(od(RO_PATTERN_NSEG), o, SidsTable{sids + od(RO_SID)}, nsid, col, cws, v, quad_out);
+            rows_scatter<T>(od.template field<RO_PATTERN_NSEG>(), o, SidsTable{sids + od.template field<RO_SID>()}, nsid, col, cws, v, quad_out);
         }
 #if ILQG_PROFILE2
         ILQG_QPH(4);
 #endif
+      };
+      if constexpr (ST) {
+        static_for<PD::op_begin, PD::op_end>([&](auto opc) {
+          constexpr int OP = decltype(opc)::value;
+          run_op(OpStatic<typename PROG::S, OP>{ops + OP * ROP_WORDS});
+        });
+      } else {
+        // An op's descriptor (ROP_WORDS words) is fetched as ONE vector load, word w by lane w, one op ahead, and its
+        // fields are read out through v_readlane: scalar loads of the descriptor count on lgkmcnt together with the LDS
+        // traffic of the op before and return out of order, so every decode drained the accumulators' read-modify-writes
+        // and then waited a scalar-cache round trip.
+        static_assert(ROP_WORDS <= 64, "an op descriptor is one word per lane");
+        const int* const opsv = reinterpret_cast<const int*>(p.row_prog) + rp[RP_OFF_OPS];
+        int next_words = (lane < ROP_WORDS && op_begin < op_end) ? opsv[op_begin * ROP_WORDS + lane] : 0;
+#pragma unroll 1
+        for (int op = op_begin; op < op_end; op++) {
+          const int words = next_words;
+          if (op + 1 < op_end) next_words = lane < ROP_WORDS ? opsv[(op + 1) * ROP_WORDS + lane] : 0;
+          run_op(OpDynamic{words});
+        }
       }
       if (pkind == RPASS_PLAYER && valid) {
         if (want_cost) a.cost_part[size_t(row) * CNP + player] = ctot;
         if (a.merit_part) {
           // pieces of ILQSolver::MeritFunction (:419-430): |r_ii|^2 and |l_i|^2 of this lane's row.  Entries no term
           // touches are exact zeros, so the sums over the touched slots (in index order) are the reference's sums.
-          const rp_cptr md = merit + player * RMERIT_WORDS;
-          const rp_cptr ls = sids + md[0];
-          const rp_cptr rs = sids + md[2];
-          const int lcnt = md[1], rcnt = md[3];
           T s1 = T(0), s2 = T(0);
-          for (int d = 0; d < rcnt; d++) {
-            const T rv = col[rs[d] * cws];
-            s1 += rv * rv;
-          }
-          for (int d = 0; d < lcnt; d++) {
-            const T lv = col[ls[d] * cws];
-            s2 += lv * lv;
+          if constexpr (ST) {
+            typedef typename PROG::S S;
+            constexpr int mb = S::w[RP_OFF_MERIT] + PD::player * RMERIT_WORDS, sb = S::w[RP_OFF_SIDS];
+            static_for<0, S::w[mb + 3]>([&](auto dc) {
+              const T rv = col[S::w[sb + S::w[mb + 2] + decltype(dc)::value] * cws];
+              s1 += rv * rv;
+            });
+            static_for<0, S::w[mb + 1]>([&](auto dc) {
+              const T lv = col[S::w[sb + S::w[mb + 0] + decltype(dc)::value] * cws];
+              s2 += lv * lv;
+            });
+          } else {
+            const rp_cptr md = merit + player * RMERIT_WORDS;
+            const rp_cptr ls = sids + md[0];
+            const rp_cptr rs = sids + md[2];
+            const int lcnt = md[1], rcnt = md[3];
+            for (int d = 0; d < rcnt; d++) {
+              const T rv = col[rs[d] * cws];
+              s1 += rv * rv;
+            }
+            for (int d = 0; d < lcnt; d++) {
+              const T lv = col[ls[d] * cws];
+              s2 += lv * lv;
+            }
           }
           a.merit_part[(size_t(row) * CNP + player) * 2 + 0] = s1;
           a.merit_part[(size_t(row) * CNP + player) * 2 + 1] = s2;
@@ -812,8 +927,17 @@ __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* map
     }
     if (!GRAD_ONLY && a.compact && (pkind == RPASS_PLAYER ? a.compact_quad : a.compact_lin)) {
       // compact row: this pass's local slots, in slot order, at the pass's base (lane = slot, loop = row)
-      const rp_cptr cb = rp + rp[RP_OFF_COMPACT];
-      const int CWD = cb[RC_W], base = cb[RC_BASE + (pkind == RPASS_PLAYER ? 1 + player : 0)];
+      int CWD, base;
+      if constexpr (ST) {
+        typedef typename PROG::S S;
+        constexpr int cbo = S::w[RP_OFF_COMPACT];
+        CWD = S::w[cbo + RC_W];
+        base = S::w[cbo + RC_BASE + (PD::pkind == RPASS_PLAYER ? 1 + PD::player : 0)];
+      } else {
+        const rp_cptr cb = rp + rp[RP_OFF_COMPACT];
+        CWD = cb[RC_W];
+        base = cb[RC_BASE + (pkind == RPASS_PLAYER ? 1 + player : 0)];
+      }
       T* const g0 = a.compact + size_t(k0) * CWD + base;
       constexpr int RB = 8;
       for (int s0 = 0; s0 < li_count; s0 += 64) {
@@ -837,8 +961,20 @@ __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* map
 #else
     ILQG_QPH(5);
 #endif
+  };
+  if constexpr (ST) {
+    static_for<0, PROG::S::w[RP_NUM_PASSES]>([&](auto psc) {
+      run_pass(PassStatic<typename PROG::S, decltype(psc)::value>{}, decltype(psc)::value);
+    });
+  } else {
+#pragma unroll 1
+    for (int ps = 0; ps < num_passes; ps++) {
+      const rp_cptr pr = passes + ps * RPASS_WORDS;
+      run_pass(PassDynamic{pr[0], pr[1], pr[2], pr[3], pr[4], pr[5], pr[6], pr[7], pr[8]}, ps);
+    }
   }
 #undef ILQG_QPH
+#undef ILQG_RP_HDR
 }
 
 // The word maps of the row program, copied into LDS once per workgroup (every thread calls, then syncs): the

@@ -709,7 +709,11 @@ __device__ __forceinline__ void roll_pair_instances(const DevProblem& p, const S
   if (g1) state_store<T>(ib1.w, ib1.L, s1);
 }
 
-template <typename T, int NX, int NP, int MU, int W, int PHASE = TRIAL_FUSED>
+template <int ID> struct RowProgSel { typedef ProgStatic<ID> type; };
+template <> struct RowProgSel<0> { typedef ProgDynamic type; };
+
+// PROGID: 0 = the row stage interprets the problem's row program; k = straight-line code for registered structure k
+template <typename T, int NX, int NP, int MU, int W, int PHASE = TRIAL_FUSED, int PROGID = 0>
 __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const short* maps,
                                                     const SolveArgs<T>& sa, int b, T* sm) {
   static_assert(PHASE == TRIAL_FUSED || W == 1, "the split phases run one wave per instance");
@@ -819,8 +823,9 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const s
         while (progress_observe(&flags[0]) < k0 + nrows) __builtin_amdgcn_s_sleep(8);
         if (kProfile && sa.prof) { const long long tq1 = clock64(); qph[6] += tq1 - tq0; }
         tl_stamp(sa.prof, b, 4 + 2 * (c < 3 ? c : 3), lane == 0);
-        // (the register-held rows of the split kernels gain nothing here — measured, B = 1024: 1.45 -> 1.435 M it/s)
-        rows_chunk<T, NX, NP * MU, NP>(p, maps, qa, k0, nrows, cw, sm_quad, lane);
+        // (the register-held rows of the split kernels gain nothing for the interpreter here — measured, B = 1024: 1.45 ->
+        // 1.435 M it/s; the static form reads its entries straight out of them)
+        rows_chunk<T, NX, NP * MU, NP, (PROGID != 0), false, typename RowProgSel<PROGID>::type>(p, maps, qa, k0, nrows, cw, sm_quad, lane);
         tl_stamp(sa.prof, b, 5 + 2 * (c < 3 ? c : 3), lane == 0);
         if (kProfile && sa.prof) { tq0 = clock64(); qph[7] += 1; }
       }

@@ -23,7 +23,7 @@ EXPORTS = [
     "ilqg_solution_splice_batch", "ilqg_solve_again_batch", "ilqg_strategy_costs_batch",
     "ilqg_check_local_nash_batch", "ilqg_check_sufficient_nash_batch",
     "ilqg_receding_horizon_shift_batch", "ilqg_default_solve_options", "ilqg_solve_batch_ex", "ilqg_solve_state_batch",
-    "ilqg_set_scratch", "ilqg_problem_last_schedule", "ilqg_copy_bandwidth",
+    "ilqg_set_scratch", "ilqg_problem_last_schedule", "ilqg_copy_bandwidth", "ilqg_problem_row_program", "ilqg_row_program_build",
 ]
 
 
@@ -148,6 +148,19 @@ def lq_feedback(dims, A, Bm, Q, l, R, r, pairs, x0=None, want_dx=True, open_loop
     return (P, alpha, dx, co) if want_costates else (P, alpha, dx)
 
 
+def row_program_build(spec, dtype=abi.F64):
+    """ilqg_row_program_build: (int32 words of the row program the library builds for `spec`, id of the registered
+    structure it matches or 0) — host only, no device needed."""
+    import numpy as np
+    desc, keep = spec.build(dtype)
+    n, sid = C.c_int32(0), C.c_int32(0)
+    _check(lib().ilqg_row_program_build(C.byref(desc), None, 0, C.byref(n), C.byref(sid)))
+    w = np.zeros(n.value, np.int32)
+    _check(lib().ilqg_row_program_build(C.byref(desc), w.ctypes.data_as(C.c_void_p), n.value, C.byref(n), C.byref(sid)))
+    del keep
+    return w, int(sid.value)
+
+
 class Problem:
     """Owns an ilqg_problem* (device tables of one reference `Problem`)."""
 
@@ -236,7 +249,7 @@ class Problem:
     def solve(self, x0, bufs=None, fixed_iters=0, augmented_lagrangian=False, forced_steps=None, split_trial=None,
               handoff=None, probe=None, counted=None, resume=False, active=None, compact_rows=None, round_bursts=None,
               log_capacity=0, log_strategies=False, max_runtime=0.0, generic_kernels=None, probe_first=0, single_wave_sweep=None, adjoint_expected_decrease=None,
-              deterministic=False):
+              deterministic=False, static_rows=None):
         """ilqg_solve_batch_ex. `bufs` (from alloc_solve_buffers) carries the warm start in and the solution out; zero
         warm start if omitted.  forced_steps [B][fixed_iters]: test mode, the given step sizes instead of the line
         search.  split_trial / handoff / probe / counted / compact_rows: None = let the library choose, True / False = force the
@@ -267,6 +280,7 @@ class Problem:
         o.probe_first = int(probe_first)
         o.single_wave_sweep = tri(self.single_wave_sweep if single_wave_sweep is None else single_wave_sweep)
         o.adjoint_expected_decrease = tri(adjoint_expected_decrease)
+        o.static_rows = tri(static_rows)
         o.max_runtime = float(max_runtime)
         il = None
         if log_capacity > 0:
@@ -297,6 +311,15 @@ class Problem:
                                             _ptr(out["last_merit"]), _ptr(out["expected_decrease"]),
                                             _ptr(out["step"]), _ptr(out["backtracks"]), _stream()))
         return out
+
+    def row_program(self):
+        """ilqg_problem_row_program: (int32 words of the row program as built, id of the registered structure or 0)."""
+        import numpy as np
+        n, sid = C.c_int32(0), C.c_int32(0)
+        _check(lib().ilqg_problem_row_program(self.h, None, 0, C.byref(n), C.byref(sid)))
+        w = np.zeros(n.value, np.int32)
+        _check(lib().ilqg_problem_row_program(self.h, w.ctypes.data_as(C.c_void_p), n.value, C.byref(n), C.byref(sid)))
+        return w, int(sid.value)
 
     def last_schedule(self):
         """ilqg_problem_last_schedule: the ILQG_SCHEDULE_* bits of the last solve on this problem."""

@@ -436,6 +436,11 @@ typedef struct {
                                      adjoint recursion inside the sweep, instead of leaving scratch rows for a forward pass
                                      in the next trial pass (AUTO: where the trial pass is split and has no wave to spare
                                      for one).  Same value up to the order of summation.                                */
+  int32_t static_rows;          /* ilqg_choice: a problem whose row program matches a registered structure
+                                     (ilqg_problem_row_program) runs the linearise / quadraticise stage of the fused trial
+                                     kernel as straight-line code compiled for that structure instead of interpreting the
+                                     program (AUTO: on).  Bit-identical.                                                */
+  int32_t reserved1;
   const struct ilqg_iterate_log* iterate_log; /* NULL, or where every logged iterate of the solve goes (below)          */
   double max_runtime;           /* > 0: the anytime exit of ILQSolver::Solve (src/ilq_solver.cpp:123-124) on the host's
                                      clock, seconds — once it has passed, instances leave the loop at their next
@@ -488,7 +493,18 @@ ilqg_status ilqg_solve_state_batch(const ilqg_problem* p, int32_t batch, const v
 #define ILQG_SCHEDULE_COUNTED 16            /* host-counted rounds (hand-off, speculative line search)            */
 #define ILQG_SCHEDULE_GENERIC 32            /* the run-time-dimensioned kernels                                   */
 #define ILQG_SCHEDULE_OPEN_LOOP 64          /* LQOpenLoopSolver's sweep                                           */
+#define ILQG_SCHEDULE_STATIC_ROWS 128       /* the row stage ran as straight-line code for a registered structure */
 ilqg_status ilqg_problem_last_schedule(const ilqg_problem* p, int32_t* schedule_out);
+
+/* The row program ilqg_problem_create compiled the problem's dynamics and cost list into (csrc/ilqg_rowprog.hpp: passes,
+ * ops, slot ids, word maps; host memory, int32 words) and the id of the registered structure it matches (0: none — the
+ * row stage interprets it).  words_out may be NULL to ask for the size only. */
+ilqg_status ilqg_problem_row_program(const ilqg_problem* p, int32_t* words_out, int32_t capacity, int32_t* num_words,
+                                     int32_t* static_id);
+/* The same straight from a description, on the host alone: everything ilqg_problem_create validates and builds before
+ * it uploads tables, without a device (the one entry point that works without one). */
+ilqg_status ilqg_row_program_build(const ilqg_problem_desc* desc, int32_t* words_out, int32_t capacity, int32_t* num_words,
+                                   int32_t* static_id);
 
 /* Replaces AugmentedLagrangianSolver::Solve (src/augmented_lagrangian_solver.cpp:72-210) with
  * max_runtime = infinity: inner ilqg_ilq_solve_batch calls capped at
@@ -633,7 +649,7 @@ const char* ilqg_last_error(void);
 ilqg_status ilqg_set_scratch(void* device_buffer, size_t bytes);
 
 /* Library / device introspection (used by the loader to fail loudly). */
-#define ILQG_ABI_VERSION 7 /* 7: ilqg_solve_options::deterministic (was reserved0), ilqg_copy_bandwidth;
+#define ILQG_ABI_VERSION 7 /* 7: ilqg_solve_options::deterministic (was reserved0) / static_rows, ilqg_copy_bandwidth, ilqg_problem_row_program, ilqg_row_program_build;
                               6: ilqg_problem_last_schedule;
                               5: ilqg_solve_options::iterate_log / max_runtime, run-time-dimensioned kernels behind every entry
                               point (any n <= 32, N <= 8, m_i), the affine constraints (ilqg_problem_desc::dense_params);

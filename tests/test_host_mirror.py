@@ -442,7 +442,9 @@ def _compare_rh_run(oracle, spec, logs, tag, compare_us=False):
         assert dev_outcome != ref_outcome
         rng = np.random.default_rng(99)
         outcomes = {ref_outcome}
-        for scale in (1e-12, 1e-12, 1e-12, 1e-12, 1e-11, 1e-11, 1e-10, 1e-10, 1e-12, 1e-12, 1e-11, 1e-10):
+        for scale in [1e-13, 1e-12, 1e-12, 1e-11, 1e-11, 1e-10, 1e-10, 1e-9] * 8:  # 64 nudged runs: the outcomes of this scene's calls are few
+            if dev_outcome in outcomes:
+                break
             again = O.receding_horizon_simulate(abi.F64, (x0 + scale * rng.standard_normal(x0.shape))[None, :], 3.0, 0.25,
                                                 max_records=32)
             Ra = int(again["num_records"][0])
