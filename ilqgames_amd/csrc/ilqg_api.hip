@@ -379,7 +379,7 @@ __global__ void __launch_bounds__(64, sizeof(T) == 8 ? ILQG_ROLL_WAVES : 1) ilq_
   trial_part_instance<T, NX, NP, MU, 1, TRIAL_ROLL>(p, nullptr, sa, b, reinterpret_cast<T*>(smem_raw));
 }
 
-template <typename T, int NX, int NP, int MU>
+template <typename T, int NX, int NP, int MU, int PROGID = 0>
 __global__ void __launch_bounds__(64) ilq_rows_kernel(DevProblem p, SolveArgs<T> sa) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int b = sa.ids ? sa.ids[blockIdx.y] : int(blockIdx.y);
@@ -391,7 +391,7 @@ __global__ void __launch_bounds__(64) ilq_rows_kernel(DevProblem p, SolveArgs<T>
   // compact rows: nothing dense is written, so the word maps of the dense images are not needed (nor their LDS)
   const short* maps = sa.compact ? nullptr : rows_maps_load(p, smem_raw);
   T* sm = reinterpret_cast<T*>(smem_raw + (sa.compact ? 0 : rows_maps_bytes(p)));
-  rows_part_instance<T, NX, NP, MU>(p, maps, sa, b, int(blockIdx.x), sm);
+  rows_part_instance<T, NX, NP, MU, PROGID>(p, maps, sa, b, int(blockIdx.x), sm);
 }
 
 template <typename T, int NX, int NP, int MU>
@@ -421,7 +421,7 @@ __global__ void __launch_bounds__(64, sizeof(T) == 8 ? (FAT ? 2 : ILQG_ROLL_WAVE
     probe_roll_instance<T, NX, NP, MU>(p, sa, sa.ids[blockIdx.x], blockIdx.x, blockIdx.y, reinterpret_cast<T*>(smem_raw));
 }
 
-template <typename T, int NX, int NP, int MU>
+template <typename T, int NX, int NP, int MU, int PROGID = 0>
 __global__ void __launch_bounds__(64, sizeof(T) == 8 ? 4 : 1) ilq_probe_rows_kernel(DevProblem p, SolveArgs<T> sa) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int slot = blockIdx.y / sa.probe_k, j = blockIdx.y % sa.probe_k;
@@ -433,7 +433,7 @@ __global__ void __launch_bounds__(64, sizeof(T) == 8 ? 4 : 1) ilq_probe_rows_ker
   }
   const short* maps = sa.compact ? nullptr : rows_maps_load(p, smem_raw);  // merit only: no dense image either way
   T* sm = reinterpret_cast<T*>(smem_raw + (sa.compact ? 0 : rows_maps_bytes(p)));
-  probe_rows_instance<T, NX, NP, MU>(p, maps, sa, b, slot, j, int(blockIdx.x), sm);
+  probe_rows_instance<T, NX, NP, MU, PROGID>(p, maps, sa, b, slot, j, int(blockIdx.x), sm);
 }
 
 template <typename T>
@@ -862,21 +862,33 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
     const size_t budget = per_instance > fixed ? (per_instance - fixed) / trial_row_waves(W) : 0;
     sa.rows_cw = rows_chunk_width(d.n, d.m, d.rp_pslots, d.rp_lslots, sizeof(T), budget);
   }
-  const size_t lds_trial = trial_lds_bytes<T>(d, W, sa.rows_cw);
   auto k_trial = ilq_trial_kernel<T, NX, NP, MU, W>;
-  // a registered row-program structure (ilqg_rowprog_static.hpp): the fused kernel whose row stage is straight-line
-  // code for it (compiled for chunks of ProgStatic::CW rows, state rows in registers) — same results, bit for bit
-  int static_prog = 0;
-  if (sa.rows_cw == 64 && opt.static_rows != ILQG_CHOICE_OFF) {
-#define X(ID_, NX_, NP_, MU_)                                                          \
-    if constexpr (NX_ == NX && NP_ == NP && MU_ == MU && rows_state_in_registers(NX, NP * MU)) \
-      if (p->static_prog == ID_) {                                                     \
-        k_trial = ilq_trial_kernel<T, NX, NP, MU, W, ID_>;                             \
-        static_prog = ID_;                                                             \
+  // A registered row-program structure (ilqg_rowprog_static.hpp): the row stage as straight-line code for it — in the
+  // fused kernel (state rows in registers, i.e. without the chunk's (x, u) image in LDS, so it takes the 64-row chunk
+  // where the interpreter's scratch would not fit four instances on a CU: n = 16 in fp64), in the split row kernel and
+  // in the merit-only row kernel of the speculative line search.  Same results, bit for bit.
+  int static_id = 0;    // the structure the split / probing row kernels are compiled for (0: they interpret)
+  int static_prog = 0;  // ... and the fused kernel
+  auto k_rows = ilq_rows_kernel<T, NX, NP, MU>;
+  auto k_prows = ilq_probe_rows_kernel<T, NX, NP, MU>;
+  if (opt.static_rows != ILQG_CHOICE_OFF) {
+#define X(ID_, NX_, NP_, MU_)                                                                                  \
+    if constexpr (NX_ == NX && NP_ == NP && MU_ == MU)                                                         \
+      if (p->static_prog == ID_) {                                                                             \
+        static_id = ID_;                                                                                       \
+        k_rows = ilq_rows_kernel<T, NX, NP, MU, ID_>;                                                          \
+        k_prows = ilq_probe_rows_kernel<T, NX, NP, MU, ID_>;                                                   \
+        if (rows_state_in_registers(NX, NP * MU) && trial_lds_bytes<T>(d, W, 64, true) <= size_t(160) * 1024 / 4) { \
+          k_trial = ilq_trial_kernel<T, NX, NP, MU, W, ID_>;                                                   \
+          static_prog = ID_;                                                                                   \
+        }                                                                                                      \
       }
     ILQG_STATIC_PROGS(X)
 #undef X
   }
+  const int rows_cw_interpreted = sa.rows_cw;
+  if (static_prog) sa.rows_cw = 64;
+  const size_t lds_trial = trial_lds_bytes<T>(d, W, sa.rows_cw, static_prog != 0);
   const bool pw = C::USE_MFMA && !p->desc.params.open_loop;  // one wave per player (MFMA feedback sweep)
   // Compact rows (ilqg_common.hpp) between the row stage and the sweep: the one-tile player-parallel sweep and the
   // open-loop sweep read them; the other sweeps take the dense arrays.
@@ -930,6 +942,10 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
                        opt.adjoint_expected_decrease != ILQG_CHOICE_OFF;
   bool split = choice(opt.split_trial, 4 * lds_trial > size_t(160) * 1024 || (big_batch && NX > 16) || want_1w);
   if (kProfile || opt.forced_steps) split = false;  // the phase profile reads the fused kernel's counters
+  if (split) {  // the split row kernels interpret the program: their chunk width is the interpreter's
+    static_prog = 0;
+    sa.rows_cw = rows_cw_interpreted;
+  }
   sa.compact = ((pw && C::MFMA_ONE_TILE && compact_on) || ol_compact) ? 1 : 0;
   const size_t split_maps_bytes = sa.compact ? 0 : rows_maps_bytes(d);  // the split row kernels' copy of the word maps
   if (split) {
@@ -941,7 +957,8 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
     double best = 0.0;
     for (int chunks = base; chunks <= base + ILQG_SPLIT_ROW_EXTRA_CHUNKS && chunks <= d.T; chunks++) {
       const int cw = (d.T + chunks - 1) / chunks;
-      const size_t lds = split_maps_bytes + split_rows_elems(d, NX, cw) * sizeof(T);
+      // (a static row kernel's scratch has the fixed strides of a 64-row chunk whatever its width: ilqg_rows.hpp)
+      const size_t lds = split_maps_bytes + split_rows_elems(d, NX, static_id ? 64 : cw) * sizeof(T);
       size_t per_cu = size_t(160) * 1024 / (lds + 256);
       if (per_cu > 8) per_cu = 8;
       const double score = double(per_cu) / double(chunks);
@@ -965,7 +982,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   sa.defer_forward = (!split && !p->desc.params.open_loop) ? 1 : 0;
   {
     constexpr size_t fwd_elems = 4 * 2 * ((NX * NX + C::SCR + 3) & ~3) + 2 * NX + 8;
-    if (trial_rows_elems(d, sa.rows_cw) < fwd_elems + 8) sa.defer_forward = 0;
+    if (trial_rows_elems(d, sa.rows_cw, static_prog != 0) < fwd_elems + 8) sa.defer_forward = 0;
   }
   // The throughput form of the one-tile feedback sweep — one wave per instance, twice the instances per CU
   // (ilqg_lq_feedback1w.hpp) — for batches of five or more instances per CU (measured, n = 14 fp64: B = 1024 1.47 M it/s
@@ -989,23 +1006,21 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   p->last_schedule = (single_wave ? ILQG_SCHEDULE_SINGLE_WAVE_SWEEP : 0) | ((single_wave && adjoint) ? ILQG_SCHEDULE_ADJOINT_DECREASE : 0) |
                      (split ? ILQG_SCHEDULE_SPLIT_TRIAL : 0) | (sa.compact ? ILQG_SCHEDULE_COMPACT_ROWS : 0) |
                      (counted ? ILQG_SCHEDULE_COUNTED : 0) | (p->desc.params.open_loop ? ILQG_SCHEDULE_OPEN_LOOP : 0) |
-                     ((static_prog && !split) ? ILQG_SCHEDULE_STATIC_ROWS : 0);
+                     ((static_prog || (static_id && split)) ? ILQG_SCHEDULE_STATIC_ROWS : 0);
   long long cap = al_mode ? (long long)(sa.prm.max_solver_iters + 1) * (sa.prm.unconstrained_solver_max_iters + 2)
                           : (long long)sa.prm.max_solver_iters + 2;
   if (split || counted) cap = (cap + 2) * ((long long)sa.prm.max_backtracking_steps + 3);
   auto k_roll = ilq_roll_kernel<T, NX, NP, MU>;
-  auto k_rows = ilq_rows_kernel<T, NX, NP, MU>;
   auto k_decide = ilq_decide_kernel<T, NX, NP, MU>;
   const size_t lds_roll = trial_phase_lds_bytes<T>(d, TRIAL_ROLL, sa.rows_cw),
                lds_decide = trial_phase_lds_bytes<T>(d, TRIAL_DECIDE, sa.rows_cw);
-  const size_t lds_rows = split_maps_bytes + split_rows_elems(d, NX, sa.rows_cw) * sizeof(T);
-  const size_t lds_prows = split_maps_bytes + probe_rows_elems(d, NX, sa.rows_cw) * sizeof(T);  // merit only
+  const size_t lds_rows = split_maps_bytes + split_rows_elems(d, NX, static_id ? 64 : sa.rows_cw) * sizeof(T);
+  const size_t lds_prows = split_maps_bytes + probe_rows_elems(d, NX, static_id ? 64 : sa.rows_cw) * sizeof(T);  // merit only
   constexpr bool pairs = rollout_pairs(NX, NP, MU);  // two rollouts per wavefront (ilqg_stages.hpp)
   const size_t lds_proll = pairs ? size_t(rollout_pair_lds_elems(d.n, d.m)) * sizeof(T) + 16 : lds_roll;
   const bool probe = lists && sa.prm.linesearch && choice(opt.probe, true);
   auto k_proll = ilq_probe_roll_kernel<T, NX, NP, MU>;
   auto k_proll_fat = ilq_probe_roll_kernel<T, NX, NP, MU, sizeof(T) == 8>;  // (fp32: the same kernel)
-  auto k_prows = ilq_probe_rows_kernel<T, NX, NP, MU>;
   const int decide_elems = int(trial_phase_quad_elems<T>(d, TRIAL_DECIDE, sa.rows_cw));
   const int row_chunks = (d.T + sa.rows_cw - 1) / sa.rows_cw;  // workgroups per instance of the row kernels
   int round_instances = batch, list = 0;  // split passes: how many instances this round covers, which list is free

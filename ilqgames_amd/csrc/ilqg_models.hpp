@@ -286,6 +286,15 @@ __device__ __forceinline__ void sub_integrate_stages(int kind, T L, double inter
 // ---------------------------------------------------------------------------
 // Geometry
 // ---------------------------------------------------------------------------
+// ---- geometry, costs, constraints ----
+// No floating-point contraction from here to the end of the file (hipcc's default fuses a * b + c into an FMA wherever the
+// optimiser sees the pair in one block — "fast-honor-pragmas").  Which pairs it sees depends on the shape of the code
+// around them: the row stage evaluates these functions from an interpreter loop, from straight-line code with every
+// kind and index folded (ilqg_rows.hpp, ProgStatic), with run-time dimensions, gradient-only ... and each form fused
+// different pairs — results that differ in the last bit, line searches that part ways.  With contraction off every form
+// rounds exactly as the source is written (the reference's own arithmetic: its CI builds have no FMA either), so all of
+// them agree bit for bit by construction.  The rollout's integrators above keep the default.
+#pragma clang fp contract(off)
 template <typename T>
 struct Seg {
   T p1x, p1y, p2x, p2y, len, ux, uy;
@@ -1016,5 +1025,7 @@ __device__ __forceinline__ void term_compute_leaf(const QuadTables<T>& tb, const
     }
   }
 }
+
+#pragma clang fp contract(fast)  // back to the translation unit's default
 
 }  // namespace ilqg

@@ -40,6 +40,9 @@
 
 namespace ilqg {
 
+// no floating-point contraction in the row stage (see ilqg_models.hpp: every form of it must round alike)
+#pragma clang fp contract(off)
+
 // Loads through this pointer type are scalar loads whenever the address is wave-uniform (the constant address
 // space: the program is written by the host before any kernel runs).
 typedef const __attribute__((address_space(4))) int* rp_cptr;
@@ -492,11 +495,14 @@ __device__ __forceinline__ Closest<T> polyline_closest_rows(typename ConstPtr<T>
 // geometry — runs the same code.  ilqg_problem_create matches the program it built against the registered structures
 // word for word (parameters masked, row_program_mask_parameters); anything else runs the interpreter.  Both produce the
 // same bits: the same expressions in the same order on the same data (tests/test_gpu_parity.py).
-struct ProgDynamic { static constexpr bool STATIC = false; static constexpr int CW = 0; };
+// The scratch of a static chunk has FIXED strides, so that every slot and every entry of the (x, u) image is an LDS
+// immediate offset: kStaticRowStride elements between slots (the 64-row chunk's width + 1), 64 between image entries —
+// whatever the number of rows the chunk really holds (any width up to 64).
+constexpr int kStaticRowStride = 65;
+struct ProgDynamic { static constexpr bool STATIC = false; };
 template <int ID> struct StaticRowProg;  // { static constexpr int kWords, w[kWords]; } per registered structure
 template <int ID> struct ProgStatic {
   static constexpr bool STATIC = true;
-  static constexpr int CW = 64;  // the chunk width the static code is compiled for (slot offsets are immediates)
   typedef StaticRowProg<ID> S;
 };
 
@@ -552,20 +558,20 @@ struct PassStatic {
 // GRAD_ONLY: a merit-only evaluation (the probing passes of the line search: merit_part, nothing else): no Hessian
 // entry is formed or stored, and the scratch holds the persistent slots and each pass's gradient slots only — the row
 // program numbers those first (rows_lds_elems_grad).
-// PROG: ProgDynamic (the interpreter) or ProgStatic<ID> (straight-line code for a registered structure; cw must be
-// PROG::CW).
+// PROG: ProgDynamic (the interpreter) or ProgStatic<ID> (straight-line code for a registered structure; the scratch is
+// laid out with the fixed strides of kStaticRowStride whatever `cw`: size it for cw = 64).
 template <typename T, int CN_, int CM_, int CNP_, bool XREG = false, bool GRAD_ONLY = false, class PROG = ProgDynamic>
 __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* maps, const QuadArgs<T>& a, int k0,
-                                           int nrows, int cw_arg, T* sm, int lane) {
+                                           int nrows, int cw, T* sm, int lane) {
   constexpr bool RT = CN_ == 0;
   constexpr bool ST = PROG::STATIC;
   static_assert(!XREG || (CN_ > 0 && CN_ <= 16 && CM_ <= 16), "register-held rows: compile-time n, m <= 16");
   const int CN = RT ? p.n : CN_, CM = RT ? p.m : CM_, CNP = RT ? p.N : CNP_;
   const int NA = CN + CM;
-  const int cw = ST ? PROG::CW : cw_arg;
-  const int cws = cw + 1;
+  const int cws = ST ? kStaticRowStride : cw + 1;  // elements between the slots of the accumulator scratch
+  const int ast = ST ? 64 : cw;                     // ... between the entries of the (x, u) image
   T* const arg = sm;
-  T* const acc = sm + (XREG ? 0 : NA) * cw;
+  T* const acc = sm + (XREG ? 0 : NA) * ast;
   typedef typename std::conditional<XREG, MixArg<T>, RowArg<T>>::type Arg;
   const rp_cptr rp = (rp_cptr)p.row_prog;
   const typename ConstPtr<T>::type segs = (typename ConstPtr<T>::type)problem_segs<T>(p);
@@ -606,7 +612,7 @@ __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* map
           const int ic = in ? i : 0;
           const int r = ic / dim, e = ic - r * dim;
           const int rs = r < nrows ? r : nrows - 1;  // lanes past the chunk's end repeat its last row (results unused)
-          dst[u] = in ? (first + e) * cw + r : -1;
+          dst[u] = in ? (first + e) * ast + r : -1;
           v[u] = g[rs * dim + e];
         }
 #pragma unroll
@@ -727,7 +733,7 @@ __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* map
           // the constant entries (dt, -dt, the identity) are in the word maps.
           const int kind = c.kind, xo = c.idx[0], uo = c.idx[1];
           const T L = T(c.weight);
-          const Arg x = rows_make_arg<T, XREG, XW, UW>(xrow, urow, xg, ug, arg, cw, CN, xo, rl, 2, kind == ILQG_DYN_AIR_3D_EVADER ? 0 : 3,
+          const Arg x = rows_make_arg<T, XREG, XW, UW>(xrow, urow, xg, ug, arg, ast, CN, xo, rl, 2, kind == ILQG_DYN_AIR_3D_EVADER ? 0 : 3,
                                                    kind == ILQG_DYN_AIR_3D_EVADER ? 1 : 4, -1);
           auto put = [&](int e, T val) { if (e < nsid) col[sid[e] * cws] = val; };
           if (kind == ILQG_DYN_POINT_MASS_2D || kind == ILQG_DYN_PLANAR_DISTURBANCE || kind == ILQG_DYN_AIR_3D_PURSUER)
@@ -736,7 +742,7 @@ __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* map
           t_sincos(x[2], &sth, &cth);
           const T ct = T(double(cth) * p.dt), st = T(double(sth) * p.dt);
           if (kind == ILQG_DYN_AIR_3D_EVADER) {  // air_3d.h:127-146
-            const T own = XREG ? T(urow[uo & (UW - 1)]) : arg[(CN + uo) * cw + rl];  // its own turn rate; c.value = the pursuer's speed
+            const T own = XREG ? T(urow[uo & (UW - 1)]) : arg[(CN + uo) * ast + rl];  // its own turn rate; c.value = the pursuer's speed
             put(0, T(double(own) * p.dt));             // A(0,1)
             put(1, T(0) - T(c.value) * st);            // A(0,2)
             put(2, T(0) - T(double(own) * p.dt));      // A(1,0)
@@ -761,7 +767,7 @@ __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* map
               put(4, T(double(x[4]) * p.dt / double(L * cphi * cphi)));  // A(2,3)
               put(5, T(double(tphi) * p.dt / double(L)));               // A(2,4)
               if (kind == ILQG_DYN_CAR_7D) {  // single_player_car_7d.h:141-151: the curvature row, all-double products
-                const T own = XREG ? T(urow[uo & (UW - 1)]) : arg[(CN + uo) * cw + rl];  // omega
+                const T own = XREG ? T(urow[uo & (UW - 1)]) : arg[(CN + uo) * ast + rl];  // omega
                 const T den = cphi * cphi * L;
                 put(6, T(2.0 * p.dt * double(own) * double(tphi) / double(den)));  // A(5,3)
                 put(7, T(p.dt / double(den)));                                     // B(5,0)
@@ -770,7 +776,7 @@ __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* map
           }
           return;
         }
-        const Arg v = rows_make_arg<T, XREG, XW, UW>(xrow, urow, xg, ug, arg, cw, CN, c.arg_off, rl, c.idx[0], c.idx[1], c.idx[2], c.idx[3]);
+        const Arg v = rows_make_arg<T, XREG, XW, UW>(xrow, urow, xg, ug, arg, ast, CN, c.arg_off, rl, c.idx[0], c.idx[1], c.idx[2], c.idx[3]);
         if (mode == ROP_AFFINE) {
           // constraints are quadraticised with the player's full PlayerCost::Quadraticize only (:483-487), from their
           // first active step on (FinalTimeConstraint)
@@ -987,5 +993,7 @@ __device__ __forceinline__ const short* rows_maps_load(const DevProblem& p, void
   __syncthreads();
   return reinterpret_cast<const short*>(dst);
 }
+
+#pragma clang fp contract(fast)  // back to the translation unit's default
 
 }  // namespace ilqg

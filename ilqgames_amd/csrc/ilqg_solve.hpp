@@ -194,8 +194,9 @@ __device__ __forceinline__ int solve_max_iters(const SolveArgs<T>& sa) {
 __host__ __device__ inline int trial_row_waves(int waves) { return waves > 1 ? waves - 1 : 1; }
 // scratch of one row wave (ilqg_rows.hpp, `cw` rows per chunk); also holds the per-row partials of the reductions
 // between passes
-__host__ __device__ inline size_t trial_rows_elems(const DevProblem& p, int cw) {
-  size_t e = rows_lds_elems(p.n, p.m, p.rp_pslots, p.rp_lslots, cw);
+// (`xreg`: the chunk keeps its (x, u) rows in registers — the statically specialised row stage — and has no LDS image)
+__host__ __device__ inline size_t trial_rows_elems(const DevProblem& p, int cw, bool xreg = false) {
+  size_t e = xreg ? rows_lds_elems_xreg(p.rp_pslots, p.rp_lslots, cw) : rows_lds_elems(p.n, p.m, p.rp_pslots, p.rp_lslots, cw);
   const size_t red = size_t(p.T) * p.N * 2 + 8;
   if (e < red) e = red;
   return (e + 3) & ~size_t(3);
@@ -213,9 +214,9 @@ __host__ __device__ inline size_t probe_rows_elems(const DevProblem& p, int nx, 
 }
 // LDS of the trial kernel: [word maps | rollout scratch | row waves x row scratch | 4 ints]
 template <typename T>
-__host__ __device__ inline size_t trial_lds_bytes(const DevProblem& p, int waves, int cw) {
+__host__ __device__ inline size_t trial_lds_bytes(const DevProblem& p, int waves, int cw, bool xreg = false) {
   const size_t re = (rollout_lds_elems(p.n, p.m) + 3) & ~size_t(3);
-  return rows_maps_bytes(p) + (re + size_t(trial_row_waves(waves)) * trial_rows_elems(p, cw)) * sizeof(T) + 16;
+  return rows_maps_bytes(p) + (re + size_t(trial_row_waves(waves)) * trial_rows_elems(p, cw, xreg)) * sizeof(T) + 16;
 }
 
 // ---------------------------------------------------------------------------
@@ -356,10 +357,10 @@ enum { TRIAL_FUSED = 0, TRIAL_ROLL = 1, TRIAL_DECIDE = 2 };
 // linearise / quadraticise scratch per wave of a trial-part kernel (TRIAL_DECIDE only needs the reductions' copy
 // of the per-row partials, TRIAL_ROLL nothing)
 template <typename T>
-__host__ __device__ inline size_t trial_phase_quad_elems(const DevProblem& p, int phase, int cw) {
+__host__ __device__ inline size_t trial_phase_quad_elems(const DevProblem& p, int phase, int cw, bool xreg = false) {
   if (phase == TRIAL_ROLL) return 0;
   if (phase == TRIAL_DECIDE) return (size_t(p.T) * p.N * 2 + 8 + 3) & ~size_t(3);
-  return trial_rows_elems(p, cw);
+  return trial_rows_elems(p, cw, xreg);
 }
 template <typename T>
 __host__ __device__ inline size_t trial_phase_lds_bytes(const DevProblem& p, int phase, int cw) {  // W = 1, no word maps
@@ -398,8 +399,12 @@ __device__ __forceinline__ QuadArgs<T> trial_quad_args(const DevProblem& p, cons
   return qa;
 }
 
+template <int ID> struct RowProgSel { typedef ProgStatic<ID> type; };
+template <> struct RowProgSel<0> { typedef ProgDynamic type; };
+
 // Row kernel of the split pass: one chunk of rows of instance b, one wave with its own scratch.
-template <typename T, int NX, int NP, int MU>
+// PROGID: 0 = interpret the problem's row program; k = straight-line code for registered structure k (ilqg_rows.hpp)
+template <typename T, int NX, int NP, int MU, int PROGID = 0>
 __device__ __forceinline__ void rows_part_instance(const DevProblem& p, const short* maps, const SolveArgs<T>& sa,
                                                    int b, int chunk, T* sm) {
   const InstanceBuffers<T> ib(p, sa, b);
@@ -407,7 +412,8 @@ __device__ __forceinline__ void rows_part_instance(const DevProblem& p, const sh
   const QuadArgs<T> qa = trial_quad_args<T>(p, ib, s, sa.compact != 0);
   const int k0 = chunk * sa.rows_cw;
   const int nrows = p.T - k0 < sa.rows_cw ? p.T - k0 : sa.rows_cw;
-  rows_chunk<T, NX, NP * MU, NP, rows_state_in_registers(NX, NP * MU)>(p, maps, qa, k0, nrows, sa.rows_cw, sm, int(threadIdx.x));
+  rows_chunk<T, NX, NP * MU, NP, rows_state_in_registers(NX, NP * MU), false, typename RowProgSel<PROGID>::type>(
+      p, maps, qa, k0, nrows, sa.rows_cw, sm, int(threadIdx.x));
 }
 
 // ---------------------------------------------------------------------------
@@ -504,7 +510,7 @@ __device__ __forceinline__ void probe_roll_pair(const DevProblem& p, const Solve
   rollout_pair<T, NX, NP * MU, (MU == 1)>(p, ra[0], ra[1], w0, w1, sm, int(threadIdx.x));
 }
 
-template <typename T, int NX, int NP, int MU>
+template <typename T, int NX, int NP, int MU, int PROGID = 0>
 __device__ __forceinline__ void probe_rows_instance(const DevProblem& p, const short* maps, const SolveArgs<T>& sa,
                                                     int b, int slot, int j, int chunk, T* sm) {
   const InstanceBuffers<T> ib(p, sa, b);
@@ -525,7 +531,8 @@ __device__ __forceinline__ void probe_rows_instance(const DevProblem& p, const s
   qa.phacc = nullptr;
   const int k0 = chunk * sa.rows_cw;
   const int nrows = p.T - k0 < sa.rows_cw ? p.T - k0 : sa.rows_cw;
-  rows_chunk<T, NX, NP * MU, NP, rows_state_in_registers(NX, NP * MU), true>(p, maps, qa, k0, nrows, sa.rows_cw, sm, int(threadIdx.x));
+  rows_chunk<T, NX, NP * MU, NP, rows_state_in_registers(NX, NP * MU), true, typename RowProgSel<PROGID>::type>(
+      p, maps, qa, k0, nrows, sa.rows_cw, sm, int(threadIdx.x));
 }
 
 // The line-search bookkeeping of the candidates, in the order the loop would have met them
@@ -709,9 +716,6 @@ __device__ __forceinline__ void roll_pair_instances(const DevProblem& p, const S
   if (g1) state_store<T>(ib1.w, ib1.L, s1);
 }
 
-template <int ID> struct RowProgSel { typedef ProgStatic<ID> type; };
-template <> struct RowProgSel<0> { typedef ProgDynamic type; };
-
 // PROGID: 0 = the row stage interprets the problem's row program; k = straight-line code for registered structure k
 template <typename T, int NX, int NP, int MU, int W, int PHASE = TRIAL_FUSED, int PROGID = 0>
 __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const short* maps,
@@ -730,7 +734,7 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const s
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
 
   const size_t re = (rollout_lds_elems(n, m) + 3) & ~size_t(3);
-  const size_t qe = trial_phase_quad_elems<T>(p, PHASE, sa.rows_cw);
+  const size_t qe = trial_phase_quad_elems<T>(p, PHASE, sa.rows_cw, PROGID != 0 && PHASE == TRIAL_FUSED);
   constexpr int RW = W > 1 ? W - 1 : 1;     // row waves: all but the integrating wave 0
   const int rwave = W > 1 ? wave - 1 : 0;   // this wave's row scratch (-1: wave 0 of a multi-wave workgroup has none)
   T* const sm_roll = sm;
@@ -825,7 +829,8 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const s
         tl_stamp(sa.prof, b, 4 + 2 * (c < 3 ? c : 3), lane == 0);
         // (the register-held rows of the split kernels gain nothing for the interpreter here — measured, B = 1024: 1.45 ->
         // 1.435 M it/s; the static form reads its entries straight out of them)
-        rows_chunk<T, NX, NP * MU, NP, (PROGID != 0), false, typename RowProgSel<PROGID>::type>(p, maps, qa, k0, nrows, cw, sm_quad, lane);
+        rows_chunk<T, NX, NP * MU, NP, (PROGID != 0 && rows_state_in_registers(NX, NP * MU)), false, typename RowProgSel<PROGID>::type>(
+            p, maps, qa, k0, nrows, cw, sm_quad, lane);
         tl_stamp(sa.prof, b, 5 + 2 * (c < 3 ? c : 3), lane == 0);
         if (kProfile && sa.prof) { tq0 = clock64(); qph[7] += 1; }
       }
