@@ -457,8 +457,8 @@ def main():
                          # the nominal 8 TB/s AND the box's measured copy bandwidth as denominators
                          "peak_measured": peak_measured,
                          "frac_of_measured": (achieved_b0 / peak_measured) if peak_measured else None,
-                         "peak_measured_source": "ilqg_copy_bandwidth (16-byte-per-lane streaming copy, 1 GiB each way, best of 10 "
-                                                 "launches, HIP events; read + write bytes counted)",
+                         "peak_measured_source": "ilqg_copy_bandwidth (16 KB contiguous per workgroup, 16 bytes per lane and load, 1 GiB each way, best "
+                                                 "of 10 launches, HIP events; read + write bytes counted)",
                          "with_rejected_trials": {"achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
                                                   "mean_backtracks": mean_bt},
                          "kernel": "ilq_lq_kernel + ilq_trial_kernel (one round = one outer iteration of the batch)",

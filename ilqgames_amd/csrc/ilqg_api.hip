@@ -511,20 +511,22 @@ __global__ void mfma_selftest_kernel(const T* X, const T* Y, const T* C, T* out)
 }
 
 // The measured-bandwidth denominator of bench.py's roofline ("measure achievable BW on the box with a copy
-// kernel"): a grid-stride float4 copy, four independent 16-byte loads per lane in flight before the first store.
+// kernel"): every workgroup copies one contiguous 16 KB piece, four 16-byte loads per lane in flight before the first
+// store.  scripts/ubench/copy_bw.hip compares shapes on the box: this one 5.65-5.98 TB/s, a grid-stride loop over the
+// same pieces 4.3-5.6, hipMemcpyDtoD 5.5.
 typedef float copy_v4f __attribute__((ext_vector_type(4)));
 __global__ void __launch_bounds__(256) copy_bandwidth_kernel(copy_v4f* __restrict__ dst, const copy_v4f* __restrict__ src, size_t n16) {
-  const size_t stride = size_t(gridDim.x) * 256;
-  size_t i = size_t(blockIdx.x) * 256 + threadIdx.x;
-  for (; i + 3 * stride < n16; i += 4 * stride) {
-    const copy_v4f a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride),
-                 c = __builtin_nontemporal_load(src + i + 2 * stride), e = __builtin_nontemporal_load(src + i + 3 * stride);
-    __builtin_nontemporal_store(a, dst + i);
-    __builtin_nontemporal_store(b, dst + i + stride);
-    __builtin_nontemporal_store(c, dst + i + 2 * stride);
-    __builtin_nontemporal_store(e, dst + i + 3 * stride);
+  const size_t b0 = size_t(blockIdx.x) * 1024, b1 = b0 + 1024 < n16 ? b0 + 1024 : n16;
+  const size_t i = b0 + threadIdx.x;
+  if (b1 - b0 == 1024) {
+    const copy_v4f a = src[i], b = src[i + 256], c = src[i + 512], e = src[i + 768];
+    dst[i] = a;
+    dst[i + 256] = b;
+    dst[i + 512] = c;
+    dst[i + 768] = e;
+  } else {
+    for (size_t k = i; k < b1; k += 256) dst[k] = src[k];
   }
-  for (; i < n16; i += stride) dst[i] = src[i];
 }
 
 // ------------------------------------------------------------------------------------
@@ -863,6 +865,14 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
     sa.rows_cw = rows_chunk_width(d.n, d.m, d.rp_pslots, d.rp_lslots, sizeof(T), budget);
   }
   auto k_trial = ilq_trial_kernel<T, NX, NP, MU, W>;
+  const bool pw = C::USE_MFMA && !p->desc.params.open_loop;  // one wave per player (MFMA feedback sweep)
+  // Compact rows (ilqg_common.hpp) between the row stage and the sweep: the one-tile player-parallel sweep and the
+  // open-loop sweep read them; the other sweeps take the dense arrays.
+  // ... and only when the [T][rp_compact_w] rows fit the space they are kept in: the dense Q, l, R, r arrays up to the
+  // sweep's scratch rows (a small or densely coupled problem's row carries the A and B words too)
+  const bool compact_on = d.rp_compact_w > 0 && size_t(d.T) * size_t(d.rp_compact_w) <= L.lqscr - L.Q &&
+                          choice(opt.compact_rows, true);
+  const bool ol_compact = p->desc.params.open_loop && compact_on;
   // A registered row-program structure (ilqg_rowprog_static.hpp): the row stage as straight-line code for it — in the
   // fused kernel (state rows in registers, i.e. without the chunk's (x, u) image in LDS, so it takes the 64-row chunk
   // where the interpreter's scratch would not fit four instances on a CU: n = 16 in fp64), in the split row kernel and
@@ -871,11 +881,15 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   int static_prog = 0;  // ... and the fused kernel
   auto k_rows = ilq_rows_kernel<T, NX, NP, MU>;
   auto k_prows = ilq_probe_rows_kernel<T, NX, NP, MU>;
-  if (opt.static_rows != ILQG_CHOICE_OFF) {
+  // (the static kernels exist for solves on compact rows: they write nothing dense)
+  const bool will_compact = (pw && C::MFMA_ONE_TILE && compact_on) || ol_compact;
+  bool static_in_regs = false;  // ... with the slots of a chunk in registers (ilqg_rows.hpp: no row scratch in LDS)
+  if (opt.static_rows != ILQG_CHOICE_OFF && will_compact) {
 #define X(ID_, NX_, NP_, MU_)                                                                                  \
     if constexpr (NX_ == NX && NP_ == NP && MU_ == MU)                                                         \
       if (p->static_prog == ID_) {                                                                             \
         static_id = ID_;                                                                                       \
+        static_in_regs = static_prog_in_registers<StaticRowProg<ID_>>();                                       \
         k_rows = ilq_rows_kernel<T, NX, NP, MU, ID_>;                                                          \
         k_prows = ilq_probe_rows_kernel<T, NX, NP, MU, ID_>;                                                   \
         if (rows_state_in_registers(NX, NP * MU) && trial_lds_bytes<T>(d, W, 64, true) <= size_t(160) * 1024 / 4) { \
@@ -889,14 +903,6 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   const int rows_cw_interpreted = sa.rows_cw;
   if (static_prog) sa.rows_cw = 64;
   const size_t lds_trial = trial_lds_bytes<T>(d, W, sa.rows_cw, static_prog != 0);
-  const bool pw = C::USE_MFMA && !p->desc.params.open_loop;  // one wave per player (MFMA feedback sweep)
-  // Compact rows (ilqg_common.hpp) between the row stage and the sweep: the one-tile player-parallel sweep and the
-  // open-loop sweep read them; the other sweeps take the dense arrays.
-  // ... and only when the [T][rp_compact_w] rows fit the space they are kept in: the dense Q, l, R, r arrays up to the
-  // sweep's scratch rows (a small or densely coupled problem's row carries the A and B words too)
-  const bool compact_on = d.rp_compact_w > 0 && size_t(d.T) * size_t(d.rp_compact_w) <= L.lqscr - L.Q &&
-                          choice(opt.compact_rows, true);
-  const bool ol_compact = p->desc.params.open_loop && compact_on;
   // fp32, one-tile sweep of three player waves, many instances per CU: the 128-register build (see ilq_lq_kernel)
   constexpr bool has_packed = sizeof(T) == 4 && C::USE_MFMA && C::MFMA_ONE_TILE && NP == 3;
   const bool packed = has_packed && pw && size_t(batch) >= size_t(5) * 256;
@@ -958,7 +964,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
     for (int chunks = base; chunks <= base + ILQG_SPLIT_ROW_EXTRA_CHUNKS && chunks <= d.T; chunks++) {
       const int cw = (d.T + chunks - 1) / chunks;
       // (a static row kernel's scratch has the fixed strides of a 64-row chunk whatever its width: ilqg_rows.hpp)
-      const size_t lds = split_maps_bytes + split_rows_elems(d, NX, static_id ? 64 : cw) * sizeof(T);
+      const size_t lds = (static_id && static_in_regs) ? size_t(16) : split_maps_bytes + split_rows_elems(d, NX, static_id ? 64 : cw) * sizeof(T);
       size_t per_cu = size_t(160) * 1024 / (lds + 256);
       if (per_cu > 8) per_cu = 8;
       const double score = double(per_cu) / double(chunks);
@@ -1014,8 +1020,12 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   auto k_decide = ilq_decide_kernel<T, NX, NP, MU>;
   const size_t lds_roll = trial_phase_lds_bytes<T>(d, TRIAL_ROLL, sa.rows_cw),
                lds_decide = trial_phase_lds_bytes<T>(d, TRIAL_DECIDE, sa.rows_cw);
-  const size_t lds_rows = split_maps_bytes + split_rows_elems(d, NX, static_id ? 64 : sa.rows_cw) * sizeof(T);
-  const size_t lds_prows = split_maps_bytes + probe_rows_elems(d, NX, static_id ? 64 : sa.rows_cw) * sizeof(T);  // merit only
+  // (a static row kernel whose slots are registers needs no scratch beyond the (x, u) image of shapes past 16 states)
+  const size_t static_regs_lds = (rows_state_in_registers(NX, NP * MU) ? 0 : size_t(d.n + d.m) * 64) * sizeof(T) + 16;
+  const size_t lds_rows = (static_id && static_in_regs) ? static_regs_lds
+                                                        : split_maps_bytes + split_rows_elems(d, NX, static_id ? 64 : sa.rows_cw) * sizeof(T);
+  const size_t lds_prows = (static_id && static_in_regs) ? static_regs_lds
+                                                         : split_maps_bytes + probe_rows_elems(d, NX, static_id ? 64 : sa.rows_cw) * sizeof(T);  // merit only
   constexpr bool pairs = rollout_pairs(NX, NP, MU);  // two rollouts per wavefront (ilqg_stages.hpp)
   const size_t lds_proll = pairs ? size_t(rollout_pair_lds_elems(d.n, d.m)) * sizeof(T) + 16 : lds_roll;
   const bool probe = lists && sa.prm.linesearch && choice(opt.probe, true);
@@ -1544,15 +1554,7 @@ ilqg_status ilqg_copy_bandwidth(void* dst, const void* src, size_t bytes, void* 
   if (!dst || !src || bytes < 16 || (bytes & 15) || (reinterpret_cast<uintptr_t>(dst) & 15) || (reinterpret_cast<uintptr_t>(src) & 15))
     return fail(ILQG_ERR_INVALID, "ilqg_copy_bandwidth: 16-byte aligned buffers and a multiple of 16 bytes");
   const size_t n16 = bytes / 16;
-  int num_cus = 256;
-  {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) num_cus = prop.multiProcessorCount;
-  }
-  // eight workgroups of 256 per CU, each lane four independent 16-byte pieces per trip (64 KB in flight per workgroup)
-  size_t blocks = (n16 + 1023) / 1024;
-  if (blocks > size_t(num_cus) * 8) blocks = size_t(num_cus) * 8;
+  const size_t blocks = (n16 + 1023) / 1024;  // 16 KB per workgroup
   hipLaunchKernelGGL(copy_bandwidth_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                      reinterpret_cast<copy_v4f*>(dst), reinterpret_cast<const copy_v4f*>(src), n16);
   HIP_TRY(hipGetLastError());

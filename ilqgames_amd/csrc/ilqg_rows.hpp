@@ -547,6 +547,27 @@ struct PassStatic {
                        li_grad = S::w[b + 8];
 };
 
+// Can a static chunk keep its accumulators in REGISTERS?  Every slot id of every op must be a compile-time constant (an
+// op whose ids spill into the program's id table, or an affine constraint, reads them at run time) and the slots of a
+// pass must fit the register file beside the row's (x, u).  Then the slots are a per-lane register array — a lane is a
+// row, so nothing is shared — the ops update registers instead of read-modify-writing LDS, and a pass's compact row
+// is stored by its own lane straight from them (contiguous slots: vector stores), with no transposed LDS read-out.
+// Such a kernel only exists for solves on compact rows (nothing dense is written by it): the launcher checks.
+template <class S>
+constexpr bool static_prog_in_registers() {
+  const int nops = (S::w[RP_OFF_SIDS] - S::w[RP_OFF_OPS]) / ROP_WORDS;
+  for (int op = 0; op < nops; op++) {
+    const int b = S::w[RP_OFF_OPS] + op * ROP_WORDS;
+    if (S::w[b + RO_MODE] == ROP_AFFINE || S::w[b + RO_NSID] > ROP_INLINE_SIDS) return false;
+  }
+  return S::w[RP_NUM_PSLOTS] + S::w[RP_MAX_LSLOTS] <= 64 && S::w[S::w[RP_OFF_COMPACT] + RC_W] > 0;
+}
+template <class PROG, bool ST = PROG::STATIC> struct ProgInRegisters { static constexpr bool value = false; static constexpr int slots = 1; };
+template <class PROG> struct ProgInRegisters<PROG, true> {
+  static constexpr bool value = static_prog_in_registers<typename PROG::S>();
+  static constexpr int slots = value ? PROG::S::w[RP_NUM_PSLOTS] + PROG::S::w[RP_MAX_LSLOTS] : 1;
+};
+
 // One chunk: rows [k0, k0 + nrows), nrows <= cw, executed by ONE wavefront (`lane` of 64) with its own LDS `sm`
 // (rows_lds_elems for this cw: 64, 32 or 16).  `maps` is the workgroup's LDS copy of the program's word maps
 // (rows_maps_load).  What is produced follows QuadArgs: A / Bm (null: skip the Jacobians), Q / l / R / r (null: not
@@ -568,7 +589,8 @@ __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* map
   static_assert(!XREG || (CN_ > 0 && CN_ <= 16 && CM_ <= 16), "register-held rows: compile-time n, m <= 16");
   const int CN = RT ? p.n : CN_, CM = RT ? p.m : CM_, CNP = RT ? p.N : CNP_;
   const int NA = CN + CM;
-  const int cws = ST ? kStaticRowStride : cw + 1;  // elements between the slots of the accumulator scratch
+  constexpr bool REGACC = ProgInRegisters<PROG>::value;  // the slots are this lane's registers, not LDS columns
+  const int cws = REGACC ? 1 : (ST ? kStaticRowStride : cw + 1);  // elements between the slots of the accumulator scratch
   const int ast = ST ? 64 : cw;                     // ... between the entries of the (x, u) image
   T* const arg = sm;
   T* const acc = sm + (XREG ? 0 : NA) * ast;
@@ -648,7 +670,8 @@ __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* map
   const bool valid = lane < nrows;
   const int row = k0 + (valid ? lane : nrows - 1);
   const int rl = rowlane ? lane : 0;
-  T* const col = acc + (rowlane ? lane : cw);
+  T racc[ProgInRegisters<PROG>::slots];  // (REGACC; every index is a compile-time constant: registers)
+  T* const col = REGACC ? racc : acc + (rowlane ? lane : cw);
   // PlayerCost::Quadraticize vs QuadraticizeControlCosts (src/ilq_solver.cpp:483-487): bit i = player i is
   // quadraticised in full at this lane's row
   unsigned full = 0;
@@ -904,6 +927,7 @@ __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* map
 #else
     ILQG_QPH(0);
 #endif
+    if constexpr (!REGACC)
     for (int rg = reg_begin; rg < (GRAD_ONLY ? reg_begin : reg_end); rg++) {
       const rp_cptr rd = regions + rg * RREG_WORDS;
       const int arr = rd[0], words = rd[1], offs = rd[2];
@@ -946,6 +970,30 @@ __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* map
       }
       T* const g0 = a.compact + size_t(k0) * CWD + base;
       constexpr int RB = 8;
+      if constexpr (REGACC) {
+        // this lane's row, from its registers: the pass's slots are contiguous in the compact row
+        typedef typename PROG::S S;
+        constexpr int cbo = S::w[RP_OFF_COMPACT], P0 = S::w[RP_NUM_PSLOTS], NL = PD::li_count;
+        constexpr int base_c = S::w[cbo + RC_BASE + (PD::pkind == RPASS_PLAYER ? 1 + PD::player : 0)], cwd_c = S::w[cbo + RC_W];
+        constexpr int full = 16 / int(sizeof(T));
+        constexpr int VW = (base_c % full == 0 && cwd_c % full == 0) ? full : ((base_c % 2 == 0 && cwd_c % 2 == 0 && full >= 2) ? 2 : 1);
+        typedef typename RowVec<T, VW>::type vec;
+        if (valid) {
+          T* const g = g0 + size_t(lane) * cwd_c;
+          static_for<0, NL / VW>([&](auto sc) {
+            constexpr int s0 = decltype(sc)::value * VW;
+            if constexpr (VW == 1) {
+              g[s0] = racc[P0 + s0];
+            } else {
+              vec v;
+#pragma unroll
+              for (int q = 0; q < VW; q++) v[q] = racc[P0 + s0 + q];
+              *reinterpret_cast<vec*>(g + s0) = v;
+            }
+          });
+          static_for<(NL / VW) * VW, NL>([&](auto sc) { g[decltype(sc)::value] = racc[P0 + decltype(sc)::value]; });
+        }
+      } else
       for (int s0 = 0; s0 < li_count; s0 += 64) {
         const bool in = s0 + lane < li_count;
         const int off = (NPS + (in ? s0 + lane : 0)) * cws;

@@ -422,7 +422,14 @@ def test_ilq_solve_matches_oracle_fp64(hip, oracle, cfg):
     assert np.array_equal(_np(out["iters"])[ok], ref["iters"][ok])
     assert np.array_equal(_np(out["status"])[ok], ref["status"][ok])
     same = (_np(out["status"]) == ref["status"]) & (_np(out["iters"]) == ref["iters"])
-    agree = np.mean(same)
+    # ... the agreement statistic over more instances than the twelve compared above (round 6: on twelve, one coin flip is
+    # 8 % — scripts/diag/free_running_agreement.py on 96 instances of cost_zoo_scene: device vs oracle 0.80, oracle vs
+    # itself 0.84-0.90, while the first twelve alone gave 0.50 on one build and 0.67 on the next)
+    x0b = examples.jittered_x0(spec, 36, seed=12)
+    refb = oracle.OracleProblem(spec).solve(abi.F64, x0b, fixed_iters=K, merit_log_len=K, threads=4)
+    outb = hip.Problem(spec, abi.F64).solve(x0b, fixed_iters=K)
+    sameb = (_np(outb["status"]) == refb["status"]) & (_np(outb["iters"]) == refb["iters"])
+    agree = np.mean(np.concatenate([same, sameb]))
     # How many instances CAN end the same way is measured, not guessed: the oracle is run again from x0 nudged by
     # 1e-12; an instance whose two oracle runs end differently has a line search that is decided by rounding (deep
     # back-tracking or a failing search: accept / reject hangs on the last bits of two ~1e5 merit values), and two
@@ -430,11 +437,14 @@ def test_ilq_solve_matches_oracle_fp64(hip, oracle, cfg):
     # SkeletonExample (no regularisation, proximity cost switching on mid-horizon) and DubinsOrigin.  The device may
     # lose at most two more instances than the oracle loses against itself; the instance-by-instance comparison at
     # forced steps is test_gpu_forced.py.
-    nudged = oracle.OracleProblem(spec).solve(abi.F64, x0 + 1e-12 * np.random.default_rng(5).standard_normal(x0.shape),
-                                              fixed_iters=K, merit_log_len=K)
-    stable = (nudged["status"] == ref["status"]) & (nudged["iters"] == ref["iters"])
+    xall = np.concatenate([x0, x0b])
+    nudged = oracle.OracleProblem(spec).solve(abi.F64, xall + 1e-12 * np.random.default_rng(5).standard_normal(xall.shape),
+                                              fixed_iters=K, merit_log_len=K, threads=4)
+    stable = (nudged["status"] == np.concatenate([ref["status"], refb["status"]])) & \
+        (nudged["iters"] == np.concatenate([ref["iters"], refb["iters"]]))
     assert np.mean(stable) >= 0.5, "the scene is too ill-conditioned to test (%.2f of the oracle's own runs agree)" % np.mean(stable)
-    assert agree >= np.mean(stable) - 2.0 / B, "too many instances end differently (%.2f agree, oracle vs itself %.2f)" % (agree, np.mean(stable))
+    # the device may lose at most a tenth of the instances more than the oracle loses against itself
+    assert agree >= np.mean(stable) - 0.1, "too many instances end differently (%.2f agree, oracle vs itself %.2f)" % (agree, np.mean(stable))
     depth = np.nan_to_num(ref["log"][:, :, 3], nan=0.0).max(axis=1)
     for b in np.where(~same)[0]:
         assert depth[b] > 12 or ref["status"][b] == 0 or _np(out["status"])[b] == 0, \
