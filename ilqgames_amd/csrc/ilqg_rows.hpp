@@ -562,6 +562,28 @@ constexpr bool static_prog_in_registers() {
   }
   return S::w[RP_NUM_PSLOTS] + S::w[RP_MAX_LSLOTS] <= 64 && S::w[S::w[RP_OFF_COMPACT] + RC_W] > 0;
 }
+// The passes of a static program cut into two sets of about equal work (ops per pass, greedily, largest first): the
+// fused trial kernel gives the chunk that can only start when the rollout has ended to BOTH its waves.  Returns the
+// first set as a bit mask over the passes.
+template <class S>
+constexpr unsigned static_prog_pass_split() {
+  const int np = S::w[RP_NUM_PASSES];
+  int wgt[32] = {0};
+  for (int ps = 0; ps < np && ps < 32; ps++) {
+    const int b = S::w[RP_OFF_PASS] + ps * RPASS_WORDS;
+    wgt[ps] = S::w[b + 1] - S::w[b + 0];
+  }
+  unsigned first = 0, taken = 0;
+  int wa = 0, wb = 0;
+  for (int k = 0; k < np && k < 32; k++) {
+    int best = -1;
+    for (int ps = 0; ps < np && ps < 32; ps++)
+      if (!((taken >> ps) & 1u) && (best < 0 || wgt[ps] > wgt[best])) best = ps;
+    taken |= 1u << best;
+    if (wa <= wb) { first |= 1u << best; wa += wgt[best]; } else { wb += wgt[best]; }
+  }
+  return first;
+}
 template <class PROG, bool ST = PROG::STATIC> struct ProgInRegisters { static constexpr bool value = false; static constexpr int slots = 1; };
 template <class PROG> struct ProgInRegisters<PROG, true> {
   static constexpr bool value = static_prog_in_registers<typename PROG::S>();
@@ -581,9 +603,11 @@ template <class PROG> struct ProgInRegisters<PROG, true> {
 // program numbers those first (rows_lds_elems_grad).
 // PROG: ProgDynamic (the interpreter) or ProgStatic<ID> (straight-line code for a registered structure; the scratch is
 // laid out with the fixed strides of kStaticRowStride whatever `cw`: size it for cw = 64).
+// pass_mask: bit ps = run pass ps of the program (the passes are independent of each other: the Jacobians, then one per
+// player, each with its own slots and outputs).
 template <typename T, int CN_, int CM_, int CNP_, bool XREG = false, bool GRAD_ONLY = false, class PROG = ProgDynamic>
 __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* maps, const QuadArgs<T>& a, int k0,
-                                           int nrows, int cw, T* sm, int lane) {
+                                           int nrows, int cw, T* sm, int lane, unsigned pass_mask = ~0u) {
   constexpr bool RT = CN_ == 0;
   constexpr bool ST = PROG::STATIC;
   static_assert(!XREG || (CN_ > 0 && CN_ <= 16 && CM_ <= 16), "register-held rows: compile-time n, m <= 16");
@@ -713,6 +737,7 @@ __device__ __forceinline__ void rows_chunk(const DevProblem& p, const short* map
     const int op_begin = pd.op_begin, op_end = pd.op_end, reg_begin = pd.reg_begin, reg_end = pd.reg_end,
               li_begin = pd.li_begin, li_count = pd.li_count;
     const int pkind = pd.pkind, player = pd.player;
+    if (!((pass_mask >> ps) & 1u)) return;  // another wave takes this pass of the chunk (the fused kernel's last chunk)
     if (GRAD_ONLY && pkind == RPASS_JACOBIANS) return;
     if (pkind == RPASS_JACOBIANS && a.A == nullptr && !(a.compact && a.compact_lin)) return;
     if (pkind == RPASS_PLAYER && !do_quad && !want_cost) return;

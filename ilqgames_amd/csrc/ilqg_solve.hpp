@@ -809,6 +809,29 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const s
       lq_forward_pass_body<T, NX, NP, MU, 64, FWD_LDSE>(fa, sm_quad, lane);
     }
     tl_stamp(sa.prof, b, 3, rwave == 0 && lane == 0);
+    // A static row stage that keeps a chunk in registers (no LDS scratch: ilqg_rows.hpp) lets BOTH waves work on the
+    // chunk that can only start when the rollout has ended: the integrating wave, idle from then on, takes one half of
+    // its passes, the row wave the other — that chunk's time is what the launch ends with.
+    typedef typename RowProgSel<PROGID>::type RowProg;
+    constexpr bool SHARE_LAST = PROGID != 0 && W == 2 && ProgInRegisters<RowProg>::value && rows_state_in_registers(NX, NP * MU);
+    if constexpr (SHARE_LAST) {
+      const int cw = sa.rows_cw;
+      const int nchunks = (Tn + cw - 1) / cw;
+      const int rem = Tn % cw;
+      constexpr unsigned first_half = static_prog_pass_split<typename RowProg::S>();
+      if (wave == 0) qa.tl = nullptr;
+#pragma unroll 1
+      for (int c = (wave == 0 ? nchunks - 1 : 0); c < nchunks; c++) {
+        const int k0 = rem == 0 ? c * cw : (c == 0 ? 0 : rem + (c - 1) * cw);  // the chunk that is not full comes first
+        const int nrows = (rem != 0 && c == 0) ? rem : cw;
+        if (wave != 0)
+          while (progress_observe(&flags[0]) < k0 + nrows) __builtin_amdgcn_s_sleep(8);
+        tl_stamp(sa.prof, b, 4 + 2 * (c < 3 ? c : 3), wave != 0 && lane == 0);
+        const unsigned mask = c == nchunks - 1 ? (wave == 0 ? first_half : ~first_half) : ~0u;
+        rows_chunk<T, NX, NP * MU, NP, true, false, RowProg>(p, maps, qa, k0, nrows, cw, sm_quad, lane, mask);
+        tl_stamp(sa.prof, b, 5 + 2 * (c < 3 ? c : 3), wave != 0 && lane == 0);
+      }
+    } else
     if (rwave >= 0) {
       const int cw = sa.rows_cw;
       const int nchunks = (Tn + cw - 1) / cw;
