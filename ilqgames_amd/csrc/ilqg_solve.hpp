@@ -882,6 +882,7 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const s
         T merit_v = T(0);
         costs_ready = merit_costs_reduce<T>(p, w + L.mpart, w + L.cpart, t_extreme, sm_quad0, int(qe), &merit_v);
         const T merit = costs_ready ? uniform(merit_v) : uniform(merit_reduce<T>(p, w + L.mpart, sm_quad0, int(qe)));
+        tl_stamp(sa.prof, b, 14, t == 0);
         const T scaled = T(prm.expected_decrease_fraction) * s.step * s.expected_decrease;
         accepted = (s.last_merit - merit >= scaled) || sa.forced_steps != nullptr;  // CheckArmijoCondition :350-362
         if (accepted) {
@@ -915,6 +916,7 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const s
         }
       }
     }
+    tl_stamp(sa.prof, b, 15, t == 0);
     if (PHASE == TRIAL_DECIDE) break;  // another pass, if the instance needs one, is the host's to launch
     // hand-off (the host gave a list to fill): a rejected step leaves the fused kernel too — the rest of this line
     // search goes through the split passes, where the next step sizes are probed side by side

@@ -435,6 +435,29 @@ struct QuadArgs {
   int tl_b = 0;
 };
 
+// Global -> LDS copy of `count` elements by the whole workgroup with a thread's loads issued together, eight at a time,
+// ahead of its LDS stores: one exposed global round trip per eight elements of a thread instead of one per element
+// (the staging loops of the reductions below were five and three dependent round trips: ~8 of the fused trial kernel's
+// last 15 us, timeline of round 6).
+template <typename T>
+__device__ __forceinline__ void stage_to_lds(T* sm, const T* g, int count) {
+  constexpr int UN = 8;
+  const int nt = blockDim.x;
+  for (int e0 = threadIdx.x; e0 < count; e0 += nt * UN) {
+    T v[UN];
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+      const int e = e0 + u * nt;
+      v[u] = g[e < count ? e : e0];
+    }
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+      const int e = e0 + u * nt;
+      if (e < count) sm[e] = v[u];
+    }
+  }
+}
+
 // Sequential left-to-right sum of `count` LDS values, eight loads in flight at a time (the adds keep
 // the reference's order; only the LDS latency overlaps).
 template <typename T, typename F>
@@ -472,14 +495,14 @@ __device__ __forceinline__ T merit_reduce(const DevProblem& p, const T* merit_pa
   __syncthreads();  // partials were written to global memory by other lanes
   const int count = p.T * p.N * 2;
   if (count + 1 <= sm_elems) {
-    for (int e = threadIdx.x; e < count; e += blockDim.x) sm[e] = merit_part[e];
+    stage_to_lds<T>(sm, merit_part, count);
     __syncthreads();
     if (threadIdx.x == 0) {
       T merit = T(0);
       const int skip = p.N * 2;  // the |l_i|^2 terms of k = 0 do not enter (:421)
-      lds_ordered_visit<T>(sm, count, [&](int e, T x) {
-        if ((e & 1) == 0 || e >= skip) merit += x;
-      });
+      // (row 0 on its own, so that the chain over the other rows is one add per element and not an add and a select)
+      for (int e = 0; e < skip && e < count; e += 2) merit += sm[e];
+      lds_ordered_visit<T>(sm + skip, count - skip, [&](int, T x) { merit += x; });
       sm[count] = T(0.5) * merit;
     }
     __syncthreads();
@@ -514,16 +537,15 @@ __device__ __forceinline__ bool merit_costs_reduce(const DevProblem& p, const T*
   __syncthreads();  // partials were written to global memory by other lanes
   T* const smc = sm + cm;
   T* const res = smc + cc;  // [merit | cost_i ... | t_extreme_i (as T) ...]
-  for (int e = threadIdx.x; e < cm; e += blockDim.x) sm[e] = merit_part[e];
-  for (int e = threadIdx.x; e < cc; e += blockDim.x) smc[e] = cost_part[e];
+  stage_to_lds<T>(sm, merit_part, cm);
+  stage_to_lds<T>(smc, cost_part, cc);
   __syncthreads();
   const int cw0 = blockDim.x > 64 ? 64 : 0;  // first lane of the cost reduction: the second wave when there is one
   if (threadIdx.x == 0) {
     T merit = T(0);
     const int skip = p.N * 2;  // the |l_i|^2 terms of k = 0 do not enter (:421)
-    lds_ordered_visit<T>(sm, cm, [&](int e, T x) {
-      if ((e & 1) == 0 || e >= skip) merit += x;
-    });
+    for (int e = 0; e < skip && e < cm; e += 2) merit += sm[e];
+    lds_ordered_visit<T>(sm + skip, cm - skip, [&](int, T x) { merit += x; });
     res[0] = T(0.5) * merit;
   }
   const int i = int(threadIdx.x) - cw0;
@@ -580,7 +602,7 @@ __device__ __forceinline__ void costs_reduce(const DevProblem& p, const T* cost_
   const int count = p.T * p.N;
   const bool staged = sm != nullptr && count <= sm_elems;
   if (staged) {
-    for (int e = threadIdx.x; e < count; e += blockDim.x) sm[e] = cost_part[e];
+    stage_to_lds<T>(sm, cost_part, count);
     __syncthreads();
   }
   if (i < p.N) {

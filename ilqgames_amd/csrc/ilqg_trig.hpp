@@ -88,10 +88,26 @@ __device__ __forceinline__ bool trig_group_any(bool mine, unsigned long long gro
 }
 #endif
 
+// The library fall-backs as real calls (ILQG_TRIG_NOINLINE=1): the inlined library code brings its Payne-Hanek tables and
+// polynomial constants into the caller, where the optimiser hoists them out of the time-step loop and the register
+// allocator spills them — for a path that never runs in a driving game.
+#ifndef ILQG_TRIG_NOINLINE
+#define ILQG_TRIG_NOINLINE 0
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && ILQG_TRIG_NOINLINE
+__device__ __attribute__((noinline, cold)) inline void slow_sincos(double x, double* s, double* c) { sincos(x, s, c); }
+__device__ __attribute__((noinline, cold)) inline double slow_tan(double x) { return tan(x); }
+#define ILQG_SLOW_SINCOS slow_sincos
+#define ILQG_SLOW_TAN slow_tan
+#else
+#define ILQG_SLOW_SINCOS sincos
+#define ILQG_SLOW_TAN tan
+#endif
+
 __host__ __device__ __forceinline__ void fast_sincos(double x, double* s, double* c, unsigned long long group = ~0ull) {
 #if defined(__HIP_DEVICE_COMPILE__)
   if (__builtin_expect(trig_group_any(!(__builtin_fabs(x) <= kTrigFastLimit), group), 0)) {
-    sincos(x, s, c);
+    ILQG_SLOW_SINCOS(x, s, c);
     return;
   }
 #endif
@@ -140,7 +156,7 @@ __host__ __device__ __forceinline__ T fast_tan_core(T x) {
 }
 __host__ __device__ __forceinline__ double fast_tan(double x, unsigned long long group = ~0ull) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  if (__builtin_expect(trig_group_any(!(__builtin_fabs(x) <= kTrigFastLimit), group), 0)) return tan(x);
+  if (__builtin_expect(trig_group_any(!(__builtin_fabs(x) <= kTrigFastLimit), group), 0)) return ILQG_SLOW_TAN(x);
 #endif
   return fast_tan_core<double>(x);
 }

@@ -35,7 +35,8 @@ print("  entry spread over the batch: %.1f us" % (tl[:, 0].max() - t0))
 for name, i, j in (("entry -> pass start", 0, 1), ("rollout (wave 0)", 1, 2), ("  steps 0-32", 20, 21), ("  steps 32-64", 21, 22), ("  steps 64-96", 22, 23),
                    ("entry -> forward pass done (row wave)", 0, 3), ("chunk 0 wait (fwd done -> start)", 3, 4), ("chunk 0", 4, 5),
                    ("chunk 0 end -> chunk 1 start", 5, 6), ("chunk 1", 6, 7), ("rollout end -> chunk 1 start", 2, 6), ("chunk 1 end -> reductions", 7, 12),
-                   ("reductions + decision", 12, 13), ("whole pass (entry -> end)", 0, 13)):
+                   ("reductions + decision", 12, 13), ("  merit + cost reduction", 12, 14), ("  decision, cost commit", 14, 15),
+                   ("  state store, end", 15, 13), ("whole pass (entry -> end)", 0, 13)):
     print("  %-44s %s" % (name, d(i, j)))
 print("last chunk of the row wave:")
 for name, i, j in (("chunk start -> (x, u) staged", 6, 40), ("persistent slot init", 40, 41), ("Jacobian pass: ops", 41, 42), ("Jacobian pass: write-out", 42, 43),
