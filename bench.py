@@ -263,6 +263,9 @@ def main():
                     help="skip the back-tracking workload reported beside the headline (three_player_intersection, n = 16)")
     ap.add_argument("--no-configs", action="store_true",
                     help="skip the `configs` block (BASELINE.json configurations 3, 4, 5 in their per-GPU form, ~40 s)")
+    ap.add_argument("--no-copy-bandwidth", action="store_true",
+                    help="skip the copy-bandwidth measurement behind roofline.peak_measured (profiling runs: keeps the copy "
+                         "kernel out of the kernel statistics)")
     ap.add_argument("--cpu-sample", type=int, default=64,
                     help="instances in one run of the CPU baseline sample (64 x 20 iterations ~ 1.3 s on one host thread)")
     args = ap.parse_args()
@@ -428,7 +431,7 @@ def main():
         flops_exec_round = sweep_flops_executed_per_step(n, m, N, open_loop) * T * B
         peak_tf = FP64_PEAK_TFLOPS if elem == 8 else FP32_PEAK_TFLOPS
         peak_measured = None
-        if args.backend == "hip":
+        if args.backend == "hip" and not args.no_copy_bandwidth:
             try:
                 peak_measured = backend.hip.copy_bandwidth_gbs()
             except Exception as e:  # the nominal figure stands on its own

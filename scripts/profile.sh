@@ -7,7 +7,7 @@
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof
-ARGS=${BENCH_ARGS:---steps 10 --warmup 2 --repeats 1 --no-cpu-baseline --no-latency --no-second-workload}
+ARGS=${BENCH_ARGS:---steps 10 --warmup 2 --repeats 1 --no-cpu-baseline --no-latency --no-second-workload --no-copy-bandwidth}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- python $ROOT/bench.py $ARGS > $OUT/bench_trace.log 2>&1

@@ -4,7 +4,7 @@ ROOT=${GRAFT_REPO_ROOT:?run on the GPU box through gpurun (GRAFT_REPO_ROOT is un
 cd "$ROOT" || exit 1
 rm -rf gpurun_out/prof_t; mkdir -p gpurun_out/prof_t
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $ROOT/gpurun_out/prof_t/trace -o bench -- python $ROOT/bench.py $1 --steps 10 --warmup 2 --repeats 1 --no-cpu-baseline --no-latency --no-second-workload > $ROOT/gpurun_out/prof_t/log 2>&1
+rocprofv3 --kernel-trace --stats -d $ROOT/gpurun_out/prof_t/trace -o bench -- python $ROOT/bench.py $1 --steps 10 --warmup 2 --repeats 1 --no-cpu-baseline --no-latency --no-second-workload --no-copy-bandwidth > $ROOT/gpurun_out/prof_t/log 2>&1
 cd $ROOT
 python - <<'PY'
 import sqlite3
