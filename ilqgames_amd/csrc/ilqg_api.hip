@@ -1275,6 +1275,14 @@ static ilqg_status launch_linquad(const ilqg_problem* p, int32_t batch, const vo
   return fail(ILQG_ERR_UNSUPPORTED, "no device kernel instantiated for this problem's dimensions");
 }
 
+// Threads of a workgroup of the run-time-dimensioned sweeps (ilqg_lq_generic.hpp: every phase strides its entries over
+// the workgroup and ends with a barrier).  -DILQG_GEN_THREADS_SMALL=n: the size for games whose phases have at most 160
+// entries (A/B measurements).
+#ifndef ILQG_GEN_THREADS_SMALL
+#define ILQG_GEN_THREADS_SMALL 256
+#endif
+static inline int generic_sweep_threads(int n, int m) { return n * (n + m) <= 160 ? ILQG_GEN_THREADS_SMALL : 256; }
+
 // LDS a CU can give one workgroup (gfx950: 160 KB)
 static constexpr size_t kLdsPerWorkgroup = size_t(160) * 1024;
 
@@ -1453,7 +1461,7 @@ static ilqg_status generic_solve(ilqg_problem* p, int32_t batch, const void* x0,
         tic = wall();
         iteration_open = true;
       }
-      hipLaunchKernelGGL(k_lq, dim3(batch), dim3(256), lds_lq, stream, d, sa);
+      hipLaunchKernelGGL(k_lq, dim3(batch), dim3(generic_sweep_threads(d.n, d.m)), lds_lq, stream, d, sa);
       HIP_TRY(hipGetLastError());
     }
     if (!want_lq && !restarted) break;
@@ -1501,7 +1509,7 @@ static ilqg_status launch_lq_generic(const ilqg_dims* d, const PairTable& pt, bo
   g.force_valu = 0;
   auto kern = lq_generic_kernel<T>;
   raise_lds_limit((const void*)kern, lds);
-  hipLaunchKernelGGL(kern, dim3(d->batch), dim3(256), lds, stream, g, gd, pt, open_loop ? 1 : 0, row);
+  hipLaunchKernelGGL(kern, dim3(d->batch), dim3(generic_sweep_threads(gd.n, gd.m)), lds, stream, g, gd, pt, open_loop ? 1 : 0, row);
   HIP_TRY(hipGetLastError());
   return ILQG_OK;
 }

@@ -152,11 +152,44 @@ ILQG_HD void gen_ed_terms(const GenDims& d, const GenLQArgs<T>& a, const PairTab
   terms[2 * i + 1] = st;
 }
 
+// The same with Q_i l_i of the step already formed (`ql` [n], the sums over e in the order above) — the forward passes
+// form them in a phase of their own, one entry per (player, row), instead of n^2 dependent global reads on one thread.
+template <typename T>
+ILQG_HD void gen_ed_terms_ql(const GenDims& d, const GenLQArgs<T>& a, const PairTable& pt, int k, const T* alpha_k,
+                             const T* x, int i, const T* ql, T* terms) {
+  const int n = d.n, mi = d.udim[i], q = pt.pii[i];
+  const T* Rii = a.R + size_t(k) * pt.Rsz + pt.roff[q];
+  const T* rii = a.r + size_t(k) * pt.rsz + pt.rgoff[q];
+  T ct = T(0);
+  for (int c = 0; c < mi; c++) {
+    T aR = T(0);
+    for (int b = 0; b < mi; b++) aR += alpha_k[d.uoff[i] + b] * Rii[b + mi * c];
+    ct += aR * rii[c];
+  }
+  T st = T(0);
+  for (int c = 0; c < n; c++) st += x[c] * ql[c];
+  terms[2 * i] = ct;
+  terms[2 * i + 1] = st;
+}
+template <typename T>
+ILQG_HD T gen_ql_entry(const GenDims& d, const GenLQArgs<T>& a, int k, int i, int c) {  // (Q_i l_i)[c] of step k
+  const int n = d.n;
+  const T* Qi = a.Q + (size_t(k) * d.N + i) * n * n;
+  const T* li = a.l + (size_t(k) * d.N + i) * n;
+  T ql = T(0);
+  for (int e = 0; e < n; e++) ql += Qi[c + n * e] * li[e];
+  return ql;
+}
+
 // LDS elements of the feedback sweep: [Z (N n^2) | zeta (N n) | BZ (m n) | SY (m (m + n + 1)) | P (m n) | alpha (m) |
 // F (n^2) | beta (n) | U (n^2) | tz (n) | yz (m) | x (2 n) | terms (2 N) | hv (4)]
+// ... | sA (n^2) | sB (n m) | sR (<= N m^2) | sr (<= N m)]: the step's A, B, R, r, staged once per step (round 6: the
+// phases read them n or m_j^2 times per entry, and read from global memory every one of those was a dependent
+// global-memory round trip inside a dot product)
 ILQG_HD size_t gen_feedback_lds_elems(int n, int N, int m) {
   return size_t(N) * n * n + size_t(N) * n + size_t(m) * n + size_t(m) * (m + n + 1) + size_t(m) * n + m + size_t(n) * n +
-         n + size_t(n) * n + n + m + 2 * size_t(n) + 2 * size_t(N) + 4;
+         n + size_t(n) * n + n + m + 2 * size_t(n) + 2 * size_t(N) + 4 +
+         size_t(n) * n + size_t(n) * m + size_t(N) * m * m + size_t(N) * m;
 }
 
 template <typename T, typename Par>
@@ -176,6 +209,10 @@ ILQG_HD void lq_feedback_generic(const GenDims& d, const GenLQArgs<T>& a, const 
   T* xb = yz + m;  // two buffers of n for the forward pass
   T* terms = xb + 2 * n;
   T* hv = terms + 2 * N;
+  T* sA = hv + 4;
+  T* sB = sA + size_t(n) * n;
+  T* sR = sB + size_t(n) * m;
+  T* sr = sR + size_t(N) * m * m;
 
   // ---- terminal step: Z_i = Q_i[T-1], zeta_i = l_i[T-1]; strategies at T-1 stay zero (:102-105, strategy.h:64-70) ----
   par(N * n * n, [&](int e) { Z[e] = a.Q[size_t(Tn - 1) * N * n * n + e]; });
@@ -188,12 +225,22 @@ ILQG_HD void lq_feedback_generic(const GenDims& d, const GenLQArgs<T>& a, const 
   });
 
   for (int k = Tn - 2; k >= 0; k--) {
-    const T* A = a.A + size_t(k) * n * n;
-    const T* B = a.Bm + size_t(k) * n * m;
     const T* Q = a.Q + size_t(k) * N * n * n;
     const T* l = a.l + size_t(k) * N * n;
-    const T* R = a.R + size_t(k) * pt.Rsz;
-    const T* r = a.r + size_t(k) * pt.rsz;
+    {  // the step's A, B, R, r into LDS: one coalesced pass, one exposed global round trip
+      const T* gA = a.A + size_t(k) * n * n;
+      const T* gB = a.Bm + size_t(k) * n * m;
+      const T* gR = a.R + size_t(k) * pt.Rsz;
+      const T* gr = a.r + size_t(k) * pt.rsz;
+      const int cA = n * n, cB = n * m, cR = pt.Rsz, cr = pt.rsz;
+      par(cA + cB + cR + cr, [&](int e) {
+        if (e < cA) sA[e] = gA[e];
+        else if (e < cA + cB) sB[e - cA] = gB[e - cA];
+        else if (e < cA + cB + cR) sR[e - cA - cB] = gR[e - cA - cB];
+        else sr[e - cA - cB - cR] = gr[e - cA - cB - cR];
+      });
+    }
+    const T *A = sA, *B = sB, *R = sR, *r = sr;
     // ---- B_i^T Z_i (the rows of the stacked system) and B_i^T zeta_i + r_ii (:128, :154-157) ----
     par(m * n + m, [&](int e) {
       if (e < m * n) {
@@ -329,19 +376,35 @@ ILQG_HD void lq_feedback_generic(const GenDims& d, const GenLQArgs<T>& a, const 
   for (int k = 0; k < Tn; k++) {
     const T* x = xb + cur * n;
     T* xn = xb + (1 - cur) * n;
-    const T* al = a.alpha + size_t(k) * m;
+    // the step's A, B, alpha (and Q_i l_i for ExpectedDecrease) staged / formed in one parallel phase: the recursion
+    // below then reads LDS only (the Z tiles of the backward sweep are free by now: Q_i l_i goes there)
+    T* const ql = Z;
+    {
+      const T* gA = a.A + size_t(k) * n * n;
+      const T* gB = a.Bm + size_t(k) * n * m;
+      const T* gal = a.alpha + size_t(k) * m;
+      const int cA = n * n, cB = n * m;
+      par(cA + cB + m + (a.ed_out ? N * n : 0), [&](int e) {
+        if (e < cA) sA[e] = gA[e];
+        else if (e < cA + cB) sB[e - cA] = gB[e - cA];
+        else if (e < cA + cB + m) sAl[e - cA - cB] = gal[e - cA - cB];
+        else {
+          const int w = e - cA - cB - m;
+          ql[w] = gen_ql_entry<T>(d, a, k, w / n, w % n);
+        }
+      });
+    }
+    const T* al = sAl;
     par(n + N, [&](int e) {
       if (e < n) {
         if (a.dx) a.dx[size_t(k) * n + e] = x[e];
-        const T* A = a.A + size_t(k) * n * n;
-        const T* B = a.Bm + size_t(k) * n * m;
         T s = T(0);
-        for (int c = 0; c < n; c++) s += A[e + n * c] * x[c];
+        for (int c = 0; c < n; c++) s += sA[e + n * c] * x[c];
         T bsum = T(0);
-        for (int q = 0; q < m; q++) bsum -= B[e + n * q] * al[q];
+        for (int q = 0; q < m; q++) bsum -= sB[e + n * q] * al[q];
         xn[e] = s + bsum;
       } else if (a.ed_out) {
-        gen_ed_terms<T>(d, a, pt, k, al, x, e - n, terms);
+        gen_ed_terms_ql<T>(d, a, pt, k, al, x, e - n, ql + size_t(e - n) * n, terms);
       }
     });
     if (a.ed_out)
@@ -371,9 +434,10 @@ ILQG_HD int gen_ol_row_elems(int n, int m, int N, bool fat) {
 }
 // LDS: [M (N n^2) | mv (N n) | W (m n) | w (m) | V (m n) | g (m) | SY (n (2 n + 1)) | MX (n^2) | tv (n) | Rw (m (m + n + 1)) |
 //       x (2 n) | terms (2 N) | hv (4) | cs (N n)]
+//       ... | sA (n^2) | sB (n m)]: the step's A and B, staged once per step (round 6, as in the feedback sweep)
 ILQG_HD size_t gen_openloop_lds_elems(int n, int N, int m) {
   return size_t(N) * n * n + size_t(N) * n + 2 * (size_t(m) * n + m) + size_t(n) * (2 * n + 1) + size_t(n) * n + n +
-         size_t(m) * (m + n + 1) + 2 * size_t(n) + 2 * size_t(N) + 4 + size_t(N) * n;
+         size_t(m) * (m + n + 1) + 2 * size_t(n) + 2 * size_t(N) + 4 + size_t(N) * n + size_t(n) * n + size_t(n) * m;
 }
 
 template <typename T, typename Par>
@@ -395,6 +459,8 @@ ILQG_HD void lq_openloop_generic(const GenDims& d, const GenLQArgs<T>& a, const 
   T* terms = xb + 2 * n;
   T* hv = terms + 2 * N;
   T* cs = hv + 4;  // M_i[k+1] x_{k+1} + m_i[k+1] of every player (costates)
+  T* sA = cs + size_t(N) * n;
+  T* sB = sA + size_t(n) * n;
 
   par(N * n * n, [&](int e) { M[e] = a.Q[size_t(Tn - 1) * N * n * n + e]; });  // :105-108
   par(N * n, [&](int e) { mv[e] = a.l[size_t(Tn - 1) * N * n + e]; });
@@ -402,8 +468,16 @@ ILQG_HD void lq_openloop_generic(const GenDims& d, const GenLQArgs<T>& a, const 
   par(m, [&](int e) { a.alpha[size_t(Tn - 1) * m + e] = T(0); });
 
   for (int k = Tn - 2; k >= 0; k--) {
-    const T* A = a.A + size_t(k) * n * n;
-    const T* B = a.Bm + size_t(k) * n * m;
+    {  // the step's A and B into LDS: one coalesced pass instead of a global read per term of every dot product
+      const T* gA = a.A + size_t(k) * n * n;
+      const T* gB = a.Bm + size_t(k) * n * m;
+      const int cA = n * n;
+      par(cA + n * m, [&](int e) {
+        if (e < cA) sA[e] = gA[e];
+        else sB[e - cA] = gB[e - cA];
+      });
+    }
+    const T *A = sA, *B = sB;
     const T* Q = a.Q + size_t(k) * N * n * n;
     const T* l = a.l + size_t(k) * N * n;
     const T* R = a.R + size_t(k) * pt.Rsz;
@@ -558,17 +632,31 @@ ILQG_HD void lq_openloop_generic(const GenDims& d, const GenLQArgs<T>& a, const 
       break;
     }
     const T* row = a.scratch + size_t(k) * ROW;
+    // the row's [X | y | V | g] staged into LDS (SY, V, g are free after the backward sweep), and Q_i l_i of the step
+    // formed in parallel for ExpectedDecrease (into M: the forward pass reads M_i[k+1] from the row)
+    T* const ql = M;
+    {
+      const int cXy = n * n + n, cV = m * n + m;
+      par(cXy + cV + (a.ed_out ? N * n : 0), [&](int e) {
+        if (e < cXy) SY[e] = row[e];
+        else if (e < cXy + m * n) V[e - cXy] = row[e];
+        else if (e < cXy + cV) g[e - cXy - m * n] = row[e];
+        else {
+          const int w = e - cXy - cV;
+          ql[w] = gen_ql_entry<T>(d, a, k, w / n, w % n);
+        }
+      });
+    }
     par(n, [&](int e) {  // x_{k+1} = X x_k + y
       T s = T(0);
-      for (int c = 0; c < n; c++) s += row[e + n * c] * x[c];
-      xn[e] = s + row[n * n + e];
+      for (int c = 0; c < n; c++) s += SY[e + n * c] * x[c];
+      xn[e] = s + SY[n * n + e];
     });
     par(m + (fat ? N * n : 0), [&](int e) {
       if (e < m) {  // alpha_i,k = V_i x_{k+1} + g_i
-        const T* Vr = row + n * n + n;
         T s = T(0);
-        for (int c = 0; c < n; c++) s += Vr[e + m * c] * xn[c];
-        a.alpha[size_t(k) * m + e] = s + Vr[m * n + e];
+        for (int c = 0; c < n; c++) s += V[e + m * c] * xn[c];
+        a.alpha[size_t(k) * m + e] = s + g[e];
       } else {  // M_i[k+1] x_{k+1} + m_i[k+1], for the costate
         const int i = (e - m) / n, rr = (e - m) % n;
         const T* Mi = row + n * n + n + m * n + m + size_t(i) * n * n;
@@ -587,7 +675,7 @@ ILQG_HD void lq_openloop_generic(const GenDims& d, const GenLQArgs<T>& a, const 
         a.costates[(size_t(k) * N + i) * n + rr] = s;
       });
     if (a.ed_out) {
-      par(N, [&](int i) { gen_ed_terms<T>(d, a, pt, k, a.alpha + size_t(k) * m, x, i, terms); });
+      par(N, [&](int i) { gen_ed_terms_ql<T>(d, a, pt, k, a.alpha + size_t(k) * m, x, i, ql + size_t(i) * n, terms); });
       par(1, [&](int) {
         T ed = hv[1];
         for (int i = 0; i < N; i++) {
