@@ -14,7 +14,9 @@ def classify(op):
         return "mfma"
     if op.startswith("ds_"):
         return "lds"
-    if op.startswith(("global_", "buffer_", "scratch_", "flat_")):
+    if op.startswith("scratch_"):
+        return "scratch"
+    if op.startswith(("global_", "buffer_", "flat_")):
         return "vmem"
     if op.startswith("s_waitcnt"):
         return "wait"

@@ -755,3 +755,59 @@ def test_instances_sharing_a_wavefront_in_the_split_rollout_do_not_see_each_othe
         for k in keys:
             assert np.array_equal(pair[k][0], whole[k][a], equal_nan=True), (a, b, k)
             assert np.array_equal(pair[k][1], whole[k][b], equal_nan=True), (a, b, k)
+
+
+@pytest.mark.parametrize("dtype", [abi.F64, abi.F32])
+def test_rollout_hands_over_to_the_library_trig_past_the_fast_range(hip, oracle, dtype):
+    """The rollouts integrate with range-limited sin / cos / tan kernels in a loop that holds no library fall-back,
+    fall back to the library's once some heading or steering angle of the trajectory's lanes leaves that range
+    (fast_sincos / fast_tan, csrc/ilqg_trig.hpp; sub_integrate_stages, csrc/ilqg_models.hpp).
+    Headline system (Car5D, Car5D, Unicycle4D): instance 0's unicycle heading crosses the limit in mid-horizon,
+    instance 1's car steering angle does (the tangent), instance 2 starts beyond it, instance 3 never leaves it and
+    shares kernels with the others.  The stand-alone rollout, the fused trial kernel and the split (two trajectories
+    per wavefront) one against the oracle; positions and speeds are compared, the huge angles separately (their ulp
+    is 1.5e-11 / 1.2e-4)."""
+    spec = examples.modified_three_player_intersection()
+    spec.params.expected_decrease_fraction = 0.001
+    spec.params.initial_alpha_scaling = 0.1
+    limit = 1.0e5 if dtype == abi.F64 else 2.0e3  # kTrigFastLimit / kTrigFastLimitF, csrc/ilqg_trig.hpp
+    B, T, n, m = 4, spec.T, spec.n, spec.m
+    x0 = examples.jittered_x0(spec, B, seed=11)
+    us_ref = np.zeros((B, T, m))
+    # state: car (x, y, theta, phi, v) x 2, unicycle (x, y, theta, v); controls (phi rate, a) x 2, (omega, a)
+    x0[0, 12] += limit - 3.0
+    us_ref[0, :, 4] = 1.0           # + 10 rad over the horizon: crosses after ~ 30 steps
+    # car 1's steering angle crosses after ~ 35 / 40 steps, on a stretch that holds no pole of the tangent
+    # (1e5 = 31830 pi + 3.106: poles at 1e5 - 1.535 and 1e5 + 1.607;  2e3 = 636 pi + 1.947: poles at 2e3 - 0.376, + 2.765)
+    x0[1, 3] = limit - (0.5 if dtype == abi.F64 else 0.05)
+    us_ref[1, :, 0] = 0.13 if dtype == abi.F64 else 0.012
+    x0[2, 7] += 3.0 * limit         # car 2's heading beyond the range from the first step
+    hd = [2, 3, 7, 8, 12]
+    rest = [i for i in range(n) if i not in hd]
+    xs_ref = np.tile(x0[:, None, :], (1, T, 1))
+    z = lambda *s: np.zeros(s)  # noqa: E731
+    op = oracle.OracleProblem(spec)
+    hp = hip.Problem(spec, dtype)
+    xs_o, us_o = op.rollout(dtype, x0, xs_ref, us_ref, z(B, T, m * n), z(B, T, m))
+    xs_d, us_d = hp.rollout(x0, xs_ref, us_ref, z(B, T, m * n), z(B, T, m))
+    assert np.abs(xs_o[0, :, 12]).max() > limit + 5 and np.abs(xs_o[0, 0, 12]) < limit   # the crossing is in the horizon
+    assert np.abs(xs_o[1, :, 3]).max() > limit + 0.05 and np.abs(xs_o[1, 0, 3]) < limit
+    ptol, atol = (1e-9, 1e-9) if dtype == abi.F64 else (2e-3, 5e-2)  # fp32: a heading driven by the tangent of an angle whose ulp is 1.2e-4
+    for b in range(B):
+        assert rel_err(_np(xs_d)[b][:, rest], xs_o[b][:, rest]) < ptol, b
+    assert np.abs(_np(xs_d)[:, :, hd] - xs_o[:, :, hd]).max() < atol * max(1.0, limit * 1e-4)
+    # instance 3 beside the others and alone: the same bits (the hand-over is decided per wavefront, its result is not)
+    xs_a, _ = hp.rollout(x0[3:], xs_ref[3:], us_ref[3:], z(1, T, m * n), z(1, T, m))
+    assert np.array_equal(_np(xs_a)[0], _np(xs_d)[3])
+    # whole iterations: fused trial kernel (one trajectory per wavefront) and the split form (two per wavefront)
+    ref = op.solve(dtype, x0, fixed_iters=2)
+    for kw in (dict(), dict(split_trial=True)):
+        out = hp.solve(x0, fixed_iters=2, **kw)
+        xd = _np(out["xs"])
+        assert np.all(np.isfinite(xd)), kw
+        ok = [b for b in range(B) if np.all(np.isfinite(ref["xs"][b]))]
+        assert 3 in ok and len(ok) >= 2
+        tol = 1e-6 if dtype == abi.F64 else 2e-2
+        assert rel_err(xd[ok][:, :, rest], ref["xs"][ok][:, :, rest]) < tol, kw
+        alone = hp.solve(x0[3:], fixed_iters=2, **kw)
+        assert np.array_equal(_np(alone["xs"])[0], xd[3]), kw
