@@ -109,11 +109,13 @@ class HipBackend:
     split_trial = None  # ilqg_solve_options::split_trial: None = the library's choice
     adjoint = None      # ilqg_solve_options::adjoint_expected_decrease
     static_rows = None  # ilqg_solve_options::static_rows
+    padded_sweep = None  # ilqg_solve_options::padded_sweep
 
     def solve(self, x0, bufs, iters):
         self.prob.solve(x0, bufs, fixed_iters=iters, counted=self.counted, probe_first=self.probe_first,
                         single_wave_sweep=self.single_wave, split_trial=self.split_trial,
-                        adjoint_expected_decrease=self.adjoint, static_rows=self.static_rows)
+                        adjoint_expected_decrease=self.adjoint, static_rows=self.static_rows,
+                        padded_sweep=self.padded_sweep)
 
     def sync(self):
         self.torch.cuda.synchronize()
@@ -255,6 +257,9 @@ def main():
                     help="ilqg_solve_options::adjoint_expected_decrease (A/B measurements)")
     ap.add_argument("--split-trial", choices=["auto", "on", "off"], default="auto",
                     help="ilqg_solve_options::split_trial (A/B measurements)")
+    ap.add_argument("--padded-sweep", choices=["auto", "on", "off"], default="auto",
+                    help="ilqg_solve_options::padded_sweep (A/B measurements: a run-time-dimensioned solve's sweep on the "
+                         "specialised kernel of the shape the game embeds in vs the all-LDS sweep)")
     ap.add_argument("--static-rows", choices=["auto", "on", "off"], default="auto",
                     help="ilqg_solve_options::static_rows (A/B measurements: straight-line row stage vs the interpreter)")
     ap.add_argument("--probe-first", type=int, default=0,
@@ -293,6 +298,7 @@ def main():
     backend.split_trial = {"auto": None, "on": True, "off": False}[args.split_trial]
     backend.adjoint = {"auto": None, "on": True, "off": False}[args.adjoint]
     backend.static_rows = {"auto": None, "on": True, "off": False}[args.static_rows]
+    backend.padded_sweep = {"auto": None, "on": True, "off": False}[args.padded_sweep]
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

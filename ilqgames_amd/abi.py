@@ -13,7 +13,7 @@ F32, F64 = 0, 1
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_NO_DEVICE = 0, 1, 2, 3, 4
 
 # ilqg_dyn_kind
-ABI_VERSION = 7  # ILQG_ABI_VERSION of include/ilqg.h these mirrors were written against
+ABI_VERSION = 8  # ILQG_ABI_VERSION of include/ilqg.h these mirrors were written against
 DYN_UNICYCLE_4D, DYN_CAR_5D, DYN_CAR_6D = 1, 2, 3
 DYN_UNICYCLE_4D_DISTURBED, DYN_PLANAR_DISTURBANCE = 4, 5  # the two rows of TwoPlayerUnicycle4D
 DYN_DUBINS_CAR = 6  # (px, py, theta), u = (omega), param0 = speed
@@ -46,6 +46,7 @@ FLAG_ORIENTED, FLAG_IS_MIN, FLAG_EQUALITY = 1, 2, 4
 # ILQG_SCHEDULE_* (ilqg_problem_last_schedule)
 SCHEDULE_SINGLE_WAVE_SWEEP, SCHEDULE_ADJOINT_DECREASE, SCHEDULE_SPLIT_TRIAL, SCHEDULE_COMPACT_ROWS = 1, 2, 4, 8
 SCHEDULE_COUNTED, SCHEDULE_GENERIC, SCHEDULE_OPEN_LOOP, SCHEDULE_STATIC_ROWS = 16, 32, 64, 128
+SCHEDULE_PADDED_SWEEP = 256
 SUM, MAX, MIN = 0, 1, 2
 
 
@@ -76,7 +77,7 @@ class SolveOptions(C.Structure):
                 ("split_trial", C.c_int32), ("handoff", C.c_int32), ("probe", C.c_int32), ("counted", C.c_int32),
                 ("compact_rows", C.c_int32), ("round_bursts", C.c_int32), ("generic_kernels", C.c_int32),
                 ("probe_first", C.c_int32), ("single_wave_sweep", C.c_int32), ("adjoint_expected_decrease", C.c_int32),
-                ("static_rows", C.c_int32), ("reserved1", C.c_int32),
+                ("static_rows", C.c_int32), ("padded_sweep", C.c_int32),
                 ("iterate_log", C.POINTER(IterateLog)), ("max_runtime", C.c_double)]
 
 

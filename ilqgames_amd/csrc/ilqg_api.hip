@@ -492,6 +492,169 @@ ilq_lq_kernel(DevProblem p, SolveArgs<T> sa) {
   lq_part_instance<T, NX, NP, MU, (KIND == LQ_PLAYER_WAVES_PACKED ? LQ_PLAYER_WAVES : KIND)>(p, sa, b, reinterpret_cast<T*>(smem_raw));
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The sweep of a run-time-dimensioned solve on a SPECIALISED sweep: a game whose (n, N, m_i) has no instantiation is
+// embedded in the smallest instantiated shape (NX >= n, NP == N, MU >= max m_i) —
+//   states n .. NX - 1:   A = 1 on the diagonal, no column of any B, no row of any Q_i or l_i;
+//   controls m_i .. MU - 1 of player i:  a zero column of B_i, a unit diagonal entry of R_ii, zeros in every other block —
+// which solves to exact zeros in the added rows of [P | alpha] and leaves every other entry the recursion of
+// src/lq_feedback_solver.cpp:110-213 (src/lq_open_loop_solver.cpp:73-195) produces for the game itself: the added
+// column of S = R + B^T Z B is the unit vector (the Gershgorin step of :163-176 reads a column at a time and leaves it
+// alone: radius 0, diagonal 1), the added rows and columns of every Z_i stay zero.  One workgroup per instance whose
+// stage is LQ: (1) the instance's dense rows, written by the run-time-dimensioned row stage, are copied into the padded
+// layout (a region of the library's scratch buffer), (2) the specialised sweep of the padded shape runs on them —
+// strategies, delta_x and ILQSolver::ExpectedDecrease as in lq_part_instance —, (3) the rows of [P | alpha] that belong
+// to the game are copied to where the solve keeps its strategies.  The copies are ~2 x the sweep's own traffic; the sweep
+// is the register-tiled one instead of the all-LDS form with a barrier per phase (ilqg_lq_generic.hpp): n = 8,
+// m_i = (1, 2), B = 1024: 1.7 ms -> see DESIGN.md 3.8.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T, int NX, int NP, int MU, bool OL>
+struct PadLayout {
+  static constexpr int M = NP * MU;
+  size_t A, B, Q, l, R, r, P, al, dx, scr, total;
+  __host__ __device__ PadLayout(int T_steps, int Rsz, int rsz) {
+    size_t o = 0;
+    auto take = [&](size_t cnt) {
+      const size_t at = o;
+      o += (cnt + 3) & ~size_t(3);
+      return at;
+    };
+    const size_t Tn = size_t(T_steps);
+    A = take(Tn * NX * NX);
+    B = take(Tn * NX * M);
+    Q = take(Tn * NP * NX * NX);
+    l = take(Tn * NP * NX);
+    R = take(Tn * Rsz);
+    r = take(Tn * rsz);
+    P = take(Tn * M * NX);
+    al = take(Tn * M);
+    dx = take(Tn * NX);
+    scr = take(Tn * size_t(OL ? OLCfg<T, NX, NP, MU>::ROW : NP * (NX + 1) + NX));
+    total = o;
+  }
+};
+
+template <typename T>
+struct PadArgs {
+  T* pad;             // [batch][PadLayout::total]
+  size_t pad_stride;  // elements
+  PairTable ptp;      // the game's control blocks at MU x MU each
+};
+
+template <typename T, int NX, int NP, int MU, bool OL>
+struct PadSweep {
+  using C = LQCfg<T, NX, NP, MU>;
+  static constexpr bool PW = !OL && C::USE_MFMA;
+  static constexpr int NT = OL ? OLCfg<T, NX, NP, MU>::NT : LQFeedbackThreads<T, NX, NP, MU, false>::NT;
+  static constexpr int WG_PER_CU = OL ? 3 : (PW ? (NX <= 16 ? NP : 2) : 1);
+  // the slot the sweep leaves ILQSolver::ExpectedDecrease in (lq_part_instance), and the LDS the launch asks for
+  static constexpr int ED_SLOT = OL ? OLCfg<T, NX, NP, MU>::LDS_ELEMS
+                                 : (PW && !C::MFMA_ONE_TILE) ? FB2Cfg<T, NX, NP, MU>::LDS_ELEMS : C::oX;
+  static constexpr size_t LDS_ELEMS = OL ? OLCfg<T, NX, NP, MU>::LDS_ELEMS + 4
+                                      : PW ? MfmaSweepLds<T, NX, NP, MU>::ELEMS + (C::MFMA_ONE_TILE ? 0 : 4) : C::LDS_ELEMS;
+};
+
+template <typename T, int NX, int NP, int MU, bool OL>
+__global__ void __launch_bounds__((PadSweep<T, NX, NP, MU, OL>::NT), (PadSweep<T, NX, NP, MU, OL>::WG_PER_CU))
+padded_lq_kernel(DevProblem p, SolveArgs<T> sa, PadArgs<T> pa) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  T* sm = reinterpret_cast<T*>(smem_raw);
+  using PS = PadSweep<T, NX, NP, MU, OL>;
+  constexpr int M = NP * MU, NT = PS::NT;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int n = p.n, m = p.m, Tn = p.T;
+  const WsLayout L(n, m, p.N, Tn, p.pairs.Rsz, p.pairs.rsz, sa.ol_row, p.num_constraints, sa.al_mode);
+  T* const w = sa.ws + size_t(b) * sa.ws_stride;
+  SolveState<T>* const st = reinterpret_cast<SolveState<T>*>(w + L.state);
+  if (st->stage != ST_LQ) return;
+  const int sacc = __builtin_amdgcn_readfirstlane(st->sacc);
+  const PadLayout<T, NX, NP, MU, OL> PL(Tn, pa.ptp.Rsz, pa.ptp.rsz);
+  T* const q = pa.pad + size_t(b) * pa.pad_stride;
+  // ---- (1) dense rows of the game -> rows of the padded shape ----
+  {
+    const T *A = w + L.A, *Bm = w + L.B, *Q = w + L.Q, *l = w + L.l, *R = w + L.R, *r = w + L.r;
+    for (int e = tid; e < Tn * NX * NX; e += NT) {
+      const int k = e / (NX * NX), f = e - k * (NX * NX), c = f / NX, row = f - c * NX;
+      q[PL.A + e] = (row < n && c < n) ? A[size_t(k) * n * n + row + n * c] : (row == c ? T(1) : T(0));
+    }
+    for (int e = tid; e < Tn * NX * M; e += NT) {
+      const int k = e / (NX * M), f = e - k * (NX * M), c = f / NX, row = f - c * NX, i = c / MU, ce = c - i * MU;
+      q[PL.B + e] = (row < n && ce < p.udim[i]) ? Bm[size_t(k) * n * m + row + n * (p.uoff[i] + ce)] : T(0);
+    }
+    for (int e = tid; e < Tn * NP * NX * NX; e += NT) {
+      const int ki = e / (NX * NX), f = e - ki * (NX * NX), c = f / NX, row = f - c * NX;  // ki = k * NP + i
+      q[PL.Q + e] = (row < n && c < n) ? Q[size_t(ki) * n * n + row + n * c] : T(0);
+    }
+    for (int e = tid; e < Tn * NP * NX; e += NT) {
+      const int ki = e / NX, row = e - ki * NX;
+      q[PL.l + e] = row < n ? l[size_t(ki) * n + row] : T(0);
+    }
+    const int Rsz_p = pa.ptp.Rsz, rsz_p = pa.ptp.rsz;  // npairs * MU * MU, npairs * MU
+    for (int e = tid; e < Tn * Rsz_p; e += NT) {
+      const int k = e / Rsz_p, f = e - k * Rsz_p, pq = f / (MU * MU), g = f - pq * (MU * MU), cb = g / MU, ca = g - cb * MU;
+      const int mj = p.udim[p.pairs.pj[pq]];
+      q[PL.R + e] = (ca < mj && cb < mj) ? R[size_t(k) * p.pairs.Rsz + p.pairs.roff[pq] + ca + mj * cb]
+                                          : ((p.pairs.pi[pq] == p.pairs.pj[pq] && ca == cb) ? T(1) : T(0));
+    }
+    for (int e = tid; e < Tn * rsz_p; e += NT) {
+      const int k = e / rsz_p, f = e - k * rsz_p, pq = f / MU, ca = f - pq * MU;
+      const int mj = p.udim[p.pairs.pj[pq]];
+      q[PL.r + e] = ca < mj ? r[size_t(k) * p.pairs.rsz + p.pairs.rgoff[pq] + ca] : T(0);
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  // ---- (2) the specialised sweep (as lq_part_instance sets it up, dense rows, its own forward pass) ----
+  LQArgs<T> la;
+  la.A = q + PL.A; la.Bm = q + PL.B; la.Q = q + PL.Q; la.l = q + PL.l; la.R = q + PL.R; la.r = q + PL.r;
+  la.x0 = nullptr;
+  la.P = q + PL.P; la.alpha = q + PL.al; la.dx = q + PL.dx;
+  la.scratch = q + PL.scr;
+  la.ed_out = sm + PS::ED_SLOT;
+  la.T_steps = Tn;
+  la.adaptive = 1;
+  la.symmetric = 1;
+  if constexpr (OL) {
+    bool blocks = true;
+#pragma unroll
+    for (int i = 0; i < NP; i++) blocks = blocks && p.xoff[i + 1] > p.xoff[i];
+    if (blocks) {  // the added states extend the last player's block (their A entries are its diagonal's)
+      la.nsub = NP;
+#pragma unroll
+      for (int i = 0; i < NP; i++) la.xoff[i] = p.xoff[i];
+      la.xoff[NP] = NX;
+    }
+    lq_openloop_instance<T, NX, NP, MU>(la, pa.ptp, sm);
+  } else {
+    lq_feedback_dispatch<T, NX, NP, MU, false>(la, pa.ptp, sm);
+  }
+  __threadfence_block();
+  __syncthreads();
+  // ---- (3) the game's rows of [P | alpha] into strategy buffer 1 - sacc ----
+  T* const Pout = sacc ? sa.P + size_t(b) * Tn * m * n : w + L.P1;
+  T* const alout = sacc ? sa.alpha + size_t(b) * Tn * m : w + L.al1;
+  for (int e = tid; e < Tn * m * n; e += NT) {
+    const int k = e / (m * n), f = e - k * (m * n), c = f / m, row = f - c * m;
+    int i = 0;
+    while (i + 1 < p.N && row >= p.uoff[i + 1]) i++;
+    Pout[e] = q[PL.P + size_t(k) * M * NX + (i * MU + row - p.uoff[i]) + M * c];
+  }
+  for (int e = tid; e < Tn * m; e += NT) {
+    const int k = e / m, row = e - k * m;
+    int i = 0;
+    while (i + 1 < p.N && row >= p.uoff[i + 1]) i++;
+    alout[e] = q[PL.al + size_t(k) * M + i * MU + row - p.uoff[i]];
+  }
+  if (tid == 0) {
+    st->expected_decrease = sm[PS::ED_SLOT];
+    st->num_iterations += 1;
+    st->step = sa.forced_steps ? sa.forced_steps[size_t(b) * sa.fixed_iters + (st->num_iterations - 1)]
+                               : T(sa.prm.initial_alpha_scaling);
+    st->bt = 0;
+    st->stage = ST_ROLLOUT;
+  }
+}
+
 // The sweep of the run-time-dimensioned solve path (lq_part_generic, ilqg_solve.hpp).
 template <typename T>
 __global__ void __launch_bounds__(256) gen_lq_kernel(DevProblem p, SolveArgs<T> sa) {
@@ -601,6 +764,10 @@ struct __attribute__((visibility("hidden"))) DimsLaunch {
                            const ilqg_solve_options& opt, hipStream_t stream);
   // pointers in QuadBatchArgs' order: xs us lambdas mu t_extreme A Bm Q l R r merit_part cost_part active
   static ilqg_status rows(const DevProblem& d, int32_t batch, const void* const* ptrs, hipStream_t stream);
+  // the sweep of a run-time-dimensioned solve whose game is embedded in this shape (padded_lq_kernel);
+  // pad_elems_out != nullptr: only report the scratch elements one instance needs
+  static ilqg_status lq_padded(const DevProblem& d, const void* solve_args, const PairTable& ptp, void* pad,
+                               size_t* pad_elems_out, bool open_loop, hipStream_t stream);
 };
 
 template <typename T, int NX, int NP, int MU>
@@ -675,6 +842,33 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::lq_openloop(const ilqg_dims* d, const Pai
   hipLaunchKernelGGL(kern, dim3(d->batch), dim3(O::NT), lds, stream, g, pt);
   HIP_TRY(hipGetLastError());
   return ILQG_OK;
+}
+
+template <typename T, int NX, int NP, int MU>
+ilqg_status DimsLaunch<T, NX, NP, MU>::lq_padded(const DevProblem& d, const void* solve_args, const PairTable& ptp,
+                                                 void* pad, size_t* pad_elems_out, bool open_loop, hipStream_t stream) {
+  if constexpr (NX == 0) {
+    return fail(ILQG_ERR_UNSUPPORTED, "no shape to embed the game in");
+  } else {
+    auto go = [&](auto ol) -> ilqg_status {
+      constexpr bool OL = decltype(ol)::value;
+      const PadLayout<T, NX, NP, MU, OL> PL(d.T, ptp.Rsz, ptp.rsz);
+      if (pad_elems_out) {
+        *pad_elems_out = PL.total;
+        return ILQG_OK;
+      }
+      const SolveArgs<T>& sa = *static_cast<const SolveArgs<T>*>(solve_args);
+      PadArgs<T> pa{(T*)pad, PL.total, ptp};
+      using PS = PadSweep<T, NX, NP, MU, OL>;
+      auto kern = padded_lq_kernel<T, NX, NP, MU, OL>;
+      const size_t lds = PS::LDS_ELEMS * sizeof(T);
+      raise_lds_limit((const void*)kern, lds);
+      hipLaunchKernelGGL(kern, dim3(sa.batch), dim3(PS::NT), lds, stream, d, sa, pa);
+      HIP_TRY(hipGetLastError());
+      return ILQG_OK;
+    };
+    return open_loop ? go(std::true_type{}) : go(std::false_type{});
+  }
 }
 
 namespace {
@@ -1342,6 +1536,49 @@ static ilqg_status generic_solve(ilqg_problem* p, int32_t batch, const void* x0,
   raise_lds_limit((const void*)k_decide, lds_decide);
   raise_lds_limit((const void*)k_exit, lds_exit);
   raise_lds_limit((const void*)k_lq, lds_lq);
+  // The sweep on a specialised kernel: the smallest instantiated shape the game embeds in (padded_lq_kernel).  AUTO: for
+  // problems that have no instantiation of their own (ilqg_problem::generic); a problem sent here by
+  // ilqg_solve_options::generic_kernels keeps the run-time-dimensioned sweeps unless padded_sweep = ON.
+  int pad_nx = 0, pad_mu = 0;
+  PairTable ptp;
+  void* pad_buf = nullptr;
+  auto padded_launch = [&](size_t* elems_out) -> ilqg_status {
+#define X(NX_, NP_, MU_)                                                                                                      \
+    if (pad_nx == NX_ && d.N == NP_ && pad_mu == MU_)                                                                          \
+      return DimsLaunch<T, NX_, NP_, MU_>::lq_padded(d, &sa, ptp, pad_buf, elems_out, p->desc.params.open_loop != 0, stream);
+    ILQG_FOR_DIMS(X)
+#undef X
+    return fail(ILQG_ERR_UNSUPPORTED, "no shape to embed the game in");
+  };
+  if (opt.padded_sweep == ILQG_CHOICE_ON || (opt.padded_sweep == ILQG_CHOICE_AUTO && p->generic)) {
+    int mumax = 0;
+    for (int i = 0; i < d.N; i++) mumax = d.udim[i] > mumax ? d.udim[i] : mumax;
+#define X(NX_, NP_, MU_)                                                                                             \
+    if (NP_ == d.N && NX_ >= d.n && MU_ >= mumax && (pad_nx == 0 || NX_ < pad_nx || (NX_ == pad_nx && MU_ < pad_mu))) { \
+      pad_nx = NX_;                                                                                                  \
+      pad_mu = MU_;                                                                                                  \
+    }
+    ILQG_FOR_DIMS(X)
+#undef X
+    if (pad_nx == 0 && opt.padded_sweep == ILQG_CHOICE_ON)
+      return fail(ILQG_ERR_UNSUPPORTED, "padded_sweep = ON: no instantiated shape holds this game (same player count, at "
+                                        "least its states and its widest control)");
+    if (pad_nx) {
+      std::vector<ilqg_pair> pairs(d.pairs.npairs);
+      std::vector<int> udim_p(kMaxPlayers, pad_mu);
+      for (int q = 0; q < d.pairs.npairs; q++) pairs[q] = {d.pairs.pi[q], d.pairs.pj[q]};
+      std::string err;
+      if (!build_pairs(pairs.data(), d.pairs.npairs, udim_p.data(), d.N, &ptp, &err)) return fail(ILQG_ERR_INVALID, err);
+      for (int q = 0; q < d.pairs.npairs; q++) ptp.from_cost[q] = d.pairs.from_cost[q];
+      size_t elems = 0;
+      ilqg_status s = padded_launch(&elems);
+      if (s != ILQG_OK) return s;
+      s = Scratch().reserve(size_t(batch) * elems * sizeof(T));
+      if (s != ILQG_OK) return s;
+      pad_buf = ilqg_shared::scratch_state().ptr;
+      p->last_schedule |= ILQG_SCHEDULE_PADDED_SWEEP;
+    }
+  }
   const int row_chunks = (d.T + sa.rows_cw - 1) / sa.rows_cw;
   long long cap = al_mode ? (long long)(sa.prm.max_solver_iters + 1) * (sa.prm.unconstrained_solver_max_iters + 2)
                           : (long long)(opt.fixed_iters > 0 ? opt.fixed_iters : sa.prm.max_solver_iters) + 2;
@@ -1461,8 +1698,13 @@ static ilqg_status generic_solve(ilqg_problem* p, int32_t batch, const void* x0,
         tic = wall();
         iteration_open = true;
       }
-      hipLaunchKernelGGL(k_lq, dim3(batch), dim3(generic_sweep_threads(d.n, d.m)), lds_lq, stream, d, sa);
-      HIP_TRY(hipGetLastError());
+      if (pad_nx) {
+        const ilqg_status s = padded_launch(nullptr);
+        if (s != ILQG_OK) return s;
+      } else {
+        hipLaunchKernelGGL(k_lq, dim3(batch), dim3(generic_sweep_threads(d.n, d.m)), lds_lq, stream, d, sa);
+        HIP_TRY(hipGetLastError());
+      }
     }
     if (!want_lq && !restarted) break;
   }
@@ -2225,7 +2467,8 @@ ilqg_status ilqg_solve_batch_ex(ilqg_problem* p, int32_t batch, const void* x0, 
     if (c < ILQG_CHOICE_AUTO || c > ILQG_CHOICE_ON) return fail(ILQG_ERR_INVALID, "scheduling choices are ilqg_choice values");
   const DevProblem& d = p->dev;
   hipStream_t st = (hipStream_t)stream;
-  if (o.generic_kernels < ILQG_CHOICE_AUTO || o.generic_kernels > ILQG_CHOICE_ON)
+  if (o.generic_kernels < ILQG_CHOICE_AUTO || o.generic_kernels > ILQG_CHOICE_ON || o.padded_sweep < ILQG_CHOICE_AUTO ||
+      o.padded_sweep > ILQG_CHOICE_ON)
     return fail(ILQG_ERR_INVALID, "scheduling choices are ilqg_choice values");
   if (p->generic || o.generic_kernels == ILQG_CHOICE_ON)
     return p->desc.dtype == ILQG_F32

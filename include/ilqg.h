@@ -440,7 +440,13 @@ typedef struct {
                                      (ilqg_problem_row_program) runs the linearise / quadraticise stage of the fused trial
                                      kernel as straight-line code compiled for that structure instead of interpreting the
                                      program (AUTO: on).  Bit-identical.                                                */
-  int32_t reserved1;
+  int32_t padded_sweep;         /* ilqg_choice: a solve on the run-time-dimensioned kernels runs its Riccati sweep on the
+                                     specialised sweep of the smallest instantiated shape the game embeds in (same player
+                                     count, at least its states and its widest control; added states are inert, added
+                                     controls have a zero column of B and a unit entry of R_ii and solve to exact zeros).
+                                     AUTO: on for problems without an instantiation of their own; ON where no shape holds
+                                     the game is ILQG_ERR_UNSUPPORTED.  The same recursion on another elimination order:
+                                     results to rounding.  (This field was reserved1 = 0 up to ABI 7: same layout.)        */
   const struct ilqg_iterate_log* iterate_log; /* NULL, or where every logged iterate of the solve goes (below)          */
   double max_runtime;           /* > 0: the anytime exit of ILQSolver::Solve (src/ilq_solver.cpp:123-124) on the host's
                                      clock, seconds — once it has passed, instances leave the loop at their next
@@ -494,6 +500,7 @@ ilqg_status ilqg_solve_state_batch(const ilqg_problem* p, int32_t batch, const v
 #define ILQG_SCHEDULE_GENERIC 32            /* the run-time-dimensioned kernels                                   */
 #define ILQG_SCHEDULE_OPEN_LOOP 64          /* LQOpenLoopSolver's sweep                                           */
 #define ILQG_SCHEDULE_STATIC_ROWS 128       /* the row stage ran as straight-line code for a registered structure */
+#define ILQG_SCHEDULE_PADDED_SWEEP 256      /* run-time-dimensioned solve, its sweep on a specialised kernel (padded_sweep) */
 ilqg_status ilqg_problem_last_schedule(const ilqg_problem* p, int32_t* schedule_out);
 
 /* The row program ilqg_problem_create compiled the problem's dynamics and cost list into (csrc/ilqg_rowprog.hpp: passes,
@@ -645,11 +652,14 @@ const char* ilqg_last_error(void);
  * by default the library keeps one grow-only device allocation per calling thread for them.  A caller that owns all
  * device memory hands a buffer of its own here (per calling thread; NULL returns to the default): nothing is
  * allocated afterwards, and a call that needs more than `bytes` fails with ILQG_ERR_INVALID and the size it needs in
- * ilqg_last_error().  The solves (ilqg_*_solve_batch*) never touch this scratch: their memory is the workspace. */
+ * ilqg_last_error().  The solves (ilqg_*_solve_batch*) keep their memory in the workspace, with one exception: a solve
+ * on the run-time-dimensioned kernels whose sweep runs on the padded specialised kernel (ilqg_solve_options::padded_sweep)
+ * stages the padded rows of every instance in this scratch (batch x T x ~(N + 3) n'^2 elements). */
 ilqg_status ilqg_set_scratch(void* device_buffer, size_t bytes);
 
 /* Library / device introspection (used by the loader to fail loudly). */
-#define ILQG_ABI_VERSION 7 /* 7: ilqg_solve_options::deterministic (was reserved0) / static_rows, ilqg_copy_bandwidth, ilqg_problem_row_program, ilqg_row_program_build;
+#define ILQG_ABI_VERSION 8 /* 8: ilqg_solve_options::padded_sweep (was reserved1), ILQG_SCHEDULE_PADDED_SWEEP;
+                              7: ilqg_solve_options::deterministic (was reserved0) / static_rows, ilqg_copy_bandwidth, ilqg_problem_row_program, ilqg_row_program_build;
                               6: ilqg_problem_last_schedule;
                               5: ilqg_solve_options::iterate_log / max_runtime, run-time-dimensioned kernels behind every entry
                               point (any n <= 32, N <= 8, m_i), the affine constraints (ilqg_problem_desc::dense_params);

@@ -184,11 +184,72 @@ def _compare_forced(hip, op, spec, dtype, x0, steps, x0_nudged, K, solve_kwargs,
 
 @pytest.mark.parametrize("scene", MIXED + ["three_unicycle_scene_open_loop"])
 @pytest.mark.parametrize("dtype", [abi.F64, abi.F32])
-def test_forced_step_solves_of_mixed_dimension_games_match_oracle_after_every_iteration(hip, oracle, scene, dtype):
+@pytest.mark.parametrize("padded", [True, False], ids=["padded_sweep", "all_lds_sweep"])
+def test_forced_step_solves_of_mixed_dimension_games_match_oracle_after_every_iteration(hip, oracle, scene, dtype, padded):
+    """Both sweeps of the run-time-dimensioned solve: the specialised sweep of the shape the game embeds in
+    (ilqg_solve_options::padded_sweep, the default for these shapes: (8, 2, (1, 2)) in (8, 2, 2), (12, 3, 2) in (14, 3, 2))
+    and the all-LDS sweeps with run-time dimensions (csrc/ilqg_lq_generic.hpp)."""
     spec = examples.CONFIGS[scene]()
     K, B = 5, 8
     x0, op, steps, x0n = _forced(oracle, spec, B, K, seed=31)
-    _compare_forced(hip, op, spec, dtype, x0, steps, x0n, K, {})
+    _compare_forced(hip, op, spec, dtype, x0, steps, x0n, K, dict(padded_sweep=padded))
+
+
+def test_padded_sweep_is_reported_requested_and_refused(hip, oracle):
+    """ilqg_problem_last_schedule says which sweep a run-time-dimensioned solve ran; ON sends a problem that was pushed onto
+    the run-time-dimensioned kernels (generic_kernels) through the padded kernel of its own shape as well — no padding,
+    the copies only — and is refused with ILQG_ERR_UNSUPPORTED where no instantiated shape holds the game (five players).
+    Free-running solves under both sweeps take the same decisions on instances the oracle's own decisions are stable on."""
+    import torch
+    spec = examples.mixed_dubins_car_scene()
+    x0 = examples.jittered_x0(spec, 12, seed=4)
+    prob = hip.Problem(spec, abi.F64)
+    a = prob.solve(x0)
+    torch.cuda.synchronize()
+    assert prob.last_schedule() & abi.SCHEDULE_GENERIC and prob.last_schedule() & abi.SCHEDULE_PADDED_SWEEP
+    b = prob.solve(x0, padded_sweep=False)
+    torch.cuda.synchronize()
+    assert prob.last_schedule() & abi.SCHEDULE_GENERIC and not prob.last_schedule() & abi.SCHEDULE_PADDED_SWEEP
+    O = oracle.OracleProblem(spec)
+    ref, refn = O.solve(abi.F64, x0), O.solve(abi.F64, x0 + 1e-12 * np.random.default_rng(0).standard_normal(x0.shape))
+    robust = [i for i in range(12) if ref["iters"][i] == refn["iters"][i] and ref["status"][i] == refn["status"][i] and
+              rel_err(ref["xs"][i], refn["xs"][i]) < 1e-7]
+    assert len(robust) >= 6
+    for i in robust:
+        assert _np(a["iters"])[i] == _np(b["iters"])[i] == ref["iters"][i], i
+        assert rel_err(_np(a["xs"])[i], _np(b["xs"])[i]) < 1e-6 and rel_err(_np(a["xs"])[i], ref["xs"][i]) < 1e-6, i
+    # an instantiated shape on the run-time-dimensioned kernels: AUTO keeps their own sweep, ON takes the padded kernel
+    spec14 = examples.modified_three_player_intersection()
+    spec14.params.expected_decrease_fraction, spec14.params.initial_alpha_scaling = 0.001, 0.1
+    x14 = examples.jittered_x0(spec14, 6, seed=2)
+    p14 = hip.Problem(spec14, abi.F64)
+    g = p14.solve(x14, fixed_iters=3, generic_kernels=True)
+    torch.cuda.synchronize()
+    assert not p14.last_schedule() & abi.SCHEDULE_PADDED_SWEEP
+    h = p14.solve(x14, fixed_iters=3, generic_kernels=True, padded_sweep=True)
+    torch.cuda.synchronize()
+    assert p14.last_schedule() & abi.SCHEDULE_PADDED_SWEEP
+    r14 = oracle.OracleProblem(spec14).solve(abi.F64, x14, fixed_iters=3)
+    for out in (g, h):
+        assert rel_err(_np(out["xs"]), r14["xs"]) < 1e-7 and rel_err(_np(out["P"]), r14["rawP"]) < 1e-6
+    # five players: no instantiated shape has five (ILQG_FOR_DIMS, csrc/ilqg_api.hip)
+    s5 = abi.ProblemSpec(T=10)
+    for _ in range(5):
+        s5.add_player(abi.DYN_UNICYCLE_4D, 0.0)
+    for i in range(5):
+        s5.quadratic(i, 1.0, 4 * i + 3, 1.0)
+        s5.quadratic(i, 1.0, -1, 0.0, control_of=i)
+    s5.x0 = np.zeros(s5.n)
+    p5 = hip.Problem(s5, abi.F64)
+    x5 = 0.1 * np.random.default_rng(3).standard_normal((3, s5.n))
+    out5 = p5.solve(x5, fixed_iters=2)   # AUTO: the all-LDS sweep
+    torch.cuda.synchronize()
+    assert not p5.last_schedule() & abi.SCHEDULE_PADDED_SWEEP
+    r5 = oracle.OracleProblem(s5).solve(abi.F64, x5, fixed_iters=2)
+    assert rel_err(_np(out5["xs"]), r5["xs"]) < 1e-9
+    with pytest.raises(hip.IlqgError) as e:
+        p5.solve(x5, fixed_iters=2, padded_sweep=True)
+    assert e.value.status == abi.ERR_UNSUPPORTED
 
 
 @pytest.mark.parametrize("scene", ["modified_three_player_intersection", "roundabout_merging"])
