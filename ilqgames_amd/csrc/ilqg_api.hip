@@ -511,7 +511,7 @@ ilq_lq_kernel(DevProblem p, SolveArgs<T> sa) {
 template <typename T, int NX, int NP, int MU, bool OL>
 struct PadLayout {
   static constexpr int M = NP * MU;
-  size_t A, B, Q, l, R, r, P, al, dx, scr, total;
+  size_t A, B, Q, l, R, r, P, al, dx, scr, x0, total;
   __host__ __device__ PadLayout(int T_steps, int Rsz, int rsz) {
     size_t o = 0;
     auto take = [&](size_t cnt) {
@@ -530,6 +530,7 @@ struct PadLayout {
     al = take(Tn * M);
     dx = take(Tn * NX);
     scr = take(Tn * size_t(OL ? OLCfg<T, NX, NP, MU>::ROW : NP * (NX + 1) + NX));
+    x0 = take(NX);
     total = o;
   }
 };
@@ -554,98 +555,156 @@ struct PadSweep {
                                       : PW ? MfmaSweepLds<T, NX, NP, MU>::ELEMS + (C::MFMA_ONE_TILE ? 0 : 4) : C::LDS_ELEMS;
 };
 
+// The game as the copies see it: its own dimensions and control blocks, and where its rows are.
+template <typename T>
+struct PadGame {
+  int n, m, N, T_steps;
+  const int *udim, *uoff;            // [N], [N + 1]
+  const PairTable* pt;               // the game's blocks at their own sizes
+  const T *A, *Bm, *Q, *l, *R, *r;   // instance bases, the game's dense rows
+  const T* x0;                       // [n] or nullptr
+  T *P, *alpha, *dx;                 // instance bases of the results; dx may be nullptr
+  int want_ed;                       // ILQSolver::ExpectedDecrease into sm[PadSweep::ED_SLOT]
+  int adaptive, symmetric;
+  const int* xoff;                   // open loop: [N + 1] state offsets of a block-diagonal A, or nullptr (dense)
+};
+
+// Steps (1) - (3) above for one instance, by the whole workgroup; `q`: the instance's region of the padded buffer.
+template <typename T, int NX, int NP, int MU, bool OL>
+__device__ __forceinline__ void padded_sweep_instance(const PadGame<T>& g, const PairTable& ptp, T* q, T* sm) {
+  using PS = PadSweep<T, NX, NP, MU, OL>;
+  constexpr int M = NP * MU, NT = PS::NT;
+  const int tid = threadIdx.x;
+  const int n = g.n, m = g.m, Tn = g.T_steps;
+  const PadLayout<T, NX, NP, MU, OL> PL(Tn, ptp.Rsz, ptp.rsz);
+  // (eight loads in flight per lane: the workgroup is two to four waves, and a load-store pair per trip leaves the
+  // copy bound by one memory latency per element)
+  auto copy = [&](T* dst, int count, auto src_of) {
+    constexpr int U = 8;
+    for (int e0 = tid; e0 < count; e0 += NT * U) {
+      T v[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int e = e0 + u * NT;
+        v[u] = e < count ? src_of(e) : T(0);
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int e = e0 + u * NT;
+        if (e < count) dst[e] = v[u];
+      }
+    }
+  };
+  // ---- (1) dense rows of the game -> rows of the padded shape ----
+  {
+    const T *A = g.A, *Bm = g.Bm, *Q = g.Q, *l = g.l, *R = g.R, *r = g.r;
+    const PairTable& pt = *g.pt;
+    copy(q + PL.A, Tn * NX * NX, [&](int e) {
+      const int k = e / (NX * NX), f = e - k * (NX * NX), c = f / NX, row = f - c * NX;
+      return (row < n && c < n) ? A[size_t(k) * n * n + row + n * c] : (row == c ? T(1) : T(0));
+    });
+    copy(q + PL.B, Tn * NX * M, [&](int e) {
+      const int k = e / (NX * M), f = e - k * (NX * M), c = f / NX, row = f - c * NX, i = c / MU, ce = c - i * MU;
+      return (row < n && ce < g.udim[i]) ? Bm[size_t(k) * n * m + row + n * (g.uoff[i] + ce)] : T(0);
+    });
+    copy(q + PL.Q, Tn * NP * NX * NX, [&](int e) {
+      const int ki = e / (NX * NX), f = e - ki * (NX * NX), c = f / NX, row = f - c * NX;  // ki = k * NP + i
+      return (row < n && c < n) ? Q[size_t(ki) * n * n + row + n * c] : T(0);
+    });
+    copy(q + PL.l, Tn * NP * NX, [&](int e) {
+      const int ki = e / NX, row = e - ki * NX;
+      return row < n ? l[size_t(ki) * n + row] : T(0);
+    });
+    const int Rsz_p = ptp.Rsz, rsz_p = ptp.rsz;  // npairs * MU * MU, npairs * MU
+    copy(q + PL.R, Tn * Rsz_p, [&](int e) {
+      const int k = e / Rsz_p, f = e - k * Rsz_p, pq = f / (MU * MU), h = f - pq * (MU * MU), cb = h / MU, ca = h - cb * MU;
+      const int mj = g.udim[pt.pj[pq]];
+      return (ca < mj && cb < mj) ? R[size_t(k) * pt.Rsz + pt.roff[pq] + ca + mj * cb]
+                                  : ((pt.pi[pq] == pt.pj[pq] && ca == cb) ? T(1) : T(0));
+    });
+    copy(q + PL.r, Tn * rsz_p, [&](int e) {
+      const int k = e / rsz_p, f = e - k * rsz_p, pq = f / MU, ca = f - pq * MU;
+      const int mj = g.udim[pt.pj[pq]];
+      return ca < mj ? r[size_t(k) * pt.rsz + pt.rgoff[pq] + ca] : T(0);
+    });
+    if (g.x0 && tid < NX) q[PL.x0 + tid] = tid < n ? g.x0[tid] : T(0);
+  }
+  __threadfence_block();
+  __syncthreads();
+  // ---- (2) the specialised sweep (dense rows, its own forward pass) ----
+  LQArgs<T> la;
+  la.A = q + PL.A; la.Bm = q + PL.B; la.Q = q + PL.Q; la.l = q + PL.l; la.R = q + PL.R; la.r = q + PL.r;
+  la.x0 = g.x0 ? q + PL.x0 : nullptr;
+  la.P = q + PL.P; la.alpha = q + PL.al;
+  const bool forward = g.dx != nullptr || g.want_ed;
+  la.dx = forward ? q + PL.dx : nullptr;
+  la.scratch = (forward || OL) ? q + PL.scr : nullptr;
+  la.ed_out = g.want_ed ? sm + PS::ED_SLOT : nullptr;
+  la.T_steps = Tn;
+  la.adaptive = g.adaptive;
+  la.symmetric = g.symmetric;
+  if constexpr (OL) {
+    if (g.xoff) {  // the added states extend the last player's block (their A entries are its diagonal's)
+      la.nsub = NP;
+#pragma unroll
+      for (int i = 0; i < NP; i++) la.xoff[i] = g.xoff[i];
+      la.xoff[NP] = NX;
+    }
+    lq_openloop_instance<T, NX, NP, MU>(la, ptp, sm);
+  } else {
+    lq_feedback_dispatch<T, NX, NP, MU, false>(la, ptp, sm);
+  }
+  __threadfence_block();
+  __syncthreads();
+  // ---- (3) the game's rows of [P | alpha] (and of delta_x) ----
+  copy(g.P, Tn * m * n, [&](int e) {
+    const int k = e / (m * n), f = e - k * (m * n), c = f / m, row = f - c * m;
+    int i = 0;
+    while (i + 1 < g.N && row >= g.uoff[i + 1]) i++;
+    return q[PL.P + size_t(k) * M * NX + (i * MU + row - g.uoff[i]) + M * c];
+  });
+  copy(g.alpha, Tn * m, [&](int e) {
+    const int k = e / m, row = e - k * m;
+    int i = 0;
+    while (i + 1 < g.N && row >= g.uoff[i + 1]) i++;
+    return q[PL.al + size_t(k) * M + i * MU + row - g.uoff[i]];
+  });
+  if (g.dx)
+    copy(g.dx, Tn * n, [&](int e) {
+      const int k = e / n, row = e - k * n;
+      return q[PL.dx + size_t(k) * NX + row];
+    });
+}
+
 template <typename T, int NX, int NP, int MU, bool OL>
 __global__ void __launch_bounds__((PadSweep<T, NX, NP, MU, OL>::NT), (PadSweep<T, NX, NP, MU, OL>::WG_PER_CU))
 padded_lq_kernel(DevProblem p, SolveArgs<T> sa, PadArgs<T> pa) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   T* sm = reinterpret_cast<T*>(smem_raw);
   using PS = PadSweep<T, NX, NP, MU, OL>;
-  constexpr int M = NP * MU, NT = PS::NT;
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const int n = p.n, m = p.m, Tn = p.T;
-  const WsLayout L(n, m, p.N, Tn, p.pairs.Rsz, p.pairs.rsz, sa.ol_row, p.num_constraints, sa.al_mode);
+  const int b = blockIdx.x;
+  const int Tn = p.T;
+  const WsLayout L(p.n, p.m, p.N, Tn, p.pairs.Rsz, p.pairs.rsz, sa.ol_row, p.num_constraints, sa.al_mode);
   T* const w = sa.ws + size_t(b) * sa.ws_stride;
   SolveState<T>* const st = reinterpret_cast<SolveState<T>*>(w + L.state);
   if (st->stage != ST_LQ) return;
   const int sacc = __builtin_amdgcn_readfirstlane(st->sacc);
-  const PadLayout<T, NX, NP, MU, OL> PL(Tn, pa.ptp.Rsz, pa.ptp.rsz);
-  T* const q = pa.pad + size_t(b) * pa.pad_stride;
-  // ---- (1) dense rows of the game -> rows of the padded shape ----
-  {
-    const T *A = w + L.A, *Bm = w + L.B, *Q = w + L.Q, *l = w + L.l, *R = w + L.R, *r = w + L.r;
-    for (int e = tid; e < Tn * NX * NX; e += NT) {
-      const int k = e / (NX * NX), f = e - k * (NX * NX), c = f / NX, row = f - c * NX;
-      q[PL.A + e] = (row < n && c < n) ? A[size_t(k) * n * n + row + n * c] : (row == c ? T(1) : T(0));
-    }
-    for (int e = tid; e < Tn * NX * M; e += NT) {
-      const int k = e / (NX * M), f = e - k * (NX * M), c = f / NX, row = f - c * NX, i = c / MU, ce = c - i * MU;
-      q[PL.B + e] = (row < n && ce < p.udim[i]) ? Bm[size_t(k) * n * m + row + n * (p.uoff[i] + ce)] : T(0);
-    }
-    for (int e = tid; e < Tn * NP * NX * NX; e += NT) {
-      const int ki = e / (NX * NX), f = e - ki * (NX * NX), c = f / NX, row = f - c * NX;  // ki = k * NP + i
-      q[PL.Q + e] = (row < n && c < n) ? Q[size_t(ki) * n * n + row + n * c] : T(0);
-    }
-    for (int e = tid; e < Tn * NP * NX; e += NT) {
-      const int ki = e / NX, row = e - ki * NX;
-      q[PL.l + e] = row < n ? l[size_t(ki) * n + row] : T(0);
-    }
-    const int Rsz_p = pa.ptp.Rsz, rsz_p = pa.ptp.rsz;  // npairs * MU * MU, npairs * MU
-    for (int e = tid; e < Tn * Rsz_p; e += NT) {
-      const int k = e / Rsz_p, f = e - k * Rsz_p, pq = f / (MU * MU), g = f - pq * (MU * MU), cb = g / MU, ca = g - cb * MU;
-      const int mj = p.udim[p.pairs.pj[pq]];
-      q[PL.R + e] = (ca < mj && cb < mj) ? R[size_t(k) * p.pairs.Rsz + p.pairs.roff[pq] + ca + mj * cb]
-                                          : ((p.pairs.pi[pq] == p.pairs.pj[pq] && ca == cb) ? T(1) : T(0));
-    }
-    for (int e = tid; e < Tn * rsz_p; e += NT) {
-      const int k = e / rsz_p, f = e - k * rsz_p, pq = f / MU, ca = f - pq * MU;
-      const int mj = p.udim[p.pairs.pj[pq]];
-      q[PL.r + e] = ca < mj ? r[size_t(k) * p.pairs.rsz + p.pairs.rgoff[pq] + ca] : T(0);
-    }
-  }
-  __threadfence_block();
-  __syncthreads();
-  // ---- (2) the specialised sweep (as lq_part_instance sets it up, dense rows, its own forward pass) ----
-  LQArgs<T> la;
-  la.A = q + PL.A; la.Bm = q + PL.B; la.Q = q + PL.Q; la.l = q + PL.l; la.R = q + PL.R; la.r = q + PL.r;
-  la.x0 = nullptr;
-  la.P = q + PL.P; la.alpha = q + PL.al; la.dx = q + PL.dx;
-  la.scratch = q + PL.scr;
-  la.ed_out = sm + PS::ED_SLOT;
-  la.T_steps = Tn;
-  la.adaptive = 1;
-  la.symmetric = 1;
-  if constexpr (OL) {
-    bool blocks = true;
-#pragma unroll
-    for (int i = 0; i < NP; i++) blocks = blocks && p.xoff[i + 1] > p.xoff[i];
-    if (blocks) {  // the added states extend the last player's block (their A entries are its diagonal's)
-      la.nsub = NP;
-#pragma unroll
-      for (int i = 0; i < NP; i++) la.xoff[i] = p.xoff[i];
-      la.xoff[NP] = NX;
-    }
-    lq_openloop_instance<T, NX, NP, MU>(la, pa.ptp, sm);
-  } else {
-    lq_feedback_dispatch<T, NX, NP, MU, false>(la, pa.ptp, sm);
-  }
-  __threadfence_block();
-  __syncthreads();
-  // ---- (3) the game's rows of [P | alpha] into strategy buffer 1 - sacc ----
-  T* const Pout = sacc ? sa.P + size_t(b) * Tn * m * n : w + L.P1;
-  T* const alout = sacc ? sa.alpha + size_t(b) * Tn * m : w + L.al1;
-  for (int e = tid; e < Tn * m * n; e += NT) {
-    const int k = e / (m * n), f = e - k * (m * n), c = f / m, row = f - c * m;
-    int i = 0;
-    while (i + 1 < p.N && row >= p.uoff[i + 1]) i++;
-    Pout[e] = q[PL.P + size_t(k) * M * NX + (i * MU + row - p.uoff[i]) + M * c];
-  }
-  for (int e = tid; e < Tn * m; e += NT) {
-    const int k = e / m, row = e - k * m;
-    int i = 0;
-    while (i + 1 < p.N && row >= p.uoff[i + 1]) i++;
-    alout[e] = q[PL.al + size_t(k) * M + i * MU + row - p.uoff[i]];
-  }
-  if (tid == 0) {
+  PadGame<T> g;
+  g.n = p.n; g.m = p.m; g.N = p.N; g.T_steps = Tn;
+  g.udim = p.udim; g.uoff = p.uoff; g.pt = &p.pairs;
+  g.A = w + L.A; g.Bm = w + L.B; g.Q = w + L.Q; g.l = w + L.l; g.R = w + L.R; g.r = w + L.r;
+  g.x0 = nullptr;
+  g.P = sacc ? sa.P + size_t(b) * Tn * p.m * p.n : w + L.P1;  // strategy buffer 1 - sacc
+  g.alpha = sacc ? sa.alpha + size_t(b) * Tn * p.m : w + L.al1;
+  g.dx = nullptr;
+  g.want_ed = 1;
+  g.adaptive = 1;
+  g.symmetric = 1;  // what the quadraticisation stage writes
+  bool blocks = OL;
+  for (int i = 0; i < p.N; i++) blocks = blocks && p.xoff[i + 1] > p.xoff[i];
+  g.xoff = blocks ? p.xoff : nullptr;
+  padded_sweep_instance<T, NX, NP, MU, OL>(g, pa.ptp, pa.pad + size_t(b) * pa.pad_stride, sm);
+  if (threadIdx.x == 0) {
     st->expected_decrease = sm[PS::ED_SLOT];
     st->num_iterations += 1;
     st->step = sa.forced_steps ? sa.forced_steps[size_t(b) * sa.fixed_iters + (st->num_iterations - 1)]
@@ -653,6 +712,33 @@ padded_lq_kernel(DevProblem p, SolveArgs<T> sa, PadArgs<T> pa) {
     st->bt = 0;
     st->stage = ST_ROLLOUT;
   }
+}
+
+// ilqg_lq_feedback_batch / ilqg_lq_openloop_batch for a shape without an instantiation of its own, on the padded sweep.
+template <typename T, int NX, int NP, int MU, bool OL>
+__global__ void __launch_bounds__((PadSweep<T, NX, NP, MU, OL>::NT), (PadSweep<T, NX, NP, MU, OL>::WG_PER_CU))
+padded_lq_batch_kernel(LQBatchArgs<T> a, GenDims d, PairTable pt, PadArgs<T> pa) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  T* sm = reinterpret_cast<T*>(smem_raw);
+  const size_t b = blockIdx.x, Tn = d.T, n = d.n, m = d.m, N = d.N;
+  PadGame<T> g;
+  g.n = d.n; g.m = d.m; g.N = d.N; g.T_steps = d.T;
+  g.udim = d.udim; g.uoff = d.uoff; g.pt = &pt;
+  g.A = a.A + b * Tn * n * n;
+  g.Bm = a.Bm + b * Tn * n * m;
+  g.Q = a.Q + b * Tn * N * n * n;
+  g.l = a.l + b * Tn * N * n;
+  g.R = a.R + b * Tn * pt.Rsz;
+  g.r = a.r + b * Tn * pt.rsz;
+  g.x0 = a.x0 ? a.x0 + b * n : nullptr;
+  g.P = a.P + b * Tn * m * n;
+  g.alpha = a.alpha + b * Tn * m;
+  g.dx = a.dx ? a.dx + b * Tn * n : nullptr;
+  g.want_ed = 0;
+  g.adaptive = OL ? 0 : a.adaptive;
+  g.symmetric = 0;
+  g.xoff = nullptr;
+  padded_sweep_instance<T, NX, NP, MU, OL>(g, pa.ptp, pa.pad + b * pa.pad_stride, sm);
 }
 
 // The sweep of the run-time-dimensioned solve path (lq_part_generic, ilqg_solve.hpp).
@@ -768,6 +854,11 @@ struct __attribute__((visibility("hidden"))) DimsLaunch {
   // pad_elems_out != nullptr: only report the scratch elements one instance needs
   static ilqg_status lq_padded(const DevProblem& d, const void* solve_args, const PairTable& ptp, void* pad,
                                size_t* pad_elems_out, bool open_loop, hipStream_t stream);
+  // ilqg_lq_feedback_batch / ilqg_lq_openloop_batch of a game embedded in this shape (padded_lq_batch_kernel): `d`, `pt`
+  // are the game's own dimensions and control blocks, `ptp` its blocks at MU x MU
+  static ilqg_status lq_padded_batch(const ilqg_dims* d, const PairTable& pt, const PairTable& ptp, bool open_loop,
+                                     const void* A, const void* Bm, const void* Q, const void* l, const void* R,
+                                     const void* r, const void* x0, void* P, void* alpha, void* dx, hipStream_t stream);
 };
 
 template <typename T, int NX, int NP, int MU>
@@ -864,6 +955,49 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::lq_padded(const DevProblem& d, const void
       const size_t lds = PS::LDS_ELEMS * sizeof(T);
       raise_lds_limit((const void*)kern, lds);
       hipLaunchKernelGGL(kern, dim3(sa.batch), dim3(PS::NT), lds, stream, d, sa, pa);
+      HIP_TRY(hipGetLastError());
+      return ILQG_OK;
+    };
+    return open_loop ? go(std::true_type{}) : go(std::false_type{});
+  }
+}
+
+template <typename T, int NX, int NP, int MU>
+ilqg_status DimsLaunch<T, NX, NP, MU>::lq_padded_batch(const ilqg_dims* d, const PairTable& pt, const PairTable& ptp,
+                                                       bool open_loop, const void* A, const void* Bm, const void* Q,
+                                                       const void* l, const void* R, const void* r, const void* x0,
+                                                       void* P, void* alpha, void* dx, hipStream_t stream) {
+  if constexpr (NX == 0) {
+    return fail(ILQG_ERR_UNSUPPORTED, "no shape to embed the game in");
+  } else {
+    auto go = [&](auto ol) -> ilqg_status {
+      constexpr bool OL = decltype(ol)::value;
+      const PadLayout<T, NX, NP, MU, OL> PL(d->T, ptp.Rsz, ptp.rsz);
+      const ilqg_status s = Scratch().reserve(size_t(d->batch) * PL.total * sizeof(T));
+      if (s != ILQG_OK) return s;
+      GenDims gd{};
+      gd.n = d->n; gd.N = d->num_players; gd.T = d->T;
+      gd.uoff[0] = 0;
+      for (int i = 0; i < gd.N; i++) {
+        gd.udim[i] = d->udim[i];
+        gd.uoff[i + 1] = gd.uoff[i] + d->udim[i];
+      }
+      gd.m = gd.uoff[gd.N];
+      LQBatchArgs<T> g;
+      g.A = (const T*)A; g.Bm = (const T*)Bm; g.Q = (const T*)Q; g.l = (const T*)l;
+      g.R = (const T*)R; g.r = (const T*)r; g.x0 = (const T*)x0;
+      g.P = (T*)P; g.alpha = (T*)alpha; g.dx = (T*)dx;
+      g.scratch = nullptr;
+      g.T_steps = d->T;
+      g.adaptive = d->adaptive_regularization;
+      g.batch = d->batch;
+      g.force_valu = 0;
+      PadArgs<T> pa{(T*)ilqg_shared::scratch_state().ptr, PL.total, ptp};
+      using PS = PadSweep<T, NX, NP, MU, OL>;
+      auto kern = padded_lq_batch_kernel<T, NX, NP, MU, OL>;
+      const size_t lds = PS::LDS_ELEMS * sizeof(T);
+      raise_lds_limit((const void*)kern, lds);
+      hipLaunchKernelGGL(kern, dim3(d->batch), dim3(PS::NT), lds, stream, g, gd, pt, pa);
       HIP_TRY(hipGetLastError());
       return ILQG_OK;
     };
@@ -1469,6 +1603,33 @@ static ilqg_status launch_linquad(const ilqg_problem* p, int32_t batch, const vo
   return fail(ILQG_ERR_UNSUPPORTED, "no device kernel instantiated for this problem's dimensions");
 }
 
+// The smallest instantiated shape a game embeds in (same player count, at least its states and its widest control), for
+// the padded sweeps (padded_lq_kernel / padded_lq_batch_kernel); false: none.
+static bool pick_padded_shape(int n, int N, const int32_t* udim, int* nx, int* mu) {
+  int mumax = 0, best_nx = 0, best_mu = 0;
+  for (int i = 0; i < N; i++) mumax = udim[i] > mumax ? udim[i] : mumax;
+#define X(NX_, NP_, MU_)                                                                                                 \
+  if (NP_ == N && NX_ >= n && MU_ >= mumax && (best_nx == 0 || NX_ < best_nx || (NX_ == best_nx && MU_ < best_mu))) { \
+    best_nx = NX_;                                                                                                       \
+    best_mu = MU_;                                                                                                       \
+  }
+  ILQG_FOR_DIMS(X)
+#undef X
+  *nx = best_nx;
+  *mu = best_mu;
+  return best_nx != 0;
+}
+
+// The game's control blocks at mu x mu each (the padded shape's PairTable)
+static bool padded_pairs(const PairTable& pt, int N, int mu, PairTable* ptp, std::string* err) {
+  std::vector<ilqg_pair> pairs(pt.npairs);
+  std::vector<int> udim_p(kMaxPlayers, mu);
+  for (int q = 0; q < pt.npairs; q++) pairs[q] = {pt.pi[q], pt.pj[q]};
+  if (!build_pairs(pairs.data(), pt.npairs, udim_p.data(), N, ptp, err)) return false;
+  for (int q = 0; q < pt.npairs; q++) ptp->from_cost[q] = pt.from_cost[q];
+  return true;
+}
+
 // Threads of a workgroup of the run-time-dimensioned sweeps (ilqg_lq_generic.hpp: every phase strides its entries over
 // the workgroup and ends with a barrier).  -DILQG_GEN_THREADS_SMALL=n: the size for games whose phases have at most 160
 // entries (A/B measurements).
@@ -1551,25 +1712,13 @@ static ilqg_status generic_solve(ilqg_problem* p, int32_t batch, const void* x0,
     return fail(ILQG_ERR_UNSUPPORTED, "no shape to embed the game in");
   };
   if (opt.padded_sweep == ILQG_CHOICE_ON || (opt.padded_sweep == ILQG_CHOICE_AUTO && p->generic)) {
-    int mumax = 0;
-    for (int i = 0; i < d.N; i++) mumax = d.udim[i] > mumax ? d.udim[i] : mumax;
-#define X(NX_, NP_, MU_)                                                                                             \
-    if (NP_ == d.N && NX_ >= d.n && MU_ >= mumax && (pad_nx == 0 || NX_ < pad_nx || (NX_ == pad_nx && MU_ < pad_mu))) { \
-      pad_nx = NX_;                                                                                                  \
-      pad_mu = MU_;                                                                                                  \
-    }
-    ILQG_FOR_DIMS(X)
-#undef X
+    pick_padded_shape(d.n, d.N, d.udim, &pad_nx, &pad_mu);
     if (pad_nx == 0 && opt.padded_sweep == ILQG_CHOICE_ON)
       return fail(ILQG_ERR_UNSUPPORTED, "padded_sweep = ON: no instantiated shape holds this game (same player count, at "
                                         "least its states and its widest control)");
     if (pad_nx) {
-      std::vector<ilqg_pair> pairs(d.pairs.npairs);
-      std::vector<int> udim_p(kMaxPlayers, pad_mu);
-      for (int q = 0; q < d.pairs.npairs; q++) pairs[q] = {d.pairs.pi[q], d.pairs.pj[q]};
       std::string err;
-      if (!build_pairs(pairs.data(), d.pairs.npairs, udim_p.data(), d.N, &ptp, &err)) return fail(ILQG_ERR_INVALID, err);
-      for (int q = 0; q < d.pairs.npairs; q++) ptp.from_cost[q] = d.pairs.from_cost[q];
+      if (!padded_pairs(d.pairs, d.N, pad_mu, &ptp, &err)) return fail(ILQG_ERR_INVALID, err);
       size_t elems = 0;
       ilqg_status s = padded_launch(&elems);
       if (s != ILQG_OK) return s;
@@ -1721,6 +1870,22 @@ static GenDims gen_dims_of(int n, int N, const int32_t* udim, int T) {
   }
   g.m = g.uoff[N];
   return g;
+}
+
+// ilqg_lq_feedback_batch / ilqg_lq_openloop_batch of a shape without an instantiation on the padded sweep of (nx, N, mu)
+template <typename T>
+static ilqg_status launch_lq_padded(const ilqg_dims* d, const PairTable& pt, int nx, int mu, bool open_loop, const void* A,
+                                    const void* Bm, const void* Q, const void* l, const void* R, const void* r,
+                                    const void* x0, void* P, void* alpha, void* dx, hipStream_t stream) {
+  PairTable ptp;
+  std::string err;
+  if (!padded_pairs(pt, d->num_players, mu, &ptp, &err)) return fail(ILQG_ERR_INVALID, err);
+#define X(NX_, NP_, MU_)                                                                                                  \
+  if (nx == NX_ && d->num_players == NP_ && mu == MU_)                                                                     \
+    return DimsLaunch<T, NX_, NP_, MU_>::lq_padded_batch(d, pt, ptp, open_loop, A, Bm, Q, l, R, r, x0, P, alpha, dx, stream);
+  ILQG_FOR_DIMS(X)
+#undef X
+  return fail(ILQG_ERR_UNSUPPORTED, "no shape to embed the game in");
 }
 
 // ilqg_lq_feedback_batch / ilqg_lq_openloop_batch for a shape without a specialised instantiation (or when the caller
@@ -1921,7 +2086,15 @@ ilqg_status ilqg_lq_feedback_batch(const ilqg_dims* d, const void* A, const void
   }
   ILQG_FOR_DIMS(X)
 #undef X
-  // no specialised instantiation (or players with different control dimensions): the run-time-dimensioned sweep
+  // no specialised instantiation (or players with different control dimensions): the game embedded in the smallest
+  // instantiated shape that holds it, on that shape's sweep (padded_lq_batch_kernel) ...
+  {
+    int nx = 0, pmu = 0;
+    if (d->sweep_formulation != ILQG_SWEEP_GENERIC && pick_padded_shape(d->n, N, d->udim, &nx, &pmu))
+      return finish(d->dtype == ILQG_F32 ? launch_lq_padded<float>(d, pt, nx, pmu, false, A, Bm, Q, l, R, r, x0, P, alpha, dx, st)
+                                         : launch_lq_padded<double>(d, pt, nx, pmu, false, A, Bm, Q, l, R, r, x0, P, alpha, dx, st));
+  }
+  // ... or, where there is none (or the caller asks for it), the run-time-dimensioned sweep
   return finish(d->dtype == ILQG_F32
                     ? launch_lq_generic<float>(d, pt, false, A, Bm, Q, l, R, r, x0, P, alpha, dx, nullptr, st)
                     : launch_lq_generic<double>(d, pt, false, A, Bm, Q, l, R, r, x0, P, alpha, dx, nullptr, st));
@@ -1956,6 +2129,12 @@ ilqg_status ilqg_lq_openloop_batch(const ilqg_dims* d, const void* A, const void
   }
   ILQG_FOR_DIMS(X)
 #undef X
+  {
+    int nx = 0, pmu = 0;  // (the padded sweep does not carry costates out: with them, the run-time-dimensioned sweep)
+    if (!costates && d->sweep_formulation != ILQG_SWEEP_GENERIC && pick_padded_shape(d->n, d->num_players, d->udim, &nx, &pmu))
+      return d->dtype == ILQG_F32 ? launch_lq_padded<float>(d, pt, nx, pmu, true, A, Bm, Q, l, R, r, x0, P, alpha, dx, st)
+                                  : launch_lq_padded<double>(d, pt, nx, pmu, true, A, Bm, Q, l, R, r, x0, P, alpha, dx, st);
+  }
   return d->dtype == ILQG_F32 ? launch_lq_generic<float>(d, pt, true, A, Bm, Q, l, R, r, x0, P, alpha, dx, costates, st)
                               : launch_lq_generic<double>(d, pt, true, A, Bm, Q, l, R, r, x0, P, alpha, dx, costates, st);
 }

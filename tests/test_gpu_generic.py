@@ -37,7 +37,12 @@ SHAPES = [  # (n, control dimensions): no specialised instantiation holds any of
 @pytest.mark.parametrize("open_loop", [False, True], ids=["feedback", "open_loop"])
 @pytest.mark.parametrize("n,ms", SHAPES, ids=["n%d_m%s" % (n, "".join(map(str, ms))) for n, ms in SHAPES])
 @pytest.mark.parametrize("dtype", [abi.F64, abi.F32])
-def test_generic_sweeps_match_oracle(hip, oracle, n, ms, open_loop, dtype):
+@pytest.mark.parametrize("formulation", ["auto", "run_time_dimensioned"])
+def test_generic_sweeps_match_oracle(hip, oracle, n, ms, open_loop, dtype, formulation):
+    """ilqg_lq_feedback_batch / ilqg_lq_openloop_batch on shapes without an instantiation.  auto: the game embedded in the
+    smallest instantiated shape that holds it, on that shape's sweep ((5, (2,1,2)) in (6,3,2), (7, (1,2)) in (8,2,2),
+    (12, (2,2,2)) in (14,3,2); the open-loop form when no costates are asked for), the run-time-dimensioned sweeps where
+    there is none (four players and more, a control of three or four dimensions); ILQG_SWEEP_GENERIC: those sweeps always."""
     rng = np.random.default_rng(100 * n + len(ms) + (7 if open_loop else 0))
     T, B = (12 if n > 16 else 25), 4
     N = len(ms)
@@ -45,16 +50,25 @@ def test_generic_sweeps_match_oracle(hip, oracle, n, ms, open_loop, dtype):
     g = random_lq_game(rng, n, list(ms), T, B, pairs=pairs)
     x0 = 0.3 * rng.standard_normal((B, n))
     d = abi.make_dims(n, list(ms), T, B, dtype, adaptive_regularization=not open_loop)
+    if formulation != "auto":
+        d.sweep_formulation = abi.SWEEP_GENERIC
     Pr, ar, dxr, cor = oracle.lq_solve(d, g["A"], g["Bm"], g["Q"], g["l"], g["R"], g["r"], pairs, x0=x0,
                                        open_loop=open_loop, want_costates=True)
-    P, alpha, dx, co = hip.lq_feedback(d, g["A"], g["Bm"], g["Q"], g["l"], g["R"], g["r"], pairs, x0=x0,
-                                       open_loop=open_loop, want_costates=True)
     tol = 1e-9 if dtype == abi.F64 else 5e-3
-    assert rel_err(_np(P), Pr) < tol and rel_err(_np(alpha), ar) < tol and rel_err(_np(dx), dxr) < tol
-    assert rel_err(_np(co), cor) < tol
-    assert np.all(_np(P)[:, -1] == 0) and np.all(_np(alpha)[:, -1] == 0)
-    if open_loop:
-        assert np.all(_np(P) == 0)
+    for want_costates in (True, False):
+        out = hip.lq_feedback(d, g["A"], g["Bm"], g["Q"], g["l"], g["R"], g["r"], pairs, x0=x0,
+                              open_loop=open_loop, want_costates=want_costates)
+        P, alpha, dx = out[:3]
+        assert rel_err(_np(P), Pr) < tol and rel_err(_np(alpha), ar) < tol and rel_err(_np(dx), dxr) < tol
+        if want_costates:
+            assert rel_err(_np(out[3]), cor) < tol
+        assert np.all(_np(P)[:, -1] == 0) and np.all(_np(alpha)[:, -1] == 0)
+        if open_loop:
+            assert np.all(_np(P) == 0)
+    # without delta_x: strategies only
+    P, alpha, _ = hip.lq_feedback(d, g["A"], g["Bm"], g["Q"], g["l"], g["R"], g["r"], pairs, x0=x0, open_loop=open_loop,
+                                  want_dx=False)
+    assert rel_err(_np(P), Pr) < tol and rel_err(_np(alpha), ar) < tol
 
 
 @pytest.mark.parametrize("dims", [(14, 3, 2), (16, 3, 2), (24, 4, 2), (4, 2, 2), (3, 1, 1)])
