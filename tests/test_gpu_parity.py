@@ -758,30 +758,35 @@ def test_instances_sharing_a_wavefront_in_the_split_rollout_do_not_see_each_othe
 
 
 @pytest.mark.parametrize("dtype", [abi.F64, abi.F32])
-def test_rollout_hands_over_to_the_library_trig_past_the_fast_range(hip, oracle, dtype):
-    """The rollouts integrate with range-limited sin / cos / tan kernels in a loop that holds no library fall-back,
-    fall back to the library's once some heading or steering angle of the trajectory's lanes leaves that range
-    (fast_sincos / fast_tan, csrc/ilqg_trig.hpp; sub_integrate_stages, csrc/ilqg_models.hpp).
-    Headline system (Car5D, Car5D, Unicycle4D): instance 0's unicycle heading crosses the limit in mid-horizon,
-    instance 1's car steering angle does (the tangent), instance 2 starts beyond it, instance 3 never leaves it and
-    shares kernels with the others.  The stand-alone rollout, the fused trial kernel and the split (two trajectories
-    per wavefront) one against the oracle; positions and speeds are compared, the huge angles separately (their ulp
-    is 1.5e-11 / 1.2e-4)."""
+def test_rollout_trig_across_and_beyond_the_fast_range(hip, oracle, dtype):
+    """The rollouts integrate with range-limited sin / cos / tan kernels (three-piece Cody-Waite reduction up to
+    kTrigFastLimit) and take a reduction of their own beyond (csrc/ilqg_trig.hpp: the same form with a wide quadrant up to
+    2^47, Payne-Hanek from there to the largest finite argument; fp32 beyond its limit goes through the double forms).
+    Headline system (Car5D, Car5D, Unicycle4D): instance 0's unicycle heading crosses the limit in mid-horizon, instance
+    1's car steering angle does (the tangent), instance 2's second car starts at three times the limit (the middle
+    form), instance 3 never leaves the fast range and shares kernels with the others, instance 4's unicycle heads 1e15
+    (Payne-Hanek; a heading that large only stays comparable while it does not change: zero turn rate).  The stand-alone
+    rollout against the oracle — 1e-9 where the heading is constant, the heading's own resolution (ulp(1e9) = 1.2e-7 rad,
+    accumulated over the horizon) where it moves —, then whole iterations on the fused trial kernel (one trajectory per
+    wavefront) and the split one (two per wavefront): instance 3 against the oracle and bit for bit as when solved alone."""
     spec = examples.modified_three_player_intersection()
     spec.params.expected_decrease_fraction = 0.001
     spec.params.initial_alpha_scaling = 0.1
-    limit = 1.0e5 if dtype == abi.F64 else 2.0e3  # kTrigFastLimit / kTrigFastLimitF, csrc/ilqg_trig.hpp
-    B, T, n, m = 4, spec.T, spec.n, spec.m
+    f64 = dtype == abi.F64
+    limit = 1.0e9 if f64 else 2.0e3  # kTrigFastLimit / kTrigFastLimitF, csrc/ilqg_trig.hpp
+    B, T, n, m = 5, spec.T, spec.n, spec.m
     x0 = examples.jittered_x0(spec, B, seed=11)
     us_ref = np.zeros((B, T, m))
     # state: car (x, y, theta, phi, v) x 2, unicycle (x, y, theta, v); controls (phi rate, a) x 2, (omega, a)
     x0[0, 12] += limit - 3.0
     us_ref[0, :, 4] = 1.0           # + 10 rad over the horizon: crosses after ~ 30 steps
-    # car 1's steering angle crosses after ~ 35 / 40 steps, on a stretch that holds no pole of the tangent
-    # (1e5 = 31830 pi + 3.106: poles at 1e5 - 1.535 and 1e5 + 1.607;  2e3 = 636 pi + 1.947: poles at 2e3 - 0.376, + 2.765)
-    x0[1, 3] = limit - (0.5 if dtype == abi.F64 else 0.05)
-    us_ref[1, :, 0] = 0.13 if dtype == abi.F64 else 0.012
-    x0[2, 7] += 3.0 * limit         # car 2's heading beyond the range from the first step
+    # car 1's steering angle crosses after ~ 40 steps, on a stretch that holds no pole of the tangent
+    # (1e9 = 318309886 pi + 0.577: poles at 1e9 - 2.148 and 1e9 + 0.994;  2e3 = 636 pi + 1.947: poles at 2e3 - 0.376, + 2.765)
+    x0[1, 3] = limit - (0.5 if f64 else 0.05)
+    us_ref[1, :, 0] = 0.11 if f64 else 0.012
+    x0[2, 7] += 3.0 * limit         # car 2's heading beyond the range from the first step (its steering angle is zero)
+    x0[4, 12] = 1.0e15              # beyond 2^47
+    assert x0[2, 8] == 0.0
     hd = [2, 3, 7, 8, 12]
     rest = [i for i in range(n) if i not in hd]
     xs_ref = np.tile(x0[:, None, :], (1, T, 1))
@@ -792,22 +797,21 @@ def test_rollout_hands_over_to_the_library_trig_past_the_fast_range(hip, oracle,
     xs_d, us_d = hp.rollout(x0, xs_ref, us_ref, z(B, T, m * n), z(B, T, m))
     assert np.abs(xs_o[0, :, 12]).max() > limit + 5 and np.abs(xs_o[0, 0, 12]) < limit   # the crossing is in the horizon
     assert np.abs(xs_o[1, :, 3]).max() > limit + 0.05 and np.abs(xs_o[1, 0, 3]) < limit
-    ptol, atol = (1e-9, 1e-9) if dtype == abi.F64 else (2e-3, 5e-2)  # fp32: a heading driven by the tangent of an angle whose ulp is 1.2e-4
-    for b in range(B):
-        assert rel_err(_np(xs_d)[b][:, rest], xs_o[b][:, rest]) < ptol, b
-    assert np.abs(_np(xs_d)[:, :, hd] - xs_o[:, :, hd]).max() < atol * max(1.0, limit * 1e-4)
-    # instance 3 beside the others and alone: the same bits (the hand-over is decided per wavefront, its result is not)
-    xs_a, _ = hp.rollout(x0[3:], xs_ref[3:], us_ref[3:], z(1, T, m * n), z(1, T, m))
+    moving = 1e-4 if f64 else 2e-3   # a heading that moves at the limit, known to its ulp
+    fixed = 1e-9 if f64 else 2e-3
+    for b, tol in enumerate((moving, moving, fixed, fixed, fixed)):
+        assert rel_err(_np(xs_d)[b][:, rest], xs_o[b][:, rest]) < tol, b
+    assert np.array_equal(_np(xs_d)[4, :, 12], xs_o[4, :, 12]) and np.array_equal(_np(xs_d)[2, :, 7], xs_o[2, :, 7])
+    assert np.abs(_np(xs_d)[:4][:, :, hd] - xs_o[:4][:, :, hd]).max() < (1e-3 if f64 else 5e-2)  # a heading driven by the tangent of a moving angle at the limit
+    # instance 3 beside the others and alone: the same bits
+    xs_a, _ = hp.rollout(x0[3:4], xs_ref[3:4], us_ref[3:4], z(1, T, m * n), z(1, T, m))
     assert np.array_equal(_np(xs_a)[0], _np(xs_d)[3])
     # whole iterations: fused trial kernel (one trajectory per wavefront) and the split form (two per wavefront)
     ref = op.solve(dtype, x0, fixed_iters=2)
+    assert np.all(np.isfinite(ref["xs"][3]))
     for kw in (dict(), dict(split_trial=True)):
         out = hp.solve(x0, fixed_iters=2, **kw)
         xd = _np(out["xs"])
-        assert np.all(np.isfinite(xd)), kw
-        ok = [b for b in range(B) if np.all(np.isfinite(ref["xs"][b]))]
-        assert 3 in ok and len(ok) >= 2
-        tol = 1e-6 if dtype == abi.F64 else 2e-2
-        assert rel_err(xd[ok][:, :, rest], ref["xs"][ok][:, :, rest]) < tol, kw
-        alone = hp.solve(x0[3:], fixed_iters=2, **kw)
+        assert rel_err(xd[3], ref["xs"][3]) < (1e-6 if f64 else 2e-2), kw
+        alone = hp.solve(x0[3:4], fixed_iters=2, **kw)
         assert np.array_equal(_np(alone["xs"])[0], xd[3]), kw

@@ -194,11 +194,13 @@ def test_bench_gpus_flag_launches_its_own_ranks():
 def test_fast_trig_of_the_rollout_is_within_its_documented_error(tmp_path):
     """csrc/ilqg_trig.hpp is __host__ __device__: tests/host/trig_check.cpp compiles it for the host (plain g++ against
     the HIP headers) and compares sine / cosine / tangent with the C library in long double over the whole fast-path
-    range, dense around the multiples of pi/2 — <= 2 ulp (tangent 3) or the program exits non-zero."""
+    range, dense around the multiples of pi/2 — <= 2 ulp (tangent 3) or the program exits non-zero — and, beyond that
+    range, the large-argument reduction (trig_reduce_large) over every binade up to the largest finite double / float, next
+    to multiples of pi/2, at the classical worst case of the reduction, and on +-inf / NaN."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = str(tmp_path / "trig_check")
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
                            os.path.join(root, "tests", "host", "trig_check.cpp"), "-o", exe])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "double:" in out.stdout and "float:" in out.stdout
+    assert "double:" in out.stdout and "float:" in out.stdout and "double beyond" in out.stdout and "float beyond" in out.stdout
