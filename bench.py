@@ -110,12 +110,13 @@ class HipBackend:
     adjoint = None      # ilqg_solve_options::adjoint_expected_decrease
     static_rows = None  # ilqg_solve_options::static_rows
     padded_sweep = None  # ilqg_solve_options::padded_sweep
+    probe_lanes = None  # ilqg_solve_options::probe_lanes
 
     def solve(self, x0, bufs, iters):
         self.prob.solve(x0, bufs, fixed_iters=iters, counted=self.counted, probe_first=self.probe_first,
                         single_wave_sweep=self.single_wave, split_trial=self.split_trial,
                         adjoint_expected_decrease=self.adjoint, static_rows=self.static_rows,
-                        padded_sweep=self.padded_sweep)
+                        padded_sweep=self.padded_sweep, probe_lanes=self.probe_lanes)
 
     def sync(self):
         self.torch.cuda.synchronize()
@@ -260,6 +261,8 @@ def main():
     ap.add_argument("--padded-sweep", choices=["auto", "on", "off"], default="auto",
                     help="ilqg_solve_options::padded_sweep (A/B measurements: a run-time-dimensioned solve's sweep on the "
                          "specialised kernel of the shape the game embeds in vs the all-LDS sweep)")
+    ap.add_argument("--probe-lanes", choices=["auto", "on", "off"], default="auto",
+                    help="ilqg_solve_options::probe_lanes (A/B measurements: probing rollouts with a lane per (candidate, subsystem))")
     ap.add_argument("--static-rows", choices=["auto", "on", "off"], default="auto",
                     help="ilqg_solve_options::static_rows (A/B measurements: straight-line row stage vs the interpreter)")
     ap.add_argument("--probe-first", type=int, default=0,
@@ -299,6 +302,7 @@ def main():
     backend.adjoint = {"auto": None, "on": True, "off": False}[args.adjoint]
     backend.static_rows = {"auto": None, "on": True, "off": False}[args.static_rows]
     backend.padded_sweep = {"auto": None, "on": True, "off": False}[args.padded_sweep]
+    backend.probe_lanes = {"auto": None, "on": True, "off": False}[args.probe_lanes]
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -77,7 +77,7 @@ class SolveOptions(C.Structure):
                 ("split_trial", C.c_int32), ("handoff", C.c_int32), ("probe", C.c_int32), ("counted", C.c_int32),
                 ("compact_rows", C.c_int32), ("round_bursts", C.c_int32), ("generic_kernels", C.c_int32),
                 ("probe_first", C.c_int32), ("single_wave_sweep", C.c_int32), ("adjoint_expected_decrease", C.c_int32),
-                ("static_rows", C.c_int32), ("padded_sweep", C.c_int32),
+                ("static_rows", C.c_int32), ("padded_sweep", C.c_int32), ("probe_lanes", C.c_int32), ("reserved2", C.c_int32),
                 ("iterate_log", C.POINTER(IterateLog)), ("max_runtime", C.c_double)]
 
 

@@ -421,6 +421,18 @@ __global__ void __launch_bounds__(64, sizeof(T) == 8 ? (FAT ? 2 : ILQG_ROLL_WAVE
     probe_roll_instance<T, NX, NP, MU>(p, sa, sa.ids[blockIdx.x], blockIdx.x, blockIdx.y, reinterpret_cast<T*>(smem_raw));
 }
 
+// The probing rollouts of a round that fills the chip: 64 / NP candidates of one instance per wavefront, a lane per
+// (candidate, subsystem), the RK4 stages in sequence (rollout_lanes, ilqg_stages.hpp) — an eighth of the instructions
+// per trajectory of the paired form above, a longer chain per step: the launcher takes it where the round has more
+// rollouts than the chip holds at once.
+template <typename T, int NX, int NP, int MU>
+__global__ void __launch_bounds__(64, 4) ilq_probe_roll_lanes_kernel(DevProblem p, SolveArgs<T> sa) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  if constexpr (rollout_pairs(NX, NP, MU))
+    probe_roll_lanes<T, NX, NP, MU>(p, sa, sa.ids[blockIdx.x], blockIdx.x, rollout_lanes_per_wave(NP) * int(blockIdx.y),
+                                    reinterpret_cast<T*>(smem_raw));
+}
+
 template <typename T, int NX, int NP, int MU, int PROGID = 0>
 __global__ void __launch_bounds__(64, sizeof(T) == 8 ? 4 : 1) ilq_probe_rows_kernel(DevProblem p, SolveArgs<T> sa) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -1359,17 +1371,23 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   const bool probe = lists && sa.prm.linesearch && choice(opt.probe, true);
   auto k_proll = ilq_probe_roll_kernel<T, NX, NP, MU>;
   auto k_proll_fat = ilq_probe_roll_kernel<T, NX, NP, MU, sizeof(T) == 8>;  // (fp32: the same kernel)
+  auto k_proll_lanes = ilq_probe_roll_lanes_kernel<T, NX, NP, MU>;
+  const size_t lds_proll_lanes = pairs ? size_t(rollout_lanes_lds_elems(d.n, d.m, d.N)) * sizeof(T) + 16 : 0;
+  const int probe_lanes_min = opt.probe_lanes == ILQG_CHOICE_OFF ? (1 << 30) : (opt.probe_lanes == ILQG_CHOICE_ON ? 2 : 8);
   const int decide_elems = int(trial_phase_quad_elems<T>(d, TRIAL_DECIDE, sa.rows_cw));
   const int row_chunks = (d.T + sa.rows_cw - 1) / sa.rows_cw;  // workgroups per instance of the row kernels
   int round_instances = batch, list = 0;  // split passes: how many instances this round covers, which list is free
   int tail_rounds = 0;                    // rounds since the whole batch was last in one
   bool probed_in_tail = false;            // the current tail has launched a probing pass
+  bool deep_tails = false;                // a tail of this solve kept half of its list through three rounds (see the ramp below)
+  int tail_first_instances = 0;
   if (lists) {
     raise_lds_limit((const void*)k_roll, lds_proll);
     raise_lds_limit((const void*)k_rows, lds_rows);
     raise_lds_limit((const void*)k_decide, lds_decide);
     raise_lds_limit((const void*)k_proll, lds_proll);
     raise_lds_limit((const void*)k_proll_fat, lds_proll);
+    raise_lds_limit((const void*)k_proll_lanes, lds_proll_lanes);
     raise_lds_limit((const void*)k_prows, lds_prows);
   }
   sa.first = resume ? 2 : 1;
@@ -1461,8 +1479,31 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
         }
         long long ramp = (long long)first << (tail_rounds < 8 ? tail_rounds : 8);
         if (ramp < 2) ramp = 2;
+        // Deep searches: once a tail of this solve has kept half of its list through three rounds (2 + 4 + 8 or more
+        // rejected candidates each: they are mostly on their way through all max_backtracking_steps), later tails skip the
+        // ramp.  A probing round costs one wave's chain per time step until its waves fill the chip, so every candidate up
+        // to that point is free: with the lane form (rollout_lanes: 64 / N candidates per wavefront) that is
+        // C floor(2400 / instances) candidates per instance — whole wavefronts —, as far as the pool holds them.
+        // (config 5's scene: rounds of 4, 10, 20, 21, 42 ... candidates -> 16 - 63 from a tail's first round on;
+        // config 4's ~1600 back-tracking instances are mostly done after a step or two: they keep the ramp.)
+        constexpr int C_lane = rollout_lanes_per_wave(NP > 0 ? NP : 1);
+        if (sa.ids && tail_rounds == 0) tail_first_instances = round_instances;
+        if (sa.ids && tail_rounds == 3 && 2 * round_instances >= tail_first_instances) deep_tails = true;
+        if (sa.ids && deep_tails && opt.probe_first <= 0) {
+          int k_deep = probe_k;  // what the pool holds
+          if (pairs && opt.probe_lanes != ILQG_CHOICE_OFF) {
+            const int free_waves = 2400 / round_instances;
+            const int k_lane = C_lane * (free_waves > 1 ? free_waves : 1);
+            if (k_deep > k_lane) k_deep = k_lane;
+            if (k_deep >= C_lane) k_deep = k_deep / C_lane * C_lane;
+          }
+          if (ramp < k_deep) ramp = k_deep;
+        }
         if (probe_k > ramp) probe_k = int(ramp);
       }
+#ifdef ILQG_DEBUG_PROBE
+      if (sa.ids) fprintf(stderr, "tail %d instances %d probe_k %d deep %d\n", tail_rounds, round_instances, probe_k, int(deep_tails));
+#endif
       if (sa.ids) tail_rounds++;
       // see generic_solve: instances in ST_PROBE are only picked up again by a probing launch
       if (probe && sa.ids && probed_in_tail && probe_k < 2) return fail(ILQG_ERR_HIP, "a probing line-search tail lost its probe launch");
@@ -1474,7 +1515,22 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
         const int proll_y = pairs ? (probe_k + 1) / 2 : probe_k;
         // the register-rich build while every rollout of the round is resident at once at two waves per SIMD
         const bool fat = (long long)round_instances * proll_y <= 8ll * num_cus;
-        hipLaunchKernelGGL(fat ? k_proll_fat : k_proll, dim3(round_instances, proll_y), dim3(64), lds_proll, stream, d, sa);
+        // A lane per (candidate, subsystem) where that is the shorter round.  A round of W waves takes about
+        // max(one wave's chain, W / SIMDs x a wave's issue time) per time step; measured on the n = 15 scene (cycles per
+        // step): the paired form ~1500 / ~550, the lane form — thirteen trigonometric evaluations in sequence,
+        // ~1180 instructions — ~3500 / ~1530, for 64 / N candidates instead of two.  So the lane form wins once its
+        // own waves fill the chip (config 5's scene from 16 candidates per instance on), and loses a round of a few
+        // deep searches (n = 16: ~100 instances x 128 candidates are 700 lane waves, one chain long).
+        constexpr int C = rollout_lanes_per_wave(NP > 0 ? NP : 1);
+        const double simds = 4.0 * num_cus;
+        const double w_pair = double(round_instances) * proll_y, w_lane = double(round_instances) * ((probe_k + C - 1) / C);
+        const double t_pair = std::max(1500.0, w_pair / simds * 550.0), t_lane = std::max(3500.0, w_lane / simds * 1530.0);
+        const bool lanes = pairs && probe_k >= probe_lanes_min && (opt.probe_lanes == ILQG_CHOICE_ON || t_lane < 0.9 * t_pair);
+        if (lanes) {
+          hipLaunchKernelGGL(k_proll_lanes, dim3(round_instances, (probe_k + C - 1) / C), dim3(64), lds_proll_lanes, stream, d, sa);
+        } else {
+          hipLaunchKernelGGL(fat ? k_proll_fat : k_proll, dim3(round_instances, proll_y), dim3(64), lds_proll, stream, d, sa);
+        }
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(k_prows, dim3(row_chunks, round_instances * probe_k),
                            dim3(64), lds_prows, stream, d, sa);
@@ -2647,7 +2703,7 @@ ilqg_status ilqg_solve_batch_ex(ilqg_problem* p, int32_t batch, const void* x0, 
   const DevProblem& d = p->dev;
   hipStream_t st = (hipStream_t)stream;
   if (o.generic_kernels < ILQG_CHOICE_AUTO || o.generic_kernels > ILQG_CHOICE_ON || o.padded_sweep < ILQG_CHOICE_AUTO ||
-      o.padded_sweep > ILQG_CHOICE_ON)
+      o.padded_sweep > ILQG_CHOICE_ON || o.probe_lanes < ILQG_CHOICE_AUTO || o.probe_lanes > ILQG_CHOICE_ON)
     return fail(ILQG_ERR_INVALID, "scheduling choices are ilqg_choice values");
   if (p->generic || o.generic_kernels == ILQG_CHOICE_ON)
     return p->desc.dtype == ILQG_F32

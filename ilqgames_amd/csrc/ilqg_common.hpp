@@ -141,6 +141,10 @@ __device__ __forceinline__ T sgn(T x) {
   return T((T(0) < x) - (x < T(0)));
 }
 
+// fma in the operands' type (__builtin_fma on floats is the DOUBLE operation behind two conversions)
+__host__ __device__ __forceinline__ float t_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__host__ __device__ __forceinline__ double t_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
 template <typename T>
 __device__ __forceinline__ T shfl(T v, int lane) {
   return __shfl(v, lane, 64);

@@ -189,6 +189,9 @@ __device__ __forceinline__ float div_by(float x, float c, float rc) {
   return __builtin_fmaf(r, rc, q);
 }
 
+// (No implicit contraction from here to the end of the two stage-form integrators: their fused multiply-adds are written
+// out, so the lane-per-stage and the stages-in-a-lane forms round alike wherever they are inlined.)
+#pragma clang fp contract(off)
 // The RK4 (2 sub-steps) of one subsystem with ONE STAGE PER LANE and the stage values in closed form.
 // Lanes base..base+7 form the group; lane q = 4 s + j evaluates stage j of sub-step s.  What makes this possible:
 // the steering angle (or the unicycle's heading), the speed and the acceleration are driven by inputs that are
@@ -219,23 +222,23 @@ __device__ __forceinline__ void sub_integrate_stages(int kind, T L, double inter
   // ---- the input-driven components at this lane's stage and at the end of the step ----
   const T ang0 = car ? x[3] : x[2];
   const T hk = h * u0;
-  const T ang_q = __builtin_fma(cq, hk, ang0);
-  const T ang_end = __builtin_fma(T(2), hk, ang0);
+  const T ang_q = t_fma(cq, hk, ang0);
+  const T ang_end = t_fma(T(2), hk, ang0);
   const T v0 = car ? x[4] : x[3];
   const T hj = h * u1;  // Car6D: h jerk; otherwise h a
   T v_q, v_end, a_end = T(0);
   {
     const T a0 = x[5];
     const T a_1 = a0 + hj;
-    const T v_1 = __builtin_fma(T(0.5) * h, hj, __builtin_fma(h, a0, v0));
+    const T v_1 = t_fma(T(0.5) * h, hj, t_fma(h, a0, v0));
     const T vb = s1 ? v_1 : v0, ab = s1 ? a_1 : a0;
     const T bj = j == 2 ? T(0.25) : (j == 3 ? T(0.5) : T(0));
-    const T v6_q = __builtin_fma(bj * h, hj, __builtin_fma(aj * h, ab, vb));
-    const T v6_end = __builtin_fma(T(0.5) * h, hj, __builtin_fma(h, a_1, v_1));
-    const T v5_q = __builtin_fma(cq, hj, v0), v5_end = __builtin_fma(T(2), hj, v0);
+    const T v6_q = t_fma(bj * h, hj, t_fma(aj * h, ab, vb));
+    const T v6_end = t_fma(T(0.5) * h, hj, t_fma(h, a_1, v_1));
+    const T v5_q = t_fma(cq, hj, v0), v5_end = t_fma(T(2), hj, v0);
     v_q = car6 ? v6_q : v5_q;
     v_end = car6 ? v6_end : v5_end;
-    a_end = __builtin_fma(T(2), hj, a0);
+    a_end = t_fma(T(2), hj, a0);
     if (dubins) v_q = L;
   }
   // ---- heading at this lane's stage ----
@@ -246,18 +249,20 @@ __device__ __forceinline__ void sub_integrate_stages(int kind, T L, double inter
     lds_sync(true);
     const T* g = gth + (lane & ~7);
     const T k0 = g[0], k1 = g[1], k2 = g[2], k3 = g[3], k4 = g[4], k5 = g[5], k6 = g[6], k7 = g[7];
-    const T kprev = gth[lane > 0 ? lane - 1 : 0];  // the previous stage's derivative (unused by stage 0: aj = 0)
-    const T th1 = x[2] + div_by(k0 + T(2) * (k1 + k2) + k3, six, rsix);
-    const T th2 = th1 + div_by(k4 + T(2) * (k5 + k6) + k7, six, rsix);
+    // the previous stage's derivative; stage 0 has none (aj = 0) and takes a zero — the neighbouring lane belongs to
+    // another subsystem or, in rollout_pair, to the other trajectory, whose non-finite value 0 * would turn into a NaN here
+    const T kprev = (lane & 7) ? gth[lane - 1] : T(0);
+    const T th1 = x[2] + div_by(t_fma(T(2), k1 + k2, k0) + k3, six, rsix);
+    const T th2 = th1 + div_by(t_fma(T(2), k5 + k6, k4) + k7, six, rsix);
     const T thb = s1 ? th1 : x[2];
-    th_q = car ? __builtin_fma(aj, kprev, thb) : ang_q;
+    th_q = car ? t_fma(aj, kprev, thb) : ang_q;
     th_end = car ? th2 : ang_end;
   }
   // ---- position rates of this lane's stage, then the two RK4 combinations ----
   T sn, cs;
   fast_sincos(th_q, &sn, &cs, group);
-  const T kx = DIST ? h * (v_q * cs + d0) : h * (v_q * cs);
-  const T ky = DIST ? h * (v_q * sn + d1) : h * (v_q * sn);
+  const T kx = DIST ? h * t_fma(v_q, cs, d0) : h * (v_q * cs);
+  const T ky = DIST ? h * t_fma(v_q, sn, d1) : h * (v_q * sn);
   T* gxy = gth + 64;
   gxy[2 * lane] = kx;
   gxy[2 * lane + 1] = ky;
@@ -268,8 +273,8 @@ __device__ __forceinline__ void sub_integrate_stages(int kind, T L, double inter
   for (int s = 0; s < 2; s++) {
     const T a1 = gq[8 * s + 0], b1 = gq[8 * s + 1], a2 = gq[8 * s + 2], b2 = gq[8 * s + 3];
     const T a3 = gq[8 * s + 4], b3 = gq[8 * s + 5], a4 = gq[8 * s + 6], b4 = gq[8 * s + 7];
-    px += div_by(a1 + T(2) * (a2 + a3) + a4, six, rsix);
-    py += div_by(b1 + T(2) * (b2 + b3) + b4, six, rsix);
+    px += div_by(t_fma(T(2), a2 + a3, a1) + a4, six, rsix);
+    py += div_by(t_fma(T(2), b2 + b3, b1) + b4, six, rsix);
   }
   x[0] = px;
   x[1] = py;
@@ -282,6 +287,105 @@ __device__ __forceinline__ void sub_integrate_stages(int kind, T L, double inter
     x[3] = v_end;
   }
 }
+
+// What a lane hands another through LDS in sub_integrate_stages is a rounded value the optimiser cannot look into; here
+// the eight stages sit in one lane, and a product feeding a sum of another stage would be fused into it (the
+// translation unit contracts) — one rounding less than the exchange form.  This keeps a stage's results opaque.
+template <typename T>
+__device__ __forceinline__ T stage_value(T v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
+// sub_integrate_stages with the EIGHT STAGES IN ONE LANE: the same expressions stage by stage, the same roundings — a
+// trajectory comes out bit for bit as from the stage-parallel form (tests/test_gpu_parity.py: the speculative line search
+// hands a probed trajectory over in place of the regular pass's) — for rollouts that are many at once: a lane per
+// (trajectory, subsystem) issues ~1/8 of the instructions per trajectory (rollout_lanes, ilqg_stages.hpp).  Stages with
+// the same input-driven angle (c_q: 1 and 2, 3 and 4, 5 and 6) share their tangent.
+template <typename T, bool DUB = false>
+__device__ __forceinline__ void sub_integrate_stages_seq(int kind, T L, double interval, T* x, T u0, T u1) {
+  const T h = T(interval / 2.0);
+  const T six = T(6.0), rsix = T(1.0) / T(6.0), rL = T(1.0) / L;
+  const bool dubins = DUB && kind == ILQG_DYN_DUBINS_CAR;
+  const bool car = kind == ILQG_DYN_CAR_5D || kind == ILQG_DYN_CAR_6D;
+  const bool car6 = car && kind == ILQG_DYN_CAR_6D;
+  const T ang0 = car ? x[3] : x[2];
+  const T hk = h * u0;
+  const T ang_end = t_fma(T(2), hk, ang0);
+  const T v0 = car ? x[4] : x[3];
+  const T hj = h * u1;
+  const T a0 = x[5];
+  const T a_1 = a0 + hj;
+  const T v_1 = t_fma(T(0.5) * h, hj, t_fma(h, a0, v0));
+  const T v6_end = t_fma(T(0.5) * h, hj, t_fma(h, a_1, v_1));
+  const T v5_end = t_fma(T(2), hj, v0);
+  const T v_end = car6 ? v6_end : v5_end;
+  const T a_end = t_fma(T(2), hj, a0);
+  T ang[8], vq[8], kth[8];
+#pragma unroll
+  for (int q = 0; q < 8; q++) {
+    const int j = q & 3;
+    const bool s1 = q >= 4;
+    const T aj = j == 0 ? T(0) : (j == 3 ? T(1) : T(0.5));
+    const T cq = aj + (s1 ? T(1) : T(0));
+    ang[q] = t_fma(cq, hk, ang0);
+    const T vb = s1 ? v_1 : v0, ab = s1 ? a_1 : a0;
+    const T bj = j == 2 ? T(0.25) : (j == 3 ? T(0.5) : T(0));
+    const T v6_q = t_fma(bj * h, hj, t_fma(aj * h, ab, vb));
+    const T v5_q = t_fma(cq, hj, v0);
+    vq[q] = car6 ? v6_q : v5_q;
+    if (dubins) vq[q] = L;
+    kth[q] = T(0);
+  }
+  T th1 = x[2], th2 = x[2];
+  if (car) {
+    T tn[8];
+    tn[0] = fast_tan(ang[0]);
+    tn[1] = fast_tan(ang[1]);
+    tn[2] = tn[1];
+    tn[3] = fast_tan(ang[3]);
+    tn[4] = tn[3];
+    tn[5] = fast_tan(ang[5]);
+    tn[6] = tn[5];
+    tn[7] = fast_tan(ang[7]);
+#pragma unroll
+    for (int q = 0; q < 8; q++) kth[q] = stage_value(h * (div_by(vq[q], L, rL) * tn[q]));
+    th1 = x[2] + div_by(t_fma(T(2), kth[1] + kth[2], kth[0]) + kth[3], six, rsix);
+    th2 = th1 + div_by(t_fma(T(2), kth[5] + kth[6], kth[4]) + kth[7], six, rsix);
+  }
+  const T th_end = car ? th2 : ang_end;
+  T kx[8], ky[8];
+#pragma unroll
+  for (int q = 0; q < 8; q++) {
+    const int j = q & 3;
+    const bool s1 = q >= 4;
+    const T aj = j == 0 ? T(0) : (j == 3 ? T(1) : T(0.5));
+    const T thb = s1 ? th1 : x[2];
+    const T kprev = q > 0 ? kth[q - 1] : T(0);
+    const T th_q = car ? t_fma(aj, kprev, thb) : ang[q];
+    T sn, cs;
+    fast_sincos(th_q, &sn, &cs);
+    kx[q] = stage_value(h * (vq[q] * cs));
+    ky[q] = stage_value(h * (vq[q] * sn));
+  }
+  T px = x[0], py = x[1];
+#pragma unroll
+  for (int s = 0; s < 2; s++) {
+    px += div_by(t_fma(T(2), kx[4 * s + 1] + kx[4 * s + 2], kx[4 * s]) + kx[4 * s + 3], six, rsix);
+    py += div_by(t_fma(T(2), ky[4 * s + 1] + ky[4 * s + 2], ky[4 * s]) + ky[4 * s + 3], six, rsix);
+  }
+  x[0] = px;
+  x[1] = py;
+  x[2] = th_end;
+  if (car) {
+    x[3] = ang_end;
+    x[4] = v_end;
+    if (car6) x[5] = a_end;
+  } else if (!dubins) {
+    x[3] = v_end;
+  }
+}
+#pragma clang fp contract(fast)
 
 // ---------------------------------------------------------------------------
 // Geometry

@@ -510,6 +510,33 @@ __device__ __forceinline__ void probe_roll_pair(const DevProblem& p, const Solve
   rollout_pair<T, NX, NP * MU, (MU == 1)>(p, ra[0], ra[1], w0, w1, sm, int(threadIdx.x));
 }
 
+// C = 64 / N candidates of one instance per wavefront, a lane per (candidate, subsystem) (rollout_lanes): candidates
+// j0 .. j0 + C - 1.  The wanted candidates are a prefix (probe_wanted is monotone in j); the other lanes repeat
+// candidate j0 and store nothing.
+template <typename T, int NX, int NP, int MU>
+__device__ __forceinline__ void probe_roll_lanes(const DevProblem& p, const SolveArgs<T>& sa, int b, int slot, int j0, T* sm) {
+  const InstanceBuffers<T> ib(p, sa, b);
+  const SolveState<T> s = state_load<T>(ib.w, ib.L);
+  if (j0 >= sa.probe_k || !probe_wanted(sa, s, j0)) return;
+  const ProbeEntry E(p.n, p.m, p.N, p.T);
+  const int snew = 1 - s.sacc;
+  const int t = int(threadIdx.x);
+  const int c = t / NP;
+  const bool act = c < rollout_lanes_per_wave(NP) && j0 + c < sa.probe_k && probe_wanted(sa, s, j0 + c);
+  const int j = act ? j0 + c : j0;
+  T* const e = sa.probe_pool + (size_t(slot) * sa.probe_k + j) * E.total;
+  RolloutArgs<T> ra;
+  ra.x0 = ib.XS(s.cur);
+  ra.xs_ref = ib.XS(s.cur);
+  ra.us_ref = ib.US(s.cur);
+  ra.P = ib.PB(snew);
+  ra.alpha = ib.AL(snew);
+  ra.alpha_scale = T(0);
+  ra.xs = nullptr;
+  ra.us = nullptr;
+  rollout_lanes<T, NX, NP * MU, NP, (MU == 1)>(p, ra, probe_step(sa, s, j), e + E.xs, e + E.us, act, sm, t);
+}
+
 template <typename T, int NX, int NP, int MU, int PROGID = 0>
 __device__ __forceinline__ void probe_rows_instance(const DevProblem& p, const short* maps, const SolveArgs<T>& sa,
                                                     int b, int slot, int j, int chunk, T* sm) {

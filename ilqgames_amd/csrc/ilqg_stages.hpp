@@ -153,12 +153,12 @@ __device__ __forceinline__ void rollout_instance(const DevProblem& p, const Roll
             }
 #pragma unroll
           for (int c = 0; c < CH; c++)
-            if (c0 + c < CN) s += pr[c] * dv[c];
+            if (c0 + c < CN) s = t_fma(pr[c], dv[c], s);
         }
       } else {
-        for (int c = 0; c < n; c++) s += sP[t + m * c] * sdx[c];
+        for (int c = 0; c < n; c++) s = t_fma(sP[t + m * c], sdx[c], s);
       }
-      const T u = (sur[t] - s) - a.alpha_scale * sal[t];
+      const T u = t_fma(-a.alpha_scale, sal[t], sur[t] - s);
       su[t] = u;
       a.us[size_t(k) * m + t] = u;
     }
@@ -312,9 +312,9 @@ __device__ __forceinline__ void rollout_pair(const DevProblem& p, const RolloutA
           }
 #pragma unroll
         for (int c = 0; c < CH; c++)
-          if (c0 + c < CN) s += pr[c] * dv[c];
+          if (c0 + c < CN) s = t_fma(pr[c], dv[c], s);
       }
-      const T u = (sur[tl] - s) - alpha_scale * sal[tl];
+      const T u = t_fma(-alpha_scale, sal[tl], sur[tl] - s);
       su[tl] = u;
       if (act) us_out[size_t(k) * m + tl] = u;
     }
@@ -324,6 +324,105 @@ __device__ __forceinline__ void rollout_pair(const DevProblem& p, const RolloutA
       const T u0 = integ ? su[uo] : T(0), u1 = integ ? su[uo + 1] : T(0);
       sub_integrate_stages<T, false, DUB>(kind, Lp, p.dt, xj, u0, u1, q, t, gth, any_car, T(0), T(0),
                                           h ? 0xffffffff00000000ull : 0x00000000ffffffffull);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Many rollouts of ONE instance per wavefront: a lane per (trajectory, subsystem).  The candidates of a speculative line
+// search differ in one number — the step size that scales alpha — and share the instance's gains, references and
+// starting point; a probing round integrates thousands of them (a failing search walks through all 100 step sizes), and
+// at two trajectories per wavefront it was bound by the instructions it issues (~500 per step for the pair).  Here lane
+// c N + i carries subsystem i of trajectory c (C = 64 / N trajectories: 21 for three players) through the same
+// arithmetic: its state in registers, its rows of  u = (u_ref - P dx) - step alpha  as MU chains in the reference's
+// order over the trajectory's dx (exchanged through LDS), and the eight RK4 stages one after the other
+// (sub_integrate_stages_seq, ilqg_models.hpp) — ~1/8 of the instructions per trajectory, bit for bit the trajectory
+// rollout_instance / rollout_pair produce.  `steps[c]`, `xs[c]`, `us[c]` per lane; act: the lane's trajectory is wanted.
+// The stage-parallel integrator's family only (cars, unicycles, Dubins cars: where rollout_pairs() holds).
+// ---------------------------------------------------------------------------
+__host__ __device__ constexpr int rollout_lanes_per_wave(int np) { return 64 / np; }
+__host__ __device__ inline int rollout_lanes_dx_stride(int n) { return n | 1; }  // odd: the candidates' rows on distinct banks
+__host__ __device__ inline int rollout_lanes_lds_elems(int n, int m, int np) {
+  return 2 * rollout_stage_elems(n, m) + ((rollout_lanes_per_wave(np) * rollout_lanes_dx_stride(n) + 3) & ~3);
+}
+
+template <typename T, int CN, int CM, int NP, bool DUB>
+__device__ __forceinline__ void rollout_lanes(const DevProblem& p, const RolloutArgs<T>& a, T step, T* xs_out, T* us_out,
+                                              bool act, T* sm, int t) {
+  static_assert(CN > 0 && CM > 0 && NP > 0, "compile-time dimensions");
+  constexpr int n = CN, m = CM, MU = CM / NP, C = rollout_lanes_per_wave(NP);
+  const int Tn = p.T;
+  const int WP = rollout_stage_elems(n, m);
+  T* const stg = sm;  // two staged blocks [P | alpha | u_ref | x_ref]
+  const int DS = rollout_lanes_dx_stride(n);
+  const int c = t / NP, i = t - c * NP;
+  const bool live = c < C;                   // (64 - C NP lanes idle)
+  T* const sdx = sm + 2 * WP + (live ? c : 0) * DS;  // this trajectory's dx
+  constexpr int S = int(sizeof(T));
+  auto issue = [&](int k, int buf) {
+    T* d = stg + buf * WP;
+    dma_g2l<64, false>(a.P + size_t(k) * m * n, d, m * n * S, t);
+    dma_g2l<64, false>(a.alpha + size_t(k) * m, d + m * n, m * S, t);
+    dma_g2l<64, false>(a.us_ref + size_t(k) * m, d + m * n + m, m * S, t);
+    dma_g2l<64, false>(a.xs_ref + size_t(k) * n, d + m * n + 2 * m, n * S, t);
+  };
+  constexpr int XS = 6;
+  T xj[XS];
+  const int kind = p.sub_kind[i];
+  const int xo = p.xoff[i], uo = p.uoff[i], xd = p.xoff[i + 1] - xo, ud = p.udim[i];
+  const T Lp = T(p.sub_param[i]);
+#pragma unroll
+  for (int e = 0; e < XS; e++) xj[e] = (e < xd) ? a.x0[xo + e] : T(0);
+  const bool store = act && live;
+  issue(0, 0);
+#pragma unroll 1
+  for (int k = 0; k < Tn; k++) {
+    dma_wait();
+    const T* sP = stg + (k & 1) * WP;
+    const T* sal = sP + m * n;
+    const T* sur = sal + m;
+    const T* sxr = sur + m;
+#pragma unroll
+    for (int e = 0; e < XS; e++)
+      if (e < xd) {
+        if (live) sdx[xo + e] = xj[e] - sxr[xo + e];
+        if (store) xs_out[size_t(k) * n + xo + e] = xj[e];
+      }
+    lds_sync(true);
+    T u[MU];
+    {
+      T sacc[MU];
+#pragma unroll
+      for (int e = 0; e < MU; e++) sacc[e] = T(0);
+      constexpr int CH = 8;
+#pragma unroll
+      for (int c0 = 0; c0 < CN; c0 += CH) {
+        T dv[CH], pr[MU][CH];
+#pragma unroll
+        for (int cc = 0; cc < CH; cc++)
+          if (c0 + cc < CN) {
+            dv[cc] = sdx[c0 + cc];
+#pragma unroll
+            for (int e = 0; e < MU; e++) pr[e][cc] = sP[uo + (e < ud ? e : 0) + m * (c0 + cc)];
+          }
+#pragma unroll
+        for (int cc = 0; cc < CH; cc++)
+          if (c0 + cc < CN) {
+#pragma unroll
+            for (int e = 0; e < MU; e++) sacc[e] = t_fma(pr[e][cc], dv[cc], sacc[e]);
+          }
+      }
+#pragma unroll
+      for (int e = 0; e < MU; e++) {
+        const int row = uo + (e < ud ? e : 0);
+        u[e] = t_fma(-step, sal[row], sur[row] - sacc[e]);
+        if (store && e < ud) us_out[size_t(k) * m + row] = u[e];
+      }
+    }
+    lds_sync(true);  // every lane has read the staged block and the dx rows: the next request may overwrite block k - 1, the next step's dx these
+    if (k + 1 < Tn) {
+      issue(k + 1, (k + 1) & 1);
+      sub_integrate_stages_seq<T, DUB>(kind, Lp, p.dt, xj, u[0], MU > 1 ? u[MU > 1 ? 1 : 0] : T(0));
     }
   }
 }

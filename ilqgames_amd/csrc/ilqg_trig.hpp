@@ -21,6 +21,10 @@
 
 #include <hip/hip_runtime.h>
 
+// No implicit contraction in this header: every fused multiply-add below is written out, so the functions compile to the
+// same operations wherever they are inlined (the rollouts hand trajectories to one another bit for bit).
+#pragma clang fp contract(off)
+
 namespace ilqg {
 
 // With FMAs every step of x - n hi - n lo - n lo2 rounds once — the first not at all: the difference is a multiple of
@@ -65,7 +69,7 @@ __host__ __device__ __forceinline__ void trig_kernels(double r, double* s, doubl
   *s = __builtin_fma(r * z, ps, r);
   // 1 - z/2 + z^2 pc, with the rounding error of (1 - z/2) put back (k_cos.c)
   const double hz = 0.5 * z, w = 1.0 - hz;
-  *c = w + (((1.0 - w) - hz) + z * z * pc);
+  *c = w + __builtin_fma(z * z, pc, (1.0 - w) - hz);
 }
 __host__ __device__ __forceinline__ void trig_kernels(float r, float* s, float* c) {
   const float z = r * r;
@@ -322,3 +326,5 @@ __host__ __device__ __forceinline__ float fast_tan(float x, unsigned long long g
 }
 
 }  // namespace ilqg
+
+#pragma clang fp contract(fast)  // back to the translation unit's default

@@ -249,7 +249,7 @@ class Problem:
     def solve(self, x0, bufs=None, fixed_iters=0, augmented_lagrangian=False, forced_steps=None, split_trial=None,
               handoff=None, probe=None, counted=None, resume=False, active=None, compact_rows=None, round_bursts=None,
               log_capacity=0, log_strategies=False, max_runtime=0.0, generic_kernels=None, probe_first=0, single_wave_sweep=None, adjoint_expected_decrease=None,
-              deterministic=False, static_rows=None, padded_sweep=None):
+              deterministic=False, static_rows=None, padded_sweep=None, probe_lanes=None):
         """ilqg_solve_batch_ex. `bufs` (from alloc_solve_buffers) carries the warm start in and the solution out; zero
         warm start if omitted.  forced_steps [B][fixed_iters]: test mode, the given step sizes instead of the line
         search.  split_trial / handoff / probe / counted / compact_rows: None = let the library choose, True / False = force the
@@ -282,6 +282,7 @@ class Problem:
         o.adjoint_expected_decrease = tri(adjoint_expected_decrease)
         o.static_rows = tri(static_rows)
         o.padded_sweep = tri(padded_sweep)
+        o.probe_lanes = tri(probe_lanes)
         o.max_runtime = float(max_runtime)
         il = None
         if log_capacity > 0:

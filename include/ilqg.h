@@ -447,6 +447,13 @@ typedef struct {
                                      AUTO: on for problems without an instantiation of their own; ON where no shape holds
                                      the game is ILQG_ERR_UNSUPPORTED.  The same recursion on another elimination order:
                                      results to rounding.  (This field was reserved1 = 0 up to ABI 7: same layout.)        */
+  int32_t probe_lanes;          /* ilqg_choice: the probing rollouts of the speculative line search with a lane per
+                                     (candidate, subsystem) — 64 / N candidates of an instance per wavefront, the RK4 stages
+                                     of a step one after the other in the lane — instead of two candidates per wavefront
+                                     with a lane per stage: an eighth of the instructions per rollout, a longer chain per
+                                     step (AUTO: rounds with more rollouts than the chip holds at once, eight or more
+                                     candidates per instance).  Bit-identical trajectories.  (ABI 8)                      */
+  int32_t reserved2;
   const struct ilqg_iterate_log* iterate_log; /* NULL, or where every logged iterate of the solve goes (below)          */
   double max_runtime;           /* > 0: the anytime exit of ILQSolver::Solve (src/ilq_solver.cpp:123-124) on the host's
                                      clock, seconds — once it has passed, instances leave the loop at their next
@@ -658,7 +665,8 @@ const char* ilqg_last_error(void);
 ilqg_status ilqg_set_scratch(void* device_buffer, size_t bytes);
 
 /* Library / device introspection (used by the loader to fail loudly). */
-#define ILQG_ABI_VERSION 8 /* 8: ilqg_solve_options::padded_sweep (was reserved1), ILQG_SCHEDULE_PADDED_SWEEP;
+#define ILQG_ABI_VERSION 8 /* 8: ilqg_solve_options::padded_sweep (was reserved1) / probe_lanes (new, with reserved2: the struct grew by
+                                 eight bytes), ILQG_SCHEDULE_PADDED_SWEEP;
                               7: ilqg_solve_options::deterministic (was reserved0) / static_rows, ilqg_copy_bandwidth, ilqg_problem_row_program, ilqg_row_program_build;
                               6: ilqg_problem_last_schedule;
                               5: ilqg_solve_options::iterate_log / max_runtime, run-time-dimensioned kernels behind every entry

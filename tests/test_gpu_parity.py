@@ -631,6 +631,37 @@ def test_split_trial_pass_is_the_fused_kernel_bit_for_bit(hip, cfg, al, dtype):
     assert fused["iters"].max() >= 2
 
 
+@pytest.mark.parametrize("cfg,al,dtype", [("modified_three_player_intersection", False, abi.F64),
+                                          ("modified_three_player_intersection", False, abi.F32),
+                                          ("three_player_intersection", True, abi.F64),
+                                          ("three_player_intersection", False, abi.F32),
+                                          ("three_player_collision_avoidance_reachability", False, abi.F64),
+                                          ("roundabout_merging", False, abi.F64)])
+def test_probing_rollouts_with_a_lane_per_subsystem_are_the_paired_ones_bit_for_bit(hip, cfg, al, dtype):
+    """ilqg_solve_options::probe_lanes: the speculative line search's rollouts with 64 / N candidates of an instance per
+    wavefront, a lane per (candidate, subsystem) walking the eight RK4 stages in sequence (rollout_lanes,
+    sub_integrate_stages_seq), against the form with two candidates per wavefront and a lane per stage — and against no
+    probing at all.  A probed trajectory is handed over in place of the regular pass's rollout, so every output of a
+    free-running solve — line searches that back-track, fail, diverge past the fast trigonometric range — must come back
+    identical.  (n = 14 own parameters: the line search fails at iteration 2; n = 16: ~10 % of the instances back-track
+    tens of steps; the reachability scene: 35 rejected steps per iteration; n = 24: four players, 16 candidates per wave.)"""
+    spec = examples.CONFIGS[cfg]()
+    spec.params.max_solver_iters = 8
+    spec.params.unconstrained_solver_max_iters = 4
+    B = 40
+    x0 = examples.jittered_x0(spec, B, seed=5)
+    outs = []
+    for kw in (dict(probe=True, probe_lanes=True), dict(probe=True, probe_lanes=False), dict(probe=False)):
+        out = hip.Problem(spec, dtype).solve(x0, augmented_lagrangian=al, split_trial=True, **kw)
+        outs.append({k: _np(v).copy() for k, v in out.items() if hasattr(v, "shape") and k != "ws"})
+    st = hip.Problem(spec, dtype)
+    o = st.solve(x0, augmented_lagrangian=al, split_trial=True, probe=True, probe_lanes=True)
+    assert int(_np(st.solve_state(o, augmented_lagrangian=al)["backtracks"]).sum()) > B // 4   # the line searches did back-track
+    for other in outs[1:]:
+        for k in outs[0]:
+            assert np.array_equal(outs[0][k], other[k], equal_nan=True), (k, cfg)
+
+
 def test_augmented_lagrangian_with_a_polyline_constraint_fp64(hip, oracle):
     """Polyline2SignedDistanceConstraint through AugmentedLagrangianSolver (examples.cost_zoo_scene: a wall that bulges
     into player 1's lane makes the constraint active mid-horizon, next to the other cost kinds of that scene)."""
