@@ -692,6 +692,9 @@ def baseline_configs_block(examples, abi, local_rank):
     # config 5's scene as a fixed-iteration solve (what --baseline-config 5 times), then config 5 as written
     out["config5_scene_fixed_iterations_b2048"] = timed_workload(examples, abi, "three_player_collision_avoidance_reachability",
                                                                  "f64", 2048, 5, local_rank)
+    # a game whose dimensions have no instantiation (a test scene, not a reference example: Dubins car m = 1 beside
+    # Car5D m = 2, n = 8): the run-time-dimensioned kernels, its sweep on the padded (8, 2, 2) kernel
+    out["mixed_dubins_car_scene_b1024"] = timed_workload(examples, abi, "mixed_dubins_car_scene", "f64", 1024, 10, local_rank)
     out["config5_receding_horizon_al_b2048"] = receding_horizon_workload(examples, abi, local_rank)
     # ... and in fp32, the reference's own arithmetic (include/ilqgames/utils/types.h:68-69), in which its x0 passes
     out["config5_receding_horizon_al_b2048_f32"] = receding_horizon_workload(examples, abi, local_rank, dtype_name="f32")
