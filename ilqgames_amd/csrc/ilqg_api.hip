@@ -1053,7 +1053,10 @@ struct ilqg_problem {
   std::vector<int> row_prog_host;  // the program as built (ilqg_problem_row_program)
   int static_prog = 0;             // id of the registered structure it matches (ilqg_rowprog_static.hpp), 0: none
   int* d_unfinished = nullptr;  // instances still running after an LQ-kernel launch
-  int* h_unfinished = nullptr;  // pinned host mirror
+  int* h_unfinished = nullptr;  // pinned host mirror: [0..3] the counters, [8] the sequence number of read_round_counters
+  int* h_unfinished_dev = nullptr;  // ... as the device addresses it
+  int publish_seq = 0;
+  bool counters_clean = false;  // d_unfinished was cleared by the last thing that touched it (read_round_counters)
   int mu_uniform = 0;
   bool has_route_progress = false;  // a RouteProgressCost term: its tables are a first solve's (initial time 0)
   int last_schedule = 0;  // ILQG_SCHEDULE_* of the last solve (ilqg_problem_last_schedule)
@@ -1092,6 +1095,54 @@ struct ilqg_problem {
     return mean + 3.0 * std::sqrt(var / (al_loop_count - 1));
   }
 };
+
+// The round counters' way back to the host.  A counted solve reads them once per round (twice with the augmented
+// Lagrangian's restarts), and while it does the device idles: what a read-back costs is the gap between two rounds.
+// A copy command plus a stream synchronisation is ~20 us of that; instead a one-wave kernel behind the round's last
+// launch stores the four counters and then a sequence number into host memory (pinned, coherent, mapped), and the
+// host spins on the sequence number.  ILQG_READBACK=copy keeps the copy + synchronise form (A/B measurements);
+// a device fault shows up in the periodic hipStreamQuery.
+namespace {
+__global__ void ilq_publish_kernel(int* counts, int* host, int seq) {
+  const int t = threadIdx.x;
+  if (t < 4) {
+    __hip_atomic_store(host + t, counts[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    counts[t] = 0;  // ... and the next round finds them cleared (ilqg_problem::counters_clean): one fill command less
+  }
+  __threadfence_system();
+  if (t == 0) __hip_atomic_store(host + 8, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+inline ilqg_status read_round_counters(ilqg_problem* p, hipStream_t stream) {
+  static const bool copy_form = [] {
+    const char* e = getenv("ILQG_READBACK");
+    return e && std::string(e) == "copy";
+  }();
+  p->counters_clean = false;
+  if (copy_form || !p->h_unfinished_dev) {
+    HIP_TRY(hipMemcpyAsync(p->h_unfinished, p->d_unfinished, 4 * sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return ILQG_OK;
+  }
+  const int seq = ++p->publish_seq;
+  hipLaunchKernelGGL(ilq_publish_kernel, dim3(1), dim3(64), 0, stream, p->d_unfinished, p->h_unfinished_dev, seq);
+  HIP_TRY(hipGetLastError());
+  p->counters_clean = true;
+  volatile int* const flag = p->h_unfinished + 8;
+  for (long long spins = 0;; spins++) {
+    if (__atomic_load_n(const_cast<int*>(flag), __ATOMIC_ACQUIRE) == seq) return ILQG_OK;
+    __builtin_ia32_pause();
+    if ((spins & 0xffff) == 0xffff) {  // every ~65 k polls: has the stream died, or drained without our store?
+      const hipError_t q = hipStreamQuery(stream);
+      if (q == hipSuccess) {
+        if (__atomic_load_n(const_cast<int*>(flag), __ATOMIC_ACQUIRE) == seq) return ILQG_OK;
+        return fail(ILQG_ERR_HIP, "the round counters never reached the host");
+      }
+      if (q != hipErrorNotReady) return fail(ILQG_ERR_HIP, std::string("hipStreamQuery: ") + hipGetErrorString(q));
+    }
+  }
+}
+}  // namespace
 
 // The outer loop's clock of AugmentedLagrangianSolver::Solve under a max_runtime (src/augmented_lagrangian_solver.cpp:
 // 104-110,193): `elapsed` starts at the first inner solve's ALLOWANCE (max_runtime / max_solver_iters, not the time it
@@ -1391,6 +1442,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
     raise_lds_limit((const void*)k_prows, lds_prows);
   }
   sa.first = resume ? 2 : 1;
+  p->counters_clean = false;  // whatever an earlier solve left in the round counters
   int waiting_lq = 0, waiting_exit = 0;  // split passes: instances already through this iteration's line search
   // Free-running solves: the kernels select their instances by the stage each one is in, so a round launched for
   // nobody is harmless — the host therefore enqueues BURSTS of whole rounds (trial, exit, sweep) and reads the
@@ -1429,7 +1481,8 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
       // a fixed-iteration solve knows its last round: no burst runs past it
       const long long left = (fixed_iters > 0 && !al_mode) ? (long long)fixed_iters - round : (long long)burst;
       for (int q = 1; q < burst && q <= left; q++) {  // rounds without a read-back
-        HIP_TRY(hipMemsetAsync(p->d_unfinished, 0, 4 * sizeof(int), stream));
+        if (!p->counters_clean) HIP_TRY(hipMemsetAsync(p->d_unfinished, 0, 4 * sizeof(int), stream));
+        p->counters_clean = false;
         if (split) {  // the three-kernel form of the pass over the whole batch (no probing: nobody is listed)
           sa.ids_next = pass_ids + size_t(list) * batch;
           sa.round_count = batch;
@@ -1453,7 +1506,8 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
         round++;
       }
     }
-    if (counted) HIP_TRY(hipMemsetAsync(p->d_unfinished, 0, 4 * sizeof(int), stream));
+    if (counted && !p->counters_clean) HIP_TRY(hipMemsetAsync(p->d_unfinished, 0, 4 * sizeof(int), stream));
+    p->counters_clean = false;  // (the round's kernels count into them)
     if (split || sa.ids) {  // a split pass: the whole batch (split mode) or the listed back-tracking instances
       sa.ids_next = pass_ids + size_t(list) * batch;
       // Step sizes probed per listed instance: as many as the pool holds for a list this long, doubling from two
@@ -1554,8 +1608,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
     sa.first = 0;
     int want_lq = 1, want_exit = 0, restarted = 0, again = 0;
     if (counted) {
-      HIP_TRY(hipMemcpyAsync(p->h_unfinished, p->d_unfinished, 4 * sizeof(int), hipMemcpyDeviceToHost, stream));
-      HIP_TRY(hipStreamSynchronize(stream));
+      if (read_round_counters(p, stream) != ILQG_OK) return ILQG_ERR_HIP;
       want_lq = p->h_unfinished[0];
       want_exit = p->h_unfinished[1];
       again = p->h_unfinished[3];
@@ -1605,9 +1658,9 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
       if (outer.before_exit()) sa.outer_closed = 1;  // out of time: inner solves that end now are the last ones
       hipLaunchKernelGGL(k_exit, dim3(batch), dim3(64), lds_exit, stream, d, sa);
       HIP_TRY(hipGetLastError());
+      p->counters_clean = false;
       if (counted && al_mode) {
-        HIP_TRY(hipMemcpyAsync(p->h_unfinished, p->d_unfinished, 4 * sizeof(int), hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
+        if (read_round_counters(p, stream) != ILQG_OK) return ILQG_ERR_HIP;
         restarted = p->h_unfinished[2];
         if (restarted) inner_elapsed = 0.0;  // the next inner solve's own budget
         outer.after_exit(restarted);
@@ -1804,13 +1857,15 @@ static ilqg_status generic_solve(ilqg_problem* p, int32_t batch, const void* x0,
     HIP_TRY(hipMemsetAsync(il.count, 0, sizeof(int) * size_t(batch), stream));
   }
   sa.first = resume ? 2 : 1;
+  p->counters_clean = false;  // whatever an earlier solve left in the round counters
   sa.ids = nullptr;
   sa.ids_next = nullptr;
   int waiting_lq = 0, waiting_exit = 0;
   int round_instances = batch, list = 0, tail_rounds = 0;
   bool probed_in_tail = false;
   for (long long round = 0;; round++) {
-    HIP_TRY(hipMemsetAsync(p->d_unfinished, 0, 4 * sizeof(int), stream));
+    if (!p->counters_clean) HIP_TRY(hipMemsetAsync(p->d_unfinished, 0, 4 * sizeof(int), stream));
+    p->counters_clean = false;
     sa.ids_next = pass_ids + size_t(list) * batch;
     if (sa.ids && probe) {
       // step sizes probed per listed instance this round: what the pool holds for a list this long, ramping up over the
@@ -1850,8 +1905,7 @@ static ilqg_status generic_solve(ilqg_problem* p, int32_t batch, const void* x0,
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_decide, dim3(round_instances), dim3(64), lds_decide, stream, d, sa);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(p->h_unfinished, p->d_unfinished, 4 * sizeof(int), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
+    if (read_round_counters(p, stream) != ILQG_OK) return ILQG_ERR_HIP;
     waiting_lq += p->h_unfinished[0];
     waiting_exit += p->h_unfinished[1];
     if (round > cap) return fail(ILQG_ERR_HIP, "solve did not terminate within its iteration bound");
@@ -1886,13 +1940,13 @@ static ilqg_status generic_solve(ilqg_problem* p, int32_t batch, const void* x0,
       HIP_TRY(hipGetLastError());
     }
     if (want_exit) {
-      HIP_TRY(hipMemsetAsync(p->d_unfinished, 0, 4 * sizeof(int), stream));
+      if (!p->counters_clean) HIP_TRY(hipMemsetAsync(p->d_unfinished, 0, 4 * sizeof(int), stream));
       if (outer.before_exit()) sa.outer_closed = 1;
       hipLaunchKernelGGL(k_exit, dim3(batch), dim3(64), lds_exit, stream, d, sa);
       HIP_TRY(hipGetLastError());
+      p->counters_clean = false;
       if (al_mode) {
-        HIP_TRY(hipMemcpyAsync(p->h_unfinished, p->d_unfinished, 4 * sizeof(int), hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
+        if (read_round_counters(p, stream) != ILQG_OK) return ILQG_ERR_HIP;
         restarted = p->h_unfinished[2];
         if (restarted) inner_elapsed = 0.0;
         outer.after_exit(restarted);
@@ -2542,7 +2596,11 @@ static ilqg_status problem_create_impl(const ilqg_problem_desc* desc, ilqg_probl
   // the term table is uploaded last: it carries the argument offsets computed above
   if (e == hipSuccess) e = hipMemcpy(p->d_terms, dt.data(), sizeof(DevTerm) * dt.size(), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMalloc(&p->d_unfinished, 4 * sizeof(int));
-  if (e == hipSuccess) e = hipHostMalloc(&p->h_unfinished, 4 * sizeof(int));
+  if (e == hipSuccess) e = hipHostMalloc(&p->h_unfinished, 16 * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent);
+  if (e == hipSuccess) {
+    for (int i = 0; i < 16; i++) p->h_unfinished[i] = 0;
+    if (hipHostGetDevicePointer((void**)&p->h_unfinished_dev, p->h_unfinished, 0) != hipSuccess) p->h_unfinished_dev = nullptr;
+  }
   if (e == hipSuccess) e = hipMalloc(&p->d_row_prog, sizeof(int) * rph.words.size());
   if (e == hipSuccess) e = hipMemcpy(p->d_row_prog, rph.words.data(), sizeof(int) * rph.words.size(), hipMemcpyHostToDevice);
   d.row_prog = p->d_row_prog;
