@@ -14,6 +14,9 @@
 // different numbers of iterations and back-tracks without masks or compaction: a part returns at once
 // for an instance that is not waiting for it.
 #pragma once
+#ifndef ILQG_ROLL_PRIO
+#define ILQG_ROLL_PRIO 1  // the integrating wave of a trial pass issues ahead of the row waves it shares SIMDs with (fp32 headline +1.7 %, fp64 +0.3 %)
+#endif
 
 #include "ilqg_lq.hpp"
 #include "ilqg_lq_openloop.hpp"
@@ -364,7 +367,9 @@ __host__ __device__ inline size_t trial_phase_quad_elems(const DevProblem& p, in
 }
 template <typename T>
 __host__ __device__ inline size_t trial_phase_lds_bytes(const DevProblem& p, int phase, int cw) {  // W = 1, no word maps
-  const size_t re = (rollout_lds_elems(p.n, p.m) + 3) & ~size_t(3);
+  // (the decision kernel integrates nothing: without the rollout's region a CU holds a wave slot's worth of its
+  // workgroups — each one a chain of global round trips — instead of 18: B = 8192, fp64: 126 -> 120 us per launch)
+  const size_t re = phase == TRIAL_DECIDE ? 0 : (rollout_lds_elems(p.n, p.m) + 3) & ~size_t(3);
   return (re + trial_phase_quad_elems<T>(p, phase, cw)) * sizeof(T) + 16;
 }
 
@@ -760,7 +765,7 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const s
   T* const costs = sa.total_costs + size_t(b) * N;
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
 
-  const size_t re = (rollout_lds_elems(n, m) + 3) & ~size_t(3);
+  const size_t re = PHASE == TRIAL_DECIDE ? 0 : (rollout_lds_elems(n, m) + 3) & ~size_t(3);  // (trial_phase_lds_bytes)
   const size_t qe = trial_phase_quad_elems<T>(p, PHASE, sa.rows_cw, PROGID != 0 && PHASE == TRIAL_FUSED);
   constexpr int RW = W > 1 ? W - 1 : 1;     // row waves: all but the integrating wave 0
   const int rwave = W > 1 ? wave - 1 : 0;   // this wave's row scratch (-1: wave 0 of a multi-wave workgroup has none)
@@ -790,6 +795,9 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const s
     __syncthreads();
     tl_stamp(sa.prof, b, 1, t == 0);
     if (roll && wave == 0) {
+#if ILQG_ROLL_PRIO
+      __builtin_amdgcn_s_setprio(ILQG_ROLL_PRIO);
+#endif
       if constexpr (NX > 0)
         rollout_instance<T, NX, NP * MU, (NX == 4 && NP == 2), (MU == 1), (NX == 3 && NP == 2 && MU == 1),
                          (NX == 4 * NP && MU == 2 && NP <= 2), dims_use_plain_rk4(NX, NP, MU)>(
@@ -797,6 +805,9 @@ __device__ __forceinline__ void trial_part_instance(const DevProblem& p, const s
                                          (kProfile && sa.prof) ? rph : nullptr, kTimeline ? sa.prof : nullptr, b);
       else
         rollout_instance_rt<T>(p, ra, sm_roll, lane);
+#if ILQG_ROLL_PRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
     }
     tl_stamp(sa.prof, b, 2, t == 0);
     if (roll && W == 1) {
