@@ -467,7 +467,7 @@ __global__ void __launch_bounds__(64) ilq_deadline_kernel(DevProblem p, SolveArg
 // Exit kernel: return path of ILQSolver::Solve / AugmentedLagrangianSolver bookkeeping for the instances
 // whose inner solve has ended (converged, out of iterations, or line search exhausted).
 template <typename T, int NX, int NP, int MU>
-__global__ void __launch_bounds__(64) ilq_exit_kernel(DevProblem p, SolveArgs<T> sa) {
+__global__ void __launch_bounds__(256) ilq_exit_kernel(DevProblem p, SolveArgs<T> sa) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int b = blockIdx.x;
   {
@@ -1113,6 +1113,14 @@ __global__ void ilq_publish_kernel(int* counts, int* host, int seq) {
   if (t == 0) __hip_atomic_store(host + 8, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// How many instances of a masked batch take part (ilqg_solve_options::active): into the fourth round counter.
+__global__ void ilq_count_active_kernel(const int* active, int batch, int* counts) {
+  int mine = 0;
+  for (int b = threadIdx.x; b < batch; b += blockDim.x) mine += active[b] != 0;
+  for (int off = 32; off >= 1; off >>= 1) mine += __shfl_xor(mine, off, 64);
+  if ((threadIdx.x & 63) == 0 && mine) atomicAdd(counts + 3, mine);
+}
+
 inline ilqg_status read_round_counters(ilqg_problem* p, hipStream_t stream) {
   static const bool copy_form = [] {
     const char* e = getenv("ILQG_READBACK");
@@ -1294,9 +1302,24 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   const int rows_cw_interpreted = sa.rows_cw;
   if (static_prog) sa.rows_cw = 64;
   const size_t lds_trial = trial_lds_bytes<T>(d, W, sa.rows_cw, static_prog != 0);
+  // The schedules below are chosen by how many instances the chip will hold at once.  Under a mask that is the number
+  // of instances taking part, not the length of the buffers: a receding-horizon loop replans the few dozen plans
+  // still running of a batch of 2048 (src/receding_horizon_simulator.cpp:77), and the throughput forms chosen for 2048
+  // — single-wave sweep, adjoint expected decrease, split trial pass — are latency forms three times slower for them
+  // (config 5 as written: 400 us per sweep launch instead of 140).  A free-running solve waits for the device every
+  // round anyway, so it counts its mask first (one more read-back per call); a fixed-iteration solve stays
+  // asynchronous and keeps the buffer length.
+  int sched_batch = batch;
+  if (active && !opt.forced_steps && !opt.deterministic && !(fixed_iters > 0 && !al_mode)) {
+    HIP_TRY(hipMemsetAsync(p->d_unfinished, 0, 4 * sizeof(int), stream));  // (whatever an earlier solve left there)
+    hipLaunchKernelGGL(ilq_count_active_kernel, dim3(1), dim3(256), 0, stream, active, int(batch), p->d_unfinished);
+    HIP_TRY(hipGetLastError());
+    if (read_round_counters(p, stream) != ILQG_OK) return ILQG_ERR_HIP;
+    sched_batch = p->h_unfinished[3] > 0 ? p->h_unfinished[3] : 1;
+  }
   // fp32, one-tile sweep of three player waves, many instances per CU: the 128-register build (see ilq_lq_kernel)
   constexpr bool has_packed = sizeof(T) == 4 && C::USE_MFMA && C::MFMA_ONE_TILE && NP == 3;
-  const bool packed = has_packed && pw && size_t(batch) >= size_t(5) * 256;
+  const bool packed = has_packed && pw && size_t(sched_batch) >= size_t(5) * 256;
   auto k_lq_multi = packed ? ilq_lq_kernel<T, NX, NP, MU, (has_packed ? LQ_PLAYER_WAVES_PACKED : LQ_VALU_FEEDBACK)>
             : pw ? ilq_lq_kernel<T, NX, NP, MU, (C::USE_MFMA ? LQ_PLAYER_WAVES : LQ_VALU_FEEDBACK)>
                  : (p->desc.params.open_loop ? (ol_compact ? ilq_lq_kernel<T, NX, NP, MU, LQ_OPEN_LOOP_COMPACT> : ilq_lq_kernel<T, NX, NP, MU, LQ_OPEN_LOOP>)
@@ -1323,19 +1346,22 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) num_cus = prop.multiProcessorCount;
   }
-  const bool big_batch = size_t(batch) >= size_t(8) * num_cus;
+  // (the exit kernel copies an instance's final iterate, T m n words of strategies among them: four waves where the
+  // instances are few and the kernel is a link of the round's chain, one where they share the chip's bandwidth anyway)
+  const int nt_exit = sched_batch <= 2 * num_cus ? 256 : 64;
+  const bool big_batch = size_t(sched_batch) >= size_t(8) * num_cus;
   // the whole batch resident at once (four instances per CU): fair issue arbitration among the co-resident instances
 #ifndef ILQG_PRIO_ROTATION
 #define ILQG_PRIO_ROTATION 1
 #endif
-  sa.prio_div = (ILQG_PRIO_ROTATION && batch > num_cus && batch <= 4 * num_cus) ? num_cus : 0;
+  sa.prio_div = (ILQG_PRIO_ROTATION && sched_batch > num_cus && sched_batch <= 4 * num_cus) ? num_cus : 0;
   // ... and wherever the single-wave sweep (below) will run: it takes its expected decrease from its own adjoint pass, so
   // nothing is left for the fused kernel's row wave to overlap with the rollout, and the three split kernels each keep
   // more instances on a CU than the fused one (measured, n = 14, B = 8192, LQ single-wave + adjoint: fp64 1.58 M it/s
   // fused vs 1.65 M split, fp32 2.61 M vs 2.77 M; B = 2048 fp64 1.40 M vs 1.50 M).
   constexpr bool has_1w = W1Cfg<T, NX, NP, MU>::SUPPORTED && C::USE_MFMA && C::MFMA_ONE_TILE;
   const bool want_1w = has_1w && pw && compact_on && !kProfile && d.rp_compact_w <= W1Cfg<T, NX, NP, MU>::kWords &&
-                       choice(opt.single_wave_sweep, !opt.deterministic && size_t(batch) >= size_t(5) * num_cus) &&
+                       choice(opt.single_wave_sweep, !opt.deterministic && size_t(sched_batch) >= size_t(5) * num_cus) &&
                        opt.adjoint_expected_decrease != ILQG_CHOICE_OFF;
   bool split = choice(opt.split_trial, 4 * lds_trial > size_t(160) * 1024 || (big_batch && NX > 16) || want_1w);
   if (kProfile || opt.forced_steps) split = false;  // the phase profile reads the fused kernel's counters
@@ -1391,7 +1417,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   const bool adjoint = choice(opt.adjoint_expected_decrease, sa.defer_forward == 0);
   const bool single_wave = has_1w && pw && sa.compact && !kProfile && (adjoint || sa.defer_forward) &&
                            d.rp_compact_w <= W1Cfg<T, NX, NP, MU>::kWords &&
-                           choice(opt.single_wave_sweep, !opt.deterministic && size_t(batch) >= size_t(5) * num_cus);
+                           choice(opt.single_wave_sweep, !opt.deterministic && size_t(sched_batch) >= size_t(5) * num_cus);
   auto k_lq = single_wave ? ilq_lq_kernel<T, NX, NP, MU, (has_1w ? LQ_SINGLE_WAVE : LQ_VALU_FEEDBACK)> : k_lq_multi;
   const int nt_lq = single_wave ? 64 : nt_lq_multi;
   const size_t lds_lq = single_wave ? size_t(W1Cfg<T, NX, NP, MU>::ELEMS + 4) * sizeof(T) : lds_lq_multi;
@@ -1499,7 +1525,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
         HIP_TRY(hipGetLastError());
         sa.first = 0;
         if (log_iterates() != ILQG_OK) return ILQG_ERR_HIP;
-        hipLaunchKernelGGL(k_exit, dim3(batch), dim3(64), lds_exit, stream, d, sa);
+        hipLaunchKernelGGL(k_exit, dim3(batch), dim3(nt_exit), lds_exit, stream, d, sa);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(k_lq, dim3(batch), dim3(nt_lq), lds_lq, stream, d, sa);
         HIP_TRY(hipGetLastError());
@@ -1656,7 +1682,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
     if ((want_exit || want_lq) && log_iterates() != ILQG_OK) return ILQG_ERR_HIP;
     if (want_exit) {
       if (outer.before_exit()) sa.outer_closed = 1;  // out of time: inner solves that end now are the last ones
-      hipLaunchKernelGGL(k_exit, dim3(batch), dim3(64), lds_exit, stream, d, sa);
+      hipLaunchKernelGGL(k_exit, dim3(batch), dim3(nt_exit), lds_exit, stream, d, sa);
       HIP_TRY(hipGetLastError());
       p->counters_clean = false;
       if (counted && al_mode) {

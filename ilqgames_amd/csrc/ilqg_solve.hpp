@@ -238,18 +238,34 @@ __device__ __forceinline__ void solve_exit_path(const DevProblem& p, const QuadT
   T *const xs0 = ib.xs0, *const us0 = ib.us0, *const P0 = ib.P0, *const al0 = ib.al0;
   T* const lambdas = w + L.lambdas;
   const int t = threadIdx.x;
+  // Copies with eight loads in flight per lane: a load-store pair per trip is one memory latency per element and lane,
+  // and for the few dozen plans of a receding-horizon replan this kernel is a link of every round's chain (the
+  // strategies alone are T m n words; config 5 as written: 90 -> 25 us per launch).
+  auto copy = [&](T* dst, const T* src, int count, T scale, bool scaled) {
+    constexpr int U = 8;
+    const int nt = blockDim.x;
+    for (int e0 = t; e0 < count; e0 += nt * U) {
+      T v[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int e = e0 + u * nt;
+        v[u] = e < count ? src[e] : T(0);
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int e = e0 + u * nt;
+        if (e < count) dst[e] = scaled ? v[u] * scale : v[u];
+      }
+    }
+  };
   __syncthreads();
       // ---- the log's final iterate goes back through buffer 0 (alpha carries the accepted step) ----
       if (s.cur == 1) {
-        for (int e = t; e < Tn * n; e += blockDim.x) xs0[e] = (w + L.xs1)[e];
-        for (int e = t; e < Tn * m; e += blockDim.x) us0[e] = (w + L.us1)[e];
+        copy(xs0, w + L.xs1, Tn * n, T(1), false);
+        copy(us0, w + L.us1, Tn * m, T(1), false);
       }
-      if (s.sacc == 1)
-        for (int e = t; e < Tn * m * n; e += blockDim.x) P0[e] = (w + L.P1)[e];
-      {
-        const T* src = ib.AL(s.sacc);
-        for (int e = t; e < Tn * m; e += blockDim.x) al0[e] = src[e] * s.acc_scale;
-      }
+      if (s.sacc == 1) copy(P0, w + L.P1, Tn * m * n, T(1), false);
+      copy(al0, ib.AL(s.sacc), Tn * m, s.acc_scale, true);
       __syncthreads();
       s.stage = ST_DONE;
       if (sa.al_mode) {  // AugmentedLagrangianSolver::Solve, src/augmented_lagrangian_solver.cpp:72-210
@@ -266,47 +282,63 @@ __device__ __forceinline__ void solve_exit_path(const DevProblem& p, const QuadT
             s.max_err > T(prm.constraint_error_tolerance) && !sa.outer_closed) {
           // ---- multiplier update at the final operating point (:116-140) ----
           T my_err = -dinf<T>();
-          for (int cs = t; cs < p.num_constraints; cs += blockDim.x) {  // a thread per constraint slot, in strides
+          // A thread per (constraint slot, time step), in strides: the errors are independent of one another, and a
+          // multiplier is touched by the steps whose TimeIndex is its own — a run of consecutive steps (the index is
+          // monotone in k; the reference's float product makes a step now and then land on its predecessor's), which
+          // the first step of the run applies in the reference's order.  (One thread per slot walking the steps was a
+          // chain of T global round trips: most of this kernel's 135 us in config 5's replans.)
+          auto time_index = [&](int k) {  // Constraint::IncrementLambda (constraint.h:98-102) at TimeIndex(t0 + dt*float(k))
+            const double tt = 0.0 + p.dt * double(float(k));
+            return int(static_cast<size_t>(tt / p.dt));
+          };
+          for (int e = t; e < p.num_constraints * Tn; e += blockDim.x) {
+            const int cs = e / Tn, k = e - cs * Tn;
             int ti = 0;
-            for (int e = 0; e < p.num_terms; e++)
-              if (tb.terms[e].slot == cs) ti = e;
+            for (int q = 0; q < p.num_terms; q++)
+              if (tb.terms[q].slot == cs) ti = q;
             const DevTerm c = tb.terms[ti];
             const bool on_state = c.role == ILQG_ROLE_STATE_CONSTRAINT;
-            for (int k = 0; k < Tn; k++) {
-              const T* v = on_state ? xs0 + size_t(k) * n : us0 + size_t(k) * m + p.uoff[c.arg];
+            auto error_at = [&](int kk) {
+              const T* v = on_state ? xs0 + size_t(kk) * n : us0 + size_t(kk) * m + p.uoff[c.arg];
               // FinalTimeConstraint::Evaluate (constraint/final_time_constraint.h:66-70): 0 before its threshold
-              const T err = k < c.k_start ? T(0) : term_evaluate_leaf<T>(tb, ti, v, c.arg_dim);
-              my_err = err > my_err ? err : my_err;
-              // Constraint::IncrementLambda (constraint.h:98-102) at TimeIndex(t0 + dt*float(k))
-              const double tt = 0.0 + p.dt * double(float(k));
-              const int tidx = int(static_cast<size_t>(tt / p.dt));
-              const T nl = lambdas[cs * Tn + tidx] + s.mu * err;
-              lambdas[cs * Tn + tidx] = ((c.flags & ILQG_FLAG_EQUALITY) || nl > T(0)) ? nl : T(0);
+              return kk < c.k_start ? T(0) : term_evaluate_leaf<T>(tb, ti, v, c.arg_dim);
+            };
+            const T err = error_at(k);
+            my_err = err > my_err ? err : my_err;
+            const int tidx = time_index(k);
+            if (k > 0 && time_index(k - 1) == tidx) continue;  // applied by the first step of its run
+            T lam = lambdas[cs * Tn + tidx];
+            T step_err = err;
+            for (int kk = k;;) {
+              const T nl = lam + s.mu * step_err;
+              lam = ((c.flags & ILQG_FLAG_EQUALITY) || nl > T(0)) ? nl : T(0);
+              if (++kk >= Tn || time_index(kk) != tidx) break;
+              step_err = error_at(kk);
             }
+            lambdas[cs * Tn + tidx] = lam;
           }
-          if (t < 64) {
 #pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-              const T o = __shfl_xor(my_err, off, 64);
-              my_err = o > my_err ? o : my_err;
-            }
-            if (t == 0) sm[0] = my_err;
+          for (int off = 32; off >= 1; off >>= 1) {
+            const T o = __shfl_xor(my_err, off, 64);
+            my_err = o > my_err ? o : my_err;
           }
+          if ((t & 63) == 0) sm[t >> 6] = my_err;  // (a workgroup of up to 64 waves)
           __syncthreads();
           s.max_err = sm[0];
+          for (int q = 1; q < int(blockDim.x + 63) / 64; q++) s.max_err = sm[q] > s.max_err ? sm[q] : s.max_err;
           __syncthreads();
           s.mu *= T(prm.geometric_mu_scaling);  // :143
           // Problem::OverwriteSolution only after a successful inner solve (:151-154)
           if (s.ok) {
-            for (int e = t; e < Tn * n; e += blockDim.x) (w + L.wxs)[e] = xs0[e];
-            for (int e = t; e < Tn * m; e += blockDim.x) (w + L.wus)[e] = us0[e];
-            for (int e = t; e < Tn * m * n; e += blockDim.x) (w + L.wP)[e] = P0[e];
-            for (int e = t; e < Tn * m; e += blockDim.x) (w + L.wal)[e] = al0[e];
+            copy(w + L.wxs, xs0, Tn * n, T(1), false);
+            copy(w + L.wus, us0, Tn * m, T(1), false);
+            copy(w + L.wP, P0, Tn * m * n, T(1), false);
+            copy(w + L.wal, al0, Tn * m, T(1), false);
           } else {
-            for (int e = t; e < Tn * n; e += blockDim.x) xs0[e] = (w + L.wxs)[e];
-            for (int e = t; e < Tn * m; e += blockDim.x) us0[e] = (w + L.wus)[e];
-            for (int e = t; e < Tn * m * n; e += blockDim.x) P0[e] = (w + L.wP)[e];
-            for (int e = t; e < Tn * m; e += blockDim.x) al0[e] = (w + L.wal)[e];
+            copy(xs0, w + L.wxs, Tn * n, T(1), false);
+            copy(us0, w + L.wus, Tn * m, T(1), false);
+            copy(P0, w + L.wP, Tn * m * n, T(1), false);
+            copy(al0, w + L.wal, Tn * m, T(1), false);
           }
           __syncthreads();
           // ---- next ILQSolver::Solve call: fresh locals, persistent last_merit / t_extreme ----

@@ -413,7 +413,11 @@ typedef struct {
                                       every batch): an instance's result is the same bits whatever batch it is solved in
                                       (tests/test_gpu_single_wave.py).  Costs the large-batch throughput form.  (This
                                       field was reserved0 = 0 up to ABI 6: same layout.)                              */
-  const int32_t* active;        /* [B] device int32 or NULL: instances with 0 are skipped, their buffers untouched  */
+  const int32_t* active;        /* [B] device int32 or NULL: instances with 0 are skipped, their buffers untouched.
+                                     A free-running solve (which waits for the device every round anyway) counts the
+                                     mask first and lets every ILQG_CHOICE_AUTO below go by the instances taking part,
+                                     not by B; fixed_iters > 0 without the augmented Lagrangian stays asynchronous and
+                                     goes by B.                                                                        */
   const void* forced_steps;     /* [B][fixed_iters] device (problem dtype) or NULL.  Test mode: iteration q of
                                       instance b scales its strategies by forced_steps[b][q], integrates and
                                       quadraticises once and ACCEPTS, whatever CheckArmijoCondition says — the

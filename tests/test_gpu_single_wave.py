@@ -105,6 +105,46 @@ def test_last_schedule_reports_what_auto_chose(hip):
 
 
 @pytest.mark.parametrize("dtype", [abi.F64, abi.F32])
+def test_a_masked_batch_is_scheduled_by_the_instances_that_take_part(hip, dtype):
+    """A free-running solve under ilqg_solve_options::active counts its mask before it chooses a schedule (the receding-
+    horizon loop replans the few plans still running of a large batch, src/receding_horizon_simulator.cpp:77): 40
+    instances of a buffer of five per CU run the schedule of a batch of 40 — no single-wave sweep, no split trial pass —
+    and return the bits of those 40 solved alone; the other rows are left as they were."""
+    import torch
+    spec = examples.modified_three_player_intersection()
+    spec.params.initial_alpha_scaling = 0.1
+    spec.params.expected_decrease_fraction = 0.001
+    spec.params.max_backtracking_steps = 100
+    spec.params.max_solver_iters = 6
+    cus = hip.device_info()[1]
+    B = 5 * cus
+    x0 = examples.jittered_x0(spec, B, seed=9)
+    prob = hip.Problem(spec, dtype)
+    rows = np.arange(17, B, B // 40)[:40]
+    mask = np.zeros(B, np.int32)
+    mask[rows] = 1
+    bufs = prob.alloc_solve_buffers(B)
+    skipped = np.nonzero(mask == 0)[0]
+    for q in ("xs", "us", "P", "alpha", "costs"):
+        bufs[q][torch.from_numpy(skipped).cuda()] = 7.0  # (the rows taking part keep the zero warm start)
+    out = prob.solve(x0, bufs=bufs, active=torch.from_numpy(mask).cuda())
+    torch.cuda.synchronize()
+    sched = prob.last_schedule()
+    assert not sched & abi.SCHEDULE_SINGLE_WAVE_SWEEP and not sched & abi.SCHEDULE_SPLIT_TRIAL
+    alone = prob.solve(x0[rows])
+    torch.cuda.synchronize()
+    assert prob.last_schedule() == sched
+    for q in ("xs", "us", "P", "alpha", "costs", "iters", "status", "converged"):
+        assert np.array_equal(_np(out[q])[rows], _np(alone[q])), q
+    for q in ("xs", "us", "P", "alpha", "costs"):
+        assert np.all(_np(out[q])[skipped] == 7.0), q
+    # a fixed-iteration solve stays asynchronous: it keeps the schedule of the buffer's length
+    prob.solve(x0, bufs=bufs, active=torch.from_numpy(mask).cuda(), fixed_iters=1)
+    torch.cuda.synchronize()
+    assert prob.last_schedule() & abi.SCHEDULE_SINGLE_WAVE_SWEEP
+
+
+@pytest.mark.parametrize("dtype", [abi.F64, abi.F32])
 def test_deterministic_option_gives_the_same_bits_at_every_batch_size(hip, dtype):
     """ilqg_solve_options::deterministic: no scheduling choice depends on the batch size, so the SAME 64 initial states
     return the same bits solved alone, as rows of a 1024-instance batch and as rows of an 8192-instance batch (where
