@@ -496,6 +496,7 @@ __global__ void __launch_bounds__((KIND == LQ_SINGLE_WAVE ? 64 : KIND == LQ_VALU
 ilq_lq_kernel(DevProblem p, SolveArgs<T> sa) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int b = blockIdx.x;
+  if (sa.clear_counters && b == 0 && threadIdx.x < 4) sa.unfinished[threadIdx.x] = 0;  // (SolveArgs::clear_counters)
   {
     const WsLayout L(p.n, p.m, p.N, p.T, p.pairs.Rsz, p.pairs.rsz, sa.ol_row, p.num_constraints, sa.al_mode);
     const int stage = reinterpret_cast<const SolveState<T>*>(sa.ws + size_t(b) * sa.ws_stride + L.state)->stage;
@@ -1467,6 +1468,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
     raise_lds_limit((const void*)k_proll_lanes, lds_proll_lanes);
     raise_lds_limit((const void*)k_prows, lds_prows);
   }
+  sa.clear_counters = 1;
   sa.first = resume ? 2 : 1;
   p->counters_clean = false;  // whatever an earlier solve left in the round counters
   int waiting_lq = 0, waiting_exit = 0;  // split passes: instances already through this iteration's line search
@@ -1529,6 +1531,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(k_lq, dim3(batch), dim3(nt_lq), lds_lq, stream, d, sa);
         HIP_TRY(hipGetLastError());
+        p->counters_clean = true;  // (SolveArgs::clear_counters)
         round++;
       }
     }
@@ -1699,6 +1702,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
       }
       hipLaunchKernelGGL(k_lq, dim3(batch), dim3(nt_lq), lds_lq, stream, d, sa);
       HIP_TRY(hipGetLastError());
+      p->counters_clean = true;  // (SolveArgs::clear_counters)
     }
     if (!want_lq && !restarted) break;
     if (round > cap) return fail(ILQG_ERR_HIP, "solve did not terminate within its iteration bound");

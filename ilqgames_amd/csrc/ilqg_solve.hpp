@@ -61,6 +61,9 @@ struct SolveArgs {
   int probe_k;          // step sizes probed per instance this round (<= kProbeCandidates)
   int outer_closed;     // 1: the augmented-Lagrangian outer loop is out of time (max_runtime): an inner solve that ends
                         //    now ends the instance's solve instead of starting another (augmented_lagrangian_solver.cpp:107-110)
+  int clear_counters;   // 1: the sweep kernel's first workgroup clears the round counters — nothing counts between a
+                        //    round's sweep and the next round's first kernel, and the next round then needs no fill
+                        //    command in front of it (~5 us of every round of a free-running solve)
 };
 
 
