@@ -1608,7 +1608,11 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
         const double simds = 4.0 * num_cus;
         const double w_pair = double(round_instances) * proll_y, w_lane = double(round_instances) * ((probe_k + C - 1) / C);
         const double t_pair = std::max(1500.0, w_pair / simds * 550.0), t_lane = std::max(3500.0, w_lane / simds * 1530.0);
-        const bool lanes = pairs && probe_k >= probe_lanes_min && (opt.probe_lanes == ILQG_CHOICE_ON || t_lane < 0.9 * t_pair);
+        // (n > 16: the lane form's step carries a 2 n-term control product per lane and, for the six-state cars, spills
+        // inside the time loop — n = 24 on the feedback sweep: 2.2 ms per launch against 0.4-0.6 for the paired form,
+        // 99 k -> 83 k it/s; the model's constants are the n = 15 scene's, so AUTO leaves those shapes on pairs.)
+        const bool lanes = pairs && probe_k >= probe_lanes_min &&
+                           (opt.probe_lanes == ILQG_CHOICE_ON || (NX <= 16 && t_lane < 0.9 * t_pair));
         if (lanes) {
           hipLaunchKernelGGL(k_proll_lanes, dim3(round_instances, (probe_k + C - 1) / C), dim3(64), lds_proll_lanes, stream, d, sa);
         } else {
