@@ -524,9 +524,29 @@ def latency_figures(backend, examples, abi, args, x0_d):
         torch.cuda.synchronize()
         lat.append(time.perf_counter() - l0)
     it = int(lb["iters"][0].item())
-    return {"ms_per_solve": sorted(lat)[1] * 1e3, "iterations": it, "ms_per_iteration": sorted(lat)[1] * 1e3 / max(1, it),
-            "converged": int(lb["converged"][0].item()), "success": int(lb["status"][0].item()), "instances": 1,
-            "mode": "free-running to convergence_tolerance = 1.0, alpha0 = 0.5, fraction 0.001, zero warm start"}
+    out = {"ms_per_solve": sorted(lat)[1] * 1e3, "iterations": it, "ms_per_iteration": sorted(lat)[1] * 1e3 / max(1, it),
+           "converged": int(lb["converged"][0].item()), "success": int(lb["status"][0].item()), "instances": 1,
+           "mode": "free-running to convergence_tolerance = 1.0, alpha0 = 0.5, fraction 0.001, zero warm start"}
+    if args.dtype == "f64":
+        # the same solve in the reference's own arithmetic (include/ilqgames/utils/types.h:68-69: float)
+        prob32 = backend.hip.Problem(spec, abi.F32)
+        x32 = x0_d[:1].float()
+        lb32 = prob32.alloc_solve_buffers(1)
+        prob32.solve(x32, lb32)
+        lat32 = []
+        for _ in range(3):
+            for k in ("xs", "us", "P", "alpha"):
+                lb32[k].zero_()
+            torch.cuda.synchronize()
+            l0 = time.perf_counter()
+            prob32.solve(x32, lb32)
+            torch.cuda.synchronize()
+            lat32.append(time.perf_counter() - l0)
+        it32 = int(lb32["iters"][0].item())
+        out["f32"] = {"ms_per_solve": sorted(lat32)[1] * 1e3, "iterations": it32,
+                      "ms_per_iteration": sorted(lat32)[1] * 1e3 / max(1, it32),
+                      "converged": int(lb32["converged"][0].item()), "success": int(lb32["status"][0].item())}
+    return out
 
 
 def timed_workload(examples, abi, cfg, dtype_name, B, steps, local_rank, warmup=3, reps=5, linesearch="own"):

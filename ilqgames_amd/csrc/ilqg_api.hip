@@ -1472,6 +1472,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   sa.first = resume ? 2 : 1;
   p->counters_clean = false;  // whatever an earlier solve left in the round counters
   int waiting_lq = 0, waiting_exit = 0;  // split passes: instances already through this iteration's line search
+  bool exit_pending = false;             // a burst round went without its exit launch (see the burst loop)
   // Free-running solves: the kernels select their instances by the stage each one is in, so a round launched for
   // nobody is harmless — the host therefore enqueues BURSTS of whole rounds (trial, exit, sweep) and reads the
   // counters back once per burst instead of once per round (a read-back is a stream synchronisation: ~20-30 us against
@@ -1527,8 +1528,15 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
         HIP_TRY(hipGetLastError());
         sa.first = 0;
         if (log_iterates() != ILQG_OK) return ILQG_ERR_HIP;
-        hipLaunchKernelGGL(k_exit, dim3(batch), dim3(nt_exit), lds_exit, stream, d, sa);
-        HIP_TRY(hipGetLastError());
+        // The exit path inside a burst only where it starts something (the augmented Lagrangian's next inner solve);
+        // an ILQSolver::Solve that ends here waits for the burst's last round, whose exit launch is then unconditional
+        // (a launch for nobody is ~5 us of every round of a lone instance).
+        if (al_mode) {
+          hipLaunchKernelGGL(k_exit, dim3(batch), dim3(nt_exit), lds_exit, stream, d, sa);
+          HIP_TRY(hipGetLastError());
+        } else {
+          exit_pending = true;
+        }
         hipLaunchKernelGGL(k_lq, dim3(batch), dim3(nt_lq), lds_lq, stream, d, sa);
         HIP_TRY(hipGetLastError());
         p->counters_clean = true;  // (SolveArgs::clear_counters)
@@ -1670,6 +1678,10 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
     } else if (round == fixed_iters) {
       want_lq = 0;
       want_exit = 1;
+    }
+    if (exit_pending) {  // instances that ended in a burst round without an exit launch
+      want_exit = 1;
+      exit_pending = false;
     }
     if (timed && want_lq) {
       // the loop condition of src/ilq_solver.cpp:123-124 for the iteration the batch is about to start
