@@ -1307,7 +1307,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   // of instances taking part, not the length of the buffers: a receding-horizon loop replans the few dozen plans
   // still running of a batch of 2048 (src/receding_horizon_simulator.cpp:77), and the throughput forms chosen for 2048
   // — single-wave sweep, adjoint expected decrease, split trial pass — are latency forms three times slower for them
-  // (config 5 as written: 400 us per sweep launch instead of 140).  A free-running solve waits for the device every
+  // (config 5 as written: 400 us per sweep launch instead of 190).  A free-running solve waits for the device every
   // round anyway, so it counts its mask first (one more read-back per call); a fixed-iteration solve stays
   // asynchronous and keeps the buffer length.
   int sched_batch = batch;

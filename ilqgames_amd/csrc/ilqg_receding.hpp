@@ -239,14 +239,30 @@ __global__ void __launch_bounds__(64) receding_sync_kernel(DevProblem p, Recedin
   const int cnt = end - first;
   __syncthreads();
   if (first > 0 || xs != pl.xs) {
-    for (int kk = 0; kk < cnt; kk++) {
-      for (int e = t; e < n; e += 64) xs[size_t(kk) * n + e] = pl.xs[size_t(kk + first) * n + e];
-      for (int e = t; e < m; e += 64) {
-        us[size_t(kk) * m + e] = pl.us[size_t(kk + first) * m + e];
-        al[size_t(kk) * m + e] = pl.al[size_t(kk + first) * m + e];
+    // Each array as one ascending copy, eight loads per lane in flight: a batch's loads all precede its stores and every
+    // later batch reads higher addresses than anything written so far (the source is `first` rows ahead), so the
+    // in-place shift stays correct on the one wavefront this kernel runs (row by row, every row's loads waited behind
+    // the previous row's stores, which may alias).
+    auto shift = [&](T* dst, const T* src, int count) {
+      constexpr int U = 8;
+      for (int e0 = t; e0 < count; e0 += 64 * U) {
+        T v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const int e = e0 + 64 * u;
+          v[u] = e < count ? src[e] : T(0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const int e = e0 + 64 * u;
+          if (e < count) dst[e] = v[u];
+        }
       }
-      for (int e = t; e < m * n; e += 64) P[size_t(kk) * m * n + e] = pl.P[size_t(kk + first) * m * n + e];
-    }
+    };
+    shift(xs, pl.xs + size_t(first) * n, cnt * n);
+    shift(us, pl.us + size_t(first) * m, cnt * m);
+    shift(al, pl.al + size_t(first) * m, cnt * m);
+    shift(P, pl.P + size_t(first) * m * n, cnt * m * n);
   }
   __syncthreads();
   if (cnt < Tn) {

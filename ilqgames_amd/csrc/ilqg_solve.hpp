@@ -676,8 +676,22 @@ __device__ __forceinline__ void probe_pick_instance(const DevProblem& p, const S
     const T* const e = e0 + size_t(tried) * E.total;
     T* const xs_dst = ib.XS(1 - s.cur);
     T* const us_dst = ib.US(1 - s.cur);
-    for (int i = threadIdx.x; i < p.T * p.n; i += blockDim.x) xs_dst[i] = e[E.xs + i];
-    for (int i = threadIdx.x; i < p.T * p.m; i += blockDim.x) us_dst[i] = e[E.us + i];
+    // (eight loads per lane in flight: a load-store pair per trip is a global round trip per 128 elements of a
+    // trajectory, ~17 of them in a row for a lone instance)
+    auto copy = [&](T* dst, const T* src, int count) {
+      constexpr int U = 8;
+      const int nt = blockDim.x;
+      for (int i0 = threadIdx.x; i0 < count; i0 += nt * U) {
+        T v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) v[u] = src[i0 + u * nt < count ? i0 + u * nt : i0];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+          if (i0 + u * nt < count) dst[i0 + u * nt] = v[u];
+      }
+    };
+    copy(xs_dst, e + E.xs, p.T * p.n);
+    copy(us_dst, e + E.us, p.T * p.m);
     s.qmode = Q_TRIAL;
     s.stage = ST_QUAD;
   } else if (s.bt < prm.max_backtracking_steps) {
