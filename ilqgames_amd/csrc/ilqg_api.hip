@@ -448,14 +448,9 @@ __global__ void __launch_bounds__(64, sizeof(T) == 8 ? 4 : 1) ilq_probe_rows_ker
   probe_rows_instance<T, NX, NP, MU, PROGID>(p, maps, sa, b, slot, j, int(blockIdx.x), sm);
 }
 
-// (grid: kProbeMeritLanes candidates of a listed instance per workgroup, ilqg_solve.hpp)
-template <typename T>
-__global__ void __launch_bounds__(64) ilq_probe_merit_kernel(DevProblem p, SolveArgs<T> sa) {
-  probe_merit_instance<T>(p, sa, sa.ids[blockIdx.y], blockIdx.y, kProbeMeritLanes * int(blockIdx.x));
-}
 template <typename T>
 __global__ void __launch_bounds__(kProbeCandidates) ilq_probe_pick_kernel(DevProblem p, SolveArgs<T> sa) {
-  __shared__ T merits[kProbeCandidates];  // the candidates' merit values (ilq_probe_merit_kernel)
+  __shared__ T merits[kProbeCandidates];  // the candidates' merit values, reduced here one lane per candidate
   probe_pick_instance<T>(p, sa, sa.ids[blockIdx.x], blockIdx.x, merits);
 }
 
@@ -1635,9 +1630,6 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
         hipLaunchKernelGGL(k_prows, dim3(row_chunks, round_instances * probe_k),
                            dim3(64), lds_prows, stream, d, sa);
         HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(ilq_probe_merit_kernel<T>, dim3((probe_k + kProbeMeritLanes - 1) / kProbeMeritLanes, round_instances),
-                           dim3(64), 0, stream, d, sa);
-        HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(ilq_probe_pick_kernel<T>, dim3(round_instances), dim3(kProbeCandidates), 0, stream, d, sa);
         HIP_TRY(hipGetLastError());
       }
@@ -1946,9 +1938,6 @@ static ilqg_status generic_solve(ilqg_problem* p, int32_t batch, const void* x0,
         hipLaunchKernelGGL(k_proll, dim3(round_instances, probe_k), dim3(64), lds_roll, stream, d, sa);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(k_prows, dim3(row_chunks, round_instances * probe_k), dim3(64), lds_prows, stream, d, sa);
-        HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(ilq_probe_merit_kernel<T>, dim3((probe_k + kProbeMeritLanes - 1) / kProbeMeritLanes, round_instances),
-                           dim3(64), 0, stream, d, sa);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(ilq_probe_pick_kernel<T>, dim3(round_instances), dim3(kProbeCandidates), 0, stream, d, sa);
         HIP_TRY(hipGetLastError());

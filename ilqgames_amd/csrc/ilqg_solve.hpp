@@ -468,7 +468,7 @@ __device__ __forceinline__ void rows_part_instance(const DevProblem& p, const sh
 constexpr int kProbeCandidates = 128;           // most step sizes probed per instance and round (a failing search walks
                                                 // through all max_backtracking_steps of them — 100 in the examples — and a
                                                 // round costs the latency of one rollout whatever it probes)
-constexpr int kProbeStage = 64;                 // partials per candidate the pick kernel's loads run ahead of its additions
+constexpr int kProbeStage = 16;                 // partials per candidate the pick kernel's loads run ahead of its additions
 constexpr int kProbeEntries = 32768;            // pool size: candidates of all listed instances of one round
 constexpr int kProbeRoundBudget = 8192;         // rollouts the first probing round of a tail may hold (doubling after): what
                                                 // the chip integrates at once, two per wavefront at four waves per SIMD
@@ -602,90 +602,62 @@ __device__ __forceinline__ void probe_rows_instance(const DevProblem& p, const s
       p, maps, qa, k0, nrows, sa.rows_cw, sm, int(threadIdx.x));
 }
 
-// A candidate's merit value = the per-row partials of its pool entry summed in merit_reduce's order, one lane per
-// candidate (the sum is a serial chain; a probing round has thousands of them), kProbeMeritLanes candidates per
-// workgroup.  A lane walks T N 2 words of its own entry, every load a cache line of its own, and what a workgroup waits
-// for is the lines a CU keeps in flight, not the number of round trips (128 candidates of an instance on one CU: 40 us
-// whatever the prefetch depth — round 6, SQ counters: 88 % of the wave cycles waiting, 211 load instructions per
-// wave); so the candidates of an instance are spread over 128 / kProbeMeritLanes CUs and the picking workgroup reads
-// the finished values from the entries.  (Round 5: transposing the partials through LDS with contiguous half-wave
-// reads was three times slower — the staging loop's own round trips.)
-constexpr int kProbeMeritLanes = 16;
-template <typename T>
-__device__ __forceinline__ void probe_merit_instance(const DevProblem& p, const SolveArgs<T>& sa, int b, int slot, int j0) {
-  const InstanceBuffers<T> ib(p, sa, b);
-  const SolveState<T> s = state_load<T>(ib.w, ib.L);
-  if (!probe_wanted(sa, s, 0)) return;
-  const ilqg_solver_params& prm = sa.prm;
-  const ProbeEntry E(p.n, p.m, p.N, p.T);
-  T* const e0 = sa.probe_pool + size_t(slot) * sa.probe_k * E.total;
-  const int count = p.T * p.N * 2, skip = p.N * 2;  // the |l_i|^2 terms of k = 0 do not enter (:421)
-  const int j = j0 + int(threadIdx.x);
-  if (int(threadIdx.x) >= kProbeMeritLanes || j >= sa.probe_k || s.bt + j >= prm.max_backtracking_steps) return;
-  const T* const mp = e0 + size_t(j) * E.total + E.mpart;
-  T merit = T(0);
-  // Elements [e0, e0 + nvalid) in order, K loads in flight (indices past the end re-read the last element and are not
-  // added); `head`: the odd elements below `skip` do not enter.  One global round trip per call instead of one per
-  // element (a scalar loop here is load, wait, add).
-  auto batch = [&](auto Kc, int eb, int nvalid, bool head) {
-    constexpr int K = decltype(Kc)::value;
-    T v[K];
-#pragma unroll
-    for (int u = 0; u < K; u++) v[u] = mp[eb + u < count ? eb + u : count - 1];
-#pragma unroll
-    for (int u = 0; u < K; u++) {
-      const bool use = u < nvalid && !(head && eb + u < skip && ((eb + u) & 1) != 0);
-      merit = use ? merit + v[u] : merit;
-    }
-  };
-  constexpr int kHead = 16;  // covers 2 N <= 16 and leaves the blocks below on a multiple of four elements
-  int e = ((skip + 3) & ~3) < count ? ((skip + 3) & ~3) : count;
-  if (e > kHead) e = kHead;  // (N <= 8; a wider head would take a second call)
-  batch(std::integral_constant<int, kHead>{}, 0, e, true);
-  for (; e < skip && e < count; e++)  // (only past kHead: never for N <= 8)
-    if ((e & 1) == 0) merit += mp[e];
-  T x[kProbeStage], y[kProbeStage];
-  if (e + kProbeStage <= count) {
-#pragma unroll
-    for (int u = 0; u < kProbeStage; u++) x[u] = mp[e + u];
-  }
-  for (; e + kProbeStage <= count; e += kProbeStage) {
-    const bool more = e + 2 * kProbeStage <= count;
-    if (more) {
-#pragma unroll
-      for (int u = 0; u < kProbeStage; u++) y[u] = mp[e + kProbeStage + u];
-    }
-#pragma unroll
-    for (int u = 0; u < kProbeStage; u++) merit += x[u];
-    if (more) {
-#pragma unroll
-      for (int u = 0; u < kProbeStage; u++) x[u] = y[u];
-    }
-  }
-  if (e < count) batch(std::integral_constant<int, kProbeStage>{}, e, count - e, false);
-  e0[size_t(j) * E.total + E.merit] = T(0.5) * merit;
-}
-
 // The line-search bookkeeping of the candidates, in the order the loop would have met them
 // (CheckArmijoCondition :350-362, the back-tracking branch of ModifyLQStrategies :333-347).
-// `merits` (LDS, kProbeCandidates elements): the candidates' merit values (probe_merit_instance), fetched side by side.
+// `merits` (LDS, kProbeCandidates elements): lane j forms candidate j's merit value first — the per-row partials of its
+// pool entry, summed in merit_reduce's order (one lane per candidate, not one workgroup: the sum is a serial chain either
+// way, and a probing round has thousands of them; round 3 had a kernel of its own for it).  Null: read from the entries.
 template <typename T>
 __device__ __forceinline__ void probe_pick_instance(const DevProblem& p, const SolveArgs<T>& sa, int b, int slot,
-                                                    T* merits) {
+                                                    T* merits = nullptr) {
   const InstanceBuffers<T> ib(p, sa, b);
   SolveState<T> s = state_load<T>(ib.w, ib.L);
   if (!probe_wanted(sa, s, 0)) return;
   const ilqg_solver_params& prm = sa.prm;
   const ProbeEntry E(p.n, p.m, p.N, p.T);
   const T* const e0 = sa.probe_pool + size_t(slot) * sa.probe_k * E.total;
-  for (int j = threadIdx.x; j < sa.probe_k; j += blockDim.x)
-    if (s.bt + j < prm.max_backtracking_steps) merits[j] = e0[size_t(j) * E.total + E.merit];
-  __syncthreads();
+  if (merits) {
+    // Candidate j's merit value = its per-row partials summed in merit_reduce's order, one lane per candidate (a serial
+    // chain either way; the candidates' entries are far apart, so every load of a lane is a cache line of its own).  What
+    // it costs is the round trips, so the loads run a block of kProbeStage partials ahead of the additions.
+    // (Measured and dropped in round 5: transposing the partials through LDS with contiguous half-wave reads — the
+    // staging loop's own round trips made the kernel three times slower.)
+    const int count = p.T * p.N * 2, skip = p.N * 2;  // the |l_i|^2 terms of k = 0 do not enter (:421)
+    for (int j = threadIdx.x; j < sa.probe_k; j += blockDim.x) {
+      if (s.bt + j >= prm.max_backtracking_steps) continue;
+      const T* const mp = e0 + size_t(j) * E.total + E.mpart;
+      T merit = T(0);
+      int e = 0;
+      for (; e < skip && e < count; e++)
+        if ((e & 1) == 0) merit += mp[e];
+      T x[kProbeStage], y[kProbeStage];
+      if (e + kProbeStage <= count) {
+#pragma unroll
+        for (int u = 0; u < kProbeStage; u++) x[u] = mp[e + u];
+      }
+      for (; e + kProbeStage <= count; e += kProbeStage) {
+        const bool more = e + 2 * kProbeStage <= count;
+        if (more) {
+#pragma unroll
+          for (int u = 0; u < kProbeStage; u++) y[u] = mp[e + kProbeStage + u];
+        }
+#pragma unroll
+        for (int u = 0; u < kProbeStage; u++) merit += x[u];
+        if (more) {
+#pragma unroll
+          for (int u = 0; u < kProbeStage; u++) x[u] = y[u];
+        }
+      }
+      for (; e < count; e++) merit += mp[e];
+      merits[j] = T(0.5) * merit;
+    }
+    __syncthreads();
+  }
   int tried = 0;
   bool found = false;
   T step = s.step, last_tried = s.step;
   for (int j = 0; j < sa.probe_k && s.bt + j < prm.max_backtracking_steps; j++) {
-    const T merit = merits[j];
+    const T merit = merits ? merits[j] : e0[size_t(j) * E.total + E.merit];
     const T scaled = T(prm.expected_decrease_fraction) * step * s.expected_decrease;
     if (s.last_merit - merit >= scaled) {
       found = true;
