@@ -640,9 +640,10 @@ def receding_horizon_workload(examples, abi, local_rank, batch=2048, replans=12,
         if r <= 1:
             active_masks.append(info["active"].cpu().numpy().astype(bool))
 
-    # untimed warm-up, as for every other workload: the first call and one replan (the replans run kernels the first
-    # call does not — the schedule of a few dozen instances — and the first launch of a kernel loads its code object:
-    # 75-200 ms in the first replan of a process, which a 12-replan average is not meant to carry)
+    # untimed warm-up, as for every other workload: the first call and one replan.  The loop around the solver calls is
+    # this harness's (torch.where / sum / mask updates on device tensors), and the first use of each of those torch
+    # kernels loads its code object: 55 + 100 + 68 ms of idle device in the first replan of a traced process
+    # (scripts/trace_cmd.sh), 75-270 ms un-traced — not something a 12-replan average of the library should carry.
     prob.receding_horizon_simulate(x0, final_time=1e9, planner_runtime=tick, extra_time=tick, solve_time=tick,
                                    augmented_lagrangian=True, max_records=2)
     torch.cuda.synchronize()
