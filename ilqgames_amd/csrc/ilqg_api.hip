@@ -292,9 +292,13 @@ inline WsTail ws_tail(const DevProblem& d, int batch, size_t elem, int ol_row) {
   WsTail t;
   t.ids_off = up(size_t(L.total) * elem * size_t(batch));
   t.pool_off = up(t.ids_off + size_t(2) * batch * sizeof(int));
-  // eight candidates per instance up to kProbeEntries, and never fewer than two full rounds' worth for a single
-  // instance (a lone instance in a failing line search walks through all its step sizes: 128 a round, not 8)
-  t.pool_entries = batch * 16 < kProbeEntries ? batch * 16 : kProbeEntries;
+  // sixteen candidates per instance up to kProbeEntries; a small batch gets every candidate of every instance up to
+  // one round's budget (a few dozen instances in failing line searches walk through all their step sizes, 128 a round
+  // each: config 5's 47 surviving plans as a dense batch, 752 entries: 75 ms per replan; 6016: see DESIGN.md 3.13),
+  // and never fewer than two full rounds' worth for a single instance
+  const long long small = std::min<long long>((long long)batch * kProbeCandidates, kProbeRoundBudget);
+  const long long want = std::max<long long>((long long)batch * 16, small);
+  t.pool_entries = int(std::min<long long>(want, kProbeEntries));
   if (t.pool_entries < 2 * kProbeCandidates) t.pool_entries = 2 * kProbeCandidates;
   t.total = up(t.pool_off + size_t(t.pool_entries) * ProbeEntry(d.n, d.m, d.N, d.T).total * elem);
   return t;
