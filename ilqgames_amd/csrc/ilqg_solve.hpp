@@ -468,7 +468,7 @@ __device__ __forceinline__ void rows_part_instance(const DevProblem& p, const sh
 constexpr int kProbeCandidates = 128;           // most step sizes probed per instance and round (a failing search walks
                                                 // through all max_backtracking_steps of them — 100 in the examples — and a
                                                 // round costs the latency of one rollout whatever it probes)
-constexpr int kProbeStage = 16;                 // partials per candidate the pick kernel's loads run ahead of its additions
+constexpr int kProbeStage = 32;                 // partials per candidate the pick kernel's loads run ahead of its additions
 constexpr int kProbeEntries = 32768;            // pool size: candidates of all listed instances of one round
 constexpr int kProbeRoundBudget = 8192;         // rollouts the first probing round of a tail may hold (doubling after): what
                                                 // the chip integrates at once, two per wavefront at four waves per SIMD
@@ -627,28 +627,48 @@ __device__ __forceinline__ void probe_pick_instance(const DevProblem& p, const S
       if (s.bt + j >= prm.max_backtracking_steps) continue;
       const T* const mp = e0 + size_t(j) * E.total + E.mpart;
       T merit = T(0);
-      int e = 0;
-      for (; e < skip && e < count; e++)
+      // Elements [eb, eb + nvalid) in order with K loads in flight (indices past the end re-read the last element and
+      // are not added; `head`: the odd elements below `skip` do not enter): one round trip for the head and one for
+      // the tail, where a scalar loop is a round trip per element.
+      auto batch = [&](auto Kc, int eb, int nvalid, bool head) {
+        constexpr int K = decltype(Kc)::value;
+        T v[K];
+#pragma unroll
+        for (int u = 0; u < K; u++) v[u] = mp[eb + u < count ? eb + u : count - 1];
+#pragma unroll
+        for (int u = 0; u < K; u++) {
+          const bool use = u < nvalid && !(head && eb + u < skip && ((eb + u) & 1) != 0);
+          merit = use ? merit + v[u] : merit;
+        }
+      };
+      constexpr int kHead = 16;  // 2 N <= 16 elements of step 0, up to a multiple of four
+      int e = ((skip + 3) & ~3) < count ? ((skip + 3) & ~3) : count;
+      if (e > kHead) e = kHead;
+      batch(std::integral_constant<int, kHead>{}, 0, e, true);
+      for (; e < skip && e < count; e++)  // (only past kHead: never for N <= 8)
         if ((e & 1) == 0) merit += mp[e];
+      // full blocks, the two register blocks taking turns (no copies between them)
       T x[kProbeStage], y[kProbeStage];
-      if (e + kProbeStage <= count) {
+      const int nb = (count - e) / kProbeStage;
+      auto load = [&](T (&dst)[kProbeStage], int at) {
 #pragma unroll
-        for (int u = 0; u < kProbeStage; u++) x[u] = mp[e + u];
+        for (int u = 0; u < kProbeStage; u++) dst[u] = mp[at + u];
+      };
+      auto add = [&](const T (&src)[kProbeStage]) {
+#pragma unroll
+        for (int u = 0; u < kProbeStage; u++) merit += src[u];
+      };
+      if (nb > 0) load(x, e);
+      for (int bi = 0; bi < nb;) {
+        if (bi + 1 < nb) load(y, e + (bi + 1) * kProbeStage);
+        add(x);
+        if (++bi >= nb) break;
+        if (bi + 1 < nb) load(x, e + (bi + 1) * kProbeStage);
+        add(y);
+        ++bi;
       }
-      for (; e + kProbeStage <= count; e += kProbeStage) {
-        const bool more = e + 2 * kProbeStage <= count;
-        if (more) {
-#pragma unroll
-          for (int u = 0; u < kProbeStage; u++) y[u] = mp[e + kProbeStage + u];
-        }
-#pragma unroll
-        for (int u = 0; u < kProbeStage; u++) merit += x[u];
-        if (more) {
-#pragma unroll
-          for (int u = 0; u < kProbeStage; u++) x[u] = y[u];
-        }
-      }
-      for (; e < count; e++) merit += mp[e];
+      e += nb * kProbeStage;
+      if (e < count) batch(std::integral_constant<int, kProbeStage>{}, e, count - e, false);
       merits[j] = T(0.5) * merit;
     }
     __syncthreads();
