@@ -416,10 +416,13 @@ __global__ void __launch_bounds__(64) ilq_decide_kernel(DevProblem p, SolveArgs<
 // candidates, which costs the latency of one rollout however empty the chip is, runs a third faster without them (n = 16,
 // 6 instances x 128 candidates: 248 -> 166 us; the n = 16 constrained workload at B = 1024: 517 -> 533 k it/s); a round
 // that fills the chip wants the occupancy back (config 5's scene: 255 k it/s lean, 244 k fat).  The launcher picks.
-template <typename T, int NX, int NP, int MU, bool FAT = false>
+// SINGLE: one candidate per wavefront (rollout_instance) also where the shape has the paired form — for a round whose
+// candidates all find a SIMD of their own, where a launch costs one rollout's chain and the paired chain is the longer
+// one (n = 15, a few instances x 128 candidates: 176 us paired).
+template <typename T, int NX, int NP, int MU, bool FAT = false, bool SINGLE = false>
 __global__ void __launch_bounds__(64, sizeof(T) == 8 ? (FAT ? 2 : ILQG_ROLL_WAVES) : 1) ilq_probe_roll_kernel(DevProblem p, SolveArgs<T> sa) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  if constexpr (rollout_pairs(NX, NP, MU))  // candidates 2 y and 2 y + 1 in the two halves of the wave
+  if constexpr (rollout_pairs(NX, NP, MU) && !SINGLE)  // candidates 2 y and 2 y + 1 in the two halves of the wave
     probe_roll_pair<T, NX, NP, MU>(p, sa, sa.ids[blockIdx.x], blockIdx.x, 2 * int(blockIdx.y), reinterpret_cast<T*>(smem_raw));
   else
     probe_roll_instance<T, NX, NP, MU>(p, sa, sa.ids[blockIdx.x], blockIdx.x, blockIdx.y, reinterpret_cast<T*>(smem_raw));
@@ -1453,6 +1456,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
   const bool probe = lists && sa.prm.linesearch && choice(opt.probe, true);
   auto k_proll = ilq_probe_roll_kernel<T, NX, NP, MU>;
   auto k_proll_fat = ilq_probe_roll_kernel<T, NX, NP, MU, sizeof(T) == 8>;  // (fp32: the same kernel)
+  auto k_proll_single = ilq_probe_roll_kernel<T, NX, NP, MU, sizeof(T) == 8, true>;
   auto k_proll_lanes = ilq_probe_roll_lanes_kernel<T, NX, NP, MU>;
   const size_t lds_proll_lanes = pairs ? size_t(rollout_lanes_lds_elems(d.n, d.m, d.N)) * sizeof(T) + 16 : 0;
   const int probe_lanes_min = opt.probe_lanes == ILQG_CHOICE_OFF ? (1 << 30) : (opt.probe_lanes == ILQG_CHOICE_ON ? 2 : 8);
@@ -1469,6 +1473,7 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
     raise_lds_limit((const void*)k_decide, lds_decide);
     raise_lds_limit((const void*)k_proll, lds_proll);
     raise_lds_limit((const void*)k_proll_fat, lds_proll);
+    raise_lds_limit((const void*)k_proll_single, lds_roll);
     raise_lds_limit((const void*)k_proll_lanes, lds_proll_lanes);
     raise_lds_limit((const void*)k_prows, lds_prows);
   }
@@ -1625,8 +1630,13 @@ ilqg_status DimsLaunch<T, NX, NP, MU>::solve(ilqg_problem* p, int32_t batch, con
         // 99 k -> 83 k it/s; the model's constants are the n = 15 scene's, so AUTO leaves those shapes on pairs.)
         const bool lanes = pairs && probe_k >= probe_lanes_min &&
                            (opt.probe_lanes == ILQG_CHOICE_ON || (NX <= 16 && t_lane < 0.9 * t_pair));
+        // a candidate per wavefront while every one of them finds a SIMD of its own
+        const bool single = pairs && !lanes && (long long)round_instances * probe_k <= 4ll * num_cus &&
+                            opt.probe_lanes != ILQG_CHOICE_ON;
         if (lanes) {
           hipLaunchKernelGGL(k_proll_lanes, dim3(round_instances, (probe_k + C - 1) / C), dim3(64), lds_proll_lanes, stream, d, sa);
+        } else if (single) {
+          hipLaunchKernelGGL(k_proll_single, dim3(round_instances, probe_k), dim3(64), lds_roll, stream, d, sa);
         } else {
           hipLaunchKernelGGL(fat ? k_proll_fat : k_proll, dim3(round_instances, proll_y), dim3(64), lds_proll, stream, d, sa);
         }
